@@ -1,0 +1,212 @@
+"""ctypes/numpy front-end of oracle/vlg_oracle.c, plus brute-force tree enumerators.
+
+TEST INFRASTRUCTURE.  Parity status: PINNED against outputs of the reference itself
+(tests/golden/*.npz via tests/golden/make_golden.py) -- see tests/test_oracle_golden.py.
+"""
+import ctypes
+import itertools
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libvlg_oracle.so")
+NEGINF = -1e12  # src/model/torch_struct/semirings/semirings.py:16 (standalone value)
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("vlg_oracle.c", "vlg_oracle_impl.h")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.orc_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def max_threads():
+    return int(_load().orc_max_threads())
+
+
+def set_threads(n):
+    _load().orc_set_threads(int(n))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _suffix(dtype):
+    dtype = np.dtype(dtype)
+    assert dtype in (np.float32, np.float64)
+    return dtype, ("_f32" if dtype == np.float32 else "_f64")
+
+
+def dmv1o_merge(dec, attach, root, one=0.0, zero=NEGINF):
+    """DMV1o.merge, src/model/torch_struct/distributions.py:253-265 (always float32 out)."""
+    B, L = dec.shape[:2]
+    N = L + 1
+    attach_wroot = np.full((B, N, N, 2), zero, dtype=np.float32)
+    dec_wroot = np.full((B, N, 2, 2, 2), zero, dtype=np.float32)
+    attach_wroot[:, 0, 1:, 1] = root          # NOCHILD = 1
+    attach_wroot[:, 1:, 1:, :] = attach
+    dec_wroot[:, 0, 1, :, :] = one            # RIGHT = 1
+    dec_wroot[:, 1:] = dec
+    return dec_wroot, attach_wroot
+
+
+def dmv1o(dec, attach, lengths, semiring="log", dtype=np.float32, grad=True, glogZ=None, neg_inf=NEGINF):
+    """DMV1oStruct._dp (dmv.py:19-66) + its autograd outside.  dec [B,N,2,2,2], attach [B,N,N,2].
+    Returns logZ [B,1] (helpers.py:101-116 keeps the trailing 1), grad_dec, grad_attach."""
+    dtype, suf = _suffix(dtype)
+    dec = np.ascontiguousarray(dec, dtype=dtype)
+    attach = np.ascontiguousarray(attach, dtype=dtype)
+    lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+    B, N = dec.shape[:2]
+    assert dec.shape == (B, N, 2, 2, 2) and attach.shape == (B, N, N, 2) and lengths.shape == (B,)
+    logZ = np.empty((B,), dtype=dtype)
+    gdec = np.empty_like(dec) if grad else None
+    gatt = np.empty_like(attach) if grad else None
+    if glogZ is not None:
+        glogZ = np.ascontiguousarray(glogZ, dtype=dtype).reshape(B)
+    rc = getattr(_load(), "orc_dmv1o" + suf)(
+        _p(dec), _p(attach), _p(lengths), B, N, 0 if semiring == "log" else 1, ctypes.c_double(neg_inf),
+        _p(glogZ), _p(logZ), _p(gdec), _p(gatt))
+    assert rc == 0, rc
+    return logZ.reshape(B, 1), gdec, gatt
+
+
+def deptree(arc, lengths=None, semiring="log", dtype=np.float32, grad=True, glogZ=None, neg_inf=NEGINF):
+    """DepTree._dp (deptree.py:25-76) + its autograd outside.  arc [B,N,N] head->child, root = 0.
+    Returns logZ [B], grad_arc [B,N,N]."""
+    dtype, suf = _suffix(dtype)
+    arc = np.ascontiguousarray(arc, dtype=dtype)
+    B, N = arc.shape[:2]
+    assert arc.shape == (B, N, N), "Non-square potentials"
+    if lengths is not None:
+        lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+    logZ = np.empty((B,), dtype=dtype)
+    garc = np.empty_like(arc) if grad else None
+    if glogZ is not None:
+        glogZ = np.ascontiguousarray(glogZ, dtype=dtype).reshape(B)
+    rc = getattr(_load(), "orc_deptree" + suf)(
+        _p(arc), _p(lengths), B, N, 0 if semiring == "log" else 1, ctypes.c_double(neg_inf), _p(glogZ), _p(logZ),
+        _p(garc))
+    assert rc == 0, rc
+    return logZ, garc
+
+
+def bilinear_align(txt, vis, tmask=None, vmask=None, dtype=np.float32, neg_inf=-1e20, full=True, maxV=False,
+                   maxQ=False, diag=False):
+    """gather_logit_simple, src/model/joint.py:406-419.  txt [B,Q,d], vis [A,V,d] -> attmap [B,A,Q,V]."""
+    dtype, suf = _suffix(dtype)
+    txt = np.ascontiguousarray(txt, dtype=dtype)
+    vis = np.ascontiguousarray(vis, dtype=dtype)
+    B, Q, d = txt.shape
+    A, V, d2 = vis.shape
+    assert d == d2
+    tm = None if tmask is None else np.ascontiguousarray(tmask, dtype=np.uint8)
+    vm = None if vmask is None else np.ascontiguousarray(vmask, dtype=np.uint8)
+    o_full = np.empty((B, A, Q, V), dtype=dtype) if full else None
+    o_maxV = np.empty((B, A, Q), dtype=dtype) if maxV else None
+    o_maxQ = np.empty((B, A, V), dtype=dtype) if maxQ else None
+    o_diag = np.empty((B, Q, V), dtype=dtype) if diag else None
+    rc = getattr(_load(), "orc_bilinear_align" + suf)(
+        _p(txt), _p(vis), _p(tm), _p(vm), B, A, Q, V, d, ctypes.c_double(neg_inf), _p(o_full), _p(o_maxV), _p(o_maxQ),
+        _p(o_diag))
+    assert rc == 0, rc
+    return dict(full=o_full, maxV=o_maxV, maxQ=o_maxQ, diag=o_diag)
+
+
+def attn_fuse(vis, txt, vis_mid, enc_x, gamma, beta, eps=1e-5, dtype=np.float32):
+    """Attention-fuse, src/model/joint.py:670-674.  Returns (attmap [B,L,V], out [B,L,h])."""
+    dtype, suf = _suffix(dtype)
+    vis, txt, vis_mid, enc_x, gamma, beta = (np.ascontiguousarray(x, dtype=dtype)
+                                             for x in (vis, txt, vis_mid, enc_x, gamma, beta))
+    B, V, d = vis.shape
+    L = txt.shape[1] - 1
+    h = vis_mid.shape[2]
+    assert txt.shape == (B, L + 1, d) and vis_mid.shape == (B, V, h) and enc_x.shape == (B, L, h)
+    att = np.empty((B, L, V), dtype=dtype)
+    out = np.empty((B, L, h), dtype=dtype)
+    rc = getattr(_load(), "orc_attn_fuse" + suf)(
+        _p(vis), _p(txt), _p(vis_mid), _p(enc_x), _p(gamma), _p(beta), B, L, V, d, h, ctypes.c_double(eps), _p(att),
+        _p(out))
+    assert rc == 0, rc
+    return att, out
+
+
+# ----------------------------------------------------------------------------------------------
+# Brute-force enumerators (pure Python, tiny N only): an algorithm-independent known answer.
+# ----------------------------------------------------------------------------------------------
+def _projective_single_root_trees(n_words):
+    """All head vectors (heads[c] for c = 1..n_words, 0 = root) that are projective, spanning and
+    single-rooted -- the support of both DPs (deptree.py:325-378 states the same predicates)."""
+    N = n_words + 1
+    for heads in itertools.product(range(N), repeat=n_words):
+        h = (-1,) + heads
+        if sum(1 for c in range(1, N) if h[c] == 0) != 1:
+            continue
+        ok = all(h[c] != c for c in range(1, N))
+        for c in range(1, N):                      # acyclic / spanning
+            seen, x = set(), c
+            while ok and x != 0:
+                if x in seen:
+                    ok = False
+                seen.add(x)
+                x = h[x]
+        if not ok:
+            continue
+        for c in range(1, N):                      # projective: every word strictly inside an arc descends from its head
+            lo, hi = min(c, h[c]), max(c, h[c])
+            for m in range(lo + 1, hi):
+                x = m
+                while x != 0 and x != h[c]:
+                    x = h[x]
+                if x != h[c]:
+                    ok = False
+        if ok:
+            yield h
+
+
+def enumerate_deptree(arc, length):
+    """log-sum and max over trees of sum_c arc[head(c), c] (float64)."""
+    scores = [sum(float(arc[h[c], c]) for c in range(1, length + 1)) for h in _projective_single_root_trees(length)]
+    m = max(scores)
+    return m + math.log(sum(math.exp(s - m) for s in scores)), m
+
+
+def enumerate_dmv1o(dec, attach, length):
+    """log-sum and max over trees of the valence-DMV score implied by dmv.py:36-62: for each head
+    and direction the children are generated OUTSIDE-IN; the first (outermost) attachment is scored
+    with valence NOCHILD, later (inner) ones with HASCHILD, and the STOP decision with the valence
+    reached after the last attachment.  The root (index 0) only generates to the right."""
+    NOCHILD, HASCHILD, LEFT, RIGHT, GO, STOP = 1, 0, 0, 1, 0, 1
+    scores = []
+    for h in _projective_single_root_trees(length):
+        s = 0.0
+        for head in range(0, length + 1):
+            for direction in (LEFT, RIGHT):
+                if head == 0 and direction == LEFT:
+                    continue
+                kids = [c for c in range(1, length + 1) if h[c] == head and ((c < head) == (direction == LEFT))]
+                kids.sort(key=lambda c: -abs(c - head))           # outermost first
+                val = NOCHILD
+                for c in kids:
+                    s += float(dec[head, direction, val, GO]) + float(attach[head, c, val])
+                    val = HASCHILD
+                s += float(dec[head, direction, val, STOP])
+        scores.append(s)
+    m = max(scores)
+    return m + math.log(sum(math.exp(s - m) for s in scores)), m

@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING THE REFERENCE in the build container.
+
+Run from the repo root:   python tests/golden/make_golden.py
+
+The reference (LouChao98/VLGAE, mounted read-only at /root/reference) has no tests or
+golden vectors of its own for this path, so parity is pinned on
+outputs of the reference itself, produced here and committed as small .npz files.
+Only arrays are written: inputs and the reference's outputs.  No reference source, byte
+code or pickled module is stored.  The GPU box never sees /root/reference.
+
+Reference entry points exercised (paths relative to /root/reference):
+  * src/model/torch_struct/distributions.py:245-265  DMV1o, DMV1o.merge
+  * src/model/torch_struct/distributions.py:116-133,162-174,190-193  .max/.argmax/.marginals/.partition
+  * src/model/torch_struct/dmv.py:19-66              DMV1oStruct._dp (inside; outside = autograd)
+  * src/model/torch_struct/deptree.py:25-76,213-228  DepTree._dp, DepTree.enumerate
+  * src/model/joint.py:406-419                       DependencyBoxRel.gather_logit_simple
+  * src/model/joint.py:670-674                       attention-fuse (needs a constructed module, so
+                                                     those five lines are re-issued here with the
+                                                     same torch ops on the same tensors)
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import  # noqa: E402
+
+warnings.filterwarnings("ignore", message="Named tensors")
+torch.set_num_threads(8)
+
+ts = _ref_import.import_torch_struct()
+DMV1o, DependencyCRF = ts.DMV1o, ts.DependencyCRF
+
+
+def _np(t):
+    return t.detach().rename(None).cpu().numpy() if t.names and any(t.names) else t.detach().cpu().numpy()
+
+
+def make_lengths(g, B, L, mode):
+    if mode == "full":
+        return torch.full((B,), L, dtype=torch.long)
+    if mode == "rand":
+        ln = torch.randint(1, L + 1, (B,), generator=g)
+        ln[0] = L
+        return ln
+    return torch.tensor(mode, dtype=torch.long)
+
+
+def dmv_inputs(seed, B, L, normalise_attach):
+    """Synthetic potentials shaped like what the scorer emits."""
+    g = torch.Generator().manual_seed(seed)
+    dec = torch.randn(B, L, 2, 2, 2, generator=g).log_softmax(-1)
+    attach = torch.randn(B, L, L, 2, generator=g)
+    if normalise_attach:
+        attach = attach.log_softmax(2)
+    root = torch.randn(B, L, generator=g).log_softmax(-1)
+    return g, dec, attach, root
+
+
+def dmv_case(name, seed, B, L, lengths_mode, normalise_attach=False, store_merged=False):
+    g, dec, attach, root = dmv_inputs(seed, B, L, normalise_attach)
+    lengths = make_lengths(g, B, L, lengths_mode)
+    wts = torch.rand(B, generator=g) + 0.5
+    out = dict(dec=_np(dec), attach=_np(attach), root=_np(root), lengths=_np(lengths), wts=_np(wts))
+
+    mdec, mattach = DMV1o.merge(dec, attach, root)
+    if store_merged:
+        out["merged_dec"], out["merged_attach"] = _np(mdec), _np(mattach)
+
+    for tag, dt in (("", torch.float32), ("64", torch.float64)):
+        d = mdec.to(dt).detach().requires_grad_()
+        a = mattach.to(dt).detach().requires_grad_()
+        dist = DMV1o([d, a], lengths)
+        logZ = dist.partition                                   # [B,1]
+        gd, ga = torch.autograd.grad(logZ.sum(), [d, a])
+        out["logZ" + tag], out["grad_dec" + tag], out["grad_attach" + tag] = _np(logZ), _np(gd), _np(ga)
+
+        d = mdec.to(dt).detach().requires_grad_()
+        a = mattach.to(dt).detach().requires_grad_()
+        dist = DMV1o([d, a], lengths)
+        mx = dist.max
+        mgd, mga = torch.autograd.grad(mx.sum(), [d, a])
+        out["max" + tag], out["maxgrad_dec" + tag], out["maxgrad_attach" + tag] = _np(mx), _np(mgd), _np(mga)
+
+    # weighted upstream gradient (exercises grad_logZ scaling), fp32
+    d = mdec.detach().requires_grad_()
+    a = mattach.detach().requires_grad_()
+    dist = DMV1o([d, a], lengths)
+    wgd, wga = torch.autograd.grad((dist.partition.squeeze(-1) * wts).sum(), [d, a])
+    out["wgrad_dec"], out["wgrad_attach"] = _np(wgd), _np(wga)
+
+    # lazy properties used by the callers (joint.py:254-258, ldndmv.py:294-303)
+    d = mdec.detach().requires_grad_()
+    a = mattach.detach().requires_grad_()
+    dist = DMV1o([d, a], lengths)
+    out["argmax"] = _np(dist.argmax)                            # [B,N,N,2] 0/1
+    out["marginals"] = _np(dist.marginals)                      # [B,N,N,2]
+    arc = dist.argmax.sum(-1).nonzero()
+    predicted = lengths.new_zeros(B, L + 1)
+    predicted[arc[:, 0], arc[:, 2]] = arc[:, 1]
+    out["predicted"] = _np(predicted)
+    arc_margin = torch.from_numpy(out["grad_attach"]).sum(-1)
+    out["arc_marginal"] = _np(arc_margin)
+
+    # MBR chain: DependencyCRF over arc marginals, Max semiring (ldndmv.py:294-299)
+    crf = DependencyCRF(arc_margin.clone(), lengths)
+    out["mbr_argmax"] = _np(crf.argmax)
+    out["mbr_max"] = _np(crf.max)
+
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: B={B} L={L} lengths={out['lengths'].tolist()[:8]} logZ[0]={out['logZ'][0, 0]:.6f}")
+
+
+def deptree_case(name, seed, B, N, lengths_mode, enumerate_=False, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    arc = torch.randn(B, N, N, generator=g) * scale
+    lengths = make_lengths(g, B, N - 1, lengths_mode)
+    wts = torch.rand(B, generator=g) + 0.5
+    out = dict(arc=_np(arc), lengths=_np(lengths), wts=_np(wts))
+    for tag, dt in (("", torch.float32), ("64", torch.float64)):
+        a = arc.to(dt).clone()
+        dist = DependencyCRF(a, lengths)
+        out["logZ" + tag] = _np(dist.partition)                 # [B]
+        out["marginals" + tag] = _np(dist.marginals)            # [B,N,N]
+        out["max" + tag] = _np(dist.max)
+        out["argmax" + tag] = _np(dist.argmax)
+    a = arc.clone().requires_grad_()
+    dist = DependencyCRF(a, lengths)
+    (wg,) = torch.autograd.grad((dist.partition * wts).sum(), [a])
+    out["wgrad"] = _np(wg)
+    if enumerate_:
+        # brute-force over all projective single-root trees: the only known-answer device in-tree
+        from torch_struct.deptree import DepTree
+        from torch_struct import LogSemiring, MaxSemiring
+        out["enum_logZ"] = _np(DepTree(LogSemiring).enumerate(arc.double(), non_proj=False, multi_root=False)[0])
+        out["enum_max"] = _np(DepTree(MaxSemiring).enumerate(arc.double(), non_proj=False, multi_root=False)[0])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: B={B} N={N} logZ[0]={out['logZ'][0]:.6f}")
+
+
+def align_cases():
+    src, joint = _ref_import.import_joint()
+    fn = joint.DependencyBoxRel.gather_logit_simple
+    for name, seed, B, A, Q, V, d, bf16 in (
+        ("align_B4_A4_Q22_V10_s0", 0, 4, 4, 22, 10, 128, False),
+        ("align_B3_A5_Q7_V3_d32_s1", 1, 3, 5, 7, 3, 32, False),
+        ("align_B8_A8_Q82_V36_s2_bf16", 2, 8, 8, 82, 36, 128, True),
+    ):
+        g = torch.Generator().manual_seed(seed)
+        txt = torch.randn(B, Q, d, generator=g)
+        vis = torch.randn(A, V, d, generator=g)
+        if bf16:  # bf16-rounded inputs, reference run in fp32 on the up-cast values
+            txt, vis = txt.bfloat16().float(), vis.bfloat16().float()
+        tmask = torch.rand(B, Q, generator=g) > 0.1
+        vmask = torch.rand(A, V, generator=g) > 0.1
+        tmask[:, 0] = False                                     # root slot is masked (joint.py:204,248-249)
+        att = fn(None, None,
+                 (vis.refine_names("A", "V", "Y"), vmask.refine_names("A", "V"), None),
+                 (txt.refine_names("B", "Q", "X"), tmask.refine_names("B", "Q"), None), None)
+        assert att.names == ("B", "A", "Q", "V")
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), txt=_np(txt), vis=_np(vis),
+                            tmask=_np(tmask), vmask=_np(vmask), attmap=_np(att),
+                            neg_inf=np.float32(-src.INF))
+        print(f"{name}: attmap {tuple(att.shape)}")
+
+
+def attnfuse_cases():
+    """joint.py:670-674 re-issued with the same torch ops (module construction needs a DataModule)."""
+    for name, seed, B, L, V, d, h in (
+        ("attnfuse_B4_L10_V10_s0", 0, 4, 10, 10, 128, 256),
+        ("attnfuse_B8_L40_V36_s1", 1, 8, 40, 36, 128, 256),
+        ("attnfuse_B3_L5_V35_d64_h96_s2", 2, 3, 5, 35, 64, 96),
+    ):
+        g = torch.Generator().manual_seed(seed)
+        vis = torch.randn(B, V, d, generator=g)                 # vis[0]
+        txt = torch.randn(B, L + 1, d, generator=g)             # txt[0] (root slot first)
+        vis_mid = torch.randn(B, V, h, generator=g)             # vis[3]
+        enc_x = torch.randn(B, L, h, generator=g)               # encoded['x']
+        ln = torch.nn.LayerNorm(h)
+        with torch.no_grad():
+            ln.weight.copy_(torch.rand(h, generator=g) + 0.5)
+            ln.bias.copy_(torch.randn(h, generator=g) * 0.1)
+            attmap = torch.einsum("bvd, bqd -> bqv", vis, txt[:, 1:]).softmax(2)
+            x = torch.einsum("bqv,bvh->bqh", attmap, vis_mid)
+            out = ln(enc_x + x)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), vis=_np(vis), txt=_np(txt), vis_mid=_np(vis_mid),
+                            enc_x=_np(enc_x), ln_weight=_np(ln.weight), ln_bias=_np(ln.bias),
+                            ln_eps=np.float32(ln.eps), attmap=_np(attmap), out=_np(out))
+        print(f"{name}: out {tuple(out.shape)}")
+
+
+if __name__ == "__main__":
+    dmv_case("dmv_B4_L10_s0", 0, 4, 10, "rand", store_merged=True)
+    dmv_case("dmv_B4_L10_s1_full", 1, 4, 10, "full")
+    dmv_case("dmv_B5_L7_s2", 2, 5, 7, [7, 5, 3, 1, 6], normalise_attach=True)
+    dmv_case("dmv_B3_L1_s3", 3, 3, 1, "full")
+    dmv_case("dmv_B3_L2_s4", 4, 3, 2, [2, 1, 2])
+    dmv_case("dmv_B8_L40_s0", 0, 8, 40, "rand")
+    dmv_case("dmv_B4_L40_s1_full", 1, 4, 40, "full", normalise_attach=True)
+    dmv_case("dmv_B4_L80_s0", 0, 4, 80, "rand")
+    deptree_case("deptree_B4_N6_s0_enum", 0, 4, 6, "full", enumerate_=True)
+    deptree_case("deptree_B3_N5_s1_enum", 1, 3, 5, "full", enumerate_=True, scale=3.0)
+    deptree_case("deptree_B4_N11_s0", 0, 4, 11, "rand")
+    deptree_case("deptree_B8_N41_s1", 1, 8, 41, "rand")
+    deptree_case("deptree_B2_N81_s2", 2, 2, 81, "rand")
+    deptree_case("deptree_B3_N2_s3", 3, 3, 2, "full")
+    align_cases()
+    attnfuse_cases()
