@@ -1,0 +1,118 @@
+/*
+ * vlgae_amd.h -- C ABI of the MI355X-native structured-DP hot path of VLGAE.
+ *
+ * The reference (LouChao98/VLGAE) is pure Python/PyTorch and has NO foreign-function interface
+ * for this path; the entry points below are what a binding for it would bind.  Each one cites
+ * the reference interface it replaces (paths relative to the reference checkout).  The host
+ * side that mirrors the reference's Python API on top of this ABI is vlgae_amd/torch_struct/
+ * (ctypes; see INTEGRATION.md for the exact stub a maintainer adds).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer to a contiguous, caller-owned buffer (in practice the
+ *     data_ptr() of a PyTorch-ROCm tensor).  The library allocates and frees nothing.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Calls only
+ *     enqueue work: no host synchronisation, no hidden allocation -> HIP-graph capturable.
+ *   - Thread-safe / re-entrant (PyTorch runs backward on its own thread): no global mutable
+ *     state; the last error message is thread-local.
+ *   - Return 0 on success; a VLG_ERR_* code (> 0x1000) or a hipError_t value otherwise, with a
+ *     human-readable message available from vlg_last_error().  Nothing throws across the ABI.
+ *   - Input element type: VLG_F32 or VLG_BF16 (`in_dtype`).  Charts, log-sum-exp accumulators
+ *     and all outputs are fp32.
+ *   - `lengths[b]` = number of words of sentence b (root excluded), 1 <= len <= N-1.  A sentence
+ *     with an out-of-range length gets logZ = NaN and all-zero gradients.
+ *   - Semiring zero is the finite sentinel -1e12 (semirings.py:16,128), never -inf.
+ */
+#ifndef VLGAE_AMD_H
+#define VLGAE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VLG_F32 = 0, VLG_BF16 = 1 };
+enum { VLG_SEMIRING_LOG = 0, VLG_SEMIRING_MAX = 1 };
+enum {
+    VLG_OP_DMV1O_INSIDE = 0,
+    VLG_OP_DMV1O_INSIDE_OUTSIDE = 1,
+    VLG_OP_DEPTREE_INSIDE = 2,
+    VLG_OP_DEPTREE_INSIDE_OUTSIDE = 3
+};
+enum {
+    VLG_ERR_SHAPE = 0x1001,     /* mirrors the reference's shape asserts (deptree.py:149,154) */
+    VLG_ERR_DTYPE = 0x1002,
+    VLG_ERR_ARG = 0x1003,
+    VLG_ERR_WORKSPACE = 0x1004
+};
+
+/* DMV1oStruct._dp through _Struct.sum -- src/model/torch_struct/dmv.py:19-66, helpers.py:101-116
+ * (what `DMV1o([dec, attach], lengths).partition` / `.max` evaluate, distributions.py:116-124,190-193).
+ *   dec    [B,N,2(dir),2(valence),2(decision)]   attach [B,N(head),N(child),2(valence)]   (root-merged)
+ *   logZ   [B]  log-partition (semiring 0) or Viterbi score (semiring 1)
+ *   ws     workspace of vlg_workspace_bytes(VLG_OP_DMV1O_INSIDE, B, N, semiring) bytes (0 for N <= ~100). */
+int vlg_dmv1o_inside(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype,
+                     int semiring, float* logZ, void* ws, size_t ws_bytes, void* stream);
+
+/* Inside + outside in ONE launch.  Replaces `torch.autograd.grad(dist.partition.sum(), [dec, attach])`
+ * (src/model/joint.py:255,320; ldndmv.py:269,295; dmv.py:121), `_Struct.marginals` (helpers.py:118-157)
+ * and the backward of `-dist.partition.sum()` / `-dist.max.sum()` (ldndmv.py:277-281).
+ *   grad_logZ   [B] upstream gradient of logZ, or NULL for all-ones
+ *   grad_dec    [B,N,2,2,2], grad_attach [B,N,N,2]: d(sum_b grad_logZ[b]*logZ[b]) / d(potentials) =
+ *               posterior expected counts (Log) or the 0/1 indicator of the best tree (Max; first
+ *               arg-max on ties like torch.max).  Fully written, exact zeros at padded positions. */
+int vlg_dmv1o_inside_outside(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype,
+                             int semiring, const float* grad_logZ, float* logZ, float* grad_dec, float* grad_attach,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/* DepTree._dp -- src/model/torch_struct/deptree.py:25-76 (`DependencyCRF(arc, lengths).partition/.max`).
+ *   arc [B,N,N] head -> child scores, root at index 0; lengths may be NULL (= N-1, deptree.py:151-152). */
+int vlg_deptree_inside(const void* arc, const int64_t* lengths, int B, int N, int in_dtype, int semiring, float* logZ,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* `DependencyCRF(...).marginals` / `.argmax` -- distributions.py:126-133,162-174 via helpers.py:118-157.
+ *   grad_arc [B,N,N] arc marginals (Log) or the 0/1 best tree (Max). */
+int vlg_deptree_inside_outside(const void* arc, const int64_t* lengths, int B, int N, int in_dtype, int semiring,
+                               const float* grad_logZ, float* logZ, float* grad_arc, void* ws, size_t ws_bytes,
+                               void* stream);
+
+/* DMV1o.merge -- src/model/torch_struct/distributions.py:253-265.
+ *   dec [B,L,2,2,2], attach [B,L,L,2], root [B,L]  ->  dec_wroot [B,L+1,2,2,2], attach_wroot [B,L+1,L+1,2]
+ *   (always fp32, like the reference's torch.full). */
+int vlg_dmv1o_merge(const void* dec, const void* attach, const void* root, int B, int L, int in_dtype, float one,
+                    float zero, float* dec_wroot, float* attach_wroot, void* stream);
+
+/* Bytes of caller-provided scratch the op needs for (B, N); 0 when the charts fit in LDS. */
+size_t vlg_workspace_bytes(int op, int B, int N, int semiring);
+
+/* Region x word bilinear alignment -- DependencyBoxRel.gather_logit_simple, src/model/joint.py:406-419:
+ *   attmap[b,a,q,v] = sum_k txt[b,q,k] * vis[a,v,k];  = neg_inf where !vmask[a,v] or !tmask[b,q]
+ *   txt [B,Q,d], vis [A,V,d] (in_dtype), tmask [B,Q] / vmask [A,V] uint8 (NULL = all true).
+ * Any subset of the outputs may be requested (NULL = skip):
+ *   out_full [B,A,Q,V] fp32           (the reference's return value)
+ *   out_maxV [B,A,Q]   max over V     (consumer: loss_grounding_factor_ce, joint.py:473-476)
+ *   out_maxQ [B,A,V]   max over Q     (joint.py:478-483)
+ *   out_diag [B,Q,V]   attmap[b,b]    (decode_grounding_on_factor, joint.py:519-524; needs A == B) */
+int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A,
+                       int Q, int V, int d, int in_dtype, float neg_inf, float* out_full, float* out_maxV,
+                       float* out_maxQ, float* out_diag, void* stream);
+
+/* Attention-fuse that feeds the parser -- DependencyBoxRel._forward, src/model/joint.py:670-674:
+ *   att = softmax_v(vis[b] . txt[b,1:]) ; x = att . vis_mid[b] ; out = LayerNorm(enc_x + x) * gamma + beta
+ *   vis [B,V,d], txt [B,L+1,d] (root slot first, skipped), vis_mid [B,V,h], enc_x [B,L,h] (in_dtype);
+ *   gamma, beta [h] fp32; out [B,L,h] fp32; out_att [B,L,V] fp32 optional (NULL = skip). */
+int vlg_attn_fuse(const void* vis, const void* txt, const void* vis_mid, const void* enc_x, const float* gamma,
+                  const float* beta, int B, int L, int V, int d, int h, int in_dtype, float eps, float* out_att,
+                  float* out, void* stream);
+
+/* Thread-local message for the last non-zero return on this thread ("" if none). */
+const char* vlg_last_error(void);
+
+/* Library / ABI version, e.g. 100 = 0.1.0. */
+int vlg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLGAE_AMD_H */

@@ -1,0 +1,158 @@
+// emu_dp.cpp -- HOST PHASE EMULATOR of the structured-DP workgroup.  TEST INFRASTRUCTURE ONLY.
+//
+// There is no GPU in the build container, so the CPU test-suite executes the *same* per-thread
+// kernel bodies (vlgae_amd/csrc/vlg_dp_core.h: dmv_run / dep_run) with `nt` host threads standing
+// in for the lanes of one workgroup.  __syncthreads() is replaced by a token barrier that also
+// serialises the threads inside every barrier-delimited phase in a chosen order (forward,
+// reverse or shuffled).  A phase whose result depends on that order has an intra-phase race;
+// the tests require bit-identical results across orders and parity with the oracle.
+//
+// This is NOT a CPU fallback: nothing in vlgae_amd/ loads it, and the product raises if the
+// HIP library is missing.
+#include <algorithm>
+#include <condition_variable>
+#include <cstdint>
+#include <mutex>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../../vlgae_amd/csrc/vlg_dp_core.h"
+
+namespace {
+
+struct Token {
+    std::mutex mu;
+    std::condition_variable cv;
+    long ticket = 0;
+    int nt = 1;
+    void wait_for(long t) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return ticket == t; });
+    }
+    void advance() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ++ticket;
+        }
+        cv.notify_all();
+    }
+};
+
+std::vector<int> make_order(int nt, int order) {
+    std::vector<int> rank(nt);
+    for (int t = 0; t < nt; ++t) rank[t] = t;
+    if (order == 1) std::reverse(rank.begin(), rank.end());
+    if (order >= 2) { std::mt19937 g(order); std::shuffle(rank.begin(), rank.end(), g); }
+    return rank;   // rank[tid] = position of tid inside every phase
+}
+
+template <typename Body>
+void run_workgroup(int nt, int order, Body body) {
+    Token tok;
+    tok.nt = nt;
+    const std::vector<int> rank = make_order(nt, order);
+    std::vector<std::thread> th;
+    for (int tid = 0; tid < nt; ++tid)
+        th.emplace_back([&, tid] {
+            long phase = 0;
+            const int rho = rank[tid];
+            tok.wait_for(rho);
+            auto sync = [&] {
+                tok.advance();
+                ++phase;
+                tok.wait_for(phase * nt + rho);
+            };
+            body(tid, sync);
+            tok.advance();
+        });
+    for (auto& t : th) t.join();
+}
+
+template <int SR, bool BWD, typename In>
+void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int len, int N, float glogZ, float* logZ,
+                 float* gdec, float* gatt, int nt, int order) {
+    const int P = vlg::chart_pitch(N);
+    const size_t cells = (size_t)N * P;
+    std::vector<float2> C(cells), I(cells), gC(cells), gI(cells);
+    std::vector<float> S(cells), decs(N * 8), gdecs(N * 8);
+    std::vector<unsigned char> bpS(cells), bpC(cells * 2);
+    vlg::DmvCtx c;
+    c.Ne = len + 1; c.len = len; c.P = P;
+    c.C = C.data(); c.I = I.data(); c.S = S.data(); c.gC = gC.data(); c.gI = gI.data();
+    c.decs = decs.data(); c.gdecs = gdecs.data(); c.bpS = bpS.data(); c.bpC = bpC.data();
+    run_workgroup(nt, order, [&](int tid, auto sync) {
+        vlg::dmv_run<SR, BWD, In>(c, dec, attach, N, glogZ, logZ, gdec, gatt, tid, nt, sync);
+    });
+}
+
+template <int SR, bool BWD, typename In>
+void emu_dep_one(const typename In::T* arc, int len, int N, float glogZ, float* logZ, float* garc, int nt, int order) {
+    const int P = vlg::chart_pitch(N);
+    const size_t cells = (size_t)N * P;
+    std::vector<float> C(cells), I(cells), gC(cells), gI(cells), S(cells);
+    std::vector<unsigned char> bpS(cells), bpC(cells);
+    vlg::DepCtx c;
+    c.Ne = len + 1; c.len = len; c.P = P;
+    c.C = C.data(); c.I = I.data(); c.S = S.data(); c.gC = gC.data(); c.gI = gI.data();
+    c.bpS = bpS.data(); c.bpC = bpC.data();
+    run_workgroup(nt, order, [&](int tid, auto sync) {
+        vlg::dep_run<SR, BWD, In>(c, arc, N, glogZ, logZ, garc, tid, nt, sync);
+    });
+}
+
+template <typename In>
+int dmv_batch(const void* dec_, const void* attach_, const int64_t* lengths, int B, int N, int semiring,
+              const float* glogZ, float* logZ, float* gdec, float* gatt, int nt, int order) {
+    auto dec = (const typename In::T*)dec_;
+    auto attach = (const typename In::T*)attach_;
+    for (int b = 0; b < B; ++b) {
+        const int len = (int)lengths[b];
+        const size_t doff = (size_t)b * N * 8, aoff = (size_t)b * N * N * 2;
+        if (len < 1 || len > N - 1) return -1;
+        const float g = glogZ ? glogZ[b] : 1.f;
+        if (gdec) {
+            if (semiring == 0) emu_dmv_one<0, true, In>(dec + doff, attach + aoff, len, N, g, logZ + b, gdec + doff, gatt + aoff, nt, order);
+            else emu_dmv_one<1, true, In>(dec + doff, attach + aoff, len, N, g, logZ + b, gdec + doff, gatt + aoff, nt, order);
+        } else {
+            if (semiring == 0) emu_dmv_one<0, false, In>(dec + doff, attach + aoff, len, N, g, logZ + b, nullptr, nullptr, nt, order);
+            else emu_dmv_one<1, false, In>(dec + doff, attach + aoff, len, N, g, logZ + b, nullptr, nullptr, nt, order);
+        }
+    }
+    return 0;
+}
+
+template <typename In>
+int dep_batch(const void* arc_, const int64_t* lengths, int B, int N, int semiring, const float* glogZ, float* logZ,
+              float* garc, int nt, int order) {
+    auto arc = (const typename In::T*)arc_;
+    for (int b = 0; b < B; ++b) {
+        const int len = lengths ? (int)lengths[b] : N - 1;
+        const size_t off = (size_t)b * N * N;
+        if (len < 1 || len > N - 1) return -1;
+        const float g = glogZ ? glogZ[b] : 1.f;
+        if (garc) {
+            if (semiring == 0) emu_dep_one<0, true, In>(arc + off, len, N, g, logZ + b, garc + off, nt, order);
+            else emu_dep_one<1, true, In>(arc + off, len, N, g, logZ + b, garc + off, nt, order);
+        } else {
+            if (semiring == 0) emu_dep_one<0, false, In>(arc + off, len, N, g, logZ + b, nullptr, nt, order);
+            else emu_dep_one<1, false, In>(arc + off, len, N, g, logZ + b, nullptr, nt, order);
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+int emu_dmv1o(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype, int semiring,
+              const float* glogZ, float* logZ, float* gdec, float* gatt, int nt, int order) {
+    return in_dtype == 0 ? dmv_batch<vlg::F32In>(dec, attach, lengths, B, N, semiring, glogZ, logZ, gdec, gatt, nt, order)
+                         : dmv_batch<vlg::BF16In>(dec, attach, lengths, B, N, semiring, glogZ, logZ, gdec, gatt, nt, order);
+}
+int emu_deptree(const void* arc, const int64_t* lengths, int B, int N, int in_dtype, int semiring, const float* glogZ,
+                float* logZ, float* garc, int nt, int order) {
+    return in_dtype == 0 ? dep_batch<vlg::F32In>(arc, lengths, B, N, semiring, glogZ, logZ, garc, nt, order)
+                         : dep_batch<vlg::BF16In>(arc, lengths, B, N, semiring, glogZ, logZ, garc, nt, order);
+}
+}

@@ -1,0 +1,345 @@
+"""GPU parity tests proper: the HIP path (through the C ABI / the drop-in Python API) against
+  (1) golden vectors produced by the reference itself (tests/golden/*.npz),
+  (2) the CPU oracle on fresh seeded inputs,
+  (3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (floating point; stated per check):
+  logZ      |err| <= 2e-5 * max(1, |logZ|)   vs fp64 reference   (fp32 charts: 1 ulp at |logZ|~170 is 1.5e-5)
+  marginals max-abs-err <= 1e-4 (north-star bound); we assert the tighter 2e-5
+  Max semiring: best-tree indicators bit-exact, scores to 1e-5 relative
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, golden_ids, load
+
+pytestmark = pytest.mark.gpu
+
+MARG_TOL = 2e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    return x if dtype is None else x.to(dtype)
+
+
+def logz_tol(ref):
+    return 2e-5 * np.maximum(1.0, np.abs(ref))
+
+
+@pytest.fixture(scope="module")
+def ts():
+    import vlgae_amd.torch_struct as ts
+    from vlgae_amd import _C
+    _C.lib()   # must load: the product has no fallback
+    return ts
+
+
+# ------------------------------------------------------------------------------------------------ DMV1o
+@pytest.mark.parametrize("path", golden_files("dmv_"), ids=golden_ids("dmv_"))
+def test_dmv1o_golden(ts, path):
+    g = load(path)
+    dec, attach, root, lengths = t(g["dec"]), t(g["attach"]), t(g["root"]), t(g["lengths"])
+    mdec, mattach = ts.DMV1o.merge(dec, attach, root)
+    if "merged_dec" in g:   # merge is fill/copy: bit-exact
+        assert torch.equal(mdec.cpu(), torch.from_numpy(g["merged_dec"]))
+        assert torch.equal(mattach.cpu(), torch.from_numpy(g["merged_attach"]))
+    # the call pattern of joint.py:251-256 / ldndmv.py:289-303
+    with torch.enable_grad():
+        d = mdec.detach().requires_grad_()
+        a = mattach.detach().requires_grad_()
+        dist = ts.DMV1o([d, a], lengths)
+        logZ = dist.partition
+        assert tuple(logZ.shape) == (len(g["lengths"]), 1)
+        gd, ga = torch.autograd.grad(logZ.sum(), [d, a])
+    assert np.all(np.abs(logZ.cpu().numpy() - g["logZ64"]) <= logz_tol(g["logZ64"]))
+    assert np.abs(gd.cpu().numpy() - g["grad_dec64"]).max() <= MARG_TOL
+    assert np.abs(ga.cpu().numpy() - g["grad_attach64"]).max() <= MARG_TOL
+    assert np.abs(ga.sum(-1).cpu().numpy() - g["arc_marginal"]).max() <= MARG_TOL
+    # padded positions: exactly zero
+    for b, ln in enumerate(g["lengths"]):
+        assert float(ga[b, ln + 1:].abs().max() if ln + 1 < ga.shape[1] else 0) == 0.0
+        assert float(ga[b, :, ln + 1:].abs().max() if ln + 1 < ga.shape[1] else 0) == 0.0
+
+    # Max semiring: value, one-hot gradient, argmax property, predicted heads (joint.py:256-258)
+    with torch.enable_grad():
+        d = mdec.detach().requires_grad_()
+        a = mattach.detach().requires_grad_()
+        dist = ts.DMV1o([d, a], lengths)
+        mx = dist.max
+        mgd, mga = torch.autograd.grad(mx.sum(), [d, a])
+        am = dist.argmax
+    assert np.allclose(mx.cpu().numpy(), g["max"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(mgd.cpu().numpy(), g["maxgrad_dec"])
+    assert np.array_equal(mga.cpu().numpy(), g["maxgrad_attach"])
+    assert np.array_equal(am.cpu().numpy(), g["argmax"])
+    arc = am.sum(-1).nonzero()
+    predicted = lengths.new_zeros(len(g["lengths"]), g["dec"].shape[1] + 1)
+    predicted[arc[:, 0], arc[:, 2]] = arc[:, 1]
+    assert np.array_equal(predicted.cpu().numpy(), g["predicted"])
+    # .marginals lazy property == attach gradient
+    assert np.abs(dist.marginals.cpu().numpy() - g["marginals"]).max() <= MARG_TOL
+
+    # weighted upstream gradient (grad_logZ scaling) through .backward()
+    d = mdec.detach().requires_grad_()
+    a = mattach.detach().requires_grad_()
+    (ts.DMV1o([d, a], lengths).partition.squeeze(-1) * t(g["wts"])).sum().backward()
+    assert np.abs(d.grad.cpu().numpy() - g["wgrad_dec"]).max() <= 2 * MARG_TOL
+    assert np.abs(a.grad.cpu().numpy() - g["wgrad_attach"]).max() <= 2 * MARG_TOL
+
+    # MBR chain (ldndmv.py:294-299): DependencyCRF over arc marginals, Max semiring.
+    # Fed with the REFERENCE's marginals so that near-ties cannot flip on 1e-6 differences.
+    crf = ts.DependencyCRF(t(g["arc_marginal"]), lengths)
+    assert np.array_equal(crf.argmax.cpu().numpy(), g["mbr_argmax"])
+    assert np.allclose(crf.max.cpu().numpy(), g["mbr_max"], rtol=1e-5, atol=1e-5)
+
+
+def test_dmv1o_no_grad_and_bf16(ts, oracle_mod):
+    g = load(golden_files("dmv_B8_L40_s0")[0])
+    md, ma = oracle_mod.dmv1o_merge(g["dec"], g["attach"], g["root"])
+    lengths = t(g["lengths"])
+    with torch.no_grad():   # inside-only kernel
+        lz = ts.DMV1o([t(md), t(ma)], lengths).partition
+    assert np.all(np.abs(lz.cpu().numpy() - g["logZ64"]) <= logz_tol(g["logZ64"]))
+    # bf16 potentials: parity is defined against the reference algorithm on the SAME bf16-rounded inputs
+    md16, ma16 = t(md).bfloat16(), t(ma).bfloat16()
+    ref_lz, ref_gd, ref_ga = oracle_mod.dmv1o(md16.float().cpu().numpy(), ma16.float().cpu().numpy(), g["lengths"],
+                                              "log", np.float64)
+    d = md16.detach().requires_grad_()
+    a = ma16.detach().requires_grad_()
+    lz = ts.DMV1o([d, a], lengths).partition
+    gd, ga = torch.autograd.grad(lz.sum(), [d, a])
+    assert lz.dtype == torch.float32   # charts / outputs stay fp32
+    assert np.all(np.abs(lz.cpu().numpy() - ref_lz) <= logz_tol(ref_lz))
+    assert np.abs(ga.float().cpu().numpy() - ref_ga).max() <= 4e-3   # gradient cast back to bf16 (8 bits)
+    from vlgae_amd.torch_struct import functional as F
+    _, gd32, ga32 = F.dmv1o_run(md16, ma16, lengths, 0, True)
+    assert np.abs(gd32.cpu().numpy() - ref_gd).max() <= MARG_TOL
+    assert np.abs(ga32.cpu().numpy() - ref_ga).max() <= MARG_TOL
+
+
+@pytest.mark.parametrize("B,L,seed", [(64, 40, 11), (16, 63, 12), (8, 80, 13), (4, 120, 14), (33, 5, 15)])
+def test_dmv1o_vs_oracle_random(ts, oracle_mod, B, L, seed):
+    """Fresh seeded inputs at sizes the oracle finishes in seconds; covers the LDS path (N<=66), the
+    workspace path (N=81: value charts in HBM/L2) and the all-global path (N=121)."""
+    rng = np.random.default_rng(seed)
+    dec = rng.standard_normal((B, L, 2, 2, 2)).astype(np.float32)
+    dec = dec - np.log(np.exp(dec).sum(-1, keepdims=True))
+    attach = rng.standard_normal((B, L, L, 2)).astype(np.float32)
+    root = rng.standard_normal((B, L)).astype(np.float32)
+    lengths = rng.integers(1, L + 1, size=B)
+    lengths[0] = L
+    md, ma = oracle_mod.dmv1o_merge(dec, attach, root)
+    for sr, name in ((0, "log"), (1, "max")):
+        ref_lz, ref_gd, ref_ga = oracle_mod.dmv1o(md, ma, lengths, name, np.float64)
+        from vlgae_amd.torch_struct import functional as F
+        lz, gd, ga = F.dmv1o_run(t(md), t(ma), t(lengths), sr, True)
+        lz0, _, _ = F.dmv1o_run(t(md), t(ma), t(lengths), sr, False)
+        assert np.all(np.abs(lz.cpu().numpy()[:, None] - ref_lz) <= logz_tol(ref_lz)), name
+        assert torch.equal(lz, lz0), "inside-only and fused kernels must agree bit for bit"
+        if sr == 0:
+            assert np.abs(gd.cpu().numpy() - ref_gd).max() <= MARG_TOL
+            assert np.abs(ga.cpu().numpy() - ref_ga).max() <= MARG_TOL
+        else:   # best tree: compare as trees (ties have measure zero for continuous inputs)
+            assert np.array_equal(ga.cpu().numpy(), ref_ga.astype(np.float32))
+            assert np.array_equal(gd.cpu().numpy(), ref_gd.astype(np.float32))
+
+
+def test_dmv1o_properties_full_size(ts):
+    """BASELINE.json config 2 (B=256, L=40): size-independent identities."""
+    B, L = 256, 40
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    dec = torch.randn(B, L, 2, 2, 2, generator=gen).log_softmax(-1).to(dev())
+    attach = torch.randn(B, L, L, 2, generator=gen).to(dev())
+    root = torch.randn(B, L, generator=gen).log_softmax(-1).to(dev())
+    lengths = torch.randint(1, L + 1, (B,), generator=gen)
+    lengths[0] = L
+    lengths = lengths.to(dev())
+    md, ma = ts.DMV1o.merge(dec, attach, root)
+    d, a = md.detach().requires_grad_(), ma.detach().requires_grad_()
+    dist = ts.DMV1o([d, a], lengths)
+    gd, ga = torch.autograd.grad(dist.partition.sum(), [d, a])
+    lf = lengths.float()
+    assert torch.allclose(ga.sum((1, 2, 3)), lf, atol=2e-4)                 # (ii) one head per word
+    assert torch.allclose(gd.sum((1, 2, 3, 4)), 3 * lf + 1, atol=5e-4)      # (iii) decisions: 2 STOP + 1 GO per word, + root STOP
+    col = ga.sum(-1).sum(1)                                                 # (iv) every word has exactly one head
+    idx = torch.arange(L + 1, device=dev())[None]
+    valid = (idx >= 1) & (idx <= lengths[:, None])
+    assert torch.allclose(col[valid], torch.ones_like(col[valid]), atol=2e-4)
+    assert float(col[~valid].abs().max()) == 0.0                            # (v) padding: exact zeros
+    assert float(ga.min()) >= 0.0 and float(ga.max()) <= 1.0 + 1e-5
+    # Max <= Log, and the best tree is a tree
+    mx = ts.DMV1o([md, ma], lengths).max
+    assert bool((mx <= dist.partition + 1e-4).all())
+    am = ts.DMV1o([md, ma], lengths).argmax.sum(-1)
+    assert torch.equal(am.sum(1)[valid], torch.ones_like(am.sum(1)[valid]))
+    assert torch.equal(am[:, 0].sum(-1), torch.ones(B, device=dev()))       # single root
+    # (i) dec == 0 and valence-independent attach  ==>  DMV1o == DependencyCRF on the same arcs
+    arc = torch.randn(B, L + 1, L + 1, generator=gen).to(dev())
+    z = torch.zeros(B, L + 1, 2, 2, 2, device=dev())
+    lz_dmv = ts.DMV1o([z, arc[..., None].expand(-1, -1, -1, 2).contiguous()], lengths).partition.squeeze(-1)
+    arc_crf = arc.clone()
+    arc_crf[:, :, 0] = -1e12   # DMV never attaches the root as a child; CRF needs the same exclusion
+    lz_crf = ts.DependencyCRF(arc_crf, lengths).partition
+    # DMV's root has valence NOCHILD only for its single child; with valence-independent scores they coincide
+    assert torch.allclose(lz_dmv, lz_crf, rtol=1e-5, atol=1e-3)
+    # determinism: same launch twice, bit-identical (no atomics anywhere in the kernels)
+    gd2, ga2 = torch.autograd.grad(ts.DMV1o([d, a], lengths).partition.sum(), [d, a])
+    assert torch.equal(ga, ga2) and torch.equal(gd, gd2)
+
+
+def test_dmv1o_edge_cases(ts):
+    # B = 0
+    lz = ts.DMV1o([torch.zeros(0, 5, 2, 2, 2, device=dev()), torch.zeros(0, 5, 5, 2, device=dev())],
+                  torch.zeros(0, dtype=torch.long, device=dev())).partition
+    assert tuple(lz.shape) == (0, 1)
+    # out-of-range length: NaN score, zero counts, neighbours unaffected
+    from vlgae_amd.torch_struct import functional as F
+    md = torch.randn(3, 6, 2, 2, 2, device=dev())
+    ma = torch.randn(3, 6, 6, 2, device=dev())
+    lz, gd, ga = F.dmv1o_run(md, ma, torch.tensor([5, 9, 0], device=dev()), 0, True)
+    assert torch.isfinite(lz[0]) and torch.isnan(lz[1]) and torch.isnan(lz[2])
+    assert float(ga[1:].abs().max()) == 0.0 and float(gd[1:].abs().max()) == 0.0
+    # shape violations raise (mirrors the reference's asserts)
+    with pytest.raises(ValueError):
+        F.dmv1o_run(md, ma[:, :5], torch.tensor([5, 5, 5], device=dev()), 0, False)
+    with pytest.raises(RuntimeError):
+        F.dmv1o_run(torch.zeros(2, 300, 2, 2, 2, device=dev()), torch.zeros(2, 300, 300, 2, device=dev()),
+                    torch.tensor([5, 5], device=dev()), 0, False)
+    # non-contiguous inputs and CPU-resident lengths are accepted
+    big = torch.randn(3, 6, 6, 4, device=dev())
+    lz2, _, _ = F.dmv1o_run(md, big[..., ::2], torch.tensor([5, 4, 3]), 0, False)
+    lz3, _, _ = F.dmv1o_run(md, big[..., ::2].contiguous(), torch.tensor([5, 4, 3], device=dev()), 0, False)
+    assert torch.equal(lz2, lz3)
+
+
+# ------------------------------------------------------------------------------------------------ DepTree
+@pytest.mark.parametrize("path", golden_files("deptree_"), ids=golden_ids("deptree_"))
+def test_deptree_golden(ts, path):
+    g = load(path)
+    arc, lengths = t(g["arc"]), t(g["lengths"])
+    dist = ts.DependencyCRF(arc.clone(), lengths)
+    lz = dist.partition
+    assert tuple(lz.shape) == (arc.shape[0],)
+    assert np.all(np.abs(lz.cpu().numpy() - g["logZ64"]) <= logz_tol(g["logZ64"]))
+    assert np.abs(dist.marginals.cpu().numpy() - g["marginals64"]).max() <= MARG_TOL
+    assert np.allclose(dist.max.cpu().numpy(), g["max"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(dist.argmax.cpu().numpy(), g["argmax"])
+    if "enum_logZ" in g:   # brute force over all projective single-root trees (deptree.py:213-228)
+        assert np.all(np.abs(lz.cpu().numpy() - g["enum_logZ"]) <= logz_tol(g["enum_logZ"]))
+        assert np.allclose(dist.max.cpu().numpy(), g["enum_max"], rtol=1e-5, atol=1e-5)
+    a = arc.clone().requires_grad_()
+    (ts.DependencyCRF(a, lengths).partition * t(g["wts"])).sum().backward()
+    assert np.abs(a.grad.cpu().numpy() - g["wgrad"]).max() <= 2 * MARG_TOL
+    # lengths=None means N-1 (deptree.py:151-152)
+    if np.all(g["lengths"] == arc.shape[1] - 1):
+        assert torch.equal(ts.DependencyCRF(arc.clone()).partition, lz)
+
+
+@pytest.mark.parametrize("B,N,seed", [(64, 41, 21), (8, 81, 22), (4, 150, 23), (300, 4, 24)])
+def test_deptree_vs_oracle_random(ts, oracle_mod, B, N, seed):
+    rng = np.random.default_rng(seed)
+    arc = rng.standard_normal((B, N, N)).astype(np.float32)
+    lengths = rng.integers(1, N, size=B)
+    lengths[0] = N - 1
+    from vlgae_amd.torch_struct import functional as F
+    for sr, name in ((0, "log"), (1, "max")):
+        ref_lz, ref_g = oracle_mod.deptree(arc, lengths, name, np.float64)
+        lz, garc = F.deptree_run(t(arc), t(lengths), sr, True)
+        assert np.all(np.abs(lz.cpu().numpy() - ref_lz) <= logz_tol(ref_lz))
+        if sr == 0:
+            assert np.abs(garc.cpu().numpy() - ref_g).max() <= MARG_TOL
+            col = garc.sum(1).cpu().numpy()   # column sums are 1 inside the sentence, 0 outside
+            for b in range(B):
+                assert np.allclose(col[b, 1:lengths[b] + 1], 1.0, atol=1e-4)
+                assert np.all(col[b, lengths[b] + 1:] == 0) and col[b, 0] == 0
+        else:
+            assert np.array_equal(garc.cpu().numpy(), ref_g.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------ alignment
+@pytest.mark.parametrize("path", golden_files("align_"), ids=golden_ids("align_"))
+def test_bilinear_align_golden(path):
+    from vlgae_amd import align
+    g = load(path)
+    txt, vis, tm, vm = t(g["txt"]), t(g["vis"]), t(g["tmask"]), t(g["vmask"])
+    out = align.gather_logit(None, (vis.refine_names("A", "V", "Y"), vm.refine_names("A", "V"), None),
+                             (txt.refine_names("B", "Q", "X"), tm.refine_names("B", "Q"), None), None)
+    assert out.names == ("B", "A", "Q", "V")
+    got = out.rename(None).cpu().numpy()
+    ref = g["attmap"]
+    masked = ref <= -1e19
+    assert np.array_equal(got[masked], ref[masked])                     # exactly -INF (1e20) where masked
+    assert np.abs(got[~masked] - ref[~masked]).max() <= 2e-4           # fp32 dot of length d, |x| ~ sqrt(d)
+    if "bf16" in path:   # bf16 kernel input path on the same (bf16-representable) values
+        o16 = align.bilinear_align(txt.bfloat16(), vis.bfloat16(), tm, vm)["full"].cpu().numpy()
+        assert np.abs(o16[~masked] - ref[~masked]).max() <= 2e-4
+    # fused epilogues against the materialised tensor
+    B, A = txt.shape[0], vis.shape[0]
+    r = align.bilinear_align(txt, vis, tm, vm, full=True, max_v=True, max_q=True, diag=(A == B))
+    full = r["full"]
+    assert torch.equal(r["max_v"], full.max(-1).values)
+    assert torch.equal(r["max_q"], full.max(-2).values)
+    if A == B:
+        assert torch.equal(r["diag"], full[torch.arange(B), torch.arange(B)])
+    r2 = align.bilinear_align(txt, vis, tm, vm, full=False, max_v=True, max_q=True)
+    assert torch.equal(r2["max_v"], r["max_v"]) and torch.equal(r2["max_q"], r["max_q"]) and "full" not in r2
+
+
+def test_bilinear_align_backward_and_sizes(oracle_mod):
+    from vlgae_amd import align
+    rng = np.random.default_rng(5)
+    for (B, A, Q, V, d) in [(3, 2, 5, 70, 16), (2, 9, 130, 3, 40), (5, 5, 82, 36, 128)]:
+        txt = rng.standard_normal((B, Q, d)).astype(np.float32)
+        vis = rng.standard_normal((A, V, d)).astype(np.float32)
+        tm = rng.random((B, Q)) > 0.2
+        vm = rng.random((A, V)) > 0.2
+        ref = oracle_mod.bilinear_align(txt, vis, tm, vm, np.float64, -1e20, full=True, maxV=True, maxQ=True)
+        r = align.bilinear_align(t(txt), t(vis), t(tm), t(vm), max_v=True, max_q=True)
+        keep = ref["full"] > -1e19
+        assert np.abs(r["full"].cpu().numpy()[keep] - ref["full"][keep]).max() <= 1e-4
+        assert np.all(r["full"].cpu().numpy()[~keep] == np.float32(-1e20))
+        assert np.allclose(r["max_v"].cpu().numpy(), ref["maxV"], atol=1e-4, rtol=0)
+        assert np.allclose(r["max_q"].cpu().numpy(), ref["maxQ"], atol=1e-4, rtol=0)
+    # gradients of the contraction (masked entries carry none)
+    tx = t(txt).requires_grad_()
+    vi = t(vis).requires_grad_()
+    w = torch.randn(B, A, Q, V, device=dev())
+    out = align.gather_logit(None, (vi, t(vm), None), (tx, t(tm), None), None).rename(None)
+    (out * w).sum().backward()
+    keepm = (t(tm)[:, None, :, None] & t(vm)[None, :, None, :]).float()
+    tx2 = t(txt).requires_grad_()
+    vi2 = t(vis).requires_grad_()
+    (torch.einsum("avd,bqd->baqv", vi2, tx2) * w * keepm).sum().backward()
+    assert torch.allclose(tx.grad, tx2.grad, atol=1e-3, rtol=1e-4)
+    assert torch.allclose(vi.grad, vi2.grad, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("path", golden_files("attnfuse_"), ids=golden_ids("attnfuse_"))
+def test_attn_fuse_golden(path):
+    from vlgae_amd import align
+    g = load(path)
+    out, att = align.attention_fuse(t(g["vis"]), t(g["txt"]), t(g["vis_mid"]), t(g["enc_x"]), t(g["ln_weight"]),
+                                    t(g["ln_bias"]), float(g["ln_eps"]), return_attmap=True)
+    assert np.abs(att.cpu().numpy() - g["attmap"]).max() <= 2e-5       # softmax probabilities
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= 1e-4          # LayerNorm output, O(1) values
+
+
+def test_attn_fuse_large_v(oracle_mod):
+    """V = 1296 factors (the shipped config's 35 + 35^2 + 35 + 1) exercises the word-chunked launch."""
+    from vlgae_amd import align
+    rng = np.random.default_rng(9)
+    B, L, V, d, h = 2, 13, 1296, 128, 256
+    vis, txt = rng.standard_normal((B, V, d)).astype(np.float32) * 0.3, rng.standard_normal((B, L + 1, d)).astype(np.float32) * 0.3
+    mid, enc = rng.standard_normal((B, V, h)).astype(np.float32), rng.standard_normal((B, L, h)).astype(np.float32)
+    gm, bt = (rng.random(h) + 0.5).astype(np.float32), rng.standard_normal(h).astype(np.float32)
+    ref_att, ref_out = oracle_mod.attn_fuse(vis, txt, mid, enc, gm, bt, 1e-5, np.float64)
+    out, att = align.attention_fuse(t(vis), t(txt), t(mid), t(enc), t(gm), t(bt), 1e-5, return_attmap=True)
+    assert np.abs(att.cpu().numpy() - ref_att).max() <= 2e-5
+    assert np.abs(out.cpu().numpy() - ref_out).max() <= 1e-4

@@ -1,0 +1,77 @@
+"""ctypes binding of the C ABI in include/vlgae_amd.h.
+
+The HIP library is the ONLY compute path of this package: if it is missing or fails to load,
+importing an op raises.  There is no CPU / eager-PyTorch fallback.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "_lib", "libvlgae_amd.so")
+
+F32, BF16 = 0, 1
+SEMIRING_LOG, SEMIRING_MAX = 0, 1
+OP_DMV1O_INSIDE, OP_DMV1O_INSIDE_OUTSIDE, OP_DEPTREE_INSIDE, OP_DEPTREE_INSIDE_OUTSIDE = 0, 1, 2, 3
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# symbol -> (restype, argtypes); one entry per declaration in include/vlgae_amd.h
+SIGNATURES = {
+    "vlg_dmv1o_inside": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "vlg_dmv1o_inside_outside": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vlg_deptree_inside": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "vlg_deptree_inside_outside": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vlg_dmv1o_merge": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "vlg_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "vlg_bilinear_align": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "vlg_attn_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "vlg_last_error": (ctypes.c_char_p, []),
+    "vlg_version": (_i, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libvlgae_amd.so (once).  Raises if it has not been built: no fallback exists."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"vlgae_amd: HIP extension not built ({LIB_PATH} missing). Run `python -m vlgae_amd.build` "
+                "(needs hipcc, cross-compiles for gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().vlg_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"vlgae_amd.{what} failed (code {rc:#x}): {msg}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"vlgae_amd.{what}: tensors must live on an MI355X (got device '{t.device}'). This package has no CPU path.")
+
+
+def in_dtype(t):
+    """Kernel input element type for tensor t and the tensor to hand over (contiguous)."""
+    if t.dtype == torch.bfloat16:
+        return BF16, t.contiguous()
+    return F32, t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()

@@ -1,0 +1,14 @@
+// vlg_capi.cpp -- thread-local error state and version of the C ABI (include/vlgae_amd.h).
+#include "vlg_common.h"
+
+namespace vlg {
+char* error_buffer() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+}  // namespace vlg
+
+extern "C" {
+const char* vlg_last_error(void) { return vlg::error_buffer(); }
+int vlg_version(void) { return 100; }
+}

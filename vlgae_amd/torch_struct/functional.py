@@ -1,0 +1,167 @@
+"""Autograd-aware entry points over the C ABI (include/vlgae_amd.h).
+
+The reference differentiates its inside loop with autograd (hundreds of AsStridedBackward nodes per
+call).  Here the outside pass is part of the same kernel launch as the inside
+pass: when any potential requires grad, forward() runs the fused inside+outside kernel and keeps the
+unit-upstream expected counts; backward() only scales them by the incoming gradient of logZ.
+"""
+import torch
+
+from .. import _C
+from .semirings import NEGINF
+
+
+def _workspace(op, B, N, semiring, device):
+    nbytes = _C.lib().vlg_workspace_bytes(op, B, N, semiring)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+def _lengths(lengths, B, device, allow_none=False):
+    if lengths is None:
+        if allow_none:
+            return None
+        raise ValueError("lengths is required")
+    if not torch.is_tensor(lengths):
+        lengths = torch.as_tensor(lengths)
+    lengths = lengths.to(device=device, dtype=torch.int64).contiguous()
+    if lengths.shape != (B,):
+        raise ValueError(f"lengths must have shape ({B},), got {tuple(lengths.shape)}")
+    return lengths
+
+
+def dmv1o_run(dec, attach, lengths, semiring, want_grad, grad_logZ=None):
+    """Raw launcher.  dec [B,N,2,2,2], attach [B,N,N,2] -> logZ [B] (+ grad_dec, grad_attach fp32)."""
+    _C.require_gpu(dec, "dmv1o")
+    if dec.dim() != 5 or tuple(dec.shape[2:]) != (2, 2, 2):
+        raise ValueError(f"dec must be [B,N,2,2,2], got {tuple(dec.shape)}")
+    B, N = dec.shape[:2]
+    if tuple(attach.shape) != (B, N, N, 2):
+        raise ValueError(f"attach must be [B,N,N,2] = {(B, N, N, 2)}, got {tuple(attach.shape)}")
+    if dec.dtype != attach.dtype:
+        attach = attach.to(dec.dtype)
+    dt, dec_c = _C.in_dtype(dec.detach())
+    _, att_c = _C.in_dtype(attach.detach())
+    lengths = _lengths(lengths, B, dec.device)
+    logZ = torch.empty(B, dtype=torch.float32, device=dec.device)
+    L = _C.lib()
+    if want_grad:
+        gdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dec.device)
+        gatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dec.device)
+        ws, nb = _workspace(_C.OP_DMV1O_INSIDE_OUTSIDE, B, N, semiring, dec.device)
+        g = None if grad_logZ is None else grad_logZ.detach().to(torch.float32).reshape(B).contiguous()
+        _C.check(L.vlg_dmv1o_inside_outside(_C.ptr(dec_c), _C.ptr(att_c), _C.ptr(lengths), B, N, dt, semiring,
+                                            _C.ptr(g), _C.ptr(logZ), _C.ptr(gdec), _C.ptr(gatt), _C.ptr(ws), nb,
+                                            _C.stream_of(dec)), "dmv1o_inside_outside")
+        return logZ, gdec, gatt
+    ws, nb = _workspace(_C.OP_DMV1O_INSIDE, B, N, semiring, dec.device)
+    _C.check(L.vlg_dmv1o_inside(_C.ptr(dec_c), _C.ptr(att_c), _C.ptr(lengths), B, N, dt, semiring, _C.ptr(logZ),
+                                _C.ptr(ws), nb, _C.stream_of(dec)), "dmv1o_inside")
+    return logZ, None, None
+
+
+def deptree_run(arc, lengths, semiring, want_grad, grad_logZ=None):
+    """Raw launcher.  arc [B,N,N] -> logZ [B] (+ grad_arc fp32)."""
+    _C.require_gpu(arc, "deptree")
+    if arc.dim() != 3:
+        raise ValueError("potentials must have dim of 3 (unlabeled)")   # deptree.py:30-31 (labeled: out of scope)
+    B, N, N2 = arc.shape
+    assert N == N2, "Non-square potentials"                              # deptree.py:149
+    dt, arc_c = _C.in_dtype(arc.detach())
+    lengths = _lengths(lengths, B, arc.device, allow_none=True)
+    logZ = torch.empty(B, dtype=torch.float32, device=arc.device)
+    L = _C.lib()
+    if want_grad:
+        garc = torch.empty((B, N, N), dtype=torch.float32, device=arc.device)
+        ws, nb = _workspace(_C.OP_DEPTREE_INSIDE_OUTSIDE, B, N, semiring, arc.device)
+        g = None if grad_logZ is None else grad_logZ.detach().to(torch.float32).reshape(B).contiguous()
+        _C.check(L.vlg_deptree_inside_outside(_C.ptr(arc_c), _C.ptr(lengths), B, N, dt, semiring, _C.ptr(g),
+                                              _C.ptr(logZ), _C.ptr(garc), _C.ptr(ws), nb, _C.stream_of(arc)),
+                 "deptree_inside_outside")
+        return logZ, garc
+    ws, nb = _workspace(_C.OP_DEPTREE_INSIDE, B, N, semiring, arc.device)
+    _C.check(L.vlg_deptree_inside(_C.ptr(arc_c), _C.ptr(lengths), B, N, dt, semiring, _C.ptr(logZ), _C.ptr(ws), nb,
+                                  _C.stream_of(arc)), "deptree_inside")
+    return logZ, None
+
+
+class _DMV1oSum(torch.autograd.Function):
+    """semiring-sum over all trees; d/d(potentials) = expected counts (Log) / best tree (Max)."""
+
+    @staticmethod
+    def forward(ctx, dec, attach, lengths, semiring):
+        want = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        logZ, gdec, gatt = dmv1o_run(dec, attach, lengths, semiring, want)
+        if want:
+            ctx.save_for_backward(gdec, gatt)
+        ctx.in_dtypes = (dec.dtype, attach.dtype)
+        return logZ.to(dec.dtype if dec.dtype == torch.float64 else torch.float32).unsqueeze(-1)   # [B,1], helpers.py:116
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gdec, gatt = ctx.saved_tensors
+        g = grad_out.reshape(-1).to(torch.float32)
+        gd = (gdec * g.view(-1, 1, 1, 1, 1)).to(ctx.in_dtypes[0]) if ctx.needs_input_grad[0] else None
+        ga = (gatt * g.view(-1, 1, 1, 1)).to(ctx.in_dtypes[1]) if ctx.needs_input_grad[1] else None
+        return gd, ga, None, None
+
+
+class _DepTreeSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, arc, lengths, semiring):
+        want = ctx.needs_input_grad[0]
+        logZ, garc = deptree_run(arc, lengths, semiring, want)
+        if want:
+            ctx.save_for_backward(garc)
+        ctx.in_dtype = arc.dtype
+        return logZ.to(arc.dtype if arc.dtype == torch.float64 else torch.float32)                  # [B], deptree.py:75
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (garc,) = ctx.saved_tensors
+        return (garc * grad_out.reshape(-1, 1, 1).to(torch.float32)).to(ctx.in_dtype), None, None
+
+
+def dmv1o_sum(dec, attach, lengths, semiring):
+    return _DMV1oSum.apply(dec, attach, lengths, semiring)
+
+
+def deptree_sum(arc, lengths, semiring):
+    return _DepTreeSum.apply(arc, lengths, semiring)
+
+
+def dmv1o_merge(dec, attach, root, one=0.0, zero=NEGINF):
+    """DMV1o.merge (distributions.py:253-265): root-augmented potentials, always float32."""
+    _C.require_gpu(dec, "dmv1o_merge")
+    B, Lw = dec.shape[:2]
+    if tuple(dec.shape) != (B, Lw, 2, 2, 2) or tuple(attach.shape) != (B, Lw, Lw, 2) or tuple(root.shape) != (B, Lw):
+        raise ValueError(f"merge: dec {tuple(dec.shape)}, attach {tuple(attach.shape)}, root {tuple(root.shape)}")
+    dt, dec_c = _C.in_dtype(dec.detach())
+    attach = attach.detach().to(dec_c.dtype).contiguous()
+    root = root.detach().to(dec_c.dtype).contiguous()
+    N = Lw + 1
+    dec_w = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dec.device)
+    att_w = torch.empty((B, N, N, 2), dtype=torch.float32, device=dec.device)
+    _C.check(_C.lib().vlg_dmv1o_merge(_C.ptr(dec_c), _C.ptr(attach), _C.ptr(root), B, Lw, dt, float(one), float(zero),
+                                      _C.ptr(dec_w), _C.ptr(att_w), _C.stream_of(dec)), "dmv1o_merge")
+    return dec_w, att_w
+
+
+class _Merge(torch.autograd.Function):
+    """merge is fill + copy; its adjoint is three slices (the reference gets this from autograd on the
+    in-place index assignments of distributions.py:260-264)."""
+
+    @staticmethod
+    def forward(ctx, dec, attach, root, one, zero):
+        ctx.in_dtypes = (dec.dtype, attach.dtype, root.dtype)
+        return dmv1o_merge(dec, attach, root, one, zero)
+
+    @staticmethod
+    def backward(ctx, g_dec_w, g_att_w):
+        d0, d1, d2 = ctx.in_dtypes
+        return (g_dec_w[:, 1:].to(d0), g_att_w[:, 1:, 1:, :].to(d1), g_att_w[:, 0, 1:, 1].to(d2), None, None)
+
+
+def dmv1o_merge_autograd(dec, attach, root, one=0.0, zero=NEGINF):
+    return _Merge.apply(dec, attach, root, one, zero)
