@@ -1,0 +1,65 @@
+"""ctypes front-end of the host phase emulator (tests/emu/emu_dp.cpp).  TEST INFRASTRUCTURE ONLY."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libvlg_emu.so")
+_CORE = os.path.join(_HERE, "..", "..", "vlgae_amd", "csrc", "vlg_dp_core.h")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(_HERE, "emu_dp.cpp")
+        stale = (not os.path.exists(_SO)) or any(os.path.getmtime(f) > os.path.getmtime(_SO) for f in (src, _CORE))
+        if stale:
+            os.makedirs(os.path.dirname(_SO), exist_ok=True)
+            subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", src, "-o", _SO], check=True)
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _bf16_bits(a):
+    """round-to-nearest-even fp32 -> bf16 bit patterns (uint16)"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def dmv1o(dec, attach, lengths, semiring=0, grad=True, glogZ=None, nt=16, order=0, bf16=False):
+    B, N = dec.shape[:2]
+    if bf16:
+        dec, attach = _bf16_bits(dec), _bf16_bits(attach)
+    else:
+        dec, attach = np.ascontiguousarray(dec, np.float32), np.ascontiguousarray(attach, np.float32)
+    ln = np.ascontiguousarray(lengths, np.int64)
+    lz = np.full(B, np.nan, np.float32)
+    gd = np.full((B, N, 2, 2, 2), np.nan, np.float32) if grad else None
+    ga = np.full((B, N, N, 2), np.nan, np.float32) if grad else None
+    g = None if glogZ is None else np.ascontiguousarray(glogZ, np.float32)
+    rc = lib().emu_dmv1o(_p(dec), _p(attach), _p(ln), B, N, int(bf16), semiring, _p(g), _p(lz), _p(gd), _p(ga), nt, order)
+    assert rc == 0
+    return lz, gd, ga
+
+
+def deptree(arc, lengths, semiring=0, grad=True, glogZ=None, nt=16, order=0):
+    B, N = arc.shape[:2]
+    arc = np.ascontiguousarray(arc, np.float32)
+    ln = None if lengths is None else np.ascontiguousarray(lengths, np.int64)
+    lz = np.full(B, np.nan, np.float32)
+    ga = np.full((B, N, N), np.nan, np.float32) if grad else None
+    g = None if glogZ is None else np.ascontiguousarray(glogZ, np.float32)
+    rc = lib().emu_deptree(_p(arc), _p(ln), B, N, 0, semiring, _p(g), _p(lz), _p(ga), nt, order)
+    assert rc == 0
+    return lz, ga
+
+
+def canary_trips():
+    return int(lib().emu_canary_trips())

@@ -69,36 +69,53 @@ void run_workgroup(int nt, int order, Body body) {
     for (auto& t : th) t.join();
 }
 
+// The working set is carved out of ONE buffer with exactly the kernel's layout (DmvLayout / DepLayout),
+// followed by a canary: a phase body that writes an array the layout did not allocate (e.g. the
+// outside-pass tape when only the inside pass was requested) trips it.
+constexpr size_t kCanary = 1 << 16;
+static int g_canary_trips = 0;
+
+struct Arena {
+    std::vector<unsigned char> buf;
+    size_t total;
+    explicit Arena(size_t total_) : buf(total_ + kCanary, 0xA5), total(total_) {}
+    char* at(size_t off) { return reinterpret_cast<char*>(buf.data()) + off; }
+    void check() {
+        for (size_t i = total; i < buf.size(); ++i)
+            if (buf[i] != 0xA5) { ++g_canary_trips; return; }
+    }
+};
+
 template <int SR, bool BWD, typename In>
 void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int len, int N, float glogZ, float* logZ,
                  float* gdec, float* gatt, int nt, int order) {
-    const int P = vlg::chart_pitch(N);
-    const size_t cells = (size_t)N * P;
-    std::vector<float2> C(cells), I(cells), gC(cells), gI(cells);
-    std::vector<float> S(cells), decs(N * 8), gdecs(N * 8);
-    std::vector<unsigned char> bpS(cells), bpC(cells * 2);
+    const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX);
+    Arena A(L.total);
     vlg::DmvCtx c;
-    c.Ne = len + 1; c.len = len; c.P = P;
-    c.C = C.data(); c.I = I.data(); c.S = S.data(); c.gC = gC.data(); c.gI = gI.data();
-    c.decs = decs.data(); c.gdecs = gdecs.data(); c.bpS = bpS.data(); c.bpC = bpC.data();
+    c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
+    c.C = (float2*)A.at(L.C); c.I = (float2*)A.at(L.I); c.S = (float*)A.at(L.S);
+    c.bpS = (unsigned char*)A.at(L.bpS); c.bpC = (unsigned char*)A.at(L.bpC);
+    c.gC = (float2*)A.at(L.gC); c.gI = (float2*)A.at(L.gI);
+    c.decs = (float*)A.at(L.decs); c.gdecs = (float*)A.at(L.gdecs);
     run_workgroup(nt, order, [&](int tid, auto sync) {
         vlg::dmv_run<SR, BWD, In>(c, dec, attach, N, glogZ, logZ, gdec, gatt, tid, nt, sync);
     });
+    A.check();
 }
 
 template <int SR, bool BWD, typename In>
 void emu_dep_one(const typename In::T* arc, int len, int N, float glogZ, float* logZ, float* garc, int nt, int order) {
-    const int P = vlg::chart_pitch(N);
-    const size_t cells = (size_t)N * P;
-    std::vector<float> C(cells), I(cells), gC(cells), gI(cells), S(cells);
-    std::vector<unsigned char> bpS(cells), bpC(cells);
+    const vlg::DepLayout L(N, BWD, SR == VLG_SR_MAX);
+    Arena A(L.total);
     vlg::DepCtx c;
-    c.Ne = len + 1; c.len = len; c.P = P;
-    c.C = C.data(); c.I = I.data(); c.S = S.data(); c.gC = gC.data(); c.gI = gI.data();
-    c.bpS = bpS.data(); c.bpC = bpC.data();
+    c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
+    c.C = (float*)A.at(L.C); c.I = (float*)A.at(L.I); c.S = (float*)A.at(L.S);
+    c.bpS = (unsigned char*)A.at(L.bpS); c.bpC = (unsigned char*)A.at(L.bpC);
+    c.gC = (float*)A.at(L.gC); c.gI = (float*)A.at(L.gI);
     run_workgroup(nt, order, [&](int tid, auto sync) {
         vlg::dep_run<SR, BWD, In>(c, arc, N, glogZ, logZ, garc, tid, nt, sync);
     });
+    A.check();
 }
 
 template <typename In>
@@ -145,6 +162,7 @@ int dep_batch(const void* arc_, const int64_t* lengths, int B, int N, int semiri
 }  // namespace
 
 extern "C" {
+int emu_canary_trips(void) { return g_canary_trips; }
 int emu_dmv1o(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype, int semiring,
               const float* glogZ, float* logZ, float* gdec, float* gatt, int nt, int order) {
     return in_dtype == 0 ? dmv_batch<vlg::F32In>(dec, attach, lengths, B, N, semiring, glogZ, logZ, gdec, gatt, nt, order)

@@ -1,0 +1,95 @@
+"""CPU: the per-thread bodies of the HIP kernels (vlgae_amd/csrc/vlg_dp_core.h), executed by the host
+phase emulator, against golden vectors from the reference and against the oracle.
+
+What this proves without a GPU: index arithmetic, phase ordering, the ownership argument of the
+outside pass (results must be bit-identical for every intra-phase thread order and thread count), and
+that no phase touches memory outside the kernel's own chart layout (canary).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_files, golden_ids, load
+from emu import emu
+
+
+def _tol(ref):
+    return 2e-5 * np.maximum(1.0, np.abs(ref))
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("dmv_") if "L80" not in p],
+                         ids=[i for i in golden_ids("dmv_") if "L80" not in i])
+def test_emu_dmv1o_golden(oracle_mod, path):
+    g = load(path)
+    md, ma = oracle_mod.dmv1o_merge(g["dec"], g["attach"], g["root"])
+    lz, gd, ga = emu.dmv1o(md, ma, g["lengths"], 0, nt=16, order=0)
+    assert np.all(np.abs(lz - g["logZ64"][:, 0]) <= _tol(g["logZ64"][:, 0]))
+    assert np.abs(gd - g["grad_dec64"]).max() <= 2e-5
+    assert np.abs(ga - g["grad_attach64"]).max() <= 2e-5
+    # thread order / thread count independence, bit for bit (no intra-phase races, no atomics)
+    for nt, order in ((7, 1), (33, 5)):
+        lz2, gd2, ga2 = emu.dmv1o(md, ma, g["lengths"], 0, nt=nt, order=order)
+        assert np.array_equal(lz, lz2) and np.array_equal(gd, gd2) and np.array_equal(ga, ga2)
+    # inside-only kernel: same logZ bit for bit, and must not touch the outside-pass tape
+    lz3, _, _ = emu.dmv1o(md, ma, g["lengths"], 0, grad=False, nt=12, order=2)
+    assert np.array_equal(lz, lz3)
+    # Max semiring: exact
+    mz, mgd, mga = emu.dmv1o(md, ma, g["lengths"], 1, nt=16, order=3)
+    assert np.allclose(mz, g["max"][:, 0], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(mgd, g["maxgrad_dec"]) and np.array_equal(mga, g["maxgrad_attach"])
+    mz2, _, _ = emu.dmv1o(md, ma, g["lengths"], 1, grad=False, nt=9, order=1)
+    assert np.array_equal(mz, mz2)
+    # upstream gradient scaling
+    _, wgd, wga = emu.dmv1o(md, ma, g["lengths"], 0, glogZ=g["wts"], nt=16)
+    assert np.abs(wgd - g["wgrad_dec"]).max() <= 4e-5 and np.abs(wga - g["wgrad_attach"]).max() <= 4e-5
+    assert emu.canary_trips() == 0
+
+
+def test_emu_dmv1o_bf16_inputs(oracle_mod):
+    g = load(golden_files("dmv_B4_L10_s0")[0])
+    md, ma = oracle_mod.dmv1o_merge(g["dec"], g["attach"], g["root"])
+    bits_d, bits_a = emu._bf16_bits(md), emu._bf16_bits(ma)
+    md16 = (bits_d.astype(np.uint32) << 16).view(np.float32)
+    ma16 = (bits_a.astype(np.uint32) << 16).view(np.float32)
+    ref_lz, ref_gd, ref_ga = oracle_mod.dmv1o(md16, ma16, g["lengths"], "log", np.float64)
+    lz, gd, ga = emu.dmv1o(md, ma, g["lengths"], 0, bf16=True)
+    assert np.all(np.abs(lz - ref_lz[:, 0]) <= _tol(ref_lz[:, 0]))
+    assert np.abs(gd - ref_gd).max() <= 2e-5 and np.abs(ga - ref_ga).max() <= 2e-5
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("deptree_") if "N81" not in p],
+                         ids=[i for i in golden_ids("deptree_") if "N81" not in i])
+def test_emu_deptree_golden(path):
+    g = load(path)
+    lz, ga = emu.deptree(g["arc"], g["lengths"], 0, nt=16, order=0)
+    assert np.all(np.abs(lz - g["logZ64"]) <= _tol(g["logZ64"]))
+    assert np.abs(ga - g["marginals64"]).max() <= 2e-5
+    lz2, ga2 = emu.deptree(g["arc"], g["lengths"], 0, nt=5, order=1)
+    assert np.array_equal(lz, lz2) and np.array_equal(ga, ga2)
+    lz3, _ = emu.deptree(g["arc"], g["lengths"], 0, grad=False, nt=11, order=4)
+    assert np.array_equal(lz, lz3)
+    mz, mga = emu.deptree(g["arc"], g["lengths"], 1, nt=16, order=2)
+    assert np.allclose(mz, g["max"], rtol=1e-6, atol=1e-6) and np.array_equal(mga, g["argmax"])
+    mz2, _ = emu.deptree(g["arc"], g["lengths"], 1, grad=False, nt=3)
+    assert np.array_equal(mz, mz2)
+    _, wg = emu.deptree(g["arc"], g["lengths"], 0, glogZ=g["wts"])
+    assert np.abs(wg - g["wgrad"]).max() <= 4e-5
+    if np.all(g["lengths"] == g["arc"].shape[1] - 1):
+        lz4, _ = emu.deptree(g["arc"], None, 0, grad=False)
+        assert np.array_equal(lz, lz4)
+    assert emu.canary_trips() == 0
+
+
+def test_emu_ties_take_first_argmax(oracle_mod):
+    """All-equal potentials: every tree ties.  torch.max's backward goes to the FIRST maximal index
+    (semirings.py:199-200); the kernels' back-pointers must reproduce the same single tree."""
+    B, N = 2, 7
+    md = np.zeros((B, N, 2, 2, 2), np.float32)
+    ma = np.zeros((B, N, N, 2), np.float32)
+    ma[:, :, 0, :] = -1e12      # the root is nobody's child
+    md[:, 0, 0] = -1e12         # and has no LEFT decisions (merge's fill)
+    ma[:, 0, :, 0] = -1e12      # root attaches with valence NOCHILD only
+    lengths = np.array([6, 4])
+    ref = oracle_mod.dmv1o(md, ma, lengths, "max", np.float32)
+    mz, mgd, mga = emu.dmv1o(md, ma, lengths, 1, nt=8, order=1)
+    assert np.array_equal(mz, ref[0][:, 0]) and np.array_equal(mgd, ref[1]) and np.array_equal(mga, ref[2])
+    assert np.array_equal(mga.sum((1, 2, 3)), lengths.astype(np.float32))     # still a tree

@@ -20,28 +20,6 @@ namespace vlg {
 constexpr int kThreads = 256;               // 4 wave64 = one wave per SIMD of the CU
 constexpr size_t kLdsBudget = 160 * 1024;   // CDNA4 LDS per CU / per workgroup
 
-__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-
-// Byte layout of one sentence's charts, shared by the LDS carve and the global workspace.
-struct DmvLayout {
-    size_t C, I, S, bpS, bpC, gC, gI, decs, gdecs, value_end, total;
-    __host__ __device__ DmvLayout(int N, bool bwd, bool is_max) {
-        const size_t cells = (size_t)N * chart_pitch(N);
-        size_t o = 0;
-        C = o; o = align16(o + cells * 8);
-        I = o; o = align16(o + cells * 8);
-        S = o; o = align16(o + (bwd ? cells * 4 : 0));
-        bpS = o; o = align16(o + (bwd && is_max ? cells : 0));
-        bpC = o; o = align16(o + (bwd && is_max ? cells * 2 : 0));
-        value_end = o;
-        gC = o; o = align16(o + (bwd ? cells * 8 : 0));
-        gI = o; o = align16(o + (bwd ? cells * 8 : 0));
-        decs = o; o = align16(o + (size_t)N * 32);
-        gdecs = o; o = align16(o + (bwd ? (size_t)N * 32 : 0));
-        total = o;
-    }
-};
-
 // MODE 0: everything in LDS.  MODE 1: value charts (C, I, S, back-pointers) in the global workspace,
 // adjoints + dec staging in LDS.  MODE 2: everything in the global workspace.
 __host__ inline int pick_mode(const DmvLayout& L) {
@@ -102,22 +80,6 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
 }
 
 // ---- DepTree --------------------------------------------------------------------------------------
-struct DepLayout {
-    size_t C, I, S, bpS, bpC, gC, gI, value_end, total;
-    __host__ __device__ DepLayout(int N, bool bwd, bool is_max) {
-        const size_t cells = (size_t)N * chart_pitch(N);
-        size_t o = 0;
-        C = o; o = align16(o + cells * 4);
-        I = o; o = align16(o + cells * 4);
-        S = o; o = align16(o + (bwd ? cells * 4 : 0));
-        bpS = o; o = align16(o + (bwd && is_max ? cells : 0));
-        bpC = o; o = align16(o + (bwd && is_max ? cells : 0));
-        value_end = o;
-        gC = o; o = align16(o + (bwd ? cells * 4 : 0));
-        gI = o; o = align16(o + (bwd ? cells * 4 : 0));
-        total = o;
-    }
-};
 __host__ inline int pick_mode(const DepLayout& L) {
     if (L.total <= kLdsBudget) return 0;
     if (L.total - L.value_end <= kLdsBudget) return 1;

@@ -33,14 +33,17 @@
 #define VLG_HD __device__ __forceinline__
 #define VLG_HOSTDEV __host__ __device__ inline
 #define VLG_HDM __device__ __forceinline__   // member-function form
+#define VLG_HOSTDEV_M __host__ __device__
 #define VLG_EXP(x) __expf(x)
 #define VLG_LOG(x) __logf(x)
 #else
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #define VLG_HD static inline
 #define VLG_HOSTDEV static inline
 #define VLG_HDM inline
+#define VLG_HOSTDEV_M
 #define VLG_EXP(x) expf(x)
 #define VLG_LOG(x) logf(x)
 struct float2 { float x, y; };
@@ -96,7 +99,7 @@ struct DmvCtx {
 // ------------------------------------------------------------------------------------------------
 // DMV1o phase F1(w): SL / SR and the incomplete spans.  2 * (Ne - w) work items.
 // ------------------------------------------------------------------------------------------------
-template <int SR>
+template <int SR, bool BWD>
 VLG_HD void dmv_f1(const DmvCtx& c, int w, int tid, int nt) {
     const int P = c.P, n = c.Ne - w;
     for (int idx = tid; idx < 2 * n; idx += nt) {
@@ -119,13 +122,13 @@ VLG_HD void dmv_f1(const DmvCtx& c, int w, int tid, int nt) {
             out = m + VLG_LOG(s);
         }
         if (side == 0) {
-            c.S[j * P + i] = out;
-            if (SR == VLG_SR_MAX) c.bpS[j * P + i] = (unsigned char)am;
+            if (BWD) c.S[j * P + i] = out;
+            if (BWD && SR == VLG_SR_MAX) c.bpS[j * P + i] = (unsigned char)am;
             float2 a = c.I[j * P + i];
             c.I[j * P + i] = make_float2(a.x + out, a.y + out);
         } else {
-            c.S[i * P + j] = out;
-            if (SR == VLG_SR_MAX) c.bpS[i * P + j] = (unsigned char)am;
+            if (BWD) c.S[i * P + j] = out;
+            if (BWD && SR == VLG_SR_MAX) c.bpS[i * P + j] = (unsigned char)am;
             float2 a = c.I[i * P + j + 1];
             c.I[i * P + j + 1] = make_float2(a.x + out, a.y + out);
         }
@@ -135,7 +138,7 @@ VLG_HD void dmv_f1(const DmvCtx& c, int w, int tid, int nt) {
 // ------------------------------------------------------------------------------------------------
 // DMV1o phase F2(w): complete spans.  4 * (Ne - w) work items (span, side, valence).
 // ------------------------------------------------------------------------------------------------
-template <int SR>
+template <int SR, bool BWD>
 VLG_HD void dmv_f2(const DmvCtx& c, int w, int tid, int nt) {
     const int P = c.P, n = c.Ne - w;
     for (int idx = tid; idx < 4 * n; idx += nt) {
@@ -157,7 +160,7 @@ VLG_HD void dmv_f2(const DmvCtx& c, int w, int tid, int nt) {
                 out = m + VLG_LOG(s);
             }
             ((float*)(c.C + j * P + i))[v] = out;
-            if (SR == VLG_SR_MAX) c.bpC[(j * P + i) * 2 + v] = (unsigned char)am;
+            if (BWD && SR == VLG_SR_MAX) c.bpC[(j * P + i) * 2 + v] = (unsigned char)am;
         } else {
             const float* a = (const float*)(c.I + i * P + i + 2) + v;   // IR(i, i+1+r).v at +2r
             const float2* b = c.C + (i + 1) * P + j + 1;                // CR(i+1+r, j) at +r*P
@@ -173,7 +176,7 @@ VLG_HD void dmv_f2(const DmvCtx& c, int w, int tid, int nt) {
             }
             if (i == 0 && w != c.len) out = VLG_NEGINF;   // single-root constraint, dmv.py:63
             ((float*)(c.C + i * P + j + 1))[v] = out;
-            if (SR == VLG_SR_MAX) c.bpC[(i * P + j + 1) * 2 + v] = (unsigned char)am;
+            if (BWD && SR == VLG_SR_MAX) c.bpC[(i * P + j + 1) * 2 + v] = (unsigned char)am;
         }
     }
 }
@@ -277,7 +280,7 @@ struct DepCtx {
     unsigned char* bpC;
 };
 
-template <int SR>
+template <int SR, bool BWD>
 VLG_HD void dep_f1(const DepCtx& c, int w, int tid, int nt) {
     const int P = c.P, n = c.Ne - w;
     for (int i = tid; i < n; i += nt) {
@@ -296,14 +299,14 @@ VLG_HD void dep_f1(const DepCtx& c, int w, int tid, int nt) {
             for (int r = 0; r < w; ++r) s += VLG_EXP(cr[r] + cl[r] - m);
             out = m + VLG_LOG(s);
         }
-        c.S[i * P + j] = out;
-        if (SR == VLG_SR_MAX) c.bpS[i * P + j] = (unsigned char)am;
+        if (BWD) c.S[i * P + j] = out;
+        if (BWD && SR == VLG_SR_MAX) c.bpS[i * P + j] = (unsigned char)am;
         c.I[j * P + i] += out;
         c.I[i * P + j + 1] += out;
     }
 }
 
-template <int SR>
+template <int SR, bool BWD>
 VLG_HD void dep_f2(const DepCtx& c, int w, int tid, int nt) {
     const int P = c.P, n = c.Ne - w;
     for (int idx = tid; idx < 2 * n; idx += nt) {
@@ -325,7 +328,7 @@ VLG_HD void dep_f2(const DepCtx& c, int w, int tid, int nt) {
                 out = m + VLG_LOG(s);
             }
             c.C[j * P + i] = out;
-            if (SR == VLG_SR_MAX) c.bpC[j * P + i] = (unsigned char)am;
+            if (BWD && SR == VLG_SR_MAX) c.bpC[j * P + i] = (unsigned char)am;
         } else {
             const float* a = c.I + i * P + i + 2;
             const float* b = c.C + (i + 1) * P + j + 1;
@@ -341,7 +344,7 @@ VLG_HD void dep_f2(const DepCtx& c, int w, int tid, int nt) {
             }
             if (i == 0 && w != c.len) out = VLG_NEGINF;   // deptree.py:71-72
             c.C[i * P + j + 1] = out;
-            if (SR == VLG_SR_MAX) c.bpC[i * P + j + 1] = (unsigned char)am;
+            if (BWD && SR == VLG_SR_MAX) c.bpC[i * P + j + 1] = (unsigned char)am;
         }
     }
 }
@@ -427,9 +430,9 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
     sync();
     // ---- inside -----------------------------------------------------------------------------------
     for (int w = 1; w < Ne; ++w) {
-        dmv_f1<SR>(c, w, tid, nt);
+        dmv_f1<SR, BWD>(c, w, tid, nt);
         sync();
-        dmv_f2<SR>(c, w, tid, nt);
+        dmv_f2<SR, BWD>(c, w, tid, nt);
         sync();
     }
     if (tid == 0) *logZ = c.C[len + 1].y;   // CR(0,len).NOCHILD, dmv.py:65
@@ -489,9 +492,9 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
     }
     sync();
     for (int w = 1; w < Ne; ++w) {
-        dep_f1<SR>(c, w, tid, nt);
+        dep_f1<SR, BWD>(c, w, tid, nt);
         sync();
-        dep_f2<SR>(c, w, tid, nt);
+        dep_f2<SR, BWD>(c, w, tid, nt);
         sync();
     }
     if (tid == 0) *logZ = c.C[len + 1];   // CR(0,len), deptree.py:74-75
@@ -517,5 +520,45 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
 
 // chart pitch: odd and >= N + 1 so that row-strided (column) walks hit distinct LDS banks
 VLG_HOSTDEV int chart_pitch(int N) { return (N + 1) | 1; }
+
+// ---- byte layout of one sentence's working set, shared by the LDS carve, the global workspace and
+//      the host phase emulator (which allocates EXACTLY this, with canaries behind it) ------------------
+VLG_HOSTDEV size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+struct DmvLayout {
+    size_t C, I, S, bpS, bpC, gC, gI, decs, gdecs, value_end, total;
+    VLG_HOSTDEV_M DmvLayout(int N, bool bwd, bool is_max) {
+        const size_t cells = (size_t)N * chart_pitch(N);
+        size_t o = 0;
+        C = o; o = align16(o + cells * 8);
+        I = o; o = align16(o + cells * 8);
+        S = o; o = align16(o + (bwd ? cells * 4 : 0));
+        bpS = o; o = align16(o + (bwd && is_max ? cells : 0));
+        bpC = o; o = align16(o + (bwd && is_max ? cells * 2 : 0));
+        value_end = o;
+        gC = o; o = align16(o + (bwd ? cells * 8 : 0));
+        gI = o; o = align16(o + (bwd ? cells * 8 : 0));
+        decs = o; o = align16(o + (size_t)N * 32);
+        gdecs = o; o = align16(o + (bwd ? (size_t)N * 32 : 0));
+        total = o;
+    }
+};
+
+struct DepLayout {
+    size_t C, I, S, bpS, bpC, gC, gI, value_end, total;
+    VLG_HOSTDEV_M DepLayout(int N, bool bwd, bool is_max) {
+        const size_t cells = (size_t)N * chart_pitch(N);
+        size_t o = 0;
+        C = o; o = align16(o + cells * 4);
+        I = o; o = align16(o + cells * 4);
+        S = o; o = align16(o + (bwd ? cells * 4 : 0));
+        bpS = o; o = align16(o + (bwd && is_max ? cells : 0));
+        bpC = o; o = align16(o + (bwd && is_max ? cells : 0));
+        value_end = o;
+        gC = o; o = align16(o + (bwd ? cells * 4 : 0));
+        gI = o; o = align16(o + (bwd ? cells * 4 : 0));
+        total = o;
+    }
+};
 
 }  // namespace vlg
