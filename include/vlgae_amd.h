@@ -106,6 +106,10 @@ int vlg_attn_fuse(const void* vis, const void* txt, const void* vis_mid, const v
                   const float* beta, int B, int L, int V, int d, int h, int in_dtype, float eps, float* out_att,
                   float* out, void* stream);
 
+/* Device self-test of the cross-lane (DPP / ds_swizzle) exchange primitives the DP kernels rely on.
+ * `scratch` = one device int; after the stream drains it holds 0 iff the primitives behave as assumed. */
+int vlg_selftest_xlane(int* scratch, void* stream);
+
 /* Thread-local message for the last non-zero return on this thread ("" if none). */
 const char* vlg_last_error(void);
 

@@ -10,6 +10,7 @@
 // This is NOT a CPU fallback: nothing in vlgae_amd/ loads it, and the product raises if the
 // HIP library is missing.
 #include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <cstdint>
 #include <mutex>
@@ -47,23 +48,72 @@ std::vector<int> make_order(int nt, int order) {
     return rank;   // rank[tid] = position of tid inside every phase
 }
 
+// Host stand-in for the device's cross-lane policy (DevX in vlg_dp.hip).  sync() is the token barrier;
+// the group all-reduces go through a shared exchange buffer and replay the device's butterfly tree
+// (lane t combines with lane t^1, then t^2, ...) so that host and device results agree bit for bit.
+struct HostX {
+    Token* tok;
+    int nt, tid, rho;
+    long phase = 0;
+    float* xf;   // [nt][8]
+    int* xi;     // [nt][8]
+
+    void sync() {
+        tok->advance();
+        ++phase;
+        tok->wait_for(phase * nt + rho);
+    }
+    template <int n, typename Op>
+    void butterfly(float* v, int* a, int G, Op op) {
+        if (G == 1) return;   // uniform over the workgroup
+        for (int k = 0; k < n; ++k) { xf[tid * 8 + k] = v[k]; if (a) xi[tid * 8 + k] = a[k]; }
+        sync();
+        const int base = tid & ~(G - 1);
+        for (int k = 0; k < n; ++k) {
+            float cur[64], nxt[64];
+            int ci[64], ni[64];
+            for (int t = 0; t < G; ++t) { cur[t] = xf[(base + t) * 8 + k]; ci[t] = a ? xi[(base + t) * 8 + k] : 0; }
+            for (int s = 1; s < G; s <<= 1) {
+                for (int t = 0; t < G; ++t) op(cur[t], ci[t], cur[t ^ s], ci[t ^ s], nxt[t], ni[t]);
+                for (int t = 0; t < G; ++t) { cur[t] = nxt[t]; ci[t] = ni[t]; }
+            }
+            v[k] = cur[tid - base];
+            if (a) a[k] = ci[tid - base];
+        }
+        sync();
+    }
+    template <int n>
+    void allreduce_max(float* v, int G) {
+        butterfly<n>(v, nullptr, G, [](float x, int, float y, int, float& o, int& oi) { o = fmaxf(x, y); oi = 0; });
+    }
+    template <int n>
+    void allreduce_sum(float* v, int G) {
+        butterfly<n>(v, nullptr, G, [](float x, int, float y, int, float& o, int& oi) { o = x + y; oi = 0; });
+    }
+    template <int n>
+    void allreduce_argmax(float* v, int* a, int G) {
+        butterfly<n>(v, a, G, [](float x, int xa, float y, int ya, float& o, int& oi) {
+            const bool take = y > x || (y == x && ya < xa);
+            o = take ? y : x;
+            oi = take ? ya : xa;
+        });
+    }
+};
+
 template <typename Body>
 void run_workgroup(int nt, int order, Body body) {
     Token tok;
     tok.nt = nt;
     const std::vector<int> rank = make_order(nt, order);
+    std::vector<float> xf((size_t)nt * 8);
+    std::vector<int> xi((size_t)nt * 8);
     std::vector<std::thread> th;
     for (int tid = 0; tid < nt; ++tid)
         th.emplace_back([&, tid] {
-            long phase = 0;
-            const int rho = rank[tid];
-            tok.wait_for(rho);
-            auto sync = [&] {
-                tok.advance();
-                ++phase;
-                tok.wait_for(phase * nt + rho);
-            };
-            body(tid, sync);
+            HostX x;
+            x.tok = &tok; x.nt = nt; x.tid = tid; x.rho = rank[tid]; x.xf = xf.data(); x.xi = xi.data();
+            tok.wait_for(x.rho);
+            body(tid, x);
             tok.advance();
         });
     for (auto& t : th) t.join();
@@ -89,31 +139,31 @@ struct Arena {
 template <int SR, bool BWD, typename In>
 void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int len, int N, float glogZ, float* logZ,
                  float* gdec, float* gatt, int nt, int order) {
-    const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX);
-    Arena A(L.total);
+    const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, 0);   // mode 0: one contiguous carve, like LDS
+    Arena A(L.lds_bytes);
     vlg::DmvCtx c;
     c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
-    c.C = (float2*)A.at(L.C); c.I = (float2*)A.at(L.I); c.S = (float*)A.at(L.S);
-    c.bpS = (unsigned char*)A.at(L.bpS); c.bpC = (unsigned char*)A.at(L.bpC);
-    c.gC = (float2*)A.at(L.gC); c.gI = (float2*)A.at(L.gI);
-    c.decs = (float*)A.at(L.decs); c.gdecs = (float*)A.at(L.gdecs);
-    run_workgroup(nt, order, [&](int tid, auto sync) {
-        vlg::dmv_run<SR, BWD, In>(c, dec, attach, N, glogZ, logZ, gdec, gatt, tid, nt, sync);
+    c.C = (float2*)A.at(L.C.off); c.I = (float2*)A.at(L.I.off); c.S = (float*)A.at(L.S.off);
+    c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);
+    c.gCc = (float2*)A.at(L.gCc.off); c.gCi = (float2*)A.at(L.gCi.off); c.gI = (float2*)A.at(L.gI.off);
+    c.decs = (float*)A.at(L.decs.off); c.gdecs = (float*)A.at(L.gdecs.off);
+    run_workgroup(nt, order, [&](int tid, HostX& x) {
+        vlg::dmv_run<SR, BWD, In>(c, dec, attach, N, glogZ, logZ, gdec, gatt, tid, nt, x);
     });
     A.check();
 }
 
 template <int SR, bool BWD, typename In>
 void emu_dep_one(const typename In::T* arc, int len, int N, float glogZ, float* logZ, float* garc, int nt, int order) {
-    const vlg::DepLayout L(N, BWD, SR == VLG_SR_MAX);
-    Arena A(L.total);
+    const vlg::DepLayout L(N, BWD, SR == VLG_SR_MAX, 0);
+    Arena A(L.lds_bytes);
     vlg::DepCtx c;
     c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
-    c.C = (float*)A.at(L.C); c.I = (float*)A.at(L.I); c.S = (float*)A.at(L.S);
-    c.bpS = (unsigned char*)A.at(L.bpS); c.bpC = (unsigned char*)A.at(L.bpC);
-    c.gC = (float*)A.at(L.gC); c.gI = (float*)A.at(L.gI);
-    run_workgroup(nt, order, [&](int tid, auto sync) {
-        vlg::dep_run<SR, BWD, In>(c, arc, N, glogZ, logZ, garc, tid, nt, sync);
+    c.C = (float*)A.at(L.C.off); c.I = (float*)A.at(L.I.off); c.S = (float*)A.at(L.S.off);
+    c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);
+    c.gCc = (float*)A.at(L.gCc.off); c.gCi = (float*)A.at(L.gCi.off); c.gI = (float*)A.at(L.gI.off);
+    run_workgroup(nt, order, [&](int tid, HostX& x) {
+        vlg::dep_run<SR, BWD, In>(c, arc, N, glogZ, logZ, garc, tid, nt, x);
     });
     A.check();
 }

@@ -9,7 +9,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "_lib", "libvlgae_amd.so")
+LIB_PATH = os.environ.get("VLGAE_AMD_LIB") or os.path.join(_PKG, "_lib", "libvlgae_amd.so")
 
 F32, BF16 = 0, 1
 SEMIRING_LOG, SEMIRING_MAX = 0, 1
@@ -27,6 +27,7 @@ SIGNATURES = {
     "vlg_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vlg_bilinear_align": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "vlg_attn_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "vlg_selftest_xlane": (_i, [_vp, _vp]),
     "vlg_last_error": (ctypes.c_char_p, []),
     "vlg_version": (_i, []),
 }

@@ -17,21 +17,107 @@
 
 namespace vlg {
 
-constexpr int kThreads = 256;               // 4 wave64 = one wave per SIMD of the CU
+#ifndef VLG_DP_THREADS
+#define VLG_DP_THREADS 256
+#endif
+constexpr int kThreads = VLG_DP_THREADS;    // lanes per sentence (workgroup size)
 constexpr size_t kLdsBudget = 160 * 1024;   // CDNA4 LDS per CU / per workgroup
 
-// MODE 0: everything in LDS.  MODE 1: value charts (C, I, S, back-pointers) in the global workspace,
-// adjoints + dec staging in LDS.  MODE 2: everything in the global workspace.
-__host__ inline int pick_mode(const DmvLayout& L) {
-    if (L.total <= kLdsBudget) return 0;
-    if (L.total - L.value_end <= kLdsBudget) return 1;
-    return 2;
+// ---- cross-lane exchange: lane l <- lane l ^ K, for values that are uniform over aligned K-blocks ------
+// (true at every step of an ascending butterfly all-reduce).  K = 1, 2 are quad permutes; K = 4 / 8 use
+// the DPP half-row / row mirrors (the partner block's value is uniform, so any lane of it will do);
+// K = 16 is a bit-mode ds_swizzle inside each 32-lane half; K = 32 goes through ds_bpermute.
+template <int K>
+__device__ __forceinline__ int xlane_i(int v) {
+    if (K == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    if (K == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    if (K == 4) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    if (K == 8) return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false);   // row_mirror
+    if (K == 16) return __builtin_amdgcn_ds_swizzle(v, 0x401F);                     // and 0x1F, or 0, xor 0x10
+    return __shfl_xor(v, 32, 64);
 }
-__host__ inline size_t lds_bytes(const DmvLayout& L, int mode) {
-    return mode == 0 ? L.total : mode == 1 ? L.total - L.value_end : 0;
+template <int K>
+__device__ __forceinline__ float xlane(float v) { return __int_as_float(xlane_i<K>(__float_as_int(v))); }
+
+struct DevX {
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+
+    template <int K, int n>
+    __device__ __forceinline__ void step_max(float* v) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) v[k] = fmaxf(v[k], xlane<K>(v[k]));
+    }
+    template <int K, int n>
+    __device__ __forceinline__ void step_sum(float* v) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) v[k] += xlane<K>(v[k]);
+    }
+    template <int K, int n>
+    __device__ __forceinline__ void step_argmax(float* v, int* a) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            const float pv = xlane<K>(v[k]);
+            const int pa = xlane_i<K>(a[k]);
+            const bool take = pv > v[k] || (pv == v[k] && pa < a[k]);   // first arg-max wins ties
+            v[k] = take ? pv : v[k];
+            a[k] = take ? pa : a[k];
+        }
+    }
+    // G is uniform over the workgroup, so these branches never diverge
+    template <int n>
+    __device__ __forceinline__ void allreduce_max(float* v, int G) {
+        if (G > 1) step_max<1, n>(v);
+        if (G > 2) step_max<2, n>(v);
+        if (G > 4) step_max<4, n>(v);
+        if (G > 8) step_max<8, n>(v);
+        if (G > 16) step_max<16, n>(v);
+        if (G > 32) step_max<32, n>(v);
+    }
+    template <int n>
+    __device__ __forceinline__ void allreduce_sum(float* v, int G) {
+        if (G > 1) step_sum<1, n>(v);
+        if (G > 2) step_sum<2, n>(v);
+        if (G > 4) step_sum<4, n>(v);
+        if (G > 8) step_sum<8, n>(v);
+        if (G > 16) step_sum<16, n>(v);
+        if (G > 32) step_sum<32, n>(v);
+    }
+    template <int n>
+    __device__ __forceinline__ void allreduce_argmax(float* v, int* a, int G) {
+        if (G > 1) step_argmax<1, n>(v, a);
+        if (G > 2) step_argmax<2, n>(v, a);
+        if (G > 4) step_argmax<4, n>(v, a);
+        if (G > 8) step_argmax<8, n>(v, a);
+        if (G > 16) step_argmax<16, n>(v, a);
+        if (G > 32) step_argmax<32, n>(v, a);
+    }
+};
+
+// self-test of the exchange primitives against __shfl_xor on block-uniform data (tests/test_gpu_parity.py)
+__global__ void xlane_selftest_kernel(int* out) {
+    const int lane = threadIdx.x & 63;
+    int bad = 0;
+#define VLG_CHK(K)                                                                    \
+    {                                                                                 \
+        const int v = (lane / K) * 1000 + 7;        /* uniform over aligned K-blocks */ \
+        if (xlane_i<K>(v) != __shfl_xor(v, K, 64)) bad |= K;                          \
+    }
+    VLG_CHK(1) VLG_CHK(2) VLG_CHK(4) VLG_CHK(8) VLG_CHK(16) VLG_CHK(32)
+#undef VLG_CHK
+    float m[2] = {(float)((lane * 37) % 64), -(float)lane};
+    int am[2] = {lane, lane};
+    DevX x;
+    x.allreduce_argmax<2>(m, am, 64);
+    if (m[0] != 63.f || m[1] != 0.f || am[1] != 0) bad |= 128;
+    float s[1] = {1.0f};
+    x.allreduce_sum<1>(s, 16);
+    if (s[0] != 16.f) bad |= 256;
+    atomicOr(out, bad);
 }
-__host__ inline size_t ws_bytes_per_sentence(const DmvLayout& L, int mode) {
-    return mode == 0 ? 0 : mode == 1 ? L.value_end : L.total;
+
+template <typename T>
+__device__ __forceinline__ T* region_ptr(const Region& r, char* smem, char* wsb) {
+    return reinterpret_cast<T*>((r.lds ? smem : wsb) + r.off);
 }
 
 template <int SR, int MODE, bool BWD, typename In>
@@ -55,41 +141,25 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
         return;
     }
 
-    const DmvLayout L(N, BWD, SR == VLG_SR_MAX);
+    const DmvLayout L(N, BWD, SR == VLG_SR_MAX, MODE);
     char* wsb = ws + (size_t)b * ws_stride;
-    auto vptr = [&](size_t off) -> char* { return MODE == 0 ? smem + off : wsb + off; };            // value charts
-    auto aptr = [&](size_t off) -> char* {                                                           // adjoints, staging
-        return MODE == 2 ? wsb + off : smem + (off - (MODE == 1 ? L.value_end : 0));
-    };
     DmvCtx c;
     c.Ne = len + 1;
     c.len = len;
     c.P = chart_pitch(N);
-    c.C = reinterpret_cast<float2*>(vptr(L.C));
-    c.I = reinterpret_cast<float2*>(vptr(L.I));
-    c.S = reinterpret_cast<float*>(vptr(L.S));
-    c.bpS = reinterpret_cast<unsigned char*>(vptr(L.bpS));
-    c.bpC = reinterpret_cast<unsigned char*>(vptr(L.bpC));
-    c.gC = reinterpret_cast<float2*>(aptr(L.gC));
-    c.gI = reinterpret_cast<float2*>(aptr(L.gI));
-    c.decs = reinterpret_cast<float*>(aptr(L.decs));
-    c.gdecs = reinterpret_cast<float*>(aptr(L.gdecs));
+    c.C = region_ptr<float2>(L.C, smem, wsb);
+    c.I = region_ptr<float2>(L.I, smem, wsb);
+    c.S = region_ptr<float>(L.S, smem, wsb);
+    c.bpS = region_ptr<unsigned char>(L.bpS, smem, wsb);
+    c.bpC = region_ptr<unsigned char>(L.bpC, smem, wsb);
+    c.gCc = region_ptr<float2>(L.gCc, smem, wsb);
+    c.gCi = region_ptr<float2>(L.gCi, smem, wsb);
+    c.gI = region_ptr<float2>(L.gI, smem, wsb);
+    c.decs = region_ptr<float>(L.decs, smem, wsb);
+    c.gdecs = region_ptr<float>(L.gdecs, smem, wsb);
+    DevX x;
     dmv_run<SR, BWD, In>(c, dec + dec_off, attach + att_off, N, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b,
-                         BWD ? gdec + dec_off : nullptr, BWD ? gatt + att_off : nullptr, tid, kThreads,
-                         [] { __syncthreads(); });
-}
-
-// ---- DepTree --------------------------------------------------------------------------------------
-__host__ inline int pick_mode(const DepLayout& L) {
-    if (L.total <= kLdsBudget) return 0;
-    if (L.total - L.value_end <= kLdsBudget) return 1;
-    return 2;
-}
-__host__ inline size_t lds_bytes(const DepLayout& L, int mode) {
-    return mode == 0 ? L.total : mode == 1 ? L.total - L.value_end : 0;
-}
-__host__ inline size_t ws_bytes_per_sentence(const DepLayout& L, int mode) {
-    return mode == 0 ? 0 : mode == 1 ? L.value_end : L.total;
+                         BWD ? gdec + dec_off : nullptr, BWD ? gatt + att_off : nullptr, tid, kThreads, x);
 }
 
 template <int SR, int MODE, bool BWD, typename In>
@@ -108,25 +178,23 @@ __global__ __launch_bounds__(kThreads) void deptree_kernel(const typename In::T*
             for (int i = tid; i < N * N; i += kThreads) garc[arc_off + i] = 0.f;
         return;
     }
-    const DepLayout L(N, BWD, SR == VLG_SR_MAX);
+    const DepLayout L(N, BWD, SR == VLG_SR_MAX, MODE);
     char* wsb = ws + (size_t)b * ws_stride;
-    auto vptr = [&](size_t off) -> char* { return MODE == 0 ? smem + off : wsb + off; };
-    auto aptr = [&](size_t off) -> char* {
-        return MODE == 2 ? wsb + off : smem + (off - (MODE == 1 ? L.value_end : 0));
-    };
     DepCtx c;
     c.Ne = len + 1;
     c.len = len;
     c.P = chart_pitch(N);
-    c.C = reinterpret_cast<float*>(vptr(L.C));
-    c.I = reinterpret_cast<float*>(vptr(L.I));
-    c.S = reinterpret_cast<float*>(vptr(L.S));
-    c.bpS = reinterpret_cast<unsigned char*>(vptr(L.bpS));
-    c.bpC = reinterpret_cast<unsigned char*>(vptr(L.bpC));
-    c.gC = reinterpret_cast<float*>(aptr(L.gC));
-    c.gI = reinterpret_cast<float*>(aptr(L.gI));
+    c.C = region_ptr<float>(L.C, smem, wsb);
+    c.I = region_ptr<float>(L.I, smem, wsb);
+    c.S = region_ptr<float>(L.S, smem, wsb);
+    c.bpS = region_ptr<unsigned char>(L.bpS, smem, wsb);
+    c.bpC = region_ptr<unsigned char>(L.bpC, smem, wsb);
+    c.gCc = region_ptr<float>(L.gCc, smem, wsb);
+    c.gCi = region_ptr<float>(L.gCi, smem, wsb);
+    c.gI = region_ptr<float>(L.gI, smem, wsb);
+    DevX x;
     dep_run<SR, BWD, In>(c, arc + arc_off, N, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b,
-                         BWD ? garc + arc_off : nullptr, tid, kThreads, [] { __syncthreads(); });
+                         BWD ? garc + arc_off : nullptr, tid, kThreads, x);
 }
 
 // ---- DMV1o.merge (distributions.py:253-265): root-augmented potentials, always fp32 out ----------
@@ -194,7 +262,8 @@ static int dispatch_dmv_mode(int mode, const void* dec, const void* attach, cons
     switch (mode) {
         case 0: return launch_dmv<SR, 0, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, ws, ws_stride, lds, s);
         case 1: return launch_dmv<SR, 1, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, ws, ws_stride, lds, s);
-        default: return launch_dmv<SR, 2, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, ws, ws_stride, lds, s);
+        case 2: return launch_dmv<SR, 2, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, ws, ws_stride, lds, s);
+        default: return launch_dmv<SR, 3, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, ws, ws_stride, lds, s);
     }
 }
 
@@ -209,9 +278,9 @@ static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, 
     if (!dec || !attach || !lengths || !logZ || (BWD && (!gdec || !gatt)))
         if (B > 0) return set_error(VLG_ERR_ARG, "dmv1o: null buffer");
     if (B == 0) return 0;
-    const DmvLayout L(N, BWD, semiring == VLG_SR_MAX);
-    const int mode = pick_mode(L);
-    const size_t ws_stride = ws_bytes_per_sentence(L, mode), lds = lds_bytes(L, mode);
+    const int mode = pick_mode<DmvLayout>(N, BWD, semiring == VLG_SR_MAX, kLdsBudget);
+    const DmvLayout L(N, BWD, semiring == VLG_SR_MAX, mode);
+    const size_t ws_stride = L.ws_bytes, lds = L.lds_bytes;
     if (ws_stride * (size_t)B > ws_bytes || (ws_stride && !ws))
         return set_error(VLG_ERR_WORKSPACE, "dmv1o: N=%d needs a %zu-byte workspace (got %zu); see vlg_workspace_bytes",
                          N, ws_stride * (size_t)B, ws_bytes);
@@ -243,7 +312,8 @@ static int dispatch_dep_mode(int mode, const void* arc, const int64_t* lengths, 
     switch (mode) {
         case 0: return launch_dep<SR, 0, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, ws, ws_stride, lds, s);
         case 1: return launch_dep<SR, 1, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, ws, ws_stride, lds, s);
-        default: return launch_dep<SR, 2, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, ws, ws_stride, lds, s);
+        case 2: return launch_dep<SR, 2, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, ws, ws_stride, lds, s);
+        default: return launch_dep<SR, 3, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, ws, ws_stride, lds, s);
     }
 }
 
@@ -257,9 +327,9 @@ static int run_dep(const void* arc, const int64_t* lengths, int B, int N, int in
     if (!arc || !logZ || (BWD && !garc))
         if (B > 0) return set_error(VLG_ERR_ARG, "deptree: null buffer");
     if (B == 0) return 0;
-    const DepLayout L(N, BWD, semiring == VLG_SR_MAX);
-    const int mode = pick_mode(L);
-    const size_t ws_stride = ws_bytes_per_sentence(L, mode), lds = lds_bytes(L, mode);
+    const int mode = pick_mode<DepLayout>(N, BWD, semiring == VLG_SR_MAX, kLdsBudget);
+    const DepLayout L(N, BWD, semiring == VLG_SR_MAX, mode);
+    const size_t ws_stride = L.ws_bytes, lds = L.lds_bytes;
     if (ws_stride * (size_t)B > ws_bytes || (ws_stride && !ws))
         return set_error(VLG_ERR_WORKSPACE, "deptree: N=%d needs a %zu-byte workspace (got %zu)", N,
                          ws_stride * (size_t)B, ws_bytes);
@@ -309,13 +379,28 @@ int vlg_deptree_inside_outside(const void* arc, const int64_t* lengths, int B, i
 size_t vlg_workspace_bytes(int op, int B, int N, int semiring) {
     if (B <= 0 || N < 2) return 0;
     const bool is_max = semiring == VLG_SR_MAX;
+    using namespace vlg;
     switch (op) {
-        case VLG_OP_DMV1O_INSIDE: { vlg::DmvLayout L(N, false, is_max); return vlg::ws_bytes_per_sentence(L, vlg::pick_mode(L)) * B; }
-        case VLG_OP_DMV1O_INSIDE_OUTSIDE: { vlg::DmvLayout L(N, true, is_max); return vlg::ws_bytes_per_sentence(L, vlg::pick_mode(L)) * B; }
-        case VLG_OP_DEPTREE_INSIDE: { vlg::DepLayout L(N, false, is_max); return vlg::ws_bytes_per_sentence(L, vlg::pick_mode(L)) * B; }
-        case VLG_OP_DEPTREE_INSIDE_OUTSIDE: { vlg::DepLayout L(N, true, is_max); return vlg::ws_bytes_per_sentence(L, vlg::pick_mode(L)) * B; }
+        case VLG_OP_DMV1O_INSIDE:
+            return DmvLayout(N, false, is_max, pick_mode<DmvLayout>(N, false, is_max, kLdsBudget)).ws_bytes * B;
+        case VLG_OP_DMV1O_INSIDE_OUTSIDE:
+            return DmvLayout(N, true, is_max, pick_mode<DmvLayout>(N, true, is_max, kLdsBudget)).ws_bytes * B;
+        case VLG_OP_DEPTREE_INSIDE:
+            return DepLayout(N, false, is_max, pick_mode<DepLayout>(N, false, is_max, kLdsBudget)).ws_bytes * B;
+        case VLG_OP_DEPTREE_INSIDE_OUTSIDE:
+            return DepLayout(N, true, is_max, pick_mode<DepLayout>(N, true, is_max, kLdsBudget)).ws_bytes * B;
         default: return 0;
     }
+}
+
+/* Debug aid used by the GPU tests: checks the DPP / swizzle lane-exchange primitives on this device.
+ * Returns 0 when they behave as the kernels assume; `scratch` is one device int. */
+int vlg_selftest_xlane(int* scratch, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int), s);
+    if (e != hipSuccess) return vlg::set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(vlg::xlane_selftest_kernel, dim3(1), dim3(128), 0, s, scratch);
+    return vlg::check_launch("xlane_selftest_kernel");
 }
 
 int vlg_dmv1o_merge(const void* dec, const void* attach, const void* root, int B, int L, int in_dtype, float one,

@@ -3,8 +3,9 @@
 // Each function is the work of ONE thread (tid of nt) in ONE barrier-delimited phase of the
 // span-width loop.  The HIP kernels (vlg_dp.hip) call them between __syncthreads(); the
 // host-side phase emulator used by the CPU test-suite (tests/emu/emu_dp.cpp) calls the very
-// same bodies for tid = 0..nt-1 (in both orders, to expose intra-phase races).  Nothing here
-// is a CPU fallback: the product only ever runs these through the gfx950 kernels.
+// same bodies with host threads standing in for lanes (in several serialisation orders, to expose
+// intra-phase races).  Nothing here is a CPU fallback: the product only ever runs these through
+// the gfx950 kernels.
 //
 // Algorithm (reference: /root/reference/src/model/torch_struct/dmv.py:19-66 and
 // deptree.py:25-76; their outside pass is autograd).  Notation, h = head:
@@ -21,11 +22,19 @@
 //   CL(j,i).v = (+)_r CL(i+r,i).NC + IL(j,i+r).v                                                     (dmv.py:58-59)
 //   CR(i,j).v = (+)_r IR(i,i+1+r).v + CR(i+1+r,j).NC                                                 (dmv.py:61-62)
 //   CR(0,w).* = zero unless w == len                                                                 (dmv.py:63)
+//
+// Work decomposition (both passes): the Ne-w spans of a width are dealt to groups of G lanes
+// (G a power of two <= 64, so a group never straddles a wavefront); the lanes of a group split the
+// split-point range r = 0..w-1 and combine with a butterfly all-reduce (DPP on the GPU).  Only the
+// r = 0 term of CL and the r = w-1 term of CR depend on the incomplete span of the SAME width, and
+// that span belongs to the same group -- so ONE barrier per width suffices in each pass.
+//
 // Outside: every cell is written once, so the charts are the tape; the adjoint of
 // out = lse_r t_r is t_r_bar += out_bar * exp(t_r - out) (Max semiring: the first arg-max only).
-// Phase B1 distributes the adjoints of the complete spans of width w, phase B2 those of the
-// incomplete spans; within a phase every read-modify-write target is owned by exactly one
-// (span, r) pair, so no atomics are needed (ownership argument: DESIGN.md, "Outside pass").
+// Adjoints of complete spans are accumulated in two arrays, gCc (contributions that come from
+// complete-span parents) and gCi (from incomplete-span parents): within a phase every
+// read-modify-write target is then owned by exactly one (span, r) pair -- no atomics, results are
+// bit-reproducible (ownership argument: DESIGN.md, "Outside pass").
 #pragma once
 
 #if defined(__HIPCC__)
@@ -36,10 +45,12 @@
 #define VLG_HOSTDEV_M __host__ __device__
 #define VLG_EXP(x) __expf(x)
 #define VLG_LOG(x) __logf(x)
+#define VLG_BITS2F(u) __uint_as_float(u)
 #else
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #define VLG_HD static inline
 #define VLG_HOSTDEV static inline
 #define VLG_HDM inline
@@ -48,12 +59,6 @@
 #define VLG_LOG(x) logf(x)
 struct float2 { float x, y; };
 static inline float2 make_float2(float a, float b) { float2 r; r.x = a; r.y = b; return r; }
-#endif
-
-#if defined(__HIPCC__)
-#define VLG_BITS2F(u) __uint_as_float(u)
-#else
-#include <cstring>
 static inline float vlg_bits2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 #define VLG_BITS2F(u) vlg_bits2f(u)
 #endif
@@ -61,6 +66,7 @@ static inline float vlg_bits2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); re
 #define VLG_NEGINF (-1e12f)  // semiring zero, semirings.py:16,128 (finite sentinel, never -inf)
 #define VLG_SR_LOG 0
 #define VLG_SR_MAX 1
+#define VLG_LOWEST (-3.0e38f)
 
 namespace vlg {
 
@@ -78,108 +84,34 @@ struct BF16In {
     }
 };
 
-// dec[h] is 8 floats [dir][val][decision]; helpers for the staged copy.
+// chart pitch: odd and >= N + 1 so that row-strided (column) walks hit distinct LDS banks
+VLG_HOSTDEV int chart_pitch(int N) { return (N + 1) | 1; }
+
+// lanes per span at width w: the largest power of two G <= 64 with (spans * G <= nt) and G < 2w
+VLG_HD int group_size(int spans, int w, int nt) {
+    int G = 1;
+    while (G < 64 && G < w && spans * (G * 2) <= nt) G <<= 1;
+    return G;
+}
+
+// dec[h] is 8 floats [dir][val][decision]
 VLG_HD int dec_idx(int dir, int val, int z) { return (dir * 2 + val) * 2 + z; }
 
 struct DmvCtx {
     int Ne;         // len + 1: only spans inside [0, len] are ever read by valid cells
     int len;
-    int P;          // chart pitch (cells), odd, >= Ne + 1
+    int P;          // chart pitch (cells), odd, >= N + 1
     float2* C;      // complete spans   [Ne][P]
     float2* I;      // incomplete spans [Ne][P]  (pre-loaded with attach + dec[...,GO])
     float* S;       // SL(i,j) at S[j*P+i], SR(i,j) at S[i*P+j]
-    float2* gC;     // adjoints
-    float2* gI;
+    float2* gCc;    // adjoint of C, part contributed by complete-span parents
+    float2* gCi;    // adjoint of C, part contributed by incomplete-span parents
+    float2* gI;     // adjoint of I (== d logZ / d attach once complete)
     float* decs;    // staged dec        [Ne][8]
     float* gdecs;   // adjoint of dec    [Ne][8]
     unsigned char* bpS;   // Max semiring back-pointers (first arg-max r), same indexing as S
     unsigned char* bpC;   // [Ne][P][2]
 };
-
-// ------------------------------------------------------------------------------------------------
-// DMV1o phase F1(w): SL / SR and the incomplete spans.  2 * (Ne - w) work items.
-// ------------------------------------------------------------------------------------------------
-template <int SR, bool BWD>
-VLG_HD void dmv_f1(const DmvCtx& c, int w, int tid, int nt) {
-    const int P = c.P, n = c.Ne - w;
-    for (int idx = tid; idx < 2 * n; idx += nt) {
-        const int i = idx >> 1, side = idx & 1, j = i + w;
-        const float2* cr = c.C + i * P + i + 1;   // CR(i, i+r)   at +r
-        const float2* cl = c.C + j * P + i + 1;   // CL(j, i+r+1) at +r
-        float m = -3.0e38f;
-        int am = 0;
-        for (int r = 0; r < w; ++r) {
-            const float t = side == 0 ? cr[r].y + cl[r].x : cr[r].x + cl[r].y;
-            if (t > m) { m = t; am = r; }
-        }
-        float out = m;
-        if (SR == VLG_SR_LOG) {
-            float s = 0.f;
-            for (int r = 0; r < w; ++r) {
-                const float t = side == 0 ? cr[r].y + cl[r].x : cr[r].x + cl[r].y;
-                s += VLG_EXP(t - m);
-            }
-            out = m + VLG_LOG(s);
-        }
-        if (side == 0) {
-            if (BWD) c.S[j * P + i] = out;
-            if (BWD && SR == VLG_SR_MAX) c.bpS[j * P + i] = (unsigned char)am;
-            float2 a = c.I[j * P + i];
-            c.I[j * P + i] = make_float2(a.x + out, a.y + out);
-        } else {
-            if (BWD) c.S[i * P + j] = out;
-            if (BWD && SR == VLG_SR_MAX) c.bpS[i * P + j] = (unsigned char)am;
-            float2 a = c.I[i * P + j + 1];
-            c.I[i * P + j + 1] = make_float2(a.x + out, a.y + out);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// DMV1o phase F2(w): complete spans.  4 * (Ne - w) work items (span, side, valence).
-// ------------------------------------------------------------------------------------------------
-template <int SR, bool BWD>
-VLG_HD void dmv_f2(const DmvCtx& c, int w, int tid, int nt) {
-    const int P = c.P, n = c.Ne - w;
-    for (int idx = tid; idx < 4 * n; idx += nt) {
-        const int i = idx >> 2, side = (idx >> 1) & 1, v = idx & 1, j = i + w;
-        float m = -3.0e38f;
-        int am = 0;
-        float out;
-        if (side == 0) {
-            const float2* a = c.C + i * P + i;        // CL(i+r, i) at +r*P
-            const float* b = (const float*)(c.I + j * P + i) + v;   // IL(j, i+r).v at +2r
-            for (int r = 0; r < w; ++r) {
-                const float t = a[r * P].y + b[2 * r];
-                if (t > m) { m = t; am = r; }
-            }
-            out = m;
-            if (SR == VLG_SR_LOG) {
-                float s = 0.f;
-                for (int r = 0; r < w; ++r) s += VLG_EXP(a[r * P].y + b[2 * r] - m);
-                out = m + VLG_LOG(s);
-            }
-            ((float*)(c.C + j * P + i))[v] = out;
-            if (BWD && SR == VLG_SR_MAX) c.bpC[(j * P + i) * 2 + v] = (unsigned char)am;
-        } else {
-            const float* a = (const float*)(c.I + i * P + i + 2) + v;   // IR(i, i+1+r).v at +2r
-            const float2* b = c.C + (i + 1) * P + j + 1;                // CR(i+1+r, j) at +r*P
-            for (int r = 0; r < w; ++r) {
-                const float t = a[2 * r] + b[r * P].y;
-                if (t > m) { m = t; am = r; }
-            }
-            out = m;
-            if (SR == VLG_SR_LOG) {
-                float s = 0.f;
-                for (int r = 0; r < w; ++r) s += VLG_EXP(a[2 * r] + b[r * P].y - m);
-                out = m + VLG_LOG(s);
-            }
-            if (i == 0 && w != c.len) out = VLG_NEGINF;   // single-root constraint, dmv.py:63
-            ((float*)(c.C + i * P + j + 1))[v] = out;
-            if (BWD && SR == VLG_SR_MAX) c.bpC[(i * P + j + 1) * 2 + v] = (unsigned char)am;
-        }
-    }
-}
 
 // weight of term r in a reduction with result `out`, scaled by the upstream adjoint g
 template <int SR>
@@ -188,75 +120,191 @@ VLG_HD float adj_w(float g, float t, float out, int r, int bp) {
     return g != 0.f ? g * VLG_EXP(t - out) : 0.f;
 }
 
-// ------------------------------------------------------------------------------------------------
-// DMV1o phase B1(w): adjoints of the complete spans of width w.  (Ne - w) * w work items.
-// ------------------------------------------------------------------------------------------------
+// running max with first-index tie-break (torch.max semantics, semirings.py:199-200)
+VLG_HD void upd_max(float& m, int& am, float t, int r) {
+    if (t > m) { m = t; am = r; }
+}
+
+// fold the single same-width term (value t, index rt) into a partial reduction (m, s, am).
+// `t_first`: the extra term precedes every index of the partial (r = 0) -> it wins ties.
 template <int SR>
-VLG_HD void dmv_b1(const DmvCtx& c, int w, int tid, int nt) {
-    const int P = c.P, n = c.Ne - w, total = n * w;
-    const float inv_w = 1.0f / (float)w;
-    for (int idx = tid; idx < total; idx += nt) {
-        int i = (int)(((float)idx + 0.5f) * inv_w);
-        int r = idx - i * w;
-        const int j = i + w;
-        // CL(j,i).v = (+)_r CL(i+r,i).NC + IL(j,i+r).v
-        {
-            const float2 g = c.gC[j * P + i];
-            const float2 out = c.C[j * P + i];
-            const float a = c.C[(i + r) * P + i].y;
-            const float2 il = c.I[j * P + i + r];
-            int bp0 = 0, bp1 = 0;
-            if (SR == VLG_SR_MAX) { bp0 = c.bpC[(j * P + i) * 2]; bp1 = c.bpC[(j * P + i) * 2 + 1]; }
-            const float w0 = adj_w<SR>(g.x, a + il.x, out.x, r, bp0);
-            const float w1 = adj_w<SR>(g.y, a + il.y, out.y, r, bp1);
-            float2 t = c.gI[j * P + i + r];
-            c.gI[j * P + i + r] = make_float2(t.x + w0, t.y + w1);
-            c.gC[(i + r) * P + i].y += w0 + w1;
+VLG_HD float fold_term(float m, float s, int am, float t, int rt, bool t_first, int& bp) {
+    if (SR == VLG_SR_MAX) {
+        const bool take = t_first ? (t >= m) : (t > m);
+        bp = take ? rt : am;
+        return take ? t : m;
+    }
+    bp = 0;
+    const float M = fmaxf(m, t);
+    return M + VLG_LOG(s * VLG_EXP(m - M) + VLG_EXP(t - M));
+}
+
+// ------------------------------------------------------------------------------------------------
+// DMV1o inside, width w: ONE phase.  X provides the group all-reduces (DPP on device).
+// ------------------------------------------------------------------------------------------------
+template <int SR, bool BWD, typename X>
+VLG_HD void dmv_fw(const DmvCtx& c, int w, int tid, int nt, X& x) {
+    const int P = c.P, spans = c.Ne - w;
+    const int G = group_size(spans, w, nt), per = nt / G;
+    const int rr = tid & (G - 1), slot = tid / G;
+    for (int base = 0; base < spans; base += per) {
+        const bool live = base + slot < spans;
+        const int i = live ? base + slot : 0, j = i + w;   // dead lanes shadow span 0 and never store
+        const float2* cr = c.C + i * P + i + 1;      // CR(i, i+r)    at [r]
+        const float2* cl = c.C + j * P + i + 1;      // CL(j, i+r+1)  at [r]
+        const float2* ca = c.C + i * P + i;          // CL(i+r, i)    at [r*P]
+        const float2* il = c.I + j * P + i;          // IL(j, i+r)    at [r]
+        const float2* ir = c.I + i * P + i + 2;      // IR(i, i+1+r)  at [r]
+        const float2* cb = c.C + (i + 1) * P + j + 1;   // CR(i+1+r, j)  at [r*P]
+        // reductions: 0 SL, 1 SR, 2 CL.x, 3 CL.y (r >= 1), 4 CR.x, 5 CR.y (r <= w-2)
+        float m[6];
+        int am[6];
+        for (int k = 0; k < 6; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
+        for (int r = rr; r < w; r += G) {
+            const float2 a = cr[r], b = cl[r];
+            upd_max(m[0], am[0], a.y + b.x, r);
+            upd_max(m[1], am[1], a.x + b.y, r);
+            if (r >= 1) {
+                const float u = ca[r * P].y;
+                const float2 v = il[r];
+                upd_max(m[2], am[2], u + v.x, r);
+                upd_max(m[3], am[3], u + v.y, r);
+            }
+            if (r <= w - 2) {
+                const float2 v = ir[r];
+                const float u = cb[r * P].y;
+                upd_max(m[4], am[4], v.x + u, r);
+                upd_max(m[5], am[5], v.y + u, r);
+            }
         }
-        // CR(i,j).v = (+)_r IR(i,i+1+r).v + CR(i+1+r,j).NC      (masked cell: no adjoint, dmv.py:63)
-        {
-            float2 g = c.gC[i * P + j + 1];
-            if (i == 0 && w != c.len) g = make_float2(0.f, 0.f);
-            const float2 out = c.C[i * P + j + 1];
-            const float2 ir = c.I[i * P + i + r + 2];
-            const float a = c.C[(i + 1 + r) * P + j + 1].y;
-            int bp0 = 0, bp1 = 0;
-            if (SR == VLG_SR_MAX) { bp0 = c.bpC[(i * P + j + 1) * 2]; bp1 = c.bpC[(i * P + j + 1) * 2 + 1]; }
-            const float w0 = adj_w<SR>(g.x, ir.x + a, out.x, r, bp0);
-            const float w1 = adj_w<SR>(g.y, ir.y + a, out.y, r, bp1);
-            float2 t = c.gI[i * P + i + r + 2];
-            c.gI[i * P + i + r + 2] = make_float2(t.x + w0, t.y + w1);
-            c.gC[(i + 1 + r) * P + j + 1].y += w0 + w1;
+        if (SR == VLG_SR_MAX) x.template allreduce_argmax<6>(m, am, G);
+        else x.template allreduce_max<6>(m, G);
+        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (SR == VLG_SR_LOG) {
+            for (int r = rr; r < w; r += G) {
+                const float2 a = cr[r], b = cl[r];
+                s[0] += VLG_EXP(a.y + b.x - m[0]);
+                s[1] += VLG_EXP(a.x + b.y - m[1]);
+                if (r >= 1) {
+                    const float u = ca[r * P].y;
+                    const float2 v = il[r];
+                    s[2] += VLG_EXP(u + v.x - m[2]);
+                    s[3] += VLG_EXP(u + v.y - m[3]);
+                }
+                if (r <= w - 2) {
+                    const float2 v = ir[r];
+                    const float u = cb[r * P].y;
+                    s[4] += VLG_EXP(v.x + u - m[4]);
+                    s[5] += VLG_EXP(v.y + u - m[5]);
+                }
+            }
+            x.template allreduce_sum<6>(s, G);
+        }
+        const float SL = SR == VLG_SR_LOG ? m[0] + VLG_LOG(s[0]) : m[0];
+        const float SRv = SR == VLG_SR_LOG ? m[1] + VLG_LOG(s[1]) : m[1];
+        const float2 aL = c.I[j * P + i], aR = c.I[i * P + j + 1];   // attach + dec[...,GO], staged at load
+        const float2 ILn = make_float2(aL.x + SL, aL.y + SL);
+        const float2 IRn = make_float2(aR.x + SRv, aR.y + SRv);
+        const float c0 = c.C[i * P + i].y;          // CL(i,i).NC : partner of the r = 0 term of CL(j,i)
+        const float c1 = c.C[j * P + j + 1].y;      // CR(j,j).NC : partner of the r = w-1 term of CR(i,j)
+        int b0, b1, b2, b3;
+        float CLx = fold_term<SR>(m[2], s[2], am[2], c0 + ILn.x, 0, true, b0);
+        float CLy = fold_term<SR>(m[3], s[3], am[3], c0 + ILn.y, 0, true, b1);
+        float CRx = fold_term<SR>(m[4], s[4], am[4], IRn.x + c1, w - 1, false, b2);
+        float CRy = fold_term<SR>(m[5], s[5], am[5], IRn.y + c1, w - 1, false, b3);
+        if (i == 0 && w != c.len) { CRx = VLG_NEGINF; CRy = VLG_NEGINF; }   // single root, dmv.py:63
+        if (live && rr == 0) {
+            c.I[j * P + i] = ILn;
+            c.I[i * P + j + 1] = IRn;
+            c.C[j * P + i] = make_float2(CLx, CLy);
+            c.C[i * P + j + 1] = make_float2(CRx, CRy);
+            if (BWD) {
+                c.S[j * P + i] = SL;
+                c.S[i * P + j] = SRv;
+                if (SR == VLG_SR_MAX) {
+                    c.bpS[j * P + i] = (unsigned char)am[0];
+                    c.bpS[i * P + j] = (unsigned char)am[1];
+                    c.bpC[(j * P + i) * 2] = (unsigned char)b0;
+                    c.bpC[(j * P + i) * 2 + 1] = (unsigned char)b1;
+                    c.bpC[(i * P + j + 1) * 2] = (unsigned char)b2;
+                    c.bpC[(i * P + j + 1) * 2 + 1] = (unsigned char)b3;
+                }
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// DMV1o phase B2(w): adjoints of the incomplete spans of width w.  (Ne - w) * w work items.
+// DMV1o outside, width w: ONE phase (complete spans of width w, then the incomplete spans of the
+// same width whose adjoint they complete).
 // ------------------------------------------------------------------------------------------------
-template <int SR>
-VLG_HD void dmv_b2(const DmvCtx& c, int w, int tid, int nt) {
-    const int P = c.P, n = c.Ne - w, total = n * w;
-    const float inv_w = 1.0f / (float)w;
-    for (int idx = tid; idx < total; idx += nt) {
-        int i = (int)(((float)idx + 0.5f) * inv_w);
-        int r = idx - i * w;
-        const int j = i + w;
-        const float2 gil = c.gI[j * P + i];        // total adjoint of IL(j,i).v == d logZ / d attach[j,i,v]
-        const float2 gir = c.gI[i * P + j + 1];
+template <int SR, typename X>
+VLG_HD void dmv_bw(const DmvCtx& c, int w, int tid, int nt, X& x) {
+    const int P = c.P, spans = c.Ne - w;
+    const int G = group_size(spans, w, nt), per = nt / G;
+    const int rr = tid & (G - 1), slot = tid / G;
+    for (int base = 0; base < spans; base += per) {
+        const bool live = base + slot < spans;
+        const int i = live ? base + slot : 0, j = i + w;
+        const int kL = j * P + i, kR = i * P + j + 1;          // CL(j,i) / IL(j,i) and CR(i,j) / IR(i,j) slots
+        float2 gcl = make_float2(0.f, 0.f), gcr = make_float2(0.f, 0.f);
+        if (live) {
+            const float2 a = c.gCc[kL], b = c.gCi[kL];
+            gcl = make_float2(a.x + b.x, a.y + b.y);
+            if (!(i == 0 && w != c.len)) {   // the masked cell was overwritten: no adjoint (dmv.py:63)
+                const float2 a2 = c.gCc[kR], b2 = c.gCi[kR];
+                gcr = make_float2(a2.x + b2.x, a2.y + b2.y);
+            }
+        }
+        const float2 ocl = c.C[kL], ocr = c.C[kR];
+        const float2 gil_old = c.gI[kL], gir_old = c.gI[kR];
+        int bl0 = 0, bl1 = 0, br0 = 0, br1 = 0, bsl = 0, bsr = 0;
+        if (SR == VLG_SR_MAX) {
+            bl0 = c.bpC[kL * 2]; bl1 = c.bpC[kL * 2 + 1]; br0 = c.bpC[kR * 2]; br1 = c.bpC[kR * 2 + 1];
+            bsl = c.bpS[j * P + i]; bsr = c.bpS[i * P + j];
+        }
+        float self[4] = {0.f, 0.f, 0.f, 0.f};   // r = 0 share of gIL(j,i), r = w-1 share of gIR(i,j)
+        for (int r = rr; r < w; r += G) {
+            {   // CL(j,i).v = (+)_r CL(i+r,i).NC + IL(j,i+r).v
+                const float a = c.C[(i + r) * P + i].y;
+                const float2 v = c.I[kL + r];
+                const float w0 = adj_w<SR>(gcl.x, a + v.x, ocl.x, r, bl0);
+                const float w1 = adj_w<SR>(gcl.y, a + v.y, ocl.y, r, bl1);
+                if (r == 0) { self[0] = w0; self[1] = w1; }
+                else if (live) { const float2 t = c.gI[kL + r]; c.gI[kL + r] = make_float2(t.x + w0, t.y + w1); }
+                if (live) c.gCc[(i + r) * P + i].y += w0 + w1;
+            }
+            {   // CR(i,j).v = (+)_r IR(i,i+1+r).v + CR(i+1+r,j).NC
+                const float2 v = c.I[i * P + i + r + 2];
+                const float a = c.C[(i + 1 + r) * P + j + 1].y;
+                const float w0 = adj_w<SR>(gcr.x, v.x + a, ocr.x, r, br0);
+                const float w1 = adj_w<SR>(gcr.y, v.y + a, ocr.y, r, br1);
+                if (r == w - 1) { self[2] = w0; self[3] = w1; }
+                else if (live) { const float2 t = c.gI[i * P + i + r + 2]; c.gI[i * P + i + r + 2] = make_float2(t.x + w0, t.y + w1); }
+                if (live) c.gCc[(i + 1 + r) * P + j + 1].y += w0 + w1;
+            }
+        }
+        x.template allreduce_sum<4>(self, G);   // one lane holds each value: this is a broadcast
+        const float2 gil = make_float2(gil_old.x + self[0], gil_old.y + self[1]);   // complete adjoint of IL(j,i)
+        const float2 gir = make_float2(gir_old.x + self[2], gir_old.y + self[3]);
         const float gsl = gil.x + gil.y, gsr = gir.x + gir.y;
-        const float2 cr = c.C[i * P + i + r + 1];  // CR(i, i+r)
-        const float2 cl = c.C[j * P + i + r + 1];  // CL(j, i+r+1)
-        int bpl = 0, bpr = 0;
-        if (SR == VLG_SR_MAX) { bpl = c.bpS[j * P + i]; bpr = c.bpS[i * P + j]; }
-        const float wl = adj_w<SR>(gsl, cr.y + cl.x, c.S[j * P + i], r, bpl);   // SL term: CR.NC + CL.HC
-        const float wr = adj_w<SR>(gsr, cr.x + cl.y, c.S[i * P + j], r, bpr);   // SR term: CR.HC + CL.NC
-        float2 t = c.gC[i * P + i + r + 1];
-        c.gC[i * P + i + r + 1] = make_float2(t.x + wr, t.y + wl);
-        t = c.gC[j * P + i + r + 1];
-        c.gC[j * P + i + r + 1] = make_float2(t.x + wl, t.y + wr);
-        if (r == 0) {   // dec[h,dir,v,GO] enters every incomplete span headed by h (dmv.py:36-37)
-            c.gdecs[j * 8 + dec_idx(0, 0, 0)] += gil.x;
+        const float SLv = c.S[j * P + i], SRv = c.S[i * P + j];
+        for (int r = rr; r < w; r += G) {
+            const float2 a = c.C[i * P + i + r + 1];  // CR(i, i+r)
+            const float2 b = c.C[j * P + i + r + 1];  // CL(j, i+r+1)
+            const float wl = adj_w<SR>(gsl, a.y + b.x, SLv, r, bsl);   // SL term: CR.NC + CL.HC
+            const float wr = adj_w<SR>(gsr, a.x + b.y, SRv, r, bsr);   // SR term: CR.HC + CL.NC
+            if (live) {
+                float2 t = c.gCi[i * P + i + r + 1];
+                c.gCi[i * P + i + r + 1] = make_float2(t.x + wr, t.y + wl);
+                t = c.gCi[j * P + i + r + 1];
+                c.gCi[j * P + i + r + 1] = make_float2(t.x + wl, t.y + wr);
+            }
+        }
+        if (live && rr == 0) {
+            c.gI[kL] = gil;   // == d logZ / d attach[j,i,:]
+            c.gI[kR] = gir;   // == d logZ / d attach[i,j,:]
+            c.gdecs[j * 8 + dec_idx(0, 0, 0)] += gil.x;   // dec[h,dir,v,GO] enters every incomplete span headed by h
             c.gdecs[j * 8 + dec_idx(0, 1, 0)] += gil.y;
             c.gdecs[i * 8 + dec_idx(1, 0, 0)] += gir.x;
             c.gdecs[i * 8 + dec_idx(1, 1, 0)] += gir.y;
@@ -274,144 +322,136 @@ struct DepCtx {
     float* C;
     float* I;       // pre-loaded with arc scores
     float* S;
-    float* gC;
+    float* gCc;
+    float* gCi;
     float* gI;
     unsigned char* bpS;
     unsigned char* bpC;
 };
 
-template <int SR, bool BWD>
-VLG_HD void dep_f1(const DepCtx& c, int w, int tid, int nt) {
-    const int P = c.P, n = c.Ne - w;
-    for (int i = tid; i < n; i += nt) {
-        const int j = i + w;
+template <int SR, bool BWD, typename X>
+VLG_HD void dep_fw(const DepCtx& c, int w, int tid, int nt, X& x) {
+    const int P = c.P, spans = c.Ne - w;
+    const int G = group_size(spans, w, nt), per = nt / G;
+    const int rr = tid & (G - 1), slot = tid / G;
+    for (int base = 0; base < spans; base += per) {
+        const bool live = base + slot < spans;
+        const int i = live ? base + slot : 0, j = i + w;
         const float* cr = c.C + i * P + i + 1;
         const float* cl = c.C + j * P + i + 1;
-        float m = -3.0e38f;
-        int am = 0;
-        for (int r = 0; r < w; ++r) {
-            const float t = cr[r] + cl[r];
-            if (t > m) { m = t; am = r; }
+        const float* ca = c.C + i * P + i;
+        const float* il = c.I + j * P + i;
+        const float* ir = c.I + i * P + i + 2;
+        const float* cb = c.C + (i + 1) * P + j + 1;
+        float m[3];
+        int am[3];
+        for (int k = 0; k < 3; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
+        for (int r = rr; r < w; r += G) {
+            upd_max(m[0], am[0], cr[r] + cl[r], r);
+            if (r >= 1) upd_max(m[1], am[1], ca[r * P] + il[r], r);
+            if (r <= w - 2) upd_max(m[2], am[2], ir[r] + cb[r * P], r);
         }
-        float out = m;
+        if (SR == VLG_SR_MAX) x.template allreduce_argmax<3>(m, am, G);
+        else x.template allreduce_max<3>(m, G);
+        float s[3] = {0.f, 0.f, 0.f};
         if (SR == VLG_SR_LOG) {
-            float s = 0.f;
-            for (int r = 0; r < w; ++r) s += VLG_EXP(cr[r] + cl[r] - m);
-            out = m + VLG_LOG(s);
+            for (int r = rr; r < w; r += G) {
+                s[0] += VLG_EXP(cr[r] + cl[r] - m[0]);
+                if (r >= 1) s[1] += VLG_EXP(ca[r * P] + il[r] - m[1]);
+                if (r <= w - 2) s[2] += VLG_EXP(ir[r] + cb[r * P] - m[2]);
+            }
+            x.template allreduce_sum<3>(s, G);
         }
-        if (BWD) c.S[i * P + j] = out;
-        if (BWD && SR == VLG_SR_MAX) c.bpS[i * P + j] = (unsigned char)am;
-        c.I[j * P + i] += out;
-        c.I[i * P + j + 1] += out;
-    }
-}
-
-template <int SR, bool BWD>
-VLG_HD void dep_f2(const DepCtx& c, int w, int tid, int nt) {
-    const int P = c.P, n = c.Ne - w;
-    for (int idx = tid; idx < 2 * n; idx += nt) {
-        const int i = idx >> 1, side = idx & 1, j = i + w;
-        float m = -3.0e38f;
-        int am = 0;
-        float out;
-        if (side == 0) {
-            const float* a = c.C + i * P + i;
-            const float* b = c.I + j * P + i;
-            for (int r = 0; r < w; ++r) {
-                const float t = a[r * P] + b[r];
-                if (t > m) { m = t; am = r; }
+        const float T = SR == VLG_SR_LOG ? m[0] + VLG_LOG(s[0]) : m[0];
+        const float ILn = c.I[j * P + i] + T, IRn = c.I[i * P + j + 1] + T;   // deptree.py:58,62
+        int b0, b1;
+        const float CLv = fold_term<SR>(m[1], s[1], am[1], c.C[i * P + i] + ILn, 0, true, b0);
+        float CRv = fold_term<SR>(m[2], s[2], am[2], IRn + c.C[j * P + j + 1], w - 1, false, b1);
+        if (i == 0 && w != c.len) CRv = VLG_NEGINF;   // deptree.py:71-72
+        if (live && rr == 0) {
+            c.I[j * P + i] = ILn;
+            c.I[i * P + j + 1] = IRn;
+            c.C[j * P + i] = CLv;
+            c.C[i * P + j + 1] = CRv;
+            if (BWD) {
+                c.S[i * P + j] = T;
+                if (SR == VLG_SR_MAX) {
+                    c.bpS[i * P + j] = (unsigned char)am[0];
+                    c.bpC[j * P + i] = (unsigned char)b0;
+                    c.bpC[i * P + j + 1] = (unsigned char)b1;
+                }
             }
-            out = m;
-            if (SR == VLG_SR_LOG) {
-                float s = 0.f;
-                for (int r = 0; r < w; ++r) s += VLG_EXP(a[r * P] + b[r] - m);
-                out = m + VLG_LOG(s);
-            }
-            c.C[j * P + i] = out;
-            if (BWD && SR == VLG_SR_MAX) c.bpC[j * P + i] = (unsigned char)am;
-        } else {
-            const float* a = c.I + i * P + i + 2;
-            const float* b = c.C + (i + 1) * P + j + 1;
-            for (int r = 0; r < w; ++r) {
-                const float t = a[r] + b[r * P];
-                if (t > m) { m = t; am = r; }
-            }
-            out = m;
-            if (SR == VLG_SR_LOG) {
-                float s = 0.f;
-                for (int r = 0; r < w; ++r) s += VLG_EXP(a[r] + b[r * P] - m);
-                out = m + VLG_LOG(s);
-            }
-            if (i == 0 && w != c.len) out = VLG_NEGINF;   // deptree.py:71-72
-            c.C[i * P + j + 1] = out;
-            if (BWD && SR == VLG_SR_MAX) c.bpC[i * P + j + 1] = (unsigned char)am;
         }
     }
 }
 
-template <int SR>
-VLG_HD void dep_b1(const DepCtx& c, int w, int tid, int nt) {
-    const int P = c.P, n = c.Ne - w, total = n * w;
-    const float inv_w = 1.0f / (float)w;
-    for (int idx = tid; idx < total; idx += nt) {
-        int i = (int)(((float)idx + 0.5f) * inv_w);
-        int r = idx - i * w;
-        const int j = i + w;
-        {
-            const float g = c.gC[j * P + i];
-            const float t = c.C[(i + r) * P + i] + c.I[j * P + i + r];
-            const float wt = adj_w<SR>(g, t, c.C[j * P + i], r, SR == VLG_SR_MAX ? c.bpC[j * P + i] : 0);
-            c.gI[j * P + i + r] += wt;
-            c.gC[(i + r) * P + i] += wt;
+template <int SR, typename X>
+VLG_HD void dep_bw(const DepCtx& c, int w, int tid, int nt, X& x) {
+    const int P = c.P, spans = c.Ne - w;
+    const int G = group_size(spans, w, nt), per = nt / G;
+    const int rr = tid & (G - 1), slot = tid / G;
+    for (int base = 0; base < spans; base += per) {
+        const bool live = base + slot < spans;
+        const int i = live ? base + slot : 0, j = i + w;
+        const int kL = j * P + i, kR = i * P + j + 1;
+        float gl = 0.f, gr = 0.f;
+        if (live) {
+            gl = c.gCc[kL] + c.gCi[kL];
+            if (!(i == 0 && w != c.len)) gr = c.gCc[kR] + c.gCi[kR];
         }
-        {
-            float g = c.gC[i * P + j + 1];
-            if (i == 0 && w != c.len) g = 0.f;
-            const float t = c.I[i * P + i + r + 2] + c.C[(i + 1 + r) * P + j + 1];
-            const float wt = adj_w<SR>(g, t, c.C[i * P + j + 1], r, SR == VLG_SR_MAX ? c.bpC[i * P + j + 1] : 0);
-            c.gI[i * P + i + r + 2] += wt;
-            c.gC[(i + 1 + r) * P + j + 1] += wt;
+        const float ol = c.C[kL], orr = c.C[kR];
+        const float gil_old = c.gI[kL], gir_old = c.gI[kR];
+        int bl = 0, br = 0, bs = 0;
+        if (SR == VLG_SR_MAX) { bl = c.bpC[kL]; br = c.bpC[kR]; bs = c.bpS[i * P + j]; }
+        float self[2] = {0.f, 0.f};
+        for (int r = rr; r < w; r += G) {
+            const float wl = adj_w<SR>(gl, c.C[(i + r) * P + i] + c.I[kL + r], ol, r, bl);
+            if (r == 0) self[0] = wl;
+            else if (live) c.gI[kL + r] += wl;
+            if (live) c.gCc[(i + r) * P + i] += wl;
+            const float wr = adj_w<SR>(gr, c.I[i * P + i + r + 2] + c.C[(i + 1 + r) * P + j + 1], orr, r, br);
+            if (r == w - 1) self[1] = wr;
+            else if (live) c.gI[i * P + i + r + 2] += wr;
+            if (live) c.gCc[(i + 1 + r) * P + j + 1] += wr;
         }
-    }
-}
-
-template <int SR>
-VLG_HD void dep_b2(const DepCtx& c, int w, int tid, int nt) {
-    const int P = c.P, n = c.Ne - w, total = n * w;
-    const float inv_w = 1.0f / (float)w;
-    for (int idx = tid; idx < total; idx += nt) {
-        int i = (int)(((float)idx + 0.5f) * inv_w);
-        int r = idx - i * w;
-        const int j = i + w;
-        const float gs = c.gI[j * P + i] + c.gI[i * P + j + 1];
-        const float t = c.C[i * P + i + r + 1] + c.C[j * P + i + r + 1];
-        const float wt = adj_w<SR>(gs, t, c.S[i * P + j], r, SR == VLG_SR_MAX ? c.bpS[i * P + j] : 0);
-        c.gC[i * P + i + r + 1] += wt;
-        c.gC[j * P + i + r + 1] += wt;
+        x.template allreduce_sum<2>(self, G);
+        const float gil = gil_old + self[0], gir = gir_old + self[1];
+        const float gs = gil + gir, Tv = c.S[i * P + j];
+        for (int r = rr; r < w; r += G) {
+            const float wt = adj_w<SR>(gs, c.C[i * P + i + r + 1] + c.C[j * P + i + r + 1], Tv, r, bs);
+            if (live) {
+                c.gCi[i * P + i + r + 1] += wt;
+                c.gCi[j * P + i + r + 1] += wt;
+            }
+        }
+        if (live && rr == 0) {
+            c.gI[kL] = gil;   // == d logZ / d arc[j,i]
+            c.gI[kR] = gir;
+        }
     }
 }
 
 // ================================================================================================
-// Whole-sentence drivers: the body of one workgroup.  `sync()` is __syncthreads() on the GPU and
+// Whole-sentence drivers: the body of one workgroup.  `x.sync()` is __syncthreads() on the GPU and
 // the token barrier of the host phase emulator in the CPU tests.  Pointers in the context are
 // already carved (LDS and/or workspace); dec/attach/gdec/gatt/logZ point at THIS sentence.
 // ================================================================================================
-template <int SR, bool BWD, typename In, typename Sync>
+template <int SR, bool BWD, typename In, typename X>
 VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename In::T* attach, int N, float glogZ,
-                    float* logZ, float* gdec, float* gatt, int tid, int nt, Sync sync) {
+                    float* logZ, float* gdec, float* gatt, int tid, int nt, X& x) {
     const int Ne = c.Ne, P = c.P, len = c.len;
     // ---- stage: charts to the semiring zero (dmv.py:34-35), dec into fast memory -----------------
     const float2 zz = make_float2(VLG_NEGINF, VLG_NEGINF), oo = make_float2(0.f, 0.f);
     for (int i = tid; i < Ne * P; i += nt) {
         c.C[i] = zz;
         c.I[i] = zz;
-        if (BWD) { c.gC[i] = oo; c.gI[i] = oo; }
+        if (BWD) { c.gCc[i] = oo; c.gCi[i] = oo; c.gI[i] = oo; }
     }
     for (int i = tid; i < Ne * 8; i += nt) {
         c.decs[i] = In::ld(dec, i);
         if (BWD) c.gdecs[i] = 0.f;
     }
-    sync();
+    x.sync();
     // incomplete-span slots are pre-loaded with attach + dec[...,GO] (dmv.py:36-37); the width-0
     // complete spans with the STOP scores (dmv.py:39-40).  This folds the reference's
     // attach_left / attach_right temporaries into the load stage.
@@ -427,24 +467,20 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
             else c.I[h * P + ch + 1] = make_float2(a.x + d[4], a.y + d[6]);
         }
     }
-    sync();
+    x.sync();
     // ---- inside -----------------------------------------------------------------------------------
     for (int w = 1; w < Ne; ++w) {
-        dmv_f1<SR, BWD>(c, w, tid, nt);
-        sync();
-        dmv_f2<SR, BWD>(c, w, tid, nt);
-        sync();
+        dmv_fw<SR, BWD>(c, w, tid, nt, x);
+        x.sync();
     }
     if (tid == 0) *logZ = c.C[len + 1].y;   // CR(0,len).NOCHILD, dmv.py:65
     if (!BWD) return;
     // ---- outside: adjoint replay ------------------------------------------------------------------
-    if (tid == 0) c.gC[len + 1].y = glogZ;
-    sync();
+    if (tid == 0) c.gCc[len + 1].y = glogZ;
+    x.sync();
     for (int w = Ne - 1; w >= 1; --w) {
-        dmv_b1<SR>(c, w, tid, nt);
-        sync();
-        dmv_b2<SR>(c, w, tid, nt);
-        sync();
+        dmv_bw<SR>(c, w, tid, nt, x);
+        x.sync();
     }
     // expected counts out (coalesced; padded positions get exact zeros like the reference)
     for (int idx = tid; idx < N * N; idx += nt) {
@@ -462,22 +498,25 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
         if (h < Ne) {
             const int dir = k >> 2, v = (k >> 1) & 1;
             if ((k & 1) == 0) g = c.gdecs[h * 8 + k];                                   // GO
-            else g = reinterpret_cast<const float*>(c.gC + h * P + h + dir)[v];         // STOP = width-0 span
+            else {                                                                      // STOP = width-0 span
+                const int q = h * P + h + dir;
+                g = reinterpret_cast<const float*>(c.gCc + q)[v] + reinterpret_cast<const float*>(c.gCi + q)[v];
+            }
         }
         gdec[idx] = g;
     }
 }
 
-template <int SR, bool BWD, typename In, typename Sync>
+template <int SR, bool BWD, typename In, typename X>
 VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glogZ, float* logZ, float* garc, int tid,
-                    int nt, Sync sync) {
+                    int nt, X& x) {
     const int Ne = c.Ne, P = c.P, len = c.len;
     for (int i = tid; i < Ne * P; i += nt) {
         c.C[i] = VLG_NEGINF;   // deptree.py:42-43
         c.I[i] = VLG_NEGINF;
-        if (BWD) { c.gC[i] = 0.f; c.gI[i] = 0.f; }
+        if (BWD) { c.gCc[i] = 0.f; c.gCi[i] = 0.f; c.gI[i] = 0.f; }
     }
-    sync();
+    x.sync();
     // arcs beyond the sentence are never read (the reference masks them on a clone, deptree.py:159-161)
     for (int idx = tid; idx < Ne * Ne; idx += nt) {
         const int h = idx / Ne, ch = idx - h * Ne;
@@ -490,22 +529,18 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
             else c.I[h * P + ch + 1] = a;
         }
     }
-    sync();
+    x.sync();
     for (int w = 1; w < Ne; ++w) {
-        dep_f1<SR, BWD>(c, w, tid, nt);
-        sync();
-        dep_f2<SR, BWD>(c, w, tid, nt);
-        sync();
+        dep_fw<SR, BWD>(c, w, tid, nt, x);
+        x.sync();
     }
     if (tid == 0) *logZ = c.C[len + 1];   // CR(0,len), deptree.py:74-75
     if (!BWD) return;
-    if (tid == 0) c.gC[len + 1] = glogZ;
-    sync();
+    if (tid == 0) c.gCc[len + 1] = glogZ;
+    x.sync();
     for (int w = Ne - 1; w >= 1; --w) {
-        dep_b1<SR>(c, w, tid, nt);
-        sync();
-        dep_b2<SR>(c, w, tid, nt);
-        sync();
+        dep_bw<SR>(c, w, tid, nt, x);
+        x.sync();
     }
     for (int idx = tid; idx < N * N; idx += nt) {
         const int h = idx / N, ch = idx - h * N;
@@ -518,47 +553,76 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
     }
 }
 
-// chart pitch: odd and >= N + 1 so that row-strided (column) walks hit distinct LDS banks
-VLG_HOSTDEV int chart_pitch(int N) { return (N + 1) | 1; }
-
 // ---- byte layout of one sentence's working set, shared by the LDS carve, the global workspace and
-//      the host phase emulator (which allocates EXACTLY this, with canaries behind it) ------------------
+//      the host phase emulator (which allocates EXACTLY this, with canaries behind it).
+// Placement modes (what lives in LDS; the rest goes to the caller's workspace, L2-resident):
+//   0: everything          1: adjoints + staging (value charts in workspace)
+//   2: gCc, gCi + staging  3: staging only
 VLG_HOSTDEV size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+struct Region {
+    size_t off;
+    bool lds;
+};
+
+struct Carver {
+    size_t lds = 0, ws = 0;
+    VLG_HOSTDEV_M Region take(size_t bytes, bool in_lds) {
+        Region r;
+        r.lds = in_lds;
+        if (in_lds) { r.off = lds; lds = align16(lds + bytes); }
+        else { r.off = ws; ws = align16(ws + bytes); }
+        return r;
+    }
+};
+
 struct DmvLayout {
-    size_t C, I, S, bpS, bpC, gC, gI, decs, gdecs, value_end, total;
-    VLG_HOSTDEV_M DmvLayout(int N, bool bwd, bool is_max) {
+    Region C, I, S, bpS, bpC, gCc, gCi, gI, decs, gdecs;
+    size_t lds_bytes, ws_bytes;
+    VLG_HOSTDEV_M DmvLayout(int N, bool bwd, bool is_max, int mode) {
         const size_t cells = (size_t)N * chart_pitch(N);
-        size_t o = 0;
-        C = o; o = align16(o + cells * 8);
-        I = o; o = align16(o + cells * 8);
-        S = o; o = align16(o + (bwd ? cells * 4 : 0));
-        bpS = o; o = align16(o + (bwd && is_max ? cells : 0));
-        bpC = o; o = align16(o + (bwd && is_max ? cells * 2 : 0));
-        value_end = o;
-        gC = o; o = align16(o + (bwd ? cells * 8 : 0));
-        gI = o; o = align16(o + (bwd ? cells * 8 : 0));
-        decs = o; o = align16(o + (size_t)N * 32);
-        gdecs = o; o = align16(o + (bwd ? (size_t)N * 32 : 0));
-        total = o;
+        Carver k;
+        const bool v = mode < 1, a1 = mode < 3, a2 = mode < 2;
+        C = k.take(cells * 8, v);
+        I = k.take(cells * 8, v);
+        S = k.take(bwd ? cells * 4 : 0, v);
+        bpS = k.take(bwd && is_max ? cells : 0, v);
+        bpC = k.take(bwd && is_max ? cells * 2 : 0, v);
+        gCc = k.take(bwd ? cells * 8 : 0, a1);
+        gCi = k.take(bwd ? cells * 8 : 0, a1);
+        gI = k.take(bwd ? cells * 8 : 0, a2);
+        decs = k.take((size_t)N * 32, true);
+        gdecs = k.take(bwd ? (size_t)N * 32 : 0, true);
+        lds_bytes = k.lds;
+        ws_bytes = k.ws;
     }
 };
 
 struct DepLayout {
-    size_t C, I, S, bpS, bpC, gC, gI, value_end, total;
-    VLG_HOSTDEV_M DepLayout(int N, bool bwd, bool is_max) {
+    Region C, I, S, bpS, bpC, gCc, gCi, gI;
+    size_t lds_bytes, ws_bytes;
+    VLG_HOSTDEV_M DepLayout(int N, bool bwd, bool is_max, int mode) {
         const size_t cells = (size_t)N * chart_pitch(N);
-        size_t o = 0;
-        C = o; o = align16(o + cells * 4);
-        I = o; o = align16(o + cells * 4);
-        S = o; o = align16(o + (bwd ? cells * 4 : 0));
-        bpS = o; o = align16(o + (bwd && is_max ? cells : 0));
-        bpC = o; o = align16(o + (bwd && is_max ? cells : 0));
-        value_end = o;
-        gC = o; o = align16(o + (bwd ? cells * 4 : 0));
-        gI = o; o = align16(o + (bwd ? cells * 4 : 0));
-        total = o;
+        Carver k;
+        const bool v = mode < 1, a1 = mode < 3, a2 = mode < 2;
+        C = k.take(cells * 4, v);
+        I = k.take(cells * 4, v);
+        S = k.take(bwd ? cells * 4 : 0, v);
+        bpS = k.take(bwd && is_max ? cells : 0, v);
+        bpC = k.take(bwd && is_max ? cells : 0, v);
+        gCc = k.take(bwd ? cells * 4 : 0, a1);
+        gCi = k.take(bwd ? cells * 4 : 0, a1);
+        gI = k.take(bwd ? cells * 4 : 0, a2);
+        lds_bytes = k.lds;
+        ws_bytes = k.ws;
     }
 };
+
+template <typename Layout>
+VLG_HOSTDEV int pick_mode(int N, bool bwd, bool is_max, size_t lds_budget) {
+    for (int mode = 0; mode < 3; ++mode)
+        if (Layout(N, bwd, is_max, mode).lds_bytes <= lds_budget) return mode;
+    return 3;
+}
 
 }  // namespace vlg
