@@ -1,0 +1,83 @@
+"""CPU, world_size 2, gloo: the multi-GPU path shards sentences across ranks and combines the
+marginal-loss gradient with ONE all-reduce.  The per-rank compute here is the oracle (the HIP path needs
+a GPU); what is under test is vlgae_amd.dist -- sharding, the double-buffered asynchronous reducer and
+its equivalence with the unsharded batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import oracle
+    from vlgae_amd import dist as vdist
+    oracle.set_threads(1)
+    r, lr, w = vdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+
+    rng = np.random.default_rng(0)                 # every rank draws the same global batch
+    B, L = 10, 9                                   # 10 over 2 ranks = 5 + 5; also try an uneven split below
+    dec = rng.standard_normal((B, L, 2, 2, 2)).astype(np.float32)
+    attach = rng.standard_normal((B, L, L, 2)).astype(np.float32)
+    root = rng.standard_normal((B, L)).astype(np.float32)
+    lengths = rng.integers(1, L + 1, size=B)
+    md, ma = oracle.dmv1o_merge(dec, attach, root)
+    N = L + 1
+    n_grad = N * 8 + N * N * 2
+
+    results = {}
+    for n_items in (B, B - 3):                     # 7 items -> 4 + 3
+        s, e = vdist.shard_bounds(n_items, rank, world)
+        md_s, ma_s, ln_s = vdist.shard_batch([torch.from_numpy(md[:n_items]), torch.from_numpy(ma[:n_items]),
+                                              torch.from_numpy(lengths[:n_items])], rank, world)
+        assert md_s.shape[0] == e - s
+        red = vdist.GradAllReducer(n_grad, torch.device("cpu"))
+        steps = []
+        for step in range(3):                      # several steps: exercises the double buffering
+            scale = float(step + 1)
+            lz, gd, ga = oracle.dmv1o(md_s.numpy(), ma_s.numpy(), ln_s.numpy(), "log", np.float32,
+                                      glogZ=np.full(e - s, scale, np.float32))
+            buf = red.buffer
+            buf[:N * 8] = torch.from_numpy(gd.reshape(e - s, -1).sum(0))
+            buf[N * 8:] = torch.from_numpy(ga.reshape(e - s, -1).sum(0))
+            reduced = red.launch()                 # asynchronous; flips to the other buffer
+            if step == 1:                          # two collectives in flight at once (steps 0 and 1)
+                red.wait()
+                steps.append(prev.clone())
+                steps.append(reduced.clone())
+            elif step == 2:
+                red.wait()
+                steps.append(reduced.clone())
+            prev = reduced
+        _, gd_all, ga_all = oracle.dmv1o(md[:n_items], ma[:n_items], lengths[:n_items], "log", np.float32)
+        full = np.concatenate([gd_all.reshape(n_items, -1).sum(0), ga_all.reshape(n_items, -1).sum(0)])
+        errs = [float(np.abs(steps[k].numpy() - (k + 1) * full).max()) for k in range(3)]
+        results[n_items] = errs
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array([results[B], results[B - 3]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_sharded_gradient_allreduce_matches_full_batch(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        errs = np.load(tmp_path / f"rank{rank}.npy")
+        assert errs.shape == (2, 3) and errs.max() <= 2e-4, errs     # sums of ~10 fp32 expected-count tensors

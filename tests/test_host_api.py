@@ -1,0 +1,96 @@
+"""CPU: host-side mirror of the reference's interface -- names, constants, shapes, error behaviour --
+and the rule that the product has no CPU / oracle fallback."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_api_surface_matches_reference_names():
+    import vlgae_amd.torch_struct as ts
+    # src/model/torch_struct/dmv.py:7-15
+    assert (ts.NOCHILD, ts.HASCHILD, ts.LEFT, ts.RIGHT, ts.GO, ts.STOP) == (1, 0, 0, 1, 0, 1)
+    assert (ts.DIR_NUM, ts.VAL_NUM, ts.DEC_NUM) == (2, 2, 2)
+    assert ts.NEGINF == -1e12 and ts.LogSemiring.zero == -1e12 and ts.MaxSemiring.zero == -1e12
+    for cls in (ts.DMV1o, ts.DependencyCRF):
+        assert issubclass(cls, ts.StructDistribution)
+        for prop in ("partition", "max", "argmax", "marginals", "mode"):
+            assert hasattr(cls, prop)
+    assert callable(ts.DMV1o.merge)
+    from vlgae_amd import align
+    import inspect
+    assert list(inspect.signature(align.gather_logit_simple).parameters) == ["self", "inputs", "vis", "txt", "vp"]
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must raise, not silently compute somewhere else."""
+    import vlgae_amd.torch_struct as ts
+    from vlgae_amd import align
+    dec, attach = torch.zeros(2, 5, 2, 2, 2), torch.zeros(2, 5, 5, 2)
+    lengths = torch.tensor([4, 3])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ts.DMV1o([dec, attach], lengths).partition
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ts.DMV1o([dec, attach], lengths).argmax
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ts.DependencyCRF(torch.zeros(2, 5, 5), lengths).marginals
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ts.DMV1o.merge(torch.zeros(2, 4, 2, 2, 2), torch.zeros(2, 4, 4, 2), torch.zeros(2, 4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        align.bilinear_align(torch.zeros(2, 3, 8), torch.zeros(2, 4, 8))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        align.attention_fuse(torch.zeros(2, 4, 8), torch.zeros(2, 4, 8), torch.zeros(2, 4, 6), torch.zeros(2, 3, 6),
+                             torch.ones(6), torch.zeros(6))
+
+
+def test_product_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+(oracle|tests)\b|cpu_oracle|libvlg_oracle|libvlg_emu", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "vlgae_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), f"{f} references test infrastructure"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from vlgae_amd import _C
+    monkeypatch.setattr(_C, "_lib", None)
+    monkeypatch.setattr(_C, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _C.lib()
+
+
+def test_out_of_scope_api_raises():
+    import vlgae_amd.torch_struct as ts
+    d = ts.DependencyCRF(torch.zeros(1, 4, 4))
+    for call in (lambda: d.entropy, lambda: d.kmax(2), lambda: d.topk(2), lambda: d.sample((1,)), lambda: d.count,
+                 lambda: d.kl(d), lambda: d.cross_entropy(d), lambda: d.risk(None), lambda: d.gumbel_crf(),
+                 lambda: d.enumerate_support()):
+        with pytest.raises(NotImplementedError):
+            call()
+    with pytest.raises(AssertionError):
+        ts.DependencyCRF(torch.zeros(1, 4, 4), multiroot=True)       # deptree.py:26-27
+
+
+def test_distribution_metadata():
+    import vlgae_amd.torch_struct as ts
+    dec, attach = torch.zeros(3, 6, 2, 2, 2), torch.zeros(3, 6, 6, 2)
+    d = ts.DMV1o([dec, attach], torch.tensor([5, 4, 3]))
+    assert d.batch_shape == torch.Size([3]) and d.event_shape == torch.Size([6, 2, 2, 2])   # distributions.py:45-53,248-251
+    assert d.log_potentials[1] is attach
+    c = ts.DependencyCRF(torch.zeros(3, 6, 6))
+    assert c.batch_shape == torch.Size([3]) and c.event_shape == torch.Size([6, 6]) and c.lengths is None
+
+
+def test_shard_bounds():
+    from vlgae_amd.dist import shard_bounds
+    for n in (0, 1, 7, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,123 @@
+"""CPU: pin the oracle (oracle/vlg_oracle.c) on golden vectors produced by the reference itself
+(tests/golden/make_golden.py) and on brute-force enumeration.  The reference has no tests or fixtures of
+its own for this path; these vectors are what "parity" means in this repo.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_files, golden_ids, load
+
+
+@pytest.mark.parametrize("path", golden_files("dmv_"), ids=golden_ids("dmv_"))
+def test_oracle_dmv1o_matches_reference(oracle_mod, path):
+    g = load(path)
+    md, ma = oracle_mod.dmv1o_merge(g["dec"], g["attach"], g["root"])
+    if "merged_dec" in g:
+        assert np.array_equal(md, g["merged_dec"]) and np.array_equal(ma, g["merged_attach"])
+    # fp64 oracle == reference run in fp64, to rounding
+    lz, gd, ga = oracle_mod.dmv1o(md, ma, g["lengths"], "log", np.float64)
+    assert np.abs(lz - g["logZ64"]).max() <= 1e-11
+    assert np.abs(gd - g["grad_dec64"]).max() <= 1e-11 and np.abs(ga - g["grad_attach64"]).max() <= 1e-11
+    mz, mgd, mga = oracle_mod.dmv1o(md, ma, g["lengths"], "max", np.float64)
+    assert np.abs(mz - g["max64"]).max() <= 1e-11
+    assert np.array_equal(mgd, g["maxgrad_dec64"]) and np.array_equal(mga, g["maxgrad_attach64"])
+    # fp32 oracle vs reference fp32: both are fp32 evaluations of the same recurrences
+    lz32, gd32, ga32 = oracle_mod.dmv1o(md, ma, g["lengths"], "log", np.float32)
+    assert np.all(np.abs(lz32 - g["logZ"]) <= 4e-5 * np.maximum(1, np.abs(g["logZ"])))
+    assert np.abs(gd32 - g["grad_dec"]).max() <= 5e-5 and np.abs(ga32 - g["grad_attach"]).max() <= 5e-5
+    mz32, mgd32, mga32 = oracle_mod.dmv1o(md, ma, g["lengths"], "max", np.float32)
+    assert np.allclose(mz32, g["max"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(mgd32, g["maxgrad_dec"]) and np.array_equal(mga32, g["maxgrad_attach"])
+    assert np.array_equal(mga32, g["argmax"])                       # .argmax == Max-semiring attach gradient
+    assert np.abs(ga32 - g["marginals"]).max() <= 5e-5              # .marginals == Log-semiring attach gradient
+    # upstream-gradient scaling
+    _, wgd, wga = oracle_mod.dmv1o(md, ma, g["lengths"], "log", np.float32, glogZ=g["wts"])
+    assert np.abs(wgd - g["wgrad_dec"]).max() <= 1e-4 and np.abs(wga - g["wgrad_attach"]).max() <= 1e-4
+    # call-site contract (joint.py:256-258): predicted heads from the best tree
+    B, N = md.shape[:2]
+    pred = np.zeros((B, N), dtype=np.int64)
+    b, h, c = np.nonzero(mga32.sum(-1))
+    pred[b, c] = h
+    assert np.array_equal(pred, g["predicted"])
+    # MBR chain (ldndmv.py:294-299)
+    mbr_max, mbr_arg = oracle_mod.deptree(g["arc_marginal"], g["lengths"], "max", np.float32)
+    assert np.array_equal(mbr_arg, g["mbr_argmax"]) and np.allclose(mbr_max, g["mbr_max"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("path", golden_files("deptree_"), ids=golden_ids("deptree_"))
+def test_oracle_deptree_matches_reference(oracle_mod, path):
+    g = load(path)
+    lz, ga = oracle_mod.deptree(g["arc"], g["lengths"], "log", np.float64)
+    assert np.abs(lz - g["logZ64"]).max() <= 1e-11 and np.abs(ga - g["marginals64"]).max() <= 1e-11
+    mz, mga = oracle_mod.deptree(g["arc"], g["lengths"], "max", np.float64)
+    assert np.abs(mz - g["max64"]).max() <= 1e-11 and np.array_equal(mga, g["argmax64"])
+    lz32, ga32 = oracle_mod.deptree(g["arc"], g["lengths"], "log", np.float32)
+    assert np.all(np.abs(lz32 - g["logZ"]) <= 4e-5 * np.maximum(1, np.abs(g["logZ"])))
+    assert np.abs(ga32 - g["marginals"]).max() <= 5e-5
+    _, wg = oracle_mod.deptree(g["arc"], g["lengths"], "log", np.float32, glogZ=g["wts"])
+    assert np.abs(wg - g["wgrad"]).max() <= 1e-4
+    if "enum_logZ" in g:
+        # the reference's own brute-force enumerator (deptree.py:213-228) and ours agree with the DP
+        assert np.abs(lz - g["enum_logZ"]).max() <= 1e-10 and np.abs(mz - g["enum_max"]).max() <= 1e-10
+        for b in range(len(lz)):
+            e_lz, e_mx = oracle_mod.enumerate_deptree(g["arc"][b].astype(np.float64), int(g["lengths"][b]))
+            assert abs(e_lz - lz[b]) <= 1e-10 and abs(e_mx - mz[b]) <= 1e-10
+
+
+def test_oracle_dmv1o_bruteforce(oracle_mod):
+    """The reference has no enumerator for DMV1o; ours scores every projective single-root tree with the
+    valence rules read off dmv.py:36-62 and must agree with the DP (ragged lengths included)."""
+    g = load(golden_files("dmv_B5_L7_s2")[0])
+    md, ma = oracle_mod.dmv1o_merge(g["dec"], g["attach"], g["root"])
+    lz, _, _ = oracle_mod.dmv1o(md, ma, g["lengths"], "log", np.float64, grad=False)
+    mz, _, _ = oracle_mod.dmv1o(md, ma, g["lengths"], "max", np.float64, grad=False)
+    for b, ln in enumerate(g["lengths"]):
+        e_lz, e_mx = oracle_mod.enumerate_dmv1o(md[b].astype(np.float64), ma[b].astype(np.float64), int(ln))
+        assert abs(e_lz - lz[b, 0]) <= 1e-10 and abs(e_mx - mz[b, 0]) <= 1e-10
+
+
+def test_oracle_identities(oracle_mod):
+    """SURVEY.md section 4 (i)-(v) on the oracle, B=16 L=40."""
+    rng = np.random.default_rng(3)
+    B, L = 16, 40
+    dec = np.log(rng.dirichlet(np.ones(2), size=(B, L, 2, 2))).astype(np.float32)
+    attach = rng.standard_normal((B, L, L, 2)).astype(np.float32)
+    root = rng.standard_normal((B, L)).astype(np.float32)
+    lengths = rng.integers(1, L + 1, size=B)
+    lengths[0] = L
+    md, ma = oracle_mod.dmv1o_merge(dec, attach, root)
+    _, gd, ga = oracle_mod.dmv1o(md, ma, lengths, "log", np.float64)
+    assert np.allclose(ga.sum((1, 2, 3)), lengths, atol=1e-9)                 # (ii)
+    assert np.allclose(gd.sum((1, 2, 3, 4)), 3 * lengths + 1, atol=1e-9)      # (iii)
+    for b, ln in enumerate(lengths):                                          # (v) exact zeros on padding
+        assert np.all(ga[b, ln + 1:] == 0) and np.all(ga[b, :, ln + 1:] == 0) and np.all(gd[b, ln + 1:] == 0)
+    arc = rng.standard_normal((B, L + 1, L + 1)).astype(np.float32)
+    lz_crf, m = oracle_mod.deptree(arc, lengths, "log", np.float64)
+    for b, ln in enumerate(lengths):                                          # (iv)
+        assert np.allclose(m[b].sum(0)[1:ln + 1], 1.0, atol=1e-9) and np.all(m[b].sum(0)[ln + 1:] == 0)
+    z = np.zeros((B, L + 1, 2, 2, 2), np.float32)                             # (i) DMV1o degenerates to the CRF
+    lz_dmv, _, _ = oracle_mod.dmv1o(z, np.repeat(arc[..., None], 2, -1), lengths, "log", np.float64, grad=False)
+    assert np.allclose(lz_dmv[:, 0], lz_crf, atol=1e-9)
+
+
+@pytest.mark.parametrize("path", golden_files("align_"), ids=golden_ids("align_"))
+def test_oracle_align_matches_reference(oracle_mod, path):
+    g = load(path)
+    o = oracle_mod.bilinear_align(g["txt"], g["vis"], g["tmask"], g["vmask"], np.float32, float(g["neg_inf"]),
+                                  full=True, maxV=True, maxQ=True, diag=g["txt"].shape[0] == g["vis"].shape[0])
+    ref = g["attmap"]
+    masked = ref <= -1e19
+    assert np.array_equal(o["full"][masked], ref[masked])
+    assert np.abs(o["full"][~masked] - ref[~masked]).max() <= 2e-5
+    assert np.array_equal(o["maxV"], o["full"].max(-1)) and np.array_equal(o["maxQ"], o["full"].max(-2))
+    if o["diag"] is not None:
+        idx = np.arange(ref.shape[0])
+        assert np.array_equal(o["diag"], o["full"][idx, idx])
+
+
+@pytest.mark.parametrize("path", golden_files("attnfuse_"), ids=golden_ids("attnfuse_"))
+def test_oracle_attnfuse_matches_reference(oracle_mod, path):
+    g = load(path)
+    att, out = oracle_mod.attn_fuse(g["vis"], g["txt"], g["vis_mid"], g["enc_x"], g["ln_weight"], g["ln_bias"],
+                                    float(g["ln_eps"]), np.float64)
+    assert np.abs(att - g["attmap"]).max() <= 5e-6 and np.abs(out - g["out"]).max() <= 2e-5
