@@ -3,8 +3,13 @@
 //   vlg_bilinear_align : DependencyBoxRel.gather_logit_simple  (src/model/joint.py:406-419)
 //   vlg_attn_fuse      : the attention-fuse feeding the parser  (src/model/joint.py:670-674)
 //
-// v1: LDS-tiled fp32 FMA kernels with the mask / max-over-V / max-over-Q / batch-diagonal epilogue
-// fused behind the contraction (the [B,A,Q,V] tensor is only written when the caller asks for it).
+// The contraction runs on the matrix cores: v_mfma_f32_16x16x32_bf16 for bf16 features (fp32
+// accumulate), v_mfma_f32_16x16x4_f32 for fp32 features (exact fp32 products, the reference's numerics).
+// Both operands are K-contiguous in memory ([.,.,d]), which IS the MFMA fragment order, so fragments
+// are loaded straight from global memory with one 16-byte load per lane -- no LDS staging, no
+// transposes.  The epilogue (mask -> -INF, max over V, max over Q, batch diagonal) is fused behind
+// the contraction through a per-wave LDS tile, so the [B,A,Q,V] tensor is only written when asked for.
+// A generic fp32-FMA kernel remains for shapes the MFMA path does not take (d > 128 or unaligned d).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -102,6 +107,238 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(
             for (int i = tid; i < V; i += kAlignThreads) out_maxQ[((size_t)b * A + a) * V + i] = maxQ_s[i];
         __syncthreads();
     }
+}
+
+// ---- MFMA path --------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kCTB = 3;      // col tiles (16 regions each) per LDS tile pass: 48 regions
+constexpr int kTileVP = kCTB * 16 + 4;   // tile pitch 52: rows stay 16-byte aligned, and 52q + 9p hits 32 distinct banks
+
+template <bool F32IN>
+struct MfmaCfg;
+template <>
+struct MfmaCfg<false> {      // bf16 in: K-chunks of 32, 6 row tiles (96 queries) of A fragments resident
+    using T = uint16_t;
+    using Frag = bf16x8;
+    static constexpr int KW = 32, RTB = 6, EPL = 8;   // EPL = elements per lane per chunk (16 bytes)
+};
+template <>
+struct MfmaCfg<true> {       // fp32 in: K-chunks of 16, 3 row tiles (48 queries)
+    using T = float;
+    using Frag = f32x4;
+    static constexpr int KW = 16, RTB = 3, EPL = 4;
+};
+
+template <bool F32IN>
+__device__ __forceinline__ f32x4 mma_chunk(const typename MfmaCfg<F32IN>::Frag& a,
+                                           const typename MfmaCfg<F32IN>::Frag& b, f32x4 acc) {
+    if constexpr (F32IN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+        return acc;
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    }
+}
+
+// One block = caption b x (4 waves x a_per_wave images); each wave owns its images and its LDS tile.
+// d == KCH * KW exactly (dispatch guarantees it), so fragment loads need no K guards: lane l of a 16-row
+// operand tile loads elements [row l&15][kc*KW + EPL*(l>>4) .. +EPL) -- one 16-byte load, and the kc offsets
+// are instruction immediates.  Rows past the end are clamped; their products are never stored.
+template <bool F32IN, int KCH, bool TILE>
+__global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
+    const typename MfmaCfg<F32IN>::T* __restrict__ txt, const typename MfmaCfg<F32IN>::T* __restrict__ vis,
+    const uint8_t* __restrict__ tmask, const uint8_t* __restrict__ vmask, int B, int A, int Q, int V,
+    float neg_inf, float* __restrict__ out_full, float* __restrict__ out_maxV, float* __restrict__ out_maxQ,
+    float* __restrict__ out_diag, int a_per_wave) {
+    using C = MfmaCfg<F32IN>;
+    using Frag = typename C::Frag;
+    constexpr int RTB = C::RTB, QB = RTB * 16, VB = kCTB * 16, d = KCH * C::KW;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    float* tile = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (QB * kTileVP + QB);   // [QB][kTileVP]
+    float* mv = tile + QB * kTileVP;                                                         // [QB] running max over V
+    const int a_begin = (blockIdx.x * 4 + wave) * a_per_wave;
+    const typename C::T* txt_b = txt + (size_t)b * Q * d;
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;   // C/D fragment: row = 4*(l>>4) + reg, col = l&15
+    const int koff = C::EPL * (lane >> 4);
+
+    for (int q0 = 0; q0 < Q; q0 += QB) {
+        const int qn = min(QB, Q - q0);
+        Frag afrag[RTB][KCH];   // caption fragments stay in registers across all images of this wave
+#pragma unroll
+        for (int rt = 0; rt < RTB; ++rt) {
+            const Frag* rowp = reinterpret_cast<const Frag*>(txt_b + (size_t)min(q0 + rt * 16 + ccol, Q - 1) * d + koff);
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) afrag[rt][kc] = rowp[kc * (C::KW / C::EPL)];
+        }
+        // query-side keep bits of this lane's C rows (row = 16*rt + 4*(l>>4) + e), hoisted out of the image loop
+        unsigned tkeep = 0;
+#pragma unroll
+        for (int rt = 0; rt < RTB; ++rt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = q0 + rt * 16 + crow + e;
+                const unsigned m = tmask ? tmask[(size_t)b * Q + min(q, Q - 1)] : 1u;
+                tkeep |= ((q < Q && m != 0) ? 1u : 0u) << (rt * 4 + e);
+            }
+
+        // Work items of this wave in order: (image a, region group v0) -> kCTB region tiles each.  The region
+        // fragments (and their keep bits) run through a 3-deep register ring that is always two tiles
+        // (~2 x RTB x KCH MFMAs) ahead of the matrix cores, across group and image boundaries.
+        const int n_img = max(0, min(a_per_wave, A - a_begin));
+        const int n_grp = (V + VB - 1) / VB, n_items = n_img * n_grp;
+        auto load_tile = [&](int item, int ct, Frag* f, unsigned& keep) {
+            const int it = min(item, n_items - 1);            // past the end: re-load the last tile, never used
+            const int ai = it / n_grp, v0 = (it - ai * n_grp) * VB;
+            const int vrow = min(v0 + ct * 16 + ccol, V - 1);
+            const size_t arow = (size_t)(a_begin + ai) * V + vrow;
+            const Frag* rowp = reinterpret_cast<const Frag*>(vis + arow * d + koff);
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) f[kc] = rowp[kc * (C::KW / C::EPL)];
+            keep = vmask ? vmask[arow] : 1u;
+        };
+        Frag f0[KCH], f1[KCH], f2[KCH];
+        unsigned k0 = 0, k1 = 0, k2 = 0;
+        if (n_items > 0) { load_tile(0, 0, f0, k0); load_tile(0, 1, f1, k1); }
+
+        for (int item = 0; item < n_items; ++item) {
+            const int ai = item / n_grp, v0 = (item - ai * n_grp) * VB;
+            const int a = a_begin + ai, vn = min(VB, V - v0);
+            const size_t ob = ((size_t)b * A + a) * Q;   // row base of this (b, a) pair
+            float cmax[kCTB];   // running max over this lane's rows, per region column (for max over Q)
+
+            auto compute = [&](int ct, const Frag* bf, unsigned keepv) {
+                // rows past Q and masked rows / columns all take the fill value, so one select + one max per element
+                const unsigned lane_keep = (v0 + ct * 16 + ccol < V && keepv != 0) ? tkeep : 0u;
+                float cm = neg_infinity();
+                float* tcol = tile + crow * kTileVP + ct * 16 + ccol;   // + (16*rt + e) * kTileVP: immediate offsets
+#pragma unroll
+                for (int rt = 0; rt < RTB; ++rt) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kc = 0; kc < KCH; ++kc) acc = mma_chunk<F32IN>(afrag[rt][kc], bf[kc], acc);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float val = (lane_keep >> (rt * 4 + e)) & 1u ? acc[e] : neg_inf;   // joint.py:417-418
+                        if (TILE) tcol[(rt * 16 + e) * kTileVP] = val;
+                        cm = fmaxf(cm, val);
+                    }
+                }
+                return cm;
+            };
+            load_tile(item, 2, f2, k2);
+            cmax[0] = compute(0, f0, k0);
+            load_tile(item + 1, 0, f0, k0);
+            cmax[1] = compute(1, f1, k1);
+            load_tile(item + 1, 1, f1, k1);
+            cmax[2] = compute(2, f2, k2);
+            static_assert(kCTB == 3, "the fragment ring is written for three region tiles per group");
+
+            // ---- max over Q straight from the accumulators: lanes l, l^16, l^32, l^48 hold the same column ----
+            if (out_maxQ) {
+#pragma unroll
+                for (int ct = 0; ct < kCTB; ++ct) {
+                    float m = cmax[ct];
+                    m = fmaxf(m, __shfl_xor(m, 16, 64));
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    const int vcol = v0 + ct * 16 + ccol;
+                    if (lane < 16 && vcol < V) {
+                        float* dst = out_maxQ + ((size_t)b * A + a) * V + vcol;
+                        *dst = q0 == 0 ? m : fmaxf(*dst, m);   // same wave handles every row group of (b, a)
+                    }
+                }
+            }
+            if (TILE) {
+                __builtin_amdgcn_wave_barrier();
+                // ---- copy-out from the wave's LDS tile (pitch kTileVP) to the output block (pitch V) ----
+                if (out_full || (out_diag && a == b)) {
+                    float* dst_full = out_full ? out_full + (ob + q0) * V + v0 : nullptr;
+                    float* dst_diag = (out_diag && a == b) ? out_diag + ((size_t)b * Q + q0) * V + v0 : nullptr;
+                    if ((vn & 3) == 0 && (V & 3) == 0) {
+                        // 16 bytes per lane: vn/4 lanes per row, 64/(vn/4) rows per step, two steps in flight
+                        const int c4 = vn >> 2, rps = 64 / c4;
+                        const int lr = lane / c4, lc = lane - lr * c4;
+                        const bool act = lr < rps;
+                        for (int qb = 0; qb < qn; qb += 2 * rps) {
+                            const int qa = qb + lr, qc = qa + rps;
+                            float4 ta, tc;
+                            if (act && qa < qn) ta = *reinterpret_cast<const float4*>(tile + qa * kTileVP + lc * 4);
+                            if (act && qc < qn) tc = *reinterpret_cast<const float4*>(tile + qc * kTileVP + lc * 4);
+                            if (act && qa < qn) {
+                                if (dst_full) *reinterpret_cast<float4*>(dst_full + (size_t)qa * V + lc * 4) = ta;
+                                if (dst_diag) *reinterpret_cast<float4*>(dst_diag + (size_t)qa * V + lc * 4) = ta;
+                            }
+                            if (act && qc < qn) {
+                                if (dst_full) *reinterpret_cast<float4*>(dst_full + (size_t)qc * V + lc * 4) = tc;
+                                if (dst_diag) *reinterpret_cast<float4*>(dst_diag + (size_t)qc * V + lc * 4) = tc;
+                            }
+                        }
+                    } else {   // odd widths: scalar, (q, v) advanced with carry instead of a division per element
+                        const int dq = 64 / vn, dv = 64 - dq * vn;
+                        int q = lane / vn, v = lane - q * vn;
+                        for (int idx = lane; idx < qn * vn; idx += 64) {
+                            const float val = tile[q * kTileVP + v];
+                            if (dst_full) dst_full[(size_t)q * V + v] = val;
+                            if (dst_diag) dst_diag[(size_t)q * V + v] = val;
+                            q += dq;
+                            v += dv;
+                            if (v >= vn) { v -= vn; ++q; }
+                        }
+                    }
+                }
+                if (out_maxV) {
+                    // 4 lanes per query row, each scans a quarter of the regions; 16 rows per pass
+                    const int part = lane & 3, vq = (vn + 3) >> 2, vlo = part * vq, vhi = min(vn, vlo + vq);
+                    static_assert(kCTB * 16 <= 48, "a quarter row is at most 12 regions");
+                    for (int qb = 0; qb < qn; qb += 16) {
+                        const int q = qb + (lane >> 2);
+                        const float* row = tile + min(q, qn - 1) * kTileVP;
+                        float r[12];   // all twelve reads in flight together, then a max tree
+#pragma unroll
+                        for (int u = 0; u < 12; ++u) r[u] = row[min(vlo + u, kTileVP - 1)];
+                        float m0 = neg_infinity(), m1 = neg_infinity();
+#pragma unroll
+                        for (int u = 0; u < 12; u += 2) {
+                            m0 = fmaxf(m0, vlo + u < vhi ? r[u] : neg_infinity());
+                            m1 = fmaxf(m1, vlo + u + 1 < vhi ? r[u + 1] : neg_infinity());
+                        }
+                        float m = fmaxf(m0, m1);
+                        m = fmaxf(m, __shfl_xor(m, 1, 64));
+                        m = fmaxf(m, __shfl_xor(m, 2, 64));
+                        if (part == 0 && q < qn) {
+                            if (v0 != 0) m = fmaxf(m, mv[q]);
+                            if (v0 + VB >= V) out_maxV[ob + q0 + q] = m;
+                            else mv[q] = m;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+template <bool F32IN, int KCH, bool TILE>
+static int launch_align_mfma(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A,
+                             int Q, int V, float neg_inf, float* out_full, float* out_maxV, float* out_maxQ,
+                             float* out_diag, hipStream_t s) {
+    using C = MfmaCfg<F32IN>;
+    const int a_per_wave = A >= 2048 ? 16 : A >= 64 ? 8 : 1;
+    dim3 grid((A + 4 * a_per_wave - 1) / (4 * a_per_wave), B);
+    constexpr int QB = C::RTB * 16;
+    const size_t lds = TILE ? sizeof(float) * 4 * (size_t)(QB * kTileVP + QB) : 0;
+    auto k = align_mfma_kernel<F32IN, KCH, TILE>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k, grid, dim3(kAlignThreads), lds, s, (const typename C::T*)txt, (const typename C::T*)vis, tmask,
+                       vmask, B, A, Q, V, neg_inf, out_full, out_maxV, out_maxQ, out_diag, a_per_wave);
+    return check_launch("align_mfma_kernel");
 }
 
 // One block = one sentence b and a chunk of QC words.
@@ -207,12 +444,29 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
     if (B == 0 || A == 0) return 0;
     if (!txt || !vis) return set_error(VLG_ERR_ARG, "bilinear_align: null input");
     if (!out_full && !out_maxV && !out_maxQ && !out_diag) return set_error(VLG_ERR_ARG, "bilinear_align: no output requested");
+    if (B > 65535) return set_error(VLG_ERR_SHAPE, "bilinear_align: B=%d exceeds grid.y", B);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "bilinear_align: in_dtype %d", in_dtype);
+
+    // ---- matrix-core path: d a whole number of MFMA K-chunks (the model's d = 128; also 64) ----
+    const bool f32in = in_dtype == VLG_F32;
+    const bool tile = out_full || out_diag || out_maxV;   // max over Q alone needs no LDS round trip
+#define VLG_MFMA(F32, KCHV)                                                                                         \
+    return tile ? launch_align_mfma<F32, KCHV, true>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, out_maxV, \
+                                                     out_maxQ, out_diag, s)                                           \
+                : launch_align_mfma<F32, KCHV, false>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, out_maxV, \
+                                                      out_maxQ, out_diag, s)
+    if (!f32in && d == 128) { VLG_MFMA(false, 4); }
+    if (!f32in && d == 64) { VLG_MFMA(false, 2); }
+    if (f32in && d == 128) { VLG_MFMA(true, 8); }
+    if (f32in && d == 64) { VLG_MFMA(true, 4); }
+#undef VLG_MFMA
+
+    // ---- generic fp32-FMA path ----
     const size_t lds = sizeof(float) * ((size_t)(kQT + kVT) * (d + 1) + (size_t)kQT * (kVT + 1) + Q + V);
     if (lds > 160 * 1024) return set_error(VLG_ERR_SHAPE, "bilinear_align: d=%d Q=%d V=%d exceed the LDS tile budget", d, Q, V);
     int a_per_block = 8;
-    if (B > 65535) return set_error(VLG_ERR_SHAPE, "bilinear_align: B=%d exceeds grid.y", B);
     dim3 grid((A + a_per_block - 1) / a_per_block, B);
-    hipStream_t s = (hipStream_t)stream;
 #define VLG_LAUNCH(INV)                                                                                            \
     do {                                                                                                           \
         auto k = align_kernel<INV>;                                                                                \
@@ -224,9 +478,8 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
         hipLaunchKernelGGL(k, grid, dim3(kAlignThreads), lds, s, (const INV::T*)txt, (const INV::T*)vis, tmask,    \
                            vmask, B, A, Q, V, d, neg_inf, out_full, out_maxV, out_maxQ, out_diag, a_per_block);    \
     } while (0)
-    if (in_dtype == VLG_F32) VLG_LAUNCH(F32In);
-    else if (in_dtype == VLG_BF16) VLG_LAUNCH(BF16In);
-    else return set_error(VLG_ERR_DTYPE, "bilinear_align: in_dtype %d", in_dtype);
+    if (f32in) VLG_LAUNCH(F32In);
+    else VLG_LAUNCH(BF16In);
 #undef VLG_LAUNCH
     return check_launch("align_kernel");
 }
