@@ -61,10 +61,11 @@ def cpu_baseline(B, L, seed, budget_s):
     box's host cores on a bounded sample of the same workload."""
     import oracle
     oracle.build()
+    threads = oracle.max_threads()
+    B = max(B, 16 * threads)          # enough sentences per core for the OpenMP loop to scale
     dec, attach, root = synth(B, L, seed, "cpu", torch.float32)
     md, ma = oracle.dmv1o_merge(dec.numpy(), attach.numpy(), root.numpy())
     lengths = np.full(B, L, dtype=np.int64)
-    threads = oracle.max_threads()
     oracle.dmv1o(md[:8], ma[:8], lengths[:8], "log", np.float32)      # warm
     reps, t_total = 0, 0.0
     while t_total < budget_s and reps < 50:
@@ -183,6 +184,14 @@ def main():
     achieved = alg_bytes / kern_s / 1e9
     exp_ops = exp_class_ops(lengths_np)
     exp_peak = N_CU * SIMD_PER_CU * TRANS_LANES_PER_CLK * CLOCK_GHZ * 1e9
+    # HBM bytes per launch from the PMC counters: cannot be collected live (rocprofv3 --pmc runs in its own pass);
+    # taken from the committed profile of THIS workload, with the gfx950 FETCH_SIZE x2 correction applied.
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")
+    if os.path.exists(prof) and (B, L, args.dtype, bool(args.ragged)) == (256, 40, "bf16", False):
+        t = json.load(open(prof)).get("dmv1o_kernel")
+        if t:
+            traffic = (2.0 * t["FETCH_SIZE"]["avg_KB"] + t["WRITE_SIZE"]["avg_KB"]) * 1024.0
     out = {
         "metric": "sentences/sec, batched inside-outside L=%d B=%d" % (L, B),
         "value": sent_per_s, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,8 +204,9 @@ def main():
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "allreduce_floats": (max(n_grad, pad) if world > 1 else 0)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "dmv1o_kernel<Log,LDS,fused>", "kernel_us": kern_s * 1e6,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/r01_b_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)" if traffic else None,
+                     "kernel": "dmv1o_kernel<Log, mode 0 (all charts in LDS), fused inside+outside>", "kernel_us": kern_s * 1e6,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "latency-bound DP: 2(N-1) barrier-separated width steps per sentence, one workgroup "
                              "per sentence; see exp_rate for the bound that binds"},

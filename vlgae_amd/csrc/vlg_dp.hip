@@ -18,7 +18,7 @@
 namespace vlg {
 
 #ifndef VLG_DP_THREADS
-#define VLG_DP_THREADS 256
+#define VLG_DP_THREADS 512
 #endif
 constexpr int kThreads = VLG_DP_THREADS;    // lanes per sentence (workgroup size)
 constexpr size_t kLdsBudget = 160 * 1024;   // CDNA4 LDS per CU / per workgroup
