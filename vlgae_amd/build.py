@@ -18,6 +18,9 @@ LIB_PATH = os.path.join(LIB_DIR, "libvlgae_amd.so")
 ARCH = "gfx950"
 SOURCES = ("vlg_dp.hip", "vlg_align.hip", "vlg_capi.cpp")
 FLAGS = ("-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-x", "hip")
+# per-file extras.  vlg_dp.hip never produces or consumes inf / NaN in arithmetic (the semiring zero is the
+# finite -1e12), so fmaxf can be a bare v_max_f32 instead of canonicalise + max.
+EXTRA_FLAGS = {"vlg_dp.hip": ("-ffinite-math-only",)}
 
 
 def _hipcc():
@@ -44,7 +47,7 @@ def build_library(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src + ".o")
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", *FLAGS, *EXTRA_FLAGS.get(src, ()), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

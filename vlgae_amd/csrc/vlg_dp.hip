@@ -39,18 +39,45 @@ __device__ __forceinline__ int xlane_i(int v) {
 template <int K>
 __device__ __forceinline__ float xlane(float v) { return __int_as_float(xlane_i<K>(__float_as_int(v))); }
 
+// Fused DPP reduction steps: dst = op(dst, lane-permuted dst) in ONE instruction per value.  hipcc does not
+// fold v_mov_b32_dpp into the consuming VALU op here, so the steps are written as inline asm; the leading
+// s_nop covers the "VALU write -> DPP read" wait states that the assembler does not insert for asm blocks.
+#define VLG_DPP_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define VLG_DPP_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+#define VLG_DPP_HM "row_half_mirror row_mask:0xf bank_mask:0xf"
+#define VLG_DPP_RM "row_mirror row_mask:0xf bank_mask:0xf"
+
+template <int K>
+__device__ __forceinline__ float dpp_max(float v) {
+    if (K == 1) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " VLG_DPP_QP1 : "+v"(v));
+    else if (K == 2) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " VLG_DPP_QP2 : "+v"(v));
+    else if (K == 4) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " VLG_DPP_HM : "+v"(v));
+    else if (K == 8) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " VLG_DPP_RM : "+v"(v));
+    else v = fmaxf(v, xlane<K>(v));
+    return v;
+}
+template <int K>
+__device__ __forceinline__ float dpp_add(float v) {
+    if (K == 1) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " VLG_DPP_QP1 : "+v"(v));
+    else if (K == 2) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " VLG_DPP_QP2 : "+v"(v));
+    else if (K == 4) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " VLG_DPP_HM : "+v"(v));
+    else if (K == 8) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " VLG_DPP_RM : "+v"(v));
+    else v += xlane<K>(v);
+    return v;
+}
+
 struct DevX {
     __device__ __forceinline__ void sync() { __syncthreads(); }
 
     template <int K, int n>
     __device__ __forceinline__ void step_max(float* v) {
 #pragma unroll
-        for (int k = 0; k < n; ++k) v[k] = fmaxf(v[k], xlane<K>(v[k]));
+        for (int k = 0; k < n; ++k) v[k] = dpp_max<K>(v[k]);
     }
     template <int K, int n>
     __device__ __forceinline__ void step_sum(float* v) {
 #pragma unroll
-        for (int k = 0; k < n; ++k) v[k] += xlane<K>(v[k]);
+        for (int k = 0; k < n; ++k) v[k] = dpp_add<K>(v[k]);
     }
     template <int K, int n>
     __device__ __forceinline__ void step_argmax(float* v, int* a) {

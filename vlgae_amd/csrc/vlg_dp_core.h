@@ -43,8 +43,8 @@
 #define VLG_HOSTDEV __host__ __device__ inline
 #define VLG_HDM __device__ __forceinline__   // member-function form
 #define VLG_HOSTDEV_M __host__ __device__
-#define VLG_EXP(x) __expf(x)
-#define VLG_LOG(x) __logf(x)
+#define VLG_EXP(x) __builtin_amdgcn_exp2f(x)   // v_exp_f32: 2^x
+#define VLG_LOG(x) __builtin_amdgcn_logf(x)    // v_log_f32: log2 x
 #define VLG_BITS2F(u) __uint_as_float(u)
 #else
 #include <cmath>
@@ -55,8 +55,8 @@
 #define VLG_HOSTDEV static inline
 #define VLG_HDM inline
 #define VLG_HOSTDEV_M
-#define VLG_EXP(x) expf(x)
-#define VLG_LOG(x) logf(x)
+#define VLG_EXP(x) exp2f(x)
+#define VLG_LOG(x) log2f(x)
 struct float2 { float x, y; };
 static inline float2 make_float2(float a, float b) { float2 r; r.x = a; r.y = b; return r; }
 static inline float vlg_bits2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
@@ -67,6 +67,11 @@ static inline float vlg_bits2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); re
 #define VLG_SR_LOG 0
 #define VLG_SR_MAX 1
 #define VLG_LOWEST (-3.0e38f)
+// Charts are kept in log2 units so that the hardware's native 2^x / log2 x need no scaling multiplies:
+// potentials are multiplied by log2(e) once at load, logZ by ln(2) once at store; the adjoint weights
+// exp(t - out) = 2^((t - out) log2 e) are ratios and need no correction.
+#define VLG_LOG2E 1.44269504088896340736f
+#define VLG_LN2 0.69314718055994530942f
 
 namespace vlg {
 
@@ -117,7 +122,8 @@ struct DmvCtx {
 template <int SR>
 VLG_HD float adj_w(float g, float t, float out, int r, int bp) {
     if (SR == VLG_SR_MAX) return r == bp ? g : 0.f;
-    return g != 0.f ? g * VLG_EXP(t - out) : 0.f;
+    // t <= out up to rounding; the clamp also keeps a zero adjoint zero when `out` is a masked / sentinel cell
+    return g * VLG_EXP(fminf(t - out, 0.f));
 }
 
 // running max with first-index tie-break (torch.max semantics, semirings.py:199-200)
@@ -448,7 +454,7 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
         if (BWD) { c.gCc[i] = oo; c.gCi[i] = oo; c.gI[i] = oo; }
     }
     for (int i = tid; i < Ne * 8; i += nt) {
-        c.decs[i] = In::ld(dec, i);
+        c.decs[i] = In::ld(dec, i) * VLG_LOG2E;
         if (BWD) c.gdecs[i] = 0.f;
     }
     x.sync();
@@ -463,8 +469,8 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
             c.C[h * P + h + 1] = make_float2(d[5], d[7]);    // CR(h,h).v = dec[h,RIGHT,v,STOP]
         } else {
             const float2 a = In::ld2(attach, ((size_t)h * N + ch) * 2);
-            if (ch < h) c.I[h * P + ch] = make_float2(a.x + d[0], a.y + d[2]);
-            else c.I[h * P + ch + 1] = make_float2(a.x + d[4], a.y + d[6]);
+            if (ch < h) c.I[h * P + ch] = make_float2(fmaf(a.x, VLG_LOG2E, d[0]), fmaf(a.y, VLG_LOG2E, d[2]));
+            else c.I[h * P + ch + 1] = make_float2(fmaf(a.x, VLG_LOG2E, d[4]), fmaf(a.y, VLG_LOG2E, d[6]));
         }
     }
     x.sync();
@@ -473,7 +479,7 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
         dmv_fw<SR, BWD>(c, w, tid, nt, x);
         x.sync();
     }
-    if (tid == 0) *logZ = c.C[len + 1].y;   // CR(0,len).NOCHILD, dmv.py:65
+    if (tid == 0) *logZ = c.C[len + 1].y * VLG_LN2;   // CR(0,len).NOCHILD, dmv.py:65
     if (!BWD) return;
     // ---- outside: adjoint replay ------------------------------------------------------------------
     if (tid == 0) c.gCc[len + 1].y = glogZ;
@@ -524,7 +530,7 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
             c.C[h * P + h] = 0.f;        // semiring one, deptree.py:44
             c.C[h * P + h + 1] = 0.f;
         } else {
-            const float a = In::ld(arc, (size_t)h * N + ch);
+            const float a = In::ld(arc, (size_t)h * N + ch) * VLG_LOG2E;
             if (ch < h) c.I[h * P + ch] = a;
             else c.I[h * P + ch + 1] = a;
         }
@@ -534,7 +540,7 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
         dep_fw<SR, BWD>(c, w, tid, nt, x);
         x.sync();
     }
-    if (tid == 0) *logZ = c.C[len + 1];   // CR(0,len), deptree.py:74-75
+    if (tid == 0) *logZ = c.C[len + 1] * VLG_LN2;   // CR(0,len), deptree.py:74-75
     if (!BWD) return;
     if (tid == 0) c.gCc[len + 1] = glogZ;
     x.sync();
