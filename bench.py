@@ -98,9 +98,14 @@ def main():
     from vlgae_amd.torch_struct import functional as F
     import vlgae_amd.torch_struct as ts
 
-    rank, local_rank, world = vdist.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    # Debug aid for boxes with fewer GPUs than ranks (functional test of the N > 1 path only, never a
+    # measurement): VLGAE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo instead of RCCL.
+    share = os.environ.get("VLGAE_BENCH_SHARE_GPU") == "1"
+    rank, local_rank, world = vdist.init_from_env(backend="gloo" if share else None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = _C.lib()
@@ -201,7 +206,7 @@ def main():
                                f"B={B}/GPU L={L} N={N}, potentials stored {args.dtype}, fp32 charts; "
                                "BASELINE.json configs[1]" + (" sharded x%d, configs[2]" % world if world > 1 else ""),
                    "global_batch": B * world, "seq_len": L, "ragged": bool(args.ragged),
-                   "parallelism": f"dp{world}" if world > 1 else "single",
+                   "parallelism": (f"dp{world}" if world > 1 else "single") + (" (DEBUG: ranks share one GPU, gloo)" if share else ""),
                    "allreduce_floats": (max(n_grad, pad) if world > 1 else 0)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

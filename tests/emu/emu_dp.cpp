@@ -52,6 +52,7 @@ std::vector<int> make_order(int nt, int order) {
 // the group all-reduces go through a shared exchange buffer and replay the device's butterfly tree
 // (lane t combines with lane t^1, then t^2, ...) so that host and device results agree bit for bit.
 struct HostX {
+    static constexpr bool kSkipDeadWaves = false;   // here an all-reduce is a barrier: every lane takes part
     Token* tok;
     int nt, tid, rho;
     long phase = 0;

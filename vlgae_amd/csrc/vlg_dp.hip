@@ -67,6 +67,7 @@ __device__ __forceinline__ float dpp_add(float v) {
 }
 
 struct DevX {
+    static constexpr bool kSkipDeadWaves = true;   // the all-reduces are wave-local: a wave without spans can skip a phase
     __device__ __forceinline__ void sync() { __syncthreads(); }
 
     template <int K, int n>

@@ -92,13 +92,6 @@ struct BF16In {
 // chart pitch: odd and >= N + 1 so that row-strided (column) walks hit distinct LDS banks
 VLG_HOSTDEV int chart_pitch(int N) { return (N + 1) | 1; }
 
-// lanes per span at width w: the largest power of two G <= 64 with (spans * G <= nt) and G < 2w
-VLG_HD int group_size(int spans, int w, int nt) {
-    int G = 1;
-    while (G < 64 && G < w && spans * (G * 2) <= nt) G <<= 1;
-    return G;
-}
-
 // dec[h] is 8 floats [dir][val][decision]
 VLG_HD int dec_idx(int dir, int val, int z) { return (dir * 2 + val) * 2 + z; }
 
@@ -145,26 +138,69 @@ VLG_HD float fold_term(float m, float s, int am, float t, int rt, bool t_first, 
     return M + VLG_LOG(s * VLG_EXP(m - M) + VLG_EXP(t - M));
 }
 
+// lanes per span as a power of two: returns log2 G
+VLG_HD int group_log2(int spans, int w, int nt) {
+    int lg = 0;
+    while (lg < 6 && (1 << lg) < w && spans * (2 << lg) <= nt) ++lg;
+    return lg;
+}
+
 // ------------------------------------------------------------------------------------------------
-// DMV1o inside, width w: ONE phase.  X provides the group all-reduces (DPP on device).
+// DMV1o inside, width w, ONE span handled by a group of G = 2^lg lanes (this lane covers split points
+// r = rr, rr+G, ...).  TU > 0: exactly TU iterations per lane, the six terms of every iteration stay in
+// registers between the max pass and the sum pass (no LDS re-read, no branches: out-of-range r is
+// clamped for the loads and masked to the lowest float).  TU == 0: generic loops for long spans.
+// X provides the group all-reduces (fused DPP steps on device).
 // ------------------------------------------------------------------------------------------------
-template <int SR, bool BWD, typename X>
-VLG_HD void dmv_fw(const DmvCtx& c, int w, int tid, int nt, X& x) {
-    const int P = c.P, spans = c.Ne - w;
-    const int G = group_size(spans, w, nt), per = nt / G;
-    const int rr = tid & (G - 1), slot = tid / G;
-    for (int base = 0; base < spans; base += per) {
-        const bool live = base + slot < spans;
-        const int i = live ? base + slot : 0, j = i + w;   // dead lanes shadow span 0 and never store
-        const float2* cr = c.C + i * P + i + 1;      // CR(i, i+r)    at [r]
-        const float2* cl = c.C + j * P + i + 1;      // CL(j, i+r+1)  at [r]
-        const float2* ca = c.C + i * P + i;          // CL(i+r, i)    at [r*P]
-        const float2* il = c.I + j * P + i;          // IL(j, i+r)    at [r]
-        const float2* ir = c.I + i * P + i + 2;      // IR(i, i+1+r)  at [r]
-        const float2* cb = c.C + (i + 1) * P + j + 1;   // CR(i+1+r, j)  at [r*P]
-        // reductions: 0 SL, 1 SR, 2 CL.x, 3 CL.y (r >= 1), 4 CR.x, 5 CR.y (r <= w-2)
-        float m[6];
-        int am[6];
+template <int SR, bool BWD, int TU, typename X>
+VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr, X& x) {
+    const int P = c.P, j = i + w, G = 1 << lg;
+    const float2* cr = c.C + i * P + i + 1;      // CR(i, i+r)    at [r]
+    const float2* cl = c.C + j * P + i + 1;      // CL(j, i+r+1)  at [r]
+    const float2* ca = c.C + i * P + i;          // CL(i+r, i)    at [r*P]
+    const float2* il = c.I + j * P + i;          // IL(j, i+r)    at [r]
+    const float2* ir = c.I + i * P + i + 2;      // IR(i, i+1+r)  at [r]
+    const float2* cb = c.C + (i + 1) * P + j + 1;   // CR(i+1+r, j)  at [r*P]
+    // per-span constants first: their LDS latency hides under the reductions
+    const float2 aL = c.I[j * P + i], aR = c.I[i * P + j + 1];   // attach + dec[...,GO], staged at load
+    const float c0 = c.C[i * P + i].y;          // CL(i,i).NC : partner of the r = 0 term of CL(j,i)
+    const float c1 = c.C[j * P + j + 1].y;      // CR(j,j).NC : partner of the r = w-1 term of CR(i,j)
+    // reductions: 0 SL, 1 SR, 2 CL.x, 3 CL.y (r >= 1), 4 CR.x, 5 CR.y (r <= w-2)
+    float m[6], s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int am[6];
+    if (TU > 0) {
+        float t[TU > 0 ? TU : 1][6];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int r = rr + (u << lg), rc = r < w ? r : w - 1;
+            const float2 a = cr[rc], b = cl[rc], va = il[rc], vb = ir[rc];
+            const float ua = ca[rc * P].y, ub = cb[rc * P].y;
+            const bool v0 = r < w, v1 = v0 && r >= 1, v2 = r <= w - 2;
+            t[u][0] = v0 ? a.y + b.x : VLG_LOWEST;
+            t[u][1] = v0 ? a.x + b.y : VLG_LOWEST;
+            t[u][2] = v1 ? ua + va.x : VLG_LOWEST;
+            t[u][3] = v1 ? ua + va.y : VLG_LOWEST;
+            t[u][4] = v2 ? vb.x + ub : VLG_LOWEST;
+            t[u][5] = v2 ? vb.y + ub : VLG_LOWEST;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            m[k] = t[0][k];
+            am[k] = rr;
+#pragma unroll
+            for (int u = 1; u < TU; ++u)
+                if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + (u << lg); }   // strict: first index wins ties
+        }
+        if (SR == VLG_SR_MAX) x.template allreduce_argmax<6>(m, am, G);
+        else x.template allreduce_max<6>(m, G);
+        if (SR == VLG_SR_LOG) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int u = 0; u < TU; ++u) s[k] += VLG_EXP(t[u][k] - m[k]);   // masked terms: 2^(-3e38) = 0
+            x.template allreduce_sum<6>(s, G);
+        }
+    } else {
         for (int k = 0; k < 6; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
         for (int r = rr; r < w; r += G) {
             const float2 a = cr[r], b = cl[r];
@@ -185,7 +221,6 @@ VLG_HD void dmv_fw(const DmvCtx& c, int w, int tid, int nt, X& x) {
         }
         if (SR == VLG_SR_MAX) x.template allreduce_argmax<6>(m, am, G);
         else x.template allreduce_max<6>(m, G);
-        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (SR == VLG_SR_LOG) {
             for (int r = rr; r < w; r += G) {
                 const float2 a = cr[r], b = cl[r];
@@ -206,105 +241,130 @@ VLG_HD void dmv_fw(const DmvCtx& c, int w, int tid, int nt, X& x) {
             }
             x.template allreduce_sum<6>(s, G);
         }
-        const float SL = SR == VLG_SR_LOG ? m[0] + VLG_LOG(s[0]) : m[0];
-        const float SRv = SR == VLG_SR_LOG ? m[1] + VLG_LOG(s[1]) : m[1];
-        const float2 aL = c.I[j * P + i], aR = c.I[i * P + j + 1];   // attach + dec[...,GO], staged at load
-        const float2 ILn = make_float2(aL.x + SL, aL.y + SL);
-        const float2 IRn = make_float2(aR.x + SRv, aR.y + SRv);
-        const float c0 = c.C[i * P + i].y;          // CL(i,i).NC : partner of the r = 0 term of CL(j,i)
-        const float c1 = c.C[j * P + j + 1].y;      // CR(j,j).NC : partner of the r = w-1 term of CR(i,j)
-        int b0, b1, b2, b3;
-        float CLx = fold_term<SR>(m[2], s[2], am[2], c0 + ILn.x, 0, true, b0);
-        float CLy = fold_term<SR>(m[3], s[3], am[3], c0 + ILn.y, 0, true, b1);
-        float CRx = fold_term<SR>(m[4], s[4], am[4], IRn.x + c1, w - 1, false, b2);
-        float CRy = fold_term<SR>(m[5], s[5], am[5], IRn.y + c1, w - 1, false, b3);
-        if (i == 0 && w != c.len) { CRx = VLG_NEGINF; CRy = VLG_NEGINF; }   // single root, dmv.py:63
-        if (live && rr == 0) {
-            c.I[j * P + i] = ILn;
-            c.I[i * P + j + 1] = IRn;
-            c.C[j * P + i] = make_float2(CLx, CLy);
-            c.C[i * P + j + 1] = make_float2(CRx, CRy);
-            if (BWD) {
-                c.S[j * P + i] = SL;
-                c.S[i * P + j] = SRv;
-                if (SR == VLG_SR_MAX) {
-                    c.bpS[j * P + i] = (unsigned char)am[0];
-                    c.bpS[i * P + j] = (unsigned char)am[1];
-                    c.bpC[(j * P + i) * 2] = (unsigned char)b0;
-                    c.bpC[(j * P + i) * 2 + 1] = (unsigned char)b1;
-                    c.bpC[(i * P + j + 1) * 2] = (unsigned char)b2;
-                    c.bpC[(i * P + j + 1) * 2 + 1] = (unsigned char)b3;
-                }
+    }
+    const float SL = SR == VLG_SR_LOG ? m[0] + VLG_LOG(s[0]) : m[0];
+    const float SRv = SR == VLG_SR_LOG ? m[1] + VLG_LOG(s[1]) : m[1];
+    const float2 ILn = make_float2(aL.x + SL, aL.y + SL);
+    const float2 IRn = make_float2(aR.x + SRv, aR.y + SRv);
+    int b0, b1, b2, b3;
+    float CLx = fold_term<SR>(m[2], s[2], am[2], c0 + ILn.x, 0, true, b0);
+    float CLy = fold_term<SR>(m[3], s[3], am[3], c0 + ILn.y, 0, true, b1);
+    float CRx = fold_term<SR>(m[4], s[4], am[4], IRn.x + c1, w - 1, false, b2);
+    float CRy = fold_term<SR>(m[5], s[5], am[5], IRn.y + c1, w - 1, false, b3);
+    if (i == 0 && w != c.len) { CRx = VLG_NEGINF; CRy = VLG_NEGINF; }   // single root, dmv.py:63
+    if (live && rr == 0) {
+        c.I[j * P + i] = ILn;
+        c.I[i * P + j + 1] = IRn;
+        c.C[j * P + i] = make_float2(CLx, CLy);
+        c.C[i * P + j + 1] = make_float2(CRx, CRy);
+        if (BWD) {
+            c.S[j * P + i] = SL;
+            c.S[i * P + j] = SRv;
+            if (SR == VLG_SR_MAX) {
+                c.bpS[j * P + i] = (unsigned char)am[0];
+                c.bpS[i * P + j] = (unsigned char)am[1];
+                c.bpC[(j * P + i) * 2] = (unsigned char)b0;
+                c.bpC[(j * P + i) * 2 + 1] = (unsigned char)b1;
+                c.bpC[(i * P + j + 1) * 2] = (unsigned char)b2;
+                c.bpC[(i * P + j + 1) * 2 + 1] = (unsigned char)b3;
             }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// DMV1o outside, width w: ONE phase (complete spans of width w, then the incomplete spans of the
-// same width whose adjoint they complete).
-// ------------------------------------------------------------------------------------------------
-template <int SR, typename X>
-VLG_HD void dmv_bw(const DmvCtx& c, int w, int tid, int nt, X& x) {
-    const int P = c.P, spans = c.Ne - w;
-    const int G = group_size(spans, w, nt), per = nt / G;
-    const int rr = tid & (G - 1), slot = tid / G;
+template <int SR, bool BWD, typename X>
+VLG_HD void dmv_fw(const DmvCtx& c, int w, int tid, int nt, X& x) {
+    const int spans = c.Ne - w;
+    const int lg = group_log2(spans, w, nt), G = 1 << lg, per = nt >> lg;
+    const int rr = tid & (G - 1), slot = tid >> lg;
+    const int T = (w + G - 1) >> lg;   // split points per lane; uniform over the workgroup
     for (int base = 0; base < spans; base += per) {
         const bool live = base + slot < spans;
-        const int i = live ? base + slot : 0, j = i + w;
-        const int kL = j * P + i, kR = i * P + j + 1;          // CL(j,i) / IL(j,i) and CR(i,j) / IR(i,j) slots
-        float2 gcl = make_float2(0.f, 0.f), gcr = make_float2(0.f, 0.f);
-        if (live) {
-            const float2 a = c.gCc[kL], b = c.gCi[kL];
-            gcl = make_float2(a.x + b.x, a.y + b.y);
-            if (!(i == 0 && w != c.len)) {   // the masked cell was overwritten: no adjoint (dmv.py:63)
-                const float2 a2 = c.gCc[kR], b2 = c.gCi[kR];
-                gcr = make_float2(a2.x + b2.x, a2.y + b2.y);
-            }
+        const int i = live ? base + slot : 0;   // dead lanes shadow span 0 and never store
+        if (X::kSkipDeadWaves && (base + ((tid & ~63) >> lg)) >= spans) continue;   // whole wavefront past the last span
+        if (T == 1) dmv_fw_span<SR, BWD, 1>(c, w, lg, i, live, rr, x);
+        else if (T == 2) dmv_fw_span<SR, BWD, 2>(c, w, lg, i, live, rr, x);
+        else if (T == 3) dmv_fw_span<SR, BWD, 3>(c, w, lg, i, live, rr, x);
+        else if (T == 4) dmv_fw_span<SR, BWD, 4>(c, w, lg, i, live, rr, x);
+        else dmv_fw_span<SR, BWD, 0>(c, w, lg, i, live, rr, x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DMV1o outside, width w, ONE span (complete spans of width w, then the incomplete spans of the same
+// width whose adjoint they complete).  All loads -- including the read half of every read-modify-write
+// -- are issued before the first store, so nothing waits on an earlier store of the same phase.
+// ------------------------------------------------------------------------------------------------
+template <int SR, int TU, typename X>
+VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr, X& x) {
+    const int P = c.P, j = i + w, G = 1 << lg;
+    const int kL = j * P + i, kR = i * P + j + 1;          // CL(j,i) / IL(j,i) and CR(i,j) / IR(i,j) slots
+    float2 gcl = make_float2(0.f, 0.f), gcr = make_float2(0.f, 0.f);
+    {
+        const float2 a = c.gCc[kL], b = c.gCi[kL], a2 = c.gCc[kR], b2 = c.gCi[kR];
+        if (live) gcl = make_float2(a.x + b.x, a.y + b.y);
+        if (live && !(i == 0 && w != c.len)) gcr = make_float2(a2.x + b2.x, a2.y + b2.y);   // masked cell: dmv.py:63
+    }
+    const float2 ocl = c.C[kL], ocr = c.C[kR];
+    const float2 gil_old = c.gI[kL], gir_old = c.gI[kR];
+    const float SLv = c.S[j * P + i], SRv = c.S[i * P + j];
+    int bl0 = 0, bl1 = 0, br0 = 0, br1 = 0, bsl = 0, bsr = 0;
+    if (SR == VLG_SR_MAX) {
+        bl0 = c.bpC[kL * 2]; bl1 = c.bpC[kL * 2 + 1]; br0 = c.bpC[kR * 2]; br1 = c.bpC[kR * 2 + 1];
+        bsl = c.bpS[j * P + i]; bsr = c.bpS[i * P + j];
+    }
+    float self[4] = {0.f, 0.f, 0.f, 0.f};   // r = 0 share of gIL(j,i), r = w-1 share of gIR(i,j)
+    if (TU > 0) {
+        // value loads and the read halves of the RMWs, for every iteration of this lane
+        float2 va[TU > 0 ? TU : 1], vb[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1], xb[TU > 0 ? TU : 1];
+        float ua[TU > 0 ? TU : 1], ub[TU > 0 ? TU : 1];
+        float2 o_gil[TU > 0 ? TU : 1], o_gir[TU > 0 ? TU : 1], o_ga[TU > 0 ? TU : 1], o_gb[TU > 0 ? TU : 1];
+        float o_ca[TU > 0 ? TU : 1], o_cb[TU > 0 ? TU : 1];
+        float w0[TU > 0 ? TU : 1], w1[TU > 0 ? TU : 1], u0[TU > 0 ? TU : 1], u1[TU > 0 ? TU : 1];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int r = rr + (u << lg), rc = r < w ? r : w - 1;
+            ua[u] = c.C[(i + rc) * P + i].y;          // CL(i+r, i).NC
+            va[u] = c.I[kL + rc];                     // IL(j, i+r)
+            vb[u] = c.I[i * P + i + rc + 2];          // IR(i, i+1+r)
+            ub[u] = c.C[(i + 1 + rc) * P + j + 1].y;  // CR(i+1+r, j).NC
+            xa[u] = c.C[i * P + i + rc + 1];          // CR(i, i+r)
+            xb[u] = c.C[j * P + i + rc + 1];          // CL(j, i+r+1)
+            o_gil[u] = c.gI[kL + rc];
+            o_gir[u] = c.gI[i * P + i + rc + 2];
+            o_ca[u] = c.gCc[(i + rc) * P + i].y;
+            o_cb[u] = c.gCc[(i + 1 + rc) * P + j + 1].y;
+            o_ga[u] = c.gCi[i * P + i + rc + 1];
+            o_gb[u] = c.gCi[j * P + i + rc + 1];
         }
-        const float2 ocl = c.C[kL], ocr = c.C[kR];
-        const float2 gil_old = c.gI[kL], gir_old = c.gI[kR];
-        int bl0 = 0, bl1 = 0, br0 = 0, br1 = 0, bsl = 0, bsr = 0;
-        if (SR == VLG_SR_MAX) {
-            bl0 = c.bpC[kL * 2]; bl1 = c.bpC[kL * 2 + 1]; br0 = c.bpC[kR * 2]; br1 = c.bpC[kR * 2 + 1];
-            bsl = c.bpS[j * P + i]; bsr = c.bpS[i * P + j];
-        }
-        float self[4] = {0.f, 0.f, 0.f, 0.f};   // r = 0 share of gIL(j,i), r = w-1 share of gIR(i,j)
-        for (int r = rr; r < w; r += G) {
-            {   // CL(j,i).v = (+)_r CL(i+r,i).NC + IL(j,i+r).v
-                const float a = c.C[(i + r) * P + i].y;
-                const float2 v = c.I[kL + r];
-                const float w0 = adj_w<SR>(gcl.x, a + v.x, ocl.x, r, bl0);
-                const float w1 = adj_w<SR>(gcl.y, a + v.y, ocl.y, r, bl1);
-                if (r == 0) { self[0] = w0; self[1] = w1; }
-                else if (live) { const float2 t = c.gI[kL + r]; c.gI[kL + r] = make_float2(t.x + w0, t.y + w1); }
-                if (live) c.gCc[(i + r) * P + i].y += w0 + w1;
-            }
-            {   // CR(i,j).v = (+)_r IR(i,i+1+r).v + CR(i+1+r,j).NC
-                const float2 v = c.I[i * P + i + r + 2];
-                const float a = c.C[(i + 1 + r) * P + j + 1].y;
-                const float w0 = adj_w<SR>(gcr.x, v.x + a, ocr.x, r, br0);
-                const float w1 = adj_w<SR>(gcr.y, v.y + a, ocr.y, r, br1);
-                if (r == w - 1) { self[2] = w0; self[3] = w1; }
-                else if (live) { const float2 t = c.gI[i * P + i + r + 2]; c.gI[i * P + i + r + 2] = make_float2(t.x + w0, t.y + w1); }
-                if (live) c.gCc[(i + 1 + r) * P + j + 1].y += w0 + w1;
-            }
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int r = rr + (u << lg);
+            const bool ok = r < w;
+            // CL(j,i).v = (+)_r CL(i+r,i).NC + IL(j,i+r).v ;  CR(i,j).v = (+)_r IR(i,i+1+r).v + CR(i+1+r,j).NC
+            w0[u] = ok ? adj_w<SR>(gcl.x, ua[u] + va[u].x, ocl.x, r, bl0) : 0.f;
+            w1[u] = ok ? adj_w<SR>(gcl.y, ua[u] + va[u].y, ocl.y, r, bl1) : 0.f;
+            u0[u] = ok ? adj_w<SR>(gcr.x, vb[u].x + ub[u], ocr.x, r, br0) : 0.f;
+            u1[u] = ok ? adj_w<SR>(gcr.y, vb[u].y + ub[u], ocr.y, r, br1) : 0.f;
+            if (r == 0) { self[0] = w0[u]; self[1] = w1[u]; }
+            if (r == w - 1) { self[2] = u0[u]; self[3] = u1[u]; }
         }
         x.template allreduce_sum<4>(self, G);   // one lane holds each value: this is a broadcast
         const float2 gil = make_float2(gil_old.x + self[0], gil_old.y + self[1]);   // complete adjoint of IL(j,i)
         const float2 gir = make_float2(gir_old.x + self[2], gir_old.y + self[3]);
         const float gsl = gil.x + gil.y, gsr = gir.x + gir.y;
-        const float SLv = c.S[j * P + i], SRv = c.S[i * P + j];
-        for (int r = rr; r < w; r += G) {
-            const float2 a = c.C[i * P + i + r + 1];  // CR(i, i+r)
-            const float2 b = c.C[j * P + i + r + 1];  // CL(j, i+r+1)
-            const float wl = adj_w<SR>(gsl, a.y + b.x, SLv, r, bsl);   // SL term: CR.NC + CL.HC
-            const float wr = adj_w<SR>(gsr, a.x + b.y, SRv, r, bsr);   // SR term: CR.HC + CL.NC
-            if (live) {
-                float2 t = c.gCi[i * P + i + r + 1];
-                c.gCi[i * P + i + r + 1] = make_float2(t.x + wr, t.y + wl);
-                t = c.gCi[j * P + i + r + 1];
-                c.gCi[j * P + i + r + 1] = make_float2(t.x + wl, t.y + wr);
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int r = rr + (u << lg);
+            if (live && r < w) {
+                const float wl = adj_w<SR>(gsl, xa[u].y + xb[u].x, SLv, r, bsl);   // SL term: CR.NC + CL.HC
+                const float wr = adj_w<SR>(gsr, xa[u].x + xb[u].y, SRv, r, bsr);   // SR term: CR.HC + CL.NC
+                if (r != 0) c.gI[kL + r] = make_float2(o_gil[u].x + w0[u], o_gil[u].y + w1[u]);
+                if (r != w - 1) c.gI[i * P + i + r + 2] = make_float2(o_gir[u].x + u0[u], o_gir[u].y + u1[u]);
+                c.gCc[(i + r) * P + i].y = o_ca[u] + (w0[u] + w1[u]);
+                c.gCc[(i + 1 + r) * P + j + 1].y = o_cb[u] + (u0[u] + u1[u]);
+                c.gCi[i * P + i + r + 1] = make_float2(o_ga[u].x + wr, o_ga[u].y + wl);
+                c.gCi[j * P + i + r + 1] = make_float2(o_gb[u].x + wl, o_gb[u].y + wr);
             }
         }
         if (live && rr == 0) {
@@ -315,6 +375,69 @@ VLG_HD void dmv_bw(const DmvCtx& c, int w, int tid, int nt, X& x) {
             c.gdecs[i * 8 + dec_idx(1, 0, 0)] += gir.x;
             c.gdecs[i * 8 + dec_idx(1, 1, 0)] += gir.y;
         }
+        return;
+    }
+    for (int r = rr; r < w; r += G) {
+        {   // CL(j,i).v = (+)_r CL(i+r,i).NC + IL(j,i+r).v
+            const float a = c.C[(i + r) * P + i].y;
+            const float2 v = c.I[kL + r];
+            const float w0 = adj_w<SR>(gcl.x, a + v.x, ocl.x, r, bl0);
+            const float w1 = adj_w<SR>(gcl.y, a + v.y, ocl.y, r, bl1);
+            if (r == 0) { self[0] = w0; self[1] = w1; }
+            else if (live) { const float2 t = c.gI[kL + r]; c.gI[kL + r] = make_float2(t.x + w0, t.y + w1); }
+            if (live) c.gCc[(i + r) * P + i].y += w0 + w1;
+        }
+        {   // CR(i,j).v = (+)_r IR(i,i+1+r).v + CR(i+1+r,j).NC
+            const float2 v = c.I[i * P + i + r + 2];
+            const float a = c.C[(i + 1 + r) * P + j + 1].y;
+            const float w0 = adj_w<SR>(gcr.x, v.x + a, ocr.x, r, br0);
+            const float w1 = adj_w<SR>(gcr.y, v.y + a, ocr.y, r, br1);
+            if (r == w - 1) { self[2] = w0; self[3] = w1; }
+            else if (live) { const float2 t = c.gI[i * P + i + r + 2]; c.gI[i * P + i + r + 2] = make_float2(t.x + w0, t.y + w1); }
+            if (live) c.gCc[(i + 1 + r) * P + j + 1].y += w0 + w1;
+        }
+    }
+    x.template allreduce_sum<4>(self, G);
+    const float2 gil = make_float2(gil_old.x + self[0], gil_old.y + self[1]);
+    const float2 gir = make_float2(gir_old.x + self[2], gir_old.y + self[3]);
+    const float gsl = gil.x + gil.y, gsr = gir.x + gir.y;
+    for (int r = rr; r < w; r += G) {
+        const float2 a = c.C[i * P + i + r + 1];  // CR(i, i+r)
+        const float2 b = c.C[j * P + i + r + 1];  // CL(j, i+r+1)
+        const float wl = adj_w<SR>(gsl, a.y + b.x, SLv, r, bsl);
+        const float wr = adj_w<SR>(gsr, a.x + b.y, SRv, r, bsr);
+        if (live) {
+            float2 t = c.gCi[i * P + i + r + 1];
+            c.gCi[i * P + i + r + 1] = make_float2(t.x + wr, t.y + wl);
+            t = c.gCi[j * P + i + r + 1];
+            c.gCi[j * P + i + r + 1] = make_float2(t.x + wl, t.y + wr);
+        }
+    }
+    if (live && rr == 0) {
+        c.gI[kL] = gil;
+        c.gI[kR] = gir;
+        c.gdecs[j * 8 + dec_idx(0, 0, 0)] += gil.x;
+        c.gdecs[j * 8 + dec_idx(0, 1, 0)] += gil.y;
+        c.gdecs[i * 8 + dec_idx(1, 0, 0)] += gir.x;
+        c.gdecs[i * 8 + dec_idx(1, 1, 0)] += gir.y;
+    }
+}
+
+template <int SR, typename X>
+VLG_HD void dmv_bw(const DmvCtx& c, int w, int tid, int nt, X& x) {
+    const int spans = c.Ne - w;
+    const int lg = group_log2(spans, w, nt), G = 1 << lg, per = nt >> lg;
+    const int rr = tid & (G - 1), slot = tid >> lg;
+    const int T = (w + G - 1) >> lg;
+    for (int base = 0; base < spans; base += per) {
+        const bool live = base + slot < spans;
+        const int i = live ? base + slot : 0;
+        if (X::kSkipDeadWaves && (base + ((tid & ~63) >> lg)) >= spans) continue;
+        // (register-resident iterations are capped at 2 here: each one holds 12 loads + 4 weights, and a third
+        //  would push the kernel past 128 VGPRs = one 512-lane workgroup per CU instead of two)
+        if (T == 1) dmv_bw_span<SR, 1>(c, w, lg, i, live, rr, x);
+        else if (T == 2) dmv_bw_span<SR, 2>(c, w, lg, i, live, rr, x);
+        else dmv_bw_span<SR, 0>(c, w, lg, i, live, rr, x);
     }
 }
 
@@ -335,22 +458,47 @@ struct DepCtx {
     unsigned char* bpC;
 };
 
-template <int SR, bool BWD, typename X>
-VLG_HD void dep_fw(const DepCtx& c, int w, int tid, int nt, X& x) {
-    const int P = c.P, spans = c.Ne - w;
-    const int G = group_size(spans, w, nt), per = nt / G;
-    const int rr = tid & (G - 1), slot = tid / G;
-    for (int base = 0; base < spans; base += per) {
-        const bool live = base + slot < spans;
-        const int i = live ? base + slot : 0, j = i + w;
-        const float* cr = c.C + i * P + i + 1;
-        const float* cl = c.C + j * P + i + 1;
-        const float* ca = c.C + i * P + i;
-        const float* il = c.I + j * P + i;
-        const float* ir = c.I + i * P + i + 2;
-        const float* cb = c.C + (i + 1) * P + j + 1;
-        float m[3];
-        int am[3];
+template <int SR, bool BWD, int TU, typename X>
+VLG_HD void dep_fw_span(const DepCtx& c, int w, int lg, int i, bool live, int rr, X& x) {
+    const int P = c.P, j = i + w, G = 1 << lg;
+    const float* cr = c.C + i * P + i + 1;
+    const float* cl = c.C + j * P + i + 1;
+    const float* ca = c.C + i * P + i;
+    const float* il = c.I + j * P + i;
+    const float* ir = c.I + i * P + i + 2;
+    const float* cb = c.C + (i + 1) * P + j + 1;
+    const float aL = c.I[j * P + i], aR = c.I[i * P + j + 1];   // arc scores, staged at load
+    const float c0 = c.C[i * P + i], c1 = c.C[j * P + j + 1];
+    float m[3], s[3] = {0.f, 0.f, 0.f};
+    int am[3];
+    if (TU > 0) {
+        float t[TU > 0 ? TU : 1][3];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int r = rr + (u << lg), rc = r < w ? r : w - 1;
+            const float a = cr[rc], b = cl[rc], ua = ca[rc * P], va = il[rc], vb = ir[rc], ub = cb[rc * P];
+            t[u][0] = r < w ? a + b : VLG_LOWEST;
+            t[u][1] = (r < w && r >= 1) ? ua + va : VLG_LOWEST;
+            t[u][2] = r <= w - 2 ? vb + ub : VLG_LOWEST;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            m[k] = t[0][k];
+            am[k] = rr;
+#pragma unroll
+            for (int u = 1; u < TU; ++u)
+                if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + (u << lg); }
+        }
+        if (SR == VLG_SR_MAX) x.template allreduce_argmax<3>(m, am, G);
+        else x.template allreduce_max<3>(m, G);
+        if (SR == VLG_SR_LOG) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int u = 0; u < TU; ++u) s[k] += VLG_EXP(t[u][k] - m[k]);
+            x.template allreduce_sum<3>(s, G);
+        }
+    } else {
         for (int k = 0; k < 3; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
         for (int r = rr; r < w; r += G) {
             upd_max(m[0], am[0], cr[r] + cl[r], r);
@@ -359,7 +507,6 @@ VLG_HD void dep_fw(const DepCtx& c, int w, int tid, int nt, X& x) {
         }
         if (SR == VLG_SR_MAX) x.template allreduce_argmax<3>(m, am, G);
         else x.template allreduce_max<3>(m, G);
-        float s[3] = {0.f, 0.f, 0.f};
         if (SR == VLG_SR_LOG) {
             for (int r = rr; r < w; r += G) {
                 s[0] += VLG_EXP(cr[r] + cl[r] - m[0]);
@@ -368,72 +515,155 @@ VLG_HD void dep_fw(const DepCtx& c, int w, int tid, int nt, X& x) {
             }
             x.template allreduce_sum<3>(s, G);
         }
-        const float T = SR == VLG_SR_LOG ? m[0] + VLG_LOG(s[0]) : m[0];
-        const float ILn = c.I[j * P + i] + T, IRn = c.I[i * P + j + 1] + T;   // deptree.py:58,62
-        int b0, b1;
-        const float CLv = fold_term<SR>(m[1], s[1], am[1], c.C[i * P + i] + ILn, 0, true, b0);
-        float CRv = fold_term<SR>(m[2], s[2], am[2], IRn + c.C[j * P + j + 1], w - 1, false, b1);
-        if (i == 0 && w != c.len) CRv = VLG_NEGINF;   // deptree.py:71-72
-        if (live && rr == 0) {
-            c.I[j * P + i] = ILn;
-            c.I[i * P + j + 1] = IRn;
-            c.C[j * P + i] = CLv;
-            c.C[i * P + j + 1] = CRv;
-            if (BWD) {
-                c.S[i * P + j] = T;
-                if (SR == VLG_SR_MAX) {
-                    c.bpS[i * P + j] = (unsigned char)am[0];
-                    c.bpC[j * P + i] = (unsigned char)b0;
-                    c.bpC[i * P + j + 1] = (unsigned char)b1;
-                }
+    }
+    const float T = SR == VLG_SR_LOG ? m[0] + VLG_LOG(s[0]) : m[0];
+    const float ILn = aL + T, IRn = aR + T;   // deptree.py:58,62
+    int b0, b1;
+    const float CLv = fold_term<SR>(m[1], s[1], am[1], c0 + ILn, 0, true, b0);
+    float CRv = fold_term<SR>(m[2], s[2], am[2], IRn + c1, w - 1, false, b1);
+    if (i == 0 && w != c.len) CRv = VLG_NEGINF;   // deptree.py:71-72
+    if (live && rr == 0) {
+        c.I[j * P + i] = ILn;
+        c.I[i * P + j + 1] = IRn;
+        c.C[j * P + i] = CLv;
+        c.C[i * P + j + 1] = CRv;
+        if (BWD) {
+            c.S[i * P + j] = T;
+            if (SR == VLG_SR_MAX) {
+                c.bpS[i * P + j] = (unsigned char)am[0];
+                c.bpC[j * P + i] = (unsigned char)b0;
+                c.bpC[i * P + j + 1] = (unsigned char)b1;
             }
         }
     }
 }
 
-template <int SR, typename X>
-VLG_HD void dep_bw(const DepCtx& c, int w, int tid, int nt, X& x) {
-    const int P = c.P, spans = c.Ne - w;
-    const int G = group_size(spans, w, nt), per = nt / G;
-    const int rr = tid & (G - 1), slot = tid / G;
+template <int SR, bool BWD, typename X>
+VLG_HD void dep_fw(const DepCtx& c, int w, int tid, int nt, X& x) {
+    const int spans = c.Ne - w;
+    const int lg = group_log2(spans, w, nt), G = 1 << lg, per = nt >> lg;
+    const int rr = tid & (G - 1), slot = tid >> lg;
+    const int T = (w + G - 1) >> lg;
     for (int base = 0; base < spans; base += per) {
         const bool live = base + slot < spans;
-        const int i = live ? base + slot : 0, j = i + w;
-        const int kL = j * P + i, kR = i * P + j + 1;
-        float gl = 0.f, gr = 0.f;
-        if (live) {
-            gl = c.gCc[kL] + c.gCi[kL];
-            if (!(i == 0 && w != c.len)) gr = c.gCc[kR] + c.gCi[kR];
+        const int i = live ? base + slot : 0;
+        if (X::kSkipDeadWaves && (base + ((tid & ~63) >> lg)) >= spans) continue;
+        if (T == 1) dep_fw_span<SR, BWD, 1>(c, w, lg, i, live, rr, x);
+        else if (T == 2) dep_fw_span<SR, BWD, 2>(c, w, lg, i, live, rr, x);
+        else if (T == 3) dep_fw_span<SR, BWD, 3>(c, w, lg, i, live, rr, x);
+        else if (T == 4) dep_fw_span<SR, BWD, 4>(c, w, lg, i, live, rr, x);
+        else dep_fw_span<SR, BWD, 0>(c, w, lg, i, live, rr, x);
+    }
+}
+
+template <int SR, int TU, typename X>
+VLG_HD void dep_bw_span(const DepCtx& c, int w, int lg, int i, bool live, int rr, X& x) {
+    const int P = c.P, j = i + w, G = 1 << lg;
+    const int kL = j * P + i, kR = i * P + j + 1;
+    float gl = 0.f, gr = 0.f;
+    {
+        const float a = c.gCc[kL], b = c.gCi[kL], a2 = c.gCc[kR], b2 = c.gCi[kR];
+        if (live) gl = a + b;
+        if (live && !(i == 0 && w != c.len)) gr = a2 + b2;
+    }
+    const float ol = c.C[kL], orr = c.C[kR];
+    const float gil_old = c.gI[kL], gir_old = c.gI[kR];
+    const float Tv = c.S[i * P + j];
+    int bl = 0, br = 0, bs = 0;
+    if (SR == VLG_SR_MAX) { bl = c.bpC[kL]; br = c.bpC[kR]; bs = c.bpS[i * P + j]; }
+    float self[2] = {0.f, 0.f};
+    if (TU > 0) {
+        float ua[TU > 0 ? TU : 1], va[TU > 0 ? TU : 1], vb[TU > 0 ? TU : 1], ub[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1],
+            xb[TU > 0 ? TU : 1];
+        float o_gil[TU > 0 ? TU : 1], o_gir[TU > 0 ? TU : 1], o_ca[TU > 0 ? TU : 1], o_cb[TU > 0 ? TU : 1],
+            o_ga[TU > 0 ? TU : 1], o_gb[TU > 0 ? TU : 1], wl[TU > 0 ? TU : 1], wr[TU > 0 ? TU : 1];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int r = rr + (u << lg), rc = r < w ? r : w - 1;
+            ua[u] = c.C[(i + rc) * P + i];
+            va[u] = c.I[kL + rc];
+            vb[u] = c.I[i * P + i + rc + 2];
+            ub[u] = c.C[(i + 1 + rc) * P + j + 1];
+            xa[u] = c.C[i * P + i + rc + 1];
+            xb[u] = c.C[j * P + i + rc + 1];
+            o_gil[u] = c.gI[kL + rc];
+            o_gir[u] = c.gI[i * P + i + rc + 2];
+            o_ca[u] = c.gCc[(i + rc) * P + i];
+            o_cb[u] = c.gCc[(i + 1 + rc) * P + j + 1];
+            o_ga[u] = c.gCi[i * P + i + rc + 1];
+            o_gb[u] = c.gCi[j * P + i + rc + 1];
         }
-        const float ol = c.C[kL], orr = c.C[kR];
-        const float gil_old = c.gI[kL], gir_old = c.gI[kR];
-        int bl = 0, br = 0, bs = 0;
-        if (SR == VLG_SR_MAX) { bl = c.bpC[kL]; br = c.bpC[kR]; bs = c.bpS[i * P + j]; }
-        float self[2] = {0.f, 0.f};
-        for (int r = rr; r < w; r += G) {
-            const float wl = adj_w<SR>(gl, c.C[(i + r) * P + i] + c.I[kL + r], ol, r, bl);
-            if (r == 0) self[0] = wl;
-            else if (live) c.gI[kL + r] += wl;
-            if (live) c.gCc[(i + r) * P + i] += wl;
-            const float wr = adj_w<SR>(gr, c.I[i * P + i + r + 2] + c.C[(i + 1 + r) * P + j + 1], orr, r, br);
-            if (r == w - 1) self[1] = wr;
-            else if (live) c.gI[i * P + i + r + 2] += wr;
-            if (live) c.gCc[(i + 1 + r) * P + j + 1] += wr;
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int r = rr + (u << lg);
+            const bool ok = r < w;
+            wl[u] = ok ? adj_w<SR>(gl, ua[u] + va[u], ol, r, bl) : 0.f;
+            wr[u] = ok ? adj_w<SR>(gr, vb[u] + ub[u], orr, r, br) : 0.f;
+            if (r == 0) self[0] = wl[u];
+            if (r == w - 1) self[1] = wr[u];
         }
         x.template allreduce_sum<2>(self, G);
-        const float gil = gil_old + self[0], gir = gir_old + self[1];
-        const float gs = gil + gir, Tv = c.S[i * P + j];
-        for (int r = rr; r < w; r += G) {
-            const float wt = adj_w<SR>(gs, c.C[i * P + i + r + 1] + c.C[j * P + i + r + 1], Tv, r, bs);
-            if (live) {
-                c.gCi[i * P + i + r + 1] += wt;
-                c.gCi[j * P + i + r + 1] += wt;
+        const float gil = gil_old + self[0], gir = gir_old + self[1], gs = gil + gir;
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int r = rr + (u << lg);
+            if (live && r < w) {
+                const float wt = adj_w<SR>(gs, xa[u] + xb[u], Tv, r, bs);
+                if (r != 0) c.gI[kL + r] = o_gil[u] + wl[u];
+                if (r != w - 1) c.gI[i * P + i + r + 2] = o_gir[u] + wr[u];
+                c.gCc[(i + r) * P + i] = o_ca[u] + wl[u];
+                c.gCc[(i + 1 + r) * P + j + 1] = o_cb[u] + wr[u];
+                c.gCi[i * P + i + r + 1] = o_ga[u] + wt;
+                c.gCi[j * P + i + r + 1] = o_gb[u] + wt;
             }
         }
         if (live && rr == 0) {
             c.gI[kL] = gil;   // == d logZ / d arc[j,i]
             c.gI[kR] = gir;
         }
+        return;
+    }
+    for (int r = rr; r < w; r += G) {
+        const float wl = adj_w<SR>(gl, c.C[(i + r) * P + i] + c.I[kL + r], ol, r, bl);
+        if (r == 0) self[0] = wl;
+        else if (live) c.gI[kL + r] += wl;
+        if (live) c.gCc[(i + r) * P + i] += wl;
+        const float wr = adj_w<SR>(gr, c.I[i * P + i + r + 2] + c.C[(i + 1 + r) * P + j + 1], orr, r, br);
+        if (r == w - 1) self[1] = wr;
+        else if (live) c.gI[i * P + i + r + 2] += wr;
+        if (live) c.gCc[(i + 1 + r) * P + j + 1] += wr;
+    }
+    x.template allreduce_sum<2>(self, G);
+    const float gil = gil_old + self[0], gir = gir_old + self[1];
+    const float gs = gil + gir;
+    for (int r = rr; r < w; r += G) {
+        const float wt = adj_w<SR>(gs, c.C[i * P + i + r + 1] + c.C[j * P + i + r + 1], Tv, r, bs);
+        if (live) {
+            c.gCi[i * P + i + r + 1] += wt;
+            c.gCi[j * P + i + r + 1] += wt;
+        }
+    }
+    if (live && rr == 0) {
+        c.gI[kL] = gil;
+        c.gI[kR] = gir;
+    }
+}
+
+template <int SR, typename X>
+VLG_HD void dep_bw(const DepCtx& c, int w, int tid, int nt, X& x) {
+    const int spans = c.Ne - w;
+    const int lg = group_log2(spans, w, nt), G = 1 << lg, per = nt >> lg;
+    const int rr = tid & (G - 1), slot = tid >> lg;
+    const int T = (w + G - 1) >> lg;
+    for (int base = 0; base < spans; base += per) {
+        const bool live = base + slot < spans;
+        const int i = live ? base + slot : 0;
+        if (X::kSkipDeadWaves && (base + ((tid & ~63) >> lg)) >= spans) continue;
+        if (T == 1) dep_bw_span<SR, 1>(c, w, lg, i, live, rr, x);
+        else if (T == 2) dep_bw_span<SR, 2>(c, w, lg, i, live, rr, x);
+        else if (T == 3) dep_bw_span<SR, 3>(c, w, lg, i, live, rr, x);
+        else if (T == 4) dep_bw_span<SR, 4>(c, w, lg, i, live, rr, x);
+        else dep_bw_span<SR, 0>(c, w, lg, i, live, rr, x);
     }
 }
 
