@@ -66,6 +66,16 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v;
 }
 
+template <int K>
+__device__ __forceinline__ int dpp_min_i(int v) {
+    if (K == 1) asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " VLG_DPP_QP1 : "+v"(v));
+    else if (K == 2) asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " VLG_DPP_QP2 : "+v"(v));
+    else if (K == 4) asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " VLG_DPP_HM : "+v"(v));
+    else if (K == 8) asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " VLG_DPP_RM : "+v"(v));
+    else v = min(v, xlane_i<K>(v));
+    return v;
+}
+
 struct DevX {
     static constexpr bool kSkipDeadWaves = true;   // the all-reduces are wave-local: a wave without spans can skip a phase
     __device__ __forceinline__ void sync() { __syncthreads(); }
@@ -81,15 +91,9 @@ struct DevX {
         for (int k = 0; k < n; ++k) v[k] = dpp_add<K>(v[k]);
     }
     template <int K, int n>
-    __device__ __forceinline__ void step_argmax(float* v, int* a) {
+    __device__ __forceinline__ void step_min_i(int* a) {
 #pragma unroll
-        for (int k = 0; k < n; ++k) {
-            const float pv = xlane<K>(v[k]);
-            const int pa = xlane_i<K>(a[k]);
-            const bool take = pv > v[k] || (pv == v[k] && pa < a[k]);   // first arg-max wins ties
-            v[k] = take ? pv : v[k];
-            a[k] = take ? pa : a[k];
-        }
+        for (int k = 0; k < n; ++k) a[k] = dpp_min_i<K>(a[k]);
     }
     // G is uniform over the workgroup, so these branches never diverge
     template <int n>
@@ -110,14 +114,22 @@ struct DevX {
         if (G > 16) step_sum<16, n>(v);
         if (G > 32) step_sum<32, n>(v);
     }
+    // arg-max with torch.max's tie-break (first index): all-reduce the values, then the SMALLEST index among
+    // the lanes that hold the maximum -- two fused-DPP butterflies instead of a (value, index) pair exchange
     template <int n>
     __device__ __forceinline__ void allreduce_argmax(float* v, int* a, int G) {
-        if (G > 1) step_argmax<1, n>(v, a);
-        if (G > 2) step_argmax<2, n>(v, a);
-        if (G > 4) step_argmax<4, n>(v, a);
-        if (G > 8) step_argmax<8, n>(v, a);
-        if (G > 16) step_argmax<16, n>(v, a);
-        if (G > 32) step_argmax<32, n>(v, a);
+        float own[n];
+#pragma unroll
+        for (int k = 0; k < n; ++k) own[k] = v[k];
+        allreduce_max<n>(v, G);
+#pragma unroll
+        for (int k = 0; k < n; ++k) a[k] = own[k] == v[k] ? a[k] : 0x7fffffff;
+        if (G > 1) step_min_i<1, n>(a);
+        if (G > 2) step_min_i<2, n>(a);
+        if (G > 4) step_min_i<4, n>(a);
+        if (G > 8) step_min_i<8, n>(a);
+        if (G > 16) step_min_i<16, n>(a);
+        if (G > 32) step_min_i<32, n>(a);
     }
 };
 
