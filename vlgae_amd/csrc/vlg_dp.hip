@@ -40,96 +40,106 @@ template <int K>
 __device__ __forceinline__ float xlane(float v) { return __int_as_float(xlane_i<K>(__float_as_int(v))); }
 
 // Fused DPP reduction steps: dst = op(dst, lane-permuted dst) in ONE instruction per value.  hipcc does not
-// fold v_mov_b32_dpp into the consuming VALU op here, so the steps are written as inline asm; the leading
-// s_nop covers the "VALU write -> DPP read" wait states that the assembler does not insert for asm blocks.
+// fold v_mov_b32_dpp into the consuming VALU op here, so a whole butterfly step (all n values) is one inline
+// asm block; its leading s_nop covers the "VALU write -> DPP read" wait states that the assembler does not
+// insert for asm.  Steps 16 and 32 use gfx950's v_permlane16_swap / v_permlane32_swap: with both operands
+// holding x, the two results are (own, partner) in some order on every lane, so op(r0, r1) is the step --
+// no LDS round trip (ds_swizzle / ds_bpermute cost a full LDS latency per value).
 #define VLG_DPP_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
 #define VLG_DPP_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
 #define VLG_DPP_HM "row_half_mirror row_mask:0xf bank_mask:0xf"
 #define VLG_DPP_RM "row_mirror row_mask:0xf bank_mask:0xf"
+#define VLG_DPP1(OP, C) "\n\t" OP " %0, %0, %0 " C
+#define VLG_DPP2(OP, C) VLG_DPP1(OP, C) "\n\t" OP " %1, %1, %1 " C
+#define VLG_DPP3(OP, C) VLG_DPP2(OP, C) "\n\t" OP " %2, %2, %2 " C
+#define VLG_DPP4(OP, C) VLG_DPP3(OP, C) "\n\t" OP " %3, %3, %3 " C
+#define VLG_DPP6(OP, C) VLG_DPP4(OP, C) "\n\t" OP " %4, %4, %4 " C "\n\t" OP " %5, %5, %5 " C
 
-template <int K>
-__device__ __forceinline__ float dpp_max(float v) {
-    if (K == 1) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " VLG_DPP_QP1 : "+v"(v));
-    else if (K == 2) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " VLG_DPP_QP2 : "+v"(v));
-    else if (K == 4) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " VLG_DPP_HM : "+v"(v));
-    else if (K == 8) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " VLG_DPP_RM : "+v"(v));
-    else v = fmaxf(v, xlane<K>(v));
-    return v;
-}
-template <int K>
-__device__ __forceinline__ float dpp_add(float v) {
-    if (K == 1) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " VLG_DPP_QP1 : "+v"(v));
-    else if (K == 2) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " VLG_DPP_QP2 : "+v"(v));
-    else if (K == 4) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " VLG_DPP_HM : "+v"(v));
-    else if (K == 8) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " VLG_DPP_RM : "+v"(v));
-    else v += xlane<K>(v);
-    return v;
+// one butterfly step over n registers of type T with DPP control string C
+#define VLG_DPP_STEP(OP, C, v, n)                                                                                    \
+    do {                                                                                                             \
+        if constexpr ((n) == 6) asm("s_nop 1" VLG_DPP6(OP, C) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])); \
+        else if constexpr ((n) == 4) asm("s_nop 1" VLG_DPP4(OP, C) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); \
+        else if constexpr ((n) == 3) asm("s_nop 1" VLG_DPP3(OP, C) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));          \
+        else if constexpr ((n) == 2) asm("s_nop 1" VLG_DPP2(OP, C) : "+v"(v[0]), "+v"(v[1]));                       \
+        else {                                                                                                       \
+            _Pragma("unroll") for (int k = 0; k < (n); ++k) asm("s_nop 1" VLG_DPP1(OP, C) : "+v"(v[k]));           \
+        }                                                                                                            \
+    } while (0)
+
+enum { kOpMax = 0, kOpAdd = 1, kOpMinI = 2 };
+
+template <int OPK, int K, int n, typename T>
+__device__ __forceinline__ void butterfly_step(T* v) {
+    if constexpr (K <= 8) {
+        if constexpr (OPK == kOpMax) {
+            if constexpr (K == 1) VLG_DPP_STEP("v_max_f32_dpp", VLG_DPP_QP1, v, n);
+            else if constexpr (K == 2) VLG_DPP_STEP("v_max_f32_dpp", VLG_DPP_QP2, v, n);
+            else if constexpr (K == 4) VLG_DPP_STEP("v_max_f32_dpp", VLG_DPP_HM, v, n);
+            else VLG_DPP_STEP("v_max_f32_dpp", VLG_DPP_RM, v, n);
+        } else if constexpr (OPK == kOpAdd) {
+            if constexpr (K == 1) VLG_DPP_STEP("v_add_f32_dpp", VLG_DPP_QP1, v, n);
+            else if constexpr (K == 2) VLG_DPP_STEP("v_add_f32_dpp", VLG_DPP_QP2, v, n);
+            else if constexpr (K == 4) VLG_DPP_STEP("v_add_f32_dpp", VLG_DPP_HM, v, n);
+            else VLG_DPP_STEP("v_add_f32_dpp", VLG_DPP_RM, v, n);
+        } else {
+            if constexpr (K == 1) VLG_DPP_STEP("v_min_i32_dpp", VLG_DPP_QP1, v, n);
+            else if constexpr (K == 2) VLG_DPP_STEP("v_min_i32_dpp", VLG_DPP_QP2, v, n);
+            else if constexpr (K == 4) VLG_DPP_STEP("v_min_i32_dpp", VLG_DPP_HM, v, n);
+            else VLG_DPP_STEP("v_min_i32_dpp", VLG_DPP_RM, v, n);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            unsigned u;
+            if constexpr (sizeof(T) == 4 && OPK == kOpMinI) u = (unsigned)v[k];
+            else u = __float_as_uint((float)v[k]);
+            const auto r = K == 16 ? __builtin_amdgcn_permlane16_swap(u, u, false, false)
+                                   : __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            if constexpr (OPK == kOpMax) v[k] = (T)fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            else if constexpr (OPK == kOpAdd) v[k] = (T)(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+            else v[k] = (T)min((int)r[0], (int)r[1]);
+        }
+    }
 }
 
-template <int K>
-__device__ __forceinline__ int dpp_min_i(int v) {
-    if (K == 1) asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " VLG_DPP_QP1 : "+v"(v));
-    else if (K == 2) asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " VLG_DPP_QP2 : "+v"(v));
-    else if (K == 4) asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " VLG_DPP_HM : "+v"(v));
-    else if (K == 8) asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " VLG_DPP_RM : "+v"(v));
-    else v = min(v, xlane_i<K>(v));
-    return v;
+template <int OPK, int n, typename T>
+__device__ __forceinline__ void butterfly(T* v, int G) {   // G is uniform over the workgroup: no divergence
+    if (G > 1) butterfly_step<OPK, 1, n>(v);
+    if (G > 2) butterfly_step<OPK, 2, n>(v);
+    if (G > 4) butterfly_step<OPK, 4, n>(v);
+    if (G > 8) butterfly_step<OPK, 8, n>(v);
+    if (G > 16) butterfly_step<OPK, 16, n>(v);
+    if (G > 32) butterfly_step<OPK, 32, n>(v);
 }
 
 struct DevX {
     static constexpr bool kSkipDeadWaves = true;   // the all-reduces are wave-local: a wave without spans can skip a phase
     __device__ __forceinline__ void sync() { __syncthreads(); }
-
-    template <int K, int n>
-    __device__ __forceinline__ void step_max(float* v) {
-#pragma unroll
-        for (int k = 0; k < n; ++k) v[k] = dpp_max<K>(v[k]);
+#ifdef VLG_STAMP
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+    __device__ __forceinline__ void stamp(int k) {   // acc[k] += cycles since the previous stamp (k = 0 restarts)
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (k > 0) acc[k] += t - last;
+        last = t;
     }
-    template <int K, int n>
-    __device__ __forceinline__ void step_sum(float* v) {
-#pragma unroll
-        for (int k = 0; k < n; ++k) v[k] = dpp_add<K>(v[k]);
-    }
-    template <int K, int n>
-    __device__ __forceinline__ void step_min_i(int* a) {
-#pragma unroll
-        for (int k = 0; k < n; ++k) a[k] = dpp_min_i<K>(a[k]);
-    }
-    // G is uniform over the workgroup, so these branches never diverge
+#endif
     template <int n>
-    __device__ __forceinline__ void allreduce_max(float* v, int G) {
-        if (G > 1) step_max<1, n>(v);
-        if (G > 2) step_max<2, n>(v);
-        if (G > 4) step_max<4, n>(v);
-        if (G > 8) step_max<8, n>(v);
-        if (G > 16) step_max<16, n>(v);
-        if (G > 32) step_max<32, n>(v);
-    }
+    __device__ __forceinline__ void allreduce_max(float* v, int G) { butterfly<kOpMax, n>(v, G); }
     template <int n>
-    __device__ __forceinline__ void allreduce_sum(float* v, int G) {
-        if (G > 1) step_sum<1, n>(v);
-        if (G > 2) step_sum<2, n>(v);
-        if (G > 4) step_sum<4, n>(v);
-        if (G > 8) step_sum<8, n>(v);
-        if (G > 16) step_sum<16, n>(v);
-        if (G > 32) step_sum<32, n>(v);
-    }
+    __device__ __forceinline__ void allreduce_sum(float* v, int G) { butterfly<kOpAdd, n>(v, G); }
     // arg-max with torch.max's tie-break (first index): all-reduce the values, then the SMALLEST index among
-    // the lanes that hold the maximum -- two fused-DPP butterflies instead of a (value, index) pair exchange
+    // the lanes that hold the maximum -- two fused butterflies instead of a (value, index) pair exchange
     template <int n>
     __device__ __forceinline__ void allreduce_argmax(float* v, int* a, int G) {
         float own[n];
 #pragma unroll
         for (int k = 0; k < n; ++k) own[k] = v[k];
-        allreduce_max<n>(v, G);
+        butterfly<kOpMax, n>(v, G);
 #pragma unroll
         for (int k = 0; k < n; ++k) a[k] = own[k] == v[k] ? a[k] : 0x7fffffff;
-        if (G > 1) step_min_i<1, n>(a);
-        if (G > 2) step_min_i<2, n>(a);
-        if (G > 4) step_min_i<4, n>(a);
-        if (G > 8) step_min_i<8, n>(a);
-        if (G > 16) step_min_i<16, n>(a);
-        if (G > 32) step_min_i<32, n>(a);
+        butterfly<kOpMinI, n>(a, G);
     }
 };
 
@@ -152,6 +162,15 @@ __global__ void xlane_selftest_kernel(int* out) {
     float s[1] = {1.0f};
     x.allreduce_sum<1>(s, 16);
     if (s[0] != 16.f) bad |= 256;
+    float s6[6], m6[6];
+    for (int k = 0; k < 6; ++k) { s6[k] = (float)(k + 1); m6[k] = (float)((lane * (k + 3)) % 61); }
+    x.allreduce_sum<6>(s6, 64);
+    x.allreduce_max<6>(m6, 64);
+    for (int k = 0; k < 6; ++k)
+        if (s6[k] != 64.f * (k + 1) || m6[k] != 60.f) bad |= 512;
+    float s4[4] = {1.f, 2.f, 3.f, (float)lane};
+    x.allreduce_sum<4>(s4, 32);
+    if (s4[0] != 32.f || s4[2] != 96.f || s4[3] != (lane < 32 ? 496.f : 1520.f)) bad |= 1024;
     atomicOr(out, bad);
 }
 

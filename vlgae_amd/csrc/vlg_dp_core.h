@@ -67,6 +67,11 @@ static inline float vlg_bits2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); re
 #define VLG_SR_LOG 0
 #define VLG_SR_MAX 1
 #define VLG_LOWEST (-3.0e38f)
+#if defined(VLG_STAMP) && defined(__HIPCC__)
+#define VLG_STAMP_AT(x, k) (x).stamp(k)   // diagnostic build: cycle stamps between the segments of a phase
+#else
+#define VLG_STAMP_AT(x, k) ((void)0)
+#endif
 // Charts are kept in log2 units so that the hardware's native 2^x / log2 x need no scaling multiplies:
 // potentials are multiplied by log2(e) once at load, logZ by ln(2) once at store; the adjoint weights
 // exp(t - out) = 2^((t - out) log2 e) are ratios and need no correction.
@@ -168,6 +173,7 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
     // reductions: 0 SL, 1 SR, 2 CL.x, 3 CL.y (r >= 1), 4 CR.x, 5 CR.y (r <= w-2)
     float m[6], s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int am[6];
+    VLG_STAMP_AT(x, 0);
     if (TU > 0) {
         float t[TU > 0 ? TU : 1][6];
 #pragma unroll
@@ -191,15 +197,19 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
             for (int u = 1; u < TU; ++u)
                 if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + (u << lg); }   // strict: first index wins ties
         }
+        VLG_STAMP_AT(x, 1);
         if (SR == VLG_SR_MAX) x.template allreduce_argmax<6>(m, am, G);
         else x.template allreduce_max<6>(m, G);
+        VLG_STAMP_AT(x, 2);
         if (SR == VLG_SR_LOG) {
 #pragma unroll
             for (int k = 0; k < 6; ++k)
 #pragma unroll
                 for (int u = 0; u < TU; ++u) s[k] += VLG_EXP(t[u][k] - m[k]);   // masked terms: 2^(-3e38) = 0
+            VLG_STAMP_AT(x, 3);
             x.template allreduce_sum<6>(s, G);
         }
+        VLG_STAMP_AT(x, 4);
     } else {
         for (int k = 0; k < 6; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
         for (int r = rr; r < w; r += G) {
@@ -252,6 +262,7 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
     float CRx = fold_term<SR>(m[4], s[4], am[4], IRn.x + c1, w - 1, false, b2);
     float CRy = fold_term<SR>(m[5], s[5], am[5], IRn.y + c1, w - 1, false, b3);
     if (i == 0 && w != c.len) { CRx = VLG_NEGINF; CRy = VLG_NEGINF; }   // single root, dmv.py:63
+    VLG_STAMP_AT(x, 5);
     if (live && rr == 0) {
         c.I[j * P + i] = ILn;
         c.I[i * P + j + 1] = IRn;
@@ -705,19 +716,46 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
     }
     x.sync();
     // ---- inside -----------------------------------------------------------------------------------
+#if defined(VLG_STAMP) && defined(__HIPCC__)
+    unsigned long long st_body = 0, st_sync = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_stage = 0;
+    unsigned long long st_bbody = 0, st_bsync = 0;
+    for (int w = 1; w < Ne; ++w) {
+        const unsigned long long a = __builtin_amdgcn_s_memtime();
+        dmv_fw<SR, BWD>(c, w, tid, nt, x);
+        const unsigned long long b = __builtin_amdgcn_s_memtime();
+        x.sync();
+        const unsigned long long d = __builtin_amdgcn_s_memtime();
+        st_body += b - a;
+        st_sync += d - b;
+    }
+#else
     for (int w = 1; w < Ne; ++w) {
         dmv_fw<SR, BWD>(c, w, tid, nt, x);
         x.sync();
     }
+#endif
     if (tid == 0) *logZ = c.C[len + 1].y * VLG_LN2;   // CR(0,len).NOCHILD, dmv.py:65
     if (!BWD) return;
     // ---- outside: adjoint replay ------------------------------------------------------------------
     if (tid == 0) c.gCc[len + 1].y = glogZ;
     x.sync();
+#if defined(VLG_STAMP) && defined(__HIPCC__)
+    for (int w = Ne - 1; w >= 1; --w) {
+        const unsigned long long a = __builtin_amdgcn_s_memtime();
+        dmv_bw<SR>(c, w, tid, nt, x);
+        const unsigned long long b = __builtin_amdgcn_s_memtime();
+        x.sync();
+        const unsigned long long d = __builtin_amdgcn_s_memtime();
+        st_bbody += b - a;
+        st_bsync += d - b;
+    }
+    const unsigned long long st_end = __builtin_amdgcn_s_memtime();
+#else
     for (int w = Ne - 1; w >= 1; --w) {
         dmv_bw<SR>(c, w, tid, nt, x);
         x.sync();
     }
+#endif
     // expected counts out (coalesced; padded positions get exact zeros like the reference)
     for (int idx = tid; idx < N * N; idx += nt) {
         const int h = idx / N, ch = idx - h * N;
@@ -741,6 +779,16 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
         }
         gdec[idx] = g;
     }
+#if defined(VLG_STAMP) && defined(__HIPCC__)
+    x.sync();
+    if ((tid & 63) == 0) {   // diagnostic build only: per-wave cycle sums overwrite the (padded) last rows of grad_dec
+        float* o = gdec + (size_t)(N - 1 - (tid >> 6)) * 8;
+        o[0] = (float)st_body; o[1] = (float)st_sync; o[2] = (float)st_bbody; o[3] = (float)st_bsync;
+        o[4] = (float)(st_end - st_t0); o[5] = (float)st_stage; o[6] = 0.f; o[7] = 0.f;
+        float* o2 = gdec + (size_t)(N - 1 - 8 - (tid >> 6)) * 8;
+        for (int k = 0; k < 8; ++k) o2[k] = (float)x.acc[k];
+    }
+#endif
 }
 
 template <int SR, bool BWD, typename In, typename X>
