@@ -77,6 +77,17 @@ int vlg_deptree_inside_outside(const void* arc, const int64_t* lengths, int B, i
                                const float* grad_logZ, float* logZ, float* grad_arc, void* ws, size_t ws_bytes,
                                void* stream);
 
+/* Best tree as a head vector, on the device -- replaces the callers' `dist.argmax.sum(-1).nonzero()` + scatter
+ * (src/model/ldndmv.py:301-303, joint.py:256-258, dmv.py:127-129), which synchronises the host every step.
+ *   heads [B,N] int64: heads[b,c] = head of word c in the Viterbi tree (0 = the root token), 0 for c = 0 and padding
+ *   best_score [B]: the Max-semiring value (`dist.max`).  Workspace as for VLG_OP_*_INSIDE_OUTSIDE, semiring 1. */
+int vlg_dmv1o_decode(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype,
+                     float* best_score, int64_t* heads, void* ws, size_t ws_bytes, void* stream);
+
+/* Same for the projective CRF; with `arc` = arc marginals this is the MBR decode of ldndmv.py:294-299. */
+int vlg_deptree_decode(const void* arc, const int64_t* lengths, int B, int N, int in_dtype, float* best_score,
+                       int64_t* heads, void* ws, size_t ws_bytes, void* stream);
+
 /* DMV1o.merge -- src/model/torch_struct/distributions.py:253-265.
  *   dec [B,L,2,2,2], attach [B,L,L,2], root [B,L]  ->  dec_wroot [B,L+1,2,2,2], attach_wroot [B,L+1,L+1,2]
  *   (always fp32, like the reference's torch.full). */

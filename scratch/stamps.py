@@ -21,6 +21,6 @@ for ln in (32,):
         if r[4] == 0: continue
         print(f' wave {wv}: fw body {r[0]/ln:7.0f} sync {r[1]/ln:7.0f} | bw body {r[2]/ln:7.0f} sync {r[3]/ln:7.0f}  cycles/phase | total {r[4]:9.0f} ticks')
     st2 = gd[:, L + 1 - 8 - nw:L + 1 - 8, :].reshape(B, nw, 8).flip(1).mean(0)
-    names = ['-', 'loads+terms+localmax', 'allreduce max', 'exp+sum', 'allreduce sum', 'log+fold', '-', '-']
+    names = ['stores', 'loads+terms+localmax', 'allreduce max', 'exp+sum', 'allreduce sum', 'log+fold', 'preamble+barrier(+bw!)', 'ptr setup+const loads']
     for wv in range(min(nw, 2)):
-        print(f' wave {wv} fw segments (cycles/phase): ' + ', '.join(f'{names[k]}={st2[wv][k].item()/ln:.0f}' for k in range(1, 6)))
+        print(f' wave {wv} fw segments (cycles/phase): ' + ', '.join(f'{names[k]}={st2[wv][k].item()/ln:.0f}' for k in range(0, 8)))

@@ -63,3 +63,23 @@ def deptree(arc, lengths, semiring=0, grad=True, glogZ=None, nt=16, order=0):
 
 def canary_trips():
     return int(lib().emu_canary_trips())
+
+
+def dmv1o_decode(dec, attach, lengths, nt=16, order=0):
+    B, N = dec.shape[:2]
+    dec, attach = np.ascontiguousarray(dec, np.float32), np.ascontiguousarray(attach, np.float32)
+    ln = np.ascontiguousarray(lengths, np.int64)
+    best = np.full(B, np.nan, np.float32)
+    heads = np.full((B, N), -1, np.int64)
+    assert lib().emu_dmv1o_decode(_p(dec), _p(attach), _p(ln), B, N, _p(best), _p(heads), nt, order) == 0
+    return best, heads
+
+
+def deptree_decode(arc, lengths, nt=16, order=0):
+    B, N = arc.shape[:2]
+    arc = np.ascontiguousarray(arc, np.float32)
+    ln = np.ascontiguousarray(lengths, np.int64)
+    best = np.full(B, np.nan, np.float32)
+    heads = np.full((B, N), -1, np.int64)
+    assert lib().emu_deptree_decode(_p(arc), _p(ln), B, N, _p(best), _p(heads), nt, order) == 0
+    return best, heads

@@ -139,7 +139,7 @@ struct Arena {
 
 template <int SR, bool BWD, typename In>
 void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int len, int N, float glogZ, float* logZ,
-                 float* gdec, float* gatt, int nt, int order) {
+                 float* gdec, float* gatt, int nt, int order, long long* heads = nullptr) {
     const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, 0);   // mode 0: one contiguous carve, like LDS
     Arena A(L.lds_bytes);
     vlg::DmvCtx c;
@@ -149,13 +149,14 @@ void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int le
     c.gCc = (float2*)A.at(L.gCc.off); c.gCi = (float2*)A.at(L.gCi.off); c.gI = (float2*)A.at(L.gI.off);
     c.decs = (float*)A.at(L.decs.off); c.gdecs = (float*)A.at(L.gdecs.off);
     run_workgroup(nt, order, [&](int tid, HostX& x) {
-        vlg::dmv_run<SR, BWD, In>(c, dec, attach, N, glogZ, logZ, gdec, gatt, tid, nt, x);
+        vlg::dmv_run<SR, BWD, In>(c, dec, attach, N, glogZ, logZ, gdec, gatt, heads, tid, nt, x);
     });
     A.check();
 }
 
 template <int SR, bool BWD, typename In>
-void emu_dep_one(const typename In::T* arc, int len, int N, float glogZ, float* logZ, float* garc, int nt, int order) {
+void emu_dep_one(const typename In::T* arc, int len, int N, float glogZ, float* logZ, float* garc, int nt, int order,
+                 long long* heads = nullptr) {
     const vlg::DepLayout L(N, BWD, SR == VLG_SR_MAX, 0);
     Arena A(L.lds_bytes);
     vlg::DepCtx c;
@@ -164,7 +165,7 @@ void emu_dep_one(const typename In::T* arc, int len, int N, float glogZ, float* 
     c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);
     c.gCc = (float*)A.at(L.gCc.off); c.gCi = (float*)A.at(L.gCi.off); c.gI = (float*)A.at(L.gI.off);
     run_workgroup(nt, order, [&](int tid, HostX& x) {
-        vlg::dep_run<SR, BWD, In>(c, arc, N, glogZ, logZ, garc, tid, nt, x);
+        vlg::dep_run<SR, BWD, In>(c, arc, N, glogZ, logZ, garc, heads, tid, nt, x);
     });
     A.check();
 }
@@ -214,6 +215,21 @@ int dep_batch(const void* arc_, const int64_t* lengths, int B, int N, int semiri
 
 extern "C" {
 int emu_canary_trips(void) { return g_canary_trips; }
+// decode mode: Max semiring, heads out, no gradient buffers (f32 inputs)
+int emu_dmv1o_decode(const float* dec, const float* attach, const int64_t* lengths, int B, int N, float* best,
+                     long long* heads, int nt, int order) {
+    for (int b = 0; b < B; ++b)
+        emu_dmv_one<1, true, vlg::F32In>(dec + (size_t)b * N * 8, attach + (size_t)b * N * N * 2, (int)lengths[b], N, 1.f,
+                                         best + b, nullptr, nullptr, nt, order, heads + (size_t)b * N);
+    return 0;
+}
+int emu_deptree_decode(const float* arc, const int64_t* lengths, int B, int N, float* best, long long* heads, int nt,
+                       int order) {
+    for (int b = 0; b < B; ++b)
+        emu_dep_one<1, true, vlg::F32In>(arc + (size_t)b * N * N, (int)lengths[b], N, 1.f, best + b, nullptr, nt, order,
+                                         heads + (size_t)b * N);
+    return 0;
+}
 int emu_dmv1o(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype, int semiring,
               const float* glogZ, float* logZ, float* gdec, float* gatt, int nt, int order) {
     return in_dtype == 0 ? dmv_batch<vlg::F32In>(dec, attach, lengths, B, N, semiring, glogZ, logZ, gdec, gatt, nt, order)

@@ -107,3 +107,19 @@ def test_emu_ties_take_first_argmax(oracle_mod):
     mz, mgd, mga = emu.dmv1o(md, ma, lengths, 1, nt=8, order=1)
     assert np.array_equal(mz, ref[0][:, 0]) and np.array_equal(mgd, ref[1]) and np.array_equal(mga, ref[2])
     assert np.array_equal(mga.sum((1, 2, 3)), lengths.astype(np.float32))     # still a tree
+
+
+def test_emu_decode_heads(oracle_mod):
+    """Decode mode: heads written by the kernel body == the callers' nonzero()+scatter on the reference's argmax."""
+    g = load(golden_files("dmv_B4_L10_s0")[0])
+    md, ma = oracle_mod.dmv1o_merge(g["dec"], g["attach"], g["root"])
+    best, heads = emu.dmv1o_decode(md, ma, g["lengths"], nt=16, order=1)
+    assert np.array_equal(heads, g["predicted"]) and np.allclose(best, g["max"][:, 0], rtol=1e-6, atol=1e-6)
+    # MBR: DependencyCRF over the reference's arc marginals
+    best2, heads2 = emu.deptree_decode(g["arc_marginal"], g["lengths"], nt=16, order=2)
+    B, N = heads2.shape
+    ref = np.zeros((B, N), np.int64)
+    b, h, c = np.nonzero(g["mbr_argmax"])
+    ref[b, c] = h
+    assert np.array_equal(heads2, ref) and np.allclose(best2, g["mbr_max"], rtol=1e-6, atol=1e-6)
+    assert emu.canary_trips() == 0

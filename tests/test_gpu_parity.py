@@ -107,6 +107,10 @@ def test_dmv1o_golden(ts, path):
     # Fed with the REFERENCE's marginals so that near-ties cannot flip on 1e-6 differences.
     crf = ts.DependencyCRF(t(g["arc_marginal"]), lengths)
     assert np.array_equal(crf.argmax.detach().cpu().numpy(), g["mbr_argmax"])
+    mbr_heads = np.zeros(g["predicted"].shape, np.int64)
+    bb, hh, cc = np.nonzero(g["mbr_argmax"])
+    mbr_heads[bb, cc] = hh
+    assert np.array_equal(crf.argmax_heads.cpu().numpy(), mbr_heads)
     assert np.allclose(crf.max.detach().cpu().numpy(), g["mbr_max"], rtol=1e-5, atol=1e-5)
 
 

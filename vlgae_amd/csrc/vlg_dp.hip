@@ -118,10 +118,10 @@ struct DevX {
     __device__ __forceinline__ void sync() { __syncthreads(); }
 #ifdef VLG_STAMP
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
-    __device__ __forceinline__ void stamp(int k) {   // acc[k] += cycles since the previous stamp (k = 0 restarts)
+    __device__ __forceinline__ void stamp(int k) {   // acc[k & 7] += cycles since the previous stamp
         unsigned long long t;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        if (k > 0) acc[k] += t - last;
+        acc[k & 7] += t - last;
         last = t;
     }
 #endif
@@ -185,7 +185,8 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
                                                          const int64_t* __restrict__ lengths, int N,
                                                          const float* __restrict__ glogZ, float* __restrict__ logZ,
                                                          float* __restrict__ gdec, float* __restrict__ gatt,
-                                                         char* __restrict__ ws, size_t ws_stride) {
+                                                         long long* __restrict__ heads, char* __restrict__ ws,
+                                                         size_t ws_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int len = (int)lengths[b];
@@ -194,8 +195,9 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
     if (len < 1 || len > N - 1) {   // not a sentence: NaN score, zero counts (block-uniform branch)
         if (tid == 0) logZ[b] = __uint_as_float(0x7fc00000u);
         if (BWD) {
-            for (int i = tid; i < N * N * 2; i += kThreads) gatt[att_off + i] = 0.f;
-            for (int i = tid; i < N * 8; i += kThreads) gdec[dec_off + i] = 0.f;
+            if (gatt) for (int i = tid; i < N * N * 2; i += kThreads) gatt[att_off + i] = 0.f;
+            if (gdec) for (int i = tid; i < N * 8; i += kThreads) gdec[dec_off + i] = 0.f;
+            if (heads) for (int i = tid; i < N; i += kThreads) heads[(size_t)b * N + i] = 0;
         }
         return;
     }
@@ -218,23 +220,26 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
     c.gdecs = region_ptr<float>(L.gdecs, smem, wsb);
     DevX x;
     dmv_run<SR, BWD, In>(c, dec + dec_off, attach + att_off, N, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b,
-                         BWD ? gdec + dec_off : nullptr, BWD ? gatt + att_off : nullptr, tid, kThreads, x);
+                         (BWD && gdec) ? gdec + dec_off : nullptr, (BWD && gatt) ? gatt + att_off : nullptr,
+                         (BWD && heads) ? heads + (size_t)b * N : nullptr, tid, kThreads, x);
 }
 
 template <int SR, int MODE, bool BWD, typename In>
 __global__ __launch_bounds__(kThreads) void deptree_kernel(const typename In::T* __restrict__ arc,
                                                            const int64_t* __restrict__ lengths, int N,
                                                            const float* __restrict__ glogZ, float* __restrict__ logZ,
-                                                           float* __restrict__ garc, char* __restrict__ ws,
-                                                           size_t ws_stride) {
+                                                           float* __restrict__ garc, long long* __restrict__ heads,
+                                                           char* __restrict__ ws, size_t ws_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int len = lengths ? (int)lengths[b] : N - 1;   // lengths=None -> N-1 (deptree.py:151-152)
     const size_t arc_off = (size_t)b * N * N;
     if (len < 1 || len > N - 1) {
         if (tid == 0) logZ[b] = __uint_as_float(0x7fc00000u);
-        if (BWD)
-            for (int i = tid; i < N * N; i += kThreads) garc[arc_off + i] = 0.f;
+        if (BWD) {
+            if (garc) for (int i = tid; i < N * N; i += kThreads) garc[arc_off + i] = 0.f;
+            if (heads) for (int i = tid; i < N; i += kThreads) heads[(size_t)b * N + i] = 0;
+        }
         return;
     }
     const DepLayout L(N, BWD, SR == VLG_SR_MAX, MODE);
@@ -253,7 +258,8 @@ __global__ __launch_bounds__(kThreads) void deptree_kernel(const typename In::T*
     c.gI = region_ptr<float>(L.gI, smem, wsb);
     DevX x;
     dep_run<SR, BWD, In>(c, arc + arc_off, N, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b,
-                         BWD ? garc + arc_off : nullptr, tid, kThreads, x);
+                         (BWD && garc) ? garc + arc_off : nullptr, (BWD && heads) ? heads + (size_t)b * N : nullptr, tid,
+                         kThreads, x);
 }
 
 // ---- DMV1o.merge (distributions.py:253-265): root-augmented potentials, always fp32 out ----------
@@ -305,36 +311,37 @@ static int prep(K kernel, size_t lds) {
 
 template <int SR, int MODE, bool BWD, typename In>
 static int launch_dmv(const void* dec, const void* attach, const int64_t* lengths, int B, int N, const float* glogZ,
-                      float* logZ, float* gdec, float* gatt, void* ws, size_t ws_stride, size_t lds,
-                      hipStream_t stream) {
+                      float* logZ, float* gdec, float* gatt, int64_t* heads, void* ws, size_t ws_stride,
+                      size_t lds, hipStream_t stream) {
     auto k = dmv1o_kernel<SR, MODE, BWD, In>;
     if (int rc = prep(k, lds)) return rc;
     hipLaunchKernelGGL(k, dim3(B), dim3(kThreads), lds, stream, (const typename In::T*)dec,
-                       (const typename In::T*)attach, lengths, N, glogZ, logZ, gdec, gatt, (char*)ws, ws_stride);
+                       (const typename In::T*)attach, lengths, N, glogZ, logZ, gdec, gatt, (long long*)heads, (char*)ws,
+                       ws_stride);
     return check_launch("dmv1o_kernel");
 }
 
 template <int SR, bool BWD, typename In>
 static int dispatch_dmv_mode(int mode, const void* dec, const void* attach, const int64_t* lengths, int B, int N,
-                             const float* glogZ, float* logZ, float* gdec, float* gatt, void* ws, size_t ws_stride,
-                             size_t lds, hipStream_t s) {
+                             const float* glogZ, float* logZ, float* gdec, float* gatt, int64_t* heads, void* ws,
+                             size_t ws_stride, size_t lds, hipStream_t s) {
     switch (mode) {
-        case 0: return launch_dmv<SR, 0, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, ws, ws_stride, lds, s);
-        case 1: return launch_dmv<SR, 1, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, ws, ws_stride, lds, s);
-        case 2: return launch_dmv<SR, 2, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, ws, ws_stride, lds, s);
-        default: return launch_dmv<SR, 3, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, ws, ws_stride, lds, s);
+        case 0: return launch_dmv<SR, 0, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, heads, ws, ws_stride, lds, s);
+        case 1: return launch_dmv<SR, 1, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, heads, ws, ws_stride, lds, s);
+        case 2: return launch_dmv<SR, 2, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, heads, ws, ws_stride, lds, s);
+        default: return launch_dmv<SR, 3, BWD, In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, heads, ws, ws_stride, lds, s);
     }
 }
 
 template <bool BWD>
 static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype,
-                   int semiring, const float* glogZ, float* logZ, float* gdec, float* gatt, void* ws, size_t ws_bytes,
-                   void* stream) {
+                   int semiring, const float* glogZ, float* logZ, float* gdec, float* gatt, int64_t* heads, void* ws,
+                   size_t ws_bytes, void* stream) {
     if (B < 0 || N < 2) return set_error(VLG_ERR_SHAPE, "dmv1o: need B >= 0 and N >= 2 (got B=%d N=%d)", B, N);
     if (N > 255) return set_error(VLG_ERR_SHAPE, "dmv1o: N=%d exceeds the supported maximum of 255", N);
     if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "dmv1o: in_dtype %d", in_dtype);
     if (semiring != VLG_SR_LOG && semiring != VLG_SR_MAX) return set_error(VLG_ERR_ARG, "dmv1o: semiring %d", semiring);
-    if (!dec || !attach || !lengths || !logZ || (BWD && (!gdec || !gatt)))
+    if (!dec || !attach || !lengths || !logZ || (BWD && !heads && (!gdec || !gatt)))
         if (B > 0) return set_error(VLG_ERR_ARG, "dmv1o: null buffer");
     if (B == 0) return 0;
     const int mode = pick_mode<DmvLayout>(N, BWD, semiring == VLG_SR_MAX, kLdsBudget);
@@ -345,7 +352,7 @@ static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, 
                          N, ws_stride * (size_t)B, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
 #define VLG_GO(SRV, INV) \
-    return dispatch_dmv_mode<SRV, BWD, INV>(mode, dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, ws, ws_stride, lds, s)
+    return dispatch_dmv_mode<SRV, BWD, INV>(mode, dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, heads, ws, ws_stride, lds, s)
     if (semiring == VLG_SR_LOG) {
         if (in_dtype == VLG_F32) VLG_GO(VLG_SR_LOG, F32In);
         VLG_GO(VLG_SR_LOG, BF16In);
@@ -357,33 +364,35 @@ static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, 
 
 template <int SR, int MODE, bool BWD, typename In>
 static int launch_dep(const void* arc, const int64_t* lengths, int B, int N, const float* glogZ, float* logZ,
-                      float* garc, void* ws, size_t ws_stride, size_t lds, hipStream_t stream) {
+                      float* garc, int64_t* heads, void* ws, size_t ws_stride, size_t lds, hipStream_t stream) {
     auto k = deptree_kernel<SR, MODE, BWD, In>;
     if (int rc = prep(k, lds)) return rc;
     hipLaunchKernelGGL(k, dim3(B), dim3(kThreads), lds, stream, (const typename In::T*)arc, lengths, N, glogZ, logZ,
-                       garc, (char*)ws, ws_stride);
+                       garc, (long long*)heads, (char*)ws, ws_stride);
     return check_launch("deptree_kernel");
 }
 
 template <int SR, bool BWD, typename In>
 static int dispatch_dep_mode(int mode, const void* arc, const int64_t* lengths, int B, int N, const float* glogZ,
-                             float* logZ, float* garc, void* ws, size_t ws_stride, size_t lds, hipStream_t s) {
+                             float* logZ, float* garc, int64_t* heads, void* ws, size_t ws_stride, size_t lds,
+                             hipStream_t s) {
     switch (mode) {
-        case 0: return launch_dep<SR, 0, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, ws, ws_stride, lds, s);
-        case 1: return launch_dep<SR, 1, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, ws, ws_stride, lds, s);
-        case 2: return launch_dep<SR, 2, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, ws, ws_stride, lds, s);
-        default: return launch_dep<SR, 3, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, ws, ws_stride, lds, s);
+        case 0: return launch_dep<SR, 0, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, heads, ws, ws_stride, lds, s);
+        case 1: return launch_dep<SR, 1, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, heads, ws, ws_stride, lds, s);
+        case 2: return launch_dep<SR, 2, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, heads, ws, ws_stride, lds, s);
+        default: return launch_dep<SR, 3, BWD, In>(arc, lengths, B, N, glogZ, logZ, garc, heads, ws, ws_stride, lds, s);
     }
 }
 
 template <bool BWD>
 static int run_dep(const void* arc, const int64_t* lengths, int B, int N, int in_dtype, int semiring,
-                   const float* glogZ, float* logZ, float* garc, void* ws, size_t ws_bytes, void* stream) {
+                   const float* glogZ, float* logZ, float* garc, int64_t* heads, void* ws, size_t ws_bytes,
+                   void* stream) {
     if (B < 0 || N < 2) return set_error(VLG_ERR_SHAPE, "deptree: need B >= 0 and N >= 2 (got B=%d N=%d)", B, N);
     if (N > 255) return set_error(VLG_ERR_SHAPE, "deptree: N=%d exceeds the supported maximum of 255", N);
     if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "deptree: in_dtype %d", in_dtype);
     if (semiring != VLG_SR_LOG && semiring != VLG_SR_MAX) return set_error(VLG_ERR_ARG, "deptree: semiring %d", semiring);
-    if (!arc || !logZ || (BWD && !garc))
+    if (!arc || !logZ || (BWD && !garc && !heads))
         if (B > 0) return set_error(VLG_ERR_ARG, "deptree: null buffer");
     if (B == 0) return 0;
     const int mode = pick_mode<DepLayout>(N, BWD, semiring == VLG_SR_MAX, kLdsBudget);
@@ -394,7 +403,7 @@ static int run_dep(const void* arc, const int64_t* lengths, int B, int N, int in
                          ws_stride * (size_t)B, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
 #define VLG_GO(SRV, INV) \
-    return dispatch_dep_mode<SRV, BWD, INV>(mode, arc, lengths, B, N, glogZ, logZ, garc, ws, ws_stride, lds, s)
+    return dispatch_dep_mode<SRV, BWD, INV>(mode, arc, lengths, B, N, glogZ, logZ, garc, heads, ws, ws_stride, lds, s)
     if (semiring == VLG_SR_LOG) {
         if (in_dtype == VLG_F32) VLG_GO(VLG_SR_LOG, F32In);
         VLG_GO(VLG_SR_LOG, BF16In);
@@ -413,26 +422,40 @@ extern "C" {
 
 int vlg_dmv1o_inside(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype,
                      int semiring, float* logZ, void* ws, size_t ws_bytes, void* stream) {
-    return vlg::run_dmv<false>(dec, attach, lengths, B, N, in_dtype, semiring, nullptr, logZ, nullptr, nullptr, ws,
-                               ws_bytes, stream);
+    return vlg::run_dmv<false>(dec, attach, lengths, B, N, in_dtype, semiring, nullptr, logZ, nullptr, nullptr, nullptr,
+                               ws, ws_bytes, stream);
 }
 
 int vlg_dmv1o_inside_outside(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype,
                              int semiring, const float* grad_logZ, float* logZ, float* grad_dec, float* grad_attach,
                              void* ws, size_t ws_bytes, void* stream) {
     return vlg::run_dmv<true>(dec, attach, lengths, B, N, in_dtype, semiring, grad_logZ, logZ, grad_dec, grad_attach,
-                              ws, ws_bytes, stream);
+                              nullptr, ws, ws_bytes, stream);
 }
 
 int vlg_deptree_inside(const void* arc, const int64_t* lengths, int B, int N, int in_dtype, int semiring, float* logZ,
                        void* ws, size_t ws_bytes, void* stream) {
-    return vlg::run_dep<false>(arc, lengths, B, N, in_dtype, semiring, nullptr, logZ, nullptr, ws, ws_bytes, stream);
+    return vlg::run_dep<false>(arc, lengths, B, N, in_dtype, semiring, nullptr, logZ, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
 int vlg_deptree_inside_outside(const void* arc, const int64_t* lengths, int B, int N, int in_dtype, int semiring,
                                const float* grad_logZ, float* logZ, float* grad_arc, void* ws, size_t ws_bytes,
                                void* stream) {
-    return vlg::run_dep<true>(arc, lengths, B, N, in_dtype, semiring, grad_logZ, logZ, grad_arc, ws, ws_bytes, stream);
+    return vlg::run_dep<true>(arc, lengths, B, N, in_dtype, semiring, grad_logZ, logZ, grad_arc, nullptr, ws, ws_bytes, stream);
+}
+
+int vlg_dmv1o_decode(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype,
+                     float* best_score, int64_t* heads, void* ws, size_t ws_bytes, void* stream) {
+    if (B > 0 && !heads) return vlg::set_error(VLG_ERR_ARG, "dmv1o_decode: null heads");
+    return vlg::run_dmv<true>(dec, attach, lengths, B, N, in_dtype, VLG_SR_MAX, nullptr, best_score, nullptr, nullptr,
+                              heads, ws, ws_bytes, stream);
+}
+
+int vlg_deptree_decode(const void* arc, const int64_t* lengths, int B, int N, int in_dtype, float* best_score,
+                       int64_t* heads, void* ws, size_t ws_bytes, void* stream) {
+    if (B > 0 && !heads) return vlg::set_error(VLG_ERR_ARG, "deptree_decode: null heads");
+    return vlg::run_dep<true>(arc, lengths, B, N, in_dtype, VLG_SR_MAX, nullptr, best_score, nullptr, heads, ws,
+                              ws_bytes, stream);
 }
 
 size_t vlg_workspace_bytes(int op, int B, int N, int semiring) {

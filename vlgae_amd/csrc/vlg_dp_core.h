@@ -159,6 +159,7 @@ VLG_HD int group_log2(int spans, int w, int nt) {
 // ------------------------------------------------------------------------------------------------
 template <int SR, bool BWD, int TU, typename X>
 VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr, X& x) {
+    VLG_STAMP_AT(x, 6);   // since the end of the previous span: phase preamble + barrier
     const int P = c.P, j = i + w, G = 1 << lg;
     const float2* cr = c.C + i * P + i + 1;      // CR(i, i+r)    at [r]
     const float2* cl = c.C + j * P + i + 1;      // CL(j, i+r+1)  at [r]
@@ -173,7 +174,7 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
     // reductions: 0 SL, 1 SR, 2 CL.x, 3 CL.y (r >= 1), 4 CR.x, 5 CR.y (r <= w-2)
     float m[6], s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int am[6];
-    VLG_STAMP_AT(x, 0);
+    VLG_STAMP_AT(x, 7);   // pointer set-up + per-span constant loads
     if (TU > 0) {
         float t[TU > 0 ? TU : 1][6];
 #pragma unroll
@@ -281,6 +282,7 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
             }
         }
     }
+    VLG_STAMP_AT(x, 8);   // stores
 }
 
 template <int SR, bool BWD, typename X>
@@ -685,7 +687,7 @@ VLG_HD void dep_bw(const DepCtx& c, int w, int tid, int nt, X& x) {
 // ================================================================================================
 template <int SR, bool BWD, typename In, typename X>
 VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename In::T* attach, int N, float glogZ,
-                    float* logZ, float* gdec, float* gatt, int tid, int nt, X& x) {
+                    float* logZ, float* gdec, float* gatt, long long* heads, int tid, int nt, X& x) {
     const int Ne = c.Ne, P = c.P, len = c.len;
     // ---- stage: charts to the semiring zero (dmv.py:34-35), dec into fast memory -----------------
     const float2 zz = make_float2(VLG_NEGINF, VLG_NEGINF), oo = make_float2(0.f, 0.f);
@@ -756,7 +758,13 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
         x.sync();
     }
 #endif
-    // expected counts out (coalesced; padded positions get exact zeros like the reference)
+    // expected counts out (coalesced; padded positions get exact zeros like the reference).  Decode mode
+    // (heads != null): heads[c] = the h with a non-zero attach count -- what the callers compute on the host
+    // with `argmax.sum(-1).nonzero()` + a scatter (ldndmv.py:301-303, joint.py:256-258); 0 for root / padding.
+    if (heads) {
+        for (int i = tid; i < N; i += nt) heads[i] = 0;
+        x.sync();
+    }
     for (int idx = tid; idx < N * N; idx += nt) {
         const int h = idx / N, ch = idx - h * N;
         float2 g = oo;
@@ -764,21 +772,23 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
             if (ch < h) g = c.gI[h * P + ch];
             else if (ch > h) g = c.gI[h * P + ch + 1];
         }
-        *reinterpret_cast<float2*>(gatt + (size_t)idx * 2) = g;
+        if (gatt) *reinterpret_cast<float2*>(gatt + (size_t)idx * 2) = g;
+        if (heads && g.x + g.y != 0.f) heads[ch] = h;
     }
-    for (int idx = tid; idx < N * 8; idx += nt) {
-        const int h = idx >> 3, k = idx & 7;
-        float g = 0.f;
-        if (h < Ne) {
-            const int dir = k >> 2, v = (k >> 1) & 1;
-            if ((k & 1) == 0) g = c.gdecs[h * 8 + k];                                   // GO
-            else {                                                                      // STOP = width-0 span
-                const int q = h * P + h + dir;
-                g = reinterpret_cast<const float*>(c.gCc + q)[v] + reinterpret_cast<const float*>(c.gCi + q)[v];
+    if (gdec)
+        for (int idx = tid; idx < N * 8; idx += nt) {
+            const int h = idx >> 3, k = idx & 7;
+            float g = 0.f;
+            if (h < Ne) {
+                const int dir = k >> 2, v = (k >> 1) & 1;
+                if ((k & 1) == 0) g = c.gdecs[h * 8 + k];                                   // GO
+                else {                                                                      // STOP = width-0 span
+                    const int q = h * P + h + dir;
+                    g = reinterpret_cast<const float*>(c.gCc + q)[v] + reinterpret_cast<const float*>(c.gCi + q)[v];
+                }
             }
+            gdec[idx] = g;
         }
-        gdec[idx] = g;
-    }
 #if defined(VLG_STAMP) && defined(__HIPCC__)
     x.sync();
     if ((tid & 63) == 0) {   // diagnostic build only: per-wave cycle sums overwrite the (padded) last rows of grad_dec
@@ -792,8 +802,8 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
 }
 
 template <int SR, bool BWD, typename In, typename X>
-VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glogZ, float* logZ, float* garc, int tid,
-                    int nt, X& x) {
+VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glogZ, float* logZ, float* garc,
+                    long long* heads, int tid, int nt, X& x) {
     const int Ne = c.Ne, P = c.P, len = c.len;
     for (int i = tid; i < Ne * P; i += nt) {
         c.C[i] = VLG_NEGINF;   // deptree.py:42-43
@@ -826,6 +836,10 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
         dep_bw<SR>(c, w, tid, nt, x);
         x.sync();
     }
+    if (heads) {
+        for (int i = tid; i < N; i += nt) heads[i] = 0;
+        x.sync();
+    }
     for (int idx = tid; idx < N * N; idx += nt) {
         const int h = idx / N, ch = idx - h * N;
         float g = 0.f;
@@ -833,7 +847,8 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
             if (ch < h) g = c.gI[h * P + ch];
             else if (ch > h) g = c.gI[h * P + ch + 1];
         }
-        garc[idx] = g;
+        if (garc) garc[idx] = g;
+        if (heads && g != 0.f) heads[ch] = h;
     }
 }
 

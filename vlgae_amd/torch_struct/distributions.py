@@ -124,6 +124,14 @@ class DMV1o(StructDistribution):
         _, _, gatt = F.dmv1o_run(dec, attach, self.lengths, semiring.kernel_id, True)
         return gatt.to(attach.dtype) if attach.dtype == torch.float64 else gatt
 
+    @lazy_property
+    def argmax_heads(self):
+        """Extension (not in the reference): the best tree as `predicted` heads [B,N], computed on the device.
+        Same result as `arc = self.argmax.sum(-1).nonzero(); predicted[arc[:,0], arc[:,2]] = arc[:,1]`
+        (joint.py:256-258) without the host synchronisation of `nonzero()`."""
+        dec, attach = self.log_potentials
+        return F.dmv1o_decode(dec, attach, self.lengths)[1]
+
     @staticmethod
     def merge(dec: Tensor, attach: Tensor, root: Tensor, one=0, zero=NEGINF):
         """Root-augmented potentials (distributions.py:253-265): the root is token 0, generates only to
@@ -150,6 +158,11 @@ class DependencyCRF(StructDistribution):
         arc = self.log_potentials
         _, garc = F.deptree_run(arc, self.lengths, semiring.kernel_id, True)
         return garc.to(arc.dtype) if arc.dtype == torch.float64 else garc
+
+    @lazy_property
+    def argmax_heads(self):
+        "Extension: best tree as heads [B,N] on the device (see DMV1o.argmax_heads; MBR decode of ldndmv.py:294-303)."
+        return F.deptree_decode(self.log_potentials, self.lengths)[1]
 
     def log_prob(self, value):
         "log p(tree) for 0/1 arc indicators `value` [..., B, N, N] (distributions.py:55-75)."

@@ -86,6 +86,43 @@ def deptree_run(arc, lengths, semiring, want_grad, grad_logZ=None):
     return logZ, None
 
 
+def dmv1o_decode(dec, attach, lengths):
+    """Viterbi tree as a head vector, entirely on the device (no `nonzero()` host sync).
+    Returns (best_score [B], heads [B,N] int64): heads[b,c] = head of word c (0 = root token); 0 at c = 0 / padding.
+    Equals `predicted` of src/model/joint.py:256-258 and, shifted by one, of ldndmv.py:301-303."""
+    _C.require_gpu(dec, "dmv1o_decode")
+    B, N = dec.shape[:2]
+    if tuple(dec.shape) != (B, N, 2, 2, 2) or tuple(attach.shape) != (B, N, N, 2):
+        raise ValueError(f"dec {tuple(dec.shape)} / attach {tuple(attach.shape)}: expected [B,N,2,2,2] / [B,N,N,2]")
+    if dec.dtype != attach.dtype:
+        attach = attach.to(dec.dtype)
+    dt, dec_c = _C.in_dtype(dec.detach())
+    _, att_c = _C.in_dtype(attach.detach())
+    lengths = _lengths(lengths, B, dec.device)
+    best = torch.empty(B, dtype=torch.float32, device=dec.device)
+    heads = torch.empty((B, N), dtype=torch.int64, device=dec.device)
+    ws, nb = _workspace(_C.OP_DMV1O_INSIDE_OUTSIDE, B, N, _C.SEMIRING_MAX, dec.device)
+    _C.check(_C.lib().vlg_dmv1o_decode(_C.ptr(dec_c), _C.ptr(att_c), _C.ptr(lengths), B, N, dt, _C.ptr(best),
+                                       _C.ptr(heads), _C.ptr(ws), nb, _C.stream_of(dec)), "dmv1o_decode")
+    return best, heads
+
+
+def deptree_decode(arc, lengths=None):
+    """Best projective single-root tree of arc scores [B,N,N] as heads [B,N] (see dmv1o_decode).  With `arc` = arc
+    marginals this is the MBR decode of src/model/ldndmv.py:294-299."""
+    _C.require_gpu(arc, "deptree_decode")
+    B, N, N2 = arc.shape
+    assert N == N2, "Non-square potentials"
+    dt, arc_c = _C.in_dtype(arc.detach())
+    lengths = _lengths(lengths, B, arc.device, allow_none=True)
+    best = torch.empty(B, dtype=torch.float32, device=arc.device)
+    heads = torch.empty((B, N), dtype=torch.int64, device=arc.device)
+    ws, nb = _workspace(_C.OP_DEPTREE_INSIDE_OUTSIDE, B, N, _C.SEMIRING_MAX, arc.device)
+    _C.check(_C.lib().vlg_deptree_decode(_C.ptr(arc_c), _C.ptr(lengths), B, N, dt, _C.ptr(best), _C.ptr(heads),
+                                         _C.ptr(ws), nb, _C.stream_of(arc)), "deptree_decode")
+    return best, heads
+
+
 class _DMV1oSum(torch.autograd.Function):
     """semiring-sum over all trees; d/d(potentials) = expected counts (Log) / best tree (Max)."""
 
