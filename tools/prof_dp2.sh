@@ -1,8 +1,8 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-export VLGAE_AMD_LIB=$PWD/scratch/variants/lib_nt256.so
+export VLGAE_AMD_LIB=$PWD/tools/variants/lib_nt256.so
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmcd_$tag -- python scratch/time_fw.py > gpurun_out/pmcd_$tag.log 2>&1
+  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmcd_$tag -- python tools/time_fw.py > gpurun_out/pmcd_$tag.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections

@@ -1,11 +1,3 @@
-"""Index constants of the DMV potentials -- same names and values as the reference
-(src/model/torch_struct/dmv.py:7-15); imported by callers such as ldndmv.py:22 and dmv_helper/*."""
-NOCHILD = 1
-HASCHILD = 0
-LEFT = 0
-RIGHT = 1
-GO = 0
-STOP = 1
-DIR_NUM = 2
-VAL_NUM = 2
-DEC_NUM = 2
+"""`from ...torch_struct.dmv import LEFT, RIGHT, NOCHILD, ...` keeps working for callers of the reference
+layout (src/model/ldndmv.py:22, src/model/dmv_helper/*.py); the values live in constants.py."""
+from .constants import DEC_NUM, DIR_NUM, GO, HASCHILD, LEFT, NOCHILD, RIGHT, STOP, VAL_NUM  # noqa: F401
