@@ -88,6 +88,22 @@ int vlg_dmv1o_decode(const void* dec, const void* attach, const int64_t* lengths
 int vlg_deptree_decode(const void* arc, const int64_t* lengths, int B, int N, int in_dtype, float* best_score,
                        int64_t* heads, void* ws, size_t ws_bytes, void* stream);
 
+/* The DMV DP fed directly from the scorer's rule tables.  Folds into the kernel's load
+ * stage what DiscriminativeNDMV._forward does between the scorer and the DP (src/model/ldndmv.py:189-209):
+ *   attach[b,h,c,v] = attach_rule[b, h, token[b,c], dir(h,c), v]   (gather by the child's token + tril/triu select)
+ *                   = mask_fill where head_mask[b,h]                (function_mask, ldndmv.py:194-198)
+ *   root[b,c]       = root_rule[(b,) token[b,c]]                    (ldndmv.py:207)
+ *   DMV1o.merge(dec, attach, root)                                  (ldndmv.py:209)
+ * and returns the expected counts in RULE space (the adjoint of those gathers):
+ *   attach_rule [B,L,T,2(dir),2(val)], dec [B,L,2,2,2], root_rule [T] (root_per_sentence = 0) or [B,T] (= 1),
+ *   token [B,L] int64 in [0,T), head_mask [B,L] uint8 or NULL, lengths [B];
+ *   logZ [B]; grad_rule [B,L,T,2,2], grad_dec [B,L,2,2,2], grad_root [B,T] (all three or none; zero-filled here);
+ *   heads [B,L+1] optional (Viterbi heads, semiring 1).  Workspace: vlg_workspace_bytes(VLG_OP_DMV1O_*, B, L+1, semiring). */
+int vlg_dmv1o_rules(const void* attach_rule, const void* dec, const void* root_rule, int root_per_sentence,
+                    const int64_t* token, const uint8_t* head_mask, const int64_t* lengths, int B, int L, int T,
+                    int in_dtype, int semiring, float mask_fill, const float* grad_logZ, float* logZ, float* grad_rule,
+                    float* grad_dec, float* grad_root, int64_t* heads, void* ws, size_t ws_bytes, void* stream);
+
 /* DMV1o.merge -- src/model/torch_struct/distributions.py:253-265.
  *   dec [B,L,2,2,2], attach [B,L,L,2], root [B,L]  ->  dec_wroot [B,L+1,2,2,2], attach_wroot [B,L+1,L+1,2]
  *   (always fp32, like the reference's torch.full). */

@@ -87,6 +87,53 @@ def dmv1o(dec, attach, lengths, semiring="log", dtype=np.float32, grad=True, glo
     return logZ.reshape(B, 1), gdec, gatt
 
 
+def dmv1o_rules(attach_rule, dec, root_rule, token, lengths, head_mask=None, semiring="log", dtype=np.float32,
+                grad=True, mask_fill=-1e20):
+    """Scorer -> DP glue of DiscriminativeNDMV._forward restated in numpy (src/model/ldndmv.py:189-209), then the
+    DP oracle, then the adjoint of the glue (scatter-add over repeated tokens).
+      attach_rule [B,L,T,2(dir),2(val)], dec [B,L,2,2,2], root_rule [T] or [1,T] or [B,T], token [B,L] in [0,T)
+    Returns logZ [B,1], grad_rule [B,L,T,2,2], grad_dec [B,L,2,2,2], grad_root [B,T] (per sentence), heads-free."""
+    dtype = np.dtype(dtype)
+    attach_rule = np.asarray(attach_rule, dtype=dtype)
+    dec = np.asarray(dec, dtype=dtype)
+    B, L, T = attach_rule.shape[:3]
+    root_rule = np.broadcast_to(np.asarray(root_rule, dtype=dtype).reshape(-1, T), (B, T))
+    token = np.asarray(token, dtype=np.int64)
+    bi = np.arange(B)[:, None, None]
+    hi = np.arange(L)[None, :, None]
+    ci = np.arange(L)[None, None, :]
+    tok = token[:, None, :]                                              # child's token id
+    left = attach_rule[bi, hi, tok, 0, :]                                # [B,L(head),L(child),val]  (:189-190)
+    right = attach_rule[bi, hi, tok, 1, :]
+    attach = np.where((ci < hi)[..., None], left, np.where((ci > hi)[..., None], right, 0))   # tril / triu  (:191-194)
+    if head_mask is not None:
+        attach = np.where(np.asarray(head_mask, dtype=bool)[:, :, None, None], dtype.type(mask_fill), attach)   # :195-199
+    root = np.take_along_axis(root_rule, token, axis=1)                 # :207
+    N = L + 1                                                           # DMV1o.merge, distributions.py:253-265
+    ma = np.full((B, N, N, 2), NEGINF, dtype=dtype)
+    md = np.full((B, N, 2, 2, 2), NEGINF, dtype=dtype)
+    ma[:, 0, 1:, 1] = root
+    ma[:, 1:, 1:, :] = attach
+    md[:, 0, 1, :, :] = 0
+    md[:, 1:] = dec
+    logZ, gmd, gma = dmv1o(md, ma, lengths, semiring, dtype, grad=grad)
+    if not grad:
+        return logZ, None, None, None
+    g_att = gma[:, 1:, 1:, :].copy()
+    if head_mask is not None:
+        g_att[np.asarray(head_mask, dtype=bool)] = 0                   # masked_fill: no gradient
+    g_rule = np.zeros_like(attach_rule)
+    bb, hh, cc = np.broadcast_arrays(bi, hi, ci)
+    tt = np.broadcast_to(tok, (B, L, L))
+    lm, rm = (cc < hh), (cc > hh)
+    for v in range(2):
+        np.add.at(g_rule, (bb[lm], hh[lm], tt[lm], 0, v), g_att[..., v][lm])
+        np.add.at(g_rule, (bb[rm], hh[rm], tt[rm], 1, v), g_att[..., v][rm])
+    g_root = np.zeros((B, T), dtype=dtype)
+    np.add.at(g_root, (np.arange(B)[:, None].repeat(L, 1), token), gma[:, 0, 1:, 1])
+    return logZ, g_rule, gmd[:, 1:].copy(), g_root
+
+
 def deptree(arc, lengths=None, semiring="log", dtype=np.float32, grad=True, glogZ=None, neg_inf=NEGINF):
     """DepTree._dp (deptree.py:25-76) + its autograd outside.  arc [B,N,N] head->child, root = 0.
     Returns logZ [B], grad_arc [B,N,N]."""
@@ -178,6 +225,51 @@ def _projective_single_root_trees(n_words):
                     ok = False
         if ok:
             yield h
+
+
+def dmv1o_tree_score(dec, attach, heads, length):
+    """Score of ONE tree (heads[c] for c = 1..length, 0 = root) under the valence rules of dmv.py:36-62 (see
+    enumerate_dmv1o).  Used to compare Viterbi trees by value when ties make the arg-max non-unique."""
+    NOCHILD, HASCHILD, LEFT, RIGHT, GO, STOP = 1, 0, 0, 1, 0, 1
+    s = 0.0
+    for head in range(0, length + 1):
+        for direction in (LEFT, RIGHT):
+            if head == 0 and direction == LEFT:
+                continue
+            kids = [c for c in range(1, length + 1) if heads[c] == head and ((c < head) == (direction == LEFT))]
+            kids.sort(key=lambda c: -abs(c - head))
+            val = NOCHILD
+            for c in kids:
+                s += float(dec[head, direction, val, GO]) + float(attach[head, c, val])
+                val = HASCHILD
+            s += float(dec[head, direction, val, STOP])
+    return s
+
+
+def is_projective_tree(heads, length):
+    "heads[1..length] form a spanning, single-rooted, projective tree over 0..length."
+    return _is_proj([int(x) for x in heads[:length + 1]], length)
+
+
+def _is_proj(h, n):
+    if sum(1 for c in range(1, n + 1) if h[c] == 0) != 1:
+        return False
+    for c in range(1, n + 1):
+        seen, x = set(), c
+        while x != 0:
+            if x in seen or not (0 <= h[x] <= n) or h[x] == x:
+                return False
+            seen.add(x)
+            x = h[x]
+    for c in range(1, n + 1):
+        lo, hi = min(c, h[c]), max(c, h[c])
+        for m in range(lo + 1, hi):
+            x = m
+            while x != 0 and x != h[c]:
+                x = h[x]
+            if x != h[c]:
+                return False
+    return True
 
 
 def enumerate_deptree(arc, length):

@@ -83,3 +83,25 @@ def deptree_decode(arc, lengths, nt=16, order=0):
     heads = np.full((B, N), -1, np.int64)
     assert lib().emu_deptree_decode(_p(arc), _p(ln), B, N, _p(best), _p(heads), nt, order) == 0
     return best, heads
+
+
+def dmv1o_rules(attach_rule, dec, root_rule, token, lengths, head_mask=None, semiring=0, grad=True, heads=False,
+                fill=-1e20, nt=16, order=0):
+    B, L, T = attach_rule.shape[:3]
+    rule = np.ascontiguousarray(attach_rule, np.float32)
+    dec = np.ascontiguousarray(dec, np.float32)
+    root = np.ascontiguousarray(np.asarray(root_rule, np.float32).reshape(-1, T))
+    per_sentence = int(root.shape[0] == B and B > 1)
+    tok = np.ascontiguousarray(token, np.int64)
+    ln = np.ascontiguousarray(lengths, np.int64)
+    hm = None if head_mask is None else np.ascontiguousarray(head_mask, np.uint8)
+    lz = np.full(B, np.nan, np.float32)
+    g_rule = np.zeros((B, L, T, 2, 2), np.float32) if grad else None
+    g_dec = np.zeros((B, L, 2, 2, 2), np.float32) if grad else None
+    g_root = np.zeros((B, T), np.float32) if grad else None
+    hd = np.full((B, L + 1), -1, np.int64) if heads else None
+    import ctypes
+    rc = lib().emu_dmv1o_rules(_p(rule), _p(dec), _p(root), per_sentence, _p(tok), _p(hm), _p(ln), B, L, T, semiring,
+                               ctypes.c_float(fill), _p(lz), _p(g_rule), _p(g_dec), _p(g_root), _p(hd), nt, order)
+    assert rc == 0
+    return lz, g_rule, g_dec, g_root, hd

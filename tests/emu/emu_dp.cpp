@@ -148,9 +148,27 @@ void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int le
     c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);
     c.gCc = (float2*)A.at(L.gCc.off); c.gCi = (float2*)A.at(L.gCi.off); c.gI = (float2*)A.at(L.gI.off);
     c.decs = (float*)A.at(L.decs.off); c.gdecs = (float*)A.at(L.gdecs.off);
+    vlg::MergedIO<In> io;
+    io.dec = dec; io.attach = attach; io.N = N; io.gdec = gdec; io.gatt = gatt; io.heads = heads;
     run_workgroup(nt, order, [&](int tid, HostX& x) {
-        vlg::dmv_run<SR, BWD, In>(c, dec, attach, N, glogZ, logZ, gdec, gatt, heads, tid, nt, x);
+        vlg::dmv_run<SR, BWD>(c, io, glogZ, logZ, tid, nt, x);
     });
+    A.check();
+}
+
+// rule-table input (RuleIO): one sentence
+template <int SR, bool BWD>
+void emu_rules_one(const vlg::RuleIO<vlg::F32In>& io, int len, float glogZ, float* logZ, int nt, int order) {
+    const int N = io.L + 1;
+    const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, 0);
+    Arena A(L.lds_bytes);
+    vlg::DmvCtx c;
+    c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
+    c.C = (float2*)A.at(L.C.off); c.I = (float2*)A.at(L.I.off); c.S = (float*)A.at(L.S.off);
+    c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);
+    c.gCc = (float2*)A.at(L.gCc.off); c.gCi = (float2*)A.at(L.gCi.off); c.gI = (float2*)A.at(L.gI.off);
+    c.decs = (float*)A.at(L.decs.off); c.gdecs = (float*)A.at(L.gdecs.off);
+    run_workgroup(nt, order, [&](int tid, HostX& x) { vlg::dmv_run<SR, BWD>(c, io, glogZ, logZ, tid, nt, x); });
     A.check();
 }
 
@@ -215,6 +233,28 @@ int dep_batch(const void* arc_, const int64_t* lengths, int B, int N, int semiri
 
 extern "C" {
 int emu_canary_trips(void) { return g_canary_trips; }
+// rule-table entry (f32): grads must be zero-filled by the caller; any of them may be null together (inside only)
+int emu_dmv1o_rules(const float* rule, const float* dec, const float* root, int root_per_sentence, const int64_t* token,
+                    const unsigned char* head_mask, const int64_t* lengths, int B, int L, int T, int semiring, float fill,
+                    float* logZ, float* g_rule, float* g_dec, float* g_root, long long* heads, int nt, int order) {
+    for (int b = 0; b < B; ++b) {
+        vlg::RuleIO<vlg::F32In> io;
+        io.rule = rule + (size_t)b * L * T * 4; io.dec = dec + (size_t)b * L * 8;
+        io.root = root + (root_per_sentence ? (size_t)b * T : 0);
+        io.token = (const long long*)token + (size_t)b * L;
+        io.head_mask = head_mask ? head_mask + (size_t)b * L : nullptr;
+        io.L = L; io.T = T; io.fill = fill;
+        io.g_rule = g_rule ? g_rule + (size_t)b * L * T * 4 : nullptr;
+        io.g_dec = g_dec ? g_dec + (size_t)b * L * 8 : nullptr;
+        io.g_root = g_root ? g_root + (size_t)b * T : nullptr;
+        io.heads = heads ? heads + (size_t)b * (L + 1) : nullptr;
+        const bool bwd = g_rule || heads;
+        const int len = (int)lengths[b];
+        if (semiring == 0) { if (bwd) emu_rules_one<0, true>(io, len, 1.f, logZ + b, nt, order); else emu_rules_one<0, false>(io, len, 1.f, logZ + b, nt, order); }
+        else { if (bwd) emu_rules_one<1, true>(io, len, 1.f, logZ + b, nt, order); else emu_rules_one<1, false>(io, len, 1.f, logZ + b, nt, order); }
+    }
+    return 0;
+}
 // decode mode: Max semiring, heads out, no gradient buffers (f32 inputs)
 int emu_dmv1o_decode(const float* dec, const float* attach, const int64_t* lengths, int B, int N, float* best,
                      long long* heads, int nt, int order) {

@@ -14,6 +14,8 @@ Reference entry points exercised (paths relative to /root/reference):
   * src/model/torch_struct/distributions.py:116-133,162-174,190-193  .max/.argmax/.marginals/.partition
   * src/model/torch_struct/dmv.py:19-66              DMV1oStruct._dp (inside; outside = autograd)
   * src/model/torch_struct/deptree.py:25-76,213-228  DepTree._dp, DepTree.enumerate
+  * src/model/ldndmv.py:185-209                      scorer -> DP glue (gather by token, tril/triu select, function
+                                                     mask, root gather, merge), re-issued with the same torch ops
   * src/model/joint.py:406-419                       DependencyBoxRel.gather_logit_simple
   * src/model/joint.py:670-674                       attention-fuse (needs a constructed module, so
                                                      those five lines are re-issued here with the
@@ -116,6 +118,60 @@ def dmv_case(name, seed, B, L, lengths_mode, normalise_attach=False, store_merge
     print(f"{name}: B={B} L={L} lengths={out['lengths'].tolist()[:8]} logZ[0]={out['logZ'][0, 0]:.6f}")
 
 
+def rules_case(name, seed, B, L, T, lengths_mode, use_mask, root_per_sentence=False):
+    """Scorer -> DP glue of DiscriminativeNDMV._forward (src/model/ldndmv.py:185-209), re-issued with the same torch
+    ops on synthetic rule tables (the module itself needs a DataModule), followed by the reference DMV1o."""
+    LEFT, RIGHT = 0, 1
+    g = torch.Generator().manual_seed(seed)
+    attach_rule = torch.randn(B, L, T, 2, 2, generator=g).log_softmax(2)
+    dec = torch.randn(B, L, 2, 2, 2, generator=g).log_softmax(-1)
+    root_rule = (torch.randn(B if root_per_sentence else 1, T, generator=g)).log_softmax(-1)
+    token = torch.randint(0, T, (B, L), generator=g)
+    head_mask = (torch.rand(B, L, generator=g) < 0.15) if use_mask else torch.zeros(B, L, dtype=torch.bool)
+    lengths = make_lengths(g, B, L, lengths_mode)
+    INF = 1e20                                                    # src/__init__.py:110
+    out = dict(attach_rule=_np(attach_rule), dec=_np(dec), root_rule=_np(root_rule), token=_np(token),
+               head_mask=_np(head_mask), lengths=_np(lengths), root_per_sentence=np.int64(root_per_sentence))
+    for tag, dt in (("", torch.float32), ("64", torch.float64)):
+        ar = attach_rule.to(dt).requires_grad_()
+        dc = dec.to(dt).requires_grad_()
+        rr = root_rule.to(dt).requires_grad_()
+        b, n = B, L
+        target_size = torch.Size([b, n, n, 2, 2])
+        attach_prob = ar.gather(2, token.reshape(b, 1, n, 1, 1).expand(target_size))            # ldndmv.py:189-190
+        left_mask = torch.tril(torch.ones(n, n, dtype=dt), diagonal=-1)
+        right_mask = torch.triu(torch.ones(n, n, dtype=dt), diagonal=1)
+        attach_prob = attach_prob[..., LEFT, :] * left_mask.unsqueeze(0).unsqueeze(-1) \
+            + attach_prob[..., RIGHT, :] * right_mask.unsqueeze(0).unsqueeze(-1)                 # :191-194
+        if use_mask:
+            attach_prob = attach_prob.masked_fill(head_mask.view(b, n, 1, 1), -INF)              # :195-199 (not in place)
+        root_prob = rr.expand(b, -1)
+        root = torch.gather(root_prob, 1, token)                                                 # :207
+        md, ma = DMV1o.merge(dc, attach_prob, root)                                              # :209
+        if dt == torch.float64:                # merge builds fp32 buffers (torch.full): redo its five lines in fp64
+            N = L + 1
+            ma = torch.full((b, N, N, 2), -1e12, dtype=dt)
+            md = torch.full((b, N, 2, 2, 2), -1e12, dtype=dt)
+            ma[:, 0, 1:, 1] = root
+            ma[:, 1:, 1:, :] = attach_prob
+            md[:, 0, 1, :, :] = 0
+            md[:, 1:] = dc
+        dist = DMV1o([md, ma], lengths)
+        logZ = dist.partition
+        g_ar, g_dc, g_rr = torch.autograd.grad(logZ.sum(), [ar, dc, rr])
+        out["logZ" + tag], out["grad_rule" + tag] = _np(logZ), _np(g_ar)
+        out["grad_dec" + tag], out["grad_root" + tag] = _np(g_dc), _np(g_rr)
+        if tag == "":
+            out["merged_dec"], out["merged_attach"] = _np(md), _np(ma)
+            arc = DMV1o([md.detach().requires_grad_(), ma.detach().requires_grad_()], lengths).argmax.sum(-1).nonzero()
+            predicted = lengths.new_zeros(B, L + 1)
+            predicted[arc[:, 0], arc[:, 2]] = arc[:, 1]
+            out["predicted"] = _np(predicted)
+            out["max"] = _np(DMV1o([md.detach(), ma.detach()], lengths).max)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: B={B} L={L} T={T} logZ[0]={out['logZ'][0, 0]:.6f}")
+
+
 def deptree_case(name, seed, B, N, lengths_mode, enumerate_=False, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     arc = torch.randn(B, N, N, generator=g) * scale
@@ -203,6 +259,9 @@ if __name__ == "__main__":
     dmv_case("dmv_B8_L40_s0", 0, 8, 40, "rand")
     dmv_case("dmv_B4_L40_s1_full", 1, 4, 40, "full", normalise_attach=True)
     dmv_case("dmv_B4_L80_s0", 0, 4, 80, "rand")
+    rules_case("rules_B4_L10_T7_s0", 0, 4, 10, 7, "rand", use_mask=True)
+    rules_case("rules_B3_L8_T3_s1_rootps", 1, 3, 8, 3, "rand", use_mask=False, root_per_sentence=True)
+    rules_case("rules_B4_L40_T45_s2", 2, 4, 40, 45, "rand", use_mask=True)
     deptree_case("deptree_B4_N6_s0_enum", 0, 4, 6, "full", enumerate_=True)
     deptree_case("deptree_B3_N5_s1_enum", 1, 3, 5, "full", enumerate_=True, scale=3.0)
     deptree_case("deptree_B4_N11_s0", 0, 4, 11, "rand")

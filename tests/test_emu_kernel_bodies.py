@@ -123,3 +123,33 @@ def test_emu_decode_heads(oracle_mod):
     ref[b, c] = h
     assert np.array_equal(heads2, ref) and np.allclose(best2, g["mbr_max"], rtol=1e-6, atol=1e-6)
     assert emu.canary_trips() == 0
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("rules_") if "L40" not in p],
+                         ids=[i for i in golden_ids("rules_") if "L40" not in i])
+def test_emu_rules_golden(oracle_mod, path):
+    """Rule-table input path (RuleIO): gather / direction select / function mask / merge folded into the load
+    stage, rule-space expected counts out -- against the reference's own ops (ldndmv.py:185-209 + DMV1o)."""
+    g = load(path)
+    hm = g["head_mask"] if g["head_mask"].any() else None
+    lz, gr, gd, groot, _ = emu.dmv1o_rules(g["attach_rule"], g["dec"], g["root_rule"], g["token"], g["lengths"], hm,
+                                           nt=16, order=0)
+    assert np.all(np.abs(lz - g["logZ64"][:, 0]) <= _tol(g["logZ64"][:, 0]))
+    assert np.abs(gr - g["grad_rule64"]).max() <= MARG_TOL and np.abs(gd - g["grad_dec64"]).max() <= MARG_TOL
+    got_root = groot if int(g["root_per_sentence"]) else groot.sum(0, keepdims=True)
+    assert np.abs(got_root - g["grad_root64"]).max() <= 4 * MARG_TOL
+    lz2, gr2, gd2, groot2, _ = emu.dmv1o_rules(g["attach_rule"], g["dec"], g["root_rule"], g["token"], g["lengths"], hm,
+                                               nt=16, order=3)
+    assert np.array_equal(lz, lz2) and np.array_equal(gd, gd2)
+    assert np.abs(gr - gr2).max() <= 1e-6        # scatter-add over repeated tokens: summation order may differ
+    lz3, *_ = emu.dmv1o_rules(g["attach_rule"], g["dec"], g["root_rule"], g["token"], g["lengths"], hm, grad=False)
+    assert np.array_equal(lz, lz3)
+    mz, _, _, _, heads = emu.dmv1o_rules(g["attach_rule"], g["dec"], g["root_rule"], g["token"], g["lengths"], hm,
+                                         semiring=1, grad=False, heads=True)
+    assert np.allclose(mz, g["max"][:, 0], rtol=1e-6, atol=1e-5)
+    # repeated tokens make equal-score trees common in rule space: compare the Viterbi trees by VALUE
+    for b, ln in enumerate(g["lengths"]):
+        assert oracle_mod.is_projective_tree(heads[b], int(ln)) and np.all(heads[b, ln + 1:] == 0)
+        sc = oracle_mod.dmv1o_tree_score(g["merged_dec"][b], g["merged_attach"][b], heads[b], int(ln))
+        assert abs(sc - g["max"][b, 0]) <= 1e-4 * max(1.0, abs(g["max"][b, 0]))
+    assert emu.canary_trips() == 0

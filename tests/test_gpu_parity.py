@@ -234,6 +234,41 @@ def test_dmv1o_edge_cases(ts):
     assert torch.equal(lz2, lz3)
 
 
+@pytest.mark.parametrize("path", golden_files("rules_"), ids=golden_ids("rules_"))
+def test_dmv1o_rules_golden(ts, path):
+    """the DP fed from the scorer's rule tables == the reference's gather / mask / merge ops + DMV1o."""
+    g = load(path)
+    hm = t(g["head_mask"]) if g["head_mask"].any() else None
+    ar = t(g["attach_rule"]).requires_grad_()
+    dc = t(g["dec"]).requires_grad_()
+    root_np = g["root_rule"] if int(g["root_per_sentence"]) else g["root_rule"][0]
+    rr = t(root_np).requires_grad_()
+    dist = ts.DMV1oRules(ar, dc, rr, t(g["token"]), t(g["lengths"]), head_mask=hm)
+    logZ = dist.partition
+    assert tuple(logZ.shape) == (ar.shape[0], 1)
+    g_ar, g_dc, g_rr = torch.autograd.grad(logZ.sum(), [ar, dc, rr])
+    assert np.all(np.abs(logZ.detach().cpu().numpy() - g["logZ64"]) <= logz_tol(g["logZ64"]))
+    assert np.abs(g_ar.cpu().numpy() - g["grad_rule64"]).max() <= MARG_TOL
+    assert np.abs(g_dc.cpu().numpy() - g["grad_dec64"]).max() <= MARG_TOL
+    assert np.abs(g_rr.cpu().numpy().reshape(g["grad_root64"].shape) - g["grad_root64"]).max() <= 4 * MARG_TOL
+    # identical to the merged-potential path on the reference's merged tensors
+    lz_m = ts.DMV1o([t(g["merged_dec"]), t(g["merged_attach"])], t(g["lengths"])).partition
+    assert torch.allclose(lz_m, logZ.detach(), rtol=1e-6, atol=1e-4)
+    assert np.allclose(dist.max.detach().cpu().numpy(), g["max"], rtol=1e-5, atol=1e-5)
+    import oracle   # repeated tokens make equal-score trees common in rule space: compare Viterbi trees by value
+    heads = dist.argmax_heads.cpu().numpy()
+    for b, ln in enumerate(g["lengths"]):
+        assert oracle.is_projective_tree(heads[b], int(ln)) and np.all(heads[b, ln + 1:] == 0)
+        sc = oracle.dmv1o_tree_score(g["merged_dec"][b], g["merged_attach"][b], heads[b], int(ln))
+        assert abs(sc - g["max"][b, 0]) <= 1e-4 * max(1.0, abs(g["max"][b, 0]))
+    # bf16 rule tables are read as bf16 by the kernel
+    d16 = ts.DMV1oRules(ar.detach().bfloat16(), dc.detach().bfloat16(), rr.detach().bfloat16(), t(g["token"]),
+                        t(g["lengths"]), head_mask=hm)
+    ref16 = ts.DMV1oRules(ar.detach().bfloat16().float(), dc.detach().bfloat16().float(), rr.detach().bfloat16().float(),
+                          t(g["token"]), t(g["lengths"]), head_mask=hm)
+    assert torch.allclose(d16.partition, ref16.partition, rtol=1e-6, atol=1e-4)
+
+
 # ------------------------------------------------------------------------------------------------ DepTree
 @pytest.mark.parametrize("path", golden_files("deptree_"), ids=golden_ids("deptree_"))
 def test_deptree_golden(ts, path):

@@ -121,3 +121,14 @@ def test_oracle_attnfuse_matches_reference(oracle_mod, path):
     att, out = oracle_mod.attn_fuse(g["vis"], g["txt"], g["vis_mid"], g["enc_x"], g["ln_weight"], g["ln_bias"],
                                     float(g["ln_eps"]), np.float64)
     assert np.abs(att - g["attmap"]).max() <= 5e-6 and np.abs(out - g["out"]).max() <= 2e-5
+
+
+@pytest.mark.parametrize("path", golden_files("rules_"), ids=golden_ids("rules_"))
+def test_oracle_rules_matches_reference(oracle_mod, path):
+    g = load(path)
+    hm = g["head_mask"] if g["head_mask"].any() else None
+    lz, gr, gd, groot = oracle_mod.dmv1o_rules(g["attach_rule"], g["dec"], g["root_rule"], g["token"], g["lengths"], hm,
+                                               "log", np.float64)
+    got_root = groot if int(g["root_per_sentence"]) else groot.sum(0, keepdims=True)
+    assert np.abs(lz - g["logZ64"]).max() <= 1e-11 and np.abs(gr - g["grad_rule64"]).max() <= 1e-11
+    assert np.abs(gd - g["grad_dec64"]).max() <= 1e-11 and np.abs(got_root - g["grad_root64"]).max() <= 1e-11

@@ -179,6 +179,26 @@ __device__ __forceinline__ T* region_ptr(const Region& r, char* smem, char* wsb)
     return reinterpret_cast<T*>((r.lds ? smem : wsb) + r.off);
 }
 
+template <int SR, int MODE, bool BWD>
+__device__ __forceinline__ DmvCtx carve_dmv(int N, int len, char* smem, char* wsb) {
+    const DmvLayout L(N, BWD, SR == VLG_SR_MAX, MODE);
+    DmvCtx c;
+    c.Ne = len + 1;
+    c.len = len;
+    c.P = chart_pitch(N);
+    c.C = region_ptr<float2>(L.C, smem, wsb);
+    c.I = region_ptr<float2>(L.I, smem, wsb);
+    c.S = region_ptr<float>(L.S, smem, wsb);
+    c.bpS = region_ptr<unsigned char>(L.bpS, smem, wsb);
+    c.bpC = region_ptr<unsigned char>(L.bpC, smem, wsb);
+    c.gCc = region_ptr<float2>(L.gCc, smem, wsb);
+    c.gCi = region_ptr<float2>(L.gCi, smem, wsb);
+    c.gI = region_ptr<float2>(L.gI, smem, wsb);
+    c.decs = region_ptr<float>(L.decs, smem, wsb);
+    c.gdecs = region_ptr<float>(L.gdecs, smem, wsb);
+    return c;
+}
+
 template <int SR, int MODE, bool BWD, typename In>
 __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* __restrict__ dec,
                                                          const typename In::T* __restrict__ attach,
@@ -202,26 +222,53 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
         return;
     }
 
-    const DmvLayout L(N, BWD, SR == VLG_SR_MAX, MODE);
     char* wsb = ws + (size_t)b * ws_stride;
-    DmvCtx c;
-    c.Ne = len + 1;
-    c.len = len;
-    c.P = chart_pitch(N);
-    c.C = region_ptr<float2>(L.C, smem, wsb);
-    c.I = region_ptr<float2>(L.I, smem, wsb);
-    c.S = region_ptr<float>(L.S, smem, wsb);
-    c.bpS = region_ptr<unsigned char>(L.bpS, smem, wsb);
-    c.bpC = region_ptr<unsigned char>(L.bpC, smem, wsb);
-    c.gCc = region_ptr<float2>(L.gCc, smem, wsb);
-    c.gCi = region_ptr<float2>(L.gCi, smem, wsb);
-    c.gI = region_ptr<float2>(L.gI, smem, wsb);
-    c.decs = region_ptr<float>(L.decs, smem, wsb);
-    c.gdecs = region_ptr<float>(L.gdecs, smem, wsb);
+    const DmvCtx c = carve_dmv<SR, MODE, BWD>(N, len, smem, wsb);
+    MergedIO<In> io;
+    io.dec = dec + dec_off;
+    io.attach = attach + att_off;
+    io.N = N;
+    io.gdec = (BWD && gdec) ? gdec + dec_off : nullptr;
+    io.gatt = (BWD && gatt) ? gatt + att_off : nullptr;
+    io.heads = (BWD && heads) ? heads + (size_t)b * N : nullptr;
     DevX x;
-    dmv_run<SR, BWD, In>(c, dec + dec_off, attach + att_off, N, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b,
-                         (BWD && gdec) ? gdec + dec_off : nullptr, (BWD && gatt) ? gatt + att_off : nullptr,
-                         (BWD && heads) ? heads + (size_t)b * N : nullptr, tid, kThreads, x);
+    dmv_run<SR, BWD>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);
+}
+
+// The same DP fed from the scorer's rule tables (RuleIO): no gathered [B,L,L,2,2]
+// tensor, no masks, no merged copies in HBM.  N = L + 1 positions; gradients return in rule space.
+template <int SR, int MODE, bool BWD, typename In>
+__global__ __launch_bounds__(kThreads) void dmv1o_rules_kernel(
+    const typename In::T* __restrict__ rule, const typename In::T* __restrict__ dec,
+    const typename In::T* __restrict__ root, int root_stride, const int64_t* __restrict__ token,
+    const uint8_t* __restrict__ head_mask, const int64_t* __restrict__ lengths, int Lw, int T, float fill,
+    const float* __restrict__ glogZ, float* __restrict__ logZ, float* __restrict__ g_rule, float* __restrict__ g_dec,
+    float* __restrict__ g_root, long long* __restrict__ heads, char* __restrict__ ws, size_t ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, N = Lw + 1;
+    const int len = (int)lengths[b];
+    if (len < 1 || len > Lw) {   // outputs were zero-filled by the launcher
+        if (tid == 0) logZ[b] = __uint_as_float(0x7fc00000u);
+        if (BWD && heads) for (int i = tid; i < N; i += kThreads) heads[(size_t)b * N + i] = 0;
+        return;
+    }
+    char* wsb = ws + (size_t)b * ws_stride;
+    const DmvCtx c = carve_dmv<SR, MODE, BWD>(N, len, smem, wsb);
+    RuleIO<In> io;
+    io.rule = rule + (size_t)b * Lw * T * 4;
+    io.dec = dec + (size_t)b * Lw * 8;
+    io.root = root + (size_t)b * root_stride;
+    io.token = reinterpret_cast<const long long*>(token) + (size_t)b * Lw;
+    io.head_mask = head_mask ? head_mask + (size_t)b * Lw : nullptr;
+    io.L = Lw;
+    io.T = T;
+    io.fill = fill;
+    io.g_rule = (BWD && g_rule) ? g_rule + (size_t)b * Lw * T * 4 : nullptr;
+    io.g_dec = (BWD && g_dec) ? g_dec + (size_t)b * Lw * 8 : nullptr;
+    io.g_root = (BWD && g_root) ? g_root + (size_t)b * T : nullptr;
+    io.heads = (BWD && heads) ? heads + (size_t)b * N : nullptr;
+    DevX x;
+    dmv_run<SR, BWD>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);
 }
 
 template <int SR, int MODE, bool BWD, typename In>
@@ -362,6 +409,43 @@ static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, 
 #undef VLG_GO
 }
 
+struct RulesArgs {
+    const void *rule, *dec, *root;
+    int root_stride;
+    const int64_t* token;
+    const uint8_t* head_mask;
+    const int64_t* lengths;
+    int B, L, T;
+    float fill;
+    const float* glogZ;
+    float *logZ, *g_rule, *g_dec, *g_root;
+    int64_t* heads;
+    void* ws;
+    size_t ws_stride, lds;
+    hipStream_t s;
+};
+
+template <int SR, int MODE, bool BWD, typename In>
+static int launch_rules(const RulesArgs& a) {
+    auto k = dmv1o_rules_kernel<SR, MODE, BWD, In>;
+    if (int rc = prep(k, a.lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(a.B), dim3(kThreads), a.lds, a.s, (const typename In::T*)a.rule,
+                       (const typename In::T*)a.dec, (const typename In::T*)a.root, a.root_stride, a.token, a.head_mask,
+                       a.lengths, a.L, a.T, a.fill, a.glogZ, a.logZ, a.g_rule, a.g_dec, a.g_root, (long long*)a.heads,
+                       (char*)a.ws, a.ws_stride);
+    return check_launch("dmv1o_rules_kernel");
+}
+
+template <int SR, bool BWD, typename In>
+static int dispatch_rules_mode(int mode, const RulesArgs& a) {
+    switch (mode) {
+        case 0: return launch_rules<SR, 0, BWD, In>(a);
+        case 1: return launch_rules<SR, 1, BWD, In>(a);
+        case 2: return launch_rules<SR, 2, BWD, In>(a);
+        default: return launch_rules<SR, 3, BWD, In>(a);
+    }
+}
+
 template <int SR, int MODE, bool BWD, typename In>
 static int launch_dep(const void* arc, const int64_t* lengths, int B, int N, const float* glogZ, float* logZ,
                       float* garc, int64_t* heads, void* ws, size_t ws_stride, size_t lds, hipStream_t stream) {
@@ -456,6 +540,45 @@ int vlg_deptree_decode(const void* arc, const int64_t* lengths, int B, int N, in
     if (B > 0 && !heads) return vlg::set_error(VLG_ERR_ARG, "deptree_decode: null heads");
     return vlg::run_dep<true>(arc, lengths, B, N, in_dtype, VLG_SR_MAX, nullptr, best_score, nullptr, heads, ws,
                               ws_bytes, stream);
+}
+
+int vlg_dmv1o_rules(const void* attach_rule, const void* dec, const void* root_rule, int root_per_sentence,
+                    const int64_t* token, const uint8_t* head_mask, const int64_t* lengths, int B, int L, int T,
+                    int in_dtype, int semiring, float mask_fill, const float* grad_logZ, float* logZ, float* grad_rule,
+                    float* grad_dec, float* grad_root, int64_t* heads, void* ws, size_t ws_bytes, void* stream) {
+    using namespace vlg;
+    const int N = L + 1;
+    if (B < 0 || L < 1 || T < 1) return set_error(VLG_ERR_SHAPE, "dmv1o_rules: bad shape B=%d L=%d T=%d", B, L, T);
+    if (N > 255) return set_error(VLG_ERR_SHAPE, "dmv1o_rules: L=%d exceeds the supported maximum of 254", L);
+    if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "dmv1o_rules: in_dtype %d", in_dtype);
+    if (semiring != VLG_SR_LOG && semiring != VLG_SR_MAX) return set_error(VLG_ERR_ARG, "dmv1o_rules: semiring %d", semiring);
+    if (B == 0) return 0;
+    if (!attach_rule || !dec || !root_rule || !token || !lengths || !logZ) return set_error(VLG_ERR_ARG, "dmv1o_rules: null buffer");
+    const bool bwd = grad_rule || grad_dec || grad_root || heads;
+    if (bwd && !heads && !(grad_rule && grad_dec && grad_root))
+        return set_error(VLG_ERR_ARG, "dmv1o_rules: pass all three gradient buffers (or only heads)");
+    const bool is_max = semiring == VLG_SR_MAX;
+    const int mode = pick_mode<DmvLayout>(N, bwd, is_max, kLdsBudget);
+    const DmvLayout Lay(N, bwd, is_max, mode);
+    if (Lay.ws_bytes * (size_t)B > ws_bytes || (Lay.ws_bytes && !ws))
+        return set_error(VLG_ERR_WORKSPACE, "dmv1o_rules: L=%d needs a %zu-byte workspace (got %zu)", L, Lay.ws_bytes * (size_t)B, ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    if (grad_rule) {   // rule-space counts are accumulated with atomics: start from zero
+        hipError_t e = hipMemsetAsync(grad_rule, 0, sizeof(float) * (size_t)B * L * T * 4, s);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_root, 0, sizeof(float) * (size_t)B * T, s);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_dec, 0, sizeof(float) * (size_t)B * L * 8, s);
+        if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    RulesArgs a{attach_rule, dec, root_rule, root_per_sentence ? T : 0, token, head_mask, lengths, B, L, T, mask_fill,
+                grad_logZ, logZ, grad_rule, grad_dec, grad_root, heads, ws, Lay.ws_bytes, Lay.lds_bytes, s};
+#define VLG_GO(SRV, INV) return bwd ? dispatch_rules_mode<SRV, true, INV>(mode, a) : dispatch_rules_mode<SRV, false, INV>(mode, a)
+    if (!is_max) {
+        if (in_dtype == VLG_F32) VLG_GO(VLG_SR_LOG, F32In);
+        VLG_GO(VLG_SR_LOG, BF16In);
+    }
+    if (in_dtype == VLG_F32) VLG_GO(VLG_SR_MAX, F32In);
+    VLG_GO(VLG_SR_MAX, BF16In);
+#undef VLG_GO
 }
 
 size_t vlg_workspace_bytes(int op, int B, int N, int semiring) {

@@ -46,6 +46,7 @@
 #define VLG_EXP(x) __builtin_amdgcn_exp2f(x)   // v_exp_f32: 2^x
 #define VLG_LOG(x) __builtin_amdgcn_logf(x)    // v_log_f32: log2 x
 #define VLG_BITS2F(u) __uint_as_float(u)
+#define VLG_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #else
 #include <cmath>
 #include <cstddef>
@@ -61,6 +62,7 @@ struct float2 { float x, y; };
 static inline float2 make_float2(float a, float b) { float2 r; r.x = a; r.y = b; return r; }
 static inline float vlg_bits2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 #define VLG_BITS2F(u) vlg_bits2f(u)
+#define VLG_ATOMIC_ADD(p, v) (*(p) += (v))
 #endif
 
 #define VLG_NEGINF (-1e12f)  // semiring zero, semirings.py:16,128 (finite sentinel, never -inf)
@@ -681,13 +683,90 @@ VLG_HD void dep_bw(const DepCtx& c, int w, int tid, int nt, X& x) {
 }
 
 // ================================================================================================
+// I/O policies of the DMV driver: how one sentence's potentials enter the load stage and where its
+// expected counts go.  `h`, `ch` are positions in the root-augmented sentence (0 = root).
+// ================================================================================================
+// (a) root-merged potentials -- what `DMV1o([dec, attach], lengths)` takes (distributions.py:245-251).
+template <typename In>
+struct MergedIO {
+    const typename In::T* dec;      // [N][2][2][2]
+    const typename In::T* attach;   // [N][N][2]
+    int N;
+    float* gdec;                    // may be null (decode mode)
+    float* gatt;
+    long long* heads;               // may be null
+    VLG_HDM int out_extent(int) const { return N; }   // outputs cover the padded square: zeros beyond the sentence
+    VLG_HDM float ld_dec(int i) const { return In::ld(dec, i); }
+    VLG_HDM float2 ld_attach(int h, int ch) const { return In::ld2(attach, ((size_t)h * N + ch) * 2); }
+    VLG_HDM void st_attach(int h, int ch, float2 g) const {
+        if (gatt) *reinterpret_cast<float2*>(gatt + ((size_t)h * N + ch) * 2) = g;
+        if (heads && g.x + g.y != 0.f) heads[ch] = h;
+    }
+    VLG_HDM bool wants_dec() const { return gdec != nullptr; }
+    VLG_HDM void st_dec(int h, int k, float g) const { gdec[h * 8 + k] = g; }
+    VLG_HDM void clear_heads(int tid, int nt) const {
+        if (heads) for (int i = tid; i < N; i += nt) heads[i] = 0;
+    }
+};
+
+// (b) the scorer's rule tables -- SURVEY.md section 8(f)1.  Folds into the load stage what the reference does
+// with five tensor ops before the DP (src/model/ldndmv.py:189-209): gather attach_rule by the child's token id,
+// pick the LEFT / RIGHT slice by tril / triu masks, mask function-word heads, gather root by token id, and
+// DMV1o.merge.  Expected counts go back in RULE space (the adjoint of that gather is a scatter-add over
+// repeated tokens: fp32 atomics into this sentence's slice; the caller zero-fills it).
+template <typename In>
+struct RuleIO {
+    const typename In::T* rule;     // attach_rule of this sentence [L][T][2(dir)][2(val)]
+    const typename In::T* dec;      // [L][2][2][2]
+    const typename In::T* root;     // root log-probs [T]
+    const long long* token;         // [L]
+    const unsigned char* head_mask; // [L] non-zero = this word takes no children (function_mask); may be null
+    int L, T;
+    float fill;                     // the reference's -INF fill for masked heads (src/__init__.py:110)
+    float* g_rule;                  // [L][T][2][2], zero-filled by the caller; may be null
+    float* g_dec;                   // [L][2][2][2]
+    float* g_root;                  // [T], zero-filled by the caller
+    long long* heads;               // [L+1]; may be null
+    VLG_HDM int out_extent(int Ne) const { return Ne; }   // only real positions: everything else is already zero
+    VLG_HDM float ld_dec(int i) const {
+        const int h = i >> 3, k = i & 7;
+        if (h == 0) return (k >> 2) == 1 ? 0.f : VLG_NEGINF;                 // dec_wroot[0,RIGHT] = one, else zero
+        return In::ld(dec, (h - 1) * 8 + k);
+    }
+    VLG_HDM size_t rule_index(int h, int ch) const {                          // h, ch >= 1, h != ch
+        return ((((size_t)(h - 1) * T + (size_t)token[ch - 1]) * 2 + (ch < h ? 0 : 1)) * 2);
+    }
+    VLG_HDM float2 ld_attach(int h, int ch) const {
+        if (ch == 0) return make_float2(VLG_NEGINF, VLG_NEGINF);             // nobody attaches the root
+        if (h == 0) return make_float2(VLG_NEGINF, In::ld(root, (size_t)token[ch - 1]));   // [0, c, NOCHILD] = root
+        if (head_mask && head_mask[h - 1]) return make_float2(fill, fill);
+        return In::ld2(rule, rule_index(h, ch));
+    }
+    VLG_HDM void st_attach(int h, int ch, float2 g) const {
+        if (heads && g.x + g.y != 0.f) heads[ch] = h;
+        if (!g_rule || ch == 0 || h == ch) return;
+        if (h == 0) { if (g.y != 0.f) VLG_ATOMIC_ADD(g_root + token[ch - 1], g.y); return; }
+        if (head_mask && head_mask[h - 1]) return;                           // masked_fill_: no gradient
+        float* p = g_rule + rule_index(h, ch);
+        if (g.x != 0.f) VLG_ATOMIC_ADD(p, g.x);
+        if (g.y != 0.f) VLG_ATOMIC_ADD(p + 1, g.y);
+    }
+    VLG_HDM bool wants_dec() const { return g_dec != nullptr; }
+    VLG_HDM void st_dec(int h, int k, float g) const {
+        if (h >= 1) g_dec[(h - 1) * 8 + k] = g;
+    }
+    VLG_HDM void clear_heads(int tid, int nt) const {
+        if (heads) for (int i = tid; i < L + 1; i += nt) heads[i] = 0;
+    }
+};
+
+// ================================================================================================
 // Whole-sentence drivers: the body of one workgroup.  `x.sync()` is __syncthreads() on the GPU and
 // the token barrier of the host phase emulator in the CPU tests.  Pointers in the context are
 // already carved (LDS and/or workspace); dec/attach/gdec/gatt/logZ point at THIS sentence.
 // ================================================================================================
-template <int SR, bool BWD, typename In, typename X>
-VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename In::T* attach, int N, float glogZ,
-                    float* logZ, float* gdec, float* gatt, long long* heads, int tid, int nt, X& x) {
+template <int SR, bool BWD, typename IO, typename X>
+VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int tid, int nt, X& x) {
     const int Ne = c.Ne, P = c.P, len = c.len;
     // ---- stage: charts to the semiring zero (dmv.py:34-35), dec into fast memory -----------------
     const float2 zz = make_float2(VLG_NEGINF, VLG_NEGINF), oo = make_float2(0.f, 0.f);
@@ -697,7 +776,7 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
         if (BWD) { c.gCc[i] = oo; c.gCi[i] = oo; c.gI[i] = oo; }
     }
     for (int i = tid; i < Ne * 8; i += nt) {
-        c.decs[i] = In::ld(dec, i) * VLG_LOG2E;
+        c.decs[i] = io.ld_dec(i) * VLG_LOG2E;
         if (BWD) c.gdecs[i] = 0.f;
     }
     x.sync();
@@ -711,7 +790,7 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
             c.C[h * P + h] = make_float2(d[1], d[3]);        // CL(h,h).v = dec[h,LEFT ,v,STOP]
             c.C[h * P + h + 1] = make_float2(d[5], d[7]);    // CR(h,h).v = dec[h,RIGHT,v,STOP]
         } else {
-            const float2 a = In::ld2(attach, ((size_t)h * N + ch) * 2);
+            const float2 a = io.ld_attach(h, ch);
             if (ch < h) c.I[h * P + ch] = make_float2(fmaf(a.x, VLG_LOG2E, d[0]), fmaf(a.y, VLG_LOG2E, d[2]));
             else c.I[h * P + ch + 1] = make_float2(fmaf(a.x, VLG_LOG2E, d[4]), fmaf(a.y, VLG_LOG2E, d[6]));
         }
@@ -761,22 +840,20 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
     // expected counts out (coalesced; padded positions get exact zeros like the reference).  Decode mode
     // (heads != null): heads[c] = the h with a non-zero attach count -- what the callers compute on the host
     // with `argmax.sum(-1).nonzero()` + a scatter (ldndmv.py:301-303, joint.py:256-258); 0 for root / padding.
-    if (heads) {
-        for (int i = tid; i < N; i += nt) heads[i] = 0;
-        x.sync();
-    }
-    for (int idx = tid; idx < N * N; idx += nt) {
-        const int h = idx / N, ch = idx - h * N;
+    io.clear_heads(tid, nt);
+    x.sync();
+    const int E = io.out_extent(Ne);
+    for (int idx = tid; idx < E * E; idx += nt) {
+        const int h = idx / E, ch = idx - h * E;
         float2 g = oo;
         if (h < Ne && ch < Ne) {
             if (ch < h) g = c.gI[h * P + ch];
             else if (ch > h) g = c.gI[h * P + ch + 1];
         }
-        if (gatt) *reinterpret_cast<float2*>(gatt + (size_t)idx * 2) = g;
-        if (heads && g.x + g.y != 0.f) heads[ch] = h;
+        io.st_attach(h, ch, g);
     }
-    if (gdec)
-        for (int idx = tid; idx < N * 8; idx += nt) {
+    if (io.wants_dec())
+        for (int idx = tid; idx < E * 8; idx += nt) {
             const int h = idx >> 3, k = idx & 7;
             float g = 0.f;
             if (h < Ne) {
@@ -787,15 +864,15 @@ VLG_HD void dmv_run(const DmvCtx& c, const typename In::T* dec, const typename I
                     g = reinterpret_cast<const float*>(c.gCc + q)[v] + reinterpret_cast<const float*>(c.gCi + q)[v];
                 }
             }
-            gdec[idx] = g;
+            io.st_dec(h, k, g);
         }
 #if defined(VLG_STAMP) && defined(__HIPCC__)
     x.sync();
     if ((tid & 63) == 0) {   // diagnostic build only: per-wave cycle sums overwrite the (padded) last rows of grad_dec
-        float* o = gdec + (size_t)(N - 1 - (tid >> 6)) * 8;
+        float* o = io.gdec + (size_t)(io.N - 1 - (tid >> 6)) * 8;
         o[0] = (float)st_body; o[1] = (float)st_sync; o[2] = (float)st_bbody; o[3] = (float)st_bsync;
         o[4] = (float)(st_end - st_t0); o[5] = (float)st_stage; o[6] = 0.f; o[7] = 0.f;
-        float* o2 = gdec + (size_t)(N - 1 - 8 - (tid >> 6)) * 8;
+        float* o2 = io.gdec + (size_t)(io.N - 1 - 8 - (tid >> 6)) * 8;
         for (int k = 0; k < 8; ++k) o2[k] = (float)x.acc[k];
     }
 #endif

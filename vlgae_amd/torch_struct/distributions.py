@@ -139,6 +139,43 @@ class DMV1o(StructDistribution):
         return F.dmv1o_merge_autograd(dec, attach, root, one, zero)
 
 
+class DMV1oRules(StructDistribution):
+    """Extension: the DMV of `DMV1o`, parameterised by the scorer's rule tables instead of
+    merged per-position potentials.  It replaces this block of DiscriminativeNDMV._forward + loss
+    (src/model/ldndmv.py:185-209, 277-281)
+
+        attach = attach_rule.gather(2, token...)  -> tril/triu direction select -> function mask
+        root   = root_rule.gather(1, token);  merged = DMV1o.merge(dec, attach, root);  DMV1o(merged, lengths)
+
+    with one kernel launch that gathers inside its load stage and returns gradients in rule space.
+
+      attach_rule [B,L,T,2(dir),2(valence)]   log-probs over the T child tokens (ldndmv.py:185)
+      dec         [B,L,2,2,2]                 root_rule [T] / [1,T] / [B,T]      token [B,L] int64
+      head_mask   [B,L] bool, True = the word takes no children (`function_mask`, ldndmv.py:194-198)
+    partition / max: [B,1], differentiable w.r.t. attach_rule, dec, root_rule.  argmax_heads: [B,L+1]."""
+
+    def __init__(self, attach_rule, dec, root_rule, token, lengths, head_mask=None, mask_fill=-1e20, args={}):
+        super().__init__(dec, lengths=lengths, args=args)
+        self.log_potentials = [attach_rule, dec, root_rule]
+        self.token, self.head_mask, self.mask_fill = token, head_mask, mask_fill
+
+    def _sum(self, semiring):
+        a, d, r = self.log_potentials
+        return F.dmv1o_rules_sum(a, d, r, self.token, self.lengths, self.head_mask, semiring.kernel_id, self.mask_fill)
+
+    def _marginals(self, semiring):
+        "Rule-space expected counts (Log) or best-tree rule indicators (Max): the attach_rule part."
+        a, d, r = self.log_potentials
+        return F.dmv1o_rules_run(a, d, r, self.token, self.lengths, semiring.kernel_id, True, self.head_mask,
+                                 False, self.mask_fill)["grad_rule"]
+
+    @lazy_property
+    def argmax_heads(self):
+        a, d, r = self.log_potentials
+        return F.dmv1o_rules_run(a, d, r, self.token, self.lengths, MaxSemiring.kernel_id, False, self.head_mask, True,
+                                 self.mask_fill)["heads"]
+
+
 class DependencyCRF(StructDistribution):
     """Projective single-root dependency CRF (reference: distributions.py:269-298, deptree.py:14-76).
 

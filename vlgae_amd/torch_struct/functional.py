@@ -123,6 +123,78 @@ def deptree_decode(arc, lengths=None):
     return best, heads
 
 
+def dmv1o_rules_run(attach_rule, dec, root_rule, token, lengths, semiring, want_grad, head_mask=None, want_heads=False,
+                    mask_fill=-1e20, grad_logZ=None):
+    """Raw launcher of the rule-table DP (include/vlgae_amd.h: vlg_dmv1o_rules).
+    attach_rule [B,L,T,2,2], dec [B,L,2,2,2], root_rule [T] / [1,T] / [B,T], token [B,L] int64, head_mask [B,L] bool.
+    Returns dict(logZ [B], grad_rule, grad_dec, grad_root [B,T], heads [B,L+1]) with the requested entries."""
+    _C.require_gpu(attach_rule, "dmv1o_rules")
+    B, L, T = attach_rule.shape[:3]
+    if tuple(attach_rule.shape) != (B, L, T, 2, 2) or tuple(dec.shape) != (B, L, 2, 2, 2) or tuple(token.shape) != (B, L):
+        raise ValueError(f"attach_rule {tuple(attach_rule.shape)}, dec {tuple(dec.shape)}, token {tuple(token.shape)}")
+    root2 = root_rule.reshape(-1, T)
+    if root2.shape[0] not in (1, B):
+        raise ValueError(f"root_rule must be [T], [1,T] or [B,T]; got {tuple(root_rule.shape)}")
+    dt, rule_c = _C.in_dtype(attach_rule.detach())
+    dec_c = dec.detach().to(rule_c.dtype).contiguous()
+    root_c = root2.detach().to(rule_c.dtype).contiguous()
+    dev = attach_rule.device
+    token = token.to(device=dev, dtype=torch.int64).contiguous()
+    hm = None if head_mask is None else head_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    lengths = _lengths(lengths, B, dev)
+    out = {"logZ": torch.empty(B, dtype=torch.float32, device=dev)}
+    g_rule = g_dec = g_root = heads = None
+    if want_grad:
+        g_rule = torch.empty((B, L, T, 2, 2), dtype=torch.float32, device=dev)
+        g_dec = torch.empty((B, L, 2, 2, 2), dtype=torch.float32, device=dev)
+        g_root = torch.empty((B, T), dtype=torch.float32, device=dev)
+        out.update(grad_rule=g_rule, grad_dec=g_dec, grad_root=g_root)
+    if want_heads:
+        heads = torch.empty((B, L + 1), dtype=torch.int64, device=dev)
+        out["heads"] = heads
+    op = _C.OP_DMV1O_INSIDE_OUTSIDE if (want_grad or want_heads) else _C.OP_DMV1O_INSIDE
+    ws, nb = _workspace(op, B, L + 1, semiring, dev)
+    g = None if grad_logZ is None else grad_logZ.detach().to(torch.float32).reshape(B).contiguous()
+    _C.check(_C.lib().vlg_dmv1o_rules(_C.ptr(rule_c), _C.ptr(dec_c), _C.ptr(root_c), int(root2.shape[0] == B and B > 1),
+                                      _C.ptr(token), _C.ptr(hm),
+                                      _C.ptr(lengths), B, L, T, dt, semiring, float(mask_fill), _C.ptr(g),
+                                      _C.ptr(out["logZ"]), _C.ptr(g_rule), _C.ptr(g_dec), _C.ptr(g_root), _C.ptr(heads),
+                                      _C.ptr(ws), nb, _C.stream_of(attach_rule)), "dmv1o_rules")
+    return out
+
+
+class _DMV1oRulesSum(torch.autograd.Function):
+    """semiring-sum over trees as a function of the scorer's rule tables; backward = rule-space expected counts."""
+
+    @staticmethod
+    def forward(ctx, attach_rule, dec, root_rule, token, lengths, head_mask, semiring, mask_fill):
+        want = any(ctx.needs_input_grad[:3])
+        r = dmv1o_rules_run(attach_rule, dec, root_rule, token, lengths, semiring, want, head_mask, False, mask_fill)
+        if want:
+            ctx.save_for_backward(r["grad_rule"], r["grad_dec"], r["grad_root"])
+        ctx.meta = (attach_rule.dtype, dec.dtype, root_rule.dtype, tuple(root_rule.shape))
+        return r["logZ"].unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g_rule, g_dec, g_root = ctx.saved_tensors
+        d0, d1, d2, root_shape = ctx.meta
+        g = grad_out.reshape(-1).to(torch.float32)
+        gr = (g_rule * g.view(-1, 1, 1, 1, 1)).to(d0) if ctx.needs_input_grad[0] else None
+        gd = (g_dec * g.view(-1, 1, 1, 1, 1)).to(d1) if ctx.needs_input_grad[1] else None
+        gt = None
+        if ctx.needs_input_grad[2]:
+            gt = g_root * g.view(-1, 1)
+            B, T = gt.shape
+            per_sentence = len(root_shape) == 2 and root_shape[0] == B and B > 1
+            gt = (gt if per_sentence else gt.sum(0)).reshape(root_shape).to(d2)   # a shared root table sums over the batch
+        return gr, gd, gt, None, None, None, None, None
+
+
+def dmv1o_rules_sum(attach_rule, dec, root_rule, token, lengths, head_mask=None, semiring=0, mask_fill=-1e20):
+    return _DMV1oRulesSum.apply(attach_rule, dec, root_rule, token, lengths, head_mask, semiring, mask_fill)
+
+
 class _DMV1oSum(torch.autograd.Function):
     """semiring-sum over all trees; d/d(potentials) = expected counts (Log) / best tree (Max)."""
 
