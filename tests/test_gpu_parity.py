@@ -269,6 +269,30 @@ def test_dmv1o_rules_golden(ts, path):
     assert torch.allclose(d16.partition, ref16.partition, rtol=1e-6, atol=1e-4)
 
 
+def test_dmv1o_hip_graph_capture(ts):
+    """The C ABI only enqueues work on the stream it is given (no allocation, no synchronisation), so a step can
+    be captured into a HIP graph and replayed on new data in place."""
+    from vlgae_amd.torch_struct import functional as F
+    B, L = 32, 24
+    gen = torch.Generator().manual_seed(3)
+    md = torch.randn(B, L + 1, 2, 2, 2, generator=gen).to(dev())
+    ma = torch.randn(B, L + 1, L + 1, 2, generator=gen).to(dev())
+    lengths = torch.randint(1, L + 1, (B,), generator=gen).to(dev())
+    F.dmv1o_run(md, ma, lengths, 0, True)           # warm-up outside capture (sets kernel attributes once)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        lz, gd, ga = F.dmv1o_run(md, ma, lengths, 0, True)
+    for seed in (4, 5):
+        gen = torch.Generator().manual_seed(seed)
+        md.copy_(torch.randn(B, L + 1, 2, 2, 2, generator=gen))
+        ma.copy_(torch.randn(B, L + 1, L + 1, 2, generator=gen))
+        graph.replay()
+        torch.cuda.synchronize()
+        lz2, gd2, ga2 = F.dmv1o_run(md, ma, lengths, 0, True)
+        assert torch.equal(lz, lz2) and torch.equal(gd, gd2) and torch.equal(ga, ga2)
+
+
 # ------------------------------------------------------------------------------------------------ DepTree
 @pytest.mark.parametrize("path", golden_files("deptree_"), ids=golden_ids("deptree_"))
 def test_deptree_golden(ts, path):
