@@ -404,6 +404,13 @@ def test_attn_fuse_golden(path):
                                     t(g["ln_bias"]), float(g["ln_eps"]), return_attmap=True)
     assert np.abs(att.detach().cpu().numpy() - g["attmap"]).max() <= 2e-5       # softmax probabilities
     assert np.abs(out.detach().cpu().numpy() - g["out"]).max() <= 1e-4          # LayerNorm output, O(1) values
+    # without the attention map the register-blocked fast kernel runs (h <= 256, 16-byte aligned rows)
+    out2 = align.attention_fuse(t(g["vis"]), t(g["txt"]), t(g["vis_mid"]), t(g["enc_x"]), t(g["ln_weight"]),
+                                t(g["ln_bias"]), float(g["ln_eps"]))
+    assert np.abs(out2.cpu().numpy() - g["out"]).max() <= 1e-4
+    out3 = align.attention_fuse(t(g["vis"]).bfloat16(), t(g["txt"]).bfloat16(), t(g["vis_mid"]).bfloat16(),
+                                t(g["enc_x"]).bfloat16(), t(g["ln_weight"]), t(g["ln_bias"]), float(g["ln_eps"]))
+    assert np.abs(out3.cpu().numpy() - g["out"]).max() <= 0.15                   # bf16-rounded inputs (8 bits), O(1) outputs
 
 
 def test_attn_fuse_large_v(oracle_mod):
@@ -418,3 +425,12 @@ def test_attn_fuse_large_v(oracle_mod):
     out, att = align.attention_fuse(t(vis), t(txt), t(mid), t(enc), t(gm), t(bt), 1e-5, return_attmap=True)
     assert np.abs(att.detach().cpu().numpy() - ref_att).max() <= 2e-5
     assert np.abs(out.detach().cpu().numpy() - ref_out).max() <= 1e-4
+    out2 = align.attention_fuse(t(vis), t(txt), t(mid), t(enc), t(gm), t(bt), 1e-5)
+    assert np.abs(out2.cpu().numpy() - ref_out).max() <= 1e-4
+    # a mid-sized V that still fits the fast kernel's LDS budget, ragged tile (V % 32 != 0), L > 40 (two word chunks)
+    B, L, V = 3, 47, 203
+    vis, txt = rng.standard_normal((B, V, d)).astype(np.float32) * 0.3, rng.standard_normal((B, L + 1, d)).astype(np.float32) * 0.3
+    mid, enc = rng.standard_normal((B, V, h)).astype(np.float32), rng.standard_normal((B, L, h)).astype(np.float32)
+    _, ref_out = oracle_mod.attn_fuse(vis, txt, mid, enc, gm, bt, 1e-5, np.float64)
+    out3 = align.attention_fuse(t(vis), t(txt), t(mid), t(enc), t(gm), t(bt), 1e-5)
+    assert np.abs(out3.cpu().numpy() - ref_out).max() <= 1e-4

@@ -430,6 +430,160 @@ __global__ __launch_bounds__(kAlignThreads) void attn_fuse_kernel(
     }
 }
 
+// ---- attention-fuse, fast path -------------------------------------------------------------------------
+// Same data flow as attn_fuse_kernel (which stays as the any-shape fallback and for out_att), written for
+// throughput: 16-byte LDS reads, register blocking (5 words x 1 region per thread for the scores; one output
+// channel x all words per thread for att . vis_mid with the region tile of that channel held in registers),
+// every loop fully unrolled so the LDS latency is paid once per tile, not once per element.
+constexpr int kQCap = 40;   // words per block (register-resident accumulators)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const uint16_t* p) {   // four bf16 -> fp32
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <typename In>
+__global__ __launch_bounds__(kAlignThreads) void attn_fuse_fast_kernel(
+    const typename In::T* __restrict__ vis, const typename In::T* __restrict__ txt,
+    const typename In::T* __restrict__ vis_mid, const typename In::T* __restrict__ enc_x,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int Lq, int V, int d, int h, float eps,
+    float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const int q0 = blockIdx.x * kQCap, qn = min(kQCap, Lq - q0);
+    const int dp = d + 4, hp = h + 4, Vp = ((V + 31) & ~31) + 4;   // rows padded to whole 32-region tiles
+    // LDS: [att_s QCap x Vp][st_s QCap x 2][region (union): txt_s QCap x dp + vis tile 32 x dp | mid tile 32 x hp | y_s QCap x hp]
+    float* att_s = smem;
+    float* st_s = att_s + kQCap * Vp;
+    float* region = st_s + kQCap * 2;
+    float* txt_s = region;
+    float* vtile = region + kQCap * dp;
+
+    // ---- words of this block (root slot skipped: txt[:, 1:], joint.py:671) ----
+    for (int i = tid; i < qn * (d >> 2); i += kAlignThreads) {
+        const int q = i / (d >> 2), k4 = i - q * (d >> 2);
+        *reinterpret_cast<float4*>(txt_s + q * dp + k4 * 4) = ld4(txt + ((size_t)b * (Lq + 1) + 1 + q0 + q) * d + k4 * 4);
+    }
+    // ---- scores: thread = (region v of the tile, word group qg); words qg, qg+8, ... ----
+    const int sv = tid & 31, qg = tid >> 5;
+    for (int v0 = 0; v0 < V; v0 += 32) {
+        const int vn = min(32, V - v0);
+        __syncthreads();
+        for (int i = tid; i < vn * (d >> 2); i += kAlignThreads) {
+            const int v = i / (d >> 2), k4 = i - v * (d >> 2);
+            *reinterpret_cast<float4*>(vtile + v * dp + k4 * 4) = ld4(vis + ((size_t)b * V + v0 + v) * d + k4 * 4);
+        }
+        __syncthreads();
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* yrow = vtile + min(sv, vn - 1) * dp;
+        for (int k4 = 0; k4 < (d >> 2); ++k4) {
+            const float4 y = *reinterpret_cast<const float4*>(yrow + k4 * 4);
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const float4 x = *reinterpret_cast<const float4*>(txt_s + min(qg + 8 * u, qn - 1) * dp + k4 * 4);
+                acc[u] = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, acc[u]))));
+            }
+        }
+        if (sv < vn)
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+                if (qg + 8 * u < qn) att_s[(qg + 8 * u) * Vp + v0 + sv] = acc[u];
+    }
+    __syncthreads();
+    // ---- softmax over regions: 4 lanes per word (NO region masking: faithful to joint.py:670-672) ----
+    {
+        const int q = tid >> 2, part = tid & 3, vq = (V + 3) >> 2, lo = part * vq, hi = min(V, lo + vq);
+        if (q < kQCap) {   // 160 lanes, whole waves only diverge at the tail
+            float* row = att_s + min(q, qn - 1) * Vp;
+            float m = neg_infinity();
+            for (int v = lo; v < hi; ++v) m = fmaxf(m, row[v]);
+            m = fmaxf(m, __shfl_xor(m, 1, 64));
+            m = fmaxf(m, __shfl_xor(m, 2, 64));
+            float z = 0.f;
+            for (int v = lo; v < hi; ++v) z += __expf(row[v] - m);
+            z += __shfl_xor(z, 1, 64);
+            z += __shfl_xor(z, 2, 64);
+            const float inv = 1.f / z;
+            if (q < qn)
+                for (int v = lo; v < hi; ++v) row[v] = __expf(row[v] - m) * inv;
+        }
+    }
+    // zero the padding columns so that whole 32-region tiles can be consumed below
+    for (int i = tid; i < qn * (Vp - V); i += kAlignThreads) {
+        const int q = i / (Vp - V), v = V + (i - q * (Vp - V));
+        att_s[q * Vp + v] = 0.f;
+    }
+    // ---- y = att . vis_mid : thread owns output channels c = tid (+256, ...), all words in registers ----
+    float* mtile = region;   // [32][hp]   (txt_s / vis tile are dead from here on)
+    for (int c0 = 0; c0 < h; c0 += kAlignThreads) {
+        const int c = c0 + tid;
+        const bool cin = c < h;
+        float yacc[kQCap];
+#pragma unroll
+        for (int q = 0; q < kQCap; ++q) yacc[q] = 0.f;
+        for (int v0 = 0; v0 < V; v0 += 32) {
+            const int vn = min(32, V - v0);
+            __syncthreads();
+            for (int i = tid; i < 32 * (h >> 2); i += kAlignThreads) {   // rows past vn are zero-filled
+                const int v = i / (h >> 2), c4 = i - v * (h >> 2);
+                const float4 val = v < vn ? ld4(vis_mid + ((size_t)b * V + v0 + v) * h + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(mtile + v * hp + c4 * 4) = val;
+            }
+            __syncthreads();
+            float mreg[32];
+#pragma unroll
+            for (int v = 0; v < 32; ++v) mreg[v] = mtile[v * hp + (cin ? c : 0)];
+#pragma unroll
+            for (int q = 0; q < kQCap; ++q) {
+                if (q < qn) {   // block-uniform
+                    const float* arow = att_s + q * Vp + v0;
+                    float a = yacc[q];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float4 p = *reinterpret_cast<const float4*>(arow + 4 * j);   // broadcast read
+                        a = fmaf(p.x, mreg[4 * j], fmaf(p.y, mreg[4 * j + 1], fmaf(p.z, mreg[4 * j + 2], fmaf(p.w, mreg[4 * j + 3], a))));
+                    }
+                    yacc[q] = a;
+                }
+            }
+        }
+        // residual: y = enc_x + att . vis_mid, parked in LDS for the row statistics
+        __syncthreads();
+        float* y_s = region;   // [QCap][hp]
+#pragma unroll
+        for (int q = 0; q < kQCap; ++q)
+            if (q < qn && cin) y_s[q * hp + c] = yacc[q] + In::ld(enc_x, ((size_t)b * Lq + q0 + q) * h + c);
+        // (for h > 256 the loop over c0 would overwrite y_s before the statistics: handled by the launcher, h <= 256)
+    }
+    __syncthreads();
+    // ---- LayerNorm statistics: wave w takes words w, w+4, ...; biased variance like nn.LayerNorm ----
+    {
+        const float* y_s = region;
+        for (int q = wave; q < qn; q += 4) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int c = lane; c < h; c += 64) { const float t = y_s[q * hp + c]; s1 += t; s2 = fmaf(t, t, s2); }
+#pragma unroll
+            for (int k = 1; k < 64; k <<= 1) { s1 += __shfl_xor(s1, k, 64); s2 += __shfl_xor(s2, k, 64); }
+            if (lane == 0) {
+                const float mean = s1 / (float)h;
+                st_s[q * 2] = mean;
+                st_s[q * 2 + 1] = rsqrtf(fmaxf(s2 / (float)h - mean * mean, 0.f) + eps);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const float* y_s = region;
+        for (int i = tid; i < qn * h; i += kAlignThreads) {
+            const int q = i / h, c = i - q * h;
+            out[((size_t)b * Lq + q0) * h + i] = (y_s[q * hp + c] - st_s[q * 2]) * st_s[q * 2 + 1] * gamma[c] + beta[c];
+        }
+    }
+}
+
 }  // namespace vlg
 
 extern "C" {
@@ -492,14 +646,41 @@ int vlg_attn_fuse(const void* vis, const void* txt, const void* vis_mid, const v
         return set_error(VLG_ERR_SHAPE, "attn_fuse: bad shape B=%d L=%d V=%d d=%d h=%d", B, L, V, d, h);
     if (B == 0) return 0;
     if (!vis || !txt || !vis_mid || !enc_x || !gamma || !beta || !out) return set_error(VLG_ERR_ARG, "attn_fuse: null buffer");
+    if (B > 65535) return set_error(VLG_ERR_SHAPE, "attn_fuse: B=%d exceeds grid.y", B);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "attn_fuse: in_dtype %d", in_dtype);
+    // ---- fast path: 16-byte aligned rows, one pass over the output channels, no attention map requested ----
+    if (!out_att && d % 4 == 0 && h % 4 == 0 && h <= kAlignThreads) {
+        const size_t dp = d + 4, hp = h + 4, Vp = ((V + 31) & ~31) + 4;
+        size_t region = (size_t)kQCap * dp + 32 * dp;
+        if (32 * hp > region) region = 32 * hp;
+        if ((size_t)kQCap * hp > region) region = (size_t)kQCap * hp;
+        const size_t lds_fast = sizeof(float) * ((size_t)kQCap * Vp + kQCap * 2 + region);
+        if (lds_fast <= 156 * 1024) {
+            dim3 grid((L + kQCap - 1) / kQCap, B);
+#define VLG_FAST(INV)                                                                                              \
+    do {                                                                                                           \
+        auto k = attn_fuse_fast_kernel<INV>;                                                                       \
+        if (lds_fast > 60 * 1024) {                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);        \
+            if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));        \
+        }                                                                                                          \
+        hipLaunchKernelGGL(k, grid, dim3(kAlignThreads), lds_fast, s, (const INV::T*)vis, (const INV::T*)txt,      \
+                           (const INV::T*)vis_mid, (const INV::T*)enc_x, gamma, beta, L, V, d, h, eps, out);       \
+    } while (0)
+            if (in_dtype == VLG_F32) VLG_FAST(F32In);
+            else VLG_FAST(BF16In);
+#undef VLG_FAST
+            return check_launch("attn_fuse_fast_kernel");
+        }
+    }
     const size_t tile_f = (size_t)kFT * (size_t)((d + 1) > h ? (d + 1) : h);
     const size_t per_q = (size_t)(d + 1) + V + h + 2;
     int QC = L < 32 ? L : 32;
     while (QC > 1 && sizeof(float) * (tile_f + per_q * QC) > 150 * 1024) QC >>= 1;
     const size_t lds = sizeof(float) * (tile_f + per_q * QC);
     if (lds > 150 * 1024) return set_error(VLG_ERR_SHAPE, "attn_fuse: V=%d d=%d h=%d exceed the LDS budget", V, d, h);
-    if (B > 65535) return set_error(VLG_ERR_SHAPE, "attn_fuse: B=%d exceeds grid.y", B);
-    hipStream_t s = (hipStream_t)stream;
 #define VLG_LAUNCH(INV)                                                                                            \
     do {                                                                                                           \
         auto k = attn_fuse_kernel<INV>;                                                                            \
@@ -513,8 +694,7 @@ int vlg_attn_fuse(const void* vis, const void* txt, const void* vis_mid, const v
                            h, eps, QC, out_att, out);                                                              \
     } while (0)
     if (in_dtype == VLG_F32) VLG_LAUNCH(F32In);
-    else if (in_dtype == VLG_BF16) VLG_LAUNCH(BF16In);
-    else return set_error(VLG_ERR_DTYPE, "attn_fuse: in_dtype %d", in_dtype);
+    else VLG_LAUNCH(BF16In);
 #undef VLG_LAUNCH
     return check_launch("attn_fuse_kernel");
 }
