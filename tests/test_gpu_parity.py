@@ -404,7 +404,7 @@ def test_attn_fuse_golden(path):
                                     t(g["ln_bias"]), float(g["ln_eps"]), return_attmap=True)
     assert np.abs(att.detach().cpu().numpy() - g["attmap"]).max() <= 2e-5       # softmax probabilities
     assert np.abs(out.detach().cpu().numpy() - g["out"]).max() <= 1e-4          # LayerNorm output, O(1) values
-    # without the attention map the register-blocked fast kernel runs (h <= 256, 16-byte aligned rows)
+    # without the attention map the matrix-core kernel runs (h <= 256, d and h multiples of 16)
     out2 = align.attention_fuse(t(g["vis"]), t(g["txt"]), t(g["vis_mid"]), t(g["enc_x"]), t(g["ln_weight"]),
                                 t(g["ln_bias"]), float(g["ln_eps"]))
     assert np.abs(out2.cpu().numpy() - g["out"]).max() <= 1e-4
@@ -427,10 +427,37 @@ def test_attn_fuse_large_v(oracle_mod):
     assert np.abs(out.detach().cpu().numpy() - ref_out).max() <= 1e-4
     out2 = align.attention_fuse(t(vis), t(txt), t(mid), t(enc), t(gm), t(bt), 1e-5)
     assert np.abs(out2.cpu().numpy() - ref_out).max() <= 1e-4
-    # a mid-sized V that still fits the fast kernel's LDS budget, ragged tile (V % 32 != 0), L > 40 (two word chunks)
+    # a mid-sized V: four region chunks in the matrix-core kernel, ragged last chunk, three word tiles
     B, L, V = 3, 47, 203
     vis, txt = rng.standard_normal((B, V, d)).astype(np.float32) * 0.3, rng.standard_normal((B, L + 1, d)).astype(np.float32) * 0.3
     mid, enc = rng.standard_normal((B, V, h)).astype(np.float32), rng.standard_normal((B, L, h)).astype(np.float32)
     _, ref_out = oracle_mod.attn_fuse(vis, txt, mid, enc, gm, bt, 1e-5, np.float64)
     out3 = align.attention_fuse(t(vis), t(txt), t(mid), t(enc), t(gm), t(bt), 1e-5)
     assert np.abs(out3.cpu().numpy() - ref_out).max() <= 1e-4
+
+
+@pytest.mark.parametrize("B,L,V,d,h", [
+    (3, 40, 36, 128, 256),    # the benchmark shape: one chunk of three region tiles
+    (2, 1, 1, 16, 16),        # smallest legal case: one word, one region, one channel tile
+    (2, 16, 16, 32, 64),      # exact tiles everywhere
+    (2, 17, 17, 48, 80),      # one past a tile in words and regions; d and h not powers of two
+    (2, 33, 64, 144, 240),    # d = 128 + 16: a short second K chunk; V = 64 is the largest single chunk
+    (2, 9, 65, 256, 128),     # V = 65: second streamed chunk holds a single region; two full K chunks
+    (1, 50, 130, 64, 256),    # three streamed chunks, ragged last
+])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_attn_fuse_mfma_shapes(oracle_mod, B, L, V, d, h, dt):
+    """Matrix-core attention-fuse against the fp64 oracle over tile / chunk edge cases (joint.py:670-674)."""
+    from vlgae_amd import align
+    rng = np.random.default_rng(B * 1000 + L * 31 + V)
+    vis, txt = rng.standard_normal((B, V, d)).astype(np.float32) * 0.4, rng.standard_normal((B, L + 1, d)).astype(np.float32) * 0.4
+    mid, enc = rng.standard_normal((B, V, h)).astype(np.float32), rng.standard_normal((B, L, h)).astype(np.float32)
+    gm, bt = (rng.random(h) + 0.5).astype(np.float32), rng.standard_normal(h).astype(np.float32)
+    args = [t(vis), t(txt), t(mid), t(enc)]
+    if dt == "bf16":   # the oracle sees the same bf16-rounded values, so the tolerance stays the fp32 one
+        args = [a.bfloat16() for a in args]
+        vis, txt, mid, enc = (a.float().cpu().numpy() for a in args)
+    _, ref_out = oracle_mod.attn_fuse(vis, txt, mid, enc, gm, bt, 1e-5, np.float64)
+    out = align.attention_fuse(*args, t(gm), t(bt), 1e-5)
+    assert out.shape == (B, L, h) and out.dtype == torch.float32
+    assert np.abs(out.cpu().numpy() - ref_out).max() <= 1e-4

@@ -435,7 +435,20 @@ __global__ __launch_bounds__(kAlignThreads) void attn_fuse_kernel(
 // throughput: 16-byte LDS reads, register blocking (5 words x 1 region per thread for the scores; one output
 // channel x all words per thread for att . vis_mid with the region tile of that channel held in registers),
 // every loop fully unrolled so the LDS latency is paid once per tile, not once per element.
-constexpr int kQCap = 40;   // words per block (register-resident accumulators)
+// ---- matrix-core path ----------------------------------------------------------------------------------
+// One WAVE = one sentence x 16 words; no LDS, no barriers, every wave independent (B * ceil(L/16) waves).
+// Both contractions run as v_mfma_f32_16x16x4_f32 (exact fp32 products; bf16 inputs are widened on load), chained
+// without moving data between lanes:
+//   GEMM 1 computes the TRANSPOSED score tile  S^T[region][word] = vis . txt^T  (A = region rows, B = word rows),
+//          whose accumulator layout  lane (r, g), register n  <->  (word r, region 16t + 4g + n)  ...
+//   GEMM 2 ... is exactly the B-operand layout of  Y^T[channel][word] = mid^T . P^T  when the K index of MFMA (t, n)
+//          is read as region 16t + 4g + n, so the softmaxed accumulators feed the second MFMA directly.
+// The softmax over regions and the LayerNorm over channels are both "registers x the four 16-lane groups" reductions
+// (two xor-shuffles).  Operand fragments come straight from global memory: a lane's four K values of a chunk are 16
+// contiguous bytes, and the dot product does not care that the K order is permuted identically on both operands.
+constexpr int kAttnMaxCT = 16;  // channel tiles of 16: h <= 256
+constexpr int kAttnKJ = 8;      // 16-feature groups per K chunk (128 features)
+constexpr int kAttnPF = 4;      // channel tiles of vis_mid operands in flight ahead of the MFMAs
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ld4(const uint16_t* p) {   // four bf16 -> fp32
@@ -443,145 +456,195 @@ __device__ __forceinline__ float4 ld4(const uint16_t* p) {   // four bf16 -> fp3
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                        __uint_as_float(u.y & 0xffff0000u));
 }
+// Buffer-addressed element read: a per-lane offset (VGPR) reused by a run of reads + a uniform offset (SGPR) per read.
+__device__ __forceinline__ float buf_ld(F32In, __amdgpu_buffer_rsrc_t r, int lane_off, int uni_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off * 4, uni_off * 4, 0));
+}
+__device__ __forceinline__ float buf_ld(BF16In, __amdgpu_buffer_rsrc_t r, int lane_off, int uni_off) {
+    const unsigned short u = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, lane_off * 2, uni_off * 2, 0);
+    return __uint_as_float((uint32_t)u << 16);
+}
+__device__ __forceinline__ float group_sum4(float x) {   // sum over the four 16-lane groups
+    x += __shfl_xor(x, 16, 64);
+    return x + __shfl_xor(x, 32, 64);
+}
+__device__ __forceinline__ float group_max4(float x) {
+    x = fmaxf(x, __shfl_xor(x, 16, 64));
+    return fmaxf(x, __shfl_xor(x, 32, 64));
+}
 
-template <typename In>
-__global__ __launch_bounds__(kAlignThreads) void attn_fuse_fast_kernel(
+// T (region tiles) is a template parameter and everything else is predicated by clamping, not branching: a uniform
+// branch would end the basic block and make every group of operand loads wait out its full latency before the next
+// is issued (measured: 31 us with branches).  Channel tiles past h/16 recompute tile h/16-1 and are never stored.
+template <typename In, int T>
+__global__ __launch_bounds__(64) void attn_fuse_mfma_kernel(
     const typename In::T* __restrict__ vis, const typename In::T* __restrict__ txt,
     const typename In::T* __restrict__ vis_mid, const typename In::T* __restrict__ enc_x,
     const float* __restrict__ gamma, const float* __restrict__ beta, int Lq, int V, int d, int h, float eps,
     float* __restrict__ out) {
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y, q0 = blockIdx.x * 16;
+    const int CT = h >> 4;
+    const int qw = min(q0 + r, Lq - 1);   // this lane's word (clamped; rows past Lq are never stored)
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* smem = reinterpret_cast<float*>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
-    const int q0 = blockIdx.x * kQCap, qn = min(kQCap, Lq - q0);
-    const int dp = d + 4, hp = h + 4, Vp = ((V + 31) & ~31) + 4;   // rows padded to whole 32-region tiles
-    // LDS: [att_s QCap x Vp][st_s QCap x 2][region (union): txt_s QCap x dp + vis tile 32 x dp | mid tile 32 x hp | y_s QCap x hp]
-    float* att_s = smem;
-    float* st_s = att_s + kQCap * Vp;
-    float* region = st_s + kQCap * 2;
-    float* txt_s = region;
-    float* vtile = region + kQCap * dp;
+    float* tile = reinterpret_cast<float*>(smem_raw);   // [16 words][hp]
+    const int hp = h + 4;
+    float4 erows[16];   // residual rows, needed only after both GEMMs: the read latency is free
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        erows[i] = ld4(enc_x + ((size_t)b * Lq + min(q0 + i, Lq - 1)) * h + min(4 * lane, h - 4));
 
-    // ---- words of this block (root slot skipped: txt[:, 1:], joint.py:671) ----
-    for (int i = tid; i < qn * (d >> 2); i += kAlignThreads) {
-        const int q = i / (d >> 2), k4 = i - q * (d >> 2);
-        *reinterpret_cast<float4*>(txt_s + q * dp + k4 * 4) = ld4(txt + ((size_t)b * (Lq + 1) + 1 + q0 + q) * d + k4 * 4);
-    }
-    // ---- scores: thread = (region v of the tile, word group qg); words qg, qg+8, ... ----
-    const int sv = tid & 31, qg = tid >> 5;
-    for (int v0 = 0; v0 < V; v0 += 32) {
-        const int vn = min(32, V - v0);
-        __syncthreads();
-        for (int i = tid; i < vn * (d >> 2); i += kAlignThreads) {
-            const int v = i / (d >> 2), k4 = i - v * (d >> 2);
-            *reinterpret_cast<float4*>(vtile + v * dp + k4 * 4) = ld4(vis + ((size_t)b * V + v0 + v) * d + k4 * 4);
-        }
-        __syncthreads();
-        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* yrow = vtile + min(sv, vn - 1) * dp;
-        for (int k4 = 0; k4 < (d >> 2); ++k4) {
-            const float4 y = *reinterpret_cast<const float4*>(yrow + k4 * 4);
+    const typename In::T* trow = txt + ((size_t)b * (Lq + 1) + 1 + qw) * d + 4 * g;   // root slot skipped: txt[:, 1:]
+    const __amdgpu_buffer_rsrc_t mid_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(vis_mid + (size_t)b * V * h), 0, (int)(V * h * sizeof(typename In::T)), 0x00020000);
+    f32x4 Y[kAttnMaxCT];
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const float4 x = *reinterpret_cast<const float4*>(txt_s + min(qg + 8 * u, qn - 1) * dp + k4 * 4);
-                acc[u] = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, acc[u]))));
+    for (int ct = 0; ct < kAttnMaxCT; ++ct) Y[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = neg_infinity(), z_run = 0.f;   // running softmax statistics of this lane's word
+
+    // Regions stream through in chunks of 16 T (one chunk when V <= 64, the benchmark's case); between chunks the
+    // accumulators are rescaled by exp(old max - new max), the usual streaming softmax.
+    for (int v0 = 0; v0 < V; v0 += 16 * T) {
+        // ---- GEMM 1: S^T[region v0+16t+4g+n][word r] (joint.py:670-672) ----
+        f32x4 S[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const typename In::T* vrow[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) vrow[t] = vis + ((size_t)b * V + min(v0 + 16 * t + r, V - 1)) * d + 4 * g;
+        for (int k0 = 0; k0 < d; k0 += 16 * kAttnKJ) {
+            const int nj = min(kAttnKJ, (d - k0) >> 4);
+            float4 wf[kAttnKJ];
+#pragma unroll
+            for (int j = 0; j < kAttnKJ; ++j) {
+                const float4 x = ld4(trow + k0 + 16 * min(j, nj - 1));
+                wf[j] = j < nj ? x : zero4;
             }
-        }
-        if (sv < vn)
 #pragma unroll
-            for (int u = 0; u < 5; ++u)
-                if (qg + 8 * u < qn) att_s[(qg + 8 * u) * Vp + v0 + sv] = acc[u];
-    }
-    __syncthreads();
-    // ---- softmax over regions: 4 lanes per word (NO region masking: faithful to joint.py:670-672) ----
-    {
-        const int q = tid >> 2, part = tid & 3, vq = (V + 3) >> 2, lo = part * vq, hi = min(V, lo + vq);
-        if (q < kQCap) {   // 160 lanes, whole waves only diverge at the tail
-            float* row = att_s + min(q, qn - 1) * Vp;
-            float m = neg_infinity();
-            for (int v = lo; v < hi; ++v) m = fmaxf(m, row[v]);
-            m = fmaxf(m, __shfl_xor(m, 1, 64));
-            m = fmaxf(m, __shfl_xor(m, 2, 64));
-            float z = 0.f;
-            for (int v = lo; v < hi; ++v) z += __expf(row[v] - m);
-            z += __shfl_xor(z, 1, 64);
-            z += __shfl_xor(z, 2, 64);
-            const float inv = 1.f / z;
-            if (q < qn)
-                for (int v = lo; v < hi; ++v) row[v] = __expf(row[v] - m) * inv;
-        }
-    }
-    // zero the padding columns so that whole 32-region tiles can be consumed below
-    for (int i = tid; i < qn * (Vp - V); i += kAlignThreads) {
-        const int q = i / (Vp - V), v = V + (i - q * (Vp - V));
-        att_s[q * Vp + v] = 0.f;
-    }
-    // ---- y = att . vis_mid : thread owns output channels c = tid (+256, ...), all words in registers ----
-    float* mtile = region;   // [32][hp]   (txt_s / vis tile are dead from here on)
-    for (int c0 = 0; c0 < h; c0 += kAlignThreads) {
-        const int c = c0 + tid;
-        const bool cin = c < h;
-        float yacc[kQCap];
+            for (int t = 0; t < T; ++t) {
+                float4 rf[kAttnKJ];
 #pragma unroll
-        for (int q = 0; q < kQCap; ++q) yacc[q] = 0.f;
-        for (int v0 = 0; v0 < V; v0 += 32) {
-            const int vn = min(32, V - v0);
-            __syncthreads();
-            for (int i = tid; i < 32 * (h >> 2); i += kAlignThreads) {   // rows past vn are zero-filled
-                const int v = i / (h >> 2), c4 = i - v * (h >> 2);
-                const float4 val = v < vn ? ld4(vis_mid + ((size_t)b * V + v0 + v) * h + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(mtile + v * hp + c4 * 4) = val;
-            }
-            __syncthreads();
-            float mreg[32];
+                for (int j = 0; j < kAttnKJ; ++j) {
+                    const float4 x = ld4(vrow[t] + k0 + 16 * min(j, nj - 1));
+                    rf[j] = j < nj ? x : zero4;
+                }
 #pragma unroll
-            for (int v = 0; v < 32; ++v) mreg[v] = mtile[v * hp + (cin ? c : 0)];
-#pragma unroll
-            for (int q = 0; q < kQCap; ++q) {
-                if (q < qn) {   // block-uniform
-                    const float* arow = att_s + q * Vp + v0;
-                    float a = yacc[q];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float4 p = *reinterpret_cast<const float4*>(arow + 4 * j);   // broadcast read
-                        a = fmaf(p.x, mreg[4 * j], fmaf(p.y, mreg[4 * j + 1], fmaf(p.z, mreg[4 * j + 2], fmaf(p.w, mreg[4 * j + 3], a))));
-                    }
-                    yacc[q] = a;
+                for (int j = 0; j < kAttnKJ; ++j) {
+                    S[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[j].x, wf[j].x, S[t], 0, 0, 0);
+                    S[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[j].y, wf[j].y, S[t], 0, 0, 0);
+                    S[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[j].z, wf[j].z, S[t], 0, 0, 0);
+                    S[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[j].w, wf[j].w, S[t], 0, 0, 0);
                 }
             }
         }
-        // residual: y = enc_x + att . vis_mid, parked in LDS for the row statistics
-        __syncthreads();
-        float* y_s = region;   // [QCap][hp]
+        // ---- softmax over regions (NO region masking: faithful to joint.py:670-672; only the tile padding is dropped) ----
+        float m = m_run;
 #pragma unroll
-        for (int q = 0; q < kQCap; ++q)
-            if (q < qn && cin) y_s[q * hp + c] = yacc[q] + In::ld(enc_x, ((size_t)b * Lq + q0 + q) * h + c);
-        // (for h > 256 the loop over c0 would overwrite y_s before the statistics: handled by the launcher, h <= 256)
-    }
-    __syncthreads();
-    // ---- LayerNorm statistics: wave w takes words w, w+4, ...; biased variance like nn.LayerNorm ----
-    {
-        const float* y_s = region;
-        for (int q = wave; q < qn; q += 4) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int c = lane; c < h; c += 64) { const float t = y_s[q * hp + c]; s1 += t; s2 = fmaf(t, t, s2); }
+        for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int k = 1; k < 64; k <<= 1) { s1 += __shfl_xor(s1, k, 64); s2 += __shfl_xor(s2, k, 64); }
-            if (lane == 0) {
-                const float mean = s1 / (float)h;
-                st_s[q * 2] = mean;
-                st_s[q * 2 + 1] = rsqrtf(fmaxf(s2 / (float)h - mean * mean, 0.f) + eps);
+            for (int n = 0; n < 4; ++n) {
+                if (v0 + 16 * t + 4 * g + n >= V) S[t][n] = neg_infinity();
+                m = fmaxf(m, S[t][n]);
             }
+        m = group_max4(m);   // finite: every chunk holds at least one real region
+        const float rescale = __expf(m_run - m);   // 0 on the first chunk
+        float z = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                S[t][n] = __expf(S[t][n] - m);
+                z += S[t][n];
+            }
+        z_run = z_run * rescale + group_sum4(z);
+        m_run = m;
+        if (v0 > 0) {
+#pragma unroll
+            for (int ct = 0; ct < kAttnMaxCT; ++ct) Y[ct] *= rescale;
+        }
+
+        // ---- GEMM 2: Y^T[channel 16ct+4g+n][word r] += mid[region][channel] * exp(score - max) ----
+        int mid_lane[T][4];   // region (clamped: padding rows carry zero weight), channel r (+ 16ct uniform)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) mid_lane[t][n] = min(v0 + 16 * t + 4 * g + n, V - 1) * h + r;
+        // Operand ring, kAttnPF channel tiles ahead: with ~3 waves per CU nothing else hides the read latency.
+        float mv[kAttnPF + 1][T][4];
+#pragma unroll
+        for (int p = 0; p < kAttnPF; ++p)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mv[p][t][n] = buf_ld(In{}, mid_b, mid_lane[t][n], 16 * min(p, CT - 1));
+        __builtin_amdgcn_sched_barrier(0);   // keep the ring's issue order: the scheduler otherwise sinks the reads
+#pragma unroll
+        for (int ct = 0; ct < kAttnMaxCT; ++ct) {
+            if (ct + kAttnPF < kAttnMaxCT) {   // compile-time
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        mv[(ct + kAttnPF) % (kAttnPF + 1)][t][n] =
+                            buf_ld(In{}, mid_b, mid_lane[t][n], 16 * min(ct + kAttnPF, CT - 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    Y[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(mv[ct % (kAttnPF + 1)][t][n], S[t][n], Y[ct], 0, 0, 0);
         }
     }
-    __syncthreads();
-    {
-        const float* y_s = region;
-        for (int i = tid; i < qn * h; i += kAlignThreads) {
-            const int q = i / h, c = i - q * h;
-            out[((size_t)b * Lq + q0) * h + i] = (y_s[q * hp + c] - st_s[q * 2]) * st_s[q * 2 + 1] * gamma[c] + beta[c];
-        }
+    const float zinv = 1.f / z_run;
+#pragma unroll
+    for (int ct = 0; ct < kAttnMaxCT; ++ct) Y[ct] *= zinv;
+
+    // ---- residual + LayerNorm over channels (biased variance like nn.LayerNorm) ----
+    // enc_x rows were requested at kernel start as whole rows (one instruction = one contiguous row); they meet the
+    // accumulators in LDS, and the result leaves as whole rows again.  Reading / writing in accumulator layout directly
+    // moves 64-byte pieces.
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (4 * lane < h) *reinterpret_cast<float4*>(tile + i * hp + 4 * lane) = erows[i];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < kAttnMaxCT; ++ct) {
+        float* cell = tile + r * hp + 16 * min(ct, CT - 1) + 4 * g;
+        const float4 e = *reinterpret_cast<const float4*>(cell);
+        const float keep = ct < CT ? 1.f : 0.f;
+        Y[ct][0] += e.x; Y[ct][1] += e.y; Y[ct][2] += e.z; Y[ct][3] += e.w;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { s1 = fmaf(keep, Y[ct][n], s1); s2 = fmaf(keep * Y[ct][n], Y[ct][n], s2); }
+        if (ct < CT) *reinterpret_cast<float4*>(cell) = make_float4(Y[ct][0], Y[ct][1], Y[ct][2], Y[ct][3]);
     }
+    s1 = group_sum4(s1);
+    s2 = group_sum4(s2);
+    const float mean = s1 / (float)h;
+    const float rstd = rsqrtf(fmaxf(s2 / (float)h - mean * mean, 0.f) + eps);
+    const int cl = min(4 * lane, h - 4);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + cl);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + cl);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float mu = __shfl(mean, i, 64), rs = __shfl(rstd, i, 64);   // word i's statistics live in lanes r == i
+        const float4 y = *reinterpret_cast<const float4*>(tile + i * hp + cl);
+        float4 o;
+        o.x = (y.x - mu) * rs * gm.x + bt.x;
+        o.y = (y.y - mu) * rs * gm.y + bt.y;
+        o.z = (y.z - mu) * rs * gm.z + bt.z;
+        o.w = (y.w - mu) * rs * gm.w + bt.w;
+        if (q0 + i < Lq && 4 * lane < h) *reinterpret_cast<float4*>(out + ((size_t)b * Lq + q0 + i) * h + cl) = o;
+    }
+}
+
+template <typename In, int T>
+static void launch_attn_mfma(const void* vis, const void* txt, const void* vis_mid, const void* enc_x, const float* gamma,
+                             const float* beta, int B, int L, int V, int d, int h, float eps, float* out, hipStream_t s) {
+    using P = const typename In::T*;
+    hipLaunchKernelGGL((attn_fuse_mfma_kernel<In, T>), dim3((L + 15) / 16, B), dim3(64), sizeof(float) * 16 * (h + 4), s, (P)vis, (P)txt, (P)vis_mid,
+                       (P)enc_x, gamma, beta, L, V, d, h, eps, out);
 }
 
 }  // namespace vlg
@@ -649,31 +712,18 @@ int vlg_attn_fuse(const void* vis, const void* txt, const void* vis_mid, const v
     if (B > 65535) return set_error(VLG_ERR_SHAPE, "attn_fuse: B=%d exceeds grid.y", B);
     hipStream_t s = (hipStream_t)stream;
     if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "attn_fuse: in_dtype %d", in_dtype);
-    // ---- fast path: 16-byte aligned rows, one pass over the output channels, no attention map requested ----
-    if (!out_att && d % 4 == 0 && h % 4 == 0 && h <= kAlignThreads) {
-        const size_t dp = d + 4, hp = h + 4, Vp = ((V + 31) & ~31) + 4;
-        size_t region = (size_t)kQCap * dp + 32 * dp;
-        if (32 * hp > region) region = 32 * hp;
-        if ((size_t)kQCap * hp > region) region = (size_t)kQCap * hp;
-        const size_t lds_fast = sizeof(float) * ((size_t)kQCap * Vp + kQCap * 2 + region);
-        if (lds_fast <= 156 * 1024) {
-            dim3 grid((L + kQCap - 1) / kQCap, B);
-#define VLG_FAST(INV)                                                                                              \
-    do {                                                                                                           \
-        auto k = attn_fuse_fast_kernel<INV>;                                                                       \
-        if (lds_fast > 60 * 1024) {                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                   \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);        \
-            if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));        \
-        }                                                                                                          \
-        hipLaunchKernelGGL(k, grid, dim3(kAlignThreads), lds_fast, s, (const INV::T*)vis, (const INV::T*)txt,      \
-                           (const INV::T*)vis_mid, (const INV::T*)enc_x, gamma, beta, L, V, d, h, eps, out);       \
-    } while (0)
-            if (in_dtype == VLG_F32) VLG_FAST(F32In);
-            else VLG_FAST(BF16In);
-#undef VLG_FAST
-            return check_launch("attn_fuse_fast_kernel");
-        }
+    // ---- matrix-core path: one wave per 16 words, no attention map requested ----
+    if (!out_att && d % 16 == 0 && h % 16 == 0 && h <= 16 * kAttnMaxCT && (size_t)V * h * 4 < (1u << 31)) {
+#define VLG_ATTN(INV)                                                                                              \
+    switch (V > 48 ? 4 : (V + 15) / 16) { /* region tiles per chunk; V > 64 streams chunks of 64 */                  \
+        case 1: launch_attn_mfma<INV, 1>(vis, txt, vis_mid, enc_x, gamma, beta, B, L, V, d, h, eps, out, s); break; \
+        case 2: launch_attn_mfma<INV, 2>(vis, txt, vis_mid, enc_x, gamma, beta, B, L, V, d, h, eps, out, s); break; \
+        case 3: launch_attn_mfma<INV, 3>(vis, txt, vis_mid, enc_x, gamma, beta, B, L, V, d, h, eps, out, s); break; \
+        default: launch_attn_mfma<INV, 4>(vis, txt, vis_mid, enc_x, gamma, beta, B, L, V, d, h, eps, out, s); break; \
+    }
+        if (in_dtype == VLG_F32) { VLG_ATTN(F32In) } else { VLG_ATTN(BF16In) }
+#undef VLG_ATTN
+        return check_launch("attn_fuse_mfma_kernel");
     }
     const size_t tile_f = (size_t)kFT * (size_t)((d + 1) > h ? (d + 1) : h);
     const size_t per_q = (size_t)(d + 1) + V + h + 2;
