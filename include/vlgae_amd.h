@@ -133,6 +133,19 @@ int vlg_attn_fuse(const void* vis, const void* txt, const void* vis_mid, const v
                   const float* beta, int B, int L, int V, int d, int h, int in_dtype, float eps, float* out_att,
                   float* out, void* stream);
 
+/* Adjoint of vlg_attn_fuse -- what autograd derives for src/model/joint.py:670-674 (the fuse sits inside
+ * DependencyBoxRel._forward, so training back-propagates through it into the feature encoders and the LayerNorm).
+ *   dout [B,L,h] fp32 = cotangent of `out`; inputs as in vlg_attn_fuse (in_dtype), gamma [h] fp32.
+ *   d_vis [B,V,d], d_txt [B,L+1,d] (root slot row = 0), d_vis_mid [B,V,h], d_enc_x [B,L,h], d_gamma [h], d_beta [h]: fp32,
+ *   all written (no accumulation).  Needs d, h multiples of 16 and <= 256 (VLG_ERR_SHAPE otherwise).
+ *   ws: vlg_attn_fuse_backward_workspace(B, L, V, h) bytes of device scratch (softmax / score-gradient tiles, partial
+ *   LayerNorm-parameter sums).  Bit-reproducible: no atomics, fixed summation orders. */
+size_t vlg_attn_fuse_backward_workspace(int B, int L, int V, int h);
+int vlg_attn_fuse_backward(const void* vis, const void* txt, const void* vis_mid, const void* enc_x, const float* gamma,
+                           const float* dout, int B, int L, int V, int d, int h, int in_dtype, float eps, void* ws,
+                           size_t ws_bytes, float* d_vis, float* d_txt, float* d_vis_mid, float* d_enc_x, float* d_gamma,
+                           float* d_beta, void* stream);
+
 /* Device self-test of the cross-lane (DPP / ds_swizzle) exchange primitives the DP kernels rely on.
  * `scratch` = one device int; after the stream drains it holds 0 iff the primitives behave as assumed. */
 int vlg_selftest_xlane(int* scratch, void* stream);

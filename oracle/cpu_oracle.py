@@ -194,6 +194,25 @@ def attn_fuse(vis, txt, vis_mid, enc_x, gamma, beta, eps=1e-5, dtype=np.float32)
     return att, out
 
 
+def attn_fuse_backward(vis, txt, vis_mid, enc_x, gamma, dout, eps=1e-5, dtype=np.float32):
+    """Adjoint of `attn_fuse` for the cotangent `dout` [B,L,h] of its output.
+    Returns (d_vis, d_txt, d_vis_mid, d_enc_x, d_gamma, d_beta); d_txt[:, 0] (the root slot) is zero."""
+    dtype, suf = _suffix(dtype)
+    vis, txt, vis_mid, enc_x, gamma, dout = (np.ascontiguousarray(x, dtype=dtype)
+                                             for x in (vis, txt, vis_mid, enc_x, gamma, dout))
+    B, V, d = vis.shape
+    L = txt.shape[1] - 1
+    h = vis_mid.shape[2]
+    assert txt.shape == (B, L + 1, d) and vis_mid.shape == (B, V, h) and enc_x.shape == (B, L, h) and dout.shape == (B, L, h)
+    outs = [np.empty_like(vis), np.empty_like(txt), np.empty_like(vis_mid), np.empty_like(enc_x), np.empty(h, dtype=dtype),
+            np.empty(h, dtype=dtype)]
+    rc = getattr(_load(), "orc_attn_fuse_bwd" + suf)(
+        _p(vis), _p(txt), _p(vis_mid), _p(enc_x), _p(gamma), _p(dout), B, L, V, d, h, ctypes.c_double(eps),
+        *(_p(o) for o in outs))
+    assert rc == 0, rc
+    return tuple(outs)
+
+
 # ----------------------------------------------------------------------------------------------
 # Brute-force enumerators (pure Python, tiny N only): an algorithm-independent known answer.
 # ----------------------------------------------------------------------------------------------

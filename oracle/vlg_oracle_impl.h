@@ -421,6 +421,114 @@ int FN(orc_attn_fuse)(const REAL *vis, const REAL *txt, const REAL *vis_mid, con
     return fail ? -1 : 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Adjoint of the attention-fuse above (what autograd derives for joint.py:670-674), by hand:
+ *   y = enc_x + M,  M = P . mid,  P = softmax_v(S),  S = t . vis^T,  out = yhat * gamma + beta,  yhat = (y - mean) * rstd
+ *   d_beta  = sum_{b,q} dout                       d_gamma = sum_{b,q} dout * yhat
+ *   dyhat   = dout * gamma
+ *   dy      = rstd * (dyhat - mean_c(dyhat) - yhat * mean_c(dyhat * yhat))         (LayerNorm, biased variance)
+ *   d_enc_x = dy
+ *   dP[q,v] = sum_c dy[q,c] mid[v,c]               d_mid[v,c] = sum_q P[q,v] dy[q,c]
+ *   dS      = P o (dP - sum_v P o dP)                                               (softmax)
+ *   d_txt[1+q,:] = sum_v dS[q,v] vis[v,:]          d_vis[v,:] = sum_q dS[q,v] txt[1+q,:]      d_txt[0,:] = 0
+ * One thread per sentence (the sums over words stay inside a sentence); d_gamma / d_beta are reduced over
+ * sentences serially afterwards so the result does not depend on the thread count.
+ * ------------------------------------------------------------------------------------------ */
+int FN(orc_attn_fuse_bwd)(const REAL *vis, const REAL *txt, const REAL *vis_mid, const REAL *enc_x, const REAL *gamma,
+                          const REAL *dout, int B, int Lq, int V, int d, int h, double eps, REAL *d_vis, REAL *d_txt,
+                          REAL *d_mid, REAL *d_enc, REAL *d_gamma, REAL *d_beta) {
+    int fail = 0;
+    REAL *part = (REAL *)calloc((size_t)B * 2 * h + 1, sizeof(REAL));   /* per-sentence d_gamma / d_beta */
+    if (!part) return -1;
+#pragma omp parallel
+    {
+        REAL *s = (REAL *)malloc(sizeof(REAL) * (size_t)(2 * V + 3 * h));
+        if (!s) {
+#pragma omp atomic write
+            fail = 1;
+        }
+#pragma omp barrier
+        if (!fail) {
+            REAL *dp = s + V, *y = dp + V, *yh = y + h, *dy = yh + h;
+#pragma omp for schedule(static)
+            for (int b = 0; b < B; ++b) {
+                REAL *dv = d_vis + (size_t)b * V * d, *dm = d_mid + (size_t)b * V * h;
+                for (size_t i = 0; i < (size_t)V * d; ++i) dv[i] = 0;
+                for (size_t i = 0; i < (size_t)V * h; ++i) dm[i] = 0;
+                for (int k = 0; k < d; ++k) d_txt[(size_t)b * (Lq + 1) * d + k] = 0;
+                for (int q = 0; q < Lq; ++q) {
+                    const REAL *x = txt + ((size_t)b * (Lq + 1) + 1 + q) * d;
+                    REAL m = (REAL)-INFINITY;
+                    for (int v = 0; v < V; ++v) {
+                        const REAL *r = vis + ((size_t)b * V + v) * d;
+                        REAL acc = 0;
+                        for (int k = 0; k < d; ++k) acc += r[k] * x[k];
+                        s[v] = acc;
+                        if (acc > m) m = acc;
+                    }
+                    REAL z = 0;
+                    for (int v = 0; v < V; ++v) { s[v] = EXP(s[v] - m); z += s[v]; }
+                    for (int v = 0; v < V; ++v) s[v] /= z;
+                    REAL mean = 0;
+                    for (int c = 0; c < h; ++c) {
+                        REAL acc = 0;
+                        for (int v = 0; v < V; ++v) acc += s[v] * vis_mid[((size_t)b * V + v) * h + c];
+                        y[c] = enc_x[((size_t)b * Lq + q) * h + c] + acc;
+                        mean += y[c];
+                    }
+                    mean /= h;
+                    REAL var = 0;
+                    for (int c = 0; c < h; ++c) var += (y[c] - mean) * (y[c] - mean);
+                    var /= h;
+                    const REAL rstd = (REAL)1 / SQRT(var + (REAL)eps);
+                    const REAL *go = dout + ((size_t)b * Lq + q) * h;
+                    REAL c1 = 0, c2 = 0;
+                    for (int c = 0; c < h; ++c) {
+                        yh[c] = (y[c] - mean) * rstd;
+                        part[((size_t)b * 2) * h + c] += go[c] * yh[c];
+                        part[((size_t)b * 2 + 1) * h + c] += go[c];
+                        const REAL dyh = go[c] * gamma[c];
+                        c1 += dyh;
+                        c2 += dyh * yh[c];
+                    }
+                    c1 /= h;
+                    c2 /= h;
+                    for (int c = 0; c < h; ++c) {
+                        dy[c] = rstd * (go[c] * gamma[c] - c1 - yh[c] * c2);
+                        d_enc[((size_t)b * Lq + q) * h + c] = dy[c];
+                    }
+                    REAL dot = 0;
+                    for (int v = 0; v < V; ++v) {
+                        const REAL *mr = vis_mid + ((size_t)b * V + v) * h;
+                        REAL acc = 0;
+                        for (int c = 0; c < h; ++c) { acc += dy[c] * mr[c]; dm[(size_t)v * h + c] += s[v] * dy[c]; }
+                        dp[v] = acc;
+                        dot += s[v] * acc;
+                    }
+                    REAL *dx = d_txt + ((size_t)b * (Lq + 1) + 1 + q) * d;
+                    for (int k = 0; k < d; ++k) dx[k] = 0;
+                    for (int v = 0; v < V; ++v) {
+                        const REAL ds = s[v] * (dp[v] - dot);
+                        const REAL *r = vis + ((size_t)b * V + v) * d;
+                        for (int k = 0; k < d; ++k) { dx[k] += ds * r[k]; dv[(size_t)v * d + k] += ds * x[k]; }
+                    }
+                }
+            }
+        }
+        free(s);
+    }
+    if (!fail) {
+        for (int c = 0; c < h; ++c) { d_gamma[c] = 0; d_beta[c] = 0; }
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < h; ++c) {
+                d_gamma[c] += part[((size_t)b * 2) * h + c];
+                d_beta[c] += part[((size_t)b * 2 + 1) * h + c];
+            }
+    }
+    free(part);
+    return fail ? -1 : 0;
+}
+
 #undef DEC
 #undef ATT
 #undef GDEC

@@ -241,12 +241,19 @@ def attnfuse_cases():
         with torch.no_grad():
             ln.weight.copy_(torch.rand(h, generator=g) + 0.5)
             ln.bias.copy_(torch.randn(h, generator=g) * 0.1)
-            attmap = torch.einsum("bvd, bqd -> bqv", vis, txt[:, 1:]).softmax(2)
-            x = torch.einsum("bqv,bvh->bqh", attmap, vis_mid)
-            out = ln(enc_x + x)
+        dout = torch.randn(B, L, h, generator=g)               # cotangent of encoded['x'] (drawn last: earlier draws unchanged)
+        leaves = [vis, txt, vis_mid, enc_x]
+        for t_ in leaves:
+            t_.requires_grad_(True)
+        attmap = torch.einsum("bvd, bqd -> bqv", vis, txt[:, 1:]).softmax(2)
+        x = torch.einsum("bqv,bvh->bqh", attmap, vis_mid)
+        out = ln(enc_x + x)
+        grads = torch.autograd.grad(out, leaves + [ln.weight, ln.bias], dout)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), vis=_np(vis), txt=_np(txt), vis_mid=_np(vis_mid),
                             enc_x=_np(enc_x), ln_weight=_np(ln.weight), ln_bias=_np(ln.bias),
-                            ln_eps=np.float32(ln.eps), attmap=_np(attmap), out=_np(out))
+                            ln_eps=np.float32(ln.eps), attmap=_np(attmap), out=_np(out), dout=_np(dout),
+                            g_vis=_np(grads[0]), g_txt=_np(grads[1]), g_vis_mid=_np(grads[2]), g_enc_x=_np(grads[3]),
+                            g_ln_weight=_np(grads[4]), g_ln_bias=_np(grads[5]))
         print(f"{name}: out {tuple(out.shape)}")
 
 

@@ -461,3 +461,71 @@ def test_attn_fuse_mfma_shapes(oracle_mod, B, L, V, d, h, dt):
     out = align.attention_fuse(*args, t(gm), t(bt), 1e-5)
     assert out.shape == (B, L, h) and out.dtype == torch.float32
     assert np.abs(out.cpu().numpy() - ref_out).max() <= 1e-4
+
+
+ATTN_GRAD_NAMES = ("g_vis", "g_txt", "g_vis_mid", "g_enc_x", "g_ln_weight", "g_ln_bias")
+
+
+def _attn_grads(arrs, gm, bt, dout, eps, bf16=False):
+    """Gradients of attention_fuse through torch.autograd (i.e. through vlg_attn_fuse_backward)."""
+    from vlgae_amd import align
+    leaves = [t(a) for a in arrs]
+    if bf16:
+        leaves = [a.bfloat16() for a in leaves]
+    leaves += [t(gm), t(bt)]
+    for a in leaves:
+        a.requires_grad_(True)
+    out = align.attention_fuse(*leaves, eps)
+    return out, torch.autograd.grad(out, leaves, t(dout))
+
+
+@pytest.mark.parametrize("path", golden_files("attnfuse_"), ids=golden_ids("attnfuse_"))
+def test_attn_fuse_backward_golden(path):
+    """Adjoint kernels vs torch autograd through the reference's own ops (fixtures: tests/golden/make_golden.py)."""
+    g = load(path)
+    out, grads = _attn_grads([g["vis"], g["txt"], g["vis_mid"], g["enc_x"]], g["ln_weight"], g["ln_bias"], g["dout"],
+                             float(g["ln_eps"]))
+    assert np.abs(out.detach().cpu().numpy() - g["out"]).max() <= 1e-4
+    for name, got in zip(ATTN_GRAD_NAMES, grads):
+        ref = g[name]
+        assert tuple(got.shape) == ref.shape, name
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), name
+    assert not grads[1][:, 0].any()   # root slot
+
+
+@pytest.mark.parametrize("B,L,V,d,h", [
+    (3, 40, 36, 128, 256),    # the benchmark shape
+    (2, 1, 1, 16, 16),        # one word, one region: softmax is the constant 1, dS = 0
+    (2, 16, 16, 32, 64),
+    (2, 17, 17, 48, 80),
+    (2, 33, 64, 144, 240),    # d > 128: sixteen feature tiles in the adjoint
+    (2, 9, 65, 256, 128),     # streamed chunks, second holds one region
+    (1, 50, 130, 64, 256),
+])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_attn_fuse_backward_shapes(oracle_mod, B, L, V, d, h, dt):
+    rng = np.random.default_rng(B * 977 + L * 29 + V)
+    vis, txt = rng.standard_normal((B, V, d)).astype(np.float32) * 0.4, rng.standard_normal((B, L + 1, d)).astype(np.float32) * 0.4
+    mid, enc = rng.standard_normal((B, V, h)).astype(np.float32), rng.standard_normal((B, L, h)).astype(np.float32)
+    gm, bt = (rng.random(h) + 0.5).astype(np.float32), rng.standard_normal(h).astype(np.float32)
+    dout = rng.standard_normal((B, L, h)).astype(np.float32)
+    arrs = [vis, txt, mid, enc]
+    if dt == "bf16":   # the oracle sees the same bf16-rounded values
+        arrs = [torch.from_numpy(a).bfloat16().float().numpy() for a in arrs]
+    ref = oracle_mod.attn_fuse_backward(*arrs, gm, dout, 1e-5, np.float64)
+    out, grads = _attn_grads(arrs, gm, bt, dout, 1e-5, bf16=(dt == "bf16"))
+    for i, (name, got, want) in enumerate(zip(ATTN_GRAD_NAMES, grads, ref)):
+        assert got.dtype == (torch.bfloat16 if dt == "bf16" and i < 4 else torch.float32), name
+        tol = (1e-2 if dt == "bf16" and i < 4 else 1e-4) * max(1.0, np.abs(want).max())   # bf16 grads are rounded on return
+        assert np.abs(got.float().cpu().numpy() - want).max() <= tol, name
+
+
+def test_attn_fuse_backward_reproducible():
+    """No atomics, fixed summation orders: two runs give identical bits."""
+    rng = np.random.default_rng(5)
+    B, L, V, d, h = 16, 40, 36, 128, 256
+    arrs = [rng.standard_normal(s).astype(np.float32) for s in ((B, V, d), (B, L + 1, d), (B, V, h), (B, L, h))]
+    gm, bt, dout = np.ones(h, np.float32), np.zeros(h, np.float32), rng.standard_normal((B, L, h)).astype(np.float32)
+    _, g1 = _attn_grads(arrs, gm, bt, dout, 1e-5)
+    _, g2 = _attn_grads(arrs, gm, bt, dout, 1e-5)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))

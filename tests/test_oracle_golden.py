@@ -123,6 +123,19 @@ def test_oracle_attnfuse_matches_reference(oracle_mod, path):
     assert np.abs(att - g["attmap"]).max() <= 5e-6 and np.abs(out - g["out"]).max() <= 2e-5
 
 
+@pytest.mark.parametrize("path", golden_files("attnfuse_"), ids=golden_ids("attnfuse_"))
+def test_oracle_attnfuse_backward_matches_reference(oracle_mod, path):
+    """Hand-derived adjoint vs torch autograd through the reference's own ops (joint.py:670-674)."""
+    g = load(path)
+    got = oracle_mod.attn_fuse_backward(g["vis"], g["txt"], g["vis_mid"], g["enc_x"], g["ln_weight"], g["dout"],
+                                        float(g["ln_eps"]), np.float64)
+    for name, arr in zip(("g_vis", "g_txt", "g_vis_mid", "g_enc_x", "g_ln_weight", "g_ln_bias"), got):
+        ref = g[name]
+        assert arr.shape == ref.shape, name
+        assert np.abs(arr - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), name   # the reference ran in fp32
+    assert not got[1][:, 0].any()   # the root slot never enters the scores
+
+
 @pytest.mark.parametrize("path", golden_files("rules_"), ids=golden_ids("rules_"))
 def test_oracle_rules_matches_reference(oracle_mod, path):
     g = load(path)

@@ -31,6 +31,9 @@ SIGNATURES = {
     "vlg_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vlg_bilinear_align": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "vlg_attn_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "vlg_attn_fuse_backward_workspace": (_sz, [_i, _i, _i, _i]),
+    "vlg_attn_fuse_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp]),
     "vlg_selftest_xlane": (_i, [_vp, _vp]),
     "vlg_last_error": (ctypes.c_char_p, []),
     "vlg_version": (_i, []),

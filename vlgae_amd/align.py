@@ -98,11 +98,58 @@ def gather_logit_simple(self, inputs, vis, txt, vp):
     return gather_logit(inputs, vis, txt, vp)
 
 
+def _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, want_att):
+    B, V, d = vis_c.shape
+    L, h = txt_c.shape[1] - 1, mid_c.shape[2]
+    out = torch.empty((B, L, h), dtype=torch.float32, device=vis_c.device)
+    att = torch.empty((B, L, V), dtype=torch.float32, device=vis_c.device) if want_att else None
+    _C.check(_C.lib().vlg_attn_fuse(_C.ptr(vis_c), _C.ptr(txt_c), _C.ptr(mid_c), _C.ptr(enc_c), _C.ptr(gamma),
+                                    _C.ptr(beta), B, L, V, d, h, dt, float(eps), _C.ptr(att), _C.ptr(out),
+                                    _C.stream_of(vis_c)), "attn_fuse")
+    return out, att
+
+
+class _AttnFuse(torch.autograd.Function):
+    """joint.py:670-674 with gradients to the four feature tensors and the LayerNorm parameters (the fuse sits in
+    DependencyBoxRel._forward, so the parser's loss back-propagates through it).  The adjoint recomputes the forward
+    per 16-word tile instead of saving the attention map."""
+
+    @staticmethod
+    def forward(ctx, vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps):
+        dt, vis_c = _C.in_dtype(vis_feat.detach())
+        txt_c, mid_c, enc_c = (t.detach().to(vis_c.dtype).contiguous() for t in (txt_feat, vis_mid, enc_x))
+        gamma = ln_weight.detach().to(torch.float32).contiguous()
+        beta = ln_bias.detach().to(torch.float32).contiguous()
+        out, _ = _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, False)
+        ctx.save_for_backward(vis_c, txt_c, mid_c, enc_c, gamma)
+        ctx.meta = (dt, float(eps), vis_feat.dtype, txt_feat.dtype, vis_mid.dtype, enc_x.dtype, ln_weight.dtype, ln_bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        vis_c, txt_c, mid_c, enc_c, gamma = ctx.saved_tensors
+        dt, eps, *dtypes = ctx.meta
+        B, V, d = vis_c.shape
+        L, h = txt_c.shape[1] - 1, mid_c.shape[2]
+        dev = vis_c.device
+        dout = dout.to(torch.float32).contiguous()
+        nbytes = _C.lib().vlg_attn_fuse_backward_workspace(B, L, V, h)
+        ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dev)
+        outs = [torch.empty(shape, dtype=torch.float32, device=dev)
+                for shape in ((B, V, d), (B, L + 1, d), (B, V, h), (B, L, h), (h,), (h,))]
+        _C.check(_C.lib().vlg_attn_fuse_backward(_C.ptr(vis_c), _C.ptr(txt_c), _C.ptr(mid_c), _C.ptr(enc_c), _C.ptr(gamma),
+                                                 _C.ptr(dout), B, L, V, d, h, dt, eps, _C.ptr(ws), nbytes,
+                                                 *(_C.ptr(o) for o in outs), _C.stream_of(vis_c)), "attn_fuse_backward")
+        grads = [o.to(t) if ctx.needs_input_grad[i] else None for i, (o, t) in enumerate(zip(outs, dtypes))]
+        return (*grads, None)
+
+
 def attention_fuse(vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps=1e-5, return_attmap=False):
     """joint.py:670-674:  LayerNorm(enc_x + softmax_v(<vis, txt[:,1:]>) @ vis_mid).
 
     vis_feat [B,V,d], txt_feat [B,L+1,d] (root slot first), vis_mid [B,V,h], enc_x [B,L,h]; LayerNorm
-    parameters [h].  Inference-path op (no autograd): returns float32 [B,L,h] (and attmap [B,L,V])."""
+    parameters [h].  Returns float32 [B,L,h]; differentiable in all six tensors (the adjoint kernels need d and h
+    to be multiples of 16 and <= 256).  `return_attmap=True` also returns attmap [B,L,V] (inspection; no autograd)."""
     vis_feat, txt_feat, vis_mid, enc_x = (_plain(t) for t in (vis_feat, txt_feat, vis_mid, enc_x))
     _C.require_gpu(vis_feat, "attention_fuse")
     B, V, d = vis_feat.shape
@@ -111,14 +158,12 @@ def attention_fuse(vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps=1
     if tuple(txt_feat.shape) != (B, L + 1, d) or tuple(vis_mid.shape) != (B, V, h) or tuple(enc_x.shape) != (B, L, h):
         raise ValueError(f"attention_fuse: vis {tuple(vis_feat.shape)} txt {tuple(txt_feat.shape)} "
                          f"vis_mid {tuple(vis_mid.shape)} enc_x {tuple(enc_x.shape)}")
+    tensors = (vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias)
+    if not return_attmap and torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        return _AttnFuse.apply(*tensors, float(eps))
     dt, vis_c = _C.in_dtype(vis_feat.detach())
-    tdt = vis_c.dtype
-    txt_c, mid_c, enc_c = (t.detach().to(tdt).contiguous() for t in (txt_feat, vis_mid, enc_x))
+    txt_c, mid_c, enc_c = (t.detach().to(vis_c.dtype).contiguous() for t in (txt_feat, vis_mid, enc_x))
     gamma = ln_weight.detach().to(torch.float32).contiguous()
     beta = ln_bias.detach().to(torch.float32).contiguous()
-    out = torch.empty((B, L, h), dtype=torch.float32, device=vis_feat.device)
-    att = torch.empty((B, L, V), dtype=torch.float32, device=vis_feat.device) if return_attmap else None
-    _C.check(_C.lib().vlg_attn_fuse(_C.ptr(vis_c), _C.ptr(txt_c), _C.ptr(mid_c), _C.ptr(enc_c), _C.ptr(gamma),
-                                    _C.ptr(beta), B, L, V, d, h, dt, float(eps), _C.ptr(att), _C.ptr(out),
-                                    _C.stream_of(vis_feat)), "attn_fuse")
+    out, att = _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, return_attmap)
     return (out, att) if return_attmap else out
