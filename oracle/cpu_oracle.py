@@ -213,6 +213,58 @@ def attn_fuse_backward(vis, txt, vis_mid, enc_x, gamma, dout, eps=1e-5, dtype=np
     return tuple(outs)
 
 
+def grounding_prior(tag, factor_names, vis_split, pos_for, Q):
+    """The additive POS prior of joint.py:446-470 as a table: returns (pen [B,Q,S] float64, seg_of_v [V] uint8).
+    For every named factor f in {obj, rel, attr} whose POS set contains the token's tag, every region OUTSIDE f's
+    segment loses 100; the rows touched are q = 1..L (the word queries), the root slot and the arc queries keep 0."""
+    tag = np.asarray(tag)
+    B, L = tag.shape
+    S = len(vis_split)
+    seg_of_v = np.repeat(np.arange(S, dtype=np.uint8), np.asarray(vis_split, dtype=np.int64))
+    pen = np.zeros((B, Q, S), dtype=np.float64)
+    for f, name in enumerate(factor_names):
+        if str(name) not in ("obj", "rel", "attr"):
+            continue
+        hit = np.isin(tag, np.asarray(pos_for[str(name)]))          # [B,L]
+        for s_ in range(S):
+            if s_ != f:
+                pen[:, 1:L + 1, s_] += 100.0 * hit
+    return pen, seg_of_v
+
+
+def grounding_loss(txt, vis, tmask, vmask, marginal, num_token, w_vis2txt=1.0, pen=None, seg_of_v=None,
+                   neg_inf=-1e20, dtype=np.float32, want_grad=True):
+    """gather_logit_simple + loss_grounding_factor_ce (joint.py:406-419, 439-491), A == B.
+    Returns dict(txt2vis, vis2txt, total, maxV, argV, maxQ, argQ[, g_txt, g_vis])."""
+    dtype, suf = _suffix(dtype)
+    txt, vis, marginal = (np.ascontiguousarray(x, dtype=dtype) for x in (txt, vis, marginal))
+    B, Q, d = txt.shape
+    A, V, d2 = vis.shape
+    assert A == B and d == d2 and marginal.shape == (B, Q)
+    tm = None if tmask is None else np.ascontiguousarray(tmask, dtype=np.uint8)
+    vm = None if vmask is None else np.ascontiguousarray(vmask, dtype=np.uint8)
+    n_seg = 0
+    if pen is not None:
+        pen = np.ascontiguousarray(pen, dtype=dtype)
+        seg_of_v = np.ascontiguousarray(seg_of_v, dtype=np.uint8)
+        n_seg = pen.shape[2]
+        assert pen.shape == (B, Q, n_seg) and seg_of_v.shape == (V,)
+    sums = np.empty(3, dtype=dtype)
+    maxV, argV = np.empty((B, A, Q), dtype=dtype), np.empty((B, A, Q), dtype=np.int32)
+    maxQ, argQ = np.empty((B, A, V), dtype=dtype), np.empty((B, A, V), dtype=np.int32)
+    g_txt = np.empty_like(txt) if want_grad else None
+    g_vis = np.empty_like(vis) if want_grad else None
+    rc = getattr(_load(), "orc_grounding_loss" + suf)(
+        _p(txt), _p(vis), _p(tm), _p(vm), _p(marginal), _p(pen), _p(seg_of_v), n_seg, B, Q, V, d, ctypes.c_double(neg_inf),
+        ctypes.c_double(float(num_token)), ctypes.c_double(float(w_vis2txt)), _p(sums), _p(maxV), _p(argV), _p(maxQ),
+        _p(argQ), _p(g_txt), _p(g_vis))
+    assert rc == 0, rc
+    out = dict(txt2vis=float(sums[0]), vis2txt=float(sums[1]), total=float(sums[2]), maxV=maxV, argV=argV, maxQ=maxQ, argQ=argQ)
+    if want_grad:
+        out.update(g_txt=g_txt, g_vis=g_vis)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # Brute-force enumerators (pure Python, tiny N only): an algorithm-independent known answer.
 # ----------------------------------------------------------------------------------------------

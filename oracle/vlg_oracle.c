@@ -4,6 +4,7 @@
  * OpenMP parallelises over sentences only (the DP itself is the scalar loop of the reference).
  */
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP

@@ -529,6 +529,123 @@ int FN(orc_attn_fuse_bwd)(const REAL *vis, const REAL *txt, const REAL *vis_mid,
     return fail ? -1 : 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Grounding loss on the alignment, src/model/joint.py:406-419 (gather_logit_simple) + :439-491
+ * (loss_grounding_factor_ce), and its gradient to both feature tensors.  A == B (caption b pairs with image b).
+ *   att[b,a,q,v] = <txt[b,q], vis[a,v]>, masked entries = neg_inf (joint.py:417-418); on the diagonal pairs a == b the
+ *   POS prior subtracts pen[b,q,seg(v)] (joint.py:446-470; the caller builds pen from the tags: 100 for every named
+ *   factor whose POS set holds the token's tag and whose segment is not seg(v); rows q outside 1..L carry 0).
+ *   mV[b,a,q] = max_v att   ->  txt2vis = - sum_{b,q} marg[b,q] * log_softmax_a(mV)[b,b,q]        (joint.py:472-476)
+ *   mQ[b,a,v] = max_q att   ->  vis2txt = - sum_{a,v} vmask[a,v] * log_softmax_b(mQ)[a,a,v]       (joint.py:478-483)
+ *   total = txt2vis / (txt2vis + 1e-6) * num  +  w * vis2txt / (vis2txt + 1e-6) * num  (denominators detached)
+ * Gradient: d total / d txt2vis = num / (txt2vis + 1e-6) etc.; through log_softmax (p - delta), through max (to the
+ * first arg-max), through masked_fill (nothing where either mask is off), through the contraction.
+ * out_sums = {txt2vis, vis2txt, total}.  Optional outputs may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+int FN(orc_grounding_loss)(const REAL *txt, const REAL *vis, const uint8_t *tmask, const uint8_t *vmask, const REAL *marg,
+                           const REAL *pen, const uint8_t *seg_of_v, int n_seg, int B, int Q, int V, int d,
+                           double neg_inf, double num_token, double w_v2t, REAL *out_sums, REAL *out_maxV,
+                           int32_t *out_argV, REAL *out_maxQ, int32_t *out_argQ, REAL *g_txt, REAL *g_vis) {
+    const int A = B;
+    REAL *mV = (REAL *)malloc(sizeof(REAL) * (size_t)B * A * Q), *mQ = (REAL *)malloc(sizeof(REAL) * (size_t)B * A * V);
+    int32_t *aV = (int32_t *)malloc(sizeof(int32_t) * (size_t)B * A * Q), *aQ = (int32_t *)malloc(sizeof(int32_t) * (size_t)B * A * V);
+    if (!mV || !mQ || !aV || !aQ) { free(mV); free(mQ); free(aV); free(aQ); return -1; }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int a = 0; a < A; ++a) {
+            REAL *mv = mV + ((size_t)b * A + a) * Q, *mq = mQ + ((size_t)b * A + a) * V;
+            int32_t *av = aV + ((size_t)b * A + a) * Q, *aq = aQ + ((size_t)b * A + a) * V;
+            for (int v = 0; v < V; ++v) { mq[v] = (REAL)-INFINITY; aq[v] = 0; }
+            for (int q = 0; q < Q; ++q) {
+                const REAL *x = txt + ((size_t)b * Q + q) * d;
+                REAL best = (REAL)-INFINITY;
+                int bi = 0;
+                for (int v = 0; v < V; ++v) {
+                    REAL val;
+                    if ((tmask && !tmask[(size_t)b * Q + q]) || (vmask && !vmask[(size_t)a * V + v])) val = (REAL)neg_inf;
+                    else {
+                        const REAL *r = vis + ((size_t)a * V + v) * d;
+                        REAL acc = 0;
+                        for (int k = 0; k < d; ++k) acc += x[k] * r[k];
+                        val = acc;
+                    }
+                    if (pen && a == b) val -= pen[((size_t)b * Q + q) * n_seg + seg_of_v[v]];
+                    if (val > best) { best = val; bi = v; }
+                    if (val > mq[v]) { mq[v] = val; aq[v] = q; }
+                }
+                mv[q] = best;
+                av[q] = bi;
+            }
+        }
+    /* the two cross-entropies */
+    double t2v = 0, v2t = 0;
+    for (int b = 0; b < B; ++b)
+        for (int q = 0; q < Q; ++q) {
+            REAL m = (REAL)-INFINITY, z = 0;
+            for (int a = 0; a < A; ++a) if (mV[((size_t)b * A + a) * Q + q] > m) m = mV[((size_t)b * A + a) * Q + q];
+            for (int a = 0; a < A; ++a) z += EXP(mV[((size_t)b * A + a) * Q + q] - m);
+            t2v -= (double)marg[(size_t)b * Q + q] * (double)((mV[((size_t)b * A + b) * Q + q] - m) - LOG(z));
+        }
+    for (int a = 0; a < A; ++a)
+        for (int v = 0; v < V; ++v) {
+            REAL m = (REAL)-INFINITY, z = 0;
+            for (int b = 0; b < B; ++b) if (mQ[((size_t)b * A + a) * V + v] > m) m = mQ[((size_t)b * A + a) * V + v];
+            for (int b = 0; b < B; ++b) z += EXP(mQ[((size_t)b * A + a) * V + v] - m);
+            const double keep = vmask ? (vmask[(size_t)a * V + v] ? 1.0 : 0.0) : 1.0;
+            v2t -= keep * (double)((mQ[((size_t)a * A + a) * V + v] - m) - LOG(z));
+        }
+    const double c1 = num_token / (t2v + 1e-6), c2 = w_v2t > 0 ? w_v2t * num_token / (v2t + 1e-6) : 0.0;
+    if (out_sums) {
+        out_sums[0] = (REAL)t2v;
+        out_sums[1] = (REAL)v2t;
+        out_sums[2] = (REAL)(t2v * c1 + v2t * c2);
+    }
+    if (out_maxV) memcpy(out_maxV, mV, sizeof(REAL) * (size_t)B * A * Q);
+    if (out_argV) memcpy(out_argV, aV, sizeof(int32_t) * (size_t)B * A * Q);
+    if (out_maxQ) memcpy(out_maxQ, mQ, sizeof(REAL) * (size_t)B * A * V);
+    if (out_argQ) memcpy(out_argQ, aQ, sizeof(int32_t) * (size_t)B * A * V);
+    if (g_txt && g_vis) {
+        for (size_t i = 0; i < (size_t)B * Q * d; ++i) g_txt[i] = 0;
+        for (size_t i = 0; i < (size_t)A * V * d; ++i) g_vis[i] = 0;
+        /* serial on purpose: the scatter into g_vis / g_txt has a fixed order */
+        for (int b = 0; b < B; ++b)
+            for (int q = 0; q < Q; ++q) {
+                if (tmask && !tmask[(size_t)b * Q + q]) continue;
+                REAL m = (REAL)-INFINITY, z = 0;
+                for (int a = 0; a < A; ++a) if (mV[((size_t)b * A + a) * Q + q] > m) m = mV[((size_t)b * A + a) * Q + q];
+                for (int a = 0; a < A; ++a) z += EXP(mV[((size_t)b * A + a) * Q + q] - m);
+                for (int a = 0; a < A; ++a) {
+                    const int v = aV[((size_t)b * A + a) * Q + q];
+                    if (vmask && !vmask[(size_t)a * V + v]) continue;
+                    const REAL p = EXP(mV[((size_t)b * A + a) * Q + q] - m) / z;
+                    const REAL g = (REAL)c1 * marg[(size_t)b * Q + q] * (p - (a == b ? (REAL)1 : (REAL)0));
+                    REAL *gt = g_txt + ((size_t)b * Q + q) * d, *gv = g_vis + ((size_t)a * V + v) * d;
+                    const REAL *x = txt + ((size_t)b * Q + q) * d, *r = vis + ((size_t)a * V + v) * d;
+                    for (int k = 0; k < d; ++k) { gt[k] += g * r[k]; gv[k] += g * x[k]; }
+                }
+            }
+        if (c2 != 0.0)
+            for (int a = 0; a < A; ++a)
+                for (int v = 0; v < V; ++v) {
+                    if (vmask && !vmask[(size_t)a * V + v]) continue;
+                    REAL m = (REAL)-INFINITY, z = 0;
+                    for (int b = 0; b < B; ++b) if (mQ[((size_t)b * A + a) * V + v] > m) m = mQ[((size_t)b * A + a) * V + v];
+                    for (int b = 0; b < B; ++b) z += EXP(mQ[((size_t)b * A + a) * V + v] - m);
+                    for (int b = 0; b < B; ++b) {
+                        const int q = aQ[((size_t)b * A + a) * V + v];
+                        if (tmask && !tmask[(size_t)b * Q + q]) continue;
+                        const REAL p = EXP(mQ[((size_t)b * A + a) * V + v] - m) / z;
+                        const REAL g = (REAL)c2 * (p - (a == b ? (REAL)1 : (REAL)0));
+                        REAL *gt = g_txt + ((size_t)b * Q + q) * d, *gv = g_vis + ((size_t)a * V + v) * d;
+                        const REAL *x = txt + ((size_t)b * Q + q) * d, *r = vis + ((size_t)a * V + v) * d;
+                        for (int k = 0; k < d; ++k) { gt[k] += g * r[k]; gv[k] += g * x[k]; }
+                    }
+                }
+    }
+    free(mV); free(mQ); free(aV); free(aQ);
+    return 0;
+}
+
 #undef DEC
 #undef ATT
 #undef GDEC

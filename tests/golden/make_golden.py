@@ -225,6 +225,61 @@ def align_cases():
         print(f"{name}: attmap {tuple(att.shape)}")
 
 
+def grounding_cases():
+    """The reference's own gather_logit_simple -> loss_grounding_factor_ce (joint.py:406-419, 439-491), with
+    gradients to both feature tensors through torch autograd.  `self` is a namespace carrying only what the two
+    methods read (cfg.loss_grounding_args, vis_factor_names, pos_for_*)."""
+    from types import SimpleNamespace as NS
+    src, joint = _ref_import.import_joint()
+    gather = joint.DependencyBoxRel.gather_logit_simple
+    loss_fn = joint.DependencyBoxRel.loss_grounding_factor_ce
+    for name, seed, B, L, split, d, prior, w_v2t, n_tag in (
+        ("ground_B4_L10_obj6_s0", 0, 4, 10, (("obj", 6),), 32, True, 1.0, 9),
+        ("ground_B5_L7_obj5_rel25_attr5_img1_s1", 1, 5, 7, (("obj", 5), ("rel", 25), ("attr", 5), ("img", 1)), 64, True, 1.0, 12),
+        ("ground_B3_L6_obj4_rel16_s2_noprior", 2, 3, 6, (("obj", 4), ("rel", 16)), 32, False, 0.0, 8),
+        ("ground_B8_L40_obj36_s3", 3, 8, 40, (("obj", 36),), 128, True, 1.0, 45),
+    ):
+        g = torch.Generator().manual_seed(seed)
+        names, widths = [n for n, _ in split], [w for _, w in split]
+        V, Q = sum(widths), 2 * (L + 1)
+        lengths = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+        lengths[0] = L
+        wmask = torch.arange(L)[None] < lengths[:, None]                       # vp.mask [B,L]
+        m1 = torch.cat([torch.zeros(B, 1, dtype=torch.bool), wmask], 1)
+        tmask = torch.cat([m1, m1], 1)                                          # joint.py:248-249
+        vmask = torch.rand(B, V, generator=g) > 0.15
+        vmask[:, 0] = True
+        txt = (torch.randn(B, Q, d, generator=g) * 0.5).requires_grad_(True)
+        vis = (torch.randn(B, V, d, generator=g) * 0.5).requires_grad_(True)
+        marg = torch.rand(B, Q, generator=g) * tmask                            # txt_marginal: constants (joint.py:251-268)
+        tag = torch.randint(0, n_tag, (B, L), generator=g)
+        pos = dict(obj=torch.tensor([0, 1, 2]), rel=torch.tensor([2, 3]), attr=torch.tensor([4]))   # 2 is in two sets
+        me = NS(cfg=NS(loss_grounding_args=NS(use_pos_prior=prior, vis2txt=w_v2t)), vis_factor_names=names,
+                pos_for_obj=pos["obj"], pos_for_rel=pos["rel"], pos_for_attr=pos["attr"])
+        vis_p = (vis.refine_names("A", "V", "Y"), vmask.refine_names("A", "V"), widths)
+        txt_p = (txt.refine_names("B", "Q", "X"), tmask.refine_names("B", "Q"), marg)
+        logit = gather(me, None, vis_p, txt_p, None)
+        num_token = int(lengths.sum())
+        total, parts = loss_fn(me, {"match_logit": logit, "txt_packed": txt_p, "vis_packed": vis_p},
+                               NS(tag=tag, num_token=num_token))
+        # the raw sums (the reported losses are s / (s.detach() + 1e-6) * num_token, i.e. ~num_token by construction)
+        with torch.no_grad():
+            att = logit.rename(None).clone()    # the prior was already subtracted in place on the diagonal pairs
+            mv = att.max(3).values.log_softmax(1)
+            t2v = -(mv.diagonal().T * marg).sum()
+            v2t = -(att.max(2).values.log_softmax(0).diagonal().T * vmask).sum()
+        g_txt, g_vis = torch.autograd.grad(total, [txt, vis])
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"), txt=_np(txt), vis=_np(vis), tmask=_np(tmask), vmask=_np(vmask),
+            marginal=_np(marg), tag=_np(tag), lengths=_np(lengths), num_token=np.int64(num_token),
+            factor_names=np.array(names), vis_split=np.array(widths, dtype=np.int64), use_pos_prior=np.bool_(prior),
+            vis2txt_weight=np.float32(w_v2t), pos_for_obj=_np(pos["obj"]), pos_for_rel=_np(pos["rel"]),
+            pos_for_attr=_np(pos["attr"]), total=_np(total), txt2vis_raw=_np(t2v), vis2txt_raw=_np(v2t),
+            loss_txt2vis=_np(parts["txt2vis"]), loss_vis2txt=_np(parts.get("mt_vis2txt", torch.zeros(()))),
+            attmap_prior=_np(att), g_txt=_np(g_txt), g_vis=_np(g_vis), neg_inf=np.float32(-src.INF))
+        print(f"{name}: total {float(total):.4f} txt2vis_raw {float(t2v):.4f} vis2txt_raw {float(v2t):.4f}")
+
+
 def attnfuse_cases():
     """joint.py:670-674 re-issued with the same torch ops (module construction needs a DataModule)."""
     for name, seed, B, L, V, d, h in (
@@ -277,3 +332,4 @@ if __name__ == "__main__":
     deptree_case("deptree_B3_N2_s3", 3, 3, 2, "full")
     align_cases()
     attnfuse_cases()
+    grounding_cases()

@@ -145,3 +145,25 @@ def test_oracle_rules_matches_reference(oracle_mod, path):
     got_root = groot if int(g["root_per_sentence"]) else groot.sum(0, keepdims=True)
     assert np.abs(lz - g["logZ64"]).max() <= 1e-11 and np.abs(gr - g["grad_rule64"]).max() <= 1e-11
     assert np.abs(gd - g["grad_dec64"]).max() <= 1e-11 and np.abs(got_root - g["grad_root64"]).max() <= 1e-11
+
+
+@pytest.mark.parametrize("path", golden_files("ground_"), ids=golden_ids("ground_"))
+def test_oracle_grounding_loss_matches_reference(oracle_mod, path):
+    """gather_logit_simple -> loss_grounding_factor_ce run from the reference's own methods (joint.py:406-419, 439-491)."""
+    g = load(path)
+    Q = g["txt"].shape[1]
+    pen = seg = None
+    if bool(g["use_pos_prior"]):
+        pos_for = dict(obj=g["pos_for_obj"], rel=g["pos_for_rel"], attr=g["pos_for_attr"])
+        pen, seg = oracle_mod.grounding_prior(g["tag"], g["factor_names"], g["vis_split"], pos_for, Q)
+    o = oracle_mod.grounding_loss(g["txt"], g["vis"], g["tmask"], g["vmask"], g["marginal"], int(g["num_token"]),
+                                  float(g["vis2txt_weight"]), pen, seg, float(g["neg_inf"]), np.float64)
+    att = g["attmap_prior"]                       # the reference's attmap after the in-place prior
+    assert np.allclose(o["maxV"], att.max(3), rtol=1e-5, atol=1e-5) and np.allclose(o["maxQ"], att.max(2), rtol=1e-5, atol=1e-5)
+    assert abs(o["txt2vis"] - float(g["txt2vis_raw"])) <= 2e-5 * abs(float(g["txt2vis_raw"]))
+    assert abs(o["vis2txt"] - float(g["vis2txt_raw"])) <= 2e-5 * abs(float(g["vis2txt_raw"]))
+    want_total = float(g["total"])
+    got_total = o["total"] if float(g["vis2txt_weight"]) > 0 else o["txt2vis"] / (o["txt2vis"] + 1e-6) * int(g["num_token"])
+    assert abs(got_total - want_total) <= 1e-4 * abs(want_total)
+    for name in ("g_txt", "g_vis"):
+        assert np.abs(o[name] - g[name]).max() <= 2e-5 * max(1.0, np.abs(g[name]).max()), name
