@@ -125,6 +125,25 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
                        int Q, int V, int d, int in_dtype, float neg_inf, float* out_full, float* out_maxV,
                        float* out_maxQ, float* out_diag, void* stream);
 
+/* The grounding loss on the alignment, without the [B,A,Q,V] tensor -- DependencyBoxRel.gather_logit_simple followed by
+ * loss_grounding_factor_ce, src/model/joint.py:406-419 + 439-491, A == B:
+ *   att[b,a,q,v] = <txt[b,q], vis[a,v]>, masked -> neg_inf; on the pairs a == b the POS prior subtracts
+ *   pen[b,q,seg_of_v[v]] (joint.py:446-470: pen = 100 for every named factor whose POS set holds the token's tag and
+ *   whose segment is not seg(v); NULL = no prior);
+ *   txt2vis = - sum marginal[b,q] * log_softmax_a(max_v att)[b,b,q]     (joint.py:472-476)
+ *   vis2txt = - sum vmask[a,v]    * log_softmax_b(max_q att)[a,a,v]     (joint.py:478-483)
+ *   total   = txt2vis / (txt2vis + 1e-6) * num_token + w_vis2txt * vis2txt / (vis2txt + 1e-6) * num_token
+ *             (denominators detached, joint.py:477,484-489; w_vis2txt <= 0 drops the second term like `if vis2txt > 0`)
+ *   out_sums[3] = {txt2vis, vis2txt, total} (device, fp32); g_txt [B,Q,d], g_vis [B,V,d] = d total / d features (fp32,
+ *   both or either may be NULL).  The gradient passes through the first arg-max of each maximum and only where both
+ *   masks are on.  txt, vis in in_dtype; marginal [B,Q] fp32; masks uint8 or NULL; d in {32, 64, 128}.
+ *   ws: vlg_grounding_loss_workspace(B, Q, V) bytes.  No atomics: results are bit-reproducible. */
+size_t vlg_grounding_loss_workspace(int B, int Q, int V);
+int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marginal,
+                       const float* pen, const uint8_t* seg_of_v, int n_seg, int B, int Q, int V, int d, int in_dtype,
+                       float neg_inf, float num_token, float w_vis2txt, void* ws, size_t ws_bytes, float* out_sums,
+                       float* g_txt, float* g_vis, void* stream);
+
 /* Attention-fuse that feeds the parser -- DependencyBoxRel._forward, src/model/joint.py:670-674:
  *   att = softmax_v(vis[b] . txt[b,1:]) ; x = att . vis_mid[b] ; out = LayerNorm(enc_x + x) * gamma + beta
  *   vis [B,V,d], txt [B,L+1,d] (root slot first, skipped), vis_mid [B,V,h], enc_x [B,L,h] (in_dtype);

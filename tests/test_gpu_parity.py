@@ -529,3 +529,84 @@ def test_attn_fuse_backward_reproducible():
     _, g1 = _attn_grads(arrs, gm, bt, dout, 1e-5)
     _, g2 = _attn_grads(arrs, gm, bt, dout, 1e-5)
     assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+
+
+# ---- grounding loss on the fused alignment maxima (joint.py:439-491) ----
+def _ground_inputs(g, bf16=False):
+    from vlgae_amd import align
+    txt, vis = t(g["txt"]), t(g["vis"])
+    if bf16:
+        txt, vis = txt.bfloat16(), vis.bfloat16()
+    txt.requires_grad_(True)
+    vis.requires_grad_(True)
+    pen = seg = None
+    if bool(g["use_pos_prior"]):
+        pos_for = {k: t(g["pos_for_" + k]) for k in ("obj", "rel", "attr")}
+        pen, seg = align.grounding_prior(t(g["tag"]), [str(n) for n in g["factor_names"]], [int(w) for w in g["vis_split"]],
+                                         pos_for, txt.shape[1])
+    return txt, vis, pen, seg
+
+
+@pytest.mark.parametrize("path", golden_files("ground_"), ids=golden_ids("ground_"))
+def test_grounding_loss_golden(oracle_mod, path):
+    """vlg_grounding_loss vs the reference's own gather_logit_simple -> loss_grounding_factor_ce + autograd."""
+    from vlgae_amd import align
+    g = load(path)
+    txt, vis, pen, seg = _ground_inputs(g)
+    if pen is not None:   # the host-side prior table against the oracle's restatement of joint.py:446-470
+        pos_for = dict(obj=g["pos_for_obj"], rel=g["pos_for_rel"], attr=g["pos_for_attr"])
+        open_, oseg = oracle_mod.grounding_prior(g["tag"], g["factor_names"], g["vis_split"], pos_for, txt.shape[1])
+        assert np.array_equal(pen.cpu().numpy(), open_.astype(np.float32)) and np.array_equal(seg.cpu().numpy(), oseg)
+    total, sums = align.grounding_loss_factor_ce(txt, vis, t(g["tmask"]), t(g["vmask"]), t(g["marginal"]), int(g["num_token"]),
+                                                 float(g["vis2txt_weight"]), pen, seg)
+    s = sums.cpu().numpy()
+    assert abs(s[0] - float(g["txt2vis_raw"])) <= 1e-4 * abs(float(g["txt2vis_raw"]))
+    assert abs(s[1] - float(g["vis2txt_raw"])) <= 1e-4 * abs(float(g["vis2txt_raw"]))
+    assert abs(float(total) - float(g["total"])) <= 1e-4 * abs(float(g["total"]))
+    g_txt, g_vis = torch.autograd.grad(total, [txt, vis])
+    for name, got in (("g_txt", g_txt), ("g_vis", g_vis)):
+        assert np.abs(got.cpu().numpy() - g[name]).max() <= 1e-4 * max(1.0, np.abs(g[name]).max()), name
+
+
+@pytest.mark.parametrize("B,L,V,d,dt", [(5, 7, 9, 32, "f32"), (6, 40, 36, 128, "f32"), (6, 40, 36, 128, "bf16"),
+                                        (3, 50, 70, 64, "f32"), (4, 47, 100, 128, "bf16"), (1, 3, 1, 32, "f32")])
+def test_grounding_loss_shapes(oracle_mod, B, L, V, d, dt):
+    """Against the fp64 oracle: several row groups (Q > 96 / 48), several region groups (V > 48), one pair, bf16 storage."""
+    from vlgae_amd import align
+    rng = np.random.default_rng(B * 131 + L * 7 + V)
+    Q = 2 * (L + 1)
+    lengths = rng.integers(max(1, L // 2), L + 1, B)
+    m1 = np.concatenate([np.zeros((B, 1), bool), np.arange(L)[None] < lengths[:, None]], 1)
+    tmask = np.concatenate([m1, m1], 1)
+    vmask = rng.random((B, V)) > 0.2
+    vmask[:, 0] = True
+    txt = (rng.standard_normal((B, Q, d)) * 0.5).astype(np.float32)
+    vis = (rng.standard_normal((B, V, d)) * 0.5).astype(np.float32)
+    marg = (rng.random((B, Q)) * tmask).astype(np.float32)
+    split = [V] if V < 4 else [V // 2, V - V // 2 - 1, 1]
+    names = ["obj"] if V < 4 else ["obj", "rel", "img"]
+    tag = rng.integers(0, 6, (B, L))
+    pos_for = dict(obj=np.array([0, 1]), rel=np.array([1, 2]), attr=np.array([5]))
+    pen, seg = oracle_mod.grounding_prior(tag, names, split, pos_for, Q)
+    if dt == "bf16":
+        txt, vis = (torch.from_numpy(a).bfloat16().float().numpy() for a in (txt, vis))
+    ref = oracle_mod.grounding_loss(txt, vis, tmask, vmask, marg, int(lengths.sum()), 1.0, pen, seg, -1e20, np.float64)
+    tt, tv = t(txt), t(vis)
+    if dt == "bf16":
+        tt, tv = tt.bfloat16(), tv.bfloat16()
+    tt.requires_grad_(True)
+    tv.requires_grad_(True)
+    total, sums = align.grounding_loss_factor_ce(tt, tv, t(tmask), t(vmask), t(marg), int(lengths.sum()), 1.0,
+                                                 t(pen.astype(np.float32)), t(seg))
+    s = sums.cpu().numpy()
+    assert abs(s[0] - ref["txt2vis"]) <= 1e-4 * max(1.0, abs(ref["txt2vis"]))
+    assert abs(s[1] - ref["vis2txt"]) <= 1e-4 * max(1.0, abs(ref["vis2txt"]))
+    g_txt, g_vis = torch.autograd.grad(total, [tt, tv])
+    tol = 1e-2 if dt == "bf16" else 1e-4   # bf16 gradients are rounded on return
+    assert np.abs(g_txt.float().cpu().numpy() - ref["g_txt"]).max() <= tol * max(1.0, np.abs(ref["g_txt"]).max())
+    assert np.abs(g_vis.float().cpu().numpy() - ref["g_vis"]).max() <= tol * max(1.0, np.abs(ref["g_vis"]).max())
+    # bit-reproducible: no atomics
+    total2, _ = align.grounding_loss_factor_ce(tt, tv, t(tmask), t(vmask), t(marg), int(lengths.sum()), 1.0,
+                                               t(pen.astype(np.float32)), t(seg))
+    g2 = torch.autograd.grad(total2, [tt, tv])
+    assert torch.equal(g2[0], g_txt) and torch.equal(g2[1], g_vis)

@@ -30,6 +30,9 @@ SIGNATURES = {
     "vlg_dmv1o_merge": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "vlg_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vlg_bilinear_align": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "vlg_grounding_loss_workspace": (_sz, [_i, _i, _i]),
+    "vlg_grounding_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _sz, _vp, _vp,
+                                _vp, _vp]),
     "vlg_attn_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "vlg_attn_fuse_backward_workspace": (_sz, [_i, _i, _i, _i]),
     "vlg_attn_fuse_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp, _vp,

@@ -167,3 +167,111 @@ def attention_fuse(vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps=1
     beta = ln_bias.detach().to(torch.float32).contiguous()
     out, att = _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, return_attmap)
     return (out, att) if return_attmap else out
+
+
+# ----------------------------------------------------------------------------------------------
+# Grounding loss on the fused alignment maxima (joint.py:439-491) -- no [B,A,Q,V] tensor
+# ----------------------------------------------------------------------------------------------
+def grounding_prior(tag, factor_names, vis_split, pos_for, Q):
+    """The additive POS prior of joint.py:446-470 as a table.  tag [B,L] (vp.tag); factor_names / vis_split as in
+    `self.vis_factor_names` / `vis_packed[2]`; pos_for = {"obj": tensor, "rel": tensor, "attr": tensor}
+    (`self.pos_for_*`).  Returns (pen [B,Q,S] float32, seg_of_v [V] uint8): region v of segment s loses pen[b,q,s]
+    on the pair (b, b); rows outside the word queries 1..L stay 0."""
+    B, L = tag.shape
+    S = len(vis_split)
+    dev = tag.device
+    seg_of_v = torch.repeat_interleave(torch.arange(S, dtype=torch.uint8, device=dev),
+                                       torch.as_tensor(list(vis_split), device=dev))
+    pen = torch.zeros((B, Q, S), dtype=torch.float32, device=dev)
+    for f, name in enumerate(factor_names):
+        if name not in ("obj", "rel", "attr"):
+            continue
+        hit = tag.unsqueeze(-1).eq(pos_for[name].to(dev)).any(-1).to(torch.float32) * 100.0    # joint.py:452-463
+        others = [s for s in range(S) if s != f]
+        pen[:, 1:L + 1, others] += hit.unsqueeze(-1)
+    return pen, seg_of_v
+
+
+class _GroundingLoss(torch.autograd.Function):
+    """total of loss_grounding_factor_ce with gradients to both feature tensors, computed in one pass: alignment
+    maxima + arg-max (matrix cores) -> the two cross-entropies -> sparse row updates through the arg-max positions."""
+
+    @staticmethod
+    def forward(ctx, txt_feat, vis_feat, txt_mask, vis_mask, marginal, pen, seg_of_v, num_token, w_vis2txt, neg_inf):
+        B, Q, d = txt_feat.shape
+        V = vis_feat.shape[1]
+        dt, txt_c = _C.in_dtype(txt_feat.detach())
+        vis_c = vis_feat.detach().to(txt_c.dtype).contiguous()
+        dev = txt_c.device
+        tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        vm = None if vis_mask is None else vis_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        marg = marginal.detach().to(device=dev, dtype=torch.float32).contiguous()
+        n_seg = 0
+        if pen is not None:
+            pen = pen.to(device=dev, dtype=torch.float32).contiguous()
+            seg_of_v = seg_of_v.to(device=dev, dtype=torch.uint8).contiguous()
+            n_seg = pen.shape[2]
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        nbytes = _C.lib().vlg_grounding_loss_workspace(B, Q, V)
+        ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dev)
+        sums = torch.empty(3, dtype=torch.float32, device=dev)
+        g_txt = torch.empty((B, Q, d), dtype=torch.float32, device=dev) if need else None
+        g_vis = torch.empty((B, V, d), dtype=torch.float32, device=dev) if need else None
+        _C.check(_C.lib().vlg_grounding_loss(_C.ptr(txt_c), _C.ptr(vis_c), _C.ptr(tm), _C.ptr(vm), _C.ptr(marg), _C.ptr(pen),
+                                             _C.ptr(seg_of_v), n_seg, B, Q, V, d, dt, float(neg_inf), float(num_token),
+                                             float(w_vis2txt), _C.ptr(ws), nbytes, _C.ptr(sums), _C.ptr(g_txt), _C.ptr(g_vis),
+                                             _C.stream_of(txt_c)), "grounding_loss")
+        ctx.save_for_backward(g_txt, g_vis)
+        ctx.dtypes = (txt_feat.dtype, vis_feat.dtype)
+        ctx.mark_non_differentiable(sums)
+        return sums[2].clone(), sums
+
+    @staticmethod
+    def backward(ctx, g_total, _g_sums):
+        g_txt, g_vis = ctx.saved_tensors
+        out = [None] * 10
+        if ctx.needs_input_grad[0]:
+            out[0] = (g_txt * g_total).to(ctx.dtypes[0])
+        if ctx.needs_input_grad[1]:
+            out[1] = (g_vis * g_total).to(ctx.dtypes[1])
+        return tuple(out)
+
+
+def grounding_loss_factor_ce(txt_feat, vis_feat, txt_mask, vis_mask, txt_marginal, num_token, vis2txt=1.0, pen=None,
+                             seg_of_v=None, neg_inf=-INF):
+    """gather_logit_simple + loss_grounding_factor_ce (joint.py:406-419, 439-491) for B captions x B images.
+
+    Returns (total, sums) with sums = [txt2vis, vis2txt, total] (raw sums; the reference reports
+    s / (s.detach() + 1e-6) * num_token for each, which total already contains).  `total` back-propagates to txt_feat
+    and vis_feat; txt_marginal is a constant, as in the reference (joint.py:251-268 builds it from detached scores)."""
+    txt_feat, vis_feat, txt_mask, vis_mask, txt_marginal = (_plain(t) for t in (txt_feat, vis_feat, txt_mask, vis_mask,
+                                                                                txt_marginal))
+    _C.require_gpu(txt_feat, "grounding_loss_factor_ce")
+    B, Q, d = txt_feat.shape
+    if vis_feat.shape[0] != B or vis_feat.shape[2] != d:
+        raise ValueError(f"grounding loss pairs caption b with image b: txt {tuple(txt_feat.shape)} vis {tuple(vis_feat.shape)}")
+    if tuple(txt_marginal.shape) != (B, Q):
+        raise ValueError(f"txt_marginal must be [B,Q]={(B, Q)}, got {tuple(txt_marginal.shape)}")
+    return _GroundingLoss.apply(txt_feat, vis_feat, txt_mask, vis_mask, txt_marginal, pen, seg_of_v, num_token, vis2txt,
+                                neg_inf)
+
+
+def loss_grounding_factor_ce(self, inputs, vp):
+    """The reference method's signature (joint.py:441-442), so it registers as an impl:
+    `JointModelBase.add_impl_to_group("loss_grounding", "factor|ce|mi355x")(loss_grounding_factor_ce)`.
+    Reads the packed features instead of inputs["match_logit"] (which then never needs to be built); the entries of the
+    returned dict are the reference's per-term values, detached (they are only logged there)."""
+    txt_feat, txt_mask, txt_marginal = inputs["txt_packed"]
+    vis_feat, vis_mask, vis_split = inputs["vis_packed"]
+    args = self.cfg.loss_grounding_args
+    pen = seg = None
+    if args.use_pos_prior:
+        pos_for = {"obj": self.pos_for_obj, "rel": self.pos_for_rel, "attr": self.pos_for_attr}
+        pen, seg = grounding_prior(vp.tag, self.vis_factor_names, vis_split, pos_for, txt_feat.shape[1])
+    num = vp.num_token
+    total, sums = grounding_loss_factor_ce(txt_feat, vis_feat, txt_mask, vis_mask, txt_marginal, num, float(args.vis2txt),
+                                           pen, seg)
+    loss = {"txt2vis": sums[0] / (sums[0] + 1e-6) * num}
+    if args.vis2txt > 0:
+        loss["mt_vis2txt"] = args.vis2txt * sums[1] / (sums[1] + 1e-6) * num
+    return total, loss

@@ -15,6 +15,7 @@
 
 #include "vlg_common.h"
 #include "vlg_dp_core.h"   // F32In / BF16In element loaders
+#include "vlg_ground.h"
 
 namespace vlg {
 
@@ -147,19 +148,32 @@ __device__ __forceinline__ f32x4 mma_chunk(const typename MfmaCfg<F32IN>::Frag& 
 // d == KCH * KW exactly (dispatch guarantees it), so fragment loads need no K guards: lane l of a 16-row
 // operand tile loads elements [row l&15][kc*KW + EPL*(l>>4) .. +EPL) -- one 16-byte load, and the kc offsets
 // are instruction immediates.  Rows past the end are clamped; their products are never stored.
-template <bool F32IN, int KCH, bool TILE>
+// ARGS (the grounding loss's variant, TILE only): also records WHERE each maximum sits (first position on ties, like
+// a sequential scan) and, on the diagonal pairs a == b, subtracts the POS prior pen[b,q,seg(v)] before the maxima
+// (joint.py:446-470).  Separate instantiations: the plain paths pay nothing for it.
+struct AlignArgs {
+    const float* pen;          // [B,Q,n_seg] or null
+    const uint8_t* seg_of_v;   // [V]
+    int n_seg;
+    uint16_t* argV;            // [B,A,Q] region index of max over V
+    uint16_t* argQ;            // [B,A,V] query index of max over Q
+};
+
+template <bool F32IN, int KCH, bool TILE, bool ARGS>
 __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
     const typename MfmaCfg<F32IN>::T* __restrict__ txt, const typename MfmaCfg<F32IN>::T* __restrict__ vis,
     const uint8_t* __restrict__ tmask, const uint8_t* __restrict__ vmask, int B, int A, int Q, int V,
     float neg_inf, float* __restrict__ out_full, float* __restrict__ out_maxV, float* __restrict__ out_maxQ,
-    float* __restrict__ out_diag, int a_per_wave) {
+    float* __restrict__ out_diag, int a_per_wave, AlignArgs xa) {
+    static_assert(!ARGS || TILE, "arg-max tracking reads the LDS tile");
     using C = MfmaCfg<F32IN>;
     using Frag = typename C::Frag;
     constexpr int RTB = C::RTB, QB = RTB * 16, VB = kCTB * 16, d = KCH * C::KW;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
-    float* tile = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (QB * kTileVP + QB);   // [QB][kTileVP]
-    float* mv = tile + QB * kTileVP;                                                         // [QB] running max over V
+    float* tile = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (QB * kTileVP + 2 * QB);   // [QB][kTileVP]
+    float* mv = tile + QB * kTileVP;                                                             // [QB] running max over V
+    int* mi = reinterpret_cast<int*>(mv + QB);                                                   // [QB] ... and where (ARGS)
     const int a_begin = (blockIdx.x * 4 + wave) * a_per_wave;
     const typename C::T* txt_b = txt + (size_t)b * Q * d;
     const int crow = (lane >> 4) * 4, ccol = lane & 15;   // C/D fragment: row = 4*(l>>4) + reg, col = l&15
@@ -209,12 +223,18 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
             const int a = a_begin + ai, vn = min(VB, V - v0);
             const size_t ob = ((size_t)b * A + a) * Q;   // row base of this (b, a) pair
             float cmax[kCTB];   // running max over this lane's rows, per region column (for max over Q)
+            int cidx[kCTB];     // ... and the row that holds it (ARGS)
+            const bool prior_on = ARGS && xa.pen != nullptr && a == b;   // uniform
 
             auto compute = [&](int ct, const Frag* bf, unsigned keepv) {
                 // rows past Q and masked rows / columns all take the fill value, so one select + one max per element
                 const unsigned lane_keep = (v0 + ct * 16 + ccol < V && keepv != 0) ? tkeep : 0u;
                 float cm = neg_infinity();
+                int ci = 0;
                 float* tcol = tile + crow * kTileVP + ct * 16 + ccol;   // + (16*rt + e) * kTileVP: immediate offsets
+                const float* prow = nullptr;   // prior row of this lane's first C row, at this column's segment
+                if (prior_on)
+                    prow = xa.pen + (size_t)b * Q * xa.n_seg + xa.seg_of_v[min(v0 + ct * 16 + ccol, V - 1)];
 #pragma unroll
                 for (int rt = 0; rt < RTB; ++rt) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -222,11 +242,18 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
                     for (int kc = 0; kc < KCH; ++kc) acc = mma_chunk<F32IN>(afrag[rt][kc], bf[kc], acc);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float val = (lane_keep >> (rt * 4 + e)) & 1u ? acc[e] : neg_inf;   // joint.py:417-418
+                        float val = (lane_keep >> (rt * 4 + e)) & 1u ? acc[e] : neg_inf;   // joint.py:417-418
+                        if (ARGS) {
+                            const int ql = rt * 16 + crow + e;
+                            if (prior_on) val -= prow[(size_t)min(q0 + ql, Q - 1) * xa.n_seg];   // joint.py:466-469
+                            if (val > cm) { cm = val; ci = ql; }   // rows ascend: strict > keeps the first maximum
+                        } else {
+                            cm = fmaxf(cm, val);
+                        }
                         if (TILE) tcol[(rt * 16 + e) * kTileVP] = val;
-                        cm = fmaxf(cm, val);
                     }
                 }
+                if (ARGS) cidx[ct] = q0 + ci;
                 return cm;
             };
             load_tile(item, 2, f2, k2);
@@ -242,12 +269,29 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
 #pragma unroll
                 for (int ct = 0; ct < kCTB; ++ct) {
                     float m = cmax[ct];
-                    m = fmaxf(m, __shfl_xor(m, 16, 64));
-                    m = fmaxf(m, __shfl_xor(m, 32, 64));
                     const int vcol = v0 + ct * 16 + ccol;
-                    if (lane < 16 && vcol < V) {
-                        float* dst = out_maxQ + ((size_t)b * A + a) * V + vcol;
-                        *dst = q0 == 0 ? m : fmaxf(*dst, m);   // same wave handles every row group of (b, a)
+                    if (ARGS) {   // (value, row) pairs: larger value wins, equal values keep the smaller row
+                        int mi_ = cidx[ct];
+#pragma unroll
+                        for (int k = 16; k <= 32; k <<= 1) {
+                            const float om = __shfl_xor(m, k, 64);
+                            const int oi = __shfl_xor(mi_, k, 64);
+                            if (om > m || (om == m && oi < mi_)) { m = om; mi_ = oi; }
+                        }
+                        if (lane < 16 && vcol < V) {
+                            const size_t at = ((size_t)b * A + a) * V + vcol;
+                            if (q0 == 0 || m > out_maxQ[at]) {   // later row groups only win with a strictly larger value
+                                out_maxQ[at] = m;
+                                xa.argQ[at] = (uint16_t)mi_;
+                            }
+                        }
+                    } else {
+                        m = fmaxf(m, __shfl_xor(m, 16, 64));
+                        m = fmaxf(m, __shfl_xor(m, 32, 64));
+                        if (lane < 16 && vcol < V) {
+                            float* dst = out_maxQ + ((size_t)b * A + a) * V + vcol;
+                            *dst = q0 == 0 ? m : fmaxf(*dst, m);   // same wave handles every row group of (b, a)
+                        }
                     }
                 }
             }
@@ -306,12 +350,38 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
                             m1 = fmaxf(m1, vlo + u + 1 < vhi ? r[u + 1] : neg_infinity());
                         }
                         float m = fmaxf(m0, m1);
-                        m = fmaxf(m, __shfl_xor(m, 1, 64));
-                        m = fmaxf(m, __shfl_xor(m, 2, 64));
-                        if (part == 0 && q < qn) {
-                            if (v0 != 0) m = fmaxf(m, mv[q]);
-                            if (v0 + VB >= V) out_maxV[ob + q0 + q] = m;
-                            else mv[q] = m;
+                        if (ARGS) {
+                            int mi_ = 0;
+                            m = neg_infinity();
+#pragma unroll
+                            for (int u = 0; u < 12; ++u)   // ascending scan of this lane's quarter: first maximum
+                                if (vlo + u < vhi && r[u] > m) { m = r[u]; mi_ = vlo + u; }
+                            if (vlo >= vhi) mi_ = 0x7fff;   // empty quarter: never wins a tie
+#pragma unroll
+                            for (int k = 1; k <= 2; k <<= 1) {
+                                const float om = __shfl_xor(m, k, 64);
+                                const int oi = __shfl_xor(mi_, k, 64);
+                                if (om > m || (om == m && oi < mi_)) { m = om; mi_ = oi; }
+                            }
+                            mi_ += v0;
+                            if (part == 0 && q < qn) {
+                                if (v0 != 0 && !(m > mv[q])) { m = mv[q]; mi_ = mi[q]; }   // earlier groups keep ties
+                                if (v0 + VB >= V) {
+                                    out_maxV[ob + q0 + q] = m;
+                                    xa.argV[ob + q0 + q] = (uint16_t)mi_;
+                                } else {
+                                    mv[q] = m;
+                                    mi[q] = mi_;
+                                }
+                            }
+                        } else {
+                            m = fmaxf(m, __shfl_xor(m, 1, 64));
+                            m = fmaxf(m, __shfl_xor(m, 2, 64));
+                            if (part == 0 && q < qn) {
+                                if (v0 != 0) m = fmaxf(m, mv[q]);
+                                if (v0 + VB >= V) out_maxV[ob + q0 + q] = m;
+                                else mv[q] = m;
+                            }
                         }
                     }
                 }
@@ -321,23 +391,23 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
     }
 }
 
-template <bool F32IN, int KCH, bool TILE>
+template <bool F32IN, int KCH, bool TILE, bool ARGS = false>
 static int launch_align_mfma(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A,
                              int Q, int V, float neg_inf, float* out_full, float* out_maxV, float* out_maxQ,
-                             float* out_diag, hipStream_t s) {
+                             float* out_diag, hipStream_t s, AlignArgs xa = AlignArgs{nullptr, nullptr, 0, nullptr, nullptr}) {
     using C = MfmaCfg<F32IN>;
     const int a_per_wave = A >= 2048 ? 16 : A >= 64 ? 8 : 1;
     dim3 grid((A + 4 * a_per_wave - 1) / (4 * a_per_wave), B);
     constexpr int QB = C::RTB * 16;
-    const size_t lds = TILE ? sizeof(float) * 4 * (size_t)(QB * kTileVP + QB) : 0;
-    auto k = align_mfma_kernel<F32IN, KCH, TILE>;
+    const size_t lds = TILE ? sizeof(float) * 4 * (size_t)(QB * kTileVP + 2 * QB) : 0;
+    auto k = align_mfma_kernel<F32IN, KCH, TILE, ARGS>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
         if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(k, grid, dim3(kAlignThreads), lds, s, (const typename C::T*)txt, (const typename C::T*)vis, tmask,
-                       vmask, B, A, Q, V, neg_inf, out_full, out_maxV, out_maxQ, out_diag, a_per_wave);
+                       vmask, B, A, Q, V, neg_inf, out_full, out_maxV, out_maxQ, out_diag, a_per_wave, xa);
     return check_launch("align_mfma_kernel");
 }
 
@@ -393,6 +463,47 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
     else VLG_LAUNCH(BF16In);
 #undef VLG_LAUNCH
     return check_launch("align_kernel");
+}
+
+size_t vlg_grounding_loss_workspace(int B, int Q, int V) {
+    if (B < 1 || Q < 1 || V < 1) return 0;
+    return vlg::GroundPlan(B, Q, V).bytes;
+}
+
+int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marginal,
+                       const float* pen, const uint8_t* seg_of_v, int n_seg, int B, int Q, int V, int d, int in_dtype,
+                       float neg_inf, float num_token, float w_vis2txt, void* ws, size_t ws_bytes, float* out_sums,
+                       float* g_txt, float* g_vis, void* stream) {
+    using namespace vlg;
+    if (B < 1 || Q < 1 || V < 1 || d < 1)
+        return set_error(VLG_ERR_SHAPE, "grounding_loss: bad shape B=%d Q=%d V=%d d=%d", B, Q, V, d);
+    if (Q > 65535 || V > 32767) return set_error(VLG_ERR_SHAPE, "grounding_loss: Q=%d V=%d exceed the 16-bit position range", Q, V);
+    if (d > 256) return set_error(VLG_ERR_SHAPE, "grounding_loss: d=%d > 256", d);
+    if (!txt || !vis || !marginal || !out_sums) return set_error(VLG_ERR_ARG, "grounding_loss: null buffer");
+    if (pen && (!seg_of_v || n_seg < 1)) return set_error(VLG_ERR_ARG, "grounding_loss: prior table without segments");
+    if (B > 65535) return set_error(VLG_ERR_SHAPE, "grounding_loss: B=%d exceeds grid.y", B);
+    if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "grounding_loss: in_dtype %d", in_dtype);
+    const GroundPlan p(B, Q, V);
+    if (!ws || ws_bytes < p.bytes) return set_error(VLG_ERR_WORKSPACE, "grounding_loss: workspace %zu bytes < %zu", ws_bytes, p.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    AlignArgs xa{pen, seg_of_v, n_seg, reinterpret_cast<uint16_t*>(wsf + p.off_argV), reinterpret_cast<uint16_t*>(wsf + p.off_argQ)};
+    const bool f32in = in_dtype == VLG_F32;
+    int rc = -1;
+#define VLG_GA(F32, KCHV)                                                                                          \
+    rc = launch_align_mfma<F32, KCHV, true, true>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr, wsf + p.off_maxV, \
+                                                  wsf + p.off_maxQ, nullptr, s, xa)
+    if (!f32in && d == 128) VLG_GA(false, 4);
+    else if (!f32in && d == 64) VLG_GA(false, 2);
+    else if (!f32in && d == 32) VLG_GA(false, 1);
+    else if (f32in && d == 128) VLG_GA(true, 8);
+    else if (f32in && d == 64) VLG_GA(true, 4);
+    else if (f32in && d == 32) VLG_GA(true, 2);
+    else return set_error(VLG_ERR_SHAPE, "grounding_loss: d=%d (supported: 32, 64, 128)", d);
+#undef VLG_GA
+    if (rc) return rc;
+    return launch_grounding_tail(txt, vis, tmask, vmask, marginal, B, Q, V, d, in_dtype, num_token, w_vis2txt, wsf, p, out_sums,
+                                 g_txt, g_vis, s);
 }
 
 }  // extern "C"

@@ -1,0 +1,340 @@
+// vlg_ground.hip -- the grounding loss on the fused alignment maxima (gfx950).
+//
+//   loss_grounding_factor_ce, src/model/joint.py:439-491, consuming what vlg_align.hip's ARGS variant of the alignment
+//   kernel leaves behind (max over regions / over queries of every caption x image pair, and where each maximum sits)
+//   instead of the [B,A,Q,V] tensor; and its gradient to both feature tensors.
+//
+//   1. ground_ce_kernel    : log-softmax cross-entropy along the pair axis, both directions with one kernel
+//                            (txt2vis: softmax over images of max_v, joint.py:472-476; vis2txt: softmax over captions
+//                            of max_q, :478-483).  Overwrites the maxima with w * (p - delta), the loss's derivative
+//                            w.r.t. them up to the global factor, and leaves one partial loss per block.
+//   2. ground_sum_kernel   : partial losses -> {txt2vis, vis2txt, total} and the two global factors
+//                            num / (loss + 1e-6)  (joint.py:477,484-489; denominators are detached there).
+//   3. ground_bwd_kernel   : the gradient reaches the features only through the arg-max positions (max), only where
+//                            both masks are on (masked_fill_), as  g * other_side_row  (the contraction).  One pair
+//                            is ONE row update, so this is sparse work: 2 * B*A*(Q+V) row-FMAs instead of two more
+//                            [B*Q, A*V] x [A*V, d] contractions over a 774 MB gradient tensor.
+//                            Block = one caption (gradient of txt) or one image (gradient of vis); every output row is
+//                            owned by exactly one wave, which adds its terms in a fixed order -- no atomics, and the
+//                            order is the CPU oracle's.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vlg_common.h"
+#include "vlg_dp_core.h"   // F32In / BF16In element loaders
+#include "vlg_ground.h"
+
+namespace vlg {
+
+constexpr int kCeThreads = 256;
+
+// Rows i = 0..n-1, columns j < ncols of  x[i][j] = buf[fixed * fixed_stride + i * row_stride + j]  (fixed = blockIdx.x).
+// Per column: log-softmax over i, the diagonal term i == fixed enters the loss with weight w[fixed][j].
+// The derivative is gated here, once, by the two masks (masked_fill_ passes no gradient): column j of this block must be
+// on in self_mask[fixed][j], and the arg-max position of (row i, column j) must be on in other_mask[i][.].
+template <typename W>
+__global__ __launch_bounds__(kCeThreads) void ground_ce_kernel(float* __restrict__ buf, size_t fixed_stride,
+                                                               size_t row_stride, int n, int ncols,
+                                                               const W* __restrict__ w, const uint16_t* __restrict__ arg,
+                                                               const uint8_t* __restrict__ self_mask,
+                                                               const uint8_t* __restrict__ other_mask, int n_other,
+                                                               float* __restrict__ partial) {
+    __shared__ float red[kCeThreads];
+    __shared__ float colv[kCeThreads];
+    const int fixed = blockIdx.x, tid = threadIdx.x;
+    float* base = buf + (size_t)fixed * fixed_stride;
+    float loss = 0.f;   // thread 0 accumulates the block's loss, columns in ascending order
+    for (int j0 = 0; j0 < ncols; j0 += kCeThreads) {
+        const int cw = min(kCeThreads, ncols - j0), P = kCeThreads / cw;   // P row slices per column
+        const int jl = tid % cw, part = tid / cw, j = j0 + jl;
+        const bool on = part < P;
+        // column maximum
+        float m = __uint_as_float(0xff800000u);
+        if (on)
+            for (int i = part; i < n; i += P) m = fmaxf(m, base[(size_t)i * row_stride + j]);
+        red[tid] = m;
+        __syncthreads();
+        if (tid < cw) {
+            float mm = red[tid];
+            for (int p = 1; p < P; ++p) mm = fmaxf(mm, red[p * cw + tid]);
+            colv[tid] = mm;
+        }
+        __syncthreads();
+        m = colv[jl];
+        __syncthreads();
+        // sum of exp
+        float z = 0.f;
+        if (on)
+            for (int i = part; i < n; i += P) z += __expf(base[(size_t)i * row_stride + j] - m);
+        red[tid] = z;
+        __syncthreads();
+        if (tid < cw) {
+            float zz = red[tid];
+            for (int p = 1; p < P; ++p) zz += red[p * cw + tid];   // fixed order
+            colv[tid] = zz;
+        }
+        __syncthreads();
+        z = colv[jl];
+        __syncthreads();
+        const float wt = on ? (w ? (float)w[(size_t)fixed * ncols + j] : 1.f) : 0.f;
+        if (tid < cw) red[tid] = -wt * ((base[(size_t)fixed * row_stride + j] - m) - __logf(z));   // joint.py:476-477
+        __syncthreads();
+        if (tid == 0)
+            for (int c = 0; c < cw; ++c) loss += red[c];
+        // derivative w.r.t. the maxima, in place
+        const float zinv = 1.f / z;
+        const float gate_j = on && (!self_mask || self_mask[(size_t)fixed * ncols + j]) ? wt : 0.f;
+        if (on)
+            for (int i = part; i < n; i += P) {
+                const size_t at = (size_t)fixed * fixed_stride + (size_t)i * row_stride + j;
+                const bool open_ = !other_mask || other_mask[(size_t)i * n_other + arg[at]];
+                buf[at] = open_ ? gate_j * (__expf(buf[at] - m) * zinv - (i == fixed ? 1.f : 0.f)) : 0.f;
+            }
+        __syncthreads();
+    }
+    if (tid == 0) partial[fixed] = loss;
+}
+
+// sums = {txt2vis, vis2txt, total};  coef = {c1, c2}: d total / d txt2vis, d total / d vis2txt.
+__global__ void ground_sum_kernel(const float* __restrict__ part1, const float* __restrict__ part2, int n, float num_token,
+                                  float w_v2t, float* __restrict__ sums, float* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float t2v = 0.f, v2t = 0.f;
+    for (int i = 0; i < n; ++i) t2v += part1[i];
+    for (int i = 0; i < n; ++i) v2t += part2[i];
+    const float c1 = num_token / (t2v + 1e-6f), c2 = w_v2t > 0.f ? w_v2t * num_token / (v2t + 1e-6f) : 0.f;
+    sums[0] = t2v;
+    sums[1] = v2t;
+    sums[2] = t2v * c1 + v2t * c2;
+    coef[0] = c1;
+    coef[1] = c2;
+}
+
+// ---- gradient to one side's features ---------------------------------------------------------------------------
+// SIDE_TXT: block = caption b, output rows = its queries q, the other side's rows are regions (a, v).
+//   gather part  (max over V): for every image a, row q receives  c1 * gV[b,a,q] * vis[a, argV[b,a,q]]
+//   scatter part (max over Q): term (a, v) lands on row argQ[b,a,v] with  c2 * gQ[b,a,v] * vis[a, v]
+// SIDE_VIS: block = image a, output rows = its regions v, the other side's rows are queries (b, q).
+//   scatter part (max over V): term (b, q) lands on row argV[b,a,q] with  c1 * gV[b,a,q] * txt[b, q]
+//   gather part  (max over Q): for every caption b, row v receives  c2 * gQ[b,a,v] * txt[b, argQ[b,a,v]]
+// (gV / gQ arrive already gated by the masks.)  One term = one row update of d floats, and the machine is bound by the
+// latency of the row reads, so the kernel is organised around keeping many of them in flight:
+//   * 16 waves per block; output row r belongs to wave r mod 16, for both parts -- one owner per row, so no two waves
+//     ever add into the same row and a row's terms are added in program order (run-to-run reproducible, no global atomics);
+//   * a term is served by d/4 lanes (16-byte reads), so one instruction serves 64/(d/4) terms (2 at d = 128);
+//     kGbStep such instructions are issued back to back before the first result is used;
+//   * gather terms of an owned row accumulate in registers; scatter terms first pass an ownership test 64 at a time
+//     (one per lane), the survivors are compacted in order into a small per-wave LDS queue, and full queues are
+//     drained into the row accumulators in LDS (plain read-add-write: the wave owns the rows).
+constexpr int kGbWaves = 16, kGbStep = 16, kGbQueue = 128;
+
+template <typename In>
+__device__ __forceinline__ float4 row_ld4(const typename In::T* p);
+template <>
+__device__ __forceinline__ float4 row_ld4<F32In>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 row_ld4<BF16In>(const uint16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <typename In, bool SIDE_TXT>
+__global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
+    const typename In::T* __restrict__ txt, const typename In::T* __restrict__ vis, const float* __restrict__ gV,
+    const uint16_t* __restrict__ argV, const float* __restrict__ gQ, const uint16_t* __restrict__ argQ,
+    const float* __restrict__ coef, int B, int Q, int V, int d, float* __restrict__ out) {
+    const int A = B;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int self = blockIdx.x;   // caption b (SIDE_TXT) or image a
+    const int n_rows = SIDE_TXT ? Q : V, n_other = SIDE_TXT ? V : Q;
+    const typename In::T* other = SIDE_TXT ? vis : txt;   // [B][n_other][d]
+    const float* g_gather = SIDE_TXT ? gV : gQ;
+    const uint16_t* a_gather = SIDE_TXT ? argV : argQ;
+    const float* g_scatter = SIDE_TXT ? gQ : gV;
+    const uint16_t* a_scatter = SIDE_TXT ? argQ : argV;
+    const float c_gather = SIDE_TXT ? coef[0] : coef[1], c_scatter = SIDE_TXT ? coef[1] : coef[0];
+    auto pair_base = [&](int p, int n) -> size_t { return SIDE_TXT ? ((size_t)self * A + p) * n : ((size_t)p * A + self) * n; };
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* acc = reinterpret_cast<float*>(smem_raw);                       // [n_rows][d]
+    int* q_src = reinterpret_cast<int*>(acc + (size_t)n_rows * d) + wave * kGbQueue;   // per-wave queue: source row ...
+    int* q_dst = q_src + kGbWaves * kGbQueue;                              // ... destination row ...
+    float* q_g = reinterpret_cast<float*>(q_dst + kGbWaves * kGbQueue);    // ... weight
+    for (int i = threadIdx.x; i < n_rows * d; i += 64 * kGbWaves) acc[i] = 0.f;
+    __syncthreads();
+
+    const int lpt = d >> 2, tps = 64 / lpt;     // lanes per term, terms per instruction
+    const int sub = lane / lpt, fl = (lane - sub * lpt) * 4;
+
+    // 64 terms, one per lane (src row, weight; weight 0 = padding), all for destination `dst` (uniform): registers.
+    auto gather64 = [&](int src, float g, float4& sum) {
+        for (int s0 = 0; s0 < 64; s0 += tps * kGbStep) {
+            float4 x[kGbStep];
+            float gg[kGbStep];
+#pragma unroll
+            for (int k = 0; k < kGbStep; ++k) {
+                const int i = min(s0 + k * tps + sub, 63);
+                const int si = __shfl(src, i, 64);
+                gg[k] = s0 + k * tps + sub < 64 ? __shfl(g, i, 64) : 0.f;
+                x[k] = row_ld4<In>(other + (size_t)si * d + fl);
+            }
+#pragma unroll
+            for (int k = 0; k < kGbStep; ++k) {
+                sum.x = fmaf(gg[k], x[k].x, sum.x); sum.y = fmaf(gg[k], x[k].y, sum.y);
+                sum.z = fmaf(gg[k], x[k].z, sum.z); sum.w = fmaf(gg[k], x[k].w, sum.w);
+            }
+        }
+    };
+    // up to 64 queued terms (one per lane; weight 0 = padding) into the LDS accumulators.
+    auto scatter64 = [&](int src, int dst, float g) {
+        for (int s0 = 0; s0 < 64; s0 += tps * kGbStep) {
+            float4 x[kGbStep];
+            float gg[kGbStep];
+            int dd[kGbStep];
+#pragma unroll
+            for (int k = 0; k < kGbStep; ++k) {
+                const int i = min(s0 + k * tps + sub, 63);
+                const int si = __shfl(src, i, 64);
+                dd[k] = __shfl(dst, i, 64);
+                gg[k] = s0 + k * tps + sub < 64 ? __shfl(g, i, 64) : 0.f;
+                x[k] = row_ld4<In>(other + (size_t)si * d + fl);
+            }
+            // plain read-add-write on the owner's rows.  The terms served by one instruction may share a row, so they
+            // take turns; LDS float atomics would not need that but measured 10x slower here (2.7 ms vs 0.25 ms).
+#pragma unroll
+            for (int k = 0; k < kGbStep; ++k)
+                for (int turn = 0; turn < tps; ++turn)
+                    if (sub == turn && gg[k] != 0.f) {
+                        float4* cell = reinterpret_cast<float4*>(acc + (size_t)dd[k] * d + fl);
+                        float4 c = *cell;
+                        c.x = fmaf(gg[k], x[k].x, c.x); c.y = fmaf(gg[k], x[k].y, c.y);
+                        c.z = fmaf(gg[k], x[k].z, c.z); c.w = fmaf(gg[k], x[k].w, c.w);
+                        *cell = c;
+                    }
+        }
+    };
+
+    // ---- max-over-V terms first (gather for txt, scatter for vis), then max-over-Q terms: the oracle's order ----
+    for (int phase = 0; phase < 2; ++phase) {
+        const bool do_gather = SIDE_TXT ? phase == 0 : phase == 1;
+        if (do_gather) {
+            if (c_gather == 0.f) continue;
+            for (int row = wave; row < n_rows; row += kGbWaves) {
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int p0 = 0; p0 < B; p0 += 64) {
+                    const int p = min(p0 + lane, B - 1);
+                    const size_t at = pair_base(p, n_rows) + row;
+                    const int src = p * n_other + a_gather[at];
+                    const float g = p0 + lane < B ? c_gather * g_gather[at] : 0.f;
+                    gather64(src, g, sum);
+                }
+                // the tps sub-terms of an instruction each hold a partial sum of the row: fold them in a fixed order
+                for (int k = lpt; k < 64; k <<= 1) {
+                    sum.x += __shfl_xor(sum.x, k, 64); sum.y += __shfl_xor(sum.y, k, 64);
+                    sum.z += __shfl_xor(sum.z, k, 64); sum.w += __shfl_xor(sum.w, k, 64);
+                }
+                if (sub == 0) {
+                    float4* cell = reinterpret_cast<float4*>(acc + (size_t)row * d + fl);
+                    float4 c = *cell;
+                    c.x += sum.x; c.y += sum.y; c.z += sum.z; c.w += sum.w;
+                    *cell = c;
+                }
+            }
+        } else {
+            if (c_scatter == 0.f) continue;
+            const int n_terms = B * n_other;
+            int queued = 0;   // uniform
+            for (int t0 = 0; t0 < n_terms; t0 += 64) {
+                const int t = t0 + lane;
+                int row = -1;
+                float g = 0.f;
+                if (t < n_terms) {
+                    const int p = t / n_other, pos = t - p * n_other;
+                    const size_t at = pair_base(p, n_other) + pos;
+                    const int r = a_scatter[at];
+                    g = c_scatter * g_scatter[at];
+                    if ((r & (kGbWaves - 1)) == wave && g != 0.f) row = r;
+                }
+                const unsigned long long hits = __ballot(row >= 0);
+                if (row >= 0) {   // compact in term order behind what is already queued
+                    const int at = queued + __popcll(hits & ((1ull << lane) - 1ull));
+                    q_src[at] = t;   // flat row index on the other side = p * n_other + pos
+                    q_dst[at] = row;
+                    q_g[at] = g;
+                }
+                queued += __popcll(hits);
+                if (queued >= 64) {
+                    scatter64(q_src[lane], q_dst[lane], q_g[lane]);
+                    queued -= 64;
+                    if (lane < queued) {   // move the tail to the front (tail < 64 entries: read before write per lane)
+                        const int s_ = q_src[64 + lane], d_ = q_dst[64 + lane];
+                        const float g_ = q_g[64 + lane];
+                        q_src[lane] = s_; q_dst[lane] = d_; q_g[lane] = g_;
+                    }
+                }
+            }
+            if (queued > 0) scatter64(lane < queued ? q_src[lane] : 0, lane < queued ? q_dst[lane] : 0, lane < queued ? q_g[lane] : 0.f);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x * 4; i < n_rows * d; i += 64 * kGbWaves * 4)
+        *reinterpret_cast<float4*>(out + (size_t)self * n_rows * d + i) = *reinterpret_cast<const float4*>(acc + i);
+}
+
+template <typename In>
+static int launch_bwd(const void* txt, const void* vis, const float* gV, const uint16_t* argV, const float* gQ,
+                      const uint16_t* argQ, const float* coef, int B, int Q, int V, int d, float* g_txt, float* g_vis,
+                      hipStream_t s) {
+    using P = const typename In::T*;
+    const size_t queue = (size_t)kGbWaves * kGbQueue * 12;
+    for (int side = 0; side < 2; ++side) {
+        float* out = side == 0 ? g_txt : g_vis;
+        if (!out) continue;
+        const size_t lds = sizeof(float) * (size_t)(side == 0 ? Q : V) * d + queue;
+        if (lds > 160 * 1024) return set_error(VLG_ERR_SHAPE, "grounding_loss: %d rows x d=%d exceed the LDS accumulator budget", side == 0 ? Q : V, d);
+        auto k = side == 0 ? ground_bwd_kernel<In, true> : ground_bwd_kernel<In, false>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(k, dim3(B), dim3(64 * kGbWaves), lds, s, (P)txt, (P)vis, gV, argV, gQ, argQ, coef, B, Q, V, d, out);
+    }
+    return 0;
+}
+
+GroundPlan::GroundPlan(int B, int Q, int V) {
+    const size_t nV = (size_t)B * B * Q, nQ = (size_t)B * B * V;
+    auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };   // 256-byte aligned float offsets
+    off_maxV = 0;
+    off_maxQ = up(nV);
+    off_part = off_maxQ + up(nQ);
+    off_coef = off_part + up(2 * (size_t)B);
+    off_argV = off_coef + 64;                          // uint16 arrays, offsets still counted in floats
+    off_argQ = off_argV + up((nV + 1) / 2);
+    bytes = sizeof(float) * (off_argQ + up((nQ + 1) / 2));
+}
+
+int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marg,
+                          int B, int Q, int V, int d, int in_dtype, float num_token, float w_v2t, float* ws,
+                          const GroundPlan& p, float* out_sums, float* g_txt, float* g_vis, hipStream_t s) {
+    float *mV = ws + p.off_maxV, *mQ = ws + p.off_maxQ, *part = ws + p.off_part, *coef = ws + p.off_coef;
+    const uint16_t* aV = reinterpret_cast<const uint16_t*>(ws + p.off_argV);
+    const uint16_t* aQ = reinterpret_cast<const uint16_t*>(ws + p.off_argQ);
+    // txt2vis: fixed = caption b, rows = images a: x[a][q] = mV[(b*A + a)*Q + q]; gate: tmask[b][q], vmask[a][argV]
+    hipLaunchKernelGGL(ground_ce_kernel<float>, dim3(B), dim3(kCeThreads), 0, s, mV, (size_t)B * Q, (size_t)Q, B, Q, marg, aV,
+                       tmask, vmask, V, part);
+    // vis2txt: fixed = image a, rows = captions b: x[b][v] = mQ[(b*A + a)*V + v]; weights = vis_mask as 0/1 (joint.py:481,
+    // null = all ones); gate: vmask[a][v], tmask[b][argQ]
+    hipLaunchKernelGGL(ground_ce_kernel<uint8_t>, dim3(B), dim3(kCeThreads), 0, s, mQ, (size_t)V, (size_t)B * V, B, V, vmask, aQ,
+                       vmask, tmask, Q, part + B);
+    hipLaunchKernelGGL(ground_sum_kernel, dim3(1), dim3(64), 0, s, part, part + B, B, num_token, w_v2t, out_sums, coef);
+    if (g_txt || g_vis) {
+        const int rc = in_dtype == VLG_F32 ? launch_bwd<F32In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s)
+                                           : launch_bwd<BF16In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s);
+        if (rc) return rc;
+    }
+    return check_launch("grounding_loss");
+}
+
+}  // namespace vlg
