@@ -263,6 +263,41 @@ def main():
                 "GB/s": byts / sec / 1e9, "frac_hbm": byts / sec / 1e9 / HBM_PEAK_GBS,
                 "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in, fp32 out"}
 
+        # the two consumers on the training path: attention-fuse (joint.py:670-674) and the grounding loss on the
+        # fused maxima (joint.py:439-491), forward + gradients, through the host API
+        def timed(fn, n):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / n
+        h = 256
+        mk = lambda *shape: torch.randn(*shape, generator=g).to(dev, in_dtype).requires_grad_(True)
+        f_vis, f_txt, f_mid, f_enc = mk(B, V, d), mk(B, N, d), mk(B, V, h), mk(B, L, h)
+        ln_w, ln_b = torch.ones(h, device=dev, requires_grad=True), torch.zeros(h, device=dev, requires_grad=True)
+        dout = torch.randn(B, L, h, generator=g).to(dev)
+        leaves = [f_vis, f_txt, f_mid, f_enc, ln_w, ln_b]
+        out["attention_fuse"] = {
+            "fwd_ms": timed(lambda: align.attention_fuse(f_vis.detach(), f_txt.detach(), f_mid.detach(), f_enc.detach(),
+                                                         ln_w.detach(), ln_b.detach(), 1e-5), 50),
+            "fwd_bwd_ms": timed(lambda: torch.autograd.grad(align.attention_fuse(*leaves, 1e-5), leaves, dout), 50),
+            "shape": f"B={B} L={L} V={V} d={d} h={h} {args.dtype} in; host API incl. autograd overhead"}
+        tmask = torch.ones(B, Q, dtype=torch.bool, device=dev)
+        tmask[:, 0] = tmask[:, N] = False
+        vmask = torch.ones(B, V, dtype=torch.bool, device=dev)
+        marg = torch.rand(B, Q, generator=g).to(dev) * tmask
+        g_txt, g_vis = mk(B, Q, d), mk(B, V, d)
+        def ground():
+            total, _ = align.grounding_loss_factor_ce(g_txt, g_vis, tmask, vmask, marg, B * L, 1.0)
+            return torch.autograd.grad(total, [g_txt, g_vis])
+        out["grounding_loss"] = {"fwd_bwd_ms": timed(ground, 10),
+                                 "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in; loss + gradients, no [B,A,Q,V] tensor"}
+
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(B, L, 1000, args.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = sent_per_s / out["cpu_baseline"]["value"]

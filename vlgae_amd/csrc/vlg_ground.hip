@@ -96,18 +96,22 @@ __global__ __launch_bounds__(kCeThreads) void ground_ce_kernel(float* __restrict
 }
 
 // sums = {txt2vis, vis2txt, total};  coef = {c1, c2}: d total / d txt2vis, d total / d vis2txt.
-__global__ void ground_sum_kernel(const float* __restrict__ part1, const float* __restrict__ part2, int n, float num_token,
-                                  float w_v2t, float* __restrict__ sums, float* __restrict__ coef) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One wave: lane i adds partials i, i+64, ... in order, then a fixed xor tree (same bits every run).
+__global__ __launch_bounds__(64) void ground_sum_kernel(const float* __restrict__ part1, const float* __restrict__ part2, int n,
+                                                        float num_token, float w_v2t, float* __restrict__ sums,
+                                                        float* __restrict__ coef) {
     float t2v = 0.f, v2t = 0.f;
-    for (int i = 0; i < n; ++i) t2v += part1[i];
-    for (int i = 0; i < n; ++i) v2t += part2[i];
-    const float c1 = num_token / (t2v + 1e-6f), c2 = w_v2t > 0.f ? w_v2t * num_token / (v2t + 1e-6f) : 0.f;
-    sums[0] = t2v;
-    sums[1] = v2t;
-    sums[2] = t2v * c1 + v2t * c2;
-    coef[0] = c1;
-    coef[1] = c2;
+    for (int i = threadIdx.x; i < n; i += 64) { t2v += part1[i]; v2t += part2[i]; }
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) { t2v += __shfl_xor(t2v, k, 64); v2t += __shfl_xor(v2t, k, 64); }
+    if (threadIdx.x == 0) {
+        const float c1 = num_token / (t2v + 1e-6f), c2 = w_v2t > 0.f ? w_v2t * num_token / (v2t + 1e-6f) : 0.f;
+        sums[0] = t2v;
+        sums[1] = v2t;
+        sums[2] = t2v * c1 + v2t * c2;
+        coef[0] = c1;
+        coef[1] = c2;
+    }
 }
 
 // ---- gradient to one side's features ---------------------------------------------------------------------------
