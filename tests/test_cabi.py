@@ -75,3 +75,37 @@ def test_workspace_sizing(lib):
     assert lib.vlg_workspace_bytes(_C.OP_DEPTREE_INSIDE_OUTSIDE, 256, 81, 0) == 0
     assert lib.vlg_workspace_bytes(_C.OP_DEPTREE_INSIDE_OUTSIDE, 4, 200, 0) > 0
     assert lib.vlg_workspace_bytes(99, 4, 41, 0) == 0 and lib.vlg_workspace_bytes(0, 0, 41, 0) == 0
+
+
+def test_attn_and_grounding_entry_points_validate_on_the_host(lib):
+    """Same contract for the later entry points: shape / dtype / null / workspace errors before any HIP call."""
+    P = ctypes.c_void_p
+    one = P(16)   # any non-null pointer: validation must fail before it is dereferenced
+    # attention-fuse adjoint: d, h multiples of 16 and <= 256
+    bw = lib.vlg_attn_fuse_backward
+    assert bw(one, one, one, one, one, one, 2, 5, 7, 24, 64, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1001
+    assert b"multiples of 16" in lib.vlg_last_error()
+    assert bw(one, one, one, one, one, one, 2, 5, 7, 32, 512, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1001
+    assert bw(one, one, one, one, one, one, 2, 5, 7, 32, 64, 9, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1002
+    assert bw(None, one, one, one, one, one, 2, 5, 7, 32, 64, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1003
+    need = lib.vlg_attn_fuse_backward_workspace(2, 5, 7, 64)
+    assert need > 0 and lib.vlg_attn_fuse_backward_workspace(4, 5, 7, 64) > need and lib.vlg_attn_fuse_backward_workspace(0, 5, 7, 64) == 0
+    assert bw(one, one, one, one, one, one, 2, 5, 7, 32, 64, 0, 1e-5, one, need - 1, one, one, one, one, one, one, None) == 0x1004
+    assert b"workspace" in lib.vlg_last_error()
+    # grounding loss: d in {32, 64, 128}, 16-bit positions, prior table needs its segment map
+    gl = lib.vlg_grounding_loss
+    need = lib.vlg_grounding_loss_workspace(3, 14, 9)
+    assert need > 0 and need % 256 == 0 and lib.vlg_grounding_loss_workspace(6, 14, 9) > 2 * need
+    args = lambda **kw: [kw.get("txt", one), one, None, None, one, kw.get("pen", None), kw.get("seg", None), kw.get("n_seg", 0), 3,
+                         kw.get("Q", 14), 9, kw.get("d", 32), kw.get("dt", 0), -1e20, 30.0, 1.0, one, kw.get("ws", need), one, None,
+                         None, None]
+    assert gl(*args(d=48)) == 0x1001 and b"d=48" in lib.vlg_last_error()
+    assert gl(*args(d=512)) == 0x1001
+    assert gl(*args(Q=70000)) == 0x1001
+    assert gl(*args(dt=3)) == 0x1002
+    assert gl(*args(txt=None)) == 0x1003
+    assert gl(*args(pen=one)) == 0x1003 and b"segments" in lib.vlg_last_error()
+    assert gl(*args(ws=need - 1)) == 0x1004
+    # attention-fuse forward
+    assert lib.vlg_attn_fuse(one, one, one, one, one, one, 2, 0, 7, 32, 64, 0, 1e-5, None, one, None) == 0x1001
+    assert lib.vlg_attn_fuse(one, one, one, one, one, one, 0, 5, 7, 32, 64, 0, 1e-5, None, one, None) == 0      # empty batch
