@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64) void ground_sum_kernel(const float* __restrict_
 //   * gather terms of an owned row accumulate in registers; scatter terms first pass an ownership test 64 at a time
 //     (one per lane), the survivors are compacted in order into a small per-wave LDS queue, and full queues are
 //     drained into the row accumulators in LDS (plain read-add-write: the wave owns the rows).
-constexpr int kGbWaves = 16, kGbStep = 16, kGbQueue = 128;
+constexpr int kGbWaves = 16, kGbStep = 16, kGbQueue = 128, kGbScan = 4, kGbDrain = 8;
 
 template <typename In>
 __device__ __forceinline__ float4 row_ld4(const typename In::T* p);
@@ -143,7 +143,9 @@ __device__ __forceinline__ float4 row_ld4<BF16In>(const uint16_t* p) {
                        __uint_as_float(u.y & 0xffff0000u));
 }
 
-template <typename In, bool SIDE_TXT>
+// NS > 0: this block has at most 16 NS output rows, so a wave owns at most NS of them and the scatter part keeps them in
+// registers too (per-lane slot select); NS == 0: any number of rows, scatter drains into the LDS rows by read-add-write.
+template <typename In, bool SIDE_TXT, int NS>
 __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
     const typename In::T* __restrict__ txt, const typename In::T* __restrict__ vis, const float* __restrict__ gV,
     const uint16_t* __restrict__ argV, const float* __restrict__ gQ, const uint16_t* __restrict__ argQ,
@@ -190,32 +192,48 @@ __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
             }
         }
     };
-    // up to 64 queued terms (one per lane; weight 0 = padding) into the LDS accumulators.
+    // up to 64 queued terms (one per lane; weight 0 = padding) into the row accumulators.
+    float4 racc[NS > 0 ? NS : 1];
     auto scatter64 = [&](int src, int dst, float g) {
-        for (int s0 = 0; s0 < 64; s0 += tps * kGbStep) {
-            float4 x[kGbStep];
-            float gg[kGbStep];
-            int dd[kGbStep];
+        for (int s0 = 0; s0 < 64; s0 += tps * kGbDrain) {
+            float4 x[kGbDrain];
+            float gg[kGbDrain];
+            int dd[kGbDrain];
 #pragma unroll
-            for (int k = 0; k < kGbStep; ++k) {
+            for (int k = 0; k < kGbDrain; ++k) {
                 const int i = min(s0 + k * tps + sub, 63);
                 const int si = __shfl(src, i, 64);
                 dd[k] = __shfl(dst, i, 64);
                 gg[k] = s0 + k * tps + sub < 64 ? __shfl(g, i, 64) : 0.f;
                 x[k] = row_ld4<In>(other + (size_t)si * d + fl);
             }
-            // plain read-add-write on the owner's rows.  The terms served by one instruction may share a row, so they
-            // take turns; LDS float atomics would not need that but measured 10x slower here (2.7 ms vs 0.25 ms).
+            if (NS > 0) {
+                // the wave owns rows wave, wave + 16, ...: slot = row / 16.  Lanes serving different terms of one
+                // instruction may hold different slots, so the select is per lane.
 #pragma unroll
-            for (int k = 0; k < kGbStep; ++k)
-                for (int turn = 0; turn < tps; ++turn)
-                    if (sub == turn && gg[k] != 0.f) {
-                        float4* cell = reinterpret_cast<float4*>(acc + (size_t)dd[k] * d + fl);
-                        float4 c = *cell;
-                        c.x = fmaf(gg[k], x[k].x, c.x); c.y = fmaf(gg[k], x[k].y, c.y);
-                        c.z = fmaf(gg[k], x[k].z, c.z); c.w = fmaf(gg[k], x[k].w, c.w);
-                        *cell = c;
+                for (int k = 0; k < kGbDrain; ++k) {
+                    const int slot = dd[k] >> 4;
+#pragma unroll
+                    for (int sl = 0; sl < NS; ++sl) {
+                        const float gs = slot == sl ? gg[k] : 0.f;
+                        racc[sl].x = fmaf(gs, x[k].x, racc[sl].x); racc[sl].y = fmaf(gs, x[k].y, racc[sl].y);
+                        racc[sl].z = fmaf(gs, x[k].z, racc[sl].z); racc[sl].w = fmaf(gs, x[k].w, racc[sl].w);
                     }
+                }
+            } else {
+                // plain read-add-write on the owner's rows.  The terms served by one instruction may share a row, so
+                // they take turns; LDS float atomics would not need that but measured 10x slower (2.7 ms vs 0.25 ms).
+#pragma unroll
+                for (int k = 0; k < kGbDrain; ++k)
+                    for (int turn = 0; turn < tps; ++turn)
+                        if (sub == turn && gg[k] != 0.f) {
+                            float4* cell = reinterpret_cast<float4*>(acc + (size_t)dd[k] * d + fl);
+                            float4 c = *cell;
+                            c.x = fmaf(gg[k], x[k].x, c.x); c.y = fmaf(gg[k], x[k].y, c.y);
+                            c.z = fmaf(gg[k], x[k].z, c.z); c.w = fmaf(gg[k], x[k].w, c.w);
+                            *cell = c;
+                        }
+            }
         }
     };
 
@@ -247,38 +265,65 @@ __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
             }
         } else {
             if (c_scatter == 0.f) continue;
+#pragma unroll
+            for (int sl = 0; sl < (NS > 0 ? NS : 1); ++sl) racc[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int n_terms = B * n_other;
             int queued = 0;   // uniform
-            for (int t0 = 0; t0 < n_terms; t0 += 64) {
-                const int t = t0 + lane;
-                int row = -1;
-                float g = 0.f;
-                if (t < n_terms) {
+            // kGbScan batches of 64 terms per trip: all their index / weight reads are in flight together (one batch per
+            // trip made the scan itself the bottleneck: a memory round trip per 64 terms, 16 waves each scanning all terms)
+            for (int t00 = 0; t00 < n_terms; t00 += 64 * kGbScan) {
+                int rows_[kGbScan];
+                float gs_[kGbScan];
+#pragma unroll
+                for (int u = 0; u < kGbScan; ++u) {
+                    const int t = min(t00 + 64 * u + lane, n_terms - 1);
                     const int p = t / n_other, pos = t - p * n_other;
                     const size_t at = pair_base(p, n_other) + pos;
-                    const int r = a_scatter[at];
-                    g = c_scatter * g_scatter[at];
-                    if ((r & (kGbWaves - 1)) == wave && g != 0.f) row = r;
+                    rows_[u] = a_scatter[at];
+                    gs_[u] = t00 + 64 * u + lane < n_terms ? c_scatter * g_scatter[at] : 0.f;
                 }
-                const unsigned long long hits = __ballot(row >= 0);
-                if (row >= 0) {   // compact in term order behind what is already queued
-                    const int at = queued + __popcll(hits & ((1ull << lane) - 1ull));
-                    q_src[at] = t;   // flat row index on the other side = p * n_other + pos
-                    q_dst[at] = row;
-                    q_g[at] = g;
-                }
-                queued += __popcll(hits);
-                if (queued >= 64) {
-                    scatter64(q_src[lane], q_dst[lane], q_g[lane]);
-                    queued -= 64;
-                    if (lane < queued) {   // move the tail to the front (tail < 64 entries: read before write per lane)
-                        const int s_ = q_src[64 + lane], d_ = q_dst[64 + lane];
-                        const float g_ = q_g[64 + lane];
-                        q_src[lane] = s_; q_dst[lane] = d_; q_g[lane] = g_;
+#pragma unroll
+                for (int u = 0; u < kGbScan; ++u) {
+                    const int t = t00 + 64 * u + lane;
+                    const int row = ((rows_[u] & (kGbWaves - 1)) == wave && gs_[u] != 0.f) ? rows_[u] : -1;
+                    const unsigned long long hits = __ballot(row >= 0);
+                    if (hits == 0) continue;
+                    if (row >= 0) {   // compact in term order behind what is already queued
+                        const int at = queued + __popcll(hits & ((1ull << lane) - 1ull));
+                        q_src[at] = t;   // flat row index on the other side = p * n_other + pos
+                        q_dst[at] = row;
+                        q_g[at] = gs_[u];
+                    }
+                    queued += __popcll(hits);
+                    if (queued >= 64) {
+                        scatter64(q_src[lane], q_dst[lane], q_g[lane]);
+                        queued -= 64;
+                        if (lane < queued) {   // move the tail to the front (tail < 64 entries: read before write per lane)
+                            const int s_ = q_src[64 + lane], d_ = q_dst[64 + lane];
+                            const float g_ = q_g[64 + lane];
+                            q_src[lane] = s_; q_dst[lane] = d_; q_g[lane] = g_;
+                        }
                     }
                 }
             }
             if (queued > 0) scatter64(lane < queued ? q_src[lane] : 0, lane < queued ? q_dst[lane] : 0, lane < queued ? q_g[lane] : 0.f);
+            if (NS > 0) {
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    float4 sum = racc[sl];
+                    for (int k = lpt; k < 64; k <<= 1) {   // fold the sub-term partials in a fixed order
+                        sum.x += __shfl_xor(sum.x, k, 64); sum.y += __shfl_xor(sum.y, k, 64);
+                        sum.z += __shfl_xor(sum.z, k, 64); sum.w += __shfl_xor(sum.w, k, 64);
+                    }
+                    const int row = wave + kGbWaves * sl;
+                    if (sub == 0 && row < n_rows) {
+                        float4* cell = reinterpret_cast<float4*>(acc + (size_t)row * d + fl);
+                        float4 c = *cell;
+                        c.x += sum.x; c.y += sum.y; c.z += sum.z; c.w += sum.w;
+                        *cell = c;
+                    }
+                }
+            }
         }
     }
     __syncthreads();
@@ -297,7 +342,11 @@ static int launch_bwd(const void* txt, const void* vis, const float* gV, const u
         if (!out) continue;
         const size_t lds = sizeof(float) * (size_t)(side == 0 ? Q : V) * d + queue;
         if (lds > 160 * 1024) return set_error(VLG_ERR_SHAPE, "grounding_loss: %d rows x d=%d exceed the LDS accumulator budget", side == 0 ? Q : V, d);
-        auto k = side == 0 ? ground_bwd_kernel<In, true> : ground_bwd_kernel<In, false>;
+        const int rows = side == 0 ? Q : V;
+        void (*k)(P, P, const float*, const uint16_t*, const float*, const uint16_t*, const float*, int, int, int, int, float*);
+        // register slots pay off up to 3 rows per wave; with 6 the per-lane selects cost more than the LDS round trips
+        if (side == 0) k = rows <= 48 ? ground_bwd_kernel<In, true, 3> : ground_bwd_kernel<In, true, 0>;
+        else k = rows <= 48 ? ground_bwd_kernel<In, false, 3> : ground_bwd_kernel<In, false, 0>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
