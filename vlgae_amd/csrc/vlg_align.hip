@@ -230,11 +230,44 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
                 // rows past Q and masked rows / columns all take the fill value, so one select + one max per element
                 const unsigned lane_keep = (v0 + ct * 16 + ccol < V && keepv != 0) ? tkeep : 0u;
                 float cm = neg_infinity();
-                int ci = 0;
                 float* tcol = tile + crow * kTileVP + ct * 16 + ccol;   // + (16*rt + e) * kTileVP: immediate offsets
-                const float* prow = nullptr;   // prior row of this lane's first C row, at this column's segment
-                if (prior_on)
-                    prow = xa.pen + (size_t)b * Q * xa.n_seg + xa.seg_of_v[min(v0 + ct * 16 + ccol, V - 1)];
+                if (ARGS) {
+                    // one (max, row) pair per row tile, merged afterwards: a single running pair would chain
+                    // 4 RTB dependent compare-selects (the plain path's v_max chain is reassociated by the compiler)
+                    const float* prow = nullptr;   // prior row of this lane's first C row, at this column's segment
+                    if (prior_on)
+                        prow = xa.pen + (size_t)b * Q * xa.n_seg + xa.seg_of_v[min(v0 + ct * 16 + ccol, V - 1)];
+                    float pm[RTB];
+                    int pi[RTB];
+#pragma unroll
+                    for (int rt = 0; rt < RTB; ++rt) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kc = 0; kc < KCH; ++kc) acc = mma_chunk<F32IN>(afrag[rt][kc], bf[kc], acc);
+                        float v4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float val = (lane_keep >> (rt * 4 + e)) & 1u ? acc[e] : neg_inf;   // joint.py:417-418
+                            if (prior_on) val -= prow[(size_t)min(q0 + rt * 16 + crow + e, Q - 1) * xa.n_seg];   // joint.py:466-469
+                            tcol[(rt * 16 + e) * kTileVP] = val;
+                            v4[e] = val;
+                        }
+                        // first maximum of the four rows (ascending): two independent pairs, then merge
+                        const bool b01 = v4[1] > v4[0], b23 = v4[3] > v4[2];
+                        const float m01 = b01 ? v4[1] : v4[0], m23 = b23 ? v4[3] : v4[2];
+                        const int i01 = b01 ? 1 : 0, i23 = b23 ? 3 : 2;
+                        const bool bb = m23 > m01;
+                        pm[rt] = bb ? m23 : m01;
+                        pi[rt] = rt * 16 + crow + (bb ? i23 : i01);
+                    }
+                    cm = pm[0];
+                    int ci = pi[0];
+#pragma unroll
+                    for (int rt = 1; rt < RTB; ++rt)
+                        if (pm[rt] > cm) { cm = pm[rt]; ci = pi[rt]; }   // row tiles ascend: strict > keeps the first maximum
+                    cidx[ct] = q0 + ci;
+                    return cm;
+                }
 #pragma unroll
                 for (int rt = 0; rt < RTB; ++rt) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -242,18 +275,11 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
                     for (int kc = 0; kc < KCH; ++kc) acc = mma_chunk<F32IN>(afrag[rt][kc], bf[kc], acc);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float val = (lane_keep >> (rt * 4 + e)) & 1u ? acc[e] : neg_inf;   // joint.py:417-418
-                        if (ARGS) {
-                            const int ql = rt * 16 + crow + e;
-                            if (prior_on) val -= prow[(size_t)min(q0 + ql, Q - 1) * xa.n_seg];   // joint.py:466-469
-                            if (val > cm) { cm = val; ci = ql; }   // rows ascend: strict > keeps the first maximum
-                        } else {
-                            cm = fmaxf(cm, val);
-                        }
+                        const float val = (lane_keep >> (rt * 4 + e)) & 1u ? acc[e] : neg_inf;   // joint.py:417-418
                         if (TILE) tcol[(rt * 16 + e) * kTileVP] = val;
+                        cm = fmaxf(cm, val);
                     }
                 }
-                if (ARGS) cidx[ct] = q0 + ci;
                 return cm;
             };
             load_tile(item, 2, f2, k2);
@@ -351,11 +377,22 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
                         }
                         float m = fmaxf(m0, m1);
                         if (ARGS) {
-                            int mi_ = 0;
-                            m = neg_infinity();
+                            // first maximum of this lane's quarter (ascending positions): pairwise tree, the
+                            // earlier position wins ties at every merge
+                            float tm[12];
+                            int ti[12];
 #pragma unroll
-                            for (int u = 0; u < 12; ++u)   // ascending scan of this lane's quarter: first maximum
-                                if (vlo + u < vhi && r[u] > m) { m = r[u]; mi_ = vlo + u; }
+                            for (int u = 0; u < 12; ++u) {
+                                tm[u] = vlo + u < vhi ? r[u] : neg_infinity();
+                                ti[u] = vlo + u;
+                            }
+#pragma unroll
+                            for (int span = 1; span < 12; span <<= 1)
+#pragma unroll
+                                for (int u = 0; u + span < 12; u += 2 * span)
+                                    if (tm[u + span] > tm[u]) { tm[u] = tm[u + span]; ti[u] = ti[u + span]; }
+                            m = tm[0];
+                            int mi_ = ti[0];
                             if (vlo >= vhi) mi_ = 0x7fff;   // empty quarter: never wins a tie
 #pragma unroll
                             for (int k = 1; k <= 2; k <<= 1) {

@@ -467,6 +467,12 @@ VLG_HD void dmv_bw(const DmvCtx& c, int w, int tid, int nt, X& x) {
         //  would push the kernel past 128 VGPRs = one 512-lane workgroup per CU instead of two)
         if (T == 1) dmv_bw_span<SR, 1>(c, w, lg, i, live, rr, x);
         else if (T == 2) dmv_bw_span<SR, 2>(c, w, lg, i, live, rr, x);
+#if defined(VLG_DP_BW_TU_MAX) && VLG_DP_BW_TU_MAX >= 3
+        else if (T == 3) dmv_bw_span<SR, 3>(c, w, lg, i, live, rr, x);
+#endif
+#if defined(VLG_DP_BW_TU_MAX) && VLG_DP_BW_TU_MAX >= 4
+        else if (T == 4) dmv_bw_span<SR, 4>(c, w, lg, i, live, rr, x);
+#endif
         else dmv_bw_span<SR, 0>(c, w, lg, i, live, rr, x);
     }
 }
