@@ -213,6 +213,39 @@ def attn_fuse_backward(vis, txt, vis_mid, enc_x, gamma, dout, eps=1e-5, dtype=np
     return tuple(outs)
 
 
+def arc_encoder(child, parent, w1, w2=None, b=None, dtype=np.float32):
+    """joint.py:281-287: einsum('bcx,xhy,bcy->bch', child, w1, parent) + (child + parent) @ w2 + b.  [..., X] inputs."""
+    dtype, suf = _suffix(dtype)
+    lead = child.shape[:-1]
+    child, parent, w1 = (np.ascontiguousarray(a, dtype=dtype) for a in (child, parent, w1))
+    X, H, Y = w1.shape
+    M = int(np.prod(lead))
+    assert child.shape[-1] == X and parent.shape == lead + (Y,) and (w2 is None or X == Y)
+    w2c = None if w2 is None else np.ascontiguousarray(w2, dtype=dtype)
+    bc = None if b is None else np.ascontiguousarray(b, dtype=dtype)
+    out = np.empty(lead + (H,), dtype=dtype)
+    rc = getattr(_load(), "orc_arc_encoder" + suf)(_p(child), _p(parent), _p(w1), _p(w2c), _p(bc), M, X, H, Y, _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def arc_encoder_backward(child, parent, w1, w2, g, dtype=np.float32):
+    """Adjoint of `arc_encoder` for the cotangent g [..., H]: (d_child, d_parent, d_w1, d_w2 or None, d_b)."""
+    dtype, suf = _suffix(dtype)
+    lead = child.shape[:-1]
+    child, parent, w1, g = (np.ascontiguousarray(a, dtype=dtype) for a in (child, parent, w1, g))
+    X, H, Y = w1.shape
+    M = int(np.prod(lead))
+    w2c = None if w2 is None else np.ascontiguousarray(w2, dtype=dtype)
+    d_child, d_parent, d_w1 = np.empty_like(child), np.empty_like(parent), np.empty_like(w1)
+    d_w2 = None if w2 is None else np.empty_like(w2c)
+    d_b = np.empty(H, dtype=dtype)
+    rc = getattr(_load(), "orc_arc_encoder_bwd" + suf)(_p(child), _p(parent), _p(w1), _p(w2c), _p(g), M, X, H, Y, _p(d_child),
+                                                       _p(d_parent), _p(d_w1), _p(d_w2), _p(d_b))
+    assert rc == 0, rc
+    return d_child, d_parent, d_w1, d_w2, d_b
+
+
 def grounding_prior(tag, factor_names, vis_split, pos_for, Q):
     """The additive POS prior of joint.py:446-470 as a table: returns (pen [B,Q,S] float64, seg_of_v [V] uint8).
     For every named factor f in {obj, rel, attr} whose POS set contains the token's tag, every region OUTSIDE f's

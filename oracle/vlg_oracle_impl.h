@@ -646,6 +646,86 @@ int FN(orc_grounding_loss)(const REAL *txt, const REAL *vis, const uint8_t *tmas
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Arc encoder of lang_feat word+maxdep, src/model/joint.py:281-287:
+ *   arc[m,h] = sum_{x,y} child[m,x] * w1[x,h,y] * parent[m,y]  +  sum_x (child + parent)[m,x] * w2[x,h]  +  b[h]
+ * (m runs over batch x positions) and its adjoint for the cotangent g[m,h]:
+ *   d_child[m,x] = sum_{h,y} g w1 parent + sum_h g[m,h] w2[x,h]          d_parent likewise (w1 contracted over x, h)
+ *   d_w1[x,h,y]  = sum_m child[m,x] g[m,h] parent[m,y]     d_w2[x,h] = sum_m (child + parent)[m,x] g[m,h]     d_b = sum_m g
+ * w2 / b may be NULL (trilinear term only).  Gradient outputs may be NULL individually.
+ * ------------------------------------------------------------------------------------------ */
+int FN(orc_arc_encoder)(const REAL *child, const REAL *parent, const REAL *w1, const REAL *w2, const REAL *b, int M,
+                        int X, int H, int Y, REAL *out) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m)
+        for (int h = 0; h < H; ++h) {
+            REAL acc = b ? b[h] : (REAL)0;
+            for (int x = 0; x < X; ++x) {
+                const REAL *wr = w1 + ((size_t)x * H + h) * Y;
+                REAL t = 0;
+                for (int y = 0; y < Y; ++y) t += wr[y] * parent[(size_t)m * Y + y];
+                acc += child[(size_t)m * X + x] * t;
+                if (w2) acc += (child[(size_t)m * X + x] + parent[(size_t)m * Y + x]) * w2[(size_t)x * H + h];
+            }
+            out[(size_t)m * H + h] = acc;
+        }
+    return 0;
+}
+
+int FN(orc_arc_encoder_bwd)(const REAL *child, const REAL *parent, const REAL *w1, const REAL *w2, const REAL *g, int M, int X,
+                            int H, int Y, REAL *d_child, REAL *d_parent, REAL *d_w1, REAL *d_w2, REAL *d_b) {
+    if (d_child || d_parent) {
+#pragma omp parallel for schedule(static)
+        for (int m = 0; m < M; ++m) {
+            if (d_child)
+                for (int x = 0; x < X; ++x) {
+                    REAL acc = 0;
+                    for (int h = 0; h < H; ++h) {
+                        const REAL *wr = w1 + ((size_t)x * H + h) * Y;
+                        REAL t = 0;
+                        for (int y = 0; y < Y; ++y) t += wr[y] * parent[(size_t)m * Y + y];
+                        acc += g[(size_t)m * H + h] * (t + (w2 ? w2[(size_t)x * H + h] : (REAL)0));
+                    }
+                    d_child[(size_t)m * X + x] = acc;
+                }
+            if (d_parent)
+                for (int y = 0; y < Y; ++y) {
+                    REAL acc = 0;
+                    for (int h = 0; h < H; ++h) {
+                        REAL t = 0;
+                        for (int x = 0; x < X; ++x) t += child[(size_t)m * X + x] * w1[((size_t)x * H + h) * Y + y];
+                        acc += g[(size_t)m * H + h] * (t + (w2 ? w2[(size_t)y * H + h] : (REAL)0));
+                    }
+                    d_parent[(size_t)m * Y + y] = acc;
+                }
+        }
+    }
+    if (d_w1) {
+#pragma omp parallel for schedule(static)
+        for (int x = 0; x < X; ++x)
+            for (int h = 0; h < H; ++h)
+                for (int y = 0; y < Y; ++y) {
+                    REAL acc = 0;
+                    for (int m = 0; m < M; ++m) acc += child[(size_t)m * X + x] * g[(size_t)m * H + h] * parent[(size_t)m * Y + y];
+                    d_w1[((size_t)x * H + h) * Y + y] = acc;
+                }
+    }
+    if (d_w2)
+        for (int x = 0; x < X; ++x)
+            for (int h = 0; h < H; ++h) {
+                REAL acc = 0;
+                for (int m = 0; m < M; ++m) acc += (child[(size_t)m * X + x] + parent[(size_t)m * Y + x]) * g[(size_t)m * H + h];
+                d_w2[(size_t)x * H + h] = acc;
+            }
+    if (d_b)
+        for (int h = 0; h < H; ++h) {
+            REAL acc = 0;
+            for (int m = 0; m < M; ++m) acc += g[(size_t)m * H + h];
+            d_b[h] = acc;
+        }
+    return 0;
+}
+
 #undef DEC
 #undef ATT
 #undef GDEC

@@ -312,6 +312,37 @@ def attnfuse_cases():
         print(f"{name}: out {tuple(out.shape)}")
 
 
+def arcenc_cases():
+    """joint.py:281-287 re-issued with the same torch ops (the method around them needs the whole model).
+    The X = 128 case keeps the fixture small: w1 is stored as rank-4 factors (w1 = sum_r u[:,r] v[:,r] z[:,r], rebuilt by
+    the tests) and only a strided sample of its gradient is kept."""
+    for name, seed, B, C, X, rank in (("arcenc_B3_C6_X32_s0", 0, 3, 6, 32, 0), ("arcenc_B4_C11_X64_s1", 1, 4, 11, 64, 0),
+                                      ("arcenc_B2_C41_X128_s2", 2, 2, 41, 128, 4)):
+        g = torch.Generator().manual_seed(seed)
+        child = (torch.randn(B, C, X, generator=g) * 0.5).requires_grad_(True)
+        parent = (torch.randn(B, C, X, generator=g) * 0.5).requires_grad_(True)
+        extra = {}
+        if rank:
+            u, v, z = (torch.randn(X, rank, generator=g) * 0.3 for _ in range(3))
+            w1 = torch.einsum("xr,hr,yr->xhy", u, v, z).contiguous().requires_grad_(True)
+            extra = dict(w1_u=_np(u), w1_v=_np(v), w1_z=_np(z))
+        else:
+            w1 = (torch.randn(X, X, X, generator=g) * (1.0 / X)).requires_grad_(True)   # arc_encoder_w1
+        w2 = (torch.randn(X, X, generator=g) * (1.0 / X ** 0.5)).requires_grad_(True)   # arc_encoder_w2
+        b = (torch.randn(X, generator=g) * 0.1).requires_grad_(True)                    # arc_encoder_b
+        dout = torch.randn(B, C, X, generator=g)
+        arc = torch.einsum("bcx,xhy,bcy->bch", child, w1, parent) + torch.matmul(child + parent, w2) + b
+        grads = torch.autograd.grad(arc, [child, parent, w1, w2, b], dout)
+        if rank:
+            extra["g_w1_sample"] = _np(grads[2][::5, ::7, ::3])
+        else:
+            extra.update(w1=_np(w1), g_w1=_np(grads[2]))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), child=_np(child), parent=_np(parent), w2=_np(w2),
+                            b=_np(b), dout=_np(dout), arc=_np(arc), g_child=_np(grads[0]), g_parent=_np(grads[1]),
+                            g_w2=_np(grads[3]), g_b=_np(grads[4]), **extra)
+        print(f"{name}: arc {tuple(arc.shape)}")
+
+
 if __name__ == "__main__":
     dmv_case("dmv_B4_L10_s0", 0, 4, 10, "rand", store_merged=True)
     dmv_case("dmv_B4_L10_s1_full", 1, 4, 10, "full")
@@ -333,3 +364,4 @@ if __name__ == "__main__":
     align_cases()
     attnfuse_cases()
     grounding_cases()
+    arcenc_cases()

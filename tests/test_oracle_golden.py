@@ -167,3 +167,17 @@ def test_oracle_grounding_loss_matches_reference(oracle_mod, path):
     assert abs(got_total - want_total) <= 1e-4 * abs(want_total)
     for name in ("g_txt", "g_vis"):
         assert np.abs(o[name] - g[name]).max() <= 2e-5 * max(1.0, np.abs(g[name]).max()), name
+
+
+@pytest.mark.parametrize("path", golden_files("arcenc_"), ids=golden_ids("arcenc_"))
+def test_oracle_arc_encoder_matches_reference(oracle_mod, path):
+    """joint.py:281-287 (einsum + matmul + bias) and its autograd gradients."""
+    from conftest import arcenc_check_w1_grad, arcenc_w1
+    g = load(path)
+    w1 = arcenc_w1(g)
+    arc = oracle_mod.arc_encoder(g["child"], g["parent"], w1, g["w2"], g["b"], np.float64)
+    assert np.abs(arc - g["arc"]).max() <= 2e-5 * max(1.0, np.abs(g["arc"]).max())
+    d_child, d_parent, d_w1, d_w2, d_b = oracle_mod.arc_encoder_backward(g["child"], g["parent"], w1, g["w2"], g["dout"], np.float64)
+    for name, arr in (("g_child", d_child), ("g_parent", d_parent), ("g_w2", d_w2), ("g_b", d_b)):
+        assert np.abs(arr - g[name]).max() <= 2e-5 * max(1.0, np.abs(g[name]).max()), name
+    arcenc_check_w1_grad(d_w1, g, 2e-5)
