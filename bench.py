@@ -298,6 +298,16 @@ def main():
         out["grounding_loss"] = {"fwd_bwd_ms": timed(ground, 10),
                                  "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in; loss + gradients, no [B,A,Q,V] tensor"}
 
+        # arc encoder's trilinear term (joint.py:282-284): M = B * (L + 1) rows, 128^3 weights
+        a_child, a_parent = mk(B, N, d), mk(B, N, d)
+        a_w1 = (torch.randn(d, d, d, generator=g) / d).to(dev, in_dtype).requires_grad_(True)
+        a_dout = torch.randn(B, N, d, generator=g).to(dev)
+        out["arc_trilinear"] = {
+            "fwd_ms": timed(lambda: align.arc_trilinear(a_child.detach(), a_w1.detach(), a_parent.detach()), 20),
+            "fwd_bwd_ms": timed(lambda: torch.autograd.grad(align.arc_trilinear(a_child, a_w1, a_parent),
+                                                            [a_child, a_w1, a_parent], a_dout), 10),
+            "shape": f"M={B * N} X=H=Y={d} {args.dtype} in; einsum('bcx,xhy,bcy->bch') without the [M,H,Y] intermediate"}
+
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(B, L, 1000, args.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = sent_per_s / out["cpu_baseline"]["value"]

@@ -144,6 +144,22 @@ int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, c
                        float neg_inf, float num_token, float w_vis2txt, void* ws, size_t ws_bytes, float* out_sums,
                        float* g_txt, float* g_vis, void* stream);
 
+/* The arc encoder's trilinear term -- lang_feat word+maxdep, src/model/joint.py:281-284:
+ *   out[m,h] = sum_{x,y} child[m,x] * w[x,h,y] * parent[m,y]        (m = flattened batch x position)
+ *   child [M,X], parent [M,Y], w [X,H,Y] in in_dtype; out [M,H] fp32.  Y in {32, 64, 128}; H a multiple of 16, <= 128;
+ *   X <= 256.  The [M,H,Y] intermediate torch.einsum materialises is never built. */
+int vlg_trilinear(const void* child, const void* w, const void* parent, int M, int X, int H, int Y, int in_dtype, float* out,
+                  void* stream);
+
+/* Adjoint of vlg_trilinear for the cotangent g [M,H] (fp32): d_child [M,X], d_w [X,H,Y], d_parent [M,Y], all fp32, each
+ * optional (NULL = skip).  The two input gradients are the forward kernel run on permuted copies of w; d_w contracts over
+ * m from transposed copies of the three operands.  H and Y in {32, 64, 128}; X a multiple of 16, <= 128 (for d_child).
+ * With bf16 operands the cotangent (and the product child * g inside d_w) is rounded to bf16, like any bf16 autograd.
+ * ws: vlg_trilinear_backward_workspace(M, X, H, Y, in_dtype) bytes. */
+size_t vlg_trilinear_backward_workspace(int M, int X, int H, int Y, int in_dtype);
+int vlg_trilinear_backward(const void* child, const void* w, const void* parent, const float* g, int M, int X, int H, int Y,
+                           int in_dtype, void* ws, size_t ws_bytes, float* d_child, float* d_w, float* d_parent, void* stream);
+
 /* Attention-fuse that feeds the parser -- DependencyBoxRel._forward, src/model/joint.py:670-674:
  *   att = softmax_v(vis[b] . txt[b,1:]) ; x = att . vis_mid[b] ; out = LayerNorm(enc_x + x) * gamma + beta
  *   vis [B,V,d], txt [B,L+1,d] (root slot first, skipped), vis_mid [B,V,h], enc_x [B,L,h] (in_dtype);

@@ -109,3 +109,20 @@ def test_attn_and_grounding_entry_points_validate_on_the_host(lib):
     # attention-fuse forward
     assert lib.vlg_attn_fuse(one, one, one, one, one, one, 2, 0, 7, 32, 64, 0, 1e-5, None, one, None) == 0x1001
     assert lib.vlg_attn_fuse(one, one, one, one, one, one, 0, 5, 7, 32, 64, 0, 1e-5, None, one, None) == 0      # empty batch
+
+
+def test_trilinear_entry_points_validate_on_the_host(lib):
+    P = ctypes.c_void_p
+    one = P(16)
+    tri, bwd = lib.vlg_trilinear, lib.vlg_trilinear_backward
+    assert tri(one, one, one, 10, 32, 24, 32, 0, one, None) == 0x1001 and b"multiple of 16" in lib.vlg_last_error()
+    assert tri(one, one, one, 10, 32, 256, 32, 0, one, None) == 0x1001
+    assert tri(one, one, one, 10, 32, 32, 48, 0, one, None) == 0x1001 and b"contracted dimension 48" in lib.vlg_last_error()
+    assert tri(one, one, one, 10, 32, 32, 32, 2, one, None) == 0x1002
+    assert tri(None, one, one, 10, 32, 32, 32, 0, one, None) == 0x1003
+    assert tri(None, None, None, 0, 32, 32, 32, 0, None, None) == 0                  # no rows: nothing to do
+    need = lib.vlg_trilinear_backward_workspace(100, 32, 64, 32, 1)
+    assert need > 0 and need % 256 == 0 and lib.vlg_trilinear_backward_workspace(100, 32, 64, 32, 0) > need   # fp32 copies are larger
+    assert bwd(one, one, one, one, 100, 32, 64, 32, 1, one, need - 1, one, one, one, None) == 0x1004
+    assert bwd(one, one, one, one, 100, 32, 48, 32, 1, one, need, one, one, one, None) == 0x1001
+    assert bwd(one, one, one, None, 100, 32, 64, 32, 1, one, need, one, one, one, None) == 0x1003

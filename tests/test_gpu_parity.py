@@ -610,3 +610,47 @@ def test_grounding_loss_shapes(oracle_mod, B, L, V, d, dt):
                                                t(pen.astype(np.float32)), t(seg))
     g2 = torch.autograd.grad(total2, [tt, tv])
     assert torch.equal(g2[0], g_txt) and torch.equal(g2[1], g_vis)
+
+
+# ---- arc encoder (joint.py:281-287): trilinear term on the matrix cores ----
+@pytest.mark.parametrize("path", golden_files("arcenc_"), ids=golden_ids("arcenc_"))
+def test_arc_encoder_golden(path):
+    from conftest import arcenc_check_w1_grad, arcenc_w1
+    from vlgae_amd import align
+    g = load(path)
+    leaves = [t(g["child"]), t(g["parent"]), t(arcenc_w1(g)), t(g["w2"]), t(g["b"])]
+    for a in leaves:
+        a.requires_grad_(True)
+    arc = align.arc_encoder(*leaves)
+    assert np.abs(arc.detach().cpu().numpy() - g["arc"]).max() <= 1e-4 * max(1.0, np.abs(g["arc"]).max())
+    grads = torch.autograd.grad(arc, leaves, t(g["dout"]))
+    for name, got in (("g_child", grads[0]), ("g_parent", grads[1]), ("g_w2", grads[3]), ("g_b", grads[4])):
+        assert np.abs(got.cpu().numpy() - g[name]).max() <= 1e-4 * max(1.0, np.abs(g[name]).max()), name
+    arcenc_check_w1_grad(grads[2].cpu().numpy(), g, 1e-4)
+
+
+@pytest.mark.parametrize("M,X,H,Y,dt", [(100, 32, 32, 32, "f32"), (333, 64, 128, 32, "f32"), (77, 128, 64, 128, "f32"),
+                                        (1050, 128, 128, 128, "bf16"), (65, 48, 32, 64, "bf16"), (1, 16, 32, 32, "f32")])
+def test_arc_trilinear_shapes(oracle_mod, M, X, H, Y, dt):
+    """Ragged row counts (M % 64, M % 32 != 0), unequal X / H / Y, against the fp64 oracle."""
+    from vlgae_amd import align
+    rng = np.random.default_rng(M * 7 + X)
+    child, parent = (rng.standard_normal((M, X)) * 0.5).astype(np.float32), (rng.standard_normal((M, Y)) * 0.5).astype(np.float32)
+    w1 = (rng.standard_normal((X, H, Y)) / np.sqrt(X * Y)).astype(np.float32)
+    g = rng.standard_normal((M, H)).astype(np.float32)
+    if dt == "bf16":
+        child, parent, w1 = (torch.from_numpy(a).bfloat16().float().numpy() for a in (child, parent, w1))
+    ref = oracle_mod.arc_encoder(child, parent, w1, None, None, np.float64)
+    d_child, d_parent, d_w1, _, _ = oracle_mod.arc_encoder_backward(child, parent, w1, None, g, np.float64)
+    leaves = [t(child), t(w1), t(parent)]
+    if dt == "bf16":
+        leaves = [a.bfloat16() for a in leaves]
+    for a in leaves:
+        a.requires_grad_(True)
+    out = align.arc_trilinear(*leaves)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (M, H)
+    assert np.abs(out.detach().cpu().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    grads = torch.autograd.grad(out, leaves, t(g))
+    tol = 2e-2 if dt == "bf16" else 1e-4   # bf16: the cotangent and the returned gradients are rounded to 8 bits
+    for name, got, want in (("d_child", grads[0], d_child), ("d_w1", grads[1], d_w1), ("d_parent", grads[2], d_parent)):
+        assert np.abs(got.float().cpu().numpy() - want).max() <= tol * max(1.0, np.abs(want).max()), name

@@ -275,3 +275,67 @@ def loss_grounding_factor_ce(self, inputs, vp):
     if args.vis2txt > 0:
         loss["mt_vis2txt"] = args.vis2txt * sums[1] / (sums[1] + 1e-6) * num
     return total, loss
+
+
+# ----------------------------------------------------------------------------------------------
+# Arc encoder (lang_feat word+maxdep, joint.py:281-287)
+# ----------------------------------------------------------------------------------------------
+def _trilinear_launch(child_c, w_c, parent_c, dt):
+    M, X = child_c.shape
+    H, Y = w_c.shape[1], w_c.shape[2]
+    out = torch.empty((M, H), dtype=torch.float32, device=child_c.device)
+    _C.check(_C.lib().vlg_trilinear(_C.ptr(child_c), _C.ptr(w_c), _C.ptr(parent_c), M, X, H, Y, dt, _C.ptr(out),
+                                    _C.stream_of(child_c)), "trilinear")
+    return out
+
+
+class _ArcTrilinear(torch.autograd.Function):
+    """einsum('bcx,xhy,bcy->bch', child, w1, parent) without the [B,C,H,Y] intermediate, differentiable in all three."""
+
+    @staticmethod
+    def forward(ctx, child, w1, parent):
+        lead = child.shape[:-1]
+        X, H, Y = w1.shape
+        dt, child_c = _C.in_dtype(child.detach().reshape(-1, X))
+        w_c = w1.detach().to(child_c.dtype).contiguous()
+        parent_c = parent.detach().reshape(-1, Y).to(child_c.dtype).contiguous()
+        out = _trilinear_launch(child_c, w_c, parent_c, dt)
+        ctx.save_for_backward(child_c, w_c, parent_c)
+        ctx.meta = (dt, lead, child.dtype, w1.dtype, parent.dtype)
+        return out.reshape(*lead, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        child_c, w_c, parent_c = ctx.saved_tensors
+        dt, lead, t_child, t_w, t_parent = ctx.meta
+        M, X = child_c.shape
+        H, Y = w_c.shape[1], w_c.shape[2]
+        dev = child_c.device
+        g = g.reshape(M, H).to(torch.float32).contiguous()
+        need = ctx.needs_input_grad
+        d_child = torch.empty((M, X), dtype=torch.float32, device=dev) if need[0] else None
+        d_w = torch.empty((X, H, Y), dtype=torch.float32, device=dev) if need[1] else None
+        d_parent = torch.empty((M, Y), dtype=torch.float32, device=dev) if need[2] else None
+        nbytes = _C.lib().vlg_trilinear_backward_workspace(M, X, H, Y, dt)
+        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+        _C.check(_C.lib().vlg_trilinear_backward(_C.ptr(child_c), _C.ptr(w_c), _C.ptr(parent_c), _C.ptr(g), M, X, H, Y, dt,
+                                                 _C.ptr(ws), nbytes, _C.ptr(d_child), _C.ptr(d_w), _C.ptr(d_parent),
+                                                 _C.stream_of(child_c)), "trilinear_backward")
+        return (d_child.reshape(*lead, X).to(t_child) if need[0] else None, d_w.to(t_w) if need[1] else None,
+                d_parent.reshape(*lead, Y).to(t_parent) if need[2] else None)
+
+
+def arc_trilinear(child, w1, parent):
+    """torch.einsum('bcx,xhy,bcy->bch', child, w1, parent) (joint.py:282-284); float32 result [..., H]."""
+    child, parent = _plain(child), _plain(parent)
+    _C.require_gpu(child, "arc_trilinear")
+    X, H, Y = w1.shape
+    if child.shape[-1] != X or parent.shape[-1] != Y or child.shape[:-1] != parent.shape[:-1]:
+        raise ValueError(f"arc_trilinear: child {tuple(child.shape)} w1 {tuple(w1.shape)} parent {tuple(parent.shape)}")
+    return _ArcTrilinear.apply(child, w1, parent)
+
+
+def arc_encoder(child_repr, parent_repr, arc_encoder_w1, arc_encoder_w2, arc_encoder_b):
+    """joint.py:281-287: the trilinear term on the matrix cores, the affine term as a plain library GEMM."""
+    tri = arc_trilinear(child_repr, arc_encoder_w1, parent_repr)
+    return tri + torch.matmul(_plain(child_repr) + _plain(parent_repr), arc_encoder_w2).float() + arc_encoder_b.float()

@@ -16,6 +16,7 @@
 #include "vlg_common.h"
 #include "vlg_dp_core.h"   // F32In / BF16In element loaders
 #include "vlg_ground.h"
+#include "vlg_mfma.h"
 
 namespace vlg {
 
@@ -111,38 +112,9 @@ __global__ __launch_bounds__(kAlignThreads) void align_kernel(
 }
 
 // ---- MFMA path --------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int kCTB = 3;      // col tiles (16 regions each) per LDS tile pass: 48 regions
 constexpr int kTileVP = kCTB * 16 + 4;   // tile pitch 52: rows stay 16-byte aligned, and 52q + 9p hits 32 distinct banks
-
-template <bool F32IN>
-struct MfmaCfg;
-template <>
-struct MfmaCfg<false> {      // bf16 in: K-chunks of 32, 6 row tiles (96 queries) of A fragments resident
-    using T = uint16_t;
-    using Frag = bf16x8;
-    static constexpr int KW = 32, RTB = 6, EPL = 8;   // EPL = elements per lane per chunk (16 bytes)
-};
-template <>
-struct MfmaCfg<true> {       // fp32 in: K-chunks of 16, 3 row tiles (48 queries)
-    using T = float;
-    using Frag = f32x4;
-    static constexpr int KW = 16, RTB = 3, EPL = 4;
-};
-
-template <bool F32IN>
-__device__ __forceinline__ f32x4 mma_chunk(const typename MfmaCfg<F32IN>::Frag& a,
-                                           const typename MfmaCfg<F32IN>::Frag& b, f32x4 acc) {
-    if constexpr (F32IN) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
-        return acc;
-    } else {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-    }
-}
 
 // One block = caption b x (4 waves x a_per_wave images); each wave owns its images and its LDS tile.
 // d == KCH * KW exactly (dispatch guarantees it), so fragment loads need no K guards: lane l of a 16-row

@@ -1,0 +1,406 @@
+// vlg_arc.hip -- the arc encoder's trilinear contraction on the matrix cores (gfx950) and its C-ABI entry points.
+//
+//   lang_feat word+maxdep, src/model/joint.py:281-284:   arc[b,c,h] = sum_{x,y} child[b,c,x] * w1[x,h,y] * parent[b,c,y]
+//   (SURVEY.md section 8 f2).  torch evaluates the einsum pairwise and materialises [B,C,H,Y] (688 MB fp32 at B = 256,
+//   C = 41, 128^3 weights) on the way; here the inner product over y is an MFMA tile that is scaled by child[m,x] and
+//   added to the output accumulators without ever leaving registers.
+//
+//   tri_kernel      out[m,h] = sum_x c[m,x] * ( sum_y w[x,h,y] * p[m,y] )          (m = flattened batch x position)
+//                   For each x the bracket is a [rows m] x [cols h] MFMA tile over K = y, contiguous on both operands
+//                   (p rows and w[x,h,:] rows), so fragments are 16-byte reads straight from global memory.
+//                   The SAME kernel gives both input gradients with a permuted copy of the weights:
+//                     d_child [m,x] = sum_y p[m,y] * ( sum_h wA[y,x,h] * g[m,h] ),   wA[y,x,h] = w[x,h,y]
+//                     d_parent[m,y] = sum_x c[m,x] * ( sum_h wB[x,y,h] * g[m,h] ),   wB[x,y,h] = w[x,h,y]
+//   tri_dw_kernel   d_w[x,h,y] = sum_m c[m,x] g[m,h] p[m,y]: K = m, so the three operands are read from transposed copies
+//                   ([dim][M], m contiguous); the A operand c[m,x] * g[m,h] is formed in registers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vlg_common.h"
+#include "vlg_mfma.h"
+
+namespace vlg {
+
+constexpr int kTriRT = 4;     // row tiles of 16 per block: its rows share every weight fragment
+constexpr int kTriRows = 16 * kTriRT;
+constexpr int kTriWaves = 4;  // waves per block; wave w takes h-tiles w, w + 4, ...
+constexpr int kTriHPW = 2;    // h-tiles per wave: H <= 128
+
+template <bool F32IN>
+__device__ __forceinline__ float tri_ld(const typename MfmaCfg<F32IN>::T* p, size_t i) {
+    if constexpr (F32IN) return p[i];
+    else return __uint_as_float((uint32_t)p[i] << 16);
+}
+
+// out[m,h] = sum_x c[m,x] * sum_y w[x,h,y] * p[m,y];  Y == KCH * KW, H % 16 == 0, H <= 128.
+template <bool F32IN, int KCH>
+__global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename MfmaCfg<F32IN>::T* __restrict__ c,
+                                                             const typename MfmaCfg<F32IN>::T* __restrict__ w,
+                                                             const typename MfmaCfg<F32IN>::T* __restrict__ p, int M, int X,
+                                                             int H, float* __restrict__ out) {
+    using C = MfmaCfg<F32IN>;
+    using Frag = typename C::Frag;
+    constexpr int Y = KCH * C::KW, FPK = C::KW / C::EPL;   // fragment stride between K chunks, in Frag units
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* cT = reinterpret_cast<float*>(smem_raw);   // [X][kTriRows]: c of this block's rows, transposed, fp32
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 16 * kTriRT;
+    for (int i = threadIdx.x; i < kTriRows * X; i += 64 * kTriWaves) {
+        const int row = i / X, x = i - row * X;   // coalesced read, transposed write
+        cT[x * kTriRows + row] = m0 + row < M ? tri_ld<F32IN>(c, (size_t)(m0 + row) * X + x) : 0.f;
+    }
+    // A operand: this block's p rows, resident for the whole x loop
+    Frag pf[kTriRT][KCH];
+#pragma unroll
+    for (int rt = 0; rt < kTriRT; ++rt) {
+        const Frag* rowp = reinterpret_cast<const Frag*>(p + (size_t)min(m0 + 16 * rt + r, M - 1) * Y + C::EPL * g);
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) pf[rt][kc] = rowp[kc * FPK];
+    }
+    const int n_ht = H >> 4;
+    // B operand of (x, j): rows h = 16 (wave + 4 j) + r of w[x], clamped (tiles past H are never stored)
+    auto load_w = [&](int x, Frag (&f)[kTriHPW][KCH]) {
+#pragma unroll
+        for (int j = 0; j < kTriHPW; ++j) {
+            const int ht = min(wave + kTriWaves * j, n_ht - 1);
+            const Frag* rowp = reinterpret_cast<const Frag*>(w + ((size_t)x * H + 16 * ht + r) * Y + C::EPL * g);
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) f[j][kc] = rowp[kc * FPK];
+        }
+    };
+    f32x4 acc[kTriRT][kTriHPW];
+#pragma unroll
+    for (int rt = 0; rt < kTriRT; ++rt)
+#pragma unroll
+        for (int j = 0; j < kTriHPW; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Frag wcur[kTriHPW][KCH], wnext[kTriHPW][KCH];
+    load_w(0, wcur);
+    __syncthreads();
+    for (int x = 0; x < X; ++x) {
+        load_w(min(x + 1, X - 1), wnext);   // next x's weight rows are in flight under this x's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        float4 cv[kTriRT];
+#pragma unroll
+        for (int rt = 0; rt < kTriRT; ++rt) cv[rt] = *reinterpret_cast<const float4*>(cT + x * kTriRows + 16 * rt + 4 * g);
+#pragma unroll
+        for (int j = 0; j < kTriHPW; ++j)
+#pragma unroll
+            for (int rt = 0; rt < kTriRT; ++rt) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) d = mma_chunk<F32IN>(pf[rt][kc], wcur[j][kc], d);
+                acc[rt][j][0] = fmaf(cv[rt].x, d[0], acc[rt][j][0]);   // rows 4g + n of the tile: c[m, x] scales row m
+                acc[rt][j][1] = fmaf(cv[rt].y, d[1], acc[rt][j][1]);
+                acc[rt][j][2] = fmaf(cv[rt].z, d[2], acc[rt][j][2]);
+                acc[rt][j][3] = fmaf(cv[rt].w, d[3], acc[rt][j][3]);
+            }
+#pragma unroll
+        for (int j = 0; j < kTriHPW; ++j)
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) wcur[j][kc] = wnext[j][kc];
+    }
+#pragma unroll
+    for (int j = 0; j < kTriHPW; ++j) {
+        const int ht = wave + kTriWaves * j;
+        if (ht < n_ht)
+#pragma unroll
+            for (int rt = 0; rt < kTriRT; ++rt)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int m = m0 + 16 * rt + 4 * g + n;
+                    if (m < M) out[(size_t)m * H + 16 * ht + r] = acc[rt][j][n];
+                }
+    }
+}
+
+template <bool F32IN, int KCH>
+static void launch_tri(const void* c, const void* w, const void* p, int M, int X, int H, float* out, hipStream_t s) {
+    using T = typename MfmaCfg<F32IN>::T;
+    hipLaunchKernelGGL((tri_kernel<F32IN, KCH>), dim3((M + 16 * kTriRT - 1) / (16 * kTriRT)), dim3(64 * kTriWaves),
+                       sizeof(float) * kTriRows * X, s, (const T*)c, (const T*)w, (const T*)p, M, X, H, out);
+}
+
+// Y (the contracted, memory-contiguous dimension) decides the instantiation.
+static int dispatch_tri(const void* c, const void* w, const void* p, int M, int X, int H, int Y, bool f32in, float* out,
+                        hipStream_t s) {
+    if (f32in) {
+        if (Y == 128) launch_tri<true, 8>(c, w, p, M, X, H, out, s);
+        else if (Y == 64) launch_tri<true, 4>(c, w, p, M, X, H, out, s);
+        else if (Y == 32) launch_tri<true, 2>(c, w, p, M, X, H, out, s);
+        else return set_error(VLG_ERR_SHAPE, "trilinear: contracted dimension %d (supported: 32, 64, 128)", Y);
+    } else {
+        if (Y == 128) launch_tri<false, 4>(c, w, p, M, X, H, out, s);
+        else if (Y == 64) launch_tri<false, 2>(c, w, p, M, X, H, out, s);
+        else if (Y == 32) launch_tri<false, 1>(c, w, p, M, X, H, out, s);
+        else return set_error(VLG_ERR_SHAPE, "trilinear: contracted dimension %d (supported: 32, 64, 128)", Y);
+    }
+    return check_launch("tri_kernel");
+}
+
+// ---- helpers for the adjoint ----------------------------------------------------------------------------------------
+// dst[a][b][c] (in T) = src[x][h][y] with (a, b, c) a permutation of (x, h, y):  mode 0: [y][x][h],  mode 1: [x][y][h].
+template <typename T>
+__global__ __launch_bounds__(256) void tri_permute_kernel(const T* __restrict__ src, T* __restrict__ dst, int X, int H, int Y,
+                                                          int mode) {
+    const size_t n = (size_t)X * H * Y;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int h = (int)(i % H);   // dst index = ((a * B + b) * H + h): h is the fastest dimension in both modes
+        const size_t ab = i / H;
+        int x, y;
+        if (mode == 0) { x = (int)(ab % X); y = (int)(ab / X); }
+        else { y = (int)(ab % Y); x = (int)(ab / Y); }
+        dst[i] = src[((size_t)x * H + h) * Y + y];
+    }
+}
+
+// dst[d][m] (in T, row pitch Mp, zero beyond M) = src[m][d];  CAST: src is fp32 and is rounded to T, else src is T.
+template <typename T, bool CAST>
+__global__ __launch_bounds__(256) void tri_transpose_kernel(const void* __restrict__ src_, T* __restrict__ dst, int M, int D,
+                                                            int Mp) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, d0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int m = m0 + k, d = d0 + tx;
+        float v = 0.f;
+        if (m < M && d < D) {
+            if constexpr (CAST) v = reinterpret_cast<const float*>(src_)[(size_t)m * D + d];
+            else if constexpr (sizeof(T) == 4) v = reinterpret_cast<const float*>(src_)[(size_t)m * D + d];
+            else v = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(src_)[(size_t)m * D + d] << 16);
+        }
+        tile[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int d = d0 + k, m = m0 + tx;
+        if (d < D && m < Mp) {
+            const float v = tile[tx][k];
+            if constexpr (sizeof(T) == 4) dst[(size_t)d * Mp + m] = v;
+            else {   // round to nearest even bf16
+                const uint32_t u = __float_as_uint(v);
+                dst[(size_t)d * Mp + m] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            }
+        }
+    }
+}
+
+// row-major copy of the fp32 cotangent in the operand type
+__global__ __launch_bounds__(256) void tri_cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t u = __float_as_uint(src[i]);
+        dst[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+}
+
+// d_w[x,h,y] = sum_m c[m,x] g[m,h] p[m,y] from the transposed copies cT [X][Mp], gT [H][Mp], pT [Y][Mp] (m contiguous, zero
+// padded to Mp, a multiple of the K chunk).  Wave = (x, a group of kDwHT h-tiles) x all y-tiles; the A operand of chunk
+// k is gT[h][k..] * cT[x][k..] formed in registers (for bf16: product in fp32, rounded back to bf16).
+constexpr int kDwHT = 4;   // h-tiles per wave: their A fragments reuse every p fragment
+constexpr int kDwYT = 8;   // y-tiles: Y <= 128
+
+template <bool F32IN>
+__device__ __forceinline__ typename MfmaCfg<F32IN>::Frag frag_mul(const typename MfmaCfg<F32IN>::Frag& a,
+                                                                const typename MfmaCfg<F32IN>::Frag& b) {
+    if constexpr (F32IN) return a * b;
+    else {
+        typename MfmaCfg<false>::Frag o;
+        const uint32_t* ua = reinterpret_cast<const uint32_t*>(&a);
+        const uint32_t* ub = reinterpret_cast<const uint32_t*>(&b);
+        uint32_t* uo = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // two bf16 per dword
+            const float lo = __uint_as_float(ua[i] << 16) * __uint_as_float(ub[i] << 16);
+            const float hi = __uint_as_float(ua[i] & 0xffff0000u) * __uint_as_float(ub[i] & 0xffff0000u);
+            const uint32_t ul = __float_as_uint(lo), uh = __float_as_uint(hi);
+            uo[i] = ((ul + 0x7fffu + ((ul >> 16) & 1u)) >> 16) | ((uh + 0x7fffu + ((uh >> 16) & 1u)) & 0xffff0000u);
+        }
+        return o;
+    }
+}
+
+constexpr int kDwSplit = 4;   // waves per block: wave s takes K chunks s, s + 4, ...; partial tiles meet in LDS, fixed order
+
+template <bool F32IN>
+__global__ __launch_bounds__(64 * kDwSplit) void tri_dw_kernel(const typename MfmaCfg<F32IN>::T* __restrict__ cT,
+                                                    const typename MfmaCfg<F32IN>::T* __restrict__ gT,
+                                                    const typename MfmaCfg<F32IN>::T* __restrict__ pT, int Mp, int X, int H,
+                                                    int Y, float* __restrict__ d_w) {
+    using C = MfmaCfg<F32IN>;
+    using Frag = typename C::Frag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int x = blockIdx.x, hg = blockIdx.y;   // h-tiles hg * kDwHT ..
+    const int n_ht = H >> 4, n_yt = Y >> 4, n_chunk = Mp / C::KW;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f32x4* part = reinterpret_cast<f32x4*>(smem_raw);   // [kDwSplit - 1][kDwHT * kDwYT][64 lanes]
+    const Frag* crow = reinterpret_cast<const Frag*>(cT + (size_t)x * Mp + C::EPL * g);   // same for every row of the A tile
+    const Frag* grow[kDwHT];
+    const Frag* prow[kDwYT];
+#pragma unroll
+    for (int j = 0; j < kDwHT; ++j)
+        grow[j] = reinterpret_cast<const Frag*>(gT + (size_t)(16 * min(hg * kDwHT + j, n_ht - 1) + r) * Mp + C::EPL * g);
+#pragma unroll
+    for (int t = 0; t < kDwYT; ++t) prow[t] = reinterpret_cast<const Frag*>(pT + (size_t)(16 * min(t, n_yt - 1) + r) * Mp + C::EPL * g);
+    constexpr int FPK = C::KW / C::EPL;
+    f32x4 acc[kDwHT][kDwYT];
+#pragma unroll
+    for (int j = 0; j < kDwHT; ++j)
+#pragma unroll
+        for (int t = 0; t < kDwYT; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int k_first = min(wave, n_chunk - 1) * FPK;
+    Frag cf = crow[k_first], gf[kDwHT], pf[kDwYT];
+#pragma unroll
+    for (int j = 0; j < kDwHT; ++j) gf[j] = grow[j][k_first];
+#pragma unroll
+    for (int t = 0; t < kDwYT; ++t) pf[t] = prow[t][k_first];
+    for (int k = wave; k < n_chunk; k += kDwSplit) {
+        const int kn = min(k + kDwSplit, n_chunk - 1) * FPK;
+        const Frag cn = crow[kn];   // next chunk's operands are in flight under this chunk's MFMAs
+        Frag gn[kDwHT], pn[kDwYT];
+#pragma unroll
+        for (int j = 0; j < kDwHT; ++j) gn[j] = grow[j][kn];
+#pragma unroll
+        for (int t = 0; t < kDwYT; ++t) pn[t] = prow[t][kn];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kDwHT; ++j) {
+            const Frag a = frag_mul<F32IN>(gf[j], cf);
+#pragma unroll
+            for (int t = 0; t < kDwYT; ++t) acc[j][t] = mma_chunk<F32IN>(a, pf[t], acc[j][t]);
+        }
+        cf = cn;
+#pragma unroll
+        for (int j = 0; j < kDwHT; ++j) gf[j] = gn[j];
+#pragma unroll
+        for (int t = 0; t < kDwYT; ++t) pf[t] = pn[t];
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < kDwHT; ++j)
+#pragma unroll
+            for (int t = 0; t < kDwYT; ++t) part[((wave - 1) * kDwHT * kDwYT + j * kDwYT + t) * 64 + lane] = acc[j][t];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int sp = 0; sp < kDwSplit - 1; ++sp)
+#pragma unroll
+        for (int j = 0; j < kDwHT; ++j)
+#pragma unroll
+            for (int t = 0; t < kDwYT; ++t) acc[j][t] += part[(sp * kDwHT * kDwYT + j * kDwYT + t) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < kDwHT; ++j) {
+        const int ht = hg * kDwHT + j;
+        if (ht < n_ht)
+#pragma unroll
+            for (int t = 0; t < kDwYT; ++t)
+                if (t < n_yt)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)   // tile rows = h, cols = y
+                        d_w[((size_t)x * H + 16 * ht + 4 * g + n) * Y + 16 * t + r] = acc[j][t][n];
+    }
+}
+
+struct TriBwdPlan {   // scratch carving (bytes), shared by the size query and the launcher
+    size_t esz, Mp, off_wA, off_wB, off_gB, off_cT, off_gT, off_pT, bytes;
+    TriBwdPlan(int M, int X, int H, int Y, bool f32in) {
+        esz = f32in ? 4 : 2;
+        const int kw = f32in ? 16 : 32;
+        Mp = ((size_t)M + kw - 1) / kw * kw;
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t wbytes = up((size_t)X * H * Y * esz);
+        off_wA = 0;
+        off_wB = wbytes;
+        off_gB = 2 * wbytes;
+        off_cT = off_gB + up((size_t)M * H * esz);
+        off_gT = off_cT + up((size_t)X * Mp * esz);
+        off_pT = off_gT + up((size_t)H * Mp * esz);
+        bytes = off_pT + up((size_t)Y * Mp * esz);
+    }
+};
+
+template <bool F32IN>
+static int run_tri_backward(const void* child, const void* w, const void* parent, const float* g, int M, int X, int H, int Y,
+                            char* ws, const TriBwdPlan& p, float* d_child, float* d_w, float* d_parent, hipStream_t s) {
+    using T = typename MfmaCfg<F32IN>::T;
+    T *wA = (T*)(ws + p.off_wA), *wB = (T*)(ws + p.off_wB), *gB = (T*)(ws + p.off_gB);
+    T *cT = (T*)(ws + p.off_cT), *gT = (T*)(ws + p.off_gT), *pT = (T*)(ws + p.off_pT);
+    const int pblocks = 1024;
+    const void* g_op = g;   // the cotangent in the operand type, row-major
+    if constexpr (!F32IN) {
+        hipLaunchKernelGGL(tri_cast_bf16_kernel, dim3(512), dim3(256), 0, s, g, (uint16_t*)gB, (size_t)M * H);
+        g_op = gB;
+    }
+    if (d_child) {   // d_child[m,x] = sum_y p[m,y] * sum_h wA[y,x,h] g[m,h]: roles (c, w, p) := (p, wA, g); "X" = Y, "H" = X, "Y" = H
+        if (X % 16 || X > 16 * kTriWaves * kTriHPW) return set_error(VLG_ERR_SHAPE, "trilinear_backward: X=%d must be a multiple of 16 and <= 128", X);
+        hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wA, X, H, Y, 0);
+        if (int rc = dispatch_tri(parent, wA, g_op, M, Y, X, H, F32IN, d_child, s)) return rc;
+    }
+    if (d_parent) {  // d_parent[m,y] = sum_x c[m,x] * sum_h wB[x,y,h] g[m,h]: roles (c, w, p) := (c, wB, g); "H" = Y, "Y" = H
+        if (Y % 16 || Y > 16 * kTriWaves * kTriHPW) return set_error(VLG_ERR_SHAPE, "trilinear_backward: Y=%d must be a multiple of 16 and <= 128", Y);
+        hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wB, X, H, Y, 1);
+        if (int rc = dispatch_tri(child, wB, g_op, M, X, Y, H, F32IN, d_parent, s)) return rc;
+    }
+    if (d_w) {
+        if (Y > 16 * kDwYT || Y % 16) return set_error(VLG_ERR_SHAPE, "trilinear_backward: Y=%d must be a multiple of 16 and <= 128", Y);
+        const int Mp = (int)p.Mp;
+        dim3 tb(256);
+        hipLaunchKernelGGL((tri_transpose_kernel<T, false>), dim3((Mp + 31) / 32, (X + 31) / 32), tb, 0, s, child, cT, M, X, Mp);
+        hipLaunchKernelGGL((tri_transpose_kernel<T, true>), dim3((Mp + 31) / 32, (H + 31) / 32), tb, 0, s, (const void*)g, gT, M, H, Mp);
+        hipLaunchKernelGGL((tri_transpose_kernel<T, false>), dim3((Mp + 31) / 32, (Y + 31) / 32), tb, 0, s, parent, pT, M, Y, Mp);
+        const size_t lds = sizeof(float) * 4 * (size_t)(kDwSplit - 1) * kDwHT * kDwYT * 64;   // 96 KB
+        auto k = tri_dw_kernel<F32IN>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k, dim3(X, ((H >> 4) + kDwHT - 1) / kDwHT), dim3(64 * kDwSplit), lds, s, cT, gT, pT, Mp, X, H, Y, d_w);
+    }
+    return check_launch("trilinear_backward");
+}
+
+static int check_dims(const char* what, int M, int X, int H, int Y) {
+    if (M < 0 || X < 1 || H < 1 || Y < 1) return set_error(VLG_ERR_SHAPE, "%s: bad shape M=%d X=%d H=%d Y=%d", what, M, X, H, Y);
+    if (H % 16 || H > 16 * kTriWaves * kTriHPW) return set_error(VLG_ERR_SHAPE, "%s: H=%d must be a multiple of 16 and <= 128", what, H);
+    if (X > 256) return set_error(VLG_ERR_SHAPE, "%s: X=%d > 256", what, X);
+    return 0;
+}
+
+}  // namespace vlg
+
+extern "C" {
+
+int vlg_trilinear(const void* child, const void* w, const void* parent, int M, int X, int H, int Y, int in_dtype, float* out,
+                  void* stream) {
+    using namespace vlg;
+    if (int rc = check_dims("trilinear", M, X, H, Y)) return rc;
+    if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "trilinear: in_dtype %d", in_dtype);
+    if (M == 0) return 0;
+    if (!child || !w || !parent || !out) return set_error(VLG_ERR_ARG, "trilinear: null buffer");
+    return dispatch_tri(child, w, parent, M, X, H, Y, in_dtype == VLG_F32, out, (hipStream_t)stream);
+}
+
+size_t vlg_trilinear_backward_workspace(int M, int X, int H, int Y, int in_dtype) {
+    if (M < 1 || X < 1 || H < 1 || Y < 1) return 0;
+    return vlg::TriBwdPlan(M, X, H, Y, in_dtype == VLG_F32).bytes;
+}
+
+int vlg_trilinear_backward(const void* child, const void* w, const void* parent, const float* g, int M, int X, int H, int Y,
+                           int in_dtype, void* ws, size_t ws_bytes, float* d_child, float* d_w, float* d_parent, void* stream) {
+    using namespace vlg;
+    if (int rc = check_dims("trilinear_backward", M, X, H, Y)) return rc;
+    if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "trilinear_backward: in_dtype %d", in_dtype);
+    if (Y != 32 && Y != 64 && Y != 128) return set_error(VLG_ERR_SHAPE, "trilinear_backward: Y=%d (supported: 32, 64, 128)", Y);
+    if (H != 32 && H != 64 && H != 128) return set_error(VLG_ERR_SHAPE, "trilinear_backward: H=%d (supported: 32, 64, 128)", H);
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        if (d_w) {
+            hipError_t e = hipMemsetAsync(d_w, 0, sizeof(float) * (size_t)X * H * Y, s);
+            if (e != hipSuccess) return set_error((int)e, "trilinear_backward: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
+    if (!child || !w || !parent || !g) return set_error(VLG_ERR_ARG, "trilinear_backward: null buffer");
+    const TriBwdPlan p(M, X, H, Y, in_dtype == VLG_F32);
+    if (!ws || ws_bytes < p.bytes) return set_error(VLG_ERR_WORKSPACE, "trilinear_backward: workspace %zu bytes < %zu", ws_bytes, p.bytes);
+    return in_dtype == VLG_F32 ? run_tri_backward<true>(child, w, parent, g, M, X, H, Y, (char*)ws, p, d_child, d_w, d_parent, s)
+                               : run_tri_backward<false>(child, w, parent, g, M, X, H, Y, (char*)ws, p, d_child, d_w, d_parent, s);
+}
+
+}  // extern "C"
