@@ -235,7 +235,7 @@ def main():
                        "what": "DMV1o([dec,attach],lengths).partition.sum() + torch.autograd.grad, 1 GPU"}
 
     # ---- secondary: the region x word alignment that feeds / consumes the DP (joint.py:406-419) ----
-    if not args.no_align:
+    if not args.no_align and world == 1:   # single-GPU secondary measurements; multi-GPU runs report the headline only
         from vlgae_amd import align
         Q, V, d = 2 * N, args.regions, 128
         g = torch.Generator().manual_seed(5)

@@ -22,7 +22,8 @@
 namespace vlg {
 
 constexpr int kTriRT = 4;     // row tiles of 16 per block: its rows share every weight fragment
-constexpr int kTriRows = 16 * kTriRT;
+constexpr int kTriRG = 1;     // row groups per block (2 was tried so that their waves share weight reads through L1: the 8-wave block caps the waves at 256 registers and spills, 5x slower)
+constexpr int kTriRows = 16 * kTriRT * kTriRG;
 constexpr int kTriWaves = 4;  // waves per block; wave w takes h-tiles w, w + 4, ...
 constexpr int kTriHPW = 2;    // h-tiles per wave: H <= 128
 
@@ -34,7 +35,7 @@ __device__ __forceinline__ float tri_ld(const typename MfmaCfg<F32IN>::T* p, siz
 
 // out[m,h] = sum_x c[m,x] * sum_y w[x,h,y] * p[m,y];  Y == KCH * KW, H % 16 == 0, H <= 128.
 template <bool F32IN, int KCH>
-__global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename MfmaCfg<F32IN>::T* __restrict__ c,
+__global__ __launch_bounds__(64 * kTriWaves * kTriRG) void tri_kernel(const typename MfmaCfg<F32IN>::T* __restrict__ c,
                                                              const typename MfmaCfg<F32IN>::T* __restrict__ w,
                                                              const typename MfmaCfg<F32IN>::T* __restrict__ p, int M, int X,
                                                              int H, float* __restrict__ out) {
@@ -43,11 +44,12 @@ __global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename Mfma
     constexpr int Y = KCH * C::KW, FPK = C::KW / C::EPL;   // fragment stride between K chunks, in Frag units
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* cT = reinterpret_cast<float*>(smem_raw);   // [X][kTriRows]: c of this block's rows, transposed, fp32
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * 16 * kTriRT;
-    for (int i = threadIdx.x; i < kTriRows * X; i += 64 * kTriWaves) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wave = wid % kTriWaves, rg = wid / kTriWaves;
+    const int r = lane & 15, g = lane >> 4;
+    const int mb = blockIdx.x * kTriRows, m0 = mb + 16 * kTriRT * rg;   // block's first row, this wave's first row
+    for (int i = threadIdx.x; i < kTriRows * X; i += 64 * kTriWaves * kTriRG) {
         const int row = i / X, x = i - row * X;   // coalesced read, transposed write
-        cT[x * kTriRows + row] = m0 + row < M ? tri_ld<F32IN>(c, (size_t)(m0 + row) * X + x) : 0.f;
+        cT[x * kTriRows + row] = mb + row < M ? tri_ld<F32IN>(c, (size_t)(mb + row) * X + x) : 0.f;
     }
     // A operand: this block's p rows, resident for the whole x loop
     Frag pf[kTriRT][KCH];
@@ -73,31 +75,36 @@ __global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename Mfma
     for (int rt = 0; rt < kTriRT; ++rt)
 #pragma unroll
         for (int j = 0; j < kTriHPW; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    Frag wcur[kTriHPW][KCH], wnext[kTriHPW][KCH];
-    load_w(0, wcur);
+    // weight rows run through a register ring PF x-planes deep: one plane's MFMAs (0.2 us) do not cover an L2 round trip
+    constexpr int PF = F32IN ? 2 : 4;
+    Frag wring[PF][kTriHPW][KCH];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) load_w(min(u, X - 1), wring[u]);
     __syncthreads();
-    for (int x = 0; x < X; ++x) {
-        load_w(min(x + 1, X - 1), wnext);   // next x's weight rows are in flight under this x's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        float4 cv[kTriRT];
+    for (int x0 = 0; x0 < X; x0 += PF) {
 #pragma unroll
-        for (int rt = 0; rt < kTriRT; ++rt) cv[rt] = *reinterpret_cast<const float4*>(cT + x * kTriRows + 16 * rt + 4 * g);
+        for (int u = 0; u < PF; ++u) {
+            const int x = min(x0 + u, X - 1);
+            const float live = x0 + u < X ? 1.f : 0.f;   // the tail of a partial ring pass contributes nothing
+            float4 cv[kTriRT];
 #pragma unroll
-        for (int j = 0; j < kTriHPW; ++j)
+            for (int rt = 0; rt < kTriRT; ++rt) cv[rt] = *reinterpret_cast<const float4*>(cT + x * kTriRows + 16 * (kTriRT * rg + rt) + 4 * g);
 #pragma unroll
-            for (int rt = 0; rt < kTriRT; ++rt) {
-                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < kTriHPW; ++j)
 #pragma unroll
-                for (int kc = 0; kc < KCH; ++kc) d = mma_chunk<F32IN>(pf[rt][kc], wcur[j][kc], d);
-                acc[rt][j][0] = fmaf(cv[rt].x, d[0], acc[rt][j][0]);   // rows 4g + n of the tile: c[m, x] scales row m
-                acc[rt][j][1] = fmaf(cv[rt].y, d[1], acc[rt][j][1]);
-                acc[rt][j][2] = fmaf(cv[rt].z, d[2], acc[rt][j][2]);
-                acc[rt][j][3] = fmaf(cv[rt].w, d[3], acc[rt][j][3]);
-            }
+                for (int rt = 0; rt < kTriRT; ++rt) {
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < kTriHPW; ++j)
-#pragma unroll
-            for (int kc = 0; kc < KCH; ++kc) wcur[j][kc] = wnext[j][kc];
+                    for (int kc = 0; kc < KCH; ++kc) d = mma_chunk<F32IN>(pf[rt][kc], wring[u][j][kc], d);
+                    acc[rt][j][0] = fmaf(cv[rt].x * live, d[0], acc[rt][j][0]);   // rows 4g + n: c[m, x] scales row m
+                    acc[rt][j][1] = fmaf(cv[rt].y * live, d[1], acc[rt][j][1]);
+                    acc[rt][j][2] = fmaf(cv[rt].z * live, d[2], acc[rt][j][2]);
+                    acc[rt][j][3] = fmaf(cv[rt].w * live, d[3], acc[rt][j][3]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(min(x0 + u + PF, X - 1), wring[u]);   // refill this slot: PF - 1 planes of MFMAs until it is needed
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int j = 0; j < kTriHPW; ++j) {
@@ -114,25 +121,36 @@ __global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename Mfma
 }
 
 template <bool F32IN, int KCH>
-static void launch_tri(const void* c, const void* w, const void* p, int M, int X, int H, float* out, hipStream_t s) {
+static int launch_tri(const void* c, const void* w, const void* p, int M, int X, int H, float* out, hipStream_t s) {
     using T = typename MfmaCfg<F32IN>::T;
-    hipLaunchKernelGGL((tri_kernel<F32IN, KCH>), dim3((M + 16 * kTriRT - 1) / (16 * kTriRT)), dim3(64 * kTriWaves),
-                       sizeof(float) * kTriRows * X, s, (const T*)c, (const T*)w, (const T*)p, M, X, H, out);
+    const size_t lds = sizeof(float) * kTriRows * X;
+    auto k = tri_kernel<F32IN, KCH>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k, dim3((M + kTriRows - 1) / kTriRows), dim3(64 * kTriWaves * kTriRG), lds, s, (const T*)c, (const T*)w,
+                       (const T*)p, M, X, H, out);
+    return 0;
 }
 
 // Y (the contracted, memory-contiguous dimension) decides the instantiation.
 static int dispatch_tri(const void* c, const void* w, const void* p, int M, int X, int H, int Y, bool f32in, float* out,
                         hipStream_t s) {
     if (f32in) {
-        if (Y == 128) launch_tri<true, 8>(c, w, p, M, X, H, out, s);
-        else if (Y == 64) launch_tri<true, 4>(c, w, p, M, X, H, out, s);
-        else if (Y == 32) launch_tri<true, 2>(c, w, p, M, X, H, out, s);
+        int rc;
+        if (Y == 128) rc = launch_tri<true, 8>(c, w, p, M, X, H, out, s);
+        else if (Y == 64) rc = launch_tri<true, 4>(c, w, p, M, X, H, out, s);
+        else if (Y == 32) rc = launch_tri<true, 2>(c, w, p, M, X, H, out, s);
         else return set_error(VLG_ERR_SHAPE, "trilinear: contracted dimension %d (supported: 32, 64, 128)", Y);
+        if (rc) return rc;
     } else {
-        if (Y == 128) launch_tri<false, 4>(c, w, p, M, X, H, out, s);
-        else if (Y == 64) launch_tri<false, 2>(c, w, p, M, X, H, out, s);
-        else if (Y == 32) launch_tri<false, 1>(c, w, p, M, X, H, out, s);
+        int rc;
+        if (Y == 128) rc = launch_tri<false, 4>(c, w, p, M, X, H, out, s);
+        else if (Y == 64) rc = launch_tri<false, 2>(c, w, p, M, X, H, out, s);
+        else if (Y == 32) rc = launch_tri<false, 1>(c, w, p, M, X, H, out, s);
         else return set_error(VLG_ERR_SHAPE, "trilinear: contracted dimension %d (supported: 32, 64, 128)", Y);
+        if (rc) return rc;
     }
     return check_launch("tri_kernel");
 }
