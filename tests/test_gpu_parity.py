@@ -654,3 +654,65 @@ def test_arc_trilinear_shapes(oracle_mod, M, X, H, Y, dt):
     tol = 2e-2 if dt == "bf16" else 1e-4   # bf16: the cotangent and the returned gradients are rounded to 8 bits
     for name, got, want in (("d_child", grads[0], d_child), ("d_w1", grads[1], d_w1), ("d_parent", grads[2], d_parent)):
         assert np.abs(got.float().cpu().numpy() - want).max() <= tol * max(1.0, np.abs(want).max()), name
+
+
+def test_training_step_chain(oracle_mod):
+    """One pass over the whole path as the model wires it (joint.py:245-287 lang_feat_max_tree, :406-491 grounding):
+    DMV marginals + best heads -> txt_marginal and parent gather -> arc encoder -> alignment -> grounding loss -> gradients
+    to the feature tensors and the arc-encoder weights.  Ours end to end vs the same wiring in plain torch ops; the DP
+    results (parity-tested on their own above) feed both sides as the constants they are in the reference (joint.py:251-264)."""
+    import vlgae_amd.torch_struct as ts
+    from vlgae_amd import align
+    rng = np.random.default_rng(77)
+    B, L, V, d = 6, 9, 12, 32
+    N, Q = L + 1, 2 * (L + 1)
+    lengths = np.array([9, 7, 9, 4, 8, 5])
+    dec = np.log(rng.dirichlet(np.ones(2), (B, L, 2, 2))).astype(np.float32)
+    attach = rng.standard_normal((B, L, L, 2)).astype(np.float32)
+    root = np.log(rng.dirichlet(np.ones(L), B)).astype(np.float32)
+    # ---- DP: ours on the GPU, oracle on the CPU; both give arc marginals and the best heads ----
+    md, ma = ts.DMV1o.merge(t(dec), t(attach), t(root))
+    ma_ = ma.detach().requires_grad_(True)
+    dist = ts.DMV1o([md, ma_], t(lengths))
+    arc_margin = torch.autograd.grad(dist.partition.sum(), ma_)[0].sum(-1)          # joint.py:255
+    heads = ts.DMV1o([md, ma], t(lengths)).argmax_heads                              # replaces joint.py:256-258
+    wmask = np.arange(L)[None] < lengths[:, None]
+    mask1 = np.concatenate([np.zeros((B, 1), bool), wmask], 1)
+    margin = arc_margin.gather(-1, heads.unsqueeze(-1)).squeeze(-1) * t(mask1)      # joint.py:262-264 (add_marginal)
+    txt_marginal = torch.cat([t(mask1).float(), margin], 1)                          # joint.py:266
+    tmask = t(np.concatenate([mask1, mask1], 1))
+    assert np.allclose(arc_margin.sum((1, 2)).cpu().numpy(), lengths, atol=1e-3)     # one head per word
+    # ---- features: the two sides of the chain share the leaves ----
+    def leaves():
+        g = torch.Generator().manual_seed(3)
+        mk = lambda *s, sc=0.5: (torch.randn(*s, generator=g) * sc).to(dev()).requires_grad_(True)
+        return dict(child=mk(B, N, d), parent_src=mk(B, N, d), word=mk(B, N, d), w1=mk(d, d, d, sc=1.0 / d), w2=mk(d, d, sc=0.2),
+                    b=mk(d, sc=0.1), vis=mk(B, V, d))
+    vmask = t(rng.random((B, V)) > 0.15)
+    vmask[:, 0] = True
+    num_token = int(lengths.sum())
+    idx = heads.unsqueeze(-1).expand(-1, -1, d)
+
+    def run(ours):
+        p = leaves()
+        parent = p["parent_src"].gather(1, idx)                                      # joint.py:278-280
+        if ours:
+            arc = align.arc_encoder(p["child"], parent, p["w1"], p["w2"], p["b"])
+            txt = torch.cat([p["word"], arc], 1)
+            total, _ = align.grounding_loss_factor_ce(txt, p["vis"], tmask, vmask, txt_marginal, num_token, 1.0)
+        else:
+            arc = torch.einsum("bcx,xhy,bcy->bch", p["child"], p["w1"], parent) + torch.matmul(p["child"] + parent, p["w2"]) + p["b"]
+            txt = torch.cat([p["word"], arc], 1)
+            att = torch.einsum("avd,bqd->baqv", p["vis"], txt)
+            att = att.masked_fill(~vmask[None, :, None, :], -1e20).masked_fill(~tmask[:, None, :, None], -1e20)
+            t2v = -(att.max(3).values.log_softmax(1).diagonal().T * txt_marginal).sum()
+            v2t = -(att.max(2).values.log_softmax(0).diagonal().T * vmask).sum()
+            total = t2v / (t2v.detach() + 1e-6) * num_token + v2t / (v2t.detach() + 1e-6) * num_token
+        names = sorted(p)
+        return total, dict(zip(names, torch.autograd.grad(total, [p[k] for k in names])))
+
+    (t1, g1), (t2, g2) = run(True), run(False)
+    assert abs(float(t1) - float(t2)) <= 1e-4 * abs(float(t2))
+    for k in g2:
+        scale = max(1e-3, float(g2[k].abs().max()))
+        assert float((g1[k] - g2[k]).abs().max()) <= 2e-4 * scale, k
