@@ -91,6 +91,9 @@ struct HostX {
     void allreduce_sum(float* v, int G) {
         butterfly<n>(v, nullptr, G, [](float x, int, float y, int, float& o, int& oi) { o = x + y; oi = 0; });
     }
+    // only the source lanes hold non-zero values, so the device's broadcast equals a sum over the group
+    void group_bcast4(float* v, int G, int, int) { allreduce_sum<4>(v, G); }
+    void group_bcast2(float* v, int G, int, int) { allreduce_sum<2>(v, G); }
     template <int n>
     void allreduce_argmax(float* v, int* a, int G) {
         butterfly<n>(v, a, G, [](float x, int xa, float y, int ya, float& o, int& oi) {

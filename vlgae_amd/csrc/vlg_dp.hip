@@ -129,6 +129,21 @@ struct DevX {
     __device__ __forceinline__ void allreduce_max(float* v, int G) { butterfly<kOpMax, n>(v, G); }
     template <int n>
     __device__ __forceinline__ void allreduce_sum(float* v, int G) { butterfly<kOpAdd, n>(v, G); }
+    // v[0], v[1] are held by lane `src01` of every group of G lanes, v[2], v[3] by lane `src23` (zero elsewhere): hand them
+    // to the whole group.  Four ds_bpermute instead of 4 log2 G butterfly adds.
+    __device__ __forceinline__ void group_bcast2(float* v, int G, int src0, int src1) {
+        const int base = (int)(threadIdx.x & 63) & ~(G - 1);
+        v[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((base | src0) << 2, __builtin_bit_cast(int, v[0])));
+        v[1] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((base | src1) << 2, __builtin_bit_cast(int, v[1])));
+    }
+    __device__ __forceinline__ void group_bcast4(float* v, int G, int src01, int src23) {
+        const int base = (int)(threadIdx.x & 63) & ~(G - 1);
+        const int a01 = (base | src01) << 2, a23 = (base | src23) << 2;
+        v[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a01, __builtin_bit_cast(int, v[0])));
+        v[1] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a01, __builtin_bit_cast(int, v[1])));
+        v[2] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a23, __builtin_bit_cast(int, v[2])));
+        v[3] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a23, __builtin_bit_cast(int, v[3])));
+    }
     // arg-max with torch.max's tie-break (first index): all-reduce the values, then the SMALLEST index among
     // the lanes that hold the maximum -- two fused butterflies instead of a (value, index) pair exchange
     template <int n>

@@ -379,7 +379,7 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
             if (r == 0) { self[0] = w0[u]; self[1] = w1[u]; }
             if (r == w - 1) { self[2] = u0[u]; self[3] = u1[u]; }
         }
-        x.template allreduce_sum<4>(self, G);   // one lane holds each value: this is a broadcast
+        x.group_bcast4(self, G, 0, (w - 1) & (G - 1));   // one lane holds each pair: lanes 0 and (w-1) mod G
         const float2 gil = make_float2(gil_old.x + self[0], gil_old.y + self[1]);   // complete adjoint of IL(j,i)
         const float2 gir = make_float2(gir_old.x + self[2], gir_old.y + self[3]);
         const float gsl = gil.x + gil.y, gsr = gir.x + gir.y;
@@ -427,7 +427,7 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
             if (live) c.gCc[(i + 1 + r) * P + j + 1].y += w0 + w1;
         }
     }
-    x.template allreduce_sum<4>(self, G);
+    x.group_bcast4(self, G, 0, (w - 1) & (G - 1));
     const float2 gil = make_float2(gil_old.x + self[0], gil_old.y + self[1]);
     const float2 gir = make_float2(gir_old.x + self[2], gir_old.y + self[3]);
     const float gsl = gil.x + gil.y, gsr = gir.x + gir.y;
@@ -638,7 +638,7 @@ VLG_HD void dep_bw_span(const DepCtx& c, int w, int lg, int i, bool live, int rr
             if (r == 0) self[0] = wl[u];
             if (r == w - 1) self[1] = wr[u];
         }
-        x.template allreduce_sum<2>(self, G);
+        x.group_bcast2(self, G, 0, (w - 1) & (G - 1));   // lane 0 holds self[0], lane (w-1) mod G holds self[1]
         const float gil = gil_old + self[0], gir = gir_old + self[1], gs = gil + gir;
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
@@ -669,7 +669,7 @@ VLG_HD void dep_bw_span(const DepCtx& c, int w, int lg, int i, bool live, int rr
         else if (live) c.gI[i * P + i + r + 2] += wr;
         if (live) c.gCc[(i + 1 + r) * P + j + 1] += wr;
     }
-    x.template allreduce_sum<2>(self, G);
+    x.group_bcast2(self, G, 0, (w - 1) & (G - 1));
     const float gil = gil_old + self[0], gir = gir_old + self[1];
     const float gs = gil + gir;
     for (int r = rr; r < w; r += G) {
