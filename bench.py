@@ -192,7 +192,7 @@ def main():
     # HBM bytes per launch from the PMC counters: cannot be collected live (rocprofv3 --pmc runs in its own pass);
     # taken from the committed profile of THIS workload, with the gfx950 FETCH_SIZE x2 correction applied.
     traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
+    prof = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
     if os.path.exists(prof) and (B, L, args.dtype, bool(args.ragged)) == (256, 40, "bf16", False):
         t = json.load(open(prof)).get("dmv1o_kernel")
         if t:
@@ -210,7 +210,7 @@ def main():
                    "allreduce_floats": (max(n_grad, pad) if world > 1 else 0)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r01_e_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)" if traffic else None,
+                     "traffic_source": "profiles/r01_g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)" if traffic else None,
                      "kernel": "dmv1o_kernel<Log, mode 0 (all charts in LDS), fused inside+outside>", "kernel_us": kern_s * 1e6,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "latency-bound DP: 2(N-1) barrier-separated width steps per sentence, one workgroup "

@@ -91,9 +91,18 @@ struct HostX {
     void allreduce_sum(float* v, int G) {
         butterfly<n>(v, nullptr, G, [](float x, int, float y, int, float& o, int& oi) { o = x + y; oi = 0; });
     }
-    // only the source lanes hold non-zero values, so the device's broadcast equals a sum over the group
-    void group_bcast4(float* v, int G, int, int) { allreduce_sum<4>(v, G); }
-    void group_bcast2(float* v, int G, int, int) { allreduce_sum<2>(v, G); }
+    // true broadcasts, like the device's ds_bpermute: only the source lane's value is ever read
+    template <int n>
+    void bcast(float* v, int G, const int* src) {
+        if (G == 1) return;
+        for (int k = 0; k < n; ++k) xf[tid * 8 + k] = v[k];
+        sync();
+        const int base = tid & ~(G - 1);
+        for (int k = 0; k < n; ++k) v[k] = xf[(base + src[k]) * 8 + k];
+        sync();
+    }
+    void group_bcast4(float* v, int G, int s01, int s23) { const int src[4] = {s01, s01, s23, s23}; bcast<4>(v, G, src); }
+    void group_bcast2(float* v, int G, int s0, int s1) { const int src[2] = {s0, s1}; bcast<2>(v, G, src); }
     template <int n>
     void allreduce_argmax(float* v, int* a, int G) {
         butterfly<n>(v, a, G, [](float x, int xa, float y, int ya, float& o, int& oi) {
