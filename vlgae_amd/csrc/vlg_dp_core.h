@@ -786,6 +786,57 @@ struct RuleIO {
 // the token barrier of the host phase emulator in the CPU tests.  Pointers in the context are
 // already carved (LDS and/or workspace); dec/attach/gdec/gatt/logZ point at THIS sentence.
 // ================================================================================================
+// ------------------------------------------------------------------------------------------------
+// Best tree from the Max semiring's back-pointers, by walking the derivation from the root span instead of replaying
+// the whole outside pass with one-hot weights (which costs as much as the inside pass; the walk visits ~4N spans).
+// One lane walks; the stack lives in the (unused) gCc chart.  Every attachment it meets sets gI[...] = 1 at that
+// (head, child, valence), which the common output loop turns into the one-hot attach tensor and the head vector.
+//   entry = kind | a << 2 | b << 10 | v << 18     kind: 0 CL(a=head, b=left end)   1 CR(a=head, b=right end)
+//                                                       2 IL(a=head j, b=child)     3 IR(a=head i, b=child)
+//   recurrences as in dmv_fw_span (valence index 0 = .x HASCHILD, 1 = .y NOCHILD):
+//   CL(j,i).v = CL(i+r,i).NC + IL(j,i+r).v           CR(i,j).v = IR(i,i+1+r).v + CR(i+1+r,j).NC
+//   IL(j,k).v = attach + CR(k,k+r).NC + CL(j,k+r+1).HC        IR(i,k).v = attach + CR(i,i+r).HC + CL(k,i+r+1).NC
+// ------------------------------------------------------------------------------------------------
+VLG_HD int walk_entry(int kind, int a, int b, int v) { return kind | (a << 2) | (b << 10) | (v << 18); }
+
+VLG_HD void dmv_walk(const DmvCtx& c, float g) {
+    const int P = c.P;
+    int* stack = reinterpret_cast<int*>(c.gCc);   // at most one pending sibling per open span: far below N * P entries
+    int top = 0;
+    int e = walk_entry(1, 0, c.len, 1);           // CR(0, len).NOCHILD: what logZ reads (dmv.py:65)
+    // the span being expanded stays in a register and one child is followed directly; only its sibling goes through
+    // the stack, so a step costs one dependent LDS read (the back-pointer), not a push-pop round trip as well
+    for (;;) {
+        const int kind = e & 3, a = (e >> 2) & 255, b = (e >> 10) & 255, v = (e >> 18) & 1;
+        if (kind < 2 && a == b) {   // width-0 complete span: a leaf
+            if (top == 0) break;
+            e = stack[--top];
+            continue;
+        }
+        int sib;
+        if (kind == 0) {            // CL(head a, left end b)
+            const int r = c.bpC[(a * P + b) * 2 + v];
+            sib = walk_entry(0, b + r, b, 1);
+            e = walk_entry(2, a, b + r, v);
+        } else if (kind == 1) {     // CR(head a, right end b)
+            const int r = c.bpC[(a * P + b + 1) * 2 + v];
+            sib = walk_entry(1, a + 1 + r, b, 1);
+            e = walk_entry(3, a, a + 1 + r, v);
+        } else if (kind == 2) {     // IL(head a, child b): child to the left
+            reinterpret_cast<float*>(c.gI + a * P + b)[v] = g;
+            const int r = c.bpS[a * P + b];
+            sib = walk_entry(1, b, b + r, 1);
+            e = walk_entry(0, a, b + r + 1, 0);
+        } else {                    // IR(head a, child b): child to the right
+            reinterpret_cast<float*>(c.gI + a * P + b + 1)[v] = g;
+            const int r = c.bpS[a * P + b];
+            sib = walk_entry(1, a, a + r, 0);
+            e = walk_entry(0, b, a + r + 1, 1);
+        }
+        stack[top++] = sib;
+    }
+}
+
 template <int SR, bool BWD, typename IO, typename X>
 VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int tid, int nt, X& x) {
     const int Ne = c.Ne, P = c.P, len = c.len;
@@ -839,6 +890,10 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     if (tid == 0) *logZ = c.C[len + 1].y * VLG_LN2;   // CR(0,len).NOCHILD, dmv.py:65
     if (!BWD) return;
     // ---- outside: adjoint replay ------------------------------------------------------------------
+    if (SR == VLG_SR_MAX && !io.wants_dec()) {   // only the tree is wanted: walk the back-pointers
+        if (tid == 0) dmv_walk(c, glogZ);
+        x.sync();
+    } else {
     if (tid == 0) c.gCc[len + 1].y = glogZ;
     x.sync();
 #if defined(VLG_STAMP) && defined(__HIPCC__)
@@ -858,6 +913,7 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
         x.sync();
     }
 #endif
+    }
     // expected counts out (coalesced; padded positions get exact zeros like the reference).  Decode mode
     // (heads != null): heads[c] = the h with a non-zero attach count -- what the callers compute on the host
     // with `argmax.sum(-1).nonzero()` + a scatter (ldndmv.py:301-303, joint.py:256-258); 0 for root / padding.
@@ -899,6 +955,43 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
 #endif
 }
 
+// DepTree: the same walk without valences (single back-pointer per cell).
+VLG_HD void dep_walk(const DepCtx& c, float g) {
+    const int P = c.P;
+    int* stack = reinterpret_cast<int*>(c.gCc);
+    int top = 0;
+    int e = walk_entry(1, 0, c.len, 0);   // CR(0, len), deptree.py:74-75
+    for (;;) {
+        const int kind = e & 3, a = (e >> 2) & 255, b = (e >> 10) & 255;
+        if (kind < 2 && a == b) {
+            if (top == 0) break;
+            e = stack[--top];
+            continue;
+        }
+        int sib;
+        if (kind == 0) {
+            const int r = c.bpC[a * P + b];
+            sib = walk_entry(0, b + r, b, 0);
+            e = walk_entry(2, a, b + r, 0);
+        } else if (kind == 1) {
+            const int r = c.bpC[a * P + b + 1];
+            sib = walk_entry(1, a + 1 + r, b, 0);
+            e = walk_entry(3, a, a + 1 + r, 0);
+        } else if (kind == 2) {
+            c.gI[a * P + b] = g;
+            const int r = c.bpS[b * P + a];   // IL(j,k) and IR(k,j) share T(k,j), kept once at [left end][right end]
+            sib = walk_entry(1, b, b + r, 0);
+            e = walk_entry(0, a, b + r + 1, 0);
+        } else {
+            c.gI[a * P + b + 1] = g;
+            const int r = c.bpS[a * P + b];
+            sib = walk_entry(1, a, a + r, 0);
+            e = walk_entry(0, b, a + r + 1, 0);
+        }
+        stack[top++] = sib;
+    }
+}
+
 template <int SR, bool BWD, typename In, typename X>
 VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glogZ, float* logZ, float* garc,
                     long long* heads, int tid, int nt, X& x) {
@@ -928,11 +1021,16 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
     }
     if (tid == 0) *logZ = c.C[len + 1] * VLG_LN2;   // CR(0,len), deptree.py:74-75
     if (!BWD) return;
-    if (tid == 0) c.gCc[len + 1] = glogZ;
-    x.sync();
-    for (int w = Ne - 1; w >= 1; --w) {
-        dep_bw<SR>(c, w, tid, nt, x);
+    if (SR == VLG_SR_MAX) {   // the best tree's arcs are all the Max semiring's gradient is: walk the back-pointers
+        if (tid == 0) dep_walk(c, glogZ);
         x.sync();
+    } else {
+        if (tid == 0) c.gCc[len + 1] = glogZ;
+        x.sync();
+        for (int w = Ne - 1; w >= 1; --w) {
+            dep_bw<SR>(c, w, tid, nt, x);
+            x.sync();
+        }
     }
     if (heads) {
         for (int i = tid; i < N; i += nt) heads[i] = 0;
