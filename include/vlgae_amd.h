@@ -61,7 +61,9 @@ int vlg_dmv1o_inside(const void* dec, const void* attach, const int64_t* lengths
  *   grad_logZ   [B] upstream gradient of logZ, or NULL for all-ones
  *   grad_dec    [B,N,2,2,2], grad_attach [B,N,N,2]: d(sum_b grad_logZ[b]*logZ[b]) / d(potentials) =
  *               posterior expected counts (Log) or the 0/1 indicator of the best tree (Max; first
- *               arg-max on ties like torch.max).  Fully written, exact zeros at padded positions. */
+ *               arg-max on ties like torch.max).  Fully written, exact zeros at padded positions.
+ *               grad_dec may be NULL (attach counts only -- what `.marginals` / `.argmax` keep, dmv.py:68-69); with the
+ *               Max semiring the tree is then read off the back-pointers instead of replaying the outside pass. */
 int vlg_dmv1o_inside_outside(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype,
                              int semiring, const float* grad_logZ, float* logZ, float* grad_dec, float* grad_attach,
                              void* ws, size_t ws_bytes, void* stream);

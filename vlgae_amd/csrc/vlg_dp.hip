@@ -403,7 +403,7 @@ static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, 
     if (N > 255) return set_error(VLG_ERR_SHAPE, "dmv1o: N=%d exceeds the supported maximum of 255", N);
     if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "dmv1o: in_dtype %d", in_dtype);
     if (semiring != VLG_SR_LOG && semiring != VLG_SR_MAX) return set_error(VLG_ERR_ARG, "dmv1o: semiring %d", semiring);
-    if (!dec || !attach || !lengths || !logZ || (BWD && !heads && (!gdec || !gatt)))
+    if (!dec || !attach || !lengths || !logZ || (BWD && !heads && !gatt))   // gdec may be null: attach counts only
         if (B > 0) return set_error(VLG_ERR_ARG, "dmv1o: null buffer");
     if (B == 0) return 0;
     const int mode = pick_mode<DmvLayout>(N, BWD, semiring == VLG_SR_MAX, kLdsBudget);

@@ -121,7 +121,7 @@ class DMV1o(StructDistribution):
         # part; the fused kernel returns exactly that gradient.  (Not differentiable a second time:
         # no caller does -- inputs are always detached leaves, joint.py:252-253.)
         dec, attach = self.log_potentials
-        _, _, gatt = F.dmv1o_run(dec, attach, self.lengths, semiring.kernel_id, True)
+        _, _, gatt = F.dmv1o_run(dec, attach, self.lengths, semiring.kernel_id, True, want_dec=False)
         return gatt.to(attach.dtype) if attach.dtype == torch.float64 else gatt
 
     @lazy_property

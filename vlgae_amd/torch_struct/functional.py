@@ -31,8 +31,9 @@ def _lengths(lengths, B, device, allow_none=False):
     return lengths
 
 
-def dmv1o_run(dec, attach, lengths, semiring, want_grad, grad_logZ=None):
-    """Raw launcher.  dec [B,N,2,2,2], attach [B,N,N,2] -> logZ [B] (+ grad_dec, grad_attach fp32)."""
+def dmv1o_run(dec, attach, lengths, semiring, want_grad, grad_logZ=None, want_dec=True):
+    """Raw launcher.  dec [B,N,2,2,2], attach [B,N,N,2] -> logZ [B] (+ grad_dec, grad_attach fp32).
+    want_dec=False: attach counts only (grad_dec is None; the Max semiring then takes the back-pointer walk)."""
     _C.require_gpu(dec, "dmv1o")
     if dec.dim() != 5 or tuple(dec.shape[2:]) != (2, 2, 2):
         raise ValueError(f"dec must be [B,N,2,2,2], got {tuple(dec.shape)}")
@@ -47,7 +48,7 @@ def dmv1o_run(dec, attach, lengths, semiring, want_grad, grad_logZ=None):
     logZ = torch.empty(B, dtype=torch.float32, device=dec.device)
     L = _C.lib()
     if want_grad:
-        gdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dec.device)
+        gdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dec.device) if want_dec else None
         gatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dec.device)
         ws, nb = _workspace(_C.OP_DMV1O_INSIDE_OUTSIDE, B, N, semiring, dec.device)
         g = None if grad_logZ is None else grad_logZ.detach().to(torch.float32).reshape(B).contiguous()
