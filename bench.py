@@ -234,6 +234,20 @@ def main():
     out["api_path"] = {"sentences_per_s": B * n_api / (time.perf_counter() - t0),
                        "what": "DMV1o([dec,attach],lengths).partition.sum() + torch.autograd.grad, 1 GPU"}
 
+    # ---- Viterbi decode of the same batch: Max-semiring inside + back-pointer walk -> head vector (joint.py:256-258) ----
+    from vlgae_amd.torch_struct import functional as Fn
+    for _ in range(5):
+        Fn.dmv1o_decode(md, ma, lengths)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        Fn.dmv1o_decode(md, ma, lengths)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    out["decode"] = {"us": e0.elapsed_time(e1) / 50 * 1e3, "sentences_per_s": B * 50 / (e0.elapsed_time(e1) * 1e-3),
+                     "what": "dmv1o_decode: best tree as heads [B,N], on device"}
+
     # ---- secondary: the region x word alignment that feeds / consumes the DP (joint.py:406-419) ----
     if not args.no_align and world == 1:   # single-GPU secondary measurements; multi-GPU runs report the headline only
         from vlgae_amd import align
