@@ -152,9 +152,11 @@ struct Arena {
 template <int SR, bool BWD, typename In>
 void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int len, int N, float glogZ, float* logZ,
                  float* gdec, float* gatt, int nt, int order, long long* heads = nullptr) {
-    const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, 0);   // mode 0: one contiguous carve, like LDS
+    const bool walk = BWD && SR == VLG_SR_MAX && gdec == nullptr;   // the launcher's rule (vlg_dp.hip: run_dmv)
+    const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, 0, walk);   // mode 0: one contiguous carve, like LDS
     Arena A(L.lds_bytes);
     vlg::DmvCtx c;
+    c.walk = walk;
     c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
     c.C = (float2*)A.at(L.C.off); c.I = (float2*)A.at(L.I.off); c.S = (float*)A.at(L.S.off);
     c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);
@@ -172,9 +174,11 @@ void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int le
 template <int SR, bool BWD>
 void emu_rules_one(const vlg::RuleIO<vlg::F32In>& io, int len, float glogZ, float* logZ, int nt, int order) {
     const int N = io.L + 1;
-    const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, 0);
+    const bool walk = BWD && SR == VLG_SR_MAX && io.g_dec == nullptr;
+    const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, 0, walk);
     Arena A(L.lds_bytes);
     vlg::DmvCtx c;
+    c.walk = walk;
     c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
     c.C = (float2*)A.at(L.C.off); c.I = (float2*)A.at(L.I.off); c.S = (float*)A.at(L.S.off);
     c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);

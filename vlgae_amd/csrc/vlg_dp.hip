@@ -195,9 +195,10 @@ __device__ __forceinline__ T* region_ptr(const Region& r, char* smem, char* wsb)
 }
 
 template <int SR, int MODE, bool BWD>
-__device__ __forceinline__ DmvCtx carve_dmv(int N, int len, char* smem, char* wsb) {
-    const DmvLayout L(N, BWD, SR == VLG_SR_MAX, MODE);
+__device__ __forceinline__ DmvCtx carve_dmv(int N, int len, char* smem, char* wsb, bool walk) {
+    const DmvLayout L(N, BWD, SR == VLG_SR_MAX, MODE, walk);
     DmvCtx c;
+    c.walk = walk;
     c.Ne = len + 1;
     c.len = len;
     c.P = chart_pitch(N);
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
     }
 
     char* wsb = ws + (size_t)b * ws_stride;
-    const DmvCtx c = carve_dmv<SR, MODE, BWD>(N, len, smem, wsb);
+    const DmvCtx c = carve_dmv<SR, MODE, BWD>(N, len, smem, wsb, BWD && SR == VLG_SR_MAX && gdec == nullptr);
     MergedIO<In> io;
     io.dec = dec + dec_off;
     io.attach = attach + att_off;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void dmv1o_rules_kernel(
         return;
     }
     char* wsb = ws + (size_t)b * ws_stride;
-    const DmvCtx c = carve_dmv<SR, MODE, BWD>(N, len, smem, wsb);
+    const DmvCtx c = carve_dmv<SR, MODE, BWD>(N, len, smem, wsb, BWD && SR == VLG_SR_MAX && g_dec == nullptr);
     RuleIO<In> io;
     io.rule = rule + (size_t)b * Lw * T * 4;
     io.dec = dec + (size_t)b * Lw * 8;
@@ -406,8 +407,9 @@ static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, 
     if (!dec || !attach || !lengths || !logZ || (BWD && !heads && !gatt))   // gdec may be null: attach counts only
         if (B > 0) return set_error(VLG_ERR_ARG, "dmv1o: null buffer");
     if (B == 0) return 0;
-    const int mode = pick_mode<DmvLayout>(N, BWD, semiring == VLG_SR_MAX, kLdsBudget);
-    const DmvLayout L(N, BWD, semiring == VLG_SR_MAX, mode);
+    const bool walk = BWD && semiring == VLG_SR_MAX && !gdec;   // tree only: lean layout, back-pointer walk (the kernel derives the same flag)
+    const int mode = pick_mode<DmvLayout>(N, BWD, semiring == VLG_SR_MAX, kLdsBudget, walk);
+    const DmvLayout L(N, BWD, semiring == VLG_SR_MAX, mode, walk);
     const size_t ws_stride = L.ws_bytes, lds = L.lds_bytes;
     if (ws_stride * (size_t)B > ws_bytes || (ws_stride && !ws))
         return set_error(VLG_ERR_WORKSPACE, "dmv1o: N=%d needs a %zu-byte workspace (got %zu); see vlg_workspace_bytes",
@@ -573,8 +575,9 @@ int vlg_dmv1o_rules(const void* attach_rule, const void* dec, const void* root_r
     if (bwd && !heads && !(grad_rule && grad_dec && grad_root))
         return set_error(VLG_ERR_ARG, "dmv1o_rules: pass all three gradient buffers (or only heads)");
     const bool is_max = semiring == VLG_SR_MAX;
-    const int mode = pick_mode<DmvLayout>(N, bwd, is_max, kLdsBudget);
-    const DmvLayout Lay(N, bwd, is_max, mode);
+    const bool walk = bwd && is_max && !grad_dec;
+    const int mode = pick_mode<DmvLayout>(N, bwd, is_max, kLdsBudget, walk);
+    const DmvLayout Lay(N, bwd, is_max, mode, walk);
     if (Lay.ws_bytes * (size_t)B > ws_bytes || (Lay.ws_bytes && !ws))
         return set_error(VLG_ERR_WORKSPACE, "dmv1o_rules: L=%d needs a %zu-byte workspace (got %zu)", L, Lay.ws_bytes * (size_t)B, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -603,8 +606,11 @@ size_t vlg_workspace_bytes(int op, int B, int N, int semiring) {
     switch (op) {
         case VLG_OP_DMV1O_INSIDE:
             return DmvLayout(N, false, is_max, pick_mode<DmvLayout>(N, false, is_max, kLdsBudget)).ws_bytes * B;
-        case VLG_OP_DMV1O_INSIDE_OUTSIDE:
-            return DmvLayout(N, true, is_max, pick_mode<DmvLayout>(N, true, is_max, kLdsBudget)).ws_bytes * B;
+        case VLG_OP_DMV1O_INSIDE_OUTSIDE: {   // covers both the replay layout and (Max, tree only) the leaner walk layout
+            const size_t full = DmvLayout(N, true, is_max, pick_mode<DmvLayout>(N, true, is_max, kLdsBudget)).ws_bytes;
+            const size_t lean = is_max ? DmvLayout(N, true, true, pick_mode<DmvLayout>(N, true, true, kLdsBudget, true), true).ws_bytes : 0;
+            return (full > lean ? full : lean) * B;
+        }
         case VLG_OP_DEPTREE_INSIDE:
             return DepLayout(N, false, is_max, pick_mode<DepLayout>(N, false, is_max, kLdsBudget)).ws_bytes * B;
         case VLG_OP_DEPTREE_INSIDE_OUTSIDE:

@@ -116,6 +116,7 @@ struct DmvCtx {
     float* gdecs;   // adjoint of dec    [Ne][8]
     unsigned char* bpS;   // Max semiring back-pointers (first arg-max r), same indexing as S
     unsigned char* bpC;   // [Ne][P][2]
+    bool walk;            // Max semiring, tree only: no S / gCi / gdecs, gCc is just the walk's stack (lean layout)
 };
 
 // weight of term r in a reduction with result `out`, scaled by the upstream adjoint g
@@ -287,8 +288,10 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
         c.C[j * P + i] = make_float2(CLx, CLy);
         c.C[i * P + j + 1] = make_float2(CRx, CRy);
         if (BWD) {
-            c.S[j * P + i] = SL;
-            c.S[i * P + j] = SRv;
+            if (!c.walk) {   // the tape of the outside replay; the back-pointer walk does not read it
+                c.S[j * P + i] = SL;
+                c.S[i * P + j] = SRv;
+            }
             if (SR == VLG_SR_MAX) {
                 c.bpS[j * P + i] = (unsigned char)am[0];
                 c.bpS[i * P + j] = (unsigned char)am[1];
@@ -564,7 +567,7 @@ VLG_HD void dep_fw_span(const DepCtx& c, int w, int lg, int i, bool live, int rr
         c.C[j * P + i] = CLv;
         c.C[i * P + j + 1] = CRv;
         if (BWD) {
-            c.S[i * P + j] = T;
+            if (SR != VLG_SR_MAX) c.S[i * P + j] = T;   // the outside replay's tape; the Max semiring walks back-pointers
             if (SR == VLG_SR_MAX) {
                 c.bpS[i * P + j] = (unsigned char)am[0];
                 c.bpC[j * P + i] = (unsigned char)b0;
@@ -801,7 +804,7 @@ VLG_HD int walk_entry(int kind, int a, int b, int v) { return kind | (a << 2) | 
 
 VLG_HD void dmv_walk(const DmvCtx& c, float g) {
     const int P = c.P;
-    int* stack = reinterpret_cast<int*>(c.gCc);   // at most one pending sibling per open span: far below N * P entries
+    int* stack = reinterpret_cast<int*>(c.gCc);   // at most one pending sibling per open span: depth <= 2N (layout: 2N + 4)
     int top = 0;
     int e = walk_entry(1, 0, c.len, 1);           // CR(0, len).NOCHILD: what logZ reads (dmv.py:65)
     // the span being expanded stays in a register and one child is followed directly; only its sibling goes through
@@ -845,11 +848,14 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     for (int i = tid; i < Ne * P; i += nt) {
         c.C[i] = zz;
         c.I[i] = zz;
-        if (BWD) { c.gCc[i] = oo; c.gCi[i] = oo; c.gI[i] = oo; }
+        if (BWD) {
+            c.gI[i] = oo;
+            if (!c.walk) { c.gCc[i] = oo; c.gCi[i] = oo; }
+        }
     }
     for (int i = tid; i < Ne * 8; i += nt) {
         c.decs[i] = io.ld_dec(i) * VLG_LOG2E;
-        if (BWD) c.gdecs[i] = 0.f;
+        if (BWD && !c.walk) c.gdecs[i] = 0.f;
     }
     x.sync();
     // incomplete-span slots are pre-loaded with attach + dec[...,GO] (dmv.py:36-37); the width-0
@@ -890,7 +896,7 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     if (tid == 0) *logZ = c.C[len + 1].y * VLG_LN2;   // CR(0,len).NOCHILD, dmv.py:65
     if (!BWD) return;
     // ---- outside: adjoint replay ------------------------------------------------------------------
-    if (SR == VLG_SR_MAX && !io.wants_dec()) {   // only the tree is wanted: walk the back-pointers
+    if (SR == VLG_SR_MAX && c.walk) {   // only the tree is wanted (the launcher chose the lean layout): walk the back-pointers
         if (tid == 0) dmv_walk(c, glogZ);
         x.sync();
     } else {
@@ -999,7 +1005,10 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
     for (int i = tid; i < Ne * P; i += nt) {
         c.C[i] = VLG_NEGINF;   // deptree.py:42-43
         c.I[i] = VLG_NEGINF;
-        if (BWD) { c.gCc[i] = 0.f; c.gCi[i] = 0.f; c.gI[i] = 0.f; }
+        if (BWD) {
+            c.gI[i] = 0.f;
+            if (SR != VLG_SR_MAX) { c.gCc[i] = 0.f; c.gCi[i] = 0.f; }   // Max: gCc is only the walk's stack
+        }
     }
     x.sync();
     // arcs beyond the sentence are never read (the reference masks them on a clone, deptree.py:159-161)
@@ -1074,20 +1083,37 @@ struct Carver {
 struct DmvLayout {
     Region C, I, S, bpS, bpC, gCc, gCi, gI, decs, gdecs;
     size_t lds_bytes, ws_bytes;
-    VLG_HOSTDEV_M DmvLayout(int N, bool bwd, bool is_max, int mode) {
+    // walk: Max semiring with only the tree wanted -- no replay tape (S), no adjoint charts; gCc shrinks to the walk's
+    // stack, gI stays (the one-hot attach output / head vector is read from it).  Its modes keep the value charts and
+    // back-pointers in LDS longest:  0: everything   1: gI in the workspace   2+: value charts too.
+    VLG_HOSTDEV_M DmvLayout(int N, bool bwd, bool is_max, int mode, bool walk = false) {
         const size_t cells = (size_t)N * chart_pitch(N);
         Carver k;
-        const bool v = mode < 1, a1 = mode < 3, a2 = mode < 2;
-        C = k.take(cells * 8, v);
-        I = k.take(cells * 8, v);
-        S = k.take(bwd ? cells * 4 : 0, v);
-        bpS = k.take(bwd && is_max ? cells : 0, v);
-        bpC = k.take(bwd && is_max ? cells * 2 : 0, v);
-        gCc = k.take(bwd ? cells * 8 : 0, a1);
-        gCi = k.take(bwd ? cells * 8 : 0, a1);
-        gI = k.take(bwd ? cells * 8 : 0, a2);
-        decs = k.take((size_t)N * 32, true);
-        gdecs = k.take(bwd ? (size_t)N * 32 : 0, true);
+        if (walk) {
+            const bool v = mode < 2, a2 = mode < 1;
+            C = k.take(cells * 8, v);
+            I = k.take(cells * 8, v);
+            S = k.take(0, v);
+            bpS = k.take(cells, v);
+            bpC = k.take(cells * 2, v);
+            gCc = k.take((2 * (size_t)N + 4) * 4, true);   // the walk's stack: one pending sibling per open span, depth <= 2N
+            gCi = k.take(0, true);
+            gI = k.take(cells * 8, a2);
+            decs = k.take((size_t)N * 32, true);
+            gdecs = k.take(0, true);
+        } else {
+            const bool v = mode < 1, a1 = mode < 3, a2 = mode < 2;
+            C = k.take(cells * 8, v);
+            I = k.take(cells * 8, v);
+            S = k.take(bwd ? cells * 4 : 0, v);
+            bpS = k.take(bwd && is_max ? cells : 0, v);
+            bpC = k.take(bwd && is_max ? cells * 2 : 0, v);
+            gCc = k.take(bwd ? cells * 8 : 0, a1);
+            gCi = k.take(bwd ? cells * 8 : 0, a1);
+            gI = k.take(bwd ? cells * 8 : 0, a2);
+            decs = k.take((size_t)N * 32, true);
+            gdecs = k.take(bwd ? (size_t)N * 32 : 0, true);
+        }
         lds_bytes = k.lds;
         ws_bytes = k.ws;
     }
@@ -1096,27 +1122,40 @@ struct DmvLayout {
 struct DepLayout {
     Region C, I, S, bpS, bpC, gCc, gCi, gI;
     size_t lds_bytes, ws_bytes;
-    VLG_HOSTDEV_M DepLayout(int N, bool bwd, bool is_max, int mode) {
+    // Max semiring + gradient = always the back-pointer walk (see DmvLayout's walk variant)
+    VLG_HOSTDEV_M DepLayout(int N, bool bwd, bool is_max, int mode, bool = false) {
         const size_t cells = (size_t)N * chart_pitch(N);
         Carver k;
-        const bool v = mode < 1, a1 = mode < 3, a2 = mode < 2;
-        C = k.take(cells * 4, v);
-        I = k.take(cells * 4, v);
-        S = k.take(bwd ? cells * 4 : 0, v);
-        bpS = k.take(bwd && is_max ? cells : 0, v);
-        bpC = k.take(bwd && is_max ? cells : 0, v);
-        gCc = k.take(bwd ? cells * 4 : 0, a1);
-        gCi = k.take(bwd ? cells * 4 : 0, a1);
-        gI = k.take(bwd ? cells * 4 : 0, a2);
+        if (bwd && is_max) {
+            const bool v = mode < 2, a2 = mode < 1;
+            C = k.take(cells * 4, v);
+            I = k.take(cells * 4, v);
+            S = k.take(0, v);
+            bpS = k.take(cells, v);
+            bpC = k.take(cells, v);
+            gCc = k.take((2 * (size_t)N + 4) * 4, true);   // the walk's stack: one pending sibling per open span, depth <= 2N
+            gCi = k.take(0, true);
+            gI = k.take(cells * 4, a2);
+        } else {
+            const bool v = mode < 1, a1 = mode < 3, a2 = mode < 2;
+            C = k.take(cells * 4, v);
+            I = k.take(cells * 4, v);
+            S = k.take(bwd ? cells * 4 : 0, v);
+            bpS = k.take(0, v);
+            bpC = k.take(0, v);
+            gCc = k.take(bwd ? cells * 4 : 0, a1);
+            gCi = k.take(bwd ? cells * 4 : 0, a1);
+            gI = k.take(bwd ? cells * 4 : 0, a2);
+        }
         lds_bytes = k.lds;
         ws_bytes = k.ws;
     }
 };
 
 template <typename Layout>
-VLG_HOSTDEV int pick_mode(int N, bool bwd, bool is_max, size_t lds_budget) {
+VLG_HOSTDEV int pick_mode(int N, bool bwd, bool is_max, size_t lds_budget, bool walk = false) {
     for (int mode = 0; mode < 3; ++mode)
-        if (Layout(N, bwd, is_max, mode).lds_bytes <= lds_budget) return mode;
+        if (Layout(N, bwd, is_max, mode, walk).lds_bytes <= lds_budget) return mode;
     return 3;
 }
 
