@@ -247,6 +247,17 @@ def main():
     torch.cuda.synchronize(dev)
     out["decode"] = {"us": e0.elapsed_time(e1) / 50 * 1e3, "sentences_per_s": B * 50 / (e0.elapsed_time(e1) * 1e-3),
                      "what": "dmv1o_decode: best tree as heads [B,N], on device"}
+    pair = lambda: ts.DMV1o([md, ma], lengths).marginals_and_heads()
+    for _ in range(5):
+        pair()
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(50):
+        pair()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    out["marginals_and_heads"] = {"us": e0.elapsed_time(e1) / 50 * 1e3,
+                                  "what": "arc marginals + Viterbi heads of one batch (joint.py:251-258), two HIP streams"}
 
     # ---- secondary: the region x word alignment that feeds / consumes the DP (joint.py:406-419) ----
     if not args.no_align and world == 1:   # single-GPU secondary measurements; multi-GPU runs report the headline only

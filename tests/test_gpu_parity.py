@@ -716,3 +716,18 @@ def test_training_step_chain(oracle_mod):
     for k in g2:
         scale = max(1e-3, float(g2[k].abs().max()))
         assert float((g1[k] - g2[k]).abs().max()) <= 2e-4 * scale, k
+
+
+def test_marginals_and_heads_two_streams(ts):
+    """The overlapped pair equals the two separate calls bit for bit (same kernels, different streams)."""
+    g = torch.Generator().manual_seed(11)
+    B, L = 64, 23
+    dec = torch.randn(B, L, 2, 2, 2, generator=g).log_softmax(-1).to(dev())
+    attach = torch.randn(B, L, L, 2, generator=g).to(dev())
+    root = torch.randn(B, L, generator=g).log_softmax(-1).to(dev())
+    lengths = torch.randint(3, L + 1, (B,), generator=g).to(dev())
+    md, ma = ts.DMV1o.merge(dec, attach, root)
+    for _ in range(3):   # repeated: the side stream is reused and must stay ordered with the current one
+        marg, heads = ts.DMV1o([md, ma], lengths).marginals_and_heads()
+        d2 = ts.DMV1o([md, ma], lengths)
+        assert torch.equal(marg, d2.marginals) and torch.equal(heads, d2.argmax_heads)

@@ -132,6 +132,13 @@ class DMV1o(StructDistribution):
         dec, attach = self.log_potentials
         return F.dmv1o_decode(dec, attach, self.lengths)[1]
 
+    def marginals_and_heads(self):
+        """Extension: (`marginals`, `argmax_heads`) with the two DPs overlapped on two HIP streams -- the pair
+        lang_feat_max_tree asks for every step (joint.py:251-258)."""
+        dec, attach = self.log_potentials
+        _, gatt, heads = F.dmv1o_marginals_and_heads(dec, attach, self.lengths)
+        return gatt, heads
+
     @staticmethod
     def merge(dec: Tensor, attach: Tensor, root: Tensor, one=0, zero=NEGINF):
         """Root-augmented potentials (distributions.py:253-265): the root is token 0, generates only to

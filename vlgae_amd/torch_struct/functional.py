@@ -275,3 +275,28 @@ class _Merge(torch.autograd.Function):
 
 def dmv1o_merge_autograd(dec, attach, root, one=0.0, zero=NEGINF):
     return _Merge.apply(dec, attach, root, one, zero)
+
+
+_SIDE_STREAMS = {}
+
+
+def dmv1o_marginals_and_heads(dec, attach, lengths):
+    """What lang_feat_max_tree needs from one sentence batch (joint.py:251-258): the arc marginals
+    d logZ / d attach AND the Viterbi heads.  The two are independent DPs over the same potentials; at one
+    workgroup per CU each leaves most of the machine idle and their LDS footprints (78 KB + 49 KB at N = 41) fit one
+    CU together, so the decode runs on a side HIP stream next to the inside-outside launch and joins before returning.
+    Returns (logZ [B], marginals [B,N,N,2], heads [B,N])."""
+    _C.require_gpu(dec, "dmv1o_marginals_and_heads")
+    cur = torch.cuda.current_stream(dec.device)
+    side = _SIDE_STREAMS.get(dec.device)
+    if side is None:
+        side = _SIDE_STREAMS[dec.device] = torch.cuda.Stream(device=dec.device)
+    side.wait_stream(cur)                       # the potentials are produced on the current stream
+    with torch.cuda.stream(side):
+        _, heads = dmv1o_decode(dec, attach, lengths)
+    logZ, _, gatt = dmv1o_run(dec, attach, lengths, _C.SEMIRING_LOG, True, want_dec=False)
+    cur.wait_stream(side)
+    heads.record_stream(cur)                    # allocated on the side stream, consumed on the current one
+    for t in (dec, attach):
+        t.record_stream(side)
+    return logZ, gatt, heads
