@@ -21,9 +21,6 @@
 
 namespace vlg {
 
-constexpr int kTriRT = 4;     // row tiles of 16 per block: its rows share every weight fragment
-constexpr int kTriRG = 1;     // row groups per block (2 was tried so that their waves share weight reads through L1: the 8-wave block caps the waves at 256 registers and spills, 5x slower)
-constexpr int kTriRows = 16 * kTriRT * kTriRG;
 constexpr int kTriWaves = 4;  // waves per block; wave w takes h-tiles w, w + 4, ...
 constexpr int kTriHPW = 2;    // h-tiles per wave: H <= 128
 
@@ -33,28 +30,33 @@ __device__ __forceinline__ float tri_ld(const typename MfmaCfg<F32IN>::T* p, siz
     else return __uint_as_float((uint32_t)p[i] << 16);
 }
 
-// out[m,h] = sum_x c[m,x] * sum_y w[x,h,y] * p[m,y];  Y == KCH * KW, H % 16 == 0, H <= 128.
-template <bool F32IN, int KCH>
-__global__ __launch_bounds__(64 * kTriWaves * kTriRG) void tri_kernel(const typename MfmaCfg<F32IN>::T* __restrict__ c,
+// out[m,h] (+)= sum_{x in this block's range} c[m,x] * sum_y w[x,h,y] * p[m,y];  Y == KCH * KW, H % 16 == 0, H <= 128.
+// Block = 16 RT rows x all of H x one of gridDim.y ranges of x.  Every wave streams the weight rows of its h-tiles for
+// every x of the range straight from global memory (16-byte fragment reads through a register ring), so the cost per MFMA
+// of that stream falls with RT; the x split keeps the block count up when RT grows.  With two ranges the two partial sums
+// are added into a zeroed `out` with atomics -- 0 + a + b is the same bits in either order.
+template <bool F32IN, int KCH, int RT>
+__global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename MfmaCfg<F32IN>::T* __restrict__ c,
                                                              const typename MfmaCfg<F32IN>::T* __restrict__ w,
                                                              const typename MfmaCfg<F32IN>::T* __restrict__ p, int M, int X,
                                                              int H, float* __restrict__ out) {
     using C = MfmaCfg<F32IN>;
     using Frag = typename C::Frag;
     constexpr int Y = KCH * C::KW, FPK = C::KW / C::EPL;   // fragment stride between K chunks, in Frag units
+    constexpr int ROWS = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* cT = reinterpret_cast<float*>(smem_raw);   // [X][kTriRows]: c of this block's rows, transposed, fp32
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wave = wid % kTriWaves, rg = wid / kTriWaves;
-    const int r = lane & 15, g = lane >> 4;
-    const int mb = blockIdx.x * kTriRows, m0 = mb + 16 * kTriRT * rg;   // block's first row, this wave's first row
-    for (int i = threadIdx.x; i < kTriRows * X; i += 64 * kTriWaves * kTriRG) {
-        const int row = i / X, x = i - row * X;   // coalesced read, transposed write
-        cT[x * kTriRows + row] = mb + row < M ? tri_ld<F32IN>(c, (size_t)(mb + row) * X + x) : 0.f;
+    float* cT = reinterpret_cast<float*>(smem_raw);   // [x range][ROWS]: c of this block's rows, transposed, fp32
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * ROWS;
+    const int xper = (X + gridDim.y - 1) / gridDim.y, xb = blockIdx.y * xper, xe = min(X, xb + xper), nx = xe - xb;
+    for (int i = threadIdx.x; i < ROWS * nx; i += 64 * kTriWaves) {
+        const int row = i / nx, x = i - row * nx;   // coalesced read, transposed write
+        cT[x * ROWS + row] = m0 + row < M ? tri_ld<F32IN>(c, (size_t)(m0 + row) * X + xb + x) : 0.f;
     }
     // A operand: this block's p rows, resident for the whole x loop
-    Frag pf[kTriRT][KCH];
+    Frag pf[RT][KCH];
 #pragma unroll
-    for (int rt = 0; rt < kTriRT; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         const Frag* rowp = reinterpret_cast<const Frag*>(p + (size_t)min(m0 + 16 * rt + r, M - 1) * Y + C::EPL * g);
 #pragma unroll
         for (int kc = 0; kc < KCH; ++kc) pf[rt][kc] = rowp[kc * FPK];
@@ -70,29 +72,29 @@ __global__ __launch_bounds__(64 * kTriWaves * kTriRG) void tri_kernel(const type
             for (int kc = 0; kc < KCH; ++kc) f[j][kc] = rowp[kc * FPK];
         }
     };
-    f32x4 acc[kTriRT][kTriHPW];
+    f32x4 acc[RT][kTriHPW];
 #pragma unroll
-    for (int rt = 0; rt < kTriRT; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int j = 0; j < kTriHPW; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // weight rows run through a register ring PF x-planes deep: one plane's MFMAs (0.2 us) do not cover an L2 round trip
-    constexpr int PF = F32IN ? 2 : 4;
+    // weight rows run through a register ring PF x-planes deep: one plane's MFMAs do not cover an L2 round trip
+    constexpr int PF = (F32IN || RT > 4) ? 2 : 4;
     Frag wring[PF][kTriHPW][KCH];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) load_w(min(u, X - 1), wring[u]);
+    for (int u = 0; u < PF; ++u) load_w(min(xb + u, xe - 1), wring[u]);
     __syncthreads();
-    for (int x0 = 0; x0 < X; x0 += PF) {
+    for (int x0 = xb; x0 < xe; x0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int x = min(x0 + u, X - 1);
-            const float live = x0 + u < X ? 1.f : 0.f;   // the tail of a partial ring pass contributes nothing
-            float4 cv[kTriRT];
+            const int x = min(x0 + u, xe - 1);
+            const float live = x0 + u < xe ? 1.f : 0.f;   // the tail of a partial ring pass contributes nothing
+            float4 cv[RT];
 #pragma unroll
-            for (int rt = 0; rt < kTriRT; ++rt) cv[rt] = *reinterpret_cast<const float4*>(cT + x * kTriRows + 16 * (kTriRT * rg + rt) + 4 * g);
+            for (int rt = 0; rt < RT; ++rt) cv[rt] = *reinterpret_cast<const float4*>(cT + (x - xb) * ROWS + 16 * rt + 4 * g);
 #pragma unroll
             for (int j = 0; j < kTriHPW; ++j)
 #pragma unroll
-                for (int rt = 0; rt < kTriRT; ++rt) {
+                for (int rt = 0; rt < RT; ++rt) {
                     f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int kc = 0; kc < KCH; ++kc) d = mma_chunk<F32IN>(pf[rt][kc], wring[u][j][kc], d);
@@ -102,20 +104,25 @@ __global__ __launch_bounds__(64 * kTriWaves * kTriRG) void tri_kernel(const type
                     acc[rt][j][3] = fmaf(cv[rt].w * live, d[3], acc[rt][j][3]);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            load_w(min(x0 + u + PF, X - 1), wring[u]);   // refill this slot: PF - 1 planes of MFMAs until it is needed
+            load_w(min(x0 + u + PF, xe - 1), wring[u]);   // refill this slot: PF - 1 planes of MFMAs until it is needed
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    const bool split = gridDim.y > 1;
 #pragma unroll
     for (int j = 0; j < kTriHPW; ++j) {
         const int ht = wave + kTriWaves * j;
         if (ht < n_ht)
 #pragma unroll
-            for (int rt = 0; rt < kTriRT; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const int m = m0 + 16 * rt + 4 * g + n;
-                    if (m < M) out[(size_t)m * H + 16 * ht + r] = acc[rt][j][n];
+                    if (m < M) {
+                        float* o = out + (size_t)m * H + 16 * ht + r;
+                        if (split) atomicAdd(o, acc[rt][j][n]);
+                        else *o = acc[rt][j][n];
+                    }
                 }
     }
 }
@@ -123,13 +130,21 @@ __global__ __launch_bounds__(64 * kTriWaves * kTriRG) void tri_kernel(const type
 template <bool F32IN, int KCH>
 static int launch_tri(const void* c, const void* w, const void* p, int M, int X, int H, float* out, hipStream_t s) {
     using T = typename MfmaCfg<F32IN>::T;
-    const size_t lds = sizeof(float) * kTriRows * X;
-    auto k = tri_kernel<F32IN, KCH>;
+    // bf16: 128 rows per block and the x range split in two (same block count, half the weight stream per MFMA);
+    // fp32: 64 rows, one range (its fragments are twice the registers, and the fp32 MFMA rate binds anyway)
+    constexpr int RT = F32IN ? 4 : 8;
+    const int xs = (!F32IN && X >= 32) ? 2 : 1;
+    const size_t lds = sizeof(float) * 16 * RT * ((X + xs - 1) / xs);
+    auto k = tri_kernel<F32IN, KCH, RT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(k, dim3((M + kTriRows - 1) / kTriRows), dim3(64 * kTriWaves * kTriRG), lds, s, (const T*)c, (const T*)w,
+    if (xs > 1) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)M * H, s);
+        if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k, dim3((M + 16 * RT - 1) / (16 * RT), xs), dim3(64 * kTriWaves), lds, s, (const T*)c, (const T*)w,
                        (const T*)p, M, X, H, out);
     return 0;
 }
