@@ -131,7 +131,7 @@ struct AlignArgs {
     uint16_t* argQ;            // [B,A,V] query index of max over Q
 };
 
-template <bool F32IN, int KCH, bool TILE, bool ARGS>
+template <bool F32IN, int KCH, bool TILE, bool ARGS, int RTBV = MfmaCfg<F32IN>::RTB>
 __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
     const typename MfmaCfg<F32IN>::T* __restrict__ txt, const typename MfmaCfg<F32IN>::T* __restrict__ vis,
     const uint8_t* __restrict__ tmask, const uint8_t* __restrict__ vmask, int B, int A, int Q, int V,
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
     static_assert(!ARGS || TILE, "arg-max tracking reads the LDS tile");
     using C = MfmaCfg<F32IN>;
     using Frag = typename C::Frag;
-    constexpr int RTB = C::RTB, QB = RTB * 16, VB = kCTB * 16, d = KCH * C::KW;
+    constexpr int RTB = RTBV, QB = RTB * 16, VB = kCTB * 16, d = KCH * C::KW;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
     float* tile = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (QB * kTileVP + 2 * QB);   // [QB][kTileVP]
@@ -400,16 +400,16 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
     }
 }
 
-template <bool F32IN, int KCH, bool TILE, bool ARGS = false>
+template <bool F32IN, int KCH, bool TILE, bool ARGS = false, int RTBV = MfmaCfg<F32IN>::RTB>
 static int launch_align_mfma(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A,
                              int Q, int V, float neg_inf, float* out_full, float* out_maxV, float* out_maxQ,
                              float* out_diag, hipStream_t s, AlignArgs xa = AlignArgs{nullptr, nullptr, 0, nullptr, nullptr}) {
     using C = MfmaCfg<F32IN>;
     const int a_per_wave = A >= 2048 ? 16 : A >= 64 ? 8 : 1;
     dim3 grid((A + 4 * a_per_wave - 1) / (4 * a_per_wave), B);
-    constexpr int QB = C::RTB * 16;
+    constexpr int QB = RTBV * 16;
     const size_t lds = TILE ? sizeof(float) * 4 * (size_t)(QB * kTileVP + 2 * QB) : 0;
-    auto k = align_mfma_kernel<F32IN, KCH, TILE, ARGS>;
+    auto k = align_mfma_kernel<F32IN, KCH, TILE, ARGS, RTBV>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
@@ -499,8 +499,12 @@ int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, c
     AlignArgs xa{pen, seg_of_v, n_seg, reinterpret_cast<uint16_t*>(wsf + p.off_argV), reinterpret_cast<uint16_t*>(wsf + p.off_argQ)};
     const bool f32in = in_dtype == VLG_F32;
     int rc = -1;
+    // 48 query rows per pass for both dtypes: the per-wave LDS tile limits occupancy, and a second block per CU hides this
+    // variant's long epilogue behind the other block's MFMAs (bf16, measured: 96 rows 535 us, 64 rows ~700, 48 rows 383,
+    // 32 rows ~450; the plain tile paths gain nothing from it: 0.27 vs 0.25 ms full tensor, 0.26 vs 0.27 ms fused maxima)
+#define VLG_GA_RTB 3
 #define VLG_GA(F32, KCHV)                                                                                          \
-    rc = launch_align_mfma<F32, KCHV, true, true>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr, wsf + p.off_maxV, \
+    rc = launch_align_mfma<F32, KCHV, true, true, VLG_GA_RTB>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr, wsf + p.off_maxV, \
                                                   wsf + p.off_maxQ, nullptr, s, xa)
     if (!f32in && d == 128) VLG_GA(false, 4);
     else if (!f32in && d == 64) VLG_GA(false, 2);
