@@ -89,3 +89,21 @@ def in_dtype(t):
     if t.dtype == torch.bfloat16:
         return BF16, t.contiguous()
     return F32, t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def alloc_f32(device, shapes, extra_bytes=0):
+    """One float32 allocation carved into 256-byte aligned views of the given shapes (None entries are skipped and
+    returned as None), plus a trailing scratch view of `extra_bytes`.  The ops here are small enough that a handful of
+    separate torch.empty calls costs as much host time as the kernels take."""
+    import math
+    offs, total = [], 0
+    for shp in shapes:
+        if shp is None:
+            offs.append(None)
+            continue
+        n = math.prod(shp)
+        offs.append((total, n))
+        total += (n + 63) & ~63
+    flat = torch.empty(total + (extra_bytes + 3) // 4, dtype=torch.float32, device=device)
+    views = [None if o is None else flat[o[0]:o[0] + o[1]].view(shp) for o, shp in zip(offs, shapes)]
+    return views, flat[total:]

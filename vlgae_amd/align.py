@@ -132,15 +132,16 @@ class _AttnFuse(torch.autograd.Function):
         B, V, d = vis_c.shape
         L, h = txt_c.shape[1] - 1, mid_c.shape[2]
         dev = vis_c.device
-        dout = dout.to(torch.float32).contiguous()
+        if dout.dtype != torch.float32 or not dout.is_contiguous():
+            dout = dout.to(torch.float32).contiguous()
         nbytes = _C.lib().vlg_attn_fuse_backward_workspace(B, L, V, h)
-        ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dev)
-        outs = [torch.empty(shape, dtype=torch.float32, device=dev)
-                for shape in ((B, V, d), (B, L + 1, d), (B, V, h), (B, L, h), (h,), (h,))]
+        # one allocation for the six gradients and the scratch (host overhead matters at these sizes)
+        outs, ws = _C.alloc_f32(dev, ((B, V, d), (B, L + 1, d), (B, V, h), (B, L, h), (h,), (h,)), nbytes)
         _C.check(_C.lib().vlg_attn_fuse_backward(_C.ptr(vis_c), _C.ptr(txt_c), _C.ptr(mid_c), _C.ptr(enc_c), _C.ptr(gamma),
                                                  _C.ptr(dout), B, L, V, d, h, dt, eps, _C.ptr(ws), nbytes,
                                                  *(_C.ptr(o) for o in outs), _C.stream_of(vis_c)), "attn_fuse_backward")
-        grads = [o.to(t) if ctx.needs_input_grad[i] else None for i, (o, t) in enumerate(zip(outs, dtypes))]
+        grads = [(o if o.dtype == t else o.to(t)) if ctx.needs_input_grad[i] else None
+                 for i, (o, t) in enumerate(zip(outs, dtypes))]
         return (*grads, None)
 
 
@@ -213,10 +214,7 @@ class _GroundingLoss(torch.autograd.Function):
             n_seg = pen.shape[2]
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         nbytes = _C.lib().vlg_grounding_loss_workspace(B, Q, V)
-        ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dev)
-        sums = torch.empty(3, dtype=torch.float32, device=dev)
-        g_txt = torch.empty((B, Q, d), dtype=torch.float32, device=dev) if need else None
-        g_vis = torch.empty((B, V, d), dtype=torch.float32, device=dev) if need else None
+        (sums, g_txt, g_vis), ws = _C.alloc_f32(dev, ((3,), (B, Q, d) if need else None, (B, V, d) if need else None), nbytes)
         _C.check(_C.lib().vlg_grounding_loss(_C.ptr(txt_c), _C.ptr(vis_c), _C.ptr(tm), _C.ptr(vm), _C.ptr(marg), _C.ptr(pen),
                                              _C.ptr(seg_of_v), n_seg, B, Q, V, d, dt, float(neg_inf), float(num_token),
                                              float(w_vis2txt), _C.ptr(ws), nbytes, _C.ptr(sums), _C.ptr(g_txt), _C.ptr(g_vis),
@@ -311,13 +309,13 @@ class _ArcTrilinear(torch.autograd.Function):
         M, X = child_c.shape
         H, Y = w_c.shape[1], w_c.shape[2]
         dev = child_c.device
-        g = g.reshape(M, H).to(torch.float32).contiguous()
+        g = g.reshape(M, H)
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.to(torch.float32).contiguous()
         need = ctx.needs_input_grad
-        d_child = torch.empty((M, X), dtype=torch.float32, device=dev) if need[0] else None
-        d_w = torch.empty((X, H, Y), dtype=torch.float32, device=dev) if need[1] else None
-        d_parent = torch.empty((M, Y), dtype=torch.float32, device=dev) if need[2] else None
         nbytes = _C.lib().vlg_trilinear_backward_workspace(M, X, H, Y, dt)
-        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+        (d_child, d_w, d_parent), ws = _C.alloc_f32(dev, ((M, X) if need[0] else None, (X, H, Y) if need[1] else None,
+                                                          (M, Y) if need[2] else None), nbytes)
         _C.check(_C.lib().vlg_trilinear_backward(_C.ptr(child_c), _C.ptr(w_c), _C.ptr(parent_c), _C.ptr(g), M, X, H, Y, dt,
                                                  _C.ptr(ws), nbytes, _C.ptr(d_child), _C.ptr(d_w), _C.ptr(d_parent),
                                                  _C.stream_of(child_c)), "trilinear_backward")
