@@ -160,7 +160,7 @@ void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int le
     c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
     c.C = (float2*)A.at(L.C.off); c.I = (float2*)A.at(L.I.off); c.S = (float*)A.at(L.S.off);
     c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);
-    c.gCc = (float2*)A.at(L.gCc.off); c.gCi = (float2*)A.at(L.gCi.off); c.gI = (float2*)A.at(L.gI.off);
+    c.gCc = (float*)A.at(L.gCc.off); c.gCi = (float2*)A.at(L.gCi.off); c.gI = (float2*)A.at(L.gI.off);
     c.decs = (float*)A.at(L.decs.off); c.gdecs = (float*)A.at(L.gdecs.off);
     vlg::MergedIO<In> io;
     io.dec = dec; io.attach = attach; io.N = N; io.gdec = gdec; io.gatt = gatt; io.heads = heads;
@@ -182,7 +182,7 @@ void emu_rules_one(const vlg::RuleIO<vlg::F32In>& io, int len, float glogZ, floa
     c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
     c.C = (float2*)A.at(L.C.off); c.I = (float2*)A.at(L.I.off); c.S = (float*)A.at(L.S.off);
     c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);
-    c.gCc = (float2*)A.at(L.gCc.off); c.gCi = (float2*)A.at(L.gCi.off); c.gI = (float2*)A.at(L.gI.off);
+    c.gCc = (float*)A.at(L.gCc.off); c.gCi = (float2*)A.at(L.gCi.off); c.gI = (float2*)A.at(L.gI.off);
     c.decs = (float*)A.at(L.decs.off); c.gdecs = (float*)A.at(L.gdecs.off);
     run_workgroup(nt, order, [&](int tid, HostX& x) { vlg::dmv_run<SR, BWD>(c, io, glogZ, logZ, tid, nt, x); });
     A.check();

@@ -207,7 +207,7 @@ __device__ __forceinline__ DmvCtx carve_dmv(int N, int len, char* smem, char* ws
     c.S = region_ptr<float>(L.S, smem, wsb);
     c.bpS = region_ptr<unsigned char>(L.bpS, smem, wsb);
     c.bpC = region_ptr<unsigned char>(L.bpC, smem, wsb);
-    c.gCc = region_ptr<float2>(L.gCc, smem, wsb);
+    c.gCc = region_ptr<float>(L.gCc, smem, wsb);
     c.gCi = region_ptr<float2>(L.gCi, smem, wsb);
     c.gI = region_ptr<float2>(L.gI, smem, wsb);
     c.decs = region_ptr<float>(L.decs, smem, wsb);

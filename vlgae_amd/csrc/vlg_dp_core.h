@@ -32,7 +32,8 @@
 // Outside: every cell is written once, so the charts are the tape; the adjoint of
 // out = lse_r t_r is t_r_bar += out_bar * exp(t_r - out) (Max semiring: the first arg-max only).
 // Adjoints of complete spans are accumulated in two arrays, gCc (contributions that come from
-// complete-span parents) and gCi (from incomplete-span parents): within a phase every
+// complete-span parents; those only ever reach the NOCHILD component, so gCc is a plain float
+// chart) and gCi (from incomplete-span parents): within a phase every
 // read-modify-write target is then owned by exactly one (span, r) pair -- no atomics, results are
 // bit-reproducible (ownership argument: DESIGN.md, "Outside pass").
 #pragma once
@@ -109,7 +110,7 @@ struct DmvCtx {
     float2* C;      // complete spans   [Ne][P]
     float2* I;      // incomplete spans [Ne][P]  (pre-loaded with attach + dec[...,GO])
     float* S;       // SL(i,j) at S[j*P+i], SR(i,j) at S[i*P+j]
-    float2* gCc;    // adjoint of C, part contributed by complete-span parents
+    float* gCc;     // adjoint of C.NOCHILD, part contributed by complete-span parents (HASCHILD gets none from them)
     float2* gCi;    // adjoint of C, part contributed by incomplete-span parents
     float2* gI;     // adjoint of I (== d logZ / d attach once complete)
     float* decs;    // staged dec        [Ne][8]
@@ -334,9 +335,10 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
     const int kL = j * P + i, kR = i * P + j + 1;          // CL(j,i) / IL(j,i) and CR(i,j) / IR(i,j) slots
     float2 gcl = make_float2(0.f, 0.f), gcr = make_float2(0.f, 0.f);
     {
-        const float2 a = c.gCc[kL], b = c.gCi[kL], a2 = c.gCc[kR], b2 = c.gCi[kR];
-        if (live) gcl = make_float2(a.x + b.x, a.y + b.y);
-        if (live && !(i == 0 && w != c.len)) gcr = make_float2(a2.x + b2.x, a2.y + b2.y);   // masked cell: dmv.py:63
+        const float a = c.gCc[kL], a2 = c.gCc[kR];
+        const float2 b = c.gCi[kL], b2 = c.gCi[kR];
+        if (live) gcl = make_float2(b.x, a + b.y);
+        if (live && !(i == 0 && w != c.len)) gcr = make_float2(b2.x, a2 + b2.y);   // masked cell: dmv.py:63
     }
     const float2 ocl = c.C[kL], ocr = c.C[kR];
     const float2 gil_old = c.gI[kL], gir_old = c.gI[kR];
@@ -365,8 +367,8 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
             xb[u] = c.C[j * P + i + rc + 1];          // CL(j, i+r+1)
             o_gil[u] = c.gI[kL + rc];
             o_gir[u] = c.gI[i * P + i + rc + 2];
-            o_ca[u] = c.gCc[(i + rc) * P + i].y;
-            o_cb[u] = c.gCc[(i + 1 + rc) * P + j + 1].y;
+            o_ca[u] = c.gCc[(i + rc) * P + i];
+            o_cb[u] = c.gCc[(i + 1 + rc) * P + j + 1];
             o_ga[u] = c.gCi[i * P + i + rc + 1];
             o_gb[u] = c.gCi[j * P + i + rc + 1];
         }
@@ -394,8 +396,8 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
                 const float wr = adj_w<SR>(gsr, xa[u].x + xb[u].y, SRv, r, bsr);   // SR term: CR.HC + CL.NC
                 if (r != 0) c.gI[kL + r] = make_float2(o_gil[u].x + w0[u], o_gil[u].y + w1[u]);
                 if (r != w - 1) c.gI[i * P + i + r + 2] = make_float2(o_gir[u].x + u0[u], o_gir[u].y + u1[u]);
-                c.gCc[(i + r) * P + i].y = o_ca[u] + (w0[u] + w1[u]);
-                c.gCc[(i + 1 + r) * P + j + 1].y = o_cb[u] + (u0[u] + u1[u]);
+                c.gCc[(i + r) * P + i] = o_ca[u] + (w0[u] + w1[u]);
+                c.gCc[(i + 1 + r) * P + j + 1] = o_cb[u] + (u0[u] + u1[u]);
                 c.gCi[i * P + i + r + 1] = make_float2(o_ga[u].x + wr, o_ga[u].y + wl);
                 c.gCi[j * P + i + r + 1] = make_float2(o_gb[u].x + wl, o_gb[u].y + wr);
             }
@@ -418,7 +420,7 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
             const float w1 = adj_w<SR>(gcl.y, a + v.y, ocl.y, r, bl1);
             if (r == 0) { self[0] = w0; self[1] = w1; }
             else if (live) { const float2 t = c.gI[kL + r]; c.gI[kL + r] = make_float2(t.x + w0, t.y + w1); }
-            if (live) c.gCc[(i + r) * P + i].y += w0 + w1;
+            if (live) c.gCc[(i + r) * P + i] += w0 + w1;
         }
         {   // CR(i,j).v = (+)_r IR(i,i+1+r).v + CR(i+1+r,j).NC
             const float2 v = c.I[i * P + i + r + 2];
@@ -427,7 +429,7 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr
             const float w1 = adj_w<SR>(gcr.y, v.y + a, ocr.y, r, br1);
             if (r == w - 1) { self[2] = w0; self[3] = w1; }
             else if (live) { const float2 t = c.gI[i * P + i + r + 2]; c.gI[i * P + i + r + 2] = make_float2(t.x + w0, t.y + w1); }
-            if (live) c.gCc[(i + 1 + r) * P + j + 1].y += w0 + w1;
+            if (live) c.gCc[(i + 1 + r) * P + j + 1] += w0 + w1;
         }
     }
     x.group_bcast4(self, G, 0, (w - 1) & (G - 1));
@@ -850,7 +852,7 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
         c.I[i] = zz;
         if (BWD) {
             c.gI[i] = oo;
-            if (!c.walk) { c.gCc[i] = oo; c.gCi[i] = oo; }
+            if (!c.walk) { c.gCc[i] = 0.f; c.gCi[i] = oo; }
         }
     }
     for (int i = tid; i < Ne * 8; i += nt) {
@@ -900,7 +902,7 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
         if (tid == 0) dmv_walk(c, glogZ);
         x.sync();
     } else {
-    if (tid == 0) c.gCc[len + 1].y = glogZ;
+    if (tid == 0) c.gCc[len + 1] = glogZ;
     x.sync();
 #if defined(VLG_STAMP) && defined(__HIPCC__)
     for (int w = Ne - 1; w >= 1; --w) {
@@ -944,7 +946,7 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
                 if ((k & 1) == 0) g = c.gdecs[h * 8 + k];                                   // GO
                 else {                                                                      // STOP = width-0 span
                     const int q = h * P + h + dir;
-                    g = reinterpret_cast<const float*>(c.gCc + q)[v] + reinterpret_cast<const float*>(c.gCi + q)[v];
+                    g = (v == 1 ? c.gCc[q] : 0.f) + reinterpret_cast<const float*>(c.gCi + q)[v];
                 }
             }
             io.st_dec(h, k, g);
@@ -1108,7 +1110,7 @@ struct DmvLayout {
             S = k.take(bwd ? cells * 4 : 0, v);
             bpS = k.take(bwd && is_max ? cells : 0, v);
             bpC = k.take(bwd && is_max ? cells * 2 : 0, v);
-            gCc = k.take(bwd ? cells * 8 : 0, a1);
+            gCc = k.take(bwd ? cells * 4 : 0, a1);
             gCi = k.take(bwd ? cells * 8 : 0, a1);
             gI = k.take(bwd ? cells * 8 : 0, a2);
             decs = k.take((size_t)N * 32, true);
