@@ -441,7 +441,12 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
     // ---- matrix-core path: d a whole number of MFMA K-chunks (the model's d = 128; also 64) ----
     const bool f32in = in_dtype == VLG_F32;
     const bool tile = out_full || out_diag || out_maxV;   // max over Q alone needs no LDS round trip
+    // the full tensor is bound by its writes and keeps 96-row passes (bf16); the maxima-only tile path gains a little from
+    // 48-row passes (two blocks per CU: 0.274 -> 0.257 ms)
 #define VLG_MFMA(F32, KCHV)                                                                                         \
+    if (tile && !out_full)                                                                                          \
+        return launch_align_mfma<F32, KCHV, true, false, 3>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, out_maxV, \
+                                                            out_maxQ, out_diag, s);                                  \
     return tile ? launch_align_mfma<F32, KCHV, true>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, out_maxV, \
                                                      out_maxQ, out_diag, s)                                           \
                 : launch_align_mfma<F32, KCHV, false>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, out_maxV, \
