@@ -517,14 +517,30 @@ __global__ __launch_bounds__(64) void attn_fuse_bwd_words_kernel(
                 vlane[t][n] = min(v, V - 1) * d + r;
             }
         // GEMM 4: d_txt^T[feature][word] += sum_v vis[v][feature] * dS[word][v]; B operand = dS as it sits
+        // operand ring kAttnPF feature tiles ahead, as in the forward's second contraction
+        float vv[kAttnPF + 1][T][4];
+#pragma unroll
+        for (int pfi = 0; pfi < kAttnPF; ++pfi)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) vv[pfi][t][n] = buf_ld(In{}, vis_rs, vlane[t][n], 16 * min(pfi, FT - 1));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ft = 0; ft < FTM; ++ft) {
-            const int f0 = 16 * min(ft, FT - 1);
+            if (ft + kAttnPF < FTM) {   // compile-time
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        vv[(ft + kAttnPF) % (kAttnPF + 1)][t][n] = buf_ld(In{}, vis_rs, vlane[t][n], 16 * min(ft + kAttnPF, FT - 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    dT[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf_ld(In{}, vis_rs, vlane[t][n], f0), S[t][n], dT[ft], 0, 0, 0);
+                    dT[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[ft % (kAttnPF + 1)][t][n], S[t][n], dT[ft], 0, 0, 0);
         }
     }
     if (live) {
@@ -569,20 +585,25 @@ __global__ __launch_bounds__(64) void attn_fuse_bwd_regions_kernel(
             wl_h[e] = w * h + r;
             wl_d[e] = w * d + r;
         }
+        // every A value of this word chunk is requested before the first MFMA (one round trip per chunk, not per tile)
+        float dyv[kAttnMaxCT][4], tv[FTM][4];
 #pragma unroll
-        for (int ct = 0; ct < kAttnMaxCT; ++ct) {
-            const int c0 = 16 * min(ct, CT - 1);
+        for (int ct = 0; ct < kAttnMaxCT; ++ct)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                dM[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf_ld(F32In{}, dy_rs, wl_h[e], c0), pv[e], dM[ct], 0, 0, 0);
-        }
+            for (int e = 0; e < 4; ++e) dyv[ct][e] = buf_ld(F32In{}, dy_rs, wl_h[e], 16 * min(ct, CT - 1));
 #pragma unroll
-        for (int ft = 0; ft < FTM; ++ft) {
-            const int f0 = 16 * min(ft, FT - 1);
+        for (int ft = 0; ft < FTM; ++ft)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                dV[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf_ld(In{}, t_rs, wl_d[e], f0), sv[e], dV[ft], 0, 0, 0);
-        }
+            for (int e = 0; e < 4; ++e) tv[ft][e] = buf_ld(In{}, t_rs, wl_d[e], 16 * min(ft, FT - 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < kAttnMaxCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dM[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dyv[ct][e], pv[e], dM[ct], 0, 0, 0);
+#pragma unroll
+        for (int ft = 0; ft < FTM; ++ft)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dV[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[ft][e], sv[e], dV[ft], 0, 0, 0);
     }
     if (v < V) {   // accumulator layout: lane (r,g), register n <-> region v (col r), channel / feature 16ct + 4g + n
         float* mrow = d_mid + ((size_t)b * V + v) * h + 4 * g;
