@@ -44,14 +44,18 @@ def build_library(force=False, verbose=False):
     if not (force or _stale()):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
-    for src in SOURCES:
+
+    def compile_one(src):
         obj = os.path.join(LIB_DIR, src + ".o")
         cmd = [_hipcc(), f"--offload-arch={ARCH}", *FLAGS, *EXTRA_FLAGS.get(src, ()), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as pool:   # independent translation units
+        objs = list(pool.map(compile_one, SOURCES))
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
