@@ -490,13 +490,27 @@ __global__ __launch_bounds__(64) void attn_fuse_bwd_words_kernel(
                 S[t][n] = v0 + 16 * t + 4 * g + n < V ? __expf(S[t][n] - m_run) * zinv : 0.f;   // P
             dP[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // GEMM 3: dP^T[region][word] = sum_c mid[region][c] * dy[word][c]; A fragment = 16 contiguous bytes of a mid row
+        // GEMM 3: dP^T[region][word] = sum_c mid[region][c] * dy[word][c]; A fragment = 16 contiguous bytes of a mid row.
+        // All region tiles advance together over the channel tiles, their fragments kAttnPF tiles ahead in a register ring.
+        const typename In::T* mrow[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const typename In::T* mrow = mid_p + (size_t)min(v0 + 16 * t + r, V - 1) * h + 4 * g;
+        for (int t = 0; t < T; ++t) mrow[t] = mid_p + (size_t)min(v0 + 16 * t + r, V - 1) * h + 4 * g;
+        float4 mf[kAttnPF + 1][T];
 #pragma unroll
-            for (int ct = 0; ct < kAttnMaxCT; ++ct) {
-                const float4 a = ld4(mrow + 16 * min(ct, CT - 1));   // dy of tiles past CT is zero
+        for (int pfi = 0; pfi < kAttnPF; ++pfi)
+#pragma unroll
+            for (int t = 0; t < T; ++t) mf[pfi][t] = ld4(mrow[t] + 16 * min(pfi, CT - 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < kAttnMaxCT; ++ct) {
+            if (ct + kAttnPF < kAttnMaxCT) {   // compile-time
+#pragma unroll
+                for (int t = 0; t < T; ++t) mf[(ct + kAttnPF) % (kAttnPF + 1)][t] = ld4(mrow[t] + 16 * min(ct + kAttnPF, CT - 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {   // dy of tiles past CT is zero
+                const float4 a = mf[ct % (kAttnPF + 1)][t];
                 dP[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, DY[ct][0], dP[t], 0, 0, 0);
                 dP[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, DY[ct][1], dP[t], 0, 0, 0);
                 dP[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, DY[ct][2], dP[t], 0, 0, 0);
