@@ -278,32 +278,36 @@ __global__ __launch_bounds__(64 * kDwSplit) void tri_dw_kernel(const typename Mf
     for (int j = 0; j < kDwHT; ++j)
 #pragma unroll
         for (int t = 0; t < kDwYT; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int k_first = min(wave, n_chunk - 1) * FPK;
-    Frag cf = crow[k_first], gf[kDwHT], pf[kDwYT];
+    // operands of the wave's chunks run through a register ring PFD chunks deep: one chunk's MFMAs (0.2 us bf16) cover a
+    // fraction of an L2 round trip, and with one wave per SIMD nothing else hides it (depth 1 measured 120 us bf16)
+    constexpr int PFD = F32IN ? 2 : 1;   // bf16: deeper rings spill next to the 128 accumulators and measured slower (128 vs 120 us)
+    Frag cf[PFD], gf[PFD][kDwHT], pf[PFD][kDwYT];
+    auto fetch = [&](int k, int slot) {   // chunk index k (clamped: the tail re-reads the last chunk, masked below)
+        const int kk = min(k, n_chunk - 1) * FPK;
+        cf[slot] = crow[kk];
 #pragma unroll
-    for (int j = 0; j < kDwHT; ++j) gf[j] = grow[j][k_first];
+        for (int j = 0; j < kDwHT; ++j) gf[slot][j] = grow[j][kk];
 #pragma unroll
-    for (int t = 0; t < kDwYT; ++t) pf[t] = prow[t][k_first];
-    for (int k = wave; k < n_chunk; k += kDwSplit) {
-        const int kn = min(k + kDwSplit, n_chunk - 1) * FPK;
-        const Frag cn = crow[kn];   // next chunk's operands are in flight under this chunk's MFMAs
-        Frag gn[kDwHT], pn[kDwYT];
+        for (int t = 0; t < kDwYT; ++t) pf[slot][t] = prow[t][kk];
+    };
 #pragma unroll
-        for (int j = 0; j < kDwHT; ++j) gn[j] = grow[j][kn];
+    for (int u = 0; u < PFD; ++u) fetch(wave + kDwSplit * u, u);
+    for (int k0 = wave; k0 < n_chunk; k0 += kDwSplit * PFD) {
 #pragma unroll
-        for (int t = 0; t < kDwYT; ++t) pn[t] = prow[t][kn];
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < PFD; ++u) {
+            const int k = k0 + kDwSplit * u;
+            if (k < n_chunk) {   // uniform
 #pragma unroll
-        for (int j = 0; j < kDwHT; ++j) {
-            const Frag a = frag_mul<F32IN>(gf[j], cf);
+                for (int j = 0; j < kDwHT; ++j) {
+                    const Frag a = frag_mul<F32IN>(gf[u][j], cf[u]);
 #pragma unroll
-            for (int t = 0; t < kDwYT; ++t) acc[j][t] = mma_chunk<F32IN>(a, pf[t], acc[j][t]);
+                    for (int t = 0; t < kDwYT; ++t) acc[j][t] = mma_chunk<F32IN>(a, pf[u][t], acc[j][t]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(k + kDwSplit * PFD, u);   // refill this slot: PFD - 1 chunks of MFMAs until it is needed
+            __builtin_amdgcn_sched_barrier(0);
         }
-        cf = cn;
-#pragma unroll
-        for (int j = 0; j < kDwHT; ++j) gf[j] = gn[j];
-#pragma unroll
-        for (int t = 0; t < kDwYT; ++t) pf[t] = pn[t];
     }
     if (wave > 0) {
 #pragma unroll
