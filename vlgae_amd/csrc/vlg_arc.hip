@@ -127,13 +127,17 @@ __global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename Mfma
     }
 }
 
+#ifndef VLG_TRI_RT32
+#define VLG_TRI_RT32 3
+#endif
 template <bool F32IN, int KCH>
 static int launch_tri(const void* c, const void* w, const void* p, int M, int X, int H, float* out, hipStream_t s) {
     using T = typename MfmaCfg<F32IN>::T;
     // bf16: 128 rows per block and the x range split in two (same block count, half the weight stream per MFMA);
-    // fp32: 64 rows, one range (its fragments are twice the registers, and the fp32 MFMA rate binds anyway)
-    constexpr int RT = F32IN ? 4 : 8;
-    const int xs = (!F32IN && X >= 32) ? 2 : 1;
+    // fp32: 48 rows and the same split -- 438 blocks instead of 164 for 256 CUs (512 -> 422 us); the fp32 MFMA rate
+    // binds from there
+    constexpr int RT = F32IN ? VLG_TRI_RT32 : 8;
+    const int xs = X >= 32 ? 2 : 1;
     const size_t lds = sizeof(float) * 16 * RT * ((X + xs - 1) / xs);
     auto k = tri_kernel<F32IN, KCH, RT>;
     if (lds > 48 * 1024) {
