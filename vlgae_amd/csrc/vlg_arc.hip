@@ -127,17 +127,9 @@ __global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename Mfma
     }
 }
 
-#ifndef VLG_TRI_RT32
-#define VLG_TRI_RT32 3
-#endif
-template <bool F32IN, int KCH>
-static int launch_tri(const void* c, const void* w, const void* p, int M, int X, int H, float* out, hipStream_t s) {
+template <bool F32IN, int KCH, int RT>
+static int launch_tri_rt(const void* c, const void* w, const void* p, int M, int X, int H, int xs, float* out, hipStream_t s) {
     using T = typename MfmaCfg<F32IN>::T;
-    // bf16: 128 rows per block and the x range split in two (same block count, half the weight stream per MFMA);
-    // fp32: 48 rows and the same split -- 438 blocks instead of 164 for 256 CUs (512 -> 422 us); the fp32 MFMA rate
-    // binds from there
-    constexpr int RT = F32IN ? VLG_TRI_RT32 : 8;
-    const int xs = X >= 32 ? 2 : 1;
     const size_t lds = sizeof(float) * 16 * RT * ((X + xs - 1) / xs);
     auto k = tri_kernel<F32IN, KCH, RT>;
     if (lds > 48 * 1024) {
@@ -151,6 +143,45 @@ static int launch_tri(const void* c, const void* w, const void* p, int M, int X,
     hipLaunchKernelGGL(k, dim3((M + 16 * RT - 1) / (16 * RT), xs), dim3(64 * kTriWaves), lds, s, (const T*)c, (const T*)w,
                        (const T*)p, M, X, H, out);
     return 0;
+}
+
+static int device_cus() {
+    static int n = 0;   // one device per process (the launch contract); 256 on MI355X
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+// Rows per block.  The timings below behave as if a CU ran one four-wave block at a time: the launch takes
+// ceil(blocks / CUs) rounds of (weight stream of the x range, constant) + (MFMA work, ~ rows).  Fitted on M = 10 496:
+// bf16 is stream-heavy (76 us + 2.2 us per 16 rows: 96 rows x 2 ranges = 220 blocks in one round, 90 us, against
+// 94 us for 128 rows and 156 us for 80 rows = 264 blocks = two rounds); fp32 is MFMA-heavy (75 + 51 us per 16 rows:
+// 48 rows x 2 = 438 blocks, 422 us, against 164 blocks of 64 rows on 256 CUs, 512 us).
+template <bool F32IN, int KCH>
+static int launch_tri(const void* c, const void* w, const void* p, int M, int X, int H, float* out, hipStream_t s) {
+    const int xs = X >= 32 ? 2 : 1;
+    const int cus = device_cus();
+    const float stream = F32IN ? 1.5f : 34.f;   // the constant term in units of one 16-row MFMA pass
+    const int cand[3] = {F32IN ? 3 : 4, F32IN ? 4 : 6, F32IN ? 4 : 8};
+    int best = cand[2];
+    float best_cost = 0.f;
+    for (int i = 0; i < 3; ++i) {
+        const long blocks = (long)((M + 16 * cand[i] - 1) / (16 * cand[i])) * xs;
+        const float cost = (float)((blocks + cus - 1) / cus) * ((float)cand[i] + stream);
+        if (i == 0 || cost < best_cost) { best = cand[i]; best_cost = cost; }
+    }
+    if constexpr (F32IN) {
+        if (best == 3) return launch_tri_rt<true, KCH, 3>(c, w, p, M, X, H, xs, out, s);
+        return launch_tri_rt<true, KCH, 4>(c, w, p, M, X, H, xs, out, s);
+    } else {
+        if (best == 4) return launch_tri_rt<false, KCH, 4>(c, w, p, M, X, H, xs, out, s);
+        if (best == 6) return launch_tri_rt<false, KCH, 6>(c, w, p, M, X, H, xs, out, s);
+        return launch_tri_rt<false, KCH, 8>(c, w, p, M, X, H, xs, out, s);
+    }
 }
 
 // Y (the contracted, memory-contiguous dimension) decides the instantiation.
