@@ -234,6 +234,25 @@ def test_dmv1o_edge_cases(ts):
     assert torch.equal(lz2, lz3)
 
 
+def test_dmv1o_create_graph_is_tolerated(ts):
+    """callers may pass create_graph=True (helpers.py:139-152 does); the first derivative is the same and a
+    second derivative fails loudly instead of silently dropping the dependence on the potentials."""
+    g = torch.Generator().manual_seed(7)
+    d = torch.randn(4, 9, 2, 2, 2, generator=g).to(dev()).requires_grad_()
+    a = torch.randn(4, 9, 9, 2, generator=g).to(dev()).requires_grad_()
+    lengths = torch.tensor([8, 5, 3, 1], device=dev())
+    with torch.no_grad():                                   # eval loop of ldndmv.py:289 around enable_grad
+        with torch.enable_grad():
+            (m0,) = torch.autograd.grad(ts.DMV1o([d, a], lengths).partition.sum(), a)
+            (m1,) = torch.autograd.grad(ts.DMV1o([d, a], lengths).partition.sum(), a, create_graph=True)
+    assert torch.equal(m0, m1.detach())
+    with pytest.raises(RuntimeError):
+        m1.sum().backward()
+    crf = ts.DependencyCRF(a[..., 0], lengths)
+    (c1,) = torch.autograd.grad(crf.partition.sum(), a, create_graph=True)
+    assert torch.isfinite(c1).all()
+
+
 @pytest.mark.parametrize("path", golden_files("rules_"), ids=golden_ids("rules_"))
 def test_dmv1o_rules_golden(ts, path):
     """the DP fed from the scorer's rule tables == the reference's gather / mask / merge ops + DMV1o."""

@@ -9,6 +9,7 @@ registry unchanged:  JointModelBase.add_impl_to_group("gather_logit", "mi355x")(
 (base.py:118-142; selected by `gather_logit_mode` in config/model/vlgae.yaml:57).
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _C
 
@@ -64,6 +65,7 @@ class _GatherLogit(torch.autograd.Function):
         return bilinear_align(txt_feat, vis_feat, txt_mask, vis_mask, neg_inf)["full"]
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         txt_feat, vis_feat, txt_mask, vis_mask = ctx.saved_tensors
         g = g.to(torch.float32)
@@ -126,6 +128,7 @@ class _AttnFuse(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         vis_c, txt_c, mid_c, enc_c, gamma = ctx.saved_tensors
         dt, eps, *dtypes = ctx.meta
@@ -225,6 +228,7 @@ class _GroundingLoss(torch.autograd.Function):
         return sums[2].clone(), sums
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_total, _g_sums):
         g_txt, g_vis = ctx.saved_tensors
         out = [None] * 10
@@ -303,6 +307,7 @@ class _ArcTrilinear(torch.autograd.Function):
         return out.reshape(*lead, H)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         child_c, w_c, parent_c = ctx.saved_tensors
         dt, lead, t_child, t_w, t_parent = ctx.meta

@@ -6,6 +6,7 @@ pass: when any potential requires grad, forward() runs the fused inside+outside 
 unit-upstream expected counts; backward() only scales them by the incoming gradient of logZ.
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from .. import _C
 from .semirings import NEGINF
@@ -177,6 +178,7 @@ class _DMV1oRulesSum(torch.autograd.Function):
         return r["logZ"].unsqueeze(-1)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         g_rule, g_dec, g_root = ctx.saved_tensors
         d0, d1, d2, root_shape = ctx.meta
@@ -209,6 +211,7 @@ class _DMV1oSum(torch.autograd.Function):
         return logZ.to(dec.dtype if dec.dtype == torch.float64 else torch.float32).unsqueeze(-1)   # [B,1], helpers.py:116
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         gdec, gatt = ctx.saved_tensors
         g = grad_out.reshape(-1).to(torch.float32)
@@ -228,6 +231,7 @@ class _DepTreeSum(torch.autograd.Function):
         return logZ.to(arc.dtype if arc.dtype == torch.float64 else torch.float32)                  # [B], deptree.py:75
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         (garc,) = ctx.saved_tensors
         return (garc * grad_out.reshape(-1, 1, 1).to(torch.float32)).to(ctx.in_dtype), None, None
@@ -268,6 +272,7 @@ class _Merge(torch.autograd.Function):
         return dmv1o_merge(dec, attach, root, one, zero)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_dec_w, g_att_w):
         d0, d1, d2 = ctx.in_dtypes
         return (g_dec_w[:, 1:].to(d0), g_att_w[:, 1:, 1:, :].to(d1), g_att_w[:, 0, 1:, 1].to(d2), None, None)
