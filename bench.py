@@ -323,6 +323,10 @@ def main():
         out["grounding_loss"] = {"fwd_bwd_ms": timed(ground, 10),
                                  "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in; loss + gradients, no [B,A,Q,V] tensor"}
 
+        out["grounding_decode"] = {
+            "ms": timed(lambda: align.grounding_decode(g_txt.detach(), g_vis.detach(), tmask, vmask), 20),
+            "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in; alignment (diag + max_v) + top-5 / image arg-max, joint.py:512-596"}
+
         # arc encoder's trilinear term (joint.py:282-284): M = B * (L + 1) rows, 128^3 weights
         a_child, a_parent = mk(B, N, d), mk(B, N, d)
         a_w1 = (torch.randn(d, d, d, generator=g) / d).to(dev, in_dtype).requires_grad_(True)

@@ -146,6 +146,20 @@ int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, c
                        float neg_inf, float num_token, float w_vis2txt, void* ws, size_t ws_bytes, float* out_sums,
                        float* g_txt, float* g_vis, void* stream);
 
+/* The tensor half of decode_grounding_on_factor, src/model/joint.py:512-596, on the fused
+ * outputs of vlg_bilinear_align (out_diag -> logit, out_maxV -> maxV):
+ *   logit [B,Q,V] fp32 is edited IN PLACE like the reference's diagonal copy: minus pen[b,q,seg_of_v[v]] (POS prior,
+ *   :528-552; pen / seg_of_v NULL = off), then with use_heuristic (:554-594): a query row whose best column is one of
+ *   the n_box box columns [0, n_box) (and is > -1e5) selects that box for its sentence; relation columns
+ *   rel_offset + i * n_box + j lose 100 unless both boxes are selected (rows >= n_word_rows do not vote) and are set
+ *   to -1e10 on i == j; attribute columns attr_offset + i are set to -1e10 unless box i is selected (offsets -1 = no
+ *   such block).  top5 [B,Q,5] int32 = the five best columns of every row in descending order (:596; equal values by
+ *   ascending column, -1 past V); factor2img [B,Q] int32 = first arg-max over a of maxV [B,A,Q] (:520; both or
+ *   neither NULL). */
+int vlg_grounding_decode(float* logit, const float* pen, const uint8_t* seg_of_v, int n_seg, int B, int Q, int V,
+                         int use_heuristic, int n_box, int rel_offset, int attr_offset, int n_word_rows, const float* maxV,
+                         int A, int32_t* factor2img, int32_t* top5, void* stream);
+
 /* The arc encoder's trilinear term -- lang_feat word+maxdep, src/model/joint.py:281-284:
  *   out[m,h] = sum_{x,y} child[m,x] * w[x,h,y] * parent[m,y]        (m = flattened batch x position)
  *   child [M,X], parent [M,Y], w [X,H,Y] in in_dtype; out [M,H] fp32.  Y in {32, 64, 128}; H a multiple of 16, <= 128;

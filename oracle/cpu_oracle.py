@@ -301,6 +301,82 @@ def grounding_loss(txt, vis, tmask, vmask, marginal, num_token, w_vis2txt=1.0, p
 # ----------------------------------------------------------------------------------------------
 # Brute-force enumerators (pure Python, tiny N only): an algorithm-independent known answer.
 # ----------------------------------------------------------------------------------------------
+def grounding_decode(diag, max_v, tag, factor_names, vis_split, pos_for, use_pos_prior=True, use_heuristic=True):
+    """Tensor half of decode_grounding_on_factor (joint.py:516-596) in float32, the reference's dtype.
+    diag [B,Q,V] = batch diagonal of the alignment tensor (:522-525), max_v [B,A,Q] = its max over V; tag [B,L].
+    Returns dict(logit = the edited diagonal block, top5 [B,Q,min(5,V)] (descending; equal values by ascending column),
+    factor2img [B,Q])."""
+    x = np.array(diag, dtype=np.float32, copy=True)
+    tag = np.asarray(tag)
+    B, Q, V = x.shape
+    L = tag.shape[1]
+    names = [str(n) for n in factor_names]
+    widths = [int(w) for w in vis_split]
+    factor2img = np.argmax(np.asarray(max_v), axis=1)                    # :520 (first maximum)
+    if use_pos_prior:                                                     # :528-552
+        offset = 0
+        for name, width in zip(names, widths):
+            if name in ("obj", "rel", "attr"):
+                hit = np.isin(tag, np.asarray(pos_for[name])).astype(np.float32)[..., None]   # [B,L,1]
+                x[:, 1:L + 1, :offset] -= np.float32(1e10) * hit
+                x[:, 1:L + 1, offset + width:] -= np.float32(1e10) * hit
+            offset += width
+    if use_heuristic:                                                     # :554-594
+        n_box = widths[0]
+        starts = np.concatenate([[0], np.cumsum(widths)])
+        aligned = x.max(-1)                                               # [B,Q]
+        box_val, box_ind = x[..., :n_box].max(-1), x[..., :n_box].argmax(-1)
+        allowed = (box_val == aligned) & (box_val > np.float32(-1e5))
+        if "rel" in names:
+            o = int(starts[names.index("rel")])
+            a = allowed.copy()
+            a[:, L + 1:] = False                                          # :571
+            for b in range(B):
+                sel = np.zeros(n_box, dtype=bool)
+                sel[box_ind[b][a[b]]] = True
+                pair = (sel[:, None] & sel[None, :]).reshape(-1)
+                x[b, :, o:o + n_box * n_box][:, ~pair] -= np.float32(100)                      # :580
+                x[b, :, o + np.arange(n_box) * (n_box + 1)] = np.float32(-1e10)               # :582
+        if "attr" in names:
+            o = int(starts[names.index("attr")])
+            for b in range(B):
+                sel = np.zeros(n_box, dtype=bool)
+                sel[box_ind[b][allowed[b]]] = True
+                x[b, :, o:o + n_box][:, ~sel] = np.float32(-1e10)                              # :594
+    order = np.argsort(-x.astype(np.float64), axis=-1, kind="stable")[..., :5]                # :596
+    return dict(logit=x, top5=order, factor2img=factor2img)
+
+
+def grounding_decode_lists(top5, factor2img, tmask, factor_names, vis_split, vis_box_index=None):
+    """The list half of decode_grounding_on_factor (joint.py:598-629): columns -> (factor name, box id | (box, box)),
+    rows filtered by the query mask (filter_list, src/utility/fn.py:143-151)."""
+    import bisect
+    names = [str(n) for n in factor_names]
+    widths = [int(w) for w in vis_split]
+    starts = [0] + list(np.cumsum(widths))
+    out_f, out_i = [], []
+    for b in range(len(top5)):
+        box_index = list(range(200)) if vis_box_index is None else [int(i) for i in vis_box_index[b]]
+        rows_f, rows_i = [], []
+        for q in range(len(top5[b])):
+            if not tmask[b][q]:
+                continue
+            cands = []
+            for idx in top5[b][q]:
+                idx = int(idx)
+                grp = bisect.bisect_left(starts, idx)
+                if starts[grp] != idx:
+                    grp -= 1
+                idx -= starts[grp]
+                name = names[grp]
+                cands.append([name, [box_index[idx // widths[0]], box_index[idx % widths[0]]] if name == "rel" else box_index[idx]])
+            rows_f.append(cands)
+            rows_i.append(int(factor2img[b][q]))
+        out_f.append(rows_f)
+        out_i.append(rows_i)
+    return out_f, out_i
+
+
 def _projective_single_root_trees(n_words):
     """All head vectors (heads[c] for c = 1..n_words, 0 = root) that are projective, spanning and
     single-rooted -- the support of both DPs (deptree.py:325-378 states the same predicates)."""

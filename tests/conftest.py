@@ -45,6 +45,33 @@ def arcenc_check_w1_grad(got, g, tol):
     assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), "g_w1"
 
 
+def gdecode_check_lists(got_factor, got_img, g, logit_after):
+    """Compare the two result lists of decode_grounding_on_factor with the fixture's (joint.py:598-629).  Candidate k of a
+    row is compared only where its value is not tied with a neighbour in the sorted row: torch.argsort leaves the order
+    of equal values open, and the edited rows hold many equal fills (-1e10, -1e20)."""
+    import json
+    want_factor = json.loads(str(g["txt_to_factor"]))
+    want_img = json.loads(str(g["txt_to_img"]))
+    assert [[int(t) for t in row] for row in got_img] == want_img
+    tmask = g["tmask"]
+    assert len(got_factor) == len(want_factor)
+    n_cmp = 0
+    for b in range(len(want_factor)):
+        rows = [q for q in range(tmask.shape[1]) if tmask[b, q]]
+        assert len(got_factor[b]) == len(want_factor[b]) == len(rows)
+        for r, q in enumerate(rows):
+            v = np.sort(logit_after[b, q])[::-1]
+            assert len(got_factor[b][r]) == len(want_factor[b][r]) == min(5, len(v))
+            for k in range(min(5, len(v))):
+                tied = (k + 1 < len(v) and v[k] == v[k + 1]) or (k > 0 and v[k] == v[k - 1])
+                if tied:
+                    continue
+                got = json.loads(json.dumps(got_factor[b][r][k]))     # tuples -> lists, like the fixture
+                assert got == want_factor[b][r][k], (b, q, k)
+                n_cmp += 1
+    assert n_cmp > 0
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     import oracle

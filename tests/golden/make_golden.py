@@ -280,6 +280,67 @@ def grounding_cases():
         print(f"{name}: total {float(total):.4f} txt2vis_raw {float(t2v):.4f} vis2txt_raw {float(v2t):.4f}")
 
 
+def decode_cases():
+    """The reference's own gather_logit_simple -> decode_grounding_on_factor (joint.py:406-419, 512-629) through a stub
+    `self` / `vp` carrying only what the method reads.  Saved: the inputs, the diagonal block before and after the method's
+    in-place edits (the method edits a view of match_logit's diagonal, so it is read back from there), max over V, the
+    top-5 VALUES per row (indices of equal values are not defined by torch.argsort) and the method's two result lists."""
+    import json
+    from types import SimpleNamespace as NS
+    src, joint = _ref_import.import_joint()
+    gather = joint.DependencyBoxRel.gather_logit_simple
+    decode = joint.DependencyBoxRel.decode_grounding_on_factor
+
+    class VP(dict):            # `"vis_box_index" in vp` and attribute access, like the reference's variable pool
+        __getattr__ = dict.__getitem__
+
+    for name, seed, B, L, split, d, prior, heur, n_tag, with_index in (
+        ("gdecode_B4_L6_obj5_s0", 0, 4, 6, (("obj", 5),), 32, True, True, 6, False),
+        ("gdecode_B5_L7_obj4_rel16_attr4_img1_s1", 1, 5, 7, (("obj", 4), ("rel", 16), ("attr", 4), ("img", 1)), 32, True, True, 7, True),
+        ("gdecode_B3_L5_obj6_rel36_s2_noprior", 2, 3, 5, (("obj", 6), ("rel", 36)), 32, False, True, 6, False),
+        ("gdecode_B3_L9_obj8_attr8_s3_noheur", 3, 3, 9, (("obj", 8), ("attr", 8)), 64, True, False, 6, True),
+    ):
+        g = torch.Generator().manual_seed(seed)
+        names, widths = [n for n, _ in split], [w for _, w in split]
+        V, Q = sum(widths), 2 * (L + 1)
+        lengths = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+        lengths[0] = L
+        wmask = torch.arange(L)[None] < lengths[:, None]
+        m1 = torch.cat([torch.zeros(B, 1, dtype=torch.bool), wmask], 1)
+        tmask = torch.cat([m1, m1], 1)
+        vmask = torch.rand(B, V, generator=g) > 0.1
+        vmask[:, 0] = True
+        txt = torch.randn(B, Q, d, generator=g) * 0.5
+        vis = torch.randn(B, V, d, generator=g) * 0.5
+        tag = torch.randint(0, n_tag, (B, L), generator=g)
+        pos = dict(obj=torch.tensor([0, 1, 2]), rel=torch.tensor([2, 3]), attr=torch.tensor([4]))
+        box_index = [torch.randperm(200, generator=g)[:widths[0]].tolist() for _ in range(B)] if with_index else None
+        me = NS(cfg=NS(decode_grounding_args=NS(use_pos_prior=prior, use_heuristic=heur)), vis_factor_names=names,
+                pos_for_obj=pos["obj"], pos_for_rel=pos["rel"], pos_for_attr=pos["attr"])
+        vis_p = (vis.refine_names("A", "V", "Y"), vmask.refine_names("A", "V"), widths)
+        txt_p = (txt.refine_names("B", "Q", "X"), tmask.refine_names("B", "Q"), None)
+        logit = gather(me, None, vis_p, txt_p, None)
+        plain = logit.rename(None)
+        diag_before = plain.diagonal().permute(2, 0, 1).clone()              # [B,Q,V]
+        max_v = plain.max(3).values.clone()                                   # [B,A,Q]
+        vp = VP(tag=tag, mask=wmask, seq_len_cpu=lengths.tolist())
+        if box_index is not None:
+            vp["vis_box_index"] = torch.tensor(box_index)
+        out = decode(me, {"match_logit": logit, "vis_packed": vis_p, "txt_packed": txt_p}, vp)
+        diag_after = plain.diagonal().permute(2, 0, 1).clone()               # the method's in-place edits land here
+        top_vals = diag_after.sort(-1, descending=True).values[..., :5]
+        to_img = [[int(t) for t in row] for row in out["txt_to_img"]]
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"), txt=_np(txt), vis=_np(vis), tmask=_np(tmask), vmask=_np(vmask), tag=_np(tag),
+            lengths=_np(lengths), factor_names=np.array(names), vis_split=np.array(widths, dtype=np.int64),
+            use_pos_prior=np.bool_(prior), use_heuristic=np.bool_(heur), pos_for_obj=_np(pos["obj"]),
+            pos_for_rel=_np(pos["rel"]), pos_for_attr=_np(pos["attr"]),
+            vis_box_index=np.array(box_index if box_index is not None else [], dtype=np.int64),
+            diag_before=_np(diag_before), diag_after=_np(diag_after), max_v=_np(max_v), top_vals=_np(top_vals),
+            txt_to_factor=np.array(json.dumps(out["txt_to_factor"])), txt_to_img=np.array(json.dumps(to_img)))
+        print(f"{name}: diag {tuple(diag_after.shape)} edited {int((diag_after != diag_before).sum())} entries")
+
+
 def attnfuse_cases():
     """joint.py:670-674 re-issued with the same torch ops (module construction needs a DataModule)."""
     for name, seed, B, L, V, d, h in (
@@ -364,4 +425,5 @@ if __name__ == "__main__":
     align_cases()
     attnfuse_cases()
     grounding_cases()
+    decode_cases()
     arcenc_cases()

@@ -111,6 +111,23 @@ def test_attn_and_grounding_entry_points_validate_on_the_host(lib):
     assert lib.vlg_attn_fuse(one, one, one, one, one, one, 0, 5, 7, 32, 64, 0, 1e-5, None, one, None) == 0      # empty batch
 
 
+def test_grounding_decode_validates_on_the_host(lib):
+    P = ctypes.c_void_p
+    one = P(16)
+    dec = lib.vlg_grounding_decode
+    ok = lambda **kw: [kw.get("logit", one), kw.get("pen", None), kw.get("seg", None), kw.get("n_seg", 0), kw.get("B", 2), 14,
+                       kw.get("V", 40), kw.get("heur", 1), kw.get("n_box", 5), kw.get("rel", 5), kw.get("attr", 30), 7,
+                       kw.get("maxV", None), 2, kw.get("f2i", None), kw.get("top", one), None]
+    assert dec(*ok(B=0)) == 0                                           # empty batch: nothing to do
+    assert dec(*ok(V=0)) == 0x1001
+    assert dec(*ok(logit=None)) == 0x1003 and dec(*ok(top=None)) == 0x1003
+    assert dec(*ok(pen=one)) == 0x1003 and b"seg_of_v" in lib.vlg_last_error()
+    assert dec(*ok(maxV=one)) == 0x1003 and b"factor2img" in lib.vlg_last_error()
+    assert dec(*ok(n_box=0)) == 0x1001
+    assert dec(*ok(rel=20)) == 0x1001 and b"relation block" in lib.vlg_last_error()      # 20 + 5^2 > 40
+    assert dec(*ok(attr=36)) == 0x1001 and b"attribute block" in lib.vlg_last_error()    # 36 + 5 > 40
+
+
 def test_trilinear_entry_points_validate_on_the_host(lib):
     P = ctypes.c_void_p
     one = P(16)

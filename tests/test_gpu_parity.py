@@ -631,6 +631,94 @@ def test_grounding_loss_shapes(oracle_mod, B, L, V, d, dt):
     assert torch.equal(g2[0], g_txt) and torch.equal(g2[1], g_vis)
 
 
+# ---- grounding decoder (joint.py:512-629) on the fused alignment outputs ----
+class _VP(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _decode_stub(g):
+    from types import SimpleNamespace as NS
+    me = NS(cfg=NS(decode_grounding_args=NS(use_pos_prior=bool(g["use_pos_prior"]), use_heuristic=bool(g["use_heuristic"]))),
+            vis_factor_names=[str(n) for n in g["factor_names"]], pos_for_obj=t(g["pos_for_obj"]),
+            pos_for_rel=t(g["pos_for_rel"]), pos_for_attr=t(g["pos_for_attr"]))
+    L = g["tag"].shape[1]
+    vp = _VP(tag=t(g["tag"]), mask=torch.zeros(len(g["tag"]), L, dtype=torch.bool))
+    if g["vis_box_index"].size:
+        vp["vis_box_index"] = torch.from_numpy(g["vis_box_index"])
+    return me, vp
+
+
+@pytest.mark.parametrize("path", golden_files("gdecode_"), ids=golden_ids("gdecode_"))
+def test_grounding_decode_golden(path):
+    """decode_grounding_on_factor registered from vlgae_amd.align vs the reference's own method (lists and edited block)."""
+    from conftest import gdecode_check_lists
+    from vlgae_amd import align
+    g = load(path)
+    me, vp = _decode_stub(g)
+    split = [int(w) for w in g["vis_split"]]
+    inputs = {"txt_packed": (t(g["txt"]), t(g["tmask"]), None), "vis_packed": (t(g["vis"]), t(g["vmask"]), split)}
+    out = align.decode_grounding_on_factor(me, inputs, vp)
+    gdecode_check_lists(out["txt_to_factor"], out["txt_to_img"], g, g["diag_after"])
+    # the edited block itself: same fp32 edits on alignment values that agree to rounding
+    names = me.vis_factor_names
+    start = np.concatenate([[0], np.cumsum(split)])
+    pen = seg = None
+    if bool(g["use_pos_prior"]):
+        pos_for = {k: t(g["pos_for_" + k]) for k in ("obj", "rel", "attr")}
+        pen, seg = align.grounding_prior(t(g["tag"]), names, split, pos_for, g["txt"].shape[1], scale=1e10)
+    r = align.grounding_decode(t(g["txt"]), t(g["vis"]), t(g["tmask"]), t(g["vmask"]), pen, seg, bool(g["use_heuristic"]),
+                               split[0], int(start[names.index("rel")]) if "rel" in names else -1,
+                               int(start[names.index("attr")]) if "attr" in names else -1, g["tag"].shape[1] + 1)
+    got = r["logit"].cpu().numpy()
+    assert np.allclose(got, g["diag_after"], rtol=1e-5, atol=1e-4)
+    top = r["top5"].cpu().numpy().astype(np.int64)
+    assert np.allclose(np.take_along_axis(got, top[..., :g["top_vals"].shape[-1]], -1), g["top_vals"], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,L,n_box,with_rel,with_attr,d,dt", [(6, 40, 36, True, True, 128, "f32"), (3, 12, 10, True, False, 64, "bf16"),
+                                                               (4, 9, 70, False, True, 32, "f32"), (2, 5, 3, False, False, 32, "f32")])
+def test_grounding_decode_shapes(oracle_mod, B, L, n_box, with_rel, with_attr, d, dt):
+    """Edits, top five and image arg-max against the oracle on the kernel's own alignment block (bit-exact: the same fp32
+    operations per element); the shipped factor layout obj + rel (n_box^2 columns) + attr + img at V = 1369."""
+    from vlgae_amd import align
+    rng = np.random.default_rng(B * 17 + L + n_box)
+    names, split = ["obj"], [n_box]
+    if with_rel:
+        names.append("rel"); split.append(n_box * n_box)
+    if with_attr:
+        names.append("attr"); split.append(n_box)
+    names.append("img"); split.append(1)
+    V, Q = sum(split), 2 * (L + 1)
+    lengths = rng.integers(max(1, L // 2), L + 1, B)
+    m1 = np.concatenate([np.zeros((B, 1), bool), np.arange(L)[None] < lengths[:, None]], 1)
+    tmask = np.concatenate([m1, m1], 1)
+    vmask = rng.random((B, V)) > 0.1
+    vmask[:, 0] = True
+    txt = t((rng.standard_normal((B, Q, d)) * 0.5).astype(np.float32))
+    vis = t((rng.standard_normal((B, V, d)) * 0.5).astype(np.float32))
+    if dt == "bf16":
+        txt, vis = txt.bfloat16(), vis.bfloat16()
+    tag = rng.integers(0, 6, (B, L))
+    pos_for = dict(obj=np.array([0, 1]), rel=np.array([1, 2]), attr=np.array([5]))
+    start = np.concatenate([[0], np.cumsum(split)])
+    pen, seg = align.grounding_prior(t(tag), names, split, {k: t(v) for k, v in pos_for.items()}, Q, scale=1e10)
+    before = align.bilinear_align(txt, vis, t(tmask), t(vmask), full=False, max_v=True, diag=True)
+    r = align.grounding_decode(txt, vis, t(tmask), t(vmask), pen, seg, True, n_box,
+                               int(start[names.index("rel")]) if with_rel else -1,
+                               int(start[names.index("attr")]) if with_attr else -1, L + 1)
+    ref = oracle_mod.grounding_decode(before["diag"].cpu().numpy(), before["max_v"].cpu().numpy(), tag, names, split, pos_for,
+                                      True, True)
+    got = r["logit"].cpu().numpy()
+    assert np.array_equal(got, ref["logit"])
+    assert np.array_equal(r["top5"].cpu().numpy()[..., :min(5, V)], ref["top5"])
+    assert np.array_equal(r["factor2img"].cpu().numpy(), ref["factor2img"])
+    # no prior, no heuristic: the block is untouched and only sorted
+    r0 = align.grounding_decode(txt, vis, t(tmask), t(vmask))
+    assert torch.equal(r0["logit"], before["diag"])
+    assert np.array_equal(r0["top5"].cpu().numpy()[..., :min(5, V)],
+                          np.argsort(-before["diag"].cpu().numpy().astype(np.float64), axis=-1, kind="stable")[..., :5])
+
+
 # ---- arc encoder (joint.py:281-287): trilinear term on the matrix cores ----
 @pytest.mark.parametrize("path", golden_files("arcenc_"), ids=golden_ids("arcenc_"))
 def test_arc_encoder_golden(path):

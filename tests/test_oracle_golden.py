@@ -169,6 +169,24 @@ def test_oracle_grounding_loss_matches_reference(oracle_mod, path):
         assert np.abs(o[name] - g[name]).max() <= 2e-5 * max(1.0, np.abs(g[name]).max()), name
 
 
+@pytest.mark.parametrize("path", golden_files("gdecode_"), ids=golden_ids("gdecode_"))
+def test_oracle_grounding_decode_matches_reference(oracle_mod, path):
+    """gather_logit_simple -> decode_grounding_on_factor run from the reference's own methods (joint.py:406-419, 512-629)."""
+    from conftest import gdecode_check_lists
+    g = load(path)
+    al = oracle_mod.bilinear_align(g["txt"], g["vis"], g["tmask"], g["vmask"], np.float32, -1e20, full=False, maxV=True, diag=True)
+    assert np.allclose(al["diag"], g["diag_before"], rtol=1e-5, atol=1e-5) and np.allclose(al["maxV"], g["max_v"], rtol=1e-5, atol=1e-5)
+    pos_for = dict(obj=g["pos_for_obj"], rel=g["pos_for_rel"], attr=g["pos_for_attr"])
+    o = oracle_mod.grounding_decode(g["diag_before"], g["max_v"], g["tag"], g["factor_names"], g["vis_split"], pos_for,
+                                    bool(g["use_pos_prior"]), bool(g["use_heuristic"]))
+    assert np.array_equal(o["logit"], g["diag_after"])                                   # same fp32 edits, bit for bit
+    assert np.array_equal(np.take_along_axis(o["logit"], o["top5"], -1), g["top_vals"])
+    box_index = g["vis_box_index"] if g["vis_box_index"].size else None
+    factor, img = oracle_mod.grounding_decode_lists(o["top5"], o["factor2img"], g["tmask"], g["factor_names"], g["vis_split"],
+                                                    box_index)
+    gdecode_check_lists(factor, img, g, g["diag_after"])
+
+
 @pytest.mark.parametrize("path", golden_files("arcenc_"), ids=golden_ids("arcenc_"))
 def test_oracle_arc_encoder_matches_reference(oracle_mod, path):
     """joint.py:281-287 (einsum + matmul + bias) and its autograd gradients."""

@@ -176,8 +176,8 @@ def attention_fuse(vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps=1
 # ----------------------------------------------------------------------------------------------
 # Grounding loss on the fused alignment maxima (joint.py:439-491) -- no [B,A,Q,V] tensor
 # ----------------------------------------------------------------------------------------------
-def grounding_prior(tag, factor_names, vis_split, pos_for, Q):
-    """The additive POS prior of joint.py:446-470 as a table.  tag [B,L] (vp.tag); factor_names / vis_split as in
+def grounding_prior(tag, factor_names, vis_split, pos_for, Q, scale=100.0):
+    """The additive POS prior of joint.py:446-470 (scale 100) / :528-552 (the decoder's, scale 1e10) as a table.  tag [B,L] (vp.tag); factor_names / vis_split as in
     `self.vis_factor_names` / `vis_packed[2]`; pos_for = {"obj": tensor, "rel": tensor, "attr": tensor}
     (`self.pos_for_*`).  Returns (pen [B,Q,S] float32, seg_of_v [V] uint8): region v of segment s loses pen[b,q,s]
     on the pair (b, b); rows outside the word queries 1..L stay 0."""
@@ -190,7 +190,7 @@ def grounding_prior(tag, factor_names, vis_split, pos_for, Q):
     for f, name in enumerate(factor_names):
         if name not in ("obj", "rel", "attr"):
             continue
-        hit = tag.unsqueeze(-1).eq(pos_for[name].to(dev)).any(-1).to(torch.float32) * 100.0    # joint.py:452-463
+        hit = tag.unsqueeze(-1).eq(pos_for[name].to(dev)).any(-1).to(torch.float32) * scale    # joint.py:452-463
         others = [s for s in range(S) if s != f]
         pen[:, 1:L + 1, others] += hit.unsqueeze(-1)
     return pen, seg_of_v
@@ -277,6 +277,87 @@ def loss_grounding_factor_ce(self, inputs, vp):
     if args.vis2txt > 0:
         loss["mt_vis2txt"] = args.vis2txt * sums[1] / (sums[1] + 1e-6) * num
     return total, loss
+
+
+# ----------------------------------------------------------------------------------------------
+# Grounding decoder on the fused alignment outputs (joint.py:512-629) -- no [B,A,Q,V] tensor
+# ----------------------------------------------------------------------------------------------
+def grounding_decode(txt_feat, vis_feat, txt_mask, vis_mask, pen=None, seg_of_v=None, use_heuristic=False, n_box=0,
+                     rel_offset=-1, attr_offset=-1, n_word_rows=0, neg_inf=-INF):
+    """gather_logit_simple + the tensor half of decode_grounding_on_factor (joint.py:406-419, 516-596) for B captions x B
+    images: the diagonal block and max over V come straight from the alignment kernel, then one launch applies the POS
+    prior (`pen`, `seg_of_v` from grounding_prior(..., scale=1e10)) and the box heuristics and extracts the five best
+    columns of every query row.  Returns dict(logit [B,Q,V] float32 (edited block), top5 [B,Q,5] int32 (descending,
+    equal values by ascending column, -1 past V), factor2img [B,Q] int32)."""
+    r = bilinear_align(txt_feat, vis_feat, txt_mask, vis_mask, neg_inf, full=False, max_v=True, diag=True)
+    logit, max_v = r["diag"], r["max_v"]
+    B, Q, V = logit.shape
+    if max_v.shape[1] != B:
+        raise ValueError(f"grounding decode pairs caption b with image b: {B} captions, {max_v.shape[1]} images")
+    dev = logit.device
+    if pen is not None:
+        pen = pen.to(device=dev, dtype=torch.float32).contiguous()
+        seg_of_v = seg_of_v.to(device=dev, dtype=torch.uint8).contiguous()
+        if pen.shape[:2] != (B, Q) or seg_of_v.numel() != V:
+            raise ValueError(f"pen {tuple(pen.shape)} / seg_of_v {tuple(seg_of_v.shape)} do not match B={B} Q={Q} V={V}")
+    top5 = torch.empty((B, Q, 5), dtype=torch.int32, device=dev)
+    f2i = torch.empty((B, Q), dtype=torch.int32, device=dev)
+    _C.check(_C.lib().vlg_grounding_decode(_C.ptr(logit), _C.ptr(pen), _C.ptr(seg_of_v), 0 if pen is None else pen.shape[2],
+                                           B, Q, V, int(bool(use_heuristic)), int(n_box), int(rel_offset), int(attr_offset),
+                                           int(n_word_rows), _C.ptr(max_v), B, _C.ptr(f2i), _C.ptr(top5),
+                                           _C.stream_of(logit)), "grounding_decode")
+    return {"logit": logit, "top5": top5, "factor2img": f2i}
+
+
+def _filter_list(data, mask):
+    """src/utility/fn.py:143-151: keep the entries whose mask entry is true, recursively over nested lists."""
+    if isinstance(mask[0], list):
+        return [_filter_list(d, m) for d, m in zip(data, mask)]
+    if isinstance(mask[0], int):
+        return [d for d, m in zip(data, mask) if m]
+    raise ValueError(f"Bad mask value: {mask}")
+
+
+def decode_grounding_on_factor(self, inputs, vp):
+    """The reference method's signature (joint.py:512-513), so it registers as an impl:
+    `JointModelBase.add_impl_to_group("decode_grounding", "on_factor|mi355x")(decode_grounding_on_factor)`.
+    Reads the packed features instead of inputs["match_logit"]; returns the same dict: txt_to_factor[b][query][k] =
+    (factor name, box id) or ("rel", (box id, box id)) for the five best factors of every unmasked query, and
+    txt_to_img[b][query] = the image whose best region matches the query best."""
+    from bisect import bisect_left
+    from itertools import accumulate
+    txt_feat, txt_mask, _ = inputs["txt_packed"]
+    vis_feat, vis_mask, vis_split = inputs["vis_packed"]
+    args = self.cfg.decode_grounding_args
+    names = list(self.vis_factor_names)
+    vis_split = [int(w) for w in vis_split]
+    pen = seg = None
+    if args.use_pos_prior:                                            # joint.py:528-552
+        pos_for = {"obj": self.pos_for_obj, "rel": self.pos_for_rel, "attr": self.pos_for_attr}
+        pen, seg = grounding_prior(vp.tag, names, vis_split, pos_for, txt_feat.shape[1], scale=1e10)
+    start = [0] + list(accumulate(vis_split))
+    out = grounding_decode(txt_feat, vis_feat, txt_mask, vis_mask, pen, seg, bool(args.use_heuristic), vis_split[0],
+                           start[names.index("rel")] if "rel" in names else -1,
+                           start[names.index("attr")] if "attr" in names else -1, vp.mask.shape[1] + 1)
+    match = out["top5"][..., :min(5, sum(vis_split))].tolist()         # the one host sync of the decoder, as in :596
+    box_ids = vp.vis_box_index.tolist() if "vis_box_index" in vp else [list(range(200)) for _ in range(len(match))]
+    processed = []
+    for inst_match, box_index in zip(match, box_ids):                  # joint.py:598-622
+        inst = []
+        for candidates in inst_match:
+            row = []
+            for idx in candidates:
+                group = bisect_left(start, idx)
+                if start[group] != idx:
+                    group -= 1
+                name = names[group]
+                idx -= start[group]
+                row.append((name, (box_index[idx // vis_split[0]], box_index[idx % vis_split[0]]) if name == "rel"
+                            else box_index[idx]))
+            inst.append(row)
+        processed.append(inst)
+    keep = _plain(txt_mask).tolist()
+    return {"txt_to_factor": _filter_list(processed, keep), "txt_to_img": _filter_list(out["factor2img"], keep)}
 
 
 # ----------------------------------------------------------------------------------------------
