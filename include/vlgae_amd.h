@@ -146,6 +146,20 @@ int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, c
                        float neg_inf, float num_token, float w_vis2txt, void* ws, size_t ws_bytes, float* out_sums,
                        float* g_txt, float* g_vis, void* stream);
 
+/* gather_logit_reduced, src/model/joint.py:421-432 (the input of loss_grounding_cap_img_ll :493-499 and
+ * decode_grounding_on_image :506-510), for B captions x B images without the [B,B,Q,V] tensor:
+ *   out_logit[b,a] = sum_q marginal[b,q] * max_v <txt[b,q], vis[a,v]> / sum_q marginal[b,q]      (masked entries = neg_inf)
+ * The forward leaves the maxima, their positions and the denominators in ws (vlg_align_reduced_workspace(B, Q) bytes);
+ * vlg_align_reduced_backward turns g_logit [B,B] into g_txt [B,Q,d] / g_vis [B,V,d] (fp32, either may be NULL) through the
+ * first arg-max of each maximum, only where both masks are on (masked_fill_, joint.py:417-418).  It reads the forward's
+ * ws and may be called more than once.  marginal [B,Q] fp32 is a constant (no gradient).  d in {32, 64, 128}. */
+size_t vlg_align_reduced_workspace(int B, int Q);
+int vlg_align_reduced(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marginal, int B,
+                      int Q, int V, int d, int in_dtype, float neg_inf, void* ws, size_t ws_bytes, float* out_logit, void* stream);
+int vlg_align_reduced_backward(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marginal,
+                               const float* g_logit, int B, int Q, int V, int d, int in_dtype, void* ws, size_t ws_bytes,
+                               float* g_txt, float* g_vis, void* stream);
+
 /* The tensor half of decode_grounding_on_factor, src/model/joint.py:512-596, on the fused
  * outputs of vlg_bilinear_align (out_diag -> logit, out_maxV -> maxV):
  *   logit [B,Q,V] fp32 is edited IN PLACE like the reference's diagonal copy: minus pen[b,q,seg_of_v[v]] (POS prior,

@@ -301,6 +301,33 @@ def grounding_loss(txt, vis, tmask, vmask, marginal, num_token, w_vis2txt=1.0, p
 # ----------------------------------------------------------------------------------------------
 # Brute-force enumerators (pure Python, tiny N only): an algorithm-independent known answer.
 # ----------------------------------------------------------------------------------------------
+def gather_logit_reduced(txt, vis, tmask, vmask, marginal, g_logit=None, neg_inf=-1e20, dtype=np.float64):
+    """gather_logit_simple + gather_logit_reduced (joint.py:406-432): logit[b,a] = sum_q marginal[b,q] max_v att[b,a,q,v] /
+    sum_q marginal[b,q].  With g_logit [B,A] also the gradients to txt and vis: through the first arg-max of every maximum
+    and only where both masks are on (masked_fill_ passes no gradient)."""
+    al = bilinear_align(txt, vis, tmask, vmask, dtype, neg_inf, full=True)
+    att = al["full"].astype(np.float64)
+    marginal = np.asarray(marginal, dtype=np.float64)
+    den = marginal.sum(1, keepdims=True)                                        # [B,1]
+    logit = (att.max(-1) * marginal[:, None, :]).sum(-1) / den
+    out = dict(logit=logit)
+    if g_logit is not None:
+        B, A, Q, V = att.shape
+        arg = att.argmax(-1)                                                    # [B,A,Q] first maximum
+        tm = np.ones((B, Q), bool) if tmask is None else np.asarray(tmask, bool)
+        vm = np.ones((A, V), bool) if vmask is None else np.asarray(vmask, bool)
+        coef = np.asarray(g_logit, np.float64)[:, :, None] * (marginal / den)[:, None, :]      # [B,A,Q]
+        coef = coef * tm[:, None, :] * vm[np.arange(A)[None, :, None], arg]
+        t64, v64 = np.asarray(txt, np.float64), np.asarray(vis, np.float64)
+        g_txt = np.einsum("baq,baqd->bqd", coef, v64[np.arange(A)[None, :, None], arg])
+        g_vis = np.zeros_like(v64)
+        for b in range(B):
+            for a in range(A):
+                np.add.at(g_vis[a], arg[b, a], coef[b, a][:, None] * t64[b])
+        out.update(g_txt=g_txt, g_vis=g_vis)
+    return out
+
+
 def grounding_decode(diag, max_v, tag, factor_names, vis_split, pos_for, use_pos_prior=True, use_heuristic=True):
     """Tensor half of decode_grounding_on_factor (joint.py:516-596) in float32, the reference's dtype.
     diag [B,Q,V] = batch diagonal of the alignment tensor (:522-525), max_v [B,A,Q] = its max over V; tag [B,L].

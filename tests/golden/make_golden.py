@@ -280,6 +280,39 @@ def grounding_cases():
         print(f"{name}: total {float(total):.4f} txt2vis_raw {float(t2v):.4f} vis2txt_raw {float(v2t):.4f}")
 
 
+def reduced_cases():
+    """The reference's own gather_logit_reduced -> loss_grounding_cap_img_ll (joint.py:421-432, 493-499: cross-entropy over the
+    images of every caption) with torch autograd gradients to both feature tensors."""
+    from types import SimpleNamespace as NS
+    src, joint = _ref_import.import_joint()
+    cls = joint.DependencyBoxRel
+    for name, seed, B, L, V, d in (("reduced_B4_L6_V7_s0", 0, 4, 6, 7, 32), ("reduced_B6_L40_V36_s1", 1, 6, 40, 36, 128)):
+        g = torch.Generator().manual_seed(seed)
+        Q = 2 * (L + 1)
+        lengths = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+        lengths[0] = L
+        wmask = torch.arange(L)[None] < lengths[:, None]
+        m1 = torch.cat([torch.zeros(B, 1, dtype=torch.bool), wmask], 1)
+        tmask = torch.cat([m1, m1], 1)
+        vmask = torch.rand(B, V, generator=g) > 0.15
+        vmask[:, 0] = True
+        txt = (torch.randn(B, Q, d, generator=g) * 0.5).requires_grad_(True)
+        vis = (torch.randn(B, V, d, generator=g) * 0.5).requires_grad_(True)
+        marg = torch.rand(B, Q, generator=g) * tmask
+        me = NS(training=True, criteria=torch.nn.CrossEntropyLoss())
+        me.gather_logit_simple = lambda inputs, vis_p, txt_p, vp: cls.gather_logit_simple(me, inputs, vis_p, txt_p, vp)
+        vis_p = (vis.refine_names("A", "V", "Y"), vmask.refine_names("A", "V"), [V])
+        txt_p = (txt.refine_names("B", "Q", "X"), tmask.refine_names("B", "Q"), marg)
+        logit = cls.gather_logit_reduced(me, None, vis_p, txt_p, None)
+        loss, _ = cls.loss_grounding_cap_img_ll(me, {"match_logit": logit.rename(None)}, NS(batch_size=B))
+        g_logit, = torch.autograd.grad(loss, logit, retain_graph=True)
+        g_txt, g_vis = torch.autograd.grad(loss, [txt, vis])
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), txt=_np(txt), vis=_np(vis), tmask=_np(tmask), vmask=_np(vmask),
+                            marginal=_np(marg), logit=_np(logit.rename(None)), loss=_np(loss), g_logit=_np(g_logit.rename(None)),
+                            g_txt=_np(g_txt), g_vis=_np(g_vis))
+        print(f"{name}: logit {tuple(logit.shape)} loss {float(loss):.4f}")
+
+
 def decode_cases():
     """The reference's own gather_logit_simple -> decode_grounding_on_factor (joint.py:406-419, 512-629) through a stub
     `self` / `vp` carrying only what the method reads.  Saved: the inputs, the diagonal block before and after the method's
@@ -426,4 +459,5 @@ if __name__ == "__main__":
     attnfuse_cases()
     grounding_cases()
     decode_cases()
+    reduced_cases()
     arcenc_cases()

@@ -111,6 +111,21 @@ def test_attn_and_grounding_entry_points_validate_on_the_host(lib):
     assert lib.vlg_attn_fuse(one, one, one, one, one, one, 0, 5, 7, 32, 64, 0, 1e-5, None, one, None) == 0      # empty batch
 
 
+def test_align_reduced_validates_on_the_host(lib):
+    P = ctypes.c_void_p
+    one = P(16)
+    fw, bw = lib.vlg_align_reduced, lib.vlg_align_reduced_backward
+    need = lib.vlg_align_reduced_workspace(3, 14)
+    assert need > 0 and need % 256 == 0 and lib.vlg_align_reduced_workspace(0, 14) == 0
+    assert fw(one, one, None, None, one, 3, 14, 9, 48, 0, -1e20, one, need, one, None) == 0x1001 and b"d=48" in lib.vlg_last_error()
+    assert fw(one, one, None, None, one, 3, 14, 9, 32, 5, -1e20, one, need, one, None) == 0x1002
+    assert fw(None, one, None, None, one, 3, 14, 9, 32, 0, -1e20, one, need, one, None) == 0x1003
+    assert fw(one, one, None, None, one, 3, 14, 9, 32, 0, -1e20, one, need - 1, one, None) == 0x1004
+    assert fw(one, one, None, None, one, 3, 14, 9, 32, 0, -1e20, one, need, None, None) == 0x1003
+    assert bw(one, one, None, None, one, one, 3, 14, 9, 32, 0, one, need, None, None, None) == 0x1003
+    assert bw(one, one, None, None, one, one, 3, 70000, 9, 32, 0, one, need, one, one, None) == 0x1001
+
+
 def test_grounding_decode_validates_on_the_host(lib):
     P = ctypes.c_void_p
     one = P(16)

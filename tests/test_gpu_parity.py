@@ -631,6 +631,53 @@ def test_grounding_loss_shapes(oracle_mod, B, L, V, d, dt):
     assert torch.equal(g2[0], g_txt) and torch.equal(g2[1], g_vis)
 
 
+# ---- gather_logit_reduced (joint.py:421-432) + the caption-image cross-entropy (:493-499) ----
+@pytest.mark.parametrize("path", golden_files("reduced_"), ids=golden_ids("reduced_"))
+def test_gather_logit_reduced_golden(path):
+    from vlgae_amd import align
+    g = load(path)
+    txt, vis = t(g["txt"]).requires_grad_(), t(g["vis"]).requires_grad_()
+    logit = align.gather_logit_reduced(None, None, (vis, t(g["vmask"]), None), (txt, t(g["tmask"]), t(g["marginal"])), None)
+    assert np.allclose(logit.detach().cpu().numpy(), g["logit"], rtol=1e-4, atol=1e-4)
+    loss = torch.nn.functional.cross_entropy(logit, torch.arange(len(logit), device=dev()))      # joint.py:498
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * max(1.0, abs(float(g["loss"])))
+    g_txt, g_vis = torch.autograd.grad(loss, [txt, vis])
+    for name, got in (("g_txt", g_txt), ("g_vis", g_vis)):
+        assert np.abs(got.cpu().numpy() - g[name]).max() <= 1e-4 * max(1.0, np.abs(g[name]).max()), name
+
+
+@pytest.mark.parametrize("B,L,V,d,dt", [(5, 7, 9, 32, "f32"), (6, 40, 36, 128, "bf16"), (3, 50, 70, 64, "f32"), (1, 3, 1, 32, "f32")])
+def test_gather_logit_reduced_shapes(oracle_mod, B, L, V, d, dt):
+    from vlgae_amd import align
+    rng = np.random.default_rng(B * 31 + L + V)
+    Q = 2 * (L + 1)
+    lengths = rng.integers(max(1, L // 2), L + 1, B)
+    m1 = np.concatenate([np.zeros((B, 1), bool), np.arange(L)[None] < lengths[:, None]], 1)
+    tmask = np.concatenate([m1, m1], 1)
+    vmask = rng.random((B, V)) > 0.2
+    vmask[:, 0] = True
+    txt = (rng.standard_normal((B, Q, d)) * 0.5).astype(np.float32)
+    vis = (rng.standard_normal((B, V, d)) * 0.5).astype(np.float32)
+    marg = (rng.random((B, Q)) * tmask).astype(np.float32)
+    g_logit = rng.standard_normal((B, B)).astype(np.float32)
+    if dt == "bf16":
+        txt, vis = (torch.from_numpy(a).bfloat16().float().numpy() for a in (txt, vis))
+    ref = oracle_mod.gather_logit_reduced(txt, vis, tmask, vmask, marg, g_logit)
+    tt, tv = t(txt), t(vis)
+    if dt == "bf16":
+        tt, tv = tt.bfloat16(), tv.bfloat16()
+    tt.requires_grad_(True)
+    tv.requires_grad_(True)
+    logit = align.gather_logit_reduced(None, None, (tv, t(vmask), None), (tt, t(tmask), t(marg)), None)
+    assert np.allclose(logit.detach().cpu().numpy(), ref["logit"], rtol=1e-4, atol=1e-4)
+    g_txt, g_vis = torch.autograd.grad(logit, [tt, tv], t(g_logit), retain_graph=True)
+    tol = 1e-2 if dt == "bf16" else 1e-4   # bf16 gradients are rounded on return
+    assert np.abs(g_txt.float().cpu().numpy() - ref["g_txt"]).max() <= tol * max(1.0, np.abs(ref["g_txt"]).max())
+    assert np.abs(g_vis.float().cpu().numpy() - ref["g_vis"]).max() <= tol * max(1.0, np.abs(ref["g_vis"]).max())
+    g2 = torch.autograd.grad(logit, [tt, tv], t(g_logit))       # the backward may run again on the same forward state
+    assert torch.equal(g2[0], g_txt) and torch.equal(g2[1], g_vis)
+
+
 # ---- grounding decoder (joint.py:512-629) on the fused alignment outputs ----
 class _VP(dict):
     __getattr__ = dict.__getitem__

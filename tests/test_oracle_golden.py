@@ -169,6 +169,20 @@ def test_oracle_grounding_loss_matches_reference(oracle_mod, path):
         assert np.abs(o[name] - g[name]).max() <= 2e-5 * max(1.0, np.abs(g[name]).max()), name
 
 
+@pytest.mark.parametrize("path", golden_files("reduced_"), ids=golden_ids("reduced_"))
+def test_oracle_gather_logit_reduced_matches_reference(oracle_mod, path):
+    """gather_logit_reduced + the cross-entropy of loss_grounding_cap_img_ll, run from the reference's own methods
+    (joint.py:421-432, 493-499), with autograd gradients."""
+    g = load(path)
+    o = oracle_mod.gather_logit_reduced(g["txt"], g["vis"], g["tmask"], g["vmask"], g["marginal"], g["g_logit"])
+    assert np.allclose(o["logit"], g["logit"], rtol=2e-5, atol=2e-5)
+    z = o["logit"] - o["logit"].max(1, keepdims=True)
+    ce = -(z - np.log(np.exp(z).sum(1, keepdims=True)))[np.arange(len(z)), np.arange(len(z))].mean()
+    assert abs(ce - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    for name in ("g_txt", "g_vis"):
+        assert np.abs(o[name] - g[name]).max() <= 2e-5 * max(1.0, np.abs(g[name]).max()), name
+
+
 @pytest.mark.parametrize("path", golden_files("gdecode_"), ids=golden_ids("gdecode_"))
 def test_oracle_grounding_decode_matches_reference(oracle_mod, path):
     """gather_logit_simple -> decode_grounding_on_factor run from the reference's own methods (joint.py:406-419, 512-629)."""

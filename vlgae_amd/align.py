@@ -100,6 +100,66 @@ def gather_logit_simple(self, inputs, vis, txt, vp):
     return gather_logit(inputs, vis, txt, vp)
 
 
+class _GatherLogitReduced(torch.autograd.Function):
+    """gather_logit_reduced (joint.py:421-432) for B captions x B images: [B,B] marginal-weighted mean over the queries of
+    the max over regions, with gradients to both feature tensors through the arg-max positions.  The marginal is a
+    constant (joint.py:251-268 builds it from detached scores)."""
+
+    @staticmethod
+    def forward(ctx, txt_feat, vis_feat, txt_mask, vis_mask, marginal, neg_inf):
+        dt, txt_c = _C.in_dtype(txt_feat.detach())
+        vis_c = vis_feat.detach().to(txt_c.dtype).contiguous()
+        B, Q, d = txt_c.shape
+        V = vis_c.shape[1]
+        dev = txt_c.device
+        tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        vm = None if vis_mask is None else vis_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        marg = marginal.detach().to(device=dev, dtype=torch.float32).contiguous()
+        nbytes = _C.lib().vlg_align_reduced_workspace(B, Q)
+        (logit,), ws = _C.alloc_f32(dev, ((B, B),), nbytes)
+        _C.check(_C.lib().vlg_align_reduced(_C.ptr(txt_c), _C.ptr(vis_c), _C.ptr(tm), _C.ptr(vm), _C.ptr(marg), B, Q, V, d, dt,
+                                            float(neg_inf), _C.ptr(ws), nbytes, _C.ptr(logit), _C.stream_of(txt_c)),
+                 "align_reduced")
+        ctx.save_for_backward(txt_c, vis_c, tm, vm, marg, ws)
+        ctx.meta = (dt, nbytes, txt_feat.dtype, vis_feat.dtype)
+        return logit
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        txt_c, vis_c, tm, vm, marg, ws = ctx.saved_tensors
+        dt, nbytes, t_dtype, v_dtype = ctx.meta
+        B, Q, d = txt_c.shape
+        V = vis_c.shape[1]
+        g = g.to(torch.float32).contiguous()
+        (g_txt, g_vis), _ = _C.alloc_f32(txt_c.device, ((B, Q, d) if ctx.needs_input_grad[0] else None,
+                                                        (B, V, d) if ctx.needs_input_grad[1] else None))
+        if g_txt is not None or g_vis is not None:
+            _C.check(_C.lib().vlg_align_reduced_backward(_C.ptr(txt_c), _C.ptr(vis_c), _C.ptr(tm), _C.ptr(vm), _C.ptr(marg),
+                                                         _C.ptr(g), B, Q, V, d, dt, _C.ptr(ws), nbytes, _C.ptr(g_txt),
+                                                         _C.ptr(g_vis), _C.stream_of(txt_c)), "align_reduced_backward")
+        return (None if g_txt is None else g_txt.to(t_dtype), None if g_vis is None else g_vis.to(v_dtype), None, None, None,
+                None)
+
+
+def gather_logit_reduced(self, inputs, vis, txt, vp):
+    """The reference method's signature (joint.py:421-422), so it registers as an impl:
+    `JointModelBase.add_impl_to_group("gather_logit", "reduced|mi355x")(gather_logit_reduced)`.
+    vis = (feat[B,V,d], mask[B,V], _), txt = (feat[B,Q,d], mask[B,Q], marginal[B,Q]); returns logit [B(captions), B(images)],
+    the input of loss_grounding_cap_img_ll (:493-499) and decode_grounding_on_image (:506-510), which stay as they are."""
+    vis_feat, vis_mask, _ = vis
+    txt_feat, txt_mask, txt_marginal = txt
+    txt_feat, vis_feat, txt_mask, vis_mask, txt_marginal = (_plain(t) for t in (txt_feat, vis_feat, txt_mask, vis_mask,
+                                                                                txt_marginal))
+    _C.require_gpu(txt_feat, "gather_logit_reduced")
+    B, Q, d = txt_feat.shape
+    if vis_feat.shape[0] != B or vis_feat.shape[2] != d:
+        raise ValueError(f"gather_logit_reduced pairs B captions with B images: txt {tuple(txt_feat.shape)} vis {tuple(vis_feat.shape)}")
+    if tuple(txt_marginal.shape) != (B, Q):
+        raise ValueError(f"txt_marginal must be [B,Q]={(B, Q)}, got {tuple(txt_marginal.shape)}")
+    return _GatherLogitReduced.apply(txt_feat, vis_feat, txt_mask, vis_mask, txt_marginal, -INF)
+
+
 def _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, want_att):
     B, V, d = vis_c.shape
     L, h = txt_c.shape[1] - 1, mid_c.shape[2]

@@ -524,4 +524,58 @@ int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, c
                                  g_txt, g_vis, s);
 }
 
+size_t vlg_align_reduced_workspace(int B, int Q) {
+    if (B < 1 || Q < 1) return 0;
+    return vlg::ReducedPlan(B, Q).bytes;
+}
+
+static int reduced_check(const char* what, const void* txt, const void* vis, const float* marginal, int B, int Q, int V, int d,
+                         int in_dtype, const void* ws, size_t ws_bytes, size_t need) {
+    using namespace vlg;
+    if (B < 1 || Q < 1 || V < 1 || d < 1) return set_error(VLG_ERR_SHAPE, "%s: bad shape B=%d Q=%d V=%d d=%d", what, B, Q, V, d);
+    if (Q > 65535 || V > 32767) return set_error(VLG_ERR_SHAPE, "%s: Q=%d V=%d exceed the 16-bit position range", what, Q, V);
+    if (B > 65535) return set_error(VLG_ERR_SHAPE, "%s: B=%d exceeds grid.y", what, B);
+    if (d != 32 && d != 64 && d != 128) return set_error(VLG_ERR_SHAPE, "%s: d=%d (supported: 32, 64, 128)", what, d);
+    if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "%s: in_dtype %d", what, in_dtype);
+    if (!txt || !vis || !marginal) return set_error(VLG_ERR_ARG, "%s: null buffer", what);
+    if (!ws || ws_bytes < need) return set_error(VLG_ERR_WORKSPACE, "%s: workspace %zu bytes < %zu", what, ws_bytes, need);
+    return 0;
+}
+
+int vlg_align_reduced(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marginal, int B,
+                      int Q, int V, int d, int in_dtype, float neg_inf, void* ws, size_t ws_bytes, float* out_logit, void* stream) {
+    using namespace vlg;
+    const ReducedPlan p(B > 0 ? B : 1, Q > 0 ? Q : 1);
+    if (int rc = reduced_check("align_reduced", txt, vis, marginal, B, Q, V, d, in_dtype, ws, ws_bytes, p.bytes)) return rc;
+    if (!out_logit) return set_error(VLG_ERR_ARG, "align_reduced: null output");
+    hipStream_t s = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    AlignArgs xa{nullptr, nullptr, 0, reinterpret_cast<uint16_t*>(wsf + p.off_argV), nullptr};
+    const bool f32in = in_dtype == VLG_F32;
+    int rc = -1;
+#define VLG_RA(F32, KCHV)                                                                                                     \
+    rc = launch_align_mfma<F32, KCHV, true, true, 3>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr, wsf + p.off_maxV, \
+                                                     nullptr, nullptr, s, xa)
+    if (!f32in && d == 128) VLG_RA(false, 4);
+    else if (!f32in && d == 64) VLG_RA(false, 2);
+    else if (!f32in && d == 32) VLG_RA(false, 1);
+    else if (f32in && d == 128) VLG_RA(true, 8);
+    else if (f32in && d == 64) VLG_RA(true, 4);
+    else VLG_RA(true, 2);
+#undef VLG_RA
+    if (rc) return rc;
+    return launch_reduced_logit(wsf + p.off_maxV, marginal, B, Q, wsf + p.off_sum, out_logit, s);
+}
+
+int vlg_align_reduced_backward(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marginal,
+                               const float* g_logit, int B, int Q, int V, int d, int in_dtype, void* ws, size_t ws_bytes,
+                               float* g_txt, float* g_vis, void* stream) {
+    using namespace vlg;
+    const ReducedPlan p(B > 0 ? B : 1, Q > 0 ? Q : 1);
+    if (int rc = reduced_check("align_reduced_backward", txt, vis, marginal, B, Q, V, d, in_dtype, ws, ws_bytes, p.bytes)) return rc;
+    if (!g_logit || (!g_txt && !g_vis)) return set_error(VLG_ERR_ARG, "align_reduced_backward: null buffer");
+    return launch_reduced_backward(txt, vis, tmask, vmask, marginal, g_logit, B, Q, V, d, in_dtype, (float*)ws, p, g_txt, g_vis,
+                                   (hipStream_t)stream);
+}
+
 }  // extern "C"

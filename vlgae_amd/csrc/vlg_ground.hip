@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "vlg_common.h"
 #include "vlg_dp_core.h"   // F32In / BF16In element loaders
 #include "vlg_ground.h"
@@ -354,6 +356,74 @@ static int launch_bwd(const void* txt, const void* vis, const float* gV, const u
         hipLaunchKernelGGL(k, dim3(B), dim3(64 * kGbWaves), lds, s, (P)txt, (P)vis, gV, argV, gQ, argQ, coef, B, Q, V, d, out);
     }
     return 0;
+}
+
+// ---- gather_logit_reduced (joint.py:421-432) on the same machinery ----------------------------------------------------
+// Block = caption b; wave = image a (strided); lanes over the queries, then a fixed xor tree: same bits every run.
+__global__ __launch_bounds__(256) void reduced_logit_kernel(const float* __restrict__ maxV, const float* __restrict__ marg,
+                                                            int B, int Q, float* __restrict__ sums, float* __restrict__ logit) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, A = B;
+    const float* w = marg + (size_t)b * Q;
+    float den = 0.f;
+    for (int q = lane; q < Q; q += 64) den += w[q];
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) den += __shfl_xor(den, k, 64);
+    if (threadIdx.x == 0) sums[b] = den;
+    for (int a = wave; a < A; a += 4) {
+        const float* m = maxV + ((size_t)b * A + a) * Q;
+        float num = 0.f;
+        for (int q = lane; q < Q; q += 64) num += m[q] * w[q];
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) num += __shfl_xor(num, k, 64);
+        if (lane == 0) logit[(size_t)b * A + a] = num / den;
+    }
+}
+
+// gV[b,a,q] = g_logit[b,a] * marginal[b,q] / sum[b] where both masks are on at the arg-max (masked_fill_ passes nothing), else 0.
+__global__ __launch_bounds__(256) void reduced_coef_kernel(const float* __restrict__ g_logit, const float* __restrict__ marg,
+                                                           const float* __restrict__ sums, const uint16_t* __restrict__ argV,
+                                                           const uint8_t* __restrict__ tmask, const uint8_t* __restrict__ vmask,
+                                                           int B, int Q, int V, float* __restrict__ gV, float* __restrict__ coef) {
+    const int A = B;
+    const size_t n = (size_t)B * A * Q;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pair = i / Q;
+        const int q = (int)(i - pair * Q), b = (int)(pair / A), a = (int)(pair - (size_t)b * A);
+        const bool open_ = (!tmask || tmask[(size_t)b * Q + q]) && (!vmask || vmask[(size_t)a * V + argV[i]]);
+        gV[i] = open_ ? g_logit[pair] * marg[(size_t)b * Q + q] / sums[b] : 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { coef[0] = 1.f; coef[1] = 0.f; }   // max-over-V terms only
+}
+
+ReducedPlan::ReducedPlan(int B, int Q) {
+    const size_t nV = (size_t)B * B * Q;
+    auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    off_maxV = 0;
+    off_gV = up(nV);
+    off_sum = off_gV + up(nV);
+    off_coef = off_sum + up((size_t)B);
+    off_argV = off_coef + 64;
+    bytes = sizeof(float) * (off_argV + up((nV + 1) / 2));
+}
+
+int launch_reduced_logit(const float* maxV, const float* marg, int B, int Q, float* sums, float* logit, hipStream_t s) {
+    hipLaunchKernelGGL(reduced_logit_kernel, dim3(B), dim3(256), 0, s, maxV, marg, B, Q, sums, logit);
+    return check_launch("reduced_logit_kernel");
+}
+
+int launch_reduced_backward(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marg,
+                            const float* g_logit, int B, int Q, int V, int d, int in_dtype, float* ws, const ReducedPlan& p,
+                            float* g_txt, float* g_vis, hipStream_t s) {
+    float *gV = ws + p.off_gV, *coef = ws + p.off_coef;
+    const uint16_t* aV = reinterpret_cast<const uint16_t*>(ws + p.off_argV);
+    const size_t n = (size_t)B * B * Q;
+    hipLaunchKernelGGL(reduced_coef_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, s, g_logit, marg,
+                       ws + p.off_sum, aV, tmask, vmask, B, Q, V, gV, coef);
+    // the max-over-Q arrays are never read (their factor coef[1] is 0): any valid pointers do
+    const int rc = in_dtype == VLG_F32 ? launch_bwd<F32In>(txt, vis, gV, aV, gV, aV, coef, B, Q, V, d, g_txt, g_vis, s)
+                                       : launch_bwd<BF16In>(txt, vis, gV, aV, gV, aV, coef, B, Q, V, d, g_txt, g_vis, s);
+    if (rc) return rc;
+    return check_launch("align_reduced_backward");
 }
 
 GroundPlan::GroundPlan(int B, int Q, int V) {
