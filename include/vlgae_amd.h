@@ -169,10 +169,12 @@ int vlg_align_reduced_backward(const void* txt, const void* vis, const uint8_t* 
  *   to -1e10 on i == j; attribute columns attr_offset + i are set to -1e10 unless box i is selected (offsets -1 = no
  *   such block).  top5 [B,Q,5] int32 = the five best columns of every row in descending order (:596; equal values by
  *   ascending column, -1 past V); factor2img [B,Q] int32 = first arg-max over a of maxV [B,A,Q] (:520; both or
- *   neither NULL). */
+ *   neither NULL).  ws (vlg_grounding_decode_workspace(B, n_box) bytes) is optional: with it, batches smaller than the
+ *   chip spread each sentence's rows over several workgroups (two launches); NULL = one workgroup per sentence. */
+size_t vlg_grounding_decode_workspace(int B, int n_box);
 int vlg_grounding_decode(float* logit, const float* pen, const uint8_t* seg_of_v, int n_seg, int B, int Q, int V,
                          int use_heuristic, int n_box, int rel_offset, int attr_offset, int n_word_rows, const float* maxV,
-                         int A, int32_t* factor2img, int32_t* top5, void* stream);
+                         int A, int32_t* factor2img, int32_t* top5, void* ws, size_t ws_bytes, void* stream);
 
 /* The arc encoder's trilinear term -- lang_feat word+maxdep, src/model/joint.py:281-284:
  *   out[m,h] = sum_{x,y} child[m,x] * w[x,h,y] * parent[m,y]        (m = flattened batch x position)

@@ -132,7 +132,8 @@ def test_grounding_decode_validates_on_the_host(lib):
     dec = lib.vlg_grounding_decode
     ok = lambda **kw: [kw.get("logit", one), kw.get("pen", None), kw.get("seg", None), kw.get("n_seg", 0), kw.get("B", 2), 14,
                        kw.get("V", 40), kw.get("heur", 1), kw.get("n_box", 5), kw.get("rel", 5), kw.get("attr", 30), 7,
-                       kw.get("maxV", None), 2, kw.get("f2i", None), kw.get("top", one), None]
+                       kw.get("maxV", None), 2, kw.get("f2i", None), kw.get("top", one), None, 0, None]
+    assert lib.vlg_grounding_decode_workspace(4, 36) == 512 and lib.vlg_grounding_decode_workspace(0, 36) == 0
     assert dec(*ok(B=0)) == 0                                           # empty batch: nothing to do
     assert dec(*ok(V=0)) == 0x1001
     assert dec(*ok(logit=None)) == 0x1003 and dec(*ok(top=None)) == 0x1003

@@ -759,6 +759,11 @@ def test_grounding_decode_shapes(oracle_mod, B, L, n_box, with_rel, with_attr, d
     assert np.array_equal(got, ref["logit"])
     assert np.array_equal(r["top5"].cpu().numpy()[..., :min(5, V)], ref["top5"])
     assert np.array_equal(r["factor2img"].cpu().numpy(), ref["factor2img"])
+    # one workgroup per sentence (no row split): same bits
+    r1 = align.grounding_decode(txt, vis, t(tmask), t(vmask), pen, seg, True, n_box,
+                                int(start[names.index("rel")]) if with_rel else -1,
+                                int(start[names.index("attr")]) if with_attr else -1, L + 1, split_rows=False)
+    assert torch.equal(r1["logit"], r["logit"]) and torch.equal(r1["top5"], r["top5"]) and torch.equal(r1["factor2img"], r["factor2img"])
     # no prior, no heuristic: the block is untouched and only sorted
     r0 = align.grounding_decode(txt, vis, t(tmask), t(vmask))
     assert torch.equal(r0["logit"], before["diag"])

@@ -343,12 +343,13 @@ def loss_grounding_factor_ce(self, inputs, vp):
 # Grounding decoder on the fused alignment outputs (joint.py:512-629) -- no [B,A,Q,V] tensor
 # ----------------------------------------------------------------------------------------------
 def grounding_decode(txt_feat, vis_feat, txt_mask, vis_mask, pen=None, seg_of_v=None, use_heuristic=False, n_box=0,
-                     rel_offset=-1, attr_offset=-1, n_word_rows=0, neg_inf=-INF):
+                     rel_offset=-1, attr_offset=-1, n_word_rows=0, neg_inf=-INF, split_rows=True):
     """gather_logit_simple + the tensor half of decode_grounding_on_factor (joint.py:406-419, 516-596) for B captions x B
     images: the diagonal block and max over V come straight from the alignment kernel, then one launch applies the POS
     prior (`pen`, `seg_of_v` from grounding_prior(..., scale=1e10)) and the box heuristics and extracts the five best
     columns of every query row.  Returns dict(logit [B,Q,V] float32 (edited block), top5 [B,Q,5] int32 (descending,
-    equal values by ascending column, -1 past V), factor2img [B,Q] int32)."""
+    equal values by ascending column, -1 past V), factor2img [B,Q] int32).  `split_rows=False` keeps one workgroup per
+    sentence even for small batches (same results; the kernel's single-launch form)."""
     r = bilinear_align(txt_feat, vis_feat, txt_mask, vis_mask, neg_inf, full=False, max_v=True, diag=True)
     logit, max_v = r["diag"], r["max_v"]
     B, Q, V = logit.shape
@@ -362,9 +363,11 @@ def grounding_decode(txt_feat, vis_feat, txt_mask, vis_mask, pen=None, seg_of_v=
             raise ValueError(f"pen {tuple(pen.shape)} / seg_of_v {tuple(seg_of_v.shape)} do not match B={B} Q={Q} V={V}")
     top5 = torch.empty((B, Q, 5), dtype=torch.int32, device=dev)
     f2i = torch.empty((B, Q), dtype=torch.int32, device=dev)
+    nbytes = _C.lib().vlg_grounding_decode_workspace(B, int(n_box)) if split_rows else 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
     _C.check(_C.lib().vlg_grounding_decode(_C.ptr(logit), _C.ptr(pen), _C.ptr(seg_of_v), 0 if pen is None else pen.shape[2],
                                            B, Q, V, int(bool(use_heuristic)), int(n_box), int(rel_offset), int(attr_offset),
-                                           int(n_word_rows), _C.ptr(max_v), B, _C.ptr(f2i), _C.ptr(top5),
+                                           int(n_word_rows), _C.ptr(max_v), B, _C.ptr(f2i), _C.ptr(top5), _C.ptr(ws), nbytes,
                                            _C.stream_of(logit)), "grounding_decode")
     return {"logit": logit, "top5": top5, "factor2img": f2i}
 
