@@ -13,6 +13,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "vlg_common.h"
 #include "vlg_dp_core.h"   // F32In / BF16In element loaders
 #include "vlg_ground.h"
@@ -123,6 +126,11 @@ constexpr int kTileVP = kCTB * 16 + 4;   // tile pitch 52: rows stay 16-byte ali
 // ARGS (the grounding loss's variant, TILE only): also records WHERE each maximum sits (first position on ties, like
 // a sequential scan) and, on the diagonal pairs a == b, subtracts the POS prior pen[b,q,seg(v)] before the maxima
 // (joint.py:446-470).  Separate instantiations: the plain paths pay nothing for it.
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
 struct AlignArgs {
     const float* pen;          // [B,Q,n_seg] or null
     const uint8_t* seg_of_v;   // [V]
@@ -131,13 +139,17 @@ struct AlignArgs {
     uint16_t* argQ;            // [B,A,V] query index of max over Q
 };
 
-template <bool F32IN, int KCH, bool TILE, bool ARGS, int RTBV = MfmaCfg<F32IN>::RTB>
+// DIRECT (fused-maxima dispatch, no full tensor): no LDS tile -- max over V is kept per lane and row across the region tiles
+// of an image and folded over the 16 column lanes (DPP) once per image.  The batch-diagonal block, when asked for, comes from
+// a second launch over the B diagonal pairs only (a_per_wave < 0).
+template <bool F32IN, int KCH, bool TILE, bool ARGS, int RTBV = MfmaCfg<F32IN>::RTB, bool DIRECT = false>
 __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
     const typename MfmaCfg<F32IN>::T* __restrict__ txt, const typename MfmaCfg<F32IN>::T* __restrict__ vis,
     const uint8_t* __restrict__ tmask, const uint8_t* __restrict__ vmask, int B, int A, int Q, int V,
     float neg_inf, float* __restrict__ out_full, float* __restrict__ out_maxV, float* __restrict__ out_maxQ,
     float* __restrict__ out_diag, int a_per_wave, AlignArgs xa) {
     static_assert(!ARGS || TILE, "arg-max tracking reads the LDS tile");
+    static_assert(!DIRECT || !ARGS, "the direct path keeps no positions");
     using C = MfmaCfg<F32IN>;
     using Frag = typename C::Frag;
     constexpr int RTB = RTBV, QB = RTB * 16, VB = kCTB * 16, d = KCH * C::KW;
@@ -146,7 +158,8 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
     float* tile = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (QB * kTileVP + 2 * QB);   // [QB][kTileVP]
     float* mv = tile + QB * kTileVP;                                                             // [QB] running max over V
     int* mi = reinterpret_cast<int*>(mv + QB);                                                   // [QB] ... and where (ARGS)
-    const int a_begin = (blockIdx.x * 4 + wave) * a_per_wave;
+    const bool diag_only = a_per_wave < 0;   // only the pairs a == b (the batch-diagonal block by itself): wave 0, image b
+    const int a_begin = diag_only ? b : (blockIdx.x * 4 + wave) * a_per_wave;
     const typename C::T* txt_b = txt + (size_t)b * Q * d;
     const int crow = (lane >> 4) * 4, ccol = lane & 15;   // C/D fragment: row = 4*(l>>4) + reg, col = l&15
     const int koff = C::EPL * (lane >> 4);
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
         // Work items of this wave in order: (image a, region group v0) -> kCTB region tiles each.  The region
         // fragments (and their keep bits) run through a 3-deep register ring that is always two tiles
         // (~2 x RTB x KCH MFMAs) ahead of the matrix cores, across group and image boundaries.
-        const int n_img = max(0, min(a_per_wave, A - a_begin));
+        const int n_img = diag_only ? 1 : max(0, min(a_per_wave, A - a_begin));
         const int n_grp = (V + VB - 1) / VB, n_items = n_img * n_grp;
         auto load_tile = [&](int item, int ct, Frag* f, unsigned& keep) {
             const int it = min(item, n_items - 1);            // past the end: re-load the last tile, never used
@@ -188,17 +201,29 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
         };
         Frag f0[KCH], f1[KCH], f2[KCH];
         unsigned k0 = 0, k1 = 0, k2 = 0;
-        if (n_items > 0) { load_tile(0, 0, f0, k0); load_tile(0, 1, f1, k1); }
+        float rm[DIRECT ? RTB : 1][4];   // DIRECT: running max over V of this lane's C rows, at its column, across an image's groups
+        // diagonal-only launches produce no maxima, so an image's region groups are independent: they are dealt out over the
+        // waves and blocks of the caption instead of running through one wave
+        const int i_first = diag_only ? wave + 4 * (int)blockIdx.x : 0, i_step = diag_only ? 4 * (int)gridDim.x : 1;
+        if (i_first < n_items) { load_tile(i_first, 0, f0, k0); load_tile(i_first, 1, f1, k1); }
 
-        for (int item = 0; item < n_items; ++item) {
+        for (int item = i_first; item < n_items; item += i_step) {
             const int ai = item / n_grp, v0 = (item - ai * n_grp) * VB;
             const int a = a_begin + ai, vn = min(VB, V - v0);
             const size_t ob = ((size_t)b * A + a) * Q;   // row base of this (b, a) pair
             float cmax[kCTB];   // running max over this lane's rows, per region column (for max over Q)
             int cidx[kCTB];     // ... and the row that holds it (ARGS)
             const bool prior_on = ARGS && xa.pen != nullptr && a == b;   // uniform
+            const bool use_tile = TILE && (!DIRECT || out_full != nullptr || (out_diag != nullptr && a == b));   // uniform
+            if (DIRECT && v0 == 0) {
+#pragma unroll
+                for (int rt = 0; rt < RTB; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rm[rt][e] = neg_infinity();
+            }
 
-            auto compute = [&](int ct, const Frag* bf, unsigned keepv) {
+            auto compute = [&](int ct, const Frag* bf, unsigned keepv, auto write_tile) {
+                constexpr bool WT = decltype(write_tile)::value;
                 // rows past Q and masked rows / columns all take the fill value, so one select + one max per element
                 const unsigned lane_keep = (v0 + ct * 16 + ccol < V && keepv != 0) ? tkeep : 0u;
                 float cm = neg_infinity();
@@ -248,18 +273,27 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float val = (lane_keep >> (rt * 4 + e)) & 1u ? acc[e] : neg_inf;   // joint.py:417-418
-                        if (TILE) tcol[(rt * 16 + e) * kTileVP] = val;
+                        if (WT) tcol[(rt * 16 + e) * kTileVP] = val;
+                        if (DIRECT && !WT) rm[rt][e] = fmaxf(rm[rt][e], val);
                         cm = fmaxf(cm, val);
                     }
                 }
                 return cm;
             };
             load_tile(item, 2, f2, k2);
-            cmax[0] = compute(0, f0, k0);
-            load_tile(item + 1, 0, f0, k0);
-            cmax[1] = compute(1, f1, k1);
-            load_tile(item + 1, 1, f1, k1);
-            cmax[2] = compute(2, f2, k2);
+            if (use_tile) {
+                cmax[0] = compute(0, f0, k0, std::true_type{});
+                load_tile(item + i_step, 0, f0, k0);
+                cmax[1] = compute(1, f1, k1, std::true_type{});
+                load_tile(item + i_step, 1, f1, k1);
+                cmax[2] = compute(2, f2, k2, std::true_type{});
+            } else {
+                cmax[0] = compute(0, f0, k0, std::false_type{});
+                load_tile(item + i_step, 0, f0, k0);
+                cmax[1] = compute(1, f1, k1, std::false_type{});
+                load_tile(item + i_step, 1, f1, k1);
+                cmax[2] = compute(2, f2, k2, std::false_type{});
+            }
             static_assert(kCTB == 3, "the fragment ring is written for three region tiles per group");
 
             // ---- max over Q straight from the accumulators: lanes l, l^16, l^32, l^48 hold the same column ----
@@ -293,7 +327,22 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
                     }
                 }
             }
-            if (TILE) {
+            if (DIRECT && !use_tile && out_maxV && v0 + VB >= V) {
+                // ---- max over V of the whole image from the per-lane maxima: fold the 16 column lanes ----
+#pragma unroll
+                for (int rt = 0; rt < RTB; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float m = rm[rt][e];   // DPP steps inside the 16-lane row: one v_max each, no LDS round trip
+                        m = fmaxf(m, row_dpp<0xB1>(m));    // quad_perm [1,0,3,2]
+                        m = fmaxf(m, row_dpp<0x4E>(m));    // quad_perm [2,3,0,1]
+                        m = fmaxf(m, row_dpp<0x141>(m));   // row_half_mirror
+                        m = fmaxf(m, row_dpp<0x140>(m));   // row_mirror
+                        const int q = rt * 16 + crow + e;
+                        if (ccol == 0 && q < qn) out_maxV[ob + q0 + q] = m;
+                    }
+            }
+            if (TILE && use_tile) {
                 __builtin_amdgcn_wave_barrier();
                 // ---- copy-out from the wave's LDS tile (pitch kTileVP) to the output block (pitch V) ----
                 if (out_full || (out_diag && a == b)) {
@@ -400,16 +449,18 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
     }
 }
 
-template <bool F32IN, int KCH, bool TILE, bool ARGS = false, int RTBV = MfmaCfg<F32IN>::RTB>
+template <bool F32IN, int KCH, bool TILE, bool ARGS = false, int RTBV = MfmaCfg<F32IN>::RTB, bool DIRECT = false>
 static int launch_align_mfma(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A,
                              int Q, int V, float neg_inf, float* out_full, float* out_maxV, float* out_maxQ,
-                             float* out_diag, hipStream_t s, AlignArgs xa = AlignArgs{nullptr, nullptr, 0, nullptr, nullptr}) {
+                             float* out_diag, hipStream_t s, AlignArgs xa = AlignArgs{nullptr, nullptr, 0, nullptr, nullptr},
+                             bool diag_only = false) {
     using C = MfmaCfg<F32IN>;
-    const int a_per_wave = A >= 2048 ? 16 : A >= 64 ? 8 : 1;
-    dim3 grid((A + 4 * a_per_wave - 1) / (4 * a_per_wave), B);
+    const int a_per_wave = diag_only ? -1 : A >= 2048 ? 16 : A >= 64 ? 8 : 1;
+    const int n_grp = (V + kCTB * 16 - 1) / (kCTB * 16);
+    dim3 grid(diag_only ? std::max(1, std::min((n_grp + 3) / 4, 16)) : (A + 4 * a_per_wave - 1) / (4 * a_per_wave), B);
     constexpr int QB = RTBV * 16;
     const size_t lds = TILE ? sizeof(float) * 4 * (size_t)(QB * kTileVP + 2 * QB) : 0;
-    auto k = align_mfma_kernel<F32IN, KCH, TILE, ARGS, RTBV>;
+    auto k = align_mfma_kernel<F32IN, KCH, TILE, ARGS, RTBV, DIRECT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
@@ -441,12 +492,27 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
     // ---- matrix-core path: d a whole number of MFMA K-chunks (the model's d = 128; also 64) ----
     const bool f32in = in_dtype == VLG_F32;
     const bool tile = out_full || out_diag || out_maxV;   // max over Q alone needs no LDS round trip
-    // the full tensor is bound by its writes and keeps 96-row passes (bf16); the maxima-only tile path gains a little from
-    // 48-row passes (two blocks per CU: 0.274 -> 0.257 ms)
+    // the full tensor is bound by its writes and keeps 96-row passes (bf16).  Fused maxima without the full tensor:
+    //   * one region group per image (V <= 48, config-2): the LDS-tile path with 48-row passes (two blocks per CU: 0.274 ->
+    //     0.257 ms); keeping max over V in registers instead measured the same or worse there (0.24 ms alone, 0.32 vs 0.28 ms
+    //     with the diagonal block);
+    //   * several groups per image (the shipped factor layout, V = 1369): max over V stays in registers across the groups
+    //     and is folded once per image (DIRECT, no LDS: 1.28 -> 0.74 ms at B = 64), the diagonal block comes from a second
+    //     launch over the B diagonal pairs;
+    //   * the diagonal block alone: only those B pairs are computed (0.187 -> 0.012 ms).
 #define VLG_MFMA(F32, KCHV)                                                                                         \
-    if (tile && !out_full)                                                                                          \
-        return launch_align_mfma<F32, KCHV, true, false, 3>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, out_maxV, \
-                                                            out_maxQ, out_diag, s);                                  \
+    if (tile && !out_full) {                                                                                        \
+        if ((out_maxV || out_maxQ) && V <= kCTB * 16)                                                               \
+            return launch_align_mfma<F32, KCHV, true, false, 3>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, nullptr, out_maxV, \
+                                                                out_maxQ, out_diag, s);                             \
+        if (out_maxV || out_maxQ) {                                                                                 \
+            const int rc = launch_align_mfma<F32, KCHV, false, false, MfmaCfg<F32>::RTB, true>(                     \
+                txt, vis, tmask, vmask, B, A, Q, V, neg_inf, nullptr, out_maxV, out_maxQ, nullptr, s);              \
+            if (rc || !out_diag) return rc;                                                                         \
+        }                                                                                                           \
+        return launch_align_mfma<F32, KCHV, true, false, 3>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, nullptr, nullptr,  \
+                                                            nullptr, out_diag, s, AlignArgs{nullptr, nullptr, 0, nullptr, nullptr}, true); \
+    }                                                                                                               \
     return tile ? launch_align_mfma<F32, KCHV, true>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, out_maxV, \
                                                      out_maxQ, out_diag, s)                                           \
                 : launch_align_mfma<F32, KCHV, false>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, out_maxV, \
