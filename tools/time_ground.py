@@ -1,4 +1,5 @@
-"""Grounding loss forward + gradients at config-2 (B = A = 256, Q = 82, V = 36, d = 128): vlg_grounding_loss vs the
+"""Grounding loss forward + gradients at config-2 (B = A = 256, Q = 82, V = 36, d = 128; `--shipped`: B = 64, V = 1369):
+vlg_grounding_loss vs the
 reference's formulation in torch ops (einsum -> masked_fill -> max -> log_softmax -> diagonal; autograd).
 Run under rocprofv3 --kernel-trace --stats for per-kernel times."""
 import sys, torch
@@ -6,6 +7,8 @@ sys.path.insert(0, '.')
 from vlgae_amd import align
 dev = torch.device('cuda:0')
 B, L, V, d = 256, 40, 36, 128
+if len(sys.argv) > 1 and sys.argv[1] == '--shipped':   # the shipped factor layout: obj 36 + rel 1296 + attr 36 + img 1, batch 64
+    B, V = 64, 1369
 Q = 2 * (L + 1)
 g = torch.Generator().manual_seed(0)
 lengths = torch.randint(L // 2, L + 1, (B,), generator=g)

@@ -151,11 +151,14 @@ template <typename In, bool SIDE_TXT, int NS>
 __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
     const typename In::T* __restrict__ txt, const typename In::T* __restrict__ vis, const float* __restrict__ gV,
     const uint16_t* __restrict__ argV, const float* __restrict__ gQ, const uint16_t* __restrict__ argQ,
-    const float* __restrict__ coef, int B, int Q, int V, int d, float* __restrict__ out) {
+    const float* __restrict__ coef, int B, int Q, int V, int d, int rows_per_block, float* __restrict__ out) {
     const int A = B;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int self = blockIdx.x;   // caption b (SIDE_TXT) or image a
-    const int n_rows = SIDE_TXT ? Q : V, n_other = SIDE_TXT ? V : Q;
+    const int n_all = SIDE_TXT ? Q : V, n_other = SIDE_TXT ? V : Q;
+    // this block's output rows [row0, row0 + n_rows) of `self` (blockIdx.y: more rows than the LDS accumulators hold, e.g.
+    // the 1369 factors of the shipped obj + rel + attr + img layout)
+    const int row0 = blockIdx.y * rows_per_block, n_rows = min(rows_per_block, n_all - row0);
     const typename In::T* other = SIDE_TXT ? vis : txt;   // [B][n_other][d]
     const float* g_gather = SIDE_TXT ? gV : gQ;
     const uint16_t* a_gather = SIDE_TXT ? argV : argQ;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
                 float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int p0 = 0; p0 < B; p0 += 64) {
                     const int p = min(p0 + lane, B - 1);
-                    const size_t at = pair_base(p, n_rows) + row;
+                    const size_t at = pair_base(p, n_all) + row0 + row;
                     const int src = p * n_other + a_gather[at];
                     const float g = p0 + lane < B ? c_gather * g_gather[at] : 0.f;
                     gather64(src, g, sum);
@@ -287,7 +290,8 @@ __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
 #pragma unroll
                 for (int u = 0; u < kGbScan; ++u) {
                     const int t = t00 + 64 * u + lane;
-                    const int row = ((rows_[u] & (kGbWaves - 1)) == wave && gs_[u] != 0.f) ? rows_[u] : -1;
+                    const int lr = rows_[u] - row0;   // local row; owned if in this block's range and lr mod 16 == wave
+                    const int row = (lr >= 0 && lr < n_rows && (lr & (kGbWaves - 1)) == wave && gs_[u] != 0.f) ? lr : -1;
                     const unsigned long long hits = __ballot(row >= 0);
                     if (hits == 0) continue;
                     if (row >= 0) {   // compact in term order behind what is already queued
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
     }
     __syncthreads();
     for (int i = threadIdx.x * 4; i < n_rows * d; i += 64 * kGbWaves * 4)
-        *reinterpret_cast<float4*>(out + (size_t)self * n_rows * d + i) = *reinterpret_cast<const float4*>(acc + i);
+        *reinterpret_cast<float4*>(out + ((size_t)self * n_all + row0) * d + i) = *reinterpret_cast<const float4*>(acc + i);
 }
 
 template <typename In>
@@ -342,10 +346,14 @@ static int launch_bwd(const void* txt, const void* vis, const float* gV, const u
     for (int side = 0; side < 2; ++side) {
         float* out = side == 0 ? g_txt : g_vis;
         if (!out) continue;
-        const size_t lds = sizeof(float) * (size_t)(side == 0 ? Q : V) * d + queue;
-        if (lds > 160 * 1024) return set_error(VLG_ERR_SHAPE, "grounding_loss: %d rows x d=%d exceed the LDS accumulator budget", side == 0 ? Q : V, d);
         const int rows = side == 0 ? Q : V;
-        void (*k)(P, P, const float*, const uint16_t*, const float*, const uint16_t*, const float*, int, int, int, int, float*);
+        // output rows per block: what the LDS accumulators hold (128 KB with the queues), in multiples of 16, evenly split
+        const int cap = (int)((128 * 1024 - queue) / (sizeof(float) * d)) & ~15;
+        if (cap < 16) return set_error(VLG_ERR_SHAPE, "grounding_loss: d=%d exceeds the LDS accumulator budget", d);
+        const int ny = (rows + cap - 1) / cap;
+        const int rpb = ny == 1 ? rows : (((rows + ny - 1) / ny) + 15) & ~15;
+        const size_t lds = sizeof(float) * (size_t)rpb * d + queue;
+        void (*k)(P, P, const float*, const uint16_t*, const float*, const uint16_t*, const float*, int, int, int, int, int, float*);
         // register slots pay off up to 3 rows per wave; with 6 the per-lane selects cost more than the LDS round trips
         if (side == 0) k = rows <= 48 ? ground_bwd_kernel<In, true, 3> : ground_bwd_kernel<In, true, 0>;
         else k = rows <= 48 ? ground_bwd_kernel<In, false, 3> : ground_bwd_kernel<In, false, 0>;
@@ -353,7 +361,8 @@ static int launch_bwd(const void* txt, const void* vis, const float* gV, const u
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(k, dim3(B), dim3(64 * kGbWaves), lds, s, (P)txt, (P)vis, gV, argV, gQ, argQ, coef, B, Q, V, d, out);
+        hipLaunchKernelGGL(k, dim3(B, (rows + rpb - 1) / rpb), dim3(64 * kGbWaves), lds, s, (P)txt, (P)vis, gV, argV, gQ, argQ, coef,
+                           B, Q, V, d, rpb, out);
     }
     return 0;
 }
