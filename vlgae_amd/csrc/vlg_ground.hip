@@ -147,7 +147,13 @@ __device__ __forceinline__ float4 row_ld4<BF16In>(const uint16_t* p) {
 
 // NS > 0: this block has at most 16 NS output rows, so a wave owns at most NS of them and the scatter part keeps them in
 // registers too (per-lane slot select); NS == 0: any number of rows, scatter drains into the LDS rows by read-add-write.
-template <typename In, bool SIDE_TXT, int NS>
+// COOP (16-row blocks, i.e. one output row per wave, and many scattered terms per block): the scan of the scattered terms
+// is done once per block instead of once per wave -- all 1024 lanes read kCoopTerms terms per trip (coalesced), the ones that
+// land in this block's rows are compacted IN TERM ORDER into a block queue in LDS (ballots + a 64-entry prefix over
+// (batch, wave)), and the waves then pick their own row's entries from LDS and sum the source rows in registers.
+constexpr int kCoopCap = 8192, kCoopBatches = 4, kCoopTerms = 64 * kGbWaves * kCoopBatches;
+
+template <typename In, bool SIDE_TXT, int NS, bool COOP = false>
 __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
     const typename In::T* __restrict__ txt, const typename In::T* __restrict__ vis, const float* __restrict__ gV,
     const uint16_t* __restrict__ argV, const float* __restrict__ gQ, const uint16_t* __restrict__ argQ,
@@ -270,9 +276,98 @@ __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
             }
         } else {
             if (c_scatter == 0.f) continue;
+            const int n_terms = B * n_other;
+            if (COOP) {
+                static_assert(!COOP || (NS == 0 && kGbWaves * kCoopBatches == 64), "one prefix lane per (batch, wave)");
+                int* bq_src = reinterpret_cast<int*>(acc + (size_t)n_rows * d) + 3 * kGbWaves * kGbQueue;   // [kCoopCap] source row (after the per-wave lists)
+                int* bq_lr = bq_src + kCoopCap;                                  // [kCoopCap] local destination row
+                float* bq_g = reinterpret_cast<float*>(bq_lr + kCoopCap);        // [kCoopCap] weight
+                int* cnt = reinterpret_cast<int*>(bq_g + kCoopCap);              // [64] hits per (batch, wave) of the trip
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                int queued = 0, filled = 0;   // this wave's list / the block queue (both uniform)
+                auto drain = [&]() {
+                    for (int i0 = 0; i0 < filled; i0 += 64) {
+                        const int i = i0 + lane;
+                        const bool mine = i < filled && bq_lr[min(i, kCoopCap - 1)] == wave;
+                        const unsigned long long hits = __ballot(mine);
+                        if (hits == 0) continue;
+                        if (mine) {
+                            const int at = queued + __popcll(hits & ((1ull << lane) - 1ull));
+                            q_src[at] = bq_src[i];
+                            q_g[at] = bq_g[i];
+                        }
+                        queued += __popcll(hits);
+                        if (queued >= 64) {
+                            gather64(q_src[lane], q_g[lane], sum);
+                            queued -= 64;
+                            if (lane < queued) {
+                                const int s_ = q_src[64 + lane];
+                                const float g_ = q_g[64 + lane];
+                                q_src[lane] = s_; q_g[lane] = g_;
+                            }
+                        }
+                    }
+                };
+                for (int t0 = 0; t0 < n_terms; t0 += kCoopTerms) {
+                    int lr_[kCoopBatches];
+                    float gs_[kCoopBatches];
+                    unsigned long long hb[kCoopBatches];
+#pragma unroll
+                    for (int u = 0; u < kCoopBatches; ++u) {
+                        const int tt = t0 + u * 64 * kGbWaves + (int)threadIdx.x, t = min(tt, n_terms - 1);
+                        const int p = t / n_other, pos = t - p * n_other;
+                        const size_t at = pair_base(p, n_other) + pos;
+                        lr_[u] = (int)a_scatter[at] - row0;
+                        gs_[u] = tt < n_terms ? c_scatter * g_scatter[at] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kCoopBatches; ++u) {
+                        hb[u] = __ballot(lr_[u] >= 0 && lr_[u] < n_rows && gs_[u] != 0.f);
+                        if (lane == 0) cnt[u * kGbWaves + wave] = __popcll(hb[u]);
+                    }
+                    __syncthreads();
+                    int incl = cnt[lane];   // lane <-> (batch, wave) in term order; inclusive prefix over the 64 counts
+#pragma unroll
+                    for (int k = 1; k < 64; k <<= 1) {
+                        const int o = __shfl_up(incl, k, 64);
+                        if (lane >= k) incl += o;
+                    }
+                    const int total = __shfl(incl, 63, 64);
+#pragma unroll
+                    for (int u = 0; u < kCoopBatches; ++u) {
+                        const int e = u * kGbWaves + wave;
+                        const int base = filled + __shfl(incl, e, 64) - __popcll(hb[u]);
+                        if ((hb[u] >> lane) & 1ull) {
+                            const int at = base + __popcll(hb[u] & ((1ull << lane) - 1ull));
+                            bq_src[at] = min(t0 + u * 64 * kGbWaves + (int)threadIdx.x, n_terms - 1);
+                            bq_lr[at] = lr_[u];
+                            bq_g[at] = gs_[u];
+                        }
+                    }
+                    filled += total;
+                    __syncthreads();
+                    if (filled > kCoopCap - kCoopTerms) {
+                        drain();
+                        filled = 0;
+                        __syncthreads();
+                    }
+                }
+                drain();
+                if (queued > 0) gather64(lane < queued ? q_src[lane] : 0, lane < queued ? q_g[lane] : 0.f, sum);
+                for (int k = lpt; k < 64; k <<= 1) {
+                    sum.x += __shfl_xor(sum.x, k, 64); sum.y += __shfl_xor(sum.y, k, 64);
+                    sum.z += __shfl_xor(sum.z, k, 64); sum.w += __shfl_xor(sum.w, k, 64);
+                }
+                if (sub == 0 && wave < n_rows) {
+                    float4* cell = reinterpret_cast<float4*>(acc + (size_t)wave * d + fl);
+                    float4 c = *cell;
+                    c.x += sum.x; c.y += sum.y; c.z += sum.z; c.w += sum.w;
+                    *cell = c;
+                }
+                continue;
+            }
 #pragma unroll
             for (int sl = 0; sl < (NS > 0 ? NS : 1); ++sl) racc[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int n_terms = B * n_other;
             int queued = 0;   // uniform
             // kGbScan batches of 64 terms per trip: all their index / weight reads are in flight together (one batch per
             // trip made the scan itself the bottleneck: a memory round trip per 64 terms, 16 waves each scanning all terms)
@@ -350,13 +445,18 @@ static int launch_bwd(const void* txt, const void* vis, const float* gV, const u
         // output rows per block: what the LDS accumulators hold (128 KB with the queues), in multiples of 16, evenly split
         const int cap = (int)((128 * 1024 - queue) / (sizeof(float) * d)) & ~15;
         if (cap < 16) return set_error(VLG_ERR_SHAPE, "grounding_loss: d=%d exceeds the LDS accumulator budget", d);
-        const int ny = (rows + cap - 1) / cap;
+        int ny = (rows + cap - 1) / cap;
+        // small batches: more row chunks per caption / image so that the launch covers the chip (every chunk scans all the
+        // scattered terms but applies only its own rows; B = 64, V = 1369: caption side 2.0 -> 0.3 ms)
+        if (B * ny < 256) ny = std::max(ny, std::min((rows + 15) / 16, (512 + B - 1) / B));
         const int rpb = ny == 1 ? rows : (((rows + ny - 1) / ny) + 15) & ~15;
-        const size_t lds = sizeof(float) * (size_t)rpb * d + queue;
+        // one row per wave and a long list of scattered terms: scan them once per block (COOP)
+        const bool coop = rows > 48 && rpb == kGbWaves && (size_t)B * (side == 0 ? V : Q) >= 2 * (size_t)kCoopTerms;
+        const size_t lds = sizeof(float) * (size_t)rpb * d + queue + (coop ? (size_t)kCoopCap * 12 + 256 : 0);
         void (*k)(P, P, const float*, const uint16_t*, const float*, const uint16_t*, const float*, int, int, int, int, int, float*);
         // register slots pay off up to 3 rows per wave; with 6 the per-lane selects cost more than the LDS round trips
-        if (side == 0) k = rows <= 48 ? ground_bwd_kernel<In, true, 3> : ground_bwd_kernel<In, true, 0>;
-        else k = rows <= 48 ? ground_bwd_kernel<In, false, 3> : ground_bwd_kernel<In, false, 0>;
+        if (side == 0) k = rows <= 48 ? ground_bwd_kernel<In, true, 3> : coop ? ground_bwd_kernel<In, true, 0, true> : ground_bwd_kernel<In, true, 0>;
+        else k = rows <= 48 ? ground_bwd_kernel<In, false, 3> : coop ? ground_bwd_kernel<In, false, 0, true> : ground_bwd_kernel<In, false, 0>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
