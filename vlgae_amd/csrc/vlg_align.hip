@@ -131,6 +131,9 @@ __device__ __forceinline__ float row_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 
+template <int CTRL>
+__device__ __forceinline__ int row_dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+
 struct AlignArgs {
     const float* pen;          // [B,Q,n_seg] or null
     const uint8_t* seg_of_v;   // [V]
@@ -148,8 +151,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
     const uint8_t* __restrict__ tmask, const uint8_t* __restrict__ vmask, int B, int A, int Q, int V,
     float neg_inf, float* __restrict__ out_full, float* __restrict__ out_maxV, float* __restrict__ out_maxQ,
     float* __restrict__ out_diag, int a_per_wave, AlignArgs xa) {
-    static_assert(!ARGS || TILE, "arg-max tracking reads the LDS tile");
-    static_assert(!DIRECT || !ARGS, "the direct path keeps no positions");
+    static_assert(!ARGS || TILE || DIRECT, "arg-max tracking reads the LDS tile or keeps (max, position) pairs in registers");
     using C = MfmaCfg<F32IN>;
     using Frag = typename C::Frag;
     constexpr int RTB = RTBV, QB = RTB * 16, VB = kCTB * 16, d = KCH * C::KW;
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
         Frag f0[KCH], f1[KCH], f2[KCH];
         unsigned k0 = 0, k1 = 0, k2 = 0;
         float rm[DIRECT ? RTB : 1][4];   // DIRECT: running max over V of this lane's C rows, at its column, across an image's groups
+        int ri[DIRECT && ARGS ? RTB : 1][4];   // ... and the region that holds it (first one: columns only ascend for a lane)
         // diagonal-only launches produce no maxima, so an image's region groups are independent: they are dealt out over the
         // waves and blocks of the caption instead of running through one wave
         const int i_first = diag_only ? wave + 4 * (int)blockIdx.x : 0, i_step = diag_only ? 4 * (int)gridDim.x : 1;
@@ -219,7 +222,10 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
 #pragma unroll
                 for (int rt = 0; rt < RTB; ++rt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rm[rt][e] = neg_infinity();
+                    for (int e = 0; e < 4; ++e) {
+                        rm[rt][e] = neg_infinity();
+                        if (ARGS) ri[rt][e] = 0x7fff;
+                    }
             }
 
             auto compute = [&](int ct, const Frag* bf, unsigned keepv, auto write_tile) {
@@ -246,7 +252,8 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
                         for (int e = 0; e < 4; ++e) {
                             float val = (lane_keep >> (rt * 4 + e)) & 1u ? acc[e] : neg_inf;   // joint.py:417-418
                             if (prior_on) val -= prow[(size_t)min(q0 + rt * 16 + crow + e, Q - 1) * xa.n_seg];   // joint.py:466-469
-                            tcol[(rt * 16 + e) * kTileVP] = val;
+                            if (WT) tcol[(rt * 16 + e) * kTileVP] = val;
+                            if (DIRECT && !WT && val > rm[rt][e]) { rm[rt][e] = val; ri[rt][e] = v0 + ct * 16 + ccol < V ? v0 + ct * 16 + ccol : 0x7fff; }
                             v4[e] = val;
                         }
                         // first maximum of the four rows (ascending): two independent pairs, then merge
@@ -334,11 +341,26 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float m = rm[rt][e];   // DPP steps inside the 16-lane row: one v_max each, no LDS round trip
+                        const int q = rt * 16 + crow + e;
+                        if (ARGS) {   // (value, region) pairs: larger value wins, equal values keep the smaller region
+                            int mi_ = ri[rt][e];
+                            auto step = [&](float om, int oi) {
+                                if (om > m || (om == m && oi < mi_)) { m = om; mi_ = oi; }
+                            };
+                            step(row_dpp<0xB1>(m), row_dpp_i<0xB1>(mi_));
+                            step(row_dpp<0x4E>(m), row_dpp_i<0x4E>(mi_));
+                            step(row_dpp<0x141>(m), row_dpp_i<0x141>(mi_));
+                            step(row_dpp<0x140>(m), row_dpp_i<0x140>(mi_));
+                            if (ccol == 0 && q < qn) {
+                                out_maxV[ob + q0 + q] = m;
+                                xa.argV[ob + q0 + q] = (uint16_t)mi_;
+                            }
+                            continue;
+                        }
                         m = fmaxf(m, row_dpp<0xB1>(m));    // quad_perm [1,0,3,2]
                         m = fmaxf(m, row_dpp<0x4E>(m));    // quad_perm [2,3,0,1]
                         m = fmaxf(m, row_dpp<0x141>(m));   // row_half_mirror
                         m = fmaxf(m, row_dpp<0x140>(m));   // row_mirror
-                        const int q = rt * 16 + crow + e;
                         if (ccol == 0 && q < qn) out_maxV[ob + q0 + q] = m;
                     }
             }
@@ -574,9 +596,14 @@ int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, c
     // variant's long epilogue behind the other block's MFMAs (bf16, measured: 96 rows 535 us, 64 rows ~700, 48 rows 383,
     // 32 rows ~450; the plain tile paths gain nothing from it: 0.27 vs 0.25 ms full tensor, 0.26 vs 0.27 ms fused maxima)
 #define VLG_GA_RTB 3
+    // several region groups per image (V > 48, the shipped factor layout): (max, position) pairs stay in registers across
+    // the groups instead of going through the LDS tile per group
 #define VLG_GA(F32, KCHV)                                                                                          \
-    rc = launch_align_mfma<F32, KCHV, true, true, VLG_GA_RTB>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr, wsf + p.off_maxV, \
-                                                  wsf + p.off_maxQ, nullptr, s, xa)
+    rc = V > kCTB * 16                                                                                             \
+             ? launch_align_mfma<F32, KCHV, false, true, VLG_GA_RTB, true>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr,        \
+                                                                         wsf + p.off_maxV, wsf + p.off_maxQ, nullptr, s, xa)        \
+             : launch_align_mfma<F32, KCHV, true, true, VLG_GA_RTB>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr,               \
+                                                                    wsf + p.off_maxV, wsf + p.off_maxQ, nullptr, s, xa)
     if (!f32in && d == 128) VLG_GA(false, 4);
     else if (!f32in && d == 64) VLG_GA(false, 2);
     else if (!f32in && d == 32) VLG_GA(false, 1);
@@ -620,8 +647,11 @@ int vlg_align_reduced(const void* txt, const void* vis, const uint8_t* tmask, co
     const bool f32in = in_dtype == VLG_F32;
     int rc = -1;
 #define VLG_RA(F32, KCHV)                                                                                                     \
-    rc = launch_align_mfma<F32, KCHV, true, true, 3>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr, wsf + p.off_maxV, \
-                                                     nullptr, nullptr, s, xa)
+    rc = V > kCTB * 16                                                                                                        \
+             ? launch_align_mfma<F32, KCHV, false, true, 3, true>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr,           \
+                                                                   wsf + p.off_maxV, nullptr, nullptr, s, xa)                      \
+             : launch_align_mfma<F32, KCHV, true, true, 3>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr, wsf + p.off_maxV, \
+                                                           nullptr, nullptr, s, xa)
     if (!f32in && d == 128) VLG_RA(false, 4);
     else if (!f32in && d == 64) VLG_RA(false, 2);
     else if (!f32in && d == 32) VLG_RA(false, 1);
