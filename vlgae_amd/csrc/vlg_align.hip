@@ -477,7 +477,9 @@ static int launch_align_mfma(const void* txt, const void* vis, const uint8_t* tm
                              float* out_diag, hipStream_t s, AlignArgs xa = AlignArgs{nullptr, nullptr, 0, nullptr, nullptr},
                              bool diag_only = false) {
     using C = MfmaCfg<F32IN>;
-    const int a_per_wave = diag_only ? -1 : A >= 2048 ? 16 : A >= 64 ? 8 : 1;
+    int a_per_wave = diag_only ? -1 : A >= 2048 ? 16 : A >= 64 ? 8 : 1;
+    // small batches (the shipped B = 64): fewer images per wave rather than fewer workgroups than CUs
+    while (a_per_wave > 1 && (long)((A + 4 * a_per_wave - 1) / (4 * a_per_wave)) * B < 512) a_per_wave >>= 1;
     const int n_grp = (V + kCTB * 16 - 1) / (kCTB * 16);
     dim3 grid(diag_only ? std::max(1, std::min((n_grp + 3) / 4, 16)) : (A + 4 * a_per_wave - 1) / (4 * a_per_wave), B);
     constexpr int QB = RTBV * 16;
