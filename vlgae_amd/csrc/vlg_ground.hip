@@ -28,7 +28,7 @@
 
 namespace vlg {
 
-constexpr int kCeThreads = 256;
+constexpr int kCeThreads = 256, kCeMaxY = 8;   // threads per block; most column shares per row of blocks
 
 // Rows i = 0..n-1, columns j < ncols of  x[i][j] = buf[fixed * fixed_stride + i * row_stride + j]  (fixed = blockIdx.x).
 // Per column: log-softmax over i, the diagonal term i == fixed enters the loss with weight w[fixed][j].
@@ -46,8 +46,11 @@ __global__ __launch_bounds__(kCeThreads) void ground_ce_kernel(float* __restrict
     const int fixed = blockIdx.x, tid = threadIdx.x;
     float* base = buf + (size_t)fixed * fixed_stride;
     float loss = 0.f;   // thread 0 accumulates the block's loss, columns in ascending order
-    for (int j0 = 0; j0 < ncols; j0 += kCeThreads) {
-        const int cw = min(kCeThreads, ncols - j0), P = kCeThreads / cw;   // P row slices per column
+    // blockIdx.y: this block's share of the columns (whole 256-column strips), so that few long rows still cover the chip
+    const int strips = (ncols + kCeThreads - 1) / kCeThreads, spb = (strips + gridDim.y - 1) / gridDim.y;
+    const int j_begin = blockIdx.y * spb * kCeThreads, j_end = min(ncols, j_begin + spb * kCeThreads);
+    for (int j0 = j_begin; j0 < j_end; j0 += kCeThreads) {
+        const int cw = min(kCeThreads, j_end - j0), P = kCeThreads / cw;   // P row slices per column
         const int jl = tid % cw, part = tid / cw, j = j0 + jl;
         const bool on = part < P;
         // column maximum
@@ -94,16 +97,17 @@ __global__ __launch_bounds__(kCeThreads) void ground_ce_kernel(float* __restrict
             }
         __syncthreads();
     }
-    if (tid == 0) partial[fixed] = loss;
+    if (tid == 0) partial[(size_t)fixed * gridDim.y + blockIdx.y] = loss;
 }
 
 // sums = {txt2vis, vis2txt, total};  coef = {c1, c2}: d total / d txt2vis, d total / d vis2txt.
 // One wave: lane i adds partials i, i+64, ... in order, then a fixed xor tree (same bits every run).
-__global__ __launch_bounds__(64) void ground_sum_kernel(const float* __restrict__ part1, const float* __restrict__ part2, int n,
-                                                        float num_token, float w_v2t, float* __restrict__ sums,
+__global__ __launch_bounds__(64) void ground_sum_kernel(const float* __restrict__ part1, const float* __restrict__ part2, int n1,
+                                                        int n2, float num_token, float w_v2t, float* __restrict__ sums,
                                                         float* __restrict__ coef) {
     float t2v = 0.f, v2t = 0.f;
-    for (int i = threadIdx.x; i < n; i += 64) { t2v += part1[i]; v2t += part2[i]; }
+    for (int i = threadIdx.x; i < n1; i += 64) t2v += part1[i];
+    for (int i = threadIdx.x; i < n2; i += 64) v2t += part2[i];
 #pragma unroll
     for (int k = 1; k < 64; k <<= 1) { t2v += __shfl_xor(t2v, k, 64); v2t += __shfl_xor(v2t, k, 64); }
     if (threadIdx.x == 0) {
@@ -541,7 +545,7 @@ GroundPlan::GroundPlan(int B, int Q, int V) {
     off_maxV = 0;
     off_maxQ = up(nV);
     off_part = off_maxQ + up(nQ);
-    off_coef = off_part + up(2 * (size_t)B);
+    off_coef = off_part + up(2 * (size_t)B * kCeMaxY);
     off_argV = off_coef + 64;                          // uint16 arrays, offsets still counted in floats
     off_argQ = off_argV + up((nV + 1) / 2);
     bytes = sizeof(float) * (off_argQ + up((nQ + 1) / 2));
@@ -553,14 +557,21 @@ int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask
     float *mV = ws + p.off_maxV, *mQ = ws + p.off_maxQ, *part = ws + p.off_part, *coef = ws + p.off_coef;
     const uint16_t* aV = reinterpret_cast<const uint16_t*>(ws + p.off_argV);
     const uint16_t* aQ = reinterpret_cast<const uint16_t*>(ws + p.off_argQ);
+    // column shares per caption / image: only when B alone leaves CUs idle and there are several 256-column strips
+    auto shares = [&](int ncols) {
+        const int strips = (ncols + kCeThreads - 1) / kCeThreads;
+        return B >= 256 ? 1 : std::max(1, std::min(std::min(strips, kCeMaxY), (256 + B - 1) / B));
+    };
+    const int y1 = shares(Q), y2 = shares(V);
     // txt2vis: fixed = caption b, rows = images a: x[a][q] = mV[(b*A + a)*Q + q]; gate: tmask[b][q], vmask[a][argV]
-    hipLaunchKernelGGL(ground_ce_kernel<float>, dim3(B), dim3(kCeThreads), 0, s, mV, (size_t)B * Q, (size_t)Q, B, Q, marg, aV,
+    hipLaunchKernelGGL(ground_ce_kernel<float>, dim3(B, y1), dim3(kCeThreads), 0, s, mV, (size_t)B * Q, (size_t)Q, B, Q, marg, aV,
                        tmask, vmask, V, part);
     // vis2txt: fixed = image a, rows = captions b: x[b][v] = mQ[(b*A + a)*V + v]; weights = vis_mask as 0/1 (joint.py:481,
     // null = all ones); gate: vmask[a][v], tmask[b][argQ]
-    hipLaunchKernelGGL(ground_ce_kernel<uint8_t>, dim3(B), dim3(kCeThreads), 0, s, mQ, (size_t)V, (size_t)B * V, B, V, vmask, aQ,
-                       vmask, tmask, Q, part + B);
-    hipLaunchKernelGGL(ground_sum_kernel, dim3(1), dim3(64), 0, s, part, part + B, B, num_token, w_v2t, out_sums, coef);
+    float* part2 = part + (size_t)B * y1;
+    hipLaunchKernelGGL(ground_ce_kernel<uint8_t>, dim3(B, y2), dim3(kCeThreads), 0, s, mQ, (size_t)V, (size_t)B * V, B, V, vmask, aQ,
+                       vmask, tmask, Q, part2);
+    hipLaunchKernelGGL(ground_sum_kernel, dim3(1), dim3(64), 0, s, part, part2, B * y1, B * y2, num_token, w_v2t, out_sums, coef);
     if (g_txt || g_vis) {
         const int rc = in_dtype == VLG_F32 ? launch_bwd<F32In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s)
                                            : launch_bwd<BF16In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s);
