@@ -268,12 +268,12 @@ def main():
         vis = torch.randn(B, V, d, generator=g).to(dev, in_dtype)
         for full in (True, False):
             kw = dict(full=full, max_v=not full, max_q=not full)
-            for _ in range(3):
+            for _ in range(20):   # long enough for the clocks to settle after the idle gap before this section
                 r = align.bilinear_align(txt, vis, **kw)
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            n_al = 10
+            n_al = 100
             for _ in range(n_al):
                 r = align.bilinear_align(txt, vis, **kw)
             e1.record()
@@ -291,16 +291,21 @@ def main():
         # the two consumers on the training path: attention-fuse (joint.py:670-674) and the grounding loss on the
         # fused maxima (joint.py:439-491), forward + gradients, through the host API
         def timed(fn, n):
+            """ms per call: median of three windows of n calls (a host hiccup inside one window -- an allocator refill,
+            a scheduler tick -- otherwise lands in a host-bound entry as a 10x outlier)."""
+            for _ in range(10):
+                fn()
+            wins = []
             for _ in range(3):
-                fn()
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(n):
-                fn()
-            e1.record()
-            torch.cuda.synchronize(dev)
-            return e0.elapsed_time(e1) / n
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                wins.append(e0.elapsed_time(e1) / n)
+            return sorted(wins)[1]
         h = 256
         mk = lambda *shape: torch.randn(*shape, generator=g).to(dev, in_dtype).requires_grad_(True)
         f_vis, f_txt, f_mid, f_enc = mk(B, V, d), mk(B, N, d), mk(B, V, h), mk(B, L, h)
