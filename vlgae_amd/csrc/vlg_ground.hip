@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
 template <typename In>
 static int launch_bwd(const void* txt, const void* vis, const float* gV, const uint16_t* argV, const float* gQ,
                       const uint16_t* argQ, const float* coef, int B, int Q, int V, int d, float* g_txt, float* g_vis,
-                      hipStream_t s) {
+                      hipStream_t s, bool max_q_terms = true) {
     using P = const typename In::T*;
     const size_t queue = (size_t)kGbWaves * kGbQueue * 12;
     for (int side = 0; side < 2; ++side) {
@@ -450,12 +450,16 @@ static int launch_bwd(const void* txt, const void* vis, const float* gV, const u
         const int cap = (int)((128 * 1024 - queue) / (sizeof(float) * d)) & ~15;
         if (cap < 16) return set_error(VLG_ERR_SHAPE, "grounding_loss: d=%d exceeds the LDS accumulator budget", d);
         int ny = (rows + cap - 1) / cap;
-        // small batches: more row chunks per caption / image so that the launch covers the chip (every chunk scans all the
-        // scattered terms but applies only its own rows; B = 64, V = 1369: caption side 2.0 -> 0.3 ms)
-        if (B * ny < 256) ny = std::max(ny, std::min((rows + 15) / 16, (512 + B - 1) / B));
+        // more row chunks per caption / image: small batches need them to cover the chip, and with enough scattered terms
+        // one row per wave plus the block-level scan wins outright (B = 64, V = 1369: caption side 2.0 -> 0.42 ms; config-2:
+        // 1.22 -> 1.18 ms for the whole loss; the same chunking without the block-level scan: 1.59 ms)
+        // terms scattered onto this side's rows: the max-over-Q ones for captions (absent when their factor is 0), max-over-V for images
+        const size_t n_scatter = side == 0 ? (max_q_terms ? (size_t)B * V : 0) : (size_t)B * Q;
+        if (rows > 48 && n_scatter >= 2 * (size_t)kCoopTerms) ny = (rows + 15) / 16;   // one row per wave + block-level scan (COOP)
+        else if (B * ny < 256) ny = std::max(ny, std::min((rows + 15) / 16, (512 + B - 1) / B));
         const int rpb = ny == 1 ? rows : (((rows + ny - 1) / ny) + 15) & ~15;
         // one row per wave and a long list of scattered terms: scan them once per block (COOP)
-        const bool coop = rows > 48 && rpb == kGbWaves && (size_t)B * (side == 0 ? V : Q) >= 2 * (size_t)kCoopTerms;
+        const bool coop = rows > 48 && rpb == kGbWaves && n_scatter >= 2 * (size_t)kCoopTerms;
         const size_t lds = sizeof(float) * (size_t)rpb * d + queue + (coop ? (size_t)kCoopCap * 12 + 256 : 0);
         void (*k)(P, P, const float*, const uint16_t*, const float*, const uint16_t*, const float*, int, int, int, int, int, float*);
         // register slots pay off up to 3 rows per wave; with 6 the per-lane selects cost more than the LDS round trips
@@ -533,8 +537,8 @@ int launch_reduced_backward(const void* txt, const void* vis, const uint8_t* tma
     hipLaunchKernelGGL(reduced_coef_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, s, g_logit, marg,
                        ws + p.off_sum, aV, tmask, vmask, B, Q, V, gV, coef);
     // the max-over-Q arrays are never read (their factor coef[1] is 0): any valid pointers do
-    const int rc = in_dtype == VLG_F32 ? launch_bwd<F32In>(txt, vis, gV, aV, gV, aV, coef, B, Q, V, d, g_txt, g_vis, s)
-                                       : launch_bwd<BF16In>(txt, vis, gV, aV, gV, aV, coef, B, Q, V, d, g_txt, g_vis, s);
+    const int rc = in_dtype == VLG_F32 ? launch_bwd<F32In>(txt, vis, gV, aV, gV, aV, coef, B, Q, V, d, g_txt, g_vis, s, false)
+                                       : launch_bwd<BF16In>(txt, vis, gV, aV, gV, aV, coef, B, Q, V, d, g_txt, g_vis, s, false);
     if (rc) return rc;
     return check_launch("align_reduced_backward");
 }
@@ -573,8 +577,8 @@ int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask
                        vmask, tmask, Q, part2);
     hipLaunchKernelGGL(ground_sum_kernel, dim3(1), dim3(64), 0, s, part, part2, B * y1, B * y2, num_token, w_v2t, out_sums, coef);
     if (g_txt || g_vis) {
-        const int rc = in_dtype == VLG_F32 ? launch_bwd<F32In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s)
-                                           : launch_bwd<BF16In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s);
+        const int rc = in_dtype == VLG_F32 ? launch_bwd<F32In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s, w_v2t > 0.f)
+                                           : launch_bwd<BF16In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s, w_v2t > 0.f);
         if (rc) return rc;
     }
     return check_launch("grounding_loss");
