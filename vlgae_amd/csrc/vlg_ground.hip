@@ -455,16 +455,16 @@ static int launch_bwd(const void* txt, const void* vis, const float* gV, const u
         // 1.22 -> 1.18 ms for the whole loss; the same chunking without the block-level scan: 1.59 ms)
         // terms scattered onto this side's rows: the max-over-Q ones for captions (absent when their factor is 0), max-over-V for images
         const size_t n_scatter = side == 0 ? (max_q_terms ? (size_t)B * V : 0) : (size_t)B * Q;
-        if (rows > 48 && n_scatter >= 2 * (size_t)kCoopTerms) ny = (rows + 15) / 16;   // one row per wave + block-level scan (COOP)
+        if (n_scatter >= 2 * (size_t)kCoopTerms) ny = (rows + 15) / 16;   // one row per wave + block-level scan (COOP)
         else if (B * ny < 256) ny = std::max(ny, std::min((rows + 15) / 16, (512 + B - 1) / B));
         const int rpb = ny == 1 ? rows : (((rows + ny - 1) / ny) + 15) & ~15;
         // one row per wave and a long list of scattered terms: scan them once per block (COOP)
-        const bool coop = rows > 48 && rpb == kGbWaves && n_scatter >= 2 * (size_t)kCoopTerms;
+        const bool coop = (rpb == kGbWaves || rows <= kGbWaves) && n_scatter >= 2 * (size_t)kCoopTerms;
         const size_t lds = sizeof(float) * (size_t)rpb * d + queue + (coop ? (size_t)kCoopCap * 12 + 256 : 0);
         void (*k)(P, P, const float*, const uint16_t*, const float*, const uint16_t*, const float*, int, int, int, int, int, float*);
         // register slots pay off up to 3 rows per wave; with 6 the per-lane selects cost more than the LDS round trips
-        if (side == 0) k = rows <= 48 ? ground_bwd_kernel<In, true, 3> : coop ? ground_bwd_kernel<In, true, 0, true> : ground_bwd_kernel<In, true, 0>;
-        else k = rows <= 48 ? ground_bwd_kernel<In, false, 3> : coop ? ground_bwd_kernel<In, false, 0, true> : ground_bwd_kernel<In, false, 0>;
+        if (side == 0) k = coop ? ground_bwd_kernel<In, true, 0, true> : rows <= 48 ? ground_bwd_kernel<In, true, 3> : ground_bwd_kernel<In, true, 0>;
+        else k = coop ? ground_bwd_kernel<In, false, 0, true> : rows <= 48 ? ground_bwd_kernel<In, false, 3> : ground_bwd_kernel<In, false, 0>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
