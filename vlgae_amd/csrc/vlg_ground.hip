@@ -155,7 +155,13 @@ __device__ __forceinline__ float4 row_ld4<BF16In>(const uint16_t* p) {
 // is done once per block instead of once per wave -- all 1024 lanes read kCoopTerms terms per trip (coalesced), the ones that
 // land in this block's rows are compacted IN TERM ORDER into a block queue in LDS (ballots + a 64-entry prefix over
 // (batch, wave)), and the waves then pick their own row's entries from LDS and sum the source rows in registers.
-constexpr int kCoopCap = 8192, kCoopBatches = 4, kCoopTerms = 64 * kGbWaves * kCoopBatches;
+#ifndef VLG_COOP_BATCHES
+#define VLG_COOP_BATCHES 4
+#endif
+#ifndef VLG_COOP_CAP
+#define VLG_COOP_CAP 8192
+#endif
+constexpr int kCoopCap = VLG_COOP_CAP, kCoopBatches = VLG_COOP_BATCHES, kCoopTerms = 64 * kGbWaves * kCoopBatches;
 
 template <typename In, bool SIDE_TXT, int NS, bool COOP = false>
 __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
             if (c_scatter == 0.f) continue;
             const int n_terms = B * n_other;
             if (COOP) {
-                static_assert(!COOP || (NS == 0 && kGbWaves * kCoopBatches == 64), "one prefix lane per (batch, wave)");
+                static_assert(!COOP || (NS == 0 && kGbWaves * kCoopBatches <= 64 && kCoopCap >= 2 * kCoopTerms), "one prefix lane per (batch, wave)");
                 int* bq_src = reinterpret_cast<int*>(acc + (size_t)n_rows * d) + 3 * kGbWaves * kGbQueue;   // [kCoopCap] source row (after the per-wave lists)
                 int* bq_lr = bq_src + kCoopCap;                                  // [kCoopCap] local destination row
                 float* bq_g = reinterpret_cast<float*>(bq_lr + kCoopCap);        // [kCoopCap] weight
@@ -330,13 +336,13 @@ __global__ __launch_bounds__(64 * kGbWaves) void ground_bwd_kernel(
                         if (lane == 0) cnt[u * kGbWaves + wave] = __popcll(hb[u]);
                     }
                     __syncthreads();
-                    int incl = cnt[lane];   // lane <-> (batch, wave) in term order; inclusive prefix over the 64 counts
+                    int incl = lane < kGbWaves * kCoopBatches ? cnt[lane] : 0;   // lane <-> (batch, wave) in term order; inclusive prefix
 #pragma unroll
                     for (int k = 1; k < 64; k <<= 1) {
                         const int o = __shfl_up(incl, k, 64);
                         if (lane >= k) incl += o;
                     }
-                    const int total = __shfl(incl, 63, 64);
+                    const int total = __shfl(incl, kGbWaves * kCoopBatches - 1, 64);
 #pragma unroll
                     for (int u = 0; u < kCoopBatches; ++u) {
                         const int e = u * kGbWaves + wave;
