@@ -332,6 +332,21 @@ def main():
             "ms": timed(lambda: align.grounding_decode(g_txt.detach(), g_vis.detach(), tmask, vmask), 20),
             "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in; alignment (diag + max_v) + top-5 / image arg-max, joint.py:512-596"}
 
+        # the same two at the reference's shipped factor layout (config/data/vlparse.yaml: 36 boxes -> obj 36 + rel 1296 +
+        # attr 36 + img 1 = 1369 columns, batch 64): 29 region groups per image, fewer captions than CUs
+        Bs, Vs = 64, 1369
+        s_txt, s_vis = mk(Bs, Q, d), mk(Bs, Vs, d)
+        s_tmask, s_vmask = tmask[:Bs], torch.ones(Bs, Vs, dtype=torch.bool, device=dev)
+        s_marg = marg[:Bs]
+        def ground_shipped():
+            total, _ = align.grounding_loss_factor_ce(s_txt, s_vis, s_tmask, s_vmask, s_marg, Bs * L, 1.0)
+            return torch.autograd.grad(total, [s_txt, s_vis])
+        out["shipped_layout"] = {
+            "grounding_loss_fwd_bwd_ms": timed(ground_shipped, 10),
+            "grounding_decode_ms": timed(lambda: align.grounding_decode(s_txt.detach(), s_vis.detach(), s_tmask, s_vmask), 10),
+            "shape": f"B=A={Bs} Q={Q} V={Vs} d={d} {args.dtype} in"}
+        del s_txt, s_vis
+
         # arc encoder's trilinear term (joint.py:282-284): M = B * (L + 1) rows, 128^3 weights
         a_child, a_parent = mk(B, N, d), mk(B, N, d)
         a_w1 = (torch.randn(d, d, d, generator=g) / d).to(dev, in_dtype).requires_grad_(True)
