@@ -2,29 +2,33 @@
 """bench.py -- sentences/sec of the batched inside-outside hot path on MI355X.
 
     python bench.py                          # 1 GPU, B=256 L=40 (BASELINE.json configs[1])
+    python bench.py --gpus 8                 # starts 8 fresh rank processes itself (torch.distributed.run), relays rank 0
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W          # the driver's form: ranks already exist
 
 A "step" is one pass of the hot path over one batch of synthetic root-merged potentials already resident
 in HBM: the fused DMV1o inside+outside launch (Log semiring) producing logZ [B] and the expected counts
 grad_dec [B,N,2,2,2] / grad_attach [B,N,N,2] -- what `torch.autograd.grad(DMV1o(...).partition.sum(), ...)`
 costs in the reference (src/model/joint.py:254-255).  With N > 1 ranks every rank owns 256 sentences (weak
-scaling, global batch 256*N, configs[2]) and each step ends with ONE RCCL all-reduce of the
-marginal-loss gradient (batch-summed expected counts, optionally padded to a model-sized buffer with
---grad-mb), issued asynchronously so it overlaps the next step's kernel; all of them complete inside the
-timed region.
+scaling, global batch 256*N, configs[2]) and each step ends with ONE RCCL all-reduce of the gradient: the
+batch-summed expected counts at the head of a flat fp32 buffer padded to the size of the VLGAE model's
+gradient (--grad-mb, default 28 MB), issued asynchronously so it overlaps the next step's
+kernel; all of them complete inside the timed region.  `value` is measured with that model-sized
+collective; `value_dp_grad_only` repeats the timed region with only the DP's own 14.8 KB gradient.
 
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# HSA reads this once, when the first HIP call initialises the runtime: it must be in the environment before that
+# (the host driver only supports dmabuf IPC; without it RCCL fails with hipIpcGetMemHandle: invalid argument).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,8 +39,52 @@ TRANS_LANES_PER_CLK = 8        # v_exp_f32 / v_log_f32: 8 cycles per wave64 inst
 CLOCK_GHZ = 2.4
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=256, help="sentences per GPU")
+    ap.add_argument("--len", type=int, default=40, dest="L")
+    ap.add_argument("--regions", type=int, default=36)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"], help="storage type of the potentials")
+    ap.add_argument("--ragged", action="store_true", help="random lengths instead of all = L")
+    ap.add_argument("--grad-mb", type=float, default=28.0,
+                    help="size of the all-reduced flat gradient in MB (default: the VLGAE model's ~7 M fp32 parameters)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--no-secondary", "--no-align", action="store_true", dest="no_secondary",
+                    help="headline only: skip the secondary single-GPU measurements")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes and relay rank 0's JSON line.
+
+    Runs BEFORE torch is imported: this parent never touches the GPU (no HIP call, not even a device count), it
+    only spawns `python -m torch.distributed.run ... bench.py <same args>` as a child, forwards the child's JSON
+    line(s) to stdout and everything else to stderr, and exits with the child's return code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    for line in proc.stdout:
+        is_json = line.lstrip().startswith("{") and '"metric"' in line
+        (sys.stdout if is_json else sys.stderr).write(line)
+        (sys.stdout if is_json else sys.stderr).flush()
+    return proc.wait()
+
+
 def synth(B, L, seed, device, dtype):
     """Potentials shaped like the scorer's output (normalised log-probs), SURVEY.md section 8d."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     dec = torch.randn(B, L, 2, 2, 2, generator=g).log_softmax(-1)
     attach = torch.randn(B, L, L, 2, generator=g)
@@ -52,20 +100,24 @@ def algorithmic_bytes(B, N, in_bytes):
 
 def exp_class_ops(lengths):
     """inside N^3-N lse terms + ~2x that outside, per sentence with N = len+1."""
-    n = lengths.astype(np.float64) + 1
+    import numpy as np
+    n = np.asarray(lengths, dtype=np.float64) + 1
     return float((3 * (n ** 3 - n)).sum())
 
 
 def cpu_baseline(B, L, seed, budget_s):
     """The CPU oracle (C restatement of the reference algorithm, fp32, OpenMP over sentences) timed on this
-    box's host cores on a bounded sample of the same workload."""
+    box's host cores on a bounded sample of the same workload.  BASELINE.md section 4 relates it to the
+    reference's own PyTorch-CPU path (measured side by side in the build container)."""
+    import numpy as np
+    import torch
     import oracle
     oracle.build()
     threads = oracle.max_threads()
-    B = max(B, 16 * threads)          # enough sentences per core for the OpenMP loop to scale
-    dec, attach, root = synth(B, L, seed, "cpu", torch.float32)
+    Bc = max(B, 16 * threads)          # enough sentences per core for the OpenMP loop to scale
+    dec, attach, root = synth(Bc, L, seed, "cpu", torch.float32)
     md, ma = oracle.dmv1o_merge(dec.numpy(), attach.numpy(), root.numpy())
-    lengths = np.full(B, L, dtype=np.int64)
+    lengths = np.full(Bc, L, dtype=np.int64)
     oracle.dmv1o(md[:8], ma[:8], lengths[:8], "log", np.float32)      # warm
     reps, t_total = 0, 0.0
     while t_total < budget_s and reps < 400:
@@ -73,296 +125,280 @@ def cpu_baseline(B, L, seed, budget_s):
         oracle.dmv1o(md, ma, lengths, "log", np.float32)
         t_total += time.perf_counter() - t0
         reps += 1
-    return {"value": B * reps / t_total, "unit": "sentences/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x (B={B}, L={L}) fp32 inside+outside, C oracle (oracle/vlg_oracle.c), "
-                      f"{threads} OpenMP threads, {t_total:.1f} s"}
+    return {"value": Bc * reps / t_total, "unit": "sentences/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x (B={Bc}, L={L}) fp32 inside+outside, C oracle (oracle/vlg_oracle.c), "
+                      f"{threads} OpenMP threads, {t_total:.1f} s",
+            "reference_equivalent_note": "the reference's own PyTorch-CPU path ran 0.08-0.12x of this port on the same "
+                                         "8 threads in the build container (BASELINE.md section 4)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=256, help="sentences per GPU")
-    ap.add_argument("--len", type=int, default=40, dest="L")
-    ap.add_argument("--regions", type=int, default=36)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"], help="storage type of the potentials")
-    ap.add_argument("--ragged", action="store_true", help="random lengths instead of all = L")
-    ap.add_argument("--grad-mb", type=float, default=0.0, help="pad the all-reduced gradient to this many MB")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
-    ap.add_argument("--no-align", action="store_true", help="skip the secondary alignment measurement")
-    args = ap.parse_args()
+def kernel_source_id():
+    """Short hash of the DP kernel sources: committed PMC profiles carry it so stale traffic figures are not reused."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("vlg_dp.hip", "vlg_dp_core.h"):
+        h.update(open(os.path.join(ROOT, "vlgae_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
 
-    from vlgae_amd import _C
+
+def pmc_traffic(workload_key):
+    """HBM bytes per launch from the PMC counters.  They cannot be collected live (rocprofv3 --pmc runs in its own
+    passes), so the figure comes from the newest committed profile of THIS workload -- FETCH_SIZE x2 (gfx950
+    correction) + WRITE_SIZE -- and is labelled with the kernel-source hash it was taken at."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        t = d.get(workload_key) or (d.get("dmv1o_kernel") if workload_key == "dmv1o_B256_L40_bf16" else None)
+        if t and "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+            best = (path, d, t)
+    if best is None:
+        return None, None
+    path, d, t = best
+    traffic = (2.0 * t["FETCH_SIZE"]["avg_KB"] + t["WRITE_SIZE"]["avg_KB"]) * 1024.0
+    same = d.get("kernel_source_id") == kernel_source_id()
+    src = (f"{os.path.relpath(path, ROOT)} (committed rocprofv3 --pmc passes FETCH_SIZE / WRITE_SIZE, FETCH x2; "
+           f"profiled at kernel source {d.get('kernel_source_id', 'r01')}, "
+           f"{'same as' if same else 'DIFFERENT from'} this build {kernel_source_id()} -- the byte traffic is set by the "
+           "I/O stage, which only moves when the load/store policy changes)")
+    return traffic, src
+
+
+class Headline:
+    """Buffers and launch closure of the headline workload on one rank."""
+
+    def __init__(self, args, rank, dev, dry):
+        import numpy as np
+        import torch
+        self.args, self.dev, self.dry = args, dev, dry
+        B, L = args.batch, args.L
+        N = L + 1
+        self.B, self.L, self.N = B, L, N
+        self.in_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        if args.ragged:
+            lengths = torch.randint(1, L + 1, (B,), generator=torch.Generator().manual_seed(7 + rank))
+            lengths[0] = L
+        else:
+            lengths = torch.full((B,), L, dtype=torch.long)
+        self.lengths_np = lengths.numpy().copy()
+        self.logZ = torch.empty(B, dtype=torch.float32, device=dev)
+        self.gdec = torch.zeros((B, N, 2, 2, 2), dtype=torch.float32, device=dev)
+        self.gatt = torch.zeros((B, N, N, 2), dtype=torch.float32, device=dev)
+        self.n_grad = N * 8 + N * N * 2
+        if dry:
+            self.launch = lambda: None
+            self.count_sum = lambda out: out[:self.n_grad].fill_(1.0)
+            return
+        from vlgae_amd import _C
+        import vlgae_amd.torch_struct as ts
+        lib = _C.lib()
+        dec, attach, root = synth(B, L, 1000 + rank, dev, torch.float32)
+        md32, ma32 = ts.DMV1o.merge(dec, attach, root)                    # merge is the scorer's job (ldndmv.py:209)
+        self.md, self.ma = md32.to(self.in_dtype).contiguous(), ma32.to(self.in_dtype).contiguous()
+        self.lengths = lengths.to(dev)
+        ws_bytes = lib.vlg_workspace_bytes(_C.OP_DMV1O_INSIDE_OUTSIDE, B, N, 0)
+        self.ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        dt_code = _C.BF16 if self.in_dtype == torch.bfloat16 else _C.F32
+        self.stream = torch.cuda.current_stream(dev)
+        sp = _C.ctypes.c_void_p(self.stream.cuda_stream)
+        p = [_C.ptr(x) for x in (self.md, self.ma, self.lengths, self.logZ, self.gdec, self.gatt, self.ws)]
+
+        def launch():
+            rc = lib.vlg_dmv1o_inside_outside(p[0], p[1], p[2], B, N, dt_code, 0, None, p[3], p[4], p[5], p[6], ws_bytes, sp)
+            if rc:
+                _C.check(rc, "dmv1o_inside_outside")
+
+        def count_sum(out):   # marginal-loss gradient of position-tied parameters = batch-summed counts, one launch
+            rc = lib.vlg_dmv1o_count_sum(p[4], p[5], B, N, _C.ptr(out), sp)
+            if rc:
+                _C.check(rc, "dmv1o_count_sum")
+
+        self.launch, self.count_sum = launch, count_sum
+
+
+def run(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     from vlgae_amd import dist as vdist
-    from vlgae_amd.torch_struct import functional as F
-    import vlgae_amd.torch_struct as ts
 
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
-    # Debug aid for boxes with fewer GPUs than ranks (functional test of the N > 1 path only, never a
-    # measurement): VLGAE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo instead of RCCL.
-    share = os.environ.get("VLGAE_BENCH_SHARE_GPU") == "1"
-    rank, local_rank, world = vdist.init_from_env(backend="gloo" if share else None)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    if share:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    lib = _C.lib()
-
-    B, L = args.batch, args.L
-    N = L + 1
-    in_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    dec, attach, root = synth(B, L, 1000 + rank, dev, torch.float32)
-    md32, ma32 = ts.DMV1o.merge(dec, attach, root)                    # merge is the scorer's job (ldndmv.py:209)
-    md, ma = md32.to(in_dtype).contiguous(), ma32.to(in_dtype).contiguous()
-    if args.ragged:
-        lengths = torch.randint(1, L + 1, (B,), generator=torch.Generator().manual_seed(7 + rank))
-        lengths[0] = L
+    dry = os.environ.get("VLGAE_BENCH_DRYRUN") == "1"      # CPU/gloo plumbing test of the launcher path: NO kernels run
+    share = os.environ.get("VLGAE_BENCH_SHARE_GPU") == "1"  # debug: every rank on cuda:0 over gloo (never a measurement)
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world_env == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world_env}"
+    backend = "gloo" if (dry or share) else None            # None -> nccl (= RCCL); chosen without probing the GPU
+    rank, local_rank, world = vdist.init_from_env(backend=backend)
+    if dry:
+        dev = torch.device("cpu")
     else:
-        lengths = torch.full((B,), L, dtype=torch.long)
-    lengths_np = lengths.numpy().copy()
-    lengths = lengths.to(dev)
+        assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+        local_rank = 0 if share else local_rank
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    sync = (lambda: None) if dry else (lambda: torch.cuda.synchronize(dev))
 
-    logZ = torch.empty(B, dtype=torch.float32, device=dev)
-    gdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dev)
-    gatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dev)
-    ws_bytes = lib.vlg_workspace_bytes(_C.OP_DMV1O_INSIDE_OUTSIDE, B, N, 0)
-    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-    dt_code = _C.BF16 if in_dtype == torch.bfloat16 else _C.F32
-    stream = torch.cuda.current_stream(dev)
-    sp = _C.ctypes.c_void_p(stream.cuda_stream)
-    p = [_C.ptr(x) for x in (md, ma, lengths, logZ, gdec, gatt, ws)]
-
-    n_grad = N * 8 + N * N * 2
-    pad = int(args.grad_mb * 1e6 / 4)
-    reducer = vdist.GradAllReducer(max(n_grad, pad), dev) if world > 1 else None
-
-    def step():
-        rc = lib.vlg_dmv1o_inside_outside(p[0], p[1], p[2], B, N, dt_code, 0, None, p[3], p[4], p[5], p[6], ws_bytes, sp)
-        if rc:
-            _C.check(rc, "dmv1o_inside_outside")
-        if reducer is not None:   # marginal-loss gradient of position-tied parameters = batch-summed counts
-            buf = reducer.buffer
-            torch.sum(gdec.view(B, -1), 0, out=buf[:N * 8])
-            torch.sum(gatt.view(B, -1), 0, out=buf[N * 8:n_grad])
-            reducer.launch()
+    h = Headline(args, rank, dev, dry)
+    B, L, N = h.B, h.L, h.N
 
     def barrier():
-        torch.cuda.synchronize(dev)
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    if reducer is not None:
-        reducer.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
+    def timed_region(reducer):
+        """W untimed warmup steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
+        def step():
+            h.launch()
+            if reducer is not None:
+                h.count_sum(reducer.buffer)
+                reducer.launch()
+        for _ in range(args.warmup):
+            step()
+        if reducer is not None:
+            reducer.wait()
+        barrier()
+        if not dry:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(h.stream)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if not dry:
+            ev1.record(h.stream)
+        if reducer is not None:
+            reducer.wait()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        gpu_ms = None if dry else ev0.elapsed_time(ev1)
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, gpu_ms
+
+    comm = {}
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        comm["rccl_ranks_seen"] = int(round(float(ones.item())))
+        comm["backend"] = dist.get_backend()
+        n_model = max(h.n_grad, int(args.grad_mb * 1e6 / 4))
+        big = vdist.GradAllReducer(n_model, dev)
+        # the collective alone: one all-reduce of the model-sized buffer at a time, host-synchronised
+        for _ in range(3):
+            dist.all_reduce(big.bufs[0])
+        barrier()
+        t0 = time.perf_counter()
+        n_ar = 10
+        for _ in range(n_ar):
+            dist.all_reduce(big.bufs[0])
+        barrier()
+        ar_s = (time.perf_counter() - t0) / n_ar
+        big.bufs[0].zero_()
+        comm.update(allreduce_ms=ar_s * 1e3, allreduce_bytes=n_model * 4,
+                    allreduce_busbw_GBs=2.0 * (world - 1) / world * n_model * 4 / ar_s / 1e9)
+        elapsed, gpu_ms = timed_region(big)
+        small = vdist.GradAllReducer(h.n_grad, dev)
+        elapsed_small, _ = timed_region(small)
+        # the reduced counts must be the sum over ranks: every rank's attach counts sum to its word count
+        total_words = torch.tensor([float(h.lengths_np.sum())], dtype=torch.float64, device=dev)
+        dist.all_reduce(total_words)
+        if not dry:
+            got = float(small.bufs[small.cur ^ 1][N * 8:h.n_grad].sum().item())
+            assert abs(got - float(total_words.item())) < 1e-3 * float(total_words.item()), (got, float(total_words.item()))
+    else:
+        elapsed, gpu_ms = timed_region(None)
+        elapsed_small = None
 
     # ---- checks outside the timed region: finite, and counts sum to the number of words ----
-    assert bool(torch.isfinite(logZ).all()), "non-finite logZ"
-    arcs = float(gatt.sum().item())
-    assert abs(arcs - float(lengths_np.sum())) < 1e-3 * lengths_np.sum(), (arcs, lengths_np.sum())
+    if not dry:
+        assert bool(torch.isfinite(h.logZ).all()), "non-finite logZ"
+        arcs = float(h.gatt.sum().item())
+        assert abs(arcs - float(h.lengths_np.sum())) < 1e-3 * h.lengths_np.sum(), (arcs, h.lengths_np.sum())
 
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
     sent_per_s = B * world * args.steps / elapsed
-    kern_s = gpu_ms * 1e-3 / args.steps                   # HIP events on the launch stream, back-to-back launches
-    alg_bytes = algorithmic_bytes(B, N, 2 if in_dtype == torch.bfloat16 else 4)
-    achieved = alg_bytes / kern_s / 1e9
-    exp_ops = exp_class_ops(lengths_np)
-    exp_peak = N_CU * SIMD_PER_CU * TRANS_LANES_PER_CLK * CLOCK_GHZ * 1e9
-    # HBM bytes per launch from the PMC counters: cannot be collected live (rocprofv3 --pmc runs in its own pass);
-    # taken from the committed profile of THIS workload, with the gfx950 FETCH_SIZE x2 correction applied.
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
-    if os.path.exists(prof) and (B, L, args.dtype, bool(args.ragged)) == (256, 40, "bf16", False):
-        t = json.load(open(prof)).get("dmv1o_kernel")
-        if t:
-            traffic = (2.0 * t["FETCH_SIZE"]["avg_KB"] + t["WRITE_SIZE"]["avg_KB"]) * 1024.0
     out = {
         "metric": "sentences/sec, batched inside-outside L=%d B=%d" % (L, B),
         "value": sent_per_s, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "storage_dtype": args.dtype,
+        "data": "synthetic" if not dry else "DRY RUN: no kernels ran (launcher / collective plumbing on CPU, gloo); not a measurement",
         "config": {"workload": "DMV1o inside+outside (Log semiring) -> logZ + expected counts, "
-                               f"B={B}/GPU L={L} N={N}, potentials stored {args.dtype}, fp32 charts; "
+                               f"B={B}/GPU L={L} N={N}, potentials stored {args.dtype}, fp32 charts and arithmetic; "
                                "BASELINE.json configs[1]" + (" sharded x%d, configs[2]" % world if world > 1 else ""),
                    "global_batch": B * world, "seq_len": L, "ragged": bool(args.ragged),
                    "parallelism": (f"dp{world}" if world > 1 else "single") + (" (DEBUG: ranks share one GPU, gloo)" if share else ""),
-                   "allreduce_floats": (max(n_grad, pad) if world > 1 else 0)},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r01_g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)" if traffic else None,
-                     "kernel": "dmv1o_kernel<Log, mode 0 (all charts in LDS), fused inside+outside>", "kernel_us": kern_s * 1e6,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "latency-bound DP: 2(N-1) barrier-separated width steps per sentence, one workgroup "
-                             "per sentence; see exp_rate for the bound that binds"},
-        "exp_rate": {"achieved_Gops": exp_ops / kern_s / 1e9, "peak_Gops": exp_peak / 1e9,
-                     "frac": exp_ops / kern_s / exp_peak, "ops_per_launch": exp_ops,
-                     "note": "exp-class ops (N^3-N inside + 2x outside per sentence) vs v_exp_f32 issue peak "
-                             "256 CU x 4 SIMD x 8 lanes/clk x 2.4 GHz"},
+                   "allreduce_floats": (comm["allreduce_bytes"] // 4 if world > 1 else 0)},
     }
+    if world > 1:
+        out["value_dp_grad_only"] = B * world * args.steps / elapsed_small
+        out["ms_per_step_dp_grad_only"] = elapsed_small * 1e3 / args.steps
+        out["comm"] = dict(comm, note="value: every step all-reduces the model-sized flat gradient (--grad-mb, one RCCL call, "
+                                      "overlapping the next step's kernel); value_dp_grad_only: only the DP's own "
+                                      f"{h.n_grad * 4} B of batch-summed counts")
+    if dry:
+        out["dry_run"] = True
+        print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    # ---- the same step through the drop-in Python API (DMV1o(...).partition + autograd.grad) ----
-    d_, a_ = md.detach().requires_grad_(), ma.detach().requires_grad_()
-    for _ in range(10):
-        torch.autograd.grad(ts.DMV1o([d_, a_], lengths).partition.sum(), [d_, a_])
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    n_api = 100
-    for _ in range(n_api):
-        torch.autograd.grad(ts.DMV1o([d_, a_], lengths).partition.sum(), [d_, a_])
-    torch.cuda.synchronize(dev)
-    out["api_path"] = {"sentences_per_s": B * n_api / (time.perf_counter() - t0),
-                       "what": "DMV1o([dec,attach],lengths).partition.sum() + torch.autograd.grad, 1 GPU"}
+    kern_s = gpu_ms * 1e-3 / args.steps                   # HIP events on the launch stream, back-to-back launches
+    alg_bytes = algorithmic_bytes(B, N, 2 if args.dtype == "bf16" else 4)
+    achieved = alg_bytes / kern_s / 1e9
+    exp_ops = exp_class_ops(h.lengths_np)
+    exp_peak = N_CU * SIMD_PER_CU * TRANS_LANES_PER_CLK * CLOCK_GHZ * 1e9
+    traffic, traffic_src = (None, None)
+    if (B, L, args.dtype, bool(args.ragged)) == (256, 40, "bf16", False):
+        traffic, traffic_src = pmc_traffic("dmv1o_B256_L40_bf16")
+    out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                       "kernel": "dmv1o_kernel<Log, mode 0 (all charts in LDS), fused inside+outside>",
+                       "kernel_us": kern_s * 1e6 if world == 1 else None,
+                       "stream_us_per_step": kern_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
+                       "note": "latency-bound DP: 2(N-1) barrier-separated width steps per sentence, one workgroup "
+                               "per sentence; see exp_rate for the bound that binds"
+                               + ("" if world == 1 else "; multi-GPU: the stream time per step includes the count-sum launch and waits on the collective")}
+    out["exp_rate"] = {"achieved_Gops": exp_ops / kern_s / 1e9, "peak_Gops": exp_peak / 1e9,
+                       "frac": exp_ops / kern_s / exp_peak, "ops_per_launch": exp_ops,
+                       "note": "exp-class ops (N^3-N inside + 2x outside per sentence) vs v_exp_f32 issue peak "
+                               "256 CU x 4 SIMD x 8 lanes/clk x 2.4 GHz"}
 
-    # ---- Viterbi decode of the same batch: Max-semiring inside + back-pointer walk -> head vector (joint.py:256-258) ----
-    from vlgae_amd.torch_struct import functional as Fn
-    for _ in range(5):
-        Fn.dmv1o_decode(md, ma, lengths)
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(50):
-        Fn.dmv1o_decode(md, ma, lengths)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    out["decode"] = {"us": e0.elapsed_time(e1) / 50 * 1e3, "sentences_per_s": B * 50 / (e0.elapsed_time(e1) * 1e-3),
-                     "what": "dmv1o_decode: best tree as heads [B,N], on device"}
-    pair = lambda: ts.DMV1o([md, ma], lengths).marginals_and_heads()
-    for _ in range(5):
-        pair()
-    torch.cuda.synchronize(dev)
-    e0.record()
-    for _ in range(50):
-        pair()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    out["marginals_and_heads"] = {"us": e0.elapsed_time(e1) / 50 * 1e3,
-                                  "what": "arc marginals + Viterbi heads of one batch (joint.py:251-258), two HIP streams"}
-
-    # ---- secondary: the region x word alignment that feeds / consumes the DP (joint.py:406-419) ----
-    if not args.no_align and world == 1:   # single-GPU secondary measurements; multi-GPU runs report the headline only
-        from vlgae_amd import align
-        Q, V, d = 2 * N, args.regions, 128
-        g = torch.Generator().manual_seed(5)
-        txt = torch.randn(B, Q, d, generator=g).to(dev, in_dtype)
-        vis = torch.randn(B, V, d, generator=g).to(dev, in_dtype)
-        for full in (True, False):
-            kw = dict(full=full, max_v=not full, max_q=not full)
-            for _ in range(20):   # long enough for the clocks to settle after the idle gap before this section
-                r = align.bilinear_align(txt, vis, **kw)
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            n_al = 100
-            for _ in range(n_al):
-                r = align.bilinear_align(txt, vis, **kw)
-            e1.record()
-            torch.cuda.synchronize(dev)
-            del r
-            sec = e0.elapsed_time(e1) * 1e-3 / n_al
-            flops = 2.0 * B * B * Q * V * d
-            esz = 2 if in_dtype == torch.bfloat16 else 4
-            byts = (B * Q + B * V) * d * esz + (B * B * Q * V * 4 if full else (B * B * (Q + V)) * 4)
-            out["align_full" if full else "align_fused_max"] = {
-                "sentences_per_s": B / sec, "ms": sec * 1e3, "TFLOP/s": flops / sec / 1e12,
-                "GB/s": byts / sec / 1e9, "frac_hbm": byts / sec / 1e9 / HBM_PEAK_GBS,
-                "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in, fp32 out"}
-
-        # the two consumers on the training path: attention-fuse (joint.py:670-674) and the grounding loss on the
-        # fused maxima (joint.py:439-491), forward + gradients, through the host API
-        def timed(fn, n):
-            """ms per call: median of three windows of n calls (a host hiccup inside one window -- an allocator refill,
-            a scheduler tick -- otherwise lands in a host-bound entry as a 10x outlier)."""
-            for _ in range(10):
-                fn()
-            wins = []
-            for _ in range(3):
-                torch.cuda.synchronize(dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(n):
-                    fn()
-                e1.record()
-                torch.cuda.synchronize(dev)
-                wins.append(e0.elapsed_time(e1) / n)
-            return sorted(wins)[1]
-        h = 256
-        mk = lambda *shape: torch.randn(*shape, generator=g).to(dev, in_dtype).requires_grad_(True)
-        f_vis, f_txt, f_mid, f_enc = mk(B, V, d), mk(B, N, d), mk(B, V, h), mk(B, L, h)
-        ln_w, ln_b = torch.ones(h, device=dev, requires_grad=True), torch.zeros(h, device=dev, requires_grad=True)
-        dout = torch.randn(B, L, h, generator=g).to(dev)
-        leaves = [f_vis, f_txt, f_mid, f_enc, ln_w, ln_b]
-        out["attention_fuse"] = {
-            "fwd_ms": timed(lambda: align.attention_fuse(f_vis.detach(), f_txt.detach(), f_mid.detach(), f_enc.detach(),
-                                                         ln_w.detach(), ln_b.detach(), 1e-5), 50),
-            "fwd_bwd_ms": timed(lambda: torch.autograd.grad(align.attention_fuse(*leaves, 1e-5), leaves, dout), 50),
-            "shape": f"B={B} L={L} V={V} d={d} h={h} {args.dtype} in; host API incl. autograd overhead"}
-        tmask = torch.ones(B, Q, dtype=torch.bool, device=dev)
-        tmask[:, 0] = tmask[:, N] = False
-        vmask = torch.ones(B, V, dtype=torch.bool, device=dev)
-        marg = torch.rand(B, Q, generator=g).to(dev) * tmask
-        g_txt, g_vis = mk(B, Q, d), mk(B, V, d)
-        def ground():
-            total, _ = align.grounding_loss_factor_ce(g_txt, g_vis, tmask, vmask, marg, B * L, 1.0)
-            return torch.autograd.grad(total, [g_txt, g_vis])
-        out["grounding_loss"] = {"fwd_bwd_ms": timed(ground, 10),
-                                 "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in; loss + gradients, no [B,A,Q,V] tensor"}
-
-        out["grounding_decode"] = {
-            "ms": timed(lambda: align.grounding_decode(g_txt.detach(), g_vis.detach(), tmask, vmask), 20),
-            "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in; alignment (diag + max_v) + top-5 / image arg-max, joint.py:512-596"}
-
-        # the same two at the reference's shipped factor layout (config/data/vlparse.yaml: 36 boxes -> obj 36 + rel 1296 +
-        # attr 36 + img 1 = 1369 columns, batch 64): 29 region groups per image, fewer captions than CUs
-        Bs, Vs = 64, 1369
-        s_txt, s_vis = mk(Bs, Q, d), mk(Bs, Vs, d)
-        s_tmask, s_vmask = tmask[:Bs], torch.ones(Bs, Vs, dtype=torch.bool, device=dev)
-        s_marg = marg[:Bs]
-        def ground_shipped():
-            total, _ = align.grounding_loss_factor_ce(s_txt, s_vis, s_tmask, s_vmask, s_marg, Bs * L, 1.0)
-            return torch.autograd.grad(total, [s_txt, s_vis])
-        out["shipped_layout"] = {
-            "grounding_loss_fwd_bwd_ms": timed(ground_shipped, 10),
-            "grounding_decode_ms": timed(lambda: align.grounding_decode(s_txt.detach(), s_vis.detach(), s_tmask, s_vmask), 10),
-            "shape": f"B=A={Bs} Q={Q} V={Vs} d={d} {args.dtype} in"}
-        del s_txt, s_vis
-
-        # arc encoder's trilinear term (joint.py:282-284): M = B * (L + 1) rows, 128^3 weights
-        a_child, a_parent = mk(B, N, d), mk(B, N, d)
-        a_w1 = (torch.randn(d, d, d, generator=g) / d).to(dev, in_dtype).requires_grad_(True)
-        a_dout = torch.randn(B, N, d, generator=g).to(dev)
-        out["arc_trilinear"] = {
-            "fwd_ms": timed(lambda: align.arc_trilinear(a_child.detach(), a_w1.detach(), a_parent.detach()), 20),
-            "fwd_bwd_ms": timed(lambda: torch.autograd.grad(align.arc_trilinear(a_child, a_w1, a_parent),
-                                                            [a_child, a_w1, a_parent], a_dout), 10),
-            "shape": f"M={B * N} X=H=Y={d} {args.dtype} in; einsum('bcx,xhy,bcy->bch') without the [M,H,Y] intermediate"}
+    if world == 1 and not args.no_secondary:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_secondary
+        bench_secondary.run_all(out, args, h, dev)
 
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(B, L, 1000, args.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = sent_per_s / out["cpu_baseline"]["value"]
+        if "long_sentence" in out:
+            cb = cpu_baseline(B, 80, 1000, min(args.cpu_seconds, 8.0))
+            out["long_sentence"]["cpu_baseline"] = cb
+            out["long_sentence"]["speedup_vs_cpu_baseline"] = out["long_sentence"]["sentences_per_s"] / cb["value"]
     print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+    run(args)
 
 
 if __name__ == "__main__":

@@ -112,6 +112,11 @@ int vlg_dmv1o_rules(const void* attach_rule, const void* dec, const void* root_r
 int vlg_dmv1o_merge(const void* dec, const void* attach, const void* root, int B, int L, int in_dtype, float one,
                     float zero, float* dec_wroot, float* attach_wroot, void* stream);
 
+/* Batch sum of the expected counts, out[N*8 + N*N*2] = sum_b [grad_dec[b] | grad_attach[b]]: the gradient of
+ * position-tied potentials, i.e. the marginal-loss gradient that the data-parallel all-reduce carries
+ * (Lightning DDP in the reference, config/trainer/train.yaml:27-29; bench.py's multi-GPU step).  Fixed summation order. */
+int vlg_dmv1o_count_sum(const float* grad_dec, const float* grad_attach, int B, int N, float* out, void* stream);
+
 /* Bytes of caller-provided scratch the op needs for (B, N); 0 when the charts fit in LDS. */
 size_t vlg_workspace_bytes(int op, int B, int N, int semiring);
 

@@ -81,3 +81,51 @@ def test_sharded_gradient_allreduce_matches_full_batch(tmp_path):
     for rank in range(world):
         errs = np.load(tmp_path / f"rank{rank}.npy")
         assert errs.shape == (2, 3) and errs.max() <= 2e-4, errs     # sums of ~10 fp32 expected-count tensors
+
+
+def _run_bench(cmd, extra_env):
+    import json
+    import subprocess
+    env = dict(os.environ, VLGAE_BENCH_DRYRUN="1", OMP_NUM_THREADS="1", **extra_env)
+    env.pop("WORLD_SIZE", None)
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]   # gloo's own C++ chatter
+    assert len(lines) == 1, proc.stdout          # exactly ONE JSON line on stdout, from rank 0
+    return json.loads(lines[0])
+
+
+def _check_dry_line(out, world):
+    assert out["dry_run"] is True and "DRY RUN" in out["data"]      # can never be mistaken for a measurement
+    assert out["n_gpus"] == world and out["scaling"] == "weak" and out["steps"] == 3 and out["warmup"] == 1
+    assert out["config"]["global_batch"] == 256 * world and out["config"]["parallelism"] == f"dp{world}"
+    assert out["comm"]["rccl_ranks_seen"] == world and out["comm"]["backend"] == "gloo"
+    assert out["config"]["allreduce_floats"] == 125000 and out["comm"]["allreduce_bytes"] == 500000
+    assert out["comm"]["allreduce_ms"] > 0 and out["value"] > 0 and out["value_dp_grad_only"] > 0
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_ranks_and_relays_one_json_line():
+    """`python bench.py --gpus 2` with no torchrun around it: the parent (which never touches a GPU) starts the rank
+    processes, rank 0's JSON line comes back on stdout.  VLGAE_BENCH_DRYRUN=1 swaps the kernels for no-ops and RCCL for
+    gloo so the launcher / process-group / reducer path runs on CPU."""
+    out = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--grad-mb", "0.5",
+                      "--cpu-seconds", "0"], {})
+    _check_dry_line(out, 2)
+
+
+@pytest.mark.timeout(300)
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    out = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                      "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
+                      "--steps", "3", "--warmup", "1", "--grad-mb", "0.5", "--cpu-seconds", "0"], {})
+    _check_dry_line(out, 2)
+
+
+def test_bench_parent_does_not_import_torch_before_spawning():
+    """The self-launching parent must not initialise the GPU: it decides from argv/env alone, before `import torch`."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    top_imports = {a.name.split(".")[0] for n in tree.body if isinstance(n, ast.Import) for a in n.names}
+    top_imports |= {n.module.split(".")[0] for n in tree.body if isinstance(n, ast.ImportFrom)}
+    assert "torch" not in top_imports and "vlgae_amd" not in top_imports and "numpy" not in top_imports

@@ -894,3 +894,22 @@ def test_marginals_and_heads_two_streams(ts):
         marg, heads = ts.DMV1o([md, ma], lengths).marginals_and_heads()
         d2 = ts.DMV1o([md, ma], lengths)
         assert torch.equal(marg, d2.marginals) and torch.equal(heads, d2.argmax_heads)
+
+
+@pytest.mark.parametrize("B,N", [(256, 41), (7, 5), (1, 2), (300, 81)])
+def test_count_sum_matches_batch_sum(B, N):
+    """vlg_dmv1o_count_sum: the batch-summed expected counts the data-parallel all-reduce carries (bench.py's multi-GPU
+    step).  Against a float64 sum: the kernel's fixed-order fp32 sum of B terms is within B * 2^-24 relative."""
+    from vlgae_amd import _C
+    g = torch.Generator().manual_seed(B * 131 + N)
+    gdec = torch.rand(B, N, 2, 2, 2, generator=g).to(dev())
+    gatt = torch.rand(B, N, N, 2, generator=g).to(dev())
+    out = torch.full((N * 8 + N * N * 2 + 5,), -7.0, device=dev())
+    _C.check(_C.lib().vlg_dmv1o_count_sum(_C.ptr(gdec), _C.ptr(gatt), B, N, _C.ptr(out), _C.stream_of(out)), "count_sum")
+    want = torch.cat([gdec.double().view(B, -1).sum(0), gatt.double().view(B, -1).sum(0)])
+    got = out[:-5].double()
+    assert float((got - want).abs().max()) <= B * 2.0 ** -22
+    assert bool((out[-5:] == -7.0).all())          # nothing written past the end
+    out2 = torch.empty_like(out)
+    _C.check(_C.lib().vlg_dmv1o_count_sum(_C.ptr(gdec), _C.ptr(gatt), B, N, _C.ptr(out2), _C.stream_of(out)), "count_sum")
+    assert torch.equal(out2[:-5], out[:-5])        # fixed order: identical bits run to run

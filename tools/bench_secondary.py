@@ -1,0 +1,199 @@
+"""Secondary single-GPU measurements appended to bench.py's JSON line (rank 0, N = 1 only).
+
+None of them is the headline `value`; each entry says what it timed.  Kernel-only entries use HIP events on the launch
+stream around back-to-back launches; "host API" entries include the Python / autograd overhead of the drop-in classes.
+"""
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+N_CU, SIMD_PER_CU, TRANS_LANES_PER_CLK, CLOCK_GHZ = 256, 4, 8, 2.4
+
+
+def _events(fn, n, warm, dev):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e-3 / n      # seconds per call
+
+
+def timed(fn, n, dev):
+    """ms per call: median of three windows of n calls (a host hiccup inside one window -- an allocator refill,
+    a scheduler tick -- otherwise lands in a host-bound entry as a 10x outlier)."""
+    for _ in range(10):
+        fn()
+    wins = []
+    for _ in range(3):
+        wins.append(_events(fn, n, 0, dev) * 1e3)
+    return sorted(wins)[1]
+
+
+def dp_raw(B, L, dtype, dev, seed=1000):
+    """Raw C-ABI launch closure of the fused DMV1o inside+outside kernel on fresh synthetic potentials."""
+    import bench
+    from vlgae_amd import _C
+    import vlgae_amd.torch_struct as ts
+    lib = _C.lib()
+    N = L + 1
+    dec, attach, root = bench.synth(B, L, seed, dev, torch.float32)
+    md32, ma32 = ts.DMV1o.merge(dec, attach, root)
+    md, ma = md32.to(dtype).contiguous(), ma32.to(dtype).contiguous()
+    lengths = torch.full((B,), L, dtype=torch.long, device=dev)
+    logZ = torch.empty(B, dtype=torch.float32, device=dev)
+    gdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dev)
+    gatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dev)
+    ws_bytes = lib.vlg_workspace_bytes(_C.OP_DMV1O_INSIDE_OUTSIDE, B, N, 0)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    code = _C.BF16 if dtype == torch.bfloat16 else _C.F32
+    sp = _C.ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = [_C.ptr(x) for x in (md, ma, lengths, logZ, gdec, gatt, ws)]
+    keep = (md, ma, lengths, logZ, gdec, gatt, ws)
+
+    def launch():
+        rc = lib.vlg_dmv1o_inside_outside(p[0], p[1], p[2], B, N, code, 0, None, p[3], p[4], p[5], p[6], ws_bytes, sp)
+        if rc:
+            _C.check(rc, "dmv1o_inside_outside")
+    launch.keep = keep
+    launch.ws_bytes = ws_bytes
+    return launch
+
+
+def dp_entry(B, L, dtype_name, dev, n=100):
+    import bench
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    launch = dp_raw(B, L, dtype, dev)
+    sec = _events(launch, n, 10, dev)
+    logZ, gatt = launch.keep[3], launch.keep[5]
+    assert bool(torch.isfinite(logZ).all())
+    assert abs(float(gatt.sum().item()) - B * L) < 1e-3 * B * L
+    N = L + 1
+    alg = bench.algorithmic_bytes(B, N, 2 if dtype_name == "bf16" else 4)
+    ops = bench.exp_class_ops(np.full(B, L))
+    exp_peak = N_CU * SIMD_PER_CU * TRANS_LANES_PER_CLK * CLOCK_GHZ * 1e9
+    return {"us": sec * 1e6, "sentences_per_s": B / sec,
+            "workload": f"DMV1o inside+outside (Log), B={B} L={L} N={N}, potentials stored {dtype_name}, raw C-ABI launches",
+            "workspace_bytes": int(launch.ws_bytes),
+            "roofline": {"bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg, "traffic": None},
+            "exp_rate": {"achieved_Gops": ops / sec / 1e9, "peak_Gops": exp_peak / 1e9, "frac": ops / sec / exp_peak}}
+
+
+def run_all(out, args, h, dev):
+    import vlgae_amd.torch_struct as ts
+    from vlgae_amd.torch_struct import functional as Fn
+    from vlgae_amd import align
+    B, L, N = h.B, h.L, h.N
+    md, ma, lengths = h.md, h.ma, h.lengths
+    in_dtype = h.in_dtype
+
+    # ---- the same headline step with fp32-stored potentials (what DMV1o.merge emits, distributions.py:253-265) ----
+    other = "f32" if args.dtype == "bf16" else "bf16"
+    out["headline_" + other] = dp_entry(B, L, other, dev)
+
+    # ---- configs[3]: B=256 L=80 long-sentence stress, fused inside+outside ----
+    if L != 80:
+        out["long_sentence"] = dp_entry(B, 80, args.dtype, dev, n=30)
+
+    # ---- the same step through the drop-in Python API (DMV1o(...).partition + autograd.grad) ----
+    d_, a_ = md.detach().requires_grad_(), ma.detach().requires_grad_()
+    for _ in range(10):
+        torch.autograd.grad(ts.DMV1o([d_, a_], lengths).partition.sum(), [d_, a_])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n_api = 100
+    for _ in range(n_api):
+        torch.autograd.grad(ts.DMV1o([d_, a_], lengths).partition.sum(), [d_, a_])
+    torch.cuda.synchronize(dev)
+    out["api_path"] = {"sentences_per_s": B * n_api / (time.perf_counter() - t0),
+                       "what": "DMV1o([dec,attach],lengths).partition.sum() + torch.autograd.grad, 1 GPU"}
+
+    # ---- Viterbi decode of the same batch: Max-semiring inside + back-pointer walk -> head vector (joint.py:256-258) ----
+    sec = _events(lambda: Fn.dmv1o_decode(md, ma, lengths), 50, 5, dev)
+    out["decode"] = {"us": sec * 1e6, "sentences_per_s": B / sec, "what": "dmv1o_decode: best tree as heads [B,N], on device"}
+    sec = _events(lambda: ts.DMV1o([md, ma], lengths).marginals_and_heads(), 50, 5, dev)
+    out["marginals_and_heads"] = {"us": sec * 1e6,
+                                  "what": "arc marginals + Viterbi heads of one batch (joint.py:251-258), two HIP streams"}
+
+    # ---- the region x word alignment that feeds / consumes the DP (joint.py:406-419) ----
+    # features as SURVEY 8(d) specifies: 2048-d region / 768-d word vectors through fixed-seed Linear(-> 128), no bias
+    Q, V, d = 2 * N, args.regions, 128
+    g = torch.Generator().manual_seed(5)
+    w_vis = (torch.randn(2048, d, generator=g) / 2048 ** 0.5).to(dev)
+    w_txt = (torch.randn(768, d, generator=g) / 768 ** 0.5).to(dev)
+    vis = (torch.randn(B, V, 2048, generator=g).to(dev) @ w_vis).to(in_dtype).contiguous()
+    txt = (torch.randn(B, Q, 768, generator=g).to(dev) @ w_txt).to(in_dtype).contiguous()
+    del w_vis, w_txt
+    for full in (True, False):
+        kw = dict(full=full, max_v=not full, max_q=not full)
+        sec = _events(lambda: align.bilinear_align(txt, vis, **kw), 100, 20, dev)
+        flops = 2.0 * B * B * Q * V * d
+        esz = 2 if in_dtype == torch.bfloat16 else 4
+        byts = (B * Q + B * V) * d * esz + (B * B * Q * V * 4 if full else (B * B * (Q + V)) * 4)
+        out["align_full" if full else "align_fused_max"] = {
+            "sentences_per_s": B / sec, "ms": sec * 1e3, "TFLOP/s": flops / sec / 1e12,
+            "frac_mfma_bf16_peak": flops / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS if in_dtype == torch.bfloat16 else None,
+            "GB/s": byts / sec / 1e9, "frac_hbm": byts / sec / 1e9 / HBM_PEAK_GBS,
+            "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in (2048-d / 768-d features through fixed-seed Linear->128), fp32 out"}
+
+    # the two consumers on the training path: attention-fuse (joint.py:670-674) and the grounding loss on the
+    # fused maxima (joint.py:439-491), forward + gradients, through the host API
+    hdim = 256
+    mk = lambda *shape: torch.randn(*shape, generator=g).to(dev, in_dtype).requires_grad_(True)
+    f_vis, f_txt, f_mid, f_enc = mk(B, V, d), mk(B, N, d), mk(B, V, hdim), mk(B, L, hdim)
+    ln_w, ln_b = torch.ones(hdim, device=dev, requires_grad=True), torch.zeros(hdim, device=dev, requires_grad=True)
+    dout = torch.randn(B, L, hdim, generator=g).to(dev)
+    leaves = [f_vis, f_txt, f_mid, f_enc, ln_w, ln_b]
+    out["attention_fuse"] = {
+        "fwd_ms": timed(lambda: align.attention_fuse(f_vis.detach(), f_txt.detach(), f_mid.detach(), f_enc.detach(),
+                                                     ln_w.detach(), ln_b.detach(), 1e-5), 50, dev),
+        "fwd_bwd_ms": timed(lambda: torch.autograd.grad(align.attention_fuse(*leaves, 1e-5), leaves, dout), 50, dev),
+        "shape": f"B={B} L={L} V={V} d={d} h={hdim} {args.dtype} in; host API incl. autograd overhead"}
+    tmask = torch.ones(B, Q, dtype=torch.bool, device=dev)
+    tmask[:, 0] = tmask[:, N] = False
+    vmask = torch.ones(B, V, dtype=torch.bool, device=dev)
+    marg = torch.rand(B, Q, generator=g).to(dev) * tmask
+    g_txt, g_vis = mk(B, Q, d), mk(B, V, d)
+
+    def ground():
+        total, _ = align.grounding_loss_factor_ce(g_txt, g_vis, tmask, vmask, marg, B * L, 1.0)
+        return torch.autograd.grad(total, [g_txt, g_vis])
+    out["grounding_loss"] = {"fwd_bwd_ms": timed(ground, 10, dev),
+                             "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in; loss + gradients, no [B,A,Q,V] tensor"}
+    out["grounding_decode"] = {
+        "ms": timed(lambda: align.grounding_decode(g_txt.detach(), g_vis.detach(), tmask, vmask), 20, dev),
+        "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in; alignment (diag + max_v) + top-5 / image arg-max, joint.py:512-596"}
+
+    # the same two at the reference's shipped factor layout (config/data/vlparse.yaml: 36 boxes -> obj 36 + rel 1296 +
+    # attr 36 + img 1 = 1369 columns, batch 64): 29 region groups per image, fewer captions than CUs
+    Bs, Vs = 64, 1369
+    s_txt, s_vis = mk(Bs, Q, d), mk(Bs, Vs, d)
+    s_tmask, s_vmask = tmask[:Bs], torch.ones(Bs, Vs, dtype=torch.bool, device=dev)
+    s_marg = marg[:Bs]
+
+    def ground_shipped():
+        total, _ = align.grounding_loss_factor_ce(s_txt, s_vis, s_tmask, s_vmask, s_marg, Bs * L, 1.0)
+        return torch.autograd.grad(total, [s_txt, s_vis])
+    out["shipped_layout"] = {
+        "grounding_loss_fwd_bwd_ms": timed(ground_shipped, 10, dev),
+        "grounding_decode_ms": timed(lambda: align.grounding_decode(s_txt.detach(), s_vis.detach(), s_tmask, s_vmask), 10, dev),
+        "shape": f"B=A={Bs} Q={Q} V={Vs} d={d} {args.dtype} in"}
+    del s_txt, s_vis
+
+    # arc encoder's trilinear term (joint.py:282-284): M = B * (L + 1) rows, 128^3 weights
+    a_child, a_parent = mk(B, N, d), mk(B, N, d)
+    a_w1 = (torch.randn(d, d, d, generator=g) / d).to(dev, in_dtype).requires_grad_(True)
+    a_dout = torch.randn(B, N, d, generator=g).to(dev)
+    out["arc_trilinear"] = {
+        "fwd_ms": timed(lambda: align.arc_trilinear(a_child.detach(), a_w1.detach(), a_parent.detach()), 20, dev),
+        "fwd_bwd_ms": timed(lambda: torch.autograd.grad(align.arc_trilinear(a_child, a_w1, a_parent),
+                                                        [a_child, a_w1, a_parent], a_dout), 10, dev),
+        "shape": f"M={B * N} X=H=Y={d} {args.dtype} in; einsum('bcx,xhy,bcy->bch') without the [M,H,Y] intermediate"}

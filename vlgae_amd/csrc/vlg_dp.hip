@@ -360,6 +360,31 @@ __global__ void merge_kernel(const typename In::T* __restrict__ dec, const typen
     }
 }
 
+// ---- batch sum of the expected counts: out[m] = sum_b counts[b][m] over the concatenation [grad_dec | grad_attach].
+// This is the marginal-loss gradient of position-tied parameters -- the quantity the data-parallel all-reduce
+// carries in bench.py (the reference's DDP gradient sum, config/trainer/train.yaml:27-29).  One block = 64 columns x
+// 16 row groups; fixed summation order (no atomics), coalesced 256-byte rows per wavefront.
+__global__ __launch_bounds__(1024) void count_sum_kernel(const float* __restrict__ gdec, const float* __restrict__ gatt,
+                                                         int B, int Md, int Ma, float* __restrict__ out) {
+    __shared__ float part[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (col < Md + Ma) {
+        const float* src = col < Md ? gdec + col : gatt + (col - Md);
+        const size_t pitch = col < Md ? Md : Ma;
+#pragma unroll 4
+        for (int b = rg; b < B; b += 16) acc += src[(size_t)b * pitch];
+    }
+    part[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0 && col < Md + Ma) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+        out[col] = t;
+    }
+}
+
 // ---- launch plumbing --------------------------------------------------------------------------------
 template <typename K>
 static int prep(K kernel, size_t lds) {
@@ -647,6 +672,15 @@ int vlg_dmv1o_merge(const void* dec, const void* attach, const void* root, int B
     else
         return vlg::set_error(VLG_ERR_DTYPE, "merge: in_dtype %d", in_dtype);
     return vlg::check_launch("merge_kernel");
+}
+
+int vlg_dmv1o_count_sum(const float* grad_dec, const float* grad_attach, int B, int N, float* out, void* stream) {
+    if (B < 0 || N < 2) return vlg::set_error(VLG_ERR_SHAPE, "count_sum: need B >= 0 and N >= 2 (got B=%d N=%d)", B, N);
+    if (!grad_dec || !grad_attach || !out) return vlg::set_error(VLG_ERR_ARG, "count_sum: null buffer");
+    const int Md = N * 8, Ma = N * N * 2;
+    hipLaunchKernelGGL(vlg::count_sum_kernel, dim3((Md + Ma + 63) / 64), dim3(1024), 0, (hipStream_t)stream, grad_dec,
+                       grad_attach, B, Md, Ma, out);
+    return vlg::check_launch("count_sum_kernel");
 }
 
 }  // extern "C"

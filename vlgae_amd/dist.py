@@ -9,23 +9,30 @@ overlaps the next step's kernels.  On CPU (tests) the same code runs on `gloo`.
 """
 import os
 
+# The host driver only supports dmabuf IPC; HSA reads this flag ONCE, when the runtime initialises (the first HIP call
+# of the process, torch.cuda.is_available() included), so it has to be in the environment before anything below can
+# touch the GPU.  Launchers that import this module late should export it themselves (bench.py does, at its top).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
-    Returns (rank, local_rank, world_size).  world_size == 1 needs no process group."""
+    Returns (rank, local_rank, world_size).  world_size == 1 needs no process group.
+
+    backend: "nccl" (= RCCL over xGMI, the product path) unless the caller or VLGAE_DIST_BACKEND says otherwise
+    ("gloo": CPU tests).  It is chosen from arguments / environment only -- never by probing the GPU, which would
+    initialise HSA before the process group exists."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = backend or os.environ.get("VLGAE_DIST_BACKEND", "nccl")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank)   # one process per GPU: RCCL binds the communicator to the current device
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
