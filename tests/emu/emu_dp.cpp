@@ -59,6 +59,8 @@ struct HostX {
     float* xf;   // [nt][8]
     int* xi;     // [nt][8]
 
+    bool uniform(bool v) { return v; }
+    int uniform(int v) { return v; }
     void sync() {
         tok->advance();
         ++phase;

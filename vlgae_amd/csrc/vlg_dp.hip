@@ -116,6 +116,9 @@ __device__ __forceinline__ void butterfly(T* v, int G) {   // G is uniform over 
 struct DevX {
     static constexpr bool kSkipDeadWaves = true;   // the all-reduces are wave-local: a wave without spans can skip a phase
     __device__ __forceinline__ void sync() { __syncthreads(); }
+    // a value the caller knows to be wave-uniform: pin it to an SGPR so that branches on it are scalar branches
+    __device__ __forceinline__ bool uniform(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+    __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #ifdef VLG_STAMP
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
     __device__ __forceinline__ void stamp(int k) {   // acc[k & 7] += cycles since the previous stamp

@@ -170,158 +170,189 @@ VLG_HD int group_log2(int spans, int w, int nt, int budget) {
 #define VLG_GROUP_LOG2_BW(spans, w, nt) group_log2(spans, w, nt, VLG_DP_LANES_BW)
 
 // ------------------------------------------------------------------------------------------------
-// DMV1o inside, width w, ONE span handled by a group of G = 2^lg lanes (this lane covers split points
-// r = rr, rr+G, ...).  TU > 0: exactly TU iterations per lane, the six terms of every iteration stay in
-// registers between the max pass and the sum pass (no LDS re-read, no branches: out-of-range r is
-// clamped for the loads and masked to the lowest float).  TU == 0: generic loops for long spans.
-// X provides the group all-reduces (fused DPP steps on device).
+// Schedule of a pass.  The lane-group size G = 2^lg is non-decreasing in the width (both conditions of group_log2
+// relax as w grows and the span count Ne - w shrinks), so a pass is at most seven SEGMENTS of constant lg and the
+// width loop runs inside a function that has lg as a template parameter: butterflies are fully unrolled, the
+// lane -> (span, split-point residue) mapping and every per-lane address base are computed once per segment, and
+// the per-width preamble shrinks to a handful of scalar adds.  first[k] = smallest w with lg(w) >= k:
+//   lg(w) >= k  <=>  2^(k-1) < w  and  (Ne - w) 2^k <= cap      (group_log2's loop conditions for l = k-1)
 // ------------------------------------------------------------------------------------------------
-template <int SR, bool BWD, int TU, typename X>
-VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr, X& x) {
+struct Sched {
+    int first[8];   // segment k covers first[k] <= w < first[k+1]; first[0] = 1, first[7] = Ne
+};
+VLG_HD Sched make_sched(int Ne, int lanes, int budget) {
+    const int cap = budget < lanes ? budget : lanes;
+    Sched s;
+    s.first[0] = 1;
+    for (int k = 1; k <= 6; ++k) {
+        int a = (1 << (k - 1)) + 1, b = Ne - (cap >> k);
+        int f = a > b ? a : b;
+        if (f < s.first[k - 1]) f = s.first[k - 1];
+        s.first[k] = f < Ne ? f : Ne;
+    }
+    s.first[7] = Ne;
+    return s;
+}
+
+#if defined(__HIPCC__)
+#define VLG_MUL24(a, b) __mul24((a), (b))   // v_mul_i32_i24: full rate (v_mul_lo_u32 is quarter rate); all chart indices < 2^17
+#else
+#define VLG_MUL24(a, b) ((a) * (b))
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// DMV1o inside, width w, ONE span (i, j = i + w), ONE direction, handled by a group of G = 2^LG lanes (this lane covers
+// split points r = rr, rr+G, ...).  The left-facing chain SL -> IL(j,i) -> CL(j,i) and the right-facing chain
+// SR -> IR(i,j) -> CR(i,j) of a span do not depend on each other within a width, so the two halves of the workgroup
+// take one each (DIR 0 / 1): three reductions per lane instead of six, on twice the wavefronts.
+// TU > 0: exactly TU iterations per lane, the terms of every iteration stay in registers between the max pass and the
+// sum pass (no LDS re-read, no branches: out-of-range r is clamped for the loads and masked to the lowest float).
+// TU == 0: generic loops for long spans.  D = i (P + 1) is the chart index of the diagonal cell of row i.
+//   DIR 0 reductions: 0 SL, 1 CL.x, 2 CL.y (r >= 1)        DIR 1: 0 SR, 1 CR.x, 2 CR.y (r <= w-2)
+// ------------------------------------------------------------------------------------------------
+template <int SR, bool BWD, int DIR, int TU, typename X>
+VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x) {
     VLG_STAMP_AT(x, 6);   // since the end of the previous span: phase preamble + barrier
-    const int P = c.P, j = i + w, G = 1 << lg;
-    const float2* cr = c.C + i * P + i + 1;      // CR(i, i+r)    at [r]
-    const float2* cl = c.C + j * P + i + 1;      // CL(j, i+r+1)  at [r]
-    const float2* ca = c.C + i * P + i;          // CL(i+r, i)    at [r*P]
-    const float2* il = c.I + j * P + i;          // IL(j, i+r)    at [r]
-    const float2* ir = c.I + i * P + i + 2;      // IR(i, i+1+r)  at [r]
-    const float2* cb = c.C + (i + 1) * P + j + 1;   // CR(i+1+r, j)  at [r*P]
+    const int P = c.P, DW = D + VLG_MUL24(w, P);   // DW: chart index of (row j, column i)
+    const float* Cf = reinterpret_cast<const float*>(c.C);
+    // element indices at r = 0 (float units for the single-component reads)
+    const int eA = 2 * (D + 1) + (DIR == 0 ? 1 : 0);          // CR(i, i+r):   .NC for SL, .HC for SR
+    const int eB = 2 * (DW + 1) + (DIR == 0 ? 0 : 1);         // CL(j, i+r+1): .HC for SL, .NC for SR
+    const int eU = DIR == 0 ? 2 * D + 1 : 2 * (D + P + w + 1) + 1;   // CL(i+r, i).NC  |  CR(i+1+r, j).NC   (stride P)
+    const int eV = DIR == 0 ? DW : D + 2;                     // IL(j, i+r)     |  IR(i, i+1+r)
+    const int kO = DIR == 0 ? DW : D + w + 1;                 // this span's own slot: IL(j,i) / CL(j,i)  |  IR(i,j) / CR(i,j)
     // per-span constants first: their LDS latency hides under the reductions
-    const float2 aL = c.I[j * P + i], aR = c.I[i * P + j + 1];   // attach + dec[...,GO], staged at load
-    const float c0 = c.C[i * P + i].y;          // CL(i,i).NC : partner of the r = 0 term of CL(j,i)
-    const float c1 = c.C[j * P + j + 1].y;      // CR(j,j).NC : partner of the r = w-1 term of CR(i,j)
-    // reductions: 0 SL, 1 SR, 2 CL.x, 3 CL.y (r >= 1), 4 CR.x, 5 CR.y (r <= w-2)
-    float m[6], s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int am[6];
+    const float2 aX = c.I[kO];                                // attach + dec[...,GO], staged at load
+    const float cX = DIR == 0 ? Cf[2 * D + 1] : Cf[2 * (DW + w + 1) + 1];   // CL(i,i).NC | CR(j,j).NC: partner of the same-width term
+    float m[3], s[3] = {0.f, 0.f, 0.f};
+    int am[3];
     VLG_STAMP_AT(x, 7);   // pointer set-up + per-span constant loads
     if (TU > 0) {
-        float t[TU > 0 ? TU : 1][6];
+        float t[TU > 0 ? TU : 1][3];
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            const int r = rr + (u << lg), rc = r < w ? r : w - 1;
-            const float2 a = cr[rc], b = cl[rc], va = il[rc], vb = ir[rc];
-            const float ua = ca[rc * P].y, ub = cb[rc * P].y;
-            const bool v0 = r < w, v1 = v0 && r >= 1, v2 = r <= w - 2;
-            t[u][0] = v0 ? a.y + b.x : VLG_LOWEST;
-            t[u][1] = v0 ? a.x + b.y : VLG_LOWEST;
-            t[u][2] = v1 ? ua + va.x : VLG_LOWEST;
-            t[u][3] = v1 ? ua + va.y : VLG_LOWEST;
-            t[u][4] = v2 ? vb.x + ub : VLG_LOWEST;
-            t[u][5] = v2 ? vb.y + ub : VLG_LOWEST;
+            const int r = rr + u * G, rc = r < w ? r : w - 1;
+            const float a = Cf[eA + 2 * rc], b = Cf[eB + 2 * rc];
+            const float uu = Cf[eU + 2 * VLG_MUL24(rc, P)];
+            const float2 vv = c.I[eV + rc];
+            const bool v0 = r < w, v1 = DIR == 0 ? (v0 && r >= 1) : (r <= w - 2);
+            t[u][0] = v0 ? a + b : VLG_LOWEST;
+            t[u][1] = v1 ? uu + vv.x : VLG_LOWEST;
+            t[u][2] = v1 ? uu + vv.y : VLG_LOWEST;
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < 3; ++k) {
             m[k] = t[0][k];
             am[k] = rr;
 #pragma unroll
             for (int u = 1; u < TU; ++u)
-                if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + (u << lg); }   // strict: first index wins ties
+                if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + u * G; }   // strict: first index wins ties
         }
         VLG_STAMP_AT(x, 1);
-        if (SR == VLG_SR_MAX) x.template allreduce_argmax<6>(m, am, G);
-        else x.template allreduce_max<6>(m, G);
+        if (SR == VLG_SR_MAX) x.template allreduce_argmax<3>(m, am, G);
+        else x.template allreduce_max<3>(m, G);
         VLG_STAMP_AT(x, 2);
         if (SR == VLG_SR_LOG) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
+            for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int u = 0; u < TU; ++u) s[k] += VLG_EXP(t[u][k] - m[k]);   // masked terms: 2^(-3e38) = 0
             VLG_STAMP_AT(x, 3);
-            x.template allreduce_sum<6>(s, G);
+            x.template allreduce_sum<3>(s, G);
         }
         VLG_STAMP_AT(x, 4);
     } else {
-        for (int k = 0; k < 6; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
+        for (int k = 0; k < 3; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
         for (int r = rr; r < w; r += G) {
-            const float2 a = cr[r], b = cl[r];
-            upd_max(m[0], am[0], a.y + b.x, r);
-            upd_max(m[1], am[1], a.x + b.y, r);
-            if (r >= 1) {
-                const float u = ca[r * P].y;
-                const float2 v = il[r];
-                upd_max(m[2], am[2], u + v.x, r);
-                upd_max(m[3], am[3], u + v.y, r);
-            }
-            if (r <= w - 2) {
-                const float2 v = ir[r];
-                const float u = cb[r * P].y;
-                upd_max(m[4], am[4], v.x + u, r);
-                upd_max(m[5], am[5], v.y + u, r);
+            upd_max(m[0], am[0], Cf[eA + 2 * r] + Cf[eB + 2 * r], r);
+            if (DIR == 0 ? r >= 1 : r <= w - 2) {
+                const float uu = Cf[eU + 2 * VLG_MUL24(r, P)];
+                const float2 vv = c.I[eV + r];
+                upd_max(m[1], am[1], uu + vv.x, r);
+                upd_max(m[2], am[2], uu + vv.y, r);
             }
         }
-        if (SR == VLG_SR_MAX) x.template allreduce_argmax<6>(m, am, G);
-        else x.template allreduce_max<6>(m, G);
+        if (SR == VLG_SR_MAX) x.template allreduce_argmax<3>(m, am, G);
+        else x.template allreduce_max<3>(m, G);
         if (SR == VLG_SR_LOG) {
             for (int r = rr; r < w; r += G) {
-                const float2 a = cr[r], b = cl[r];
-                s[0] += VLG_EXP(a.y + b.x - m[0]);
-                s[1] += VLG_EXP(a.x + b.y - m[1]);
-                if (r >= 1) {
-                    const float u = ca[r * P].y;
-                    const float2 v = il[r];
-                    s[2] += VLG_EXP(u + v.x - m[2]);
-                    s[3] += VLG_EXP(u + v.y - m[3]);
-                }
-                if (r <= w - 2) {
-                    const float2 v = ir[r];
-                    const float u = cb[r * P].y;
-                    s[4] += VLG_EXP(v.x + u - m[4]);
-                    s[5] += VLG_EXP(v.y + u - m[5]);
+                s[0] += VLG_EXP(Cf[eA + 2 * r] + Cf[eB + 2 * r] - m[0]);
+                if (DIR == 0 ? r >= 1 : r <= w - 2) {
+                    const float uu = Cf[eU + 2 * VLG_MUL24(r, P)];
+                    const float2 vv = c.I[eV + r];
+                    s[1] += VLG_EXP(uu + vv.x - m[1]);
+                    s[2] += VLG_EXP(uu + vv.y - m[2]);
                 }
             }
-            x.template allreduce_sum<6>(s, G);
+            x.template allreduce_sum<3>(s, G);
         }
     }
-    const float SL = SR == VLG_SR_LOG ? m[0] + VLG_LOG(s[0]) : m[0];
-    const float SRv = SR == VLG_SR_LOG ? m[1] + VLG_LOG(s[1]) : m[1];
-    const float2 ILn = make_float2(aL.x + SL, aL.y + SL);
-    const float2 IRn = make_float2(aR.x + SRv, aR.y + SRv);
-    int b0, b1, b2, b3;
-    float CLx = fold_term<SR>(m[2], s[2], am[2], c0 + ILn.x, 0, true, b0);
-    float CLy = fold_term<SR>(m[3], s[3], am[3], c0 + ILn.y, 0, true, b1);
-    float CRx = fold_term<SR>(m[4], s[4], am[4], IRn.x + c1, w - 1, false, b2);
-    float CRy = fold_term<SR>(m[5], s[5], am[5], IRn.y + c1, w - 1, false, b3);
-    if (i == 0 && w != c.len) { CRx = VLG_NEGINF; CRy = VLG_NEGINF; }   // single root, dmv.py:63
+    const float Sv = SR == VLG_SR_LOG ? m[0] + VLG_LOG(s[0]) : m[0];       // SL | SR
+    const float2 In = make_float2(aX.x + Sv, aX.y + Sv);                    // IL(j,i) | IR(i,j)
+    int b0, b1;
+    // the same-width term: r = 0 of CL(j,i) (it precedes every other index -> wins ties), r = w-1 of CR(i,j)
+    float Cx = fold_term<SR>(m[1], s[1], am[1], cX + In.x, DIR == 0 ? 0 : w - 1, DIR == 0, b0);
+    float Cy = fold_term<SR>(m[2], s[2], am[2], cX + In.y, DIR == 0 ? 0 : w - 1, DIR == 0, b1);
+    if (DIR == 1 && D == 0 && w != c.len) { Cx = VLG_NEGINF; Cy = VLG_NEGINF; }   // single root, dmv.py:63  (D == 0 <=> i == 0)
     VLG_STAMP_AT(x, 5);
     if (live && rr == 0) {
-        c.I[j * P + i] = ILn;
-        c.I[i * P + j + 1] = IRn;
-        c.C[j * P + i] = make_float2(CLx, CLy);
-        c.C[i * P + j + 1] = make_float2(CRx, CRy);
+        c.I[kO] = In;
+        c.C[kO] = make_float2(Cx, Cy);
         if (BWD) {
-            if (!c.walk) {   // the tape of the outside replay; the back-pointer walk does not read it
-                c.S[j * P + i] = SL;
-                c.S[i * P + j] = SRv;
-            }
+            const int kS = DIR == 0 ? DW : D + w;      // SL(i,j) at S[j*P+i], SR(i,j) at S[i*P+j]
+            if (!c.walk) c.S[kS] = Sv;                 // the tape of the outside replay; the back-pointer walk does not read it
             if (SR == VLG_SR_MAX) {
-                c.bpS[j * P + i] = (unsigned char)am[0];
-                c.bpS[i * P + j] = (unsigned char)am[1];
-                c.bpC[(j * P + i) * 2] = (unsigned char)b0;
-                c.bpC[(j * P + i) * 2 + 1] = (unsigned char)b1;
-                c.bpC[(i * P + j + 1) * 2] = (unsigned char)b2;
-                c.bpC[(i * P + j + 1) * 2 + 1] = (unsigned char)b3;
+                c.bpS[kS] = (unsigned char)am[0];
+                c.bpC[kO * 2] = (unsigned char)b0;
+                c.bpC[kO * 2 + 1] = (unsigned char)b1;
             }
         }
     }
     VLG_STAMP_AT(x, 8);   // stores
 }
 
-template <int SR, bool BWD, typename X>
-VLG_HD void dmv_fw(const DmvCtx& c, int w, int tid, int nt, X& x) {
-    const int spans = c.Ne - w;
-    const int lg = VLG_GROUP_LOG2_FW(spans, w, nt), G = 1 << lg, per = nt >> lg;
-    const int rr = tid & (G - 1), slot = tid >> lg;
+// one width of the inside pass for this lane: G = 2^LG lanes per (span, direction); LG < 0: G is a run-time value
+template <int SR, bool BWD, int DIR, int LG, typename X>
+VLG_HD void dmv_fw_width(const DmvCtx& c, int w, int lgr, int t, int nd, X& x) {
+    const int lg = LG >= 0 ? LG : lgr, G = 1 << lg, per = nd >> lg;
+    const int rr = t & (G - 1), slot = t >> lg, spans = c.Ne - w;
     const int T = (w + G - 1) >> lg;   // split points per lane; uniform over the workgroup
     for (int base = 0; base < spans; base += per) {
         const bool live = base + slot < spans;
         const int i = live ? base + slot : 0;   // dead lanes shadow span 0 and never store
-        if (X::kSkipDeadWaves && (base + ((tid & ~63) >> lg)) >= spans) continue;   // whole wavefront past the last span
-        if (T == 1) dmv_fw_span<SR, BWD, 1>(c, w, lg, i, live, rr, x);
-        else if (T == 2) dmv_fw_span<SR, BWD, 2>(c, w, lg, i, live, rr, x);
-        else if (T == 3) dmv_fw_span<SR, BWD, 3>(c, w, lg, i, live, rr, x);
-        else if (T == 4) dmv_fw_span<SR, BWD, 4>(c, w, lg, i, live, rr, x);
-        else dmv_fw_span<SR, BWD, 0>(c, w, lg, i, live, rr, x);
+        if (X::kSkipDeadWaves && (base + ((t & ~63) >> lg)) >= spans) continue;   // whole wavefront past the last span
+        const int D = VLG_MUL24(i, c.P + 1);
+        if (T == 1) dmv_fw_span<SR, BWD, DIR, 1>(c, w, G, D, live, rr, x);
+        else if (T == 2) dmv_fw_span<SR, BWD, DIR, 2>(c, w, G, D, live, rr, x);
+        else if (T == 3) dmv_fw_span<SR, BWD, DIR, 3>(c, w, G, D, live, rr, x);
+        else if (T == 4) dmv_fw_span<SR, BWD, DIR, 4>(c, w, G, D, live, rr, x);
+        else dmv_fw_span<SR, BWD, DIR, 0>(c, w, G, D, live, rr, x);
     }
+}
+
+// all widths of one segment (constant group size), one barrier per width
+template <int SR, bool BWD, int LG, typename X>
+VLG_HD void dmv_fw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& x) {
+    const int nd = nt >> 1;                 // lanes per direction
+    const bool right = x.uniform(tid >= nd);   // wave-uniform on the device (nd is a multiple of 64)
+    const int t = right ? tid - nd : tid;
+    for (int w = w0; w < w1; ++w) {
+        if (right) dmv_fw_width<SR, BWD, 1, LG>(c, w, LG, t, nd, x);
+        else dmv_fw_width<SR, BWD, 0, LG>(c, w, LG, t, nd, x);
+        x.sync();
+    }
+}
+
+template <int SR, bool BWD, typename X>
+VLG_HD void dmv_fw_all(const DmvCtx& c, int tid, int nt, X& x) {
+    const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_FW);
+    dmv_fw_segment<SR, BWD, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 3>(c, sc.first[3], sc.first[4], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 4>(c, sc.first[4], sc.first[5], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 5>(c, sc.first[5], sc.first[6], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 6>(c, sc.first[6], sc.first[7], tid, nt, x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -880,20 +911,13 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
 #if defined(VLG_STAMP) && defined(__HIPCC__)
     unsigned long long st_body = 0, st_sync = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_stage = 0;
     unsigned long long st_bbody = 0, st_bsync = 0;
-    for (int w = 1; w < Ne; ++w) {
+    {   // (per-width body / barrier split is no longer taken: the width loop lives inside the segment functions)
         const unsigned long long a = __builtin_amdgcn_s_memtime();
-        dmv_fw<SR, BWD>(c, w, tid, nt, x);
-        const unsigned long long b = __builtin_amdgcn_s_memtime();
-        x.sync();
-        const unsigned long long d = __builtin_amdgcn_s_memtime();
-        st_body += b - a;
-        st_sync += d - b;
+        dmv_fw_all<SR, BWD>(c, tid, nt, x);
+        st_body += __builtin_amdgcn_s_memtime() - a;
     }
 #else
-    for (int w = 1; w < Ne; ++w) {
-        dmv_fw<SR, BWD>(c, w, tid, nt, x);
-        x.sync();
-    }
+    dmv_fw_all<SR, BWD>(c, tid, nt, x);
 #endif
     if (tid == 0) *logZ = c.C[len + 1].y * VLG_LN2;   // CR(0,len).NOCHILD, dmv.py:65
     if (!BWD) return;
