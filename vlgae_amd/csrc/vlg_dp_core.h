@@ -158,7 +158,7 @@ VLG_HD float fold_term(float m, float s, int am, float t, int rt, bool t_first, 
 #define VLG_DP_LANES_FW 256
 #endif
 #ifndef VLG_DP_LANES_BW
-#define VLG_DP_LANES_BW 512
+#define VLG_DP_LANES_BW 256   // per direction (the two directions of a span run on separate halves of the workgroup)
 #endif
 VLG_HD int group_log2(int spans, int w, int nt, int budget) {
     const int cap = budget < nt ? budget : nt;
@@ -356,161 +356,149 @@ VLG_HD void dmv_fw_all(const DmvCtx& c, int tid, int nt, X& x) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// DMV1o outside, width w, ONE span (complete spans of width w, then the incomplete spans of the same
-// width whose adjoint they complete).  All loads -- including the read half of every read-modify-write
-// -- are issued before the first store, so nothing waits on an earlier store of the same phase.
+// DMV1o outside, width w, ONE span, ONE direction (DIR 0: the adjoints of CL(j,i), then of IL(j,i) through SL;
+// DIR 1: CR(i,j), then IR(i,j) through SR).  The two directions of a span touch disjoint adjoint words -- the
+// left one owns gI row j, the CL half of gCc, and the (.NC of CR(i,.), .HC of CL(j,.)) components of gCi; the right
+// one the mirror set -- so, like the inside pass, they run on separate halves of the workgroup.
+// All loads -- including the read half of every read-modify-write -- are issued before the first store, so
+// nothing waits on an earlier store of the same phase.
 // ------------------------------------------------------------------------------------------------
-template <int SR, int TU, typename X>
-VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int lg, int i, bool live, int rr, X& x) {
-    const int P = c.P, j = i + w, G = 1 << lg;
-    const int kL = j * P + i, kR = i * P + j + 1;          // CL(j,i) / IL(j,i) and CR(i,j) / IR(i,j) slots
-    float2 gcl = make_float2(0.f, 0.f), gcr = make_float2(0.f, 0.f);
+template <int SR, int DIR, int TU, typename X>
+VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, int hd, bool live, int rr, X& x) {
+    const int P = c.P, DW = D + VLG_MUL24(w, P);
+    const float* Cf = reinterpret_cast<const float*>(c.C);
+    float* gCif = reinterpret_cast<float*>(c.gCi);
+    const int eA = 2 * (D + 1) + (DIR == 0 ? 1 : 0);          // CR(i, i+r):   .NC for SL, .HC for SR   (also its gCi word)
+    const int eB = 2 * (DW + 1) + (DIR == 0 ? 0 : 1);         // CL(j, i+r+1): .HC for SL, .NC for SR
+    const int eU = DIR == 0 ? D : D + P + w + 1;              // cell of CL(i+r, i) | CR(i+1+r, j)   (stride P): value .NC, adjoint gCc
+    const int eV = DIR == 0 ? DW : D + 2;                     // IL(j, i+r) | IR(i, i+1+r)
+    const int kO = DIR == 0 ? DW : D + w + 1;                 // this span's own slot
+    const int kS = DIR == 0 ? DW : D + w;                     // SL(i,j) at S[j*P+i], SR(i,j) at S[i*P+j]
+    const int selfr = DIR == 0 ? 0 : w - 1;                   // the split point whose incomplete span has this same width
+    float2 gc = make_float2(0.f, 0.f);                        // total adjoint of CL(j,i) | CR(i,j)
     {
-        const float a = c.gCc[kL], a2 = c.gCc[kR];
-        const float2 b = c.gCi[kL], b2 = c.gCi[kR];
-        if (live) gcl = make_float2(b.x, a + b.y);
-        if (live && !(i == 0 && w != c.len)) gcr = make_float2(b2.x, a2 + b2.y);   // masked cell: dmv.py:63
+        const float a = c.gCc[kO];
+        const float2 b = c.gCi[kO];
+        if (live && !(DIR == 1 && D == 0 && w != c.len)) gc = make_float2(b.x, a + b.y);   // masked root cell: dmv.py:63
     }
-    const float2 ocl = c.C[kL], ocr = c.C[kR];
-    const float2 gil_old = c.gI[kL], gir_old = c.gI[kR];
-    const float SLv = c.S[j * P + i], SRv = c.S[i * P + j];
-    int bl0 = 0, bl1 = 0, br0 = 0, br1 = 0, bsl = 0, bsr = 0;
-    if (SR == VLG_SR_MAX) {
-        bl0 = c.bpC[kL * 2]; bl1 = c.bpC[kL * 2 + 1]; br0 = c.bpC[kR * 2]; br1 = c.bpC[kR * 2 + 1];
-        bsl = c.bpS[j * P + i]; bsr = c.bpS[i * P + j];
-    }
-    float self[4] = {0.f, 0.f, 0.f, 0.f};   // r = 0 share of gIL(j,i), r = w-1 share of gIR(i,j)
+    const float2 oc = c.C[kO], gi_old = c.gI[kO];
+    const float Sv = c.S[kS];
+    int b0 = 0, b1 = 0, bs = 0;
+    if (SR == VLG_SR_MAX) { b0 = c.bpC[kO * 2]; b1 = c.bpC[kO * 2 + 1]; bs = c.bpS[kS]; }
+    float self[2] = {0.f, 0.f};   // share of gI(own slot) that comes from this very span: r = 0 (left) / r = w-1 (right)
     if (TU > 0) {
-        // value loads and the read halves of the RMWs, for every iteration of this lane
-        float2 va[TU > 0 ? TU : 1], vb[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1], xb[TU > 0 ? TU : 1];
-        float ua[TU > 0 ? TU : 1], ub[TU > 0 ? TU : 1];
-        float2 o_gil[TU > 0 ? TU : 1], o_gir[TU > 0 ? TU : 1], o_ga[TU > 0 ? TU : 1], o_gb[TU > 0 ? TU : 1];
-        float o_ca[TU > 0 ? TU : 1], o_cb[TU > 0 ? TU : 1];
-        float w0[TU > 0 ? TU : 1], w1[TU > 0 ? TU : 1], u0[TU > 0 ? TU : 1], u1[TU > 0 ? TU : 1];
+        float uu[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1], xb[TU > 0 ? TU : 1], o_c[TU > 0 ? TU : 1], o_ga[TU > 0 ? TU : 1],
+            o_gb[TU > 0 ? TU : 1], w0[TU > 0 ? TU : 1], w1[TU > 0 ? TU : 1];
+        float2 vv[TU > 0 ? TU : 1], o_gi[TU > 0 ? TU : 1];
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            const int r = rr + (u << lg), rc = r < w ? r : w - 1;
-            ua[u] = c.C[(i + rc) * P + i].y;          // CL(i+r, i).NC
-            va[u] = c.I[kL + rc];                     // IL(j, i+r)
-            vb[u] = c.I[i * P + i + rc + 2];          // IR(i, i+1+r)
-            ub[u] = c.C[(i + 1 + rc) * P + j + 1].y;  // CR(i+1+r, j).NC
-            xa[u] = c.C[i * P + i + rc + 1];          // CR(i, i+r)
-            xb[u] = c.C[j * P + i + rc + 1];          // CL(j, i+r+1)
-            o_gil[u] = c.gI[kL + rc];
-            o_gir[u] = c.gI[i * P + i + rc + 2];
-            o_ca[u] = c.gCc[(i + rc) * P + i];
-            o_cb[u] = c.gCc[(i + 1 + rc) * P + j + 1];
-            o_ga[u] = c.gCi[i * P + i + rc + 1];
-            o_gb[u] = c.gCi[j * P + i + rc + 1];
+            const int r = rr + u * G, rc = r < w ? r : w - 1, rP = VLG_MUL24(rc, P);
+            uu[u] = Cf[2 * (eU + rP) + 1];
+            vv[u] = c.I[eV + rc];
+            xa[u] = Cf[eA + 2 * rc];
+            xb[u] = Cf[eB + 2 * rc];
+            o_gi[u] = c.gI[eV + rc];
+            o_c[u] = c.gCc[eU + rP];
+            o_ga[u] = gCif[eA + 2 * rc];
+            o_gb[u] = gCif[eB + 2 * rc];
         }
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            const int r = rr + (u << lg);
+            const int r = rr + u * G;
             const bool ok = r < w;
-            // CL(j,i).v = (+)_r CL(i+r,i).NC + IL(j,i+r).v ;  CR(i,j).v = (+)_r IR(i,i+1+r).v + CR(i+1+r,j).NC
-            w0[u] = ok ? adj_w<SR>(gcl.x, ua[u] + va[u].x, ocl.x, r, bl0) : 0.f;
-            w1[u] = ok ? adj_w<SR>(gcl.y, ua[u] + va[u].y, ocl.y, r, bl1) : 0.f;
-            u0[u] = ok ? adj_w<SR>(gcr.x, vb[u].x + ub[u], ocr.x, r, br0) : 0.f;
-            u1[u] = ok ? adj_w<SR>(gcr.y, vb[u].y + ub[u], ocr.y, r, br1) : 0.f;
-            if (r == 0) { self[0] = w0[u]; self[1] = w1[u]; }
-            if (r == w - 1) { self[2] = u0[u]; self[3] = u1[u]; }
+            w0[u] = ok ? adj_w<SR>(gc.x, uu[u] + vv[u].x, oc.x, r, b0) : 0.f;
+            w1[u] = ok ? adj_w<SR>(gc.y, uu[u] + vv[u].y, oc.y, r, b1) : 0.f;
+            if (r == selfr) { self[0] = w0[u]; self[1] = w1[u]; }
         }
-        x.group_bcast4(self, G, 0, (w - 1) & (G - 1));   // one lane holds each pair: lanes 0 and (w-1) mod G
-        const float2 gil = make_float2(gil_old.x + self[0], gil_old.y + self[1]);   // complete adjoint of IL(j,i)
-        const float2 gir = make_float2(gir_old.x + self[2], gir_old.y + self[3]);
-        const float gsl = gil.x + gil.y, gsr = gir.x + gir.y;
+        x.group_bcast2(self, G, selfr & (G - 1), selfr & (G - 1));   // one lane of the group holds the pair
+        const float2 gi = make_float2(gi_old.x + self[0], gi_old.y + self[1]);   // complete adjoint of IL(j,i) | IR(i,j)
+        const float gs = gi.x + gi.y;
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            const int r = rr + (u << lg);
+            const int r = rr + u * G;
             if (live && r < w) {
-                const float wl = adj_w<SR>(gsl, xa[u].y + xb[u].x, SLv, r, bsl);   // SL term: CR.NC + CL.HC
-                const float wr = adj_w<SR>(gsr, xa[u].x + xb[u].y, SRv, r, bsr);   // SR term: CR.HC + CL.NC
-                if (r != 0) c.gI[kL + r] = make_float2(o_gil[u].x + w0[u], o_gil[u].y + w1[u]);
-                if (r != w - 1) c.gI[i * P + i + r + 2] = make_float2(o_gir[u].x + u0[u], o_gir[u].y + u1[u]);
-                c.gCc[(i + r) * P + i] = o_ca[u] + (w0[u] + w1[u]);
-                c.gCc[(i + 1 + r) * P + j + 1] = o_cb[u] + (u0[u] + u1[u]);
-                c.gCi[i * P + i + r + 1] = make_float2(o_ga[u].x + wr, o_ga[u].y + wl);
-                c.gCi[j * P + i + r + 1] = make_float2(o_gb[u].x + wl, o_gb[u].y + wr);
+                const float ws = adj_w<SR>(gs, xa[u] + xb[u], Sv, r, bs);
+                if (r != selfr) c.gI[eV + r] = make_float2(o_gi[u].x + w0[u], o_gi[u].y + w1[u]);
+                c.gCc[eU + VLG_MUL24(r, P)] = o_c[u] + (w0[u] + w1[u]);
+                gCif[eA + 2 * r] = o_ga[u] + ws;
+                gCif[eB + 2 * r] = o_gb[u] + ws;
             }
         }
         if (live && rr == 0) {
-            c.gI[kL] = gil;   // == d logZ / d attach[j,i,:]
-            c.gI[kR] = gir;   // == d logZ / d attach[i,j,:]
-            c.gdecs[j * 8 + dec_idx(0, 0, 0)] += gil.x;   // dec[h,dir,v,GO] enters every incomplete span headed by h
-            c.gdecs[j * 8 + dec_idx(0, 1, 0)] += gil.y;
-            c.gdecs[i * 8 + dec_idx(1, 0, 0)] += gir.x;
-            c.gdecs[i * 8 + dec_idx(1, 1, 0)] += gir.y;
+            c.gI[kO] = gi;   // == d logZ / d attach[j,i,:] | attach[i,j,:]
+            c.gdecs[hd * 8 + dec_idx(DIR, 0, 0)] += gi.x;   // dec[h,dir,v,GO] enters every incomplete span headed by h
+            c.gdecs[hd * 8 + dec_idx(DIR, 1, 0)] += gi.y;
         }
         return;
     }
     for (int r = rr; r < w; r += G) {
-        {   // CL(j,i).v = (+)_r CL(i+r,i).NC + IL(j,i+r).v
-            const float a = c.C[(i + r) * P + i].y;
-            const float2 v = c.I[kL + r];
-            const float w0 = adj_w<SR>(gcl.x, a + v.x, ocl.x, r, bl0);
-            const float w1 = adj_w<SR>(gcl.y, a + v.y, ocl.y, r, bl1);
-            if (r == 0) { self[0] = w0; self[1] = w1; }
-            else if (live) { const float2 t = c.gI[kL + r]; c.gI[kL + r] = make_float2(t.x + w0, t.y + w1); }
-            if (live) c.gCc[(i + r) * P + i] += w0 + w1;
-        }
-        {   // CR(i,j).v = (+)_r IR(i,i+1+r).v + CR(i+1+r,j).NC
-            const float2 v = c.I[i * P + i + r + 2];
-            const float a = c.C[(i + 1 + r) * P + j + 1].y;
-            const float w0 = adj_w<SR>(gcr.x, v.x + a, ocr.x, r, br0);
-            const float w1 = adj_w<SR>(gcr.y, v.y + a, ocr.y, r, br1);
-            if (r == w - 1) { self[2] = w0; self[3] = w1; }
-            else if (live) { const float2 t = c.gI[i * P + i + r + 2]; c.gI[i * P + i + r + 2] = make_float2(t.x + w0, t.y + w1); }
-            if (live) c.gCc[(i + 1 + r) * P + j + 1] += w0 + w1;
-        }
+        const int rP = VLG_MUL24(r, P);
+        const float a = Cf[2 * (eU + rP) + 1];
+        const float2 v = c.I[eV + r];
+        const float q0 = adj_w<SR>(gc.x, a + v.x, oc.x, r, b0);
+        const float q1 = adj_w<SR>(gc.y, a + v.y, oc.y, r, b1);
+        if (r == selfr) { self[0] = q0; self[1] = q1; }
+        else if (live) { const float2 t = c.gI[eV + r]; c.gI[eV + r] = make_float2(t.x + q0, t.y + q1); }
+        if (live) c.gCc[eU + rP] += q0 + q1;
     }
-    x.group_bcast4(self, G, 0, (w - 1) & (G - 1));
-    const float2 gil = make_float2(gil_old.x + self[0], gil_old.y + self[1]);
-    const float2 gir = make_float2(gir_old.x + self[2], gir_old.y + self[3]);
-    const float gsl = gil.x + gil.y, gsr = gir.x + gir.y;
+    x.group_bcast2(self, G, selfr & (G - 1), selfr & (G - 1));
+    const float2 gi = make_float2(gi_old.x + self[0], gi_old.y + self[1]);
+    const float gs = gi.x + gi.y;
     for (int r = rr; r < w; r += G) {
-        const float2 a = c.C[i * P + i + r + 1];  // CR(i, i+r)
-        const float2 b = c.C[j * P + i + r + 1];  // CL(j, i+r+1)
-        const float wl = adj_w<SR>(gsl, a.y + b.x, SLv, r, bsl);
-        const float wr = adj_w<SR>(gsr, a.x + b.y, SRv, r, bsr);
+        const float ws = adj_w<SR>(gs, Cf[eA + 2 * r] + Cf[eB + 2 * r], Sv, r, bs);
         if (live) {
-            float2 t = c.gCi[i * P + i + r + 1];
-            c.gCi[i * P + i + r + 1] = make_float2(t.x + wr, t.y + wl);
-            t = c.gCi[j * P + i + r + 1];
-            c.gCi[j * P + i + r + 1] = make_float2(t.x + wl, t.y + wr);
+            gCif[eA + 2 * r] += ws;
+            gCif[eB + 2 * r] += ws;
         }
     }
     if (live && rr == 0) {
-        c.gI[kL] = gil;
-        c.gI[kR] = gir;
-        c.gdecs[j * 8 + dec_idx(0, 0, 0)] += gil.x;
-        c.gdecs[j * 8 + dec_idx(0, 1, 0)] += gil.y;
-        c.gdecs[i * 8 + dec_idx(1, 0, 0)] += gir.x;
-        c.gdecs[i * 8 + dec_idx(1, 1, 0)] += gir.y;
+        c.gI[kO] = gi;
+        c.gdecs[hd * 8 + dec_idx(DIR, 0, 0)] += gi.x;
+        c.gdecs[hd * 8 + dec_idx(DIR, 1, 0)] += gi.y;
+    }
+}
+
+template <int SR, int DIR, int LG, typename X>
+VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x) {
+    constexpr int G = 1 << LG;
+    const int per = nd >> LG, rr = t & (G - 1), slot = t >> LG, spans = c.Ne - w;
+    const int T = (w + G - 1) >> LG;
+    for (int base = 0; base < spans; base += per) {
+        const bool live = base + slot < spans;
+        const int i = live ? base + slot : 0;
+        if (X::kSkipDeadWaves && (base + ((t & ~63) >> LG)) >= spans) continue;
+        const int D = VLG_MUL24(i, c.P + 1), hd = DIR == 0 ? i + w : i;
+        if (T == 1) dmv_bw_span<SR, DIR, 1>(c, w, G, D, hd, live, rr, x);
+        else if (T == 2) dmv_bw_span<SR, DIR, 2>(c, w, G, D, hd, live, rr, x);
+        else if (T == 3) dmv_bw_span<SR, DIR, 3>(c, w, G, D, hd, live, rr, x);
+        else if (T == 4) dmv_bw_span<SR, DIR, 4>(c, w, G, D, hd, live, rr, x);
+        else dmv_bw_span<SR, DIR, 0>(c, w, G, D, hd, live, rr, x);
+    }
+}
+
+// widths w1-1 ... w0 of one segment, descending, one barrier per width
+template <int SR, int LG, typename X>
+VLG_HD void dmv_bw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& x) {
+    const int nd = nt >> 1;
+    const bool right = x.uniform(tid >= nd);
+    const int t = right ? tid - nd : tid;
+    for (int w = w1 - 1; w >= w0; --w) {
+        if (right) dmv_bw_width<SR, 1, LG>(c, w, t, nd, x);
+        else dmv_bw_width<SR, 0, LG>(c, w, t, nd, x);
+        x.sync();
     }
 }
 
 template <int SR, typename X>
-VLG_HD void dmv_bw(const DmvCtx& c, int w, int tid, int nt, X& x) {
-    const int spans = c.Ne - w;
-    const int lg = VLG_GROUP_LOG2_BW(spans, w, nt), G = 1 << lg, per = nt >> lg;
-    const int rr = tid & (G - 1), slot = tid >> lg;
-    const int T = (w + G - 1) >> lg;
-    for (int base = 0; base < spans; base += per) {
-        const bool live = base + slot < spans;
-        const int i = live ? base + slot : 0;
-        if (X::kSkipDeadWaves && (base + ((tid & ~63) >> lg)) >= spans) continue;
-        // (register-resident iterations are capped at 2 here: each one holds 12 loads + 4 weights, and a third
-        //  would push the kernel past 128 VGPRs = one 512-lane workgroup per CU instead of two)
-        if (T == 1) dmv_bw_span<SR, 1>(c, w, lg, i, live, rr, x);
-        else if (T == 2) dmv_bw_span<SR, 2>(c, w, lg, i, live, rr, x);
-#if defined(VLG_DP_BW_TU_MAX) && VLG_DP_BW_TU_MAX >= 3
-        else if (T == 3) dmv_bw_span<SR, 3>(c, w, lg, i, live, rr, x);
-#endif
-#if defined(VLG_DP_BW_TU_MAX) && VLG_DP_BW_TU_MAX >= 4
-        else if (T == 4) dmv_bw_span<SR, 4>(c, w, lg, i, live, rr, x);
-#endif
-        else dmv_bw_span<SR, 0>(c, w, lg, i, live, rr, x);
-    }
+VLG_HD void dmv_bw_all(const DmvCtx& c, int tid, int nt, X& x) {
+    const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_BW);
+    dmv_bw_segment<SR, 6>(c, sc.first[6], sc.first[7], tid, nt, x);
+    dmv_bw_segment<SR, 5>(c, sc.first[5], sc.first[6], tid, nt, x);
+    dmv_bw_segment<SR, 4>(c, sc.first[4], sc.first[5], tid, nt, x);
+    dmv_bw_segment<SR, 3>(c, sc.first[3], sc.first[4], tid, nt, x);
+    dmv_bw_segment<SR, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
+    dmv_bw_segment<SR, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
+    dmv_bw_segment<SR, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
 }
 
 // ================================================================================================
@@ -929,21 +917,14 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     if (tid == 0) c.gCc[len + 1] = glogZ;
     x.sync();
 #if defined(VLG_STAMP) && defined(__HIPCC__)
-    for (int w = Ne - 1; w >= 1; --w) {
+    {
         const unsigned long long a = __builtin_amdgcn_s_memtime();
-        dmv_bw<SR>(c, w, tid, nt, x);
-        const unsigned long long b = __builtin_amdgcn_s_memtime();
-        x.sync();
-        const unsigned long long d = __builtin_amdgcn_s_memtime();
-        st_bbody += b - a;
-        st_bsync += d - b;
+        dmv_bw_all<SR>(c, tid, nt, x);
+        st_bbody += __builtin_amdgcn_s_memtime() - a;
     }
     const unsigned long long st_end = __builtin_amdgcn_s_memtime();
 #else
-    for (int w = Ne - 1; w >= 1; --w) {
-        dmv_bw<SR>(c, w, tid, nt, x);
-        x.sync();
-    }
+    dmv_bw_all<SR>(c, tid, nt, x);
 #endif
     }
     // expected counts out (coalesced; padded positions get exact zeros like the reference).  Decode mode
