@@ -33,8 +33,11 @@ def _bf16_bits(a):
     return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
 
 
-def dmv1o(dec, attach, lengths, semiring=0, grad=True, glogZ=None, nt=16, order=0, bf16=False):
+def dmv1o(dec, attach, lengths, semiring=0, grad=True, glogZ=None, nt=16, order=0, bf16=False, mode=0):
+    """mode: DmvLayout placement mode to emulate (0 = everything in one arena; 1 = the overlay mode: value charts in the
+    first arena during the inside pass, copied to a second arena -- the workspace -- before the outside pass)."""
     B, N = dec.shape[:2]
+    lib().emu_set_dmv_mode(int(mode))
     if bf16:
         dec, attach = _bf16_bits(dec), _bf16_bits(attach)
     else:
@@ -45,6 +48,7 @@ def dmv1o(dec, attach, lengths, semiring=0, grad=True, glogZ=None, nt=16, order=
     ga = np.full((B, N, N, 2), np.nan, np.float32) if grad else None
     g = None if glogZ is None else np.ascontiguousarray(glogZ, np.float32)
     rc = lib().emu_dmv1o(_p(dec), _p(attach), _p(ln), B, N, int(bf16), semiring, _p(g), _p(lz), _p(gd), _p(ga), nt, order)
+    lib().emu_set_dmv_mode(0)
     assert rc == 0
     return lz, gd, ga
 

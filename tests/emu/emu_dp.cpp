@@ -59,6 +59,7 @@ struct HostX {
     float* xf;   // [nt][8]
     int* xi;     // [nt][8]
 
+    void lockstep() { sync(); }   // device: lanes of a group share a wavefront (see DevX::lockstep)
     bool uniform(bool v) { return v; }
     int uniform(int v) { return v; }
     void sync() {
@@ -139,6 +140,7 @@ void run_workgroup(int nt, int order, Body body) {
 // outside-pass tape when only the inside pass was requested) trips it.
 constexpr size_t kCanary = 1 << 16;
 static int g_canary_trips = 0;
+static int g_mode = 0;   // DMV placement mode to emulate (0: one carve; 1..3: part of the working set in a second arena = the workspace)
 
 struct Arena {
     std::vector<unsigned char> buf;
@@ -155,21 +157,24 @@ template <int SR, bool BWD, typename In>
 void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int len, int N, float glogZ, float* logZ,
                  float* gdec, float* gatt, int nt, int order, long long* heads = nullptr) {
     const bool walk = BWD && SR == VLG_SR_MAX && gdec == nullptr;   // the launcher's rule (vlg_dp.hip: run_dmv)
-    const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, 0, walk);   // mode 0: one contiguous carve, like LDS
-    Arena A(L.lds_bytes);
+    const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, g_mode, walk);   // mode 0: one contiguous carve, like LDS
+    Arena A(L.lds_bytes), W(L.ws_bytes);
+    auto at = [&](const vlg::Region& r) { return r.lds ? A.at(r.off) : W.at(r.off); };
     vlg::DmvCtx c;
     c.walk = walk;
     c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
-    c.C = (float2*)A.at(L.C.off); c.I = (float2*)A.at(L.I.off); c.S = (float*)A.at(L.S.off);
-    c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);
-    c.gCc = (float*)A.at(L.gCc.off); c.gCi = (float2*)A.at(L.gCi.off); c.gI = (float2*)A.at(L.gI.off);
-    c.decs = (float*)A.at(L.decs.off); c.gdecs = (float*)A.at(L.gdecs.off);
+    c.C = (float2*)at(L.C_in); c.I = (float2*)at(L.I_in); c.C2 = (float2*)at(L.C); c.I2 = (float2*)at(L.I);
+    c.S = (float*)at(L.S);
+    c.bpS = (unsigned char*)at(L.bpS); c.bpC = (unsigned char*)at(L.bpC);
+    c.gCc = (float*)at(L.gCc); c.gCi = (float2*)at(L.gCi); c.gI = (float2*)at(L.gI);
+    c.decs = (float*)at(L.decs); c.gdecs = (float*)at(L.gdecs);
     vlg::MergedIO<In> io;
     io.dec = dec; io.attach = attach; io.N = N; io.gdec = gdec; io.gatt = gatt; io.heads = heads;
     run_workgroup(nt, order, [&](int tid, HostX& x) {
         vlg::dmv_run<SR, BWD>(c, io, glogZ, logZ, tid, nt, x);
     });
     A.check();
+    W.check();
 }
 
 // rule-table input (RuleIO): one sentence
@@ -182,7 +187,7 @@ void emu_rules_one(const vlg::RuleIO<vlg::F32In>& io, int len, float glogZ, floa
     vlg::DmvCtx c;
     c.walk = walk;
     c.Ne = len + 1; c.len = len; c.P = vlg::chart_pitch(N);
-    c.C = (float2*)A.at(L.C.off); c.I = (float2*)A.at(L.I.off); c.S = (float*)A.at(L.S.off);
+    c.C = (float2*)A.at(L.C.off); c.I = (float2*)A.at(L.I.off); c.C2 = c.C; c.I2 = c.I; c.S = (float*)A.at(L.S.off);
     c.bpS = (unsigned char*)A.at(L.bpS.off); c.bpC = (unsigned char*)A.at(L.bpC.off);
     c.gCc = (float*)A.at(L.gCc.off); c.gCi = (float2*)A.at(L.gCi.off); c.gI = (float2*)A.at(L.gI.off);
     c.decs = (float*)A.at(L.decs.off); c.gdecs = (float*)A.at(L.gdecs.off);
@@ -251,6 +256,7 @@ int dep_batch(const void* arc_, const int64_t* lengths, int B, int N, int semiri
 
 extern "C" {
 int emu_canary_trips(void) { return g_canary_trips; }
+void emu_set_dmv_mode(int mode) { g_mode = mode; }
 // rule-table entry (f32): grads must be zero-filled by the caller; any of them may be null together (inside only)
 int emu_dmv1o_rules(const float* rule, const float* dec, const float* root, int root_per_sentence, const int64_t* token,
                     const unsigned char* head_mask, const int64_t* lengths, int B, int L, int T, int semiring, float fill,

@@ -50,6 +50,10 @@ def test_emu_dmv1o_golden(oracle_mod, path):
     assert np.array_equal(mgd, g["maxgrad_dec"]) and np.array_equal(mga, g["maxgrad_attach"])
     mz2, _, _ = emu.dmv1o(md, ma, g["lengths"], 1, grad=False, nt=8, order=1)
     assert np.array_equal(mz, mz2)   # max is exact: independent of the lane count
+    # overlay placement (DmvLayout mode 1: value charts copied out, adjoint charts laid over them): same bits, both semirings
+    for sr, want in ((0, (lz, gd, ga)), (1, (mz, mgd, mga))):
+        got = emu.dmv1o(md, ma, g["lengths"], sr, nt=16, order=3 if sr else 0, mode=1)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
     # upstream gradient scaling
     _, wgd, wga = emu.dmv1o(md, ma, g["lengths"], 0, glogZ=g["wts"], nt=16)
     assert np.abs(wgd - g["wgrad_dec"]).max() <= 4e-5 and np.abs(wga - g["wgrad_attach"]).max() <= 4e-5

@@ -209,6 +209,54 @@ def test_dmv1o_properties_full_size(ts):
     assert torch.equal(ga, ga2) and torch.equal(gd, gd2)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_dmv1o_long_sentences_full_size(ts, oracle_mod, dt):
+    """BASELINE.json configs[3] (B=256, L=80): the overlay placement (value charts in LDS for the inside pass, copied to
+    the workspace, adjoints laid over them for the outside pass).  Size-independent identities on the whole batch, and
+    parity with the fp64 oracle on a slice of it."""
+    B, L = 256, 80
+    gen = torch.Generator(device="cpu").manual_seed(80)
+    dec = torch.randn(B, L, 2, 2, 2, generator=gen).log_softmax(-1)
+    attach = torch.randn(B, L, L, 2, generator=gen)
+    root = torch.randn(B, L, generator=gen).log_softmax(-1)
+    lengths = torch.randint(1, L + 1, (B,), generator=gen)
+    lengths[0], lengths[1], lengths[2] = L, 61, 62                       # full length; both sides of the all-in-LDS boundary
+    md, ma = ts.DMV1o.merge(dec.to(dev()), attach.to(dev()), root.to(dev()))
+    if dt == "bf16":
+        md, ma = md.bfloat16(), ma.bfloat16()
+    lengths_d = lengths.to(dev())
+    from vlgae_amd.torch_struct import functional as Fn
+    # raw launcher: fp32 counts whatever the storage type (autograd would round them to the potentials' dtype)
+    lz, gd, ga = Fn.dmv1o_run(md, ma, lengths_d, 0, True)
+    lz = lz.reshape(B, 1)
+    lf = lengths_d.float()
+    assert bool(torch.isfinite(lz).all())
+    assert torch.allclose(ga.sum((1, 2, 3)), lf, atol=1e-3)                 # one head per word
+    assert torch.allclose(gd.sum((1, 2, 3, 4)), 3 * lf + 1, atol=2e-3)      # 2 STOP + 1 GO per word, + root STOP
+    col = ga.sum(-1).sum(1)
+    idx = torch.arange(L + 1, device=dev())[None]
+    valid = (idx >= 1) & (idx <= lengths_d[:, None])
+    assert torch.allclose(col[valid], torch.ones_like(col[valid]), atol=5e-4)
+    assert float(col[~valid].abs().max()) == 0.0                            # padding: exact zeros
+    assert float(ga.min()) >= 0.0 and float(ga.max()) <= 1.0 + 2e-5
+    _, gd2, ga2 = Fn.dmv1o_run(md, ma, lengths_d, 0, True)
+    assert torch.equal(ga, ga2) and torch.equal(gd, gd2)                    # bit-reproducible
+    # inside-only launch (all charts in LDS at this length) gives the same logZ bits as the fused launch
+    with torch.no_grad():
+        assert torch.equal(ts.DMV1o([md, ma], lengths_d).partition, lz.detach())
+    # oracle slice: the same (possibly bf16-rounded) potentials, fp64
+    n = 12
+    omd, oma = md[:n].float().cpu().numpy(), ma[:n].float().cpu().numpy()
+    rlz, rgd, rga = oracle_mod.dmv1o(omd, oma, lengths[:n].numpy(), "log", np.float64)
+    assert np.all(np.abs(lz[:n].detach().cpu().numpy().reshape(rlz.shape) - rlz) <= logz_tol(rlz))
+    # fp32 charts at |logZ| ~ 300: one ulp of a chart value is 3e-5 (DESIGN.md section 6: 2e-4 at the peakiest L >= 62 cases)
+    assert np.abs(ga[:n].cpu().numpy() - rga).max() <= 1e-4 and np.abs(gd[:n].cpu().numpy() - rgd).max() <= 2e-4
+    # Viterbi at full size: a tree per sentence, single root
+    heads_am = ts.DMV1o([md, ma], lengths_d).argmax.sum(-1)
+    assert torch.equal(heads_am.sum(1)[valid], torch.ones_like(heads_am.sum(1)[valid]))
+    assert torch.equal(heads_am[:, 0].sum(-1), torch.ones(B, device=dev()))
+
+
 def test_dmv1o_edge_cases(ts):
     # B = 0
     lz = ts.DMV1o([torch.zeros(0, 5, 2, 2, 2, device=dev()), torch.zeros(0, 5, 5, 2, device=dev())],

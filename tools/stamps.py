@@ -8,6 +8,7 @@ B, L = 256, 39   # lengths 39 with N = 41 leaves the last row of grad_dec free..
 L = 40
 dec = torch.randn(B, L, 2, 2, 2, generator=g).log_softmax(-1).to(dev); attach = torch.randn(B, L, L, 2, generator=g).to(dev); root = torch.randn(B, L, generator=g).log_softmax(-1).to(dev)
 md, ma = ts.DMV1o.merge(dec, attach, root)
+md, ma = md.bfloat16().contiguous(), ma.bfloat16().contiguous()
 for ln in (32,):
     lengths = torch.full((B,), ln, dtype=torch.long, device=dev)
     for _ in range(3): lz, gd, ga = F.dmv1o_run(md, ma, lengths, 0, True)

@@ -63,7 +63,10 @@ def lib():
                 f"vlgae_amd: HIP extension not built ({LIB_PATH} missing). Run `python -m vlgae_amd.build` "
                 "(needs hipcc, cross-compiles for gfx950). There is no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
+        partial = bool(os.environ.get("VLGAE_AMD_LIB"))   # tools/ A/B variants may hold a subset of the translation units
         for name, (res, args) in SIGNATURES.items():
+            if partial and not hasattr(handle, name):
+                continue
             fn = getattr(handle, name)   # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
         _lib = handle

@@ -116,6 +116,10 @@ __device__ __forceinline__ void butterfly(T* v, int G) {   // G is uniform over 
 struct DevX {
     static constexpr bool kSkipDeadWaves = true;   // the all-reduces are wave-local: a wave without spans can skip a phase
     __device__ __forceinline__ void sync() { __syncthreads(); }
+    // The lanes of one lane group never straddle a wavefront and a wavefront executes its instructions in order for all
+    // lanes at once, so within a group "all loads above, all stores below" needs no instruction.  (The host phase
+    // emulator, whose lanes are free-running threads, makes this point a barrier.)
+    __device__ __forceinline__ void lockstep() {}
     // a value the caller knows to be wave-uniform: pin it to an SGPR so that branches on it are scalar branches
     __device__ __forceinline__ bool uniform(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
     __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -205,8 +209,10 @@ __device__ __forceinline__ DmvCtx carve_dmv(int N, int len, char* smem, char* ws
     c.Ne = len + 1;
     c.len = len;
     c.P = chart_pitch(N);
-    c.C = region_ptr<float2>(L.C, smem, wsb);
-    c.I = region_ptr<float2>(L.I, smem, wsb);
+    c.C = region_ptr<float2>(L.C_in, smem, wsb);
+    c.I = region_ptr<float2>(L.I_in, smem, wsb);
+    c.C2 = region_ptr<float2>(L.C, smem, wsb);
+    c.I2 = region_ptr<float2>(L.I, smem, wsb);
     c.S = region_ptr<float>(L.S, smem, wsb);
     c.bpS = region_ptr<unsigned char>(L.bpS, smem, wsb);
     c.bpC = region_ptr<unsigned char>(L.bpC, smem, wsb);
@@ -443,6 +449,11 @@ static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, 
         return set_error(VLG_ERR_WORKSPACE, "dmv1o: N=%d needs a %zu-byte workspace (got %zu); see vlg_workspace_bytes",
                          N, ws_stride * (size_t)B, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
+#ifdef VLG_DP_HEADLINE_ONLY   // tools/ A/B builds: only the Log / all-in-LDS / bf16 instantiation (compiles in seconds)
+    if (semiring != VLG_SR_LOG || mode > 1 || in_dtype != VLG_BF16) return set_error(VLG_ERR_ARG, "headline-only build");
+    if (mode == 1) return launch_dmv<VLG_SR_LOG, 1, BWD, BF16In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, heads, ws, ws_stride, lds, s);
+    return launch_dmv<VLG_SR_LOG, 0, BWD, BF16In>(dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, heads, ws, ws_stride, lds, s);
+#else
 #define VLG_GO(SRV, INV) \
     return dispatch_dmv_mode<SRV, BWD, INV>(mode, dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, heads, ws, ws_stride, lds, s)
     if (semiring == VLG_SR_LOG) {
@@ -452,6 +463,7 @@ static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, 
     if (in_dtype == VLG_F32) VLG_GO(VLG_SR_MAX, F32In);
     VLG_GO(VLG_SR_MAX, BF16In);
 #undef VLG_GO
+#endif
 }
 
 struct RulesArgs {
@@ -531,6 +543,10 @@ static int run_dep(const void* arc, const int64_t* lengths, int B, int N, int in
         return set_error(VLG_ERR_WORKSPACE, "deptree: N=%d needs a %zu-byte workspace (got %zu)", N,
                          ws_stride * (size_t)B, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
+#ifdef VLG_DP_HEADLINE_ONLY
+    (void)s; (void)lds;
+    return set_error(VLG_ERR_ARG, "headline-only build");
+#else
 #define VLG_GO(SRV, INV) \
     return dispatch_dep_mode<SRV, BWD, INV>(mode, arc, lengths, B, N, glogZ, logZ, garc, heads, ws, ws_stride, lds, s)
     if (semiring == VLG_SR_LOG) {
@@ -540,6 +556,7 @@ static int run_dep(const void* arc, const int64_t* lengths, int B, int N, int in
     if (in_dtype == VLG_F32) VLG_GO(VLG_SR_MAX, F32In);
     VLG_GO(VLG_SR_MAX, BF16In);
 #undef VLG_GO
+#endif
 }
 
 }  // namespace vlg
@@ -617,6 +634,10 @@ int vlg_dmv1o_rules(const void* attach_rule, const void* dec, const void* root_r
     }
     RulesArgs a{attach_rule, dec, root_rule, root_per_sentence ? T : 0, token, head_mask, lengths, B, L, T, mask_fill,
                 grad_logZ, logZ, grad_rule, grad_dec, grad_root, heads, ws, Lay.ws_bytes, Lay.lds_bytes, s};
+#ifdef VLG_DP_HEADLINE_ONLY
+    (void)a;
+    return set_error(VLG_ERR_ARG, "headline-only build");
+#else
 #define VLG_GO(SRV, INV) return bwd ? dispatch_rules_mode<SRV, true, INV>(mode, a) : dispatch_rules_mode<SRV, false, INV>(mode, a)
     if (!is_max) {
         if (in_dtype == VLG_F32) VLG_GO(VLG_SR_LOG, F32In);
@@ -625,6 +646,7 @@ int vlg_dmv1o_rules(const void* attach_rule, const void* dec, const void* root_r
     if (in_dtype == VLG_F32) VLG_GO(VLG_SR_MAX, F32In);
     VLG_GO(VLG_SR_MAX, BF16In);
 #undef VLG_GO
+#endif
 }
 
 size_t vlg_workspace_bytes(int op, int B, int N, int semiring) {

@@ -109,6 +109,8 @@ struct DmvCtx {
     int P;          // chart pitch (cells), odd, >= N + 1
     float2* C;      // complete spans   [Ne][P]
     float2* I;      // incomplete spans [Ne][P]  (pre-loaded with attach + dec[...,GO])
+    float2* C2;     // where the outside pass reads the value charts from: == C, I unless the placement mode overlays the
+    float2* I2;     //   adjoint charts on them in LDS (then the inside pass's charts are copied out to the workspace first)
     float* S;       // SL(i,j) at S[j*P+i], SR(i,j) at S[i*P+j]
     float* gCc;     // adjoint of C.NOCHILD, part contributed by complete-span parents (HASCHILD gets none from them)
     float2* gCi;    // adjoint of C, part contributed by incomplete-span parents
@@ -232,9 +234,14 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
             const int r = rr + u * G, rc = r < w ? r : w - 1;
+#ifdef VLG_ABL_NOLOADS
+            const float a = (float)rc, b = aX.x, uu = cX;
+            const float2 vv = aX;
+#else
             const float a = Cf[eA + 2 * rc], b = Cf[eB + 2 * rc];
             const float uu = Cf[eU + 2 * VLG_MUL24(rc, P)];
             const float2 vv = c.I[eV + rc];
+#endif
             const bool v0 = r < w, v1 = DIR == 0 ? (v0 && r >= 1) : (r <= w - 2);
             t[u][0] = v0 ? a + b : VLG_LOWEST;
             t[u][1] = v1 ? uu + vv.x : VLG_LOWEST;
@@ -249,16 +256,24 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
                 if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + u * G; }   // strict: first index wins ties
         }
         VLG_STAMP_AT(x, 1);
+#ifndef VLG_ABL_NOMAXBFLY
         if (SR == VLG_SR_MAX) x.template allreduce_argmax<3>(m, am, G);
         else x.template allreduce_max<3>(m, G);
+#endif
         VLG_STAMP_AT(x, 2);
         if (SR == VLG_SR_LOG) {
+#ifdef VLG_ABL_NOEXP
+            for (int k = 0; k < 3; ++k) s[k] = t[0][k] - m[k];
+#else
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int u = 0; u < TU; ++u) s[k] += VLG_EXP(t[u][k] - m[k]);   // masked terms: 2^(-3e38) = 0
+#endif
             VLG_STAMP_AT(x, 3);
+#ifndef VLG_ABL_NOSUMBFLY
             x.template allreduce_sum<3>(s, G);
+#endif
         }
         VLG_STAMP_AT(x, 4);
     } else {
@@ -287,12 +302,19 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
             x.template allreduce_sum<3>(s, G);
         }
     }
+#ifdef VLG_ABL_NOEPI   // timing ablation (wrong results): no log / fold after the butterflies
+    const float Sv = m[0] + s[0];
+    const float2 In = make_float2(aX.x + Sv, aX.y + Sv);
+    int b0 = 0, b1 = 0;
+    float Cx = m[1] + s[1] + cX, Cy = m[2] + s[2] + cX;
+#else
     const float Sv = SR == VLG_SR_LOG ? m[0] + VLG_LOG(s[0]) : m[0];       // SL | SR
     const float2 In = make_float2(aX.x + Sv, aX.y + Sv);                    // IL(j,i) | IR(i,j)
     int b0, b1;
     // the same-width term: r = 0 of CL(j,i) (it precedes every other index -> wins ties), r = w-1 of CR(i,j)
     float Cx = fold_term<SR>(m[1], s[1], am[1], cX + In.x, DIR == 0 ? 0 : w - 1, DIR == 0, b0);
     float Cy = fold_term<SR>(m[2], s[2], am[2], cX + In.y, DIR == 0 ? 0 : w - 1, DIR == 0, b1);
+#endif
     if (DIR == 1 && D == 0 && w != c.len) { Cx = VLG_NEGINF; Cy = VLG_NEGINF; }   // single root, dmv.py:63  (D == 0 <=> i == 0)
     VLG_STAMP_AT(x, 5);
     if (live && rr == 0) {
@@ -337,9 +359,13 @@ VLG_HD void dmv_fw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& 
     const bool right = x.uniform(tid >= nd);   // wave-uniform on the device (nd is a multiple of 64)
     const int t = right ? tid - nd : tid;
     for (int w = w0; w < w1; ++w) {
+#ifndef VLG_ABL_NOBODY
         if (right) dmv_fw_width<SR, BWD, 1, LG>(c, w, LG, t, nd, x);
         else dmv_fw_width<SR, BWD, 0, LG>(c, w, LG, t, nd, x);
+#endif
+#ifndef VLG_ABL_NOBARRIER
         x.sync();
+#endif
     }
 }
 
@@ -364,7 +390,7 @@ VLG_HD void dmv_fw_all(const DmvCtx& c, int tid, int nt, X& x) {
 // nothing waits on an earlier store of the same phase.
 // ------------------------------------------------------------------------------------------------
 template <int SR, int DIR, int TU, typename X>
-VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, int hd, bool live, int rr, X& x) {
+VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x) {
     const int P = c.P, DW = D + VLG_MUL24(w, P);
     const float* Cf = reinterpret_cast<const float*>(c.C);
     float* gCif = reinterpret_cast<float*>(c.gCi);
@@ -385,7 +411,12 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, int hd, bool live,
     const float Sv = c.S[kS];
     int b0 = 0, b1 = 0, bs = 0;
     if (SR == VLG_SR_MAX) { b0 = c.bpC[kO * 2]; b1 = c.bpC[kO * 2 + 1]; bs = c.bpS[kS]; }
-    float self[2] = {0.f, 0.f};   // share of gI(own slot) that comes from this very span: r = 0 (left) / r = w-1 (right)
+    // share of gI(own slot) that comes from this very span's complete cell: the r = 0 (left) / r = w-1 (right) term of its
+    // reduction.  Every lane of the group evaluates it (two same-address LDS reads, two weights): cheaper than handing it
+    // round from the one lane whose split-point range contains it (a ds_bpermute round trip in the middle of the phase).
+    float self[2];
+    const float su = Cf[2 * (eU + VLG_MUL24(selfr, P)) + 1];   // CL(i,i).NC | CR(j,j).NC
+    const float2 sv = c.I[eV + selfr];                          // IL(j,i) | IR(i,j): this span's own incomplete value
     if (TU > 0) {
         float uu[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1], xb[TU > 0 ? TU : 1], o_c[TU > 0 ? TU : 1], o_ga[TU > 0 ? TU : 1],
             o_gb[TU > 0 ? TU : 1], w0[TU > 0 ? TU : 1], w1[TU > 0 ? TU : 1];
@@ -408,9 +439,10 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, int hd, bool live,
             const bool ok = r < w;
             w0[u] = ok ? adj_w<SR>(gc.x, uu[u] + vv[u].x, oc.x, r, b0) : 0.f;
             w1[u] = ok ? adj_w<SR>(gc.y, uu[u] + vv[u].y, oc.y, r, b1) : 0.f;
-            if (r == selfr) { self[0] = w0[u]; self[1] = w1[u]; }
         }
-        x.group_bcast2(self, G, selfr & (G - 1), selfr & (G - 1));   // one lane of the group holds the pair
+        self[0] = adj_w<SR>(gc.x, su + sv.x, oc.x, selfr, b0);
+        self[1] = adj_w<SR>(gc.y, su + sv.y, oc.y, selfr, b1);
+        x.lockstep();   // the lanes of a group sit in one wavefront: every load above precedes every store below
         const float2 gi = make_float2(gi_old.x + self[0], gi_old.y + self[1]);   // complete adjoint of IL(j,i) | IR(i,j)
         const float gs = gi.x + gi.y;
 #pragma unroll
@@ -424,11 +456,7 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, int hd, bool live,
                 gCif[eB + 2 * r] = o_gb[u] + ws;
             }
         }
-        if (live && rr == 0) {
-            c.gI[kO] = gi;   // == d logZ / d attach[j,i,:] | attach[i,j,:]
-            c.gdecs[hd * 8 + dec_idx(DIR, 0, 0)] += gi.x;   // dec[h,dir,v,GO] enters every incomplete span headed by h
-            c.gdecs[hd * 8 + dec_idx(DIR, 1, 0)] += gi.y;
-        }
+        if (live && rr == 0) c.gI[kO] = gi;   // == d logZ / d attach[j,i,:] | attach[i,j,:]
         return;
     }
     for (int r = rr; r < w; r += G) {
@@ -437,11 +465,12 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, int hd, bool live,
         const float2 v = c.I[eV + r];
         const float q0 = adj_w<SR>(gc.x, a + v.x, oc.x, r, b0);
         const float q1 = adj_w<SR>(gc.y, a + v.y, oc.y, r, b1);
-        if (r == selfr) { self[0] = q0; self[1] = q1; }
-        else if (live) { const float2 t = c.gI[eV + r]; c.gI[eV + r] = make_float2(t.x + q0, t.y + q1); }
+        if (r != selfr && live) { const float2 t = c.gI[eV + r]; c.gI[eV + r] = make_float2(t.x + q0, t.y + q1); }
         if (live) c.gCc[eU + rP] += q0 + q1;
     }
-    x.group_bcast2(self, G, selfr & (G - 1), selfr & (G - 1));
+    self[0] = adj_w<SR>(gc.x, su + sv.x, oc.x, selfr, b0);
+    self[1] = adj_w<SR>(gc.y, su + sv.y, oc.y, selfr, b1);
+    x.lockstep();
     const float2 gi = make_float2(gi_old.x + self[0], gi_old.y + self[1]);
     const float gs = gi.x + gi.y;
     for (int r = rr; r < w; r += G) {
@@ -451,11 +480,7 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, int hd, bool live,
             gCif[eB + 2 * r] += ws;
         }
     }
-    if (live && rr == 0) {
-        c.gI[kO] = gi;
-        c.gdecs[hd * 8 + dec_idx(DIR, 0, 0)] += gi.x;
-        c.gdecs[hd * 8 + dec_idx(DIR, 1, 0)] += gi.y;
-    }
+    if (live && rr == 0) c.gI[kO] = gi;
 }
 
 template <int SR, int DIR, int LG, typename X>
@@ -467,12 +492,12 @@ VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x) {
         const bool live = base + slot < spans;
         const int i = live ? base + slot : 0;
         if (X::kSkipDeadWaves && (base + ((t & ~63) >> LG)) >= spans) continue;
-        const int D = VLG_MUL24(i, c.P + 1), hd = DIR == 0 ? i + w : i;
-        if (T == 1) dmv_bw_span<SR, DIR, 1>(c, w, G, D, hd, live, rr, x);
-        else if (T == 2) dmv_bw_span<SR, DIR, 2>(c, w, G, D, hd, live, rr, x);
-        else if (T == 3) dmv_bw_span<SR, DIR, 3>(c, w, G, D, hd, live, rr, x);
-        else if (T == 4) dmv_bw_span<SR, DIR, 4>(c, w, G, D, hd, live, rr, x);
-        else dmv_bw_span<SR, DIR, 0>(c, w, G, D, hd, live, rr, x);
+        const int D = VLG_MUL24(i, c.P + 1);
+        if (T == 1) dmv_bw_span<SR, DIR, 1>(c, w, G, D, live, rr, x);
+        else if (T == 2) dmv_bw_span<SR, DIR, 2>(c, w, G, D, live, rr, x);
+        else if (T == 3) dmv_bw_span<SR, DIR, 3>(c, w, G, D, live, rr, x);
+        else if (T == 4) dmv_bw_span<SR, DIR, 4>(c, w, G, D, live, rr, x);
+        else dmv_bw_span<SR, DIR, 0>(c, w, G, D, live, rr, x);
     }
 }
 
@@ -864,40 +889,51 @@ VLG_HD void dmv_walk(const DmvCtx& c, float g) {
 template <int SR, bool BWD, typename IO, typename X>
 VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int tid, int nt, X& x) {
     const int Ne = c.Ne, P = c.P, len = c.len;
-    // ---- stage: charts to the semiring zero (dmv.py:34-35), dec into fast memory -----------------
-    const float2 zz = make_float2(VLG_NEGINF, VLG_NEGINF), oo = make_float2(0.f, 0.f);
-    for (int i = tid; i < Ne * P; i += nt) {
-        c.C[i] = zz;
-        c.I[i] = zz;
-        if (BWD) {
-            c.gI[i] = oo;
-            if (!c.walk) { c.gCc[i] = 0.f; c.gCi[i] = oo; }
-        }
-    }
-    for (int i = tid; i < Ne * 8; i += nt) {
-        c.decs[i] = io.ld_dec(i) * VLG_LOG2E;
-        if (BWD && !c.walk) c.gdecs[i] = 0.f;
-    }
-    x.sync();
-    // incomplete-span slots are pre-loaded with attach + dec[...,GO] (dmv.py:36-37); the width-0
-    // complete spans with the STOP scores (dmv.py:39-40).  This folds the reference's
+    // ---- stage: charts to the semiring zero (dmv.py:34-35), potentials into fast memory -------------------------
+    // The potentials' global loads are issued first and land while the charts are being filled, so the launch pays
+    // one memory latency, not one per dependent step.  Incomplete-span slots are pre-loaded with attach + dec[...,GO]
+    // (dmv.py:36-37); the width-0 complete spans with the STOP scores (dmv.py:39-40).  This folds the reference's
     // attach_left / attach_right temporaries into the load stage.
-    for (int idx = tid; idx < Ne * Ne; idx += nt) {
-        const int h = idx / Ne, ch = idx - h * Ne;
-        const float* d = c.decs + h * 8;
-        if (ch == h) {
-            c.C[h * P + h] = make_float2(d[1], d[3]);        // CL(h,h).v = dec[h,LEFT ,v,STOP]
-            c.C[h * P + h + 1] = make_float2(d[5], d[7]);    // CR(h,h).v = dec[h,RIGHT,v,STOP]
-        } else {
-            const float2 a = io.ld_attach(h, ch);
-            if (ch < h) c.I[h * P + ch] = make_float2(fmaf(a.x, VLG_LOG2E, d[0]), fmaf(a.y, VLG_LOG2E, d[2]));
-            else c.I[h * P + ch + 1] = make_float2(fmaf(a.x, VLG_LOG2E, d[4]), fmaf(a.y, VLG_LOG2E, d[6]));
+    const float2 zz = make_float2(VLG_NEGINF, VLG_NEGINF), oo = make_float2(0.f, 0.f);
+    const int NN = Ne * Ne;
+    const float inv_ne = 1.0f / (float)Ne;   // (idx + 0.5) * inv_ne truncates to idx / Ne exactly for idx < 2^16 (margin 0.5 / idx >> 2^-23)
+    constexpr int KC = 4;                    // attach cells per lane in flight
+    for (int base = 0; base < NN; base += KC * nt) {
+        float2 areg[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int idx = base + tid + k * nt;
+            const int h = (int)(((float)idx + 0.5f) * inv_ne), ch = idx - h * Ne;
+            areg[k] = (idx < NN && ch != h) ? io.ld_attach(h, ch) : zz;
+        }
+        if (base == 0) {
+            for (int i = tid; i < Ne * 8; i += nt) c.decs[i] = io.ld_dec(i) * VLG_LOG2E;
+            for (int i = tid; i < Ne * P; i += nt) {
+                c.C[i] = zz;
+                c.I[i] = zz;
+            }
+            x.sync();
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int idx = base + tid + k * nt;
+            if (idx >= NN) continue;
+            const int h = (int)(((float)idx + 0.5f) * inv_ne), ch = idx - h * Ne;
+            const float* d = c.decs + h * 8;
+            if (ch == h) {
+                c.C[h * P + h] = make_float2(d[1], d[3]);        // CL(h,h).v = dec[h,LEFT ,v,STOP]
+                c.C[h * P + h + 1] = make_float2(d[5], d[7]);    // CR(h,h).v = dec[h,RIGHT,v,STOP]
+            } else if (ch < h) {
+                c.I[h * P + ch] = make_float2(fmaf(areg[k].x, VLG_LOG2E, d[0]), fmaf(areg[k].y, VLG_LOG2E, d[2]));
+            } else {
+                c.I[h * P + ch + 1] = make_float2(fmaf(areg[k].x, VLG_LOG2E, d[4]), fmaf(areg[k].y, VLG_LOG2E, d[6]));
+            }
         }
     }
     x.sync();
     // ---- inside -----------------------------------------------------------------------------------
 #if defined(VLG_STAMP) && defined(__HIPCC__)
-    unsigned long long st_body = 0, st_sync = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_stage = 0;
+    unsigned long long st_body = 0, st_sync = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_stage = 0, st_end = 0;
     unsigned long long st_bbody = 0, st_bsync = 0;
     {   // (per-width body / barrier split is no longer taken: the width loop lives inside the segment functions)
         const unsigned long long a = __builtin_amdgcn_s_memtime();
@@ -910,8 +946,23 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     if (tid == 0) *logZ = c.C[len + 1].y * VLG_LN2;   // CR(0,len).NOCHILD, dmv.py:65
     if (!BWD) return;
     // ---- outside: adjoint replay ------------------------------------------------------------------
+    if (c.C2 != c.C) {   // overlay placement (DmvLayout mode 1): the adjoint charts take over the LDS the value charts
+        for (int i = tid; i < Ne * P; i += nt) {   // occupied -- copy those out to the workspace first (coalesced)
+            c.C2[i] = c.C[i];
+            c.I2[i] = c.I[i];
+        }
+        x.sync();
+    }
+    for (int i = tid; i < Ne * P; i += nt) {
+        c.gI[i] = oo;
+        if (!c.walk) { c.gCc[i] = 0.f; c.gCi[i] = oo; }
+    }
+    x.sync();
+    DmvCtx cb = c;   // the outside pass's view: value charts where the layout keeps them for this pass
+    cb.C = c.C2;
+    cb.I = c.I2;
     if (SR == VLG_SR_MAX && c.walk) {   // only the tree is wanted (the launcher chose the lean layout): walk the back-pointers
-        if (tid == 0) dmv_walk(c, glogZ);
+        if (tid == 0) dmv_walk(cb, glogZ);
         x.sync();
     } else {
     if (tid == 0) c.gCc[len + 1] = glogZ;
@@ -919,12 +970,12 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
 #if defined(VLG_STAMP) && defined(__HIPCC__)
     {
         const unsigned long long a = __builtin_amdgcn_s_memtime();
-        dmv_bw_all<SR>(c, tid, nt, x);
+        dmv_bw_all<SR>(cb, tid, nt, x);
         st_bbody += __builtin_amdgcn_s_memtime() - a;
     }
-    const unsigned long long st_end = __builtin_amdgcn_s_memtime();
+    st_end = __builtin_amdgcn_s_memtime();
 #else
-    dmv_bw_all<SR>(c, tid, nt, x);
+    dmv_bw_all<SR>(cb, tid, nt, x);
 #endif
     }
     // expected counts out (coalesced; padded positions get exact zeros like the reference).  Decode mode
@@ -933,8 +984,9 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     io.clear_heads(tid, nt);
     x.sync();
     const int E = io.out_extent(Ne);
+    const float inv_e = 1.0f / (float)E;
     for (int idx = tid; idx < E * E; idx += nt) {
-        const int h = idx / E, ch = idx - h * E;
+        const int h = (int)(((float)idx + 0.5f) * inv_e), ch = idx - h * E;
         float2 g = oo;
         if (h < Ne && ch < Ne) {
             if (ch < h) g = c.gI[h * P + ch];
@@ -948,7 +1000,11 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
             float g = 0.f;
             if (h < Ne) {
                 const int dir = k >> 2, v = (k >> 1) & 1;
-                if ((k & 1) == 0) g = c.gdecs[h * 8 + k];                                   // GO
+                if ((k & 1) == 0) {   // GO: dec[h,dir,v,GO] enters every incomplete span headed by h towards dir (dmv.py:36-37)
+                    const float* gi = reinterpret_cast<const float*>(c.gI + h * P) + v;
+                    if (dir == 0) for (int ch = 0; ch < h; ++ch) g += gi[2 * ch];
+                    else for (int ch = h + 1; ch < Ne; ++ch) g += gi[2 * (ch + 1)];
+                }
                 else {                                                                      // STOP = width-0 span
                     const int q = h * P + h + dir;
                     g = (v == 1 ? c.gCc[q] : 0.f) + reinterpret_cast<const float*>(c.gCi + q)[v];
@@ -1089,6 +1145,7 @@ struct Carver {
 
 struct DmvLayout {
     Region C, I, S, bpS, bpC, gCc, gCi, gI, decs, gdecs;
+    Region C_in, I_in;   // the value charts as the INSIDE pass sees them (== C, I except in the overlay mode below)
     size_t lds_bytes, ws_bytes;
     // walk: Max semiring with only the tree wanted -- no replay tape (S), no adjoint charts; gCc shrinks to the walk's
     // stack, gI stays (the one-hot attach output / head vector is read from it).  Its modes keep the value charts and
@@ -1108,18 +1165,36 @@ struct DmvLayout {
             gI = k.take(cells * 8, a2);
             decs = k.take((size_t)N * 32, true);
             gdecs = k.take(0, true);
+            C_in = C;
+            I_in = I;
         } else {
             const bool v = mode < 1, a1 = mode < 3, a2 = mode < 2;
+            // mode 1 with an outside pass: the LDS cannot hold values AND adjoints, but it can hold either.  The inside
+            // pass keeps C, I in LDS (its inner loop never touches global memory; only the replay tape S and the
+            // back-pointers are streamed out), then the two charts are copied to the workspace in one coalesced sweep
+            // and the adjoint charts are laid over them for the outside pass, which reads values from the workspace.
+            const bool overlay = bwd && mode == 1;
+            if (overlay) {   // adjoints first: they start at LDS offset 0, so do the overlaid inside-pass charts
+                gCc = k.take(cells * 4, true);
+                gCi = k.take(cells * 8, true);
+                gI = k.take(cells * 8, true);
+                C_in.lds = true; C_in.off = 0;
+                I_in.lds = true; I_in.off = align16(cells * 8);   // 16 cells <= the 20 cells of adjoints
+            }
             C = k.take(cells * 8, v);
             I = k.take(cells * 8, v);
             S = k.take(bwd ? cells * 4 : 0, v);
             bpS = k.take(bwd && is_max ? cells : 0, v);
             bpC = k.take(bwd && is_max ? cells * 2 : 0, v);
-            gCc = k.take(bwd ? cells * 4 : 0, a1);
-            gCi = k.take(bwd ? cells * 8 : 0, a1);
-            gI = k.take(bwd ? cells * 8 : 0, a2);
+            if (!overlay) {
+                gCc = k.take(bwd ? cells * 4 : 0, a1);
+                gCi = k.take(bwd ? cells * 8 : 0, a1);
+                gI = k.take(bwd ? cells * 8 : 0, a2);
+                C_in = C;
+                I_in = I;
+            }
             decs = k.take((size_t)N * 32, true);
-            gdecs = k.take(bwd ? (size_t)N * 32 : 0, true);
+            gdecs = k.take(0, true);   // (dec[...,GO] counts are summed from the finished gI chart in the output stage)
         }
         lds_bytes = k.lds;
         ws_bytes = k.ws;
