@@ -45,8 +45,15 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
 
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(PKG, "..", "include", "vlgae_amd.h"), os.path.abspath(__file__)]
+
     def compile_one(src):
         obj = os.path.join(LIB_DIR, src + ".o")
+        if not force and os.path.exists(obj):   # per-object staleness: its source and every header
+            t = os.path.getmtime(obj)
+            if all(os.path.getmtime(d) <= t for d in [os.path.join(CSRC, src)] + headers):
+                return obj
         cmd = [_hipcc(), f"--offload-arch={ARCH}", *FLAGS, *EXTRA_FLAGS.get(src, ()), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -471,6 +471,176 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
     }
 }
 
+// =====================================================================================================
+// Fused maxima, one region group per image (V <= 48), bf16 features, d = 128: max over V and max over Q of every
+// (caption, image) block without the [B,A,Q,V] tensor (the grounding loss's / decoder's inputs, joint.py:473-483, :519-524).
+//
+// One workgroup = 8 captions (one per wavefront) x a range of images.  A wavefront keeps its caption's fragments for
+// 96 query rows in registers (the A operand of every MFMA); the image tiles stream through a double-buffered LDS tile
+// that all eight wavefronts read, so an image's rows leave L2 once per EIGHT captions (the per-wave streaming of
+// align_mfma_kernel moved 1.6 GB L2 -> CU at config-2 and was bound by it).  Tiles are staged through registers
+// (global_load_dwordx4 issued one image ahead -> ds_write_b128) into an XOR-swizzled image: 16-byte segment s of
+// row r sits at slot 16 r + (s ^ (r & 15)), which makes the MFMA fragment reads (16 rows x one segment per 16-lane
+// group) conflict-free without padding.  One barrier per image.
+// Epilogue, per 16-row tile, straight from the accumulators: max over the three column tiles element-wise
+// (v_max3), then one 16-lane DPP butterfly per register -> row maxima; the running element-wise maximum over the row
+// tiles gives the column maxima with one within-lane max and two cross-group shuffles per image.  Masks cost nothing
+// when a row tile / an image has none (wave-uniform tests); otherwise one select per element, as the reference's
+// masked_fill_ (joint.py:417-418).  Rows / regions past Q / V are clamped duplicates of the last one: they cannot
+// change a maximum and are never stored.
+// =====================================================================================================
+constexpr int kAMThreads = 512, kAMWaves = 8, kAMRows = 48, kAMSlots = kAMRows * 16;   // 16-byte slots per image tile
+
+#define VLG_AM_DPP4(C)                                                                                          \
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " C "\n\tv_max_f32_dpp %1, %1, %1 " C "\n\tv_max_f32_dpp %2, %2, %2 " C \
+        "\n\tv_max_f32_dpp %3, %3, %3 " C                                                                       \
+        : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3))
+
+__global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
+    const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
+    const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_maxV,
+    float* __restrict__ out_maxQ, int a_per_block) {
+    constexpr int d = 128, KCH = 4, RT = 6;
+    __shared__ uint4 tiles[2][kAMSlots];
+    __shared__ uint8_t ckeep_s[2][kAMRows];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y * kAMWaves + wave, bc = min(b, B - 1);   // a wave past the batch mirrors the last caption, stores nothing
+    const int a0 = blockIdx.x * a_per_block, n_img = min(A, a0 + a_per_block) - a0;
+    const int g = lane >> 4, ccol = lane & 15, crow = g * 4;
+    const float ninf = neg_infinity();
+
+    // staging: this thread's slots of an image tile (slot -> row, swizzled segment)
+    const int sl0 = tid, sl1 = tid + kAMThreads;           // second slot only for tid < 256
+    const int r0 = sl0 >> 4, s0 = (sl0 & 15) ^ (r0 & 15), r1 = sl1 >> 4, s1 = (sl1 & 15) ^ (r1 & 15);
+    auto stage_load = [&](int a, uint4& x0, uint4& x1, unsigned& ck) {
+        const uint16_t* img = vis + (size_t)a * V * d;
+        x0 = *reinterpret_cast<const uint4*>(img + (size_t)min(r0, V - 1) * d + s0 * 8);
+        if (tid < kAMSlots - kAMThreads) x1 = *reinterpret_cast<const uint4*>(img + (size_t)min(r1, V - 1) * d + s1 * 8);
+        if (vmask && tid < kAMRows) ck = vmask[(size_t)a * V + min(tid, V - 1)];
+    };
+    auto stage_write = [&](int buf, const uint4& x0, const uint4& x1, unsigned ck) {
+        tiles[buf][sl0] = x0;
+        if (tid < kAMSlots - kAMThreads) tiles[buf][sl1] = x1;
+        if (vmask && tid < kAMRows) ckeep_s[buf][tid] = (uint8_t)(ck != 0);
+    };
+    // fragment read offsets (in 16-byte slots) for K chunk kc: row ct*16 + ccol, segment kc*4 + g, swizzled
+    int foff[KCH];
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) foff[kc] = ccol * 16 + ((kc * 4 + g) ^ ccol);
+
+    for (int q0 = 0; q0 < Q; q0 += RT * 16) {
+        // ---- this wave's caption: 6 row tiles x 4 K-chunks of A fragments, straight from global memory ----
+        bf16x8 af[RT][KCH];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const bf16x8* rowp = reinterpret_cast<const bf16x8*>(txt + ((size_t)bc * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) af[rt][kc] = rowp[kc * 4];
+        }
+        // query-side keep bits of this lane's accumulator rows (row = 16 rt + 4 g + n) and, per row tile, whether any
+        // lane of the wave sees a masked row (wave-uniform: the unmasked tiles skip the selects)
+        unsigned tkeep = 0xffffffu, rt_masked = 0;
+        if (tmask) {
+            tkeep = 0;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    tkeep |= (tmask[(size_t)bc * Q + min(q0 + rt * 16 + crow + n, Q - 1)] ? 1u : 0u) << (rt * 4 + n);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                if (__builtin_amdgcn_ballot_w64(((tkeep >> (rt * 4)) & 15u) != 15u) != 0) rt_masked |= 1u << rt;
+        }
+
+        uint4 x0, x1 = make_uint4(0, 0, 0, 0);
+        unsigned ck = 1;
+        if (n_img > 0) {
+            stage_load(a0, x0, x1, ck);
+            stage_write(0, x0, x1, ck);
+            if (n_img > 1) stage_load(a0 + 1, x0, x1, ck);
+        }
+        __syncthreads();
+        for (int i = 0; i < n_img; ++i) {
+            const int a = a0 + i, buf = i & 1;
+            if (i + 1 < n_img) stage_write(buf ^ 1, x0, x1, ck);       // tile i+1: loaded during the previous image's MFMAs
+            if (i + 2 < n_img) stage_load(a + 2, x0, x1, ck);          // tile i+2: lands during this image's MFMAs
+            const uint4* tb = tiles[buf];
+            unsigned ckl = 7u;   // region-side keep bits of this lane's three columns
+            bool col_masked = false;
+            if (vmask) {
+                ckl = (unsigned)ckeep_s[buf][ccol] | ((unsigned)ckeep_s[buf][16 + ccol] << 1) | ((unsigned)ckeep_s[buf][32 + ccol] << 2);
+                col_masked = __builtin_amdgcn_ballot_w64(ckl != 7u) != 0;
+            }
+            // column tile outermost: only its four B fragments are live; the element-wise running maximum over the column
+            // tiles (-> row maxima) is kept per row tile, the one over the row tiles (-> column maxima) per column tile
+            f32x4 rmx[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) rmx[rt] = f32x4{ninf, ninf, ninf, ninf};
+#pragma unroll 1
+            for (int ct = 0; ct < 3; ++ct) {
+                bf16x8 bfr[KCH];
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) bfr[kc] = *reinterpret_cast<const bf16x8*>(tb + ct * 256 + foff[kc]);
+                f32x4 cmx = f32x4{ninf, ninf, ninf, ninf};
+                const unsigned ckc = (ckl >> ct) & 1u;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][kc], bfr[kc], acc, 0, 0, 0);
+                    if (col_masked || ((rt_masked >> rt) & 1u)) {   // wave-uniform: masked_fill_ of joint.py:417-418
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) acc[n] = ((tkeep >> (rt * 4 + n)) & ckc) ? acc[n] : neg_inf;
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        rmx[rt][n] = fmaxf(rmx[rt][n], acc[n]);
+                        cmx[n] = fmaxf(cmx[n], acc[n]);
+                    }
+                }
+                if (out_maxQ) {   // column maxima of this column tile: within-lane over the four rows, then across the row groups
+                    float m = fmaxf(fmaxf(cmx[0], cmx[1]), fmaxf(cmx[2], cmx[3]));
+                    m = fmaxf(m, __shfl_xor(m, 16, 64));
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    const int v = ct * 16 + ccol;
+                    if (b < B && lane < 16 && v < V) {
+                        float* dst = out_maxQ + ((size_t)b * A + a) * V + v;
+                        *dst = q0 == 0 ? m : fmaxf(*dst, m);   // the same wave handles every row group of (b, a)
+                    }
+                }
+            }
+            if (b < B && out_maxV) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    float m0 = rmx[rt][0], m1 = rmx[rt][1], m2 = rmx[rt][2], m3 = rmx[rt][3];
+                    VLG_AM_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+                    VLG_AM_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+                    VLG_AM_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf");
+                    VLG_AM_DPP4("row_mirror row_mask:0xf bank_mask:0xf");
+                    const float res = ccol == 0 ? m0 : ccol == 1 ? m1 : ccol == 2 ? m2 : m3;   // lane (g, ccol < 4) keeps row 16 rt + 4 g + ccol
+                    if (ccol < 4 && q0 + rt * 16 + crow + ccol < Q) out_maxV[((size_t)b * A + a) * Q + q0 + rt * 16 + crow + ccol] = res;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+#undef VLG_AM_DPP4
+
+static int launch_align_max(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A, int Q,
+                            int V, float neg_inf, float* out_maxV, float* out_maxQ, hipStream_t s) {
+    const int by = (B + kAMWaves - 1) / kAMWaves;
+    // enough workgroups for the chip (256 CUs, one 8-wave workgroup each), but at least 8 images per workgroup so that
+    // the caption fragments are amortised
+    int a_per_block = (int)(((long)A * by + 255) / 256);
+    if (a_per_block < 8) a_per_block = 8;
+    if (a_per_block > A) a_per_block = A;
+    dim3 grid((A + a_per_block - 1) / a_per_block, by);   // x fastest: workgroups of one caption octet spread over the XCDs
+    hipLaunchKernelGGL(align_max_kernel, grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask, vmask,
+                       B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block);
+    return check_launch("align_max_kernel");
+}
+
 template <bool F32IN, int KCH, bool TILE, bool ARGS = false, int RTBV = MfmaCfg<F32IN>::RTB, bool DIRECT = false>
 static int launch_align_mfma(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A,
                              int Q, int V, float neg_inf, float* out_full, float* out_maxV, float* out_maxQ,
@@ -541,6 +711,13 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
                                                      out_maxQ, out_diag, s)                                           \
                 : launch_align_mfma<F32, KCHV, false>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, out_maxV, \
                                                       out_maxQ, out_diag, s)
+    if (!f32in && d == 128 && !out_full && (out_maxV || out_maxQ) && V <= kAMRows) {
+        // fused maxima of one-group images: image tiles shared by eight captions through LDS
+        if (int rc = launch_align_max(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, s)) return rc;
+        if (!out_diag) return 0;
+        return launch_align_mfma<false, 4, true, false, 3>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, nullptr, nullptr, nullptr,
+                                                          out_diag, s, AlignArgs{nullptr, nullptr, 0, nullptr, nullptr}, true);
+    }
     if (!f32in && d == 128) { VLG_MFMA(false, 4); }
     if (!f32in && d == 64) { VLG_MFMA(false, 2); }
     if (f32in && d == 128) { VLG_MFMA(true, 8); }

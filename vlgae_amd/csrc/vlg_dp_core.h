@@ -169,7 +169,7 @@ VLG_HD int group_log2(int spans, int w, int nt, int budget) {
     return lg;
 }
 #define VLG_GROUP_LOG2_FW(spans, w, nt) group_log2(spans, w, nt, VLG_DP_LANES_FW)
-#define VLG_GROUP_LOG2_BW(spans, w, nt) group_log2(spans, w, nt, VLG_DP_LANES_BW)
+#define VLG_GROUP_LOG2_BW(spans, w, nt) group_log2(spans, w, nt, 512)   // DepTree outside pass: whole workgroup per width
 
 // ------------------------------------------------------------------------------------------------
 // Schedule of a pass.  The lane-group size G = 2^lg is non-decreasing in the width (both conditions of group_log2
