@@ -508,19 +508,27 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
     const int a0 = blockIdx.x * a_per_block, n_img = min(A, a0 + a_per_block) - a0;
     const int g = lane >> 4, ccol = lane & 15, crow = g * 4;
     const float ninf = neg_infinity();
+    const bool is0 = ccol == 0, is1 = ccol == 1, is2 = ccol == 2;
 
-    // staging: this thread's slots of an image tile (slot -> row, swizzled segment)
-    const int sl0 = tid, sl1 = tid + kAMThreads;           // second slot only for tid < 256
-    const int r0 = sl0 >> 4, s0 = (sl0 & 15) ^ (r0 & 15), r1 = sl1 >> 4, s1 = (sl1 & 15) ^ (r1 & 15);
-    auto stage_load = [&](int a, uint4& x0, uint4& x1, unsigned& ck) {
+    // staging: this thread's slots of an image tile (slot -> row, swizzled segment); the second one only for tid < 256
+    constexpr int NS = 2;
+    const bool has2 = tid < kAMSlots - kAMThreads;
+    int soff[NS], srow[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int sl = tid + k * kAMThreads, r = sl >> 4;
+        srow[k] = r;
+        soff[k] = ((sl & 15) ^ (r & 15)) * 8;
+    }
+    auto stage_load = [&](int a, uint4* x, unsigned& ck) {
         const uint16_t* img = vis + (size_t)a * V * d;
-        x0 = *reinterpret_cast<const uint4*>(img + (size_t)min(r0, V - 1) * d + s0 * 8);
-        if (tid < kAMSlots - kAMThreads) x1 = *reinterpret_cast<const uint4*>(img + (size_t)min(r1, V - 1) * d + s1 * 8);
+        x[0] = *reinterpret_cast<const uint4*>(img + (size_t)min(srow[0], V - 1) * d + soff[0]);
+        if (has2) x[1] = *reinterpret_cast<const uint4*>(img + (size_t)min(srow[1], V - 1) * d + soff[1]);
         if (vmask && tid < kAMRows) ck = vmask[(size_t)a * V + min(tid, V - 1)];
     };
-    auto stage_write = [&](int buf, const uint4& x0, const uint4& x1, unsigned ck) {
-        tiles[buf][sl0] = x0;
-        if (tid < kAMSlots - kAMThreads) tiles[buf][sl1] = x1;
+    auto stage_write = [&](int buf, const uint4* x, unsigned ck) {
+        tiles[buf][tid] = x[0];
+        if (has2) tiles[buf][tid + kAMThreads] = x[1];
         if (vmask && tid < kAMRows) ckeep_s[buf][tid] = (uint8_t)(ck != 0);
     };
     // fragment read offsets (in 16-byte slots) for K chunk kc: row ct*16 + ccol, segment kc*4 + g, swizzled
@@ -552,19 +560,39 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
                 if (__builtin_amdgcn_ballot_w64(((tkeep >> (rt * 4)) & 15u) != 15u) != 0) rt_masked |= 1u << rt;
         }
 
-        uint4 x0, x1 = make_uint4(0, 0, 0, 0);
+        const int qlim = Q - (q0 + crow + ccol);   // row 16 rt + crow + ccol of this pass exists iff 16 rt < qlim
+        uint4 xs[NS] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
         unsigned ck = 1;
         if (n_img > 0) {
-            stage_load(a0, x0, x1, ck);
-            stage_write(0, x0, x1, ck);
-            if (n_img > 1) stage_load(a0 + 1, x0, x1, ck);
+            stage_load(a0, xs, ck);
+            stage_write(0, xs, ck);
+            if (n_img > 1) stage_load(a0 + 1, xs, ck);
         }
         __syncthreads();
+        f32x4 rmx[RT];
+        auto row_epilogue = [&](int a) {   // row maxima of image a: one 16-lane butterfly per accumulator register
+            if (!(b < B && out_maxV)) return;
+            float* dstV = out_maxV + ((size_t)bc * A + a) * Q + q0 + crow + ccol;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float m0 = rmx[rt][0], m1 = rmx[rt][1], m2 = rmx[rt][2], m3 = rmx[rt][3];
+                VLG_AM_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+                VLG_AM_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+                VLG_AM_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf");
+                VLG_AM_DPP4("row_mirror row_mask:0xf bank_mask:0xf");
+                float res = m3;   // lane (g, ccol < 4) keeps row 16 rt + 4 g + ccol
+                res = is2 ? m2 : res;
+                res = is1 ? m1 : res;
+                res = is0 ? m0 : res;
+                if (ccol < 4 && rt * 16 < qlim) dstV[rt * 16] = res;
+            }
+        };
         for (int i = 0; i < n_img; ++i) {
             const int a = a0 + i, buf = i & 1;
-            if (i + 1 < n_img) stage_write(buf ^ 1, x0, x1, ck);       // tile i+1: loaded during the previous image's MFMAs
-            if (i + 2 < n_img) stage_load(a + 2, x0, x1, ck);          // tile i+2: lands during this image's MFMAs
+            if (i + 1 < n_img) stage_write(buf ^ 1, xs, ck);       // tile i+1: loaded during the previous image's MFMAs
+            if (i + 2 < n_img) stage_load(a + 2, xs, ck);          // tile i+2: lands during this image's MFMAs
             const uint4* tb = tiles[buf];
+            float* dstQ = out_maxQ + ((size_t)bc * A + a) * V;
             unsigned ckl = 7u;   // region-side keep bits of this lane's three columns
             bool col_masked = false;
             if (vmask) {
@@ -573,7 +601,6 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
             }
             // column tile outermost: only its four B fragments are live; the element-wise running maximum over the column
             // tiles (-> row maxima) is kept per row tile, the one over the row tiles (-> column maxima) per column tile
-            f32x4 rmx[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) rmx[rt] = f32x4{ninf, ninf, ninf, ninf};
 #pragma unroll 1
@@ -600,27 +627,24 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
                 }
                 if (out_maxQ) {   // column maxima of this column tile: within-lane over the four rows, then across the row groups
                     float m = fmaxf(fmaxf(cmx[0], cmx[1]), fmaxf(cmx[2], cmx[3]));
-                    m = fmaxf(m, __shfl_xor(m, 16, 64));
-                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    // lanes l, l^16, l^32, l^48 hold the same column: v_permlane16/32_swap with both operands = m return
+                    // (own, partner) in some order on every lane -- no LDS round trip (ds_bpermute costs one per step)
+                    {
+                        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                        m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+                    }
+                    {
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                        m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+                    }
                     const int v = ct * 16 + ccol;
                     if (b < B && lane < 16 && v < V) {
-                        float* dst = out_maxQ + ((size_t)b * A + a) * V + v;
+                        float* dst = dstQ + v;
                         *dst = q0 == 0 ? m : fmaxf(*dst, m);   // the same wave handles every row group of (b, a)
                     }
                 }
             }
-            if (b < B && out_maxV) {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    float m0 = rmx[rt][0], m1 = rmx[rt][1], m2 = rmx[rt][2], m3 = rmx[rt][3];
-                    VLG_AM_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-                    VLG_AM_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-                    VLG_AM_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf");
-                    VLG_AM_DPP4("row_mirror row_mask:0xf bank_mask:0xf");
-                    const float res = ccol == 0 ? m0 : ccol == 1 ? m1 : ccol == 2 ? m2 : m3;   // lane (g, ccol < 4) keeps row 16 rt + 4 g + ccol
-                    if (ccol < 4 && q0 + rt * 16 + crow + ccol < Q) out_maxV[((size_t)b * A + a) * Q + q0 + rt * 16 + crow + ccol] = res;
-                }
-            }
+            row_epilogue(a);
             __syncthreads();
         }
     }
