@@ -463,6 +463,98 @@ def test_bilinear_align_backward_and_sizes(oracle_mod):
     assert torch.allclose(vi.grad, vi2.grad, atol=1e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_bilinear_align_config_size(oracle_mod, dt):
+    """BASELINE.json configs[1] shapes (B = A = 256, Q = 82, V = 36, d = 128): the fused maxima / diagonal block are
+    bit-equal to reductions of the materialised tensor, masked entries are exactly -1e20, and a 40-pair slice of the
+    tensor matches the fp64 oracle."""
+    from vlgae_amd import align
+    B, Q, V, d = 256, 82, 36, 128
+    g = torch.Generator().manual_seed(256)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    txt = (torch.randn(B, Q, d, generator=g) * 0.3).to(dev(), tdt)
+    vis = (torch.randn(B, V, d, generator=g) * 0.3).to(dev(), tdt)
+    tm = torch.rand(B, Q, generator=g).to(dev()) > 0.05
+    tm[:, 0] = tm[:, 41] = False                                   # the two root slots (joint.py:204,248-249)
+    vm = torch.rand(B, V, generator=g).to(dev()) > 0.1
+    vm[:, 0] = True
+    for masks in ((None, None), (tm, vm)):
+        full = align.bilinear_align(txt, vis, masks[0], masks[1], full=True)["full"]
+        r = align.bilinear_align(txt, vis, masks[0], masks[1], full=False, max_v=True, max_q=True, diag=True)
+        assert torch.equal(r["max_v"], full.max(3).values)
+        assert torch.equal(r["max_q"], full.max(2).values)
+        assert torch.equal(r["diag"], full[torch.arange(B), torch.arange(B)])
+        r1 = align.bilinear_align(txt, vis, masks[0], masks[1], full=False, max_q=True)
+        r2 = align.bilinear_align(txt, vis, masks[0], masks[1], full=False, max_v=True)
+        assert torch.equal(r1["max_q"], r["max_q"]) and torch.equal(r2["max_v"], r["max_v"])
+        if masks[0] is not None:
+            dead = ~(tm[:, None, :, None] & vm[None, :, None, :])
+            assert bool((full[dead] == -1e20).all()) and bool((full[~dead] > -1e19).all())
+        # oracle slice: captions 0..7 x images 0..4 (40 pairs), the same (possibly bf16-rounded) features
+        nb, na = 8, 5
+        tn, vn = txt[:nb].float().cpu().numpy(), vis[:na].float().cpu().numpy()
+        ref = oracle_mod.bilinear_align(tn, vn, None if masks[0] is None else tm[:nb].cpu().numpy(),
+                                        None if masks[1] is None else vm[:na].cpu().numpy(), np.float64)["full"]
+        got = full[:nb, :na].cpu().numpy()
+        live = ref > -1e19
+        assert np.array_equal(got[~live], ref[~live].astype(np.float32))
+        assert np.abs(got[live] - ref[live]).max() <= 2e-5 * max(1.0, np.abs(ref[live]).max())   # fp32 accumulation over d = 128
+        del full, r
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_grounding_loss_and_decoder_config_shapes_vs_oracle(oracle_mod, dt):
+    """Config-2 widths (Q = 82, V = 36, d = 128) on a 32-caption batch (the loss couples every pair of the batch through
+    its soft-max, so the oracle is run on the whole of a smaller batch rather than on a slice of 256): loss sums and
+    gradients against the fp64 oracle."""
+    from vlgae_amd import align
+    B, L, V, d = 32, 40, 36, 128
+    N, Q = L + 1, 2 * (L + 1)
+    rng = np.random.default_rng(3232)
+    txt = (rng.standard_normal((B, Q, d)) * 0.3).astype(np.float32)
+    vis = (rng.standard_normal((B, V, d)) * 0.3).astype(np.float32)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    txt_t, vis_t = t(txt).to(tdt), t(vis).to(tdt)
+    txt, vis = txt_t.float().cpu().numpy(), vis_t.float().cpu().numpy()      # the oracle sees the rounded features
+    lengths = rng.integers(L // 2, L + 1, size=B)
+    m1 = np.concatenate([np.zeros((B, 1), bool), np.arange(L)[None] < lengths[:, None]], 1)
+    tmask = np.concatenate([m1, m1], 1)
+    vmask = rng.random((B, V)) > 0.1
+    vmask[:, 0] = True
+    marg = (rng.random((B, Q)) * tmask).astype(np.float32)
+    num_token = float(lengths.sum())
+    ref = oracle_mod.grounding_loss(txt, vis, tmask, vmask, marg, num_token, 1.0, dtype=np.float64)
+    a, b = txt_t.clone().requires_grad_(True), vis_t.clone().requires_grad_(True)
+    total, sums = align.grounding_loss_factor_ce(a, b, t(tmask), t(vmask), t(marg), num_token, 1.0)
+    ga, gb = torch.autograd.grad(total, [a, b])
+    s_ = sums.detach().cpu().numpy()
+    assert abs(s_[0] - ref["txt2vis"]) <= 1e-4 * max(1.0, abs(ref["txt2vis"]))
+    assert abs(s_[1] - ref["vis2txt"]) <= 1e-4 * max(1.0, abs(ref["vis2txt"]))
+    for got, want in ((ga, ref["g_txt"]), (gb, ref["g_vis"])):
+        tol = (1e-4 if dt == "f32" else 1e-2) * max(1.0, np.abs(want).max())   # bf16: the gradient itself is returned in bf16
+        assert np.abs(got.float().cpu().numpy() - want).max() <= tol
+    # decoder at the same widths: image choice and top-5 columns of the (prior-free, heuristic-free) decode vs reductions of
+    # the oracle's tensor
+    dec = align.grounding_decode(txt_t, vis_t, t(tmask), t(vmask))
+    full = oracle_mod.bilinear_align(txt, vis, tmask, vmask, np.float64)["full"]
+    mv = full.max(3)                                                                # [B,A,Q] (joint.py:519-520)
+    f2i, top5, blk = dec["factor2img"].cpu().numpy(), dec["top5"].cpu().numpy(), dec["logit"].cpu().numpy()
+    diag = full[np.arange(B), np.arange(B)]                                         # [B,Q,V]
+    assert np.abs(blk[diag > -1e19] - diag[diag > -1e19]).max() <= 2e-5 * max(1.0, np.abs(diag[diag > -1e19]).max())
+    n_img = n_top = 0
+    for b in range(B):
+        for q in np.flatnonzero(tmask[b]):
+            col = np.sort(mv[b, :, q])[::-1]
+            if col[0] - col[1] > 1e-4:                                              # unambiguous at fp32 resolution
+                assert f2i[b, q] == int(np.argmax(mv[b, :, q]))
+                n_img += 1
+            row = np.sort(diag[b, q])[::-1]
+            if row[0] - row[1] > 1e-4 and row[0] > -1e19:
+                assert top5[b, q, 0] == int(np.argmax(diag[b, q]))
+                n_top += 1
+    assert n_img > B * 10 and n_top > B * 10
+
+
 @pytest.mark.parametrize("path", golden_files("attnfuse_"), ids=golden_ids("attnfuse_"))
 def test_attn_fuse_golden(path):
     from vlgae_amd import align
@@ -867,7 +959,8 @@ def test_arc_trilinear_shapes(oracle_mod, M, X, H, Y, dt):
         assert np.abs(got.float().cpu().numpy() - want).max() <= tol * max(1.0, np.abs(want).max()), name
 
 
-def test_training_step_chain(oracle_mod):
+@pytest.mark.parametrize("B,L,V,d", [(6, 9, 12, 32), (256, 40, 36, 128)], ids=["toy", "config2"])
+def test_training_step_chain(oracle_mod, B, L, V, d):
     """One pass over the whole path as the model wires it (joint.py:245-287 lang_feat_max_tree, :406-491 grounding):
     DMV marginals + best heads -> txt_marginal and parent gather -> arc encoder -> alignment -> grounding loss -> gradients
     to the feature tensors and the arc-encoder weights.  Ours end to end vs the same wiring in plain torch ops; the DP
@@ -875,9 +968,9 @@ def test_training_step_chain(oracle_mod):
     import vlgae_amd.torch_struct as ts
     from vlgae_amd import align
     rng = np.random.default_rng(77)
-    B, L, V, d = 6, 9, 12, 32
     N, Q = L + 1, 2 * (L + 1)
-    lengths = np.array([9, 7, 9, 4, 8, 5])
+    lengths = np.array([9, 7, 9, 4, 8, 5]) if B == 6 else rng.integers(L // 2, L + 1, size=B)
+    lengths[0] = L
     dec = np.log(rng.dirichlet(np.ones(2), (B, L, 2, 2))).astype(np.float32)
     attach = rng.standard_normal((B, L, L, 2)).astype(np.float32)
     root = np.log(rng.dirichlet(np.ones(L), B)).astype(np.float32)
@@ -924,9 +1017,12 @@ def test_training_step_chain(oracle_mod):
 
     (t1, g1), (t2, g2) = run(True), run(False)
     assert abs(float(t1) - float(t2)) <= 1e-4 * abs(float(t2))
+    # config size: 65 536 pairs x 118 arg-max terms feed each gradient row -- fp32 summation order differs between the
+    # sparse row updates here and autograd's dense GEMMs there
+    rel = 2e-4 if B <= 8 else 1e-3
     for k in g2:
         scale = max(1e-3, float(g2[k].abs().max()))
-        assert float((g1[k] - g2[k]).abs().max()) <= 2e-4 * scale, k
+        assert float((g1[k] - g2[k]).abs().max()) <= rel * scale, k
 
 
 def test_marginals_and_heads_two_streams(ts):

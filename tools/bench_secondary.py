@@ -88,6 +88,9 @@ def dp_entry(B, L, dtype_name, dev, n=100):
 
 
 def run_all(out, args, h, dev):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import vlgae_amd.torch_struct as ts
     from vlgae_amd.torch_struct import functional as Fn
     from vlgae_amd import align
@@ -197,3 +200,49 @@ def run_all(out, args, h, dev):
         "fwd_bwd_ms": timed(lambda: torch.autograd.grad(align.arc_trilinear(a_child, a_w1, a_parent),
                                                         [a_child, a_w1, a_parent], a_dout), 10, dev),
         "shape": f"M={B * N} X=H=Y={d} {args.dtype} in; einsum('bcx,xhy,bcy->bch') without the [M,H,Y] intermediate"}
+
+
+    # ---- configs[4]: the chained training-step hot path (tools/train_step.py), eager and as one captured HIP graph ----
+    try:
+        out["train_step"] = train_step_entry(B, L, V, in_dtype, dev)
+    except Exception as e:   # a capture failure must not cost the headline line
+        out["train_step"] = {"error": repr(e)[:300]}
+
+
+def train_step_entry(B, L, V, dtype, dev):
+    import train_step
+    step = train_step.build(B, L, V, dev, dtype=dtype)
+    for _ in range(5):
+        step()
+
+    def wall(fn, n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e3, (t1 - t0) / n * 1e3
+    eager_ms, enqueue_ms = wall(step, 30)
+    res = {"eager_ms": eager_ms, "host_enqueue_ms": enqueue_ms,
+           "what": "attention_fuse -> 2 library GEMMs -> DMV1o marginals + Viterbi heads -> arc_encoder -> alignment maxima + "
+                   "grounding cross-entropy -> -DMV1o.max (viterbi_training) -> gradients to every feature / weight / potential "
+                   f"(tools/train_step.py; joint.py:235-292,406-491,658-675; ldndmv.py:277-281), B={B} L={L} V={V} d=128 h=256, "
+                   "synthetic encoder features (frozen BERT / Faster-RCNN weights are not in the container)",
+           "sentences_per_s_eager": B / (eager_ms * 1e-3)}
+    gr = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    with torch.cuda.graph(gr):
+        step()
+    for _ in range(5):
+        gr.replay()
+    graph_ms, _ = wall(gr.replay, 50)
+    res.update(graph_ms=graph_ms, sentences_per_s_graph=B / (graph_ms * 1e-3),
+               note="graph replay has no host work between kernels: graph_ms is the device time of the chain; "
+                    "eager_ms - graph_ms is what the Python / autograd host path still costs")
+    return res

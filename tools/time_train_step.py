@@ -1,0 +1,36 @@
+"""Eager vs HIP-graph timing of the chained training-step hot path (tools/train_step.py) + host-side profile."""
+import sys, time, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
+import train_step
+dev = torch.device('cuda:0')
+B, L, V = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 40, 36)
+step = train_step.build(B, L, V, dev)
+for _ in range(5): step()
+torch.cuda.synchronize()
+def wall(fn, n):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+print('eager: %.3f ms/step' % wall(step, 30))
+t0 = time.perf_counter()
+for _ in range(30): step()
+print('host enqueue: %.3f ms/step' % ((time.perf_counter() - t0) / 30 * 1e3)); torch.cuda.synchronize()
+try:
+    gr = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3): step()
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(gr):
+        out = step()
+    for _ in range(5): gr.replay()
+    print('graph: %.3f ms/step' % wall(gr.replay, 50))
+except Exception as e:
+    print('graph capture failed:', repr(e)[:300])
+if '--profile' in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(20): step()
+    pr.disable(); torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(35)
