@@ -132,6 +132,15 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
                        int Q, int V, int d, int in_dtype, float neg_inf, float* out_full, float* out_maxV,
                        float* out_maxQ, float* out_diag, void* stream);
 
+/* Backward of the materialised alignment tensor -- what autograd runs for joint.py:413-418 when the reference's own
+ * loss_grounding_factor_ce consumes gather_logit_simple's [B,A,Q,V] output (loss.backward()):
+ *   grad_txt[b,q,:] = tmask[b,q] * sum_{a,v} grad_out[b,a,q,v] * vmask[a,v] * vis[a,v,:]
+ *   grad_vis[a,v,:] = vmask[a,v] * sum_{b,q} grad_out[b,a,q,v] * tmask[b,q] * txt[b,q,:]      (masked_fill_ passes no gradient)
+ *   grad_out [B,A,Q,V] fp32; txt [B,Q,d], vis [A,V,d] (in_dtype); grad_txt [B,Q,d], grad_vis [A,V,d] fp32 (either may be NULL).
+ * d in {32, 64, 128}.  fp32 matrix-core products (exact), the cotangent is read in place with both masks fused. */
+int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask,
+                                int B, int A, int Q, int V, int d, int in_dtype, float* grad_txt, float* grad_vis, void* stream);
+
 /* The grounding loss on the alignment, without the [B,A,Q,V] tensor -- DependencyBoxRel.gather_logit_simple followed by
  * loss_grounding_factor_ce, src/model/joint.py:406-419 + 439-491, A == B:
  *   att[b,a,q,v] = <txt[b,q], vis[a,v]>, masked -> neg_inf; on the pairs a == b the POS prior subtracts

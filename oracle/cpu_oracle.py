@@ -176,6 +176,21 @@ def bilinear_align(txt, vis, tmask=None, vmask=None, dtype=np.float32, neg_inf=-
     return dict(full=o_full, maxV=o_maxV, maxQ=o_maxQ, diag=o_diag)
 
 
+def bilinear_align_backward(g, txt, vis, tmask=None, vmask=None, dtype=np.float64):
+    """Adjoint of `bilinear_align` (joint.py:413-418 under autograd) for a cotangent g [B,A,Q,V]: (g_txt [B,Q,d], g_vis [A,V,d])."""
+    dtype, suf = _suffix(dtype)
+    g, txt, vis = (np.ascontiguousarray(x, dtype=dtype) for x in (g, txt, vis))
+    B, Q, d = txt.shape
+    A, V, _ = vis.shape
+    assert g.shape == (B, A, Q, V)
+    tm = None if tmask is None else np.ascontiguousarray(tmask, dtype=np.uint8)
+    vm = None if vmask is None else np.ascontiguousarray(vmask, dtype=np.uint8)
+    g_txt, g_vis = np.empty_like(txt), np.empty_like(vis)
+    rc = getattr(_load(), "orc_bilinear_align_bwd" + suf)(_p(g), _p(txt), _p(vis), _p(tm), _p(vm), B, A, Q, V, d, _p(g_txt), _p(g_vis))
+    assert rc == 0, rc
+    return g_txt, g_vis
+
+
 def attn_fuse(vis, txt, vis_mid, enc_x, gamma, beta, eps=1e-5, dtype=np.float32):
     """Attention-fuse, src/model/joint.py:670-674.  Returns (attmap [B,L,V], out [B,L,h])."""
     dtype, suf = _suffix(dtype)

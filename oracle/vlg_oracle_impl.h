@@ -363,6 +363,49 @@ int FN(orc_bilinear_align)(const REAL *txt, const REAL *vis, const unsigned char
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Adjoint of the alignment above for a cotangent g [B,A,Q,V] of attmap -- what autograd derives for
+ * joint.py:413-418 (einsum, then two masked_fill_: the filled positions pass no gradient):
+ *   g_txt[b,q,:] = sum_{a,v} keep(b,a,q,v) g[b,a,q,v] vis[a,v,:]     g_vis[a,v,:] = sum_{b,q} keep(b,a,q,v) g[b,a,q,v] txt[b,q,:]
+ *   keep = tmask[b,q] && vmask[a,v]
+ * ------------------------------------------------------------------------------------------ */
+int FN(orc_bilinear_align_bwd)(const REAL *g, const REAL *txt, const REAL *vis, const unsigned char *tmask,
+                               const unsigned char *vmask, int B, int A, int Q, int V, int d, REAL *g_txt, REAL *g_vis) {
+    if (g_txt) {
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int b = 0; b < B; ++b)
+            for (int q = 0; q < Q; ++q) {
+                REAL *o = g_txt + ((size_t)b * Q + q) * d;
+                for (int k = 0; k < d; ++k) o[k] = 0;
+                if (tmask && !tmask[(size_t)b * Q + q]) continue;
+                for (int a = 0; a < A; ++a)
+                    for (int v = 0; v < V; ++v) {
+                        if (vmask && !vmask[(size_t)a * V + v]) continue;
+                        const REAL w = g[(((size_t)b * A + a) * Q + q) * V + v];
+                        const REAL *y = vis + ((size_t)a * V + v) * d;
+                        for (int k = 0; k < d; ++k) o[k] += w * y[k];
+                    }
+            }
+    }
+    if (g_vis) {
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int a = 0; a < A; ++a)
+            for (int v = 0; v < V; ++v) {
+                REAL *o = g_vis + ((size_t)a * V + v) * d;
+                for (int k = 0; k < d; ++k) o[k] = 0;
+                if (vmask && !vmask[(size_t)a * V + v]) continue;
+                for (int b = 0; b < B; ++b)
+                    for (int q = 0; q < Q; ++q) {
+                        if (tmask && !tmask[(size_t)b * Q + q]) continue;
+                        const REAL w = g[(((size_t)b * A + a) * Q + q) * V + v];
+                        const REAL *x = txt + ((size_t)b * Q + q) * d;
+                        for (int k = 0; k < d; ++k) o[k] += w * x[k];
+                    }
+            }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Attention-fuse feeding the parser, src/model/joint.py:670-674:
  *   att[b,q,:] = softmax_v( sum_d vis[b,v,d] * txt[b,1+q,d] )          (no region masking: faithful)
  *   x[b,q,:]   = sum_v att[b,q,v] * vis_mid[b,v,:]

@@ -463,6 +463,42 @@ def test_bilinear_align_backward_and_sizes(oracle_mod):
     assert torch.allclose(vi.grad, vi2.grad, atol=1e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,A,Q,V,d,dt", [(5, 5, 82, 36, 128, "f32"), (5, 5, 82, 36, 128, "bf16"), (3, 4, 7, 130, 64, "f32"),
+                                          (2, 3, 100, 5, 32, "bf16"), (1, 1, 1, 1, 128, "f32"), (4, 2, 33, 201, 128, "f32")])
+def test_bilinear_align_backward_vs_oracle(oracle_mod, B, A, Q, V, d, dt):
+    """vlg_bilinear_align_backward (the hand-written adjoint of the materialised tensor, joint.py:413-418 under autograd)
+    against the fp64 oracle: both masks, contraction lengths across the 96-element chunk boundary, one- and several-tile
+    row counts, all three feature widths, bf16 storage; through autograd (gather_logit) and directly."""
+    from vlgae_amd import align
+    rng = np.random.default_rng(B * 1000 + Q * 7 + V)
+    txt = rng.standard_normal((B, Q, d)).astype(np.float32)
+    vis = rng.standard_normal((A, V, d)).astype(np.float32)
+    tm, vm = rng.random((B, Q)) > 0.2, rng.random((A, V)) > 0.2
+    g = rng.standard_normal((B, A, Q, V)).astype(np.float32)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    tt, tv = t(txt).to(tdt), t(vis).to(tdt)
+    txt, vis = tt.float().cpu().numpy(), tv.float().cpu().numpy()
+    for masks in ((tm, vm), (None, None)):
+        ref_t, ref_v = oracle_mod.bilinear_align_backward(g, txt, vis, masks[0], masks[1], np.float64)
+        mt = None if masks[0] is None else t(masks[0])
+        mvv = None if masks[1] is None else t(masks[1])
+        gt, gv = align.bilinear_align_backward(t(g), tt, tv, mt, mvv)
+        for got, want in ((gt, ref_t), (gv, ref_v)):     # exact fp32 products, fp32 accumulation over A*V / B*Q terms
+            assert np.abs(got.cpu().numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+        only_t, none_v = align.bilinear_align_backward(t(g), tt, tv, mt, mvv, want_vis=False)
+        assert none_v is None and torch.equal(only_t, gt)
+        gt2, gv2 = align.bilinear_align_backward(t(g), tt, tv, mt, mvv)
+        assert torch.equal(gt2, gt) and torch.equal(gv2, gv)                # reproducible (two-addend atomics are order-free)
+    # through autograd, as the reference's loss would reach it
+    a_, b_ = tt.clone().requires_grad_(True), tv.clone().requires_grad_(True)
+    out = align.gather_logit(None, (b_, t(vm), None), (a_, t(tm), None), None).rename(None)
+    ga, gb = torch.autograd.grad(out, [a_, b_], t(g))
+    ref_t, ref_v = oracle_mod.bilinear_align_backward(g, txt, vis, tm, vm, np.float64)
+    tol = 2e-5 if dt == "f32" else 8e-3        # bf16 leaves get bf16 gradients
+    assert np.abs(ga.float().cpu().numpy() - ref_t).max() <= tol * max(1.0, np.abs(ref_t).max())
+    assert np.abs(gb.float().cpu().numpy() - ref_v).max() <= tol * max(1.0, np.abs(ref_v).max())
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 def test_bilinear_align_config_size(oracle_mod, dt):
     """BASELINE.json configs[1] shapes (B = A = 256, Q = 82, V = 36, d = 128): the fused maxima / diagonal block are

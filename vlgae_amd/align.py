@@ -56,8 +56,8 @@ def bilinear_align(txt_feat, vis_feat, txt_mask=None, vis_mask=None, neg_inf=-IN
 
 class _GatherLogit(torch.autograd.Function):
     """attmap with gradients to both feature tensors (the grounding loss back-propagates through it).
-    Backward of the contraction is two more contractions; masked entries carry no gradient
-    (masked_fill_, joint.py:417-418)."""
+    Backward of the contraction is two more contractions (vlg_bilinear_align_backward); masked entries carry no
+    gradient (masked_fill_, joint.py:417-418)."""
 
     @staticmethod
     def forward(ctx, txt_feat, vis_feat, txt_mask, vis_mask, neg_inf):
@@ -68,21 +68,38 @@ class _GatherLogit(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, g):
         txt_feat, vis_feat, txt_mask, vis_mask = ctx.saved_tensors
-        g = g.to(torch.float32)
-        if txt_mask is not None:
-            g = g * txt_mask[:, None, :, None].to(g.dtype)
-        if vis_mask is not None:
-            g = g * vis_mask[None, :, None, :].to(g.dtype)
-        B, A, Q, V = g.shape
-        # plain library GEMMs (rocBLAS via torch): d(txt)[b,q,:] = sum_{a,v} g * vis ; d(vis)[a,v,:] = sum_{b,q} g * txt
-        g_txt = g_vis = None
-        if ctx.needs_input_grad[0]:
-            g_txt = torch.matmul(g.permute(0, 2, 1, 3).reshape(B * Q, A * V), vis_feat.reshape(A * V, -1).float())
-            g_txt = g_txt.reshape(B, Q, -1).to(txt_feat.dtype)
-        if ctx.needs_input_grad[1]:
-            g_vis = torch.matmul(g.permute(1, 3, 0, 2).reshape(A * V, B * Q), txt_feat.reshape(B * Q, -1).float())
-            g_vis = g_vis.reshape(A, V, -1).to(vis_feat.dtype)
-        return g_txt, g_vis, None, None, None
+        g_txt, g_vis = bilinear_align_backward(g, txt_feat, vis_feat, txt_mask, vis_mask, ctx.needs_input_grad[0],
+                                               ctx.needs_input_grad[1])
+        return (None if g_txt is None else g_txt.to(txt_feat.dtype), None if g_vis is None else g_vis.to(vis_feat.dtype),
+                None, None, None)
+
+
+def bilinear_align_backward(grad_out, txt_feat, vis_feat, txt_mask=None, vis_mask=None, want_txt=True, want_vis=True):
+    """Gradients of `bilinear_align(...)["full"]` w.r.t. both feature tensors for the cotangent grad_out [B,A,Q,V] (what
+    autograd derives for joint.py:413-418; masked positions pass no gradient).  Returns (g_txt [B,Q,d], g_vis [A,V,d]) in
+    float32 (None where not wanted).  One HIP kernel per gradient reads the cotangent in place -- no permuted, masked or
+    up-cast copies of it -- on the fp32 matrix cores; there is no library-GEMM / eager fallback."""
+    txt_feat, vis_feat, txt_mask, vis_mask = _plain(txt_feat), _plain(vis_feat), _plain(txt_mask), _plain(vis_mask)
+    _C.require_gpu(txt_feat, "bilinear_align_backward")
+    B, Q, d = txt_feat.shape
+    A, V, _ = vis_feat.shape
+    if tuple(grad_out.shape) != (B, A, Q, V):
+        raise ValueError(f"grad_out must be [B,A,Q,V]={(B, A, Q, V)}, got {tuple(grad_out.shape)}")
+    dev = txt_feat.device
+    g = _plain(grad_out)
+    if g.dtype != torch.float32 or not g.is_contiguous():
+        g = g.to(torch.float32).contiguous()
+    dt, txt_c = _C.in_dtype(txt_feat.detach())
+    vis_c = vis_feat.detach().to(txt_c.dtype).contiguous()
+    tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    vm = None if vis_mask is None else vis_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    g_txt = torch.empty((B, Q, d), dtype=torch.float32, device=dev) if want_txt else None
+    g_vis = torch.empty((A, V, d), dtype=torch.float32, device=dev) if want_vis else None
+    if want_txt or want_vis:
+        _C.check(_C.lib().vlg_bilinear_align_backward(_C.ptr(g), _C.ptr(txt_c), _C.ptr(vis_c), _C.ptr(tm), _C.ptr(vm), B, A, Q, V,
+                                                      d, dt, _C.ptr(g_txt), _C.ptr(g_vis), _C.stream_of(txt_c)),
+                 "bilinear_align_backward")
+    return g_txt, g_vis
 
 
 def gather_logit(inputs, vis, txt, vp=None):

@@ -12,6 +12,7 @@
 // A generic fp32-FMA kernel remains for shapes the MFMA path does not take (d > 128 or unaligned d).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -665,6 +666,135 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
     return check_launch("align_max_kernel");
 }
 
+// =====================================================================================================
+// Backward of the materialised alignment tensor (joint.py:413-418 under loss.backward()): given the cotangent
+// g [B,A,Q,V] of attmap,
+//   d_txt[b,q,:] = tmask[b,q] * sum_{a,v} g[b,a,q,v] * vmask[a,v] * vis[a,v,:]          (SIDE 0)
+//   d_vis[a,v,:] = vmask[a,v] * sum_{b,q} g[b,a,q,v] * tmask[b,q] * txt[b,q,:]          (SIDE 1)
+// (masked_fill_ passes no gradient).  Both are the same loop with different strides into g: an output row tile
+// (16 rows of M = Q | V) per wavefront, all 128 feature columns in its accumulators, an outer loop over the O = A | B
+// tensors of the other side and the contraction over K = V | Q inside it.  v_mfma_f32_16x16x4_f32: exact fp32
+// products (the reference's numerics) and -- one element per lane per k -- no layout constraint, so g is read ONCE,
+// in place, with both masks folded into the operand load: no permuted / masked / up-cast copies of the 774 MB
+// cotangent (the torch.matmul formulation made three).  The other side's feature tile streams through a
+// double-buffered LDS tile shared by the block's waves (pitch 144: the four k rows of a fragment read hit disjoint banks).
+// =====================================================================================================
+constexpr int kBwdThreads = 256;
+
+// NCT = d / 16 column tiles; NS = k-steps (of 4) per contraction chunk, a compile-time count: a run-time bound on the
+// unrolled step loop makes hipcc shuttle all 32 accumulator registers between AGPRs and VGPRs around every step
+template <typename In, int NCT, int NS>
+__global__ __launch_bounds__(kBwdThreads) void align_bwd_kernel(
+    const float* __restrict__ g, const typename In::T* __restrict__ feat, const uint8_t* __restrict__ kmask,
+    const uint8_t* __restrict__ rmask, int O, int M, int K, long so, long sr, long sk, long sfix, int o_per_block,
+    float* __restrict__ out, int use_atomic) {
+    using T = typename In::T;
+    constexpr int D = NCT * 16, PITCH = D + 16, MAXS = NS, Kc = NS * 4;   // Kc: contraction chunk = rows of one LDS tile
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int nck = (K + Kc - 1) / Kc;                            // contraction chunks per outer index
+    T* tile0 = reinterpret_cast<T*>(smem_raw);
+    T* tile1 = tile0 + (size_t)Kc * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gk = lane >> 4, ccol = lane & 15;
+    const int fix = blockIdx.y, rt = blockIdx.x * 4 + wave;
+    const int o0 = blockIdx.z * o_per_block, o1 = min(O, o0 + o_per_block);
+    const int it0 = o0 * nck, it1 = o1 * nck;                     // iterations: (outer index, chunk) pairs
+    const int row = rt * 16 + ccol, rowc = min(row, M - 1);      // A-operand row of this lane (clamped; rows >= M are never stored)
+    const bool wave_live = rt * 16 < M;
+    const float* gb = g + (size_t)fix * sfix + (size_t)rowc * sr;
+    // the other side's feature tile of iteration `it`: global -> registers (issued one iteration ahead, so the loads land under
+    // the MFMAs) -> LDS (after the MFMAs)
+    constexpr int EPV = 16 / sizeof(T), VPR = D / EPV, NV = (Kc * VPR + kBwdThreads - 1) / kBwdThreads;
+    auto stage_load = [&](int it, uint4* x) {
+        const int o = it / nck, k0 = (it - o * nck) * Kc;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * kBwdThreads, k = i / VPR, c = (i - k * VPR) * EPV;
+            x[j] = make_uint4(0, 0, 0, 0);                        // rows past K, and rows the contraction-side mask drops: zeros
+            if (k < Kc && k0 + k < K && !(kmask && !kmask[(size_t)o * K + k0 + k]))
+                x[j] = *reinterpret_cast<const uint4*>(feat + ((size_t)o * K + k0 + k) * D + c);
+        }
+    };
+    auto stage_write = [&](T* tile, const uint4* x) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * kBwdThreads, k = i / VPR, c = (i - k * VPR) * EPV;
+            if (k < Kc) *reinterpret_cast<uint4*>(tile + (size_t)k * PITCH + c) = x[j];
+        }
+    };
+    auto load_a = [&](int it, float* a) {   // this lane's A elements: k = k0 + 4 t + gk, both masks' contraction side folded in
+        const int o = it / nck, k0 = (it - o * nck) * Kc;
+        const float* p = gb + (size_t)o * so;
+        // unconditional loads on a clamped index (no branch between them: all in flight together).  The contraction-side mask
+        // is NOT applied here: the masked feature rows are staged as zeros, which removes those terms just the same.
+#pragma unroll
+        for (int t = 0; t < MAXS; ++t) a[t] = p[(size_t)min(k0 + 4 * t + gk, K - 1) * sk];
+#pragma unroll
+        for (int t = 0; t < MAXS; ++t)
+            if (k0 + 4 * t + gk >= K) a[t] = 0.f;
+    };
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The cotangent comes from HBM: its loads run two iterations ahead of their use, in three register sets whose roles
+    // rotate by unrolling the iteration loop three times (copying a set into the next would wait for the loads just issued).
+    float a0[MAXS], a1[MAXS], a2[MAXS];
+    uint4 xs[NV];
+    if (it0 < it1) {
+        stage_load(it0, xs);
+        stage_write(tile0, xs);
+        if (wave_live) {
+            load_a(it0, a0);
+            if (it0 + 1 < it1) load_a(it0 + 1, a1);
+        }
+    }
+    __syncthreads();
+    auto body = [&](int it, const float* cur, float* ahead) {
+        T* tcur = ((it - it0) & 1) ? tile1 : tile0;
+        T* tnxt = ((it - it0) & 1) ? tile0 : tile1;
+        if (it + 1 < it1) stage_load(it + 1, xs);
+        if (wave_live && it + 2 < it1) load_a(it + 2, ahead);
+        if (wave_live) {
+            float bb[2][NCT];   // B fragments one k-step ahead of the MFMAs (the LDS latency hides under the previous step)
+            const T* bbase = tcur + (size_t)gk * PITCH + ccol;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) bb[0][c] = In::ld(bbase, c * 16);
+#pragma unroll
+            for (int t = 0; t < MAXS; ++t) {
+                if (t + 1 < MAXS) {
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) bb[(t + 1) & 1][c] = In::ld(bbase + (size_t)(4 * (t + 1)) * PITCH, c * 16);
+                }
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t], bb[t & 1][c], acc[c], 0, 0, 0);
+            }
+        }
+        if (it + 1 < it1) stage_write(tnxt, xs);
+        __syncthreads();
+    };
+    for (int it = it0; it < it1; it += 3) {
+        body(it, a0, a2);
+        if (it + 1 < it1) body(it + 1, a1, a0);
+        if (it + 2 < it1) body(it + 2, a2, a1);
+    }
+    if (!wave_live) return;
+    // accumulator tile: lane l, register n <-> row 4 (l >> 4) + n, column l & 15
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int r = rt * 16 + gk * 4 + n;
+        if (r >= M) continue;
+        const float keep = (rmask && !rmask[(size_t)fix * M + r]) ? 0.f : 1.f;
+        float* dst = out + ((size_t)fix * M + r) * D + ccol;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const float v = acc[c][n] * keep;
+            if (use_atomic) atomicAdd(dst + c * 16, v);   // two partial sums per element at most: order-free
+            else dst[c * 16] = v;
+        }
+    }
+}
+
 template <bool F32IN, int KCH, bool TILE, bool ARGS = false, int RTBV = MfmaCfg<F32IN>::RTB, bool DIRECT = false>
 static int launch_align_mfma(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A,
                              int Q, int V, float neg_inf, float* out_full, float* out_maxV, float* out_maxQ,
@@ -768,6 +898,62 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
     else VLG_LAUNCH(BF16In);
 #undef VLG_LAUNCH
     return check_launch("align_kernel");
+}
+
+int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask,
+                                int B, int A, int Q, int V, int d, int in_dtype, float* grad_txt, float* grad_vis, void* stream) {
+    using namespace vlg;
+    if (B < 1 || A < 1 || Q < 1 || V < 1) return set_error(VLG_ERR_SHAPE, "bilinear_align_backward: bad shape B=%d A=%d Q=%d V=%d", B, A, Q, V);
+    if (d != 128 && d != 64 && d != 32) return set_error(VLG_ERR_SHAPE, "bilinear_align_backward: d=%d (supported: 32, 64, 128)", d);
+    if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "bilinear_align_backward: in_dtype %d", in_dtype);
+    if (!grad_out || !txt || !vis || (!grad_txt && !grad_vis)) return set_error(VLG_ERR_ARG, "bilinear_align_backward: null buffer");
+    if (B > 65535 || A > 65535) return set_error(VLG_ERR_SHAPE, "bilinear_align_backward: B=%d A=%d exceed grid.y", B, A);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t esz = in_dtype == VLG_F32 ? 4 : 2;
+    auto go = [&](const void* feat, const uint8_t* km, const uint8_t* rm, int fixn, int O, int M, int K, long so, long sr, long sk,
+                  long sfix, float* out) -> int {
+        // k-steps per chunk from a small compile-time set (extra steps multiply zeros): 9 <-> V = 36, 21 <-> Q = 82
+        const int steps = (K + 3) / 4;
+        const int ns = steps <= 6 ? 6 : steps <= 9 ? 9 : steps <= 12 ? 12 : steps <= 21 ? 21 : 24;
+        const size_t lds = 2 * (size_t)ns * 4 * (d + 16) * esz;
+        const int tiles = (M + 15) / 16, gx = (tiles + 3) / 4;
+        // split the outer range over several workgroups; their partial sums meet in a zeroed output by atomicAdd
+        int split = 1;   // >= 3 workgroups per CU: the cotangent streams from HBM and only other waves hide that latency
+        while (split < 8 && (long)gx * fixn * split < 768 && O / (split * 2) >= 16) split *= 2;
+        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e);   // tools/ experiments only
+        const int opb = (O + split - 1) / split;
+        if (split > 1) {
+            hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)fixn * M * d, s);
+            if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        dim3 grid(gx, fixn, split);
+#define VLG_BWD3(INV, NCTV, NSV)                                                                                       \
+        do {                                                                                                           \
+            auto k = align_bwd_kernel<INV, NCTV, NSV>;                                                                 \
+            if (lds > 64 * 1024) {                                                                                     \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));        \
+            }                                                                                                          \
+            hipLaunchKernelGGL(k, grid, dim3(kBwdThreads), lds, s, grad_out, (const INV::T*)feat, km, rm, O, M, K, so, sr, sk,    \
+                               sfix, opb, out, split > 1 ? 1 : 0);                                                     \
+        } while (0)
+#define VLG_BWD(INV, NCTV)                                                                                             \
+        do {                                                                                                           \
+            if (ns == 6) VLG_BWD3(INV, NCTV, 6); else if (ns == 9) VLG_BWD3(INV, NCTV, 9); else if (ns == 12) VLG_BWD3(INV, NCTV, 12); \
+            else if (ns == 21) VLG_BWD3(INV, NCTV, 21); else VLG_BWD3(INV, NCTV, 24);                                  \
+        } while (0)
+        if (in_dtype == VLG_F32) { if (d == 128) VLG_BWD(F32In, 8); else if (d == 64) VLG_BWD(F32In, 4); else VLG_BWD(F32In, 2); }
+        else { if (d == 128) VLG_BWD(BF16In, 8); else if (d == 64) VLG_BWD(BF16In, 4); else VLG_BWD(BF16In, 2); }
+#undef VLG_BWD
+#undef VLG_BWD3
+        return check_launch("align_bwd_kernel");
+    };
+    const long QV = (long)Q * V;
+    if (grad_txt)   // rows q of caption b; outer a, contraction v:  g[((b A + a) Q + q) V + v]
+        if (int rc = go(vis, vmask, tmask, B, A, Q, V, QV, V, 1, (long)A * QV, grad_txt)) return rc;
+    if (grad_vis)   // rows v of image a; outer b, contraction q
+        if (int rc = go(txt, tmask, vmask, A, B, V, Q, (long)A * QV, 1, V, QV, grad_vis)) return rc;
+    return 0;
 }
 
 size_t vlg_grounding_loss_workspace(int B, int Q, int V) {
