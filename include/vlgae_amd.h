@@ -20,7 +20,10 @@
  *     and all outputs are fp32.
  *   - `lengths[b]` = number of words of sentence b (root excluded), 1 <= len <= N-1.  A sentence
  *     with an out-of-range length gets logZ = NaN and all-zero gradients.
- *   - Semiring zero is the finite sentinel -1e12 (semirings.py:16,128), never -inf.
+ *   - Semiring zero is the finite sentinel -1e12 (semirings.py:16,128), never -inf.  Potentials MAY contain -inf (or
+ *     anything below -1e30): they are clamped to -1e30 as they are loaded, i.e. treated as probability zero like the
+ *     reference's logsumexp does; +inf / NaN potentials are the caller's error (NaN is clamped to the floor as well).
+ *   - Every pointer of one call must belong to the CURRENT HIP device of the calling thread (launches go there).
  */
 #ifndef VLGAE_AMD_H
 #define VLGAE_AMD_H
@@ -100,7 +103,8 @@ int vlg_deptree_decode(const void* arc, const int64_t* lengths, int B, int N, in
  *   attach_rule [B,L,T,2(dir),2(val)], dec [B,L,2,2,2], root_rule [T] (root_per_sentence = 0) or [B,T] (= 1),
  *   token [B,L] int64 in [0,T), head_mask [B,L] uint8 or NULL, lengths [B];
  *   logZ [B]; grad_rule [B,L,T,2,2], grad_dec [B,L,2,2,2], grad_root [B,T] (all three or none; zero-filled here);
- *   heads [B,L+1] optional (Viterbi heads, semiring 1).  Workspace: vlg_workspace_bytes(VLG_OP_DMV1O_*, B, L+1, semiring). */
+ *   heads [B,L+1] optional (Viterbi heads: semiring must be 1, else VLG_ERR_ARG).  A sentence with a token id outside
+ *   [0,T) is treated like one with an out-of-range length: logZ = NaN, zero counts.  Workspace: vlg_workspace_bytes(VLG_OP_DMV1O_*, B, L+1, semiring). */
 int vlg_dmv1o_rules(const void* attach_rule, const void* dec, const void* root_rule, int root_per_sentence,
                     const int64_t* token, const uint8_t* head_mask, const int64_t* lengths, int B, int L, int T,
                     int in_dtype, int semiring, float mask_fill, const float* grad_logZ, float* logZ, float* grad_rule,

@@ -56,6 +56,12 @@ def test_version_and_error_plumbing(lib):
     assert lib.vlg_bilinear_align(None, None, None, None, 2, 3, 4, 5, 8, 0, -1e20, None, None, None,
                                   ctypes.c_void_p(16), None) == 0x1001                               # diag needs A == B
     assert lib.vlg_dmv1o_merge(None, None, None, 2, 0, 0, 0.0, -1e12, None, None, None) == 0x1001
+    # a head vector only exists for the Viterbi tree: heads with the Log semiring is an argument error, before any launch
+    one = ctypes.c_void_p(16)
+    assert lib.vlg_dmv1o_rules(one, one, one, 0, one, None, one, 2, 5, 7, 0, 0, -1e20, None, one, None, None, None, one,
+                               None, 0, None) == 0x1003 and b"VLG_SEMIRING_MAX" in lib.vlg_last_error()
+    assert lib.vlg_bilinear_align_backward(one, one, one, None, None, 2, 2, 5, 5, 48, 0, one, one, None) == 0x1001   # d not in {32,64,128}
+    assert lib.vlg_dmv1o_count_sum(None, None, 4, 8, None, None) == 0x1003
     with pytest.raises(RuntimeError, match="N >= 2"):
         _C.check(lib.vlg_dmv1o_inside(None, None, None, 4, 1, 0, 0, None, None, 0, None), "dmv1o_inside")
     # empty batches are a no-op success

@@ -257,6 +257,58 @@ def test_dmv1o_long_sentences_full_size(ts, oracle_mod, dt):
     assert torch.equal(heads_am[:, 0].sum(-1), torch.ones(B, device=dev()))
 
 
+def test_dmv1o_minus_inf_potentials_and_bad_tokens(ts, oracle_mod):
+    """-inf potentials (a caller masking with float('-inf')) act as probability zero, like the reference's logsumexp:
+    same logZ / counts as the reference's own finite sentinel in their place, everything finite.  Token ids outside
+    [0, T) in the rule-table entry mark the sentence invalid (NaN score, zero counts) instead of indexing out of bounds."""
+    from vlgae_amd.torch_struct import functional as Fn
+    rng = np.random.default_rng(17)
+    B, L = 6, 12
+    dec = np.log(rng.dirichlet(np.ones(2), (B, L, 2, 2))).astype(np.float32)
+    attach = rng.standard_normal((B, L, L, 2)).astype(np.float32)
+    root = np.log(rng.dirichlet(np.ones(L), B)).astype(np.float32)
+    lengths = np.array([12, 9, 12, 5, 7, 1])
+    kill = rng.random((B, L, L)) < 0.25
+    kill[:, np.arange(L), np.arange(L)] = False
+    a_inf, a_fin = attach.copy(), attach.copy()
+    a_inf[kill] = -np.inf
+    a_fin[kill] = -1e12
+    outs = []
+    for att in (a_inf, a_fin):
+        md, ma = ts.DMV1o.merge(t(dec), t(att), t(root))
+        outs.append(Fn.dmv1o_run(md, ma, t(lengths), 0, True))
+    (lz1, gd1, ga1), (lz2, gd2, ga2) = outs
+    assert bool(torch.isfinite(lz1).all() and torch.isfinite(gd1).all() and torch.isfinite(ga1).all())
+    assert torch.allclose(lz1, lz2, rtol=1e-6, atol=1e-5) and torch.allclose(ga1, ga2, atol=1e-6) and torch.allclose(gd1, gd2, atol=1e-6)
+    omd, oma = oracle_mod.dmv1o_merge(dec, a_fin, root)
+    rlz, _, rga = oracle_mod.dmv1o(omd, oma, lengths, "log", np.float64)
+    assert np.all(np.abs(lz1.cpu().numpy().reshape(rlz.shape) - rlz) <= logz_tol(rlz))
+    assert np.abs(ga1.cpu().numpy() - rga).max() <= MARG_TOL
+    assert float(ga1[torch.from_numpy(np.pad(kill, ((0, 0), (1, 0), (1, 0)))).to(dev())].abs().max()) == 0.0   # forbidden arcs: exactly zero
+    # Max semiring / decode on the same potentials: a tree that avoids every forbidden arc
+    _, heads = Fn.dmv1o_decode(*ts.DMV1o.merge(t(dec), t(a_inf), t(root)), t(lengths))
+    hh = heads.cpu().numpy()
+    for b in range(B):
+        for c in range(1, lengths[b] + 1):
+            if hh[b, c] > 0:
+                assert not kill[b, hh[b, c] - 1, c - 1]
+    # ---- rule tables: an out-of-range token id ----
+    T = 7
+    rule = rng.standard_normal((B, L, T, 2, 2)).astype(np.float32)
+    rroot = rng.standard_normal((T,)).astype(np.float32)
+    tok = rng.integers(0, T, (B, L))
+    tok_bad = tok.copy()
+    tok_bad[1, 3] = T          # inside sentence 1 (length 9)
+    tok_bad[3, 8] = -1         # beyond sentence 3's length 5: never read, the sentence stays valid
+    good = Fn.dmv1o_rules_run(t(rule), t(dec), t(rroot), t(tok), t(lengths), 0, True)
+    bad = Fn.dmv1o_rules_run(t(rule), t(dec), t(rroot), t(tok_bad), t(lengths), 0, True)
+    assert bool(torch.isnan(bad["logZ"][1])) and float(bad["grad_rule"][1].abs().max()) == 0.0 and float(bad["grad_root"][1].abs().max()) == 0.0
+    keep = [0, 2, 3, 4, 5]
+    assert torch.equal(bad["logZ"][keep], good["logZ"][keep]) and torch.equal(bad["grad_rule"][keep], good["grad_rule"][keep])
+    with pytest.raises(RuntimeError, match="VLG_SEMIRING_MAX"):
+        Fn.dmv1o_rules_run(t(rule), t(dec), t(rroot), t(tok), t(lengths), 0, False, want_heads=True)
+
+
 def test_dmv1o_edge_cases(ts):
     # B = 0
     lz = ts.DMV1o([torch.zeros(0, 5, 2, 2, 2, device=dev()), torch.zeros(0, 5, 5, 2, device=dev())],

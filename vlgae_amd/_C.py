@@ -85,6 +85,12 @@ def ptr(t):
 
 
 def stream_of(t):
+    """The HIP stream the launch goes to: the current stream of t's device.  hipLaunchKernel acts on the process's CURRENT
+    device, so a tensor that lives elsewhere must not get this far (it would launch onto the wrong GPU or fail with an
+    invalid handle): fail loudly instead."""
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"vlgae_amd: tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "wrap the call in `with torch.cuda.device(t.device):` (one process per GPU sets it once)")
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 

@@ -272,7 +272,15 @@ __global__ __launch_bounds__(kThreads) void dmv1o_rules_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, N = Lw + 1;
     const int len = (int)lengths[b];
-    if (len < 1 || len > Lw) {   // outputs were zero-filled by the launcher
+    // a token id outside [0, T) (a pad / unk id) would index the rule tables -- and scatter the counts -- out of bounds:
+    // such a sentence is "not a sentence", like an out-of-range length (block-uniform test)
+    bool bad_tok = false;
+    if (len >= 1 && len <= Lw)
+        for (int i = tid; i < len; i += kThreads) {
+            const long long tk = token[(size_t)b * Lw + i];
+            bad_tok |= tk < 0 || tk >= T;
+        }
+    if (__syncthreads_or(bad_tok) || len < 1 || len > Lw) {   // outputs were zero-filled by the launcher
         if (tid == 0) logZ[b] = __uint_as_float(0x7fc00000u);
         if (BWD && heads) for (int i = tid; i < N; i += kThreads) heads[(size_t)b * N + i] = 0;
         return;
@@ -616,6 +624,8 @@ int vlg_dmv1o_rules(const void* attach_rule, const void* dec, const void* root_r
     if (semiring != VLG_SR_LOG && semiring != VLG_SR_MAX) return set_error(VLG_ERR_ARG, "dmv1o_rules: semiring %d", semiring);
     if (B == 0) return 0;
     if (!attach_rule || !dec || !root_rule || !token || !lengths || !logZ) return set_error(VLG_ERR_ARG, "dmv1o_rules: null buffer");
+    if (heads && semiring != VLG_SR_MAX)
+        return set_error(VLG_ERR_ARG, "dmv1o_rules: a head vector is the Viterbi tree -- pass semiring = VLG_SEMIRING_MAX with heads");
     const bool bwd = grad_rule || grad_dec || grad_root || heads;
     if (bwd && !heads && !(grad_rule && grad_dec && grad_root))
         return set_error(VLG_ERR_ARG, "dmv1o_rules: pass all three gradient buffers (or only heads)");

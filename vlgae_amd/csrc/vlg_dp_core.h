@@ -89,6 +89,12 @@ struct F32In {
     static VLG_HDM float ld(const T* p, size_t i) { return p[i]; }
     static VLG_HDM float2 ld2(const T* p, size_t i) { return make_float2(p[i], p[i + 1]); }
 };
+// Potentials may carry -inf (a caller masking with float('-inf'), log_softmax underflow): the reference's logsumexp
+// treats it as probability zero.  The DP arithmetic is finite-math (sentinel -1e12, never inf - inf), so potentials are
+// clamped to a finite floor as they enter: below every real score, and small enough that sums of a few stay in range.
+#define VLG_POT_FLOOR (-1e30f)
+VLG_HD float pot_clamp(float x) { return x > VLG_POT_FLOOR ? x : VLG_POT_FLOOR; }   // also maps NaN to the floor
+VLG_HD float2 pot_clamp2(float2 x) { return make_float2(pot_clamp(x.x), pot_clamp(x.y)); }
 struct BF16In {
     using T = uint16_t;
     static VLG_HDM float ld(const T* p, size_t i) { return VLG_BITS2F((uint32_t)p[i] << 16); }
@@ -766,8 +772,8 @@ struct MergedIO {
     float* gatt;
     long long* heads;               // may be null
     VLG_HDM int out_extent(int) const { return N; }   // outputs cover the padded square: zeros beyond the sentence
-    VLG_HDM float ld_dec(int i) const { return In::ld(dec, i); }
-    VLG_HDM float2 ld_attach(int h, int ch) const { return In::ld2(attach, ((size_t)h * N + ch) * 2); }
+    VLG_HDM float ld_dec(int i) const { return pot_clamp(In::ld(dec, i)); }
+    VLG_HDM float2 ld_attach(int h, int ch) const { return pot_clamp2(In::ld2(attach, ((size_t)h * N + ch) * 2)); }
     VLG_HDM void st_attach(int h, int ch, float2 g) const {
         if (gatt) *reinterpret_cast<float2*>(gatt + ((size_t)h * N + ch) * 2) = g;
         if (heads && g.x + g.y != 0.f) heads[ch] = h;
@@ -801,16 +807,16 @@ struct RuleIO {
     VLG_HDM float ld_dec(int i) const {
         const int h = i >> 3, k = i & 7;
         if (h == 0) return (k >> 2) == 1 ? 0.f : VLG_NEGINF;                 // dec_wroot[0,RIGHT] = one, else zero
-        return In::ld(dec, (h - 1) * 8 + k);
+        return pot_clamp(In::ld(dec, (h - 1) * 8 + k));
     }
     VLG_HDM size_t rule_index(int h, int ch) const {                          // h, ch >= 1, h != ch
         return ((((size_t)(h - 1) * T + (size_t)token[ch - 1]) * 2 + (ch < h ? 0 : 1)) * 2);
     }
     VLG_HDM float2 ld_attach(int h, int ch) const {
         if (ch == 0) return make_float2(VLG_NEGINF, VLG_NEGINF);             // nobody attaches the root
-        if (h == 0) return make_float2(VLG_NEGINF, In::ld(root, (size_t)token[ch - 1]));   // [0, c, NOCHILD] = root
+        if (h == 0) return make_float2(VLG_NEGINF, pot_clamp(In::ld(root, (size_t)token[ch - 1])));   // [0, c, NOCHILD] = root
         if (head_mask && head_mask[h - 1]) return make_float2(fill, fill);
-        return In::ld2(rule, rule_index(h, ch));
+        return pot_clamp2(In::ld2(rule, rule_index(h, ch)));
     }
     VLG_HDM void st_attach(int h, int ch, float2 g) const {
         if (heads && g.x + g.y != 0.f) heads[ch] = h;
@@ -1081,7 +1087,7 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
             c.C[h * P + h] = 0.f;        // semiring one, deptree.py:44
             c.C[h * P + h + 1] = 0.f;
         } else {
-            const float a = In::ld(arc, (size_t)h * N + ch) * VLG_LOG2E;
+            const float a = pot_clamp(In::ld(arc, (size_t)h * N + ch)) * VLG_LOG2E;
             if (ch < h) c.I[h * P + ch] = a;
             else c.I[h * P + ch + 1] = a;
         }
