@@ -231,6 +231,20 @@ int vlg_attn_fuse_backward(const void* vis, const void* txt, const void* vis_mid
                            size_t ws_bytes, float* d_vis, float* d_txt, float* d_vis_mid, float* d_enc_x, float* d_gamma,
                            float* d_beta, void* stream);
 
+/* Pairwise relation features of the visual encoder -- VisBoxRelSimpleEncoder.forward, src/model/vis_encoder/box_rel.py:41-45:
+ *   rel[b,i,j,:] = LeakyReLU( rel_fc.linear( (inputs[b,i] + inputs[b,j]) / 2 ) )
+ * By linearity of the Linear layer this is LeakyReLU((y[b,i] + y[b,j]) / 2 + bias) with y = inputs W^T (one library GEMM,
+ * done by the caller); the [B,R,R,n_in] pairwise-mean tensor and the 35x larger GEMM over it never exist.
+ *   y [B,R,H], out [B,R,R,H] (both `dtype`: VLG_F32 or VLG_BF16), bias [H] fp32 (NULL = 0), slope = LeakyReLU's (0.01).
+ *   H a multiple of 4 with H/4 dividing 256. */
+int vlg_box_rel_pairwise(const void* y, const float* bias, int B, int R, int H, int dtype, float slope, void* out, void* stream);
+
+/* Its adjoint: grad_out [B,R,R,H] (`dtype`) -> grad_y [B,R,H], grad_bias [H] (fp32; grad_bias may be NULL).
+ * ws: vlg_box_rel_pairwise_backward_workspace bytes (only needed with grad_bias).  Fixed summation order. */
+size_t vlg_box_rel_pairwise_backward_workspace(int B, int R, int H);
+int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* grad_out, int B, int R, int H, int dtype, float slope,
+                                  void* ws, size_t ws_bytes, float* grad_y, float* grad_bias, void* stream);
+
 /* Device self-test of the cross-lane (DPP / ds_swizzle) exchange primitives the DP kernels rely on.
  * `scratch` = one device int; after the stream drains it holds 0 iff the primitives behave as assumed. */
 int vlg_selftest_xlane(int* scratch, void* stream);

@@ -524,3 +524,29 @@ def enumerate_dmv1o(dec, attach, length):
         scores.append(s)
     m = max(scores)
     return m + math.log(sum(math.exp(s - m) for s in scores)), m
+
+
+# ----------------------------------------------------------------------------------------------
+# Visual encoder's pairwise relation features, src/model/vis_encoder/box_rel.py:29-52 (numpy, fp64): the reference's
+# formulation restated literally -- pairwise mean of [box ; mean box] inputs, Linear, LeakyReLU -- and its adjoint.
+# ----------------------------------------------------------------------------------------------
+def box_rel(feat, weight, bias, slope=0.01, img_feat=True, dout=None):
+    """feat [B,R,n], weight [H,n_in], bias [H] -> rel [B,R*R,H]; with dout [B,R*R,H] also (g_feat, g_weight, g_bias)."""
+    feat, weight, bias = (np.asarray(x, dtype=np.float64) for x in (feat, weight, bias))
+    B, R, n = feat.shape
+    inputs = np.concatenate([feat, np.broadcast_to(feat.mean(1, keepdims=True), feat.shape)], -1) if img_feat else feat   # :33-38
+    rel_inp = (inputs[:, None, :, :] + inputs[:, :, None, :]) / 2                                                          # :41
+    pre = rel_inp @ weight.T + bias                                                                                        # rel_fc.linear
+    rel = np.where(pre > 0, pre, pre * slope).reshape(B, R * R, -1)                                                        # LeakyReLU, :45
+    if dout is None:
+        return rel
+    g_pre = np.asarray(dout, dtype=np.float64).reshape(pre.shape) * np.where(pre > 0, 1.0, slope)
+    g_bias = g_pre.sum((0, 1, 2))
+    g_weight = np.einsum("bijh,bijn->hn", g_pre, rel_inp)
+    g_rel_inp = g_pre @ weight
+    g_inputs = (g_rel_inp.sum(1) + g_rel_inp.sum(2)) / 2
+    if img_feat:
+        g_feat = g_inputs[..., :n] + g_inputs[..., n:].sum(1, keepdims=True) / R
+    else:
+        g_feat = g_inputs
+    return rel, g_feat, g_weight, g_bias

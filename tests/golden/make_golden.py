@@ -437,6 +437,30 @@ def arcenc_cases():
         print(f"{name}: arc {tuple(arc.shape)}")
 
 
+def boxrel_cases():
+    """VisBoxRelSimpleEncoder.forward (vis_encoder/box_rel.py:29-52), the reference's own module executed: pairwise-mean
+    input -> rel_fc (Linear + LeakyReLU), with gradients to the region features and the rel_fc parameters."""
+    import _ref_import
+    _ref_import.import_joint()
+    from src.model.vis_encoder import VisBoxRelSimpleEncoder
+    for name, seed, B, R, n_in, n_hidden in (("boxrel_B3_R5_in48_h32_s0", 0, 3, 5, 48, 32), ("boxrel_B1_R35_in64_h64_s1", 1, 1, 35, 64, 64)):
+        torch.manual_seed(seed)
+        enc = VisBoxRelSimpleEncoder(n_in=n_in, n_hidden=n_hidden, dropout=0., activate=True, use_attr=True, use_img=False,
+                                     img_feat=True)
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            enc.rel_fc.linear.bias.copy_(torch.randn(n_hidden, generator=g) * 0.1)     # reset_parameters zeroes it
+        feat = torch.randn(B, R, n_in, generator=g).requires_grad_(True)
+        out = enc({"vis_box_feat": feat}, None)
+        dout = torch.randn(B, R * R, n_hidden, generator=g)
+        w, b = enc.rel_fc.linear.weight, enc.rel_fc.linear.bias
+        grads = torch.autograd.grad(out["rel"], [feat, w, b], dout)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), feat=_np(feat), weight=_np(w), bias=_np(b), rel=_np(out["rel"]),
+                            dout=_np(dout), g_feat=_np(grads[0]), g_weight=_np(grads[1]), g_bias=_np(grads[2]),
+                            slope=np.float32(enc.rel_fc.activation.negative_slope))
+        print(f"{name}: rel {tuple(out['rel'].shape)}")
+
+
 if __name__ == "__main__":
     dmv_case("dmv_B4_L10_s0", 0, 4, 10, "rand", store_merged=True)
     dmv_case("dmv_B4_L10_s1_full", 1, 4, 10, "full")
@@ -461,3 +485,4 @@ if __name__ == "__main__":
     decode_cases()
     reduced_cases()
     arcenc_cases()
+    boxrel_cases()

@@ -1145,3 +1145,87 @@ def test_count_sum_matches_batch_sum(B, N):
     out2 = torch.empty_like(out)
     _C.check(_C.lib().vlg_dmv1o_count_sum(_C.ptr(gdec), _C.ptr(gatt), B, N, _C.ptr(out2), _C.stream_of(out)), "count_sum")
     assert torch.equal(out2[:-5], out[:-5])        # fixed order: identical bits run to run
+
+
+# ------------------------------------------------------------------------------------------------ visual encoder: rel features
+@pytest.mark.parametrize("path", golden_files("boxrel_"), ids=golden_ids("boxrel_"))
+def test_box_rel_golden(path):
+    """rel_features (one library GEMM + the pairwise HIP epilogue) against the reference's own VisBoxRelSimpleEncoder."""
+    from vlgae_amd import vis_encoder
+    g = load(path)
+    feat, w, b = t(g["feat"]).requires_grad_(True), t(g["weight"]).requires_grad_(True), t(g["bias"]).requires_grad_(True)
+    rel = vis_encoder.rel_features(feat, w, b, True, float(g["slope"]))
+    assert rel.shape == g["rel"].shape
+    assert np.abs(rel.detach().cpu().numpy() - g["rel"]).max() <= 2e-5 * max(1.0, np.abs(g["rel"]).max())
+    gf, gw, gb = torch.autograd.grad(rel, [feat, w, b], t(g["dout"]))
+    for got, name in ((gf, "g_feat"), (gw, "g_weight"), (gb, "g_bias")):
+        assert np.abs(got.cpu().numpy() - g[name]).max() <= 5e-5 * max(1.0, np.abs(g[name]).max()), name
+
+
+@pytest.mark.parametrize("B,R,n,H,dt", [(4, 35, 96, 256, "f32"), (3, 7, 40, 64, "f32"), (1, 1, 8, 4, "f32"), (5, 36, 64, 256, "bf16"),
+                                        (2, 33, 32, 128, "bf16")])
+def test_box_rel_vs_oracle(oracle_mod, B, R, n, H, dt):
+    from vlgae_amd import vis_encoder
+    rng = np.random.default_rng(B * 100 + R)
+    feat = rng.standard_normal((B, R, n)).astype(np.float32)
+    w = (rng.standard_normal((H, 2 * n)) / np.sqrt(2 * n)).astype(np.float32)
+    b = (rng.standard_normal(H) * 0.1).astype(np.float32)
+    dout = rng.standard_normal((B, R * R, H)).astype(np.float32)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    tf, tw, tb = (t(x).to(tdt).requires_grad_(True) for x in (feat, w, b))
+    ref = oracle_mod.box_rel(tf.detach().float().cpu().numpy(), tw.detach().float().cpu().numpy(), tb.detach().float().cpu().numpy(),
+                             0.01, True, dout)
+    rel = vis_encoder.rel_features(tf, tw, tb)
+    grads = torch.autograd.grad(rel, [tf, tw, tb], t(dout).to(tdt))
+    if dt == "f32":
+        for got, want in zip((rel.detach(), *grads), ref):
+            assert np.abs(got.float().cpu().numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    else:
+        # bf16 storage: the library GEMMs around the kernel round y and every gradient to bf16, and the rounding of y flips
+        # LeakyReLU'(pre) where pre ~ 0 -- so the chain is only checked on its forward value here, and the kernel pair itself is
+        # checked exactly: pairwise_rel on a given bf16 y against fp64 arithmetic on the same values
+        assert np.abs(rel.detach().float().cpu().numpy() - ref[0]).max() <= 2e-2 * max(1.0, np.abs(ref[0]).max())
+        y = (torch.randn(B, R, H, generator=torch.Generator().manual_seed(R)) * 2).to(dev(), tdt).requires_grad_(True)
+        bias = t(b).requires_grad_(True)
+        gout = t(dout).to(tdt).view(B, R, R, H)
+        out = vis_encoder.pairwise_rel(y, bias)
+        gy, gb = torch.autograd.grad(out, [y, bias], gout)
+        y64, g64 = y.detach().double().cpu().numpy(), gout.double().cpu().numpy()
+        pre = (y64[:, :, None] + y64[:, None, :]) / 2 + b.astype(np.float64)
+        want = np.where(pre > 0, pre, pre * 0.01)
+        assert np.abs(out.detach().float().cpu().numpy() - want).max() <= 2.0 ** -8 * max(1.0, np.abs(want).max())   # output rounded to bf16
+        gp = g64 * np.where(pre > 0, 1.0, 0.01)
+        # the kernel forms pre in fp32 from the bf16 y: identical sign decisions except within 1 fp32 ulp of zero
+        want_gy = (gp.sum(2) + gp.sum(1)) / 2
+        assert np.abs(gy.float().cpu().numpy() - want_gy).max() <= 2.0 ** -7 * max(1.0, np.abs(want_gy).max())      # returned in bf16
+        assert np.abs(gb.cpu().numpy() - gp.sum((0, 1, 2))).max() <= 1e-4 * max(1.0, np.abs(gp.sum((0, 1, 2))).max())
+    # reproducible, and nothing past the end
+    rel2 = vis_encoder.rel_features(tf, tw, tb)
+    assert torch.equal(rel2, rel)
+
+
+def test_box_rel_config_size():
+    """Shipped sizes (36 boxes, n_in = 2 x 2048, H = 256) at B = 64: against the reference formulation in torch ops on the
+    GPU (pairwise mean materialised: 1.3 GB), forward and gradients."""
+    from vlgae_amd import vis_encoder
+    B, R, n, H = 64, 36, 2048, 256
+    g = torch.Generator().manual_seed(64)
+    feat = (torch.randn(B, R, n, generator=g) * 0.5).to(dev())
+    w = (torch.randn(H, 2 * n, generator=g) / (2 * n) ** 0.5).to(dev())
+    b = (torch.randn(H, generator=g) * 0.1).to(dev())
+    dout = torch.randn(B, R * R, H, generator=g).to(dev())
+    outs = []
+    for ours in (True, False):
+        f_, w_, b_ = (x.clone().requires_grad_(True) for x in (feat, w, b))
+        if ours:
+            rel = vis_encoder.rel_features(f_, w_, b_)
+        else:
+            inputs = torch.cat([f_, f_.mean(1, keepdim=True).expand(-1, R, -1)], -1)
+            rel = torch.nn.functional.leaky_relu(torch.nn.functional.linear((inputs.unsqueeze(1) + inputs.unsqueeze(2)) / 2, w_, b_))
+            rel = rel.view(B, R * R, H)
+        outs.append((rel.detach(), *torch.autograd.grad(rel, [f_, w_, b_], dout)))
+    # forward: fp32 rounding of two summation orders over n_in = 4096.  Gradients: LeakyReLU' is discontinuous at 0, and the
+    # few of the 21 M pre-activations that land within rounding of 0 take the other slope in the other summation order --
+    # one such flip moves a gradient entry by ~ |dout| |w| ~ 4e-3
+    for k, (a, r) in enumerate(zip(*outs)):
+        assert float((a - r).abs().max()) <= (2e-5 if k == 0 else 3e-3) * max(1.0, float(r.abs().max())), k

@@ -213,3 +213,13 @@ def test_oracle_arc_encoder_matches_reference(oracle_mod, path):
     for name, arr in (("g_child", d_child), ("g_parent", d_parent), ("g_w2", d_w2), ("g_b", d_b)):
         assert np.abs(arr - g[name]).max() <= 2e-5 * max(1.0, np.abs(g[name]).max()), name
     arcenc_check_w1_grad(d_w1, g, 2e-5)
+
+
+@pytest.mark.parametrize("path", golden_files("boxrel_"), ids=golden_ids("boxrel_"))
+def test_oracle_box_rel_matches_reference(oracle_mod, path):
+    """VisBoxRelSimpleEncoder.forward (box_rel.py:29-52), the reference's own module run by make_golden.py, and its autograd."""
+    g = load(path)
+    rel, g_feat, g_w, g_b = oracle_mod.box_rel(g["feat"], g["weight"], g["bias"], float(g["slope"]), True, g["dout"])
+    for got, want in ((rel, g["rel"]), (g_feat, g["g_feat"]), (g_w, g["g_weight"]), (g_b, g["g_bias"])):
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())     # fixtures are fp32 runs of the reference

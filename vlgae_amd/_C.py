@@ -47,6 +47,9 @@ SIGNATURES = {
     "vlg_attn_fuse_backward_workspace": (_sz, [_i, _i, _i, _i]),
     "vlg_attn_fuse_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
+    "vlg_box_rel_pairwise": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "vlg_box_rel_pairwise_backward_workspace": (_sz, [_i, _i, _i]),
+    "vlg_box_rel_pairwise_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "vlg_selftest_xlane": (_i, [_vp, _vp]),
     "vlg_last_error": (ctypes.c_char_p, []),
     "vlg_version": (_i, []),
