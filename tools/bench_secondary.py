@@ -87,6 +87,19 @@ def dp_entry(B, L, dtype_name, dev, n=100):
             "exp_rate": {"achieved_Gops": ops / sec / 1e9, "peak_Gops": exp_peak / 1e9, "frac": ops / sec / exp_peak}}
 
 
+def mfma_busy(kernel):
+    """MFMA-busy fraction of a matrix-core kernel from the committed PMC passes (profiles/r02_g_mfma_busy.json; counters cannot be
+    collected inside this run: rocprofv3 --pmc needs its own passes)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_g_mfma_busy.json")
+    try:
+        d = json.load(open(path))
+        return {"frac": d[kernel]["mfma_busy"], "source": "profiles/r02_g_mfma_busy.json (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, committed rocprofv3 PMC pass)"}
+    except Exception:
+        return None
+
+
 def run_all(out, args, h, dev):
     import os
     import sys
@@ -145,6 +158,7 @@ def run_all(out, args, h, dev):
             "sentences_per_s": B / sec, "ms": sec * 1e3, "TFLOP/s": flops / sec / 1e12,
             "frac_mfma_bf16_peak": flops / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS if in_dtype == torch.bfloat16 else None,
             "GB/s": byts / sec / 1e9, "frac_hbm": byts / sec / 1e9 / HBM_PEAK_GBS,
+            "mfma_busy": mfma_busy("align_mfma_kernel<TILE> (full tensor)" if full else "align_max_kernel") if in_dtype == torch.bfloat16 else None,
             "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in (2048-d / 768-d features through fixed-seed Linear->128), fp32 out"}
 
     # the two consumers on the training path: attention-fuse (joint.py:670-674) and the grounding loss on the
@@ -159,6 +173,7 @@ def run_all(out, args, h, dev):
         "fwd_ms": timed(lambda: align.attention_fuse(f_vis.detach(), f_txt.detach(), f_mid.detach(), f_enc.detach(),
                                                      ln_w.detach(), ln_b.detach(), 1e-5), 50, dev),
         "fwd_bwd_ms": timed(lambda: torch.autograd.grad(align.attention_fuse(*leaves, 1e-5), leaves, dout), 50, dev),
+        "mfma_busy": {"fwd": mfma_busy("attn_fuse_mfma_kernel"), "bwd_words": mfma_busy("attn_fuse_bwd_words_kernel")},
         "shape": f"B={B} L={L} V={V} d={d} h={hdim} {args.dtype} in; host API incl. autograd overhead"}
     tmask = torch.ones(B, Q, dtype=torch.bool, device=dev)
     tmask[:, 0] = tmask[:, N] = False
@@ -199,6 +214,7 @@ def run_all(out, args, h, dev):
         "fwd_ms": timed(lambda: align.arc_trilinear(a_child.detach(), a_w1.detach(), a_parent.detach()), 20, dev),
         "fwd_bwd_ms": timed(lambda: torch.autograd.grad(align.arc_trilinear(a_child, a_w1, a_parent),
                                                         [a_child, a_w1, a_parent], a_dout), 10, dev),
+        "mfma_busy": {"tri_kernel": mfma_busy("tri_kernel"), "tri_dw_kernel": mfma_busy("tri_dw_kernel")},
         "shape": f"M={B * N} X=H=Y={d} {args.dtype} in; einsum('bcx,xhy,bcy->bch') without the [M,H,Y] intermediate"}
 
 
