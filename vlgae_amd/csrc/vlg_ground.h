@@ -8,7 +8,7 @@ namespace vlg {
 
 // Scratch carving for vlg_grounding_loss (offsets in floats from the workspace base).
 struct GroundPlan {
-    size_t off_maxV, off_maxQ, off_part, off_coef, off_argV, off_argQ, bytes;
+    size_t off_maxV, off_maxQ, off_part, off_coef, off_argV, off_argQ, off_featT, bytes;
     GroundPlan(int B, int Q, int V);
 };
 

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "vlg_common.h"
@@ -481,6 +483,205 @@ static int launch_bwd(const void* txt, const void* vis, const float* gV, const u
     return 0;
 }
 
+// =====================================================================================================
+// Dense route of the same gradient on the matrix cores (bf16 features, d = 128, Q <= 96, V <= 64: config-2 and anything
+// smaller).  Per caption x image pair the terms form a sparse Q x V weight matrix
+//     W_ba[q,v] = c1 gV[b,a,q] [v == argV[b,a,q]]  +  c2 gQ[b,a,v] [q == argQ[b,a,v]]
+// and  g_txt[b] = sum_a W_ba vis[a],  g_vis[a] = sum_b W_ba^T txt[b].  The sparse kernels above read one 256-byte feature
+// row per term from L2 (15.4 M rows, 3.9 GB at config-2: 0.29 + 0.29 ms, L2-bandwidth bound).  Here a pair is 96 + 72
+// v_mfma_f32_16x16x32_bf16 whose A operand W (rows of this side, contraction over the other side's positions) is BUILT IN
+// REGISTERS from the four small arrays -- two compares and two selects per element -- and whose B operand is the other
+// side's feature tile, read once per pair per block through LDS (0.6 GB of L2 -> LDS traffic in all).  The B operand
+// must be contraction-major, so the features are transposed once per call into a [tensor][d][Kp] scratch (2.4 + 5.4 MB).
+// W is rounded to bf16 (2^-9 relative per term), which is the precision the bf16 path returns its gradients in anyway;
+// fp32 features keep the sparse kernels (exact fp32 products).  One wave per 16-row tile, accumulation over the outer
+// loop in registers, fixed order: reproducible, no atomics.
+// =====================================================================================================
+constexpr int kGdD = 128;
+
+// feat [O][K][128] bf16 -> featT [O][128][Kp] bf16 (zero-padded): block = one tensor o, LDS transpose in 32-row strips
+__global__ __launch_bounds__(256) void ground_transpose_kernel(const uint16_t* __restrict__ feat, int K, int Kp,
+                                                               uint16_t* __restrict__ featT) {
+    __shared__ uint16_t t[32][kGdD + 2];
+    const int o = blockIdx.x;
+    for (int k0 = 0; k0 < Kp; k0 += 32) {
+        for (int i = threadIdx.x; i < 32 * kGdD; i += 256) {
+            const int k = i / kGdD, c = i - k * kGdD;
+            t[k][c] = k0 + k < K ? feat[((size_t)o * K + k0 + k) * kGdD + c] : (uint16_t)0;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * kGdD; i += 256) {
+            const int c = i >> 5, k = i & 31;
+            featT[((size_t)o * kGdD + c) * Kp + k0 + k] = t[k][c];
+        }
+        __syncthreads();
+    }
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 gd_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float gd_f32x4;
+
+// SIDE 0: fix = caption b, rows = its queries (M = Q), outer o = image a, contraction over regions (K = V);
+//         self terms = (argV, gV) per row, other terms = (argQ, gQ) per contraction position.
+// SIDE 1: fix = image a, rows = its regions (M = V), outer o = caption b, contraction over queries (K = Q); roles swapped.
+// NKC = Kp / 32 contraction chunks.  Block = ceil(M / 16) waves.
+template <int SIDE, int NKC, int NW>   // NW = wavefronts per block = ceil(M / 16)
+__global__ __launch_bounds__(64 * NW) void ground_bwd_dense_kernel(
+    const uint16_t* __restrict__ featT, const float* __restrict__ gV, const uint16_t* __restrict__ argV,
+    const float* __restrict__ gQ, const uint16_t* __restrict__ argQ, const float* __restrict__ coef, int B, int Q, int V,
+    float* __restrict__ out) {
+    constexpr int Kp = NKC * 32, PITCH = Kp * 2 + 16, SEGS = Kp / 8;   // padded row pitch in bytes
+    constexpr int MR = NW * 16, nthr = 64 * NW;
+    const int A = B, M = SIDE == 0 ? Q : V, K = SIDE == 0 ? V : Q;
+    // the outer range is split over gridDim.y blocks (occupancy: one block per CU leaves the LDS / barrier latency exposed)
+    const int o_per = (B + (int)gridDim.y - 1) / (int)gridDim.y, o_begin = blockIdx.y * o_per, O = min(B, o_begin + o_per);
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    auto tile = [&](int buf) -> char* { return smem_raw + buf * (kGdD * PITCH); };           // other side's features, [d][Kp] bf16
+    char* wself = smem_raw + 2 * kGdD * PITCH;                                                // W, "row's own maximum" terms   [MR][Kp] bf16
+    char* wother = wself + MR * PITCH;                                                        // W, "position points at row" terms
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fix = blockIdx.x, kg = lane >> 4, ccol = lane & 15;
+    const float c_self = SIDE == 0 ? coef[0] : coef[1], c_other = SIDE == 0 ? coef[1] : coef[0];
+    const float* g_self = SIDE == 0 ? gV : gQ;
+    const uint16_t* a_self = SIDE == 0 ? argV : argQ;
+    const float* g_other = SIDE == 0 ? gQ : gV;
+    const uint16_t* a_other = SIDE == 0 ? argQ : argV;
+    auto pair = [&](int o) -> size_t { return SIDE == 0 ? (size_t)fix * A + o : (size_t)o * A + fix; };
+    if (o_begin >= O) return;
+
+    // W is built in LDS by scatter: thread t < M owns row t of `wself` (one non-zero: column argself[t]), thread t < K owns
+    // column t of `wother` (one non-zero: row argother[t]) -- no two threads ever touch the same element, and each thread
+    // clears its previous element before writing the next one, so the tiles never need a full re-zeroing.  Where both kinds
+    // hit the same (row, column) their sum is formed by the matrix cores (two MFMAs per fragment pair).
+    for (int i = tid; i < 2 * MR * PITCH / 16; i += nthr) reinterpret_cast<uint4*>(wself)[i] = make_uint4(0, 0, 0, 0);
+    constexpr int NV = (kGdD * SEGS + nthr - 1) / nthr;   // 16-byte vectors of the feature tile per thread
+    auto stage_load = [&](int o, uint4* xs, int& ps, float& ws, int& po, float& wo) {
+        const uint4* src = reinterpret_cast<const uint4*>(featT + (size_t)o * kGdD * Kp);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * nthr;
+            if (i < kGdD * SEGS) xs[j] = src[i];
+        }
+        ps = po = -1;
+        ws = wo = 0.f;
+        if (tid < M) { ps = a_self[pair(o) * M + tid]; ws = c_self * g_self[pair(o) * M + tid]; }
+        if (tid < K) { po = a_other[pair(o) * K + tid]; wo = c_other * g_other[pair(o) * K + tid]; }
+    };
+    auto stage_tile = [&](int buf, const uint4* xs) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * nthr;
+            if (i < kGdD * SEGS) {
+                const int row = i / SEGS, seg = i - row * SEGS;
+                *reinterpret_cast<uint4*>(tile(buf) + row * PITCH + seg * 16) = xs[j];
+            }
+        }
+    };
+    auto f2bf = [](float f) -> uint16_t { return __builtin_bit_cast(uint16_t, (__bf16)f); };
+    gd_f32x4 acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = gd_f32x4{0.f, 0.f, 0.f, 0.f};
+    // Two register sets, each holding one pair's staged data (feature-tile vectors + this thread's W elements); a pair's
+    // loads are issued TWO iterations before they are consumed (the small arrays come from HBM, and one iteration is short),
+    // the sets swap roles by unrolling the pair loop twice.
+    uint4 xa[NV], xb[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) xa[j] = xb[j] = make_uint4(0, 0, 0, 0);
+    int psa, poa, psb = -1, pob = -1, ps_old = -1, po_old = -1;
+    float wsa, woa, wsb = 0.f, wob = 0.f;
+    stage_load(o_begin, xa, psa, wsa, poa, woa);
+    if (o_begin + 1 < O) stage_load(o_begin + 1, xb, psb, wsb, pob, wob);
+    __syncthreads();                       // the zero fill above
+    stage_tile(0, xa);
+    // one pair: (ps, ws, po, wo) are pair o's elements; xn holds pair o+1's feature tile; pair o+2 is loaded into the `cur` set
+    auto step = [&](int o, uint4* xcur, int& ps, float& ws, int& po, float& wo, const uint4* xnext) {
+        const int buf = (o - o_begin) & 1;
+        // ---- W of this pair: clear last pair's elements, write this pair's (same owner thread: program order) ----
+        auto welem = [&](char* w, int row, int col) { return reinterpret_cast<uint16_t*>(w + row * PITCH + col * 2); };
+        if (ps_old >= 0) *welem(wself, tid, ps_old) = 0;
+        if (po_old >= 0) *welem(wother, po_old, tid) = 0;
+        if (ps >= 0 && ps < K) *welem(wself, tid, ps) = f2bf(ws);
+        if (po >= 0 && po < M) *welem(wother, po, tid) = f2bf(wo);
+        ps_old = (ps >= 0 && ps < K) ? ps : -1;
+        po_old = (po >= 0 && po < M) ? po : -1;
+        if (o + 2 < O) stage_load(o + 2, xcur, ps, ws, po, wo);   // this set is free again: consumed two iterations from now
+        __syncthreads();                                          // W(o) and tile(o) complete
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int aoff = (wave * 16 + ccol) * PITCH + (kc * 4 + kg) * 16;
+            const gd_bf16x8 a0 = *reinterpret_cast<const gd_bf16x8*>(wself + aoff);
+            const gd_bf16x8 a1 = *reinterpret_cast<const gd_bf16x8*>(wother + aoff);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const gd_bf16x8 bf = *reinterpret_cast<const gd_bf16x8*>(tile(buf) + (c * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf, acc[c], 0, 0, 0);
+            }
+        }
+        if (o + 1 < O) stage_tile(buf ^ 1, xnext);                // the other feature buffer: last read in iteration o-1
+        __syncthreads();                                          // every wave is done with W(o) before it is rewritten
+    };
+    for (int o = o_begin; o < O; o += 2) {
+        step(o, xa, psa, wsa, poa, woa, xb);
+        if (o + 1 < O) step(o + 1, xb, psb, wsb, pob, wob, xa);
+    }
+    // accumulator tile: lane l, register n <-> row 4 (l >> 4) + n, column l & 15
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int rr = wave * 16 + kg * 4 + n;
+        if (rr < M) {
+            float* dst = out + ((size_t)fix * M + rr) * kGdD + ccol;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (gridDim.y > 1) atomicAdd(dst + c * 16, acc[c][n]);   // two partial sums into a zeroed output: order-free
+                else dst[c * 16] = acc[c][n];
+            }
+        }
+    }
+}
+
+static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, const uint16_t* argV, const float* gQ,
+                            const uint16_t* argQ, const float* coef, int B, int Q, int V, uint16_t* scratch, float* g_txt,
+                            float* g_vis, hipStream_t s) {
+    constexpr int KpV = 64, KpQ = 96;
+    uint16_t* visT = scratch;                              // [B][128][64]
+    uint16_t* txtT = scratch + (size_t)B * kGdD * KpV;     // [B][128][96]
+    auto lds = [](int Kp, int nw) { return (size_t)(2 * kGdD + 2 * nw * 16) * (Kp * 2 + 16); };
+    int split = B >= 32 ? 2 : 1;   // two blocks per caption / image (two-addend atomics stay order-free)
+    if (const char* e = getenv("VLG_GD_SPLIT")) split = atoi(e);
+    if (split > 1) {
+        hipError_t e = hipSuccess;
+        if (g_txt) e = hipMemsetAsync(g_txt, 0, sizeof(float) * (size_t)B * Q * kGdD, s);
+        if (e == hipSuccess && g_vis) e = hipMemsetAsync(g_vis, 0, sizeof(float) * (size_t)B * V * kGdD, s);
+        if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+#define VLG_GD(SIDEV, NKCV, NWV, FT, OUT)                                                                              \
+    hipLaunchKernelGGL((ground_bwd_dense_kernel<SIDEV, NKCV, NWV>), dim3(B, split), dim3(64 * NWV), lds(NKCV * 32, NWV), s, FT, gV, argV, gQ,  \
+                       argQ, coef, B, Q, V, OUT)
+    if (g_txt) {
+        hipLaunchKernelGGL(ground_transpose_kernel, dim3(B), dim3(256), 0, s, (const uint16_t*)vis, V, KpV, visT);
+        switch (std::max((Q + 15) / 16, (V + 63) / 64)) {   // waves: one per 16 rows, and at least one thread per contraction position
+            case 1: VLG_GD(0, 2, 1, visT, g_txt); break;
+            case 2: VLG_GD(0, 2, 2, visT, g_txt); break;
+            case 3: VLG_GD(0, 2, 3, visT, g_txt); break;
+            case 4: VLG_GD(0, 2, 4, visT, g_txt); break;
+            case 5: VLG_GD(0, 2, 5, visT, g_txt); break;
+            default: VLG_GD(0, 2, 6, visT, g_txt); break;
+        }
+    }
+    if (g_vis) {
+        hipLaunchKernelGGL(ground_transpose_kernel, dim3(B), dim3(256), 0, s, (const uint16_t*)txt, Q, KpQ, txtT);
+        switch (std::max((V + 15) / 16, (Q + 63) / 64)) {
+            case 1: VLG_GD(1, 3, 1, txtT, g_vis); break;
+            case 2: VLG_GD(1, 3, 2, txtT, g_vis); break;
+            case 3: VLG_GD(1, 3, 3, txtT, g_vis); break;
+            default: VLG_GD(1, 3, 4, txtT, g_vis); break;
+        }
+    }
+#undef VLG_GD
+    return 0;
+}
+
 // ---- gather_logit_reduced (joint.py:421-432) on the same machinery ----------------------------------------------------
 // Block = caption b; wave = image a (strided); lanes over the queries, then a fixed xor tree: same bits every run.
 __global__ __launch_bounds__(256) void reduced_logit_kernel(const float* __restrict__ maxV, const float* __restrict__ marg,
@@ -558,7 +759,9 @@ GroundPlan::GroundPlan(int B, int Q, int V) {
     off_coef = off_part + up(2 * (size_t)B * kCeMaxY);
     off_argV = off_coef + 64;                          // uint16 arrays, offsets still counted in floats
     off_argQ = off_argV + up((nV + 1) / 2);
-    bytes = sizeof(float) * (off_argQ + up((nQ + 1) / 2));
+    off_featT = off_argQ + up((nQ + 1) / 2);           // dense backward: transposed bf16 features [B][128][64] + [B][128][96]
+    const bool dense = Q <= 96 && V <= 64;
+    bytes = sizeof(float) * (off_featT + (dense ? up((size_t)B * 128 * (64 + 96) / 2) : 0));
 }
 
 int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marg,
@@ -582,7 +785,12 @@ int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask
     hipLaunchKernelGGL(ground_ce_kernel<uint8_t>, dim3(B, y2), dim3(kCeThreads), 0, s, mQ, (size_t)V, (size_t)B * V, B, V, vmask, aQ,
                        vmask, tmask, Q, part2);
     hipLaunchKernelGGL(ground_sum_kernel, dim3(1), dim3(64), 0, s, part, part2, B * y1, B * y2, num_token, w_v2t, out_sums, coef);
-    if (g_txt || g_vis) {
+    if ((g_txt || g_vis) && in_dtype == VLG_BF16 && d == kGdD && Q <= 96 && V <= 64 && !getenv("VLG_GROUND_SPARSE")) {
+        // bf16 features at config-2 widths: the dense route on the matrix cores
+        if (int rc = launch_bwd_dense(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, reinterpret_cast<uint16_t*>(ws + p.off_featT), g_txt,
+                                      g_vis, s))
+            return rc;
+    } else if (g_txt || g_vis) {
         const int rc = in_dtype == VLG_F32 ? launch_bwd<F32In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s, w_v2t > 0.f)
                                            : launch_bwd<BF16In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s, w_v2t > 0.f);
         if (rc) return rc;
