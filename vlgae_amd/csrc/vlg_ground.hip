@@ -606,16 +606,29 @@ __global__ __launch_bounds__(64 * NW) void ground_bwd_dense_kernel(
         po_old = (po >= 0 && po < M) ? po : -1;
         if (o + 2 < O) stage_load(o + 2, xcur, ps, ws, po, wo);   // this set is free again: consumed two iterations from now
         __syncthreads();                                          // W(o) and tile(o) complete
+        // Fragment reads are issued in batches ahead of their MFMAs (sched_barrier pins them there): left to itself hipcc
+        // reuses ONE register quad for the B fragments -- read, wait lgkmcnt(0), two MFMAs, next read -- which exposes a
+        // full LDS latency per fragment.
+        // (four B fragments in flight per batch: the whole pair's 16-24 at once costs 184-246 VGPRs and with them half the
+        // resident blocks -- measured slower than no batching at all)
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
             const int aoff = (wave * 16 + ccol) * PITCH + (kc * 4 + kg) * 16;
             const gd_bf16x8 a0 = *reinterpret_cast<const gd_bf16x8*>(wself + aoff);
             const gd_bf16x8 a1 = *reinterpret_cast<const gd_bf16x8*>(wother + aoff);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const gd_bf16x8 bf = *reinterpret_cast<const gd_bf16x8*>(tile(buf) + (c * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf, acc[c], 0, 0, 0);
+            for (int c0 = 0; c0 < 8; c0 += 4) {
+                gd_bf16x8 bf[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    bf[c] = *reinterpret_cast<const gd_bf16x8*>(tile(buf) + ((c0 + c) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf[c], acc[c0 + c], 0, 0, 0);
+                    acc[c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf[c], acc[c0 + c], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (o + 1 < O) stage_tile(buf ^ 1, xnext);                // the other feature buffer: last read in iteration o-1
