@@ -492,16 +492,19 @@ __global__ __launch_bounds__(kAlignThreads) void align_mfma_kernel(
 // =====================================================================================================
 constexpr int kAMThreads = 512, kAMWaves = 8, kAMRows = 48, kAMSlots = kAMRows * 16;   // 16-byte slots per image tile
 
-#define VLG_AM_DPP4(C)                                                                                          \
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " C "\n\tv_max_f32_dpp %1, %1, %1 " C "\n\tv_max_f32_dpp %2, %2, %2 " C \
-        "\n\tv_max_f32_dpp %3, %3, %3 " C                                                                       \
+#define VLG_AM_DPP4(OP, C)                                                                                      \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 " C "\n\t" OP " %1, %1, %1 " C "\n\t" OP " %2, %2, %2 " C "\n\t" OP " %3, %3, %3 " C \
         : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3))
 
+// ARGS (the grounding loss's variant, joint.py:446-483): also records WHERE each maximum sits (first position on ties, like a
+// sequential scan) and, on the diagonal pairs a == b, subtracts the POS prior pen[b,q,seg(v)] before the maxima.  It runs
+// 48-row passes (RT = 3): the position registers would not fit next to 96 rows of caption fragments.
+template <bool ARGS, int RT>
 __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
     const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
     const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_maxV,
-    float* __restrict__ out_maxQ, int a_per_block) {
-    constexpr int d = 128, KCH = 4, RT = 6;
+    float* __restrict__ out_maxQ, int a_per_block, AlignArgs xa) {
+    constexpr int d = 128, KCH = 4;
     __shared__ uint4 tiles[2][kAMSlots];
     __shared__ uint8_t ckeep_s[2][kAMRows];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -571,21 +574,40 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
         }
         __syncthreads();
         f32x4 rmx[RT];
+        int rix[ARGS ? RT : 1][4];   // ARGS: column tile that holds the running row maximum (first one on ties: ct ascends)
         auto row_epilogue = [&](int a) {   // row maxima of image a: one 16-lane butterfly per accumulator register
             if (!(b < B && out_maxV)) return;
-            float* dstV = out_maxV + ((size_t)bc * A + a) * Q + q0 + crow + ccol;
+            const size_t at0 = ((size_t)bc * A + a) * Q + q0 + crow + ccol;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 float m0 = rmx[rt][0], m1 = rmx[rt][1], m2 = rmx[rt][2], m3 = rmx[rt][3];
-                VLG_AM_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-                VLG_AM_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-                VLG_AM_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf");
-                VLG_AM_DPP4("row_mirror row_mask:0xf bank_mask:0xf");
+                const float o0 = m0, o1 = m1, o2 = m2, o3 = m3;
+                VLG_AM_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+                VLG_AM_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+                VLG_AM_DPP4("v_max_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf");
+                VLG_AM_DPP4("v_max_f32_dpp", "row_mirror row_mask:0xf bank_mask:0xf");
                 float res = m3;   // lane (g, ccol < 4) keeps row 16 rt + 4 g + ccol
                 res = is2 ? m2 : res;
                 res = is1 ? m1 : res;
                 res = is0 ? m0 : res;
-                if (ccol < 4 && rt * 16 < qlim) dstV[rt * 16] = res;
+                if (ARGS) {
+                    // where: the smallest region index among the lanes that hold the row maximum (a second, integer butterfly)
+                    int m0i = o0 == m0 ? rix[ARGS ? rt : 0][0] * 16 + ccol : 0x7fff, m1i = o1 == m1 ? rix[ARGS ? rt : 0][1] * 16 + ccol : 0x7fff;
+                    int m2i = o2 == m2 ? rix[ARGS ? rt : 0][2] * 16 + ccol : 0x7fff, m3i = o3 == m3 ? rix[ARGS ? rt : 0][3] * 16 + ccol : 0x7fff;
+                    {
+                        int &m0 = m0i, &m1 = m1i, &m2 = m2i, &m3 = m3i;   // the macro names its operands m0..m3
+                        VLG_AM_DPP4("v_min_i32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+                        VLG_AM_DPP4("v_min_i32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+                        VLG_AM_DPP4("v_min_i32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf");
+                        VLG_AM_DPP4("v_min_i32_dpp", "row_mirror row_mask:0xf bank_mask:0xf");
+                    }
+                    int ri = m3i;
+                    ri = is2 ? m2i : ri;
+                    ri = is1 ? m1i : ri;
+                    ri = is0 ? m0i : ri;
+                    if (ccol < 4 && rt * 16 < qlim) xa.argV[at0 + rt * 16] = (uint16_t)ri;
+                }
+                if (ccol < 4 && rt * 16 < qlim) out_maxV[at0 + rt * 16] = res;
             }
         };
         for (int i = 0; i < n_img; ++i) {
@@ -604,13 +626,17 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
             // tiles (-> row maxima) is kept per row tile, the one over the row tiles (-> column maxima) per column tile
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) rmx[rt] = f32x4{ninf, ninf, ninf, ninf};
+            const bool prior_on = ARGS && xa.pen != nullptr && a == b;   // wave-uniform: the diagonal pair of this caption
 #pragma unroll 1
             for (int ct = 0; ct < 3; ++ct) {
                 bf16x8 bfr[KCH];
 #pragma unroll
                 for (int kc = 0; kc < KCH; ++kc) bfr[kc] = *reinterpret_cast<const bf16x8*>(tb + ct * 256 + foff[kc]);
                 f32x4 cmx = f32x4{ninf, ninf, ninf, ninf};
+                int cix[4] = {0, 0, 0, 0};   // ARGS: row tile that holds the running column maximum (first one: rt ascends)
                 const unsigned ckc = (ckl >> ct) & 1u;
+                const float* prow = nullptr;   // prior row of this lane's column segment
+                if (prior_on) prow = xa.pen + (size_t)bc * Q * xa.n_seg + xa.seg_of_v[min(ct * 16 + ccol, V - 1)];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -620,13 +646,26 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
 #pragma unroll
                         for (int n = 0; n < 4; ++n) acc[n] = ((tkeep >> (rt * 4 + n)) & ckc) ? acc[n] : neg_inf;
                     }
+                    if (prior_on) {   // joint.py:466-469
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) acc[n] -= prow[(size_t)min(q0 + rt * 16 + crow + n, Q - 1) * xa.n_seg];
+                    }
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
-                        rmx[rt][n] = fmaxf(rmx[rt][n], acc[n]);
-                        cmx[n] = fmaxf(cmx[n], acc[n]);
+                        if (ARGS) {   // strict >: the earlier column tile / row tile keeps a tie
+                            const bool up = acc[n] > rmx[rt][n];
+                            rmx[rt][n] = up ? acc[n] : rmx[rt][n];
+                            rix[ARGS ? rt : 0][n] = up ? ct : rix[ARGS ? rt : 0][n];
+                            const bool upc = acc[n] > cmx[n];
+                            cmx[n] = upc ? acc[n] : cmx[n];
+                            cix[n] = upc ? rt : cix[n];
+                        } else {
+                            rmx[rt][n] = fmaxf(rmx[rt][n], acc[n]);
+                            cmx[n] = fmaxf(cmx[n], acc[n]);
+                        }
                     }
                 }
-                if (out_maxQ) {   // column maxima of this column tile: within-lane over the four rows, then across the row groups
+                if (out_maxQ && !ARGS) {   // column maxima of this column tile: within-lane over the four rows, then across the row groups
                     float m = fmaxf(fmaxf(cmx[0], cmx[1]), fmaxf(cmx[2], cmx[3]));
                     // lanes l, l^16, l^32, l^48 hold the same column: v_permlane16/32_swap with both operands = m return
                     // (own, partner) in some order on every lane -- no LDS round trip (ds_bpermute costs one per step)
@@ -644,6 +683,41 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
                         *dst = q0 == 0 ? m : fmaxf(*dst, m);   // the same wave handles every row group of (b, a)
                     }
                 }
+                if (out_maxQ && ARGS) {
+                    // (value, query) pairs: the larger value wins, equal values keep the smaller query.  Within the lane the four
+                    // rows 16 cix + 4 g + n; then the other row groups g (same column) by v_permlane16/32_swap of both halves.
+                    float m = cmx[0];
+                    int qi = cix[0] * 16 + crow;
+#pragma unroll
+                    for (int n = 1; n < 4; ++n) {
+                        const int qn = cix[n] * 16 + crow + n;
+                        const bool take = cmx[n] > m || (cmx[n] == m && qn < qi);
+                        m = take ? cmx[n] : m;
+                        qi = take ? qn : qi;
+                    }
+                    qi += q0;
+#pragma unroll
+                    for (int step = 0; step < 2; ++step) {
+                        const auto rv = step == 0 ? __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false)
+                                                  : __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                        const auto ri = step == 0 ? __builtin_amdgcn_permlane16_swap((unsigned)qi, (unsigned)qi, false, false)
+                                                  : __builtin_amdgcn_permlane32_swap((unsigned)qi, (unsigned)qi, false, false);
+                        // (r[0], r[1]) = (own, partner) in some order, the same order for both swaps: fold both halves
+                        const float va = __uint_as_float(rv[0]), vb = __uint_as_float(rv[1]);
+                        const int ia = (int)ri[0], ib = (int)ri[1];
+                        const bool tb_ = vb > va || (vb == va && ib < ia);
+                        m = tb_ ? vb : va;
+                        qi = tb_ ? ib : ia;
+                    }
+                    const int v = ct * 16 + ccol;
+                    if (b < B && lane < 16 && v < V) {
+                        const size_t at = ((size_t)bc * A + a) * V + v;
+                        if (q0 == 0 || m > out_maxQ[at]) {   // later row groups only win with a strictly larger value
+                            out_maxQ[at] = m;
+                            xa.argQ[at] = (uint16_t)qi;
+                        }
+                    }
+                }
             }
             row_epilogue(a);
             __syncthreads();
@@ -652,8 +726,10 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
 }
 #undef VLG_AM_DPP4
 
+template <bool ARGS>
 static int launch_align_max(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A, int Q,
-                            int V, float neg_inf, float* out_maxV, float* out_maxQ, hipStream_t s) {
+                            int V, float neg_inf, float* out_maxV, float* out_maxQ, hipStream_t s,
+                            AlignArgs xa = AlignArgs{nullptr, nullptr, 0, nullptr, nullptr}) {
     const int by = (B + kAMWaves - 1) / kAMWaves;
     // enough workgroups for the chip (256 CUs, one 8-wave workgroup each), but at least 8 images per workgroup so that
     // the caption fragments are amortised
@@ -661,8 +737,8 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
     if (a_per_block < 8) a_per_block = 8;
     if (a_per_block > A) a_per_block = A;
     dim3 grid((A + a_per_block - 1) / a_per_block, by);   // x fastest: workgroups of one caption octet spread over the XCDs
-    hipLaunchKernelGGL(align_max_kernel, grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask, vmask,
-                       B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block);
+    hipLaunchKernelGGL((align_max_kernel<ARGS, ARGS ? 3 : 6>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
+                       tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
     return check_launch("align_max_kernel");
 }
 
@@ -867,7 +943,7 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
                                                       out_maxQ, out_diag, s)
     if (!f32in && d == 128 && !out_full && (out_maxV || out_maxQ) && V <= kAMRows) {
         // fused maxima of one-group images: image tiles shared by eight captions through LDS
-        if (int rc = launch_align_max(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, s)) return rc;
+        if (int rc = launch_align_max<false>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, s)) return rc;
         if (!out_diag) return 0;
         return launch_align_mfma<false, 4, true, false, 3>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, nullptr, nullptr, nullptr,
                                                           out_diag, s, AlignArgs{nullptr, nullptr, 0, nullptr, nullptr}, true);
@@ -993,7 +1069,9 @@ int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, c
                                                                          wsf + p.off_maxV, wsf + p.off_maxQ, nullptr, s, xa)        \
              : launch_align_mfma<F32, KCHV, true, true, VLG_GA_RTB>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr,               \
                                                                     wsf + p.off_maxV, wsf + p.off_maxQ, nullptr, s, xa)
-    if (!f32in && d == 128) VLG_GA(false, 4);
+    if (!f32in && d == 128 && V <= kAMRows && !getenv("VLG_GROUND_OLD_ALIGN"))   // shared image tiles (align_max_kernel<ARGS>)
+        rc = launch_align_max<true>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, wsf + p.off_maxV, wsf + p.off_maxQ, s, xa);
+    else if (!f32in && d == 128) VLG_GA(false, 4);
     else if (!f32in && d == 64) VLG_GA(false, 2);
     else if (!f32in && d == 32) VLG_GA(false, 1);
     else if (f32in && d == 128) VLG_GA(true, 8);
