@@ -549,213 +549,228 @@ struct DepCtx {
     unsigned char* bpC;
 };
 
-template <int SR, bool BWD, int TU, typename X>
-VLG_HD void dep_fw_span(const DepCtx& c, int w, int lg, int i, bool live, int rr, X& x) {
-    const int P = c.P, j = i + w, G = 1 << lg;
-    const float* cr = c.C + i * P + i + 1;
-    const float* cl = c.C + j * P + i + 1;
-    const float* ca = c.C + i * P + i;
-    const float* il = c.I + j * P + i;
-    const float* ir = c.I + i * P + i + 2;
-    const float* cb = c.C + (i + 1) * P + j + 1;
-    const float aL = c.I[j * P + i], aR = c.I[i * P + j + 1];   // arc scores, staged at load
-    const float c0 = c.C[i * P + i], c1 = c.C[j * P + j + 1];
-    float m[3], s[3] = {0.f, 0.f, 0.f};
-    int am[3];
+// Inside, one span, one direction (same organisation as dmv_fw_span): DIR 0 = T -> IL(j,i) -> CL(j,i), DIR 1 = T -> IR(i,j) ->
+// CR(i,j).  Both directions need T(i,j); each computes it (same lanes, same butterfly tree: identical bits), DIR 0 stores it.
+template <int SR, bool BWD, int DIR, int TU, typename X>
+VLG_HD void dep_fw_span(const DepCtx& c, int w, int G, int D, bool live, int rr, X& x) {
+    const int P = c.P, DW = D + VLG_MUL24(w, P);
+    const int eA = D + 1, eB = DW + 1;                        // CR(i, i+r), CL(j, i+r+1)
+    const int eU = DIR == 0 ? D : D + P + w + 1;              // CL(i+r, i) | CR(i+1+r, j)   (stride P)
+    const int eV = DIR == 0 ? DW : D + 2;                     // IL(j, i+r) | IR(i, i+1+r)
+    const int kO = DIR == 0 ? DW : D + w + 1;                 // own slot: IL(j,i) / CL(j,i) | IR(i,j) / CR(i,j)
+    const float aX = c.I[kO];                                 // arc score, staged at load
+    const float cX = DIR == 0 ? c.C[D] : c.C[DW + w + 1];    // CL(i,i) | CR(j,j)
+    float m[2], s[2] = {0.f, 0.f};
+    int am[2];
     if (TU > 0) {
-        float t[TU > 0 ? TU : 1][3];
+        float t[TU > 0 ? TU : 1][2];
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            const int r = rr + (u << lg), rc = r < w ? r : w - 1;
-            const float a = cr[rc], b = cl[rc], ua = ca[rc * P], va = il[rc], vb = ir[rc], ub = cb[rc * P];
-            t[u][0] = r < w ? a + b : VLG_LOWEST;
-            t[u][1] = (r < w && r >= 1) ? ua + va : VLG_LOWEST;
-            t[u][2] = r <= w - 2 ? vb + ub : VLG_LOWEST;
+            const int r = rr + u * G, rc = r < w ? r : w - 1;
+            const float a = c.C[eA + rc], b = c.C[eB + rc], uu = c.C[eU + VLG_MUL24(rc, P)], vv = c.I[eV + rc];
+            const bool v0 = r < w, v1 = DIR == 0 ? (v0 && r >= 1) : (r <= w - 2);
+            t[u][0] = v0 ? a + b : VLG_LOWEST;
+            t[u][1] = v1 ? uu + vv : VLG_LOWEST;
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 2; ++k) {
             m[k] = t[0][k];
             am[k] = rr;
 #pragma unroll
             for (int u = 1; u < TU; ++u)
-                if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + (u << lg); }
+                if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + u * G; }
         }
-        if (SR == VLG_SR_MAX) x.template allreduce_argmax<3>(m, am, G);
-        else x.template allreduce_max<3>(m, G);
+        if (SR == VLG_SR_MAX) x.template allreduce_argmax<2>(m, am, G);
+        else x.template allreduce_max<2>(m, G);
         if (SR == VLG_SR_LOG) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int u = 0; u < TU; ++u) s[k] += VLG_EXP(t[u][k] - m[k]);
-            x.template allreduce_sum<3>(s, G);
+            x.template allreduce_sum<2>(s, G);
         }
     } else {
-        for (int k = 0; k < 3; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
+        for (int k = 0; k < 2; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
         for (int r = rr; r < w; r += G) {
-            upd_max(m[0], am[0], cr[r] + cl[r], r);
-            if (r >= 1) upd_max(m[1], am[1], ca[r * P] + il[r], r);
-            if (r <= w - 2) upd_max(m[2], am[2], ir[r] + cb[r * P], r);
+            upd_max(m[0], am[0], c.C[eA + r] + c.C[eB + r], r);
+            if (DIR == 0 ? r >= 1 : r <= w - 2) upd_max(m[1], am[1], c.C[eU + VLG_MUL24(r, P)] + c.I[eV + r], r);
         }
-        if (SR == VLG_SR_MAX) x.template allreduce_argmax<3>(m, am, G);
-        else x.template allreduce_max<3>(m, G);
+        if (SR == VLG_SR_MAX) x.template allreduce_argmax<2>(m, am, G);
+        else x.template allreduce_max<2>(m, G);
         if (SR == VLG_SR_LOG) {
             for (int r = rr; r < w; r += G) {
-                s[0] += VLG_EXP(cr[r] + cl[r] - m[0]);
-                if (r >= 1) s[1] += VLG_EXP(ca[r * P] + il[r] - m[1]);
-                if (r <= w - 2) s[2] += VLG_EXP(ir[r] + cb[r * P] - m[2]);
+                s[0] += VLG_EXP(c.C[eA + r] + c.C[eB + r] - m[0]);
+                if (DIR == 0 ? r >= 1 : r <= w - 2) s[1] += VLG_EXP(c.C[eU + VLG_MUL24(r, P)] + c.I[eV + r] - m[1]);
             }
-            x.template allreduce_sum<3>(s, G);
+            x.template allreduce_sum<2>(s, G);
         }
     }
     const float T = SR == VLG_SR_LOG ? m[0] + VLG_LOG(s[0]) : m[0];
-    const float ILn = aL + T, IRn = aR + T;   // deptree.py:58,62
-    int b0, b1;
-    const float CLv = fold_term<SR>(m[1], s[1], am[1], c0 + ILn, 0, true, b0);
-    float CRv = fold_term<SR>(m[2], s[2], am[2], IRn + c1, w - 1, false, b1);
-    if (i == 0 && w != c.len) CRv = VLG_NEGINF;   // deptree.py:71-72
+    const float In = aX + T;   // deptree.py:58,62
+    int b0;
+    float Cv = fold_term<SR>(m[1], s[1], am[1], cX + In, DIR == 0 ? 0 : w - 1, DIR == 0, b0);
+    if (DIR == 1 && D == 0 && w != c.len) Cv = VLG_NEGINF;   // deptree.py:71-72
     if (live && rr == 0) {
-        c.I[j * P + i] = ILn;
-        c.I[i * P + j + 1] = IRn;
-        c.C[j * P + i] = CLv;
-        c.C[i * P + j + 1] = CRv;
+        c.I[kO] = In;
+        c.C[kO] = Cv;
         if (BWD) {
-            if (SR != VLG_SR_MAX) c.S[i * P + j] = T;   // the outside replay's tape; the Max semiring walks back-pointers
+            if (DIR == 0 && SR != VLG_SR_MAX) c.S[D + w] = T;   // T(i,j) at [i][j]: the outside replay's tape; the Max semiring walks back-pointers
             if (SR == VLG_SR_MAX) {
-                c.bpS[i * P + j] = (unsigned char)am[0];
-                c.bpC[j * P + i] = (unsigned char)b0;
-                c.bpC[i * P + j + 1] = (unsigned char)b1;
+                if (DIR == 0) c.bpS[D + w] = (unsigned char)am[0];
+                c.bpC[kO] = (unsigned char)b0;
             }
         }
+    }
+}
+
+template <int SR, bool BWD, int DIR, int LG, typename X>
+VLG_HD void dep_fw_width(const DepCtx& c, int w, int t, int nd, X& x) {
+    constexpr int G = 1 << LG;
+    const int per = nd >> LG, rr = t & (G - 1), slot = t >> LG, spans = c.Ne - w;
+    const int T = (w + G - 1) >> LG;
+    for (int base = 0; base < spans; base += per) {
+        const bool live = base + slot < spans;
+        const int i = live ? base + slot : 0;
+        if (X::kSkipDeadWaves && (base + ((t & ~63) >> LG)) >= spans) continue;
+        const int D = VLG_MUL24(i, c.P + 1);
+        if (T == 1) dep_fw_span<SR, BWD, DIR, 1>(c, w, G, D, live, rr, x);
+        else if (T == 2) dep_fw_span<SR, BWD, DIR, 2>(c, w, G, D, live, rr, x);
+        else if (T == 3) dep_fw_span<SR, BWD, DIR, 3>(c, w, G, D, live, rr, x);
+        else if (T == 4) dep_fw_span<SR, BWD, DIR, 4>(c, w, G, D, live, rr, x);
+        else dep_fw_span<SR, BWD, DIR, 0>(c, w, G, D, live, rr, x);
+    }
+}
+
+template <int SR, bool BWD, int LG, typename X>
+VLG_HD void dep_fw_segment(const DepCtx& c, int w0, int w1, int tid, int nt, X& x) {
+    const int nd = nt >> 1;
+    const bool right = x.uniform(tid >= nd);
+    const int t = right ? tid - nd : tid;
+    for (int w = w0; w < w1; ++w) {
+        if (right) dep_fw_width<SR, BWD, 1, LG>(c, w, t, nd, x);
+        else dep_fw_width<SR, BWD, 0, LG>(c, w, t, nd, x);
+        x.sync();
     }
 }
 
 template <int SR, bool BWD, typename X>
-VLG_HD void dep_fw(const DepCtx& c, int w, int tid, int nt, X& x) {
-    const int spans = c.Ne - w;
-    const int lg = VLG_GROUP_LOG2_FW(spans, w, nt), G = 1 << lg, per = nt >> lg;
-    const int rr = tid & (G - 1), slot = tid >> lg;
-    const int T = (w + G - 1) >> lg;
-    for (int base = 0; base < spans; base += per) {
-        const bool live = base + slot < spans;
-        const int i = live ? base + slot : 0;
-        if (X::kSkipDeadWaves && (base + ((tid & ~63) >> lg)) >= spans) continue;
-        if (T == 1) dep_fw_span<SR, BWD, 1>(c, w, lg, i, live, rr, x);
-        else if (T == 2) dep_fw_span<SR, BWD, 2>(c, w, lg, i, live, rr, x);
-        else if (T == 3) dep_fw_span<SR, BWD, 3>(c, w, lg, i, live, rr, x);
-        else if (T == 4) dep_fw_span<SR, BWD, 4>(c, w, lg, i, live, rr, x);
-        else dep_fw_span<SR, BWD, 0>(c, w, lg, i, live, rr, x);
-    }
+VLG_HD void dep_fw_all(const DepCtx& c, int tid, int nt, X& x) {
+    const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_FW);
+    dep_fw_segment<SR, BWD, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
+    dep_fw_segment<SR, BWD, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
+    dep_fw_segment<SR, BWD, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
+    dep_fw_segment<SR, BWD, 3>(c, sc.first[3], sc.first[4], tid, nt, x);
+    dep_fw_segment<SR, BWD, 4>(c, sc.first[4], sc.first[5], tid, nt, x);
+    dep_fw_segment<SR, BWD, 5>(c, sc.first[5], sc.first[6], tid, nt, x);
+    dep_fw_segment<SR, BWD, 6>(c, sc.first[6], sc.first[7], tid, nt, x);
 }
 
-template <int SR, int TU, typename X>
-VLG_HD void dep_bw_span(const DepCtx& c, int w, int lg, int i, bool live, int rr, X& x) {
-    const int P = c.P, j = i + w, G = 1 << lg;
-    const int kL = j * P + i, kR = i * P + j + 1;
-    float gl = 0.f, gr = 0.f;
-    {
-        const float a = c.gCc[kL], b = c.gCi[kL], a2 = c.gCc[kR], b2 = c.gCi[kR];
-        if (live) gl = a + b;
-        if (live && !(i == 0 && w != c.len)) gr = a2 + b2;
-    }
-    const float ol = c.C[kL], orr = c.C[kR];
-    const float gil_old = c.gI[kL], gir_old = c.gI[kR];
-    const float Tv = c.S[i * P + j];
-    int bl = 0, br = 0, bs = 0;
-    if (SR == VLG_SR_MAX) { bl = c.bpC[kL]; br = c.bpC[kR]; bs = c.bpS[i * P + j]; }
-    float self[2] = {0.f, 0.f};
+// The self term of IL(j,i) / IR(i,j): the weight of the same-width term in CL(j,i) / CR(i,j) (r = 0 | w-1).  gI never
+// receives it during the sweep -- T(i,j) feeds both and the two directions of a span run concurrently, so neither may
+// write what the other reads; each recomputes both self terms, and dep_run's output stage adds them once at the end.
+template <int SR>
+VLG_HD float dep_self(const DepCtx& c, int D, int w, int dir) {
+    const int P = c.P, DW = D + VLG_MUL24(w, P);
+    const int kO = dir == 0 ? DW : D + w + 1;
+    float g = c.gCc[kO] + c.gCi[kO];
+    if (dir == 1 && D == 0 && w != c.len) g = 0.f;   // masked root cell (deptree.py:71-72)
+    const float cX = dir == 0 ? c.C[D] : c.C[DW + w + 1];
+    const int bp = SR == VLG_SR_MAX ? c.bpC[kO] : 0;
+    return adj_w<SR>(g, cX + c.I[kO], c.C[kO], dir == 0 ? 0 : w - 1, bp);
+}
+
+// Outside, one span, one direction: DIR 0 scatters CL(j,i)'s adjoint (-> IL(j,i+r), CL(i+r,i)) and T's into the CR(i,.)
+// operands; DIR 1 scatters CR(i,j)'s (-> IR(i,i+1+r), CR(i+1+r,j)) and T's into the CL(j,.) operands.
+template <int SR, int DIR, int TU, typename X>
+VLG_HD void dep_bw_span(const DepCtx& c, int w, int G, int D, bool live, int rr, X& x) {
+    const int P = c.P, DW = D + VLG_MUL24(w, P);
+    const int eU = DIR == 0 ? D : D + P + w + 1;      // CL(i+r, i) | CR(i+1+r, j)   (stride P)
+    const int eV = DIR == 0 ? DW : D + 2;             // IL(j, i+r) | IR(i, i+1+r)
+    const int eX = DIR == 0 ? D + 1 : DW + 1;         // this direction's T operand: CR(i, i+r) | CL(j, i+r+1)
+    const int kO = DIR == 0 ? DW : D + w + 1;
+    const int selfr = DIR == 0 ? 0 : w - 1;
+    float g = c.gCc[kO] + c.gCi[kO];
+    if (!live || (DIR == 1 && D == 0 && w != c.len)) g = 0.f;
+    const float oc = c.C[kO], Tv = c.S[D + w];
+    const float gs = live ? c.gI[DW] + c.gI[D + w + 1] + dep_self<SR>(c, D, w, 0) + dep_self<SR>(c, D, w, 1) : 0.f;
     if (TU > 0) {
-        float ua[TU > 0 ? TU : 1], va[TU > 0 ? TU : 1], vb[TU > 0 ? TU : 1], ub[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1],
-            xb[TU > 0 ? TU : 1];
-        float o_gil[TU > 0 ? TU : 1], o_gir[TU > 0 ? TU : 1], o_ca[TU > 0 ? TU : 1], o_cb[TU > 0 ? TU : 1],
-            o_ga[TU > 0 ? TU : 1], o_gb[TU > 0 ? TU : 1], wl[TU > 0 ? TU : 1], wr[TU > 0 ? TU : 1];
+        float uu[TU > 0 ? TU : 1], vv[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1], xb[TU > 0 ? TU : 1];
+        float o_gi[TU > 0 ? TU : 1], o_c[TU > 0 ? TU : 1], o_g[TU > 0 ? TU : 1];
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            const int r = rr + (u << lg), rc = r < w ? r : w - 1;
-            ua[u] = c.C[(i + rc) * P + i];
-            va[u] = c.I[kL + rc];
-            vb[u] = c.I[i * P + i + rc + 2];
-            ub[u] = c.C[(i + 1 + rc) * P + j + 1];
-            xa[u] = c.C[i * P + i + rc + 1];
-            xb[u] = c.C[j * P + i + rc + 1];
-            o_gil[u] = c.gI[kL + rc];
-            o_gir[u] = c.gI[i * P + i + rc + 2];
-            o_ca[u] = c.gCc[(i + rc) * P + i];
-            o_cb[u] = c.gCc[(i + 1 + rc) * P + j + 1];
-            o_ga[u] = c.gCi[i * P + i + rc + 1];
-            o_gb[u] = c.gCi[j * P + i + rc + 1];
+            const int r = rr + u * G, rc = r < w ? r : w - 1;
+            uu[u] = c.C[eU + VLG_MUL24(rc, P)];
+            vv[u] = c.I[eV + rc];
+            xa[u] = c.C[D + 1 + rc];
+            xb[u] = c.C[DW + 1 + rc];
+            o_gi[u] = c.gI[eV + rc];
+            o_c[u] = c.gCc[eU + VLG_MUL24(rc, P)];
+            o_g[u] = c.gCi[eX + rc];
         }
+        x.lockstep();   // the lanes of a group sit in one wavefront: every load above precedes every store below
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            const int r = rr + (u << lg);
-            const bool ok = r < w;
-            wl[u] = ok ? adj_w<SR>(gl, ua[u] + va[u], ol, r, bl) : 0.f;
-            wr[u] = ok ? adj_w<SR>(gr, vb[u] + ub[u], orr, r, br) : 0.f;
-            if (r == 0) self[0] = wl[u];
-            if (r == w - 1) self[1] = wr[u];
-        }
-        x.group_bcast2(self, G, 0, (w - 1) & (G - 1));   // lane 0 holds self[0], lane (w-1) mod G holds self[1]
-        const float gil = gil_old + self[0], gir = gir_old + self[1], gs = gil + gir;
-#pragma unroll
-        for (int u = 0; u < TU; ++u) {
-            const int r = rr + (u << lg);
+            const int r = rr + u * G;
             if (live && r < w) {
-                const float wt = adj_w<SR>(gs, xa[u] + xb[u], Tv, r, bs);
-                if (r != 0) c.gI[kL + r] = o_gil[u] + wl[u];
-                if (r != w - 1) c.gI[i * P + i + r + 2] = o_gir[u] + wr[u];
-                c.gCc[(i + r) * P + i] = o_ca[u] + wl[u];
-                c.gCc[(i + 1 + r) * P + j + 1] = o_cb[u] + wr[u];
-                c.gCi[i * P + i + r + 1] = o_ga[u] + wt;
-                c.gCi[j * P + i + r + 1] = o_gb[u] + wt;
+                const float wc = adj_w<SR>(g, uu[u] + vv[u], oc, r, 0);
+                const float wt = adj_w<SR>(gs, xa[u] + xb[u], Tv, r, 0);
+                if (r != selfr) c.gI[eV + r] = o_gi[u] + wc;
+                c.gCc[eU + VLG_MUL24(r, P)] = o_c[u] + wc;
+                c.gCi[eX + r] = o_g[u] + wt;
             }
-        }
-        if (live && rr == 0) {
-            c.gI[kL] = gil;   // == d logZ / d arc[j,i]
-            c.gI[kR] = gir;
         }
         return;
     }
     for (int r = rr; r < w; r += G) {
-        const float wl = adj_w<SR>(gl, c.C[(i + r) * P + i] + c.I[kL + r], ol, r, bl);
-        if (r == 0) self[0] = wl;
-        else if (live) c.gI[kL + r] += wl;
-        if (live) c.gCc[(i + r) * P + i] += wl;
-        const float wr = adj_w<SR>(gr, c.I[i * P + i + r + 2] + c.C[(i + 1 + r) * P + j + 1], orr, r, br);
-        if (r == w - 1) self[1] = wr;
-        else if (live) c.gI[i * P + i + r + 2] += wr;
-        if (live) c.gCc[(i + 1 + r) * P + j + 1] += wr;
+        if (!live) break;
+        const float wc = adj_w<SR>(g, c.C[eU + VLG_MUL24(r, P)] + c.I[eV + r], oc, r, 0);
+        const float wt = adj_w<SR>(gs, c.C[D + 1 + r] + c.C[DW + 1 + r], Tv, r, 0);
+        if (r != selfr) c.gI[eV + r] += wc;
+        c.gCc[eU + VLG_MUL24(r, P)] += wc;
+        c.gCi[eX + r] += wt;
     }
-    x.group_bcast2(self, G, 0, (w - 1) & (G - 1));
-    const float gil = gil_old + self[0], gir = gir_old + self[1];
-    const float gs = gil + gir;
-    for (int r = rr; r < w; r += G) {
-        const float wt = adj_w<SR>(gs, c.C[i * P + i + r + 1] + c.C[j * P + i + r + 1], Tv, r, bs);
-        if (live) {
-            c.gCi[i * P + i + r + 1] += wt;
-            c.gCi[j * P + i + r + 1] += wt;
-        }
+}
+
+template <int SR, int DIR, int LG, typename X>
+VLG_HD void dep_bw_width(const DepCtx& c, int w, int t, int nd, X& x) {
+    constexpr int G = 1 << LG;
+    const int per = nd >> LG, rr = t & (G - 1), slot = t >> LG, spans = c.Ne - w;
+    const int T = (w + G - 1) >> LG;
+    for (int base = 0; base < spans; base += per) {
+        const bool live = base + slot < spans;
+        const int i = live ? base + slot : 0;
+        if (X::kSkipDeadWaves && (base + ((t & ~63) >> LG)) >= spans) continue;
+        const int D = VLG_MUL24(i, c.P + 1);
+        if (T == 1) dep_bw_span<SR, DIR, 1>(c, w, G, D, live, rr, x);
+        else if (T == 2) dep_bw_span<SR, DIR, 2>(c, w, G, D, live, rr, x);
+        else if (T == 3) dep_bw_span<SR, DIR, 3>(c, w, G, D, live, rr, x);
+        else if (T == 4) dep_bw_span<SR, DIR, 4>(c, w, G, D, live, rr, x);
+        else dep_bw_span<SR, DIR, 0>(c, w, G, D, live, rr, x);
     }
-    if (live && rr == 0) {
-        c.gI[kL] = gil;
-        c.gI[kR] = gir;
+}
+
+template <int SR, int LG, typename X>
+VLG_HD void dep_bw_segment(const DepCtx& c, int w0, int w1, int tid, int nt, X& x) {
+    const int nd = nt >> 1;
+    const bool right = x.uniform(tid >= nd);
+    const int t = right ? tid - nd : tid;
+    for (int w = w1 - 1; w >= w0; --w) {
+        if (right) dep_bw_width<SR, 1, LG>(c, w, t, nd, x);
+        else dep_bw_width<SR, 0, LG>(c, w, t, nd, x);
+        x.sync();
     }
 }
 
 template <int SR, typename X>
-VLG_HD void dep_bw(const DepCtx& c, int w, int tid, int nt, X& x) {
-    const int spans = c.Ne - w;
-    const int lg = VLG_GROUP_LOG2_BW(spans, w, nt), G = 1 << lg, per = nt >> lg;
-    const int rr = tid & (G - 1), slot = tid >> lg;
-    const int T = (w + G - 1) >> lg;
-    for (int base = 0; base < spans; base += per) {
-        const bool live = base + slot < spans;
-        const int i = live ? base + slot : 0;
-        if (X::kSkipDeadWaves && (base + ((tid & ~63) >> lg)) >= spans) continue;
-        if (T == 1) dep_bw_span<SR, 1>(c, w, lg, i, live, rr, x);
-        else if (T == 2) dep_bw_span<SR, 2>(c, w, lg, i, live, rr, x);
-        else if (T == 3) dep_bw_span<SR, 3>(c, w, lg, i, live, rr, x);
-        else if (T == 4) dep_bw_span<SR, 4>(c, w, lg, i, live, rr, x);
-        else dep_bw_span<SR, 0>(c, w, lg, i, live, rr, x);
-    }
+VLG_HD void dep_bw_all(const DepCtx& c, int tid, int nt, X& x) {
+    const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_BW);
+    dep_bw_segment<SR, 6>(c, sc.first[6], sc.first[7], tid, nt, x);
+    dep_bw_segment<SR, 5>(c, sc.first[5], sc.first[6], tid, nt, x);
+    dep_bw_segment<SR, 4>(c, sc.first[4], sc.first[5], tid, nt, x);
+    dep_bw_segment<SR, 3>(c, sc.first[3], sc.first[4], tid, nt, x);
+    dep_bw_segment<SR, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
+    dep_bw_segment<SR, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
+    dep_bw_segment<SR, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
 }
 
 // ================================================================================================
@@ -1093,10 +1108,7 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
         }
     }
     x.sync();
-    for (int w = 1; w < Ne; ++w) {
-        dep_fw<SR, BWD>(c, w, tid, nt, x);
-        x.sync();
-    }
+    dep_fw_all<SR, BWD>(c, tid, nt, x);
     if (tid == 0) *logZ = c.C[len + 1] * VLG_LN2;   // CR(0,len), deptree.py:74-75
     if (!BWD) return;
     if (SR == VLG_SR_MAX) {   // the best tree's arcs are all the Max semiring's gradient is: walk the back-pointers
@@ -1105,10 +1117,7 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
     } else {
         if (tid == 0) c.gCc[len + 1] = glogZ;
         x.sync();
-        for (int w = Ne - 1; w >= 1; --w) {
-            dep_bw<SR>(c, w, tid, nt, x);
-            x.sync();
-        }
+        dep_bw_all<SR>(c, tid, nt, x);
     }
     if (heads) {
         for (int i = tid; i < N; i += nt) heads[i] = 0;
@@ -1117,9 +1126,12 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
     for (int idx = tid; idx < N * N; idx += nt) {
         const int h = idx / N, ch = idx - h * N;
         float g = 0.f;
-        if (h < Ne && ch < Ne) {
-            if (ch < h) g = c.gI[h * P + ch];
-            else if (ch > h) g = c.gI[h * P + ch + 1];
+        if (h < Ne && ch < Ne && ch != h) {
+            g = ch < h ? c.gI[h * P + ch] : c.gI[h * P + ch + 1];
+            if (SR != VLG_SR_MAX) {   // + the self term the sweep left out (dep_self)
+                const int i = ch < h ? ch : h, w = ch < h ? h - ch : ch - h;
+                g += dep_self<SR>(c, i * (P + 1), w, ch < h ? 0 : 1);
+            }
         }
         if (garc) garc[idx] = g;
         if (heads && g != 0.f) heads[ch] = h;
