@@ -245,6 +245,37 @@ size_t vlg_box_rel_pairwise_backward_workspace(int B, int R, int H);
 int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* grad_out, int B, int R, int H, int dtype, float slope,
                                   void* ws, size_t ws_bytes, float* grad_y, float* grad_bias, void* stream);
 
+/* ---- Data feed (host code; no device work, no stream).  SURVEY.md section 8 row f4. ----
+ *
+ * Length bucketing -- ConstantTokenNumSampler.kmeans, src/datamodule/sampler.py:148-191: Lloyd iterations on the sentence
+ * lengths from the caller's initial centroids (the reference draws them with torch.randperm over the distinct lengths; the
+ * host mirror draws them the same way so that the buckets are identical).  Same tie rules as the reference: nearest centroid
+ * with the lowest id winning ties; an empty cluster takes the farthest point of the biggest cluster.
+ *   seq_len [n] int32, init_centroids [k], 1 <= k <= n.  centroids [k] (first *n_clusters valid), assign [n] = bucket id in
+ *   0..*n_clusters-1 (empty clusters dropped, order kept).  Centroids are exact while a bucket holds < 2^24 tokens. */
+int vlg_feed_kmeans(const int32_t* seq_len, int64_t n, const float* init_centroids, int k, int max_it, float* centroids,
+                    int32_t* assign, int* n_clusters);
+
+/* One epoch's batches -- ConstantTokenNumSampler._init_iter + _process_batch, sampler.py:86-140.
+ *   bucket_offsets [n_buckets+1], bucket_items (CSR: sentence ids per bucket), chunks [n_buckets] = batches per bucket,
+ *   bucket_perms = the per-bucket permutations concatenated (positions within the bucket), batch_perm [sum(chunks)] = order
+ *   of the raw batches.  single_sent_threshold: sentences at least this long become batches of one (-1 = off);
+ *   sort_in_batch: stable sort by decreasing length.
+ *   out_offsets [sum(chunks) + n + 1], out_items [n]: CSR of the epoch's batches, *n_batches of them. */
+int vlg_feed_batches(const int32_t* seq_len, int64_t n, const int64_t* bucket_offsets, const int64_t* bucket_items, int n_buckets,
+                     const int64_t* chunks, const int64_t* bucket_perms, const int64_t* batch_perm, int single_sent_threshold,
+                     int sort_in_batch, int64_t* out_offsets, int64_t* out_items, int64_t* n_batches);
+
+/* Region-feature collate -- _COCODetFeatLazyLoader.__call__, src/datamodule/task/vlparse.py:36-92.
+ * vlg_feed_npy_shape: rows / columns of a 2-d little-endian f2 / f4 / f8 C-order .npy.
+ * vlg_feed_collate_npy: image i keeps n_sel[i] rows of paths[i] -- rows sel[i*sel_stride + 0..] (sel NULL = the leading rows) --
+ *   split into [feat_dim | box_dim] columns and written as float32 into feat [n, max_len, feat_dim], box [n, max_len, box_dim],
+ *   mask [n, max_len] (1 = real row); rows beyond n_sel[i] are zero.  Every byte of the three outputs is written, so they may
+ *   be uninitialised (pinned) staging memory.  n_threads reader threads (pread; no shared state). */
+int vlg_feed_npy_shape(const char* path, int64_t* rows, int64_t* cols);
+int vlg_feed_collate_npy(const char* const* paths, int n, const int32_t* sel, int sel_stride, const int32_t* n_sel, int feat_dim,
+                         int box_dim, int max_len, float* feat, float* box, uint8_t* mask, int n_threads);
+
 /* Device self-test of the cross-lane (DPP / ds_swizzle) exchange primitives the DP kernels rely on.
  * `scratch` = one device int; after the stream drains it holds 0 iff the primitives behave as assumed. */
 int vlg_selftest_xlane(int* scratch, void* stream);

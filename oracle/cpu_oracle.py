@@ -550,3 +550,55 @@ def box_rel(feat, weight, bias, slope=0.01, img_feat=True, dout=None):
     else:
         g_feat = g_inputs
     return rel, g_feat, g_weight, g_bias
+
+
+# ---------------------------------------------------------------- data feed
+def feed_kmeans(x, init_centroids, k, max_it=32):
+    """ConstantTokenNumSampler.kmeans (datamodule/sampler.py:148-191) from given initial centroids, in the reference's dense
+    form: an [n, k] distance matrix per iteration, float32 arithmetic, first-minimum / first-maximum tie rules.
+    Returns (centroids of the surviving clusters, cluster id per point renumbered over the survivors)."""
+    x = np.asarray(x, np.float32)
+    c = np.asarray(init_centroids, np.float32)          # may hold fewer than k entries (fewer distinct values than clusters)
+    dist = np.abs(x[:, None] - c[None, :])
+    y = dist.argmin(-1)
+    d = dist[np.arange(len(x)), y]
+    for _ in range(max_it):
+        while True:                                      # sampler.py:164-176
+            counts = np.bincount(y, minlength=k)
+            empty = np.nonzero(counts == 0)[0]
+            if len(empty) == 0:
+                break
+            for e in empty:
+                counts = np.bincount(y, minlength=k)
+                members = np.nonzero(y == counts.argmax())[0]
+                y[members[d[members].argmax()]] = e
+        counts = np.bincount(y, minlength=k)
+        old = c
+        c = (np.bincount(y, weights=x.astype(np.float64), minlength=k).astype(np.float32) / counts.astype(np.float32)).astype(np.float32)
+        dist = np.abs(x[:, None] - c[None, :])
+        y = dist.argmin(-1)
+        d = dist[np.arange(len(x)), y]
+        if old.shape == c.shape and (old == c).all():
+            break
+    alive = np.unique(y)
+    return c[alive], np.searchsorted(alive, y)
+
+
+def feed_batches(seq_len, buckets, chunks, bucket_perms, batch_perm, single_sent_threshold=-1, sort_in_batch=True):
+    """One epoch of ConstantTokenNumSampler (sampler.py:86-140): lists of sentence ids."""
+    raw = []
+    for items, ch, perm in zip(buckets, chunks, bucket_perms):
+        at = 0
+        for j in range(ch):
+            size = (len(items) - j - 1) // ch + 1
+            raw.append([items[p] for p in perm[at:at + size]])
+            at += size
+    out = []
+    for r in batch_perm:
+        keep = [i for i in raw[r] if single_sent_threshold == -1 or seq_len[i] < single_sent_threshold]
+        if sort_in_batch:
+            keep.sort(key=lambda i: -seq_len[i])
+        if keep:
+            out.append(keep)
+        out.extend([i] for i in raw[r] if single_sent_threshold != -1 and seq_len[i] >= single_sent_threshold)
+    return out

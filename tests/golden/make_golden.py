@@ -461,6 +461,73 @@ def boxrel_cases():
         print(f"{name}: rel {tuple(out['rel'].shape)}")
 
 
+def _csr(lists):
+    return (np.cumsum([0] + [len(l) for l in lists]).astype(np.int64),
+            np.asarray([i for l in lists for i in l], dtype=np.int64))
+
+
+def feed_cases():
+    """The data feed, the reference's own classes executed:
+    ConstantTokenNumSampler (datamodule/sampler.py:15-191) -- buckets from its k-means and three epochs of batches under a
+    fixed torch seed; _COCODetFeatLazyLoader.__call__ (datamodule/task/vlparse.py:29-114) on small synthetic .npy files
+    (their contents are in the fixture; the test writes them back to disk)."""
+    import pathlib
+    import tempfile
+    import _ref_import
+    _ref_import.import_joint()
+    from src.datamodule.sampler import ConstantTokenNumSampler
+    from src.datamodule.task.vlparse import _COCODetFeatLazyLoader
+    rng = np.random.default_rng(7)
+    #       name                         n   buckets max_token max_sent single sort   shuffle same_len  length law
+    for name, n, nb, mt, ms, thr, sib, shuffle, same, lam in (
+            ("feed_sampler_n600_b16_s0", 600, 16, 500, -1, -1, True, True, False, 11),
+            ("feed_sampler_n400_b8_thr_s1", 400, 8, 160, 6, 24, True, True, False, 14),
+            ("feed_sampler_n60_b40_few_s2", 60, 40, 64, -1, -1, False, True, False, 2),     # fewer distinct lengths than buckets
+            ("feed_sampler_n300_same_len_s3", 300, 4, 100, -1, -1, True, False, True, 5)):
+        seed = int(name[-1])
+        lens = np.clip(rng.poisson(lam, n) + 1, 1, 50).tolist()
+        torch.manual_seed(seed)
+        sm = ConstantTokenNumSampler(lens, mt, ms, nb, thr, sib, shuffle, same)
+        epochs = [list(sm) for _ in range(3)]
+        boff, bitems = _csr(sm.buckets)
+        out = dict(seq_len=np.asarray(lens, np.int32), torch_seed=seed, num_bucket=nb, max_token=mt, max_sentence=ms,
+                   single_sent_threshold=thr, sort_in_batch=sib, shuffle=shuffle, force_same_len=same,
+                   sizes=np.asarray(sm.sizes, np.float64), bucket_offsets=boff, bucket_items=bitems,
+                   chunks=np.asarray(sm.chunks, np.int64))
+        for e, batches in enumerate(epochs):
+            out[f"epoch{e}_offsets"], out[f"epoch{e}_items"] = _csr(batches)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(f"{name}: {len(sm.buckets)} buckets, {[len(b) for b in epochs]} batches")
+    rows = [36, 4, 9, 1, 2]
+    dts = [np.float16, np.float32, np.float64, np.float16, np.float32]
+    files = [(rng.integers(-4, 5, (r, 2052)) / 2).astype(dt) for r, dt in zip(rows, dts)]   # coarse values: the fixture compresses
+    sg = {i: {"obj": list(range(40)), "rel": [{"subj": int(a), "obj": int(b)} for a, b in rng.integers(0, 40, (25, 2))]}
+          for i in range(len(rows))}
+    sg[4] = {"obj": [], "rel": []}
+    order = [3, 1, 4, 0, 2]
+    with tempfile.TemporaryDirectory() as td:
+        root = pathlib.Path(td)
+        for i, f in enumerate(files):
+            np.save(root / f"{i}.npy", f)
+        batch = [(k, {"img_id": i}) for k, i in enumerate(order)]
+        out = {f"file{i}": f for i, f in enumerate(files)}
+        out["order"] = np.asarray(order)
+        out["sg_rel"] = np.asarray([[i, r["subj"], r["obj"]] for i in sg for r in sg[i]["rel"]], np.int64)
+        out["sg_nobj"] = np.asarray([len(sg[i]["obj"]) for i in range(len(rows))], np.int64)
+        for tag, sample, gold in (("lead", 0, False), ("sample6", 6, False), ("gold", 0, True), ("gold_sample6", 6, True)):
+            np.random.seed(5)
+            a, b = _COCODetFeatLazyLoader(root, sg, sample, gold)(batch)
+            if not gold:
+                out[f"{tag}_feat_f16"] = _np(a["vis_box_feat"]).astype(np.float16)   # the inputs are f16-representable: lossless
+                assert (out[f"{tag}_feat_f16"].astype(np.float32) == _np(a["vis_box_feat"])).all()
+            else:   # the gold graph changes the masks only: same features as the plain call with the same sample
+                assert (_np(a["vis_box_feat"]) == out[("lead" if sample == 0 else "sample6") + "_feat_f16"]).all()
+            out[f"{tag}_mask"], out[f"{tag}_rel"] = _np(a["vis_box_mask"]), _np(a["vis_rel_mask"])
+            out[f"{tag}_available"], out[f"{tag}_box"] = _np(a["vis_available"]), _np(b["vis_box"])
+        np.savez_compressed(os.path.join(HERE, "feed_collate_5img_s5.npz"), **out)
+        print("feed_collate_5img_s5:", {k: v.shape for k, v in out.items() if k.endswith("feat_f16")})
+
+
 if __name__ == "__main__":
     dmv_case("dmv_B4_L10_s0", 0, 4, 10, "rand", store_merged=True)
     dmv_case("dmv_B4_L10_s1_full", 1, 4, 10, "full")
@@ -486,3 +553,4 @@ if __name__ == "__main__":
     reduced_cases()
     arcenc_cases()
     boxrel_cases()
+    feed_cases()

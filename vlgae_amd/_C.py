@@ -50,6 +50,10 @@ SIGNATURES = {
     "vlg_box_rel_pairwise": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "vlg_box_rel_pairwise_backward_workspace": (_sz, [_i, _i, _i]),
     "vlg_box_rel_pairwise_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
+    "vlg_feed_kmeans": (_i, [_vp, ctypes.c_int64, _vp, _i, _i, _vp, _vp, _vp]),
+    "vlg_feed_batches": (_i, [_vp, ctypes.c_int64, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "vlg_feed_npy_shape": (_i, [ctypes.c_char_p, _vp, _vp]),
+    "vlg_feed_collate_npy": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i]),
     "vlg_selftest_xlane": (_i, [_vp, _vp]),
     "vlg_last_error": (ctypes.c_char_p, []),
     "vlg_version": (_i, []),

@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvlgae_amd.so")
 ARCH = "gfx950"
-SOURCES = ("vlg_dp.hip", "vlg_align.hip", "vlg_attn.hip", "vlg_ground.hip", "vlg_decode.hip", "vlg_arc.hip", "vlg_rel.hip", "vlg_capi.cpp")
+SOURCES = ("vlg_dp.hip", "vlg_align.hip", "vlg_attn.hip", "vlg_ground.hip", "vlg_decode.hip", "vlg_arc.hip", "vlg_rel.hip", "vlg_feed.cpp", "vlg_capi.cpp")
 FLAGS = ("-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-x", "hip")
 # per-file extras.  vlg_dp.hip never produces or consumes inf / NaN in arithmetic (the semiring zero is the
 # finite -1e12), so fmaxf can be a bare v_max_f32 instead of canonicalise + max.
