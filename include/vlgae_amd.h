@@ -245,6 +245,13 @@ size_t vlg_box_rel_pairwise_backward_workspace(int B, int R, int H);
 int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* grad_out, int B, int R, int H, int dtype, float slope,
                                   void* ws, size_t ws_bytes, float* grad_y, float* grad_bias, void* stream);
 
+/* Chain rule on the API path (helpers.py:116-157: autograd scales the unit-upstream counts by d loss / d logZ):
+ *   out_a[b,:] = counts_a[b,:] * g[b*g_stride], out_b likewise; counts fp32, outputs out_dtype (VLG_F32 / VLG_BF16, round to
+ *   nearest even like torch's cast).  g_stride 1: g [B]; 0: one scalar (the expanded gradient of `.sum()`).  n_a / n_b =
+ *   elements per sentence; either side may be empty (n = 0, pointers then ignored). */
+int vlg_scale_counts(const float* counts_a, const float* counts_b, const float* g, int g_stride, int B, int n_a, int n_b,
+                     int out_dtype, void* out_a, void* out_b, void* stream);
+
 /* ---- Data feed (host code; no device work, no stream).  SURVEY.md section 8 row f4. ----
  *
  * Length bucketing -- ConstantTokenNumSampler.kmeans, src/datamodule/sampler.py:148-191: Lloyd iterations on the sentence

@@ -1147,6 +1147,37 @@ def test_count_sum_matches_batch_sum(B, N):
     assert torch.equal(out2[:-5], out[:-5])        # fixed order: identical bits run to run
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_api_backward_scales_and_casts_in_one_launch(dtype):
+    """autograd through `.partition` / DepTree: counts * upstream gradient, cast to the potentials' dtype (vlg_scale_counts),
+    bit-equal to the torch expression it replaces -- per-sentence weights, the expanded scalar of `.sum()`, and a
+    non-contiguous upstream gradient."""
+    import vlgae_amd.torch_struct as ts
+    from vlgae_amd.torch_struct import functional as Fn
+    B, N = 9, 12
+    g = torch.Generator().manual_seed(3)
+    dec = torch.randn(B, N, 2, 2, 2, generator=g).to(dev()).to(dtype).requires_grad_(True)
+    att = torch.randn(B, N, N, 2, generator=g).to(dev()).to(dtype).requires_grad_(True)
+    lengths = torch.tensor([11, 5, 11, 1, 7, 3, 11, 2, 9], device=dev())
+    _, cd, ca = Fn.dmv1o_run(dec, att, lengths, 0, True)
+    w = torch.randn(B, 2, generator=g).to(dev())[:, :1]                      # [B,1], non-contiguous
+    for up in (w, None):
+        z = ts.DMV1o([dec, att], lengths).partition
+        loss = (z * up).sum() * 0.37 if up is not None else z.sum() * 0.37
+        gd, ga = torch.autograd.grad(loss, [dec, att])
+        scale = (up.reshape(-1) * 0.37) if up is not None else torch.full((B,), 0.37, device=dev())
+        assert gd.dtype == dtype and ga.dtype == dtype
+        assert torch.equal(gd, (cd * scale.view(-1, 1, 1, 1, 1)).to(dtype)) and torch.equal(ga, (ca * scale.view(-1, 1, 1, 1)).to(dtype))
+    arc = torch.randn(B, N, N, generator=g).to(dev()).to(dtype).requires_grad_(True)
+    _, cr = Fn.deptree_run(arc, lengths, 0, True)
+    (gr,) = torch.autograd.grad((ts.DependencyCRF(arc, lengths).partition * w.reshape(-1)).sum(), [arc])
+    assert gr.dtype == dtype and torch.equal(gr, (cr * w.reshape(-1, 1, 1)).to(dtype))
+    # only one of the two potentials wants a gradient
+    att2 = att.detach()
+    (gd2,) = torch.autograd.grad(ts.DMV1o([dec, att2], lengths).partition.sum(), [dec])
+    assert torch.equal(gd2, cd.to(dtype))
+
+
 # ------------------------------------------------------------------------------------------------ visual encoder: rel features
 @pytest.mark.parametrize("path", golden_files("boxrel_"), ids=golden_ids("boxrel_"))
 def test_box_rel_golden(path):

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vlg_box_rel_pairwise": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "vlg_box_rel_pairwise_backward_workspace": (_sz, [_i, _i, _i]),
     "vlg_box_rel_pairwise_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
+    "vlg_scale_counts": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "vlg_feed_kmeans": (_i, [_vp, ctypes.c_int64, _vp, _i, _i, _vp, _vp, _vp]),
     "vlg_feed_batches": (_i, [_vp, ctypes.c_int64, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "vlg_feed_npy_shape": (_i, [ctypes.c_char_p, _vp, _vp]),
@@ -91,14 +92,24 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+try:   # raw handles without building torch.cuda.Stream objects (every launch asks; the small ops are host-bound)
+    _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:   # pragma: no cover
+    _raw_stream = lambda index: torch.cuda.current_stream(index).cuda_stream
+    _cur_device = torch.cuda.current_device
+
+
 def stream_of(t):
     """The HIP stream the launch goes to: the current stream of t's device.  hipLaunchKernel acts on the process's CURRENT
     device, so a tensor that lives elsewhere must not get this far (it would launch onto the wrong GPU or fail with an
     invalid handle): fail loudly instead."""
-    if t.device.index is not None and t.device.index != torch.cuda.current_device():
-        raise RuntimeError(f"vlgae_amd: tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+    index = t.device.index
+    if index is None:
+        index = _cur_device()
+    elif index != _cur_device():
+        raise RuntimeError(f"vlgae_amd: tensor on {t.device} but the current device is cuda:{_cur_device()}; "
                            "wrap the call in `with torch.cuda.device(t.device):` (one process per GPU sets it once)")
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(_raw_stream(index))
 
 
 def require_gpu(t, what):
@@ -110,23 +121,43 @@ def require_gpu(t, what):
 def in_dtype(t):
     """Kernel input element type for tensor t and the tensor to hand over (contiguous)."""
     if t.dtype == torch.bfloat16:
-        return BF16, t.contiguous()
-    return F32, t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+        return BF16, t if t.is_contiguous() else t.contiguous()
+    if t.dtype == torch.float32:
+        return F32, t if t.is_contiguous() else t.contiguous()
+    return F32, t.detach().float().contiguous()
 
 
-def alloc_f32(device, shapes, extra_bytes=0):
+def alloc_f32(device, shapes, extra_bytes=0, cast=None):
     """One float32 allocation carved into 256-byte aligned views of the given shapes (None entries are skipped and
     returned as None), plus a trailing scratch view of `extra_bytes`.  The ops here are small enough that a handful of
-    separate torch.empty calls costs as much host time as the kernels take."""
+    separate torch.empty calls costs as much host time as the kernels take.
+
+    Returns (views, scratch).  `views.cast(n, dtype)` (see Carved) converts the first n tensors with ONE elementwise launch."""
     import math
-    offs, total = [], 0
+    sizes, padded = [], []
     for shp in shapes:
-        if shp is None:
-            offs.append(None)
-            continue
-        n = math.prod(shp)
-        offs.append((total, n))
-        total += (n + 63) & ~63
+        n = 0 if shp is None else math.prod(shp)
+        sizes.append(n)
+        padded.append((n + 63) & ~63)
+    total = sum(padded)
     flat = torch.empty(total + (extra_bytes + 3) // 4, dtype=torch.float32, device=device)
-    views = [None if o is None else flat[o[0]:o[0] + o[1]].view(shp) for o, shp in zip(offs, shapes)]
-    return views, flat[total:]
+    return Carved(flat, shapes, sizes, padded), flat[total:]
+
+
+class Carved(list):
+    """The views of alloc_f32, remembering the flat buffer so that a dtype change of several of them is one launch."""
+
+    def __init__(self, flat, shapes, sizes, padded):
+        self.flat, self.shapes, self.sizes, self.padded = flat, shapes, sizes, padded
+        super().__init__(self._carve(flat, len(shapes)))
+
+    def _carve(self, flat, count):
+        parts = flat[:sum(self.padded[:count])].split_with_sizes(self.padded[:count]) if count else ()
+        return [None if shp is None else (p if n == m else p[:n]).view(shp)
+                for p, shp, n, m in zip(parts, self.shapes, self.sizes, self.padded)]
+
+    def cast(self, count, dtype):
+        """The first `count` tensors in `dtype` (one conversion kernel over their common storage)."""
+        if dtype == torch.float32:
+            return list(self[:count])
+        return self._carve(self.flat[:sum(self.padded[:count])].to(dtype), count)

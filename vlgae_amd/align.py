@@ -35,8 +35,8 @@ def bilinear_align(txt_feat, vis_feat, txt_mask=None, vis_mask=None, neg_inf=-IN
         raise ValueError(f"feature dims differ: txt {d} vs vis {d2}")
     if vis_feat.dtype != txt_feat.dtype:
         vis_feat = vis_feat.to(txt_feat.dtype)
-    dt, txt_c = _C.in_dtype(txt_feat.detach())
-    _, vis_c = _C.in_dtype(vis_feat.detach())
+    dt, txt_c = _C.in_dtype(txt_feat)
+    _, vis_c = _C.in_dtype(vis_feat)
     dev = txt_feat.device
     tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
     vm = None if vis_mask is None else vis_mask.to(device=dev, dtype=torch.uint8).contiguous()
@@ -89,7 +89,7 @@ def bilinear_align_backward(grad_out, txt_feat, vis_feat, txt_mask=None, vis_mas
     g = _plain(grad_out)
     if g.dtype != torch.float32 or not g.is_contiguous():
         g = g.to(torch.float32).contiguous()
-    dt, txt_c = _C.in_dtype(txt_feat.detach())
+    dt, txt_c = _C.in_dtype(txt_feat)
     vis_c = vis_feat.detach().to(txt_c.dtype).contiguous()
     tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
     vm = None if vis_mask is None else vis_mask.to(device=dev, dtype=torch.uint8).contiguous()
@@ -124,7 +124,7 @@ class _GatherLogitReduced(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, txt_feat, vis_feat, txt_mask, vis_mask, marginal, neg_inf):
-        dt, txt_c = _C.in_dtype(txt_feat.detach())
+        dt, txt_c = _C.in_dtype(txt_feat)
         vis_c = vis_feat.detach().to(txt_c.dtype).contiguous()
         B, Q, d = txt_c.shape
         V = vis_c.shape[1]
@@ -195,7 +195,7 @@ class _AttnFuse(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps):
-        dt, vis_c = _C.in_dtype(vis_feat.detach())
+        dt, vis_c = _C.in_dtype(vis_feat)
         txt_c, mid_c, enc_c = (t.detach().to(vis_c.dtype).contiguous() for t in (txt_feat, vis_mid, enc_x))
         gamma = ln_weight.detach().to(torch.float32).contiguous()
         beta = ln_bias.detach().to(torch.float32).contiguous()
@@ -220,6 +220,8 @@ class _AttnFuse(torch.autograd.Function):
         _C.check(_C.lib().vlg_attn_fuse_backward(_C.ptr(vis_c), _C.ptr(txt_c), _C.ptr(mid_c), _C.ptr(enc_c), _C.ptr(gamma),
                                                  _C.ptr(dout), B, L, V, d, h, dt, eps, _C.ptr(ws), nbytes,
                                                  *(_C.ptr(o) for o in outs), _C.stream_of(vis_c)), "attn_fuse_backward")
+        if dtypes[0] == dtypes[1] == dtypes[2] == dtypes[3] != torch.float32:   # the four feature gradients: one cast launch
+            outs = outs.cast(4, dtypes[0]) + list(outs[4:])
         grads = [(o if o.dtype == t else o.to(t)) if ctx.needs_input_grad[i] else None
                  for i, (o, t) in enumerate(zip(outs, dtypes))]
         return (*grads, None)
@@ -242,7 +244,7 @@ def attention_fuse(vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps=1
     tensors = (vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias)
     if not return_attmap and torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
         return _AttnFuse.apply(*tensors, float(eps))
-    dt, vis_c = _C.in_dtype(vis_feat.detach())
+    dt, vis_c = _C.in_dtype(vis_feat)
     txt_c, mid_c, enc_c = (t.detach().to(vis_c.dtype).contiguous() for t in (txt_feat, vis_mid, enc_x))
     gamma = ln_weight.detach().to(torch.float32).contiguous()
     beta = ln_bias.detach().to(torch.float32).contiguous()
@@ -281,7 +283,7 @@ class _GroundingLoss(torch.autograd.Function):
     def forward(ctx, txt_feat, vis_feat, txt_mask, vis_mask, marginal, pen, seg_of_v, num_token, w_vis2txt, neg_inf):
         B, Q, d = txt_feat.shape
         V = vis_feat.shape[1]
-        dt, txt_c = _C.in_dtype(txt_feat.detach())
+        dt, txt_c = _C.in_dtype(txt_feat)
         vis_c = vis_feat.detach().to(txt_c.dtype).contiguous()
         dev = txt_c.device
         tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
@@ -309,9 +311,22 @@ class _GroundingLoss(torch.autograd.Function):
     def backward(ctx, g_total, _g_sums):
         g_txt, g_vis = ctx.saved_tensors
         out = [None] * 10
-        if ctx.needs_input_grad[0]:
+        want_t, want_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dt = ctx.dtypes[0]
+        if dt == ctx.dtypes[1] and dt in (torch.float32, torch.bfloat16) and g_total.dtype == torch.float32 and g_total.numel() == 1:
+            # scale by the upstream scalar and cast, both tensors in one launch
+            a, b = (g_txt if want_t else None), (g_vis if want_v else None)
+            oa = None if a is None else torch.empty(a.shape, dtype=dt, device=a.device)
+            ob = None if b is None else torch.empty(b.shape, dtype=dt, device=b.device)
+            if a is not None or b is not None:
+                _C.check(_C.lib().vlg_scale_counts(_C.ptr(a), _C.ptr(b), _C.ptr(g_total), 0, 1, 0 if a is None else a.numel(),
+                                                   0 if b is None else b.numel(), _C.BF16 if dt == torch.bfloat16 else _C.F32,
+                                                   _C.ptr(oa), _C.ptr(ob), _C.stream_of(g_txt)), "scale_counts")
+            out[0], out[1] = oa, ob
+            return tuple(out)
+        if want_t:
             out[0] = (g_txt * g_total).to(ctx.dtypes[0])
-        if ctx.needs_input_grad[1]:
+        if want_v:
             out[1] = (g_vis * g_total).to(ctx.dtypes[1])
         return tuple(out)
 

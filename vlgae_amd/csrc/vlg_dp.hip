@@ -402,6 +402,21 @@ __global__ __launch_bounds__(1024) void count_sum_kernel(const float* __restrict
     }
 }
 
+// Chain rule of the partition function on the API path: the fused launch keeps unit-upstream counts, autograd later hands
+// over d loss / d logZ[b]; this scales both count tensors by it and writes them in the potentials' storage type -- one
+// launch instead of two multiplies and two casts (the API path is host-bound).  g_stride 0: one scalar for
+// the whole batch (the expanded gradient of a `.sum()`).
+template <typename Out>
+__global__ __launch_bounds__(256) void scale_counts_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ g, int g_stride, int na, int nb,
+                                                           Out* __restrict__ oa, Out* __restrict__ ob) {
+    const int s = blockIdx.y;
+    const float gs = g[(size_t)s * g_stride];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < na) oa[(size_t)s * na + i] = (Out)(a[(size_t)s * na + i] * gs);
+    else if (i - na < nb) ob[(size_t)s * nb + (i - na)] = (Out)(b[(size_t)s * nb + (i - na)] * gs);
+}
+
 // ---- launch plumbing --------------------------------------------------------------------------------
 template <typename K>
 static int prep(K kernel, size_t lds) {
@@ -716,6 +731,23 @@ int vlg_dmv1o_count_sum(const float* grad_dec, const float* grad_attach, int B, 
     hipLaunchKernelGGL(vlg::count_sum_kernel, dim3((Md + Ma + 63) / 64), dim3(1024), 0, (hipStream_t)stream, grad_dec,
                        grad_attach, B, Md, Ma, out);
     return vlg::check_launch("count_sum_kernel");
+}
+
+int vlg_scale_counts(const float* counts_a, const float* counts_b, const float* g, int g_stride, int B, int n_a, int n_b,
+                     int out_dtype, void* out_a, void* out_b, void* stream) {
+    if (B < 0 || n_a < 0 || n_b < 0 || (g_stride != 0 && g_stride != 1))
+        return vlg::set_error(VLG_ERR_SHAPE, "scale_counts: bad sizes (B=%d n_a=%d n_b=%d g_stride=%d)", B, n_a, n_b, g_stride);
+    if (!g || (n_a && (!counts_a || !out_a)) || (n_b && (!counts_b || !out_b))) return vlg::set_error(VLG_ERR_ARG, "scale_counts: null buffer");
+    if (out_dtype != VLG_F32 && out_dtype != VLG_BF16) return vlg::set_error(VLG_ERR_DTYPE, "scale_counts: out_dtype %d", out_dtype);
+    if (B == 0 || n_a + n_b == 0) return 0;
+    const dim3 grid((n_a + n_b + 255) / 256, B);
+    if (out_dtype == VLG_F32)
+        hipLaunchKernelGGL(vlg::scale_counts_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, counts_a, counts_b, g, g_stride, n_a,
+                           n_b, (float*)out_a, (float*)out_b);
+    else
+        hipLaunchKernelGGL(vlg::scale_counts_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, counts_a, counts_b, g,
+                           g_stride, n_a, n_b, (__bf16*)out_a, (__bf16*)out_b);
+    return vlg::check_launch("scale_counts_kernel");
 }
 
 }  // extern "C"

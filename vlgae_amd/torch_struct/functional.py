@@ -12,8 +12,14 @@ from .. import _C
 from .semirings import NEGINF
 
 
+_WS_BYTES = {}
+
+
 def _workspace(op, B, N, semiring, device):
-    nbytes = _C.lib().vlg_workspace_bytes(op, B, N, semiring)
+    key = (op, B, N, semiring)
+    nbytes = _WS_BYTES.get(key)
+    if nbytes is None:
+        nbytes = _WS_BYTES[key] = _C.lib().vlg_workspace_bytes(op, B, N, semiring)
     if nbytes == 0:
         return None, 0
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
@@ -26,13 +32,14 @@ def _lengths(lengths, B, device, allow_none=False):
         raise ValueError("lengths is required")
     if not torch.is_tensor(lengths):
         lengths = torch.as_tensor(lengths)
-    lengths = lengths.to(device=device, dtype=torch.int64).contiguous()
+    if lengths.dtype != torch.int64 or lengths.device != device or not lengths.is_contiguous():
+        lengths = lengths.to(device=device, dtype=torch.int64).contiguous()
     if lengths.shape != (B,):
         raise ValueError(f"lengths must have shape ({B},), got {tuple(lengths.shape)}")
     return lengths
 
 
-def dmv1o_run(dec, attach, lengths, semiring, want_grad, grad_logZ=None, want_dec=True):
+def dmv1o_run(dec, attach, lengths, semiring, want_grad, grad_logZ=None, want_dec=True, logZ_shape=None):
     """Raw launcher.  dec [B,N,2,2,2], attach [B,N,N,2] -> logZ [B] (+ grad_dec, grad_attach fp32).
     want_dec=False: attach counts only (grad_dec is None; the Max semiring then takes the back-pointer walk)."""
     _C.require_gpu(dec, "dmv1o")
@@ -43,10 +50,10 @@ def dmv1o_run(dec, attach, lengths, semiring, want_grad, grad_logZ=None, want_de
         raise ValueError(f"attach must be [B,N,N,2] = {(B, N, N, 2)}, got {tuple(attach.shape)}")
     if dec.dtype != attach.dtype:
         attach = attach.to(dec.dtype)
-    dt, dec_c = _C.in_dtype(dec.detach())
-    _, att_c = _C.in_dtype(attach.detach())
+    dt, dec_c = _C.in_dtype(dec)          # only the storage is read: no detach needed
+    _, att_c = _C.in_dtype(attach)
     lengths = _lengths(lengths, B, dec.device)
-    logZ = torch.empty(B, dtype=torch.float32, device=dec.device)
+    logZ = torch.empty(logZ_shape or B, dtype=torch.float32, device=dec.device)
     L = _C.lib()
     if want_grad:
         gdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dec.device) if want_dec else None
@@ -70,7 +77,7 @@ def deptree_run(arc, lengths, semiring, want_grad, grad_logZ=None):
         raise ValueError("potentials must have dim of 3 (unlabeled)")   # deptree.py:30-31 (labeled: out of scope)
     B, N, N2 = arc.shape
     assert N == N2, "Non-square potentials"                              # deptree.py:149
-    dt, arc_c = _C.in_dtype(arc.detach())
+    dt, arc_c = _C.in_dtype(arc)
     lengths = _lengths(lengths, B, arc.device, allow_none=True)
     logZ = torch.empty(B, dtype=torch.float32, device=arc.device)
     L = _C.lib()
@@ -98,8 +105,8 @@ def dmv1o_decode(dec, attach, lengths):
         raise ValueError(f"dec {tuple(dec.shape)} / attach {tuple(attach.shape)}: expected [B,N,2,2,2] / [B,N,N,2]")
     if dec.dtype != attach.dtype:
         attach = attach.to(dec.dtype)
-    dt, dec_c = _C.in_dtype(dec.detach())
-    _, att_c = _C.in_dtype(attach.detach())
+    dt, dec_c = _C.in_dtype(dec)
+    _, att_c = _C.in_dtype(attach)
     lengths = _lengths(lengths, B, dec.device)
     best = torch.empty(B, dtype=torch.float32, device=dec.device)
     heads = torch.empty((B, N), dtype=torch.int64, device=dec.device)
@@ -115,7 +122,7 @@ def deptree_decode(arc, lengths=None):
     _C.require_gpu(arc, "deptree_decode")
     B, N, N2 = arc.shape
     assert N == N2, "Non-square potentials"
-    dt, arc_c = _C.in_dtype(arc.detach())
+    dt, arc_c = _C.in_dtype(arc)
     lengths = _lengths(lengths, B, arc.device, allow_none=True)
     best = torch.empty(B, dtype=torch.float32, device=arc.device)
     heads = torch.empty((B, N), dtype=torch.int64, device=arc.device)
@@ -137,7 +144,7 @@ def dmv1o_rules_run(attach_rule, dec, root_rule, token, lengths, semiring, want_
     root2 = root_rule.reshape(-1, T)
     if root2.shape[0] not in (1, B):
         raise ValueError(f"root_rule must be [T], [1,T] or [B,T]; got {tuple(root_rule.shape)}")
-    dt, rule_c = _C.in_dtype(attach_rule.detach())
+    dt, rule_c = _C.in_dtype(attach_rule)
     dec_c = dec.detach().to(rule_c.dtype).contiguous()
     root_c = root2.detach().to(rule_c.dtype).contiguous()
     dev = attach_rule.device
@@ -204,20 +211,44 @@ class _DMV1oSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dec, attach, lengths, semiring):
         want = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        logZ, gdec, gatt = dmv1o_run(dec, attach, lengths, semiring, want)
+        logZ, gdec, gatt = dmv1o_run(dec, attach, lengths, semiring, want, logZ_shape=(dec.shape[0], 1))   # [B,1], helpers.py:116
         if want:
             ctx.save_for_backward(gdec, gatt)
         ctx.in_dtypes = (dec.dtype, attach.dtype)
-        return logZ.to(dec.dtype if dec.dtype == torch.float64 else torch.float32).unsqueeze(-1)   # [B,1], helpers.py:116
+        return logZ.double() if dec.dtype == torch.float64 else logZ
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
         gdec, gatt = ctx.saved_tensors
-        g = grad_out.reshape(-1).to(torch.float32)
-        gd = (gdec * g.view(-1, 1, 1, 1, 1)).to(ctx.in_dtypes[0]) if ctx.needs_input_grad[0] else None
-        ga = (gatt * g.view(-1, 1, 1, 1)).to(ctx.in_dtypes[1]) if ctx.needs_input_grad[1] else None
+        want_d, want_a = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gd, ga = _scale_counts(gdec if want_d else None, gatt if want_a else None, grad_out, ctx.in_dtypes[0], ctx.in_dtypes[1])
         return gd, ga, None, None
+
+
+def _scale_counts(ca, cb, grad_out, dtype_a, dtype_b):
+    """counts * d loss / d logZ, cast to the potentials' dtypes: one launch (vlg_scale_counts) for the fp32 / bf16 cases."""
+    first = ca if ca is not None else cb
+    if first is None:
+        return None, None
+    B = first.shape[0]
+    dt = dtype_a if ca is not None else dtype_b
+    if (ca is not None and cb is not None and dtype_a != dtype_b) or (dt != torch.float32 and dt != torch.bfloat16) or B == 0:
+        g = grad_out.reshape(-1).to(torch.float32)
+        return tuple(None if c is None else (c * g.view(-1, *([1] * (c.dim() - 1)))).to(d) for c, d in ((ca, dtype_a), (cb, dtype_b)))
+    if grad_out.dtype != torch.float32:
+        grad_out = grad_out.float()
+    stride = 1
+    if grad_out.stride() == (0,) * grad_out.dim():
+        stride = 0                                                   # the expanded scalar a `.sum()` hands back
+    elif not grad_out.is_contiguous():
+        grad_out = grad_out.contiguous()
+    oa = None if ca is None else torch.empty(ca.shape, dtype=dt, device=ca.device)
+    ob = None if cb is None else torch.empty(cb.shape, dtype=dt, device=cb.device)
+    _C.check(_C.lib().vlg_scale_counts(_C.ptr(ca), _C.ptr(cb), _C.ptr(grad_out), stride, B, 0 if ca is None else ca.numel() // B,
+                                       0 if cb is None else cb.numel() // B, _C.BF16 if dt == torch.bfloat16 else _C.F32, _C.ptr(oa),
+                                       _C.ptr(ob), _C.stream_of(first)), "scale_counts")
+    return oa, ob
 
 
 class _DepTreeSum(torch.autograd.Function):
@@ -234,7 +265,7 @@ class _DepTreeSum(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_out):
         (garc,) = ctx.saved_tensors
-        return (garc * grad_out.reshape(-1, 1, 1).to(torch.float32)).to(ctx.in_dtype), None, None
+        return _scale_counts(garc, None, grad_out, ctx.in_dtype, ctx.in_dtype)[0], None, None
 
 
 def dmv1o_sum(dec, attach, lengths, semiring):
@@ -251,7 +282,7 @@ def dmv1o_merge(dec, attach, root, one=0.0, zero=NEGINF):
     B, Lw = dec.shape[:2]
     if tuple(dec.shape) != (B, Lw, 2, 2, 2) or tuple(attach.shape) != (B, Lw, Lw, 2) or tuple(root.shape) != (B, Lw):
         raise ValueError(f"merge: dec {tuple(dec.shape)}, attach {tuple(attach.shape)}, root {tuple(root.shape)}")
-    dt, dec_c = _C.in_dtype(dec.detach())
+    dt, dec_c = _C.in_dtype(dec)
     attach = attach.detach().to(dec_c.dtype).contiguous()
     root = root.detach().to(dec_c.dtype).contiguous()
     N = Lw + 1

@@ -17,7 +17,7 @@ from . import _C
 class _PairwiseRel(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, bias, slope):
-        dt, y_c = _C.in_dtype(y.detach())
+        dt, y_c = _C.in_dtype(y)
         B, R, H = y_c.shape
         b_c = None if bias is None else bias.detach().to(torch.float32).contiguous()
         out = torch.empty((B, R, R, H), dtype=y_c.dtype, device=y_c.device)
