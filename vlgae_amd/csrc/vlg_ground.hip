@@ -102,6 +102,88 @@ __global__ __launch_bounds__(kCeThreads) void ground_ce_kernel(float* __restrict
     if (tid == 0) partial[(size_t)fixed * gridDim.y + blockIdx.y] = loss;
 }
 
+// The same cross-entropy with the strip staged in LDS: a block owns `cw` columns of one caption / image, brings the
+// [n x cw] strip of maxima in with one coalesced pass (every thread has ~24 independent loads in flight, where the kernel
+// above walks a column with one dependent stream per thread and is latency-bound at one block per CU), takes the column
+// statistics from LDS, and writes the derivative back with one more coalesced pass.  Same summation orders per column.
+constexpr int kCeTileThreads = 512;
+
+template <typename W>
+__global__ __launch_bounds__(kCeTileThreads) void ground_ce_tile_kernel(float* __restrict__ buf, size_t fixed_stride, size_t row_stride,
+                                                                        int n, int ncols, int cw_max, const W* __restrict__ w,
+                                                                        const uint16_t* __restrict__ arg,
+                                                                        const uint8_t* __restrict__ self_mask,
+                                                                        const uint8_t* __restrict__ other_mask, int n_other,
+                                                                        float* __restrict__ partial) {
+    extern __shared__ float ce_lds[];
+    constexpr int NT = kCeTileThreads;
+    const int fixed = blockIdx.x, tid = threadIdx.x;
+    const int j0 = blockIdx.y * cw_max, cw = min(cw_max, ncols - j0), pitch = cw_max | 1;
+    float* tile = ce_lds;                        // [n][pitch]
+    float* red = tile + (size_t)n * pitch;       // [NT]
+    float* colm = red + NT;                      // [cw_max] column maximum
+    float* colz = colm + cw_max;                 // [cw_max] 1 / sum of exp
+    float* colg = colz + cw_max;                 // [cw_max] gate * weight
+    float* base = buf + (size_t)fixed * fixed_stride + j0;
+    const int total = n * cw, di = NT / cw, dj = NT - di * cw;
+    {   // strip in: element e = i * cw + jl, e = tid, tid + NT, ...
+        int i = tid / cw, jl = tid - i * cw;
+        for (int e = tid; e < total; e += NT) {
+            tile[i * pitch + jl] = base[(size_t)i * row_stride + jl];
+            i += di;
+            jl += dj;
+            if (jl >= cw) { jl -= cw; ++i; }
+        }
+    }
+    __syncthreads();
+    const int P = NT / cw, jl = tid % cw, part = tid / cw;   // P row slices per column
+    const bool on = part < P;
+    float m = __uint_as_float(0xff800000u);
+    if (on)
+        for (int i = part; i < n; i += P) m = fmaxf(m, tile[i * pitch + jl]);
+    red[tid] = m;
+    __syncthreads();
+    if (tid < cw) {
+        float mm = red[tid];
+        for (int p = 1; p < P; ++p) mm = fmaxf(mm, red[p * cw + tid]);
+        colm[tid] = mm;
+    }
+    __syncthreads();
+    m = colm[jl];
+    float z = 0.f;
+    if (on)
+        for (int i = part; i < n; i += P) z += __expf(tile[i * pitch + jl] - m);
+    red[tid] = z;
+    __syncthreads();
+    if (tid < cw) {
+        float zz = red[tid];
+        for (int p = 1; p < P; ++p) zz += red[p * cw + tid];   // fixed order
+        const int j = j0 + tid;
+        const float wt = w ? (float)w[(size_t)fixed * ncols + j] : 1.f;
+        colz[tid] = 1.f / zz;
+        colg[tid] = (!self_mask || self_mask[(size_t)fixed * ncols + j]) ? wt : 0.f;
+        red[tid] = -wt * ((tile[fixed * pitch + tid] - colm[tid]) - __logf(zz));   // joint.py:476-477
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float loss = 0.f;
+        for (int c = 0; c < cw; ++c) loss += red[c];   // columns in ascending order
+        partial[(size_t)fixed * gridDim.y + blockIdx.y] = loss;
+    }
+    {   // derivative w.r.t. the maxima, in place
+        const uint16_t* abase = arg + (size_t)fixed * fixed_stride + j0;
+        int i = tid / cw, c = tid - i * cw;
+        for (int e = tid; e < total; e += NT) {
+            const size_t at = (size_t)i * row_stride + c;
+            const bool open_ = !other_mask || other_mask[(size_t)i * n_other + abase[at]];
+            base[at] = open_ ? colg[c] * (__expf(tile[i * pitch + c] - colm[c]) * colz[c] - (i == fixed ? 1.f : 0.f)) : 0.f;
+            i += di;
+            c += dj;
+            if (c >= cw) { c -= cw; ++i; }
+        }
+    }
+}
+
 // sums = {txt2vis, vis2txt, total};  coef = {c1, c2}: d total / d txt2vis, d total / d vis2txt.
 // One wave: lane i adds partials i, i+64, ... in order, then a fixed xor tree (same bits every run).
 __global__ __launch_bounds__(64) void ground_sum_kernel(const float* __restrict__ part1, const float* __restrict__ part2, int n1,
@@ -497,7 +579,7 @@ static int launch_bwd(const void* txt, const void* vis, const float* gV, const u
 // fp32 features keep the sparse kernels (exact fp32 products).  One wave per 16-row tile, accumulation over the outer
 // loop in registers, fixed order: reproducible, no atomics.
 // =====================================================================================================
-constexpr int kGdD = 128;
+constexpr int kGdD = 128, kGdChunk = 8;   // feature width; pairs per staged chunk of the small arrays
 
 // feat [O][K][128] bf16 -> featT [O][128][Kp] bf16 (zero-padded): block = one tensor o, LDS transpose in 32-row strips
 __global__ __launch_bounds__(256) void ground_transpose_kernel(const uint16_t* __restrict__ feat, int K, int Kp,
@@ -524,23 +606,33 @@ typedef __attribute__((ext_vector_type(4))) float gd_f32x4;
 // SIDE 0: fix = caption b, rows = its queries (M = Q), outer o = image a, contraction over regions (K = V);
 //         self terms = (argV, gV) per row, other terms = (argQ, gQ) per contraction position.
 // SIDE 1: fix = image a, rows = its regions (M = V), outer o = caption b, contraction over queries (K = Q); roles swapped.
-// NKC = Kp / 32 contraction chunks.  Block = ceil(M / 16) waves.
-template <int SIDE, int NKC, int NW>   // NW = wavefronts per block = ceil(M / 16)
-__global__ __launch_bounds__(64 * NW) void ground_bwd_dense_kernel(
+// NKC = Kp / 32 contraction chunks, MT = ceil(M / 16) row tiles.  Block = 4 waves tiling the [MT x 8] output tiles RW x CW
+// (a wave owns RT row tiles x CT column tiles: every A fragment it reads feeds CT MFMAs, every B fragment RT -- one row
+// tile per wave, round 2's first version, re-read the whole feature tile in every wave and was LDS-bound).
+template <int SIDE, int NKC, int MT, int RW, int SEGL>
+__global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
     const uint16_t* __restrict__ featT, const float* __restrict__ gV, const uint16_t* __restrict__ argV,
     const float* __restrict__ gQ, const uint16_t* __restrict__ argQ, const float* __restrict__ coef, int B, int Q, int V,
     float* __restrict__ out) {
-    constexpr int Kp = NKC * 32, PITCH = Kp * 2 + 16, SEGS = Kp / 8;   // padded row pitch in bytes
-    constexpr int MR = NW * 16, nthr = 64 * NW;
+    // row pitch in bytes: +32 keeps the ds_read_b128 fragment reads (16 rows x 4 k-groups per instruction, serviced in the
+    // hardware's four fixed 16-lane groups, MI355X_MICROARCH.md section LDS) free of bank conflicts; +16 costs 2x on every read
+    constexpr int Kp = NKC * 32, PITCH = Kp * 2 + 32, SEGS = Kp / 8;
+    constexpr int MR = MT * 16, nthr = 256, CW = 4 / RW, RT = (MT + RW - 1) / RW, CT = 8 / CW;
     const int A = B, M = SIDE == 0 ? Q : V, K = SIDE == 0 ? V : Q;
     // the outer range is split over gridDim.y blocks (occupancy: one block per CU leaves the LDS / barrier latency exposed)
     const int o_per = (B + (int)gridDim.y - 1) / (int)gridDim.y, o_begin = blockIdx.y * o_per, O = min(B, o_begin + o_per);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     auto tile = [&](int buf) -> char* { return smem_raw + buf * (kGdD * PITCH); };           // other side's features, [d][Kp] bf16
-    char* wself = smem_raw + 2 * kGdD * PITCH;                                                // W, "row's own maximum" terms   [MR][Kp] bf16
-    char* wother = wself + MR * PITCH;                                                        // W, "position points at row" terms
+    char* wt = smem_raw + 2 * kGdD * PITCH;                                                   // W [MR][Kp] bf16
+    // the pairs' four small arrays, a chunk of kGdChunk pairs at a time (the next chunk waits in registers until the last
+    // pair of this one has built its W):  [chunk][ argS[MR] | argO[Kp] ] int16  and  [chunk][ valS[MR] | valO[Kp] ] float,
+    // the values already scaled by c1 / c2
+    constexpr int EW = MR + Kp, CH = kGdChunk;
+    int16_t* sarg = reinterpret_cast<int16_t*>(wt + MR * PITCH);
+    float* sval = reinterpret_cast<float*>(sarg + CH * EW);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fix = blockIdx.x, kg = lane >> 4, ccol = lane & 15;
+    const int rt0 = (wave / CW) * RT, ct0 = (wave % CW) * CT;
     const float c_self = SIDE == 0 ? coef[0] : coef[1], c_other = SIDE == 0 ? coef[1] : coef[0];
     const float* g_self = SIDE == 0 ? gV : gQ;
     const uint16_t* a_self = SIDE == 0 ? argV : argQ;
@@ -549,105 +641,164 @@ __global__ __launch_bounds__(64 * NW) void ground_bwd_dense_kernel(
     auto pair = [&](int o) -> size_t { return SIDE == 0 ? (size_t)fix * A + o : (size_t)o * A + fix; };
     if (o_begin >= O) return;
 
-    // W is built in LDS by scatter: thread t < M owns row t of `wself` (one non-zero: column argself[t]), thread t < K owns
-    // column t of `wother` (one non-zero: row argother[t]) -- no two threads ever touch the same element, and each thread
-    // clears its previous element before writing the next one, so the tiles never need a full re-zeroing.  Where both kinds
-    // hit the same (row, column) their sum is formed by the matrix cores (two MFMAs per fragment pair).
-    for (int i = tid; i < 2 * MR * PITCH / 16; i += nthr) reinterpret_cast<uint4*>(wself)[i] = make_uint4(0, 0, 0, 0);
-    constexpr int NV = (kGdD * SEGS + nthr - 1) / nthr;   // 16-byte vectors of the feature tile per thread
-    auto stage_load = [&](int o, uint4* xs, int& ps, float& ws, int& po, float& wo) {
+    // W is built in LDS by scatter: thread t < M owns row t (one non-zero: column argself[t]), thread t < K owns column t
+    // (one non-zero: row argother[t]).  Where the two kinds meet -- row r points at column t AND column t points at row r --
+    // the column owner writes the sum and the row owner stays out (each sees the other's index in the staged arrays), so no
+    // element has two writers; each owner clears what it wrote for the previous pair, so the tile is never re-zeroed.
+    // (the feature tiles are zeroed too: only the 16-byte segments that hold contraction positions < K are ever staged,
+    //  the padding up to Kp stays zero)
+    for (int i = tid; i < (2 * kGdD + MR) * PITCH / 16; i += nthr) reinterpret_cast<uint4*>(smem_raw)[i] = make_uint4(0, 0, 0, 0);
+    constexpr int NV = (kGdD * SEGL + nthr - 1) / nthr;   // 16-byte vectors of the feature tile per thread
+    constexpr int segs = SEGL, nvec = kGdD * SEGL;         // segments per row that hold data (SEGL >= ceil(K / 8))
+    // One register set holds the NEXT pair's feature tile in flight: loaded (branch-free) right after the previous contents
+    // went to LDS, consumed one whole step later, and nothing younger is outstanding at that point, so the drain the compiler
+    // puts there (s_waitcnt vmcnt(0): it does not count loads across the loop's back edge) costs nothing extra.
+    uint4 xs[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) xs[j] = make_uint4(0, 0, 0, 0);   // (an uninitialised array that is written under a condition ends up in scratch)
+    auto stage_load = [&](int o, uint4* xs) __attribute__((always_inline)) {
         const uint4* src = reinterpret_cast<const uint4*>(featT + (size_t)o * kGdD * Kp);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * nthr;
-            if (i < kGdD * SEGS) xs[j] = src[i];
+            const int i = min(tid + j * nthr, nvec - 1);
+            const int row = i / segs, seg = i - row * segs;
+            xs[j] = src[row * SEGS + seg];
         }
-        ps = po = -1;
-        ws = wo = 0.f;
-        if (tid < M) { ps = a_self[pair(o) * M + tid]; ws = c_self * g_self[pair(o) * M + tid]; }
-        if (tid < K) { po = a_other[pair(o) * K + tid]; wo = c_other * g_other[pair(o) * K + tid]; }
     };
-    auto stage_tile = [&](int buf, const uint4* xs) {
+    auto stage_tile = [&](int buf, const uint4* xs) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = tid + j * nthr;
-            if (i < kGdD * SEGS) {
-                const int row = i / SEGS, seg = i - row * SEGS;
+            if (i < nvec) {
+                const int row = i / segs, seg = i - row * segs;
                 *reinterpret_cast<uint4*>(tile(buf) + row * PITCH + seg * 16) = xs[j];
             }
         }
     };
-    auto f2bf = [](float f) -> uint16_t { return __builtin_bit_cast(uint16_t, (__bf16)f); };
-    gd_f32x4 acc[8];
+    // The small arrays come from HBM (each is read exactly once): a whole chunk of pairs is fetched with one burst of
+    // independent loads (raw values only -- arithmetic here would make the wave wait for what it has just issued) while the
+    // previous chunk is being worked on, so that latency is paid once per kGdChunk pairs instead of once per pair.
+    constexpr int NE = (CH * EW + nthr - 1) / nthr;   // (argument, value) entries per thread and chunk
+    int carg[NE];
+    float cval[NE];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = gd_f32x4{0.f, 0.f, 0.f, 0.f};
-    // Two register sets, each holding one pair's staged data (feature-tile vectors + this thread's W elements); a pair's
-    // loads are issued TWO iterations before they are consumed (the small arrays come from HBM, and one iteration is short),
-    // the sets swap roles by unrolling the pair loop twice.
-    uint4 xa[NV], xb[NV];
+    for (int j = 0; j < NE; ++j) { carg[j] = 0; cval[j] = 0.f; }
+    // (the 16-bit positions are fetched as the aligned dword that holds them and picked apart when they go to LDS: a 16-bit
+    //  load is widened by an instruction of its own, which the compiler places right behind the burst -- a drain)
+    unsigned cpar = 0;   // bit j: entry j's position sits in the upper half of its dword
+    // (by-value captures: a `cond ? a : b` over two by-reference captures is a run-time index into the closure object, which
+    //  then stays in memory -- scratch -- together with everything it refers to)
+    auto chunk_load = [=](int oc, int* carg, float* cval, unsigned& cpar) __attribute__((always_inline)) {
+        cpar = 0;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) xa[j] = xb[j] = make_uint4(0, 0, 0, 0);
-    int psa, poa, psb = -1, pob = -1, ps_old = -1, po_old = -1;
-    float wsa, woa, wsb = 0.f, wob = 0.f;
-    stage_load(o_begin, xa, psa, wsa, poa, woa);
-    if (o_begin + 1 < O) stage_load(o_begin + 1, xb, psb, wsb, pob, wob);
-    __syncthreads();                       // the zero fill above
-    stage_tile(0, xa);
-    // one pair: (ps, ws, po, wo) are pair o's elements; xn holds pair o+1's feature tile; pair o+2 is loaded into the `cur` set
-    auto step = [&](int o, uint4* xcur, int& ps, float& ws, int& po, float& wo, const uint4* xnext) {
-        const int buf = (o - o_begin) & 1;
-        // ---- W of this pair: clear last pair's elements, write this pair's (same owner thread: program order) ----
-        auto welem = [&](char* w, int row, int col) { return reinterpret_cast<uint16_t*>(w + row * PITCH + col * 2); };
-        if (ps_old >= 0) *welem(wself, tid, ps_old) = 0;
-        if (po_old >= 0) *welem(wother, po_old, tid) = 0;
-        if (ps >= 0 && ps < K) *welem(wself, tid, ps) = f2bf(ws);
-        if (po >= 0 && po < M) *welem(wother, po, tid) = f2bf(wo);
-        ps_old = (ps >= 0 && ps < K) ? ps : -1;
-        po_old = (po >= 0 && po < M) ? po : -1;
-        if (o + 2 < O) stage_load(o + 2, xcur, ps, ws, po, wo);   // this set is free again: consumed two iterations from now
-        __syncthreads();                                          // W(o) and tile(o) complete
-        // Fragment reads are issued in batches ahead of their MFMAs (sched_barrier pins them there): left to itself hipcc
-        // reuses ONE register quad for the B fragments -- read, wait lgkmcnt(0), two MFMAs, next read -- which exposes a
-        // full LDS latency per fragment.
-        // (four B fragments in flight per batch: the whole pair's 16-24 at once costs 184-246 VGPRs and with them half the
-        // resident blocks -- measured slower than no batching at all)
+        for (int j = 0; j < NE; ++j) {
+            const int id = min(tid + j * nthr, CH * EW - 1), p = id / EW, e = id - p * EW;
+            const size_t pr = pair(min(oc + p, O - 1));
+            const bool other = e >= MR;
+            const size_t at = other ? pr * K + min(e - MR, K - 1) : pr * M + min(e, M - 1);
+            const uint32_t* ap = reinterpret_cast<const uint32_t*>(other ? a_other : a_self) + (at >> 1);
+            const float* gp = (other ? g_other : g_self) + at;
+            carg[j] = (int)*ap;
+            cval[j] = *gp;
+            cpar |= ((unsigned)at & 1u) << j;
+        }
+    };
+    auto chunk_store = [=](const int* carg, const float* cval, unsigned cpar) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            const int aoff = (wave * 16 + ccol) * PITCH + (kc * 4 + kg) * 16;
-            const gd_bf16x8 a0 = *reinterpret_cast<const gd_bf16x8*>(wself + aoff);
-            const gd_bf16x8 a1 = *reinterpret_cast<const gd_bf16x8*>(wother + aoff);
-#pragma unroll
-            for (int c0 = 0; c0 < 8; c0 += 4) {
-                gd_bf16x8 bf[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    bf[c] = *reinterpret_cast<const gd_bf16x8*>(tile(buf) + ((c0 + c) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc[c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf[c], acc[c0 + c], 0, 0, 0);
-                    acc[c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf[c], acc[c0 + c], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < NE; ++j) {
+            const int id = tid + j * nthr;
+            if (id < CH * EW) {
+                const int p = id / EW, e = id - p * EW;
+                const bool other = e >= MR;
+                const int av = (carg[j] >> (((cpar >> j) & 1u) << 4)) & 0xffff;
+                const bool ok = other ? (e - MR < K && av < M) : (e < M && av < K);
+                sarg[id] = (int16_t)(ok ? av : -1);
+                sval[id] = (other ? c_other : c_self) * cval[j];
             }
         }
-        if (o + 1 < O) stage_tile(buf ^ 1, xnext);                // the other feature buffer: last read in iteration o-1
-        __syncthreads();                                          // every wave is done with W(o) before it is rewritten
     };
-    for (int o = o_begin; o < O; o += 2) {
-        step(o, xa, psa, wsa, poa, woa, xb);
-        if (o + 1 < O) step(o + 1, xb, psb, wsb, pob, wob, xa);
+    auto f2bf = [](float f) -> uint16_t { return __builtin_bit_cast(uint16_t, (__bf16)f); };
+    gd_f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = gd_f32x4{0.f, 0.f, 0.f, 0.f};
+    int ps_old = -1, po_old = -1;
+    chunk_load(o_begin, carg, cval, cpar);
+    stage_load(o_begin, xs);
+    __syncthreads();                       // the zero fill above
+    chunk_store(carg, cval, cpar);
+    stage_tile(0, xs);
+    stage_load(min(o_begin + 1, O - 1), xs);
+    __syncthreads();
+    for (int o = o_begin; o < O; ++o) {
+        const int step = o - o_begin, buf = step & 1, cp = step % CH;
+        if (cp == 0 && o + CH < O) chunk_load(o + CH, carg, cval, cpar);   // the chunk after this one: in flight during this step
+        // ---- W of this pair: clear last pair's elements, write this pair's (same owner thread: program order) ----
+        auto welem = [&](int row, int col) { return reinterpret_cast<uint16_t*>(wt + row * PITCH + col * 2); };
+        const int16_t* argS = sarg + cp * EW;
+        const int16_t* argO = argS + MR;
+        const float* valS = sval + cp * EW;
+        const float* valO = valS + MR;
+        // (an old element is left alone when ANOTHER thread writes this pair's value to the same place -- the column owner of
+        //  my old column pointing at my row, or the row owner of my old row pointing at my column -- since its write and my
+        //  clear are unordered; my own clear-then-write is program order, LDS operations of a wave complete in order)
+#ifndef VLG_GD_NOW
+        if (ps_old >= 0 && argO[ps_old] != tid) *welem(tid, ps_old) = 0;
+        if (po_old >= 0 && argS[po_old] != tid) *welem(po_old, tid) = 0;
+        const int my_s = tid < MR ? argS[tid] : -1, my_o = tid < Kp ? argO[tid] : -1;   // already -1 where invalid
+        const bool row_writes = my_s >= 0 && argO[my_s] != tid;   // else the column owner writes the sum
+        const bool col_writes = my_o >= 0;
+        if (row_writes) *welem(tid, my_s) = f2bf(valS[tid]);
+        if (col_writes) *welem(my_o, tid) = f2bf(valO[tid] + (argS[my_o] == tid ? valS[my_o] : 0.f));
+        ps_old = row_writes ? my_s : -1;
+        po_old = col_writes ? my_o : -1;
+#endif
+        __syncthreads();                                          // W(o) and tile(o) complete
+        // Fragment reads are issued in batches ahead of their MFMAs (sched_barrier pins them there): left to itself hipcc
+        // reuses ONE register quad for the B fragments -- read, wait lgkmcnt(0), MFMAs, next read -- which exposes a full
+        // LDS latency per fragment.
+#ifndef VLG_GD_NOMFMA
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            gd_bf16x8 af[RT], bf[CT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                af[r] = *reinterpret_cast<const gd_bf16x8*>(wt + (min(rt0 + r, MT - 1) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                bf[c] = *reinterpret_cast<const gd_bf16x8*>(tile(buf) + ((ct0 + c) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r], bf[c], acc[r][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+#ifndef VLG_GD_NOSTAGE
+        stage_tile(buf ^ 1, xs);                                  // pair o+1 into the other buffer: last read in iteration o-1
+        if (cp == CH - 1 && o + 1 < O) chunk_store(carg, cval, cpar);   // this chunk's last W is built: its arrays make way
+        stage_load(min(o + 2, O - 1), xs);
+#endif
+#ifndef VLG_GD_NOBAR2
+        __syncthreads();                                          // every wave is done with W(o) before it is rewritten
+#endif
     }
     // accumulator tile: lane l, register n <-> row 4 (l >> 4) + n, column l & 15
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int rr = wave * 16 + kg * 4 + n;
-        if (rr < M) {
-            float* dst = out + ((size_t)fix * M + rr) * kGdD + ccol;
+    for (int r = 0; r < RT; ++r) {
+        if (rt0 + r >= MT) break;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if (gridDim.y > 1) atomicAdd(dst + c * 16, acc[c][n]);   // two partial sums into a zeroed output: order-free
-                else dst[c * 16] = acc[c][n];
+        for (int n = 0; n < 4; ++n) {
+            const int rr = (rt0 + r) * 16 + kg * 4 + n;
+            if (rr < M) {
+                float* dst = out + ((size_t)fix * M + rr) * kGdD + ct0 * 16 + ccol;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (gridDim.y > 1) atomicAdd(dst + c * 16, acc[r][c][n]);   // two partial sums into a zeroed output: order-free
+                    else dst[c * 16] = acc[r][c][n];
+                }
             }
         }
     }
@@ -659,7 +810,7 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
     constexpr int KpV = 64, KpQ = 96;
     uint16_t* visT = scratch;                              // [B][128][64]
     uint16_t* txtT = scratch + (size_t)B * kGdD * KpV;     // [B][128][96]
-    auto lds = [](int Kp, int nw) { return (size_t)(2 * kGdD + 2 * nw * 16) * (Kp * 2 + 16); };
+    auto lds = [](int Kp, int mt) { return (size_t)(2 * kGdD + mt * 16) * (Kp * 2 + 32) + (size_t)kGdChunk * (mt * 16 + Kp) * (2 + 4); };
     int split = B >= 32 ? 2 : 1;   // two blocks per caption / image (two-addend atomics stay order-free)
     if (const char* e = getenv("VLG_GD_SPLIT")) split = atoi(e);
     if (split > 1) {
@@ -668,30 +819,37 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
         if (e == hipSuccess && g_vis) e = hipMemsetAsync(g_vis, 0, sizeof(float) * (size_t)B * V * kGdD, s);
         if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
-#define VLG_GD(SIDEV, NKCV, NWV, FT, OUT)                                                                              \
-    hipLaunchKernelGGL((ground_bwd_dense_kernel<SIDEV, NKCV, NWV>), dim3(B, split), dim3(64 * NWV), lds(NKCV * 32, NWV), s, FT, gV, argV, gQ,  \
-                       argQ, coef, B, Q, V, OUT)
-    if (g_txt) {
+#define VLG_GD2(SIDEV, NKCV, MTV, RWV, SEGV, FT, OUT)                                                                  \
+    hipLaunchKernelGGL((ground_bwd_dense_kernel<SIDEV, NKCV, MTV, RWV, SEGV>), dim3(B, split), dim3(256), lds(NKCV * 32, MTV), s, FT, gV, \
+                       argV, gQ, argQ, coef, B, Q, V, OUT)
+    // SEGL: 16-byte segments of a feature row that are staged; config-2's 36 regions need 5 of the 8
+#define VLG_GD(SIDEV, NKCV, MTV, RWV, FT, OUT)                                                                         \
+    do {                                                                                                               \
+        if (SIDEV == 0 && V <= 40) VLG_GD2(SIDEV, NKCV, MTV, RWV, (SIDEV == 0 ? 5 : 12), FT, OUT);                      \
+        else VLG_GD2(SIDEV, NKCV, MTV, RWV, (SIDEV == 0 ? 8 : 12), FT, OUT);                                            \
+    } while (0)
+    if (g_txt) {   // rows = queries (Q <= 96), contraction over regions (V <= 64)
         hipLaunchKernelGGL(ground_transpose_kernel, dim3(B), dim3(256), 0, s, (const uint16_t*)vis, V, KpV, visT);
-        switch (std::max((Q + 15) / 16, (V + 63) / 64)) {   // waves: one per 16 rows, and at least one thread per contraction position
-            case 1: VLG_GD(0, 2, 1, visT, g_txt); break;
-            case 2: VLG_GD(0, 2, 2, visT, g_txt); break;
-            case 3: VLG_GD(0, 2, 3, visT, g_txt); break;
-            case 4: VLG_GD(0, 2, 4, visT, g_txt); break;
-            case 5: VLG_GD(0, 2, 5, visT, g_txt); break;
-            default: VLG_GD(0, 2, 6, visT, g_txt); break;
+        switch ((Q + 15) / 16) {
+            case 1: VLG_GD(0, 2, 1, 1, visT, g_txt); break;
+            case 2: VLG_GD(0, 2, 2, 2, visT, g_txt); break;
+            case 3: VLG_GD(0, 2, 3, 1, visT, g_txt); break;
+            case 4: VLG_GD(0, 2, 4, 2, visT, g_txt); break;
+            case 5: VLG_GD(0, 2, 5, 2, visT, g_txt); break;
+            default: VLG_GD(0, 2, 6, 2, visT, g_txt); break;
         }
     }
-    if (g_vis) {
+    if (g_vis) {   // rows = regions (V <= 64), contraction over queries (Q <= 96)
         hipLaunchKernelGGL(ground_transpose_kernel, dim3(B), dim3(256), 0, s, (const uint16_t*)txt, Q, KpQ, txtT);
-        switch (std::max((V + 15) / 16, (Q + 63) / 64)) {
-            case 1: VLG_GD(1, 3, 1, txtT, g_vis); break;
-            case 2: VLG_GD(1, 3, 2, txtT, g_vis); break;
-            case 3: VLG_GD(1, 3, 3, txtT, g_vis); break;
-            default: VLG_GD(1, 3, 4, txtT, g_vis); break;
+        switch ((V + 15) / 16) {
+            case 1: VLG_GD(1, 3, 1, 1, txtT, g_vis); break;
+            case 2: VLG_GD(1, 3, 2, 2, txtT, g_vis); break;
+            case 3: VLG_GD(1, 3, 3, 1, txtT, g_vis); break;
+            default: VLG_GD(1, 3, 4, 2, txtT, g_vis); break;
         }
     }
 #undef VLG_GD
+#undef VLG_GD2
     return 0;
 }
 
@@ -783,20 +941,46 @@ int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask
     float *mV = ws + p.off_maxV, *mQ = ws + p.off_maxQ, *part = ws + p.off_part, *coef = ws + p.off_coef;
     const uint16_t* aV = reinterpret_cast<const uint16_t*>(ws + p.off_argV);
     const uint16_t* aQ = reinterpret_cast<const uint16_t*>(ws + p.off_argQ);
-    // column shares per caption / image: only when B alone leaves CUs idle and there are several 256-column strips
-    auto shares = [&](int ncols) {
-        const int strips = (ncols + kCeThreads - 1) / kCeThreads;
-        return B >= 256 ? 1 : std::max(1, std::min(std::min(strips, kCeMaxY), (256 + B - 1) / B));
+    // strips of columns per caption / image: [B x cw] floats staged in LDS, at most kCeMaxY strips
+    struct Strips { int cw, y; size_t lds; };
+    auto strips = [&](int ncols) {
+        const int budget = std::max(16, (int)(48 * 1024 / (4 * (size_t)B)));
+        int y = std::min(kCeMaxY, (ncols + budget - 1) / budget);
+        if (B < 256) y = std::max(y, std::min(std::min(kCeMaxY, (ncols + 31) / 32), (256 + B - 1) / B));   // few rows: still cover the chip
+        const int cw = (ncols + y - 1) / y;
+        y = (ncols + cw - 1) / cw;
+        return Strips{cw, y, sizeof(float) * ((size_t)B * (cw | 1) + kCeTileThreads + 3 * (size_t)cw)};
     };
-    const int y1 = shares(Q), y2 = shares(V);
+    const Strips s1 = strips(Q), s2 = strips(V);
+    const bool tiled = s1.lds <= 144 * 1024 && s2.lds <= 144 * 1024 && s1.cw <= kCeTileThreads && s2.cw <= kCeTileThreads && !getenv("VLG_GROUND_CE_OLD");
+    // column shares for the streaming kernel: only when B alone leaves CUs idle and there are several 256-column strips
+    auto shares = [&](int ncols) {
+        const int st = (ncols + kCeThreads - 1) / kCeThreads;
+        return B >= 256 ? 1 : std::max(1, std::min(std::min(st, kCeMaxY), (256 + B - 1) / B));
+    };
+    const int y1 = tiled ? s1.y : shares(Q), y2 = tiled ? s2.y : shares(V);
+    float* part2 = part + (size_t)B * y1;
     // txt2vis: fixed = caption b, rows = images a: x[a][q] = mV[(b*A + a)*Q + q]; gate: tmask[b][q], vmask[a][argV]
-    hipLaunchKernelGGL(ground_ce_kernel<float>, dim3(B, y1), dim3(kCeThreads), 0, s, mV, (size_t)B * Q, (size_t)Q, B, Q, marg, aV,
-                       tmask, vmask, V, part);
     // vis2txt: fixed = image a, rows = captions b: x[b][v] = mQ[(b*A + a)*V + v]; weights = vis_mask as 0/1 (joint.py:481,
     // null = all ones); gate: vmask[a][v], tmask[b][argQ]
-    float* part2 = part + (size_t)B * y1;
-    hipLaunchKernelGGL(ground_ce_kernel<uint8_t>, dim3(B, y2), dim3(kCeThreads), 0, s, mQ, (size_t)V, (size_t)B * V, B, V, vmask, aQ,
-                       vmask, tmask, Q, part2);
+    if (tiled) {
+        auto k1 = ground_ce_tile_kernel<float>;
+        auto k2 = ground_ce_tile_kernel<uint8_t>;
+        for (auto kp : {std::make_pair((const void*)k1, s1.lds), std::make_pair((const void*)k2, s2.lds)})
+            if (kp.second > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(kp.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kp.second);
+                if (e != hipSuccess) return set_error((int)e, "grounding_loss: hipFuncSetAttribute(%zu): %s", kp.second, hipGetErrorString(e));
+            }
+        hipLaunchKernelGGL(k1, dim3(B, y1), dim3(kCeTileThreads), s1.lds, s, mV, (size_t)B * Q, (size_t)Q, B, Q, s1.cw, marg, aV, tmask, vmask,
+                           V, part);
+        hipLaunchKernelGGL(k2, dim3(B, y2), dim3(kCeTileThreads), s2.lds, s, mQ, (size_t)V, (size_t)B * V, B, V, s2.cw, vmask, aQ, vmask, tmask,
+                           Q, part2);
+    } else {
+        hipLaunchKernelGGL(ground_ce_kernel<float>, dim3(B, y1), dim3(kCeThreads), 0, s, mV, (size_t)B * Q, (size_t)Q, B, Q, marg, aV,
+                           tmask, vmask, V, part);
+        hipLaunchKernelGGL(ground_ce_kernel<uint8_t>, dim3(B, y2), dim3(kCeThreads), 0, s, mQ, (size_t)V, (size_t)B * V, B, V, vmask, aQ,
+                           vmask, tmask, Q, part2);
+    }
     hipLaunchKernelGGL(ground_sum_kernel, dim3(1), dim3(64), 0, s, part, part2, B * y1, B * y2, num_token, w_v2t, out_sums, coef);
     if ((g_txt || g_vis) && in_dtype == VLG_BF16 && d == kGdD && Q <= 96 && V <= 64 && !getenv("VLG_GROUND_SPARSE")) {
         // bf16 features at config-2 widths: the dense route on the matrix cores
