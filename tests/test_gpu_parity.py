@@ -794,6 +794,38 @@ def _ground_inputs(g, bf16=False):
     return txt, vis, pen, seg
 
 
+@pytest.mark.parametrize("B,L,V", [(1, 1, 1), (2, 5, 3), (3, 16, 16), (9, 24, 40), (10, 24, 41), (17, 40, 36), (31, 47, 64),
+                                   (32, 7, 48), (33, 40, 5), (70, 33, 37)])
+def test_grounding_dense_backward_shapes(oracle_mod, B, L, V):
+    """The matrix-core backward (bf16, d = 128, Q <= 96, V <= 64) against the fp64 oracle over the corners of its launch logic:
+    one pair, outer ranges that are not multiples of the staged chunk, split / unsplit outer loops (B < 32 runs unsplit), odd
+    halves, 5 vs 8 staged segments per feature row (V <= 40 / > 40), every row-tile count, rows whose positions collide
+    (argV[q] = v and argQ[v] = q happens for the best pair of every block)."""
+    from vlgae_amd import align
+    rng = np.random.default_rng(B * 977 + L * 31 + V)
+    Q, d = 2 * (L + 1), 128
+    lengths = rng.integers(max(1, L // 2), L + 1, B)
+    m1 = np.concatenate([np.zeros((B, 1), bool), np.arange(L)[None] < lengths[:, None]], 1)
+    tmask = np.concatenate([m1, m1], 1)
+    vmask = rng.random((B, V)) > 0.15
+    vmask[:, 0] = True
+    txt = torch.from_numpy((rng.standard_normal((B, Q, d)) * 0.4).astype(np.float32)).bfloat16()
+    vis = torch.from_numpy((rng.standard_normal((B, V, d)) * 0.4).astype(np.float32)).bfloat16()
+    marg = (rng.random((B, Q)) * tmask).astype(np.float32)
+    num = int(lengths.sum())
+    ref = oracle_mod.grounding_loss(txt.float().numpy(), vis.float().numpy(), tmask, vmask, marg, num, 1.0, dtype=np.float64)
+    tt, tv = txt.to(dev()).requires_grad_(True), vis.to(dev()).requires_grad_(True)
+    total, sums = align.grounding_loss_factor_ce(tt, tv, t(tmask), t(vmask), t(marg), num, 1.0)
+    s_ = sums.cpu().numpy()
+    assert abs(s_[0] - ref["txt2vis"]) <= 1e-4 * max(1.0, abs(ref["txt2vis"]))
+    assert abs(s_[1] - ref["vis2txt"]) <= 1e-4 * max(1.0, abs(ref["vis2txt"]))
+    g_txt, g_vis = torch.autograd.grad(total, [tt, tv])
+    for got, want in ((g_txt, ref["g_txt"]), (g_vis, ref["g_vis"])):
+        assert np.abs(got.float().cpu().numpy() - want).max() <= 1e-2 * max(1.0, np.abs(want).max())
+    # rows / regions that are masked out receive exactly zero
+    assert not g_txt.float().cpu().numpy()[~tmask].any() and not g_vis.float().cpu().numpy()[~vmask].any()
+
+
 @pytest.mark.parametrize("path", golden_files("ground_"), ids=golden_ids("ground_"))
 def test_grounding_loss_golden(oracle_mod, path):
     """vlg_grounding_loss vs the reference's own gather_logit_simple -> loss_grounding_factor_ce + autograd."""
