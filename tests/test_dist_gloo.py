@@ -90,8 +90,10 @@ def _run_bench(cmd, extra_env):
     env.pop("WORLD_SIZE", None)
     proc = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     assert proc.returncode == 0, proc.stderr[-3000:]
-    lines = [ln for ln in proc.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]   # gloo's own C++ chatter
-    assert len(lines) == 1, proc.stdout          # exactly ONE JSON line on stdout, from rank 0
+    # gloo's own C++ chatter ("[Gloo] Rank 0 is connected to ...") goes to stdout too, unsynchronised between the ranks
+    # (fragments of it can land on lines of their own): what must hold is exactly ONE JSON line, from rank 0
+    lines = [ln for ln in proc.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1 and proc.stdout.count('"metric"') == 1, proc.stdout
     return json.loads(lines[0])
 
 
