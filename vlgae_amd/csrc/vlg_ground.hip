@@ -609,25 +609,29 @@ typedef __attribute__((ext_vector_type(4))) float gd_f32x4;
 // NKC = Kp / 32 contraction chunks, MT = ceil(M / 16) row tiles.  Block = 4 waves tiling the [MT x 8] output tiles RW x CW
 // (a wave owns RT row tiles x CT column tiles: every A fragment it reads feeds CT MFMAs, every B fragment RT -- one row
 // tile per wave, round 2's first version, re-read the whole feature tile in every wave and was LDS-bound).
-template <int SIDE, int NKC, int MT, int RW, int SEGL>
+template <int SIDE, int NKC, int MT, int RW, int SEGL, int PP>
 __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
     const uint16_t* __restrict__ featT, const float* __restrict__ gV, const uint16_t* __restrict__ argV,
     const float* __restrict__ gQ, const uint16_t* __restrict__ argQ, const float* __restrict__ coef, int B, int Q, int V,
     float* __restrict__ out) {
-    // row pitch in bytes: +32 keeps the ds_read_b128 fragment reads (16 rows x 4 k-groups per instruction, serviced in the
+    // PP pairs per step, side by side along the contraction axis: one W [MR][PP * Kp] against one feature tile [d][PP * Kp],
+    // so that the per-step latencies (barriers, the dependent LDS chain of the W construction, the drain before the tile goes
+    // to LDS, fragment-read latency) are paid once per PP pairs -- the phases of a step do not overlap (ablations).
+    // Row pitch in bytes: +32 keeps the ds_read_b128 fragment reads (16 rows x 4 k-groups per instruction, serviced in the
     // hardware's four fixed 16-lane groups, MI355X_MICROARCH.md section LDS) free of bank conflicts; +16 costs 2x on every read
-    constexpr int Kp = NKC * 32, PITCH = Kp * 2 + 32, SEGS = Kp / 8;
+    constexpr int Kp = NKC * 32, KT = PP * Kp, PITCH = KT * 2 + 32, SEGS = Kp / 8;
     constexpr int MR = MT * 16, nthr = 256, CW = 4 / RW, RT = (MT + RW - 1) / RW, CT = 8 / CW;
     const int A = B, M = SIDE == 0 ? Q : V, K = SIDE == 0 ? V : Q;
     // the outer range is split over gridDim.y blocks (occupancy: one block per CU leaves the LDS / barrier latency exposed)
     const int o_per = (B + (int)gridDim.y - 1) / (int)gridDim.y, o_begin = blockIdx.y * o_per, O = min(B, o_begin + o_per);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    auto tile = [&](int buf) -> char* { return smem_raw + buf * (kGdD * PITCH); };           // other side's features, [d][Kp] bf16
-    char* wt = smem_raw + 2 * kGdD * PITCH;                                                   // W [MR][Kp] bf16
+    char* const tile = smem_raw;                                                              // other side's features, [d][KT] bf16
+    char* const wt = smem_raw + kGdD * PITCH;                                                 // W [MR][KT] bf16
     // the pairs' four small arrays, a chunk of kGdChunk pairs at a time (the next chunk waits in registers until the last
     // pair of this one has built its W):  [chunk][ argS[MR] | argO[Kp] ] int16  and  [chunk][ valS[MR] | valO[Kp] ] float,
     // the values already scaled by c1 / c2
     constexpr int EW = MR + Kp, CH = kGdChunk;
+    static_assert(CH % PP == 0, "a step's pairs come from one chunk");
     int16_t* sarg = reinterpret_cast<int16_t*>(wt + MR * PITCH);
     float* sval = reinterpret_cast<float*>(sarg + CH * EW);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -641,39 +645,46 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
     auto pair = [&](int o) -> size_t { return SIDE == 0 ? (size_t)fix * A + o : (size_t)o * A + fix; };
     if (o_begin >= O) return;
 
-    // W is built in LDS by scatter: thread t < M owns row t (one non-zero: column argself[t]), thread t < K owns column t
-    // (one non-zero: row argother[t]).  Where the two kinds meet -- row r points at column t AND column t points at row r --
-    // the column owner writes the sum and the row owner stays out (each sees the other's index in the staged arrays), so no
-    // element has two writers; each owner clears what it wrote for the previous pair, so the tile is never re-zeroed.
-    // (the feature tiles are zeroed too: only the 16-byte segments that hold contraction positions < K are ever staged,
+    // W is built in LDS by scatter: thread t < M owns row t (one non-zero per pair: column argself[t]), thread t < K owns
+    // column t (one non-zero: row argother[t]).  Where the two kinds meet -- row r points at column t AND column t points at
+    // row r -- the column owner writes the sum and the row owner stays out (each sees the other's index in the staged arrays),
+    // so no element has two writers; each owner clears what it wrote for the previous step, so the tile is never re-zeroed.
+    // (the feature tile is zeroed too: only the 16-byte segments that hold contraction positions < K are ever staged,
     //  the padding up to Kp stays zero)
-    for (int i = tid; i < (2 * kGdD + MR) * PITCH / 16; i += nthr) reinterpret_cast<uint4*>(smem_raw)[i] = make_uint4(0, 0, 0, 0);
-    constexpr int NV = (kGdD * SEGL + nthr - 1) / nthr;   // 16-byte vectors of the feature tile per thread
+    for (int i = tid; i < (kGdD + MR) * PITCH / 16; i += nthr) reinterpret_cast<uint4*>(smem_raw)[i] = make_uint4(0, 0, 0, 0);
+    constexpr int NV = (kGdD * SEGL + nthr - 1) / nthr;   // 16-byte vectors of one pair's feature tile per thread
     constexpr int segs = SEGL, nvec = kGdD * SEGL;         // segments per row that hold data (SEGL >= ceil(K / 8))
-    // One register set holds the NEXT pair's feature tile in flight: loaded (branch-free) right after the previous contents
+    // One register set holds the NEXT step's feature tiles in flight: loaded (branch-free) right after the previous contents
     // went to LDS, consumed one whole step later, and nothing younger is outstanding at that point, so the drain the compiler
     // puts there (s_waitcnt vmcnt(0): it does not count loads across the loop's back edge) costs nothing extra.
-    uint4 xs[NV];
+    uint4 xs[PP][NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) xs[j] = make_uint4(0, 0, 0, 0);   // (an uninitialised array that is written under a condition ends up in scratch)
-    auto stage_load = [&](int o, uint4* xs) __attribute__((always_inline)) {
-        const uint4* src = reinterpret_cast<const uint4*>(featT + (size_t)o * kGdD * Kp);
+    for (int q = 0; q < PP; ++q)
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int i = min(tid + j * nthr, nvec - 1);
-            const int row = i / segs, seg = i - row * segs;
-            xs[j] = src[row * SEGS + seg];
-        }
-    };
-    auto stage_tile = [&](int buf, const uint4* xs) __attribute__((always_inline)) {
+        for (int j = 0; j < NV; ++j) xs[q][j] = make_uint4(0, 0, 0, 0);   // (an array first written under a condition ends up in scratch)
+    auto stage_load = [&](int o, uint4 (*xs)[NV]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * nthr;
-            if (i < nvec) {
+        for (int q = 0; q < PP; ++q) {
+            const uint4* src = reinterpret_cast<const uint4*>(featT + (size_t)min(o + q, O - 1) * kGdD * Kp);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = min(tid + j * nthr, nvec - 1);
                 const int row = i / segs, seg = i - row * segs;
-                *reinterpret_cast<uint4*>(tile(buf) + row * PITCH + seg * 16) = xs[j];
+                xs[q][j] = src[row * SEGS + seg];
             }
         }
+    };
+    auto stage_tile = [&](const uint4 (*xs)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < PP; ++q)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = tid + j * nthr;
+                if (i < nvec) {
+                    const int row = i / segs, seg = i - row * segs;
+                    *reinterpret_cast<uint4*>(tile + row * PITCH + q * Kp * 2 + seg * 16) = xs[q][j];
+                }
+            }
     };
     // The small arrays come from HBM (each is read exactly once): a whole chunk of pairs is fetched with one burst of
     // independent loads (raw values only -- arithmetic here would make the wave wait for what it has just issued) while the
@@ -723,66 +734,93 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
     for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[r][c] = gd_f32x4{0.f, 0.f, 0.f, 0.f};
-    int ps_old = -1, po_old = -1;
+    int ps_old[PP], po_old[PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q) ps_old[q] = po_old[q] = -1;
     chunk_load(o_begin, carg, cval, cpar);
     stage_load(o_begin, xs);
     __syncthreads();                       // the zero fill above
     chunk_store(carg, cval, cpar);
-    stage_tile(0, xs);
-    stage_load(min(o_begin + 1, O - 1), xs);
+    stage_tile(xs);
+    stage_load(min(o_begin + PP, O - 1), xs);
     __syncthreads();
-    for (int o = o_begin; o < O; ++o) {
-        const int step = o - o_begin, buf = step & 1, cp = step % CH;
+    for (int o = o_begin; o < O; o += PP) {
+        const int cp = (o - o_begin) % CH;
         if (cp == 0 && o + CH < O) chunk_load(o + CH, carg, cval, cpar);   // the chunk after this one: in flight during this step
-        // ---- W of this pair: clear last pair's elements, write this pair's (same owner thread: program order) ----
+        // ---- W of this step: clear last step's elements, write this step's (same owner thread: program order) ----
         auto welem = [&](int row, int col) { return reinterpret_cast<uint16_t*>(wt + row * PITCH + col * 2); };
-        const int16_t* argS = sarg + cp * EW;
-        const int16_t* argO = argS + MR;
-        const float* valS = sval + cp * EW;
-        const float* valO = valS + MR;
-        // (an old element is left alone when ANOTHER thread writes this pair's value to the same place -- the column owner of
-        //  my old column pointing at my row, or the row owner of my old row pointing at my column -- since its write and my
-        //  clear are unordered; my own clear-then-write is program order, LDS operations of a wave complete in order)
 #ifndef VLG_GD_NOW
-        if (ps_old >= 0 && argO[ps_old] != tid) *welem(tid, ps_old) = 0;
-        if (po_old >= 0 && argS[po_old] != tid) *welem(po_old, tid) = 0;
-        const int my_s = tid < MR ? argS[tid] : -1, my_o = tid < Kp ? argO[tid] : -1;   // already -1 where invalid
-        const bool row_writes = my_s >= 0 && argO[my_s] != tid;   // else the column owner writes the sum
-        const bool col_writes = my_o >= 0;
-        if (row_writes) *welem(tid, my_s) = f2bf(valS[tid]);
-        if (col_writes) *welem(my_o, tid) = f2bf(valO[tid] + (argS[my_o] == tid ? valS[my_o] : 0.f));
-        ps_old = row_writes ? my_s : -1;
-        po_old = col_writes ? my_o : -1;
+        {
+            // every read of the staged arrays first (for all PP pairs: independent chains), then the clears and writes
+            bool clr_s[PP], clr_o[PP], row_w[PP], col_w[PP];
+            int my_s[PP], my_o[PP];
+            float vrow[PP], vcol[PP];
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                const bool live = o + q < O;             // the last step of an odd range has one pair: its second half only clears
+                const int16_t* argS = sarg + (cp + q) * EW;
+                const int16_t* argO = argS + MR;
+                const float* valS = sval + (cp + q) * EW;
+                const float* valO = valS + MR;
+                // (an old element is left alone when ANOTHER thread writes this step's value to the same place -- the column
+                //  owner of my old column pointing at my row, or the row owner of my old row pointing at my column -- since its
+                //  write and my clear are unordered; my own clear-then-write is program order, a wave's LDS operations complete
+                //  in order)
+                clr_s[q] = ps_old[q] >= 0 && !(live && argO[max(ps_old[q], 0)] == tid);
+                clr_o[q] = po_old[q] >= 0 && !(live && argS[max(po_old[q], 0)] == tid);
+                my_s[q] = live && tid < MR ? argS[tid] : -1;   // already -1 where invalid
+                my_o[q] = live && tid < Kp ? argO[tid] : -1;
+                row_w[q] = my_s[q] >= 0 && argO[max(my_s[q], 0)] != tid;   // else the column owner writes the sum
+                col_w[q] = my_o[q] >= 0;
+                vrow[q] = valS[min(tid, MR - 1)];
+                vcol[q] = valO[min(tid, Kp - 1)] + (argS[max(my_o[q], 0)] == tid ? valS[max(my_o[q], 0)] : 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                if (clr_s[q]) *welem(tid, q * Kp + ps_old[q]) = 0;
+                if (clr_o[q]) *welem(po_old[q], q * Kp + tid) = 0;
+                if (row_w[q]) *welem(tid, q * Kp + my_s[q]) = f2bf(vrow[q]);
+                if (col_w[q]) *welem(my_o[q], q * Kp + tid) = f2bf(vcol[q]);
+                ps_old[q] = row_w[q] ? my_s[q] : -1;
+                po_old[q] = col_w[q] ? my_o[q] : -1;
+            }
+        }
 #endif
-        __syncthreads();                                          // W(o) and tile(o) complete
+        __syncthreads();                                          // W and the tile of this step complete
         // Fragment reads are issued in batches ahead of their MFMAs (sched_barrier pins them there): left to itself hipcc
         // reuses ONE register quad for the B fragments -- read, wait lgkmcnt(0), MFMAs, next read -- which exposes a full
         // LDS latency per fragment.
 #ifndef VLG_GD_NOMFMA
+        {
+            constexpr int NK = PP * NKC;
+            gd_bf16x8 af[2][RT], bf[2][CT];   // two fragment sets: chunk kc+1 is read while chunk kc's MFMAs run
+            auto frags = [&](int kc, gd_bf16x8* a, gd_bf16x8* b) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            gd_bf16x8 af[RT], bf[CT];
+                for (int r = 0; r < RT; ++r)
+                    a[r] = *reinterpret_cast<const gd_bf16x8*>(wt + (min(rt0 + r, MT - 1) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
 #pragma unroll
-            for (int r = 0; r < RT; ++r)
-                af[r] = *reinterpret_cast<const gd_bf16x8*>(wt + (min(rt0 + r, MT - 1) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
+                for (int c = 0; c < CT; ++c)
+                    b[c] = *reinterpret_cast<const gd_bf16x8*>(tile + ((ct0 + c) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
+            };
+            frags(0, af[0], bf[0]);
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
-                bf[c] = *reinterpret_cast<const gd_bf16x8*>(tile(buf) + ((ct0 + c) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int kc = 0; kc < NK; ++kc) {
+                if (kc + 1 < NK) frags(kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < RT; ++r)
+                for (int r = 0; r < RT; ++r)
 #pragma unroll
-                for (int c = 0; c < CT; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r], bf[c], acc[r][c], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int c = 0; c < CT; ++c)
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kc & 1][r], bf[kc & 1][c], acc[r][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #endif
+        __syncthreads();                                          // every wave is done with the tile and W before they change
 #ifndef VLG_GD_NOSTAGE
-        stage_tile(buf ^ 1, xs);                                  // pair o+1 into the other buffer: last read in iteration o-1
-        if (cp == CH - 1 && o + 1 < O) chunk_store(carg, cval, cpar);   // this chunk's last W is built: its arrays make way
-        stage_load(min(o + 2, O - 1), xs);
-#endif
-#ifndef VLG_GD_NOBAR2
-        __syncthreads();                                          // every wave is done with W(o) before it is rewritten
+        stage_tile(xs);                                           // the next step's pairs
+        if (cp + PP == CH && o + PP < O) chunk_store(carg, cval, cpar);   // this chunk's last W is built: its arrays make way
+        stage_load(min(o + 2 * PP, O - 1), xs);
 #endif
     }
     // accumulator tile: lane l, register n <-> row 4 (l >> 4) + n, column l & 15
@@ -810,7 +848,10 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
     constexpr int KpV = 64, KpQ = 96;
     uint16_t* visT = scratch;                              // [B][128][64]
     uint16_t* txtT = scratch + (size_t)B * kGdD * KpV;     // [B][128][96]
-    auto lds = [](int Kp, int mt) { return (size_t)(2 * kGdD + mt * 16) * (Kp * 2 + 32) + (size_t)kGdChunk * (mt * 16 + Kp) * (2 + 4); };
+    constexpr int kPP = 2;   // pairs per step
+    auto lds = [](int Kp, int mt) {
+        return (size_t)(kGdD + mt * 16) * (kPP * Kp * 2 + 32) + (size_t)kGdChunk * (mt * 16 + Kp) * (2 + 4);
+    };
     int split = B >= 32 ? 2 : 1;   // two blocks per caption / image (two-addend atomics stay order-free)
     if (const char* e = getenv("VLG_GD_SPLIT")) split = atoi(e);
     if (split > 1) {
@@ -820,8 +861,15 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
         if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
 #define VLG_GD2(SIDEV, NKCV, MTV, RWV, SEGV, FT, OUT)                                                                  \
-    hipLaunchKernelGGL((ground_bwd_dense_kernel<SIDEV, NKCV, MTV, RWV, SEGV>), dim3(B, split), dim3(256), lds(NKCV * 32, MTV), s, FT, gV, \
-                       argV, gQ, argQ, coef, B, Q, V, OUT)
+    do {                                                                                                               \
+        auto kern = ground_bwd_dense_kernel<SIDEV, NKCV, MTV, RWV, SEGV, kPP>;                                         \
+        const size_t nb = lds(NKCV * 32, MTV);                                                                         \
+        if (nb > 64 * 1024) {                                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb); \
+            if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));            \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kern, dim3(B, split), dim3(256), nb, s, FT, gV, argV, gQ, argQ, coef, B, Q, V, OUT);         \
+    } while (0)
     // SEGL: 16-byte segments of a feature row that are staged; config-2's 36 regions need 5 of the 8
 #define VLG_GD(SIDEV, NKCV, MTV, RWV, FT, OUT)                                                                         \
     do {                                                                                                               \
