@@ -456,6 +456,36 @@ def test_deptree_vs_oracle_random(ts, oracle_mod, B, N, seed):
             assert np.array_equal(garc.detach().cpu().numpy(), ref_g.astype(np.float32))
 
 
+@pytest.mark.parametrize("B,N", [(256, 41), (24, 81)])
+def test_deptree_full_size_properties_and_reproducibility(ts, B, N):
+    """DepTree at the headline batch (and at the long-sentence width): arc marginals sum to one per word, the best tree's
+    score equals the Max-semiring value, and 20 launches give identical bits (the two directions of a span run on separate
+    wave halves and share T(i,j); a race between them would show up here)."""
+    from vlgae_amd.torch_struct import functional as F
+    g = torch.Generator().manual_seed(B + N)
+    arc = torch.randn(B, N, N, generator=g).to(dev())
+    lengths = torch.randint(1, N, (B,), generator=g)
+    lengths[0] = N - 1
+    lengths = lengths.to(dev())
+    lz, garc = F.deptree_run(arc, lengths, 0, True)
+    col = garc.sum(1)
+    inside = torch.arange(N, device=dev())[None] <= lengths[:, None]
+    inside[:, 0] = False
+    assert float((col[inside] - 1).abs().max()) <= 1e-4 and float(col[~inside].abs().max()) == 0.0
+    mz, marc = F.deptree_run(arc, lengths, 1, True)
+    best, heads = F.deptree_decode(arc, lengths)
+    assert torch.equal(best, mz)
+    score = (arc * marc).sum((1, 2))
+    assert float((score - mz).abs().max()) <= 1e-3
+    picked = torch.zeros_like(marc).scatter_(1, heads.unsqueeze(1), 1.0) * inside[:, None, :]    # marc[b, head[c], c] = 1
+    assert torch.equal(picked, marc)
+    for _ in range(20):
+        lz2, garc2 = F.deptree_run(arc, lengths, 0, True)
+        assert torch.equal(lz2, lz) and torch.equal(garc2, garc)
+        _, heads2 = F.deptree_decode(arc, lengths)
+        assert torch.equal(heads2, heads)
+
+
 # ------------------------------------------------------------------------------------------------ alignment
 @pytest.mark.parametrize("path", golden_files("align_"), ids=golden_ids("align_"))
 def test_bilinear_align_golden(path):
