@@ -581,22 +581,19 @@ static int launch_bwd(const void* txt, const void* vis, const float* gV, const u
 // =====================================================================================================
 constexpr int kGdD = 128, kGdChunk = 8;   // feature width; pairs per staged chunk of the small arrays
 
-// feat [O][K][128] bf16 -> featT [O][128][Kp] bf16 (zero-padded): block = one tensor o, LDS transpose in 32-row strips
+// feat [O][K][128] bf16 -> featT [O][128][Kp] bf16 (zero-padded): block = one 32-row strip of one tensor o, LDS transpose
 __global__ __launch_bounds__(256) void ground_transpose_kernel(const uint16_t* __restrict__ feat, int K, int Kp,
                                                                uint16_t* __restrict__ featT) {
     __shared__ uint16_t t[32][kGdD + 2];
-    const int o = blockIdx.x;
-    for (int k0 = 0; k0 < Kp; k0 += 32) {
-        for (int i = threadIdx.x; i < 32 * kGdD; i += 256) {
-            const int k = i / kGdD, c = i - k * kGdD;
-            t[k][c] = k0 + k < K ? feat[((size_t)o * K + k0 + k) * kGdD + c] : (uint16_t)0;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 32 * kGdD; i += 256) {
-            const int c = i >> 5, k = i & 31;
-            featT[((size_t)o * kGdD + c) * Kp + k0 + k] = t[k][c];
-        }
-        __syncthreads();
+    const int o = blockIdx.x, k0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < 32 * kGdD; i += 256) {
+        const int k = i / kGdD, c = i - k * kGdD;
+        t[k][c] = k0 + k < K ? feat[((size_t)o * K + k0 + k) * kGdD + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * kGdD; i += 256) {
+        const int c = i >> 5, k = i & 31;
+        featT[((size_t)o * kGdD + c) * Kp + k0 + k] = t[k][c];
     }
 }
 
@@ -613,17 +610,24 @@ template <int SIDE, int NKC, int MT, int RW, int SEGL, int PP>
 __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
     const uint16_t* __restrict__ featT, const float* __restrict__ gV, const uint16_t* __restrict__ argV,
     const float* __restrict__ gQ, const uint16_t* __restrict__ argQ, const float* __restrict__ coef, int B, int Q, int V,
-    float* __restrict__ out) {
-    // PP pairs per step, side by side along the contraction axis: one W [MR][PP * Kp] against one feature tile [d][PP * Kp],
+    int KT_total, int n_kc, size_t out_split_stride, float* __restrict__ out) {
+    // A "pair" below is one STEP UNIT: (outer index o, contraction chunk kc) -- with n_kc = 1 a caption x image pair, with more
+    // (the shipped 1369-column layout) one 128-position slice of it; blockIdx.z selects a chunk of MR output rows (image side
+    // of that layout: 1369 rows).  Positions outside this block's row chunk / this unit's contraction chunk are simply not
+    // elements of its W.  KT_total = row pitch of featT in elements (n_kc * Kp).
+    // PP units per step, side by side along the contraction axis: one W [MR][PP * Kp] against one feature tile [d][PP * Kp],
     // so that the per-step latencies (barriers, the dependent LDS chain of the W construction, the drain before the tile goes
     // to LDS, fragment-read latency) are paid once per PP pairs -- the phases of a step do not overlap (ablations).
     // Row pitch in bytes: +32 keeps the ds_read_b128 fragment reads (16 rows x 4 k-groups per instruction, serviced in the
     // hardware's four fixed 16-lane groups, MI355X_MICROARCH.md section LDS) free of bank conflicts; +16 costs 2x on every read
-    constexpr int Kp = NKC * 32, KT = PP * Kp, PITCH = KT * 2 + 32, SEGS = Kp / 8;
+    constexpr int Kp = NKC * 32, KT = PP * Kp, PITCH = KT * 2 + 32;
     constexpr int MR = MT * 16, nthr = 256, CW = 4 / RW, RT = (MT + RW - 1) / RW, CT = 8 / CW;
     const int A = B, M = SIDE == 0 ? Q : V, K = SIDE == 0 ? V : Q;
     // the outer range is split over gridDim.y blocks (occupancy: one block per CU leaves the LDS / barrier latency exposed)
-    const int o_per = (B + (int)gridDim.y - 1) / (int)gridDim.y, o_begin = blockIdx.y * o_per, O = min(B, o_begin + o_per);
+    // (from here on o counts step units: unit u <-> outer index u / n_kc, contraction chunk u % n_kc)
+    const int n_units = B * n_kc;
+    const int o_per = (n_units + (int)gridDim.y - 1) / (int)gridDim.y, o_begin = blockIdx.y * o_per, O = min(n_units, o_begin + o_per);
+    const int m0 = blockIdx.z * MR;                                                           // first output row of this block
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* const tile = smem_raw;                                                              // other side's features, [d][KT] bf16
     char* const wt = smem_raw + kGdD * PITCH;                                                 // W [MR][KT] bf16
@@ -642,8 +646,8 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
     const uint16_t* a_self = SIDE == 0 ? argV : argQ;
     const float* g_other = SIDE == 0 ? gQ : gV;
     const uint16_t* a_other = SIDE == 0 ? argQ : argV;
-    auto pair = [&](int o) -> size_t { return SIDE == 0 ? (size_t)fix * A + o : (size_t)o * A + fix; };
-    if (o_begin >= O) return;
+    auto pair = [&](int oo) -> size_t { return SIDE == 0 ? (size_t)fix * A + oo : (size_t)oo * A + fix; };
+    if (o_begin >= O || m0 >= M) return;
 
     // W is built in LDS by scatter: thread t < M owns row t (one non-zero per pair: column argself[t]), thread t < K owns
     // column t (one non-zero: row argother[t]).  Where the two kinds meet -- row r points at column t AND column t points at
@@ -665,12 +669,14 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
     auto stage_load = [&](int o, uint4 (*xs)[NV]) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < PP; ++q) {
-            const uint4* src = reinterpret_cast<const uint4*>(featT + (size_t)min(o + q, O - 1) * kGdD * Kp);
+            const int u = min(o + q, O - 1), oo = u / n_kc, kc = u - oo * n_kc;
+            const uint4* src = reinterpret_cast<const uint4*>(featT + ((size_t)oo * kGdD * KT_total + (size_t)kc * Kp));
+            const int rowv = KT_total >> 3;   // uint4 per feature row
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int i = min(tid + j * nthr, nvec - 1);
                 const int row = i / segs, seg = i - row * segs;
-                xs[q][j] = src[row * SEGS + seg];
+                xs[q][j] = src[row * rowv + seg];
             }
         }
     };
@@ -704,9 +710,10 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int id = min(tid + j * nthr, CH * EW - 1), p = id / EW, e = id - p * EW;
-            const size_t pr = pair(min(oc + p, O - 1));
+            const int u = min(oc + p, O - 1), oo = u / n_kc, k0 = (u - oo * n_kc) * Kp;
+            const size_t pr = pair(oo);
             const bool other = e >= MR;
-            const size_t at = other ? pr * K + min(e - MR, K - 1) : pr * M + min(e, M - 1);
+            const size_t at = other ? pr * K + min(k0 + e - MR, K - 1) : pr * M + min(m0 + e, M - 1);
             const uint32_t* ap = reinterpret_cast<const uint32_t*>(other ? a_other : a_self) + (at >> 1);
             const float* gp = (other ? g_other : g_self) + at;
             carg[j] = (int)*ap;
@@ -714,17 +721,22 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
             cpar |= ((unsigned)at & 1u) << j;
         }
     };
-    auto chunk_store = [=](const int* carg, const float* cval, unsigned cpar) __attribute__((always_inline)) {
+    auto chunk_store = [=](int oc, const int* carg, const float* cval, unsigned cpar) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int id = tid + j * nthr;
             if (id < CH * EW) {
                 const int p = id / EW, e = id - p * EW;
+                const int u = min(oc + p, O - 1), k0 = (u % n_kc) * Kp;
                 const bool other = e >= MR;
-                const int av = (carg[j] >> (((cpar >> j) & 1u) << 4)) & 0xffff;
-                const bool ok = other ? (e - MR < K && av < M) : (e < M && av < K);
+                // position relative to this block's row chunk / this unit's contraction chunk, -1 when it lies outside
+                const int av = ((carg[j] >> (((cpar >> j) & 1u) << 4)) & 0xffff) - (other ? m0 : k0);
+                const bool ok = other ? (k0 + e - MR < K && av >= 0 && av < MR && m0 + av < M)
+                                      : (m0 + e < M && av >= 0 && av < Kp && k0 + av < K);
                 sarg[id] = (int16_t)(ok ? av : -1);
-                sval[id] = (other ? c_other : c_self) * cval[j];
+                // (bit select, not `other ? c_other : c_self`: the compiler turns that into a two-entry table in scratch)
+                const unsigned pick = other ? ~0u : 0u;
+                sval[id] = __uint_as_float((__float_as_uint(c_other) & pick) | (__float_as_uint(c_self) & ~pick)) * cval[j];
             }
         }
     };
@@ -740,7 +752,7 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
     chunk_load(o_begin, carg, cval, cpar);
     stage_load(o_begin, xs);
     __syncthreads();                       // the zero fill above
-    chunk_store(carg, cval, cpar);
+    chunk_store(o_begin, carg, cval, cpar);
     stage_tile(xs);
     stage_load(min(o_begin + PP, O - 1), xs);
     __syncthreads();
@@ -819,7 +831,7 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
         __syncthreads();                                          // every wave is done with the tile and W before they change
 #ifndef VLG_GD_NOSTAGE
         stage_tile(xs);                                           // the next step's pairs
-        if (cp + PP == CH && o + PP < O) chunk_store(carg, cval, cpar);   // this chunk's last W is built: its arrays make way
+        if (cp + PP == CH && o + PP < O) chunk_store(o + PP, carg, cval, cpar);   // this chunk's last W is built: its arrays make way
         stage_load(min(o + 2 * PP, O - 1), xs);
 #endif
     }
@@ -829,12 +841,14 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
         if (rt0 + r >= MT) break;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int rr = (rt0 + r) * 16 + kg * 4 + n;
+            const int rr = m0 + (rt0 + r) * 16 + kg * 4 + n;
             if (rr < M) {
-                float* dst = out + ((size_t)fix * M + rr) * kGdD + ct0 * 16 + ccol;
+                // out_split_stride != 0: every split writes its own partial sum (ground_partial_sum_kernel adds them in a
+                // fixed order); else two partial sums meet in a zeroed output by atomics, which is order-free for two addends
+                float* dst = out + (size_t)blockIdx.y * out_split_stride + ((size_t)fix * M + rr) * kGdD + ct0 * 16 + ccol;
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
-                    if (gridDim.y > 1) atomicAdd(dst + c * 16, acc[r][c][n]);   // two partial sums into a zeroed output: order-free
+                    if (gridDim.y > 1 && out_split_stride == 0) atomicAdd(dst + c * 16, acc[r][c][n]);
                     else dst[c * 16] = acc[r][c][n];
                 }
             }
@@ -842,58 +856,102 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
     }
 }
 
+// splits of the caption side's step units over blockIdx.y for the wide layouts: enough blocks to cover the chip
+int ground_dense_split_txt(int B, int V) {
+    const int n_kc = (V + 127) / 128, n = n_kc * B;
+    int split = std::max(1, std::min(std::min(16, n / 8), (512 + B - 1) / B));
+    while (split > 1 && (split - 1) * ((n + split - 1) / split) >= n) --split;   // no empty share: every split writes its partial sum
+    return split;
+}
+
+// out[i] = part[0][i] + part[1][i] + ... in that order (the deeper splits of the wide layouts)
+__global__ __launch_bounds__(256) void ground_partial_sum_kernel(const float* __restrict__ part, int nsplit, size_t n4,
+                                                                 float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = reinterpret_cast<const float4*>(part)[i];
+    for (int k = 1; k < nsplit; ++k) {
+        const float4 b = reinterpret_cast<const float4*>(part)[(size_t)k * n4 + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+}
+
 static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, const uint16_t* argV, const float* gQ,
-                            const uint16_t* argQ, const float* coef, int B, int Q, int V, uint16_t* scratch, float* g_txt,
-                            float* g_vis, hipStream_t s) {
-    constexpr int KpV = 64, KpQ = 96;
-    uint16_t* visT = scratch;                              // [B][128][64]
-    uint16_t* txtT = scratch + (size_t)B * kGdD * KpV;     // [B][128][96]
-    constexpr int kPP = 2;   // pairs per step
-    auto lds = [](int Kp, int mt) {
-        return (size_t)(kGdD + mt * 16) * (kPP * Kp * 2 + 32) + (size_t)kGdChunk * (mt * 16 + Kp) * (2 + 4);
+                            const uint16_t* argQ, const float* coef, int B, int Q, int V, uint16_t* scratch, float* partial,
+                            float* g_txt, float* g_vis, hipStream_t s) {
+    // config-2 widths (V <= 64): one contraction chunk per pair, two pairs per step.  Wider region axes (the shipped layout's
+    // 1369 columns): caption side -- 128-position contraction chunks, one per step; image side -- 96-row output chunks in
+    // blockIdx.z, contraction over the <= 96 queries.
+    const bool wide = V > 64;
+    const int KpQ = 96, KtV = wide ? (V + 127) / 128 * 128 : 64;
+    uint16_t* visT = scratch;                              // [B][128][KtV]
+    uint16_t* txtT = scratch + (size_t)B * kGdD * KtV;     // [B][128][96]
+    auto lds = [](int Kp, int mt, int pp) {
+        return (size_t)(kGdD + mt * 16) * (pp * Kp * 2 + 32) + (size_t)kGdChunk * (mt * 16 + Kp) * (2 + 4);
     };
     int split = B >= 32 ? 2 : 1;   // two blocks per caption / image (two-addend atomics stay order-free)
     if (const char* e = getenv("VLG_GD_SPLIT")) split = atoi(e);
-    if (split > 1) {
+    // wide caption side: B blocks x split must cover the chip, and there are B * n_kc step units to share: deeper splits write
+    // partial sums (fixed-order reduce), not atomics
+    const int n_kc_v = KtV / 128;
+    int split_txt = split;
+    if (wide) split_txt = ground_dense_split_txt(B, V);
+    const bool part_txt = wide && split_txt > 2;
+    if (split > 1 || (split_txt > 1 && !part_txt)) {
         hipError_t e = hipSuccess;
-        if (g_txt) e = hipMemsetAsync(g_txt, 0, sizeof(float) * (size_t)B * Q * kGdD, s);
-        if (e == hipSuccess && g_vis) e = hipMemsetAsync(g_vis, 0, sizeof(float) * (size_t)B * V * kGdD, s);
+        if (g_txt && !part_txt && split_txt > 1) e = hipMemsetAsync(g_txt, 0, sizeof(float) * (size_t)B * Q * kGdD, s);
+        if (e == hipSuccess && g_vis && split > 1 && !wide) e = hipMemsetAsync(g_vis, 0, sizeof(float) * (size_t)B * V * kGdD, s);
         if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
-#define VLG_GD2(SIDEV, NKCV, MTV, RWV, SEGV, FT, OUT)                                                                  \
+#define VLG_GD2(SIDEV, NKCV, MTV, RWV, SEGV, PPV, GRID, KTOT, NKC_RT, STRIDE, FT, OUT)                                  \
     do {                                                                                                               \
-        auto kern = ground_bwd_dense_kernel<SIDEV, NKCV, MTV, RWV, SEGV, kPP>;                                         \
-        const size_t nb = lds(NKCV * 32, MTV);                                                                         \
+        auto kern = ground_bwd_dense_kernel<SIDEV, NKCV, MTV, RWV, SEGV, PPV>;                                         \
+        const size_t nb = lds(NKCV * 32, MTV, PPV);                                                                    \
         if (nb > 64 * 1024) {                                                                                          \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb); \
             if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));            \
         }                                                                                                              \
-        hipLaunchKernelGGL(kern, dim3(B, split), dim3(256), nb, s, FT, gV, argV, gQ, argQ, coef, B, Q, V, OUT);         \
+        hipLaunchKernelGGL(kern, GRID, dim3(256), nb, s, FT, gV, argV, gQ, argQ, coef, B, Q, V, KTOT, NKC_RT, (size_t)(STRIDE), OUT); \
     } while (0)
     // SEGL: 16-byte segments of a feature row that are staged; config-2's 36 regions need 5 of the 8
 #define VLG_GD(SIDEV, NKCV, MTV, RWV, FT, OUT)                                                                         \
     do {                                                                                                               \
-        if (SIDEV == 0 && V <= 40) VLG_GD2(SIDEV, NKCV, MTV, RWV, (SIDEV == 0 ? 5 : 12), FT, OUT);                      \
-        else VLG_GD2(SIDEV, NKCV, MTV, RWV, (SIDEV == 0 ? 8 : 12), FT, OUT);                                            \
+        if (SIDEV == 0 && V <= 40) VLG_GD2(SIDEV, NKCV, MTV, RWV, (SIDEV == 0 ? 5 : 12), 2, dim3(B, split), NKCV * 32, 1, 0, FT, OUT); \
+        else VLG_GD2(SIDEV, NKCV, MTV, RWV, (SIDEV == 0 ? 8 : 12), 2, dim3(B, split), NKCV * 32, 1, 0, FT, OUT);        \
     } while (0)
-    if (g_txt) {   // rows = queries (Q <= 96), contraction over regions (V <= 64)
-        hipLaunchKernelGGL(ground_transpose_kernel, dim3(B), dim3(256), 0, s, (const uint16_t*)vis, V, KpV, visT);
-        switch ((Q + 15) / 16) {
-            case 1: VLG_GD(0, 2, 1, 1, visT, g_txt); break;
-            case 2: VLG_GD(0, 2, 2, 2, visT, g_txt); break;
-            case 3: VLG_GD(0, 2, 3, 1, visT, g_txt); break;
-            case 4: VLG_GD(0, 2, 4, 2, visT, g_txt); break;
-            case 5: VLG_GD(0, 2, 5, 2, visT, g_txt); break;
-            default: VLG_GD(0, 2, 6, 2, visT, g_txt); break;
+    if (g_txt) {   // rows = queries (Q <= 96), contraction over regions
+        hipLaunchKernelGGL(ground_transpose_kernel, dim3(B, KtV / 32), dim3(256), 0, s, (const uint16_t*)vis, V, KtV, visT);
+        if (wide) {
+            float* dst = part_txt ? partial : g_txt;
+            VLG_GD2(0, 4, 6, 2, 16, 1, dim3(B, split_txt), KtV, n_kc_v, part_txt ? (size_t)B * Q * kGdD : 0, visT, dst);
+            if (part_txt) {
+                const size_t n4 = (size_t)B * Q * kGdD / 4;
+                hipLaunchKernelGGL(ground_partial_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, partial, split_txt, n4,
+                                   g_txt);
+            }
+        } else {
+            switch ((Q + 15) / 16) {
+                case 1: VLG_GD(0, 2, 1, 1, visT, g_txt); break;
+                case 2: VLG_GD(0, 2, 2, 2, visT, g_txt); break;
+                case 3: VLG_GD(0, 2, 3, 1, visT, g_txt); break;
+                case 4: VLG_GD(0, 2, 4, 2, visT, g_txt); break;
+                case 5: VLG_GD(0, 2, 5, 2, visT, g_txt); break;
+                default: VLG_GD(0, 2, 6, 2, visT, g_txt); break;
+            }
         }
     }
-    if (g_vis) {   // rows = regions (V <= 64), contraction over queries (Q <= 96)
-        hipLaunchKernelGGL(ground_transpose_kernel, dim3(B), dim3(256), 0, s, (const uint16_t*)txt, Q, KpQ, txtT);
-        switch ((V + 15) / 16) {
-            case 1: VLG_GD(1, 3, 1, 1, txtT, g_vis); break;
-            case 2: VLG_GD(1, 3, 2, 2, txtT, g_vis); break;
-            case 3: VLG_GD(1, 3, 3, 1, txtT, g_vis); break;
-            default: VLG_GD(1, 3, 4, 2, txtT, g_vis); break;
+    if (g_vis) {   // rows = regions, contraction over queries (Q <= 96)
+        hipLaunchKernelGGL(ground_transpose_kernel, dim3(B, KpQ / 32), dim3(256), 0, s, (const uint16_t*)txt, Q, KpQ, txtT);
+        if (wide) {
+            VLG_GD2(1, 3, 6, 2, 12, 1, dim3(B, 1, (V + 95) / 96), KpQ, 1, 0, txtT, g_vis);   // one pair per step: two blocks fit a CU's LDS
+        } else {
+            switch ((V + 15) / 16) {
+                case 1: VLG_GD(1, 3, 1, 1, txtT, g_vis); break;
+                case 2: VLG_GD(1, 3, 2, 2, txtT, g_vis); break;
+                case 3: VLG_GD(1, 3, 3, 1, txtT, g_vis); break;
+                default: VLG_GD(1, 3, 4, 2, txtT, g_vis); break;
+            }
         }
     }
 #undef VLG_GD
@@ -978,9 +1036,14 @@ GroundPlan::GroundPlan(int B, int Q, int V) {
     off_coef = off_part + up(2 * (size_t)B * kCeMaxY);
     off_argV = off_coef + 64;                          // uint16 arrays, offsets still counted in floats
     off_argQ = off_argV + up((nV + 1) / 2);
-    off_featT = off_argQ + up((nQ + 1) / 2);           // dense backward: transposed bf16 features [B][128][64] + [B][128][96]
-    const bool dense = Q <= 96 && V <= 64;
-    bytes = sizeof(float) * (off_featT + (dense ? up((size_t)B * 128 * (64 + 96) / 2) : 0));
+    // dense backward (bf16, Q <= 96): transposed bf16 features [B][128][KtV] + [B][128][96], and for the wide layouts (V > 64)
+    // the caption side's partial sums [split][B][Q][128] fp32
+    off_featT = off_argQ + up((nQ + 1) / 2);
+    const bool dense = Q <= 96;
+    const size_t KtV = V > 64 ? (size_t)(V + 127) / 128 * 128 : 64;
+    off_partial = off_featT + (dense ? up((size_t)B * 128 * (KtV + 96) / 2) : 0);
+    const size_t partial = dense && V > 64 ? (size_t)ground_dense_split_txt(B, V) * B * Q * 128 : 0;
+    bytes = sizeof(float) * (off_partial + up(partial));
 }
 
 int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marg,
@@ -1030,10 +1093,10 @@ int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask
                            vmask, tmask, Q, part2);
     }
     hipLaunchKernelGGL(ground_sum_kernel, dim3(1), dim3(64), 0, s, part, part2, B * y1, B * y2, num_token, w_v2t, out_sums, coef);
-    if ((g_txt || g_vis) && in_dtype == VLG_BF16 && d == kGdD && Q <= 96 && V <= 64 && !getenv("VLG_GROUND_SPARSE")) {
-        // bf16 features at config-2 widths: the dense route on the matrix cores
-        if (int rc = launch_bwd_dense(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, reinterpret_cast<uint16_t*>(ws + p.off_featT), g_txt,
-                                      g_vis, s))
+    if ((g_txt || g_vis) && in_dtype == VLG_BF16 && d == kGdD && Q <= 96 && V <= 65535 && !getenv("VLG_GROUND_SPARSE")) {
+        // bf16 features, d = 128, up to 96 queries: the dense route on the matrix cores
+        if (int rc = launch_bwd_dense(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, reinterpret_cast<uint16_t*>(ws + p.off_featT),
+                                      ws + p.off_partial, g_txt, g_vis, s))
             return rc;
     } else if (g_txt || g_vis) {
         const int rc = in_dtype == VLG_F32 ? launch_bwd<F32In>(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, d, g_txt, g_vis, s, w_v2t > 0.f)
