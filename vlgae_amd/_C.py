@@ -31,7 +31,8 @@ SIGNATURES = {
     "vlg_dmv1o_count_sum": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "vlg_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vlg_bilinear_align": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
-    "vlg_bilinear_align_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "vlg_bilinear_align_backward_workspace": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "vlg_bilinear_align_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "vlg_grounding_loss_workspace": (_sz, [_i, _i, _i]),
     "vlg_grounding_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _sz, _vp, _vp,
                                 _vp, _vp]),

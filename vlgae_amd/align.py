@@ -78,7 +78,8 @@ def bilinear_align_backward(grad_out, txt_feat, vis_feat, txt_mask=None, vis_mas
     """Gradients of `bilinear_align(...)["full"]` w.r.t. both feature tensors for the cotangent grad_out [B,A,Q,V] (what
     autograd derives for joint.py:413-418; masked positions pass no gradient).  Returns (g_txt [B,Q,d], g_vis [A,V,d]) in
     float32 (None where not wanted).  One HIP kernel per gradient reads the cotangent in place -- no permuted, masked or
-    up-cast copies of it -- on the fp32 matrix cores; there is no library-GEMM / eager fallback."""
+    up-cast copies of it -- on the matrix cores (bf16 features at config-2 widths: the cotangent split into two bf16 terms;
+    otherwise fp32 MFMA); there is no library-GEMM / eager fallback."""
     txt_feat, vis_feat, txt_mask, vis_mask = _plain(txt_feat), _plain(vis_feat), _plain(txt_mask), _plain(vis_mask)
     _C.require_gpu(txt_feat, "bilinear_align_backward")
     B, Q, d = txt_feat.shape
@@ -93,13 +94,15 @@ def bilinear_align_backward(grad_out, txt_feat, vis_feat, txt_mask=None, vis_mas
     vis_c = vis_feat.detach().to(txt_c.dtype).contiguous()
     tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
     vm = None if vis_mask is None else vis_mask.to(device=dev, dtype=torch.uint8).contiguous()
-    g_txt = torch.empty((B, Q, d), dtype=torch.float32, device=dev) if want_txt else None
-    g_vis = torch.empty((A, V, d), dtype=torch.float32, device=dev) if want_vis else None
     if want_txt or want_vis:
+        nbytes = _C.lib().vlg_bilinear_align_backward_workspace(B, A, Q, V, d, dt)
+        (g_txt, g_vis), ws = _C.alloc_f32(dev, ((B, Q, d) if want_txt else None, (A, V, d) if want_vis else None), nbytes)
         _C.check(_C.lib().vlg_bilinear_align_backward(_C.ptr(g), _C.ptr(txt_c), _C.ptr(vis_c), _C.ptr(tm), _C.ptr(vm), B, A, Q, V,
-                                                      d, dt, _C.ptr(g_txt), _C.ptr(g_vis), _C.stream_of(txt_c)),
+                                                      d, dt, _C.ptr(ws) if nbytes else None, nbytes, _C.ptr(g_txt), _C.ptr(g_vis),
+                                                      _C.stream_of(txt_c)),
                  "bilinear_align_backward")
-    return g_txt, g_vis
+        return g_txt, g_vis
+    return None, None
 
 
 def gather_logit(inputs, vis, txt, vp=None):

@@ -895,6 +895,195 @@ static int launch_align_mfma(const void* txt, const void* vis, const uint8_t* tm
     return check_launch("align_mfma_kernel");
 }
 
+// =====================================================================================================
+// The same adjoint on the bf16 matrix cores (bf16 features, d = 128, rows and contraction length <= 96 per pair -- config-2).
+// The fp32 MFMA above runs at 1/16 of the bf16 rate and made the kernel compute-bound (2.2 ms for a 774 MB cotangent).  Here
+// the fp32 cotangent is split on the fly into NT bf16 terms, g = t0 + t1 (+ t2), t0 = bf16(g), t1 = bf16(g - t0), ...; the
+// features are bf16 already, every product t_i * x is exact in the fp32 accumulator, and what is dropped is below
+// 2^-17 |g| (NT = 2) / 2^-25 |g| (NT = 3: fp32's own rounding level).  The kernel then waits on HBM, not on the matrix cores.
+//   A operand: the cotangent tile of one (fix, o) pair, straight from global memory in fragment order (a lane's 8 contraction
+//     positions are contiguous for the caption side; 8 strided words for the image side), raw fp32 in registers for one
+//     step, converted right before use;
+//   B operand: the other side's features, contraction-major ([o][128][Kp] bf16 scratch, zero where the contraction mask is
+//     off), one tile per step through LDS (double-buffered), shared by the block's four waves, which tile the [MT x 8]
+//     output tiles RW x CW.
+// One barrier per step: at the top of step o everything that was in flight (cotangent of o, features of o+1) is consumed --
+// converted / written to the other LDS buffer -- and the next loads are issued before the MFMAs of step o start.
+// =====================================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 ab_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float ab_f32x4;
+
+// feat [O][K][128] bf16 -> featT [O][128][Kp] bf16, zero where mask[o][k] == 0 or k >= K: block = one 32-position strip
+__global__ __launch_bounds__(256) void align_bwd_transpose_kernel(const uint16_t* __restrict__ feat, const uint8_t* __restrict__ mask,
+                                                                  int K, int Kp, uint16_t* __restrict__ featT) {
+    __shared__ uint16_t t[32][128 + 2];
+    const int o = blockIdx.x, k0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < 32 * 128; i += 256) {
+        const int k = i >> 7, c = i & 127;
+        const bool on = k0 + k < K && (!mask || mask[(size_t)o * K + k0 + k]);
+        t[k][c] = on ? feat[((size_t)o * K + k0 + k) * 128 + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 128; i += 256) {
+        const int c = i >> 5, k = i & 31;
+        featT[((size_t)o * 128 + c) * Kp + k0 + k] = t[k][c];
+    }
+}
+
+// MT row tiles x CW column groups = 6 waves: each cotangent row tile is loaded by CW waves only (it is the HBM stream; the
+// features sit in LDS, where re-reading them per wave is cheap)
+template <bool KCONTIG, int NKC, int MT, int CW, int NT>
+__global__ __launch_bounds__(384) void align_bwd_split_kernel(const float* __restrict__ g, const uint16_t* __restrict__ featT,
+                                                              const uint8_t* __restrict__ rmask, int O, int M, int K, long so,
+                                                              long sr, long sk, long sfix, int o_per, float* __restrict__ out,
+                                                              int atomic) {
+    constexpr int Kp = NKC * 32, PITCH = Kp * 2 + 32, SEGS = Kp / 8;   // +32: conflict-free ds_read_b128 fragment reads
+    static_assert(MT * CW == 6, "six waves");
+    constexpr int RT = 1, CT = 8 / CW, nthr = 384;
+    constexpr int NV = (128 * SEGS + nthr - 1) / nthr;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, ccol = lane & 15;
+    const int fix = blockIdx.x, o_begin = blockIdx.y * o_per, o_end = min(O, o_begin + o_per);
+    const int rt0 = (wave / CW) * RT, ct0 = (wave % CW) * CT;
+    if (o_begin >= o_end) return;
+    const float* gfix = g + (size_t)fix * sfix;
+    // ---- raw loads (no arithmetic on the results until the next step: see ground_bwd_dense_kernel) ----
+    uint4 xs[NV];
+    float graw[RT][NKC][8];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) xs[j] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) graw[r][kc][j] = 0.f;
+    auto load_tile = [=](int o, uint4* xs) __attribute__((always_inline)) {
+        const uint4* src = reinterpret_cast<const uint4*>(featT + (size_t)min(o, O - 1) * 128 * Kp);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) xs[j] = src[min(tid + j * nthr, 128 * SEGS - 1)];
+    };
+    auto store_tile = [=](int buf, const uint4* xs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * nthr;
+            if (i < 128 * SEGS) {
+                const int row = i / SEGS, seg = i - row * SEGS;
+                *reinterpret_cast<uint4*>(smem_raw + (buf * 128 + row) * PITCH + seg * 16) = xs[j];
+            }
+        }
+    };
+    const bool k_quads = (K & 3) == 0 && K >= 4;
+    auto load_g = [=](int o, float (*graw)[NKC][8]) __attribute__((always_inline)) {
+        const float* go = gfix + (size_t)min(o, O - 1) * so;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int row = min((rt0 + r) * 16 + ccol, M - 1);   // rows past M are computed on a copy of the last row and dropped
+            const float* gr = go + (size_t)row * sr;
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) {
+                const int k0 = kc * 32 + kg * 8;
+                if (KCONTIG) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ks = k0 + 4 * h;
+                        if (k_quads) {   // K % 4 == 0 (block-uniform): every quad is whole or empty -- branch-free, the empty
+                                         // ones re-read the row's last quad and are zeroed at conversion
+                            const float4 v = *reinterpret_cast<const float4*>(gr + min(ks, K - 4));   // 4-byte aligned is enough
+                            graw[r][kc][4 * h + 0] = v.x; graw[r][kc][4 * h + 1] = v.y;
+                            graw[r][kc][4 * h + 2] = v.z; graw[r][kc][4 * h + 3] = v.w;
+                        } else {         // clamped words (the excess is zeroed at conversion)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) graw[r][kc][4 * h + j] = gr[min(ks + j, K - 1)];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) graw[r][kc][j] = gr[(size_t)min(k0 + j, K - 1) * sk];
+                }
+            }
+        }
+    };
+    ab_f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = ab_f32x4{0.f, 0.f, 0.f, 0.f};
+    // zero both tile buffers once (pitch padding is never written again), then the prologue: tile(o_begin) in place, tile
+    // (o_begin + 1) and the cotangent of o_begin in flight
+    for (int i = tid; i < 2 * 128 * PITCH / 16; i += nthr) reinterpret_cast<uint4*>(smem_raw)[i] = make_uint4(0, 0, 0, 0);
+    load_tile(o_begin, xs);
+    __syncthreads();
+    store_tile(0, xs);
+    load_g(o_begin, graw);
+    load_tile(o_begin + 1, xs);
+    __syncthreads();
+    // one step: everything below is unconditional (indices clamped, a step past the end multiplies zeros), so that the compiler
+    // can count the loads that stay in flight across the consumption of the older ones
+    auto step = [&](int o, float (*gr)[NKC][8]) __attribute__((always_inline)) {
+        const int buf = (o - o_begin) & 1;
+        const bool real = o < o_end;
+        // ---- consume: cotangent of o -> bf16 terms, features of o+1 -> the other buffer; reissue both ----
+        ab_bf16x8 af[NT][RT][NKC];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = real && kc * 32 + kg * 8 + j < K ? gr[r][kc][j] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const __bf16 h = (__bf16)v;
+                        af[t][r][kc][j] = h;
+                        v -= (float)h;
+                    }
+                }
+        store_tile(buf ^ 1, xs);
+        load_g(o + 1, gr);
+        load_tile(o + 2, xs);
+        // ---- MFMAs of pair o ----
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            ab_bf16x8 bf[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                bf[c] = *reinterpret_cast<const ab_bf16x8*>(smem_raw + (buf * 128 + (ct0 + c) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][r][kc], bf[c], acc[r][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    // (a second cotangent set, loaded two steps ahead, was measured: no faster -- the step is bound by instruction issue, not
+    //  by the latency of these loads -- and costs 16-24 VGPRs)
+    for (int o = o_begin; o < o_end; ++o) step(o, graw);
+    // accumulator tile: lane l, register n <-> row 4 (l >> 4) + n, column l & 15
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        if (rt0 + r >= MT) break;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int rr = (rt0 + r) * 16 + kg * 4 + n;
+            if (rr < M) {
+                const float keep = !rmask || rmask[(size_t)fix * M + rr] ? 1.f : 0.f;
+                float* dst = out + ((size_t)fix * M + rr) * 128 + ct0 * 16 + ccol;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (atomic) atomicAdd(dst + c * 16, keep * acc[r][c][n]);
+                    else dst[c * 16] = keep * acc[r][c][n];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace vlg
 
 extern "C" {
@@ -976,16 +1165,70 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
     return check_launch("align_kernel");
 }
 
+// bf16 features, d = 128, at most 96 rows and 96 contraction positions per pair: the split-term path on the bf16 matrix cores
+static bool bwd_split_ok(int in_dtype, int d, int M, int K) { return in_dtype == VLG_BF16 && d == 128 && M <= 96 && K <= 96; }
+
+size_t vlg_bilinear_align_backward_workspace(int B, int A, int Q, int V, int d, int in_dtype) {
+    if (B < 1 || A < 1 || Q < 1 || V < 1) return 0;
+    size_t n = 0;
+    if (bwd_split_ok(in_dtype, d, Q, V)) n += (size_t)A * 128 * ((V + 31) / 32 * 32);   // caption side: vis, contraction-major
+    if (bwd_split_ok(in_dtype, d, V, Q)) n += (size_t)B * 128 * ((Q + 31) / 32 * 32);   // image side: txt
+    return n * 2;
+}
+
 int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask,
-                                int B, int A, int Q, int V, int d, int in_dtype, float* grad_txt, float* grad_vis, void* stream) {
+                                int B, int A, int Q, int V, int d, int in_dtype, void* ws, size_t ws_bytes, float* grad_txt,
+                                float* grad_vis, void* stream) {
     using namespace vlg;
     if (B < 1 || A < 1 || Q < 1 || V < 1) return set_error(VLG_ERR_SHAPE, "bilinear_align_backward: bad shape B=%d A=%d Q=%d V=%d", B, A, Q, V);
     if (d != 128 && d != 64 && d != 32) return set_error(VLG_ERR_SHAPE, "bilinear_align_backward: d=%d (supported: 32, 64, 128)", d);
     if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "bilinear_align_backward: in_dtype %d", in_dtype);
     if (!grad_out || !txt || !vis || (!grad_txt && !grad_vis)) return set_error(VLG_ERR_ARG, "bilinear_align_backward: null buffer");
     if (B > 65535 || A > 65535) return set_error(VLG_ERR_SHAPE, "bilinear_align_backward: B=%d A=%d exceed grid.y", B, A);
+    const size_t need = vlg_bilinear_align_backward_workspace(B, A, Q, V, d, in_dtype);
+    if (need && (!ws || ws_bytes < need))
+        return set_error(VLG_ERR_WORKSPACE, "bilinear_align_backward: workspace %zu bytes, need %zu (vlg_bilinear_align_backward_workspace)",
+                         ws_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = in_dtype == VLG_F32 ? 4 : 2;
+    // ---- split-term path: the cotangent as bf16 terms against contraction-major bf16 features ----
+    // terms of the fp32 -> bf16 split of the cotangent: two keep 16 significant bits (relative error < 2^-17 per product, far
+    // below the bf16 rounding the features -- and the gradients autograd hands back to bf16 leaves -- already carry); a third
+    // term (fp32's own rounding level) costs half as many MFMAs and conversions again: 0.56 vs 0.45 ms on the caption side
+    constexpr int kNT = 2;
+    auto go_split = [&](const void* feat, const uint8_t* km, const uint8_t* rm, int fixn, int O, int M, int K, long so, long sr,
+                        long sk, long sfix, bool kcontig, uint16_t* featT, float* out) -> int {
+        const int Kp = (K + 31) / 32 * 32, nkc = Kp / 32;
+        hipLaunchKernelGGL(align_bwd_transpose_kernel, dim3(O, Kp / 32), dim3(256), 0, s, (const uint16_t*)feat, km, K, Kp, featT);
+        int split = 1;   // two blocks per CU at least; two-addend atomics are order-free
+        if ((long)fixn * 2 <= 1024 && O >= 16) split = 2;
+        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e);
+        const int opb = (O + split - 1) / split;
+        if (split > 1) {
+            hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)fixn * M * 128, s);
+            if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        const size_t lds = 2 * (size_t)128 * (Kp * 2 + 32);
+#define VLG_BS(KC, NKCV, MTV, CWV)                                                                                      \
+        do {                                                                                                            \
+            auto k = align_bwd_split_kernel<KC, NKCV, MTV, CWV, kNT>;                                                   \
+            if (lds > 64 * 1024) {                                                                                      \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));         \
+            }                                                                                                           \
+            hipLaunchKernelGGL(k, dim3(fixn, split), dim3(384), lds, s, grad_out, featT, rm, O, M, K, so, sr, sk, sfix, opb, out,  \
+                               split > 1 ? 1 : 0);                                                                      \
+        } while (0)
+#define VLG_BS2(KC, NKCV)                                                                                               \
+        do { if (M <= 48) VLG_BS(KC, NKCV, 3, 2); else VLG_BS(KC, NKCV, 6, 1); } while (0)
+#define VLG_BS3(KC)                                                                                                     \
+        do { if (nkc == 1) VLG_BS2(KC, 1); else if (nkc == 2) VLG_BS2(KC, 2); else VLG_BS2(KC, 3); } while (0)
+        if (kcontig) VLG_BS3(true); else VLG_BS3(false);
+#undef VLG_BS3
+#undef VLG_BS2
+#undef VLG_BS
+        return check_launch("align_bwd_split_kernel");
+    };
     auto go = [&](const void* feat, const uint8_t* km, const uint8_t* rm, int fixn, int O, int M, int K, long so, long sr, long sk,
                   long sfix, float* out) -> int {
         // k-steps per chunk from a small compile-time set (extra steps multiply zeros): 9 <-> V = 36, 21 <-> Q = 82
@@ -1025,12 +1268,21 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
         return check_launch("align_bwd_kernel");
     };
     const long QV = (long)Q * V;
-    if (grad_txt)   // rows q of caption b; outer a, contraction v:  g[((b A + a) Q + q) V + v]
-        if (int rc = go(vis, vmask, tmask, B, A, Q, V, QV, V, 1, (long)A * QV, grad_txt)) return rc;
-    if (grad_vis)   // rows v of image a; outer b, contraction q
-        if (int rc = go(txt, tmask, vmask, A, B, V, Q, (long)A * QV, 1, V, QV, grad_vis)) return rc;
+    uint16_t* visT = reinterpret_cast<uint16_t*>(ws);
+    uint16_t* txtT = visT + (bwd_split_ok(in_dtype, d, Q, V) ? (size_t)A * 128 * ((V + 31) / 32 * 32) : 0);
+    if (grad_txt) {   // rows q of caption b; outer a, contraction v:  g[((b A + a) Q + q) V + v]
+        const int rc = bwd_split_ok(in_dtype, d, Q, V) ? go_split(vis, vmask, tmask, B, A, Q, V, QV, V, 1, (long)A * QV, true, visT, grad_txt)
+                                                       : go(vis, vmask, tmask, B, A, Q, V, QV, V, 1, (long)A * QV, grad_txt);
+        if (rc) return rc;
+    }
+    if (grad_vis) {   // rows v of image a; outer b, contraction q
+        const int rc = bwd_split_ok(in_dtype, d, V, Q) ? go_split(txt, tmask, vmask, A, B, V, Q, (long)A * QV, 1, V, QV, false, txtT, grad_vis)
+                                                       : go(txt, tmask, vmask, A, B, V, Q, (long)A * QV, 1, V, QV, grad_vis);
+        if (rc) return rc;
+    }
     return 0;
 }
+
 
 size_t vlg_grounding_loss_workspace(int B, int Q, int V) {
     if (B < 1 || Q < 1 || V < 1) return 0;
