@@ -933,7 +933,9 @@ __global__ __launch_bounds__(256) void align_bwd_transpose_kernel(const uint16_t
 // MT row tiles x CW column groups = 6 waves: each cotangent row tile is loaded by CW waves only (it is the HBM stream; the
 // features sit in LDS, where re-reading them per wave is cheap)
 template <bool KCONTIG, int NKC, int MT, int CW, int NT>
-__global__ __launch_bounds__(384) void align_bwd_split_kernel(const float* __restrict__ g, const uint16_t* __restrict__ featT,
+// (three waves per SIMD = two resident blocks per CU: the second block's work is what hides the first one's load latency)
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) void align_bwd_split_kernel(
+    const float* __restrict__ g, const uint16_t* __restrict__ featT,
                                                               const uint8_t* __restrict__ rmask, int O, int M, int K, long so,
                                                               long sr, long sk, long sfix, int o_per, float* __restrict__ out,
                                                               int atomic) {
