@@ -176,6 +176,17 @@ def _run_all(out, args, h, dev):
             "mfma_busy": mfma_busy("align_mfma_kernel<TILE> (full tensor)" if full else "align_max_kernel") if in_dtype == torch.bfloat16 else None,
             "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in (2048-d / 768-d features through fixed-seed Linear->128), fp32 out"}
 
+    # ---- backward of the materialised tensor (what autograd runs when the reference's own loss consumes gather_logit_simple's
+    #      [B,A,Q,V] output): both feature gradients, each kernel reads the 4 B * B*A*Q*V cotangent once ----
+    cot = torch.randn(B, B, Q, V, generator=torch.Generator(device=dev).manual_seed(7), device=dev)
+    sec = _events(lambda: align.bilinear_align_backward(cot, txt, vis), 20, 3, dev)
+    byts = 2.0 * cot.numel() * 4
+    out["align_backward"] = {"ms": sec * 1e3, "GB/s": byts / sec / 1e9, "frac_hbm": byts / sec / 1e9 / HBM_PEAK_GBS,
+                             "TFLOP/s": 2 * 2.0 * B * B * Q * V * d / sec / 1e12,
+                             "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} features, fp32 cotangent [B,A,Q,V] "
+                                      f"({cot.numel() * 4 / 1e6:.0f} MB, read twice: once per gradient)"}
+    del cot
+
     # the two consumers on the training path: attention-fuse (joint.py:670-674) and the grounding loss on the
     # fused maxima (joint.py:439-491), forward + gradients, through the host API
     hdim = 256
