@@ -1086,6 +1086,142 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     }
 }
 
+// Caption side with a short, quad-aligned contraction (K % 4 == 0, 2 K <= 96 -- config-2's 36 regions): TWO pairs per step,
+// their contraction ranges side by side in one 96-wide fragment set (72 of 96 positions live instead of 36 of 64).  The kernel
+// above is bound by the bytes it keeps in flight (a wave waits a full loaded-HBM latency per step for 2.3 KB of cotangent);
+// this doubles them and drops a quarter of the MFMAs.  The features come from a scratch that is concatenated along the
+// contraction axis over ALL outer indices, featC [128][O K (+ padding)], so that a step's tile is 16-byte-aligned rows of it.
+__global__ __launch_bounds__(256) void align_bwd_concat_transpose_kernel(const uint16_t* __restrict__ feat, const uint8_t* __restrict__ mask,
+                                                                         int OK, long pitch, uint16_t* __restrict__ featC) {
+    __shared__ uint16_t t[32][128 + 2];
+    const int k0 = blockIdx.x * 32;   // position in the concatenated axis (o K + k)
+    for (int i = threadIdx.x; i < 32 * 128; i += 256) {
+        const int k = i >> 7, c = i & 127;
+        const bool on = k0 + k < OK && (!mask || mask[k0 + k]);
+        t[k][c] = on ? feat[(size_t)(k0 + k) * 128 + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 128; i += 256) {
+        const int c = i >> 5, k = i & 31;
+        if (k0 + k < pitch) featC[(size_t)c * pitch + k0 + k] = t[k][c];
+    }
+}
+
+template <int MT, int CW, int NT>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) void align_bwd_split2_kernel(
+    const float* __restrict__ g, const uint16_t* __restrict__ featC, long pitchC, const uint8_t* __restrict__ rmask, int O, int M,
+    int K, long so, long sr, long sfix, int o_per, float* __restrict__ out, int atomic) {
+    constexpr int NKC = 3, Kp = 96, PITCH = Kp * 2 + 32, SEGS = Kp / 8;
+    static_assert(MT * CW == 6, "six waves");
+    constexpr int CT = 8 / CW, nthr = 384, NV = (128 * SEGS + nthr - 1) / nthr;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, ccol = lane & 15;
+    const int fix = blockIdx.x, o_begin = blockIdx.y * o_per, o_end = min(O, o_begin + o_per);   // o_per is even
+    const int rt = wave / CW, ct0 = (wave % CW) * CT;
+    if (o_begin >= o_end) return;
+    const float* gfix = g + (size_t)fix * sfix;
+    const int row = min(rt * 16 + ccol, M - 1);   // rows past M are computed on a copy of the last row and dropped
+    uint4 xs[NV];
+    float graw[NKC][8];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) xs[j] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) graw[kc][j] = 0.f;
+    auto load_tile = [=](int o, uint4* xs) __attribute__((always_inline)) {   // columns o K ... o K + 95 of every feature row
+        const uint16_t* src = featC + (size_t)min(o, O - 1) * K;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = min(tid + j * nthr, 128 * SEGS - 1), r = i / SEGS, seg = i - r * SEGS;
+            xs[j] = *reinterpret_cast<const uint4*>(src + (size_t)r * pitchC + seg * 8);
+        }
+    };
+    auto store_tile = [=](int buf, const uint4* xs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * nthr;
+            if (i < 128 * SEGS) {
+                const int r = i / SEGS, seg = i - r * SEGS;
+                *reinterpret_cast<uint4*>(smem_raw + (buf * 128 + r) * PITCH + seg * 16) = xs[j];
+            }
+        }
+    };
+    // quad q of the concatenated axis (positions 4q .. 4q+3) lies in pair 4q / K at column 4q % K; quads past 2 K re-read
+    // the first one and are zeroed at conversion (branch-free: nothing here depends on a loaded value)
+    auto load_g = [=](int o, float (*graw)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kk = kc * 32 + kg * 8 + 4 * h;
+                const int p = kk >= K ? 1 : 0, v = kk < 2 * K ? kk - p * K : 0;
+                const float* gr = gfix + (size_t)min(o + (kk < 2 * K ? p : 0), O - 1) * so + (size_t)row * sr + v;
+                const float4 q = *reinterpret_cast<const float4*>(gr);   // 4-byte aligned is enough
+                graw[kc][4 * h + 0] = q.x; graw[kc][4 * h + 1] = q.y; graw[kc][4 * h + 2] = q.z; graw[kc][4 * h + 3] = q.w;
+            }
+    };
+    ab_f32x4 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = ab_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 2 * 128 * PITCH / 16; i += nthr) reinterpret_cast<uint4*>(smem_raw)[i] = make_uint4(0, 0, 0, 0);
+    load_tile(o_begin, xs);
+    __syncthreads();
+    store_tile(0, xs);
+    load_g(o_begin, graw);
+    load_tile(o_begin + 2, xs);
+    __syncthreads();
+    for (int o = o_begin; o < o_end; o += 2) {
+        const int buf = ((o - o_begin) >> 1) & 1;
+        const bool second = o + 1 < o_end;
+        // ---- consume: cotangents of (o, o+1) -> bf16 terms, features of the next step -> the other buffer; reissue both ----
+        ab_bf16x8 af[NT][NKC];
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = kc * 32 + kg * 8 + j;
+                float v = kk < K || (kk < 2 * K && second) ? graw[kc][j] : 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const __bf16 h = (__bf16)v;
+                    af[t][kc][j] = h;
+                    v -= (float)h;
+                }
+            }
+        store_tile(buf ^ 1, xs);
+        load_g(o + 2, graw);
+        load_tile(o + 4, xs);
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            ab_bf16x8 bf[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                bf[c] = *reinterpret_cast<const ab_bf16x8*>(smem_raw + (buf * 128 + (ct0 + c) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][kc], bf[c], acc[c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int rr = rt * 16 + kg * 4 + n;
+        if (rr < M) {
+            const float keep = !rmask || rmask[(size_t)fix * M + rr] ? 1.f : 0.f;
+            float* dst = out + ((size_t)fix * M + rr) * 128 + ct0 * 16 + ccol;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (atomic) atomicAdd(dst + c * 16, keep * acc[c][n]);
+                else dst[c * 16] = keep * acc[c][n];
+            }
+        }
+    }
+}
+
 }  // namespace vlg
 
 extern "C" {
@@ -1170,10 +1306,15 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
 // bf16 features, d = 128, at most 96 rows and 96 contraction positions per pair: the split-term path on the bf16 matrix cores
 static bool bwd_split_ok(int in_dtype, int d, int M, int K) { return in_dtype == VLG_BF16 && d == 128 && M <= 96 && K <= 96; }
 
+// caption side, two pairs per step on one concatenated scratch: short quad-aligned contraction
+static bool bwd_concat_ok(int K) { return (K & 3) == 0 && K >= 4 && 2 * K <= 96 && !getenv("VLG_BWD_NOCONCAT"); }
+static size_t bwd_concat_pitch(int O, int K) { return ((size_t)O * K + 96 + 7) / 8 * 8; }
+
 size_t vlg_bilinear_align_backward_workspace(int B, int A, int Q, int V, int d, int in_dtype) {
     if (B < 1 || A < 1 || Q < 1 || V < 1) return 0;
     size_t n = 0;
-    if (bwd_split_ok(in_dtype, d, Q, V)) n += (size_t)A * 128 * ((V + 31) / 32 * 32);   // caption side: vis, contraction-major
+    if (bwd_split_ok(in_dtype, d, Q, V))   // caption side: vis, contraction-major (concatenated over the images when V is short)
+        n += bwd_concat_ok(V) ? (size_t)128 * bwd_concat_pitch(A, V) : (size_t)A * 128 * ((V + 31) / 32 * 32);
     if (bwd_split_ok(in_dtype, d, V, Q)) n += (size_t)B * 128 * ((Q + 31) / 32 * 32);   // image side: txt
     return n * 2;
 }
@@ -1271,8 +1412,29 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
     };
     const long QV = (long)Q * V;
     uint16_t* visT = reinterpret_cast<uint16_t*>(ws);
-    uint16_t* txtT = visT + (bwd_split_ok(in_dtype, d, Q, V) ? (size_t)A * 128 * ((V + 31) / 32 * 32) : 0);
-    if (grad_txt) {   // rows q of caption b; outer a, contraction v:  g[((b A + a) Q + q) V + v]
+    const bool concat = bwd_split_ok(in_dtype, d, Q, V) && bwd_concat_ok(V);
+    uint16_t* txtT = visT + (!bwd_split_ok(in_dtype, d, Q, V) ? 0 : concat ? (size_t)128 * bwd_concat_pitch(A, V)
+                                                                            : (size_t)A * 128 * ((V + 31) / 32 * 32));
+    if (grad_txt && concat) {   // two images per step, their 2 V <= 96 positions side by side
+        const long pitch = (long)bwd_concat_pitch(A, V);
+        hipLaunchKernelGGL(align_bwd_concat_transpose_kernel, dim3((unsigned)((pitch + 31) / 32)), dim3(256), 0, s, (const uint16_t*)vis,
+                           vmask, A * V, pitch, visT);
+        int split = ((long)B * 2 <= 1024 && A >= 16) ? 2 : 1;
+        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e);
+        const int opb = ((A + split - 1) / split + 1) & ~1;   // even: a step's tile rows start on 16-byte boundaries of featC
+        if (split > 1) {
+            hipError_t e = hipMemsetAsync(grad_txt, 0, sizeof(float) * (size_t)B * Q * 128, s);
+            if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        const size_t lds = 2 * (size_t)128 * (96 * 2 + 32);
+        if (Q <= 48)
+            hipLaunchKernelGGL((align_bwd_split2_kernel<3, 2, kNT>), dim3(B, split), dim3(384), lds, s, grad_out, visT, pitch, tmask, A, Q, V,
+                               QV, (long)V, (long)A * QV, opb, grad_txt, split > 1 ? 1 : 0);
+        else
+            hipLaunchKernelGGL((align_bwd_split2_kernel<6, 1, kNT>), dim3(B, split), dim3(384), lds, s, grad_out, visT, pitch, tmask, A, Q, V,
+                               QV, (long)V, (long)A * QV, opb, grad_txt, split > 1 ? 1 : 0);
+        if (int rc = check_launch("align_bwd_split2_kernel")) return rc;
+    } else if (grad_txt) {   // rows q of caption b; outer a, contraction v:  g[((b A + a) Q + q) V + v]
         const int rc = bwd_split_ok(in_dtype, d, Q, V) ? go_split(vis, vmask, tmask, B, A, Q, V, QV, V, 1, (long)A * QV, true, visT, grad_txt)
                                                        : go(vis, vmask, tmask, B, A, Q, V, QV, V, 1, (long)A * QV, grad_txt);
         if (rc) return rc;
