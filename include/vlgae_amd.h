@@ -296,7 +296,7 @@ int vlg_selftest_xlane(int* scratch, void* stream);
 /* Thread-local message for the last non-zero return on this thread ("" if none). */
 const char* vlg_last_error(void);
 
-/* Library / ABI version, e.g. 100 = 0.1.0. */
+/* Library / ABI version, e.g. 110 = 0.1.1 (round 2: vlg_bilinear_align_backward takes a workspace; vlg_scale_counts, vlg_feed_* added). */
 int vlg_version(void);
 
 #ifdef __cplusplus
