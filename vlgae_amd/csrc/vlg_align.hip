@@ -940,8 +940,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                                                               long sr, long sk, long sfix, int o_per, float* __restrict__ out,
                                                               int atomic) {
     constexpr int Kp = NKC * 32, PITCH = Kp * 2 + 32, SEGS = Kp / 8;   // +32: conflict-free ds_read_b128 fragment reads
-    static_assert(MT * CW == 6, "six waves");
-    constexpr int RT = 1, CT = 8 / CW, nthr = 384;
+    static_assert(MT * CW == 6 || MT * CW == 3, "six waves, or three when every cotangent element is to be loaded once");
+    constexpr int RT = 1, CT = 8 / CW, nthr = 64 * MT * CW;
     constexpr int NV = (128 * SEGS + nthr - 1) / nthr;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, ccol = lane & 15;
@@ -975,36 +975,51 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             }
         }
     };
+    // lane offsets into one pair's cotangent block, computed once (32-bit: a pair's block is small); per step only the
+    // block-uniform base pointer moves, so a load costs no vector arithmetic
     const bool k_quads = (K & 3) == 0 && K >= 4;
-    auto load_g = [=](int o, float (*graw)[NKC][8]) __attribute__((always_inline)) {
-        const float* go = gfix + (size_t)min(o, O - 1) * so;
+    unsigned goff[RT][NKC][KCONTIG ? 2 : 8];   // BYTE offsets, unsigned: scalar base + zero-extended 32-bit vector offset is an addressing mode
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const int row = min((rt0 + r) * 16 + ccol, M - 1);   // rows past M are computed on a copy of the last row and dropped
-            const float* gr = go + (size_t)row * sr;
+    for (int r = 0; r < RT; ++r) {
+        const int row = min((rt0 + r) * 16 + ccol, M - 1);   // rows past M are computed on a copy of the last row and dropped
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int k0 = kc * 32 + kg * 8;
+            if (KCONTIG) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) goff[r][kc][h] = 4u * (unsigned)(row * (int)sr + min(k0 + 4 * h, k_quads ? K - 4 : K - 1));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) goff[r][kc][KCONTIG ? 0 : j] = 4u * (unsigned)(row * (int)sr + min(k0 + j, K - 1) * (int)sk);
+            }
+        }
+    }
+    auto load_g = [&](int o, float (*graw)[NKC][8]) __attribute__((always_inline)) {
+        const char* go = reinterpret_cast<const char*>(gfix + (size_t)min(o, O - 1) * so);   // block-uniform
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
 #pragma unroll
             for (int kc = 0; kc < NKC; ++kc) {
-                const int k0 = kc * 32 + kg * 8;
                 if (KCONTIG) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const int ks = k0 + 4 * h;
-                        if (k_quads) {   // K % 4 == 0 (block-uniform): every quad is whole or empty -- branch-free, the empty
-                                         // ones re-read the row's last quad and are zeroed at conversion
-                            const float4 v = *reinterpret_cast<const float4*>(gr + min(ks, K - 4));   // 4-byte aligned is enough
+                        if (k_quads) {   // K % 4 == 0 (block-uniform): every quad is whole or empty; the empty ones re-read the
+                                         // row's last quad and meet zero feature columns
+                            const float4 v = *reinterpret_cast<const float4*>(go + goff[r][kc][h]);   // 4-byte aligned is enough
                             graw[r][kc][4 * h + 0] = v.x; graw[r][kc][4 * h + 1] = v.y;
                             graw[r][kc][4 * h + 2] = v.z; graw[r][kc][4 * h + 3] = v.w;
-                        } else {         // clamped words (the excess is zeroed at conversion)
+                        } else {         // clamped words
+                            const int k0 = kc * 32 + kg * 8 + 4 * h;
+                            const unsigned base = goff[r][kc][h] - 4u * (unsigned)min(k0, K - 1);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) graw[r][kc][4 * h + j] = gr[min(ks + j, K - 1)];
+                            for (int j = 0; j < 4; ++j) graw[r][kc][4 * h + j] = *reinterpret_cast<const float*>(go + base + 4u * (unsigned)min(k0 + j, K - 1));
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) graw[r][kc][j] = gr[(size_t)min(k0 + j, K - 1) * sk];
+                    for (int j = 0; j < 8; ++j) graw[r][kc][j] = *reinterpret_cast<const float*>(go + goff[r][kc][KCONTIG ? 0 : j]);
                 }
             }
-        }
     };
     ab_f32x4 acc[RT][CT];
 #pragma unroll
@@ -1033,7 +1048,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float v = real && kc * 32 + kg * 8 + j < K ? gr[r][kc][j] : 0.f;
+                    // (positions past K hold a clamped, finite cotangent value and meet zero feature columns: no select)
+                    float v = real ? gr[r][kc][j] : 0.f;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const __bf16 h = (__bf16)v;
@@ -1148,16 +1164,26 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
     };
     // quad q of the concatenated axis (positions 4q .. 4q+3) lies in pair 4q / K at column 4q % K; quads past 2 K re-read
-    // the first one and are zeroed at conversion (branch-free: nothing here depends on a loaded value)
-    auto load_g = [=](int o, float (*graw)[8]) __attribute__((always_inline)) {
+    // the first one and are zeroed at conversion.  Byte offsets from the step's (block-uniform) base pointer are computed once;
+    // the second pair's quads add one pair stride (zero when the range ends on an odd pair).
+    unsigned goff[NKC][2];
+    bool gsec[NKC][2];
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kk = kc * 32 + kg * 8 + 4 * h;
+            gsec[kc][h] = kk >= K && kk < 2 * K;
+            goff[kc][h] = 4u * (unsigned)(row * (int)sr + (kk < 2 * K ? kk - (kk >= K ? K : 0) : 0));
+        }
+    auto load_g = [&](int o, float (*graw)[8]) __attribute__((always_inline)) {
+        const char* go = reinterpret_cast<const char*>(gfix + (size_t)min(o, O - 1) * so);
+        const unsigned step2 = o + 1 < O ? 4u * (unsigned)so : 0u;
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int kk = kc * 32 + kg * 8 + 4 * h;
-                const int p = kk >= K ? 1 : 0, v = kk < 2 * K ? kk - p * K : 0;
-                const float* gr = gfix + (size_t)min(o + (kk < 2 * K ? p : 0), O - 1) * so + (size_t)row * sr + v;
-                const float4 q = *reinterpret_cast<const float4*>(gr);   // 4-byte aligned is enough
+                const float4 q = *reinterpret_cast<const float4*>(go + goff[kc][h] + (gsec[kc][h] ? step2 : 0u));   // 4-byte aligned is enough
                 graw[kc][4 * h + 0] = q.x; graw[kc][4 * h + 1] = q.y; graw[kc][4 * h + 2] = q.z; graw[kc][4 * h + 3] = q.w;
             }
     };
@@ -1339,6 +1365,7 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
     // below the bf16 rounding the features -- and the gradients autograd hands back to bf16 leaves -- already carry); a third
     // term (fp32's own rounding level) costs half as many MFMAs and conversions again: 0.56 vs 0.45 ms on the caption side
     constexpr int kNT = 2;
+    constexpr int kCW3 = 2;   // column groups for <= 48 rows (1 = three-wave blocks that load every cotangent element once: 2x slower, too few waves per CU)
     auto go_split = [&](const void* feat, const uint8_t* km, const uint8_t* rm, int fixn, int O, int M, int K, long so, long sr,
                         long sk, long sfix, bool kcontig, uint16_t* featT, float* out) -> int {
         const int Kp = (K + 31) / 32 * 32, nkc = Kp / 32;
@@ -1359,11 +1386,11 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                 if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));         \
             }                                                                                                           \
-            hipLaunchKernelGGL(k, dim3(fixn, split), dim3(384), lds, s, grad_out, featT, rm, O, M, K, so, sr, sk, sfix, opb, out,  \
+            hipLaunchKernelGGL(k, dim3(fixn, split), dim3(64 * MTV * CWV), lds, s, grad_out, featT, rm, O, M, K, so, sr, sk, sfix, opb, out,  \
                                split > 1 ? 1 : 0);                                                                      \
         } while (0)
 #define VLG_BS2(KC, NKCV)                                                                                               \
-        do { if (M <= 48) VLG_BS(KC, NKCV, 3, 2); else VLG_BS(KC, NKCV, 6, 1); } while (0)
+        do { if (M <= 48) VLG_BS(KC, NKCV, 3, kCW3); else VLG_BS(KC, NKCV, 6, 1); } while (0)
 #define VLG_BS3(KC)                                                                                                     \
         do { if (nkc == 1) VLG_BS2(KC, 1); else if (nkc == 2) VLG_BS2(KC, 2); else VLG_BS2(KC, 3); } while (0)
         if (kcontig) VLG_BS3(true); else VLG_BS3(false);
