@@ -395,8 +395,8 @@ VLG_HD void dmv_fw_all(const DmvCtx& c, int tid, int nt, X& x) {
 // All loads -- including the read half of every read-modify-write -- are issued before the first store, so
 // nothing waits on an earlier store of the same phase.
 // ------------------------------------------------------------------------------------------------
-template <int SR, int DIR, int TU, typename X>
-VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x) {
+template <int SR, int DIR, int TU, typename X, bool CHUNKED = false>
+VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x, int nchunk = 1) {
     const int P = c.P, DW = D + VLG_MUL24(w, P);
     const float* Cf = reinterpret_cast<const float*>(c.C);
     float* gCif = reinterpret_cast<float*>(c.gCi);
@@ -424,42 +424,61 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
     const float su = Cf[2 * (eU + VLG_MUL24(selfr, P)) + 1];   // CL(i,i).NC | CR(j,j).NC
     const float2 sv = c.I[eV + selfr];                          // IL(j,i) | IR(i,j): this span's own incomplete value
     if (TU > 0) {
-        float uu[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1], xb[TU > 0 ? TU : 1], o_c[TU > 0 ? TU : 1], o_ga[TU > 0 ? TU : 1],
-            o_gb[TU > 0 ? TU : 1], w0[TU > 0 ? TU : 1], w1[TU > 0 ? TU : 1];
-        float2 vv[TU > 0 ? TU : 1], o_gi[TU > 0 ? TU : 1];
-#pragma unroll
-        for (int u = 0; u < TU; ++u) {
-            const int r = rr + u * G, rc = r < w ? r : w - 1, rP = VLG_MUL24(rc, P);
-            uu[u] = Cf[2 * (eU + rP) + 1];
-            vv[u] = c.I[eV + rc];
-            xa[u] = Cf[eA + 2 * rc];
-            xb[u] = Cf[eB + 2 * rc];
-            o_gi[u] = c.gI[eV + rc];
-            o_c[u] = c.gCc[eU + rP];
-            o_ga[u] = gCif[eA + 2 * rc];
-            o_gb[u] = gCif[eB + 2 * rc];
+        // nchunk > 1 (long sentences: more than 4 split points per lane): the split-point range is walked in chunks of TU per
+        // lane, each chunk with all of its loads ahead of its stores -- one memory round trip per chunk, where a loop over
+        // single split points pays one per split point (with the value charts in the workspace that round trip is an L2
+        // access: the generic loop below made the outside pass at L = 80 twice as long as the inside pass).
+        float2 gi = make_float2(0.f, 0.f);
+        float gs = 0.f;
+        if (CHUNKED) {   // needed by every chunk: ahead of the loop (the one-chunk instantiation keeps it behind its loads, below)
+            self[0] = adj_w<SR>(gc.x, su + sv.x, oc.x, selfr, b0);
+            self[1] = adj_w<SR>(gc.y, su + sv.y, oc.y, selfr, b1);
+            gi = make_float2(gi_old.x + self[0], gi_old.y + self[1]);   // complete adjoint of IL(j,i) | IR(i,j)
+            gs = gi.x + gi.y;
         }
+        for (int ch = 0; ch < (CHUNKED ? nchunk : 1); ++ch) {
+            const int r0 = rr + ch * (TU * G);
+            float uu[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1], xb[TU > 0 ? TU : 1], o_c[TU > 0 ? TU : 1], o_ga[TU > 0 ? TU : 1],
+                o_gb[TU > 0 ? TU : 1], w0[TU > 0 ? TU : 1], w1[TU > 0 ? TU : 1];
+            float2 vv[TU > 0 ? TU : 1], o_gi[TU > 0 ? TU : 1];
 #pragma unroll
-        for (int u = 0; u < TU; ++u) {
-            const int r = rr + u * G;
-            const bool ok = r < w;
-            w0[u] = ok ? adj_w<SR>(gc.x, uu[u] + vv[u].x, oc.x, r, b0) : 0.f;
-            w1[u] = ok ? adj_w<SR>(gc.y, uu[u] + vv[u].y, oc.y, r, b1) : 0.f;
-        }
-        self[0] = adj_w<SR>(gc.x, su + sv.x, oc.x, selfr, b0);
-        self[1] = adj_w<SR>(gc.y, su + sv.y, oc.y, selfr, b1);
-        x.lockstep();   // the lanes of a group sit in one wavefront: every load above precedes every store below
-        const float2 gi = make_float2(gi_old.x + self[0], gi_old.y + self[1]);   // complete adjoint of IL(j,i) | IR(i,j)
-        const float gs = gi.x + gi.y;
+            for (int u = 0; u < TU; ++u) {
+                const int r = r0 + u * G, rc = r < w ? r : w - 1, rP = VLG_MUL24(rc, P);
+                uu[u] = Cf[2 * (eU + rP) + 1];
+                vv[u] = c.I[eV + rc];
+                xa[u] = Cf[eA + 2 * rc];
+                xb[u] = Cf[eB + 2 * rc];
+                o_gi[u] = c.gI[eV + rc];
+                o_c[u] = c.gCc[eU + rP];
+                o_ga[u] = gCif[eA + 2 * rc];
+                o_gb[u] = gCif[eB + 2 * rc];
+            }
 #pragma unroll
-        for (int u = 0; u < TU; ++u) {
-            const int r = rr + u * G;
-            if (live && r < w) {
-                const float ws = adj_w<SR>(gs, xa[u] + xb[u], Sv, r, bs);
-                if (r != selfr) c.gI[eV + r] = make_float2(o_gi[u].x + w0[u], o_gi[u].y + w1[u]);
-                c.gCc[eU + VLG_MUL24(r, P)] = o_c[u] + (w0[u] + w1[u]);
-                gCif[eA + 2 * r] = o_ga[u] + ws;
-                gCif[eB + 2 * r] = o_gb[u] + ws;
+            for (int u = 0; u < TU; ++u) {
+                const int r = r0 + u * G;
+                const bool ok = r < w;
+                w0[u] = ok ? adj_w<SR>(gc.x, uu[u] + vv[u].x, oc.x, r, b0) : 0.f;
+                w1[u] = ok ? adj_w<SR>(gc.y, uu[u] + vv[u].y, oc.y, r, b1) : 0.f;
+            }
+            if (!CHUNKED) {
+                self[0] = adj_w<SR>(gc.x, su + sv.x, oc.x, selfr, b0);
+                self[1] = adj_w<SR>(gc.y, su + sv.y, oc.y, selfr, b1);
+            }
+            x.lockstep();   // the lanes of a group sit in one wavefront: every load above precedes every store below
+            if (!CHUNKED) {
+                gi = make_float2(gi_old.x + self[0], gi_old.y + self[1]);
+                gs = gi.x + gi.y;
+            }
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int r = r0 + u * G;
+                if (live && r < w) {
+                    const float ws = adj_w<SR>(gs, xa[u] + xb[u], Sv, r, bs);
+                    if (r != selfr) c.gI[eV + r] = make_float2(o_gi[u].x + w0[u], o_gi[u].y + w1[u]);
+                    c.gCc[eU + VLG_MUL24(r, P)] = o_c[u] + (w0[u] + w1[u]);
+                    gCif[eA + 2 * r] = o_ga[u] + ws;
+                    gCif[eB + 2 * r] = o_gb[u] + ws;
+                }
             }
         }
         if (live && rr == 0) c.gI[kO] = gi;   // == d logZ / d attach[j,i,:] | attach[i,j,:]
@@ -503,7 +522,7 @@ VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x) {
         else if (T == 2) dmv_bw_span<SR, DIR, 2>(c, w, G, D, live, rr, x);
         else if (T == 3) dmv_bw_span<SR, DIR, 3>(c, w, G, D, live, rr, x);
         else if (T == 4) dmv_bw_span<SR, DIR, 4>(c, w, G, D, live, rr, x);
-        else dmv_bw_span<SR, DIR, 0>(c, w, G, D, live, rr, x);
+        else dmv_bw_span<SR, DIR, 4, X, true>(c, w, G, D, live, rr, x, (T + 3) >> 2);   // chunks of four split points per lane
     }
 }
 
@@ -682,7 +701,7 @@ VLG_HD float dep_self(const DepCtx& c, int D, int w, int dir) {
 // Outside, one span, one direction: DIR 0 scatters CL(j,i)'s adjoint (-> IL(j,i+r), CL(i+r,i)) and T's into the CR(i,.)
 // operands; DIR 1 scatters CR(i,j)'s (-> IR(i,i+1+r), CR(i+1+r,j)) and T's into the CL(j,.) operands.
 template <int SR, int DIR, int TU, typename X>
-VLG_HD void dep_bw_span(const DepCtx& c, int w, int G, int D, bool live, int rr, X& x) {
+VLG_HD void dep_bw_span(const DepCtx& c, int w, int G, int D, bool live, int rr, X& x, int nchunk = 1) {
     const int P = c.P, DW = D + VLG_MUL24(w, P);
     const int eU = DIR == 0 ? D : D + P + w + 1;      // CL(i+r, i) | CR(i+1+r, j)   (stride P)
     const int eV = DIR == 0 ? DW : D + 2;             // IL(j, i+r) | IR(i, i+1+r)
@@ -694,29 +713,33 @@ VLG_HD void dep_bw_span(const DepCtx& c, int w, int G, int D, bool live, int rr,
     const float oc = c.C[kO], Tv = c.S[D + w];
     const float gs = live ? c.gI[DW] + c.gI[D + w + 1] + dep_self<SR>(c, D, w, 0) + dep_self<SR>(c, D, w, 1) : 0.f;
     if (TU > 0) {
-        float uu[TU > 0 ? TU : 1], vv[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1], xb[TU > 0 ? TU : 1];
-        float o_gi[TU > 0 ? TU : 1], o_c[TU > 0 ? TU : 1], o_g[TU > 0 ? TU : 1];
+        // nchunk > 1: chunks of TU split points per lane, each with its loads ahead of its stores (see dmv_bw_span)
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int r0 = rr + ch * (TU * G);
+            float uu[TU > 0 ? TU : 1], vv[TU > 0 ? TU : 1], xa[TU > 0 ? TU : 1], xb[TU > 0 ? TU : 1];
+            float o_gi[TU > 0 ? TU : 1], o_c[TU > 0 ? TU : 1], o_g[TU > 0 ? TU : 1];
 #pragma unroll
-        for (int u = 0; u < TU; ++u) {
-            const int r = rr + u * G, rc = r < w ? r : w - 1;
-            uu[u] = c.C[eU + VLG_MUL24(rc, P)];
-            vv[u] = c.I[eV + rc];
-            xa[u] = c.C[D + 1 + rc];
-            xb[u] = c.C[DW + 1 + rc];
-            o_gi[u] = c.gI[eV + rc];
-            o_c[u] = c.gCc[eU + VLG_MUL24(rc, P)];
-            o_g[u] = c.gCi[eX + rc];
-        }
-        x.lockstep();   // the lanes of a group sit in one wavefront: every load above precedes every store below
+            for (int u = 0; u < TU; ++u) {
+                const int r = r0 + u * G, rc = r < w ? r : w - 1;
+                uu[u] = c.C[eU + VLG_MUL24(rc, P)];
+                vv[u] = c.I[eV + rc];
+                xa[u] = c.C[D + 1 + rc];
+                xb[u] = c.C[DW + 1 + rc];
+                o_gi[u] = c.gI[eV + rc];
+                o_c[u] = c.gCc[eU + VLG_MUL24(rc, P)];
+                o_g[u] = c.gCi[eX + rc];
+            }
+            x.lockstep();   // the lanes of a group sit in one wavefront: every load above precedes every store below
 #pragma unroll
-        for (int u = 0; u < TU; ++u) {
-            const int r = rr + u * G;
-            if (live && r < w) {
-                const float wc = adj_w<SR>(g, uu[u] + vv[u], oc, r, 0);
-                const float wt = adj_w<SR>(gs, xa[u] + xb[u], Tv, r, 0);
-                if (r != selfr) c.gI[eV + r] = o_gi[u] + wc;
-                c.gCc[eU + VLG_MUL24(r, P)] = o_c[u] + wc;
-                c.gCi[eX + r] = o_g[u] + wt;
+            for (int u = 0; u < TU; ++u) {
+                const int r = r0 + u * G;
+                if (live && r < w) {
+                    const float wc = adj_w<SR>(g, uu[u] + vv[u], oc, r, 0);
+                    const float wt = adj_w<SR>(gs, xa[u] + xb[u], Tv, r, 0);
+                    if (r != selfr) c.gI[eV + r] = o_gi[u] + wc;
+                    c.gCc[eU + VLG_MUL24(r, P)] = o_c[u] + wc;
+                    c.gCi[eX + r] = o_g[u] + wt;
+                }
             }
         }
         return;
@@ -745,7 +768,7 @@ VLG_HD void dep_bw_width(const DepCtx& c, int w, int t, int nd, X& x) {
         else if (T == 2) dep_bw_span<SR, DIR, 2>(c, w, G, D, live, rr, x);
         else if (T == 3) dep_bw_span<SR, DIR, 3>(c, w, G, D, live, rr, x);
         else if (T == 4) dep_bw_span<SR, DIR, 4>(c, w, G, D, live, rr, x);
-        else dep_bw_span<SR, DIR, 0>(c, w, G, D, live, rr, x);
+        else dep_bw_span<SR, DIR, 4>(c, w, G, D, live, rr, x, (T + 3) >> 2);
     }
 }
 
