@@ -171,7 +171,9 @@ void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int le
     vlg::MergedIO<In> io;
     io.dec = dec; io.attach = attach; io.N = N; io.gdec = gdec; io.gatt = gatt; io.heads = heads;
     run_workgroup(nt, order, [&](int tid, HostX& x) {
-        vlg::dmv_run<SR, BWD>(c, io, glogZ, logZ, tid, nt, x);
+        // the long-sentence placements run the chunked form of the long spans (vlg_dp.hip: dmv_run<SR, BWD, MODE != 0>)
+        if (g_mode != 0) vlg::dmv_run<SR, BWD, true>(c, io, glogZ, logZ, tid, nt, x);
+        else vlg::dmv_run<SR, BWD, false>(c, io, glogZ, logZ, tid, nt, x);
     });
     A.check();
     W.check();

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
     io.gatt = (BWD && gatt) ? gatt + att_off : nullptr;
     io.heads = (BWD && heads) ? heads + (size_t)b * N : nullptr;
     DevX x;
-    dmv_run<SR, BWD>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);
+    dmv_run<SR, BWD, (MODE != 0)>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);   // long-sentence placements: chunked long spans
 }
 
 // The same DP fed from the scorer's rule tables (RuleIO): no gathered [B,L,L,2,2]
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void dmv1o_rules_kernel(
     io.g_root = (BWD && g_root) ? g_root + (size_t)b * T : nullptr;
     io.heads = (BWD && heads) ? heads + (size_t)b * N : nullptr;
     DevX x;
-    dmv_run<SR, BWD>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);
+    dmv_run<SR, BWD, (MODE != 0)>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);   // long-sentence placements: chunked long spans
 }
 
 template <int SR, int MODE, bool BWD, typename In>

@@ -282,7 +282,50 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
 #endif
         }
         VLG_STAMP_AT(x, 4);
+    } else if (TU < 0) {
+        // long spans in the long-sentence placements (TU < 0): the same two passes, four split points at a time -- the loads of
+        // a chunk are independent and branch-free (out-of-range r clamped for the load, masked to the lowest float), where a
+        // loop over single split points with its `if` pays an LDS round trip per split point.  Same operations in the same
+        // order as that loop: identical bits.
+        constexpr int CU = 4;
+        auto terms = [&](int r0, float (*t)[3]) {
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int r = r0 + u * G, rc = r < w ? r : w - 1;
+                const float a = Cf[eA + 2 * rc], b = Cf[eB + 2 * rc];
+                const float uu = Cf[eU + 2 * VLG_MUL24(rc, P)];
+                const float2 vv = c.I[eV + rc];
+                const bool v0 = r < w, v1 = DIR == 0 ? (v0 && r >= 1) : (r <= w - 2);
+                t[u][0] = v0 ? a + b : VLG_LOWEST;
+                t[u][1] = v1 ? uu + vv.x : VLG_LOWEST;
+                t[u][2] = v1 ? uu + vv.y : VLG_LOWEST;
+            }
+        };
+        for (int k = 0; k < 3; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
+        for (int r0 = rr; r0 < w; r0 += CU * G) {
+            float t[CU][3];
+            terms(r0, t);
+#pragma unroll
+            for (int u = 0; u < CU; ++u)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) upd_max(m[k], am[k], t[u][k], r0 + u * G);
+        }
+        if (SR == VLG_SR_MAX) x.template allreduce_argmax<3>(m, am, G);
+        else x.template allreduce_max<3>(m, G);
+        if (SR == VLG_SR_LOG) {
+            for (int r0 = rr; r0 < w; r0 += CU * G) {
+                float t[CU][3];
+                terms(r0, t);
+#pragma unroll
+                for (int u = 0; u < CU; ++u)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) s[k] += VLG_EXP(t[u][k] - m[k]);   // masked terms: 2^(-3e38) = 0
+            }
+            x.template allreduce_sum<3>(s, G);
+        }
     } else {
+        // generic loop over single split points (placements with every chart in LDS, where N <= 61 rarely gets here: the chunked
+        // form above costs the all-in-LDS kernel registers and the headline 0.8 %)
         for (int k = 0; k < 3; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
         for (int r = rr; r < w; r += G) {
             upd_max(m[0], am[0], Cf[eA + 2 * r] + Cf[eB + 2 * r], r);
@@ -340,7 +383,7 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
 }
 
 // one width of the inside pass for this lane: G = 2^LG lanes per (span, direction); LG < 0: G is a run-time value
-template <int SR, bool BWD, int DIR, int LG, typename X>
+template <int SR, bool BWD, int DIR, int LG, bool LONGSPAN, typename X>
 VLG_HD void dmv_fw_width(const DmvCtx& c, int w, int lgr, int t, int nd, X& x) {
     const int lg = LG >= 0 ? LG : lgr, G = 1 << lg, per = nd >> lg;
     const int rr = t & (G - 1), slot = t >> lg, spans = c.Ne - w;
@@ -354,20 +397,20 @@ VLG_HD void dmv_fw_width(const DmvCtx& c, int w, int lgr, int t, int nd, X& x) {
         else if (T == 2) dmv_fw_span<SR, BWD, DIR, 2>(c, w, G, D, live, rr, x);
         else if (T == 3) dmv_fw_span<SR, BWD, DIR, 3>(c, w, G, D, live, rr, x);
         else if (T == 4) dmv_fw_span<SR, BWD, DIR, 4>(c, w, G, D, live, rr, x);
-        else dmv_fw_span<SR, BWD, DIR, 0>(c, w, G, D, live, rr, x);
+        else dmv_fw_span<SR, BWD, DIR, LONGSPAN ? -1 : 0>(c, w, G, D, live, rr, x);
     }
 }
 
 // all widths of one segment (constant group size), one barrier per width
-template <int SR, bool BWD, int LG, typename X>
+template <int SR, bool BWD, int LG, bool LONGSPAN, typename X>
 VLG_HD void dmv_fw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& x) {
     const int nd = nt >> 1;                 // lanes per direction
     const bool right = x.uniform(tid >= nd);   // wave-uniform on the device (nd is a multiple of 64)
     const int t = right ? tid - nd : tid;
     for (int w = w0; w < w1; ++w) {
 #ifndef VLG_ABL_NOBODY
-        if (right) dmv_fw_width<SR, BWD, 1, LG>(c, w, LG, t, nd, x);
-        else dmv_fw_width<SR, BWD, 0, LG>(c, w, LG, t, nd, x);
+        if (right) dmv_fw_width<SR, BWD, 1, LG, LONGSPAN>(c, w, LG, t, nd, x);
+        else dmv_fw_width<SR, BWD, 0, LG, LONGSPAN>(c, w, LG, t, nd, x);
 #endif
 #ifndef VLG_ABL_NOBARRIER
         x.sync();
@@ -375,16 +418,16 @@ VLG_HD void dmv_fw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& 
     }
 }
 
-template <int SR, bool BWD, typename X>
+template <int SR, bool BWD, bool LONGSPAN, typename X>
 VLG_HD void dmv_fw_all(const DmvCtx& c, int tid, int nt, X& x) {
     const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_FW);
-    dmv_fw_segment<SR, BWD, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
-    dmv_fw_segment<SR, BWD, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
-    dmv_fw_segment<SR, BWD, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
-    dmv_fw_segment<SR, BWD, 3>(c, sc.first[3], sc.first[4], tid, nt, x);
-    dmv_fw_segment<SR, BWD, 4>(c, sc.first[4], sc.first[5], tid, nt, x);
-    dmv_fw_segment<SR, BWD, 5>(c, sc.first[5], sc.first[6], tid, nt, x);
-    dmv_fw_segment<SR, BWD, 6>(c, sc.first[6], sc.first[7], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 0, LONGSPAN>(c, sc.first[0], sc.first[1], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 1, LONGSPAN>(c, sc.first[1], sc.first[2], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 2, LONGSPAN>(c, sc.first[2], sc.first[3], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 3, LONGSPAN>(c, sc.first[3], sc.first[4], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 4, LONGSPAN>(c, sc.first[4], sc.first[5], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 5, LONGSPAN>(c, sc.first[5], sc.first[6], tid, nt, x);
+    dmv_fw_segment<SR, BWD, 6, LONGSPAN>(c, sc.first[6], sc.first[7], tid, nt, x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -609,6 +652,8 @@ VLG_HD void dep_fw_span(const DepCtx& c, int w, int G, int D, bool live, int rr,
             x.template allreduce_sum<2>(s, G);
         }
     } else {
+        // (left as a loop over single split points: the chunked form of dmv_fw_span costs this kernel registers -- and with them
+        //  resident workgroups at large batches: B = 4096 1.27 ms vs 0.78 ms -- for nothing at N = 81, where its charts sit in LDS)
         for (int k = 0; k < 2; ++k) { m[k] = VLG_LOWEST; am[k] = 0; }
         for (int r = rr; r < w; r += G) {
             upd_max(m[0], am[0], c.C[eA + r] + c.C[eB + r], r);
@@ -930,7 +975,7 @@ VLG_HD void dmv_walk(const DmvCtx& c, float g) {
     }
 }
 
-template <int SR, bool BWD, typename IO, typename X>
+template <int SR, bool BWD, bool LONGSPAN = false, typename IO, typename X>
 VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int tid, int nt, X& x) {
     const int Ne = c.Ne, P = c.P, len = c.len;
     // ---- stage: charts to the semiring zero (dmv.py:34-35), potentials into fast memory -------------------------
@@ -981,11 +1026,11 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     unsigned long long st_bbody = 0, st_bsync = 0;
     {   // (per-width body / barrier split is no longer taken: the width loop lives inside the segment functions)
         const unsigned long long a = __builtin_amdgcn_s_memtime();
-        dmv_fw_all<SR, BWD>(c, tid, nt, x);
+        dmv_fw_all<SR, BWD, LONGSPAN>(c, tid, nt, x);
         st_body += __builtin_amdgcn_s_memtime() - a;
     }
 #else
-    dmv_fw_all<SR, BWD>(c, tid, nt, x);
+    dmv_fw_all<SR, BWD, LONGSPAN>(c, tid, nt, x);
 #endif
     if (tid == 0) *logZ = c.C[len + 1].y * VLG_LN2;   // CR(0,len).NOCHILD, dmv.py:65
     if (!BWD) return;
