@@ -546,7 +546,13 @@ def test_bilinear_align_backward_and_sizes(oracle_mod):
 
 
 @pytest.mark.parametrize("B,A,Q,V,d,dt", [(5, 5, 82, 36, 128, "f32"), (5, 5, 82, 36, 128, "bf16"), (3, 4, 7, 130, 64, "f32"),
-                                          (2, 3, 100, 5, 32, "bf16"), (1, 1, 1, 1, 128, "f32"), (4, 2, 33, 201, 128, "f32")])
+                                          (2, 3, 100, 5, 32, "bf16"), (1, 1, 1, 1, 128, "f32"), (4, 2, 33, 201, 128, "f32"),
+                                          # bf16, d = 128: the split-term kernels -- odd contraction lengths (word loads), the
+                                          # concatenated two-pairs-per-step caption side at its limits (V = 4, 40, 44, 48) with odd
+                                          # and even outer counts, one / six row tiles, and shapes that fall back per side
+                                          (3, 4, 50, 37, 128, "bf16"), (2, 3, 96, 48, 128, "bf16"), (3, 2, 97, 20, 128, "bf16"),
+                                          (4, 5, 30, 40, 128, "bf16"), (2, 2, 20, 44, 128, "bf16"), (3, 3, 33, 4, 128, "bf16"),
+                                          (33, 34, 17, 36, 128, "bf16"), (2, 40, 82, 64, 128, "bf16")])
 def test_bilinear_align_backward_vs_oracle(oracle_mod, B, A, Q, V, d, dt):
     """vlg_bilinear_align_backward (the hand-written adjoint of the materialised tensor, joint.py:413-418 under autograd)
     against the fp64 oracle: both masks, contraction lengths across the 96-element chunk boundary, one- and several-tile
