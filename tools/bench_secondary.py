@@ -176,6 +176,24 @@ def _run_all(out, args, h, dev):
             "mfma_busy": mfma_busy("align_mfma_kernel<TILE> (full tensor)" if full else "align_max_kernel") if in_dtype == torch.bfloat16 else None,
             "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in (2048-d / 768-d features through fixed-seed Linear->128), fp32 out"}
 
+    # ---- the plain projections around the contraction (`vis_mlp_pre_matching` joint.py:136-138,175; the visual
+    #      encoder's box MLP box_rel.py:29-40; word / child / parent encoders joint.py:218-221): nn.Linear shapes, LEFT to the
+    #      library (hipBLASLt through torch) by design -- measured here so that the choice is on record ----
+    def gemm_entry(m, k, n):
+        a_ = torch.randn(m, k, generator=g).to(dev, in_dtype)
+        w_ = torch.randn(k, n, generator=g).to(dev, in_dtype)
+        sec_ = _events(lambda: a_ @ w_, 50, 10, dev)
+        fl = 2.0 * m * k * n
+        return {"ms": sec_ * 1e3, "TFLOP/s": fl / sec_ / 1e12,
+                "frac_mfma_bf16_peak": fl / sec_ / 1e12 / MFMA_BF16_PEAK_TFLOPS if in_dtype == torch.bfloat16 else None,
+                "GB/s": (m * k + k * n + m * n) * (2 if in_dtype == torch.bfloat16 else 4) / sec_ / 1e9, "shape": f"[{m},{k}] x [{k},{n}] {args.dtype}"}
+    out["library_gemms"] = {
+        "vis_box_mlp": gemm_entry(B * V, 2048, 256),          # region features -> hidden (box_rel.py:29-40, n_in 2048, n_hidden 256)
+        "vis_mlp_pre_matching": gemm_entry(B * V, 256, 128),  # hidden -> matching space (joint.py:136-138)
+        "word_child_parent": gemm_entry(B * N, 256, 128),     # word encodings -> child / parent (joint.py:218-221)
+        "note": "library GEMMs (torch -> hipBLASLt), not part of this package: small-N projections are memory-bound on the "
+                "activation read; the frac_mfma figure is therefore low by construction"}
+
     # ---- backward of the materialised tensor (what autograd runs when the reference's own loss consumes gather_logit_simple's
     #      [B,A,Q,V] output): both feature gradients, each kernel reads the 4 B * B*A*Q*V cotangent once ----
     cot = torch.randn(B, B, Q, V, generator=torch.Generator(device=dev).manual_seed(7), device=dev)
