@@ -1562,7 +1562,9 @@ int vlg_align_reduced(const void* txt, const void* vis, const uint8_t* tmask, co
                                                                    wsf + p.off_maxV, nullptr, nullptr, s, xa)                      \
              : launch_align_mfma<F32, KCHV, true, true, 3>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr, wsf + p.off_maxV, \
                                                            nullptr, nullptr, s, xa)
-    if (!f32in && d == 128) VLG_RA(false, 4);
+    if (!f32in && d == 128 && V <= kAMRows && !getenv("VLG_GROUND_OLD_ALIGN"))   // shared image tiles, row maxima + positions only
+        rc = launch_align_max<true>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, wsf + p.off_maxV, nullptr, s, xa);
+    else if (!f32in && d == 128) VLG_RA(false, 4);
     else if (!f32in && d == 64) VLG_RA(false, 2);
     else if (!f32in && d == 32) VLG_RA(false, 1);
     else if (f32in && d == 128) VLG_RA(true, 8);
