@@ -587,6 +587,30 @@ def test_bilinear_align_backward_vs_oracle(oracle_mod, B, A, Q, V, d, dt):
     assert np.abs(gb.float().cpu().numpy() - ref_v).max() <= tol * max(1.0, np.abs(ref_v).max())
 
 
+def test_bilinear_align_backward_config_size():
+    """The a9 backward at BASELINE configs[1] widths (B = A = 256, Q = 82, V = 36, d = 128, bf16 features: the split-term
+    kernels, caption side two pairs per step, outer ranges split over two blocks): against fp32 torch contractions of the same
+    masked cotangent (the oracle is too slow at this size; it pins the same kernels on small batches above), masked rows exactly
+    zero, and identical bits on a second run."""
+    from vlgae_amd import align
+    B, Q, V, d = 256, 82, 36, 128
+    g = torch.Generator(device=dev()).manual_seed(17)
+    txt = (torch.randn(B, Q, d, generator=g, device=dev()) * 0.5).bfloat16()
+    vis = (torch.randn(B, V, d, generator=g, device=dev()) * 0.5).bfloat16()
+    tm = torch.rand(B, Q, generator=g, device=dev()) > 0.15
+    vm = torch.rand(B, V, generator=g, device=dev()) > 0.15
+    cot = torch.randn(B, B, Q, V, generator=g, device=dev())
+    gt, gv = align.bilinear_align_backward(cot, txt, vis, tm, vm)
+    gm = cot * tm[:, None, :, None] * vm[None, :, None, :]
+    want_t = torch.einsum("baqv,avd->bqd", gm, vis.float())
+    want_v = torch.einsum("baqv,bqd->avd", gm, txt.float())
+    for got, want in ((gt, want_t), (gv, want_v)):
+        assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())   # two-term split: < 2^-17 per product; fp32 sums of 9 k / 21 k terms
+    assert not bool(gt[~tm].any()) and not bool(gv[~vm].any())
+    gt2, gv2 = align.bilinear_align_backward(cot, txt, vis, tm, vm)
+    assert torch.equal(gt, gt2) and torch.equal(gv, gv2)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 def test_bilinear_align_config_size(oracle_mod, dt):
     """BASELINE.json configs[1] shapes (B = A = 256, Q = 82, V = 36, d = 128): the fused maxima / diagonal block are
