@@ -141,11 +141,12 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
  *   grad_txt[b,q,:] = tmask[b,q] * sum_{a,v} grad_out[b,a,q,v] * vmask[a,v] * vis[a,v,:]
  *   grad_vis[a,v,:] = vmask[a,v] * sum_{b,q} grad_out[b,a,q,v] * tmask[b,q] * txt[b,q,:]      (masked_fill_ passes no gradient)
  *   grad_out [B,A,Q,V] fp32; txt [B,Q,d], vis [A,V,d] (in_dtype); grad_txt [B,Q,d], grad_vis [A,V,d] fp32 (either may be NULL).
- * d in {32, 64, 128}.  The cotangent is read in place with both masks fused.  fp32 features (and shapes outside the fast
- * path): fp32 matrix-core products, exact.  bf16 features with d = 128 and at most 96 rows / contraction positions per pair
- * (config-2): the cotangent is split on the fly into two bf16 terms (g = t0 + t1, dropping < 2^-17 |g|) and multiplied
- * on the bf16 matrix cores against contraction-major copies of the features, which live in `ws`:
- * vlg_bilinear_align_backward_workspace(...) bytes of device scratch (0 when the fast path does not apply; ws may then be NULL). */
+ * d in {32, 64, 128}.  The cotangent is read in place with both masks fused.  With d = 128 and at most 96 rows / contraction
+ * positions per pair (config-2) the products run on the bf16 matrix cores: the fp32 cotangent is split on the fly into two bf16
+ * terms (g = t0 + t1, dropping < 2^-17 |g|), bf16 features are used as they are, fp32 features as two bf16 parts (x = hi + lo;
+ * the lo x t1 product, < 2^-16 of the term, is dropped), against contraction-major copies of the features that live in `ws`:
+ * vlg_bilinear_align_backward_workspace(...) bytes of device scratch (0 when the fast path does not apply; ws may then be NULL).
+ * Other shapes: fp32 matrix-core products, exact (environment VLG_BWD_F32_EXACT=1 forces that path for fp32 features). */
 size_t vlg_bilinear_align_backward_workspace(int B, int A, int Q, int V, int d, int in_dtype);
 int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask,
                                 int B, int A, int Q, int V, int d, int in_dtype, void* ws, size_t ws_bytes, float* grad_txt,

@@ -61,7 +61,7 @@ def test_version_and_error_plumbing(lib):
     assert lib.vlg_dmv1o_rules(one, one, one, 0, one, None, one, 2, 5, 7, 0, 0, -1e20, None, one, None, None, None, one,
                                None, 0, None) == 0x1003 and b"VLG_SEMIRING_MAX" in lib.vlg_last_error()
     assert lib.vlg_bilinear_align_backward(one, one, one, None, None, 2, 2, 5, 5, 48, 0, None, 0, one, one, None) == 0x1001   # d not in {32,64,128}
-    assert lib.vlg_bilinear_align_backward_workspace(4, 4, 82, 36, 128, 1) == (128 * (4 * 36 + 96) + 4 * 128 * 96) * 2 and lib.vlg_bilinear_align_backward_workspace(4, 4, 82, 36, 128, 0) == 0
+    assert lib.vlg_bilinear_align_backward_workspace(4, 4, 82, 36, 128, 1) == (128 * (4 * 36 + 96) + 4 * 128 * 96) * 2 and lib.vlg_bilinear_align_backward_workspace(4, 4, 82, 36, 64, 0) == 0 and lib.vlg_bilinear_align_backward_workspace(4, 4, 82, 36, 128, 0) == 2 * (4 * 128 * 64 + 4 * 128 * 96) * 2
     assert lib.vlg_bilinear_align_backward(one, one, one, None, None, 4, 4, 82, 36, 128, 1, None, 0, one, one, None) == 0x1004   # fast path without its scratch
     assert lib.vlg_dmv1o_count_sum(None, None, 4, 8, None, None) == 0x1003
     with pytest.raises(RuntimeError, match="N >= 2"):

@@ -913,36 +913,48 @@ static int launch_align_mfma(const void* txt, const void* vis, const uint8_t* tm
 typedef __attribute__((ext_vector_type(8))) __bf16 ab_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float ab_f32x4;
 
-// feat [O][K][128] bf16 -> featT [O][128][Kp] bf16, zero where mask[o][k] == 0 or k >= K: block = one 32-position strip
-__global__ __launch_bounds__(256) void align_bwd_transpose_kernel(const uint16_t* __restrict__ feat, const uint8_t* __restrict__ mask,
-                                                                  int K, int Kp, uint16_t* __restrict__ featT) {
-    __shared__ uint16_t t[32][128 + 2];
+// feat [O][K][128] -> featT [O][128][Kp] bf16, zero where mask[o][k] == 0 or k >= K: block = one 32-position strip.
+// bf16 features are copied; fp32 features are split into two bf16 parts x = hi + lo (hi = bf16(x), lo = bf16(x - hi)), the lo
+// parts going to a second array of the same shape (`featT_lo`).
+template <typename T>
+__global__ __launch_bounds__(256) void align_bwd_transpose_kernel(const T* __restrict__ feat, const uint8_t* __restrict__ mask,
+                                                                  int K, int Kp, uint16_t* __restrict__ featT,
+                                                                  uint16_t* __restrict__ featT_lo) {
+    constexpr bool F32 = sizeof(T) == 4;
+    __shared__ uint16_t t[F32 ? 2 : 1][32][128 + 2];
     const int o = blockIdx.x, k0 = blockIdx.y * 32;
     for (int i = threadIdx.x; i < 32 * 128; i += 256) {
         const int k = i >> 7, c = i & 127;
         const bool on = k0 + k < K && (!mask || mask[(size_t)o * K + k0 + k]);
-        t[k][c] = on ? feat[((size_t)o * K + k0 + k) * 128 + c] : (uint16_t)0;
+        const T x = on ? feat[((size_t)o * K + k0 + k) * 128 + c] : (T)0;
+        if constexpr (F32) {
+            const __bf16 h = (__bf16)x;
+            t[0][k][c] = __builtin_bit_cast(uint16_t, h);
+            t[F32 ? 1 : 0][k][c] = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
+        } else {
+            t[0][k][c] = x;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 32 * 128; i += 256) {
         const int c = i >> 5, k = i & 31;
-        featT[((size_t)o * 128 + c) * Kp + k0 + k] = t[k][c];
+        featT[((size_t)o * 128 + c) * Kp + k0 + k] = t[0][k][c];
+        if constexpr (F32) featT_lo[((size_t)o * 128 + c) * Kp + k0 + k] = t[F32 ? 1 : 0][k][c];
     }
 }
 
 // MT row tiles x CW column groups = 6 waves: each cotangent row tile is loaded by CW waves only (it is the HBM stream; the
 // features sit in LDS, where re-reading them per wave is cheap)
-template <bool KCONTIG, int NKC, int MT, int CW, int NT>
-// (three waves per SIMD = two resident blocks per CU: the second block's work is what hides the first one's load latency)
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) void align_bwd_split_kernel(
-    const float* __restrict__ g, const uint16_t* __restrict__ featT,
-                                                              const uint8_t* __restrict__ rmask, int O, int M, int K, long so,
-                                                              long sr, long sk, long sfix, int o_per, float* __restrict__ out,
-                                                              int atomic) {
+// FS = feature parts: 1 = bf16 features; 2 = fp32 features as hi + lo bf16 tiles (featT holds the hi parts of all O tensors, then
+// the lo parts): g x = g_hi x_hi + g_hi x_lo + g_lo x_hi, dropping g_lo x_lo (< 2^-16 of the product).
+template <bool KCONTIG, int NKC, int MT, int CW, int NT, int FS>
+__device__ __forceinline__ void align_bwd_split_body(const float* __restrict__ g, const uint16_t* __restrict__ featT,
+                                                     const uint8_t* __restrict__ rmask, int O, int M, int K, long so, long sr,
+                                                     long sk, long sfix, int o_per, float* __restrict__ out, int atomic) {
     constexpr int Kp = NKC * 32, PITCH = Kp * 2 + 32, SEGS = Kp / 8;   // +32: conflict-free ds_read_b128 fragment reads
     static_assert(MT * CW == 6 || MT * CW == 3, "six waves, or three when every cotangent element is to be loaded once");
     constexpr int RT = 1, CT = 8 / CW, nthr = 64 * MT * CW;
-    constexpr int NV = (128 * SEGS + nthr - 1) / nthr;
+    constexpr int NV = (FS * 128 * SEGS + nthr - 1) / nthr, TILE = 128 * PITCH;   // LDS: [buffer][part][128][PITCH]
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, ccol = lane & 15;
     const int fix = blockIdx.x, o_begin = blockIdx.y * o_per, o_end = min(O, o_begin + o_per);
@@ -962,16 +974,20 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             for (int j = 0; j < 8; ++j) graw[r][kc][j] = 0.f;
     auto load_tile = [=](int o, uint4* xs) __attribute__((always_inline)) {
         const uint4* src = reinterpret_cast<const uint4*>(featT + (size_t)min(o, O - 1) * 128 * Kp);
+        const size_t part_stride = (size_t)O * 128 * Kp / 8;   // uint4 between the hi and the lo array
 #pragma unroll
-        for (int j = 0; j < NV; ++j) xs[j] = src[min(tid + j * nthr, 128 * SEGS - 1)];
+        for (int j = 0; j < NV; ++j) {
+            const int i = min(tid + j * nthr, FS * 128 * SEGS - 1), part = i / (128 * SEGS), e = i - part * (128 * SEGS);
+            xs[j] = src[part * part_stride + e];
+        }
     };
     auto store_tile = [=](int buf, const uint4* xs) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = tid + j * nthr;
-            if (i < 128 * SEGS) {
-                const int row = i / SEGS, seg = i - row * SEGS;
-                *reinterpret_cast<uint4*>(smem_raw + (buf * 128 + row) * PITCH + seg * 16) = xs[j];
+            if (i < FS * 128 * SEGS) {
+                const int part = i / (128 * SEGS), e = i - part * (128 * SEGS), row = e / SEGS, seg = e - row * SEGS;
+                *reinterpret_cast<uint4*>(smem_raw + (buf * FS + part) * TILE + row * PITCH + seg * 16) = xs[j];
             }
         }
     };
@@ -1028,7 +1044,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         for (int c = 0; c < CT; ++c) acc[r][c] = ab_f32x4{0.f, 0.f, 0.f, 0.f};
     // zero both tile buffers once (pitch padding is never written again), then the prologue: tile(o_begin) in place, tile
     // (o_begin + 1) and the cotangent of o_begin in flight
-    for (int i = tid; i < 2 * 128 * PITCH / 16; i += nthr) reinterpret_cast<uint4*>(smem_raw)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * FS * TILE / 16; i += nthr) reinterpret_cast<uint4*>(smem_raw)[i] = make_uint4(0, 0, 0, 0);
     load_tile(o_begin, xs);
     __syncthreads();
     store_tile(0, xs);
@@ -1062,21 +1078,24 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         load_tile(o + 2, xs);
         // ---- MFMAs of pair o ----
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            ab_bf16x8 bf[CT];
+        for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
-                bf[c] = *reinterpret_cast<const ab_bf16x8*>(smem_raw + (buf * 128 + (ct0 + c) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int part = 0; part < FS; ++part) {
+                ab_bf16x8 bf[CT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int c = 0; c < CT; ++c)
+                    bf[c] = *reinterpret_cast<const ab_bf16x8*>(smem_raw + (buf * FS + part) * TILE + ((ct0 + c) * 16 + ccol) * PITCH +
+                                                                 (kc * 4 + kg) * 16);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < RT; ++r)
+                for (int t = 0; t < (part == 0 ? NT : 1); ++t)   // the lo feature part meets the leading cotangent term only
 #pragma unroll
-                    for (int c = 0; c < CT; ++c)
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][r][kc], bf[c], acc[r][c], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+                            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t][r][kc], bf[c], acc[r][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         __syncthreads();
     };
     // (a second cotangent set, loaded two steps ahead, was measured: no faster -- the step is bound by instruction issue, not
@@ -1100,6 +1119,22 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             }
         }
     }
+}
+
+// bf16 features: three waves per SIMD = two resident blocks per CU (the second block's work hides the first one's load latency)
+template <bool KCONTIG, int NKC, int MT, int CW, int NT>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) void align_bwd_split_kernel(
+    const float* __restrict__ g, const uint16_t* __restrict__ featT, const uint8_t* __restrict__ rmask, int O, int M, int K, long so,
+    long sr, long sk, long sfix, int o_per, float* __restrict__ out, int atomic) {
+    align_bwd_split_body<KCONTIG, NKC, MT, CW, NT, 1>(g, featT, rmask, O, M, K, so, sr, sk, sfix, o_per, out, atomic);
+}
+
+// fp32 features, split: twice the LDS per block (one block per CU) and more registers
+template <bool KCONTIG, int NKC, int MT, int CW, int NT>
+__global__ __launch_bounds__(384) void align_bwd_split_f32_kernel(
+    const float* __restrict__ g, const uint16_t* __restrict__ featT, const uint8_t* __restrict__ rmask, int O, int M, int K, long so,
+    long sr, long sk, long sfix, int o_per, float* __restrict__ out, int atomic) {
+    align_bwd_split_body<KCONTIG, NKC, MT, CW, NT, 2>(g, featT, rmask, O, M, K, so, sr, sk, sfix, o_per, out, atomic);
 }
 
 // Caption side with a short, quad-aligned contraction (K % 4 == 0, 2 K <= 96 -- config-2's 36 regions): TWO pairs per step,
@@ -1330,7 +1365,9 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
 }
 
 // bf16 features, d = 128, at most 96 rows and 96 contraction positions per pair: the split-term path on the bf16 matrix cores
-static bool bwd_split_ok(int in_dtype, int d, int M, int K) { return in_dtype == VLG_BF16 && d == 128 && M <= 96 && K <= 96; }
+static bool bwd_split_ok(int in_dtype, int d, int M, int K) {
+    return (in_dtype == VLG_BF16 || (in_dtype == VLG_F32 && !getenv("VLG_BWD_F32_EXACT"))) && d == 128 && M <= 96 && K <= 96;
+}
 
 // caption side, two pairs per step on one concatenated scratch: short quad-aligned contraction
 static bool bwd_concat_ok(int K) { return (K & 3) == 0 && K >= 4 && 2 * K <= 96 && !getenv("VLG_BWD_NOCONCAT"); }
@@ -1339,9 +1376,10 @@ static size_t bwd_concat_pitch(int O, int K) { return ((size_t)O * K + 96 + 7) /
 size_t vlg_bilinear_align_backward_workspace(int B, int A, int Q, int V, int d, int in_dtype) {
     if (B < 1 || A < 1 || Q < 1 || V < 1) return 0;
     size_t n = 0;
+    const size_t parts = in_dtype == VLG_F32 ? 2 : 1;   // fp32 features: hi and lo bf16 copies
     if (bwd_split_ok(in_dtype, d, Q, V))   // caption side: vis, contraction-major (concatenated over the images when V is short)
-        n += bwd_concat_ok(V) ? (size_t)128 * bwd_concat_pitch(A, V) : (size_t)A * 128 * ((V + 31) / 32 * 32);
-    if (bwd_split_ok(in_dtype, d, V, Q)) n += (size_t)B * 128 * ((Q + 31) / 32 * 32);   // image side: txt
+        n += bwd_concat_ok(V) && parts == 1 ? (size_t)128 * bwd_concat_pitch(A, V) : parts * A * 128 * ((V + 31) / 32 * 32);
+    if (bwd_split_ok(in_dtype, d, V, Q)) n += parts * B * 128 * ((Q + 31) / 32 * 32);   // image side: txt
     return n * 2;
 }
 
@@ -1365,11 +1403,17 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
     // below the bf16 rounding the features -- and the gradients autograd hands back to bf16 leaves -- already carry); a third
     // term (fp32's own rounding level) costs half as many MFMAs and conversions again: 0.56 vs 0.45 ms on the caption side
     constexpr int kNT = 2;
+    const bool f32feat = in_dtype == VLG_F32;
     constexpr int kCW3 = 2;   // column groups for <= 48 rows (1 = three-wave blocks that load every cotangent element once: 2x slower, too few waves per CU)
     auto go_split = [&](const void* feat, const uint8_t* km, const uint8_t* rm, int fixn, int O, int M, int K, long so, long sr,
                         long sk, long sfix, bool kcontig, uint16_t* featT, float* out) -> int {
         const int Kp = (K + 31) / 32 * 32, nkc = Kp / 32;
-        hipLaunchKernelGGL(align_bwd_transpose_kernel, dim3(O, Kp / 32), dim3(256), 0, s, (const uint16_t*)feat, km, K, Kp, featT);
+        if (f32feat)
+            hipLaunchKernelGGL(align_bwd_transpose_kernel<float>, dim3(O, Kp / 32), dim3(256), 0, s, (const float*)feat, km, K, Kp, featT,
+                               featT + (size_t)O * 128 * Kp);
+        else
+            hipLaunchKernelGGL(align_bwd_transpose_kernel<uint16_t>, dim3(O, Kp / 32), dim3(256), 0, s, (const uint16_t*)feat, km, K, Kp,
+                               featT, (uint16_t*)nullptr);
         int split = 1;   // two blocks per CU at least; two-addend atomics are order-free
         if ((long)fixn * 2 <= 1024 && O >= 16) split = 2;
         if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e);
@@ -1378,10 +1422,10 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
             hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)fixn * M * 128, s);
             if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
         }
-        const size_t lds = 2 * (size_t)128 * (Kp * 2 + 32);
+        const size_t lds = (f32feat ? 4 : 2) * (size_t)128 * (Kp * 2 + 32);
 #define VLG_BS(KC, NKCV, MTV, CWV)                                                                                      \
         do {                                                                                                            \
-            auto k = align_bwd_split_kernel<KC, NKCV, MTV, CWV, kNT>;                                                   \
+            auto k = f32feat ? align_bwd_split_f32_kernel<KC, NKCV, MTV, CWV, kNT> : align_bwd_split_kernel<KC, NKCV, MTV, CWV, kNT>; \
             if (lds > 64 * 1024) {                                                                                      \
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                 if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));         \
@@ -1439,9 +1483,9 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
     };
     const long QV = (long)Q * V;
     uint16_t* visT = reinterpret_cast<uint16_t*>(ws);
-    const bool concat = bwd_split_ok(in_dtype, d, Q, V) && bwd_concat_ok(V);
+    const bool concat = bwd_split_ok(in_dtype, d, Q, V) && bwd_concat_ok(V) && !f32feat;
     uint16_t* txtT = visT + (!bwd_split_ok(in_dtype, d, Q, V) ? 0 : concat ? (size_t)128 * bwd_concat_pitch(A, V)
-                                                                            : (size_t)A * 128 * ((V + 31) / 32 * 32));
+                                                                            : (f32feat ? 2 : 1) * (size_t)A * 128 * ((V + 31) / 32 * 32));
     if (grad_txt && concat) {   // two images per step, their 2 V <= 96 positions side by side
         const long pitch = (long)bwd_concat_pitch(A, V);
         hipLaunchKernelGGL(align_bwd_concat_transpose_kernel, dim3((unsigned)((pitch + 31) / 32)), dim3(256), 0, s, (const uint16_t*)vis,
