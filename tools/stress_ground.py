@@ -7,9 +7,9 @@ import oracle
 from vlgae_amd import align
 oracle.build()
 dev = torch.device('cuda:0')
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2026)
 worst = 0.0
-for it in range(40):
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     wide = it % 4 == 3
     B = int(rng.integers(1, 70)) if not wide else int(rng.integers(1, 12))
     L = int(rng.integers(1, 48))
