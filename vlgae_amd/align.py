@@ -78,8 +78,8 @@ def bilinear_align_backward(grad_out, txt_feat, vis_feat, txt_mask=None, vis_mas
     """Gradients of `bilinear_align(...)["full"]` w.r.t. both feature tensors for the cotangent grad_out [B,A,Q,V] (what
     autograd derives for joint.py:413-418; masked positions pass no gradient).  Returns (g_txt [B,Q,d], g_vis [A,V,d]) in
     float32 (None where not wanted).  One HIP kernel per gradient reads the cotangent in place -- no permuted, masked or
-    up-cast copies of it -- on the matrix cores (bf16 features at config-2 widths: the cotangent split into two bf16 terms;
-    otherwise fp32 MFMA); there is no library-GEMM / eager fallback."""
+    up-cast copies of it -- on the matrix cores (d = 128 at config-2 widths: bf16 MFMA with the cotangent, and fp32 features,
+    split into bf16 terms -- relative error < 2^-16 per product; other shapes: exact fp32 MFMA); no library-GEMM / eager fallback."""
     txt_feat, vis_feat, txt_mask, vis_mask = _plain(txt_feat), _plain(vis_feat), _plain(txt_mask), _plain(vis_mask)
     _C.require_gpu(txt_feat, "bilinear_align_backward")
     B, Q, d = txt_feat.shape
