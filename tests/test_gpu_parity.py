@@ -1139,6 +1139,43 @@ def test_arc_trilinear_shapes(oracle_mod, M, X, H, Y, dt):
         assert np.abs(got.float().cpu().numpy() - want).max() <= tol * max(1.0, np.abs(want).max()), name
 
 
+def test_training_step_chain_as_one_hip_graph():
+    """The chained training-step hot path (tools/train_step.py: attention-fuse -> library GEMMs -> DMV marginals + heads on two
+    streams -> arc encoder -> grounding loss -> -DMV.max -> every gradient) captured as ONE HIP graph: capture succeeds (no
+    entry point synchronises, allocates through the driver or reads a device value on the host), and a replay gives the eager
+    step's loss bit for bit and its gradients to one bf16 ulp."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import train_step
+    with torch.autograd.set_multithreading_enabled(False):
+        step = train_step.build(64, 24, 20, dev(), dtype=torch.bfloat16)
+        for _ in range(3):
+            total, grads, pot_grads = step()
+        want = [total.detach().clone()] + [grads[k].clone() for k in step.names] + [g.clone() for g in pot_grads]
+        # nothing of an earlier step's autograd graph may be alive across the capture: torch 2.10 / ROCm 7 segfaults in
+        # capture_end when a loss tensor of a previous eager step is still referenced (a plain x @ w -> relu -> sum step does
+        # it too; nothing to do with these kernels)
+        del total, grads, pot_grads
+        gr = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev())
+        side.wait_stream(torch.cuda.current_stream(dev()))
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream(dev()).wait_stream(side)
+        with torch.cuda.graph(gr):
+            total_g, grads_g, pot_g = step()
+        for _ in range(2):
+            gr.replay()
+        torch.cuda.synchronize()
+        got = [total_g] + [grads_g[k] for k in step.names] + list(pot_g)
+        assert torch.equal(total_g.detach(), want[0])
+        for a, b in zip(got, want):
+            # (the loss is bit-equal; gradients that pass through torch's gather backward -- an atomic scatter-add over repeated
+            #  parents -- are order-dependent from run to run, eager or not: one bf16 ulp is allowed there)
+            assert torch.allclose(a.float(), b.float(), rtol=2.0 ** -7, atol=2.0 ** -7 * float(b.float().abs().max()))
+
+
 @pytest.mark.parametrize("B,L,V,d", [(6, 9, 12, 32), (256, 40, 36, 128)], ids=["toy", "config2"])
 def test_training_step_chain(oracle_mod, B, L, V, d):
     """One pass over the whole path as the model wires it (joint.py:245-287 lang_feat_max_tree, :406-491 grounding):

@@ -95,7 +95,7 @@ def deptree_run(arc, lengths, semiring, want_grad, grad_logZ=None):
     return logZ, None
 
 
-def dmv1o_decode(dec, attach, lengths):
+def dmv1o_decode(dec, attach, lengths, out=None):
     """Viterbi tree as a head vector, entirely on the device (no `nonzero()` host sync).
     Returns (best_score [B], heads [B,N] int64): heads[b,c] = head of word c (0 = root token); 0 at c = 0 / padding.
     Equals `predicted` of src/model/joint.py:256-258 and, shifted by one, of ldndmv.py:301-303."""
@@ -108,8 +108,11 @@ def dmv1o_decode(dec, attach, lengths):
     dt, dec_c = _C.in_dtype(dec)
     _, att_c = _C.in_dtype(attach)
     lengths = _lengths(lengths, B, dec.device)
-    best = torch.empty(B, dtype=torch.float32, device=dec.device)
-    heads = torch.empty((B, N), dtype=torch.int64, device=dec.device)
+    if out is None:
+        best = torch.empty(B, dtype=torch.float32, device=dec.device)
+        heads = torch.empty((B, N), dtype=torch.int64, device=dec.device)
+    else:   # caller-owned outputs (dmv1o_marginals_and_heads allocates them on ITS stream before switching to the side stream)
+        best, heads = out
     ws, nb = _workspace(_C.OP_DMV1O_INSIDE_OUTSIDE, B, N, _C.SEMIRING_MAX, dec.device)
     _C.check(_C.lib().vlg_dmv1o_decode(_C.ptr(dec_c), _C.ptr(att_c), _C.ptr(lengths), B, N, dt, _C.ptr(best),
                                        _C.ptr(heads), _C.ptr(ws), nb, _C.stream_of(dec)), "dmv1o_decode")
@@ -327,12 +330,16 @@ def dmv1o_marginals_and_heads(dec, attach, lengths):
     side = _SIDE_STREAMS.get(dec.device)
     if side is None:
         side = _SIDE_STREAMS[dec.device] = torch.cuda.Stream(device=dec.device)
+    # The decode's outputs are allocated HERE, on the current stream, and the side stream joins before this returns: every later
+    # use, free or reuse of them -- and of the inputs -- is ordered behind the side stream's work by that join, so no
+    # `record_stream` bookkeeping is needed (it is what made a HIP-graph capture crash while tensors of an earlier eager
+    # step were still alive: the allocator's deferred event handling for recorded streams is not capture-safe).
+    B, N = dec.shape[:2]
+    best = torch.empty(B, dtype=torch.float32, device=dec.device)
+    heads = torch.empty((B, N), dtype=torch.int64, device=dec.device)
     side.wait_stream(cur)                       # the potentials are produced on the current stream
     with torch.cuda.stream(side):
-        _, heads = dmv1o_decode(dec, attach, lengths)
+        dmv1o_decode(dec, attach, lengths, out=(best, heads))
     logZ, _, gatt = dmv1o_run(dec, attach, lengths, _C.SEMIRING_LOG, True, want_dec=False)
     cur.wait_stream(side)
-    heads.record_stream(cur)                    # allocated on the side stream, consumed on the current one
-    for t in (dec, attach):
-        t.record_stream(side)
     return logZ, gatt, heads
