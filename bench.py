@@ -51,6 +51,10 @@ def parse_args(argv=None):
     ap.add_argument("--ragged", action="store_true", help="random lengths instead of all = L")
     ap.add_argument("--grad-mb", type=float, default=28.0,
                     help="size of the all-reduced flat gradient in MB (default: the VLGAE model's ~7 M fp32 parameters)")
+    ap.add_argument("--workload", default="dp", choices=["dp", "train_step"],
+                    help="dp: the headline DMV1o inside+outside step (BASELINE.json metric); train_step: the chained "
+                         "training-step hot path of configs[4], sharded data-parallel (tools/bench_train.py)")
+    ap.add_argument("--buckets", type=int, default=2, help="train_step: pieces the flat gradient is all-reduced in")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-secondary", "--no-align", action="store_true", dest="no_secondary",
                     help="headline only: skip the secondary single-GPU measurements")
@@ -136,7 +140,7 @@ def kernel_source_id():
     """Short hash of the DP kernel sources: committed PMC profiles carry it so stale traffic figures are not reused."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("vlg_dp.hip", "vlg_dp_core.h"):
+    for f in ("vlg_dp_kernels.h", "vlg_dp_core.h"):
         h.update(open(os.path.join(ROOT, "vlgae_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 
@@ -240,14 +244,25 @@ def run(args):
         dev = torch.device("cuda", local_rank)
     sync = (lambda: None) if dry else (lambda: torch.cuda.synchronize(dev))
 
-    h = Headline(args, rank, dev, dry)
-    B, L, N = h.B, h.L, h.N
-
     def barrier():
         sync()
         if world > 1:
             dist.barrier()
         sync()
+
+    if args.workload == "train_step":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_train
+        res = bench_train.measure(args, rank, world, dev, dry, barrier)
+        if rank == 0:
+            print(json.dumps(bench_train.json_line(args, world, res, dry, share)), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    h = Headline(args, rank, dev, dry)
+    B, L, N = h.B, h.L, h.N
 
     def timed_region(reducer):
         """W untimed warmup steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
@@ -282,9 +297,7 @@ def run(args):
 
     comm = {}
     if world > 1:
-        ones = torch.ones(1, dtype=torch.float32, device=dev)
-        dist.all_reduce(ones)
-        comm["rccl_ranks_seen"] = int(round(float(ones.item())))
+        comm["rccl_ranks_seen"] = vdist.warm_up(dev)
         comm["backend"] = dist.get_backend()
         n_model = max(h.n_grad, int(args.grad_mb * 1e6 / 4))
         big = vdist.GradAllReducer(n_model, dev)
@@ -314,6 +327,22 @@ def run(args):
         elapsed, gpu_ms = timed_region(None)
         elapsed_small = None
 
+    # ---- multi-GPU: the sharded training step (configs[4]) beside the DP line, on every rank ----
+    train_sharded = None
+    if world > 1 and not args.no_secondary:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_train
+        import copy
+        targs = copy.copy(args)
+        targs.steps, targs.warmup = min(args.steps, 50), min(args.warmup, 10)
+        try:
+            train_sharded = bench_train.measure(targs, rank, world, dev, dry, barrier)
+            train_sharded.update(steps=targs.steps, warmup=targs.warmup,
+                                 what="bench.py --workload train_step on the same ranks (tools/bench_train.py): value = "
+                                      "sentences/s of the whole job, synchronous-SGD all-reduce of the model-sized gradient")
+        except Exception as e:   # every rank fails or none does (same code path); never costs the headline line
+            train_sharded = {"error": repr(e)[:300]}
+
     # ---- checks outside the timed region: finite, and counts sum to the number of words ----
     if not dry:
         assert bool(torch.isfinite(h.logZ).all()), "non-finite logZ"
@@ -340,6 +369,8 @@ def run(args):
                    "parallelism": (f"dp{world}" if world > 1 else "single") + (" (DEBUG: ranks share one GPU, gloo)" if share else ""),
                    "allreduce_floats": (comm["allreduce_bytes"] // 4 if world > 1 else 0)},
     }
+    if train_sharded is not None:
+        out["train_step_sharded"] = train_sharded
     if world > 1:
         out["value_dp_grad_only"] = B * world * args.steps / elapsed_small
         out["ms_per_step_dp_grad_only"] = elapsed_small * 1e3 / args.steps

@@ -131,3 +131,68 @@ def test_bench_parent_does_not_import_torch_before_spawning():
     top_imports = {a.name.split(".")[0] for n in tree.body if isinstance(n, ast.Import) for a in n.names}
     top_imports |= {n.module.split(".")[0] for n in tree.body if isinstance(n, ast.ImportFrom)}
     assert "torch" not in top_imports and "vlgae_amd" not in top_imports and "numpy" not in top_imports
+
+
+@pytest.mark.timeout(300)
+def test_bench_train_step_workload_sharded_dry_run():
+    """`bench.py --workload train_step --gpus 2`: the sharded training step (configs[4]) -- bucketed synchronous-SGD
+    all-reduce of the flat gradient, tail bucket started from inside the backward pass, sum-over-ranks check."""
+    out = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--grad-mb", "12",
+                      "--cpu-seconds", "0", "--workload", "train_step"], {})
+    assert out["dry_run"] is True and "DRY RUN" in out["data"]
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "configs[4]" in out["config"]["workload"]
+    assert out["config"]["global_batch"] == 512 and out["config"]["parallelism"] == "dp2"
+    comm = out["comm"]
+    assert comm["rccl_ranks_seen"] == 2 and comm["backend"] == "gloo" and comm["buckets"] == 2
+    assert comm["allreduce_bytes"] == 12_000_000 and out["config"]["allreduce_floats"] == 3_000_000
+    # the head bucket (launched last) carries slot 0 + the 2 179 712 real leaf-gradient floats; the tail is the rest
+    (t0, t1), (h0, h1) = comm["bucket_bounds"]
+    assert h0 == 0 and h1 >= 2_179_713 and (t0, t1) == (h1, 3_000_000)
+    chk = comm["sum_over_ranks_check"]
+    assert chk["slot0"] == chk["expected"] == 2 * 256 * 40
+    assert out["value"] > 0 and out["step_ms"] > 0 and out["compute_ms"] > 0 and comm["allreduce_ms"] > 0
+
+
+@pytest.mark.timeout(300)
+def test_bench_dp_line_carries_the_sharded_train_step():
+    """The default (DP) workload on N > 1 ranks also runs the sharded training step, so the driver's scaling run records
+    both without being asked."""
+    out = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--grad-mb", "10",
+                      "--cpu-seconds", "0"], {})
+    ts = out["train_step_sharded"]
+    assert "error" not in ts, ts
+    assert ts["comm"]["rccl_ranks_seen"] == 2 and ts["comm"]["buckets"] == 2 and ts["value"] > 0
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from vlgae_amd import dist as vdist
+    vdist.init_from_env(backend="gloo")
+    ok = True
+    for numel, nb, head in ((1000, 2, 10), (1000, 3, 700), (7, 4, 3), (5, 1, 5), (64, 2, 64)):
+        red = vdist.BucketedGradReducer(numel, torch.device("cpu"), n_buckets=nb, head=head)
+        # the buckets tile [0, numel) exactly once; the head sits in the bucket that is launched last
+        cover = sorted(red.bounds)
+        ok &= cover[0][0] == 0 and cover[-1][1] == numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+        ok &= red.bounds[-1][0] == 0 and red.bounds[-1][1] >= head
+        for step in range(2):
+            red.wait()
+            red.flat.copy_(torch.arange(numel, dtype=torch.float32) * (rank + 1) * (step + 1))
+            for i in range(red.n_buckets):
+                red.launch(i)
+        red.wait()
+        want = torch.arange(numel, dtype=torch.float32) * 2 * sum(r + 1 for r in range(world))
+        ok &= bool(torch.equal(red.flat, want))
+    np.save(os.path.join(out_dir, f"bucket{rank}.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bucketed_reducer_tiles_the_buffer_and_sums_over_ranks(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert int(np.load(tmp_path / f"bucket{rank}.npy")[0]) == 1

@@ -1389,3 +1389,35 @@ def test_box_rel_config_size():
     # one such flip moves a gradient entry by ~ |dout| |w| ~ 4e-3
     for k, (a, r) in enumerate(zip(*outs)):
         assert float((a - r).abs().max()) <= (2e-5 if k == 0 else 3e-3) * max(1.0, float(r.abs().max())), k
+
+
+# ------------------------------------------------------------------------------------------------ multi-GPU (RCCL)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: the RCCL (nccl backend) path of bench.py")
+@pytest.mark.parametrize("workload", ["dp", "train_step"])
+def test_bench_two_gpus_over_rccl(workload):
+    """First box with two GPUs exercises RCCL without anyone asking: `bench.py --gpus 2` self-launches two rank
+    processes on the nccl backend; the line must report both ranks in the collective, and bench.py itself asserts that
+    the all-reduced buffer is the sum over ranks (expected counts / word counts)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VLGAE_BENCH_DRYRUN", "VLGAE_BENCH_SHARE_GPU", "VLGAE_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0",
+           "--workload", workload]
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.lstrip().startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, proc.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["data"] == "synthetic" and out["value"] > 0
+    assert out["comm"]["backend"] == "nccl" and out["comm"]["rccl_ranks_seen"] == 2
+    assert out["comm"]["allreduce_ms"] > 0
+    if workload == "train_step":
+        chk = out["comm"]["sum_over_ranks_check"]
+        assert abs(chk["slot0"] - chk["expected"]) <= 1e-3 * chk["expected"]
+    else:
+        assert out["train_step_sharded"]["comm"]["rccl_ranks_seen"] == 2

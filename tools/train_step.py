@@ -48,8 +48,11 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11):
     leaves = [P[k] for k in names]
     pot = [md.detach().requires_grad_(True), ma.detach().requires_grad_(True)]
 
-    def step():
-        """forward + backward of the chain; returns (total loss, gradients by leaf name, potential gradients)."""
+    def step(stage_hook=None):
+        """forward + backward of the chain; returns (total loss, gradients by leaf name, potential gradients).
+        stage_hook, if given, is called from inside the backward pass once the gradients w.r.t. the potentials and the
+        matching-space features exist (after the DP and grounding-loss adjoints, before the arc-encoder / projection /
+        attention-fuse adjoints) -- where a data-parallel trainer starts reducing its first gradient bucket."""
         # joint.py:670-674
         x = align.attention_fuse(P["vis_feat"], P["txt_word"], P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], 1e-5)
         x = x.to(dtype)
@@ -65,6 +68,8 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11):
         parent = parent_src.gather(1, heads.unsqueeze(-1).expand(-1, -1, d))
         arc = align.arc_encoder(child, parent, P["w1"], P["w2"], P["b"])
         txt = torch.cat([child, arc.to(child.dtype)], 1)
+        if stage_hook is not None:
+            txt.register_hook(lambda g: stage_hook())
         # joint.py:406-491
         total, _ = align.grounding_loss_factor_ce(txt, P["vis_feat"], tmask, vmask, txt_marginal, num_token, 1.0)
         # ldndmv.py:277-281 (viterbi_training: true)

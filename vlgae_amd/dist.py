@@ -31,10 +31,25 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         backend = backend or os.environ.get("VLGAE_DIST_BACKEND", "nccl")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)   # one process per GPU: RCCL binds the communicator to the current device
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # device_id makes the communicator eager: it is built here, not inside the first collective of a timed section
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        warm_up(torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu"))
     return rank, local_rank, world
+
+
+def warm_up(device):
+    """One small all-reduce + barrier: communicator set-up, xGMI ring discovery and the first-call kernel loads of RCCL
+    happen here, before anything is timed.  Returns the number of ranks the collective saw (must equal world_size)."""
+    ones = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(ones)
+    seen = int(round(float(ones.item())))
+    if seen != dist.get_world_size():
+        raise RuntimeError(f"warm-up all-reduce saw {seen} ranks, world size is {dist.get_world_size()}")
+    return seen
 
 
 def shard_bounds(n_items, rank, world):
@@ -85,3 +100,51 @@ class GradAllReducer:
                 self.handles[i] = None
                 if self.average:
                     self.bufs[i].div_(self.world)
+
+
+class BucketedGradReducer:
+    """The training step's flat gradient reduced in `n_buckets` contiguous pieces with synchronous-SGD semantics
+    (what Lightning DDP does for the reference, config/trainer/train.yaml:27-29): bucket i's all-reduce is started as
+    soon as its gradients exist (`launch(i)`, asynchronous, on RCCL's own stream, ordered after the kernels already
+    enqueued on the current stream), and `wait()` -- called before the optimizer / the next step -- makes the current
+    stream (not the host) wait for all of them.  Buckets launched early overlap the rest of the backward pass."""
+
+    def __init__(self, numel, device, n_buckets=2, dtype=torch.float32, head=0):
+        """head: number of leading elements that must sit in the LAST bucket's view (the real leaf gradients, which are
+        complete only at the end of the backward pass); the rest of the buffer is dealt evenly."""
+        self.flat = torch.zeros(numel, dtype=dtype, device=device)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        n_buckets = max(1, min(n_buckets, numel))
+        # last bucket = [0, cut_last) holds the head; earlier buckets split the tail evenly
+        per = -(-numel // n_buckets)
+        last = max(per, head)
+        bounds = [(0, min(last, numel))]
+        rest = numel - bounds[0][1]
+        k = n_buckets - 1
+        lo = bounds[0][1]
+        for i in range(k):
+            hi = lo + (rest // k) + (1 if i < rest % k else 0)
+            if hi > lo:
+                bounds.append((lo, hi))
+            lo = hi
+        # launch order: early buckets first, the head-carrying bucket last
+        self.bounds = bounds[1:] + bounds[:1]
+        self.views = [self.flat[a:b] for a, b in self.bounds]
+        self.handles = []
+
+    @property
+    def n_buckets(self):
+        return len(self.views)
+
+    @property
+    def head_view(self):
+        return self.views[-1]
+
+    def launch(self, i):
+        if self.world > 1:
+            self.handles.append(dist.all_reduce(self.views[i], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
