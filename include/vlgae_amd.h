@@ -252,6 +252,52 @@ size_t vlg_box_rel_pairwise_backward_workspace(int B, int R, int H);
 int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* grad_out, int B, int R, int H, int dtype, float slope,
                                   void* ws, size_t ws_bytes, float* grad_y, float* grad_bias, void* stream);
 
+/* Weight / bias gradient of an nn.Linear over all token rows -- `MLP.linear` (src/model/nn/common.py:30,47-51) under
+ * loss.backward(), i.e. the word / child / parent encoders of src/model/joint.py:270-277 and `vis_mlp_pre_matching`
+ * (joint.py:136-138,175):   d_weight[M(out), N(in)] = dy^T x,   d_bias[M] = sum_rows dy.
+ *   dy [K, ld_dy] (first M columns used), x [K, ld_x] (first N columns used): bf16, row-major, K = B*N token rows;
+ *   M and N multiples of 64, row strides multiples of 8 elements, all buffers 16-byte aligned.
+ *   d_weight [M, N] fp32, d_bias [M] fp32 or NULL.  ws: vlg_linear_wgrad_workspace(K, M, N) bytes (0 = unsupported shape).
+ * Split over the token rows across the whole chip (bf16 MFMA, fp32 accumulate); partial tiles are added in a fixed
+ * order: bit-reproducible, no atomics. */
+size_t vlg_linear_wgrad_workspace(int K, int M, int N);
+int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes,
+                     float* d_weight, float* d_bias, void* stream);
+
+/* The byte work of `lang_feat_max_tree` (src/model/joint.py:235-292) between the DP, the encoder GEMMs and the arc encoder.
+ * Shapes: B sentences, L words, N = L + 1 positions (root first), h encoder width, d matching width; M = B*N rows.
+ *   root_cat          x [B,L,h] (in_dtype) -> x1 [B,N,h] bf16: row 0 = masked mean of the words (joint.py:262-265), rows 1.. = x (:266)
+ *   root_cat_backward d_x1 [B,N,h] (in_dtype) -> d_x [B,L,h] fp32
+ *   split             pre [M,3d] bf16 = x1 W_cat^T + b_cat (word | child | parent encoders, joint.py:267-273) ->
+ *                     txt[b,n,:] = word third (txt is [B,2N,d] bf16, the word half, :288), child [M,d] = LeakyReLU(child third),
+ *                     parent [M,d] = LeakyReLU(parent third of row heads[b,n]) (gather by the predicted heads, :271-273),
+ *                     sum [M,d] = child + parent (optional; the operand of the affine term, :285)
+ *   split_backward    d_txt [B,2N,d] (dtype; the word half is read), d_child / d_parent fp32 [M,d], d_sum fp32 [M,d] or NULL
+ *                     (added to both), child / parent (activations, bf16) -> d_pre [M,3d] bf16 (LeakyReLU', scatter-add by head
+ *                     in ascending row order)
+ *   marginal          grad_attach [B,N,N,2] fp32, heads [B,N], lengths [B] -> txt_marginal [B,2N] fp32 = cat([mask,
+ *                     arc_margin.gather(-1, predicted)]) (joint.py:246-261; use_marginal 0: cat([mask, mask]), :262),
+ *                     txt_mask [B,2N] u8 = cat([mask, mask]) with the root slot masked (:248-249)
+ *   arc_out           tri [M,d] fp32 (+ aff [M,d] bf16 or NULL) -> txt[b, N+n, :] bf16 (arc_repr, joint.py:278-288) */
+int vlg_langfeat_root_cat(const void* x, const int64_t* lengths, int B, int L, int h, int in_dtype, void* x1, void* stream);
+int vlg_langfeat_root_cat_backward(const void* d_x1, const int64_t* lengths, int B, int L, int h, int in_dtype, float* d_x,
+                                   void* stream);
+int vlg_langfeat_split(const void* pre, const int64_t* heads, int B, int N, int d, float slope, void* txt, void* child,
+                       void* parent, void* sum, void* stream);
+int vlg_langfeat_split_backward(const void* d_txt, int d_txt_dtype, const float* d_child, const float* d_parent, const float* d_sum,
+                                const void* child, const void* parent, const int64_t* heads, int B, int N, int d, float slope,
+                                void* d_pre, void* stream);
+int vlg_langfeat_marginal(const float* grad_attach, const int64_t* heads, const int64_t* lengths, int B, int N, int use_marginal,
+                          float* txt_marginal, uint8_t* txt_mask, void* stream);
+int vlg_langfeat_arc_out(const float* tri, const void* aff, int B, int N, int d, void* txt, void* stream);
+
+/* Viterbi pass with every output of the Max semiring in ONE launch: best score, the 0/1 counts of the best tree (what
+ * `-DMV1o(...).max.sum()` back-propagates, ldndmv.py:277-281) and its head vector (`argmax`, joint.py:256-258) -- the two
+ * call sites see the same potentials within a training step.  Any of grad_dec / grad_attach / heads may be NULL (not all). */
+int vlg_dmv1o_viterbi(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype,
+                      const float* grad_best, float* best_score, float* grad_dec, float* grad_attach, int64_t* heads,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* Chain rule on the API path (helpers.py:116-157: autograd scales the unit-upstream counts by d loss / d logZ):
  *   out_a[b,:] = counts_a[b,:] * g[b*g_stride], out_b likewise; counts fp32, outputs out_dtype (VLG_F32 / VLG_BF16, round to
  *   nearest even like torch's cast).  g_stride 1: g [B]; 0: one scalar (the expanded gradient of `.sum()`).  n_a / n_b =

@@ -552,6 +552,67 @@ def box_rel(feat, weight, bias, slope=0.01, img_feat=True, dout=None):
     return rel, g_feat, g_weight, g_bias
 
 
+# ----------------------------------------------------------------------------------------------
+# Encoder projection, src/model/nn/common.py:23-51 (`MLP`: Linear -> LeakyReLU; dropout is the identity at p = 0 / eval) as
+# the word / child / parent encoders of src/model/joint.py:270-277 apply it to all token rows (numpy, fp64), and its adjoint.
+# ----------------------------------------------------------------------------------------------
+def mlp(x, weight, bias=None, slope=0.01, dout=None):
+    """x [..., n_in], weight [n_out, n_in], bias [n_out] -> y [..., n_out]; slope None = no activation (activate=False).
+    With dout [..., n_out] also (g_x, g_weight, g_bias)."""
+    x, weight = np.asarray(x, dtype=np.float64), np.asarray(weight, dtype=np.float64)
+    pre = x @ weight.T                                                              # common.py:48
+    if bias is not None:
+        pre = pre + np.asarray(bias, dtype=np.float64)
+    y = pre if slope is None else np.where(pre > 0, pre, pre * slope)               # common.py:49
+    if dout is None:
+        return y
+    g_pre = np.asarray(dout, dtype=np.float64) * (1.0 if slope is None else np.where(pre > 0, 1.0, slope))
+    g2, x2 = g_pre.reshape(-1, weight.shape[0]), x.reshape(-1, weight.shape[1])
+    return y, g_pre @ weight, g2.T @ x2, g2.sum(0)
+
+
+def lang_feat(x, lengths, heads, w_word, b_word, w_child, b_child, w_parent, b_parent, w1, w2, b_arc, slope=0.01, dout=None):
+    """joint.py:262-288 (the feature half of lang_feat_max_tree), fp64: root = masked mean, x = cat([root, x]), word /
+    child / parent encoders (parent on x gathered by the predicted heads), arc_repr, txt = cat([word_repr, arc_repr]).
+    x [B,L,h], lengths [B], heads [B,L+1] -> txt [B,2(L+1),d]; with dout also the gradients, as a dict by parameter name."""
+    x = np.asarray(x, dtype=np.float64)
+    lengths, heads = np.asarray(lengths), np.asarray(heads)
+    B, L, h = x.shape
+    N = L + 1
+    mask = (np.arange(L)[None] < lengths[:, None])[..., None]
+    root = (x * mask).sum(1) / lengths[:, None]                                       # :263-265
+    x1 = np.concatenate([root[:, None], x], 1)                                        # :266
+    xg = np.take_along_axis(x1, heads[..., None], 1)                                  # :271-273
+    word = mlp(x1, w_word, b_word, None)                                              # :267 (activate: false)
+    child = mlp(x1, w_child, b_child, slope)                                          # :269
+    parent = mlp(xg, w_parent, b_parent, slope)                                       # :270
+    arc = arc_encoder(child, parent, w1, w2, b_arc, np.float64)                       # :278-286
+    txt = np.concatenate([word, arc], 1)                                              # :288
+    if dout is None:
+        return txt
+    dout = np.asarray(dout, dtype=np.float64)
+    d_child, d_parent, d_w1, d_w2, d_b = arc_encoder_backward(child, parent, w1, w2, dout[:, N:], np.float64)
+    _, gx_w, g_ww, g_bw = mlp(x1, w_word, b_word, None, dout[:, :N])
+    _, gx_c, g_wc, g_bc = mlp(x1, w_child, b_child, slope, d_child)
+    _, gx_p, g_wp, g_bp = mlp(xg, w_parent, b_parent, slope, d_parent)
+    g_x1 = gx_w + gx_c
+    for b in range(B):
+        np.add.at(g_x1[b], heads[b], gx_p[b])
+    g_x = g_x1[:, 1:] + mask * (g_x1[:, :1] / lengths[:, None, None])
+    return txt, dict(x=g_x, w_word=g_ww, b_word=g_bw, w_child=g_wc, b_child=g_bc, w_parent=g_wp, b_parent=g_bp, w1=d_w1, w2=d_w2,
+                     b_arc=d_b)
+
+
+def lang_feat_marginal(grad_attach, heads, lengths, add_marginal=True):
+    """joint.py:246-262: (txt_marginal [B,2N], txt_mask [B,2N]) from d logZ / d attach [B,N,N,2] and `predicted`."""
+    grad_attach, heads, lengths = np.asarray(grad_attach, dtype=np.float64), np.asarray(heads), np.asarray(lengths)
+    B, N = heads.shape
+    mask = np.concatenate([np.zeros((B, 1), bool), np.arange(N - 1)[None] < lengths[:, None]], 1)   # :248
+    arc_margin = grad_attach.sum(-1)                                                  # :255
+    am = np.take_along_axis(arc_margin, heads[..., None], -1)[..., 0] if add_marginal else mask.astype(np.float64)   # :258-262
+    return np.concatenate([mask.astype(np.float64), am], 1), np.concatenate([mask, mask], 1)
+
+
 # ---------------------------------------------------------------- data feed (SURVEY section 8 row f4)
 def feed_kmeans(x, init_centroids, k, max_it=32):
     """ConstantTokenNumSampler.kmeans (datamodule/sampler.py:148-191) from given initial centroids, in the reference's dense

@@ -461,6 +461,68 @@ def boxrel_cases():
         print(f"{name}: rel {tuple(out['rel'].shape)}")
 
 
+def langfeat_cases():
+    """The reference's own `DependencyBoxRel.lang_feat_max_tree` (joint.py:235-292) executed as an unbound method on a
+    namespace that carries what it reads: the three encoders (the reference's `MLP`, nn/common.py:23-51: word encoder
+    without activation, child / parent with LeakyReLU, config/model/vlgae.yaml:69-73 + joint.py:216-222; dropout 0), the arc
+    encoder's parameters and cfg.add_marginal; `DMV1o` inside it is the reference's.  Gradients of <txt, dout> by torch
+    autograd.  The d = 128 case stores w1 as rank-4 factors and a strided sample of its gradient (like arcenc_cases)."""
+    from types import SimpleNamespace as NS
+    src, joint = _ref_import.import_joint()
+    from src.model.nn import MLP
+    fn = joint.DependencyBoxRel.lang_feat_max_tree
+    for name, seed, B, L, h, d, rank, add_marginal in (("langfeat_B3_L6_h64_d32_s0", 0, 3, 6, 64, 32, 0, True),
+                                                       ("langfeat_B4_L9_h128_d64_s1_nomarg", 1, 4, 9, 128, 64, 4, False),
+                                                       ("langfeat_B2_L40_h256_d128_s2", 2, 2, 40, 256, 128, 4, True)):
+        torch.manual_seed(seed)
+        g = torch.Generator().manual_seed(seed)
+        enc = {k: MLP(n_in=h, n_hidden=d, dropout=0, activate=(k != "word")) for k in ("word", "child", "parent")}
+        with torch.no_grad():
+            for m in enc.values():                                                  # reset_parameters zeroes the bias
+                m.linear.bias.copy_(torch.randn(d, generator=g) * 0.1)
+        extra = {}
+        if rank:
+            u, v, z = (torch.randn(d, rank, generator=g) * 0.3 for _ in range(3))
+            w1 = torch.nn.Parameter(torch.einsum("xr,hr,yr->xhy", u, v, z).contiguous())
+            extra = dict(w1_u=_np(u), w1_v=_np(v), w1_z=_np(z))
+        else:
+            w1 = torch.nn.Parameter(torch.randn(d, d, d, generator=g) * (1.0 / d))
+        w2 = torch.nn.Parameter(torch.randn(d, d, generator=g) * (1.0 / d ** 0.5))
+        b_arc = torch.nn.Parameter(torch.randn(d, generator=g) * 0.1)
+        me = NS(cfg=NS(add_marginal=add_marginal), word_encoder=enc["word"], child_encoder=enc["child"],
+                parent_encoder=enc["parent"], arc_encoder_w1=w1, arc_encoder_w2=w2, arc_encoder_b=b_arc)
+        lengths = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+        lengths[0] = L
+        mask = torch.arange(L)[None] < lengths[:, None]
+        x = (torch.randn(B, L, h, generator=g) * 0.5).requires_grad_(True)
+        _, dec, attach, root = dmv_inputs(seed + 100, B, L, False)
+        mdec, mattach = ts.DMV1o.merge(dec, attach, root)
+        vp = NS(mask=mask, seq_len=lengths, batch_size=B, max_len=L)
+        txt, txt_mask, txt_marginal = fn(me, None, {"x": x}, {"merged_dec": mdec, "merged_attach": mattach}, vp)
+        txt = txt.rename(None)
+        dout = torch.randn(B, 2 * (L + 1), d, generator=g) * txt_mask.rename(None).unsqueeze(-1)   # masked rows never reach the loss
+        params = [enc["word"].linear.weight, enc["word"].linear.bias, enc["child"].linear.weight, enc["child"].linear.bias,
+                  enc["parent"].linear.weight, enc["parent"].linear.bias, w1, w2, b_arc]
+        grads = torch.autograd.grad(txt, [x] + params, dout)
+        # `predicted`, joint.py:252-258 (the method keeps it local): the same three lines on the same potentials
+        arc = ts.DMV1o([mdec.detach().requires_grad_(), mattach.detach().requires_grad_()], lengths).argmax.sum(-1).nonzero()
+        predicted = torch.zeros(B, L + 1, dtype=torch.long)
+        predicted[arc[:, 0], arc[:, 2]] = arc[:, 1]
+        if rank:
+            extra["g_w1_sample"] = _np(grads[7][::5, ::7, ::3])
+        else:
+            extra.update(w1=_np(w1), g_w1=_np(grads[7]))
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"), x=_np(x), lengths=_np(lengths), merged_dec=_np(mdec), merged_attach=_np(mattach),
+            w_word=_np(params[0]), b_word=_np(params[1]), w_child=_np(params[2]), b_child=_np(params[3]), w_parent=_np(params[4]),
+            b_parent=_np(params[5]), w2=_np(w2), b_arc=_np(b_arc), add_marginal=np.bool_(add_marginal),
+            slope=np.float32(enc["child"].activation.negative_slope), predicted=_np(predicted), txt=_np(txt),
+            txt_mask=_np(txt_mask.rename(None)), txt_marginal=_np(txt_marginal.rename(None)), dout=_np(dout), g_x=_np(grads[0]),
+            g_w_word=_np(grads[1]), g_b_word=_np(grads[2]), g_w_child=_np(grads[3]), g_b_child=_np(grads[4]),
+            g_w_parent=_np(grads[5]), g_b_parent=_np(grads[6]), g_w2=_np(grads[8]), g_b_arc=_np(grads[9]), **extra)
+        print(f"{name}: txt {tuple(txt.shape)} marginal sum {float(txt_marginal.rename(None).sum()):.4f}")
+
+
 def _csr(lists):
     return (np.cumsum([0] + [len(l) for l in lists]).astype(np.int64),
             np.asarray([i for l in lists for i in l], dtype=np.int64))
@@ -529,6 +591,10 @@ def feed_cases():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:   # `make_golden.py langfeat_cases [...]`: only the named generator functions
+        for fn_name in sys.argv[1:]:
+            globals()[fn_name]()
+        sys.exit(0)
     dmv_case("dmv_B4_L10_s0", 0, 4, 10, "rand", store_merged=True)
     dmv_case("dmv_B4_L10_s1_full", 1, 4, 10, "full")
     dmv_case("dmv_B5_L7_s2", 2, 5, 7, [7, 5, 3, 1, 6], normalise_attach=True)
@@ -553,4 +619,5 @@ if __name__ == "__main__":
     reduced_cases()
     arcenc_cases()
     boxrel_cases()
+    langfeat_cases()
     feed_cases()

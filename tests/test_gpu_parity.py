@@ -1421,3 +1421,118 @@ def test_bench_two_gpus_over_rccl(workload):
         assert abs(chk["slot0"] - chk["expected"]) <= 1e-3 * chk["expected"]
     else:
         assert out["train_step_sharded"]["comm"]["rccl_ranks_seen"] == 2
+
+
+# ------------------------------------------------------------------------------------------------ lang_feat_max_tree
+def _langfeat_params(g, device, dtype=torch.float32):
+    from conftest import arcenc_w1
+    w_enc = np.concatenate([g["w_word"], g["w_child"], g["w_parent"]], 0)
+    b_enc = np.concatenate([g["b_word"], g["b_child"], g["b_parent"]], 0)
+    return [t(a).to(dtype).requires_grad_(True) for a in (w_enc, b_enc, arcenc_w1(g), g["w2"], g["b_arc"])]
+
+
+def _langfeat_grad_close(got, ref, name, tol):
+    """Gradients that pass through LeakyReLU' (x, the child / parent encoders' parameters) are discontinuous in the
+    pre-activations: a pre-activation within bf16 rounding of zero takes the other branch than in the fp32 reference and its
+    term changes by the factor 1 / slope.  A handful of the ~10^4 pre-activations do (|pre| < 4e-3 |pre|_typ), so those
+    tensors are held to the tolerance in relative L2 norm and to 5x the tolerance element-wise; the others (word encoder, arc
+    encoder: continuous in everything) to the tolerance element-wise."""
+    scale = max(1e-6, float(np.abs(ref).max()))
+    err = np.abs(got.astype(np.float64) - ref)
+    if name in ("x", "w_child", "b_child", "w_parent", "b_parent", "w_enc", "b_enc"):
+        assert float(np.linalg.norm(err)) <= tol * max(1e-6, float(np.linalg.norm(ref))), name
+        assert float(err.max()) <= 5 * tol * max(1.0, scale), name
+    else:
+        assert float(err.max()) <= tol * max(1.0, scale), name
+
+
+@pytest.mark.parametrize("path", golden_files("langfeat_"), ids=golden_ids("langfeat_"))
+def test_lang_feat_max_tree_golden(ts, path):
+    """vlgae_amd.langfeat.lang_feat_max_tree against the reference's own method (joint.py:235-292) and torch autograd through
+    it.  The path computes in bf16 with fp32 accumulation: tolerance 2e-2 of the largest reference magnitude per tensor
+    (bf16 has 8 mantissa bits: 4e-3 per rounding, a handful of roundings per path); masks, heads exact; marginals 5e-5."""
+    from vlgae_amd import langfeat
+    from conftest import arcenc_check_w1_grad
+    g = load(path)
+    x = t(g["x"]).requires_grad_(True)
+    lengths = t(g["lengths"])
+    params = _langfeat_params(g, dev())
+    txt, txt_mask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, t(g["merged_dec"]), t(g["merged_attach"]), *params,
+                                                               add_marginal=bool(g["add_marginal"]), slope=float(g["slope"]))
+    assert txt.dtype == torch.bfloat16 and tuple(txt.shape) == g["txt"].shape
+    assert (txt_mask.cpu().numpy() == g["txt_mask"]).all()
+    assert np.abs(txt_marginal.cpu().numpy() - g["txt_marginal"]).max() <= MARG_TOL
+    tol = 2e-2
+    assert np.abs(txt.detach().float().cpu().numpy() - g["txt"]).max() <= tol * max(1.0, np.abs(g["txt"]).max())
+    grads = torch.autograd.grad(txt, [x] + params, t(g["dout"]).to(txt.dtype))
+    d = g["w2"].shape[0]
+    got = {"x": grads[0], "w_word": grads[1][:d], "w_child": grads[1][d:2 * d], "w_parent": grads[1][2 * d:], "b_word": grads[2][:d],
+           "b_child": grads[2][d:2 * d], "b_parent": grads[2][2 * d:], "w2": grads[4], "b_arc": grads[5]}
+    for k, v in got.items():
+        _langfeat_grad_close(v.float().cpu().numpy(), g["g_" + k], k, tol)
+    arcenc_check_w1_grad(grads[3].float().cpu().numpy(), g, tol)
+
+
+def test_lang_feat_max_tree_config_size(ts, oracle_mod):
+    """B = 256, L = 40, h = 256, d = 128 (BASELINE.json configs[4] widths): against the fp64 oracle on the bf16-rounded inputs
+    for a slice of the batch, run-to-run bit equality (fixed summation orders: split-K partials, scatter-add by head), and the
+    one-Viterbi-pass-per-step contract (`keep_viterbi` -> a later `DMV1o(same potentials).max` launches nothing)."""
+    from vlgae_amd import langfeat
+    from vlgae_amd.torch_struct import functional as F
+    B, L, h, d = 256, 40, 256, 128
+    g = torch.Generator().manual_seed(5)
+    bf = torch.bfloat16
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev())
+    x = rnd(B, L, h, sc=0.5).to(bf).requires_grad_(True)
+    w_enc, b_enc = rnd(3 * d, h, sc=h ** -0.5).to(bf).requires_grad_(True), rnd(3 * d, sc=0.1).to(bf).requires_grad_(True)
+    w1, w2, b_arc = rnd(d, d, d, sc=1.0 / d).to(bf).requires_grad_(True), rnd(d, d, sc=d ** -0.5).to(bf).requires_grad_(True), rnd(d, sc=0.1).to(bf).requires_grad_(True)
+    dec = torch.randn(B, L, 2, 2, 2, generator=g).log_softmax(-1).to(dev())
+    attach, root = torch.randn(B, L, L, 2, generator=g).to(dev()), torch.randn(B, L, generator=g).log_softmax(-1).to(dev())
+    md, ma = ts.DMV1o.merge(dec, attach, root)
+    md, ma = md.to(bf), ma.to(bf)
+    lengths = torch.randint(L // 2, L + 1, (B,), generator=g)
+    lengths[0] = L
+    lengths = lengths.to(dev())
+    params = [w_enc, b_enc, w1, w2, b_arc]
+    F.viterbi_forget()
+    txt, txt_mask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, md, ma, *params, keep_viterbi=True)
+    dout = (torch.randn(B, 2 * (L + 1), d, generator=g).to(dev()) * txt_mask.unsqueeze(-1)).to(bf)
+    grads = torch.autograd.grad(txt, [x] + params, dout)
+    # the Viterbi pass is remembered: .max of a detached alias of the same potentials reuses it and matches a fresh launch
+    pot = [md.detach().requires_grad_(True), ma.detach().requires_grad_(True)]
+    hit = F._viterbi_lookup(pot[0], pot[1], lengths)
+    assert hit is not None
+    best = ts.DMV1o(pot, lengths).max
+    gd, ga = torch.autograd.grad(-best.sum(), pot)
+    F.viterbi_forget()
+    best2 = ts.DMV1o(pot, lengths).max
+    gd2, ga2 = torch.autograd.grad(-best2.sum(), pot)
+    assert torch.equal(best, best2) and torch.equal(gd, gd2) and torch.equal(ga, ga2)
+    heads = ts.DMV1o([md, ma], lengths).argmax_heads
+    assert torch.equal(heads, hit[3])
+    md[0, 1, 0, 0, 0] += 1.0                                            # an in-place update through any alias invalidates the entry
+    F._viterbi_remember(md, ma, lengths, hit)
+    md[0, 1, 0, 0, 0] -= 1.0
+    assert F._viterbi_lookup(pot[0], pot[1], lengths) is None
+    F.viterbi_forget()
+    # run-to-run bit equality
+    txt_b, _, _ = langfeat.lang_feat_max_tree(x, lengths, md, ma, *params)
+    grads_b = torch.autograd.grad(txt_b, [x] + params, dout)
+    assert torch.equal(txt, txt_b) and all(torch.equal(a, b) for a, b in zip(grads, grads_b))
+    # oracle on a slice (rows of the first 6 sentences; weight gradients need the whole batch and are checked by linearity below)
+    S = 6
+    f64 = lambda a: a.detach().float().cpu().numpy().astype(np.float64)
+    wn, bn = f64(w_enc), f64(b_enc)
+    otxt, og = oracle_mod.lang_feat(f64(x)[:S], lengths[:S].cpu().numpy(), heads[:S].cpu().numpy(), wn[:d], bn[:d], wn[d:2 * d], bn[d:2 * d],
+                                    wn[2 * d:], bn[2 * d:], f64(w1), f64(w2), f64(b_arc), 0.01, f64(dout)[:S])
+    tol = 2e-2
+    assert np.abs(f64(txt)[:S] - otxt).max() <= tol * np.abs(otxt).max()
+    _langfeat_grad_close(f64(grads[0])[:S], og["x"], "x", tol)
+    # parameter gradients are sums over sentences: the batch run on the first S sentences alone must match the oracle's
+    xs = x[:S].detach().requires_grad_(True)
+    txt_s, _, _ = langfeat.lang_feat_max_tree(xs, lengths[:S].contiguous(), md[:S].contiguous(), ma[:S].contiguous(), *params)
+    gs = torch.autograd.grad(txt_s, [xs] + params, dout[:S])
+    for name, got, ref in (("w_enc", gs[1], np.concatenate([og["w_word"], og["w_child"], og["w_parent"]])),
+                           ("b_enc", gs[2], np.concatenate([og["b_word"], og["b_child"], og["b_parent"]])), ("w1", gs[3], og["w1"]),
+                           ("w2", gs[4], og["w2"]), ("b_arc", gs[5], og["b_arc"])):
+        _langfeat_grad_close(f64(got), ref, name, tol)

@@ -223,3 +223,31 @@ def test_oracle_box_rel_matches_reference(oracle_mod, path):
     for got, want in ((rel, g["rel"]), (g_feat, g["g_feat"]), (g_w, g["g_weight"]), (g_b, g["g_bias"])):
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())     # fixtures are fp32 runs of the reference
+
+
+# ------------------------------------------------------------------------------------------------ lang_feat_max_tree
+@pytest.mark.parametrize("path", golden_files("langfeat_"), ids=golden_ids("langfeat_"))
+def test_lang_feat_oracle_vs_reference(oracle_mod, path):
+    """oracle.lang_feat / lang_feat_marginal / mlp restate joint.py:246-288 + nn/common.py:47-51; the fixtures are the
+    reference's own `lang_feat_max_tree` (with its MLP modules and its DMV1o) and torch autograd through it (fp32)."""
+    from conftest import arcenc_w1, arcenc_check_w1_grad
+    g = load(path)
+    w1 = arcenc_w1(g)
+    heads, lengths = g["predicted"], g["lengths"]
+    # the DP half: marginals from the oracle's inside-outside on the same merged potentials
+    _, _, gatt = oracle_mod.dmv1o(g["merged_dec"], g["merged_attach"], lengths, "log", np.float64)
+    _, _, vatt = oracle_mod.dmv1o(g["merged_dec"], g["merged_attach"], lengths, "max", np.float64)
+    pred = np.zeros_like(heads)
+    for b, h, c in zip(*np.nonzero(vatt.sum(-1))):
+        pred[b, c] = h
+    assert (pred == heads).all()
+    marg, mask = oracle_mod.lang_feat_marginal(gatt, heads, lengths, bool(g["add_marginal"]))
+    assert (mask == g["txt_mask"]).all()
+    assert np.abs(marg - g["txt_marginal"]).max() <= 2e-5
+    txt, grads = oracle_mod.lang_feat(g["x"], lengths, heads, g["w_word"], g["b_word"], g["w_child"], g["b_child"], g["w_parent"],
+                                      g["b_parent"], w1, g["w2"], g["b_arc"], float(g["slope"]), g["dout"])
+    assert np.abs(txt - g["txt"]).max() <= 2e-5 * max(1.0, np.abs(g["txt"]).max())
+    for k in ("x", "w_word", "b_word", "w_child", "b_child", "w_parent", "b_parent", "w2", "b_arc"):
+        ref = g["g_" + k]
+        assert np.abs(grads[k] - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), k
+    arcenc_check_w1_grad(grads["w1"], g, 5e-5)

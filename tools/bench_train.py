@@ -24,14 +24,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
-TRAINABLE = ("b", "ln_b", "ln_w", "w1", "w2", "w_child", "w_parent")   # leaves of train_step.build that are parameters
+TRAINABLE = ("b", "b_enc", "ln_b", "ln_w", "w1", "w2", "w_enc")   # leaves of train_step.build that are parameters
 
 
 class _DryStep:
     """CPU stand-in for the launcher / collective plumbing tests (VLGAE_BENCH_DRYRUN=1): no kernels, fixed fake gradients."""
 
     def __init__(self, B, L, d=128, h=256):
-        shapes = dict(b=(d,), ln_b=(h,), ln_w=(h,), w1=(d, d, d), w2=(d, d), w_child=(h, d), w_parent=(h, d))
+        shapes = dict(b=(d,), b_enc=(3 * d,), ln_b=(h,), ln_w=(h,), w1=(d, d, d), w2=(d, d), w_enc=(3 * d, h))
         self.grads = {k: torch.ones(s) for k, s in shapes.items()}
         self.lengths = torch.full((B,), L, dtype=torch.long)
 
@@ -52,7 +52,7 @@ def measure(args, rank, world, dev, dry, barrier):
     else:
         step = train_step.build(B, L, V, dev, dtype=dtype, seed=11 + rank)
     n_real = sum(int(torch.Size(s).numel()) for s in
-                 (dict(b=(128,), ln_b=(256,), ln_w=(256,), w1=(128, 128, 128), w2=(128, 128), w_child=(256, 128), w_parent=(256, 128)).values()))
+                 (dict(b=(128,), b_enc=(384,), ln_b=(256,), ln_w=(256,), w1=(128, 128, 128), w2=(128, 128), w_enc=(384, 256)).values()))
     head = 1 + n_real                                  # slot 0: this rank's word count (the sum-over-ranks check)
     n_model = max(head, int(args.grad_mb * 1e6 / 4))
     red = vdist.BucketedGradReducer(n_model, dev, n_buckets=args.buckets, head=head)

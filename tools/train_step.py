@@ -10,15 +10,18 @@ Reference call sequence (shipped `vlgae` config):
   loss.backward()                                adjoints of all of the above
 
 Frozen BERT / Faster-RCNN features are not in the container: word encodings [B,L,256] and region features
-[B,V,128|256] are fixed-seed random tensors of the shapes the encoders emit; two library GEMMs (plain nn.Linear
-shapes, left to hipBLASLt as in the reference) connect the fused encodings to the 128-d matching space.
+[B,V,128|256] are fixed-seed random tensors of the shapes the encoders emit.  Round 3: the language side follows
+lang_feat_max_tree literally (vlgae_amd.langfeat: masked-mean root row, word | child | parent encoders = nn.Linear + bias
+(+ LeakyReLU) as ONE projection GEMM with concatenated weights, parent rows gathered by the predicted heads, arc encoder),
+and the step runs ONE Viterbi pass: `marginals_and_heads(keep_viterbi=True)` feeds both `argmax` (joint.py:256) and the
+parser's `-max` loss on the same potentials (ldndmv.py:277-281).
 """
 import torch
 
 
 def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11):
     import vlgae_amd.torch_struct as ts
-    from vlgae_amd import align
+    from vlgae_amd import align, langfeat
     N, Q = L + 1, 2 * (L + 1)
     g = torch.Generator().manual_seed(seed)
     rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
@@ -27,7 +30,7 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11):
     P = dict(
         vis_feat=leaf(B, V, d), txt_word=leaf(B, N, d), vis_mid=leaf(B, V, h), enc_x=leaf(B, L, h),
         ln_w=torch.ones(h, device=dev, requires_grad=True), ln_b=torch.zeros(h, device=dev, requires_grad=True),
-        w_child=leaf(h, d, sc=h ** -0.5), w_parent=leaf(h, d, sc=h ** -0.5),
+        w_enc=leaf(3 * d, h, sc=h ** -0.5), b_enc=leaf(3 * d, sc=0.1),          # word | child | parent encoders (nn.Linear layout)
         w1=leaf(d, d, d, sc=1.0 / d), w2=leaf(d, d, sc=d ** -0.5), b=leaf(d, sc=0.1),
     )
     # ---- potentials from the (out-of-scope) scorer: constants of the step, root-merged ----
@@ -39,9 +42,6 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11):
     lengths = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
     lengths[0] = L
     lengths = lengths.to(dev)
-    wmask = torch.arange(L, device=dev)[None] < lengths[:, None]
-    mask1 = torch.cat([torch.zeros(B, 1, dtype=torch.bool, device=dev), wmask], 1)           # root slot masked (joint.py:204)
-    tmask = torch.cat([mask1, mask1], 1)
     vmask = torch.ones(B, V, dtype=torch.bool, device=dev)
     num_token = float(lengths.sum().item())
     names = sorted(P)
@@ -55,24 +55,14 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11):
         attention-fuse adjoints) -- where a data-parallel trainer starts reducing its first gradient bucket."""
         # joint.py:670-674
         x = align.attention_fuse(P["vis_feat"], P["txt_word"], P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], 1e-5)
-        x = x.to(dtype)
-        x1 = torch.cat([x.new_zeros(B, 1, h), x], 1)                                         # root position
-        child, parent_src = x1 @ P["w_child"], x1 @ P["w_parent"]                           # library GEMMs (nn.Linear shapes)
-        # joint.py:251-268 (constants of the step: detached potentials)
-        with torch.no_grad():
-            marg, heads = ts.DMV1o([md, ma], lengths).marginals_and_heads()
-            arc_margin = marg.sum(-1)
-            margin = arc_margin.gather(-1, heads.unsqueeze(-1)).squeeze(-1) * mask1
-            txt_marginal = torch.cat([mask1.float(), margin], 1)
-        # joint.py:275-287
-        parent = parent_src.gather(1, heads.unsqueeze(-1).expand(-1, -1, d))
-        arc = align.arc_encoder(child, parent, P["w1"], P["w2"], P["b"])
-        txt = torch.cat([child, arc.to(child.dtype)], 1)
+        # joint.py:235-292 (the potentials are constants of this stage: detached, :252-253)
+        txt, tmask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, md, ma, P["w_enc"], P["b_enc"], P["w1"], P["w2"], P["b"],
+                                                               keep_viterbi=True)
         if stage_hook is not None:
             txt.register_hook(lambda g: stage_hook())
         # joint.py:406-491
         total, _ = align.grounding_loss_factor_ce(txt, P["vis_feat"], tmask, vmask, txt_marginal, num_token, 1.0)
-        # ldndmv.py:277-281 (viterbi_training: true)
+        # ldndmv.py:277-281 (viterbi_training: true): the Viterbi pass of lang_feat_max_tree is reused
         total = total - ts.DMV1o(pot, lengths).max.sum()
         grads = torch.autograd.grad(total, leaves + pot)
         return total, dict(zip(names, grads[:len(names)])), grads[len(names):]

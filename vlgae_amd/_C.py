@@ -51,6 +51,15 @@ SIGNATURES = {
     "vlg_box_rel_pairwise": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "vlg_box_rel_pairwise_backward_workspace": (_sz, [_i, _i, _i]),
     "vlg_box_rel_pairwise_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
+    "vlg_linear_wgrad_workspace": (_sz, [_i, _i, _i]),
+    "vlg_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "vlg_langfeat_root_cat": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vlg_langfeat_root_cat_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vlg_langfeat_split": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "vlg_langfeat_split_backward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "vlg_langfeat_marginal": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "vlg_langfeat_arc_out": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "vlg_dmv1o_viterbi": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vlg_scale_counts": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "vlg_feed_kmeans": (_i, [_vp, ctypes.c_int64, _vp, _i, _i, _vp, _vp, _vp]),
     "vlg_feed_batches": (_i, [_vp, ctypes.c_int64, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

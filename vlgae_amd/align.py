@@ -521,3 +521,69 @@ def arc_encoder(child_repr, parent_repr, arc_encoder_w1, arc_encoder_w2, arc_enc
     """joint.py:281-287: the trilinear term on the matrix cores, the affine term as a plain library GEMM."""
     tri = arc_trilinear(child_repr, arc_encoder_w1, parent_repr)
     return tri + torch.matmul(_plain(child_repr) + _plain(parent_repr), arc_encoder_w2).float() + arc_encoder_b.float()
+
+
+# ----------------------------------------------------------------------------------------------
+# Encoder projections around the contraction (MLP, src/model/nn/common.py:23-51; joint.py:136-138,175,270-277)
+# ----------------------------------------------------------------------------------------------
+def linear_wgrad(dy, x, want_bias=True):
+    """Weight / bias gradient of `y = x @ weight.T + bias` over all token rows: (dy^T x [out, in], sum_rows dy [out]), float32.
+
+    dy [K, out], x [K, in]: bf16, row-major (row strides that are multiples of 8 elements are taken in place -- column
+    slices of wider buffers), out and in multiples of 64.  Split over the rows across the whole chip, fixed summation
+    order (vlg_linear_wgrad); other shapes / dtypes raise -- callers decide (see `_Linear.backward`)."""
+    _C.require_gpu(dy, "linear_wgrad")
+    K, M = dy.shape
+    N = x.shape[1]
+    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or x.shape[0] != K:
+        raise ValueError(f"linear_wgrad: bf16 [K,out] / [K,in] expected, got {dy.dtype} {tuple(dy.shape)} / {x.dtype} {tuple(x.shape)}")
+    if dy.stride(1) != 1 or dy.stride(0) % 8 or dy.data_ptr() % 16:
+        dy = dy.contiguous()
+    if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    nbytes = _C.lib().vlg_linear_wgrad_workspace(K, M, N)
+    if nbytes == 0:
+        raise ValueError(f"linear_wgrad: unsupported shape K={K} out={M} in={N} (out, in must be multiples of 64)")
+    (dw, db), ws = _C.alloc_f32(dy.device, ((M, N), (M,) if want_bias else None), nbytes)
+    _C.check(_C.lib().vlg_linear_wgrad(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, _C.ptr(ws), nbytes,
+                                       _C.ptr(dw), _C.ptr(db), _C.stream_of(dy)), "linear_wgrad")
+    return dw, db
+
+
+def _wgrad_ok(K, M, N, dtype):
+    return dtype == torch.bfloat16 and M % 64 == 0 and N % 64 == 0 and M >= 64 and N >= 64 and K >= 2048
+
+
+class _Linear(torch.autograd.Function):
+    """x @ weight.T + bias with the tall-skinny weight gradient on the split-K kernel; forward and the input gradient are
+    plain library GEMMs (they have ~10^4 output rows and fill the chip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = (g2 @ weight).reshape(x.shape) if need_x else None
+        dw = db = None
+        if need_w or need_b:
+            if g2.dtype == x2.dtype and _wgrad_ok(x2.shape[0], g2.shape[1], x2.shape[1], g2.dtype):
+                dw, db = linear_wgrad(g2, x2, want_bias=need_b)
+                dw = dw.to(weight.dtype) if need_w else None
+                db = db.to(weight.dtype) if need_b else None
+            else:   # small or oddly shaped: the library's GEMM is the right tool
+                dw = (g2.t() @ x2) if need_w else None
+                db = g2.sum(0) if need_b else None
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """torch.nn.functional.linear for the encoder projections over all B*N token rows (weight [out, in] as nn.Linear
+    stores it); differs from the stock op only in how the weight / bias gradients are computed (see linear_wgrad)."""
+    return _Linear.apply(_plain(x), weight, bias)

@@ -221,6 +221,15 @@ int vlg_dmv1o_decode(const void* dec, const void* attach, const int64_t* lengths
                               heads, ws, ws_bytes, stream);
 }
 
+int vlg_dmv1o_viterbi(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype,
+                      const float* grad_best, float* best_score, float* grad_dec, float* grad_attach, int64_t* heads, void* ws,
+                      size_t ws_bytes, void* stream) {
+    if (B > 0 && !heads && !grad_attach) return vlg::set_error(VLG_ERR_ARG, "dmv1o_viterbi: pass grad_attach and / or heads");
+    if (B > 0 && grad_dec && !grad_attach) return vlg::set_error(VLG_ERR_ARG, "dmv1o_viterbi: grad_dec needs grad_attach");
+    return vlg::run_dmv<true>(dec, attach, lengths, B, N, in_dtype, VLG_SR_MAX, grad_best, best_score, grad_dec, grad_attach,
+                              heads, ws, ws_bytes, stream);
+}
+
 int vlg_deptree_decode(const void* arc, const int64_t* lengths, int B, int N, int in_dtype, float* best_score,
                        int64_t* heads, void* ws, size_t ws_bytes, void* stream) {
     if (B > 0 && !heads) return vlg::set_error(VLG_ERR_ARG, "deptree_decode: null heads");

@@ -1,0 +1,225 @@
+// vlg_gemm.hip -- the tall-skinny GEMMs of the encoder projections around the contraction:
+// the weight / bias gradient of an nn.Linear over all B*N token rows,
+//     dW[out,in] = dY^T X,   db[out] = sum_rows dY          (MLP.linear, src/model/nn/common.py:30,47-51 under loss.backward();
+//                                                             word / child / parent encoders, src/model/joint.py:270-277)
+// The contraction runs over the ~10^4 token rows and the result is a few hundred columns square: a library GEMM maps it to
+// (out/128) x (in/64) tiles = 4 workgroups on a 256-CU chip (74-81 us per call in the training step).  Here the rows are
+// split over the whole chip (split-K), every workgroup streams its row chunk once through LDS, and the partial tiles are
+// added in a FIXED order by a second launch -- no atomics, bit-reproducible.
+//
+// Both operands are stored row-major with the contraction index as the SLOW dimension ([rows][cols]); the MFMA wants 8
+// consecutive contraction positions per lane.  gfx950's ds_read_b64_tr_b16 does that transposition on the way out of LDS:
+// a 16-lane group reads a 4-row x 16-column block of 16-bit elements and every lane receives one column of it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vlg_common.h"
+#include "vlg_mfma.h"
+
+namespace vlg {
+
+namespace {
+
+constexpr int kGemmThreads = 256;   // 4 wavefronts, 2 x 2 over the 64 x 64 output tile
+constexpr int kTile = 64;           // output tile edge (rows of C = columns of A; columns of C = columns of B)
+constexpr int kStage = 128;         // contraction rows per LDS stage
+// LDS row pitch in bytes: 64 bf16 + 32 bytes.  A transposed read of one 32-lane half covers 8 consecutive rows x 32 bytes;
+// 160 r mod 256 = {0,160,64,224,128,32,192,96} for r = 0..7 puts them on 8 disjoint 8-bank groups (64 banks x 4 bytes).
+constexpr int kPitch = kTile * 2 + 32;
+
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+
+__device__ __forceinline__ v4i16 tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p));
+}
+
+__device__ __forceinline__ bf16x8 frag_from(v4i16 lo, v4i16 hi) {
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    v8i16 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// C_part[s] (64 x 64 tile) = sum over the rows of split s of A[k, m0..m0+63]^T B[k, n0..n0+63]; optionally the column sums of A.
+// grid = (M/64 * N/64, S); A [K, lda], B [K, ldb] bf16; part [S][M][N] fp32, part_cs [S][M] fp32 (or null).
+__global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
+                                                               const uint16_t* __restrict__ B, int ldb, int K, int M,
+                                                               int N, int KC, float* __restrict__ part,
+                                                               float* __restrict__ part_cs) {
+    __shared__ __attribute__((aligned(16))) char sA[kStage * kPitch];
+    __shared__ __attribute__((aligned(16))) char sB[kStage * kPitch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt = blockIdx.x % (M / kTile), nt = blockIdx.x / (M / kTile);
+    const int m0 = mt * kTile, n0 = nt * kTile;
+    const int s = blockIdx.y;
+    const int k_begin = s * KC, k_end = min(K, k_begin + KC);
+    const int wm = wave & 1, wn = wave >> 1;   // this wave's 32 x 32 quadrant
+
+    // global -> register staging: a tile row is 64 bf16 = 8 x 16 bytes; 256 threads cover 32 rows per pass, 4 passes per stage
+    const int c16 = tid & 7, r0 = tid >> 3;
+    const uint16_t* pa = A + (size_t)(k_begin + r0) * lda + m0 + c16 * 8;
+    const uint16_t* pb = B + (size_t)(k_begin + r0) * ldb + n0 + c16 * 8;
+    // two register sets, each one stage (4 x 16 bytes per operand and thread), loaded two stages ahead of their use
+    uint4 ra[2][4], rb[2][4];
+    auto fetch = [&](int set, int ks) {   // rows k_begin + ks + r0 + 32 p
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool ok = k_begin + ks + r0 + 32 * p < k_end;
+            ra[set][p] = ok ? *reinterpret_cast<const uint4*>(pa + (size_t)(ks + 32 * p) * lda) : make_uint4(0, 0, 0, 0);
+            rb[set][p] = ok ? *reinterpret_cast<const uint4*>(pb + (size_t)(ks + 32 * p) * ldb) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stash = [&](int set) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<uint4*>(sA + (r0 + 32 * p) * kPitch + c16 * 16) = ra[set][p];
+            *reinterpret_cast<uint4*>(sB + (r0 + 32 * p) * kPitch + c16 * 16) = rb[set][p];
+        }
+    };
+
+    // transposed-read addresses: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of its 4 x 16 block; group g
+    // takes rows 4g..4g+3 (first read) and 16+4g.. (second read) of a 32-row step -- the same row assignment on both operands
+    const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+    const int row_off = (4 * g + q) * kPitch + p4 * 8;
+    const char* a_base = sA + row_off + (wm * 32) * 2;
+    const char* b_base = sB + row_off + (wn * 32) * 2;
+
+    f32x4 acc[2][2] = {};
+    f32x4 cs[2] = {};
+    const bool want_cs = part_cs != nullptr && nt == 0 && wn == 0;   // wave-uniform
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (v8i16){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
+
+    auto stage_mma = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < kStage / 32; ++kk) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = frag_from(tr_read(a_base + kk * 32 * kPitch + t * 32), tr_read(a_base + (kk * 32 + 16) * kPitch + t * 32));
+                fb[t] = frag_from(tr_read(b_base + kk * 32 * kPitch + t * 32), tr_read(b_base + (kk * 32 + 16) * kPitch + t * 32));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (want_cs) {
+                cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], ones, cs[0], 0, 0, 0);
+                cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], ones, cs[1], 0, 0, 0);
+            }
+        }
+    };
+
+    const int rows = k_end - k_begin;
+    fetch(0, 0);
+    if (kStage < rows) fetch(1, kStage);
+    for (int ks = 0; ks < rows; ks += 2 * kStage) {
+        __syncthreads();   // the previous stage's fragment reads are done
+        stash(0);
+        __syncthreads();
+        if (ks + 2 * kStage < rows) fetch(0, ks + 2 * kStage);
+        stage_mma();
+        if (ks + kStage >= rows) break;
+        __syncthreads();
+        stash(1);
+        __syncthreads();
+        if (ks + 3 * kStage < rows) fetch(1, ks + 3 * kStage);
+        stage_mma();
+    }
+
+    // accumulator tile: lane l, register r <-> row 4 (l >> 4) + r, column l & 15
+    float* out = part + (size_t)s * M * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 32 + i * 16 + 4 * g + r, col = n0 + wn * 32 + j * 16 + (lane & 15);
+                out[(size_t)row * N + col] = acc[i][j][r];
+            }
+    if (want_cs && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part_cs[(size_t)s * M + m0 + wm * 32 + i * 16 + 4 * g + r] = cs[i][r];
+    }
+}
+
+// out[i] = sum_s part[s][i] in the order s = 0, 1, ... over the n tile elements followed by the n_cs column sums (the
+// partial column sums sit behind the partial tiles, split-major).  One element per thread: the loads of one thread are
+// independent, so eight are in flight per lane; the additions keep the order.
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int S, int n, float* __restrict__ out,
+                                                          const float* __restrict__ part_cs, int n_cs, float* __restrict__ out_cs) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const float* src;
+    float* dst;
+    size_t pitch;
+    if (i < n) { src = part + i; dst = out + i; pitch = n; }
+    else if (i - n < n_cs) { i -= n; src = part_cs + i; dst = out_cs + i; pitch = n_cs; }
+    else return;
+    float t = 0.f;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * pitch];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; s < S; ++s) t += src[(size_t)s * pitch];
+    *dst = t;
+}
+
+struct TnPlan {
+    int KC, S;
+    size_t bytes;
+};
+
+TnPlan plan_tn(int K, int M, int N) {
+    const int tiles = (M / kTile) * (N / kTile);
+    int S = (512 + tiles - 1) / tiles;                              // ~2 workgroups per CU, 3 resident at a time
+    const int max_s = (K + 2 * kStage - 1) / (2 * kStage);          // at least two stages per split: both register sets in flight from the start
+    S = S < 1 ? 1 : (S > max_s ? max_s : S);
+    int KC = ((K + S - 1) / S + kStage - 1) / kStage * kStage;      // whole stages per split
+    S = (K + KC - 1) / KC;
+    return {KC, S, sizeof(float) * (size_t)S * ((size_t)M * N + M)};
+}
+
+}  // namespace
+
+}  // namespace vlg
+
+extern "C" {
+
+size_t vlg_linear_wgrad_workspace(int K, int M, int N) {
+    if (K < 1 || M < vlg::kTile || N < vlg::kTile || M % vlg::kTile || N % vlg::kTile) return 0;
+    return vlg::plan_tn(K, M, N).bytes;
+}
+
+int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes,
+                     float* d_weight, float* d_bias, void* stream) {
+    using namespace vlg;
+    if (K < 1 || M < kTile || N < kTile || M % kTile || N % kTile)
+        return set_error(VLG_ERR_SHAPE, "linear_wgrad: need K >= 1 and M, N positive multiples of %d (got K=%d M=%d N=%d)", kTile, K, M, N);
+    if (ld_dy < M || ld_x < N || ld_dy % 8 || ld_x % 8)
+        return set_error(VLG_ERR_SHAPE, "linear_wgrad: row strides must cover the columns and be multiples of 8 elements (ld_dy=%d ld_x=%d)", ld_dy, ld_x);
+    if (!dy || !x || !d_weight || !ws) return set_error(VLG_ERR_ARG, "linear_wgrad: null buffer");
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(d_weight) |
+         reinterpret_cast<uintptr_t>(d_bias) | reinterpret_cast<uintptr_t>(ws)) & 15)
+        return set_error(VLG_ERR_ARG, "linear_wgrad: buffers must be 16-byte aligned");
+    const TnPlan pl = plan_tn(K, M, N);
+    if (ws_bytes < pl.bytes) return set_error(VLG_ERR_WORKSPACE, "linear_wgrad: needs a %zu-byte workspace (got %zu)", pl.bytes, ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)ws;
+    float* part_cs = d_bias ? part + (size_t)pl.S * M * N : nullptr;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((M / kTile) * (N / kTile), pl.S), dim3(kGemmThreads), 0, s, (const uint16_t*)dy, ld_dy,
+                       (const uint16_t*)x, ld_x, K, M, N, pl.KC, part, part_cs);
+    if (int rc = check_launch("gemm_tn_kernel")) return rc;
+    const int n = M * N, n_cs = d_bias ? M : 0;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((n + n_cs + 255) / 256), dim3(256), 0, s, part, pl.S, n, d_weight, part_cs,
+                       n_cs, d_bias);
+    return check_launch("gemm_reduce_kernel");
+}
+
+}  // extern "C"

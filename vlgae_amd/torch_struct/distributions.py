@@ -132,11 +132,13 @@ class DMV1o(StructDistribution):
         dec, attach = self.log_potentials
         return F.dmv1o_decode(dec, attach, self.lengths)[1]
 
-    def marginals_and_heads(self):
+    def marginals_and_heads(self, keep_viterbi=False):
         """Extension: (`marginals`, `argmax_heads`) with the two DPs overlapped on two HIP streams -- the pair
-        lang_feat_max_tree asks for every step (joint.py:251-258)."""
+        lang_feat_max_tree asks for every step (joint.py:251-258).  keep_viterbi=True: the Viterbi pass also produces the
+        tree counts and is remembered, so a later `DMV1o(same potentials).max` (the parser's `-max` loss, ldndmv.py:277-281)
+        and its backward launch nothing (see functional.dmv1o_marginals_and_heads)."""
         dec, attach = self.log_potentials
-        _, gatt, heads = F.dmv1o_marginals_and_heads(dec, attach, self.lengths)
+        _, gatt, heads = F.dmv1o_marginals_and_heads(dec, attach, self.lengths, keep_viterbi)
         return gatt, heads
 
     @staticmethod

@@ -119,6 +119,65 @@ def dmv1o_decode(dec, attach, lengths, out=None):
     return best, heads
 
 
+def dmv1o_viterbi(dec, attach, lengths, out=None):
+    """The Max semiring's every output in one launch: (best [B], grad_dec [B,N,2,2,2], grad_attach [B,N,N,2], heads [B,N]).
+    The counts are the 0/1 indicators of the best tree (unit upstream gradient) -- what `-DMV1o(...).max.sum()`
+    back-propagates (ldndmv.py:277-281) -- and heads is `argmax` as a head vector (joint.py:256-258)."""
+    _C.require_gpu(dec, "dmv1o_viterbi")
+    B, N = dec.shape[:2]
+    if tuple(dec.shape) != (B, N, 2, 2, 2) or tuple(attach.shape) != (B, N, N, 2):
+        raise ValueError(f"dec {tuple(dec.shape)} / attach {tuple(attach.shape)}: expected [B,N,2,2,2] / [B,N,N,2]")
+    if dec.dtype != attach.dtype:
+        attach = attach.to(dec.dtype)
+    dt, dec_c = _C.in_dtype(dec)
+    _, att_c = _C.in_dtype(attach)
+    lengths = _lengths(lengths, B, dec.device)
+    if out is None:
+        best = torch.empty(B, dtype=torch.float32, device=dec.device)
+        gdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dec.device)
+        gatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dec.device)
+        heads = torch.empty((B, N), dtype=torch.int64, device=dec.device)
+    else:
+        best, gdec, gatt, heads = out
+    ws, nb = _workspace(_C.OP_DMV1O_INSIDE_OUTSIDE, B, N, _C.SEMIRING_MAX, dec.device)
+    _C.check(_C.lib().vlg_dmv1o_viterbi(_C.ptr(dec_c), _C.ptr(att_c), _C.ptr(lengths), B, N, dt, None, _C.ptr(best), _C.ptr(gdec),
+                                        _C.ptr(gatt), _C.ptr(heads), _C.ptr(ws), nb, _C.stream_of(dec)), "dmv1o_viterbi")
+    return best, gdec, gatt, heads
+
+
+# ---- one Viterbi pass per training step ------------------------------------------------------------------------------------
+# lang_feat_max_tree takes `argmax` of the step's potentials (joint.py:256) and the parser's loss takes `-max` of the SAME
+# values a few lines later (ldndmv.py:277-281, through a different DMV1o object built on `.detach()`ed aliases).  When the
+# first caller asks for it (`marginals_and_heads(keep_viterbi=True)`), the full Viterbi result is remembered here, keyed by
+# the identity of the storage it was computed from: the key tensors are kept alive (so their addresses cannot be handed to
+# other data) and their version counters are compared (so an in-place update through any alias invalidates the entry; only
+# torch operations count -- a raw pointer write by foreign code is invisible, which is why nothing is remembered unasked).
+_VITERBI = {}
+
+
+def _viterbi_key(dec, attach, lengths):
+    return (dec.data_ptr(), attach.data_ptr(), lengths.data_ptr(), dec._version, attach._version, lengths._version,
+            tuple(dec.shape), dec.dtype, tuple(dec.stride()), tuple(attach.stride()))
+
+
+def _viterbi_remember(dec, attach, lengths, result):
+    _VITERBI[dec.device] = (_viterbi_key(dec, attach, lengths), (dec.detach(), attach.detach(), lengths), result)
+
+
+def _viterbi_lookup(dec, attach, lengths):
+    if not isinstance(lengths, torch.Tensor):
+        return None
+    hit = _VITERBI.get(dec.device)
+    if hit is None or hit[0] != _viterbi_key(dec, attach, lengths):
+        return None
+    return hit[2]
+
+
+def viterbi_forget():
+    """Drop the remembered Viterbi result (and the references that keep its potentials alive)."""
+    _VITERBI.clear()
+
+
 def deptree_decode(arc, lengths=None):
     """Best projective single-root tree of arc scores [B,N,N] as heads [B,N] (see dmv1o_decode).  With `arc` = arc
     marginals this is the MBR decode of src/model/ldndmv.py:294-299."""
@@ -214,7 +273,12 @@ class _DMV1oSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dec, attach, lengths, semiring):
         want = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        logZ, gdec, gatt = dmv1o_run(dec, attach, lengths, semiring, want, logZ_shape=(dec.shape[0], 1))   # [B,1], helpers.py:116
+        hit = _viterbi_lookup(dec, attach, lengths) if semiring == _C.SEMIRING_MAX and dec.dtype != torch.float64 else None
+        if hit is not None:   # this step's Viterbi pass already ran on these very values (marginals_and_heads(keep_viterbi=True))
+            best, gdec, gatt, _ = hit
+            logZ = best.view(-1, 1)
+        else:
+            logZ, gdec, gatt = dmv1o_run(dec, attach, lengths, semiring, want, logZ_shape=(dec.shape[0], 1))   # [B,1], helpers.py:116
         if want:
             ctx.save_for_backward(gdec, gatt)
         ctx.in_dtypes = (dec.dtype, attach.dtype)
@@ -319,12 +383,16 @@ def dmv1o_merge_autograd(dec, attach, root, one=0.0, zero=NEGINF):
 _SIDE_STREAMS = {}
 
 
-def dmv1o_marginals_and_heads(dec, attach, lengths):
+def dmv1o_marginals_and_heads(dec, attach, lengths, keep_viterbi=False):
     """What lang_feat_max_tree needs from one sentence batch (joint.py:251-258): the arc marginals
     d logZ / d attach AND the Viterbi heads.  The two are independent DPs over the same potentials; at one
     workgroup per CU each leaves most of the machine idle and their LDS footprints (78 KB + 49 KB at N = 41) fit one
     CU together, so the decode runs on a side HIP stream next to the inside-outside launch and joins before returning.
-    Returns (logZ [B], marginals [B,N,N,2], heads [B,N])."""
+    Returns (logZ [B], marginals [B,N,N,2], heads [B,N]).
+
+    keep_viterbi=True (training with `viterbi_training`, ldndmv.py:277-281): the side-stream launch is the full Viterbi pass
+    (best score + tree counts + heads, 67 us instead of the 57 us walk) and its result is remembered, so the `DMV1o(...).max`
+    that the loss takes of the same potentials later in the step launches nothing."""
     _C.require_gpu(dec, "dmv1o_marginals_and_heads")
     cur = torch.cuda.current_stream(dec.device)
     side = _SIDE_STREAMS.get(dec.device)
@@ -337,9 +405,18 @@ def dmv1o_marginals_and_heads(dec, attach, lengths):
     B, N = dec.shape[:2]
     best = torch.empty(B, dtype=torch.float32, device=dec.device)
     heads = torch.empty((B, N), dtype=torch.int64, device=dec.device)
+    if keep_viterbi:
+        vdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dec.device)
+        vatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dec.device)
+        lengths = _lengths(lengths, B, dec.device)
     side.wait_stream(cur)                       # the potentials are produced on the current stream
     with torch.cuda.stream(side):
-        dmv1o_decode(dec, attach, lengths, out=(best, heads))
+        if keep_viterbi:
+            dmv1o_viterbi(dec, attach, lengths, out=(best, vdec, vatt, heads))
+        else:
+            dmv1o_decode(dec, attach, lengths, out=(best, heads))
     logZ, _, gatt = dmv1o_run(dec, attach, lengths, _C.SEMIRING_LOG, True, want_dec=False)
     cur.wait_stream(side)
+    if keep_viterbi:
+        _viterbi_remember(dec, attach, lengths, (best, vdec, vatt, heads))
     return logZ, gatt, heads
