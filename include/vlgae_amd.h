@@ -257,12 +257,14 @@ int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* 
  * (joint.py:136-138,175):   d_weight[M(out), N(in)] = dy^T x,   d_bias[M] = sum_rows dy.
  *   dy [K, ld_dy] (first M columns used), x [K, ld_x] (first N columns used): bf16, row-major, K = B*N token rows;
  *   M and N multiples of 64, row strides multiples of 8 elements, all buffers 16-byte aligned.
- *   d_weight [M, N] fp32, d_bias [M] fp32 or NULL.  ws: vlg_linear_wgrad_workspace(K, M, N) bytes (0 = unsupported shape).
+ *   d_weight [M, N] fp32, d_bias [M] fp32 or NULL; x_colsum [N] fp32 or NULL = sum_rows x (the bias gradient when the roles
+ *   are swapped: a weight stored [in, out] as in `matmul(child + parent, arc_encoder_w2) + arc_encoder_b`, joint.py:285-286,
+ *   takes dy := the layer input and x := the cotangent).  ws: vlg_linear_wgrad_workspace(K, M, N) bytes (0 = unsupported shape).
  * Split over the token rows across the whole chip (bf16 MFMA, fp32 accumulate); partial tiles are added in a fixed
  * order: bit-reproducible, no atomics. */
 size_t vlg_linear_wgrad_workspace(int K, int M, int N);
 int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes,
-                     float* d_weight, float* d_bias, void* stream);
+                     float* d_weight, float* d_bias, float* x_colsum, void* stream);
 
 /* The byte work of `lang_feat_max_tree` (src/model/joint.py:235-292) between the DP, the encoder GEMMs and the arc encoder.
  * Shapes: B sentences, L words, N = L + 1 positions (root first), h encoder width, d matching width; M = B*N rows.
@@ -272,7 +274,7 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
  *                     txt[b,n,:] = word third (txt is [B,2N,d] bf16, the word half, :288), child [M,d] = LeakyReLU(child third),
  *                     parent [M,d] = LeakyReLU(parent third of row heads[b,n]) (gather by the predicted heads, :271-273),
  *                     sum [M,d] = child + parent (optional; the operand of the affine term, :285)
- *   split_backward    d_txt [B,2N,d] (dtype; the word half is read), d_child / d_parent fp32 [M,d], d_sum fp32 [M,d] or NULL
+ *   split_backward    d_txt [B,2N,d] (dtype; the word half is read), d_child / d_parent fp32 [M,d], d_sum [M,d] (d_sum_dtype) or NULL
  *                     (added to both), child / parent (activations, bf16) -> d_pre [M,3d] bf16 (LeakyReLU', scatter-add by head
  *                     in ascending row order)
  *   marginal          grad_attach [B,N,N,2] fp32, heads [B,N], lengths [B] -> txt_marginal [B,2N] fp32 = cat([mask,
@@ -284,9 +286,9 @@ int vlg_langfeat_root_cat_backward(const void* d_x1, const int64_t* lengths, int
                                    void* stream);
 int vlg_langfeat_split(const void* pre, const int64_t* heads, int B, int N, int d, float slope, void* txt, void* child,
                        void* parent, void* sum, void* stream);
-int vlg_langfeat_split_backward(const void* d_txt, int d_txt_dtype, const float* d_child, const float* d_parent, const float* d_sum,
-                                const void* child, const void* parent, const int64_t* heads, int B, int N, int d, float slope,
-                                void* d_pre, void* stream);
+int vlg_langfeat_split_backward(const void* d_txt, int d_txt_dtype, const float* d_child, const float* d_parent, const void* d_sum,
+                                int d_sum_dtype, const void* child, const void* parent, const int64_t* heads, int B, int N, int d,
+                                float slope, void* d_pre, void* stream);
 int vlg_langfeat_marginal(const float* grad_attach, const int64_t* heads, const int64_t* lengths, int B, int N, int use_marginal,
                           float* txt_marginal, uint8_t* txt_mask, void* stream);
 int vlg_langfeat_arc_out(const float* tri, const void* aff, int B, int N, int d, void* txt, void* stream);

@@ -556,25 +556,30 @@ def box_rel(feat, weight, bias, slope=0.01, img_feat=True, dout=None):
 # Encoder projection, src/model/nn/common.py:23-51 (`MLP`: Linear -> LeakyReLU; dropout is the identity at p = 0 / eval) as
 # the word / child / parent encoders of src/model/joint.py:270-277 apply it to all token rows (numpy, fp64), and its adjoint.
 # ----------------------------------------------------------------------------------------------
-def mlp(x, weight, bias=None, slope=0.01, dout=None):
+def mlp(x, weight, bias=None, slope=0.01, dout=None, branch=None):
     """x [..., n_in], weight [n_out, n_in], bias [n_out] -> y [..., n_out]; slope None = no activation (activate=False).
-    With dout [..., n_out] also (g_x, g_weight, g_bias)."""
+    With dout [..., n_out] also (g_x, g_weight, g_bias).  branch [..., n_out] bool: take LeakyReLU's positive branch where
+    true instead of where pre > 0 -- the adjoint of the function a reduced-precision path evaluated, whose pre-activations
+    within rounding of zero can sit on the other side."""
     x, weight = np.asarray(x, dtype=np.float64), np.asarray(weight, dtype=np.float64)
     pre = x @ weight.T                                                              # common.py:48
     if bias is not None:
         pre = pre + np.asarray(bias, dtype=np.float64)
-    y = pre if slope is None else np.where(pre > 0, pre, pre * slope)               # common.py:49
+    pos = (pre > 0) if branch is None else np.asarray(branch, dtype=bool)
+    y = pre if slope is None else np.where(pos, pre, pre * slope)                   # common.py:49
     if dout is None:
         return y
-    g_pre = np.asarray(dout, dtype=np.float64) * (1.0 if slope is None else np.where(pre > 0, 1.0, slope))
+    g_pre = np.asarray(dout, dtype=np.float64) * (1.0 if slope is None else np.where(pos, 1.0, slope))
     g2, x2 = g_pre.reshape(-1, weight.shape[0]), x.reshape(-1, weight.shape[1])
     return y, g_pre @ weight, g2.T @ x2, g2.sum(0)
 
 
-def lang_feat(x, lengths, heads, w_word, b_word, w_child, b_child, w_parent, b_parent, w1, w2, b_arc, slope=0.01, dout=None):
+def lang_feat(x, lengths, heads, w_word, b_word, w_child, b_child, w_parent, b_parent, w1, w2, b_arc, slope=0.01, dout=None,
+              child_branch=None, parent_branch=None):
     """joint.py:262-288 (the feature half of lang_feat_max_tree), fp64: root = masked mean, x = cat([root, x]), word /
     child / parent encoders (parent on x gathered by the predicted heads), arc_repr, txt = cat([word_repr, arc_repr]).
-    x [B,L,h], lengths [B], heads [B,L+1] -> txt [B,2(L+1),d]; with dout also the gradients, as a dict by parameter name."""
+    x [B,L,h], lengths [B], heads [B,L+1] -> txt [B,2(L+1),d]; with dout also the gradients, as a dict by parameter name.
+    child_branch / parent_branch [B,L+1,d] bool: LeakyReLU branches to take (see `mlp`)."""
     x = np.asarray(x, dtype=np.float64)
     lengths, heads = np.asarray(lengths), np.asarray(heads)
     B, L, h = x.shape
@@ -584,8 +589,8 @@ def lang_feat(x, lengths, heads, w_word, b_word, w_child, b_child, w_parent, b_p
     x1 = np.concatenate([root[:, None], x], 1)                                        # :266
     xg = np.take_along_axis(x1, heads[..., None], 1)                                  # :271-273
     word = mlp(x1, w_word, b_word, None)                                              # :267 (activate: false)
-    child = mlp(x1, w_child, b_child, slope)                                          # :269
-    parent = mlp(xg, w_parent, b_parent, slope)                                       # :270
+    child = mlp(x1, w_child, b_child, slope, branch=child_branch)                     # :269
+    parent = mlp(xg, w_parent, b_parent, slope, branch=parent_branch)                 # :270
     arc = arc_encoder(child, parent, w1, w2, b_arc, np.float64)                       # :278-286
     txt = np.concatenate([word, arc], 1)                                              # :288
     if dout is None:
@@ -593,8 +598,8 @@ def lang_feat(x, lengths, heads, w_word, b_word, w_child, b_child, w_parent, b_p
     dout = np.asarray(dout, dtype=np.float64)
     d_child, d_parent, d_w1, d_w2, d_b = arc_encoder_backward(child, parent, w1, w2, dout[:, N:], np.float64)
     _, gx_w, g_ww, g_bw = mlp(x1, w_word, b_word, None, dout[:, :N])
-    _, gx_c, g_wc, g_bc = mlp(x1, w_child, b_child, slope, d_child)
-    _, gx_p, g_wp, g_bp = mlp(xg, w_parent, b_parent, slope, d_parent)
+    _, gx_c, g_wc, g_bc = mlp(x1, w_child, b_child, slope, d_child, child_branch)
+    _, gx_p, g_wp, g_bp = mlp(xg, w_parent, b_parent, slope, d_parent, parent_branch)
     g_x1 = gx_w + gx_c
     for b in range(B):
         np.add.at(g_x1[b], heads[b], gx_p[b])

@@ -1432,34 +1432,31 @@ def _langfeat_params(g, device, dtype=torch.float32):
 
 
 def _langfeat_grad_close(got, ref, name, tol):
-    """Gradients that pass through LeakyReLU' (x, the child / parent encoders' parameters) are discontinuous in the
-    pre-activations: a pre-activation within bf16 rounding of zero takes the other branch than in the fp32 reference and its
-    term changes by the factor 1 / slope.  A handful of the ~10^4 pre-activations do (|pre| < 4e-3 |pre|_typ), so those
-    tensors are held to the tolerance in relative L2 norm and to 5x the tolerance element-wise; the others (word encoder, arc
-    encoder: continuous in everything) to the tolerance element-wise."""
-    scale = max(1e-6, float(np.abs(ref).max()))
-    err = np.abs(got.astype(np.float64) - ref)
-    if name in ("x", "w_child", "b_child", "w_parent", "b_parent", "w_enc", "b_enc"):
-        assert float(np.linalg.norm(err)) <= tol * max(1e-6, float(np.linalg.norm(ref))), name
-        assert float(err.max()) <= 5 * tol * max(1.0, scale), name
-    else:
-        assert float(err.max()) <= tol * max(1.0, scale), name
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(got.astype(np.float64) - ref).max()) <= tol * scale, name
 
 
 @pytest.mark.parametrize("path", golden_files("langfeat_"), ids=golden_ids("langfeat_"))
-def test_lang_feat_max_tree_golden(ts, path):
+def test_lang_feat_max_tree_golden(ts, oracle_mod, path):
     """vlgae_amd.langfeat.lang_feat_max_tree against the reference's own method (joint.py:235-292) and torch autograd through
     it.  The path computes in bf16 with fp32 accumulation: tolerance 2e-2 of the largest reference magnitude per tensor
-    (bf16 has 8 mantissa bits: 4e-3 per rounding, a handful of roundings per path); masks, heads exact; marginals 5e-5."""
+    (bf16 has 8 mantissa bits: 4e-3 per rounding, a handful of roundings per path); masks, heads exact; marginals 5e-5.
+    Gradients through LeakyReLU' are discontinuous in the pre-activations: one that is within bf16 rounding of zero takes the
+    other branch than in the fp32 reference and its term changes by the factor 1 / slope.  So the gradients are held (a) to
+    the tolerance against the oracle's adjoint evaluated on the branches the device took (the oracle itself is pinned on the
+    reference's gradients in tests/test_oracle_golden.py), with at most 1 % of the branches differing from the reference's,
+    and (b) to 8e-2 in relative L2 norm against the reference's own gradients."""
     from vlgae_amd import langfeat
-    from conftest import arcenc_check_w1_grad
+    from conftest import arcenc_check_w1_grad, arcenc_w1
     g = load(path)
     x = t(g["x"]).requires_grad_(True)
     lengths = t(g["lengths"])
     params = _langfeat_params(g, dev())
+    aux = {}
     txt, txt_mask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, t(g["merged_dec"]), t(g["merged_attach"]), *params,
-                                                               add_marginal=bool(g["add_marginal"]), slope=float(g["slope"]))
+                                                               add_marginal=bool(g["add_marginal"]), slope=float(g["slope"]), aux=aux)
     assert txt.dtype == torch.bfloat16 and tuple(txt.shape) == g["txt"].shape
+    assert (aux["heads"].cpu().numpy() == g["predicted"]).all()
     assert (txt_mask.cpu().numpy() == g["txt_mask"]).all()
     assert np.abs(txt_marginal.cpu().numpy() - g["txt_marginal"]).max() <= MARG_TOL
     tol = 2e-2
@@ -1468,9 +1465,24 @@ def test_lang_feat_max_tree_golden(ts, path):
     d = g["w2"].shape[0]
     got = {"x": grads[0], "w_word": grads[1][:d], "w_child": grads[1][d:2 * d], "w_parent": grads[1][2 * d:], "b_word": grads[2][:d],
            "b_child": grads[2][d:2 * d], "b_parent": grads[2][2 * d:], "w2": grads[4], "b_arc": grads[5]}
+    cb, pb = (aux[k].float().cpu().numpy() > 0 for k in ("child", "parent"))
+    w1 = arcenc_w1(g)
+    _, og = oracle_mod.lang_feat(g["x"], g["lengths"], g["predicted"], g["w_word"], g["b_word"], g["w_child"], g["b_child"],
+                                 g["w_parent"], g["b_parent"], w1, g["w2"], g["b_arc"], float(g["slope"]), g["dout"], cb, pb)
+    _, og_ref = oracle_mod.lang_feat(g["x"], g["lengths"], g["predicted"], g["w_word"], g["b_word"], g["w_child"], g["b_child"],
+                                     g["w_parent"], g["b_parent"], w1, g["w2"], g["b_arc"], float(g["slope"]), g["dout"])
     for k, v in got.items():
-        _langfeat_grad_close(v.float().cpu().numpy(), g["g_" + k], k, tol)
+        v = v.float().cpu().numpy()
+        _langfeat_grad_close(v, og[k], k, tol)
+        ref = g["g_" + k]
+        assert np.linalg.norm(v - ref) <= 8e-2 * np.linalg.norm(ref), k
+    _langfeat_grad_close(grads[3].float().cpu().numpy(), og["w1"], "w1", tol)
     arcenc_check_w1_grad(grads[3].float().cpu().numpy(), g, tol)
+    # the branches differ from the fp32 reference's on a handful of near-zero pre-activations only
+    x1 = np.concatenate([(g["x"] * (np.arange(g["x"].shape[1])[None] < g["lengths"][:, None])[..., None]).sum(1, keepdims=True)
+                         / g["lengths"][:, None, None], g["x"]], 1).astype(np.float64)
+    ref_cb = x1 @ g["w_child"].T.astype(np.float64) + g["b_child"] > 0
+    assert (ref_cb != cb).mean() <= 0.01
 
 
 def test_lang_feat_max_tree_config_size(ts, oracle_mod):
@@ -1495,7 +1507,8 @@ def test_lang_feat_max_tree_config_size(ts, oracle_mod):
     lengths = lengths.to(dev())
     params = [w_enc, b_enc, w1, w2, b_arc]
     F.viterbi_forget()
-    txt, txt_mask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, md, ma, *params, keep_viterbi=True)
+    aux = {}
+    txt, txt_mask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, md, ma, *params, keep_viterbi=True, aux=aux)
     dout = (torch.randn(B, 2 * (L + 1), d, generator=g).to(dev()) * txt_mask.unsqueeze(-1)).to(bf)
     grads = torch.autograd.grad(txt, [x] + params, dout)
     # the Viterbi pass is remembered: .max of a detached alias of the same potentials reuses it and matches a fresh launch
@@ -1523,14 +1536,19 @@ def test_lang_feat_max_tree_config_size(ts, oracle_mod):
     S = 6
     f64 = lambda a: a.detach().float().cpu().numpy().astype(np.float64)
     wn, bn = f64(w_enc), f64(b_enc)
+    cb, pb = (aux[k][:S].float().cpu().numpy() > 0 for k in ("child", "parent"))      # the LeakyReLU branches the device took
     otxt, og = oracle_mod.lang_feat(f64(x)[:S], lengths[:S].cpu().numpy(), heads[:S].cpu().numpy(), wn[:d], bn[:d], wn[d:2 * d], bn[d:2 * d],
-                                    wn[2 * d:], bn[2 * d:], f64(w1), f64(w2), f64(b_arc), 0.01, f64(dout)[:S])
+                                    wn[2 * d:], bn[2 * d:], f64(w1), f64(w2), f64(b_arc), 0.01, f64(dout)[:S], cb, pb)
     tol = 2e-2
     assert np.abs(f64(txt)[:S] - otxt).max() <= tol * np.abs(otxt).max()
     _langfeat_grad_close(f64(grads[0])[:S], og["x"], "x", tol)
     # parameter gradients are sums over sentences: the batch run on the first S sentences alone must match the oracle's
     xs = x[:S].detach().requires_grad_(True)
-    txt_s, _, _ = langfeat.lang_feat_max_tree(xs, lengths[:S].contiguous(), md[:S].contiguous(), ma[:S].contiguous(), *params)
+    aux_s = {}
+    txt_s, _, _ = langfeat.lang_feat_max_tree(xs, lengths[:S].contiguous(), md[:S].contiguous(), ma[:S].contiguous(), *params, aux=aux_s)
+    cb, pb = (aux_s[k].float().cpu().numpy() > 0 for k in ("child", "parent"))      # (a smaller GEMM may round differently)
+    _, og = oracle_mod.lang_feat(f64(x)[:S], lengths[:S].cpu().numpy(), heads[:S].cpu().numpy(), wn[:d], bn[:d], wn[d:2 * d], bn[d:2 * d],
+                                 wn[2 * d:], bn[2 * d:], f64(w1), f64(w2), f64(b_arc), 0.01, f64(dout)[:S], cb, pb)
     gs = torch.autograd.grad(txt_s, [xs] + params, dout[:S])
     for name, got, ref in (("w_enc", gs[1], np.concatenate([og["w_word"], og["w_child"], og["w_parent"]])),
                            ("b_enc", gs[2], np.concatenate([og["b_word"], og["b_child"], og["b_parent"]])), ("w1", gs[3], og["w1"]),

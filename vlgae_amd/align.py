@@ -526,8 +526,10 @@ def arc_encoder(child_repr, parent_repr, arc_encoder_w1, arc_encoder_w2, arc_enc
 # ----------------------------------------------------------------------------------------------
 # Encoder projections around the contraction (MLP, src/model/nn/common.py:23-51; joint.py:136-138,175,270-277)
 # ----------------------------------------------------------------------------------------------
-def linear_wgrad(dy, x, want_bias=True):
+def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None):
     """Weight / bias gradient of `y = x @ weight.T + bias` over all token rows: (dy^T x [out, in], sum_rows dy [out]), float32.
+    want_x_colsum: the second result is sum_rows x [in] instead (a weight stored [in, out]: pass the layer input as dy and the
+    cotangent as x).  out = (d_weight, second) writes into caller-owned float32 tensors.
 
     dy [K, out], x [K, in]: bf16, row-major (row strides that are multiples of 8 elements are taken in place -- column
     slices of wider buffers), out and in multiples of 64.  Split over the rows across the whole chip, fixed summation
@@ -544,9 +546,15 @@ def linear_wgrad(dy, x, want_bias=True):
     nbytes = _C.lib().vlg_linear_wgrad_workspace(K, M, N)
     if nbytes == 0:
         raise ValueError(f"linear_wgrad: unsupported shape K={K} out={M} in={N} (out, in must be multiples of 64)")
-    (dw, db), ws = _C.alloc_f32(dy.device, ((M, N), (M,) if want_bias else None), nbytes)
+    second = (N,) if want_x_colsum else ((M,) if want_bias else None)
+    if out is None:
+        (dw, db), ws = _C.alloc_f32(dy.device, ((M, N), second), nbytes)
+    else:
+        dw, db = out
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     _C.check(_C.lib().vlg_linear_wgrad(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, _C.ptr(ws), nbytes,
-                                       _C.ptr(dw), _C.ptr(db), _C.stream_of(dy)), "linear_wgrad")
+                                       _C.ptr(dw), None if want_x_colsum else _C.ptr(db), _C.ptr(db) if want_x_colsum else None,
+                                       _C.stream_of(dy)), "linear_wgrad")
     return dw, db
 
 

@@ -45,7 +45,7 @@ __device__ __forceinline__ bf16x8 frag_from(v4i16 lo, v4i16 hi) {
 __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
                                                                const uint16_t* __restrict__ B, int ldb, int K, int M,
                                                                int N, int KC, float* __restrict__ part,
-                                                               float* __restrict__ part_cs) {
+                                                               float* __restrict__ part_cs, float* __restrict__ part_csb) {
     __shared__ __attribute__((aligned(16))) char sA[kStage * kPitch];
     __shared__ __attribute__((aligned(16))) char sB[kStage * kPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,7 +86,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
 
     f32x4 acc[2][2] = {};
     f32x4 cs[2] = {};
+    f32x4 csb[2] = {};
     const bool want_cs = part_cs != nullptr && nt == 0 && wn == 0;   // wave-uniform
+    const bool want_csb = part_csb != nullptr && mt == 0 && wm == 0;
     typedef short v8i16 __attribute__((ext_vector_type(8)));
     const bf16x8 ones = __builtin_bit_cast(bf16x8, (v8i16){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
@@ -106,6 +108,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
             if (want_cs) {
                 cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], ones, cs[0], 0, 0, 0);
                 cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], ones, cs[1], 0, 0, 0);
+            }
+            if (want_csb) {   // ones^T B: every row of the result tile is the column sum
+                csb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[0], csb[0], 0, 0, 0);
+                csb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[1], csb[1], 0, 0, 0);
             }
         }
     };
@@ -144,19 +150,25 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) part_cs[(size_t)s * M + m0 + wm * 32 + i * 16 + 4 * g + r] = cs[i][r];
     }
+    if (want_csb && lane < 16) {   // row 0 of the tile: lanes 0..15, register 0
+#pragma unroll
+        for (int j = 0; j < 2; ++j) part_csb[(size_t)s * N + n0 + wn * 32 + j * 16 + lane] = csb[j][0];
+    }
 }
 
 // out[i] = sum_s part[s][i] in the order s = 0, 1, ... over the n tile elements followed by the n_cs column sums (the
 // partial column sums sit behind the partial tiles, split-major).  One element per thread: the loads of one thread are
 // independent, so eight are in flight per lane; the additions keep the order.
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int S, int n, float* __restrict__ out,
-                                                          const float* __restrict__ part_cs, int n_cs, float* __restrict__ out_cs) {
+                                                          const float* __restrict__ part_cs, int n_cs, float* __restrict__ out_cs,
+                                                          const float* __restrict__ part_csb, int n_csb, float* __restrict__ out_csb) {
     int i = blockIdx.x * 256 + threadIdx.x;
     const float* src;
     float* dst;
     size_t pitch;
     if (i < n) { src = part + i; dst = out + i; pitch = n; }
     else if (i - n < n_cs) { i -= n; src = part_cs + i; dst = out_cs + i; pitch = n_cs; }
+    else if (i - n - n_cs < n_csb) { i -= n + n_cs; src = part_csb + i; dst = out_csb + i; pitch = n_csb; }
     else return;
     float t = 0.f;
     int s = 0;
@@ -183,7 +195,7 @@ TnPlan plan_tn(int K, int M, int N) {
     S = S < 1 ? 1 : (S > max_s ? max_s : S);
     int KC = ((K + S - 1) / S + kStage - 1) / kStage * kStage;      // whole stages per split
     S = (K + KC - 1) / KC;
-    return {KC, S, sizeof(float) * (size_t)S * ((size_t)M * N + M)};
+    return {KC, S, sizeof(float) * (size_t)S * ((size_t)M * N + M + N)};
 }
 
 }  // namespace
@@ -198,7 +210,7 @@ size_t vlg_linear_wgrad_workspace(int K, int M, int N) {
 }
 
 int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes,
-                     float* d_weight, float* d_bias, void* stream) {
+                     float* d_weight, float* d_bias, float* x_colsum, void* stream) {
     using namespace vlg;
     if (K < 1 || M < kTile || N < kTile || M % kTile || N % kTile)
         return set_error(VLG_ERR_SHAPE, "linear_wgrad: need K >= 1 and M, N positive multiples of %d (got K=%d M=%d N=%d)", kTile, K, M, N);
@@ -206,19 +218,20 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
         return set_error(VLG_ERR_SHAPE, "linear_wgrad: row strides must cover the columns and be multiples of 8 elements (ld_dy=%d ld_x=%d)", ld_dy, ld_x);
     if (!dy || !x || !d_weight || !ws) return set_error(VLG_ERR_ARG, "linear_wgrad: null buffer");
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(d_weight) |
-         reinterpret_cast<uintptr_t>(d_bias) | reinterpret_cast<uintptr_t>(ws)) & 15)
+         reinterpret_cast<uintptr_t>(d_bias) | reinterpret_cast<uintptr_t>(x_colsum) | reinterpret_cast<uintptr_t>(ws)) & 15)
         return set_error(VLG_ERR_ARG, "linear_wgrad: buffers must be 16-byte aligned");
     const TnPlan pl = plan_tn(K, M, N);
     if (ws_bytes < pl.bytes) return set_error(VLG_ERR_WORKSPACE, "linear_wgrad: needs a %zu-byte workspace (got %zu)", pl.bytes, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)ws;
     float* part_cs = d_bias ? part + (size_t)pl.S * M * N : nullptr;
+    float* part_csb = x_colsum ? part + (size_t)pl.S * ((size_t)M * N + M) : nullptr;
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((M / kTile) * (N / kTile), pl.S), dim3(kGemmThreads), 0, s, (const uint16_t*)dy, ld_dy,
-                       (const uint16_t*)x, ld_x, K, M, N, pl.KC, part, part_cs);
+                       (const uint16_t*)x, ld_x, K, M, N, pl.KC, part, part_cs, part_csb);
     if (int rc = check_launch("gemm_tn_kernel")) return rc;
-    const int n = M * N, n_cs = d_bias ? M : 0;
-    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((n + n_cs + 255) / 256), dim3(256), 0, s, part, pl.S, n, d_weight, part_cs,
-                       n_cs, d_bias);
+    const int n = M * N, n_cs = d_bias ? M : 0, n_csb = x_colsum ? N : 0;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((n + n_cs + n_csb + 255) / 256), dim3(256), 0, s, part, pl.S, n, d_weight, part_cs,
+                       n_cs, d_bias, part_csb, n_csb, x_colsum);
     return check_launch("gemm_reduce_kernel");
 }
 

@@ -108,10 +108,10 @@ __global__ __launch_bounds__(256) void langfeat_split_kernel(const uint16_t* __r
 // grid = B.  The scatter-add over the children of a head is a gather over the sentence's rows in ascending order (fixed
 // summation order, no atomics).  LDS: [N][d] fp32 + N ints.
 constexpr int kSplitBwdThreads = 1024;
-template <typename T1>
+template <typename T1, typename T2>
 __global__ __launch_bounds__(kSplitBwdThreads) void langfeat_split_bwd_kernel(
     const T1* __restrict__ d_txt, const float* __restrict__ d_child, const float* __restrict__ d_parent,
-    const float* __restrict__ d_sum, const uint16_t* __restrict__ child, const uint16_t* __restrict__ parent,
+    const T2* __restrict__ d_sum, const uint16_t* __restrict__ child, const uint16_t* __restrict__ parent,
     const int64_t* __restrict__ heads, int N, int d, float slope, uint16_t* __restrict__ d_pre) {
     extern __shared__ float gbuf[];   // [N][d] parent-third cotangents before the scatter, then N head indices
     int* hd = reinterpret_cast<int*>(gbuf + N * d);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kSplitBwdThreads) void langfeat_split_bwd_kernel(
             const int i = min(i0 + u * kSplitBwdThreads, N * d - 1);
             const int n = i / d, c = i - n * d;
             const size_t m = m0 + n;
-            ex[u] = d_sum ? d_sum[m * d + c] : 0.f;
+            ex[u] = d_sum ? ldf(d_sum, m * d + c) : 0.f;
             gw[u] = ldf(d_txt, ((size_t)b * 2 * N + n) * d + c);
             gc[u] = d_child[m * d + c];
             gp[u] = d_parent[m * d + c];
@@ -246,22 +246,30 @@ int vlg_langfeat_split(const void* pre, const int64_t* heads, int B, int N, int 
     return check_launch("langfeat_split_kernel");
 }
 
-int vlg_langfeat_split_backward(const void* d_txt, int d_txt_dtype, const float* d_child, const float* d_parent, const float* d_sum,
-                                const void* child, const void* parent, const int64_t* heads, int B, int N, int d, float slope,
-                                void* d_pre, void* stream) {
+int vlg_langfeat_split_backward(const void* d_txt, int d_txt_dtype, const float* d_child, const float* d_parent, const void* d_sum,
+                                int d_sum_dtype, const void* child, const void* parent, const int64_t* heads, int B, int N, int d,
+                                float slope, void* d_pre, void* stream) {
     using namespace vlg;
     if (B < 0 || N < 2 || d < 1) return set_error(VLG_ERR_SHAPE, "langfeat_split_backward: bad shape B=%d N=%d d=%d", B, N, d);
-    if (d_txt_dtype != VLG_F32 && d_txt_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "langfeat_split_backward: dtype %d", d_txt_dtype);
+    if ((d_txt_dtype != VLG_F32 && d_txt_dtype != VLG_BF16) || (d_sum && d_sum_dtype != VLG_F32 && d_sum_dtype != VLG_BF16))
+        return set_error(VLG_ERR_DTYPE, "langfeat_split_backward: dtypes %d / %d", d_txt_dtype, d_sum_dtype);
     if ((size_t)N * (d + 1) * sizeof(float) > 64 * 1024) return set_error(VLG_ERR_SHAPE, "langfeat_split_backward: N*d = %d exceeds the 64 KB LDS tile", N * d);
     if (B == 0) return 0;
     if (!d_txt || !d_child || !d_parent || !child || !parent || !heads || !d_pre) return set_error(VLG_ERR_ARG, "langfeat_split_backward: null buffer");
     const size_t lds = sizeof(float) * (size_t)N * (d + 1);
-    if (d_txt_dtype == VLG_F32)
-        hipLaunchKernelGGL(langfeat_split_bwd_kernel<float>, dim3(B), dim3(kSplitBwdThreads), lds, (hipStream_t)stream, (const float*)d_txt, d_child,
-                           d_parent, d_sum, (const uint16_t*)child, (const uint16_t*)parent, heads, N, d, slope, (uint16_t*)d_pre);
+    const uint16_t *c = (const uint16_t*)child, *p = (const uint16_t*)parent;
+    uint16_t* o = (uint16_t*)d_pre;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(B), block(kSplitBwdThreads);
+    const bool t32 = d_txt_dtype == VLG_F32, s32 = !d_sum || d_sum_dtype == VLG_F32;
+    if (t32 && s32)
+        hipLaunchKernelGGL((langfeat_split_bwd_kernel<float, float>), grid, block, lds, s, (const float*)d_txt, d_child, d_parent, (const float*)d_sum, c, p, heads, N, d, slope, o);
+    else if (t32)
+        hipLaunchKernelGGL((langfeat_split_bwd_kernel<float, uint16_t>), grid, block, lds, s, (const float*)d_txt, d_child, d_parent, (const uint16_t*)d_sum, c, p, heads, N, d, slope, o);
+    else if (s32)
+        hipLaunchKernelGGL((langfeat_split_bwd_kernel<uint16_t, float>), grid, block, lds, s, (const uint16_t*)d_txt, d_child, d_parent, (const float*)d_sum, c, p, heads, N, d, slope, o);
     else
-        hipLaunchKernelGGL(langfeat_split_bwd_kernel<uint16_t>, dim3(B), dim3(kSplitBwdThreads), lds, (hipStream_t)stream, (const uint16_t*)d_txt,
-                           d_child, d_parent, d_sum, (const uint16_t*)child, (const uint16_t*)parent, heads, N, d, slope, (uint16_t*)d_pre);
+        hipLaunchKernelGGL((langfeat_split_bwd_kernel<uint16_t, uint16_t>), grid, block, lds, s, (const uint16_t*)d_txt, d_child, d_parent, (const uint16_t*)d_sum, c, p, heads, N, d, slope, o);
     return check_launch("langfeat_split_bwd_kernel");
 }
 

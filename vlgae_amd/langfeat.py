@@ -35,7 +35,7 @@ class _LangFeat(torch.autograd.Function):
     """x [B,L,h], heads [B,N] -> txt [B,2N,d] bf16 (word_repr | arc_repr), differentiable in x and every parameter."""
 
     @staticmethod
-    def forward(ctx, x, lengths, heads, w_enc, b_enc, w1, w2, b_arc, slope):
+    def forward(ctx, x, lengths, heads, w_enc, b_enc, w1, w2, b_arc, slope, aux):
         B, L, h = x.shape
         N, d = L + 1, w_enc.shape[0] // 3
         M, dev, lib = B * N, x.device, _C.lib()
@@ -56,6 +56,8 @@ class _LangFeat(torch.autograd.Function):
         w2_c = w2.detach().to(bf)
         aff = torch.addmm(b_arc.detach().to(bf), cps, w2_c)                                # (child + parent) w2 + b
         _C.check(lib.vlg_langfeat_arc_out(_C.ptr(tri), _C.ptr(aff), B, N, d, _C.ptr(txt), st), "langfeat_arc_out")
+        if aux is not None:   # inspection (tests): the encoders' activations, whose signs are the LeakyReLU branches the adjoint takes
+            aux.update(child=child.view(B, N, d), parent=parent.view(B, N, d))
         ctx.save_for_backward(x1, child, parent, cps, heads, lengths, w_enc_c, w1_c, w2_c)
         ctx.meta = (B, L, h, d, float(slope), x.dtype, w_enc.dtype, b_enc.dtype, w1.dtype, w2.dtype, b_arc.dtype)
         return txt
@@ -70,35 +72,43 @@ class _LangFeat(torch.autograd.Function):
         bf = torch.bfloat16
         if d_txt.dtype not in (torch.float32, bf) or not d_txt.is_contiguous():
             d_txt = d_txt.to(bf).contiguous()
-        # ---- arc half: g = d arc_repr [M,d] ----
-        g32 = d_txt[:, N:, :].to(torch.float32).reshape(M, d)                             # the trilinear adjoint takes fp32 rows
+        # every parameter gradient lives in one fp32 allocation: a single cast launch at the end
         nbytes = lib.vlg_trilinear_backward_workspace(M, d, d, d, _C.BF16)
-        (d_child, d_w1, d_parent), ws = _C.alloc_f32(dev, ((M, d), (d, d, d), (M, d)), nbytes)
+        outs, ws = _C.alloc_f32(dev, ((3 * d, h), (3 * d,), (d, d, d), (d, d), (d,), (M, d), (M, d)), nbytes)
+        d_wenc, d_benc, d_w1, d_w2, d_barc, d_child, d_parent = outs
+        # ---- arc half: g = d arc_repr [M,d] ----
+        gb = d_txt[:, N:, :].to(bf).reshape(M, d) if d_txt.dtype != bf else d_txt[:, N:, :].reshape(M, d)   # one contiguous copy
+        g32 = gb.float()                                                                    # the trilinear adjoint takes fp32 rows
         _C.check(lib.vlg_trilinear_backward(_C.ptr(child), _C.ptr(w1_c), _C.ptr(parent), _C.ptr(g32), M, d, d, d, _C.BF16,
                                             _C.ptr(ws), nbytes, _C.ptr(d_child), _C.ptr(d_w1), _C.ptr(d_parent), st), "trilinear_backward")
-        gb = d_txt[:, N:, :].reshape(M, d) if d_txt.dtype == bf else g32.to(bf)             # affine term: bf16 operands
-        if gb.stride(0) % 8 or gb.stride(1) != 1:
-            gb = gb.contiguous()
-        d_sum = (gb @ w2_c.t()).float()                                                    # d (child + parent)
-        d_w2, d_barc = _wgrad2(cps, gb)                                                     # w2 [in,out] = (x^T dy): roles swapped
+        d_sum = gb @ w2_c.t()                                                               # d (child + parent), bf16
+        if _wgrad_ok(M, d, d, bf):
+            linear_wgrad(cps, gb, want_x_colsum=True, out=(d_w2, d_barc))                  # w2 is stored [in, out]: cps^T g, sum_rows g
+        else:
+            d_w2.copy_(cps.float().t() @ g32)
+            d_barc.copy_(g32.sum(0))
         # ---- encoders ----
         d_pre = torch.empty((M, 3 * d), dtype=bf, device=dev)
         _C.check(lib.vlg_langfeat_split_backward(_C.ptr(d_txt), _C.BF16 if d_txt.dtype == bf else _C.F32, _C.ptr(d_child),
-                                                 _C.ptr(d_parent), _C.ptr(d_sum), _C.ptr(child), _C.ptr(parent), _C.ptr(heads),
+                                                 _C.ptr(d_parent), _C.ptr(d_sum), _C.BF16, _C.ptr(child), _C.ptr(parent), _C.ptr(heads),
                                                  B, N, d, slope, _C.ptr(d_pre), st), "langfeat_split_backward")
         if _wgrad_ok(M, 3 * d, h, bf):
-            d_wenc, d_benc = linear_wgrad(d_pre, x1)
+            linear_wgrad(d_pre, x1, out=(d_wenc, d_benc))
         else:
-            d_wenc, d_benc = d_pre.float().t() @ x1.float(), d_pre.float().sum(0)
+            d_wenc.copy_(d_pre.float().t() @ x1.float())
+            d_benc.copy_(d_pre.float().sum(0))
         d_x1 = d_pre @ w_enc_c                                                              # [M,h] bf16, library GEMM
         d_x = torch.empty((B, L, h), dtype=torch.float32, device=dev)
         _C.check(lib.vlg_langfeat_root_cat_backward(_C.ptr(d_x1), _C.ptr(lengths), B, L, h, _C.BF16, _C.ptr(d_x), st),
                  "langfeat_root_cat_backward")
-        cast = lambda t, dt: t if t.dtype == dt else t.to(dt)
         need = ctx.needs_input_grad
-        return (cast(d_x, t_x) if need[0] else None, None, None, cast(d_wenc, t_wenc) if need[3] else None,
-                cast(d_benc, t_benc) if need[4] else None, cast(d_w1, t_w1) if need[5] else None,
-                cast(d_w2, t_w2) if need[6] else None, cast(d_barc, t_barc) if need[7] else None, None)
+        pdt = (t_wenc, t_benc, t_w1, t_w2, t_barc)
+        pg = [d_wenc, d_benc, d_w1, d_w2, d_barc]
+        if all(t == pdt[0] for t in pdt) and pdt[0] != torch.float32:
+            pg = outs.cast(5, pdt[0])
+        else:
+            pg = [g if g.dtype == t else g.to(t) for g, t in zip(pg, pdt)]
+        return (d_x if d_x.dtype == t_x else d_x.to(t_x)) if need[0] else None, None, None, *(g if n else None for g, n in zip(pg, need[3:8])), None, None
 
 
 def _wgrad2(x, dy):
@@ -110,13 +120,14 @@ def _wgrad2(x, dy):
     return x.float().t() @ dy.float(), dy.float().sum(0)
 
 
-def arc_word_features(x, lengths, heads, w_enc, b_enc, w1, w2, b_arc, slope=0.01):
+def arc_word_features(x, lengths, heads, w_enc, b_enc, w1, w2, b_arc, slope=0.01, aux=None):
     """joint.py:262-288: txt = cat([word_encoder(x1), arc_repr]) with x1 = cat([masked mean, x]) -- [B,2N,d] bfloat16.
 
     x [B,L,h]; lengths [B] int64; heads [B,N] int64 (`predicted`, joint.py:256-258);
     w_enc [3d,h] / b_enc [3d]: the word | child | parent encoders' Linear parameters concatenated along the output
     dimension (nn.Linear layout [out,in]; word: no activation, child / parent: LeakyReLU(slope) -- config/model/vlgae.yaml:69-73,
-    joint.py:216-222); w1 [d,d,d], w2 [d,d], b_arc [d]: the arc encoder (joint.py:223-232).  Dropout is the identity (eval / p = 0)."""
+    joint.py:216-222); w1 [d,d,d], w2 [d,d], b_arc [d]: the arc encoder (joint.py:223-232).  Dropout is the identity (eval / p = 0).
+    aux: optional dict that receives the child / parent activations [B,N,d] (inspection only)."""
     x = _plain(x)
     _C.require_gpu(x, "arc_word_features")
     B, L, h = x.shape
@@ -128,16 +139,18 @@ def arc_word_features(x, lengths, heads, w_enc, b_enc, w1, w2, b_arc, slope=0.01
         raise ValueError("arc_word_features: heads must be int64 [B,L+1], lengths int64 [B]")
     if d % 16 or d > 128 or d not in (32, 64, 128):
         raise ValueError(f"arc_word_features: matching width d={d} (supported: 32, 64, 128)")
-    return _LangFeat.apply(x, lengths.contiguous(), heads.contiguous(), w_enc, b_enc, w1, w2, b_arc, float(slope))
+    return _LangFeat.apply(x, lengths.contiguous(), heads.contiguous(), w_enc, b_enc, w1, w2, b_arc, float(slope), aux)
 
 
 def lang_feat_max_tree(x, lengths, merged_dec, merged_attach, w_enc, b_enc, w1, w2, b_arc, add_marginal=True, slope=0.01,
-                       keep_viterbi=False):
+                       keep_viterbi=False, aux=None):
     """`DependencyBoxRel.lang_feat_max_tree` (joint.py:235-292) -> (txt [B,2N,d] bf16, txt_mask [B,2N] bool, txt_marginal
     [B,2N] float32).  The potentials are constants of this stage (detached, joint.py:252-253)."""
     import vlgae_amd.torch_struct as ts
     with torch.no_grad():
         marg, heads = ts.DMV1o([merged_dec.detach(), merged_attach.detach()], lengths).marginals_and_heads(keep_viterbi)
         txt_marginal, txt_mask = txt_marginal_and_mask(marg, heads, lengths, add_marginal)
-    txt = arc_word_features(x, lengths, heads, w_enc, b_enc, w1, w2, b_arc, slope)
+    if aux is not None:
+        aux["heads"] = heads
+    txt = arc_word_features(x, lengths, heads, w_enc, b_enc, w1, w2, b_arc, slope, aux)
     return txt, txt_mask, txt_marginal
