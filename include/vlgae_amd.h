@@ -293,6 +293,28 @@ int vlg_langfeat_marginal(const float* grad_attach, const int64_t* heads, const 
                           float* txt_marginal, uint8_t* txt_mask, void* stream);
 int vlg_langfeat_arc_out(const float* tri, const void* aff, int B, int N, int d, void* txt, void* stream);
 
+/* Score construction feeding the DP -- the tensor half of `DiscriminativeNDMV._forward`, src/model/ldndmv.py:179-209 with the
+ * factorised-bilinear scorers of src/model/nn/dmv_spec.py:57-76: from the scorers' projected inputs to the root-merged
+ * potentials, without the [B,L,T,2,2] rule table.
+ *   x1 [B,L,2,2,r] = attach_scorer.project1(h_parent), x2 [T,2,2,r] = attach_scorer.project2(h_child)      (in_dtype)
+ *   y1 [B,L,2,2,r] = dec_scorer.project1(h_parent),    y2 [2,2,2,r] = dec_scorer.project2(h_dec)           (in_dtype)
+ *   root_rule [T] fp32 = the root scorer's log-softmax over tokens (batch-independent, ldndmv.py:205)
+ *   token [B,L] int64 in [0,T), head_mask [B,L] u8 or NULL (function-word heads, ldndmv.py:195-199), mask_fill = -INF of
+ *   src/__init__.py:110.   Outputs (out_dtype): merged_dec [B,L+1,2,2,2], merged_attach [B,L+1,L+1,2] exactly as
+ *   `DMV1o.merge(dec, attach, root)` lays them out (distributions.py:253-265; zero = -1e12, one = 0).
+ * backward: cotangents of the two merged tensors (fp32; e.g. the DP's expected counts) -> d_x1, d_y1 [B,L,2,2,r],
+ *   d_x2 [T,2,2,r], d_y2 [2,2,2,r], d_root_rule [T] (fp32).  The softmax weights are recomputed; the batch-shared tables'
+ *   gradients are per-sentence partials added in sentence order (ws: vlg_ndmv_potentials_backward_workspace bytes).
+ * One workgroup per sentence with the token table in LDS: L, T, r must fit 160 KiB (VLG_ERR_SHAPE otherwise). */
+int vlg_ndmv_potentials(const void* x1, const void* x2, const void* y1, const void* y2, const float* root_rule, const int64_t* token,
+                        const uint8_t* head_mask, int B, int L, int T, int r, int in_dtype, float mask_fill, int out_dtype,
+                        void* merged_dec, void* merged_attach, void* stream);
+size_t vlg_ndmv_potentials_backward_workspace(int B, int L, int T, int r);
+int vlg_ndmv_potentials_backward(const void* x1, const void* x2, const void* y1, const void* y2, const int64_t* token,
+                                 const uint8_t* head_mask, const float* g_merged_dec, const float* g_merged_attach, int B, int L,
+                                 int T, int r, int in_dtype, void* ws, size_t ws_bytes, float* d_x1, float* d_x2, float* d_y1,
+                                 float* d_y2, float* d_root_rule, void* stream);
+
 /* Viterbi pass with every output of the Max semiring in ONE launch: best score, the 0/1 counts of the best tree (what
  * `-DMV1o(...).max.sum()` back-propagates, ldndmv.py:277-281) and its head vector (`argmax`, joint.py:256-258) -- the two
  * call sites see the same potentials within a training step.  Any of grad_dec / grad_attach / heads may be NULL (not all). */

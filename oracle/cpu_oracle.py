@@ -618,6 +618,61 @@ def lang_feat_marginal(grad_attach, heads, lengths, add_marginal=True):
     return np.concatenate([mask.astype(np.float64), am], 1), np.concatenate([mask, mask], 1)
 
 
+# ----------------------------------------------------------------------------------------------
+# Score construction of DiscriminativeNDMV._forward, src/model/ldndmv.py:184-209 (numpy, fp64), from the scorers' projected
+# inputs (nn/dmv_spec.py:66-76: einsum('bhdve,bcdve->bhcdv')) to the merged potentials, and its adjoint.
+# ----------------------------------------------------------------------------------------------
+def ndmv_potentials(x1, x2, y1, y2, root_rule, token, head_mask=None, mask_fill=-1e20, g_mdec=None, g_mattach=None):
+    """x1, y1 [B,L,2,2,r]; x2 [T,2,2,r]; y2 [2,2,2,r]; root_rule [T]; token [B,L] -> (merged_dec [B,N,2,2,2], merged_attach
+    [B,N,N,2]); with the cotangents also dict(x1, x2, y1, y2, root_rule)."""
+    x1, x2, y1, y2, root_rule = (np.asarray(a, dtype=np.float64) for a in (x1, x2, y1, y2, root_rule))
+    token = np.asarray(token)
+    B, L = token.shape
+    T, N = x2.shape[0], L + 1
+    score = np.einsum("bhdve,cdve->bhcdv", x1, x2)                                          # dmv_spec.py:73
+    smax = score.max(2, keepdims=True)
+    lse = smax + np.log(np.exp(score - smax).sum(2, keepdims=True))
+    attach_rule = score - lse                                                               # ldndmv.py:185 log_softmax(2)
+    bi = np.arange(B)[:, None, None]
+    hi = np.arange(L)[None, :, None]
+    gathered = attach_rule[bi, hi, token[:, None, :]]                                       # [B,L(h),L(c),2(d),2(v)], :189-190
+    left = np.tril(np.ones((L, L)), -1)[None, :, :, None]
+    right = np.triu(np.ones((L, L)), 1)[None, :, :, None]
+    attach = gathered[..., 0, :] * left + gathered[..., 1, :] * right                       # :191-194
+    hm = None if head_mask is None else np.asarray(head_mask, dtype=bool)
+    if hm is not None:
+        attach = np.where(hm[:, :, None, None], mask_fill, attach)                          # :195-199
+    dscore = np.einsum("bhdve,kdve->bhkdv", y1, y2).transpose(0, 1, 3, 4, 2)               # :201 permute(0,1,3,4,2)
+    dmax = dscore.max(-1, keepdims=True)
+    dec = dscore - (dmax + np.log(np.exp(dscore - dmax).sum(-1, keepdims=True)))
+    root = root_rule[token]                                                                 # :205-207
+    mdec = np.full((B, N, 2, 2, 2), -1e12)
+    matt = np.full((B, N, N, 2), -1e12)                                                     # distributions.py:253-265
+    mdec[:, 0, 1] = 0.0
+    mdec[:, 1:] = dec
+    matt[:, 0, 1:, 1] = root
+    matt[:, 1:, 1:] = attach
+    if g_mdec is None:
+        return mdec, matt
+    g_mdec, g_mattach = np.asarray(g_mdec, dtype=np.float64), np.asarray(g_mattach, dtype=np.float64)
+    g_attach = g_mattach[:, 1:, 1:].copy()
+    if hm is not None:
+        g_attach[hm] = 0.0
+    g_gath = np.stack([g_attach * left, g_attach * right], -2)                              # [B,L,L,2(d),2(v)]
+    g_rule = np.zeros_like(attach_rule)
+    for b in range(B):
+        for c in range(L):
+            g_rule[b, :, token[b, c]] += g_gath[b, :, c]
+    g_score = g_rule - np.exp(attach_rule) * g_rule.sum(2, keepdims=True)                   # log_softmax adjoint
+    g_dec = g_mdec[:, 1:]
+    g_dscore = (g_dec - np.exp(dec) * g_dec.sum(-1, keepdims=True)).transpose(0, 1, 4, 2, 3)  # -> [b,h,k,d,v]
+    g_root = np.zeros(T)
+    np.add.at(g_root, token, g_mattach[:, 0, 1:, 1])
+    return mdec, matt, dict(x1=np.einsum("bhcdv,cdve->bhdve", g_score, x2), x2=np.einsum("bhcdv,bhdve->cdve", g_score, x1),
+                            y1=np.einsum("bhkdv,kdve->bhdve", g_dscore, y2), y2=np.einsum("bhkdv,bhdve->kdve", g_dscore, y1),
+                            root_rule=g_root)
+
+
 # ---------------------------------------------------------------- data feed (SURVEY section 8 row f4)
 def feed_kmeans(x, init_centroids, k, max_it=32):
     """ConstantTokenNumSampler.kmeans (datamodule/sampler.py:148-191) from given initial centroids, in the reference's dense

@@ -523,6 +523,55 @@ def langfeat_cases():
         print(f"{name}: txt {tuple(txt.shape)} marginal sum {float(txt_marginal.rename(None).sum()):.4f}")
 
 
+def scorer_cases():
+    """The reference's own `DiscriminativeNDMV._forward` (ldndmv.py:171-216) executed as an unbound method on a namespace
+    carrying the reference's modules (MLP feed-forwards, DMVSkipConnectEncoder, three DMVFactorizedBilinear scorers) --
+    context_mode 'none' (extract_sent_repr / construct_token_repr pass the embedding through), no pretrained-DMV init.
+    The scorers' projected inputs are captured with forward hooks; gradients of <merged potentials, cotangents> w.r.t. them
+    (and w.r.t. root_rule) by torch autograd through the reference's ops."""
+    from types import SimpleNamespace as NS
+    src, joint = _ref_import.import_joint()
+    from src.model import ldndmv
+    from src.model.nn import MLP, DMVSkipConnectEncoder, DMVFactorizedBilinear
+    fn = ldndmv.DiscriminativeNDMV._forward
+    src.trainer = NS(current_epoch=100)
+    for name, seed, B, L, T, H, r, use_mask in (("scorer_B3_L7_T9_H24_r8_s0", 0, 3, 7, 9, 24, 8, True),
+                                                ("scorer_B4_L12_T45_H32_r16_s1", 1, 4, 12, 45, 32, 16, False),
+                                                ("scorer_B2_L40_T45_H32_r16_s2", 2, 2, 40, 45, 32, 16, True)):
+        torch.manual_seed(seed)
+        g = torch.Generator().manual_seed(seed)
+        E = 12
+        me = NS(cfg=NS(extended_valence=True, function_mask=use_mask, init_epoch=0), dmv=None,
+                head_ff=MLP(n_in=E, n_hidden=H), child_ff=MLP(n_in=E, n_hidden=H), root_ff=MLP(n_in=10, n_hidden=H),
+                dec_ff=MLP(n_in=10, n_hidden=H), mid_ff=DMVSkipConnectEncoder(hidden_size=H, n_bottleneck=6),
+                attach_scorer=DMVFactorizedBilinear(n_in=H, r=r), dec_scorer=DMVFactorizedBilinear(n_in=H, r=r),
+                root_scorer=DMVFactorizedBilinear(n_in=H, r=r), token_emb=torch.randn(T, E, generator=g),
+                root_emb=torch.randn(1, 10, generator=g), dec_emb=torch.randn(2, 10, generator=g),
+                function_mask=torch.tensor([1, 4]), extract_sent_repr=lambda enc: (None, None),
+                construct_token_repr=lambda emb, ctx, vp: emb)
+        cap = {}
+        hooks = [m.register_forward_hook(lambda mod, inp, out, k=k: cap.__setitem__(k, out))
+                 for k, m in (("x1", me.attach_scorer.project1), ("x2", me.attach_scorer.project2), ("y1", me.dec_scorer.project1),
+                              ("y2", me.dec_scorer.project2))]
+        token = torch.randint(0, T, (B, L), generator=g)
+        tag = torch.randint(0, 6, (B, L), generator=g)
+        emb = torch.randn(B, L, E, generator=g)
+        out = fn(me, {"token": token, "tag": tag}, {"emb": emb}, NS(batch_size=B, max_len=L))
+        for h in hooks:
+            h.remove()
+        md, ma = out["merged_dec"], out["merged_attach"]
+        g_md = torch.rand(B, L + 1, 2, 2, 2, generator=g)
+        g_ma = torch.rand(B, L + 1, L + 1, 2, generator=g)
+        grads = torch.autograd.grad([md, ma], [cap["x1"], cap["x2"], cap["y1"], cap["y2"], out["root_rule"]], [g_md, g_ma])
+        head_mask = tag.unsqueeze(-1).eq(me.function_mask.view(1, 1, -1)).any(-1) if use_mask else torch.zeros(B, L, dtype=torch.bool)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"), x1=_np(cap["x1"]), x2=_np(cap["x2"][0]), y1=_np(cap["y1"]), y2=_np(cap["y2"][0]),
+            root_rule=_np(out["root_rule"][0]), token=_np(token), head_mask=_np(head_mask), mask_fill=np.float32(-src.INF),
+            merged_dec=_np(md), merged_attach=_np(ma), g_merged_dec=_np(g_md), g_merged_attach=_np(g_ma), g_x1=_np(grads[0]),
+            g_x2=_np(grads[1][0]), g_y1=_np(grads[2]), g_y2=_np(grads[3][0]), g_root_rule=_np(grads[4].sum(0)))
+        print(f"{name}: merged_attach {tuple(ma.shape)} finite min {float(ma[ma > -1e11].min()):.3f}")
+
+
 def _csr(lists):
     return (np.cumsum([0] + [len(l) for l in lists]).astype(np.int64),
             np.asarray([i for l in lists for i in l], dtype=np.int64))
@@ -620,4 +669,5 @@ if __name__ == "__main__":
     arcenc_cases()
     boxrel_cases()
     langfeat_cases()
+    scorer_cases()
     feed_cases()

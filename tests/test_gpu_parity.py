@@ -1554,3 +1554,71 @@ def test_lang_feat_max_tree_config_size(ts, oracle_mod):
                            ("b_enc", gs[2], np.concatenate([og["b_word"], og["b_child"], og["b_parent"]])), ("w1", gs[3], og["w1"]),
                            ("w2", gs[4], og["w2"]), ("b_arc", gs[5], og["b_arc"])):
         _langfeat_grad_close(f64(got), ref, name, tol)
+
+
+# ------------------------------------------------------------------------------------------------ scorer -> merged potentials (f1)
+@pytest.mark.parametrize("path", golden_files("scorer_"), ids=golden_ids("scorer_"))
+def test_ndmv_potentials_golden(ts, path):
+    """vlgae_amd.scorer.ndmv_potentials against the reference's own `DiscriminativeNDMV._forward` (ldndmv.py:171-216) and torch
+    autograd through it: fp32 in, fp32 out.  Fills (-1e12, -1e20) bit-exact; scores 2e-5 (fp32 dots and log-sum-exp in a
+    different summation order); gradients 1e-4 of the largest reference magnitude."""
+    from vlgae_amd import scorer
+    g = load(path)
+    ins = [t(g[k]).requires_grad_(True) for k in ("x1", "x2", "y1", "y2", "root_rule")]
+    md, ma = scorer.ndmv_potentials(*ins, t(g["token"]), t(g["head_mask"]), float(g["mask_fill"]))
+    for got, ref in ((md, g["merged_dec"]), (ma, g["merged_attach"])):
+        got = got.detach().cpu().numpy()
+        big = np.abs(ref) > 1e11
+        assert (got[big] == ref[big]).all()
+        assert np.abs(got[~big] - ref[~big]).max() <= 2e-5
+    grads = torch.autograd.grad([md, ma], ins, [t(g["g_merged_dec"]), t(g["g_merged_attach"])])
+    for k, v in zip(("x1", "x2", "y1", "y2", "root_rule"), grads):
+        ref = g["g_" + k]
+        assert np.abs(v.cpu().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
+
+
+def test_ndmv_potentials_config_size_feeds_the_dp(ts, oracle_mod):
+    """B = 256, L = 40, T = 45, r = 16 (config/model/vlgae.yaml): the fused score construction feeding the fused DP --
+    expected counts back to the scorers' inputs in three launches -- against the fp64 oracle chain (oracle.ndmv_potentials ->
+    oracle.dmv1o -> adjoint) on a slice, run-to-run bit equality, bf16 storage of the potentials."""
+    from vlgae_amd import scorer
+    B, L, T, r = 256, 40, 45, 16
+    g = torch.Generator().manual_seed(9)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev())
+    ins = [rnd(B, L, 2, 2, r, sc=0.5).requires_grad_(True), rnd(T, 2, 2, r, sc=0.5).requires_grad_(True),
+           rnd(B, L, 2, 2, r, sc=0.5).requires_grad_(True), rnd(2, 2, 2, r, sc=0.5).requires_grad_(True),
+           torch.randn(T, generator=g).log_softmax(-1).to(dev()).requires_grad_(True)]
+    token = torch.randint(0, T, (B, L), generator=g).to(dev())
+    head_mask = (torch.rand(B, L, generator=g) < 0.1).to(dev())
+    lengths = torch.randint(L // 2, L + 1, (B,), generator=g)
+    lengths[0] = L
+    lengths = lengths.to(dev())
+
+    def run(out_dtype):
+        md, ma = scorer.ndmv_potentials(*ins, token, head_mask, out_dtype=out_dtype)
+        logZ = ts.DMV1o([md, ma], lengths).partition
+        return md, ma, logZ, torch.autograd.grad(logZ.sum(), ins)
+    md, ma, logZ, grads = run(torch.float32)
+    md2, ma2, logZ2, grads2 = run(torch.float32)
+    assert torch.equal(ma, ma2) and torch.equal(logZ, logZ2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
+    S = 5
+    f64 = lambda a: a.detach().cpu().numpy().astype(np.float64)
+    omd, oma = oracle_mod.ndmv_potentials(f64(ins[0])[:S], f64(ins[1]), f64(ins[2])[:S], f64(ins[3]), f64(ins[4]), token[:S].cpu().numpy(),
+                                          head_mask[:S].cpu().numpy())
+    big = np.abs(oma) > 1e11
+    assert (ma[:S].detach().cpu().numpy()[big] == oma[big].astype(np.float32)).all() and np.abs(f64(ma)[:S][~big] - oma[~big]).max() <= 2e-5
+    olz, ogd, oga = oracle_mod.dmv1o(omd, oma, lengths[:S].cpu().numpy(), "log", np.float64)
+    assert np.abs(f64(logZ)[:S, 0] - olz).max() <= (logz_tol(olz)).max()
+    _, _, og = oracle_mod.ndmv_potentials(f64(ins[0])[:S], f64(ins[1]), f64(ins[2])[:S], f64(ins[3]), f64(ins[4]), token[:S].cpu().numpy(),
+                                          head_mask[:S].cpu().numpy(), -1e20, ogd, oga)
+    for k, idx in (("x1", 0), ("y1", 2)):                                  # per-sentence gradients: the slice's rows
+        assert np.abs(f64(grads[idx])[:S] - og[k]).max() <= 2e-4 * max(1.0, np.abs(og[k]).max()), k
+    # batch-shared tables: gradients are sums over sentences -- the first S sentences alone must match the oracle's
+    ins_s = [ins[0][:S].detach().requires_grad_(True), ins[1], ins[2][:S].detach().requires_grad_(True), ins[3], ins[4]]
+    md_s, ma_s = scorer.ndmv_potentials(*ins_s, token[:S].contiguous(), head_mask[:S].contiguous())
+    gs = torch.autograd.grad(ts.DMV1o([md_s, ma_s], lengths[:S].contiguous()).partition.sum(), ins_s)
+    for k, idx in (("x2", 1), ("y2", 3), ("root_rule", 4)):
+        assert np.abs(f64(gs[idx]) - og[k]).max() <= 2e-4 * max(1.0, np.abs(og[k]).max()), k
+    # bf16 storage of the potentials (what the DP benchmark reads): the rounding of the stored potentials is the only difference
+    md_b, ma_b, logZ_b, _ = run(torch.bfloat16)
+    assert ma_b.dtype == torch.bfloat16 and torch.equal(ma_b, ma.to(torch.bfloat16)) and torch.equal(md_b, md.to(torch.bfloat16))

@@ -251,3 +251,21 @@ def test_lang_feat_oracle_vs_reference(oracle_mod, path):
         ref = g["g_" + k]
         assert np.abs(grads[k] - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), k
     arcenc_check_w1_grad(grads["w1"], g, 5e-5)
+
+
+# ------------------------------------------------------------------------------------------------ scorer -> merged potentials
+@pytest.mark.parametrize("path", golden_files("scorer_"), ids=golden_ids("scorer_"))
+def test_ndmv_potentials_oracle_vs_reference(oracle_mod, path):
+    """oracle.ndmv_potentials restates ldndmv.py:184-209 + nn/dmv_spec.py:66-76; the fixtures are the reference's own
+    `DiscriminativeNDMV._forward` (its scorer modules executed) and torch autograd through it (fp32)."""
+    g = load(path)
+    md, ma, grads = oracle_mod.ndmv_potentials(g["x1"], g["x2"], g["y1"], g["y2"], g["root_rule"], g["token"], g["head_mask"],
+                                               float(g["mask_fill"]), g["g_merged_dec"], g["g_merged_attach"])
+    big = np.abs(g["merged_attach"]) > 1e11                                 # -1e12 / -1e20 fills: exact
+    assert (ma[big].astype(np.float32) == g["merged_attach"][big]).all()
+    assert np.abs(ma[~big] - g["merged_attach"][~big]).max() <= 1e-5
+    bigd = np.abs(g["merged_dec"]) > 1e11
+    assert (md[bigd].astype(np.float32) == g["merged_dec"][bigd]).all() and np.abs(md[~bigd] - g["merged_dec"][~bigd]).max() <= 1e-5
+    for k in ("x1", "x2", "y1", "y2", "root_rule"):
+        ref = g["g_" + k]
+        assert np.abs(grads[k] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k

@@ -59,6 +59,9 @@ SIGNATURES = {
     "vlg_langfeat_split_backward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "vlg_langfeat_marginal": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "vlg_langfeat_arc_out": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "vlg_ndmv_potentials": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "vlg_ndmv_potentials_backward_workspace": (_sz, [_i, _i, _i, _i]),
+    "vlg_ndmv_potentials_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vlg_dmv1o_viterbi": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vlg_scale_counts": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "vlg_feed_kmeans": (_i, [_vp, ctypes.c_int64, _vp, _i, _i, _vp, _vp, _vp]),
