@@ -1608,7 +1608,8 @@ def test_ndmv_potentials_config_size_feeds_the_dp(ts, oracle_mod):
     big = np.abs(oma) > 1e11
     assert (ma[:S].detach().cpu().numpy()[big] == oma[big].astype(np.float32)).all() and np.abs(f64(ma)[:S][~big] - oma[~big]).max() <= 2e-5
     olz, ogd, oga = oracle_mod.dmv1o(omd, oma, lengths[:S].cpu().numpy(), "log", np.float64)
-    assert np.abs(f64(logZ)[:S, 0] - olz).max() <= (logz_tol(olz)).max()
+    olz = np.asarray(olz).reshape(-1)
+    assert (np.abs(f64(logZ)[:S, 0] - olz) <= logz_tol(olz)).all()
     _, _, og = oracle_mod.ndmv_potentials(f64(ins[0])[:S], f64(ins[1]), f64(ins[2])[:S], f64(ins[3]), f64(ins[4]), token[:S].cpu().numpy(),
                                           head_mask[:S].cpu().numpy(), -1e20, ogd, oga)
     for k, idx in (("x1", 0), ("y1", 2)):                                  # per-sentence gradients: the slice's rows

@@ -2,7 +2,9 @@
 
 Reference call sequence (shipped `vlgae` config):
   DependencyBoxRel._forward   joint.py:658-675   attention-fuse of region features into the word encodings     -> attention_fuse
-  [scorer -> dec/attach/root  ldndmv.py:171-216  OUT OF SCOPE: the potentials are synthetic constants here]
+  scorer -> merged potentials ldndmv.py:184-209  factorised-bilinear scores -> log-softmax over tokens -> gather / direction
+                                                 select / root gather / merge (round 3, with_scorer=True)          -> scorer.ndmv_potentials
+                                                 [with_scorer=False: the potentials are synthetic constants, as in rounds 1-2]
   lang_feat_max_tree          joint.py:235-292   DMV1o partition + autograd.grad -> arc marginals; argmax -> heads -> marginals_and_heads
                                                  arc encoder over (child, gathered parent)                        -> arc_encoder
   gather_logit + loss         joint.py:406-491   region x word alignment maxima + grounding cross-entropy         -> grounding_loss_factor_ce
@@ -19,9 +21,9 @@ parser's `-max` loss on the same potentials (ldndmv.py:277-281).
 import torch
 
 
-def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11):
+def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer=True, T=45, r=16):
     import vlgae_amd.torch_struct as ts
-    from vlgae_amd import align, langfeat
+    from vlgae_amd import align, langfeat, scorer
     N, Q = L + 1, 2 * (L + 1)
     g = torch.Generator().manual_seed(seed)
     rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
@@ -44,6 +46,11 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11):
     lengths = lengths.to(dev)
     vmask = torch.ones(B, V, dtype=torch.bool, device=dev)
     num_token = float(lengths.sum().item())
+    if with_scorer:   # the scorers' projected inputs (plain nn.Linear outputs of the out-of-scope feed-forwards), fp32 like the reference's
+        P.update(sc_x1=leaf(B, L, 2, 2, r, sc=0.5, dt=torch.float32), sc_x2=leaf(T, 2, 2, r, sc=0.5, dt=torch.float32),
+                 sc_y1=leaf(B, L, 2, 2, r, sc=0.5, dt=torch.float32), sc_y2=leaf(2, 2, 2, r, sc=0.5, dt=torch.float32),
+                 sc_root=torch.randn(T, generator=g).log_softmax(-1).to(dev).requires_grad_(True))
+        token = torch.randint(0, T, (B, L), generator=g).to(dev)
     names = sorted(P)
     leaves = [P[k] for k in names]
     pot = [md.detach().requires_grad_(True), ma.detach().requires_grad_(True)]
@@ -55,16 +62,21 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11):
         attention-fuse adjoints) -- where a data-parallel trainer starts reducing its first gradient bucket."""
         # joint.py:670-674
         x = align.attention_fuse(P["vis_feat"], P["txt_word"], P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], 1e-5)
+        if with_scorer:   # ldndmv.py:184-209: the step's potentials, bf16 storage for the DPs
+            smd, sma = scorer.ndmv_potentials(P["sc_x1"], P["sc_x2"], P["sc_y1"], P["sc_y2"], P["sc_root"], token, out_dtype=dtype)
+            cmd, cma, loss_pot = smd.detach(), sma.detach(), [smd, sma]
+        else:
+            cmd, cma, loss_pot = md, ma, pot
         # joint.py:235-292 (the potentials are constants of this stage: detached, :252-253)
-        txt, tmask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, md, ma, P["w_enc"], P["b_enc"], P["w1"], P["w2"], P["b"],
+        txt, tmask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, cmd, cma, P["w_enc"], P["b_enc"], P["w1"], P["w2"], P["b"],
                                                                keep_viterbi=True)
         if stage_hook is not None:
             txt.register_hook(lambda g: stage_hook())
         # joint.py:406-491
         total, _ = align.grounding_loss_factor_ce(txt, P["vis_feat"], tmask, vmask, txt_marginal, num_token, 1.0)
         # ldndmv.py:277-281 (viterbi_training: true): the Viterbi pass of lang_feat_max_tree is reused
-        total = total - ts.DMV1o(pot, lengths).max.sum()
-        grads = torch.autograd.grad(total, leaves + pot)
+        total = total - ts.DMV1o(loss_pot, lengths).max.sum()
+        grads = torch.autograd.grad(total, leaves + ([] if with_scorer else pot))
         return total, dict(zip(names, grads[:len(names)])), grads[len(names):]
 
     step.names, step.P, step.lengths = names, P, lengths

@@ -28,7 +28,7 @@ namespace vlg {
 
 namespace {
 
-constexpr int kScThreads = 256;
+constexpr int kScThreads = 1024;   // 16 wavefronts per sentence: the loops are LDS-latency chains, more waves hide them
 constexpr float kMergeZero = -1e12f;   // DMV1o.merge's `zero` (distributions.py:253, bound at import: semirings.py:16)
 
 struct ScLayout {   // LDS carving, in floats
@@ -58,13 +58,26 @@ __device__ __forceinline__ void load_rows(const typename In::T* src, size_t n_ro
     }
 }
 
+// length-r dot of two LDS rows; R > 0: compile-time rank (all 2R reads issued together), R = 0: run-time loop
+template <int R>
 __device__ __forceinline__ float dot_r(const float* a, const float* b, int r) {
-    float s = 0.f;
-    for (int e = 0; e < r; ++e) s = fmaf(a[e], b[e], s);
-    return s;
+    if constexpr (R > 0) {
+        float av[R], bv[R];
+#pragma unroll
+        for (int e = 0; e < R; ++e) { av[e] = a[e]; bv[e] = b[e]; }
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < R; e += 2) { s0 = fmaf(av[e], bv[e], s0); s1 = fmaf(av[e + 1], bv[e + 1], s1); }
+        return s0 + s1;
+    } else {
+        float s = 0.f;
+        for (int e = 0; e < r; ++e) s = fmaf(a[e], b[e], s);
+        return s;
+    }
 }
 
 // lse[h][dv] = logsumexp_t dot(x1[h][dv], x2[t][dv]): 4 lanes per (h, dv) pair split the tokens, then combine
+template <int R>
 __device__ __forceinline__ void compute_lse(const float* x1s, const float* x2s, float* lse, int L, int T, int r, int rp, int tid) {
     for (int p0 = 0; p0 < L * 4; p0 += kScThreads / 4) {
         const int p = p0 + (tid >> 2), part = tid & 3;
@@ -73,7 +86,7 @@ __device__ __forceinline__ void compute_lse(const float* x1s, const float* x2s, 
         const float* a = x1s + pc * rp;
         float m = -3.0e38f, s = 0.f;
         for (int t = part; t < T; t += 4) {   // online log-sum-exp
-            const float v = dot_r(a, x2s + (t * 4 + dv) * rp, r);
+            const float v = dot_r<R>(a, x2s + (t * 4 + dv) * rp, r);
             const float nm = fmaxf(m, v);
             s = s * __expf(m - nm) + __expf(v - nm);
             m = nm;
@@ -90,7 +103,7 @@ __device__ __forceinline__ void compute_lse(const float* x1s, const float* x2s, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------- forward
-template <typename In, typename Out>
+template <typename In, typename Out, int R>
 __global__ __launch_bounds__(kScThreads) void scorer_fwd_kernel(
     const typename In::T* __restrict__ x1, const typename In::T* __restrict__ x2, const typename In::T* __restrict__ y1,
     const typename In::T* __restrict__ y2, const float* __restrict__ root_rule, const int64_t* __restrict__ token,
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(kScThreads) void scorer_fwd_kernel(
         hm[i] = head_mask ? head_mask[(size_t)b * L + i] : 0;
     }
     __syncthreads();
-    compute_lse(x1s, x2s, lse, L, T, r, rp, tid);
+    compute_lse<R>(x1s, x2s, lse, L, T, r, rp, tid);
     __syncthreads();
     // ---- merged attach [N][N][2]: (h, c) positions in the root-augmented sentence ----
     Out* ma = matt + (size_t)b * N * N * 2;
@@ -128,8 +141,8 @@ __global__ __launch_bounds__(kScThreads) void scorer_fwd_kernel(
                     const int d = c < h ? 0 : 1;                       // LEFT = 0, RIGHT = 1
                     const float* xa = x1s + (h * 4 + d * 2) * rp;
                     const float* xb = x2s + (tok[c] * 4 + d * 2) * rp;
-                    v0 = dot_r(xa, xb, r) - lse[h * 4 + d * 2];
-                    v1 = dot_r(xa + rp, xb + rp, r) - lse[h * 4 + d * 2 + 1];
+                    v0 = dot_r<R>(xa, xb, r) - lse[h * 4 + d * 2];
+                    v1 = dot_r<R>(xa + rp, xb + rp, r) - lse[h * 4 + d * 2 + 1];
                 }
             }
         }
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(kScThreads) void scorer_fwd_kernel(
         if (hn == 0) g = s = (dv >> 1) == 1 ? 0.f : kMergeZero;
         else {
             const float* ya = y1s + ((hn - 1) * 4 + dv) * rp;
-            const float a0 = dot_r(ya, y2s + (0 * 4 + dv) * rp, r), a1 = dot_r(ya, y2s + (1 * 4 + dv) * rp, r);
+            const float a0 = dot_r<R>(ya, y2s + (0 * 4 + dv) * rp, r), a1 = dot_r<R>(ya, y2s + (1 * 4 + dv) * rp, r);
             const float m = fmaxf(a0, a1), z = m + __logf(__expf(a0 - m) + __expf(a1 - m));
             g = a0 - z;
             s = a1 - z;
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(kScThreads) void scorer_fwd_kernel(
 // --------------------------------------------------------------------------------------------------------------- backward
 // g_matt [B,N,N,2], g_mdec [B,N,2,2,2] fp32 -> d_x1, d_y1 [B,L,2,2,r] fp32 and per-sentence partials of d_x2 [T,2,2,r],
 // d_y2 [2,2,2,r], d_root_rule [T] (part [B][T*4*r + 8*r + T]).
-template <typename In>
+template <typename In, int R>
 __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
     const typename In::T* __restrict__ x1, const typename In::T* __restrict__ x2, const typename In::T* __restrict__ y1,
     const typename In::T* __restrict__ y2, const int64_t* __restrict__ token, const uint8_t* __restrict__ head_mask,
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
         hm[i] = head_mask ? head_mask[(size_t)b * L + i] : 0;
     }
     __syncthreads();
-    compute_lse(x1s, x2s, lse, L, T, r, rp, tid);
+    compute_lse<R>(x1s, x2s, lse, L, T, r, rp, tid);
     const float* ga = g_matt + (size_t)b * N * N * 2;
     const float* gd = g_mdec + (size_t)b * N * 8;
     // cotangent of attach[h][c][v] (0 for masked heads and on the diagonal): cnt(h, c, v)
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
         for (int c = d ? h + 1 : 0; c < (d ? L : h); ++c) s += cnt(h, c, v);
         tot[p] = s;
         const float* ya = y1s + p * rp;
-        const float a0 = dot_r(ya, y2s + (0 * 4 + (p & 3)) * rp, r), a1 = dot_r(ya, y2s + (1 * 4 + (p & 3)) * rp, r);
+        const float a0 = dot_r<R>(ya, y2s + (0 * 4 + (p & 3)) * rp, r), a1 = dot_r<R>(ya, y2s + (1 * 4 + (p & 3)) * rp, r);
         const float m = fmaxf(a0, a1), e0 = __expf(a0 - m), e1 = __expf(a1 - m), inv = 1.f / (e0 + e1);
         const float g0 = gd[(size_t)(h + 1) * 8 + (p & 3) * 2], g1 = gd[(size_t)(h + 1) * 8 + (p & 3) * 2 + 1];
         dsd[p * 2] = g0 - e0 * inv * (g0 + g1);
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
     for (int i = tid; i < L * 4 * T; i += kScThreads) {   // - softmax weight * tot
         const int p = i / T, t = i - p * T;
         const float tt = tot[p];
-        coef[i] = tt != 0.f ? -tt * __expf(dot_r(x1s + p * rp, x2s + (t * 4 + (p & 3)) * rp, r) - lse[p]) : 0.f;
+        coef[i] = tt != 0.f ? -tt * __expf(dot_r<R>(x1s + p * rp, x2s + (t * 4 + (p & 3)) * rp, r) - lse[p]) : 0.f;
     }
     __syncthreads();
     for (int p = tid; p < L * 4; p += kScThreads) {       // + the children's counts at their tokens; row p has one owner, c ascending
@@ -215,6 +228,7 @@ __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
     for (int i = tid; i < L * 4 * r; i += kScThreads) {
         const int p = i / r, e = i - p * r, dv = p & 3;
         float acc = 0.f;
+#pragma unroll 8
         for (int t = 0; t < T; ++t) acc = fmaf(coef[p * T + t], x2s[(t * 4 + dv) * rp + e], acc);
         d_x1[((size_t)b * L * 4 + p) * r + e] = acc;
         d_y1[((size_t)b * L * 4 + p) * r + e] = dsd[p * 2] * y2s[(0 * 4 + dv) * rp + e] + dsd[p * 2 + 1] * y2s[(1 * 4 + dv) * rp + e];
@@ -224,6 +238,7 @@ __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
     for (int i = tid; i < T * 4 * r; i += kScThreads) {   // d_x2[t][dv][e] = sum_h coef[h][dv][t] x1[h][dv][e], h ascending
         const int q = i / r, e = i - q * r, t = q >> 2, dv = q & 3;
         float acc = 0.f;
+#pragma unroll 8
         for (int h = 0; h < L; ++h) acc = fmaf(coef[(h * 4 + dv) * T + t], x1s[(h * 4 + dv) * rp + e], acc);
         pt[i] = acc;
     }
@@ -243,21 +258,28 @@ __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
     }
 }
 
-// out[i] = sum_b part[b][i], b ascending
+// out[i] = sum_b part[b][i] in a fixed order: 64 outputs x 4 sentence groups per block (group g adds b = g, g + 4, ...
+// ascending), then (g0 + g1) + (g2 + g3)
 __global__ __launch_bounds__(256) void scorer_reduce_kernel(const float* __restrict__ part, int B, int n, float* __restrict__ d_x2,
                                                             int n_x2, float* __restrict__ d_y2, int n_y2, float* __restrict__ d_root) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float sm[4][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float t = 0.f;
-    int b = 0;
-    for (; b + 8 <= B; b += 8) {
-        float v[8];
+    if (i < n) {
+        int b = grp;
+        for (; b + 28 < B; b += 32) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * n + i];
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 4 * u) * n + i];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t += v[u];
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; b < B; b += 4) t += part[(size_t)b * n + i];
     }
-    for (; b < B; ++b) t += part[(size_t)b * n + i];
+    sm[grp][threadIdx.x & 63] = t;
+    __syncthreads();
+    if (grp != 0 || i >= n) return;
+    t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
     if (i < n_x2) d_x2[i] = t;
     else if (i < n_x2 + n_y2) d_y2[i - n_x2] = t;
     else d_root[i - n_x2 - n_y2] = t;
@@ -298,18 +320,27 @@ int vlg_ndmv_potentials(const void* x1, const void* x2, const void* y1, const vo
     if (B == 0) return 0;
     if (!x1 || !x2 || !y1 || !y2 || !root_rule || !token || !merged_dec || !merged_attach) return set_error(VLG_ERR_ARG, "ndmv_potentials: null buffer");
     hipStream_t s = (hipStream_t)stream;
-#define VLG_GO(IN, OUT)                                                                                                             \
+#define VLG_GO_R(IN, OUT, RR)                                                                                                       \
     {                                                                                                                               \
-        auto k = scorer_fwd_kernel<IN, OUT>;                                                                                        \
+        auto k = scorer_fwd_kernel<IN, OUT, RR>;                                                                                    \
         if (int rc = prep_lds(k, lds)) return rc;                                                                                   \
         hipLaunchKernelGGL(k, dim3(B), dim3(kScThreads), lds, s, (const IN::T*)x1, (const IN::T*)x2, (const IN::T*)y1, (const IN::T*)y2, \
                            root_rule, token, head_mask, L, T, r, mask_fill, (OUT*)merged_dec, (OUT*)merged_attach);                \
+    }
+#define VLG_GO(IN, OUT)                                  \
+    {                                                    \
+        if (r == 16) VLG_GO_R(IN, OUT, 16)               \
+        else if (r == 8) VLG_GO_R(IN, OUT, 8)            \
+        else if (r == 32) VLG_GO_R(IN, OUT, 32)          \
+        else if (r == 64) VLG_GO_R(IN, OUT, 64)          \
+        else VLG_GO_R(IN, OUT, 0)                        \
     }
     if (in_dtype == VLG_F32 && out_dtype == VLG_F32) VLG_GO(F32In, float)
     else if (in_dtype == VLG_F32) VLG_GO(F32In, __bf16)
     else if (out_dtype == VLG_F32) VLG_GO(BF16In, float)
     else VLG_GO(BF16In, __bf16)
 #undef VLG_GO
+#undef VLG_GO_R
     return check_launch("scorer_fwd_kernel");
 }
 
@@ -338,19 +369,27 @@ int vlg_ndmv_potentials_backward(const void* x1, const void* x2, const void* y1,
     if (!x1 || !x2 || !y1 || !y2 || !token || !g_merged_dec || !g_merged_attach) return set_error(VLG_ERR_ARG, "ndmv_potentials_backward: null buffer");
     const size_t need = vlg_ndmv_potentials_backward_workspace(B, L, T, r);
     if (!ws || ws_bytes < need) return set_error(VLG_ERR_WORKSPACE, "ndmv_potentials_backward: workspace %zu bytes < %zu", ws_bytes, need);
-    if (in_dtype == VLG_F32) {
-        auto k = scorer_bwd_kernel<F32In>;
-        if (int rc = prep_lds(k, lds)) return rc;
-        hipLaunchKernelGGL(k, dim3(B), dim3(kScThreads), lds, s, (const float*)x1, (const float*)x2, (const float*)y1, (const float*)y2, token,
-                           head_mask, g_merged_dec, g_merged_attach, L, T, r, d_x1, d_y1, (float*)ws);
-    } else {
-        auto k = scorer_bwd_kernel<BF16In>;
-        if (int rc = prep_lds(k, lds)) return rc;
-        hipLaunchKernelGGL(k, dim3(B), dim3(kScThreads), lds, s, (const uint16_t*)x1, (const uint16_t*)x2, (const uint16_t*)y1,
-                           (const uint16_t*)y2, token, head_mask, g_merged_dec, g_merged_attach, L, T, r, d_x1, d_y1, (float*)ws);
+#define VLG_GO_R(IN, RR)                                                                                                            \
+    {                                                                                                                               \
+        auto k = scorer_bwd_kernel<IN, RR>;                                                                                         \
+        if (int rc = prep_lds(k, lds)) return rc;                                                                                   \
+        hipLaunchKernelGGL(k, dim3(B), dim3(kScThreads), lds, s, (const IN::T*)x1, (const IN::T*)x2, (const IN::T*)y1, (const IN::T*)y2, \
+                           token, head_mask, g_merged_dec, g_merged_attach, L, T, r, d_x1, d_y1, (float*)ws);                      \
     }
+#define VLG_GO(IN)                                  \
+    {                                               \
+        if (r == 16) VLG_GO_R(IN, 16)               \
+        else if (r == 8) VLG_GO_R(IN, 8)            \
+        else if (r == 32) VLG_GO_R(IN, 32)          \
+        else if (r == 64) VLG_GO_R(IN, 64)          \
+        else VLG_GO_R(IN, 0)                        \
+    }
+    if (in_dtype == VLG_F32) VLG_GO(F32In)
+    else VLG_GO(BF16In)
+#undef VLG_GO
+#undef VLG_GO_R
     if (int rc = check_launch("scorer_bwd_kernel")) return rc;
-    hipLaunchKernelGGL(scorer_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)ws, B, n, d_x2, n_x2, d_y2, n_y2, d_root_rule);
+    hipLaunchKernelGGL(scorer_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, (const float*)ws, B, n, d_x2, n_x2, d_y2, n_y2, d_root_rule);
     return check_launch("scorer_reduce_kernel");
 }
 
