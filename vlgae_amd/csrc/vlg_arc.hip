@@ -39,7 +39,7 @@ template <bool F32IN, int KCH, int RT>
 __global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename MfmaCfg<F32IN>::T* __restrict__ c,
                                                              const typename MfmaCfg<F32IN>::T* __restrict__ w,
                                                              const typename MfmaCfg<F32IN>::T* __restrict__ p, int M, int X,
-                                                             int H, float* __restrict__ out) {
+                                                             int H, int xs, float* __restrict__ out) {
     using C = MfmaCfg<F32IN>;
     using Frag = typename C::Frag;
     constexpr int Y = KCH * C::KW, FPK = C::KW / C::EPL;   // fragment stride between K chunks, in Frag units
@@ -47,8 +47,22 @@ __global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename Mfma
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* cT = reinterpret_cast<float*>(smem_raw);   // [x range][ROWS]: c of this block's rows, transposed, fp32
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * ROWS;
-    const int xper = (X + gridDim.y - 1) / gridDim.y, xb = blockIdx.y * xper, xe = min(X, xb + xper), nx = xe - xb;
+    // 1-D grid; blocks whose ids agree modulo 8 share an XCD (and its 4 MB L2).  With two x ranges, ids {0..3} + 8k take the
+    // first range and {4..7} + 8k the second: an XCD streams only ITS half of the weights (2 MB bf16 at 128^3), which then
+    // stays L2-resident next to the blocks' own rows instead of thrashing a cache of exactly the weights' size.
+    const int n_rb = (M + ROWS - 1) / ROWS;
+    int rb, yb;
+    if (xs == 2) {
+        const int grp = blockIdx.x >> 3, in8 = blockIdx.x & 7;
+        yb = in8 >> 2;
+        rb = grp * 4 + (in8 & 3);
+        if (rb >= n_rb) return;   // the grid is padded to a multiple of 8 (whole block exits: no barrier is skipped by part of it)
+    } else {
+        rb = blockIdx.x % n_rb;
+        yb = blockIdx.x / n_rb;
+    }
+    const int m0 = rb * ROWS;
+    const int xper = (X + xs - 1) / xs, xb = yb * xper, xe = min(X, xb + xper), nx = xe - xb;
     for (int i = threadIdx.x; i < ROWS * nx; i += 64 * kTriWaves) {
         const int row = i / nx, x = i - row * nx;   // coalesced read, transposed write
         cT[x * ROWS + row] = m0 + row < M ? tri_ld<F32IN>(c, (size_t)(m0 + row) * X + xb + x) : 0.f;
@@ -108,7 +122,7 @@ __global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename Mfma
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    const bool split = gridDim.y > 1;
+    const bool split = xs > 1;
 #pragma unroll
     for (int j = 0; j < kTriHPW; ++j) {
         const int ht = wave + kTriWaves * j;
@@ -140,8 +154,9 @@ static int launch_tri_rt(const void* c, const void* w, const void* p, int M, int
         hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)M * H, s);
         if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(k, dim3((M + 16 * RT - 1) / (16 * RT), xs), dim3(64 * kTriWaves), lds, s, (const T*)c, (const T*)w,
-                       (const T*)p, M, X, H, out);
+    const int n_rb = (M + 16 * RT - 1) / (16 * RT);
+    const int blocks = xs == 2 ? ((n_rb + 3) / 4) * 8 : n_rb * xs;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * kTriWaves), lds, s, (const T*)c, (const T*)w, (const T*)p, M, X, H, xs, out);
     return 0;
 }
 
@@ -371,8 +386,134 @@ __global__ __launch_bounds__(64 * kDwSplit) void tri_dw_kernel(const typename Mf
     }
 }
 
+// ---- d_w on transposed LDS reads (round 3; bf16, H = Y = 128) ---------------------------------------------------------------
+// d_w[x] = (g . c[:,x])^T p is a [128 x M] x [M x 128] product per x whose contraction index m is the slow dimension of all
+// three operands: tri_dw_kernel above reads transposed copies (three transpose launches) and streams them from L2 per
+// (x, h-group) wave at 12 % matrix-core utilisation.  Here one workgroup owns XB values of x and a chunk of the rows: each
+// 64-row stage of g and p is loaded once (row-major, coalesced), the A operand g[m,:] * c[m,x] is formed ONCE per stage as
+// it is written to LDS (fp32 product, rounded to bf16 like tri_dw_kernel's), and both operands reach the MFMA through
+// ds_read_b64_tr_b16 (vlg_mfma.h).  Row chunks give the chip 256 workgroups; their partial tiles are added in a fixed order.
+constexpr int kDw2Threads = 1024, kDw2Stage = 64, kDw2XB = 2;   // 16 waves: four per SIMD (the fragment reads' LDS latency needs them), each a 32 x 32 part of the 128 x 128 tile
+constexpr int kDw2Pitch = 128 * 2 + 32;   // 288 r mod 256 = 32 r: 8 consecutive rows on 8 disjoint 8-bank groups
+
+__device__ __forceinline__ uint32_t dw2_scale2(uint32_t v, float cf) {   // two bf16 in a dword, each times cf, rounded to nearest even
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const float lo = __uint_as_float(v << 16) * cf, hi = __uint_as_float(v & 0xffff0000u) * cf;
+    const bf16x2 o = {(__bf16)lo, (__bf16)hi};   // v_cvt_pk_bf16_f32: round to nearest even, like tri_dw_kernel's integer rounding
+    return __builtin_bit_cast(uint32_t, o);
+}
+
+__global__ __launch_bounds__(kDw2Threads) void tri_dw2_kernel(const uint16_t* __restrict__ c, const uint16_t* __restrict__ g,
+                                                              const uint16_t* __restrict__ p, int M, int X, int KC, int S,
+                                                              float* __restrict__ part) {
+    constexpr int HY = 128;
+    extern __shared__ __attribute__((aligned(16))) char dw2_smem[];   // two stage buffers of (XB + 1) tiles
+    constexpr int kTileBytes = kDw2Stage * kDw2Pitch, kBufBytes = (kDw2XB + 1) * kTileBytes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
+    // blocks whose ids agree modulo 8 share an XCD and its L2: give them the SAME row chunk (S divides 8), so a chunk of g and
+    // p is fetched from HBM / Infinity Cache once per XCD pair instead of once per workgroup
+    const int s = blockIdx.x % S, x0 = (blockIdx.x / S) * kDw2XB;
+    const int k_begin = s * KC, k_end = min(M, k_begin + KC), rows = k_end - k_begin;
+    // staging: a tile row is 128 bf16 = 16 x 16 bytes; 1024 threads cover the 64 rows of a stage in one pass
+    constexpr int NP = kDw2Stage / (kDw2Threads / 16), RPP = kDw2Threads / 16;
+    const int ch = tid & 15, r0 = tid >> 4;
+    uint4 rg[NP], rp[NP];
+    uint32_t rc[NP];
+    auto fetch = [&](int ks) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int k = k_begin + ks + r0 + RPP * q;
+            const bool ok = k < k_end;
+            rg[q] = ok ? *reinterpret_cast<const uint4*>(g + (size_t)k * HY + ch * 8) : make_uint4(0, 0, 0, 0);
+            rp[q] = ok ? *reinterpret_cast<const uint4*>(p + (size_t)k * HY + ch * 8) : make_uint4(0, 0, 0, 0);
+            rc[q] = ok ? *reinterpret_cast<const uint32_t*>(c + (size_t)k * X + x0) : 0u;   // c[k, x0], c[k, x0 + 1]
+        }
+    };
+    auto stash = [&](int buf) {
+        char* sP = dw2_smem + buf * kBufBytes + kDw2XB * kTileBytes;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int off = (r0 + RPP * q) * kDw2Pitch + ch * 16;
+            *reinterpret_cast<uint4*>(sP + off) = rp[q];
+#pragma unroll
+            for (int xb = 0; xb < kDw2XB; ++xb) {
+                const float cf = __uint_as_float(xb == 0 ? rc[q] << 16 : rc[q] & 0xffff0000u);
+                uint4 o;
+                o.x = dw2_scale2(rg[q].x, cf); o.y = dw2_scale2(rg[q].y, cf);
+                o.z = dw2_scale2(rg[q].z, cf); o.w = dw2_scale2(rg[q].w, cf);
+                *reinterpret_cast<uint4*>(dw2_smem + buf * kBufBytes + xb * kTileBytes + off) = o;
+            }
+        }
+    };
+    const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    const int row_off = (4 * g4 + q4) * kDw2Pitch + p4 * 8;
+    f32x4 acc[kDw2XB][2][2] = {};
+    // one barrier per stage: while the MFMAs of stage i read buffer i & 1, stage i + 1 (in registers since the previous
+    // iteration) is scaled and written to the other buffer, and stage i + 2 is requested from memory
+    fetch(0);
+    stash(0);
+    if (kDw2Stage < rows) fetch(kDw2Stage);
+    __syncthreads();
+    for (int ks = 0, buf = 0; ks < rows; ks += kDw2Stage, buf ^= 1) {
+        const char* base = dw2_smem + buf * kBufBytes;
+#pragma unroll
+        for (int kk = 0; kk < kDw2Stage / 32; ++kk) {
+            bf16x8 fb[2];
+            const char* pb = base + kDw2XB * kTileBytes + row_off + kk * 32 * kDw2Pitch + (wn * 32) * 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = tr_frag(tr_read(pb + j * 32), tr_read(pb + 16 * kDw2Pitch + j * 32));
+#pragma unroll
+            for (int xb = 0; xb < kDw2XB; ++xb) {
+                const char* pa = base + xb * kTileBytes + row_off + kk * 32 * kDw2Pitch + (wm * 32) * 2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16x8 fa = tr_frag(tr_read(pa + i * 32), tr_read(pa + 16 * kDw2Pitch + i * 32));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[xb][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[xb][i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (ks + kDw2Stage < rows) {
+            stash(buf ^ 1);
+            if (ks + 2 * kDw2Stage < rows) fetch(ks + 2 * kDw2Stage);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int xb = 0; xb < kDw2XB; ++xb) {
+        if (x0 + xb >= X) break;
+        float* out = part + ((size_t)s * X + x0 + xb) * HY * HY;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(size_t)(wm * 32 + i * 16 + 4 * g4 + r) * HY + wn * 32 + j * 16 + (lane & 15)] = acc[xb][i][j][r];
+    }
+}
+
+// d_w[i] = sum_s part[s][i], s ascending (n % 4 == 0)
+__global__ __launch_bounds__(256) void tri_dw2_reduce_kernel(const float* __restrict__ part, int S, size_t n, float* __restrict__ d_w) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 t = *reinterpret_cast<const float4*>(part + i);
+    for (int s = 1; s < S; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * n + i);
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(d_w + i) = t;
+}
+
+static bool dw2_applies(int M, int X, int H, int Y, bool f32in) { return !f32in && H == 128 && Y == 128 && X % kDw2XB == 0 && M >= 1024; }
+static int dw2_splits(int M, int X) {   // 1, 2, 4 or 8 (a divisor of the XCD count): ~one workgroup per CU, at least four stages each
+    int S = 8;
+    while (S > 1 && ((X / kDw2XB) * (S / 2) >= 256 || (M + S - 1) / S < 4 * kDw2Stage)) S /= 2;
+    return S;
+}
+
 struct TriBwdPlan {   // scratch carving (bytes), shared by the size query and the launcher
-    size_t esz, Mp, off_wA, off_wB, off_gB, off_cT, off_gT, off_pT, bytes;
+    size_t esz, Mp, off_wA, off_wB, off_gB, off_cT, off_gT, off_pT, off_part, bytes;
     TriBwdPlan(int M, int X, int H, int Y, bool f32in) {
         esz = f32in ? 4 : 2;
         const int kw = f32in ? 16 : 32;
@@ -385,7 +526,8 @@ struct TriBwdPlan {   // scratch carving (bytes), shared by the size query and t
         off_cT = off_gB + up((size_t)M * H * esz);
         off_gT = off_cT + up((size_t)X * Mp * esz);
         off_pT = off_gT + up((size_t)H * Mp * esz);
-        bytes = off_pT + up((size_t)Y * Mp * esz);
+        off_part = off_pT + up((size_t)Y * Mp * esz);
+        bytes = off_part + (dw2_applies(M, X, H, Y, f32in) ? up(sizeof(float) * (size_t)dw2_splits(M, X) * X * H * Y) : 0);
     }
 };
 
@@ -411,7 +553,21 @@ static int run_tri_backward(const void* child, const void* w, const void* parent
         hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wB, X, H, Y, 1);
         if (int rc = dispatch_tri(child, wB, g_op, M, X, Y, H, F32IN, d_parent, s)) return rc;
     }
-    if (d_w) {
+    if (d_w && dw2_applies(M, X, H, Y, F32IN)) {
+        if constexpr (!F32IN) {
+            const int S = dw2_splits(M, X);
+            const int KC = ((M + S - 1) / S + kDw2Stage - 1) / kDw2Stage * kDw2Stage;
+            const int Sx = S;   // a trailing chunk may be empty (its partial tile is then zero)
+            float* part = reinterpret_cast<float*>(ws + p.off_part);
+            const size_t lds = 2 * (size_t)(kDw2XB + 1) * kDw2Stage * kDw2Pitch;   // 110 KB
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(tri_dw2_kernel, dim3((X / kDw2XB) * Sx), dim3(kDw2Threads), lds, s, (const uint16_t*)child, (const uint16_t*)gB,
+                               (const uint16_t*)parent, M, X, KC, Sx, part);
+            const size_t n = (size_t)X * H * Y;
+            hipLaunchKernelGGL(tri_dw2_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, part, Sx, n, d_w);
+        }
+    } else if (d_w) {
         if (Y > 16 * kDwYT || Y % 16) return set_error(VLG_ERR_SHAPE, "trilinear_backward: Y=%d must be a multiple of 16 and <= 128", Y);
         const int Mp = (int)p.Mp;
         dim3 tb(256);

@@ -27,19 +27,6 @@ constexpr int kStage = 128;         // contraction rows per LDS stage
 // 160 r mod 256 = {0,160,64,224,128,32,192,96} for r = 0..7 puts them on 8 disjoint 8-bank groups (64 banks x 4 bytes).
 constexpr int kPitch = kTile * 2 + 32;
 
-typedef short v4i16 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
-
-__device__ __forceinline__ v4i16 tr_read(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p));
-}
-
-__device__ __forceinline__ bf16x8 frag_from(v4i16 lo, v4i16 hi) {
-    typedef short v8i16 __attribute__((ext_vector_type(8)));
-    v8i16 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-
 // C_part[s] (64 x 64 tile) = sum over the rows of split s of A[k, m0..m0+63]^T B[k, n0..n0+63]; optionally the column sums of A.
 // grid = (M/64 * N/64, S); A [K, lda], B [K, ldb] bf16; part [S][M][N] fp32, part_cs [S][M] fp32 (or null).
 __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
@@ -98,8 +85,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
             bf16x8 fa[2], fb[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                fa[t] = frag_from(tr_read(a_base + kk * 32 * kPitch + t * 32), tr_read(a_base + (kk * 32 + 16) * kPitch + t * 32));
-                fb[t] = frag_from(tr_read(b_base + kk * 32 * kPitch + t * 32), tr_read(b_base + (kk * 32 + 16) * kPitch + t * 32));
+                fa[t] = tr_frag(tr_read(a_base + kk * 32 * kPitch + t * 32), tr_read(a_base + (kk * 32 + 16) * kPitch + t * 32));
+                fb[t] = tr_frag(tr_read(b_base + kk * 32 * kPitch + t * 32), tr_read(b_base + (kk * 32 + 16) * kPitch + t * 32));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)

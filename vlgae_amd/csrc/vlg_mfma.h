@@ -41,4 +41,20 @@ __device__ __forceinline__ f32x4 mma_chunk(const typename MfmaCfg<F32IN>::Frag& 
     }
 }
 
+// ---- transposed LDS reads (gfx950 ds_read_b64_tr_b16): operands whose contraction index is the SLOW dimension in memory.
+// A 16-lane group reads a 4-row x 16-column block of 16-bit elements and every lane receives one column of it: lane 4q+p of the
+// group supplies the address of row q, columns 4p..4p+3 (8 bytes, 8-byte aligned); lane i receives column i, rows 0..3.
+// EXEC must be all ones.  Two reads (rows 4g.. and 16+4g.. of a 32-row step for group g) make one 16x16x32 operand; both
+// operands of an MFMA must use the same row assignment.
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+
+__device__ __forceinline__ v4i16 tr_read(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(p)); }
+
+__device__ __forceinline__ bf16x8 tr_frag(v4i16 lo, v4i16 hi) {
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    v8i16 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 }  // namespace vlg

@@ -332,7 +332,6 @@ int vlg_ndmv_potentials(const void* x1, const void* x2, const void* y1, const vo
         if (r == 16) VLG_GO_R(IN, OUT, 16)               \
         else if (r == 8) VLG_GO_R(IN, OUT, 8)            \
         else if (r == 32) VLG_GO_R(IN, OUT, 32)          \
-        else if (r == 64) VLG_GO_R(IN, OUT, 64)          \
         else VLG_GO_R(IN, OUT, 0)                        \
     }
     if (in_dtype == VLG_F32 && out_dtype == VLG_F32) VLG_GO(F32In, float)
@@ -381,7 +380,6 @@ int vlg_ndmv_potentials_backward(const void* x1, const void* x2, const void* y1,
         if (r == 16) VLG_GO_R(IN, 16)               \
         else if (r == 8) VLG_GO_R(IN, 8)            \
         else if (r == 32) VLG_GO_R(IN, 32)          \
-        else if (r == 64) VLG_GO_R(IN, 64)          \
         else VLG_GO_R(IN, 0)                        \
     }
     if (in_dtype == VLG_F32) VLG_GO(F32In)
