@@ -47,9 +47,16 @@ def test_sampler_properties_and_rank_sharding():
         assert len(b) == 1 or all(lens[i] < thr for i in b)                           # over-long sentences travel alone
         assert all(lens[b[q]] >= lens[b[q + 1]] for q in range(len(b) - 1))           # decreasing length inside a batch
         assert len(b) <= int(g["max_sentence"])
-    shards = [list(_sampler(g, rank=r, world_size=3)) for r in range(3)]             # same seed -> same epoch list on every rank
-    assert sorted(map(tuple, (b for s in shards for b in s))) == sorted(map(tuple, whole))
-    assert max(map(len, shards)) - min(map(len, shards)) <= 1
+    for world in (2, 3, 4, 7):
+        samplers = [_sampler(g, rank=r, world_size=world) for r in range(world)]     # same seed -> same epoch list on every rank
+        shards = [list(sm) for sm in samplers]
+        # every rank runs the SAME number of steps (a data-parallel step ends in a collective): the epoch's batch list is
+        # wrapped around to a multiple of the world size, so the union is the whole epoch plus < world repeated batches
+        per = -(-len(whole) // world)
+        assert all(len(s) == per for s in shards) and all(len(sm) == per for sm in samplers)
+        dealt = [tuple(b) for r in range(per) for s in shards for b in [s[r]]]      # round-robin order = the padded epoch list
+        assert dealt[:len(whole)] == [tuple(b) for b in whole]
+        assert dealt[len(whole):] == [tuple(b) for b in whole[:per * world - len(whole)]]
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -61,6 +61,10 @@ class _GatherLogit(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, txt_feat, vis_feat, txt_mask, vis_mask, neg_inf):
+        if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and txt_feat.shape[-1] not in (32, 64, 128):
+            # the backward kernels cover the matching widths 32 / 64 / 128: say so HERE, not inside loss.backward()
+            raise ValueError(f"gather_logit: gradients need a matching width of 32, 64 or 128 (got d={txt_feat.shape[-1]}); "
+                             "detach the features for inference-only use")
         ctx.save_for_backward(txt_feat, vis_feat, txt_mask, vis_mask)
         return bilinear_align(txt_feat, vis_feat, txt_mask, vis_mask, neg_inf)["full"]
 

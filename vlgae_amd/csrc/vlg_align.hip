@@ -1416,7 +1416,7 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
                                featT, (uint16_t*)nullptr);
         int split = 1;   // two blocks per CU at least; two-addend atomics are order-free
         if ((long)fixn * 2 <= 1024 && O >= 16) split = 2;
-        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e);
+        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;
         const int opb = (O + split - 1) / split;
         if (split > 1) {
             hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)fixn * M * 128, s);
@@ -1451,9 +1451,11 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
         const size_t lds = 2 * (size_t)ns * 4 * (d + 16) * esz;
         const int tiles = (M + 15) / 16, gx = (tiles + 3) / 4;
         // split the outer range over several workgroups; their partial sums meet in a zeroed output by atomicAdd
-        int split = 1;   // >= 3 workgroups per CU: the cotangent streams from HBM and only other waves hide that latency
-        while (split < 8 && (long)gx * fixn * split < 768 && O / (split * 2) >= 16) split *= 2;
-        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e);   // tools/ experiments only
+        // more workgroups per CU hide the cotangent's HBM latency, but the partial sums meet by atomicAdd and only TWO addends are
+        // order-free (a + b == b + a; three or more are not associative in fp32): the split stops at 2 -- bit-reproducible
+        int split = 1;
+        if ((long)gx * fixn < 768 && O / 2 >= 16) split = 2;
+        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;   // tools/ experiments only
         const int opb = (O + split - 1) / split;
         if (split > 1) {
             hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)fixn * M * d, s);
@@ -1491,7 +1493,7 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
         hipLaunchKernelGGL(align_bwd_concat_transpose_kernel, dim3((unsigned)((pitch + 31) / 32)), dim3(256), 0, s, (const uint16_t*)vis,
                            vmask, A * V, pitch, visT);
         int split = ((long)B * 2 <= 1024 && A >= 16) ? 2 : 1;
-        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e);
+        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;
         const int opb = ((A + split - 1) / split + 1) & ~1;   // even: a step's tile rows start on 16-byte boundaries of featC
         if (split > 1) {
             hipError_t e = hipMemsetAsync(grad_txt, 0, sizeof(float) * (size_t)B * Q * 128, s);

@@ -181,7 +181,7 @@ static int launch_tri(const void* c, const void* w, const void* p, int M, int X,
     const int xs = X >= 32 ? 2 : 1;
     const int cus = device_cus();
     const float stream = F32IN ? 1.5f : 34.f;   // the constant term in units of one 16-row MFMA pass
-    const int cand[3] = {F32IN ? 3 : 4, F32IN ? 4 : 6, F32IN ? 4 : 8};
+    const int cand[3] = {F32IN ? 3 : 4, F32IN ? 4 : 6, F32IN ? 4 : 6};   // (bf16 with 8 row tiles needs 512 registers + scratch: dropped)
     int best = cand[2];
     float best_cost = 0.f;
     for (int i = 0; i < 3; ++i) {
@@ -194,8 +194,7 @@ static int launch_tri(const void* c, const void* w, const void* p, int M, int X,
         return launch_tri_rt<true, KCH, 4>(c, w, p, M, X, H, xs, out, s);
     } else {
         if (best == 4) return launch_tri_rt<false, KCH, 4>(c, w, p, M, X, H, xs, out, s);
-        if (best == 6) return launch_tri_rt<false, KCH, 6>(c, w, p, M, X, H, xs, out, s);
-        return launch_tri_rt<false, KCH, 8>(c, w, p, M, X, H, xs, out, s);
+        return launch_tri_rt<false, KCH, 6>(c, w, p, M, X, H, xs, out, s);
     }
 }
 

@@ -188,6 +188,24 @@ __device__ __forceinline__ DmvCtx carve_dmv(int N, int len, char* smem, char* ws
     return c;
 }
 
+template <int SR, int MODE, bool BWD>
+__device__ __forceinline__ DepCtx carve_dep(int N, int len, char* smem, char* wsb) {
+    const DepLayout L(N, BWD, SR == VLG_SR_MAX, MODE);
+    DepCtx c;
+    c.Ne = len + 1;
+    c.len = len;
+    c.P = chart_pitch(N);
+    c.C = region_ptr<float>(L.C, smem, wsb);
+    c.I = region_ptr<float>(L.I, smem, wsb);
+    c.S = region_ptr<float>(L.S, smem, wsb);
+    c.bpS = region_ptr<unsigned char>(L.bpS, smem, wsb);
+    c.bpC = region_ptr<unsigned char>(L.bpC, smem, wsb);
+    c.gCc = region_ptr<float>(L.gCc, smem, wsb);
+    c.gCi = region_ptr<float>(L.gCi, smem, wsb);
+    c.gI = region_ptr<float>(L.gI, smem, wsb);
+    return c;
+}
+
 template <int SR, int MODE, bool BWD, typename In>
 __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* __restrict__ dec,
                                                          const typename In::T* __restrict__ attach,
@@ -286,20 +304,8 @@ __global__ __launch_bounds__(kThreads) void deptree_kernel(const typename In::T*
         }
         return;
     }
-    const DepLayout L(N, BWD, SR == VLG_SR_MAX, MODE);
     char* wsb = ws + (size_t)b * ws_stride;
-    DepCtx c;
-    c.Ne = len + 1;
-    c.len = len;
-    c.P = chart_pitch(N);
-    c.C = region_ptr<float>(L.C, smem, wsb);
-    c.I = region_ptr<float>(L.I, smem, wsb);
-    c.S = region_ptr<float>(L.S, smem, wsb);
-    c.bpS = region_ptr<unsigned char>(L.bpS, smem, wsb);
-    c.bpC = region_ptr<unsigned char>(L.bpC, smem, wsb);
-    c.gCc = region_ptr<float>(L.gCc, smem, wsb);
-    c.gCi = region_ptr<float>(L.gCi, smem, wsb);
-    c.gI = region_ptr<float>(L.gI, smem, wsb);
+    const DepCtx c = carve_dep<SR, MODE, BWD>(N, len, smem, wsb);
     DevX x;
     dep_run<SR, BWD, In>(c, arc + arc_off, N, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b,
                          (BWD && garc) ? garc + arc_off : nullptr, (BWD && heads) ? heads + (size_t)b * N : nullptr, tid,

@@ -112,7 +112,16 @@ class ConstantTokenNumSampler:
                                            _p(offs), _p(items), ctypes.byref(nb)), "feed.batches")
         offs, items = offs[:nb.value + 1].tolist(), items.tolist()
         self._all_batches = [items[offs[j]:offs[j + 1]] for j in range(nb.value)]
-        self._batches = self._all_batches[self.rank::self.world_size] if self.world_size > 1 else self._all_batches
+        if self.world_size > 1:
+            # every rank must run the SAME number of steps: the data-parallel step ends in a collective, and a rank with one
+            # batch more would wait in it forever.  The epoch's batch list is wrapped around to a multiple of the world size
+            # before it is dealt out (rank r takes batches r, r + W, ...), so ranks differ by repeated batches, never by count.
+            n_all = len(self._all_batches)
+            per = -(-n_all // self.world_size) if n_all else 0
+            padded = self._all_batches + self._all_batches[:per * self.world_size - n_all]
+            self._batches = padded[self.rank::self.world_size]
+        else:
+            self._batches = self._all_batches
         self._exhausted = False
 
     def _init_iter_with_retry(self, max_try=5):
@@ -182,10 +191,23 @@ class RegionFeatLoader:
         if pin:   # one asynchronous copy per tensor on a side stream; the consumer's stream waits on it
             if self._stream is None:
                 self._stream = torch.cuda.Stream(self.device)
+            cur = torch.cuda.current_stream(self.device)
+            # The device tensors are allocated HERE, on the consumer's stream (they belong to ITS allocator pool: when the
+            # training loop drops a batch the block is reused in that stream's order), the side stream first waits for
+            # the consumer (whatever used the block before has finished) and the consumer joins the copies before the
+            # tensors are handed out -- no record_stream bookkeeping (not HIP-graph-capture-safe), no cross-pool reuse.
+            host = [feat, box, mask] + ([] if rel is None else [rel])
+            dev_t = [torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in host]
+            if rel is not None and not rel.is_pinned():
+                host[3] = rel.pin_memory()
+            self._stream.wait_stream(cur)
             with torch.cuda.stream(self._stream):
-                feat, box, mask = (t.to(self.device, non_blocking=True) for t in (feat, box, mask))
-                rel = None if rel is None else rel.to(self.device, non_blocking=True)
-            torch.cuda.current_stream(self.device).wait_stream(self._stream)
+                for d, h in zip(dev_t, host):
+                    d.copy_(h, non_blocking=True)
+            cur.wait_stream(self._stream)
+            self._staging = host   # the pinned sources stay referenced until the next call: the copies may still be in flight
+            feat, box, mask = dev_t[:3]
+            rel = dev_t[3] if rel is not None else None
         return ({"vis_box_feat": feat, "vis_box_mask": mask, "vis_rel_mask": rel, "vis_available": mask[:, 0]},
                 {"vis_box": box})
 
