@@ -367,7 +367,8 @@ int vlg_selftest_xlane(int* scratch, void* stream);
 /* Thread-local message for the last non-zero return on this thread ("" if none). */
 const char* vlg_last_error(void);
 
-/* Library / ABI version, e.g. 110 = 0.1.1 (round 2: vlg_bilinear_align_backward takes a workspace; vlg_scale_counts, vlg_feed_* added). */
+/* Library / ABI version, e.g. 120 = 0.1.2 (round 3: vlg_linear_wgrad, vlg_langfeat_*, vlg_ndmv_potentials*, vlg_dmv1o_viterbi added;
+ * round 2, 110: vlg_bilinear_align_backward takes a workspace; vlg_scale_counts, vlg_feed_* added). */
 int vlg_version(void);
 
 #ifdef __cplusplus

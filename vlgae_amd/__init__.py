@@ -9,3 +9,14 @@ Sub-modules
 Everything computes through hand-written gfx950 kernels behind the C ABI of include/vlgae_amd.h.
 """
 __version__ = "0.1.0"
+
+
+def configure_autograd():
+    """Run autograd's backward pass on the calling thread: `torch.autograd.set_multithreading_enabled(False)`.
+
+    torch hands the backward of a GPU graph to a per-device engine thread; the hand-off is a condition-variable wake-up that
+    costs 50-120 us per `backward()` / `autograd.grad()` call on these hosts -- more than the fused DP kernel takes (82 us).
+    A one-process-per-GPU trainer has no use for that thread.  Call this once at start-up (INTEGRATION.md section 2 puts it
+    next to the import alias); `vlgae_amd.torch_struct` warns once if it sees its backward running on another thread."""
+    import torch
+    torch.autograd.set_multithreading_enabled(False)

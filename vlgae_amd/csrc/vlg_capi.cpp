@@ -10,5 +10,5 @@ char* error_buffer() {
 
 extern "C" {
 const char* vlg_last_error(void) { return vlg::error_buffer(); }
-int vlg_version(void) { return 110; }   // 0.1.1: workspace argument of vlg_bilinear_align_backward, vlg_scale_counts, the data-feed entry points
+int vlg_version(void) { return 120; }   // 0.1.2: vlg_linear_wgrad, vlg_langfeat_*, vlg_ndmv_potentials*, vlg_dmv1o_viterbi (round 3)
 }

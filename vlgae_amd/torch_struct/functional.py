@@ -5,6 +5,9 @@ call).  Here the outside pass is part of the same kernel 
 pass: when any potential requires grad, forward() runs the fused inside+outside kernel and keeps the
 unit-upstream expected counts; backward() only scales them by the incoming gradient of logZ.
 """
+import threading
+import warnings
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -281,16 +284,32 @@ class _DMV1oSum(torch.autograd.Function):
             logZ, gdec, gatt = dmv1o_run(dec, attach, lengths, semiring, want, logZ_shape=(dec.shape[0], 1))   # [B,1], helpers.py:116
         if want:
             ctx.save_for_backward(gdec, gatt)
+            ctx.fwd_thread = threading.get_ident()
         ctx.in_dtypes = (dec.dtype, attach.dtype)
         return logZ.double() if dec.dtype == torch.float64 else logZ
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
+        _note_backward_thread(ctx)
         gdec, gatt = ctx.saved_tensors
         want_d, want_a = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gd, ga = _scale_counts(gdec if want_d else None, gatt if want_a else None, grad_out, ctx.in_dtypes[0], ctx.in_dtypes[1])
         return gd, ga, None, None
+
+
+_WARNED_ENGINE_THREAD = False
+
+
+def _note_backward_thread(ctx):
+    """Warn once when backward runs on torch's autograd engine thread instead of the thread that ran forward."""
+    global _WARNED_ENGINE_THREAD
+    if not _WARNED_ENGINE_THREAD and getattr(ctx, "fwd_thread", None) not in (None, threading.get_ident()):
+        _WARNED_ENGINE_THREAD = True
+        warnings.warn("vlgae_amd: backward is running on torch's autograd engine thread; the hand-off costs 50-120 us per call, "
+                      "more than the fused DP kernel takes. A one-process-per-GPU trainer should call "
+                      "vlgae_amd.configure_autograd() (= torch.autograd.set_multithreading_enabled(False)) once at start-up.",
+                      RuntimeWarning, stacklevel=2)
 
 
 def _scale_counts(ca, cb, grad_out, dtype_a, dtype_b):
