@@ -208,6 +208,13 @@ int vlg_grounding_decode(float* logit, const float* pen, const uint8_t* seg_of_v
 int vlg_trilinear(const void* child, const void* w, const void* parent, int M, int X, int H, int Y, int in_dtype, float* out,
                   void* stream);
 
+/* The same with a caller-owned scratch for fixed-order partial sums (vlg_trilinear_workspace bytes; 0 = none needed): for bf16 and
+ * H = Y = 128 the x range is then split over ~one workgroup per CU (slabs added in a fixed order by a second launch) instead of
+ * two ranges met by atomics.  ws may be NULL / too small: the call then behaves like vlg_trilinear. */
+size_t vlg_trilinear_workspace(int M, int X, int H, int Y, int in_dtype);
+int vlg_trilinear_ws(const void* child, const void* w, const void* parent, int M, int X, int H, int Y, int in_dtype, void* ws,
+                     size_t ws_bytes, float* out, void* stream);
+
 /* Adjoint of vlg_trilinear for the cotangent g [M,H] (fp32): d_child [M,X], d_w [X,H,Y], d_parent [M,Y], all fp32, each
  * optional (NULL = skip).  The two input gradients are the forward kernel run on permuted copies of w; d_w contracts over
  * m from transposed copies of the three operands.  H and Y in {32, 64, 128}; X a multiple of 16, <= 128 (for d_child).

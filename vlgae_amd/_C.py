@@ -42,6 +42,8 @@ SIGNATURES = {
     "vlg_grounding_decode_workspace": (_sz, [_i, _i]),
     "vlg_grounding_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "vlg_trilinear": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vlg_trilinear_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "vlg_trilinear_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "vlg_trilinear_backward_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "vlg_trilinear_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "vlg_attn_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),

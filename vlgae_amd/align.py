@@ -468,9 +468,10 @@ def decode_grounding_on_factor(self, inputs, vp):
 def _trilinear_launch(child_c, w_c, parent_c, dt):
     M, X = child_c.shape
     H, Y = w_c.shape[1], w_c.shape[2]
-    out = torch.empty((M, H), dtype=torch.float32, device=child_c.device)
-    _C.check(_C.lib().vlg_trilinear(_C.ptr(child_c), _C.ptr(w_c), _C.ptr(parent_c), M, X, H, Y, dt, _C.ptr(out),
-                                    _C.stream_of(child_c)), "trilinear")
+    nbytes = _C.lib().vlg_trilinear_workspace(M, X, H, Y, dt)
+    (out,), ws = _C.alloc_f32(child_c.device, ((M, H),), nbytes)
+    _C.check(_C.lib().vlg_trilinear_ws(_C.ptr(child_c), _C.ptr(w_c), _C.ptr(parent_c), M, X, H, Y, dt, _C.ptr(ws) if nbytes else None,
+                                       nbytes, _C.ptr(out), _C.stream_of(child_c)), "trilinear")
     return out
 
 

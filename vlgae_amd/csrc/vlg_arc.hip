@@ -141,6 +141,165 @@ __global__ __launch_bounds__(64 * kTriWaves) void tri_kernel(const typename Mfma
     }
 }
 
+// ---- round 3: the same contraction with the weight planes staged through LDS (bf16, H = Y = 128) -----------------------------
+// tri_kernel keeps 96 rows of p fragments and a 4-plane weight ring in 384 registers: one wave per SIMD, every weight-fragment
+// read's L2 latency exposed (78 us at M = 10 496, 22 % of the bf16 matrix-core peak), and every 96-row block streams its half
+// of the 4 MB weight tensor from L2: 440 MB per launch at the ~5.5 TB/s the L2 -> CU fabric delivered in every variant measured
+// (a 128-row LDS-staged version moved 344 MB in 72 us whatever its pipelining or XCD mapping: the traffic, not the schedule, set
+// the time).  Here a workgroup owns 256 rows x all 128 h for a range of x -- 41 row blocks x 4 MB = 164 MB per launch -- each
+// weight plane w[x] (128 x 128 bf16 = 32 KB, contiguous) is loaded ONCE per workgroup, coalesced, into a double-buffered
+// XOR-swizzled LDS image (16-byte segment s of row r at slot 16 r + (s ^ (r & 15)): the ds_read_b128 fragment reads are
+// conflict-free without padding -- align_max_kernel's scheme) while the previous plane's MFMAs run; 8 waves, each 64 rows x 64 h
+// (p fragments resident: 64 VGPRs), two per SIMD; one barrier per plane.  c[m, x] scales the plane's result tile row-wise as
+// before.  The x range is split over `xs` workgroups (6 at M = 10 496: 246 workgroups); their partial sums go to separate slabs that
+// a second launch adds in a fixed order (bit-reproducible; two-addend atomics when the caller has no workspace).
+constexpr int kTri2Threads = 512, kTri2Rows = 256;
+
+__global__ __launch_bounds__(kTri2Threads) void tri2_kernel(const uint16_t* __restrict__ c, const uint16_t* __restrict__ w,
+                                                            const uint16_t* __restrict__ p, int M, int X, int xs,
+                                                            float* __restrict__ out, size_t part_stride, int use_atomic) {
+    constexpr int H = 128, Y = 128, KCH = 4;
+    extern __shared__ __attribute__((aligned(16))) char tri2_smem[];
+    uint4* wbuf = reinterpret_cast<uint4*>(tri2_smem);                       // [2][128 rows][16 segments]
+    float* cT = reinterpret_cast<float*>(tri2_smem + 2 * H * Y * 2);        // [x range][256 rows] fp32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
+    const int r = lane & 15, g = lane >> 4;
+    const int n_rb = (M + kTri2Rows - 1) / kTri2Rows;
+    const int rb = blockIdx.x % n_rb, yb = blockIdx.x / n_rb;
+    const int m0 = rb * kTri2Rows;
+    const int xper = (X + xs - 1) / xs, xb = yb * xper, xe = min(X, xb + xper), nx = max(xe - xb, 0);
+    for (int i = tid; i < kTri2Rows * nx; i += kTri2Threads) {   // c of this block's rows, transposed, fp32
+        const int row = i / nx, x = i - row * nx;
+        cT[x * kTri2Rows + row] = m0 + row < M ? __uint_as_float((uint32_t)c[(size_t)(m0 + row) * X + xb + x] << 16) : 0.f;
+    }
+    // A operand: this wave's 64 rows of p, resident for the whole x loop
+    bf16x8 pf[4][KCH];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const bf16x8* rowp = reinterpret_cast<const bf16x8*>(p + (size_t)min(m0 + wm * 64 + 16 * rt + r, M - 1) * Y + 8 * g);
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) pf[rt][kc] = rowp[kc * 4];
+    }
+    // staging of one weight plane: 2048 segments of 16 bytes, 4 per thread (slot: row sl >> 4, segment swizzled by the row)
+    uint4 rw0, rw1, rw2, rw3;
+    const int so0 = ((tid + 0 * kTri2Threads) >> 4) * 16 + (((tid + 0 * kTri2Threads) & 15) ^ (((tid + 0 * kTri2Threads) >> 4) & 15));
+    const int so1 = ((tid + 1 * kTri2Threads) >> 4) * 16 + (((tid + 1 * kTri2Threads) & 15) ^ (((tid + 1 * kTri2Threads) >> 4) & 15));
+    const int so2 = ((tid + 2 * kTri2Threads) >> 4) * 16 + (((tid + 2 * kTri2Threads) & 15) ^ (((tid + 2 * kTri2Threads) >> 4) & 15));
+    const int so3 = ((tid + 3 * kTri2Threads) >> 4) * 16 + (((tid + 3 * kTri2Threads) & 15) ^ (((tid + 3 * kTri2Threads) >> 4) & 15));
+#define VLG_TRI2_FETCH(x)                                                                     \
+    do {                                                                                      \
+        const uint4* src_ = reinterpret_cast<const uint4*>(w + (size_t)(x) * H * Y) + tid;    \
+        rw0 = src_[0]; rw1 = src_[kTri2Threads]; rw2 = src_[2 * kTri2Threads]; rw3 = src_[3 * kTri2Threads]; \
+    } while (0)
+#define VLG_TRI2_STASH(buf_)                                                                  \
+    do {                                                                                      \
+        uint4* dst_ = wbuf + (buf_) * (H * 16);                                               \
+        dst_[so0] = rw0; dst_[so1] = rw1; dst_[so2] = rw2; dst_[so3] = rw3;                   \
+    } while (0)
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nx > 0) {
+        VLG_TRI2_FETCH(xb);
+        VLG_TRI2_STASH(0);
+        if (nx > 1) VLG_TRI2_FETCH(xb + 1);
+    }
+    __syncthreads();
+    for (int xi = 0, buf = 0; xi < nx; ++xi, buf ^= 1) {
+        const uint4* wb = wbuf + buf * (H * 16);
+        float4 cv[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) cv[rt] = *reinterpret_cast<const float4*>(cT + xi * kTri2Rows + wm * 64 + 16 * rt + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hrow = wn * 64 + j * 16 + r;   // B operand: row h of the plane, segments kc * 4 + g
+            bf16x8 bfr[KCH];
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) bfr[kc] = __builtin_bit_cast(bf16x8, wb[hrow * 16 + ((kc * 4 + g) ^ (hrow & 15))]);
+            f32x4 d[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) d[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) d[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[rt][kc], bfr[kc], d[rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                acc[rt][j][0] = fmaf(cv[rt].x, d[rt][0], acc[rt][j][0]);
+                acc[rt][j][1] = fmaf(cv[rt].y, d[rt][1], acc[rt][j][1]);
+                acc[rt][j][2] = fmaf(cv[rt].z, d[rt][2], acc[rt][j][2]);
+                acc[rt][j][3] = fmaf(cv[rt].w, d[rt][3], acc[rt][j][3]);
+            }
+        }
+        if (xi + 1 < nx) {
+            VLG_TRI2_STASH(buf ^ 1);
+            if (xi + 2 < nx) VLG_TRI2_FETCH(xb + xi + 2);
+        }
+        __syncthreads();
+    }
+#undef VLG_TRI2_FETCH
+#undef VLG_TRI2_STASH
+    float* dstb = out + (use_atomic ? 0 : (size_t)yb * part_stride);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int m = m0 + wm * 64 + 16 * rt + 4 * g + n;
+                if (m < M) {
+                    float* o = dstb + (size_t)m * H + wn * 64 + j * 16 + r;
+                    if (use_atomic) atomicAdd(o, acc[rt][j][n]);   // two ranges: 0 + a + b is the same bits in either order
+                    else *o = acc[rt][j][n];
+                }
+            }
+}
+
+// out[i] = sum_s part[s][i], s ascending (n % 4 == 0)
+__global__ __launch_bounds__(256) void tri2_reduce_kernel(const float* __restrict__ part, int S, size_t n, float* __restrict__ out) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 t = *reinterpret_cast<const float4*>(part + i);
+    for (int s = 1; s < S; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * n + i);
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = t;
+}
+
+static bool tri2_applies(int M, int X, int H, int Y, bool f32in) { return !f32in && H == 128 && Y == 128 && M >= 1024 && X >= 2 && X <= 256; }
+static int tri2_splits(int M, int X) {   // ~one workgroup per CU
+    const int n_rb = (M + kTri2Rows - 1) / kTri2Rows;
+    int xs = (256 + n_rb / 2) / n_rb;
+    xs = xs < 1 ? 1 : (xs > 8 ? 8 : xs);
+    while (xs > 1 && X / xs < 8) --xs;
+    return xs;
+}
+static size_t tri2_part_bytes(int M, int X) { const int xs = tri2_splits(M, X); return xs > 1 ? sizeof(float) * (size_t)xs * M * 128 : 0; }
+
+// part: xs slabs of [M][128] floats (fixed-order sum into out), or null: two ranges met by atomicAdd in a zeroed out
+static int launch_tri2(const void* c, const void* w, const void* p, int M, int X, float* out, float* part, hipStream_t s) {
+    const int xs = part ? tri2_splits(M, X) : 2;
+    const int n_rb = (M + kTri2Rows - 1) / kTri2Rows;
+    const size_t lds = 2 * (size_t)128 * 128 * 2 + sizeof(float) * kTri2Rows * ((X + xs - 1) / xs);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const bool atomic = part == nullptr || xs == 1;
+    if (atomic && xs > 1) {
+        e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)M * 128, s);
+        if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(tri2_kernel, dim3(n_rb * xs), dim3(kTri2Threads), lds, s, (const uint16_t*)c, (const uint16_t*)w, (const uint16_t*)p,
+                       M, X, xs, atomic ? out : part, (size_t)M * 128, (atomic && xs > 1) ? 1 : 0);
+    if (!atomic) {
+        const size_t n = (size_t)M * 128;
+        hipLaunchKernelGGL(tri2_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, part, xs, n, out);
+    }
+    return 0;
+}
+
 template <bool F32IN, int KCH, int RT>
 static int launch_tri_rt(const void* c, const void* w, const void* p, int M, int X, int H, int xs, float* out, hipStream_t s) {
     using T = typename MfmaCfg<F32IN>::T;
@@ -200,7 +359,7 @@ static int launch_tri(const void* c, const void* w, const void* p, int M, int X,
 
 // Y (the contracted, memory-contiguous dimension) decides the instantiation.
 static int dispatch_tri(const void* c, const void* w, const void* p, int M, int X, int H, int Y, bool f32in, float* out,
-                        hipStream_t s) {
+                        hipStream_t s, float* part = nullptr) {
     if (f32in) {
         int rc;
         if (Y == 128) rc = launch_tri<true, 8>(c, w, p, M, X, H, out, s);
@@ -210,7 +369,8 @@ static int dispatch_tri(const void* c, const void* w, const void* p, int M, int 
         if (rc) return rc;
     } else {
         int rc;
-        if (Y == 128) rc = launch_tri<false, 4>(c, w, p, M, X, H, out, s);
+        if (tri2_applies(M, X, H, Y, false)) rc = launch_tri2(c, w, p, M, X, out, part, s);
+        else if (Y == 128) rc = launch_tri<false, 4>(c, w, p, M, X, H, out, s);
         else if (Y == 64) rc = launch_tri<false, 2>(c, w, p, M, X, H, out, s);
         else if (Y == 32) rc = launch_tri<false, 1>(c, w, p, M, X, H, out, s);
         else return set_error(VLG_ERR_SHAPE, "trilinear: contracted dimension %d (supported: 32, 64, 128)", Y);
@@ -526,7 +686,11 @@ struct TriBwdPlan {   // scratch carving (bytes), shared by the size query and t
         off_gT = off_cT + up((size_t)X * Mp * esz);
         off_pT = off_gT + up((size_t)H * Mp * esz);
         off_part = off_pT + up((size_t)Y * Mp * esz);
-        bytes = off_part + (dw2_applies(M, X, H, Y, f32in) ? up(sizeof(float) * (size_t)dw2_splits(M, X) * X * H * Y) : 0);
+        size_t pb = dw2_applies(M, X, H, Y, f32in) ? sizeof(float) * (size_t)dw2_splits(M, X) * X * H * Y : 0;
+        // the slabs of tri2_kernel's partial sums share the region (the three launches are stream-ordered); roles permute (X, H, Y)
+        if (tri2_applies(M, Y, X, H, f32in)) pb = pb > tri2_part_bytes(M, Y) ? pb : tri2_part_bytes(M, Y);
+        if (tri2_applies(M, X, Y, H, f32in)) pb = pb > tri2_part_bytes(M, X) ? pb : tri2_part_bytes(M, X);
+        bytes = off_part + up(pb);
     }
 };
 
@@ -545,12 +709,12 @@ static int run_tri_backward(const void* child, const void* w, const void* parent
     if (d_child) {   // d_child[m,x] = sum_y p[m,y] * sum_h wA[y,x,h] g[m,h]: roles (c, w, p) := (p, wA, g); "X" = Y, "H" = X, "Y" = H
         if (X % 16 || X > 16 * kTriWaves * kTriHPW) return set_error(VLG_ERR_SHAPE, "trilinear_backward: X=%d must be a multiple of 16 and <= 128", X);
         hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wA, X, H, Y, 0);
-        if (int rc = dispatch_tri(parent, wA, g_op, M, Y, X, H, F32IN, d_child, s)) return rc;
+        if (int rc = dispatch_tri(parent, wA, g_op, M, Y, X, H, F32IN, d_child, s, reinterpret_cast<float*>(ws + p.off_part))) return rc;
     }
     if (d_parent) {  // d_parent[m,y] = sum_x c[m,x] * sum_h wB[x,y,h] g[m,h]: roles (c, w, p) := (c, wB, g); "H" = Y, "Y" = H
         if (Y % 16 || Y > 16 * kTriWaves * kTriHPW) return set_error(VLG_ERR_SHAPE, "trilinear_backward: Y=%d must be a multiple of 16 and <= 128", Y);
         hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wB, X, H, Y, 1);
-        if (int rc = dispatch_tri(child, wB, g_op, M, X, Y, H, F32IN, d_parent, s)) return rc;
+        if (int rc = dispatch_tri(child, wB, g_op, M, X, Y, H, F32IN, d_parent, s, reinterpret_cast<float*>(ws + p.off_part))) return rc;
     }
     if (d_w && dw2_applies(M, X, H, Y, F32IN)) {
         if constexpr (!F32IN) {
@@ -601,6 +765,23 @@ int vlg_trilinear(const void* child, const void* w, const void* parent, int M, i
     if (M == 0) return 0;
     if (!child || !w || !parent || !out) return set_error(VLG_ERR_ARG, "trilinear: null buffer");
     return dispatch_tri(child, w, parent, M, X, H, Y, in_dtype == VLG_F32, out, (hipStream_t)stream);
+}
+
+size_t vlg_trilinear_workspace(int M, int X, int H, int Y, int in_dtype) {
+    if (M < 1 || X < 1 || H < 1 || Y < 1) return 0;
+    return vlg::tri2_applies(M, X, H, Y, in_dtype == VLG_F32) ? vlg::tri2_part_bytes(M, X) : 0;
+}
+
+int vlg_trilinear_ws(const void* child, const void* w, const void* parent, int M, int X, int H, int Y, int in_dtype, void* ws,
+                     size_t ws_bytes, float* out, void* stream) {
+    using namespace vlg;
+    if (int rc = check_dims("trilinear", M, X, H, Y)) return rc;
+    if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "trilinear: in_dtype %d", in_dtype);
+    if (M == 0) return 0;
+    if (!child || !w || !parent || !out) return set_error(VLG_ERR_ARG, "trilinear: null buffer");
+    const size_t need = vlg_trilinear_workspace(M, X, H, Y, in_dtype);
+    float* part = (need && ws && ws_bytes >= need) ? (float*)ws : nullptr;   // without it: the two-range form
+    return dispatch_tri(child, w, parent, M, X, H, Y, in_dtype == VLG_F32, out, (hipStream_t)stream, part);
 }
 
 size_t vlg_trilinear_backward_workspace(int M, int X, int H, int Y, int in_dtype) {

@@ -51,8 +51,10 @@ class _LangFeat(torch.autograd.Function):
         _C.check(lib.vlg_langfeat_split(_C.ptr(pre), _C.ptr(heads), B, N, d, float(slope), _C.ptr(txt), _C.ptr(child),
                                         _C.ptr(parent), _C.ptr(cps), st), "langfeat_split")
         w1_c = w1.detach().to(bf).contiguous()
-        tri = torch.empty((M, d), dtype=torch.float32, device=dev)
-        _C.check(lib.vlg_trilinear(_C.ptr(child), _C.ptr(w1_c), _C.ptr(parent), M, d, d, d, _C.BF16, _C.ptr(tri), st), "trilinear")
+        tbytes = lib.vlg_trilinear_workspace(M, d, d, d, _C.BF16)
+        (tri,), tws = _C.alloc_f32(dev, ((M, d),), tbytes)
+        _C.check(lib.vlg_trilinear_ws(_C.ptr(child), _C.ptr(w1_c), _C.ptr(parent), M, d, d, d, _C.BF16, _C.ptr(tws) if tbytes else None,
+                                      tbytes, _C.ptr(tri), st), "trilinear")
         w2_c = w2.detach().to(bf)
         aff = torch.addmm(b_arc.detach().to(bf), cps, w2_c)                                # (child + parent) w2 + b
         _C.check(lib.vlg_langfeat_arc_out(_C.ptr(tri), _C.ptr(aff), B, N, d, _C.ptr(txt), st), "langfeat_arc_out")
