@@ -1661,3 +1661,26 @@ def test_bilinear_align_backward_generic_path_is_reproducible():
     bad = torch.randn(2, 5, 48, generator=g).to(dev()).requires_grad_(True)
     with pytest.raises(ValueError, match="matching width"):
         align.gather_logit(None, (torch.randn(3, 4, 48).to(dev()), None, None), (bad, None, None))
+
+
+@pytest.mark.parametrize("B,A,Q,V", [(9, 7, 82, 36), (3, 20, 97, 44), (2, 3, 200, 40), (17, 5, 5, 4)])
+def test_bilinear_align_full_tensor_direct_kernel(oracle_mod, B, A, Q, V):
+    """align_full_kernel (round 3: the materialised tensor alone, bf16, d = 128, V <= 44, V % 4 == 0 -- swapped MFMA operands, the
+    wave's output block assembled in LDS in the output's own layout, linear copy-out) against the fp64 oracle and, bit for bit,
+    against the LDS-tile kernel (taken when a maximum is requested as well), with and without masks; several query passes
+    (Q > 96), captions past a multiple of the eight waves, a single region tile."""
+    from vlgae_amd import align
+    rng = np.random.default_rng(B * 1000 + Q)
+    txt = t(rng.standard_normal((B, Q, 128)).astype(np.float32)).bfloat16()
+    vis = t(rng.standard_normal((A, V, 128)).astype(np.float32)).bfloat16()
+    tm, vm = rng.random((B, Q)) > 0.2, rng.random((A, V)) > 0.2
+    for masks in (False, True):
+        kw = dict(txt_mask=t(tm), vis_mask=t(vm)) if masks else {}
+        got = align.bilinear_align(txt, vis, **kw)["full"]
+        other = align.bilinear_align(txt, vis, max_v=True, **kw)["full"]
+        assert torch.equal(got, other)
+        ref = oracle_mod.bilinear_align(txt.float().cpu().numpy(), vis.float().cpu().numpy(), tm if masks else None, vm if masks else None,
+                                        np.float64)["full"]
+        big = np.abs(ref) > 1e19
+        g = got.cpu().numpy()
+        assert (g[big] == np.float32(-1e20)).all() and np.abs(g[~big] - ref[~big]).max() <= 1e-3

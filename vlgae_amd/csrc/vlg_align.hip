@@ -726,6 +726,149 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
 }
 #undef VLG_AM_DPP4
 
+// =====================================================================================================
+// The materialised tensor attmap [B,A,Q,V] (what `gather_logit_simple` returns, joint.py:406-419) for one-group images
+// (V <= 48, V % 4 == 0), bf16 features, d = 128 -- round 3.  align_mfma_kernel<TILE> keeps 96 caption rows AND a three-deep
+// image-fragment ring in 286 registers (one wave per SIMD, four waves per CU), bounces every accumulator through an LDS
+// tile (26 % of its LDS cycles are bank conflicts) and pays an LDS round trip per copy-out step: 0.228 ms = 3.4 TB/s of
+// writes where a plain fill reaches 6.8.  This kernel is align_max_kernel's skeleton (image tiles shared by eight captions
+// through the double-buffered swizzled LDS image, two waves per SIMD) with the MFMA operands SWAPPED: the tile computed is
+// S^T[region][query], whose accumulator layout gives a lane four CONSECUTIVE regions of one query -- 16 contiguous bytes of
+// the output row -- so every accumulator tile goes to the wave's LDS copy of the (b, a) output block as ONE ds_write_b128
+// (18 per image instead of 72 ds_write_b32; pitch V floats = 144 bytes puts a 16-lane group on 64 distinct banks), and because
+// that copy has the output's own layout the copy-out is linear: 12 conflict-free ds_read_b128 issued together, then 12 fully
+// contiguous 1 KB stores.  (Storing the accumulators straight to global memory -- 16 rows x 64 bytes per instruction -- was
+// measured first: 0.271 ms, write-combining of half cache lines is slower than the LDS detour.)
+// =====================================================================================================
+__global__ __launch_bounds__(kAMThreads, 2) void align_full_kernel(
+    const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
+    const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_full, int a_per_block) {
+    constexpr int d = 128, KCH = 4, RT = 6;
+    __shared__ uint4 tiles[2][kAMSlots];
+    __shared__ uint8_t ckeep_s[2][kAMRows];
+    extern __shared__ __attribute__((aligned(16))) float af_otile[];   // [8 waves][96 queries][V] fp32: the output block's own layout
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* otile = af_otile + (size_t)wave * RT * 16 * V;
+    const int b = blockIdx.y * kAMWaves + wave, bc = min(b, B - 1);
+    const int a0 = blockIdx.x * a_per_block, n_img = min(A, a0 + a_per_block) - a0;
+    const int g = lane >> 4, ccol = lane & 15;
+    constexpr int NS = 2;
+    const bool has2 = tid < kAMSlots - kAMThreads;
+    int soff[NS], srow[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int sl = tid + k * kAMThreads, r = sl >> 4;
+        srow[k] = r;
+        soff[k] = ((sl & 15) ^ (r & 15)) * 8;
+    }
+    auto stage_load = [&](int a, uint4* x, unsigned& ck) {
+        const uint16_t* img = vis + (size_t)a * V * d;
+        x[0] = *reinterpret_cast<const uint4*>(img + (size_t)min(srow[0], V - 1) * d + soff[0]);
+        if (has2) x[1] = *reinterpret_cast<const uint4*>(img + (size_t)min(srow[1], V - 1) * d + soff[1]);
+        if (vmask && tid < kAMRows) ck = vmask[(size_t)a * V + min(tid, V - 1)];
+    };
+    auto stage_write = [&](int buf, const uint4* x, unsigned ck) {
+        tiles[buf][tid] = x[0];
+        if (has2) tiles[buf][tid + kAMThreads] = x[1];
+        if (vmask && tid < kAMRows) ckeep_s[buf][tid] = (uint8_t)(ck != 0);
+    };
+    int foff[KCH];
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) foff[kc] = ccol * 16 + ((kc * 4 + g) ^ ccol);
+
+    for (int q0 = 0; q0 < Q; q0 += RT * 16) {
+        const int n4 = (min(RT * 16, Q - q0) * V) >> 2;   // float4 of this pass's output block
+        // this wave's caption: 6 query tiles x 4 K-chunks, the B operand of every MFMA (column = query q0 + 16 rt + ccol)
+        bf16x8 qf[RT][KCH];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const bf16x8* rowp = reinterpret_cast<const bf16x8*>(txt + ((size_t)bc * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) qf[rt][kc] = rowp[kc * 4];
+        }
+        unsigned qkeep = 0x3fu;   // bit rt: this lane's query of row tile rt is kept
+        if (tmask) {
+            qkeep = 0;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) qkeep |= (tmask[(size_t)bc * Q + min(q0 + rt * 16 + ccol, Q - 1)] ? 1u : 0u) << rt;
+        }
+        const bool q_masked = __builtin_amdgcn_ballot_w64(qkeep != 0x3fu) != 0;
+        uint4 xs[NS] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        unsigned ck = 1;
+        if (n_img > 0) {
+            stage_load(a0, xs, ck);
+            stage_write(0, xs, ck);
+            if (n_img > 1) stage_load(a0 + 1, xs, ck);
+        }
+        __syncthreads();
+        for (int i = 0; i < n_img; ++i) {
+            const int a = a0 + i, buf = i & 1;
+            if (i + 1 < n_img) stage_write(buf ^ 1, xs, ck);
+            if (i + 2 < n_img) stage_load(a + 2, xs, ck);
+            const uint4* tb = tiles[buf];
+            float* ot = otile + ccol * V + 4 * g;                                        // + (16 rt) * V + 16 ct
+            unsigned vkeep = 0xfffu;   // bit 4 ct + n: region 16 ct + 4 g + n is kept
+            bool v_masked = false;
+            if (vmask) {
+                vkeep = 0;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) vkeep |= (unsigned)ckeep_s[buf][ct * 16 + 4 * g + n] << (4 * ct + n);
+                v_masked = __builtin_amdgcn_ballot_w64(vkeep != 0xfffu) != 0;
+            }
+#pragma unroll 1
+            for (int ct = 0; ct < 3; ++ct) {
+                bf16x8 vf[KCH];   // A operand: regions 16 ct + (lane & 15) of the image tile
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) vf[kc] = *reinterpret_cast<const bf16x8*>(tb + ct * 256 + foff[kc]);
+                const bool col_live = ct * 16 + 4 * g < V;   // V % 4 == 0: a lane's four regions are all inside or all outside
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kc], qf[rt][kc], acc, 0, 0, 0);
+                    if (q_masked || v_masked) {   // wave-uniform: masked_fill_ of joint.py:417-418
+                        const bool qk = (qkeep >> rt) & 1u;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) acc[n] = (qk && ((vkeep >> (4 * ct + n)) & 1u)) ? acc[n] : neg_inf;
+                    }
+                    if (col_live) *reinterpret_cast<float4*>(ot + (rt * 16) * V + ct * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                }
+            }
+            // linear copy-out of the wave's block (same layout as the output): all reads first, then contiguous 1 KB stores
+            __builtin_amdgcn_wave_barrier();
+            if (b < B) {
+                float4* dst4 = reinterpret_cast<float4*>(out_full + (((size_t)bc * A + a) * Q + q0) * V);
+                const float4* src4 = reinterpret_cast<const float4*>(otile);
+                constexpr int NC = (RT * 16 * 48 / 4 + 63) / 64;   // V <= 48
+                float4 tv[NC];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) tv[k] = src4[min(lane + 64 * k, n4 - 1)];
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+                    if (lane + 64 * k < n4) dst4[lane + 64 * k] = tv[k];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+static int launch_align_full(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A, int Q, int V,
+                             float neg_inf, float* out_full, hipStream_t s) {
+    const int by = (B + kAMWaves - 1) / kAMWaves;
+    int a_per_block = (int)(((long)A * by + 255) / 256);
+    if (a_per_block < 8) a_per_block = 8;
+    if (a_per_block > A) a_per_block = A;
+    dim3 grid((A + a_per_block - 1) / a_per_block, by);
+    const size_t lds = sizeof(float) * (size_t)kAMWaves * 96 * V;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_full_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(align_full_kernel, grid, dim3(kAMThreads), lds, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask, vmask, B, A, Q, V,
+                       neg_inf, out_full, a_per_block);
+    return check_launch("align_full_kernel");
+}
+
 template <bool ARGS>
 static int launch_align_max(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A, int Q,
                             int V, float neg_inf, float* out_maxV, float* out_maxQ, hipStream_t s,
@@ -1336,6 +1479,9 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
         return launch_align_mfma<false, 4, true, false, 3>(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, nullptr, nullptr, nullptr,
                                                           out_diag, s, AlignArgs{nullptr, nullptr, 0, nullptr, nullptr}, true);
     }
+    // (eight waves' output blocks of 96 x V floats next to the 24 KB image tiles: V <= 44 fits the 160 KB LDS)
+    if (!f32in && d == 128 && out_full && !out_maxV && !out_maxQ && !out_diag && V <= 44 && V % 4 == 0 && !getenv("VLG_ALIGN_FULL_OLD"))
+        return launch_align_full(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, s);   // stores straight from the accumulators
     if (!f32in && d == 128) { VLG_MFMA(false, 4); }
     if (!f32in && d == 64) { VLG_MFMA(false, 2); }
     if (f32in && d == 128) { VLG_MFMA(true, 8); }
