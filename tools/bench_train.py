@@ -42,7 +42,14 @@ class _DryStep:
 
 
 def measure(args, rank, world, dev, dry, barrier):
-    """Runs the sharded train step; returns the result dict on every rank (rank 0 prints it)."""
+    """Runs the sharded train step; returns the result dict on every rank (rank 0 prints it).  Backward runs on the calling
+    thread (one process per GPU has no use for torch's per-device engine thread): the bucket hook then
+    issues its collective from the same thread, on the same current stream, as every kernel of the step."""
+    with torch.autograd.set_multithreading_enabled(False):
+        return _measure(args, rank, world, dev, dry, barrier)
+
+
+def _measure(args, rank, world, dev, dry, barrier):
     from vlgae_amd import dist as vdist
     import train_step
     B, L, V = args.batch, args.L, args.regions

@@ -60,14 +60,15 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         stage_hook, if given, is called from inside the backward pass once the gradients w.r.t. the potentials and the
         matching-space features exist (after the DP and grounding-loss adjoints, before the arc-encoder / projection /
         attention-fuse adjoints) -- where a data-parallel trainer starts reducing its first gradient bucket."""
-        # joint.py:670-674
+        # joint.py:658-674: the fuse comes first -- the parser (joint.py:675) sees the fused encodings
         x = align.attention_fuse(P["vis_feat"], P["txt_word"], P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], 1e-5)
         if with_scorer:   # ldndmv.py:184-209: the step's potentials, bf16 storage for the DPs
             smd, sma = scorer.ndmv_potentials(P["sc_x1"], P["sc_x2"], P["sc_y1"], P["sc_y2"], P["sc_root"], token, out_dtype=dtype)
             cmd, cma, loss_pot = smd.detach(), sma.detach(), [smd, sma]
         else:
             cmd, cma, loss_pot = md, ma, pot
-        # joint.py:235-292 (the potentials are constants of this stage: detached, :252-253)
+        # joint.py:235-292 (the potentials are constants of this stage: detached, :252-253); its two DPs run on side streams
+        # beside the root row and the projection GEMM
         txt, tmask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, cmd, cma, P["w_enc"], P["b_enc"], P["w1"], P["w2"], P["b"],
                                                                keep_viterbi=True)
         if stage_hook is not None:

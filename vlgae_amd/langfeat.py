@@ -46,6 +46,8 @@ class _LangFeat(torch.autograd.Function):
         _C.check(lib.vlg_langfeat_root_cat(_C.ptr(x_c), _C.ptr(lengths), B, L, h, dt, _C.ptr(x1), st), "langfeat_root_cat")
         w_enc_c = w_enc.detach().to(bf)
         pre = torch.addmm(b_enc.detach().to(bf), x1, w_enc_c.t())                       # [M,3d]: the three encoders' Linear
+        if not torch.is_tensor(heads):   # a StructureHandle: the DPs ran on side streams beside the two launches above
+            heads = heads.wait()[2]
         txt = torch.empty((B, 2 * N, d), dtype=bf, device=dev)
         child, parent, cps = (torch.empty((M, d), dtype=bf, device=dev) for _ in range(3))
         _C.check(lib.vlg_langfeat_split(_C.ptr(pre), _C.ptr(heads), B, N, d, float(slope), _C.ptr(txt), _C.ptr(child),
@@ -125,7 +127,8 @@ def _wgrad2(x, dy):
 def arc_word_features(x, lengths, heads, w_enc, b_enc, w1, w2, b_arc, slope=0.01, aux=None):
     """joint.py:262-288: txt = cat([word_encoder(x1), arc_repr]) with x1 = cat([masked mean, x]) -- [B,2N,d] bfloat16.
 
-    x [B,L,h]; lengths [B] int64; heads [B,N] int64 (`predicted`, joint.py:256-258);
+    x [B,L,h]; lengths [B] int64; heads [B,N] int64 (`predicted`, joint.py:256-258) or the handle of `start_structure` (joined
+    inside, after the launches that do not need the heads);
     w_enc [3d,h] / b_enc [3d]: the word | child | parent encoders' Linear parameters concatenated along the output
     dimension (nn.Linear layout [out,in]; word: no activation, child / parent: LeakyReLU(slope) -- config/model/vlgae.yaml:69-73,
     joint.py:216-222); w1 [d,d,d], w2 [d,d], b_arc [d]: the arc encoder (joint.py:223-232).  Dropout is the identity (eval / p = 0).
@@ -137,20 +140,39 @@ def arc_word_features(x, lengths, heads, w_enc, b_enc, w1, w2, b_arc, slope=0.01
     if tuple(w_enc.shape) != (3 * d, h) or tuple(b_enc.shape) != (3 * d,) or tuple(w1.shape) != (d, d, d) or tuple(w2.shape) != (d, d):
         raise ValueError(f"arc_word_features: w_enc {tuple(w_enc.shape)} b_enc {tuple(b_enc.shape)} w1 {tuple(w1.shape)} w2 {tuple(w2.shape)} "
                          f"for x {tuple(x.shape)}")
-    if tuple(heads.shape) != (B, L + 1) or heads.dtype != torch.int64 or lengths.dtype != torch.int64:
-        raise ValueError("arc_word_features: heads must be int64 [B,L+1], lengths int64 [B]")
+    if torch.is_tensor(heads):
+        if tuple(heads.shape) != (B, L + 1) or heads.dtype != torch.int64:
+            raise ValueError("arc_word_features: heads must be int64 [B,L+1]")
+        heads = heads.contiguous()
+    if lengths.dtype != torch.int64:
+        raise ValueError("arc_word_features: lengths must be int64 [B]")
     if d % 16 or d > 128 or d not in (32, 64, 128):
         raise ValueError(f"arc_word_features: matching width d={d} (supported: 32, 64, 128)")
-    return _LangFeat.apply(x, lengths.contiguous(), heads.contiguous(), w_enc, b_enc, w1, w2, b_arc, float(slope), aux)
+    return _LangFeat.apply(x, lengths.contiguous(), heads, w_enc, b_enc, w1, w2, b_arc, float(slope), aux)
+
+
+def start_structure(merged_dec, merged_attach, lengths, keep_viterbi=False):
+    """The two DPs of lang_feat_max_tree (joint.py:251-258) started on side streams as soon as the potentials exist -- before the
+    attention-fuse that produces `x` -- so that they overlap it: pass the returned handle as `structure=` to lang_feat_max_tree."""
+    import vlgae_amd.torch_struct as ts
+    with torch.no_grad():
+        return ts.DMV1o([merged_dec.detach(), merged_attach.detach()], lengths).marginals_and_heads_async(keep_viterbi)
 
 
 def lang_feat_max_tree(x, lengths, merged_dec, merged_attach, w_enc, b_enc, w1, w2, b_arc, add_marginal=True, slope=0.01,
-                       keep_viterbi=False, aux=None):
+                       keep_viterbi=False, aux=None, structure=None):
     """`DependencyBoxRel.lang_feat_max_tree` (joint.py:235-292) -> (txt [B,2N,d] bf16, txt_mask [B,2N] bool, txt_marginal
-    [B,2N] float32).  The potentials are constants of this stage (detached, joint.py:252-253)."""
+    [B,2N] float32).  The potentials are constants of this stage (detached, joint.py:252-253).  `structure` = the handle of an
+    earlier `start_structure(...)` (then merged_dec / merged_attach / keep_viterbi are not used here).
+    Measured: the two DPs are joined BEFORE the root row and the projection GEMM.  Letting those launches run beside the DPs
+    (they do not need the heads) made the training step 90 us SLOWER (1.39 -> 1.48 ms as one HIP graph, same box): each DP is one
+    workgroup per CU on a 93 us critical path, and a workgroup that has to wait for a CU behind a GEMM tile lengthens that path."""
     import vlgae_amd.torch_struct as ts
     with torch.no_grad():
-        marg, heads = ts.DMV1o([merged_dec.detach(), merged_attach.detach()], lengths).marginals_and_heads(keep_viterbi)
+        if structure is not None:
+            _, marg, heads = structure.wait()
+        else:
+            marg, heads = ts.DMV1o([merged_dec.detach(), merged_attach.detach()], lengths).marginals_and_heads(keep_viterbi)
         txt_marginal, txt_mask = txt_marginal_and_mask(marg, heads, lengths, add_marginal)
     if aux is not None:
         aux["heads"] = heads

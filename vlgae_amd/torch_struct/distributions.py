@@ -141,6 +141,12 @@ class DMV1o(StructDistribution):
         _, gatt, heads = F.dmv1o_marginals_and_heads(dec, attach, self.lengths, keep_viterbi)
         return gatt, heads
 
+    def marginals_and_heads_async(self, keep_viterbi=False):
+        """`marginals_and_heads` with BOTH DPs on side streams: returns a handle at once; `handle.wait()` -> (logZ, marginals,
+        heads) joins them into the current stream.  Work enqueued in between overlaps the DPs (functional.dmv1o_structure_async)."""
+        dec, attach = self.log_potentials
+        return F.dmv1o_structure_async(dec, attach, self.lengths, keep_viterbi)
+
     @staticmethod
     def merge(dec: Tensor, attach: Tensor, root: Tensor, one=0, zero=NEGINF):
         """Root-augmented potentials (distributions.py:253-265): the root is token 0, generates only to

@@ -42,7 +42,7 @@ def _lengths(lengths, B, device, allow_none=False):
     return lengths
 
 
-def dmv1o_run(dec, attach, lengths, semiring, want_grad, grad_logZ=None, want_dec=True, logZ_shape=None):
+def dmv1o_run(dec, attach, lengths, semiring, want_grad, grad_logZ=None, want_dec=True, logZ_shape=None, out=None):
     """Raw launcher.  dec [B,N,2,2,2], attach [B,N,N,2] -> logZ [B] (+ grad_dec, grad_attach fp32).
     want_dec=False: attach counts only (grad_dec is None; the Max semiring then takes the back-pointer walk)."""
     _C.require_gpu(dec, "dmv1o")
@@ -56,11 +56,15 @@ def dmv1o_run(dec, attach, lengths, semiring, want_grad, grad_logZ=None, want_de
     dt, dec_c = _C.in_dtype(dec)          # only the storage is read: no detach needed
     _, att_c = _C.in_dtype(attach)
     lengths = _lengths(lengths, B, dec.device)
-    logZ = torch.empty(logZ_shape or B, dtype=torch.float32, device=dec.device)
     L = _C.lib()
+    if out is not None:   # caller-owned outputs (allocated on the caller's stream before it switched to a side stream)
+        logZ, gdec, gatt = out
+    else:
+        logZ = torch.empty(logZ_shape or B, dtype=torch.float32, device=dec.device)
     if want_grad:
-        gdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dec.device) if want_dec else None
-        gatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dec.device)
+        if out is None:
+            gdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dec.device) if want_dec else None
+            gatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dec.device)
         ws, nb = _workspace(_C.OP_DMV1O_INSIDE_OUTSIDE, B, N, semiring, dec.device)
         g = None if grad_logZ is None else grad_logZ.detach().to(torch.float32).reshape(B).contiguous()
         _C.check(L.vlg_dmv1o_inside_outside(_C.ptr(dec_c), _C.ptr(att_c), _C.ptr(lengths), B, N, dt, semiring,
@@ -439,3 +443,57 @@ def dmv1o_marginals_and_heads(dec, attach, lengths, keep_viterbi=False):
     if keep_viterbi:
         _viterbi_remember(dec, attach, lengths, (best, vdec, vatt, heads))
     return logZ, gatt, heads
+
+
+class StructureHandle:
+    """Both DPs of lang_feat_max_tree in flight on two side streams (see dmv1o_structure_async); `wait()` joins them into the
+    current stream and returns (logZ [B], marginals [B,N,N,2], heads [B,N])."""
+
+    def __init__(self, streams, outs, device):
+        self._streams, self._outs, self._device, self._joined = streams, outs, device, False
+
+    def wait(self):
+        if not self._joined:
+            cur = torch.cuda.current_stream(self._device)
+            for st in self._streams:
+                cur.wait_stream(st)
+            self._joined = True
+        return self._outs
+
+
+_SIDE_STREAMS2 = {}
+
+
+def dmv1o_structure_async(dec, attach, lengths, keep_viterbi=False):
+    """`dmv1o_marginals_and_heads` without occupying the current stream: the Log-semiring inside-outside pass AND the Viterbi
+    pass go to two side streams (ordered after what the current stream has enqueued so far: the potentials), and the caller
+    keeps enqueueing work that does not need them -- in the training step the attention-fuse, the root row and the encoders'
+    projection GEMM (37 us of kernels) run beside the 93 us the DPs take at one workgroup per CU each.  `.wait()` joins.
+    Outputs are allocated here, on the current stream (the reasoning of dmv1o_marginals_and_heads applies)."""
+    _C.require_gpu(dec, "dmv1o_structure_async")
+    dev = dec.device
+    cur = torch.cuda.current_stream(dev)
+    pair = _SIDE_STREAMS2.get(dev)
+    if pair is None:
+        pair = _SIDE_STREAMS2[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    B, N = dec.shape[:2]
+    lengths = _lengths(lengths, B, dev)
+    logZ = torch.empty(B, dtype=torch.float32, device=dev)
+    gatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dev)
+    best = torch.empty(B, dtype=torch.float32, device=dev)
+    heads = torch.empty((B, N), dtype=torch.int64, device=dev)
+    if keep_viterbi:
+        vdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dev)
+        vatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dev)
+    for st in pair:
+        st.wait_stream(cur)
+    with torch.cuda.stream(pair[0]):
+        dmv1o_run(dec, attach, lengths, _C.SEMIRING_LOG, True, want_dec=False, out=(logZ, None, gatt))
+    with torch.cuda.stream(pair[1]):
+        if keep_viterbi:
+            dmv1o_viterbi(dec, attach, lengths, out=(best, vdec, vatt, heads))
+        else:
+            dmv1o_decode(dec, attach, lengths, out=(best, heads))
+    if keep_viterbi:
+        _viterbi_remember(dec, attach, lengths, (best, vdec, vatt, heads))
+    return StructureHandle(pair, (logZ, gatt, heads), dev)
