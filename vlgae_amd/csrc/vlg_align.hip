@@ -1266,7 +1266,7 @@ __device__ __forceinline__ void align_bwd_split_body(const float* __restrict__ g
 
 // bf16 features: three waves per SIMD = two resident blocks per CU (the second block's work hides the first one's load latency)
 template <bool KCONTIG, int NKC, int MT, int CW, int NT>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) void align_bwd_split_kernel(
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(2, 4))) void align_bwd_split_kernel(
     const float* __restrict__ g, const uint16_t* __restrict__ featT, const uint8_t* __restrict__ rmask, int O, int M, int K, long so,
     long sr, long sk, long sfix, int o_per, float* __restrict__ out, int atomic) {
     align_bwd_split_body<KCONTIG, NKC, MT, CW, NT, 1>(g, featT, rmask, O, M, K, so, sr, sk, sfix, o_per, out, atomic);
