@@ -1131,7 +1131,8 @@ def test_arc_encoder_golden(path):
 
 
 @pytest.mark.parametrize("M,X,H,Y,dt", [(100, 32, 32, 32, "f32"), (333, 64, 128, 32, "f32"), (77, 128, 64, 128, "f32"),
-                                        (1050, 128, 128, 128, "bf16"), (65, 48, 32, 64, "bf16"), (1, 16, 32, 32, "f32")])
+                                        (1050, 128, 128, 128, "bf16"), (2501, 128, 128, 128, "bf16"), (65, 48, 32, 64, "bf16"),
+                                        (1, 16, 32, 32, "f32")])
 def test_arc_trilinear_shapes(oracle_mod, M, X, H, Y, dt):
     """Ragged row counts (M % 64, M % 32 != 0), unequal X / H / Y, against the fp64 oracle."""
     from vlgae_amd import align
@@ -1155,6 +1156,10 @@ def test_arc_trilinear_shapes(oracle_mod, M, X, H, Y, dt):
     tol = 2e-2 if dt == "bf16" else 1e-4   # bf16: the cotangent and the returned gradients are rounded to 8 bits
     for name, got, want in (("d_child", grads[0], d_child), ("d_w1", grads[1], d_w1), ("d_parent", grads[2], d_parent)):
         assert np.abs(got.float().cpu().numpy() - want).max() <= tol * max(1.0, np.abs(want).max()), name
+    if M >= 1024:   # the LDS-staged kernels (tri2_kernel, tri_dw2_kernel): fixed-order partial slabs -> run-to-run bit equality
+        out2 = align.arc_trilinear(*leaves)
+        grads2 = torch.autograd.grad(out2, leaves, t(g))
+        assert torch.equal(out, out2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
 
 
 def test_training_step_chain_as_one_hip_graph():
@@ -1684,3 +1689,36 @@ def test_bilinear_align_full_tensor_direct_kernel(oracle_mod, B, A, Q, V):
         big = np.abs(ref) > 1e19
         g = got.cpu().numpy()
         assert (g[big] == np.float32(-1e20)).all() and np.abs(g[~big] - ref[~big]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("B,L,T,r,dt", [(5, 11, 100, 12, "f32"), (3, 40, 45, 32, "bf16"), (2, 80, 30, 16, "f32"), (4, 6, 3, 5, "f32")])
+def test_ndmv_potentials_shapes(oracle_mod, B, L, T, r, dt):
+    """Ranks without a compile-time instantiation (run-time loop), long sentences, more tokens than positions, bf16 inputs;
+    and the shape the workgroup's LDS cannot hold is refused, not mis-computed."""
+    from vlgae_amd import scorer
+    rng = np.random.default_rng(B * 100 + r)
+    mk = lambda *s: (rng.standard_normal(s) * 0.5).astype(np.float32)
+    arrs = [mk(B, L, 2, 2, r), mk(T, 2, 2, r), mk(B, L, 2, 2, r), mk(2, 2, 2, r)]
+    root = np.log(rng.dirichlet(np.ones(T))).astype(np.float32)
+    token = rng.integers(0, T, size=(B, L))
+    hm = rng.random((B, L)) < 0.2
+    if dt == "bf16":
+        arrs = [torch.from_numpy(a).bfloat16().float().numpy() for a in arrs]
+    g_md, g_ma = rng.random((B, L + 1, 2, 2, 2)).astype(np.float32), rng.random((B, L + 1, L + 1, 2)).astype(np.float32)
+    omd, oma, og = oracle_mod.ndmv_potentials(*arrs, root, token, hm, -1e20, g_md, g_ma)
+    ins = [t(a).bfloat16() if dt == "bf16" else t(a) for a in arrs] + [t(root)]
+    for a in ins:
+        a.requires_grad_(True)
+    md, ma = scorer.ndmv_potentials(*ins, t(token), t(hm))
+    for got, ref in ((md, omd), (ma, oma)):
+        got = got.detach().cpu().numpy()
+        big = np.abs(ref) > 1e11
+        assert (got[big] == ref[big].astype(np.float32)).all() and np.abs(got[~big] - ref[~big]).max() <= 5e-5
+    grads = torch.autograd.grad([md, ma], ins, [t(g_md), t(g_ma)])
+    tol = 1e-2 if dt == "bf16" else 1e-4   # bf16 leaves get bf16 gradients
+    for k, v in zip(("x1", "x2", "y1", "y2", "root_rule"), grads):
+        assert np.abs(v.float().cpu().numpy() - og[k]).max() <= tol * max(1.0, np.abs(og[k]).max()), k
+    if B == 5:
+        with pytest.raises(RuntimeError, match="LDS"):
+            scorer.ndmv_potentials(t(mk(1, 40, 2, 2, 64)), t(mk(5000, 2, 2, 64)), t(mk(1, 40, 2, 2, 64)), t(mk(2, 2, 2, 64)),
+                                   t(np.zeros(5000, np.float32)), t(np.zeros((1, 40), np.int64)))
