@@ -223,6 +223,9 @@ int vlg_trilinear_ws(const void* child, const void* w, const void* parent, int M
 size_t vlg_trilinear_backward_workspace(int M, int X, int H, int Y, int in_dtype);
 int vlg_trilinear_backward(const void* child, const void* w, const void* parent, const float* g, int M, int X, int H, int Y,
                            int in_dtype, void* ws, size_t ws_bytes, float* d_child, float* d_w, float* d_parent, void* stream);
+/* The same with the cotangent in `g_dtype` (VLG_BF16 with bf16 features: taken as it is, no fp32 round trip). */
+int vlg_trilinear_backward_g(const void* child, const void* w, const void* parent, const void* g, int g_dtype, int M, int X, int H,
+                             int Y, int in_dtype, void* ws, size_t ws_bytes, float* d_child, float* d_w, float* d_parent, void* stream);
 
 /* Attention-fuse that feeds the parser -- DependencyBoxRel._forward, src/model/joint.py:670-674:
  *   att = softmax_v(vis[b] . txt[b,1:]) ; x = att . vis_mid[b] ; out = LayerNorm(enc_x + x) * gamma + beta

@@ -63,7 +63,9 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         # joint.py:658-674: the fuse comes first -- the parser (joint.py:675) sees the fused encodings
         x = align.attention_fuse(P["vis_feat"], P["txt_word"], P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], 1e-5)
         if with_scorer:   # ldndmv.py:184-209: the step's potentials, bf16 storage for the DPs
-            smd, sma = scorer.ndmv_potentials(P["sc_x1"], P["sc_x2"], P["sc_y1"], P["sc_y2"], P["sc_root"], token, out_dtype=dtype)
+            # (fp32 potentials, like `DMV1o.merge`: the DP reads either storage type at the same speed, and the counts that come
+            #  back through `-max` then need no bf16 round trip on their way into the scorer's adjoint)
+            smd, sma = scorer.ndmv_potentials(P["sc_x1"], P["sc_x2"], P["sc_y1"], P["sc_y2"], P["sc_root"], token)
             cmd, cma, loss_pot = smd.detach(), sma.detach(), [smd, sma]
         else:
             cmd, cma, loss_pot = md, ma, pot

@@ -46,6 +46,7 @@ SIGNATURES = {
     "vlg_trilinear_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "vlg_trilinear_backward_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "vlg_trilinear_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "vlg_trilinear_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "vlg_attn_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "vlg_attn_fuse_backward_workspace": (_sz, [_i, _i, _i, _i]),
     "vlg_attn_fuse_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp, _vp,

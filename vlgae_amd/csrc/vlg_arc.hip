@@ -395,6 +395,28 @@ __global__ __launch_bounds__(256) void tri_permute_kernel(const T* __restrict__ 
     }
 }
 
+// both permutations from one read of the weights: dA[y][x][h] = dB[x][y][h] = src[x][h][y].  A block = one x and a 32-wide strip of y,
+// transposed through LDS so that the reads (y fastest) and both writes (h fastest) are coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void tri_permute2_kernel(const T* __restrict__ src, T* __restrict__ dA, T* __restrict__ dB, int X, int H,
+                                                           int Y) {
+    __shared__ T tile[32][130];   // [y in strip][h], H <= 128
+    const int x = blockIdx.x, y0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < H * 32; i += 256) {
+        const int h = i >> 5, yy = i & 31;
+        if (y0 + yy < Y) tile[yy][h] = src[((size_t)x * H + h) * Y + y0 + yy];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * H; i += 256) {
+        const int yy = i / H, h = i - yy * H;
+        if (y0 + yy < Y) {
+            const T v = tile[yy][h];
+            dA[((size_t)(y0 + yy) * X + x) * H + h] = v;
+            dB[((size_t)x * Y + y0 + yy) * H + h] = v;
+        }
+    }
+}
+
 // dst[d][m] (in T, row pitch Mp, zero beyond M) = src[m][d];  CAST: src is fp32 and is rounded to T, else src is T.
 template <typename T, bool CAST>
 __global__ __launch_bounds__(256) void tri_transpose_kernel(const void* __restrict__ src_, T* __restrict__ dst, int M, int D,
@@ -695,25 +717,31 @@ struct TriBwdPlan {   // scratch carving (bytes), shared by the size query and t
 };
 
 template <bool F32IN>
-static int run_tri_backward(const void* child, const void* w, const void* parent, const float* g, int M, int X, int H, int Y,
-                            char* ws, const TriBwdPlan& p, float* d_child, float* d_w, float* d_parent, hipStream_t s) {
+static int run_tri_backward(const void* child, const void* w, const void* parent, const void* g, bool g_is_bf16, int M, int X, int H,
+                            int Y, char* ws, const TriBwdPlan& p, float* d_child, float* d_w, float* d_parent, hipStream_t s) {
     using T = typename MfmaCfg<F32IN>::T;
     T *wA = (T*)(ws + p.off_wA), *wB = (T*)(ws + p.off_wB), *gB = (T*)(ws + p.off_gB);
     T *cT = (T*)(ws + p.off_cT), *gT = (T*)(ws + p.off_gT), *pT = (T*)(ws + p.off_pT);
     const int pblocks = 1024;
     const void* g_op = g;   // the cotangent in the operand type, row-major
     if constexpr (!F32IN) {
-        hipLaunchKernelGGL(tri_cast_bf16_kernel, dim3(512), dim3(256), 0, s, g, (uint16_t*)gB, (size_t)M * H);
+        if (g_is_bf16) gB = (T*)const_cast<void*>(g);   // already in the operand type: no copy
+        else hipLaunchKernelGGL(tri_cast_bf16_kernel, dim3(512), dim3(256), 0, s, (const float*)g, (uint16_t*)gB, (size_t)M * H);
         g_op = gB;
+    }
+    bool permuted = false;
+    if (d_child && d_parent && H <= 128 && X % 16 == 0 && X <= 16 * kTriWaves * kTriHPW && Y % 16 == 0 && Y <= 16 * kTriWaves * kTriHPW) {
+        hipLaunchKernelGGL((tri_permute2_kernel<T>), dim3(X, (Y + 31) / 32), dim3(256), 0, s, (const T*)w, wA, wB, X, H, Y);
+        permuted = true;
     }
     if (d_child) {   // d_child[m,x] = sum_y p[m,y] * sum_h wA[y,x,h] g[m,h]: roles (c, w, p) := (p, wA, g); "X" = Y, "H" = X, "Y" = H
         if (X % 16 || X > 16 * kTriWaves * kTriHPW) return set_error(VLG_ERR_SHAPE, "trilinear_backward: X=%d must be a multiple of 16 and <= 128", X);
-        hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wA, X, H, Y, 0);
+        if (!permuted) hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wA, X, H, Y, 0);
         if (int rc = dispatch_tri(parent, wA, g_op, M, Y, X, H, F32IN, d_child, s, reinterpret_cast<float*>(ws + p.off_part))) return rc;
     }
     if (d_parent) {  // d_parent[m,y] = sum_x c[m,x] * sum_h wB[x,y,h] g[m,h]: roles (c, w, p) := (c, wB, g); "H" = Y, "Y" = H
         if (Y % 16 || Y > 16 * kTriWaves * kTriHPW) return set_error(VLG_ERR_SHAPE, "trilinear_backward: Y=%d must be a multiple of 16 and <= 128", Y);
-        hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wB, X, H, Y, 1);
+        if (!permuted) hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wB, X, H, Y, 1);
         if (int rc = dispatch_tri(child, wB, g_op, M, X, Y, H, F32IN, d_parent, s, reinterpret_cast<float*>(ws + p.off_part))) return rc;
     }
     if (d_w && dw2_applies(M, X, H, Y, F32IN)) {
@@ -735,7 +763,10 @@ static int run_tri_backward(const void* child, const void* w, const void* parent
         const int Mp = (int)p.Mp;
         dim3 tb(256);
         hipLaunchKernelGGL((tri_transpose_kernel<T, false>), dim3((Mp + 31) / 32, (X + 31) / 32), tb, 0, s, child, cT, M, X, Mp);
-        hipLaunchKernelGGL((tri_transpose_kernel<T, true>), dim3((Mp + 31) / 32, (H + 31) / 32), tb, 0, s, (const void*)g, gT, M, H, Mp);
+        if (!F32IN && g_is_bf16)
+            hipLaunchKernelGGL((tri_transpose_kernel<T, false>), dim3((Mp + 31) / 32, (H + 31) / 32), tb, 0, s, g, gT, M, H, Mp);
+        else
+            hipLaunchKernelGGL((tri_transpose_kernel<T, true>), dim3((Mp + 31) / 32, (H + 31) / 32), tb, 0, s, g, gT, M, H, Mp);
         hipLaunchKernelGGL((tri_transpose_kernel<T, false>), dim3((Mp + 31) / 32, (Y + 31) / 32), tb, 0, s, parent, pT, M, Y, Mp);
         const size_t lds = sizeof(float) * 4 * (size_t)(kDwSplit - 1) * kDwHT * kDwYT * 64;   // 96 KB
         auto k = tri_dw_kernel<F32IN>;
@@ -791,9 +822,16 @@ size_t vlg_trilinear_backward_workspace(int M, int X, int H, int Y, int in_dtype
 
 int vlg_trilinear_backward(const void* child, const void* w, const void* parent, const float* g, int M, int X, int H, int Y,
                            int in_dtype, void* ws, size_t ws_bytes, float* d_child, float* d_w, float* d_parent, void* stream) {
+    return vlg_trilinear_backward_g(child, w, parent, g, VLG_F32, M, X, H, Y, in_dtype, ws, ws_bytes, d_child, d_w, d_parent, stream);
+}
+
+int vlg_trilinear_backward_g(const void* child, const void* w, const void* parent, const void* g, int g_dtype, int M, int X, int H,
+                             int Y, int in_dtype, void* ws, size_t ws_bytes, float* d_child, float* d_w, float* d_parent, void* stream) {
     using namespace vlg;
     if (int rc = check_dims("trilinear_backward", M, X, H, Y)) return rc;
     if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "trilinear_backward: in_dtype %d", in_dtype);
+    if (g_dtype != VLG_F32 && !(g_dtype == VLG_BF16 && in_dtype == VLG_BF16))
+        return set_error(VLG_ERR_DTYPE, "trilinear_backward: a bf16 cotangent needs bf16 features (g_dtype %d, in_dtype %d)", g_dtype, in_dtype);
     if (Y != 32 && Y != 64 && Y != 128) return set_error(VLG_ERR_SHAPE, "trilinear_backward: Y=%d (supported: 32, 64, 128)", Y);
     if (H != 32 && H != 64 && H != 128) return set_error(VLG_ERR_SHAPE, "trilinear_backward: H=%d (supported: 32, 64, 128)", H);
     hipStream_t s = (hipStream_t)stream;
@@ -807,8 +845,9 @@ int vlg_trilinear_backward(const void* child, const void* w, const void* parent,
     if (!child || !w || !parent || !g) return set_error(VLG_ERR_ARG, "trilinear_backward: null buffer");
     const TriBwdPlan p(M, X, H, Y, in_dtype == VLG_F32);
     if (!ws || ws_bytes < p.bytes) return set_error(VLG_ERR_WORKSPACE, "trilinear_backward: workspace %zu bytes < %zu", ws_bytes, p.bytes);
-    return in_dtype == VLG_F32 ? run_tri_backward<true>(child, w, parent, g, M, X, H, Y, (char*)ws, p, d_child, d_w, d_parent, s)
-                               : run_tri_backward<false>(child, w, parent, g, M, X, H, Y, (char*)ws, p, d_child, d_w, d_parent, s);
+    const bool gb = g_dtype == VLG_BF16;
+    return in_dtype == VLG_F32 ? run_tri_backward<true>(child, w, parent, g, gb, M, X, H, Y, (char*)ws, p, d_child, d_w, d_parent, s)
+                               : run_tri_backward<false>(child, w, parent, g, gb, M, X, H, Y, (char*)ws, p, d_child, d_w, d_parent, s);
 }
 
 }  // extern "C"

@@ -82,15 +82,16 @@ class _LangFeat(torch.autograd.Function):
         d_wenc, d_benc, d_w1, d_w2, d_barc, d_child, d_parent = outs
         # ---- arc half: g = d arc_repr [M,d] ----
         gb = d_txt[:, N:, :].to(bf).reshape(M, d) if d_txt.dtype != bf else d_txt[:, N:, :].reshape(M, d)   # one contiguous copy
-        g32 = gb.float()                                                                    # the trilinear adjoint takes fp32 rows
-        _C.check(lib.vlg_trilinear_backward(_C.ptr(child), _C.ptr(w1_c), _C.ptr(parent), _C.ptr(g32), M, d, d, d, _C.BF16,
-                                            _C.ptr(ws), nbytes, _C.ptr(d_child), _C.ptr(d_w1), _C.ptr(d_parent), st), "trilinear_backward")
+        if gb.stride(1) != 1 or gb.stride(0) != d:
+            gb = gb.contiguous()
+        _C.check(lib.vlg_trilinear_backward_g(_C.ptr(child), _C.ptr(w1_c), _C.ptr(parent), _C.ptr(gb), _C.BF16, M, d, d, d, _C.BF16,
+                                              _C.ptr(ws), nbytes, _C.ptr(d_child), _C.ptr(d_w1), _C.ptr(d_parent), st), "trilinear_backward")
         d_sum = gb @ w2_c.t()                                                               # d (child + parent), bf16
         if _wgrad_ok(M, d, d, bf):
             linear_wgrad(cps, gb, want_x_colsum=True, out=(d_w2, d_barc))                  # w2 is stored [in, out]: cps^T g, sum_rows g
         else:
-            d_w2.copy_(cps.float().t() @ g32)
-            d_barc.copy_(g32.sum(0))
+            d_w2.copy_(cps.float().t() @ gb.float())
+            d_barc.copy_(gb.float().sum(0))
         # ---- encoders ----
         d_pre = torch.empty((M, 3 * d), dtype=bf, device=dev)
         _C.check(lib.vlg_langfeat_split_backward(_C.ptr(d_txt), _C.BF16 if d_txt.dtype == bf else _C.F32, _C.ptr(d_child),
