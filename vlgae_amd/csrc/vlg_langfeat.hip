@@ -113,8 +113,10 @@ __global__ __launch_bounds__(kSplitBwdThreads) void langfeat_split_bwd_kernel(
     const T1* __restrict__ d_txt, const float* __restrict__ d_child, const float* __restrict__ d_parent,
     const T2* __restrict__ d_sum, const uint16_t* __restrict__ child, const uint16_t* __restrict__ parent,
     const int64_t* __restrict__ heads, int N, int d, float slope, uint16_t* __restrict__ d_pre) {
-    extern __shared__ float gbuf[];   // [N][d] parent-third cotangents before the scatter, then N head indices
+    extern __shared__ float gbuf[];   // [N][d] parent-third cotangents before the scatter, then N head indices + their CSR by head
     int* hd = reinterpret_cast<int*>(gbuf + N * d);
+    int* order = hd + N;        // children sorted by (head, position)
+    int* start = order + N;     // start[j] .. start[j+1]: the children of head j in `order`
     const int b = blockIdx.x;
     const size_t m0 = (size_t)b * N;
     for (int n = threadIdx.x; n < N; n += kSplitBwdThreads) hd[n] = min(max((int)heads[m0 + n], 0), N - 1);
@@ -147,12 +149,24 @@ __global__ __launch_bounds__(kSplitBwdThreads) void langfeat_split_bwd_kernel(
             }
         }
     }
+    __syncthreads();   // hd (and gbuf) complete
+    // counting sort of the N children by head (N <= ~100: one thread per child / per head, N compares each)
+    for (int n = threadIdx.x; n <= N; n += kSplitBwdThreads) {
+        int lower = 0, rank = 0;
+        const int hn = n < N ? hd[n] : 0;
+        for (int k = 0; k < N; ++k) {
+            const int hk = hd[k];
+            lower += hk < n;                                   // children of heads below n (n read as a head index here)
+            rank += (hk < hn) || (hk == hn && k < n);
+        }
+        start[n] = lower;
+        if (n < N) order[rank] = n;
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < N * d; i += kSplitBwdThreads) {   // row j of the parent third = sum of its children's rows, n ascending
         const int j = i / d, c = i - j * d;
         float s = 0.f;
-        for (int n = 0; n < N; ++n)
-            if (hd[n] == j) s += gbuf[n * d + c];
+        for (int k = start[j]; k < start[j + 1]; ++k) s += gbuf[order[k] * d + c];
         d_pre[(m0 + j) * 3 * d + 2 * d + c] = f2bf(s);
     }
 }
@@ -253,10 +267,10 @@ int vlg_langfeat_split_backward(const void* d_txt, int d_txt_dtype, const float*
     if (B < 0 || N < 2 || d < 1) return set_error(VLG_ERR_SHAPE, "langfeat_split_backward: bad shape B=%d N=%d d=%d", B, N, d);
     if ((d_txt_dtype != VLG_F32 && d_txt_dtype != VLG_BF16) || (d_sum && d_sum_dtype != VLG_F32 && d_sum_dtype != VLG_BF16))
         return set_error(VLG_ERR_DTYPE, "langfeat_split_backward: dtypes %d / %d", d_txt_dtype, d_sum_dtype);
-    if ((size_t)N * (d + 1) * sizeof(float) > 64 * 1024) return set_error(VLG_ERR_SHAPE, "langfeat_split_backward: N*d = %d exceeds the 64 KB LDS tile", N * d);
+    if ((size_t)(N * (d + 3) + 1) * sizeof(float) > 64 * 1024) return set_error(VLG_ERR_SHAPE, "langfeat_split_backward: N*d = %d exceeds the 64 KB LDS tile", N * d);
     if (B == 0) return 0;
     if (!d_txt || !d_child || !d_parent || !child || !parent || !heads || !d_pre) return set_error(VLG_ERR_ARG, "langfeat_split_backward: null buffer");
-    const size_t lds = sizeof(float) * (size_t)N * (d + 1);
+    const size_t lds = sizeof(float) * (size_t)(N * (d + 3) + 1);
     const uint16_t *c = (const uint16_t*)child, *p = (const uint16_t*)parent;
     uint16_t* o = (uint16_t*)d_pre;
     hipStream_t s = (hipStream_t)stream;
