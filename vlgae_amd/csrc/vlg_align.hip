@@ -720,7 +720,9 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
                 }
             }
             row_epilogue(a);
+#ifndef VLG_ABL_AM_NOBARRIER   // tools/ ablation: what the per-image barrier costs (results are wrong without it)
             __syncthreads();
+#endif
         }
     }
 }
@@ -1090,17 +1092,21 @@ __global__ __launch_bounds__(256) void align_bwd_transpose_kernel(const T* __res
 // features sit in LDS, where re-reading them per wave is cheap)
 // FS = feature parts: 1 = bf16 features; 2 = fp32 features as hi + lo bf16 tiles (featT holds the hi parts of all O tensors, then
 // the lo parts): g x = g_hi x_hi + g_hi x_lo + g_lo x_hi, dropping g_lo x_lo (< 2^-16 of the product).
-template <bool KCONTIG, int NKC, int MT, int CW, int NT, int FS>
+// NF = fixed indices (captions / images) per workgroup: their wave sets share every staged feature tile.  Round 3: per step a block
+// moves 11.8 KB of cotangent from HBM and a 16-24 KB feature tile from L2; at the ~5.5 TB/s the HBM + L2 -> CU paths delivered
+// together in every kernel of this shape, the RE-STREAMED features were more than half of what bounds it.  NF = 2 halves them.
+template <bool KCONTIG, int NKC, int MT, int CW, int NT, int FS, int NF = 1>
 __device__ __forceinline__ void align_bwd_split_body(const float* __restrict__ g, const uint16_t* __restrict__ featT,
                                                      const uint8_t* __restrict__ rmask, int O, int M, int K, long so, long sr,
-                                                     long sk, long sfix, int o_per, float* __restrict__ out, int atomic) {
+                                                     long sk, long sfix, int o_per, float* __restrict__ out, int atomic, int nfix) {
     constexpr int Kp = NKC * 32, PITCH = Kp * 2 + 32, SEGS = Kp / 8;   // +32: conflict-free ds_read_b128 fragment reads
     static_assert(MT * CW == 6 || MT * CW == 3, "six waves, or three when every cotangent element is to be loaded once");
-    constexpr int RT = 1, CT = 8 / CW, nthr = 64 * MT * CW;
+    constexpr int RT = 1, CT = 8 / CW, WPF = MT * CW, nthr = 64 * WPF * NF;
     constexpr int NV = (FS * 128 * SEGS + nthr - 1) / nthr, TILE = 128 * PITCH;   // LDS: [buffer][part][128][PITCH]
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, ccol = lane & 15;
-    const int fix = blockIdx.x, o_begin = blockIdx.y * o_per, o_end = min(O, o_begin + o_per);
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % WPF, fi = (tid >> 6) / WPF, kg = lane >> 4, ccol = lane & 15;
+    const int fix_raw = blockIdx.x * NF + fi, fix = min(fix_raw, nfix - 1);   // a wave set past the end mirrors the last index, stores nothing
+    const int o_begin = blockIdx.y * o_per, o_end = min(O, o_begin + o_per);
     const int rt0 = (wave / CW) * RT, ct0 = (wave % CW) * CT;
     if (o_begin >= o_end) return;
     const float* gfix = g + (size_t)fix * sfix;
@@ -1244,6 +1250,7 @@ __device__ __forceinline__ void align_bwd_split_body(const float* __restrict__ g
     // (a second cotangent set, loaded two steps ahead, was measured: no faster -- the step is bound by instruction issue, not
     //  by the latency of these loads -- and costs 16-24 VGPRs)
     for (int o = o_begin; o < o_end; ++o) step(o, graw);
+    if (fix_raw >= nfix) return;   // (after the last barrier)
     // accumulator tile: lane l, register n <-> row 4 (l >> 4) + n, column l & 15
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
@@ -1265,19 +1272,19 @@ __device__ __forceinline__ void align_bwd_split_body(const float* __restrict__ g
 }
 
 // bf16 features: three waves per SIMD = two resident blocks per CU (the second block's work hides the first one's load latency)
-template <bool KCONTIG, int NKC, int MT, int CW, int NT>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(2, 4))) void align_bwd_split_kernel(
+template <bool KCONTIG, int NKC, int MT, int CW, int NT, int NF>
+__global__ __launch_bounds__(64 * MT * CW * NF) __attribute__((amdgpu_waves_per_eu(2, 4))) void align_bwd_split_kernel(
     const float* __restrict__ g, const uint16_t* __restrict__ featT, const uint8_t* __restrict__ rmask, int O, int M, int K, long so,
-    long sr, long sk, long sfix, int o_per, float* __restrict__ out, int atomic) {
-    align_bwd_split_body<KCONTIG, NKC, MT, CW, NT, 1>(g, featT, rmask, O, M, K, so, sr, sk, sfix, o_per, out, atomic);
+    long sr, long sk, long sfix, int o_per, float* __restrict__ out, int atomic, int nfix) {
+    align_bwd_split_body<KCONTIG, NKC, MT, CW, NT, 1, NF>(g, featT, rmask, O, M, K, so, sr, sk, sfix, o_per, out, atomic, nfix);
 }
 
 // fp32 features, split: twice the LDS per block (one block per CU) and more registers
 template <bool KCONTIG, int NKC, int MT, int CW, int NT>
 __global__ __launch_bounds__(384) void align_bwd_split_f32_kernel(
     const float* __restrict__ g, const uint16_t* __restrict__ featT, const uint8_t* __restrict__ rmask, int O, int M, int K, long so,
-    long sr, long sk, long sfix, int o_per, float* __restrict__ out, int atomic) {
-    align_bwd_split_body<KCONTIG, NKC, MT, CW, NT, 2>(g, featT, rmask, O, M, K, so, sr, sk, sfix, o_per, out, atomic);
+    long sr, long sk, long sfix, int o_per, float* __restrict__ out, int atomic, int nfix) {
+    align_bwd_split_body<KCONTIG, NKC, MT, CW, NT, 2, 1>(g, featT, rmask, O, M, K, so, sr, sk, sfix, o_per, out, atomic, nfix);
 }
 
 // Caption side with a short, quad-aligned contraction (K % 4 == 0, 2 K <= 96 -- config-2's 36 regions): TWO pairs per step,
@@ -1301,16 +1308,18 @@ __global__ __launch_bounds__(256) void align_bwd_concat_transpose_kernel(const u
     }
 }
 
-template <int MT, int CW, int NT>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) void align_bwd_split2_kernel(
+// NF captions per workgroup (six waves each) share every staged tile, as in align_bwd_split_body
+template <int MT, int CW, int NT, int NF>
+__global__ __launch_bounds__(384 * NF) __attribute__((amdgpu_waves_per_eu(3, 4))) void align_bwd_split2_kernel(
     const float* __restrict__ g, const uint16_t* __restrict__ featC, long pitchC, const uint8_t* __restrict__ rmask, int O, int M,
-    int K, long so, long sr, long sfix, int o_per, float* __restrict__ out, int atomic) {
+    int K, long so, long sr, long sfix, int o_per, float* __restrict__ out, int atomic, int nfix) {
     constexpr int NKC = 3, Kp = 96, PITCH = Kp * 2 + 32, SEGS = Kp / 8;
     static_assert(MT * CW == 6, "six waves");
-    constexpr int CT = 8 / CW, nthr = 384, NV = (128 * SEGS + nthr - 1) / nthr;
+    constexpr int CT = 8 / CW, nthr = 384 * NF, NV = (128 * SEGS + nthr - 1) / nthr;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, ccol = lane & 15;
-    const int fix = blockIdx.x, o_begin = blockIdx.y * o_per, o_end = min(O, o_begin + o_per);   // o_per is even
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % 6, fi = (tid >> 6) / 6, kg = lane >> 4, ccol = lane & 15;
+    const int fix_raw = blockIdx.x * NF + fi, fix = min(fix_raw, nfix - 1);   // a wave set past the end mirrors the last caption, stores nothing
+    const int o_begin = blockIdx.y * o_per, o_end = min(O, o_begin + o_per);   // o_per is even
     const int rt = wave / CW, ct0 = (wave % CW) * CT;
     if (o_begin >= o_end) return;
     const float* gfix = g + (size_t)fix * sfix;
@@ -1411,6 +1420,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
         __syncthreads();
     }
+    if (fix_raw >= nfix) return;   // (after the last barrier)
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int rr = rt * 16 + kg * 4 + n;
@@ -1560,8 +1570,10 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
         else
             hipLaunchKernelGGL(align_bwd_transpose_kernel<uint16_t>, dim3(O, Kp / 32), dim3(256), 0, s, (const uint16_t*)feat, km, K, Kp,
                                featT, (uint16_t*)nullptr);
-        int split = 1;   // two blocks per CU at least; two-addend atomics are order-free
-        if ((long)fixn * 2 <= 1024 && O >= 16) split = 2;
+        // bf16 features: two fixed indices per workgroup share each staged feature tile (12 waves, one block per CU)
+        const int nf = (!f32feat && fixn >= 64 && !getenv("VLG_BWD_NF1")) ? 2 : 1;
+        int split = 1;   // the chip covered at least once; two-addend atomics are order-free
+        if ((long)fixn * 2 <= 1024 * nf && O >= 16) split = 2;
         if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;
         const int opb = (O + split - 1) / split;
         if (split > 1) {
@@ -1571,13 +1583,17 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
         const size_t lds = (f32feat ? 4 : 2) * (size_t)128 * (Kp * 2 + 32);
 #define VLG_BS(KC, NKCV, MTV, CWV)                                                                                      \
         do {                                                                                                            \
-            auto k = f32feat ? align_bwd_split_f32_kernel<KC, NKCV, MTV, CWV, kNT> : align_bwd_split_kernel<KC, NKCV, MTV, CWV, kNT>; \
+            /* the two-index form where it fits the 168 registers of three waves per SIMD (12-wave blocks) */           \
+            constexpr int NFV = (NKCV == 3 && (MTV == 6 || KC)) ? 1 : 2;                                                \
+            const int nfe = nf == 2 ? NFV : 1;                                                                          \
+            auto k = f32feat ? align_bwd_split_f32_kernel<KC, NKCV, MTV, CWV, kNT>                                      \
+                             : (nfe == 2 ? align_bwd_split_kernel<KC, NKCV, MTV, CWV, kNT, NFV> : align_bwd_split_kernel<KC, NKCV, MTV, CWV, kNT, 1>); \
             if (lds > 64 * 1024) {                                                                                      \
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                 if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));         \
             }                                                                                                           \
-            hipLaunchKernelGGL(k, dim3(fixn, split), dim3(64 * MTV * CWV), lds, s, grad_out, featT, rm, O, M, K, so, sr, sk, sfix, opb, out,  \
-                               split > 1 ? 1 : 0);                                                                      \
+            hipLaunchKernelGGL(k, dim3((fixn + nfe - 1) / nfe, split), dim3(64 * MTV * CWV * nfe), lds, s, grad_out, featT, rm, O, M, K, so, \
+                               sr, sk, sfix, opb, out, split > 1 ? 1 : 0, fixn);                                        \
         } while (0)
 #define VLG_BS2(KC, NKCV)                                                                                               \
         do { if (M <= 48) VLG_BS(KC, NKCV, 3, kCW3); else VLG_BS(KC, NKCV, 6, 1); } while (0)
@@ -1638,7 +1654,8 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
         const long pitch = (long)bwd_concat_pitch(A, V);
         hipLaunchKernelGGL(align_bwd_concat_transpose_kernel, dim3((unsigned)((pitch + 31) / 32)), dim3(256), 0, s, (const uint16_t*)vis,
                            vmask, A * V, pitch, visT);
-        int split = ((long)B * 2 <= 1024 && A >= 16) ? 2 : 1;
+        const int nf = (B >= 64 && !getenv("VLG_BWD_NF1")) ? 2 : 1;
+        int split = ((long)B * 2 <= 1024 * nf && A >= 16) ? 2 : 1;
         if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;
         const int opb = ((A + split - 1) / split + 1) & ~1;   // even: a step's tile rows start on 16-byte boundaries of featC
         if (split > 1) {
@@ -1646,12 +1663,12 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
             if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
         }
         const size_t lds = 2 * (size_t)128 * (96 * 2 + 32);
-        if (Q <= 48)
-            hipLaunchKernelGGL((align_bwd_split2_kernel<3, 2, kNT>), dim3(B, split), dim3(384), lds, s, grad_out, visT, pitch, tmask, A, Q, V,
-                               QV, (long)V, (long)A * QV, opb, grad_txt, split > 1 ? 1 : 0);
-        else
-            hipLaunchKernelGGL((align_bwd_split2_kernel<6, 1, kNT>), dim3(B, split), dim3(384), lds, s, grad_out, visT, pitch, tmask, A, Q, V,
-                               QV, (long)V, (long)A * QV, opb, grad_txt, split > 1 ? 1 : 0);
+#define VLG_BS2K(MTV, CWV, NFV)                                                                                         \
+        hipLaunchKernelGGL((align_bwd_split2_kernel<MTV, CWV, kNT, NFV>), dim3((B + NFV - 1) / NFV, split), dim3(384 * NFV), lds, s, grad_out, \
+                           visT, pitch, tmask, A, Q, V, QV, (long)V, (long)A * QV, opb, grad_txt, split > 1 ? 1 : 0, B)
+        if (Q <= 48) { if (nf == 2) VLG_BS2K(3, 2, 2); else VLG_BS2K(3, 2, 1); }
+        else { if (nf == 2) VLG_BS2K(6, 1, 2); else VLG_BS2K(6, 1, 1); }
+#undef VLG_BS2K
         if (int rc = check_launch("align_bwd_split2_kernel")) return rc;
     } else if (grad_txt) {   // rows q of caption b; outer a, contraction v:  g[((b A + a) Q + q) V + v]
         const int rc = bwd_split_ok(in_dtype, d, Q, V) ? go_split(vis, vmask, tmask, B, A, Q, V, QV, V, 1, (long)A * QV, true, visT, grad_txt)
