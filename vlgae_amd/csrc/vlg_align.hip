@@ -729,6 +729,323 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_max_kernel(
 #undef VLG_AM_DPP4
 
 // =====================================================================================================
+// The grounding loss's maxima WITH their positions (joint.py:446-483), round 3.  align_max_kernel<true, 3> above spends its
+// time on the vector ALU, not on the matrix cores: per image and 48-row pass 36 MFMAs (576 cycles) against ~520 vector
+// instructions (2100 cycles) -- (compare, select, select) per element and direction to carry a position next to each running
+// maximum, and for the maxima over regions a 16-lane DPP butterfly per accumulator register, once for the value and once for
+// the position -- with two wavefronts per SIMD to hide the dependent DPP chains behind (217 registers): 267 us at config-2.
+// Here every score is computed TWICE, S = txt vis^T and S^T = vis txt^T -- the same two fragment sets with the MFMA's operands
+// exchanged, so no extra loads -- because the accumulator layout (a lane holds four ROWS of one column) makes a maximum over
+// the tile's rows a within-lane operation: S gives a lane queries of one region (max over Q), S^T gives it regions of one query
+// (max over V).  Both directions are then: within-lane maximum (v_max3), two v_permlane swaps across the four row groups, and
+// the position found AFTER the maximum is known -- first element equal to it, (compare, select) per element, smallest position
+// across the row groups.  No 16-lane butterflies, all 96 query rows in one pass (the position registers are gone), and the
+// matrix cores -- idle 80 % of the time before -- carry the second product.
+// =====================================================================================================
+// (fmed3(a, b, +inf) = max(a, b) without the canonicalising v_max x, x, x that fmaxf puts in front of MFMA results; chains fold to v_max3)
+static __device__ __forceinline__ float am_max(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+static __device__ __forceinline__ float am_max3(float a, float b, float c) { return am_max(am_max(a, b), c); }
+// Maximum / minimum over the four row groups of a column (lanes l, l ^ 16, l ^ 32, l ^ 48), every lane gets it: v_permlane16/32_swap
+// of a copy exchange the halves, no LDS round trip.  Hand-scheduled: left to itself hipcc canonicalises both swap results before
+// each maximum (12 instructions against 8).  Operands are results of vector-ALU instructions (never of an MFMA directly: inline
+// assembly is invisible to the compiler's MFMA hazard padding).
+static __device__ __forceinline__ float am_xg_max(float m) {
+    float t;
+    asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1\n\t"
+        "v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1"
+        : "+v"(m), "=&v"(t));
+    return m;
+}
+static __device__ __forceinline__ unsigned am_xg_min(unsigned m) {
+    unsigned t;
+    asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_min_u32 %0, %0, %1\n\t"
+        "v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_min_u32 %0, %0, %1"
+        : "+v"(m), "=&v"(t));
+    return m;
+}
+// r <- code C_p of the FIRST p with x_p == m (r unchanged when none): compares into lane masks four at a time, then their selects,
+// in descending p.  Written out because hipcc turns every formulation of this into (compare, wait two states for the mask,
+// select) pairs in one serial chain.  x_p must have been read by a compiler-visible vector instruction before (they have: m is
+// their maximum), so that an MFMA that produced them is known to have finished.
+template <int C0, int C1, int C2, int C3, int C4, int C5, int C6, int C7, int C8, int C9, int C10, int C11>
+static __device__ __forceinline__ unsigned am_first_eq12(unsigned r, float m, float x0, float x1, float x2, float x3, float x4, float x5,
+                                                         float x6, float x7, float x8, float x9, float x10, float x11) {
+    unsigned long long s0, s1, s2, s3;   // four masks in flight: a select reads the mask written four instructions earlier
+    asm("v_cmp_eq_f32_e64 %[s3], %[x11], %[m]\n\tv_cmp_eq_f32_e64 %[s2], %[x10], %[m]\n\tv_cmp_eq_f32_e64 %[s1], %[x9], %[m]\n\tv_cmp_eq_f32_e64 %[s0], %[x8], %[m]\n\tv_cndmask_b32_e64 %[r], %[r], %[c11], %[s3]\n\tv_cndmask_b32_e64 %[r], %[r], %[c10], %[s2]\n\tv_cndmask_b32_e64 %[r], %[r], %[c9], %[s1]\n\tv_cndmask_b32_e64 %[r], %[r], %[c8], %[s0]\n\tv_cmp_eq_f32_e64 %[s3], %[x7], %[m]\n\tv_cmp_eq_f32_e64 %[s2], %[x6], %[m]\n\tv_cmp_eq_f32_e64 %[s1], %[x5], %[m]\n\tv_cmp_eq_f32_e64 %[s0], %[x4], %[m]\n\tv_cndmask_b32_e64 %[r], %[r], %[c7], %[s3]\n\tv_cndmask_b32_e64 %[r], %[r], %[c6], %[s2]\n\tv_cndmask_b32_e64 %[r], %[r], %[c5], %[s1]\n\tv_cndmask_b32_e64 %[r], %[r], %[c4], %[s0]\n\tv_cmp_eq_f32_e64 %[s3], %[x3], %[m]\n\tv_cmp_eq_f32_e64 %[s2], %[x2], %[m]\n\tv_cmp_eq_f32_e64 %[s1], %[x1], %[m]\n\tv_cmp_eq_f32_e64 %[s0], %[x0], %[m]\n\tv_cndmask_b32_e64 %[r], %[r], %[c3], %[s3]\n\tv_cndmask_b32_e64 %[r], %[r], %[c2], %[s2]\n\tv_cndmask_b32_e64 %[r], %[r], %[c1], %[s1]\n\tv_cndmask_b32_e64 %[r], %[r], %[c0], %[s0]"
+        : [r] "+v"(r), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3)
+        : [m] "v"(m), [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [x4] "v"(x4), [x5] "v"(x5), [x6] "v"(x6), [x7] "v"(x7), [x8] "v"(x8), [x9] "v"(x9), [x10] "v"(x10), [x11] "v"(x11),
+          [c0] "n"(C0), [c1] "n"(C1), [c2] "n"(C2), [c3] "n"(C3), [c4] "n"(C4), [c5] "n"(C5), [c6] "n"(C6), [c7] "n"(C7), [c8] "n"(C8), [c9] "n"(C9), [c10] "n"(C10), [c11] "n"(C11));
+    return r;
+}
+
+template <bool HASQ>
+__global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
+    const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
+    const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_maxV,
+    float* __restrict__ out_maxQ, int a_per_block, AlignArgs xa) {
+    constexpr int d = 128, KCH = 4, RT = 6;
+    constexpr unsigned BIG = 0x7000u;
+    __shared__ uint4 tiles[2][kAMSlots];
+    __shared__ uint8_t ckeep_s[2][kAMRows];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything that depends on the caption lives in SGPRs
+    const int b = blockIdx.y * kAMWaves + wave, bc = min(b, B - 1);   // a wave past the batch mirrors the last caption, stores nothing
+    const int a0 = blockIdx.x * a_per_block, n_img = min(A, a0 + a_per_block) - a0;
+    const int g = lane >> 4, ccol = lane & 15, crow = g * 4;
+    constexpr int NS = 2;
+    const bool has2 = tid < kAMSlots - kAMThreads;
+    unsigned sbyte[NS];   // byte offset of this thread's slot within an image (32-bit: scalar base + vector offset addressing)
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int sl = tid + k * kAMThreads, r = sl >> 4;
+        sbyte[k] = 2u * (unsigned)(min(r, V - 1) * d + ((sl & 15) ^ (r & 15)) * 8);
+    }
+    auto stage_load = [&](int a, uint4* x, unsigned& ck) {
+        const char* img = reinterpret_cast<const char*>(vis + (size_t)a * V * d);
+        x[0] = *reinterpret_cast<const uint4*>(img + sbyte[0]);
+        if (has2) x[1] = *reinterpret_cast<const uint4*>(img + sbyte[1]);
+        if (vmask && tid < kAMRows) ck = vmask[(size_t)a * V + min(tid, V - 1)];
+    };
+    auto stage_write = [&](int buf, const uint4* x, unsigned ck) {
+        tiles[buf][tid] = x[0];
+        if (has2) tiles[buf][tid + kAMThreads] = x[1];
+        if (vmask && tid < kAMRows) ckeep_s[buf][tid] = (uint8_t)(ck != 0);
+    };
+    int foff[KCH];
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) foff[kc] = ccol * 16 + ((kc * 4 + g) ^ ccol);
+
+    for (int q0 = 0; q0 < Q; q0 += RT * 16) {   // one pass up to 96 queries
+        bf16x8 af[RT][KCH];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const bf16x8* rowp = reinterpret_cast<const bf16x8*>(txt + ((size_t)bc * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) af[rt][kc] = rowp[kc * 4];
+        }
+        // Masks (masked_fill_ of joint.py:417-418) are applied per element only along the axis a maximum runs over -- queries in
+        // S (rows 16 rt + 4 g + n: bit 4 rt + n of tkeep; only the row tiles that have a masked query, rt_masked, wave-uniform),
+        // regions in S^T -- and to the RESULT for the other axis: a masked query's row of S^T is all neg_inf, so its maximum
+        // is neg_inf at position 0 (tkeepT: bit rt = query 16 rt + ccol), likewise a masked region's column of S.
+        unsigned tkeep = 0xffffffu, tkeepT = 0x3fu, rt_masked = 0;
+        if (tmask) {
+            tkeep = 0;
+            tkeepT = 0;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    tkeep |= (tmask[(size_t)bc * Q + min(q0 + rt * 16 + crow + n, Q - 1)] ? 1u : 0u) << (rt * 4 + n);
+                tkeepT |= (tmask[(size_t)bc * Q + min(q0 + rt * 16 + ccol, Q - 1)] ? 1u : 0u) << rt;
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                if (__builtin_amdgcn_ballot_w64(((tkeep >> (rt * 4)) & 15u) != 15u) != 0) rt_masked |= 1u << rt;
+        }
+        const bool t_any = rt_masked != 0;   // (wave-uniform)
+        uint4 xs[NS] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        unsigned ck = 1;
+        if (n_img > 0) {
+            stage_load(a0, xs, ck);
+            stage_write(0, xs, ck);
+            if (n_img > 1) stage_load(a0 + 1, xs, ck);
+        }
+        __syncthreads();
+        for (int i = 0; i < n_img; ++i) {
+            const int a = a0 + i, buf = i & 1;
+            if (i + 1 < n_img) stage_write(buf ^ 1, xs, ck);       // tile i+1: loaded during the previous image's MFMAs
+            if (i + 2 < n_img) stage_load(a + 2, xs, ck);          // tile i+2: lands during this image's MFMAs
+            const uint4* tb = tiles[buf];
+            // region-side keep bits: S column 16 ct + ccol (bit ct of ckl), S^T rows 16 ct + 4 g + n (bit 4 ct + n of cklT)
+            unsigned ckl = 7u, cklT = 0xfffu;
+            bool v_any = false;
+            if (vmask) {
+                ckl = (unsigned)ckeep_s[buf][ccol] | ((unsigned)ckeep_s[buf][16 + ccol] << 1) | ((unsigned)ckeep_s[buf][32 + ccol] << 2);
+                cklT = 0;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    const unsigned w = *reinterpret_cast<const unsigned*>(&ckeep_s[buf][ct * 16 + crow]);   // four bytes, each 0 / 1
+                    cklT |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (ct * 4);
+                }
+                v_any = __builtin_amdgcn_ballot_w64(ckl != 7u || cklT != 0xfffu) != 0;
+            }
+            float* const rowV = out_maxV + ((size_t)bc * A + a) * Q + q0;          // wave-uniform bases
+            uint16_t* const rowA = xa.argV + ((size_t)bc * A + a) * Q + q0;
+            bf16x8 bfr[3][KCH];
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) bfr[ct][kc] = *reinterpret_cast<const bf16x8*>(tb + ct * 256 + foff[kc]);
+            // ---- maxima over the regions: S^T, one query tile at a time ----
+            float mrow[RT];
+            unsigned irow[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 st[3];   // rows = regions 16 ct + 4 g + n, column = query 16 rt + ccol
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kc = 0; kc < KCH; ++kc) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ct][kc], af[rt][kc], t, 0, 0, 0);
+                    st[ct] = t;
+                }
+                if (v_any) {   // wave-uniform: this image has masked regions
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) st[ct][n] = ((cklT >> (ct * 4 + n)) & 1u) ? st[ct][n] : neg_inf;
+                }
+                // twelve values in this lane, then the other three row groups; where: the first of this lane's regions that holds
+                // the maximum, then the smallest position across the row groups
+                float m = am_max3(am_max3(am_max3(st[0][0], st[0][1], st[0][2]), am_max3(st[0][3], st[1][0], st[1][1]), am_max3(st[1][2], st[1][3], st[2][0])),
+                                  st[2][1], am_max(st[2][2], st[2][3]));
+                m = am_xg_max(m);
+                unsigned vi = am_first_eq12<0, 1, 2, 3, 16, 17, 18, 19, 32, 33, 34, 35>(BIG, m, st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1],
+                                                                                         st[1][2], st[1][3], st[2][0], st[2][1], st[2][2], st[2][3]);
+                vi = am_xg_min(vi + (unsigned)crow);
+                if (t_any) {   // wave-uniform: a masked query's maximum
+                    const bool kq = ((tkeepT >> rt) & 1u) != 0;
+                    m = kq ? m : neg_inf;
+                    vi = kq ? vi : 0u;
+                }
+                mrow[rt] = m;
+                irow[rt] = vi;
+            }
+            // every lane of a column holds the six results of its column: row group g stores query tiles g and 4 + g, so that
+            // a store instruction writes 64 (32) consecutive queries
+            if (b < B && out_maxV) {
+                const float m_lo = g == 0 ? mrow[0] : g == 1 ? mrow[1] : g == 2 ? mrow[2] : mrow[3];
+                const unsigned i_lo = g == 0 ? irow[0] : g == 1 ? irow[1] : g == 2 ? irow[2] : irow[3];
+                const float m_hi = g == 0 ? mrow[4] : mrow[5];
+                const unsigned i_hi = g == 0 ? irow[4] : irow[5];
+                if (q0 + lane < Q) {
+                    rowV[lane] = m_lo;
+                    rowA[lane] = (uint16_t)i_lo;
+                }
+                if (lane < 32 && q0 + 64 + lane < Q) {
+                    rowV[64 + lane] = m_hi;
+                    rowA[64 + lane] = (uint16_t)i_hi;
+                }
+            }
+            // ---- maxima over the queries: S, one region tile at a time ----
+            if (HASQ) {
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    f32x4 sq[RT];   // rows = queries 16 rt + 4 g + n, column = region 16 ct + ccol
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][kc], bfr[ct][kc], acc, 0, 0, 0);
+                        sq[rt] = acc;
+                    }
+                    if (t_any) {
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            if ((rt_masked >> rt) & 1u) {   // wave-uniform
+#pragma unroll
+                                for (int n = 0; n < 4; ++n) sq[rt][n] = ((tkeep >> (rt * 4 + n)) & 1u) ? sq[rt][n] : neg_inf;
+                            }
+                    }
+                    float m = am_max3(am_max3(am_max3(sq[0][0], sq[0][1], sq[0][2]), am_max3(sq[0][3], sq[1][0], sq[1][1]), am_max3(sq[1][2], sq[1][3], sq[2][0])),
+                                      am_max3(am_max3(sq[2][1], sq[2][2], sq[2][3]), am_max3(sq[3][0], sq[3][1], sq[3][2]), am_max3(sq[3][3], sq[4][0], sq[4][1])),
+                                      am_max3(am_max3(sq[4][2], sq[4][3], sq[5][0]), am_max3(sq[5][1], sq[5][2], sq[5][3]), sq[5][3]));
+                    m = am_xg_max(m);
+                    // position code 4 rt + n (query 16 rt + 4 g + n; 80.. is no inline constant), later row tiles first
+                    unsigned qc = am_first_eq12<12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23>(BIG, m, sq[3][0], sq[3][1], sq[3][2], sq[3][3], sq[4][0], sq[4][1],
+                                                                                                 sq[4][2], sq[4][3], sq[5][0], sq[5][1], sq[5][2], sq[5][3]);
+                    qc = am_first_eq12<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11>(qc, m, sq[0][0], sq[0][1], sq[0][2], sq[0][3], sq[1][0], sq[1][1], sq[1][2],
+                                                                             sq[1][3], sq[2][0], sq[2][1], sq[2][2], sq[2][3]);
+                    unsigned qi = ((qc & ~3u) << 2) + (qc & 3u) + (unsigned)crow;   // BIG stays far above every query
+                    qi = am_xg_min(qi) + (unsigned)q0;
+                    if (v_any) {   // a masked region's maximum
+                        const bool kv = ((ckl >> ct) & 1u) != 0;
+                        m = kv ? m : neg_inf;
+                        qi = kv ? qi : (unsigned)q0;
+                    }
+                    const int v = ct * 16 + ccol;
+                    if (b < B && lane < 16 && v < V) {
+                        float* const colV = out_maxQ + ((size_t)bc * A + a) * V;   // wave-uniform bases
+                        uint16_t* const colA = xa.argQ + ((size_t)bc * A + a) * V;
+                        if (q0 == 0 || m > colV[v]) {   // later passes (Q > 96) only win with a strictly larger value
+                            colV[v] = m;
+                            colA[v] = (uint16_t)qi;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// The diagonal pairs (a == b) again, with the POS prior pen[b,q,seg(v)] subtracted before the maxima (joint.py:466-469): B
+// pairs of 65 536, one wavefront each, no attempt at speed -- the scores go to LDS and one lane scans a row / a column in
+// order (first position on ties, by construction).  Runs after align_argmax_kernel on the same stream and overwrites its
+// outputs for these pairs.
+__global__ __launch_bounds__(64) void align_prior_diag_kernel(
+    const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
+    const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_maxV,
+    float* __restrict__ out_maxQ, AlignArgs xa) {
+    constexpr int d = 128, KCH = 4, RT = 6, P = 49;
+    __shared__ float S[RT * 16 * P];
+    __shared__ uint8_t kq_s[RT * 16], kv_s[48];
+    const int b = blockIdx.x, a = b, lane = threadIdx.x, g = lane >> 4, ccol = lane & 15, crow = g * 4;
+    if (a >= A) return;
+    const float ninf = neg_infinity();
+    const float* pen_b = xa.pen + (size_t)b * Q * xa.n_seg;
+    for (int q0 = 0; q0 < Q; q0 += RT * 16) {
+        for (int i = lane; i < RT * 16; i += 64) kq_s[i] = tmask ? (uint8_t)(tmask[(size_t)b * Q + min(q0 + i, Q - 1)] != 0) : (uint8_t)1;
+        if (lane < 48) kv_s[lane] = vmask ? (uint8_t)(vmask[(size_t)a * V + min(lane, V - 1)] != 0) : (uint8_t)1;
+        __syncthreads();
+#pragma unroll 1
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll 1
+            for (int ct = 0; ct < 3; ++ct) {
+                const bf16x8* ap = reinterpret_cast<const bf16x8*>(txt + ((size_t)b * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
+                const bf16x8* bp = reinterpret_cast<const bf16x8*>(vis + ((size_t)a * V + min(ct * 16 + ccol, V - 1)) * d + g * 8);
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[kc * 4], bp[kc * 4], acc, 0, 0, 0);
+                const int v = min(ct * 16 + ccol, V - 1);
+                const unsigned vk = kv_s[ct * 16 + ccol];
+                const float* pen_v = pen_b + xa.seg_of_v[v];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int q = min(q0 + rt * 16 + crow + n, Q - 1);
+                    const bool keep = (vk & kq_s[rt * 16 + crow + n]) != 0;
+                    S[(rt * 16 + crow + n) * P + ct * 16 + ccol] = (keep ? acc[n] : neg_inf) - pen_v[(size_t)q * xa.n_seg];
+                }
+            }
+        __syncthreads();
+        const int nq = min(RT * 16, Q - q0);
+        if (out_maxV)
+            for (int q = lane; q < nq; q += 64) {
+                float m = ninf;
+                int vi = 0;
+                for (int v = 0; v < V; ++v) {
+                    const float x = S[q * P + v];
+                    if (x > m) { m = x; vi = v; }
+                }
+                out_maxV[((size_t)b * A + a) * Q + q0 + q] = m;
+                xa.argV[((size_t)b * A + a) * Q + q0 + q] = (uint16_t)vi;
+            }
+        if (out_maxQ && lane < V) {
+            const size_t at = ((size_t)b * A + a) * V + lane;
+            float m = q0 == 0 ? ninf : out_maxQ[at];
+            int qi = q0 == 0 ? 0 : (int)xa.argQ[at];
+            for (int q = 0; q < nq; ++q) {
+                const float x = S[q * P + lane];
+                if (x > m) { m = x; qi = q0 + q; }
+            }
+            out_maxQ[at] = m;
+            xa.argQ[at] = (uint16_t)qi;
+        }
+        __syncthreads();
+    }
+}
+
+// =====================================================================================================
 // The materialised tensor attmap [B,A,Q,V] (what `gather_logit_simple` returns, joint.py:406-419) for one-group images
 // (V <= 48, V % 4 == 0), bf16 features, d = 128 -- round 3.  align_mfma_kernel<TILE> keeps 96 caption rows AND a three-deep
 // image-fragment ring in 286 registers (one wave per SIMD, four waves per CU), bounces every accumulator through an LDS
@@ -882,8 +1199,26 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
     if (a_per_block < 8) a_per_block = 8;
     if (a_per_block > A) a_per_block = A;
     dim3 grid((A + a_per_block - 1) / a_per_block, by);   // x fastest: workgroups of one caption octet spread over the XCDs
+    if (ARGS && !getenv("VLG_ALIGN_ARGMAX_OLD")) {   // (the env switch: tools/ A-B timing only)
+        if (out_maxQ)
+            hipLaunchKernelGGL(align_argmax_kernel<true>, grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask,
+                               vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
+        else
+            hipLaunchKernelGGL(align_argmax_kernel<false>, grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask,
+                               vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
+        if (xa.pen && !getenv("VLG_DBG_NODIAG")) {
+            if (int rc = check_launch("align_argmax_kernel")) return rc;
+            hipLaunchKernelGGL(align_prior_diag_kernel, dim3(std::min(A, B)), dim3(64), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask,
+                               vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, xa);
+            return check_launch("align_prior_diag_kernel");
+        }
+        return check_launch("align_argmax_kernel");
+    }
     hipLaunchKernelGGL((align_max_kernel<ARGS, ARGS ? 3 : 6>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
                        tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
+    if (ARGS && xa.pen && getenv("VLG_DBG_DIAGAFTER"))
+        hipLaunchKernelGGL(align_prior_diag_kernel, dim3(std::min(A, B)), dim3(64), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask,
+                           vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, xa);
     return check_launch("align_max_kernel");
 }
 
