@@ -928,9 +928,11 @@ def test_grounding_loss_golden(oracle_mod, path):
 @pytest.mark.parametrize("B,L,V,d,dt", [(5, 7, 9, 32, "f32"), (6, 40, 36, 128, "f32"), (6, 40, 36, 128, "bf16"),
                                         (3, 50, 70, 64, "f32"), (4, 47, 100, 128, "bf16"), (1, 3, 1, 32, "f32"),
                                         (3, 12, 1369, 128, "f32"), (2, 9, 520, 128, "bf16"),
-                                        (6, 40, 1369, 128, "bf16"), (7, 30, 1200, 64, "f32")])
+                                        (6, 40, 1369, 128, "bf16"), (7, 30, 1200, 64, "f32"),
+                                        (5, 60, 44, 128, "bf16"), (3, 20, 17, 128, "bf16"), (9, 47, 48, 128, "bf16")])
 def test_grounding_loss_shapes(oracle_mod, B, L, V, d, dt):
-    """Against the fp64 oracle: several row groups (Q > 96 / 48), several region groups (V > 48), one pair, bf16 storage,
+    """Against the fp64 oracle: several row groups (Q > 96 / 48), several region groups (V > 48), one pair, bf16 storage
+    (V <= 48: align_argmax_kernel, two passes at Q = 122, odd and full region counts, a batch that is no multiple of eight),
     and the shipped factor layout's 1369 columns (image-side gradient rows split over several workgroups; caption side with
     one row per wave and the block-level scan of the scattered terms)."""
     from vlgae_amd import align

@@ -30,6 +30,3 @@ for B, L, V in ((6, 40, 36), (8, 40, 36), (16, 20, 36), (6, 40, 32)):
     for wp in (False, True):
         for mk in (False, True):
             run(B, L, V, wp, mk)
-os.environ["VLG_DBG_NODIAG"] = "1"
-print("no diag kernel:")
-run(6, 40, 36, True, False)

@@ -778,6 +778,25 @@ static __device__ __forceinline__ unsigned am_first_eq12(unsigned r, float m, fl
     return r;
 }
 
+// x where bit `pos` of `bits` is set, `fill` elsewhere: a sign-extending one-bit extract is the select mask of v_bitop3 (a ? b : c =
+// table 0xca) -- two vector instructions and no lane mask in SGPRs (a v_cmp / v_cndmask pair waits two states on the mask, and hipcc
+// keeps 24 of them live).  The builtin, because hipcc rewrites (x & m) | (fill & ~m) with m known to be 0 / -1 as compare + select.
+static __device__ __forceinline__ float am_keep(unsigned bits, int pos, float x, float fill) {
+    const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)bits, pos, 1);
+    return __uint_as_float(__builtin_amdgcn_bitop3_b32(mk, __float_as_uint(x), __float_as_uint(fill), 0xca));
+}
+static __device__ __forceinline__ unsigned am_keep_u(unsigned bits, int pos, unsigned x, unsigned fill) {
+    const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)bits, pos, 1);
+    return __builtin_amdgcn_bitop3_b32(mk, x, fill, 0xca);
+}
+// (wave-uniform branches whose bodies are a few selects are flattened by hipcc into selects on EVERY tile; an empty volatile
+//  statement inside keeps them branches)
+#define VLG_AM_KEEP_BRANCH() asm volatile("" ::: "memory")
+// After a group of MFMAs whose results are first read on the far side of a wave-uniform branch: hipcc pads MFMA -> vector-ALU reads
+// with s_nop within a block, but with the branch in between the reader at the branch TARGET came out two instructions after the
+// last MFMA (measured: wrong maxima in the unmasked variant only, right again with this pad; 16 states cover a 16-pass MFMA).
+#define VLG_AM_MFMA_DRAIN() asm volatile("s_nop 7\n\ts_nop 7" ::: "memory")
+
 template <bool HASQ>
 __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
     const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
@@ -786,7 +805,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
     constexpr int d = 128, KCH = 4, RT = 6;
     constexpr unsigned BIG = 0x7000u;
     __shared__ uint4 tiles[2][kAMSlots];
-    __shared__ uint8_t ckeep_s[2][kAMRows];
+    __shared__ unsigned long long kmask_s[2];   // region-side keep bits of the staged image (bit v), by wave 0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything that depends on the caption lives in SGPRs
     const int b = blockIdx.y * kAMWaves + wave, bc = min(b, B - 1);   // a wave past the batch mirrors the last caption, stores nothing
@@ -809,7 +828,10 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
     auto stage_write = [&](int buf, const uint4* x, unsigned ck) {
         tiles[buf][tid] = x[0];
         if (has2) tiles[buf][tid + kAMThreads] = x[1];
-        if (vmask && tid < kAMRows) ckeep_s[buf][tid] = (uint8_t)(ck != 0);
+        if (vmask && wave == 0) {   // (lanes 48.. hold ck = 1)
+            const unsigned long long km = __builtin_amdgcn_ballot_w64(ck != 0);
+            if (lane == 0) kmask_s[buf] = km;
+        }
     };
     int foff[KCH];
 #pragma unroll
@@ -856,18 +878,19 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
             if (i + 1 < n_img) stage_write(buf ^ 1, xs, ck);       // tile i+1: loaded during the previous image's MFMAs
             if (i + 2 < n_img) stage_load(a + 2, xs, ck);          // tile i+2: lands during this image's MFMAs
             const uint4* tb = tiles[buf];
-            // region-side keep bits: S column 16 ct + ccol (bit ct of ckl), S^T rows 16 ct + 4 g + n (bit 4 ct + n of cklT)
+            // region-side keep bits: S column 16 ct + ccol (bit ct of ckl), S^T rows 16 ct + 4 g + n (bit 4 ct + n of cklT);
+            // the image's 48-bit mask is wave-uniform, the per-lane views are only built for an image that has masked regions
             unsigned ckl = 7u, cklT = 0xfffu;
             bool v_any = false;
             if (vmask) {
-                ckl = (unsigned)ckeep_s[buf][ccol] | ((unsigned)ckeep_s[buf][16 + ccol] << 1) | ((unsigned)ckeep_s[buf][32 + ccol] << 2);
-                cklT = 0;
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {
-                    const unsigned w = *reinterpret_cast<const unsigned*>(&ckeep_s[buf][ct * 16 + crow]);   // four bytes, each 0 / 1
-                    cklT |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (ct * 4);
+                const unsigned long long kmv = kmask_s[buf];
+                const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)kmv), khi = __builtin_amdgcn_readfirstlane((unsigned)(kmv >> 32));
+                v_any = klo != 0xffffffffu || (khi & 0xffffu) != 0xffffu;
+                if (v_any) {
+                    VLG_AM_KEEP_BRANCH();
+                    ckl = ((klo >> ccol) & 1u) | (((klo >> (16 + ccol)) & 1u) << 1) | (((khi >> ccol) & 1u) << 2);
+                    cklT = ((klo >> crow) & 15u) | (((klo >> (16 + crow)) & 15u) << 4) | (((khi >> crow) & 15u) << 8);
                 }
-                v_any = __builtin_amdgcn_ballot_w64(ckl != 7u || cklT != 0xfffu) != 0;
             }
             float* const rowV = out_maxV + ((size_t)bc * A + a) * Q + q0;          // wave-uniform bases
             uint16_t* const rowA = xa.argV + ((size_t)bc * A + a) * Q + q0;
@@ -889,24 +912,27 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                     for (int kc = 0; kc < KCH; ++kc) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ct][kc], af[rt][kc], t, 0, 0, 0);
                     st[ct] = t;
                 }
+                VLG_AM_MFMA_DRAIN();
                 if (v_any) {   // wave-uniform: this image has masked regions
+                    VLG_AM_KEEP_BRANCH();
 #pragma unroll
                     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-                        for (int n = 0; n < 4; ++n) st[ct][n] = ((cklT >> (ct * 4 + n)) & 1u) ? st[ct][n] : neg_inf;
+                        for (int n = 0; n < 4; ++n) st[ct][n] = am_keep(cklT, ct * 4 + n, st[ct][n], neg_inf);
                 }
                 // twelve values in this lane, then the other three row groups; where: the first of this lane's regions that holds
                 // the maximum, then the smallest position across the row groups
-                float m = am_max3(am_max3(am_max3(st[0][0], st[0][1], st[0][2]), am_max3(st[0][3], st[1][0], st[1][1]), am_max3(st[1][2], st[1][3], st[2][0])),
-                                  st[2][1], am_max(st[2][2], st[2][3]));
+                const float t3 = am_max3(st[2][1], st[2][2], st[2][3]);   // (a repeated operand instead of a two-input maximum: that one gets canonicalised inputs)
+                float m = am_max3(am_max3(st[0][0], st[0][1], st[0][2]), am_max3(st[0][3], st[1][0], st[1][1]),
+                                  am_max3(am_max3(st[1][2], st[1][3], st[2][0]), t3, t3));
                 m = am_xg_max(m);
                 unsigned vi = am_first_eq12<0, 1, 2, 3, 16, 17, 18, 19, 32, 33, 34, 35>(BIG, m, st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1],
                                                                                          st[1][2], st[1][3], st[2][0], st[2][1], st[2][2], st[2][3]);
                 vi = am_xg_min(vi + (unsigned)crow);
                 if (t_any) {   // wave-uniform: a masked query's maximum
-                    const bool kq = ((tkeepT >> rt) & 1u) != 0;
-                    m = kq ? m : neg_inf;
-                    vi = kq ? vi : 0u;
+                    VLG_AM_KEEP_BRANCH();
+                    m = am_keep(tkeepT, rt, m, neg_inf);
+                    vi = am_keep_u(tkeepT, rt, vi, 0u);
                 }
                 mrow[rt] = m;
                 irow[rt] = vi;
@@ -939,17 +965,18 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                         for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][kc], bfr[ct][kc], acc, 0, 0, 0);
                         sq[rt] = acc;
                     }
-                    if (t_any) {
+                    VLG_AM_MFMA_DRAIN();
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt)
-                            if ((rt_masked >> rt) & 1u) {   // wave-uniform
+                    for (int rt = 0; rt < RT; ++rt)
+                        if ((rt_masked >> rt) & 1u) {   // wave-uniform: this row tile has a masked query
+                            VLG_AM_KEEP_BRANCH();
 #pragma unroll
-                                for (int n = 0; n < 4; ++n) sq[rt][n] = ((tkeep >> (rt * 4 + n)) & 1u) ? sq[rt][n] : neg_inf;
-                            }
-                    }
-                    float m = am_max3(am_max3(am_max3(sq[0][0], sq[0][1], sq[0][2]), am_max3(sq[0][3], sq[1][0], sq[1][1]), am_max3(sq[1][2], sq[1][3], sq[2][0])),
-                                      am_max3(am_max3(sq[2][1], sq[2][2], sq[2][3]), am_max3(sq[3][0], sq[3][1], sq[3][2]), am_max3(sq[3][3], sq[4][0], sq[4][1])),
-                                      am_max3(am_max3(sq[4][2], sq[4][3], sq[5][0]), am_max3(sq[5][1], sq[5][2], sq[5][3]), sq[5][3]));
+                            for (int n = 0; n < 4; ++n) sq[rt][n] = am_keep(tkeep, rt * 4 + n, sq[rt][n], neg_inf);
+                        }
+                    const float u0 = am_max3(am_max3(sq[0][0], sq[0][1], sq[0][2]), am_max3(sq[0][3], sq[1][0], sq[1][1]), am_max3(sq[1][2], sq[1][3], sq[2][0]));
+                    const float u1 = am_max3(am_max3(sq[2][1], sq[2][2], sq[2][3]), am_max3(sq[3][0], sq[3][1], sq[3][2]), am_max3(sq[3][3], sq[4][0], sq[4][1]));
+                    const float u2 = am_max3(sq[4][2], sq[4][3], sq[5][0]), u3 = am_max3(sq[5][1], sq[5][2], sq[5][3]);
+                    float m = am_max3(u0, u1, am_max3(u2, u3, u3));
                     m = am_xg_max(m);
                     // position code 4 rt + n (query 16 rt + 4 g + n; 80.. is no inline constant), later row tiles first
                     unsigned qc = am_first_eq12<12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23>(BIG, m, sq[3][0], sq[3][1], sq[3][2], sq[3][3], sq[4][0], sq[4][1],
@@ -959,9 +986,9 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                     unsigned qi = ((qc & ~3u) << 2) + (qc & 3u) + (unsigned)crow;   // BIG stays far above every query
                     qi = am_xg_min(qi) + (unsigned)q0;
                     if (v_any) {   // a masked region's maximum
-                        const bool kv = ((ckl >> ct) & 1u) != 0;
-                        m = kv ? m : neg_inf;
-                        qi = kv ? qi : (unsigned)q0;
+                        VLG_AM_KEEP_BRANCH();
+                        m = am_keep(ckl, ct, m, neg_inf);
+                        qi = am_keep_u(ckl, ct, qi, (unsigned)q0);
                     }
                     const int v = ct * 16 + ccol;
                     if (b < B && lane < 16 && v < V) {
@@ -1206,7 +1233,7 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
         else
             hipLaunchKernelGGL(align_argmax_kernel<false>, grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask,
                                vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
-        if (xa.pen && !getenv("VLG_DBG_NODIAG")) {
+        if (xa.pen) {
             if (int rc = check_launch("align_argmax_kernel")) return rc;
             hipLaunchKernelGGL(align_prior_diag_kernel, dim3(std::min(A, B)), dim3(64), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask,
                                vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, xa);
@@ -1216,9 +1243,6 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
     }
     hipLaunchKernelGGL((align_max_kernel<ARGS, ARGS ? 3 : 6>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
                        tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
-    if (ARGS && xa.pen && getenv("VLG_DBG_DIAGAFTER"))
-        hipLaunchKernelGGL(align_prior_diag_kernel, dim3(std::min(A, B)), dim3(64), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask,
-                           vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, xa);
     return check_launch("align_max_kernel");
 }
 
