@@ -795,9 +795,12 @@ static __device__ __forceinline__ unsigned am_keep_u(unsigned bits, int pos, uns
 // After a group of MFMAs whose results are first read on the far side of a wave-uniform branch: hipcc pads MFMA -> vector-ALU reads
 // with s_nop within a block, but with the branch in between the reader at the branch TARGET came out two instructions after the
 // last MFMA (measured: wrong maxima in the unmasked variant only, right again with this pad; 16 states cover a 16-pass MFMA).
-#define VLG_AM_MFMA_DRAIN() asm volatile("s_nop 7\n\ts_nop 7" ::: "memory")
+// The accumulators are tied operands: the pad can neither be scheduled ahead of the MFMAs that write them nor behind their first reader.
+#define VLG_AM_MFMA_DRAIN3(A, B, C) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(A), "+v"(B), "+v"(C))
+#define VLG_AM_MFMA_DRAIN6(A, B, C, D, E, F) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E), "+v"(F))
 
-template <bool HASQ>
+// ARGS = false: the maxima alone (the decoder's / gather_logit's fused dispatch) -- no searches, no position stores
+template <bool HASQ, bool ARGS>
 __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
     const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
     const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_maxV,
@@ -893,7 +896,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                 }
             }
             float* const rowV = out_maxV + ((size_t)bc * A + a) * Q + q0;          // wave-uniform bases
-            uint16_t* const rowA = xa.argV + ((size_t)bc * A + a) * Q + q0;
+            uint16_t* const rowA = ARGS ? xa.argV + ((size_t)bc * A + a) * Q + q0 : nullptr;
             bf16x8 bfr[3][KCH];
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct)
@@ -902,6 +905,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
             // ---- maxima over the regions: S^T, one query tile at a time ----
             float mrow[RT];
             unsigned irow[RT];
+            if (out_maxV) {   // (kernel-uniform)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 f32x4 st[3];   // rows = regions 16 ct + 4 g + n, column = query 16 rt + ccol
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                     for (int kc = 0; kc < KCH; ++kc) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ct][kc], af[rt][kc], t, 0, 0, 0);
                     st[ct] = t;
                 }
-                VLG_AM_MFMA_DRAIN();
+                VLG_AM_MFMA_DRAIN3(st[0], st[1], st[2]);
                 if (v_any) {   // wave-uniform: this image has masked regions
                     VLG_AM_KEEP_BRANCH();
 #pragma unroll
@@ -926,33 +930,37 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                 float m = am_max3(am_max3(st[0][0], st[0][1], st[0][2]), am_max3(st[0][3], st[1][0], st[1][1]),
                                   am_max3(am_max3(st[1][2], st[1][3], st[2][0]), t3, t3));
                 m = am_xg_max(m);
-                unsigned vi = am_first_eq12<0, 1, 2, 3, 16, 17, 18, 19, 32, 33, 34, 35>(BIG, m, st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1],
-                                                                                         st[1][2], st[1][3], st[2][0], st[2][1], st[2][2], st[2][3]);
-                vi = am_xg_min(vi + (unsigned)crow);
+                unsigned vi = 0;
+                if (ARGS) {
+                    vi = am_first_eq12<0, 1, 2, 3, 16, 17, 18, 19, 32, 33, 34, 35>(BIG, m, st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1],
+                                                                                    st[1][2], st[1][3], st[2][0], st[2][1], st[2][2], st[2][3]);
+                    vi = am_xg_min(vi + (unsigned)crow);
+                }
                 if (t_any) {   // wave-uniform: a masked query's maximum
                     VLG_AM_KEEP_BRANCH();
                     m = am_keep(tkeepT, rt, m, neg_inf);
-                    vi = am_keep_u(tkeepT, rt, vi, 0u);
+                    if (ARGS) vi = am_keep_u(tkeepT, rt, vi, 0u);
                 }
                 mrow[rt] = m;
                 irow[rt] = vi;
             }
             // every lane of a column holds the six results of its column: row group g stores query tiles g and 4 + g, so that
             // a store instruction writes 64 (32) consecutive queries
-            if (b < B && out_maxV) {
+            if (b < B) {
                 const float m_lo = g == 0 ? mrow[0] : g == 1 ? mrow[1] : g == 2 ? mrow[2] : mrow[3];
                 const unsigned i_lo = g == 0 ? irow[0] : g == 1 ? irow[1] : g == 2 ? irow[2] : irow[3];
                 const float m_hi = g == 0 ? mrow[4] : mrow[5];
                 const unsigned i_hi = g == 0 ? irow[4] : irow[5];
                 if (q0 + lane < Q) {
                     rowV[lane] = m_lo;
-                    rowA[lane] = (uint16_t)i_lo;
+                    if (ARGS) rowA[lane] = (uint16_t)i_lo;
                 }
                 if (lane < 32 && q0 + 64 + lane < Q) {
                     rowV[64 + lane] = m_hi;
-                    rowA[64 + lane] = (uint16_t)i_hi;
+                    if (ARGS) rowA[64 + lane] = (uint16_t)i_hi;
                 }
             }
+            }   // out_maxV
             // ---- maxima over the queries: S, one region tile at a time ----
             if (HASQ) {
 #pragma unroll
@@ -965,7 +973,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                         for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][kc], bfr[ct][kc], acc, 0, 0, 0);
                         sq[rt] = acc;
                     }
-                    VLG_AM_MFMA_DRAIN();
+                    VLG_AM_MFMA_DRAIN6(sq[0], sq[1], sq[2], sq[3], sq[4], sq[5]);
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
                         if ((rt_masked >> rt) & 1u) {   // wave-uniform: this row tile has a masked query
@@ -979,24 +987,26 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                     float m = am_max3(u0, u1, am_max3(u2, u3, u3));
                     m = am_xg_max(m);
                     // position code 4 rt + n (query 16 rt + 4 g + n; 80.. is no inline constant), later row tiles first
-                    unsigned qc = am_first_eq12<12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23>(BIG, m, sq[3][0], sq[3][1], sq[3][2], sq[3][3], sq[4][0], sq[4][1],
-                                                                                                 sq[4][2], sq[4][3], sq[5][0], sq[5][1], sq[5][2], sq[5][3]);
-                    qc = am_first_eq12<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11>(qc, m, sq[0][0], sq[0][1], sq[0][2], sq[0][3], sq[1][0], sq[1][1], sq[1][2],
-                                                                             sq[1][3], sq[2][0], sq[2][1], sq[2][2], sq[2][3]);
-                    unsigned qi = ((qc & ~3u) << 2) + (qc & 3u) + (unsigned)crow;   // BIG stays far above every query
-                    qi = am_xg_min(qi) + (unsigned)q0;
+                    unsigned qi = 0;
+                    if (ARGS) {
+                        unsigned qc = am_first_eq12<12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23>(BIG, m, sq[3][0], sq[3][1], sq[3][2], sq[3][3], sq[4][0],
+                                                                                                     sq[4][1], sq[4][2], sq[4][3], sq[5][0], sq[5][1], sq[5][2], sq[5][3]);
+                        qc = am_first_eq12<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11>(qc, m, sq[0][0], sq[0][1], sq[0][2], sq[0][3], sq[1][0], sq[1][1], sq[1][2],
+                                                                                 sq[1][3], sq[2][0], sq[2][1], sq[2][2], sq[2][3]);
+                        qi = ((qc & ~3u) << 2) + (qc & 3u) + (unsigned)crow;   // BIG stays far above every query
+                        qi = am_xg_min(qi) + (unsigned)q0;
+                    }
                     if (v_any) {   // a masked region's maximum
                         VLG_AM_KEEP_BRANCH();
                         m = am_keep(ckl, ct, m, neg_inf);
-                        qi = am_keep_u(ckl, ct, qi, (unsigned)q0);
+                        if (ARGS) qi = am_keep_u(ckl, ct, qi, (unsigned)q0);
                     }
                     const int v = ct * 16 + ccol;
                     if (b < B && lane < 16 && v < V) {
                         float* const colV = out_maxQ + ((size_t)bc * A + a) * V;   // wave-uniform bases
-                        uint16_t* const colA = xa.argQ + ((size_t)bc * A + a) * V;
                         if (q0 == 0 || m > colV[v]) {   // later passes (Q > 96) only win with a strictly larger value
                             colV[v] = m;
-                            colA[v] = (uint16_t)qi;
+                            if (ARGS) xa.argQ[((size_t)bc * A + a) * V + v] = (uint16_t)qi;
                         }
                     }
                 }
@@ -1226,20 +1236,24 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
     if (a_per_block < 8) a_per_block = 8;
     if (a_per_block > A) a_per_block = A;
     dim3 grid((A + a_per_block - 1) / a_per_block, by);   // x fastest: workgroups of one caption octet spread over the XCDs
-    if (ARGS && !getenv("VLG_ALIGN_ARGMAX_OLD")) {   // (the env switch: tools/ A-B timing only)
-        if (out_maxQ)
-            hipLaunchKernelGGL(align_argmax_kernel<true>, grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask,
-                               vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
-        else
-            hipLaunchKernelGGL(align_argmax_kernel<false>, grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask,
-                               vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
-        if (xa.pen) {
-            if (int rc = check_launch("align_argmax_kernel")) return rc;
-            hipLaunchKernelGGL(align_prior_diag_kernel, dim3(std::min(A, B)), dim3(64), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask,
-                               vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, xa);
-            return check_launch("align_prior_diag_kernel");
+    // positions wanted: both products on the matrix cores (172 vs 267 us at config-2).  The maxima alone stay with align_max_kernel:
+    // without the searches that one is not vector-ALU bound, and the second product only costs (ARGS = false measured: 149 vs 130 us)
+    if constexpr (ARGS) {
+        if (!getenv("VLG_ALIGN_ARGMAX_OLD")) {   // (the env switch: tools/ A-B timing only)
+            if (out_maxQ)
+                hipLaunchKernelGGL((align_argmax_kernel<true, true>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
+                                   tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
+            else
+                hipLaunchKernelGGL((align_argmax_kernel<false, true>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
+                                   tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
+            if (xa.pen) {
+                if (int rc = check_launch("align_argmax_kernel")) return rc;
+                hipLaunchKernelGGL(align_prior_diag_kernel, dim3(std::min(A, B)), dim3(64), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
+                                   tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, xa);
+                return check_launch("align_prior_diag_kernel");
+            }
+            return check_launch("align_argmax_kernel");
         }
-        return check_launch("align_argmax_kernel");
     }
     hipLaunchKernelGGL((align_max_kernel<ARGS, ARGS ? 3 : 6>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
                        tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
