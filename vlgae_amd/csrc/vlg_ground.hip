@@ -763,38 +763,63 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
         auto welem = [&](int row, int col) { return reinterpret_cast<uint16_t*>(wt + row * PITCH + col * 2); };
 #ifndef VLG_GD_NOW
         {
-            // every read of the staged arrays first (for all PP pairs: independent chains), then the clears and writes
-            bool clr_s[PP], clr_o[PP], row_w[PP], col_w[PP];
-            int my_s[PP], my_o[PP];
-            float vrow[PP], vcol[PP];
+            // every read of the staged arrays first (for all PP pairs: independent chains), then the clears and writes.  BRANCH-FREE
+            // (round 3): unconditional LDS reads at clamped indices, integer flags, writes that go to the row's pitch padding when
+            // they are not wanted -- as `a && b[i]` / `if (c) *p = v` every read became an exec-masked block with its own
+            // s_waitcnt lgkmcnt(0), a dozen LDS round trips in a row per pair (see ground_bwd_ws_kernel).
+            const int prow = min(tid, MR - 1), pcol = min(tid, Kp - 1);
+            uint16_t* const dummy = welem(prow, KT);   // this row's padding: never read
+            int a_ps[PP], a_po[PP], s_raw[PP], o_raw[PP];
+            float vrow[PP], vcolb[PP];
 #pragma unroll
             for (int q = 0; q < PP; ++q) {
-                const bool live = o + q < O;             // the last step of an odd range has one pair: its second half only clears
                 const int16_t* argS = sarg + (cp + q) * EW;
                 const int16_t* argO = argS + MR;
                 const float* valS = sval + (cp + q) * EW;
                 const float* valO = valS + MR;
+                a_ps[q] = argO[max(ps_old[q], 0)];
+                a_po[q] = argS[max(po_old[q], 0)];
+                s_raw[q] = argS[prow];
+                o_raw[q] = argO[pcol];
+                vrow[q] = valS[prow];
+                vcolb[q] = valO[pcol];
+            }
+            int my_s[PP], my_o[PP], a_ms[PP], a_mo[PP];
+            float v_mo[PP];
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                const int live = o + q < O ? -1 : 0;             // the last step of an odd range has one pair: its second half only clears
+                const int16_t* argS = sarg + (cp + q) * EW;
+                const int16_t* argO = argS + MR;
+                const float* valS = sval + (cp + q) * EW;
+                my_s[q] = (live & (tid < MR ? -1 : 0)) ? s_raw[q] : -1;   // already -1 where invalid
+                my_o[q] = (live & (tid < Kp ? -1 : 0)) ? o_raw[q] : -1;
+                a_ms[q] = argO[max(my_s[q], 0)];
+                a_mo[q] = argS[max(my_o[q], 0)];
+                v_mo[q] = valS[max(my_o[q], 0)];
+            }
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                const int live = o + q < O ? 1 : 0;
                 // (an old element is left alone when ANOTHER thread writes this step's value to the same place -- the column
                 //  owner of my old column pointing at my row, or the row owner of my old row pointing at my column -- since its
                 //  write and my clear are unordered; my own clear-then-write is program order, a wave's LDS operations complete
                 //  in order)
-                clr_s[q] = ps_old[q] >= 0 && !(live && argO[max(ps_old[q], 0)] == tid);
-                clr_o[q] = po_old[q] >= 0 && !(live && argS[max(po_old[q], 0)] == tid);
-                my_s[q] = live && tid < MR ? argS[tid] : -1;   // already -1 where invalid
-                my_o[q] = live && tid < Kp ? argO[tid] : -1;
-                row_w[q] = my_s[q] >= 0 && argO[max(my_s[q], 0)] != tid;   // else the column owner writes the sum
-                col_w[q] = my_o[q] >= 0;
-                vrow[q] = valS[min(tid, MR - 1)];
-                vcol[q] = valO[min(tid, Kp - 1)] + (argS[max(my_o[q], 0)] == tid ? valS[max(my_o[q], 0)] : 0.f);
-            }
-#pragma unroll
-            for (int q = 0; q < PP; ++q) {
-                if (clr_s[q]) *welem(tid, q * Kp + ps_old[q]) = 0;
-                if (clr_o[q]) *welem(po_old[q], q * Kp + tid) = 0;
-                if (row_w[q]) *welem(tid, q * Kp + my_s[q]) = f2bf(vrow[q]);
-                if (col_w[q]) *welem(my_o[q], q * Kp + tid) = f2bf(vcol[q]);
-                ps_old[q] = row_w[q] ? my_s[q] : -1;
-                po_old[q] = col_w[q] ? my_o[q] : -1;
+                const int clr_s = (ps_old[q] >= 0 ? 1 : 0) & (1 ^ (live & (a_ps[q] == tid ? 1 : 0)));
+                const int clr_o = (po_old[q] >= 0 ? 1 : 0) & (1 ^ (live & (a_po[q] == tid ? 1 : 0)));
+                const int row_w = (my_s[q] >= 0 ? 1 : 0) & (a_ms[q] != tid ? 1 : 0);   // else the column owner writes the sum
+                const int col_w = my_o[q] >= 0 ? 1 : 0;
+                const float vcol = vcolb[q] + (a_mo[q] == tid ? v_mo[q] : 0.f);
+                uint16_t* p0 = clr_s ? welem(prow, q * Kp + max(ps_old[q], 0)) : dummy;
+                uint16_t* p1 = clr_o ? welem(max(po_old[q], 0), q * Kp + pcol) : dummy;
+                uint16_t* p2 = row_w ? welem(prow, q * Kp + max(my_s[q], 0)) : dummy;
+                uint16_t* p3 = col_w ? welem(max(my_o[q], 0), q * Kp + pcol) : dummy;
+                *p0 = 0;
+                *p1 = 0;
+                *p2 = f2bf(vrow[q]);
+                *p3 = f2bf(vcol);
+                ps_old[q] = row_w ? my_s[q] : -1;
+                po_old[q] = col_w ? my_o[q] : -1;
             }
         }
 #endif
@@ -856,6 +881,320 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
     }
 }
 
+// =====================================================================================================
+// The same contraction with the two halves of a step on DIFFERENT wavefronts (round 3; one contraction chunk per pair, i.e.
+// config-2's widths).  In the kernel above a step is: build W (a dependent chain of LDS reads and scattered writes) | barrier |
+// fragment reads + MFMAs | barrier | next feature tile to LDS -- and nothing of one phase overlaps the next; with two blocks per CU
+// the matrix cores are busy a quarter of the time (164 + 178 us per call at config-2 against ~45 us of MFMA work each).
+// Here a block is 12 waves, one block per CU: waves 4-11 PRODUCE step t + 1 into the other LDS buffer -- two waves build W, four
+// stage the feature tile, two stream the pairs' small arrays, each with the code of the kernel above -- while waves 0-3 CONSUME
+// step t (fragment reads + MFMAs, the same [MT x 8] tiling), ONE barrier per step.  Both W and the feature tile are double-buffered; so are the staged small arrays (the producers would
+// otherwise need a barrier of their own between the last read of a chunk and the store of the next one).  No split of the outer
+// range by default: a block sweeps all partners of its caption / image, the result is written once -- no atomics, no zero fill.
+// =====================================================================================================
+constexpr int kGwThreads = 768;   // twelve waves: 4 consumers, 2 builders, 4 tile stagers, 2 array stagers
+template <int SIDE, int NKC, int MT, int RW, int SEGL, int PP, int UW>
+__global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
+    const uint16_t* __restrict__ featT, const float* __restrict__ gV, const uint16_t* __restrict__ argV,
+    const float* __restrict__ gQ, const uint16_t* __restrict__ argQ, const float* __restrict__ coef, int B, int Q, int V,
+    float* __restrict__ out) {
+    // UW = unit width: the columns a pair occupies in the step's contraction axis (Kp of featT, or less when the positions
+    // past K are not staged -- config-2's 36 regions: 40 instead of 64, three pairs per 128 columns instead of two)
+    constexpr int Kp = NKC * 32, KT = (PP * UW + 31) / 32 * 32, PITCH = KT * 2 + 32, NK = KT / 32;
+    constexpr int MR = MT * 16, CW = 4 / RW, RT = (MT + RW - 1) / RW, CT = 8 / CW;
+    static_assert(UW % 8 == 0 && UW <= Kp && SEGL * 8 <= UW, "a unit is whole 16-byte segments");
+    static_assert(MR <= 128 && Kp <= 128, "row and column owners are the 128 threads of the two builder waves");
+    const int A = B, M = SIDE == 0 ? Q : V, K = SIDE == 0 ? V : Q;
+    const int o_per = (B + (int)gridDim.y - 1) / (int)gridDim.y, o_begin = blockIdx.y * o_per, O = min(B, o_begin + o_per);
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TILE_B = kGdD * PITCH, W_B = MR * PITCH;
+    char* const tile0 = smem_raw;                       // [2][d][KT] bf16
+    char* const wt0 = smem_raw + 2 * TILE_B;            // [2][MR][KT] bf16
+    constexpr int EW = MR + Kp;
+    constexpr int CHP = PP == 3 ? 6 : kGdChunk;         // pairs per chunk of the small arrays: a multiple of PP
+    constexpr int SPC = CHP / PP;                       // steps per chunk
+    static_assert(CHP % PP == 0 && SPC >= 2, "a chunk in flight needs more than one step to land");
+    int16_t* const sarg0 = reinterpret_cast<int16_t*>(wt0 + 2 * W_B);          // [2][CHP][EW]
+    float* const sval0 = reinterpret_cast<float*>(sarg0 + 2 * CHP * EW);       // [2][CHP][EW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fix = blockIdx.x;
+    if (o_begin >= O) return;
+    const int T = (O - o_begin + PP - 1) / PP;          // steps
+    for (int i = tid; i < (2 * TILE_B + 2 * W_B) / 16; i += kGwThreads) reinterpret_cast<uint4*>(smem_raw)[i] = make_uint4(0, 0, 0, 0);
+    // Every role runs the same barrier sequence: three in the prologue (zero fill | chunk 0 of the small arrays | step 0 built and
+    // staged), then one per step.  A role's vector-memory loads are its own wave's: an s_waitcnt vmcnt(0) (all hipcc can place
+    // across a loop's back edge) in the wave that streams the small arrays from HBM does not hold up the wave that stages tiles.
+
+    if (wave >= 10) {
+        // ---- waves 10, 11: the pairs' small arrays, HBM -> registers one chunk ahead -> LDS (the half the builders are not reading) ----
+        const int atid = tid - 640;
+        constexpr int nthr = 128, NE = (CHP * EW + nthr - 1) / nthr;
+        const float c_self = SIDE == 0 ? coef[0] : coef[1], c_other = SIDE == 0 ? coef[1] : coef[0];
+        const float* g_self = SIDE == 0 ? gV : gQ;
+        const uint16_t* a_self = SIDE == 0 ? argV : argQ;
+        const float* g_other = SIDE == 0 ? gQ : gV;
+        const uint16_t* a_other = SIDE == 0 ? argQ : argV;
+        auto pair = [&](int oo) -> size_t { return SIDE == 0 ? (size_t)fix * A + oo : (size_t)oo * A + fix; };
+        int carg[NE];
+        float cval[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) { carg[j] = 0; cval[j] = 0.f; }
+        unsigned cpar = 0;
+        auto chunk_load = [=](int oc, int* carg, float* cval, unsigned& cpar) __attribute__((always_inline)) {
+            cpar = 0;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int id = min(atid + j * nthr, CHP * EW - 1), p = id / EW, e = id - p * EW;
+                const int oo = min(oc + p, O - 1);
+                const size_t pr = pair(oo);
+                const bool other = e >= MR;
+                const size_t at = other ? pr * K + min(e - MR, K - 1) : pr * M + min(e, M - 1);
+                const uint32_t* ap = reinterpret_cast<const uint32_t*>(other ? a_other : a_self) + (at >> 1);
+                const float* gp = (other ? g_other : g_self) + at;
+                carg[j] = (int)*ap;
+                cval[j] = *gp;
+                cpar |= ((unsigned)at & 1u) << j;
+            }
+        };
+        auto chunk_store = [=](int half, const int* carg, const float* cval, unsigned cpar) __attribute__((always_inline)) {
+            int16_t* sarg = sarg0 + half * CHP * EW;
+            float* sval = sval0 + half * CHP * EW;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int id = atid + j * nthr;
+                if (id < CHP * EW) {
+                    const int p = id / EW, e = id - p * EW;
+                    const bool other = e >= MR;
+                    const int av = (carg[j] >> (((cpar >> j) & 1u) << 4)) & 0xffff;
+                    const bool ok = other ? (e - MR < K && av < M) : (e < M && av < K);
+                    sarg[id] = (int16_t)(ok ? av : -1);
+                    const unsigned pick = other ? ~0u : 0u;
+                    sval[id] = __uint_as_float((__float_as_uint(c_other) & pick) | (__float_as_uint(c_self) & ~pick)) * cval[j];
+                }
+            }
+        };
+        chunk_load(o_begin, carg, cval, cpar);
+        __syncthreads();                                 // (the zero fill)
+        chunk_store(0, carg, cval, cpar);
+        if (SPC < T) chunk_load(o_begin + CHP, carg, cval, cpar);
+        __syncthreads();                                 // (chunk 0 visible to the builders)
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const int u = t + 1;
+            // the chunk that starts with the NEXT step: its half was last read a whole chunk ago (the current chunk sits in the
+            // other half), and the barrier below publishes it
+#ifndef VLG_GW_NOARGS   // tools/ ablations (results are wrong with any of these)
+            if (u < T && (u + 1) % SPC == 0 && (u + 1) < T) {
+                const int c = (u + 1) / SPC;
+                chunk_store(c & 1, carg, cval, cpar);
+                if ((c + 1) * SPC < T) chunk_load(o_begin + (c + 1) * CHP, carg, cval, cpar);
+            }
+#endif
+            __syncthreads();
+        }
+        return;
+    }
+
+    if (wave >= 6) {
+        // ---- waves 6-9: the other side's feature tiles, L2 -> registers one step ahead -> LDS (the buffer the consumers are not reading) ----
+        const int ttid = tid - 384;
+        constexpr int nthr = 256, NV = (kGdD * SEGL + nthr - 1) / nthr, segs = SEGL, nvec = kGdD * SEGL;
+        uint4 xs[PP][NV];
+#pragma unroll
+        for (int q = 0; q < PP; ++q)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) xs[q][j] = make_uint4(0, 0, 0, 0);
+        auto stage_load = [&](int o, uint4 (*xs)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                const int oo = min(o + q, O - 1);
+                const uint4* src = reinterpret_cast<const uint4*>(featT + (size_t)oo * kGdD * Kp);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int i = min(ttid + j * nthr, nvec - 1);
+                    const int row = i / segs, seg = i - row * segs;
+                    xs[q][j] = src[row * (Kp >> 3) + seg];
+                }
+            }
+        };
+        auto stage_tile = [&](char* tile, const uint4 (*xs)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < PP; ++q)
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int i = ttid + j * nthr;
+                    if (i < nvec) {
+                        const int row = i / segs, seg = i - row * segs;
+                        *reinterpret_cast<uint4*>(tile + row * PITCH + q * UW * 2 + seg * 16) = xs[q][j];
+                    }
+                }
+        };
+        stage_load(o_begin, xs);
+        __syncthreads();                                 // (the zero fill)
+        __syncthreads();
+        stage_tile(tile0, xs);
+        stage_load(o_begin + PP, xs);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const int u = t + 1;
+#ifndef VLG_GW_NOSTAGE
+            if (u < T) {
+                stage_tile(tile0 + (u & 1) * TILE_B, xs);
+                stage_load(o_begin + (u + 1) * PP, xs);
+            }
+#endif
+            __syncthreads();
+        }
+        return;
+    }
+
+    if (wave >= 4) {
+        // ---- waves 4, 5: W of step t + 1, built in LDS by scatter (the scheme of the kernel above: thread r < M owns row r, thread
+        //      k < K owns column k, the column owner writes the sum where the two meet, every owner clears what it wrote into this
+        //      buffer two steps ago); LDS traffic only ----
+        const int ptid = tid - 256;
+        auto f2bf = [](float f) -> uint16_t { return __builtin_bit_cast(uint16_t, (__bf16)f); };
+        int ps_old[2][PP], po_old[2][PP];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < PP; ++q) ps_old[h][q] = po_old[h][q] = -1;
+        // BRANCH-FREE: every LDS read is unconditional (clamped index, the flags are integer ands) and every write goes either to its
+        // element or to the row's pitch padding -- written as `a && b[i]` / `if (c) *p = v`, hipcc emits one exec-masked block per
+        // read, each with its own s_waitcnt lgkmcnt(0): 36 LDS round trips in a row per step (measured: the builders alone took
+        // 2500 cycles per step, three times the consumers' MFMAs).
+        auto build = [&](int u, char* wt, int* ps_o, int* po_o) __attribute__((always_inline)) {
+            const int o = o_begin + u * PP, cp = (u % SPC) * PP, half = (u / SPC) & 1;
+            const int prow = min(ptid, MR - 1), pcol = min(ptid, Kp - 1);
+            auto welem = [&](int row, int col) { return reinterpret_cast<uint16_t*>(wt + row * PITCH + col * 2); };
+            uint16_t* const dummy = welem(prow, KT);   // this row's padding: never read
+            int a_ps[PP], a_po[PP], s_raw[PP], o_raw[PP];
+            float vrow[PP], vcolb[PP];
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {   // level 1: everything addressed by known indices
+                const int16_t* argS = sarg0 + (half * CHP + cp + q) * EW;
+                const int16_t* argO = argS + MR;
+                const float* valS = sval0 + (half * CHP + cp + q) * EW;
+                const float* valO = valS + MR;
+                a_ps[q] = argO[max(ps_o[q], 0)];
+                a_po[q] = argS[max(po_o[q], 0)];
+                s_raw[q] = argS[prow];
+                o_raw[q] = argO[pcol];
+                vrow[q] = valS[prow];
+                vcolb[q] = valO[pcol];
+            }
+            int my_s[PP], my_o[PP], a_ms[PP], a_mo[PP];
+            float v_mo[PP];
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {   // level 2: addressed by what level 1 returned
+                const int live = o + q < O ? -1 : 0;
+                const int16_t* argS = sarg0 + (half * CHP + cp + q) * EW;
+                const int16_t* argO = argS + MR;
+                const float* valS = sval0 + (half * CHP + cp + q) * EW;
+                my_s[q] = (live & (ptid < MR ? -1 : 0)) ? s_raw[q] : -1;
+                my_o[q] = (live & (ptid < Kp ? -1 : 0)) ? o_raw[q] : -1;
+                a_ms[q] = argO[max(my_s[q], 0)];
+                a_mo[q] = argS[max(my_o[q], 0)];
+                v_mo[q] = valS[max(my_o[q], 0)];
+            }
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                const int live = o + q < O ? 1 : 0;
+                // (an old element is left alone when ANOTHER thread writes this step's value to the same place -- the column owner of
+                //  my old column pointing at my row, or the row owner of my old row pointing at my column -- since its write and my
+                //  clear are unordered; my own clear-then-write is program order, a wave's LDS operations complete in order)
+                const int clr_s = (ps_o[q] >= 0 ? 1 : 0) & (1 ^ (live & (a_ps[q] == ptid ? 1 : 0)));
+                const int clr_o = (po_o[q] >= 0 ? 1 : 0) & (1 ^ (live & (a_po[q] == ptid ? 1 : 0)));
+                const int row_w = (my_s[q] >= 0 ? 1 : 0) & (a_ms[q] != ptid ? 1 : 0);   // else the column owner writes the sum
+                const int col_w = my_o[q] >= 0 ? 1 : 0;
+                const float vcol = vcolb[q] + (a_mo[q] == ptid ? v_mo[q] : 0.f);
+                uint16_t* p0 = clr_s ? welem(prow, q * UW + max(ps_o[q], 0)) : dummy;
+                uint16_t* p1 = clr_o ? welem(max(po_o[q], 0), q * UW + pcol) : dummy;
+                uint16_t* p2 = row_w ? welem(prow, q * UW + max(my_s[q], 0)) : dummy;
+                uint16_t* p3 = col_w ? welem(max(my_o[q], 0), q * UW + pcol) : dummy;
+                *p0 = 0;
+                *p1 = 0;
+                *p2 = f2bf(vrow[q]);
+                *p3 = f2bf(vcol);
+                ps_o[q] = row_w ? my_s[q] : -1;
+                po_o[q] = col_w ? my_o[q] : -1;
+            }
+        };
+        __syncthreads();                                 // (the zero fill)
+        __syncthreads();                                 // (chunk 0 of the small arrays)
+        build(0, wt0, ps_old[0], po_old[0]);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const int u = t + 1;
+#ifndef VLG_GW_NOBUILD
+            if (u < T) {
+                if (u & 1) build(u, wt0 + W_B, ps_old[1], po_old[1]);
+                else build(u, wt0, ps_old[0], po_old[0]);
+            }
+#endif
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- waves 0-3: fragment reads + MFMAs of step t, tiling the [MT x 8] output tiles RW x CW ----
+    const int kg = lane >> 4, ccol = lane & 15;
+    const int rt0 = (wave / CW) * RT, ct0 = (wave % CW) * CT;
+    gd_f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = gd_f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const char* wt = wt0 + (t & 1) * W_B;
+        const char* tile = tile0 + (t & 1) * TILE_B;
+        gd_bf16x8 af[2][RT], bf[2][CT];   // two fragment sets: chunk kc+1 is read while chunk kc's MFMAs run
+        auto frags = [&](int kc, gd_bf16x8* a, gd_bf16x8* b) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                a[r] = *reinterpret_cast<const gd_bf16x8*>(wt + (min(rt0 + r, MT - 1) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                b[c] = *reinterpret_cast<const gd_bf16x8*>(tile + ((ct0 + c) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
+        };
+#ifndef VLG_GW_NOMFMA
+        frags(0, af[0], bf[0]);
+#pragma unroll
+        for (int kc = 0; kc < NK; ++kc) {
+            if (kc + 1 < NK) frags(kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kc & 1][r], bf[kc & 1][c], acc[r][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        if (rt0 + r >= MT) break;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int rr = (rt0 + r) * 16 + kg * 4 + n;
+            if (rr < M) {
+                float* dst = out + ((size_t)fix * M + rr) * kGdD + ct0 * 16 + ccol;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (gridDim.y > 1) atomicAdd(dst + c * 16, acc[r][c][n]);
+                    else dst[c * 16] = acc[r][c][n];
+                }
+            }
+        }
+    }
+}
+
 // splits of the caption side's step units over blockIdx.y for the wide layouts: enough blocks to cover the chip
 int ground_dense_split_txt(int B, int V) {
     const int n_kc = (V + 127) / 128, n = n_kc * B;
@@ -890,6 +1229,48 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
     auto lds = [](int Kp, int mt, int pp) {
         return (size_t)(kGdD + mt * 16) * (pp * Kp * 2 + 32) + (size_t)kGdChunk * (mt * 16 + Kp) * (2 + 4);
     };
+    // config-2's widths: producer / consumer wavefronts, one block per caption / image, written once (ground_bwd_ws_kernel)
+    const bool ws_ok = !wide && !getenv("VLG_GD_OLD");
+    auto lds_ws = [](int Kp, int mt, int pp, int uw) {
+        const int kt = (pp * uw + 31) / 32 * 32, chp = pp == 3 ? 6 : kGdChunk;
+        return 2 * (size_t)(kGdD + mt * 16) * (kt * 2 + 32) + 2 * (size_t)chp * (mt * 16 + Kp) * (2 + 4);
+    };
+#define VLG_WS(SIDEV, NKCV, MTV, RWV, SEGV, PPV, UWV, FT, OUT)                                                          \
+    do {                                                                                                               \
+        auto kern = ground_bwd_ws_kernel<SIDEV, NKCV, MTV, RWV, SEGV, PPV, UWV>;                                        \
+        const size_t nb = lds_ws(NKCV * 32, MTV, PPV, UWV);                                                            \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb);    \
+        if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));                \
+        hipLaunchKernelGGL(kern, dim3(B, 1), dim3(kGwThreads), nb, s, FT, gV, argV, gQ, argQ, coef, B, Q, V, OUT);             \
+    } while (0)
+#define VLG_WS0(MTV, RWV)                                                                                              \
+    do { if (V <= 40) VLG_WS(0, 2, MTV, RWV, 5, 3, 40, visT, g_txt); else VLG_WS(0, 2, MTV, RWV, 8, 2, 64, visT, g_txt); } while (0)
+    if (g_txt && ws_ok) {
+        hipLaunchKernelGGL(ground_transpose_kernel, dim3(B, KtV / 32), dim3(256), 0, s, (const uint16_t*)vis, V, KtV, visT);
+        switch ((Q + 15) / 16) {
+            case 1: VLG_WS0(1, 1); break;
+            case 2: VLG_WS0(2, 2); break;
+            case 3: VLG_WS0(3, 1); break;
+            case 4: VLG_WS0(4, 2); break;
+            case 5: VLG_WS0(5, 2); break;
+            default: VLG_WS0(6, 2); break;
+        }
+        if (int rc = check_launch("ground_bwd_ws_kernel")) return rc;
+        g_txt = nullptr;
+    }
+    if (g_vis && ws_ok && V <= 48) {   // (four region tiles: the double buffers do not fit the LDS)
+        hipLaunchKernelGGL(ground_transpose_kernel, dim3(B, KpQ / 32), dim3(256), 0, s, (const uint16_t*)txt, Q, KpQ, txtT);
+        switch ((V + 15) / 16) {
+            case 1: VLG_WS(1, 3, 1, 1, 12, 2, 96, txtT, g_vis); break;
+            case 2: VLG_WS(1, 3, 2, 2, 12, 2, 96, txtT, g_vis); break;
+            default: VLG_WS(1, 3, 3, 1, 12, 2, 96, txtT, g_vis); break;
+        }
+        if (int rc = check_launch("ground_bwd_ws_kernel")) return rc;
+        g_vis = nullptr;
+    }
+#undef VLG_WS0
+#undef VLG_WS
+    if (!g_txt && !g_vis) return 0;
     int split = B >= 32 ? 2 : 1;   // two blocks per caption / image (two-addend atomics stay order-free)
     if (const char* e = getenv("VLG_GD_SPLIT")) split = atoi(e);
     // wide caption side: B blocks x split must cover the chip, and there are B * n_kc step units to share: deeper splits write
