@@ -893,7 +893,10 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
 // range by default: a block sweeps all partners of its caption / image, the result is written once -- no atomics, no zero fill.
 // =====================================================================================================
 constexpr int kGwThreads = 768;   // twelve waves: 4 consumers, 2 builders, 4 tile stagers, 2 array stagers
-template <int SIDE, int NKC, int MT, int RW, int SEGL, int PP, int UW>
+// KS = 2: the consumers split the contraction axis between two wave pairs (each wave twice the column tiles, half the chunks:
+// fewer fragment reads per MFMA -- the image side's 3 x 2 tiles per wave read 5 fragments per 6 MFMAs and the LDS, not the matrix
+// cores, set its step); the upper pair hands its accumulators over through the LDS once, at the end.
+template <int SIDE, int NKC, int MT, int RW, int SEGL, int PP, int UW, int KS>
 __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
     const uint16_t* __restrict__ featT, const float* __restrict__ gV, const uint16_t* __restrict__ argV,
     const float* __restrict__ gQ, const uint16_t* __restrict__ argQ, const float* __restrict__ coef, int B, int Q, int V,
@@ -901,7 +904,8 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
     // UW = unit width: the columns a pair occupies in the step's contraction axis (Kp of featT, or less when the positions
     // past K are not staged -- config-2's 36 regions: 40 instead of 64, three pairs per 128 columns instead of two)
     constexpr int Kp = NKC * 32, KT = (PP * UW + 31) / 32 * 32, PITCH = KT * 2 + 32, NK = KT / 32;
-    constexpr int MR = MT * 16, CW = 4 / RW, RT = (MT + RW - 1) / RW, CT = 8 / CW;
+    constexpr int MR = MT * 16, CW = 4 / RW / KS, RT = (MT + RW - 1) / RW, CT = 8 / CW;
+    static_assert(KS == 1 || (KS == 2 && NK % 2 == 0 && 4 % (RW * KS) == 0), "two halves of the chunks");
     static_assert(UW % 8 == 0 && UW <= Kp && SEGL * 8 <= UW, "a unit is whole 16-byte segments");
     static_assert(MR <= 128 && Kp <= 128, "row and column owners are the 128 threads of the two builder waves");
     const int A = B, M = SIDE == 0 ? Q : V, K = SIDE == 0 ? V : Q;
@@ -1140,7 +1144,9 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
 
     // ---- waves 0-3: fragment reads + MFMAs of step t, tiling the [MT x 8] output tiles RW x CW ----
     const int kg = lane >> 4, ccol = lane & 15;
-    const int rt0 = (wave / CW) * RT, ct0 = (wave % CW) * CT;
+    const int ks = wave / (RW * CW), w2 = wave % (RW * CW);
+    const int rt0 = (w2 / CW) * RT, ct0 = (w2 % CW) * CT;
+    constexpr int NKs = NK / KS;
     gd_f32x4 acc[RT][CT];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -1162,10 +1168,10 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
                 b[c] = *reinterpret_cast<const gd_bf16x8*>(tile + ((ct0 + c) * 16 + ccol) * PITCH + (kc * 4 + kg) * 16);
         };
 #ifndef VLG_GW_NOMFMA
-        frags(0, af[0], bf[0]);
+        frags(ks * NKs, af[0], bf[0]);
 #pragma unroll
-        for (int kc = 0; kc < NK; ++kc) {
-            if (kc + 1 < NK) frags(kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1]);
+        for (int kc = 0; kc < NKs; ++kc) {
+            if (kc + 1 < NKs) frags(ks * NKs + kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < RT; ++r)
@@ -1176,6 +1182,25 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
         }
 #endif
         __syncthreads();
+    }
+    if (KS == 2) {   // (the producers have left: a barrier counts the waves that are still running)
+        float* xch = reinterpret_cast<float*>(smem_raw) + (size_t)w2 * (RT * CT * 4 * 64);
+        if (ks == 1) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) xch[((r * CT + c) * 4 + n) * 64 + lane] = acc[r][c][n];
+        }
+        __syncthreads();
+        if (ks == 1) return;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[r][c][n] += xch[((r * CT + c) * 4 + n) * 64 + lane];
     }
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
@@ -1237,7 +1262,7 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
     };
 #define VLG_WS(SIDEV, NKCV, MTV, RWV, SEGV, PPV, UWV, FT, OUT)                                                          \
     do {                                                                                                               \
-        auto kern = ground_bwd_ws_kernel<SIDEV, NKCV, MTV, RWV, SEGV, PPV, UWV>;                                        \
+        auto kern = ground_bwd_ws_kernel<SIDEV, NKCV, MTV, RWV, SEGV, PPV, UWV, (SIDEV == 1 && RWV == 1 ? 2 : 1)>;        \
         const size_t nb = lds_ws(NKCV * 32, MTV, PPV, UWV);                                                            \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb);    \
         if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));                \
