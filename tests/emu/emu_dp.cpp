@@ -53,6 +53,7 @@ std::vector<int> make_order(int nt, int order) {
 // (lane t combines with lane t^1, then t^2, ...) so that host and device results agree bit for bit.
 struct HostX {
     static constexpr bool kSkipDeadWaves = false;   // here an all-reduce is a barrier: every lane takes part
+    static constexpr bool kChartsInLds = false;     // heap arrays: out-of-range split points keep their clamped loads
     Token* tok;
     int nt, tid, rho;
     long phase = 0;

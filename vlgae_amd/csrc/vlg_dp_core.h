@@ -218,7 +218,11 @@ VLG_HD Sched make_sched(int Ne, int lanes, int budget) {
 // TU == 0: generic loops for long spans.  D = i (P + 1) is the chart index of the diagonal cell of row i.
 //   DIR 0 reductions: 0 SL, 1 CL.x, 2 CL.y (r >= 1)        DIR 1: 0 SR, 1 CR.x, 2 CR.y (r <= w-2)
 // ------------------------------------------------------------------------------------------------
-template <int SR, bool BWD, int DIR, int TU, typename X>
+// NOCLAMP (device, every chart in LDS): the loads of a lane's out-of-range split points are NOT clamped to the last valid one -- an
+// LDS read cannot fault (past the allocation it returns 0), its value is masked to the lowest float like the clamped duplicate was,
+// and without the clamp the addresses of a lane's TU terms are one base plus compile-time multiples of G: immediate offsets instead
+// of a min, a multiply and a shift-add per term.  (The host emulator's charts are heap arrays: it keeps the clamp.)
+template <int SR, bool BWD, int DIR, int TU, typename X, bool NOCLAMP = false>
 VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x) {
     VLG_STAMP_AT(x, 6);   // since the end of the previous span: phase preamble + barrier
     const int P = c.P, DW = D + VLG_MUL24(w, P);   // DW: chart index of (row j, column i)
@@ -239,7 +243,7 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
         float t[TU > 0 ? TU : 1][3];
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            const int r = rr + u * G, rc = r < w ? r : w - 1;
+            const int r = rr + u * G, rc = NOCLAMP ? r : (r < w ? r : w - 1);
 #ifdef VLG_ABL_NOLOADS
             const float a = (float)rc, b = aX.x, uu = cX;
             const float2 vv = aX;
@@ -257,9 +261,16 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
         for (int k = 0; k < 3; ++k) {
             m[k] = t[0][k];
             am[k] = rr;
+            if (SR == VLG_SR_LOG) {
+                // (no position wanted: a plain v_max.  The compare / select form below stays compare + select in the Log
+                //  instantiation too -- hipcc may not fold it without -fno-signed-zeros -- and each pair waits two states on VCC)
 #pragma unroll
-            for (int u = 1; u < TU; ++u)
-                if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + u * G; }   // strict: first index wins ties
+                for (int u = 1; u < TU; ++u) m[k] = fmaxf(m[k], t[u][k]);
+            } else {
+#pragma unroll
+                for (int u = 1; u < TU; ++u)
+                    if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + u * G; }   // strict: first index wins ties
+            }
         }
         VLG_STAMP_AT(x, 1);
 #ifndef VLG_ABL_NOMAXBFLY
@@ -272,9 +283,11 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
             for (int k = 0; k < 3; ++k) s[k] = t[0][k] - m[k];
 #else
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < 3; ++k) {
+                s[k] = VLG_EXP(t[0][k] - m[k]);                                  // (= 0 + the first term, bit for bit)
 #pragma unroll
-                for (int u = 0; u < TU; ++u) s[k] += VLG_EXP(t[u][k] - m[k]);   // masked terms: 2^(-3e38) = 0
+                for (int u = 1; u < TU; ++u) s[k] += VLG_EXP(t[u][k] - m[k]);   // masked terms: 2^(-3e38) = 0
+            }
 #endif
             VLG_STAMP_AT(x, 3);
 #ifndef VLG_ABL_NOSUMBFLY
@@ -393,10 +406,11 @@ VLG_HD void dmv_fw_width(const DmvCtx& c, int w, int lgr, int t, int nd, X& x) {
         const int i = live ? base + slot : 0;   // dead lanes shadow span 0 and never store
         if (X::kSkipDeadWaves && (base + ((t & ~63) >> lg)) >= spans) continue;   // whole wavefront past the last span
         const int D = VLG_MUL24(i, c.P + 1);
-        if (T == 1) dmv_fw_span<SR, BWD, DIR, 1>(c, w, G, D, live, rr, x);
-        else if (T == 2) dmv_fw_span<SR, BWD, DIR, 2>(c, w, G, D, live, rr, x);
-        else if (T == 3) dmv_fw_span<SR, BWD, DIR, 3>(c, w, G, D, live, rr, x);
-        else if (T == 4) dmv_fw_span<SR, BWD, DIR, 4>(c, w, G, D, live, rr, x);
+        constexpr bool NC = !LONGSPAN && X::kChartsInLds;
+        if (T == 1) dmv_fw_span<SR, BWD, DIR, 1, X, NC>(c, w, G, D, live, rr, x);
+        else if (T == 2) dmv_fw_span<SR, BWD, DIR, 2, X, NC>(c, w, G, D, live, rr, x);
+        else if (T == 3) dmv_fw_span<SR, BWD, DIR, 3, X, NC>(c, w, G, D, live, rr, x);
+        else if (T == 4) dmv_fw_span<SR, BWD, DIR, 4, X, NC>(c, w, G, D, live, rr, x);
         else dmv_fw_span<SR, BWD, DIR, LONGSPAN ? -1 : 0>(c, w, G, D, live, rr, x);
     }
 }
@@ -438,7 +452,7 @@ VLG_HD void dmv_fw_all(const DmvCtx& c, int tid, int nt, X& x) {
 // All loads -- including the read half of every read-modify-write -- are issued before the first store, so
 // nothing waits on an earlier store of the same phase.
 // ------------------------------------------------------------------------------------------------
-template <int SR, int DIR, int TU, typename X, bool CHUNKED = false>
+template <int SR, int DIR, int TU, typename X, bool CHUNKED = false, bool NOCLAMP = false>   // NOCLAMP: see dmv_fw_span
 VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x, int nchunk = 1) {
     const int P = c.P, DW = D + VLG_MUL24(w, P);
     const float* Cf = reinterpret_cast<const float*>(c.C);
@@ -486,7 +500,7 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
             float2 vv[TU > 0 ? TU : 1], o_gi[TU > 0 ? TU : 1];
 #pragma unroll
             for (int u = 0; u < TU; ++u) {
-                const int r = r0 + u * G, rc = r < w ? r : w - 1, rP = VLG_MUL24(rc, P);
+                const int r = r0 + u * G, rc = NOCLAMP ? r : (r < w ? r : w - 1), rP = VLG_MUL24(rc, P);
                 uu[u] = Cf[2 * (eU + rP) + 1];
                 vv[u] = c.I[eV + rc];
                 xa[u] = Cf[eA + 2 * rc];
@@ -551,9 +565,10 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
     if (live && rr == 0) c.gI[kO] = gi;
 }
 
-template <int SR, int DIR, int LG, typename X>
+template <int SR, int DIR, int LG, bool LONGSPAN, typename X>
 VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x) {
     constexpr int G = 1 << LG;
+    constexpr bool NC = !LONGSPAN && X::kChartsInLds;
     const int per = nd >> LG, rr = t & (G - 1), slot = t >> LG, spans = c.Ne - w;
     const int T = (w + G - 1) >> LG;
     for (int base = 0; base < spans; base += per) {
@@ -561,37 +576,37 @@ VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x) {
         const int i = live ? base + slot : 0;
         if (X::kSkipDeadWaves && (base + ((t & ~63) >> LG)) >= spans) continue;
         const int D = VLG_MUL24(i, c.P + 1);
-        if (T == 1) dmv_bw_span<SR, DIR, 1>(c, w, G, D, live, rr, x);
-        else if (T == 2) dmv_bw_span<SR, DIR, 2>(c, w, G, D, live, rr, x);
-        else if (T == 3) dmv_bw_span<SR, DIR, 3>(c, w, G, D, live, rr, x);
-        else if (T == 4) dmv_bw_span<SR, DIR, 4>(c, w, G, D, live, rr, x);
+        if (T == 1) dmv_bw_span<SR, DIR, 1, X, false, NC>(c, w, G, D, live, rr, x);
+        else if (T == 2) dmv_bw_span<SR, DIR, 2, X, false, NC>(c, w, G, D, live, rr, x);
+        else if (T == 3) dmv_bw_span<SR, DIR, 3, X, false, NC>(c, w, G, D, live, rr, x);
+        else if (T == 4) dmv_bw_span<SR, DIR, 4, X, false, NC>(c, w, G, D, live, rr, x);
         else dmv_bw_span<SR, DIR, 4, X, true>(c, w, G, D, live, rr, x, (T + 3) >> 2);   // chunks of four split points per lane
     }
 }
 
 // widths w1-1 ... w0 of one segment, descending, one barrier per width
-template <int SR, int LG, typename X>
+template <int SR, int LG, bool LONGSPAN, typename X>
 VLG_HD void dmv_bw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& x) {
     const int nd = nt >> 1;
     const bool right = x.uniform(tid >= nd);
     const int t = right ? tid - nd : tid;
     for (int w = w1 - 1; w >= w0; --w) {
-        if (right) dmv_bw_width<SR, 1, LG>(c, w, t, nd, x);
-        else dmv_bw_width<SR, 0, LG>(c, w, t, nd, x);
+        if (right) dmv_bw_width<SR, 1, LG, LONGSPAN>(c, w, t, nd, x);
+        else dmv_bw_width<SR, 0, LG, LONGSPAN>(c, w, t, nd, x);
         x.sync();
     }
 }
 
-template <int SR, typename X>
+template <int SR, bool LONGSPAN = true, typename X>
 VLG_HD void dmv_bw_all(const DmvCtx& c, int tid, int nt, X& x) {
     const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_BW);
-    dmv_bw_segment<SR, 6>(c, sc.first[6], sc.first[7], tid, nt, x);
-    dmv_bw_segment<SR, 5>(c, sc.first[5], sc.first[6], tid, nt, x);
-    dmv_bw_segment<SR, 4>(c, sc.first[4], sc.first[5], tid, nt, x);
-    dmv_bw_segment<SR, 3>(c, sc.first[3], sc.first[4], tid, nt, x);
-    dmv_bw_segment<SR, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
-    dmv_bw_segment<SR, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
-    dmv_bw_segment<SR, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
+    dmv_bw_segment<SR, 6, LONGSPAN>(c, sc.first[6], sc.first[7], tid, nt, x);
+    dmv_bw_segment<SR, 5, LONGSPAN>(c, sc.first[5], sc.first[6], tid, nt, x);
+    dmv_bw_segment<SR, 4, LONGSPAN>(c, sc.first[4], sc.first[5], tid, nt, x);
+    dmv_bw_segment<SR, 3, LONGSPAN>(c, sc.first[3], sc.first[4], tid, nt, x);
+    dmv_bw_segment<SR, 2, LONGSPAN>(c, sc.first[2], sc.first[3], tid, nt, x);
+    dmv_bw_segment<SR, 1, LONGSPAN>(c, sc.first[1], sc.first[2], tid, nt, x);
+    dmv_bw_segment<SR, 0, LONGSPAN>(c, sc.first[0], sc.first[1], tid, nt, x);
 }
 
 // ================================================================================================
@@ -638,9 +653,14 @@ VLG_HD void dep_fw_span(const DepCtx& c, int w, int G, int D, bool live, int rr,
         for (int k = 0; k < 2; ++k) {
             m[k] = t[0][k];
             am[k] = rr;
+            if (SR == VLG_SR_LOG) {
 #pragma unroll
-            for (int u = 1; u < TU; ++u)
-                if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + u * G; }
+                for (int u = 1; u < TU; ++u) m[k] = fmaxf(m[k], t[u][k]);
+            } else {
+#pragma unroll
+                for (int u = 1; u < TU; ++u)
+                    if (t[u][k] > m[k]) { m[k] = t[u][k]; am[k] = rr + u * G; }
+            }
         }
         if (SR == VLG_SR_MAX) x.template allreduce_argmax<2>(m, am, G);
         else x.template allreduce_max<2>(m, G);
@@ -1059,12 +1079,12 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
 #if defined(VLG_STAMP) && defined(__HIPCC__)
     {
         const unsigned long long a = __builtin_amdgcn_s_memtime();
-        dmv_bw_all<SR>(cb, tid, nt, x);
+        dmv_bw_all<SR, LONGSPAN>(cb, tid, nt, x);
         st_bbody += __builtin_amdgcn_s_memtime() - a;
     }
     st_end = __builtin_amdgcn_s_memtime();
 #else
-    dmv_bw_all<SR>(cb, tid, nt, x);
+    dmv_bw_all<SR, LONGSPAN>(cb, tid, nt, x);
 #endif
     }
     // expected counts out (coalesced; padded positions get exact zeros like the reference).  Decode mode

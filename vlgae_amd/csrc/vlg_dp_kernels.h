@@ -97,8 +97,47 @@ __device__ __forceinline__ void butterfly_step(T* v) {
     }
 }
 
+// The DPP steps of one butterfly (lane distances 1, 2, 4, 8) as ONE asm block, for n >= 3 values: between a value's step and its next
+// step lie the n - 1 >= 2 DPP instructions of the other values, which is the two wait states "VALU write -> DPP read" asks for -- so
+// only the block's leading s_nop is needed (one block per step paid s_nop 1 per step, plus the s_nop 0 hipcc puts behind every asm).
+#define VLG_DPP_FUSED(OP, NSTEPS, v, n)                                                                                              \
+    do {                                                                                                                             \
+        if constexpr ((n) == 3) {                                                                                                    \
+            if constexpr ((NSTEPS) == 2) asm("s_nop 1" VLG_DPP3(OP, VLG_DPP_QP1) VLG_DPP3(OP, VLG_DPP_QP2) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); \
+            else if constexpr ((NSTEPS) == 3) asm("s_nop 1" VLG_DPP3(OP, VLG_DPP_QP1) VLG_DPP3(OP, VLG_DPP_QP2) VLG_DPP3(OP, VLG_DPP_HM) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); \
+            else asm("s_nop 1" VLG_DPP3(OP, VLG_DPP_QP1) VLG_DPP3(OP, VLG_DPP_QP2) VLG_DPP3(OP, VLG_DPP_HM) VLG_DPP3(OP, VLG_DPP_RM) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); \
+        } else if constexpr ((n) == 4) {                                                                                             \
+            if constexpr ((NSTEPS) == 2) asm("s_nop 1" VLG_DPP4(OP, VLG_DPP_QP1) VLG_DPP4(OP, VLG_DPP_QP2) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); \
+            else if constexpr ((NSTEPS) == 3) asm("s_nop 1" VLG_DPP4(OP, VLG_DPP_QP1) VLG_DPP4(OP, VLG_DPP_QP2) VLG_DPP4(OP, VLG_DPP_HM) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); \
+            else asm("s_nop 1" VLG_DPP4(OP, VLG_DPP_QP1) VLG_DPP4(OP, VLG_DPP_QP2) VLG_DPP4(OP, VLG_DPP_HM) VLG_DPP4(OP, VLG_DPP_RM) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); \
+        } else {                                                                                                                     \
+            if constexpr ((NSTEPS) == 2) asm("s_nop 1" VLG_DPP6(OP, VLG_DPP_QP1) VLG_DPP6(OP, VLG_DPP_QP2) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])); \
+            else if constexpr ((NSTEPS) == 3) asm("s_nop 1" VLG_DPP6(OP, VLG_DPP_QP1) VLG_DPP6(OP, VLG_DPP_QP2) VLG_DPP6(OP, VLG_DPP_HM) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])); \
+            else asm("s_nop 1" VLG_DPP6(OP, VLG_DPP_QP1) VLG_DPP6(OP, VLG_DPP_QP2) VLG_DPP6(OP, VLG_DPP_HM) VLG_DPP6(OP, VLG_DPP_RM) : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])); \
+        }                                                                                                                            \
+    } while (0)
+
+template <int OPK, int NSTEPS, int n, typename T>
+__device__ __forceinline__ void butterfly_dpp_fused(T* v) {
+    if constexpr (OPK == kOpMax) VLG_DPP_FUSED("v_max_f32_dpp", NSTEPS, v, n);
+    else if constexpr (OPK == kOpAdd) VLG_DPP_FUSED("v_add_f32_dpp", NSTEPS, v, n);
+    else VLG_DPP_FUSED("v_min_i32_dpp", NSTEPS, v, n);
+}
+
 template <int OPK, int n, typename T>
 __device__ __forceinline__ void butterfly(T* v, int G) {   // G is uniform over the workgroup: no divergence
+#ifndef VLG_NO_FUSED_BUTTERFLY
+    if constexpr (n == 3 || n == 4 || n == 6) {
+        if (G >= 4) {   // (G is a compile-time constant wherever a segment function inlines this)
+            if (G == 4) butterfly_dpp_fused<OPK, 2, n>(v);
+            else if (G == 8) butterfly_dpp_fused<OPK, 3, n>(v);
+            else butterfly_dpp_fused<OPK, 4, n>(v);
+            if (G > 16) butterfly_step<OPK, 16, n>(v);
+            if (G > 32) butterfly_step<OPK, 32, n>(v);
+            return;
+        }
+    }
+#endif
     if (G > 1) butterfly_step<OPK, 1, n>(v);
     if (G > 2) butterfly_step<OPK, 2, n>(v);
     if (G > 4) butterfly_step<OPK, 4, n>(v);
@@ -109,6 +148,7 @@ __device__ __forceinline__ void butterfly(T* v, int G) {   // G is uniform over 
 
 struct DevX {
     static constexpr bool kSkipDeadWaves = true;   // the all-reduces are wave-local: a wave without spans can skip a phase
+    static constexpr bool kChartsInLds = true;     // (with LONGSPAN = false) chart reads cannot fault: see dmv_fw_span's NOCLAMP
     __device__ __forceinline__ void sync() { __syncthreads(); }
     // The lanes of one lane group never straddle a wavefront and a wavefront executes its instructions in order for all
     // lanes at once, so within a group "all loads above, all stores below" needs no instruction.  (The host phase
