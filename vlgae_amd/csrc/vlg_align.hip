@@ -800,6 +800,9 @@ static __device__ __forceinline__ unsigned am_keep_u(unsigned bits, int pos, uns
 #define VLG_AM_MFMA_DRAIN6(A, B, C, D, E, F) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E), "+v"(F))
 
 // ARGS = false: the maxima alone (the decoder's / gather_logit's fused dispatch) -- no searches, no position stores
+// Several region groups per image (V > 48, the shipped factor layout): the staged tile is one GROUP of 48 regions, the loop runs over
+// (image, group) steps; a region belongs to one group, so the maxima over the queries are per step as before, while the maxima over
+// the regions are carried across an image's groups (strictly larger wins: the earlier group keeps a tie) and stored after its last one.
 template <bool HASQ, bool ARGS>
 __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
     const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
@@ -813,20 +816,25 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything that depends on the caption lives in SGPRs
     const int b = blockIdx.y * kAMWaves + wave, bc = min(b, B - 1);   // a wave past the batch mirrors the last caption, stores nothing
     const int a0 = blockIdx.x * a_per_block, n_img = min(A, a0 + a_per_block) - a0;
+    const int NG = (V + kAMRows - 1) / kAMRows, n_step = n_img * NG;   // region groups per image; (image, group) steps of this block
     const int g = lane >> 4, ccol = lane & 15, crow = g * 4;
     constexpr int NS = 2;
     const bool has2 = tid < kAMSlots - kAMThreads;
-    unsigned sbyte[NS];   // byte offset of this thread's slot within an image (32-bit: scalar base + vector offset addressing)
+    int srow[NS];
+    unsigned sseg[NS];   // this thread's slots of a tile: row within the group, byte offset of the (swizzled) segment within a row
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int sl = tid + k * kAMThreads, r = sl >> 4;
-        sbyte[k] = 2u * (unsigned)(min(r, V - 1) * d + ((sl & 15) ^ (r & 15)) * 8);
+        srow[k] = r;
+        sseg[k] = 2u * (unsigned)(((sl & 15) ^ (r & 15)) * 8);
     }
-    auto stage_load = [&](int a, uint4* x, unsigned& ck) {
+    auto stage_load = [&](int st, uint4* x, unsigned& ck) {   // step st = (image, group)
+        const int a = a0 + st / NG, v0 = (st % NG) * kAMRows;
         const char* img = reinterpret_cast<const char*>(vis + (size_t)a * V * d);
-        x[0] = *reinterpret_cast<const uint4*>(img + sbyte[0]);
-        if (has2) x[1] = *reinterpret_cast<const uint4*>(img + sbyte[1]);
-        if (vmask && tid < kAMRows) ck = vmask[(size_t)a * V + min(tid, V - 1)];
+        // (32-bit offsets from a scalar base; rows past V are copies of the last region: they cannot change a maximum, lose every tie)
+        x[0] = *reinterpret_cast<const uint4*>(img + (2u * (unsigned)(min(v0 + srow[0], V - 1) * d) + sseg[0]));
+        if (has2) x[1] = *reinterpret_cast<const uint4*>(img + (2u * (unsigned)(min(v0 + srow[1], V - 1) * d) + sseg[1]));
+        if (vmask && tid < kAMRows) ck = vmask[(size_t)a * V + min(v0 + tid, V - 1)];
     };
     auto stage_write = [&](int buf, const uint4* x, unsigned ck) {
         tiles[buf][tid] = x[0];
@@ -870,16 +878,18 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
         const bool t_any = rt_masked != 0;   // (wave-uniform)
         uint4 xs[NS] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
         unsigned ck = 1;
-        if (n_img > 0) {
-            stage_load(a0, xs, ck);
+        if (n_step > 0) {
+            stage_load(0, xs, ck);
             stage_write(0, xs, ck);
-            if (n_img > 1) stage_load(a0 + 1, xs, ck);
+            if (n_step > 1) stage_load(1, xs, ck);
         }
         __syncthreads();
-        for (int i = 0; i < n_img; ++i) {
-            const int a = a0 + i, buf = i & 1;
-            if (i + 1 < n_img) stage_write(buf ^ 1, xs, ck);       // tile i+1: loaded during the previous image's MFMAs
-            if (i + 2 < n_img) stage_load(a + 2, xs, ck);          // tile i+2: lands during this image's MFMAs
+        float mrow[RT];       // maxima over the regions (and where), carried across an image's groups
+        unsigned irow[RT];
+        for (int i = 0; i < n_step; ++i) {
+            const int a = a0 + i / NG, grp = i % NG, v0 = grp * kAMRows, buf = i & 1;
+            if (i + 1 < n_step) stage_write(buf ^ 1, xs, ck);       // tile i+1: loaded during the previous step's MFMAs
+            if (i + 2 < n_step) stage_load(i + 2, xs, ck);          // tile i+2: lands during this step's MFMAs
             const uint4* tb = tiles[buf];
             // region-side keep bits: S column 16 ct + ccol (bit ct of ckl), S^T rows 16 ct + 4 g + n (bit 4 ct + n of cklT);
             // the image's 48-bit mask is wave-uniform, the per-lane views are only built for an image that has masked regions
@@ -903,8 +913,6 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
 #pragma unroll
                 for (int kc = 0; kc < KCH; ++kc) bfr[ct][kc] = *reinterpret_cast<const bf16x8*>(tb + ct * 256 + foff[kc]);
             // ---- maxima over the regions: S^T, one query tile at a time ----
-            float mrow[RT];
-            unsigned irow[RT];
             if (out_maxV) {   // (kernel-uniform)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -936,17 +944,24 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                                                                                     st[1][2], st[1][3], st[2][0], st[2][1], st[2][2], st[2][3]);
                     vi = am_xg_min(vi + (unsigned)crow);
                 }
-                if (t_any) {   // wave-uniform: a masked query's maximum
+                if (grp == 0) {   // (wave-uniform)
+                    mrow[rt] = m;
+                    irow[rt] = vi;
+                } else {
                     VLG_AM_KEEP_BRANCH();
-                    m = am_keep(tkeepT, rt, m, neg_inf);
-                    if (ARGS) vi = am_keep_u(tkeepT, rt, vi, 0u);
+                    const bool up = m > mrow[rt];   // strictly: the earlier group keeps a tie
+                    mrow[rt] = up ? m : mrow[rt];
+                    if (ARGS) irow[rt] = up ? vi + (unsigned)v0 : irow[rt];
                 }
-                mrow[rt] = m;
-                irow[rt] = vi;
+                if (t_any && grp == NG - 1) {   // wave-uniform: a masked query's maximum
+                    VLG_AM_KEEP_BRANCH();
+                    mrow[rt] = am_keep(tkeepT, rt, mrow[rt], neg_inf);
+                    if (ARGS) irow[rt] = am_keep_u(tkeepT, rt, irow[rt], 0u);
+                }
             }
             // every lane of a column holds the six results of its column: row group g stores query tiles g and 4 + g, so that
             // a store instruction writes 64 (32) consecutive queries
-            if (b < B) {
+            if (b < B && grp == NG - 1) {
                 const float m_lo = g == 0 ? mrow[0] : g == 1 ? mrow[1] : g == 2 ? mrow[2] : mrow[3];
                 const unsigned i_lo = g == 0 ? irow[0] : g == 1 ? irow[1] : g == 2 ? irow[2] : irow[3];
                 const float m_hi = g == 0 ? mrow[4] : mrow[5];
@@ -1001,7 +1016,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                         m = am_keep(ckl, ct, m, neg_inf);
                         if (ARGS) qi = am_keep_u(ckl, ct, qi, (unsigned)q0);
                     }
-                    const int v = ct * 16 + ccol;
+                    const int v = v0 + ct * 16 + ccol;
                     if (b < B && lane < 16 && v < V) {
                         float* const colV = out_maxQ + ((size_t)bc * A + a) * V;   // wave-uniform bases
                         if (q0 == 0 || m > colV[v]) {   // later passes (Q > 96) only win with a strictly larger value
@@ -1033,52 +1048,64 @@ __global__ __launch_bounds__(64) void align_prior_diag_kernel(
     const float* pen_b = xa.pen + (size_t)b * Q * xa.n_seg;
     for (int q0 = 0; q0 < Q; q0 += RT * 16) {
         for (int i = lane; i < RT * 16; i += 64) kq_s[i] = tmask ? (uint8_t)(tmask[(size_t)b * Q + min(q0 + i, Q - 1)] != 0) : (uint8_t)1;
-        if (lane < 48) kv_s[lane] = vmask ? (uint8_t)(vmask[(size_t)a * V + min(lane, V - 1)] != 0) : (uint8_t)1;
-        __syncthreads();
-#pragma unroll 1
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll 1
-            for (int ct = 0; ct < 3; ++ct) {
-                const bf16x8* ap = reinterpret_cast<const bf16x8*>(txt + ((size_t)b * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
-                const bf16x8* bp = reinterpret_cast<const bf16x8*>(vis + ((size_t)a * V + min(ct * 16 + ccol, V - 1)) * d + g * 8);
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[kc * 4], bp[kc * 4], acc, 0, 0, 0);
-                const int v = min(ct * 16 + ccol, V - 1);
-                const unsigned vk = kv_s[ct * 16 + ccol];
-                const float* pen_v = pen_b + xa.seg_of_v[v];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int q = min(q0 + rt * 16 + crow + n, Q - 1);
-                    const bool keep = (vk & kq_s[rt * 16 + crow + n]) != 0;
-                    S[(rt * 16 + crow + n) * P + ct * 16 + ccol] = (keep ? acc[n] : neg_inf) - pen_v[(size_t)q * xa.n_seg];
-                }
-            }
-        __syncthreads();
         const int nq = min(RT * 16, Q - q0);
-        if (out_maxV)
-            for (int q = lane; q < nq; q += 64) {
-                float m = ninf;
-                int vi = 0;
-                for (int v = 0; v < V; ++v) {
-                    const float x = S[q * P + v];
-                    if (x > m) { m = x; vi = v; }
+        float m_run[2] = {ninf, ninf};   // maxima over the regions of queries lane, lane + 64: carried across the region groups
+        int vi_run[2] = {0, 0};
+        for (int v0 = 0; v0 < V; v0 += 48) {
+            if (lane < 48) kv_s[lane] = vmask ? (uint8_t)(vmask[(size_t)a * V + min(v0 + lane, V - 1)] != 0) : (uint8_t)1;
+            __syncthreads();
+#pragma unroll 1
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll 1
+                for (int ct = 0; ct < 3; ++ct) {
+                    const bf16x8* ap = reinterpret_cast<const bf16x8*>(txt + ((size_t)b * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
+                    const int v = min(v0 + ct * 16 + ccol, V - 1);
+                    const bf16x8* bp = reinterpret_cast<const bf16x8*>(vis + ((size_t)a * V + v) * d + g * 8);
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[kc * 4], bp[kc * 4], acc, 0, 0, 0);
+                    const unsigned vk = kv_s[ct * 16 + ccol];
+                    const float* pen_v = pen_b + xa.seg_of_v[v];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const int q = min(q0 + rt * 16 + crow + n, Q - 1);
+                        const bool keep = (vk & kq_s[rt * 16 + crow + n]) != 0;
+                        S[(rt * 16 + crow + n) * P + ct * 16 + ccol] = (keep ? acc[n] : neg_inf) - pen_v[(size_t)q * xa.n_seg];
+                    }
                 }
-                out_maxV[((size_t)b * A + a) * Q + q0 + q] = m;
-                xa.argV[((size_t)b * A + a) * Q + q0 + q] = (uint16_t)vi;
+            __syncthreads();
+            const int nv = min(48, V - v0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = lane + 64 * h;
+                if (q < nq)
+                    for (int v = 0; v < nv; ++v) {
+                        const float x = S[q * P + v];
+                        if (x > m_run[h]) { m_run[h] = x; vi_run[h] = v0 + v; }
+                    }
             }
-        if (out_maxQ && lane < V) {
-            const size_t at = ((size_t)b * A + a) * V + lane;
-            float m = q0 == 0 ? ninf : out_maxQ[at];
-            int qi = q0 == 0 ? 0 : (int)xa.argQ[at];
-            for (int q = 0; q < nq; ++q) {
-                const float x = S[q * P + lane];
-                if (x > m) { m = x; qi = q0 + q; }
+            if (out_maxQ && lane < nv) {
+                const size_t at = ((size_t)b * A + a) * V + v0 + lane;
+                float m = q0 == 0 ? ninf : out_maxQ[at];
+                int qi = q0 == 0 ? 0 : (int)xa.argQ[at];
+                for (int q = 0; q < nq; ++q) {
+                    const float x = S[q * P + lane];
+                    if (x > m) { m = x; qi = q0 + q; }
+                }
+                out_maxQ[at] = m;
+                xa.argQ[at] = (uint16_t)qi;
             }
-            out_maxQ[at] = m;
-            xa.argQ[at] = (uint16_t)qi;
+            __syncthreads();
         }
-        __syncthreads();
+        if (out_maxV)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = lane + 64 * h;
+                if (q < nq) {
+                    out_maxV[((size_t)b * A + a) * Q + q0 + q] = m_run[h];
+                    xa.argV[((size_t)b * A + a) * Q + q0 + q] = (uint16_t)vi_run[h];
+                }
+            }
     }
 }
 
@@ -1230,10 +1257,11 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
                             int V, float neg_inf, float* out_maxV, float* out_maxQ, hipStream_t s,
                             AlignArgs xa = AlignArgs{nullptr, nullptr, 0, nullptr, nullptr}) {
     const int by = (B + kAMWaves - 1) / kAMWaves;
-    // enough workgroups for the chip (256 CUs, one 8-wave workgroup each), but at least 8 images per workgroup so that
-    // the caption fragments are amortised
+    // enough workgroups for the chip (256 CUs, one 8-wave workgroup each), but at least 8 image tiles per workgroup so that
+    // the caption fragments are amortised (several region groups per image -- align_argmax_kernel only -- are several tiles)
+    const int ng = ARGS ? (V + kAMRows - 1) / kAMRows : 1;
     int a_per_block = (int)(((long)A * by + 255) / 256);
-    if (a_per_block < 8) a_per_block = 8;
+    if (a_per_block < (8 + ng - 1) / ng) a_per_block = (8 + ng - 1) / ng;
     if (a_per_block > A) a_per_block = A;
     dim3 grid((A + a_per_block - 1) / a_per_block, by);   // x fastest: workgroups of one caption octet spread over the XCDs
     // positions wanted: both products on the matrix cores (172 vs 267 us at config-2).  The maxima alone stay with align_max_kernel:
@@ -2094,7 +2122,8 @@ int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, c
                                                                          wsf + p.off_maxV, wsf + p.off_maxQ, nullptr, s, xa)        \
              : launch_align_mfma<F32, KCHV, true, true, VLG_GA_RTB>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr,               \
                                                                     wsf + p.off_maxV, wsf + p.off_maxQ, nullptr, s, xa)
-    if (!f32in && d == 128 && V <= kAMRows && !getenv("VLG_GROUND_OLD_ALIGN"))   // shared image tiles (align_max_kernel<ARGS>)
+    // shared image tiles: align_argmax_kernel, any number of region groups (VLG_ALIGN_ARGMAX_OLD: the round-2 kernel for V <= 48)
+    if (!f32in && d == 128 && (V <= kAMRows || !getenv("VLG_ALIGN_ARGMAX_OLD")) && !getenv("VLG_GROUND_OLD_ALIGN"))
         rc = launch_align_max<true>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, wsf + p.off_maxV, wsf + p.off_maxQ, s, xa);
     else if (!f32in && d == 128) VLG_GA(false, 4);
     else if (!f32in && d == 64) VLG_GA(false, 2);
@@ -2144,7 +2173,7 @@ int vlg_align_reduced(const void* txt, const void* vis, const uint8_t* tmask, co
                                                                    wsf + p.off_maxV, nullptr, nullptr, s, xa)                      \
              : launch_align_mfma<F32, KCHV, true, true, 3>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr, wsf + p.off_maxV, \
                                                            nullptr, nullptr, s, xa)
-    if (!f32in && d == 128 && V <= kAMRows && !getenv("VLG_GROUND_OLD_ALIGN"))   // shared image tiles, row maxima + positions only
+    if (!f32in && d == 128 && (V <= kAMRows || !getenv("VLG_ALIGN_ARGMAX_OLD")) && !getenv("VLG_GROUND_OLD_ALIGN"))   // row maxima + positions only
         rc = launch_align_max<true>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, wsf + p.off_maxV, nullptr, s, xa);
     else if (!f32in && d == 128) VLG_RA(false, 4);
     else if (!f32in && d == 64) VLG_RA(false, 2);
