@@ -803,7 +803,7 @@ static __device__ __forceinline__ unsigned am_keep_u(unsigned bits, int pos, uns
 // Several region groups per image (V > 48, the shipped factor layout): the staged tile is one GROUP of 48 regions, the loop runs over
 // (image, group) steps; a region belongs to one group, so the maxima over the queries are per step as before, while the maxima over
 // the regions are carried across an image's groups (strictly larger wins: the earlier group keeps a tie) and stored after its last one.
-template <bool HASQ, bool ARGS>
+template <bool HASQ, bool ARGS, bool MULTI>   // MULTI = false: one group (V <= 48), the group arithmetic folds away
 __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
     const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
     const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_maxV,
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything that depends on the caption lives in SGPRs
     const int b = blockIdx.y * kAMWaves + wave, bc = min(b, B - 1);   // a wave past the batch mirrors the last caption, stores nothing
     const int a0 = blockIdx.x * a_per_block, n_img = min(A, a0 + a_per_block) - a0;
-    const int NG = (V + kAMRows - 1) / kAMRows, n_step = n_img * NG;   // region groups per image; (image, group) steps of this block
+    const int NG = MULTI ? (V + kAMRows - 1) / kAMRows : 1, n_step = n_img * NG;   // region groups per image; (image, group) steps of this block
     const int g = lane >> 4, ccol = lane & 15, crow = g * 4;
     constexpr int NS = 2;
     const bool has2 = tid < kAMSlots - kAMThreads;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
         sseg[k] = 2u * (unsigned)(((sl & 15) ^ (r & 15)) * 8);
     }
     auto stage_load = [&](int st, uint4* x, unsigned& ck) {   // step st = (image, group)
-        const int a = a0 + st / NG, v0 = (st % NG) * kAMRows;
+        const int a = MULTI ? a0 + st / NG : a0 + st, v0 = MULTI ? (st % NG) * kAMRows : 0;
         const char* img = reinterpret_cast<const char*>(vis + (size_t)a * V * d);
         // (32-bit offsets from a scalar base; rows past V are copies of the last region: they cannot change a maximum, lose every tie)
         x[0] = *reinterpret_cast<const uint4*>(img + (2u * (unsigned)(min(v0 + srow[0], V - 1) * d) + sseg[0]));
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
         float mrow[RT];       // maxima over the regions (and where), carried across an image's groups
         unsigned irow[RT];
         for (int i = 0; i < n_step; ++i) {
-            const int a = a0 + i / NG, grp = i % NG, v0 = grp * kAMRows, buf = i & 1;
+            const int a = MULTI ? a0 + i / NG : a0 + i, grp = MULTI ? i % NG : 0, v0 = grp * kAMRows, buf = i & 1;
             if (i + 1 < n_step) stage_write(buf ^ 1, xs, ck);       // tile i+1: loaded during the previous step's MFMAs
             if (i + 2 < n_step) stage_load(i + 2, xs, ck);          // tile i+2: lands during this step's MFMAs
             const uint4* tb = tiles[buf];
@@ -1269,11 +1269,13 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
     if constexpr (ARGS) {
         if (!getenv("VLG_ALIGN_ARGMAX_OLD")) {   // (the env switch: tools/ A-B timing only)
             if (out_maxQ)
-                hipLaunchKernelGGL((align_argmax_kernel<true, true>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
-                                   tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
+#define VLG_AAM(HQ, MU)                                                                                                       \
+    hipLaunchKernelGGL((align_argmax_kernel<HQ, true, MU>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask, \
+                       vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa)
+                { if (ng > 1) VLG_AAM(true, true); else VLG_AAM(true, false); }
             else
-                hipLaunchKernelGGL((align_argmax_kernel<false, true>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
-                                   tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa);
+                { if (ng > 1) VLG_AAM(false, true); else VLG_AAM(false, false); }
+#undef VLG_AAM
             if (xa.pen) {
                 if (int rc = check_launch("align_argmax_kernel")) return rc;
                 hipLaunchKernelGGL(align_prior_diag_kernel, dim3(std::min(A, B)), dim3(64), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
