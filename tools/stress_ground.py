@@ -24,12 +24,23 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     vis = torch.from_numpy((rng.standard_normal((B, V, d)) * 0.4).astype(np.float32)).bfloat16()
     marg = (rng.random((B, Q)) * tmask).astype(np.float32)
     num = int(lengths.sum())
-    ref = oracle.grounding_loss(txt.float().numpy(), vis.float().numpy(), tmask, vmask, marg, num, 1.0, dtype=np.float64)
+    pen = seg = None
+    if it % 2 == 1 and V >= 4:   # every other case with the POS prior of the diagonal pairs (joint.py:446-470)
+        tag = rng.integers(0, 6, (B, L))
+        pen, seg = oracle.grounding_prior(tag, ["obj", "rel", "img"], [V // 2, V - V // 2 - 1, 1],
+                                          dict(obj=np.array([0, 1]), rel=np.array([1, 2]), attr=np.array([5])), Q)
+        ref = oracle.grounding_loss(txt.float().numpy(), vis.float().numpy(), tmask, vmask, marg, num, 1.0, pen, seg, -1e20, np.float64)
+    else:
+        ref = oracle.grounding_loss(txt.float().numpy(), vis.float().numpy(), tmask, vmask, marg, num, 1.0, dtype=np.float64)
     tt, tv = txt.to(dev).requires_grad_(True), vis.to(dev).requires_grad_(True)
     tm, vm, mg = (torch.from_numpy(a).to(dev) for a in (tmask, vmask, marg))
     first = None
     for rep in range(5):
-        total, sums = align.grounding_loss_factor_ce(tt, tv, tm, vm, mg, num, 1.0)
+        if pen is None:
+            total, sums = align.grounding_loss_factor_ce(tt, tv, tm, vm, mg, num, 1.0)
+        else:
+            total, sums = align.grounding_loss_factor_ce(tt, tv, tm, vm, mg, num, 1.0, torch.from_numpy(pen.astype(np.float32)).to(dev),
+                                                         torch.from_numpy(seg).to(dev))
         g_txt, g_vis = torch.autograd.grad(total, [tt, tv])
         cur = (sums.clone(), g_txt.clone(), g_vis.clone())
         if first is None:
