@@ -18,7 +18,7 @@ for d in sorted(glob.glob('gpurun_out/pmcm_${tag}_*/')):
         acc=collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             n=r['Kernel_Name']
-            m=re.search(r'(ground_bwd_dense_kernel<[01]|ground_transpose_kernel|align_argmax_kernel|align_max_kernel|align_mfma_kernel|attn_fuse_mfma_kernel|attn_fuse_bwd_words_kernel|attn_fuse_bwd_regions_kernel|attn_fuse\w*kernel|tri_kernel|tri_dw_kernel|align_bwd\w*kernel)', n)
+            m=re.search(r'(ground_bwd_dense_kernel<[01]|ground_transpose_kernel|align_full_kernel|align_argmax_kernel|align_max_kernel|align_mfma_kernel|attn_fuse_mfma_kernel|attn_fuse_bwd_words_kernel|attn_fuse_bwd_regions_kernel|attn_fuse\w*kernel|tri_kernel|tri_dw_kernel|align_bwd\w*kernel)', n)
             if m:
                 key=m.group(1) + ('' if 'align_mfma' not in n else ('<TILE>' if 'true, false' in n or 'Lb1ELb0' in n else ''))
                 acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
