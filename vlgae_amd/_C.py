@@ -115,6 +115,20 @@ except AttributeError:   # pragma: no cover
     _cur_device = torch.cuda.current_device
 
 
+def mask_u8(t, device):
+    """A keep-mask as contiguous uint8 on `device`.  bool and uint8 share their storage: a view, not a conversion kernel (the
+    `.to(torch.uint8)` of a bool mask is a 5 us launch, two per grounding-loss call)."""
+    if t is None:
+        return None
+    if t.dtype == torch.bool:
+        t = t.view(torch.uint8)
+    elif t.dtype != torch.uint8:
+        t = t.to(torch.uint8)
+    if t.device != device:
+        t = t.to(device)
+    return t.contiguous()
+
+
 def stream_of(t):
     """The HIP stream the launch goes to: the current stream of t's device.  hipLaunchKernel acts on the process's CURRENT
     device, so a tensor that lives elsewhere must not get this far (it would launch onto the wrong GPU or fail with an

@@ -38,8 +38,8 @@ def bilinear_align(txt_feat, vis_feat, txt_mask=None, vis_mask=None, neg_inf=-IN
     dt, txt_c = _C.in_dtype(txt_feat)
     _, vis_c = _C.in_dtype(vis_feat)
     dev = txt_feat.device
-    tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
-    vm = None if vis_mask is None else vis_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    tm = _C.mask_u8(txt_mask, dev)
+    vm = _C.mask_u8(vis_mask, dev)
     if tm is not None and tuple(tm.shape) != (B, Q):
         raise ValueError(f"txt_mask must be [B,Q]={(B, Q)}, got {tuple(tm.shape)}")
     if vm is not None and tuple(vm.shape) != (A, V):
@@ -96,8 +96,8 @@ def bilinear_align_backward(grad_out, txt_feat, vis_feat, txt_mask=None, vis_mas
         g = g.to(torch.float32).contiguous()
     dt, txt_c = _C.in_dtype(txt_feat)
     vis_c = vis_feat.detach().to(txt_c.dtype).contiguous()
-    tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
-    vm = None if vis_mask is None else vis_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    tm = _C.mask_u8(txt_mask, dev)
+    vm = _C.mask_u8(vis_mask, dev)
     if want_txt or want_vis:
         nbytes = _C.lib().vlg_bilinear_align_backward_workspace(B, A, Q, V, d, dt)
         (g_txt, g_vis), ws = _C.alloc_f32(dev, ((B, Q, d) if want_txt else None, (A, V, d) if want_vis else None), nbytes)
@@ -136,8 +136,8 @@ class _GatherLogitReduced(torch.autograd.Function):
         B, Q, d = txt_c.shape
         V = vis_c.shape[1]
         dev = txt_c.device
-        tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
-        vm = None if vis_mask is None else vis_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        tm = _C.mask_u8(txt_mask, dev)
+        vm = _C.mask_u8(vis_mask, dev)
         marg = marginal.detach().to(device=dev, dtype=torch.float32).contiguous()
         nbytes = _C.lib().vlg_align_reduced_workspace(B, Q)
         (logit,), ws = _C.alloc_f32(dev, ((B, B),), nbytes)
@@ -293,8 +293,8 @@ class _GroundingLoss(torch.autograd.Function):
         dt, txt_c = _C.in_dtype(txt_feat)
         vis_c = vis_feat.detach().to(txt_c.dtype).contiguous()
         dev = txt_c.device
-        tm = None if txt_mask is None else txt_mask.to(device=dev, dtype=torch.uint8).contiguous()
-        vm = None if vis_mask is None else vis_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        tm = _C.mask_u8(txt_mask, dev)
+        vm = _C.mask_u8(vis_mask, dev)
         marg = marginal.detach().to(device=dev, dtype=torch.float32).contiguous()
         n_seg = 0
         if pen is not None:

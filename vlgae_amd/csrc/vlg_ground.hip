@@ -597,6 +597,27 @@ __global__ __launch_bounds__(256) void ground_transpose_kernel(const uint16_t* _
     }
 }
 
+// both sides' transposes in one launch (a ~7 us launch saved per training step): blockIdx.y < nyA -> tensor A, else tensor B
+__global__ __launch_bounds__(256) void ground_transpose2_kernel(const uint16_t* __restrict__ featA, int KA, int KpA, uint16_t* __restrict__ outA,
+                                                                int nyA, const uint16_t* __restrict__ featB, int KB, int KpB,
+                                                                uint16_t* __restrict__ outB) {
+    __shared__ uint16_t t[32][kGdD + 2];
+    const bool second = (int)blockIdx.y >= nyA;
+    const uint16_t* feat = second ? featB : featA;
+    uint16_t* featT = second ? outB : outA;
+    const int K = second ? KB : KA, Kp = second ? KpB : KpA;
+    const int o = blockIdx.x, k0 = ((int)blockIdx.y - (second ? nyA : 0)) * 32;
+    for (int i = threadIdx.x; i < 32 * kGdD; i += 256) {
+        const int k = i / kGdD, c = i - k * kGdD;
+        t[k][c] = k0 + k < K ? feat[((size_t)o * K + k0 + k) * kGdD + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * kGdD; i += 256) {
+        const int c = i >> 5, k = i & 31;
+        featT[((size_t)o * kGdD + c) * Kp + k0 + k] = t[k][c];
+    }
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 gd_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float gd_f32x4;
 
@@ -1270,8 +1291,12 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
     } while (0)
 #define VLG_WS0(MTV, RWV)                                                                                              \
     do { if (V <= 40) VLG_WS(0, 2, MTV, RWV, 5, 3, 40, visT, g_txt); else VLG_WS(0, 2, MTV, RWV, 8, 2, 64, visT, g_txt); } while (0)
+    const bool both_ws = g_txt && g_vis && ws_ok && V <= 48;
+    if (both_ws)
+        hipLaunchKernelGGL(ground_transpose2_kernel, dim3(B, KtV / 32 + KpQ / 32), dim3(256), 0, s, (const uint16_t*)vis, V, KtV, visT, KtV / 32,
+                           (const uint16_t*)txt, Q, KpQ, txtT);
     if (g_txt && ws_ok) {
-        hipLaunchKernelGGL(ground_transpose_kernel, dim3(B, KtV / 32), dim3(256), 0, s, (const uint16_t*)vis, V, KtV, visT);
+        if (!both_ws) hipLaunchKernelGGL(ground_transpose_kernel, dim3(B, KtV / 32), dim3(256), 0, s, (const uint16_t*)vis, V, KtV, visT);
         switch ((Q + 15) / 16) {
             case 1: VLG_WS0(1, 1); break;
             case 2: VLG_WS0(2, 2); break;
@@ -1284,7 +1309,7 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
         g_txt = nullptr;
     }
     if (g_vis && ws_ok && V <= 48) {   // (four region tiles: the double buffers do not fit the LDS)
-        hipLaunchKernelGGL(ground_transpose_kernel, dim3(B, KpQ / 32), dim3(256), 0, s, (const uint16_t*)txt, Q, KpQ, txtT);
+        if (!both_ws) hipLaunchKernelGGL(ground_transpose_kernel, dim3(B, KpQ / 32), dim3(256), 0, s, (const uint16_t*)txt, Q, KpQ, txtT);
         switch ((V + 15) / 16) {
             case 1: VLG_WS(1, 3, 1, 1, 12, 2, 96, txtT, g_vis); break;
             case 2: VLG_WS(1, 3, 2, 2, 12, 2, 96, txtT, g_vis); break;

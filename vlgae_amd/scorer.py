@@ -27,7 +27,7 @@ class _NdmvPotentials(torch.autograd.Function):
         dt, x1_c = _C.in_dtype(x1.detach())
         x2_c, y1_c, y2_c = (t.detach().to(x1_c.dtype).contiguous() for t in (x2, y1, y2))
         root_c = root_rule.detach().to(torch.float32).contiguous()
-        hm = None if head_mask is None else head_mask.to(torch.uint8).contiguous()
+        hm = _C.mask_u8(head_mask, x1_c.device)
         dev = x1.device
         md = torch.empty((B, N, 2, 2, 2), dtype=out_dtype, device=dev)
         ma = torch.empty((B, N, N, 2), dtype=out_dtype, device=dev)

@@ -218,7 +218,7 @@ def dmv1o_rules_run(attach_rule, dec, root_rule, token, lengths, semiring, want_
     root_c = root2.detach().to(rule_c.dtype).contiguous()
     dev = attach_rule.device
     token = token.to(device=dev, dtype=torch.int64).contiguous()
-    hm = None if head_mask is None else head_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    hm = _C.mask_u8(head_mask, dev)
     lengths = _lengths(lengths, B, dev)
     out = {"logZ": torch.empty(B, dtype=torch.float32, device=dev)}
     g_rule = g_dec = g_root = heads = None
