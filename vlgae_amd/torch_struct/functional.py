@@ -432,13 +432,18 @@ def dmv1o_marginals_and_heads(dec, attach, lengths, keep_viterbi=False):
         vdec = torch.empty((B, N, 2, 2, 2), dtype=torch.float32, device=dec.device)
         vatt = torch.empty((B, N, N, 2), dtype=torch.float32, device=dec.device)
         lengths = _lengths(lengths, B, dec.device)
-    side.wait_stream(cur)                       # the potentials are produced on the current stream
+    # The potentials are produced on the current stream: the side stream waits for an event recorded HERE, and the longer of the
+    # two launches (the Log-semiring inside-outside pass) is enqueued first -- it starts ~6 us earlier than when it followed the
+    # side-stream launch, and the pair ends when it does.
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    logZ, _, gatt = dmv1o_run(dec, attach, lengths, _C.SEMIRING_LOG, True, want_dec=False)
+    side.wait_event(ready)
     with torch.cuda.stream(side):
         if keep_viterbi:
             dmv1o_viterbi(dec, attach, lengths, out=(best, vdec, vatt, heads))
         else:
             dmv1o_decode(dec, attach, lengths, out=(best, heads))
-    logZ, _, gatt = dmv1o_run(dec, attach, lengths, _C.SEMIRING_LOG, True, want_dec=False)
     cur.wait_stream(side)
     if keep_viterbi:
         _viterbi_remember(dec, attach, lengths, (best, vdec, vatt, heads))
