@@ -311,7 +311,7 @@ class _GroundingLoss(torch.autograd.Function):
         ctx.save_for_backward(g_txt, g_vis)
         ctx.dtypes = (txt_feat.dtype, vis_feat.dtype)
         ctx.mark_non_differentiable(sums)
-        return sums[2].clone(), sums
+        return sums[2], sums   # (a 0-d view of the non-differentiable sums: no clone launch; nothing writes either in place)
 
     @staticmethod
     @once_differentiable
