@@ -109,16 +109,14 @@ __global__ __launch_bounds__(kCeThreads) void ground_ce_kernel(float* __restrict
 constexpr int kCeTileThreads = 512;
 
 template <typename W>
-__global__ __launch_bounds__(kCeTileThreads) void ground_ce_tile_kernel(float* __restrict__ buf, size_t fixed_stride, size_t row_stride,
-                                                                        int n, int ncols, int cw_max, const W* __restrict__ w,
-                                                                        const uint16_t* __restrict__ arg,
-                                                                        const uint8_t* __restrict__ self_mask,
-                                                                        const uint8_t* __restrict__ other_mask, int n_other,
-                                                                        float* __restrict__ partial) {
+__device__ __forceinline__ void ground_ce_tile_body(float* __restrict__ buf, size_t fixed_stride, size_t row_stride, int n, int ncols,
+                                                    int cw_max, const W* __restrict__ w, const uint16_t* __restrict__ arg,
+                                                    const uint8_t* __restrict__ self_mask, const uint8_t* __restrict__ other_mask,
+                                                    int n_other, float* __restrict__ partial, int by, int ny) {
     extern __shared__ float ce_lds[];
     constexpr int NT = kCeTileThreads;
     const int fixed = blockIdx.x, tid = threadIdx.x;
-    const int j0 = blockIdx.y * cw_max, cw = min(cw_max, ncols - j0), pitch = cw_max | 1;
+    const int j0 = by * cw_max, cw = min(cw_max, ncols - j0), pitch = cw_max | 1;
     float* tile = ce_lds;                        // [n][pitch]
     float* red = tile + (size_t)n * pitch;       // [NT]
     float* colm = red + NT;                      // [cw_max] column maximum
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(kCeTileThreads) void ground_ce_tile_kernel(float* _
     if (tid == 0) {
         float loss = 0.f;
         for (int c = 0; c < cw; ++c) loss += red[c];   // columns in ascending order
-        partial[(size_t)fixed * gridDim.y + blockIdx.y] = loss;
+        partial[(size_t)fixed * ny + by] = loss;
     }
     {   // derivative w.r.t. the maxima, in place
         const uint16_t* abase = arg + (size_t)fixed * fixed_stride + j0;
@@ -182,6 +180,32 @@ __global__ __launch_bounds__(kCeTileThreads) void ground_ce_tile_kernel(float* _
             if (c >= cw) { c -= cw; ++i; }
         }
     }
+}
+
+template <typename W>
+__global__ __launch_bounds__(kCeTileThreads) void ground_ce_tile_kernel(float* __restrict__ buf, size_t fixed_stride, size_t row_stride,
+                                                                        int n, int ncols, int cw_max, const W* __restrict__ w,
+                                                                        const uint16_t* __restrict__ arg,
+                                                                        const uint8_t* __restrict__ self_mask,
+                                                                        const uint8_t* __restrict__ other_mask, int n_other,
+                                                                        float* __restrict__ partial) {
+    ground_ce_tile_body<W>(buf, fixed_stride, row_stride, n, ncols, cw_max, w, arg, self_mask, other_mask, n_other, partial, (int)blockIdx.y,
+                           (int)gridDim.y);
+}
+
+// Both cross-entropies of the grounding loss in ONE launch (round 3): they are independent, 26 us each, and their strips co-reside
+// on a CU -- blockIdx.y < y1: the txt2vis strips (float weights = the marginals), else the vis2txt strips (byte weights = vis_mask).
+struct CeSide {
+    float* buf; size_t fixed_stride, row_stride; int ncols, cw_max; const void* w; const uint16_t* arg;
+    const uint8_t *self_mask, *other_mask; int n_other; float* partial; int ny;
+};
+__global__ __launch_bounds__(kCeTileThreads) void ground_ce_tile2_kernel(int n, CeSide a, CeSide b) {
+    if ((int)blockIdx.y < a.ny)
+        ground_ce_tile_body<float>(a.buf, a.fixed_stride, a.row_stride, n, a.ncols, a.cw_max, (const float*)a.w, a.arg, a.self_mask,
+                                   a.other_mask, a.n_other, a.partial, (int)blockIdx.y, a.ny);
+    else
+        ground_ce_tile_body<uint8_t>(b.buf, b.fixed_stride, b.row_stride, n, b.ncols, b.cw_max, (const uint8_t*)b.w, b.arg, b.self_mask,
+                                     b.other_mask, b.n_other, b.partial, (int)blockIdx.y - a.ny, b.ny);
 }
 
 // sums = {txt2vis, vis2txt, total};  coef = {c1, c2}: d total / d txt2vis, d total / d vis2txt.
@@ -1513,10 +1537,21 @@ int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask
                 hipError_t e = hipFuncSetAttribute(kp.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kp.second);
                 if (e != hipSuccess) return set_error((int)e, "grounding_loss: hipFuncSetAttribute(%zu): %s", kp.second, hipGetErrorString(e));
             }
+        if (!getenv("VLG_GROUND_CE_SPLIT")) {
+            const size_t lds2 = std::max(s1.lds, s2.lds);
+            if (lds2 > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)ground_ce_tile2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                if (e != hipSuccess) return set_error((int)e, "grounding_loss: hipFuncSetAttribute(%zu): %s", lds2, hipGetErrorString(e));
+            }
+            const CeSide sa{mV, (size_t)B * Q, (size_t)Q, Q, s1.cw, marg, aV, tmask, vmask, V, part, y1};
+            const CeSide sb{mQ, (size_t)V, (size_t)B * V, V, s2.cw, vmask, aQ, vmask, tmask, Q, part2, y2};
+            hipLaunchKernelGGL(ground_ce_tile2_kernel, dim3(B, y1 + y2), dim3(kCeTileThreads), lds2, s, B, sa, sb);
+        } else {
         hipLaunchKernelGGL(k1, dim3(B, y1), dim3(kCeTileThreads), s1.lds, s, mV, (size_t)B * Q, (size_t)Q, B, Q, s1.cw, marg, aV, tmask, vmask,
                            V, part);
         hipLaunchKernelGGL(k2, dim3(B, y2), dim3(kCeTileThreads), s2.lds, s, mQ, (size_t)V, (size_t)B * V, B, V, s2.cw, vmask, aQ, vmask, tmask,
                            Q, part2);
+        }
     } else {
         hipLaunchKernelGGL(ground_ce_kernel<float>, dim3(B, y1), dim3(kCeThreads), 0, s, mV, (size_t)B * Q, (size_t)Q, B, Q, marg, aV,
                            tmask, vmask, V, part);
