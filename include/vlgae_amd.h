@@ -278,30 +278,39 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
 
 /* The byte work of `lang_feat_max_tree` (src/model/joint.py:235-292) between the DP, the encoder GEMMs and the arc encoder.
  * Shapes: B sentences, L words, N = L + 1 positions (root first), h encoder width, d matching width; M = B*N rows.
- *   root_cat          x [B,L,h] (in_dtype) -> x1 [B,N,h] bf16: row 0 = masked mean of the words (joint.py:262-265), rows 1.. = x (:266)
+ * Activations are stored as bf16 or fp32 (`act_dtype` / `out_dtype`; fp32 is the reference's `precision: 32`,
+ * config/trainer/train.yaml:20); arithmetic is fp32 either way.  `drop` [B,3,d] fp32 or NULL: the SharedDropout masks
+ * (nn/dropout.py:42-63; 0 or 1/(1-p), shared over the positions of a sentence) of the word | child | parent encoders, applied
+ * AFTER the activation as `MLP.forward` does (nn/common.py:47-51); NULL = identity (eval mode); `ld_drop` = elements between
+ * consecutive sentences' masks (3d when contiguous; a [B,4,d] draw that also holds `lang_feat_word_only`'s mask passes 4d).
+ *   root_cat          x [B,L,h] (in_dtype) -> x1 [B,N,h] (out_dtype): row 0 = masked mean of the words (joint.py:262-265), rows 1.. = x (:266)
  *   root_cat_backward d_x1 [B,N,h] (in_dtype) -> d_x [B,L,h] fp32
- *   split             pre [M,3d] bf16 = x1 W_cat^T + b_cat (word | child | parent encoders, joint.py:267-273) ->
- *                     txt[b,n,:] = word third (txt is [B,2N,d] bf16, the word half, :288), child [M,d] = LeakyReLU(child third),
+ *   split             pre [M,3d] = x1 W_cat^T + b_cat (word | child | parent encoders, joint.py:267-273) ->
+ *                     txt[b,n,:] = word third (txt is [B,2N,d], the word half, :288), child [M,d] = LeakyReLU(child third),
  *                     parent [M,d] = LeakyReLU(parent third of row heads[b,n]) (gather by the predicted heads, :271-273),
- *                     sum [M,d] = child + parent (optional; the operand of the affine term, :285)
+ *                     each times its dropout mask; sum [M,d] = child + parent (optional; the operand of the affine term, :285)
  *   split_backward    d_txt [B,2N,d] (dtype; the word half is read), d_child / d_parent fp32 [M,d], d_sum [M,d] (d_sum_dtype) or NULL
- *                     (added to both), child / parent (activations, bf16) -> d_pre [M,3d] bf16 (LeakyReLU', scatter-add by head
+ *                     (added to both), child / parent (activations) -> d_pre [M,3d] (dropout mask, LeakyReLU', scatter-add by head
  *                     in ascending row order)
  *   marginal          grad_attach [B,N,N,2] fp32, heads [B,N], lengths [B] -> txt_marginal [B,2N] fp32 = cat([mask,
  *                     arc_margin.gather(-1, predicted)]) (joint.py:246-261; use_marginal 0: cat([mask, mask]), :262),
  *                     txt_mask [B,2N] u8 = cat([mask, mask]) with the root slot masked (:248-249)
- *   arc_out           tri [M,d] fp32 (+ aff [M,d] bf16 or NULL) -> txt[b, N+n, :] bf16 (arc_repr, joint.py:278-288) */
-int vlg_langfeat_root_cat(const void* x, const int64_t* lengths, int B, int L, int h, int in_dtype, void* x1, void* stream);
+ *   arc_out           tri [M,d] fp32 (+ aff [M,d] act_dtype or NULL) -> txt[b, N+n, :] (arc_repr, joint.py:278-288)
+ *   rowscale          out[b,n,:] = pre[b,n,:] * drop[b*ld_drop + :]  (one encoder's SharedDropout on [B,N,d]: the word encoder of
+ *                     `lang_feat_word_only`, joint.py:193-211, and its adjoint; in place allowed) */
+int vlg_langfeat_root_cat(const void* x, const int64_t* lengths, int B, int L, int h, int in_dtype, void* x1, int out_dtype,
+                          void* stream);
 int vlg_langfeat_root_cat_backward(const void* d_x1, const int64_t* lengths, int B, int L, int h, int in_dtype, float* d_x,
                                    void* stream);
-int vlg_langfeat_split(const void* pre, const int64_t* heads, int B, int N, int d, float slope, void* txt, void* child,
-                       void* parent, void* sum, void* stream);
+int vlg_langfeat_split(const void* pre, const int64_t* heads, const float* drop, int ld_drop, int B, int N, int d, int act_dtype, float slope,
+                       void* txt, void* child, void* parent, void* sum, void* stream);
 int vlg_langfeat_split_backward(const void* d_txt, int d_txt_dtype, const float* d_child, const float* d_parent, const void* d_sum,
-                                int d_sum_dtype, const void* child, const void* parent, const int64_t* heads, int B, int N, int d,
-                                float slope, void* d_pre, void* stream);
+                                int d_sum_dtype, const void* child, const void* parent, const int64_t* heads, const float* drop, int ld_drop,
+                                int B, int N, int d, int act_dtype, float slope, void* d_pre, void* stream);
 int vlg_langfeat_marginal(const float* grad_attach, const int64_t* heads, const int64_t* lengths, int B, int N, int use_marginal,
                           float* txt_marginal, uint8_t* txt_mask, void* stream);
-int vlg_langfeat_arc_out(const float* tri, const void* aff, int B, int N, int d, void* txt, void* stream);
+int vlg_langfeat_arc_out(const float* tri, const void* aff, int B, int N, int d, int act_dtype, void* txt, void* stream);
+int vlg_langfeat_rowscale(const void* pre, const float* drop, int B, int N, int d, int ld_drop, int act_dtype, void* out, void* stream);
 
 /* Score construction feeding the DP -- the tensor half of `DiscriminativeNDMV._forward`, src/model/ldndmv.py:179-209 with the
  * factorised-bilinear scorers of src/model/nn/dmv_spec.py:57-76: from the scorers' projected inputs to the root-merged
@@ -377,7 +386,8 @@ int vlg_selftest_xlane(int* scratch, void* stream);
 /* Thread-local message for the last non-zero return on this thread ("" if none). */
 const char* vlg_last_error(void);
 
-/* Library / ABI version, e.g. 120 = 0.1.2 (round 3: vlg_linear_wgrad, vlg_langfeat_*, vlg_ndmv_potentials*, vlg_dmv1o_viterbi added;
+/* Library / ABI version, e.g. 130 = 0.1.3 (round 4: vlg_langfeat_* take the activations' storage type and the SharedDropout masks,
+ * vlg_langfeat_rowscale added; round 3, 120: vlg_linear_wgrad, vlg_langfeat_*, vlg_ndmv_potentials*, vlg_dmv1o_viterbi added;
  * round 2, 110: vlg_bilinear_align_backward takes a workspace; vlg_scale_counts, vlg_feed_* added). */
 int vlg_version(void);
 

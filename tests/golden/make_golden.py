@@ -572,6 +572,193 @@ def scorer_cases():
         print(f"{name}: merged_attach {tuple(ma.shape)} finite min {float(ma[ma > -1e11].min()):.3f}")
 
 
+
+def trainstep_cases():
+    """One whole training step of the shipped `vlgae` model AS THE REFERENCE WIRES IT, executed by the reference's own methods
+    called unbound on namespaces that carry what they read (the modules are the reference's `MLP`, `DMVSkipConnectEncoder`,
+    `DMVFactorizedBilinear`, `SharedDropout`; `VarPool`, `reduce_loss` and `DMV1o` are the reference's too):
+
+      JointModelBase.forward order (base.py:215-241)
+        DependencyBoxRel._forward        joint.py:658-675   feat_fuse_attention (a pass-through copy, :362-398), vis_feat_unprune with
+                                                            return_mid (:137-178), lang_feat_word_only (:193-211), the attention fuse
+                                                            (:670-674) into a COPY of `encoded` (replace: false), then
+        DiscriminativeNDMV._forward      ldndmv.py:171-216  on that copy: context_mode 'mean' reads the FUSED x (extract_sent_repr :226),
+                                                            head_ff / mid_ff / scorers -> merged potentials
+        DependencyBoxRel._vis_forward    joint.py:677-691   vis_feat_unprune again, lang_feat_max_tree (:235-292) on the caller's
+                                                            `encoded` -- i.e. the UN-fused x --, gather_logit_simple (:406-419)
+      DependencyBoxRel.loss              joint.py:693-711   DiscriminativeNDMV.loss (ldndmv.py:260-285, viterbi_training: -max.sum()),
+                                                            loss_grounding_factor_ce (:439-491; use_pos_prior, vis2txt = 1),
+                                                            alpha * mt + (1 - alpha) * dep, alpha = grounding_interpolation = 0.5
+      reduce_loss('token')               utility/fn.py:50-56, pipeline.py:124,249-250
+
+    Training mode: the word / child / parent encoders' SharedDropout (p = 0.33, config/model/vlgae.yaml:69-73) is live; its
+    `get_mask` is replaced by a recorder that draws from this script's generator so that the masks are inputs of the fixture
+    (call order: word encoder in lang_feat_word_only; word, child, parent encoders in lang_feat_max_tree).  The scorer's
+    feed-forwards run with dropout 0 (out of the hot path; their dropout is torch's).  Stored: every input, every parameter,
+    the dropout masks, intermediate values (fused x, potentials, heads, txt, marginal, the loss terms) and the gradient of the
+    reduced loss w.r.t. every input feature and parameter.  `w1` of the d = 128 case is stored as rank-4 factors and only a
+    strided sample of its gradient is kept."""
+    from functools import partial
+    from types import SimpleNamespace as NS
+    src, joint = _ref_import.import_joint()
+    from src.model import ldndmv
+    from src.model.nn import MLP, DMVSkipConnectEncoder, DMVFactorizedBilinear
+    from src.model.nn.dropout import SharedDropout
+    from src.utility.var_pool import VarPool
+    from src.utility.fn import reduce_loss
+    JB, ND = joint.DependencyBoxRel, ldndmv.DiscriminativeNDMV
+    src.trainer = NS(current_epoch=100)
+    real_get_mask = SharedDropout.get_mask
+    for name, seed, B, L, boxes, factors, h, d, E, Et, T, H, nb, r, rank, p_drop, sc_gain in (
+            ("trainstep_B3_L6_box4_rel_attr_h64_d32_s0", 0, 3, 6, 4, ("rel", "attr"), 64, 32, 12, 10, 9, 24, 6, 8, 0, 0.33, 6.0),
+            ("trainstep_B4_L9_box5_rel_attr_img_h64_d32_s1_nodrop", 1, 4, 9, 5, ("rel", "attr", "img"), 64, 32, 12, 10, 11, 24, 0, 8, 0, 0.0, 8.0),
+            ("trainstep_B8_L40_box36_h256_d128_s2", 2, 8, 40, 36, (), 256, 128, 40, 24, 45, 96, 40, 16, 4, 0.33, 10.0)):
+        torch.manual_seed(seed)
+        g = torch.Generator().manual_seed(seed)
+        rnd = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+        # ---- the model: reference modules on two namespaces ----
+        enc = {k: MLP(n_in=h, n_hidden=d, dropout=p_drop, activate=(k != "word")) for k in ("word", "child", "parent")}
+        with torch.no_grad():
+            for m in enc.values():
+                m.linear.bias.copy_(rnd(d, sc=0.1))
+        if rank:
+            u, v, z = (rnd(d, rank, sc=0.3) for _ in range(3))
+            w1 = torch.nn.Parameter(torch.einsum("xr,hr,yr->xhy", u, v, z).contiguous())
+        else:
+            w1 = torch.nn.Parameter(rnd(d, d, d, sc=1.0 / d))
+        w2 = torch.nn.Parameter(rnd(d, d, sc=d ** -0.5))
+        b_arc = torch.nn.Parameter(rnd(d, sc=0.1))
+        pre_match = torch.nn.Linear(h, d, bias=False)
+        ln = torch.nn.LayerNorm(h)
+        with torch.no_grad():
+            ln.weight.copy_(torch.rand(h, generator=g) + 0.5)
+            ln.bias.copy_(rnd(h, sc=0.1))
+        dep = NS(cfg=NS(extended_valence=True, function_mask=False, init_epoch=0, viterbi_training=True, context_mode="mean",
+                        variational_mode="none"), dmv=None, variational_enc=None, training=True,
+                 head_ff=MLP(n_in=E + h, n_hidden=H), child_ff=MLP(n_in=Et, n_hidden=H), root_ff=MLP(n_in=10, n_hidden=H),
+                 dec_ff=MLP(n_in=10, n_hidden=H), mid_ff=DMVSkipConnectEncoder(hidden_size=H, n_bottleneck=nb),
+                 attach_scorer=DMVFactorizedBilinear(n_in=H, r=r), dec_scorer=DMVFactorizedBilinear(n_in=H, r=r),
+                 root_scorer=DMVFactorizedBilinear(n_in=H, r=r), token_emb=torch.nn.Parameter(rnd(T, Et)),
+                 root_emb=torch.nn.Parameter(rnd(1, 10)), dec_emb=torch.nn.Parameter(rnd(2, 10)))
+        for fn_name in ("extract_sent_repr", "construct_token_repr", "_forward", "loss"):
+            setattr(dep, fn_name, partial(getattr(ND, fn_name), dep))
+        # the scorers' default init gives near-uniform rule distributions (scores of ~0.03 around log(1/T)): every tree then scores within
+        # 1e-3 of every other and the Viterbi tree is decided by fp32 rounding.  Scale the projections so that scores have a spread of
+        # ~1.5 nats, as a trained parser's do.
+        with torch.no_grad():
+            for sc_mod in (dep.attach_scorer, dep.dec_scorer, dep.root_scorer):
+                for p_ in sc_mod.parameters():
+                    p_.mul_(sc_gain)
+        pos = dict(obj=torch.tensor([0, 1, 2]), rel=torch.tensor([2, 3]), attr=torch.tensor([4]))
+        me = NS(cfg=NS(feat_fuse_mode="attention", feat_fuse_args=NS(aug_with_matching=True, replace=False), add_rel="rel" in factors,
+                       add_attr="attr" in factors, add_image="img" in factors, add_marginal=True, grounding_interpolation=0.5,
+                       loss_grounding_args=NS(use_pos_prior=True, vis2txt=1.0)), training=True, vis_factor_names=["obj", *factors],
+                pos_for_obj=pos["obj"], pos_for_rel=pos["rel"], pos_for_attr=pos["attr"], word_encoder=enc["word"],
+                child_encoder=enc["child"], parent_encoder=enc["parent"], arc_encoder_w1=w1, arc_encoder_w2=w2, arc_encoder_b=b_arc,
+                vis_mlp_pre_matching=pre_match, feat_layernorm=ln, dependency=dep)
+        for attr_, fn_name in (("feat_fuse", "feat_fuse_attention"), ("vis_feat", "vis_feat_unprune"), ("lang_feat", "lang_feat_max_tree"),
+                               ("lang_feat_word_only", "lang_feat_word_only"), ("gather_logit", "gather_logit_simple"),
+                               ("loss_grounding", "loss_grounding_factor_ce")):
+            setattr(me, attr_, partial(getattr(JB, fn_name), me))
+        # ---- the batch ----
+        lengths = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+        lengths[0] = L
+        wmask = torch.arange(L)[None] < lengths[:, None]
+        box_mask = torch.rand(B, boxes, generator=g) > 0.2
+        box_mask[:, 0] = True
+        enc_x = rnd(B, L, h, sc=0.5).requires_grad_(True)
+        emb = rnd(B, L, E, sc=0.5).requires_grad_(True)
+        vis_enc = {"box": rnd(B, boxes, h, sc=0.5).requires_grad_(True)}
+        if "rel" in factors:
+            vis_enc["rel"] = rnd(B, boxes * boxes, h, sc=0.5).requires_grad_(True)
+        if "attr" in factors:
+            vis_enc["attr"] = rnd(B, boxes, h, sc=0.5).requires_grad_(True)
+        token = torch.randint(0, T, (B, L), generator=g)
+        tag = torch.randint(0, 7, (B, L), generator=g)
+        inputs = {"token": token, "tag": tag, "vis_box_mask": box_mask, "vis_rel_mask": True}
+        vp = VarPool(seq_len=lengths, mask=wmask, tag=tag, vis_available=torch.ones(B, dtype=torch.bool))
+        # every input feature and parameter sits on the bfloat16 grid (the reference still computes in fp32 on them), so that a
+        # bf16-storage run of the same step starts from identical numbers
+        with torch.no_grad():
+            all_mods = [*enc.values(), pre_match, ln, dep.head_ff, dep.child_ff, dep.root_ff, dep.dec_ff, dep.mid_ff, dep.attach_scorer,
+                        dep.dec_scorer, dep.root_scorer]
+            for t_ in [enc_x, emb, *vis_enc.values(), w1, w2, b_arc, dep.token_emb, dep.root_emb, dep.dec_emb,
+                       *(p_ for m in all_mods for p_ in m.parameters())]:
+                t_.copy_(t_.to(torch.bfloat16).to(torch.float32))
+        # ---- recorders: dropout masks, the two `_mid` tensors, the scorers' projected inputs ----
+        drop_masks, mids, cap = [], [], {}
+
+        def get_mask(x, p):
+            m = (torch.rand(x.shape, generator=g) >= p).to(x.dtype) / (1 - p)
+            drop_masks.append(m)
+            return m
+        SharedDropout.get_mask = staticmethod(get_mask)
+        hooks = [pre_match.register_forward_pre_hook(lambda mod, inp: mids.append(inp[0]))]
+        hooks += [m.register_forward_hook(lambda mod, inp, out, k=k: cap.__setitem__(k, out))
+                  for k, m in (("x1", dep.attach_scorer.project1), ("x2", dep.attach_scorer.project2), ("y1", dep.dec_scorer.project1),
+                               ("y2", dep.dec_scorer.project2))]
+        # ---- JointModelBase.forward (base.py:215-241) with the encoders' outputs given ----
+        encoded = {"x": enc_x, "emb": emb, **{f"vis_{k}": t for k, t in vis_enc.items()}}
+        score = JB._forward(me, inputs, encoded, vp)
+        assert encoded["x"] is enc_x                                             # the fuse went into a copy (replace: false)
+        score = {**score, **JB._vis_forward(me, inputs, vis_enc, encoded, score, vp)}
+        total, parts = JB.loss(me, score, {}, vp)
+        loss = reduce_loss("token", total, vp.num_token, vp.batch_size)
+        SharedDropout.get_mask = real_get_mask
+        for hk in hooks:
+            hk.remove()
+        assert len(mids) == 2 and len(drop_masks) == (4 if p_drop > 0 else 0)
+        # ---- gradients of the reduced loss ----
+        ff = dict(head_ff=dep.head_ff, child_ff=dep.child_ff, root_ff=dep.root_ff, dec_ff=dep.dec_ff, mid_ff=dep.mid_ff,
+                  attach_scorer=dep.attach_scorer, dec_scorer=dep.dec_scorer, root_scorer=dep.root_scorer)
+        ff_params = {f"ff.{mod}.{k}": t for mod, m in ff.items() for k, t in m.named_parameters()}
+        named = {"enc_x": enc_x, "emb": emb, **{f"vis_{k}": t for k, t in vis_enc.items()},
+                 "w_word": enc["word"].linear.weight, "b_word": enc["word"].linear.bias, "w_child": enc["child"].linear.weight,
+                 "b_child": enc["child"].linear.bias, "w_parent": enc["parent"].linear.weight, "b_parent": enc["parent"].linear.bias,
+                 "w1": w1, "w2": w2, "b_arc": b_arc, "w_vis": pre_match.weight, "ln_w": ln.weight, "ln_b": ln.bias,
+                 "token_emb": dep.token_emb, "root_emb": dep.root_emb, "dec_emb": dep.dec_emb, **ff_params}
+        extra_t = [mids[0], mids[1], cap["x1"], cap["x2"], cap["y1"], cap["y2"], score["merged_dec"], score["merged_attach"]]
+        grads = torch.autograd.grad(loss, list(named.values()) + extra_t, allow_unused=True)
+        gn = dict(zip(named, grads[:len(named)]))
+        g_mid0, g_mid1, g_x1, g_x2, g_y1, g_y2, g_md, g_ma = grads[len(named):]
+        # the fused x (the copy `_forward` handed to the parser) and the heads, recomputed with the reference's lines on the same tensors
+        with torch.no_grad():
+            vis0 = pre_match(mids[0])
+            x_word = torch.cat([(enc_x.masked_fill(~wmask.unsqueeze(2), 0).sum(1) / lengths.unsqueeze(1)).unsqueeze(1), enc_x], 1)
+            word0 = enc["word"].linear(x_word) * (drop_masks[0].unsqueeze(1) if p_drop > 0 else 1.0)
+            att = torch.einsum("bvd, bqd -> bqv", vis0, word0[:, 1:]).softmax(2)
+            x_fused = ln(enc_x + torch.einsum("bqv,bvh->bqh", att, mids[0]))
+        arc = ts.DMV1o([score["merged_dec"].detach().requires_grad_(), score["merged_attach"].detach().requires_grad_()],
+                       lengths).argmax.sum(-1).nonzero()
+        predicted = torch.zeros(B, L + 1, dtype=torch.long)
+        predicted[arc[:, 0], arc[:, 2]] = arc[:, 1]
+        txt, tmask, tmarg = score["txt_packed"]
+        vis, vmask, split = score["vis_packed"]
+        out = {f"g_{k}": _np(t) for k, t in gn.items() if t is not None and k != "w1"}
+        unused = [k for k, t in gn.items() if t is None]
+        if rank:
+            out.update(w1_u=_np(u), w1_v=_np(v), w1_z=_np(z), g_w1_sample=_np(gn["w1"][::5, ::7, ::3]))
+        else:
+            out.update(w1=_np(w1), g_w1=_np(gn["w1"]))
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            **{k: _np(t) for k, t in named.items() if k != "w1"}, **out,
+            lengths=_np(lengths), token=_np(token), tag=_np(tag), box_mask=_np(box_mask), factor_names=np.array(me.vis_factor_names),
+            vis_split=np.array(split, dtype=np.int64), pos_for_obj=_np(pos["obj"]), pos_for_rel=_np(pos["rel"]), pos_for_attr=_np(pos["attr"]),
+            drop_masks=(np.stack([_np(m) for m in drop_masks]) if drop_masks else np.zeros((0, B, d), np.float32)),
+            p_drop=np.float32(p_drop), alpha=np.float32(me.cfg.grounding_interpolation), vis2txt_weight=np.float32(1.0),
+            slope=np.float32(enc["child"].activation.negative_slope), ln_eps=np.float32(ln.eps), neg_inf=np.float32(-src.INF),
+            n_bottleneck=np.int64(nb), unused=np.array(unused),
+            vis_mid=_np(mids[0]), g_vis_mid=_np(g_mid0 + g_mid1), vis_mask=_np(vmask), x_fused=_np(x_fused),
+            sc_x1=_np(cap["x1"]), sc_x2=_np(cap["x2"][0]), sc_y1=_np(cap["y1"]), sc_y2=_np(cap["y2"][0]), root_rule=_np(score["root_rule"][0]),
+            g_sc_x1=_np(g_x1), g_sc_x2=_np(g_x2[0]), g_sc_y1=_np(g_y1), g_sc_y2=_np(g_y2[0]),
+            merged_dec=_np(score["merged_dec"]), merged_attach=_np(score["merged_attach"]), g_merged_dec=_np(g_md), g_merged_attach=_np(g_ma),
+            predicted=_np(predicted), txt=_np(txt), txt_mask=_np(tmask), txt_marginal=_np(tmarg), vis_feat=_np(vis),
+            dep_loss=_np(parts["nll"]), loss_txt2vis=_np(parts["txt2vis"]), loss_vis2txt=_np(parts["mt_vis2txt"]), total=_np(total),
+            loss=_np(loss), num_token=_np(vp.num_token))
+        print(f"{name}: loss {float(loss):.6f} total {float(total):.4f} nll {float(parts['nll']):.4f} unused {unused}")
+
+
 def _csr(lists):
     return (np.cumsum([0] + [len(l) for l in lists]).astype(np.int64),
             np.asarray([i for l in lists for i in l], dtype=np.int64))
@@ -670,4 +857,5 @@ if __name__ == "__main__":
     boxrel_cases()
     langfeat_cases()
     scorer_cases()
+    trainstep_cases()
     feed_cases()

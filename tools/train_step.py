@@ -1,41 +1,259 @@
-"""The hot path of one VLGAE training step (BASELINE.json configs[4]) chained as the model wires it, on synthetic features.
+"""One VLGAE training step (BASELINE.json configs[4]) on synthetic encoder outputs, wired AS THE REFERENCE WIRES IT.
 
-Reference call sequence (shipped `vlgae` config):
-  DependencyBoxRel._forward   joint.py:658-675   attention-fuse of region features into the word encodings     -> attention_fuse
-  scorer -> merged potentials ldndmv.py:184-209  factorised-bilinear scores -> log-softmax over tokens -> gather / direction
-                                                 select / root gather / merge (round 3, with_scorer=True)          -> scorer.ndmv_potentials
-                                                 [with_scorer=False: the potentials are synthetic constants, as in rounds 1-2]
-  lang_feat_max_tree          joint.py:235-292   DMV1o partition + autograd.grad -> arc marginals; argmax -> heads -> marginals_and_heads
-                                                 arc encoder over (child, gathered parent)                        -> arc_encoder
-  gather_logit + loss         joint.py:406-491   region x word alignment maxima + grounding cross-entropy         -> grounding_loss_factor_ce
-  DiscriminativeNDMV.loss     ldndmv.py:277-281  -DMV1o(...).max.sum()  (viterbi_training: true)                  -> DMV1o.max
-  loss.backward()                                adjoints of all of the above
+`build(...)` returns `step()`: forward + backward of the chain below; `tests/test_gpu_parity.py::test_training_step_reference_*`
+run this very function on fixtures produced by the reference's own methods (tests/golden/trainstep_*.npz, make_golden.py
+`trainstep_cases`), and `bench.py` / `tools/bench_secondary.py` time it.  Paths are relative to /root/reference.
 
-Frozen BERT / Faster-RCNN features are not in the container: word encodings [B,L,256] and region features
-[B,V,128|256] are fixed-seed random tensors of the shapes the encoders emit.  Round 3: the language side follows
-lang_feat_max_tree literally (vlgae_amd.langfeat: masked-mean root row, word | child | parent encoders = nn.Linear + bias
-(+ LeakyReLU) as ONE projection GEMM with concatenated weights, parent rows gathered by the predicted heads, arc encoder),
-and the step runs ONE Viterbi pass: `marginals_and_heads(keep_viterbi=True)` feeds both `argmax` (joint.py:256) and the
-parser's `-max` loss on the same potentials (ldndmv.py:277-281).
+  JointModelBase.forward (src/model/base.py:215-241), encoder outputs given (frozen BERT / Faster-RCNN + MLPEncoder are out of scope):
+    DependencyBoxRel._forward      src/model/joint.py:658-675
+      vis_feat_unprune             :137-178   vis_feat = vis_mlp_pre_matching(vis_mid)  (bias-free nn.Linear)          -> align.linear
+      lang_feat_word_only          :193-211   root row = masked mean, word encoder (+ SharedDropout)                  -> langfeat.lang_feat_word_only
+      attention fuse               :670-674   softmax(vis_feat . word^T) vis_mid, residual, LayerNorm                  -> align.attention_fuse
+        the fused x goes into a COPY of `encoded` (feat_fuse_args.replace: false, :376-377): only the parser sees it
+    DiscriminativeNDMV._forward    src/model/ldndmv.py:171-216  on that copy
+      context_mode 'mean'          :226,:254  h = cat([emb, mean_l(fused x)])                                          (torch)
+      head_ff / child_ff / root_ff / dec_ff (MLP, nn/common.py:23-51), mid_ff (DMVSkipConnectEncoder, nn/dmv_spec.py:6-54),
+      the scorers' project1 / project2 (nn.Linear, nn/dmv_spec.py:63-68): plain feed-forwards = library GEMMs          (torch, `scorer_feed_forward`)
+      scores -> log-softmax over tokens -> gather / direction select / root gather / merge   :184-209                   -> scorer.ndmv_potentials
+    DependencyBoxRel._vis_forward  joint.py:677-691
+      lang_feat_max_tree           :235-292   on the caller's `encoded`, i.e. the UN-fused x: DMV1o marginals + Viterbi heads of
+                                              the detached potentials, word | child | parent encoders (+ SharedDropout), arc encoder -> langfeat.lang_feat_max_tree
+      gather_logit_simple          :406-419   } never materialised: alignment maxima + arg-max on the matrix cores,
+  DependencyBoxRel.loss            :693-711   }
+      loss_grounding_factor_ce     :439-491   } POS prior (use_pos_prior: true), both cross-entropies, vis2txt = 1          -> align.grounding_loss_factor_ce
+      DiscriminativeNDMV.loss      ldndmv.py:277-281  viterbi_training: -DMV1o(potentials).max.sum() (the step's one Viterbi pass is reused)
+      alpha * mt_loss + (1 - alpha) * dep_loss, alpha = grounding_interpolation = 0.5 (config/model/vlgae.yaml:67)
+  reduce_loss('token')             src/utility/fn.py:50-56 (src/pipeline.py:124,249-250): / (num_token + 1e-12)
+  loss.backward()                  every adjoint of the above
+
+`wiring="r3"` keeps round 3's chain for continuity of the bench history (fused x fed to lang_feat_max_tree, scorer inputs and
+matching-space features as leaves, plain sum of the two losses): NOT what the reference does; see DESIGN.md section 5.
 """
 import torch
+import torch.nn.functional as F
+
+SLOPE = 0.01           # nn.LeakyReLU() default, nn/common.py:31
+FF_MODULES = ("head_ff", "child_ff", "root_ff", "dec_ff", "mid_ff", "attach_scorer", "dec_scorer", "root_scorer")
 
 
-def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer=True, T=45, r=16):
+# ----------------------------------------------------------------------------------------------------------------------------
+# The parser's feed-forwards (out of the hot path: plain Linear / LeakyReLU stacks, left to the library).  Parameter names are
+# the reference modules' own `named_parameters()` names behind "ff.<module>." so that a fixture's tensors drop in.
+# ----------------------------------------------------------------------------------------------------------------------------
+def _lin(P, name, x):
+    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+
+
+def _mlp(P, name, x, drop=None):
+    """MLP (nn/common.py:23-51): Linear -> LeakyReLU -> SharedDropout (mask [B,1,H] or None)."""
+    y = F.leaky_relu(_lin(P, f"ff.{name}.linear", x), SLOPE)
+    return y if drop is None else y * drop
+
+
+def _bottleneck(P, name, x):
+    if name + ".weight" in P:                                   # n_bottleneck == 0: one Linear
+        return _lin(P, name, x)
+    return _lin(P, name + ".1", _lin(P, name + ".0", x))      # nn.Sequential(Linear(H, nb), Linear(nb, H)), no activation between
+
+
+def _skip_connect(P, x, p_drop=0.0):
+    """DMVSkipConnectEncoder.forward (nn/dmv_spec.py:38-54): [..., H] -> [..., dir, val, H]."""
+    act = lambda t: F.leaky_relu(t, SLOPE)
+    m = "ff.mid_ff."
+    has_child = _bottleneck(P, m + "HASCHILD_linear", x) + x
+    no_child = _bottleneck(P, m + "NOCHILD_linear", x) + x
+    h = torch.stack([no_child, has_child], dim=-2)
+    h = act(_lin(P, m + "valence_linear", act(h)))
+    x4 = x.unsqueeze(-2)
+    left = _bottleneck(P, m + "LEFT_linear", h) + x4
+    right = _bottleneck(P, m + "RIGHT_linear", h) + x4
+    h = torch.stack([left, right], dim=-3)
+    h = act(_lin(P, m + "direction_linear", act(h)))
+    if p_drop > 0:
+        h = F.dropout(h, p_drop, True)
+    return _lin(P, m + "linear2", act(_lin(P, m + "linear1", h)))
+
+
+def scorer_feed_forward(P, emb, x_fused, p_mid_drop=0.0, ff_drop=None):
+    """ldndmv.py:174-205 up to the scorers' projected inputs: (x1 [B,L,2,2,r], x2 [T,2,2,r], y1 [B,L,2,2,r], y2 [2,2,2,r],
+    root_rule [T]).  context_mode 'mean' (:226): every token's representation is cat([emb, mean over ALL L positions of x])."""
+    B, L, _ = emb.shape
+    ctx = x_fused.mean(1, keepdim=True).expand(-1, L, -1)
+    h = torch.cat([emb, ctx.to(emb.dtype)], dim=-1)
+    h_parent = _skip_connect(P, _mlp(P, "head_ff", h, ff_drop), p_mid_drop)
+    h_child = _skip_connect(P, _mlp(P, "child_ff", P["token_emb"]), p_mid_drop)          # [T,2,2,H]
+    h_root = _skip_connect(P, _mlp(P, "root_ff", P["root_emb"]), p_mid_drop)             # [1,2,2,H]
+    h_dec = _skip_connect(P, _mlp(P, "dec_ff", P["dec_emb"]), p_mid_drop)                # [2,2,2,H]
+    x1, x2 = _lin(P, "ff.attach_scorer.project1", h_parent), _lin(P, "ff.attach_scorer.project2", h_child)
+    y1, y2 = _lin(P, "ff.dec_scorer.project1", h_parent), _lin(P, "ff.dec_scorer.project2", h_dec)
+    r1, r2 = _lin(P, "ff.root_scorer.project1", h_root), _lin(P, "ff.root_scorer.project2", h_child)
+    root_rule = torch.einsum("hdve,cdve->hc", r1.float(), r2.float()).log_softmax(-1)[0]   # :205: sum over (dir, val), softmax over tokens
+    return x1, x2, y1, y2, root_rule
+
+
+def init_feed_forward(g, dev, dtype, E, h, Et, T, H, nb, r):
+    """Random parameters with the reference modules' shapes (vlgae.yaml: H = 256, n_bottleneck = 150, ranks 16)."""
+    P = {}
+
+    def lin(name, n_in, n_out, bias=True):
+        P[name + ".weight"] = (torch.randn(n_out, n_in, generator=g) * n_in ** -0.5).to(dev, dtype).requires_grad_(True)
+        if bias:
+            P[name + ".bias"] = (torch.randn(n_out, generator=g) * 0.1).to(dev, dtype).requires_grad_(True)
+
+    for name, n_in in (("head_ff", E + h), ("child_ff", Et), ("root_ff", 10), ("dec_ff", 10)):
+        lin(f"ff.{name}.linear", n_in, H)
+    for name in ("HASCHILD_linear", "NOCHILD_linear", "LEFT_linear", "RIGHT_linear"):
+        if nb:
+            lin(f"ff.mid_ff.{name}.0", H, nb)
+            lin(f"ff.mid_ff.{name}.1", nb, H)
+        else:
+            lin(f"ff.mid_ff.{name}", H, H)
+    for name in ("valence_linear", "direction_linear", "linear1", "linear2"):
+        lin(f"ff.mid_ff.{name}", H, H)
+    for name in ("attach_scorer", "dec_scorer", "root_scorer"):
+        lin(f"ff.{name}.project1", H, r)
+        lin(f"ff.{name}.project2", H, r)
+    P["token_emb"] = torch.randn(T, Et, generator=g).to(dev, dtype).requires_grad_(True)
+    P["root_emb"] = torch.randn(1, 10, generator=g).to(dev, dtype).requires_grad_(True)
+    P["dec_emb"] = torch.randn(2, 10, generator=g).to(dev, dtype).requires_grad_(True)
+    return P
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer=True, T=45, r=16, wiring="reference", given=None,
+          alpha=0.5, use_pos_prior=True, vis2txt=1.0, p_drop=0.33, E=800, Et=32, H=256, nb=150, p_ff_drop=0.0, p_mid_drop=0.0,
+          factor_names=("obj",), vis_split=None, pos_for=None, ln_eps=1e-5, ff_dtype=None):
+    """The step function of one training step at B sentences of <= L words and V region columns.
+
+    wiring="reference": the chain of the module docstring.  `given` (a dict) replaces any of the synthetic inputs / parameters by
+    name (tests: the fixture's tensors) -- features enc_x [B,L,h], emb [B,L,E], vis_mid [B,V,h]; batch lengths / token / tag [B,L],
+    vis_mask [B,V], drop [4,B,d] (the SharedDropout masks in the reference's call order: word-only, then word | child | parent; or
+    None); parameters w_vis [d,h], w_enc [3d,h], b_enc [3d], ln_w, ln_b [h], w1 [d,d,d], w2 [d,d], b [d], token_emb / root_emb /
+    dec_emb and the "ff.*" feed-forward parameters.  With `given` drop absent, fresh masks are drawn every step (p_drop).
+    ff_dtype: storage / compute type of the parser's feed-forwards (torch ops; default = dtype).
+    alpha / use_pos_prior / vis2txt: config/model/vlgae.yaml:62-67.  Returns step(); step() -> (loss, {name: gradient}, ()).
+
+    wiring="r3": round 3's chain (see the module docstring); `with_scorer` only matters there."""
+    if wiring == "r3":
+        return _build_r3(B, L, V, dev, dtype, d, h, seed, with_scorer, T, r)
+    if wiring != "reference":
+        raise ValueError(wiring)
     import vlgae_amd.torch_struct as ts
     from vlgae_amd import align, langfeat, scorer
     N, Q = L + 1, 2 * (L + 1)
+    given = dict(given or {})
+    ff_dtype = dtype if ff_dtype is None else ff_dtype
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+
+    def leaf(name, make, dt=dtype):
+        t = given.pop(name) if name in given else make()
+        return t.detach().to(dev, dt).contiguous().requires_grad_(True)
+
+    # ---- features as the (frozen / out-of-scope) encoders emit them, and the trainable weights on the path ----
+    P = dict(
+        enc_x=leaf("enc_x", lambda: rnd(B, L, h)), emb=leaf("emb", lambda: rnd(B, L, E, sc=0.5), ff_dtype), vis_mid=leaf("vis_mid", lambda: rnd(B, V, h)),
+        w_vis=leaf("w_vis", lambda: rnd(d, h, sc=h ** -0.5)),
+        w_enc=leaf("w_enc", lambda: rnd(3 * d, h, sc=h ** -0.5)), b_enc=leaf("b_enc", lambda: rnd(3 * d, sc=0.1)),
+        ln_w=leaf("ln_w", lambda: torch.ones(h), torch.float32), ln_b=leaf("ln_b", lambda: torch.zeros(h), torch.float32),
+        w1=leaf("w1", lambda: rnd(d, d, d, sc=1.0 / d)), w2=leaf("w2", lambda: rnd(d, d, sc=d ** -0.5)), b=leaf("b", lambda: rnd(d, sc=0.1)),
+    )
+    ff_given = {k: given.pop(k) for k in list(given) if k.startswith("ff.") or k in ("token_emb", "root_emb", "dec_emb")}
+    if ff_given:
+        P.update({k: t.detach().to(dev, ff_dtype).contiguous().requires_grad_(True) for k, t in ff_given.items()})
+    else:
+        P.update(init_feed_forward(g, dev, ff_dtype, E, h, Et, T, H, nb, r))
+    # ---- the batch ----
+    if "lengths" in given:
+        lengths = given.pop("lengths").to(dev, torch.int64)
+    else:
+        lengths = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+        lengths[0] = L
+        lengths = lengths.to(dev)
+    token = given.pop("token").to(dev) if "token" in given else torch.randint(0, P["token_emb"].shape[0], (B, L), generator=g).to(dev)
+    tag = given.pop("tag").to(dev) if "tag" in given else torch.randint(0, 7, (B, L), generator=g).to(dev)
+    if "vis_mask" in given:
+        vmask = given.pop("vis_mask").to(dev, torch.bool)
+    else:   # ragged region lists: a random ~85 % of the boxes are real (vis_box_mask, src/datamodule/task/vlparse.py:75-92)
+        vmask = (torch.rand(B, V, generator=g) > 0.15)
+        vmask[:, 0] = True
+        vmask = vmask.to(dev)
+    fixed_drop = given.pop("drop") if "drop" in given else "draw"
+    if fixed_drop is not None and not isinstance(fixed_drop, str):
+        fixed_drop = fixed_drop.to(dev, torch.float32).permute(1, 0, 2).contiguous()      # [B,4,d]
+    if given:
+        raise ValueError(f"train_step.build: unknown given entries {sorted(given)}")
+    vis_split = list(vis_split) if vis_split is not None else [V]
+    if pos_for is None:
+        pos_for = dict(obj=torch.tensor([0, 1, 2]), rel=torch.tensor([2, 3]), attr=torch.tensor([4]))
+    pos_for = {k: t.to(dev) for k, t in pos_for.items()}
+    num_token = lengths.sum()                                     # a 0-d tensor like vp.num_token (var_pool.py:18)
+    num_token_f = float(num_token.item())
+    names = sorted(P)
+    leaves = [P[k] for k in names]
+    ff_drop = None
+    aux = {}
+    # the POS prior table (joint.py:446-470) is a function of the batch's tags only -- data, like the masks: built once per batch
+    pen = seg = None
+    if use_pos_prior:
+        pen, seg = align.grounding_prior(tag, factor_names, vis_split, pos_for, Q)
+
+    def step(stage_hook=None):
+        """forward + backward; returns (reduced loss, gradients by leaf name, ()).  stage_hook (optional) is called from inside the
+        backward pass once the adjoints of the DP and of the grounding loss have run (the cotangent of `txt` exists) -- where a
+        data-parallel trainer starts reducing its first gradient bucket."""
+        drop = fixed_drop
+        if isinstance(drop, str):
+            drop = langfeat.shared_dropout_masks(B, d, p_drop, n=4, device=dev)
+        d0, d3 = (None, None) if drop is None else (drop[:, 0:1], drop[:, 1:4])
+        w_word, b_word = P["w_enc"][:d], P["b_enc"][:d]
+        # ---- DependencyBoxRel._forward, joint.py:658-675 ----
+        vis_feat = align.linear(P["vis_mid"], P["w_vis"])                                                    # :175 (and again :688: same values)
+        word0, _, _ = langfeat.lang_feat_word_only(P["enc_x"], lengths, w_word, b_word, drop=d0)            # :667
+        x_f = align.attention_fuse(vis_feat, word0, P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], ln_eps)   # :670-674
+        # ---- DiscriminativeNDMV._forward on the fused copy, ldndmv.py:171-216 ----
+        x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, p_mid_drop, ff_drop)
+        md, ma = scorer.ndmv_potentials(x1, x2, y1, y2, root_rule, token)
+        # ---- DependencyBoxRel._vis_forward, joint.py:677-691: the UN-fused x; the potentials are constants of this stage (:252-253) ----
+        txt, tmask, tmarg = langfeat.lang_feat_max_tree(P["enc_x"], lengths, md.detach(), ma.detach(), P["w_enc"], P["b_enc"], P["w1"],
+                                                        P["w2"], P["b"], keep_viterbi=True, drop=d3, aux=aux)
+        if stage_hook is not None:
+            txt.register_hook(lambda g_: stage_hook())
+        # ---- DependencyBoxRel.loss, joint.py:693-711 ----
+        mt, sums = align.grounding_loss_factor_ce(txt, vis_feat, tmask, vmask, tmarg, num_token_f, vis2txt, pen, seg)
+        dep = -ts.DMV1o([md, ma], lengths).max.sum()              # ldndmv.py:277-281; the Viterbi pass of lang_feat_max_tree is reused
+        total = alpha * mt + (1 - alpha) * dep
+        loss = total / (num_token + 1e-12)                        # reduce_loss('token')
+        grads = torch.autograd.grad(loss, leaves)
+        # intermediates for the parity tests, DETACHED: a reference to a previous step's autograd graph kept alive across a HIP-graph
+        # capture makes torch 2.10 / ROCm 7 crash in capture_end
+        step.last = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in dict(
+            x_fused=x_f, merged_dec=md, merged_attach=ma, txt=txt, txt_mask=tmask, txt_marginal=tmarg, vis_feat=vis_feat, sums=sums,
+            dep_loss=dep, mt_loss=mt, total=total, heads=aux.get("heads")).items()}
+        return loss.detach(), dict(zip(names, grads)), ()
+
+    step.names, step.P, step.lengths, step.wiring = names, P, lengths, wiring
+    step.trainable = tuple(k for k in names if k not in ("enc_x", "emb", "vis_mid"))
+    return step
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+def _build_r3(B, L, V, dev, dtype, d, h, seed, with_scorer, T, r):
+    """Round 3's chain, unchanged (bench continuity only).  Differences from the reference's wiring: the fused x feeds
+    lang_feat_max_tree, the scorers' projected inputs / vis_feat / the fuse's word features are leaves, vis_mask is all-true, no POS
+    prior, no dropout, total = grounding + dep (no alpha, no token reduction)."""
+    import vlgae_amd.torch_struct as ts
+    from vlgae_amd import align, langfeat, scorer
+    N = L + 1
     g = torch.Generator().manual_seed(seed)
     rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
     leaf = lambda *s, sc=1.0, dt=dtype: rnd(*s, sc=sc).to(dt).requires_grad_(True)
-    # ---- leaves: features (as the frozen encoders would emit them) and the trainable weights on the path ----
     P = dict(
         vis_feat=leaf(B, V, d), txt_word=leaf(B, N, d), vis_mid=leaf(B, V, h), enc_x=leaf(B, L, h),
         ln_w=torch.ones(h, device=dev, requires_grad=True), ln_b=torch.zeros(h, device=dev, requires_grad=True),
-        w_enc=leaf(3 * d, h, sc=h ** -0.5), b_enc=leaf(3 * d, sc=0.1),          # word | child | parent encoders (nn.Linear layout)
+        w_enc=leaf(3 * d, h, sc=h ** -0.5), b_enc=leaf(3 * d, sc=0.1),
         w1=leaf(d, d, d, sc=1.0 / d), w2=leaf(d, d, sc=d ** -0.5), b=leaf(d, sc=0.1),
     )
-    # ---- potentials from the (out-of-scope) scorer: constants of the step, root-merged ----
     dec = torch.randn(B, L, 2, 2, 2, generator=g).log_softmax(-1).to(dev)
     attach = torch.randn(B, L, L, 2, generator=g).to(dev)
     root = torch.randn(B, L, generator=g).log_softmax(-1).to(dev)
@@ -46,7 +264,7 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     lengths = lengths.to(dev)
     vmask = torch.ones(B, V, dtype=torch.bool, device=dev)
     num_token = float(lengths.sum().item())
-    if with_scorer:   # the scorers' projected inputs (plain nn.Linear outputs of the out-of-scope feed-forwards), fp32 like the reference's
+    if with_scorer:
         P.update(sc_x1=leaf(B, L, 2, 2, r, sc=0.5, dt=torch.float32), sc_x2=leaf(T, 2, 2, r, sc=0.5, dt=torch.float32),
                  sc_y1=leaf(B, L, 2, 2, r, sc=0.5, dt=torch.float32), sc_y2=leaf(2, 2, 2, r, sc=0.5, dt=torch.float32),
                  sc_root=torch.randn(T, generator=g).log_softmax(-1).to(dev).requires_grad_(True))
@@ -56,31 +274,21 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     pot = [md.detach().requires_grad_(True), ma.detach().requires_grad_(True)]
 
     def step(stage_hook=None):
-        """forward + backward of the chain; returns (total loss, gradients by leaf name, potential gradients).
-        stage_hook, if given, is called from inside the backward pass once the gradients w.r.t. the potentials and the
-        matching-space features exist (after the DP and grounding-loss adjoints, before the arc-encoder / projection /
-        attention-fuse adjoints) -- where a data-parallel trainer starts reducing its first gradient bucket."""
-        # joint.py:658-674: the fuse comes first -- the parser (joint.py:675) sees the fused encodings
         x = align.attention_fuse(P["vis_feat"], P["txt_word"], P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], 1e-5)
-        if with_scorer:   # ldndmv.py:184-209: the step's potentials, bf16 storage for the DPs
-            # (fp32 potentials, like `DMV1o.merge`: the DP reads either storage type at the same speed, and the counts that come
-            #  back through `-max` then need no bf16 round trip on their way into the scorer's adjoint)
+        if with_scorer:
             smd, sma = scorer.ndmv_potentials(P["sc_x1"], P["sc_x2"], P["sc_y1"], P["sc_y2"], P["sc_root"], token)
             cmd, cma, loss_pot = smd.detach(), sma.detach(), [smd, sma]
         else:
             cmd, cma, loss_pot = md, ma, pot
-        # joint.py:235-292 (the potentials are constants of this stage: detached, :252-253); its two DPs run on side streams
-        # beside the root row and the projection GEMM
         txt, tmask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, cmd, cma, P["w_enc"], P["b_enc"], P["w1"], P["w2"], P["b"],
                                                                keep_viterbi=True)
         if stage_hook is not None:
-            txt.register_hook(lambda g: stage_hook())
-        # joint.py:406-491
+            txt.register_hook(lambda g_: stage_hook())
         total, _ = align.grounding_loss_factor_ce(txt, P["vis_feat"], tmask, vmask, txt_marginal, num_token, 1.0)
-        # ldndmv.py:277-281 (viterbi_training: true): the Viterbi pass of lang_feat_max_tree is reused
         total = total - ts.DMV1o(loss_pot, lengths).max.sum()
         grads = torch.autograd.grad(total, leaves + ([] if with_scorer else pot))
         return total, dict(zip(names, grads[:len(names)])), grads[len(names):]
 
-    step.names, step.P, step.lengths = names, P, lengths
+    step.names, step.P, step.lengths, step.wiring = names, P, lengths, "r3"
+    step.trainable = ("b", "b_enc", "ln_b", "ln_w", "w1", "w2", "w_enc")
     return step

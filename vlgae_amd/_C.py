@@ -56,12 +56,13 @@ SIGNATURES = {
     "vlg_box_rel_pairwise_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "vlg_linear_wgrad_workspace": (_sz, [_i, _i, _i]),
     "vlg_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
-    "vlg_langfeat_root_cat": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vlg_langfeat_root_cat": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_langfeat_root_cat_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "vlg_langfeat_split": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
-    "vlg_langfeat_split_backward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "vlg_langfeat_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "vlg_langfeat_split_backward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "vlg_langfeat_marginal": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "vlg_langfeat_arc_out": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "vlg_langfeat_arc_out": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vlg_langfeat_rowscale": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "vlg_ndmv_potentials": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "vlg_ndmv_potentials_backward_workspace": (_sz, [_i, _i, _i, _i]),
     "vlg_ndmv_potentials_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -10,5 +10,5 @@ char* error_buffer() {
 
 extern "C" {
 const char* vlg_last_error(void) { return vlg::error_buffer(); }
-int vlg_version(void) { return 120; }   // 0.1.2: vlg_linear_wgrad, vlg_langfeat_*, vlg_ndmv_potentials*, vlg_dmv1o_viterbi (round 3)
+int vlg_version(void) { return 130; }   // 0.1.3: vlg_langfeat_* take act_dtype + SharedDropout masks, vlg_langfeat_rowscale (round 4)
 }

@@ -167,8 +167,10 @@ def _viterbi_key(dec, attach, lengths):
             tuple(dec.shape), dec.dtype, tuple(dec.stride()), tuple(attach.stride()))
 
 
-def _viterbi_remember(dec, attach, lengths, result):
-    _VITERBI[dec.device] = (_viterbi_key(dec, attach, lengths), (dec.detach(), attach.detach(), lengths), result)
+def _viterbi_remember(dec, attach, lengths, result, pending=None):
+    """pending: the StructureHandle whose side stream is still producing `result` -- a hit joins it into the CURRENT stream
+    before the tensors are handed out, so a `.max` taken before (or on another stream than) `handle.wait()` is ordered too."""
+    _VITERBI[dec.device] = (_viterbi_key(dec, attach, lengths), (dec.detach(), attach.detach(), lengths), result, pending)
 
 
 def _viterbi_lookup(dec, attach, lengths):
@@ -177,6 +179,8 @@ def _viterbi_lookup(dec, attach, lengths):
     hit = _VITERBI.get(dec.device)
     if hit is None or hit[0] != _viterbi_key(dec, attach, lengths):
         return None
+    if hit[3] is not None:
+        hit[3].join_current()
     return hit[2]
 
 
@@ -455,14 +459,18 @@ class StructureHandle:
     current stream and returns (logZ [B], marginals [B,N,N,2], heads [B,N])."""
 
     def __init__(self, streams, outs, device):
-        self._streams, self._outs, self._device, self._joined = streams, outs, device, False
+        self._streams, self._outs, self._device, self._joined = streams, outs, device, set()
 
-    def wait(self):
-        if not self._joined:
-            cur = torch.cuda.current_stream(self._device)
+    def join_current(self):
+        """Orders the CURRENT stream behind both side streams (idempotent per stream; cheap: two event waits)."""
+        cur = torch.cuda.current_stream(self._device)
+        if cur not in self._joined:
             for st in self._streams:
                 cur.wait_stream(st)
-            self._joined = True
+            self._joined.add(cur)
+
+    def wait(self):
+        self.join_current()
         return self._outs
 
 
@@ -499,6 +507,7 @@ def dmv1o_structure_async(dec, attach, lengths, keep_viterbi=False):
             dmv1o_viterbi(dec, attach, lengths, out=(best, vdec, vatt, heads))
         else:
             dmv1o_decode(dec, attach, lengths, out=(best, heads))
-    if keep_viterbi:
-        _viterbi_remember(dec, attach, lengths, (best, vdec, vatt, heads))
-    return StructureHandle(pair, (logZ, gatt, heads), dev)
+    handle = StructureHandle(pair, (logZ, gatt, heads), dev)
+    if keep_viterbi:   # the entry carries the handle: a lookup joins the side streams before it returns the hit
+        _viterbi_remember(dec, attach, lengths, (best, vdec, vatt, heads), pending=handle)
+    return handle
