@@ -54,7 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="dp", choices=["dp", "train_step"],
                     help="dp: the headline DMV1o inside+outside step (BASELINE.json metric); train_step: the chained "
                          "training-step hot path of configs[4], sharded data-parallel (tools/bench_train.py)")
-    ap.add_argument("--buckets", type=int, default=2, help="train_step: pieces the flat gradient is all-reduced in")
+    ap.add_argument("--buckets", type=int, default=3, help="train_step: pieces the flat gradient is all-reduced in")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-secondary", "--no-align", action="store_true", dest="no_secondary",
                     help="headline only: skip the secondary single-GPU measurements")

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libvlg_emu.so")
+_SO = os.environ.get("VLG_EMU_SO") or os.path.join(_HERE, "_build", "libvlg_emu.so")   # override: a sanitizer build (tests/test_sanitizers.py)
 _CORE = os.path.join(_HERE, "..", "..", "vlgae_amd", "csrc", "vlg_dp_core.h")
 _lib = None
 
@@ -16,7 +16,7 @@ def lib():
     if _lib is None:
         src = os.path.join(_HERE, "emu_dp.cpp")
         stale = (not os.path.exists(_SO)) or any(os.path.getmtime(f) > os.path.getmtime(_SO) for f in (src, _CORE))
-        if stale:
+        if stale and not os.environ.get("VLG_EMU_SO"):
             os.makedirs(os.path.dirname(_SO), exist_ok=True)
             subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", src, "-o", _SO], check=True)
         _lib = ctypes.CDLL(_SO)

@@ -143,13 +143,15 @@ def test_bench_train_step_workload_sharded_dry_run():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "configs[4]" in out["config"]["workload"]
     assert out["config"]["global_batch"] == 512 and out["config"]["parallelism"] == "dp2"
     comm = out["comm"]
-    assert comm["rccl_ranks_seen"] == 2 and comm["backend"] == "gloo" and comm["buckets"] == 2
-    assert comm["allreduce_bytes"] == 12_000_000 and out["config"]["allreduce_floats"] == 3_000_000
-    # the head bucket (launched last) carries slot 0 + the 2 179 712 real leaf-gradient floats; the tail is the rest
-    (t0, t1), (h0, h1) = comm["bucket_bounds"]
-    assert h0 == 0 and h1 >= 2_179_713 and (t0, t1) == (h1, 3_000_000)
-    chk = comm["sum_over_ranks_check"]
-    assert chk["slot0"] == chk["expected"] == 2 * 256 * 40
+    assert comm["rccl_ranks_seen"] == 2 and comm["backend"] == "gloo" and comm["buckets"] == 3
+    assert comm["allreduce_bytes"] == out["config"]["allreduce_floats"] * 4 and out["config"]["allreduce_floats"] >= 3_000_000
+    # three buckets in readiness order: the arc encoder's (w1 | w2 | b), the parser's feed-forwards, then the encoders / LayerNorm /
+    # pre-matching projection + the check slot + filler; together they tile the buffer
+    b0, b1, b2 = comm["bucket_bounds"]
+    assert b0 == [0, 128 ** 3 + 128 * 128 + 128] and b1[0] == b0[1] and b2[0] == b1[1] and b2[1] == out["config"]["allreduce_floats"]
+    assert comm["bucket_contents"][0] == ["w1", "w2", "b"] and "w_vis" in comm["bucket_contents"][2]
+    chk = comm["mean_over_ranks_check"]
+    assert chk["slot"] == chk["expected"] == 256 * 40        # DDP averages: the mean of the two ranks' word counts
     assert out["value"] > 0 and out["step_ms"] > 0 and out["compute_ms"] > 0 and comm["allreduce_ms"] > 0
 
 
@@ -161,7 +163,7 @@ def test_bench_dp_line_carries_the_sharded_train_step():
                       "--cpu-seconds", "0"], {})
     ts = out["train_step_sharded"]
     assert "error" not in ts, ts
-    assert ts["comm"]["rccl_ranks_seen"] == 2 and ts["comm"]["buckets"] == 2 and ts["value"] > 0
+    assert ts["comm"]["rccl_ranks_seen"] == 2 and ts["comm"]["buckets"] == 3 and ts["value"] > 0
 
 
 def _bucket_worker(rank, world, port, out_dir):
@@ -172,7 +174,7 @@ def _bucket_worker(rank, world, port, out_dir):
     vdist.init_from_env(backend="gloo")
     ok = True
     for numel, nb, head in ((1000, 2, 10), (1000, 3, 700), (7, 4, 3), (5, 1, 5), (64, 2, 64)):
-        red = vdist.BucketedGradReducer(numel, torch.device("cpu"), n_buckets=nb, head=head)
+        red = vdist.BucketedGradReducer(numel, torch.device("cpu"), n_buckets=nb, head=head, average=(numel != 7))
         # the buckets tile [0, numel) exactly once; the head sits in the bucket that is launched last
         cover = sorted(red.bounds)
         ok &= cover[0][0] == 0 and cover[-1][1] == numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
@@ -183,15 +185,24 @@ def _bucket_worker(rank, world, port, out_dir):
             for i in range(red.n_buckets):
                 red.launch(i)
         red.wait()
-        want = torch.arange(numel, dtype=torch.float32) * 2 * sum(r + 1 for r in range(world))
-        ok &= bool(torch.equal(red.flat, want))
+        # DDP semantics by default: the MEAN over ranks (one case asks for the plain sum)
+        want = torch.arange(numel, dtype=torch.float32) * 2 * sum(r + 1 for r in range(world)) / (1 if numel == 7 else world)
+        ok &= bool(torch.allclose(red.flat, want, rtol=1e-6, atol=0))
+    # explicit bounds in launch order (what tools/bench_train.py passes): must tile the buffer
+    red = vdist.BucketedGradReducer(10, torch.device("cpu"), bounds=[(0, 4), (4, 6), (6, 10)])
+    ok &= red.n_buckets == 3 and red.bounds == [(0, 4), (4, 6), (6, 10)]
+    try:
+        vdist.BucketedGradReducer(10, torch.device("cpu"), bounds=[(0, 4), (5, 10)])
+        ok = False
+    except ValueError:
+        pass
     np.save(os.path.join(out_dir, f"bucket{rank}.npy"), np.array([int(ok)]))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(180)
-def test_bucketed_reducer_tiles_the_buffer_and_sums_over_ranks(tmp_path):
+def test_bucketed_reducer_tiles_the_buffer_and_averages_over_ranks(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for rank in range(world):

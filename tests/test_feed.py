@@ -57,6 +57,11 @@ def test_sampler_properties_and_rank_sharding():
         dealt = [tuple(b) for r in range(per) for s in shards for b in [s[r]]]      # round-robin order = the padded epoch list
         assert dealt[:len(whole)] == [tuple(b) for b in whole]
         assert dealt[len(whole):] == [tuple(b) for b in whole[:per * world - len(whole)]]
+    # fewer batches than ranks: the wrap is cyclic, so every rank still gets a batch
+    world = 3 * len(whole) + 1
+    shards = [list(_sampler(g, rank=r, world_size=world)) for r in range(world)]
+    assert all(len(s) == 1 for s in shards)
+    assert [tuple(s[0]) for s in shards] == [tuple(whole[i % len(whole)]) for i in range(world)]
 
 
 @pytest.mark.parametrize("seed", range(6))

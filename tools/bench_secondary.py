@@ -340,9 +340,12 @@ def round3_entries(B, L, dtype, dev, g):
     return res
 
 
-def train_step_entry(B, L, V, dtype, dev, with_scorer=True):
+def train_step_entry(B, L, V, dtype, dev, wiring="reference"):
+    """configs[4]: tools/train_step.build -- the function tests/test_gpu_parity.py::test_training_step_reference_wiring pins on
+    fixtures made by the reference's own methods -- eager and as one captured HIP graph.  wiring="r3": round 3's chain (bench
+    continuity only; it is not what the reference wires)."""
     import train_step
-    step = train_step.build(B, L, V, dev, dtype=dtype, with_scorer=with_scorer)
+    step = train_step.build(B, L, V, dev, dtype=dtype, wiring=wiring)
     for _ in range(5):
         step()
 
@@ -355,13 +358,20 @@ def train_step_entry(B, L, V, dtype, dev, with_scorer=True):
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t0) / n * 1e3, (t1 - t0) / n * 1e3
     eager_ms, enqueue_ms = wall(step, 30)
-    res = {"eager_ms": eager_ms, "host_enqueue_ms": enqueue_ms,
-           "what": ("score construction (ldndmv.py:184-209) -> " if with_scorer else "[potentials: synthetic constants] ") +
-                   "attention_fuse -> lang_feat_max_tree (DMV1o marginals || one Viterbi pass, root row, word|child|parent encoders "
-                   "as one GEMM, arc encoder) -> alignment maxima + grounding cross-entropy -> -DMV1o.max (viterbi_training) -> "
-                   "gradients to every feature / weight / scorer input "
-                   f"(tools/train_step.py; joint.py:235-292,406-491,658-675; ldndmv.py:184-209,277-281), B={B} L={L} V={V} d=128 h=256, "
-                   "synthetic encoder features (frozen BERT / Faster-RCNN weights are not in the container)",
+    if wiring == "reference":
+        what = ("one training step as the reference wires it (base.py:215-241, joint.py:658-711, ldndmv.py:171-216,260-285, fn.py:50-56): "
+                "vis_mlp_pre_matching -> lang_feat_word_only -> attention fuse -> [fused x] context mean + the parser's feed-forwards "
+                "(head_ff / mid_ff / scorer projections: torch library ops, E=800 H=256 n_bottleneck=150 r=16) -> score construction -> "
+                "[un-fused x] lang_feat_max_tree (DMV1o marginals || one Viterbi pass, word|child|parent encoders with SharedDropout p=0.33 "
+                "drawn per step, arc encoder) -> alignment maxima with the POS prior + grounding cross-entropies (ragged vis_mask) -> "
+                "-DMV1o.max -> 0.5 mt + 0.5 dep -> / num_token -> gradients to every input feature and parameter")
+    else:
+        what = ("ROUND 3's chain (not the reference's wiring: fused x into lang_feat_max_tree, scorer inputs / vis_feat / fuse word "
+                "features as leaves, no prior / dropout / alpha): score construction -> attention_fuse -> lang_feat_max_tree -> "
+                "grounding loss -> -DMV1o.max -> gradients")
+    res = {"eager_ms": eager_ms, "host_enqueue_ms": enqueue_ms, "wiring": wiring,
+           "what": what + f" (tools/train_step.py), B={B} L={L} V={V} d=128 h=256, synthetic encoder outputs (frozen BERT / Faster-RCNN "
+                          "weights are not in the container)",
            "sentences_per_s_eager": B / (eager_ms * 1e-3)}
     gr = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream(device=dev)
@@ -378,12 +388,29 @@ def train_step_entry(B, L, V, dtype, dev, with_scorer=True):
     res.update(graph_ms=graph_ms, sentences_per_s_graph=B / (graph_ms * 1e-3),
                note="graph replay has no host work between kernels: graph_ms is the device time of the chain; "
                     "eager_ms - graph_ms is what the Python / autograd host path still costs")
-    if with_scorer:   # rounds 1-2 timed the chain with the potentials as constants of the step: the comparable figure
+    if wiring == "reference":
         del gr, step
-        try:
-            c = train_step_entry(B, L, V, dtype, dev, with_scorer=False)
-            res["potentials_as_constants"] = {"graph_ms": c["graph_ms"], "eager_ms": c["eager_ms"],
-                                              "what": "the same chain without the score construction (round 2's definition of the entry)"}
+        try:   # the device time of the out-of-scope torch glue alone (the parser's feed-forwards, forward + backward), for the breakdown
+            res["parser_feed_forward_torch_ms"] = parser_ff_ms(B, L, dtype, dev)
         except Exception as e:
-            res["potentials_as_constants"] = {"error": repr(e)[:200]}
+            res["parser_feed_forward_torch_ms"] = {"error": repr(e)[:200]}
+        try:
+            c = train_step_entry(B, L, V, dtype, dev, wiring="r3")
+            res["round3_chain"] = {"graph_ms": c["graph_ms"], "eager_ms": c["eager_ms"], "what": c["what"]}
+        except Exception as e:
+            res["round3_chain"] = {"error": repr(e)[:200]}
     return res
+
+
+def parser_ff_ms(B, L, dtype, dev, E=800, h=256, Et=32, T=45, H=256, nb=150, r=16):
+    import train_step
+    g = torch.Generator().manual_seed(3)
+    P = train_step.init_feed_forward(g, dev, dtype, E, h, Et, T, H, nb, r)
+    emb = torch.randn(B, L, E, generator=g).to(dev, dtype).requires_grad_(True)
+    x = torch.randn(B, L, h, generator=g).to(dev, dtype).requires_grad_(True)
+    leaves = [emb, x] + list(P.values())
+
+    def run():
+        outs = train_step.scorer_feed_forward(P, emb, x)
+        torch.autograd.grad([o.float().sum() for o in outs], leaves, allow_unused=True)
+    return timed(run, 20, dev)

@@ -1,17 +1,19 @@
-"""bench.py --workload train_step: the chained training-step hot path (BASELINE.json configs[4]) sharded data-parallel.
+"""bench.py --workload train_step: one training step (BASELINE.json configs[4], tools/train_step.py in the reference's wiring) sharded
+data-parallel.
 
-Every rank builds its own shard of the step (tools/train_step.py: B sentences / GPU, rank-specific synthetic batch --
-the `ConstantTokenNumSampler(rank=, world_size=)` arrangement: rank r takes batches r, r+W, ...), runs forward +
-backward, packs the step's real leaf gradients of the trainable weights at the head of a flat fp32 buffer padded to the
-VLGAE model's gradient (--grad-mb, ~7 M fp32 = 28 MB) and all-reduces it over RCCL with synchronous-SGD
-semantics -- every bucket is complete (stream-wise) before the next step's first kernel, as under Lightning DDP
-(/root/reference config/trainer/train.yaml:27-29, src/pipeline.py:112-126).  The buffer goes in `--buckets` pieces:
-the tail piece(s) -- the stand-in for parameters whose gradients are complete once the DP and grounding-loss adjoints
-have run (the scorer / matching heads: DDP's first buckets) -- start reducing from a hook inside the backward pass and
-overlap the arc-encoder / projection / attention-fuse adjoints; the head piece (the real leaf gradients) goes last.
+Every rank builds its own shard of the step (B sentences / GPU, rank-specific synthetic batch -- the
+`ConstantTokenNumSampler(rank=, world_size=)` arrangement: rank r takes batches r, r+W, ...), runs forward + backward and all-reduces a
+flat fp32 gradient of the VLGAE model's size (--grad-mb, ~7 M fp32 = 28 MB) over RCCL with synchronous-SGD semantics and
+DDP's averaging -- every bucket is complete (stream-wise) before the next step's first kernel, as under Lightning DDP (/root/reference
+config/trainer/train.yaml:27-29, src/pipeline.py:112-126).  The REAL gradients of the step's parameters (arc encoder, the parser's
+feed-forwards and scorers, LayerNorm, word | child | parent encoders, vis_mlp_pre_matching: ~3.4 M floats) sit in `--buckets` pieces in
+the order they become final during the backward pass (tools/train_step.py `ready_groups`), and a piece starts reducing from a leaf hook
+the moment its last gradient exists, overlapping the adjoints still to run.  The rest of the buffer is filler for the parameters upstream
+of the encoder outputs the step starts from (embedding / encoder MLP): their backward is not part of the step, so they ride in the LAST
+piece, where nothing overlaps them.
 
-Reported: value (sentences/s, whole job), step_ms (with the collective), compute_ms (same step, no collective),
-allreduce_ms (the buckets alone, back to back), overlap_frac = 1 - (step_ms - compute_ms) / allreduce_ms.
+Reported: value (sentences/s, whole job), step_ms (with the collectives), compute_ms (same step, no collective),
+allreduce_ms (the pieces alone, back to back), overlap_frac = 1 - (step_ms - compute_ms) / allreduce_ms.
 """
 import os
 import sys
@@ -24,29 +26,68 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
-TRAINABLE = ("b", "b_enc", "ln_b", "ln_w", "w1", "w2", "w_enc")   # leaves of train_step.build that are parameters
+FF_SHAPES = dict(E=800, h=256, Et=32, T=45, H=256, nb=150, r=16)   # the parser's feed-forwards at the shipped widths (vlgae.yaml)
+
+
+def _param_shapes(d=128, h=256):
+    """name -> shape of every trainable leaf of train_step.build(wiring="reference"), and the readiness groups (no GPU needed)."""
+    f = FF_SHAPES
+    shapes = dict(b=(d,), b_enc=(3 * d,), ln_b=(h,), ln_w=(h,), w1=(d, d, d), w2=(d, d), w_enc=(3 * d, h), w_vis=(d, h),
+                  token_emb=(f["T"], f["Et"]), root_emb=(1, 10), dec_emb=(2, 10))
+
+    def lin(name, n_in, n_out):
+        shapes[name + ".weight"], shapes[name + ".bias"] = (n_out, n_in), (n_out,)
+    for name, n_in in (("head_ff", f["E"] + f["h"]), ("child_ff", f["Et"]), ("root_ff", 10), ("dec_ff", 10)):
+        lin(f"ff.{name}.linear", n_in, f["H"])
+    for name in ("HASCHILD_linear", "NOCHILD_linear", "LEFT_linear", "RIGHT_linear"):
+        lin(f"ff.mid_ff.{name}.0", f["H"], f["nb"])
+        lin(f"ff.mid_ff.{name}.1", f["nb"], f["H"])
+    for name in ("valence_linear", "direction_linear", "linear1", "linear2"):
+        lin(f"ff.mid_ff.{name}", f["H"], f["H"])
+    for name in ("attach_scorer", "dec_scorer", "root_scorer"):
+        lin(f"ff.{name}.project1", f["H"], f["r"])
+        lin(f"ff.{name}.project2", f["H"], f["r"])
+    ff_names = sorted(k for k in shapes if k.startswith("ff.") or k in ("token_emb", "root_emb", "dec_emb"))
+    return shapes, (["w1", "w2", "b"], ff_names, ["ln_w", "ln_b", "w_enc", "b_enc", "w_vis"])
 
 
 class _DryStep:
-    """CPU stand-in for the launcher / collective plumbing tests (VLGAE_BENCH_DRYRUN=1): no kernels, fixed fake gradients."""
+    """CPU stand-in for the launcher / collective plumbing tests (VLGAE_BENCH_DRYRUN=1): no kernels, fixed fake gradients handed to
+    `on_grad` in the readiness order of the real step."""
 
-    def __init__(self, B, L, d=128, h=256):
-        shapes = dict(b=(d,), b_enc=(3 * d,), ln_b=(h,), ln_w=(h,), w1=(d, d, d), w2=(d, d), w_enc=(3 * d, h))
-        self.grads = {k: torch.ones(s) for k, s in shapes.items()}
+    def __init__(self, B, L):
+        self.shapes, self.ready_groups = _param_shapes()
+        self.grads = {k: torch.ones(s) for k, s in self.shapes.items()}
         self.lengths = torch.full((B,), L, dtype=torch.long)
+        self.trainable = tuple(sorted(self.shapes))
+        self.on_grad = None
 
     def __call__(self, stage_hook=None):
         if stage_hook is not None:
             stage_hook()
+        for group in self.ready_groups:
+            for k in group:
+                if self.on_grad is not None:
+                    self.on_grad(k, self.grads[k])
         return torch.zeros(()), self.grads, ()
 
 
 def measure(args, rank, world, dev, dry, barrier):
     """Runs the sharded train step; returns the result dict on every rank (rank 0 prints it).  Backward runs on the calling
-    thread (one process per GPU has no use for torch's per-device engine thread): the bucket hook then
-    issues its collective from the same thread, on the same current stream, as every kernel of the step."""
+    thread (one process per GPU has no use for torch's per-device engine thread): the bucket hooks then
+    issue their collectives from the same thread, on the same current stream, as every kernel of the step."""
     with torch.autograd.set_multithreading_enabled(False):
         return _measure(args, rank, world, dev, dry, barrier)
+
+
+def _all_ranks_ok(ok, world, dev, dry):
+    """Every rank learns whether EVERY rank got this far, before any timed collective: a rank that failed to build its step would
+    otherwise leave the others hanging inside an all-reduce."""
+    if world <= 1:
+        return ok
+    flag = torch.tensor([1.0 if ok else 0.0], device="cpu" if dry else dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0.5)
 
 
 def _measure(args, rank, world, dev, dry, barrier):
@@ -54,41 +95,61 @@ def _measure(args, rank, world, dev, dry, barrier):
     import train_step
     B, L, V = args.batch, args.L, args.regions
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    if dry:
-        step = _DryStep(B, L)
-    else:
-        step = train_step.build(B, L, V, dev, dtype=dtype, seed=11 + rank)
-    n_real = sum(int(torch.Size(s).numel()) for s in
-                 (dict(b=(128,), b_enc=(384,), ln_b=(256,), ln_w=(256,), w1=(128, 128, 128), w2=(128, 128), w_enc=(384, 256)).values()))
-    head = 1 + n_real                                  # slot 0: this rank's word count (the sum-over-ranks check)
-    n_model = max(head, int(args.grad_mb * 1e6 / 4))
-    red = vdist.BucketedGradReducer(n_model, dev, n_buckets=args.buckets, head=head)
+    step, err = None, None
+    try:
+        if dry:
+            step = _DryStep(B, L)
+        else:
+            step = train_step.build(B, L, V, dev, dtype=dtype, seed=11 + rank, **FF_SHAPES)
+            step()                                         # one untimed step: every kernel and allocation path exercised
+    except Exception as e:                                 # noqa: BLE001 -- reported on every rank below
+        err = e
+    if not _all_ranks_ok(err is None, world, dev, dry):
+        raise RuntimeError(f"train_step could not be built on every rank (this rank: {err!r})")
+    shapes = {k: tuple(step.P[k].shape) for k in step.trainable} if not dry else step.shapes
+    # ---- the flat gradient: [ group 0 | group 1 | ... | slot 0 = word count | last group | filler up to the model's size ] ----
+    n_b = max(1, min(args.buckets, len(step.ready_groups)))
+    groups = [list(gp) for gp in step.ready_groups[:n_b - 1]] + [[k for gp in step.ready_groups[n_b - 1:] for k in gp]]
+    numel = lambda k: int(torch.Size(shapes[k]).numel())
+    offsets, bounds, o = {}, [], 0
+    for gi, gp in enumerate(groups):
+        lo = o
+        if gi == len(groups) - 1:
+            o += 1                                          # slot `check`: this rank's word count (the mean-over-ranks check)
+        for k in gp:
+            offsets[k] = o
+            o += numel(k)
+        bounds.append([lo, o])
+    n_real = o - 1
+    n_model = max(o, int(args.grad_mb * 1e6 / 4))
+    bounds[-1][1] = n_model                                 # filler: see json_line / DESIGN.md section 4
+    red = vdist.BucketedGradReducer(n_model, dev, bounds=[tuple(b) for b in bounds], average=True)
+    check = bounds[-1][0]
+    views = {k: red.flat[off:off + numel(k)] for k, off in offsets.items()}
+    group_of = {k: gi for gi, gp in enumerate(groups) for k in gp}
     words_local = float(step.lengths.sum().item())
-    head_view = red.head_view
     sync = (lambda: None) if dry else (lambda: torch.cuda.synchronize(dev))
+    pending = [0] * len(groups)
+    state = {"comm": False}
 
-    def early():                                       # inside the backward pass: start the tail bucket(s)
-        for i in range(red.n_buckets - 1):
-            red.launch(i)
+    def on_grad(name, g):                                  # inside the backward pass: the gradient of `name` is final
+        views[name].copy_(g.reshape(-1))                   # cast to fp32 in the copy
+        gi = group_of[name]
+        pending[gi] -= 1
+        if pending[gi] == 0 and state["comm"]:
+            if gi == len(groups) - 1:
+                red.flat[check:check + 1].fill_(words_local)
+            red.launch(gi)
+    step.on_grad = on_grad
 
-    def pack(grads):
-        head_view[0:1].fill_(words_local)
-        o = 1
-        for k in TRAINABLE:
-            g = grads[k]
-            n = g.numel()
-            head_view[o:o + n].copy_(g.reshape(-1))    # cast to fp32 in the copy
-            o += n
-
-    def step_comm():
-        red.wait()                                     # synchronous SGD: last step's reduced gradient before this step's first kernel
-        _, grads, _ = step(early)
-        pack(grads)
-        red.launch(red.n_buckets - 1)
-
-    def step_compute():
-        _, grads, _ = step(None)
-        pack(grads)
+    def run(comm):
+        state["comm"] = comm
+        for gi, gp in enumerate(groups):
+            pending[gi] = len(gp)
+        if comm:
+            red.wait()                                     # synchronous SGD: last step's reduced gradient before this step's first kernel
+        step(None)
+        assert not any(pending), pending                   # every parameter's gradient arrived through its hook
 
     def timed(fn, tail=None):
         for _ in range(args.warmup):
@@ -109,7 +170,7 @@ def _measure(args, rank, world, dev, dry, barrier):
             el = float(tt.item())
         return el
 
-    el_compute = timed(step_compute)
+    el_compute = timed(lambda: run(False))
     res = {}
     if world > 1:
         def ar_only():
@@ -126,22 +187,28 @@ def _measure(args, rank, world, dev, dry, barrier):
         barrier()
         ar_s = (time.perf_counter() - t0) / n_ar
         red.flat.zero_()
-        el = timed(step_comm, tail=red.wait)
+        el = timed(lambda: run(True), tail=red.wait)
         sync()
-        # the reduced buffer must be the sum over ranks: slot 0 carries every rank's word count
+        # the reduced buffer must be the MEAN over ranks (DDP's semantics): the check slot carries every rank's word count
         tot = torch.tensor([words_local], dtype=torch.float64, device=dev)
         dist.all_reduce(tot)
-        got = float(red.head_view[0].item())
-        assert abs(got - float(tot.item())) <= 1e-3 * float(tot.item()), (got, float(tot.item()))
+        got = float(red.flat[check].item())
+        want = float(tot.item()) / world
+        assert abs(got - want) <= 1e-3 * want, (got, want)
         step_ms, compute_ms, ar_ms = el * 1e3 / args.steps, el_compute * 1e3 / args.steps, ar_s * 1e3
         res["comm"] = {"backend": dist.get_backend(), "rccl_ranks_seen": vdist.warm_up(dev),
                        "allreduce_ms": ar_ms, "allreduce_bytes": n_model * 4, "buckets": red.n_buckets,
-                       "bucket_bounds": red.bounds,
+                       "bucket_bounds": red.bounds, "bucket_contents": [gp if len(gp) <= 6 else gp[:3] + [f"... {len(gp) - 3} more"] for gp in groups],
                        "allreduce_busbw_GBs": 2.0 * (world - 1) / world * n_model * 4 / ar_s / 1e9,
                        "overlap_frac": max(0.0, min(1.0, 1.0 - (step_ms - compute_ms) / ar_ms)) if ar_ms > 0 else None,
-                       "sum_over_ranks_check": {"slot0": got, "expected": float(tot.item())},
-                       "semantics": "synchronous SGD: every bucket of step k is reduced (stream-ordered) before step k+1's "
-                                    "first kernel; tail bucket(s) start from a hook inside the backward pass"}
+                       "mean_over_ranks_check": {"slot": got, "expected": want},
+                       "semantics": "synchronous SGD, gradients AVERAGED over ranks (DDP): every bucket of step k is reduced "
+                                    "(stream-ordered) before step k+1's first kernel; a bucket starts from inside the backward pass "
+                                    "the moment the last of ITS parameters' gradients exists (leaf hooks)",
+                       "payload": f"{n_real} real gradient floats of the parameters on the step's path, in readiness order; the "
+                                  f"remaining {n_model - n_real - 1} floats of the last bucket are FILLER standing for the model's parameters "
+                                  "upstream of the encoder outputs this step starts from (their backward compute is not part of the "
+                                  "step, so nothing overlaps them: they go last, as their gradients would)"}
     else:
         el = el_compute
         step_ms = compute_ms = el * 1e3 / args.steps
@@ -157,10 +224,11 @@ def json_line(args, world, res, dry, share=False):
            "ms_per_step": res["step_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype,
            "data": "synthetic" if not dry else "DRY RUN: no kernels ran (launcher / collective plumbing on CPU, gloo); not a measurement",
-           "config": {"workload": "attention-fuse -> projections -> DMV1o marginals + Viterbi heads -> arc encoder -> alignment "
-                                  "maxima + grounding cross-entropy -> -DMV1o.max -> gradients (tools/train_step.py), "
-                                  f"B={B}/GPU L={L} V={V} d=128 h=256, {args.dtype} features, synthetic encoder outputs; "
-                                  "BASELINE.json configs[4]",
+           "config": {"workload": "one training step as the reference wires it (tools/train_step.py, pinned on reference-made fixtures): "
+                                  "attention fuse -> parser feed-forwards -> score construction -> DMV1o marginals + Viterbi heads -> "
+                                  "word | child | parent encoders + arc encoder -> alignment maxima + grounding cross-entropy -> "
+                                  f"-DMV1o.max -> 0.5/0.5 -> gradients; B={B}/GPU L={L} V={V} d=128 h=256, {args.dtype} features, "
+                                  "synthetic encoder outputs; BASELINE.json configs[4]",
                       "global_batch": B * world, "seq_len": L,
                       "parallelism": (f"dp{world}" if world > 1 else "single") + (" (DEBUG: ranks share one GPU, gloo)" if share else ""),
                       "allreduce_floats": res["allreduce_floats"]},

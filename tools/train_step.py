@@ -234,6 +234,15 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
 
     step.names, step.P, step.lengths, step.wiring = names, P, lengths, wiring
     step.trainable = tuple(k for k in names if k not in ("enc_x", "emb", "vis_mid"))
+    # Parameters in the order their gradients become FINAL during the backward pass (autograd runs the later-created node first:
+    # -max, grounding loss, lang_feat_max_tree | score construction, the parser's feed-forwards | attention fuse, word-only encoder,
+    # vis_mlp_pre_matching): what a data-parallel trainer's buckets follow.  `step.on_grad(name, grad)`, if set, is called from
+    # inside the backward pass the moment a parameter's (accumulated) gradient exists.
+    ff_names = [k for k in names if k.startswith("ff.") or k in ("token_emb", "root_emb", "dec_emb")]
+    step.ready_groups = (["w1", "w2", "b"], ff_names, ["ln_w", "ln_b", "w_enc", "b_enc", "w_vis"])
+    step.on_grad = None
+    for k in step.trainable:
+        P[k].register_hook(lambda g_, k=k: step.on_grad(k, g_) if step.on_grad is not None else None)
     return step
 
 

@@ -1267,7 +1267,7 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
     // positions wanted: both products on the matrix cores (172 vs 267 us at config-2).  The maxima alone stay with align_max_kernel:
     // without the searches that one is not vector-ALU bound, and the second product only costs (ARGS = false measured: 149 vs 130 us)
     if constexpr (ARGS) {
-        if (!getenv("VLG_ALIGN_ARGMAX_OLD")) {   // (the env switch: tools/ A-B timing only)
+        if (!VLG_ENV("VLG_ALIGN_ARGMAX_OLD")) {   // (the env switch: tools/ A-B timing only)
             if (out_maxQ)
 #define VLG_AAM(HQ, MU)                                                                                                       \
     hipLaunchKernelGGL((align_argmax_kernel<HQ, true, MU>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask, \
@@ -1893,7 +1893,7 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
                                                           out_diag, s, AlignArgs{nullptr, nullptr, 0, nullptr, nullptr}, true);
     }
     // (eight waves' output blocks of 96 x V floats next to the 24 KB image tiles: V <= 44 fits the 160 KB LDS)
-    if (!f32in && d == 128 && out_full && !out_maxV && !out_maxQ && !out_diag && V <= 44 && V % 4 == 0 && !getenv("VLG_ALIGN_FULL_OLD"))
+    if (!f32in && d == 128 && out_full && !out_maxV && !out_maxQ && !out_diag && V <= 44 && V % 4 == 0 && !VLG_ENV("VLG_ALIGN_FULL_OLD"))
         return launch_align_full(txt, vis, tmask, vmask, B, A, Q, V, neg_inf, out_full, s);   // stores straight from the accumulators
     if (!f32in && d == 128) { VLG_MFMA(false, 4); }
     if (!f32in && d == 64) { VLG_MFMA(false, 2); }
@@ -1925,11 +1925,11 @@ int vlg_bilinear_align(const void* txt, const void* vis, const uint8_t* tmask, c
 
 // bf16 features, d = 128, at most 96 rows and 96 contraction positions per pair: the split-term path on the bf16 matrix cores
 static bool bwd_split_ok(int in_dtype, int d, int M, int K) {
-    return (in_dtype == VLG_BF16 || (in_dtype == VLG_F32 && !getenv("VLG_BWD_F32_EXACT"))) && d == 128 && M <= 96 && K <= 96;
+    return (in_dtype == VLG_BF16 || (in_dtype == VLG_F32 && !VLG_ENV("VLG_BWD_F32_EXACT"))) && d == 128 && M <= 96 && K <= 96;
 }
 
 // caption side, two pairs per step on one concatenated scratch: short quad-aligned contraction
-static bool bwd_concat_ok(int K) { return (K & 3) == 0 && K >= 4 && 2 * K <= 96 && !getenv("VLG_BWD_NOCONCAT"); }
+static bool bwd_concat_ok(int K) { return (K & 3) == 0 && K >= 4 && 2 * K <= 96 && !VLG_ENV("VLG_BWD_NOCONCAT"); }
 static size_t bwd_concat_pitch(int O, int K) { return ((size_t)O * K + 96 + 7) / 8 * 8; }
 
 size_t vlg_bilinear_align_backward_workspace(int B, int A, int Q, int V, int d, int in_dtype) {
@@ -1974,10 +1974,10 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
             hipLaunchKernelGGL(align_bwd_transpose_kernel<uint16_t>, dim3(O, Kp / 32), dim3(256), 0, s, (const uint16_t*)feat, km, K, Kp,
                                featT, (uint16_t*)nullptr);
         // bf16 features: two fixed indices per workgroup share each staged feature tile (12 waves, one block per CU)
-        const int nf = (!f32feat && fixn >= 64 && !getenv("VLG_BWD_NF1")) ? 2 : 1;
+        const int nf = (!f32feat && fixn >= 64 && !VLG_ENV("VLG_BWD_NF1")) ? 2 : 1;
         int split = 1;   // the chip covered at least once; two-addend atomics are order-free
         if ((long)fixn * 2 <= 1024 * nf && O >= 16) split = 2;
-        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;
+        if (const char* e = VLG_ENV("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;
         const int opb = (O + split - 1) / split;
         if (split > 1) {
             hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)fixn * M * 128, s);
@@ -2020,7 +2020,7 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
         // order-free (a + b == b + a; three or more are not associative in fp32): the split stops at 2 -- bit-reproducible
         int split = 1;
         if ((long)gx * fixn < 768 && O / 2 >= 16) split = 2;
-        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;   // tools/ experiments only
+        if (const char* e = VLG_ENV("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;   // tools/ experiments only
         const int opb = (O + split - 1) / split;
         if (split > 1) {
             hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)fixn * M * d, s);
@@ -2057,9 +2057,9 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
         const long pitch = (long)bwd_concat_pitch(A, V);
         hipLaunchKernelGGL(align_bwd_concat_transpose_kernel, dim3((unsigned)((pitch + 31) / 32)), dim3(256), 0, s, (const uint16_t*)vis,
                            vmask, A * V, pitch, visT);
-        const int nf = (B >= 64 && !getenv("VLG_BWD_NF1")) ? 2 : 1;
+        const int nf = (B >= 64 && !VLG_ENV("VLG_BWD_NF1")) ? 2 : 1;
         int split = ((long)B * 2 <= 1024 * nf && A >= 16) ? 2 : 1;
-        if (const char* e = getenv("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;
+        if (const char* e = VLG_ENV("VLG_BWD_SPLIT")) split = atoi(e) >= 2 ? 2 : 1;
         const int opb = ((A + split - 1) / split + 1) & ~1;   // even: a step's tile rows start on 16-byte boundaries of featC
         if (split > 1) {
             hipError_t e = hipMemsetAsync(grad_txt, 0, sizeof(float) * (size_t)B * Q * 128, s);
@@ -2125,7 +2125,7 @@ int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, c
              : launch_align_mfma<F32, KCHV, true, true, VLG_GA_RTB>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr,               \
                                                                     wsf + p.off_maxV, wsf + p.off_maxQ, nullptr, s, xa)
     // shared image tiles: align_argmax_kernel, any number of region groups (VLG_ALIGN_ARGMAX_OLD: the round-2 kernel for V <= 48)
-    if (!f32in && d == 128 && (V <= kAMRows || !getenv("VLG_ALIGN_ARGMAX_OLD")) && !getenv("VLG_GROUND_OLD_ALIGN"))
+    if (!f32in && d == 128 && (V <= kAMRows || !VLG_ENV("VLG_ALIGN_ARGMAX_OLD")) && !VLG_ENV("VLG_GROUND_OLD_ALIGN"))
         rc = launch_align_max<true>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, wsf + p.off_maxV, wsf + p.off_maxQ, s, xa);
     else if (!f32in && d == 128) VLG_GA(false, 4);
     else if (!f32in && d == 64) VLG_GA(false, 2);
@@ -2175,7 +2175,7 @@ int vlg_align_reduced(const void* txt, const void* vis, const uint8_t* tmask, co
                                                                    wsf + p.off_maxV, nullptr, nullptr, s, xa)                      \
              : launch_align_mfma<F32, KCHV, true, true, 3>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, nullptr, wsf + p.off_maxV, \
                                                            nullptr, nullptr, s, xa)
-    if (!f32in && d == 128 && (V <= kAMRows || !getenv("VLG_ALIGN_ARGMAX_OLD")) && !getenv("VLG_GROUND_OLD_ALIGN"))   // row maxima + positions only
+    if (!f32in && d == 128 && (V <= kAMRows || !VLG_ENV("VLG_ALIGN_ARGMAX_OLD")) && !VLG_ENV("VLG_GROUND_OLD_ALIGN"))   // row maxima + positions only
         rc = launch_align_max<true>(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, wsf + p.off_maxV, nullptr, s, xa);
     else if (!f32in && d == 128) VLG_RA(false, 4);
     else if (!f32in && d == 64) VLG_RA(false, 2);

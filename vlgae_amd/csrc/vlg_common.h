@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/vlgae_amd.h"
 
@@ -20,6 +21,10 @@ inline int set_error(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// Environment switches (tools/ A-B timing only) are read ONCE per call site: getenv walks the whole environment and is not
+// something a launch path should do on every invocation.  Each expansion owns its function-local static.
+#define VLG_ENV(name) ([]() -> const char* { static const char* const v_ = getenv(name); return v_; }())
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -1300,7 +1300,7 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
         return (size_t)(kGdD + mt * 16) * (pp * Kp * 2 + 32) + (size_t)kGdChunk * (mt * 16 + Kp) * (2 + 4);
     };
     // config-2's widths: producer / consumer wavefronts, one block per caption / image, written once (ground_bwd_ws_kernel)
-    const bool ws_ok = !wide && !getenv("VLG_GD_OLD");
+    const bool ws_ok = !wide && !VLG_ENV("VLG_GD_OLD");
     auto lds_ws = [](int Kp, int mt, int pp, int uw) {
         const int kt = (pp * uw + 31) / 32 * 32, chp = pp == 3 ? 6 : kGdChunk;
         return 2 * (size_t)(kGdD + mt * 16) * (kt * 2 + 32) + 2 * (size_t)chp * (mt * 16 + Kp) * (2 + 4);
@@ -1316,9 +1316,11 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
 #define VLG_WS0(MTV, RWV)                                                                                              \
     do { if (V <= 40) VLG_WS(0, 2, MTV, RWV, 5, 3, 40, visT, g_txt); else VLG_WS(0, 2, MTV, RWV, 8, 2, 64, visT, g_txt); } while (0)
     const bool both_ws = g_txt && g_vis && ws_ok && V <= 48;
-    if (both_ws)
+    if (both_ws) {
         hipLaunchKernelGGL(ground_transpose2_kernel, dim3(B, KtV / 32 + KpQ / 32), dim3(256), 0, s, (const uint16_t*)vis, V, KtV, visT, KtV / 32,
                            (const uint16_t*)txt, Q, KpQ, txtT);
+        if (int rc = check_launch("ground_transpose2_kernel")) return rc;
+    }
     if (g_txt && ws_ok) {
         if (!both_ws) hipLaunchKernelGGL(ground_transpose_kernel, dim3(B, KtV / 32), dim3(256), 0, s, (const uint16_t*)vis, V, KtV, visT);
         switch ((Q + 15) / 16) {
@@ -1346,7 +1348,7 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
 #undef VLG_WS
     if (!g_txt && !g_vis) return 0;
     int split = B >= 32 ? 2 : 1;   // two blocks per caption / image (two-addend atomics stay order-free)
-    if (const char* e = getenv("VLG_GD_SPLIT")) split = atoi(e);
+    if (const char* e = VLG_ENV("VLG_GD_SPLIT")) split = atoi(e);
     // wide caption side: B blocks x split must cover the chip, and there are B * n_kc step units to share: deeper splits write
     // partial sums (fixed-order reduce), not atomics
     const int n_kc_v = KtV / 128;
@@ -1518,7 +1520,7 @@ int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask
         return Strips{cw, y, sizeof(float) * ((size_t)B * (cw | 1) + kCeTileThreads + 3 * (size_t)cw)};
     };
     const Strips s1 = strips(Q), s2 = strips(V);
-    const bool tiled = s1.lds <= 144 * 1024 && s2.lds <= 144 * 1024 && s1.cw <= kCeTileThreads && s2.cw <= kCeTileThreads && !getenv("VLG_GROUND_CE_OLD");
+    const bool tiled = s1.lds <= 144 * 1024 && s2.lds <= 144 * 1024 && s1.cw <= kCeTileThreads && s2.cw <= kCeTileThreads && !VLG_ENV("VLG_GROUND_CE_OLD");
     // column shares for the streaming kernel: only when B alone leaves CUs idle and there are several 256-column strips
     auto shares = [&](int ncols) {
         const int st = (ncols + kCeThreads - 1) / kCeThreads;
@@ -1537,7 +1539,7 @@ int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask
                 hipError_t e = hipFuncSetAttribute(kp.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kp.second);
                 if (e != hipSuccess) return set_error((int)e, "grounding_loss: hipFuncSetAttribute(%zu): %s", kp.second, hipGetErrorString(e));
             }
-        if (!getenv("VLG_GROUND_CE_SPLIT")) {
+        if (!VLG_ENV("VLG_GROUND_CE_SPLIT")) {
             const size_t lds2 = std::max(s1.lds, s2.lds);
             if (lds2 > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void*)ground_ce_tile2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -1559,7 +1561,7 @@ int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask
                            vmask, tmask, Q, part2);
     }
     hipLaunchKernelGGL(ground_sum_kernel, dim3(1), dim3(64), 0, s, part, part2, B * y1, B * y2, num_token, w_v2t, out_sums, coef);
-    if ((g_txt || g_vis) && in_dtype == VLG_BF16 && d == kGdD && Q <= 96 && V <= 65535 && !getenv("VLG_GROUND_SPARSE")) {
+    if ((g_txt || g_vis) && in_dtype == VLG_BF16 && d == kGdD && Q <= 96 && V <= 65535 && !VLG_ENV("VLG_GROUND_SPARSE")) {
         // bf16 features, d = 128, up to 96 queries: the dense route on the matrix cores
         if (int rc = launch_bwd_dense(txt, vis, mV, aV, mQ, aQ, coef, B, Q, V, reinterpret_cast<uint16_t*>(ws + p.off_featT),
                                       ws + p.off_partial, g_txt, g_vis, s))

@@ -103,34 +103,44 @@ class GradAllReducer:
 
 
 class BucketedGradReducer:
-    """The training step's flat gradient reduced in `n_buckets` contiguous pieces with synchronous-SGD semantics
-    (what Lightning DDP does for the reference, config/trainer/train.yaml:27-29): bucket i's all-reduce is started as
-    soon as its gradients exist (`launch(i)`, asynchronous, on RCCL's own stream, ordered after the kernels already
-    enqueued on the current stream), and `wait()` -- called before the optimizer / the next step -- makes the current
-    stream (not the host) wait for all of them.  Buckets launched early overlap the rest of the backward pass."""
+    """The training step's flat gradient reduced in contiguous pieces with synchronous-SGD semantics (what Lightning DDP does for
+    the reference, config/trainer/train.yaml:27-29): bucket i's all-reduce is started as soon as its gradients exist (`launch(i)`,
+    asynchronous, on RCCL's own stream, ordered after the kernels already enqueued on the current stream), and `wait()` -- called
+    before the optimizer / the next step -- makes the current stream (not the host) wait for all of them.  Buckets launched early
+    overlap the rest of the backward pass.  average=True (default): the reduced buffer holds the MEAN over ranks, as DDP's does
+    (`ReduceOp.AVG` on RCCL; sum, then one division at `wait()` on backends without it)."""
 
-    def __init__(self, numel, device, n_buckets=2, dtype=torch.float32, head=0):
-        """head: number of leading elements that must sit in the LAST bucket's view (the real leaf gradients, which are
-        complete only at the end of the backward pass); the rest of the buffer is dealt evenly."""
+    def __init__(self, numel, device, n_buckets=2, dtype=torch.float32, head=0, bounds=None, average=True):
+        """bounds: explicit [(lo, hi), ...] in LAUNCH order (a partition of [0, numel)).  Otherwise -- head: number of leading
+        elements that must sit in the LAST-launched bucket's view; the rest of the buffer is dealt evenly."""
         self.flat = torch.zeros(numel, dtype=dtype, device=device)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        n_buckets = max(1, min(n_buckets, numel))
-        # last bucket = [0, cut_last) holds the head; earlier buckets split the tail evenly
-        per = -(-numel // n_buckets)
-        last = max(per, head)
-        bounds = [(0, min(last, numel))]
-        rest = numel - bounds[0][1]
-        k = n_buckets - 1
-        lo = bounds[0][1]
-        for i in range(k):
-            hi = lo + (rest // k) + (1 if i < rest % k else 0)
-            if hi > lo:
-                bounds.append((lo, hi))
-            lo = hi
-        # launch order: early buckets first, the head-carrying bucket last
-        self.bounds = bounds[1:] + bounds[:1]
+        self.average = bool(average)
+        self._native_avg = self.average and dist.is_initialized() and dist.get_backend() == "nccl"
+        if bounds is not None:
+            cover = sorted(bounds)
+            if cover[0][0] != 0 or cover[-1][1] != numel or any(a[1] != b[0] for a, b in zip(cover, cover[1:])):
+                raise ValueError(f"bucket bounds {bounds} do not tile [0, {numel})")
+            self.bounds = [tuple(b) for b in bounds]
+        else:
+            n_buckets = max(1, min(n_buckets, numel))
+            # last bucket = [0, cut_last) holds the head; earlier buckets split the tail evenly
+            per = -(-numel // n_buckets)
+            last = max(per, head)
+            bounds = [(0, min(last, numel))]
+            rest = numel - bounds[0][1]
+            k = n_buckets - 1
+            lo = bounds[0][1]
+            for i in range(k):
+                hi = lo + (rest // k) + (1 if i < rest % k else 0)
+                if hi > lo:
+                    bounds.append((lo, hi))
+                lo = hi
+            # launch order: early buckets first, the head-carrying bucket last
+            self.bounds = bounds[1:] + bounds[:1]
         self.views = [self.flat[a:b] for a, b in self.bounds]
         self.handles = []
+        self._launched = []
 
     @property
     def n_buckets(self):
@@ -142,9 +152,15 @@ class BucketedGradReducer:
 
     def launch(self, i):
         if self.world > 1:
-            self.handles.append(dist.all_reduce(self.views[i], op=dist.ReduceOp.SUM, async_op=True))
+            op = dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM
+            self.handles.append(dist.all_reduce(self.views[i], op=op, async_op=True))
+            self._launched.append(i)
 
     def wait(self):
         for h in self.handles:
             h.wait()
+        if self.average and not self._native_avg:
+            for i in self._launched:
+                self.views[i].div_(self.world)
         self.handles = []
+        self._launched = []

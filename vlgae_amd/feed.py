@@ -118,7 +118,7 @@ class ConstantTokenNumSampler:
             # before it is dealt out (rank r takes batches r, r + W, ...), so ranks differ by repeated batches, never by count.
             n_all = len(self._all_batches)
             per = -(-n_all // self.world_size) if n_all else 0
-            padded = self._all_batches + self._all_batches[:per * self.world_size - n_all]
+            padded = [self._all_batches[i % n_all] for i in range(per * self.world_size)]   # cyclic: also when n_all < world_size
             self._batches = padded[self.rank::self.world_size]
         else:
             self._batches = self._all_batches
