@@ -264,11 +264,16 @@ def run(args):
     h = Headline(args, rank, dev, dry)
     B, L, N = h.B, h.L, h.N
 
-    def timed_region(reducer):
-        """W untimed warmup steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
+    def timed_region(reducer, every=1):
+        """W untimed warmup steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.
+        every: DP launches per collective (1: one all-reduce per launch; 3: the reference's ratio -- it enters the DP three times
+        per optimizer step, SURVEY.md section 3.1: lang_feat_max_tree's partition and argmax, the loss's max -- and all-reduces once)."""
+        it = [0]
+
         def step():
             h.launch()
-            if reducer is not None:
+            it[0] += 1
+            if reducer is not None and it[0] % every == 0:
                 h.count_sum(reducer.buffer)
                 reducer.launch()
         for _ in range(args.warmup):
@@ -317,6 +322,8 @@ def run(args):
         elapsed, gpu_ms = timed_region(big)
         small = vdist.GradAllReducer(h.n_grad, dev)
         elapsed_small, _ = timed_region(small)
+        big3 = vdist.GradAllReducer(n_model, dev)
+        elapsed_per3, _ = timed_region(big3, every=3)
         # the reduced counts must be the sum over ranks: every rank's attach counts sum to its word count
         total_words = torch.tensor([float(h.lengths_np.sum())], dtype=torch.float64, device=dev)
         dist.all_reduce(total_words)
@@ -374,9 +381,14 @@ def run(args):
     if world > 1:
         out["value_dp_grad_only"] = B * world * args.steps / elapsed_small
         out["ms_per_step_dp_grad_only"] = elapsed_small * 1e3 / args.steps
-        out["comm"] = dict(comm, note="value: every step all-reduces the model-sized flat gradient (--grad-mb, one RCCL call, "
-                                      "overlapping the next step's kernel); value_dp_grad_only: only the DP's own "
-                                      f"{h.n_grad * 4} B of batch-summed counts")
+        out["value_allreduce_per_3_launches"] = B * world * args.steps / elapsed_per3
+        out["ms_per_step_allreduce_per_3_launches"] = elapsed_per3 * 1e3 / args.steps
+        out["comm"] = dict(comm, note="value: EVERY DP launch all-reduces the model-sized flat gradient (--grad-mb, one RCCL call, "
+                                      "overlapping the next launch) -- three times the reference's communication per DP entry; "
+                                      "value_allreduce_per_3_launches: the same collective once per three DP launches, the reference's "
+                                      "ratio (three DP entries per optimizer step, one DDP all-reduce: SURVEY.md 3.1) -- the figure the "
+                                      ">= 6x scaling target is to be read on (DESIGN.md section 4); value_dp_grad_only: only the DP's own "
+                                      f"{h.n_grad * 4} B of batch-summed counts per launch")
     if dry:
         out["dry_run"] = True
         print(json.dumps(out), flush=True)

@@ -104,6 +104,7 @@ def _check_dry_line(out, world):
     assert out["comm"]["rccl_ranks_seen"] == world and out["comm"]["backend"] == "gloo"
     assert out["config"]["allreduce_floats"] == 125000 and out["comm"]["allreduce_bytes"] == 500000
     assert out["comm"]["allreduce_ms"] > 0 and out["value"] > 0 and out["value_dp_grad_only"] > 0
+    assert out["value_allreduce_per_3_launches"] > 0 and "per three DP launches" in out["comm"]["note"]
 
 
 @pytest.mark.timeout(300)

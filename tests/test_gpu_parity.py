@@ -1320,6 +1320,104 @@ def test_training_step_reference_wiring(path, dtype):
           {k: float(f"{v:.2e}") for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
 
 
+def _reference_step_in_torch(step, P64, token, tag, vmask, drop, alpha, pen_args):
+    """The reference's lines for one training step (the order and the formulas of make_golden.trainstep_cases' calls: joint.py:658-711,
+    ldndmv.py:171-216,277-281, fn.py:50-56) as float64 torch ops on the step's own leaves -- an independent formulation of everything
+    except the structured DP itself (DMV1o marginals / heads / max come from this package's DP kernels on the torch-made potentials;
+    those kernels are parity-tested on their own at this size) and the parser's feed-forwards (tools/train_step.scorer_feed_forward:
+    plain torch ops, pinned by the trainstep fixtures).  Returns (loss, heads)."""
+    import train_step
+    import vlgae_amd.torch_struct as ts
+    from vlgae_amd import align
+    F = torch.nn.functional
+    lengths = step.lengths
+    B, L, h = P64["enc_x"].shape
+    d = P64["w2"].shape[0]
+    N = L + 1
+    wmask = torch.arange(L, device=lengths.device)[None] < lengths[:, None]
+    mask1 = torch.cat([wmask.new_zeros(B, 1), wmask], 1)
+    D = None if drop is None else drop.double()                                                    # [B,4,d]
+    We, be = P64["w_enc"], P64["b_enc"]
+    lin = lambda k, inp: inp @ We[k * d:(k + 1) * d].T + be[k * d:(k + 1) * d]
+    x = P64["enc_x"]
+    x1 = torch.cat([(x.masked_fill(~wmask.unsqueeze(2), 0).sum(1) / lengths.unsqueeze(1)).unsqueeze(1), x], 1)   # joint.py:204-208
+    vis = P64["vis_mid"] @ P64["w_vis"].T                                                         # :175
+    word0 = lin(0, x1) * (1.0 if D is None else D[:, 0:1])                                        # :209 (+ SharedDropout)
+    att = torch.einsum("bvd,bqd->bqv", vis, word0[:, 1:]).softmax(2)                              # :670-672
+    x_f = F.layer_norm(x + torch.einsum("bqv,bvh->bqh", att, P64["vis_mid"]), (h,), P64["ln_w"], P64["ln_b"], 1e-5)   # :673-674
+    sx1, sx2, sy1, sy2, root_rule = train_step.scorer_feed_forward(P64, P64["emb"], x_f)          # ldndmv.py:174-205
+    attach_rule = torch.einsum("bhdve,cdve->bhcdv", sx1, sx2).log_softmax(2)                      # :184
+    ap = attach_rule.gather(2, token.reshape(B, 1, L, 1, 1).expand(B, L, L, 2, 2))                # :188
+    tri = lambda k: torch.ones(L, L, device=x.device, dtype=torch.float64).tril(-1) if k == 0 else torch.ones(L, L, device=x.device, dtype=torch.float64).triu(1)
+    ap = ap[..., 0, :] * tri(0)[None, :, :, None] + ap[..., 1, :] * tri(1)[None, :, :, None]      # :189-192
+    dc = torch.einsum("bhdve,kdve->bhkdv", sy1, sy2).permute(0, 1, 3, 4, 2).log_softmax(-1)       # :201
+    rt = torch.gather(root_rule.unsqueeze(0).expand(B, -1), 1, token)                             # :205-206
+    md = torch.full((B, N, 2, 2, 2), -1e12, dtype=torch.float64, device=x.device)                 # DMV1o.merge, distributions.py:253-265
+    ma = torch.full((B, N, N, 2), -1e12, dtype=torch.float64, device=x.device)
+    md = torch.cat([torch.cat([md[:, :1, :1], torch.zeros_like(md[:, :1, 1:])], 2), dc], 1)
+    ma = torch.cat([torch.cat([ma[:, :1, :1], torch.stack([ma[:, 0, 1:, 0], rt], -1).unsqueeze(1)], 2),
+                    torch.cat([ma[:, 1:, :1], ap], 2)], 1)
+    with torch.no_grad():                                                                          # joint.py:251-258
+        marg, heads = ts.DMV1o([md.float(), ma.float()], lengths).marginals_and_heads()
+        arc_margin = marg.sum(-1).double().gather(-1, heads.unsqueeze(-1)).squeeze(-1)
+        tmarg = torch.cat([mask1.double(), arc_margin], 1)
+    tmask = torch.cat([mask1, mask1], 1)
+    word = lin(0, x1) * (1.0 if D is None else D[:, 1:2])                                         # :267
+    child = F.leaky_relu(lin(1, x1), 0.01) * (1.0 if D is None else D[:, 2:3])                    # :269
+    parent = F.leaky_relu(lin(2, x1.gather(1, heads.unsqueeze(-1).expand(-1, -1, h))), 0.01) * (1.0 if D is None else D[:, 3:4])   # :270-273
+    arc = torch.einsum("bcx,xhy,bcy->bch", child, P64["w1"], parent) + (child + parent) @ P64["w2"] + P64["b"]   # :278-287
+    txt = torch.cat([word, arc], 1)
+    att4 = torch.einsum("avd,bqd->baqv", vis, txt)                                                # :413-415
+    att4 = att4.masked_fill(~vmask[None, :, None, :], -1e20).masked_fill(~tmask[:, None, :, None], -1e20)
+    pen, seg = align.grounding_prior(tag, *pen_args, 2 * N)                                       # :446-470 as a table
+    ar = torch.arange(B, device=x.device)
+    diag = att4[ar, ar] - pen.double()[:, :, seg.long()]
+    att4 = att4.clone()
+    att4[ar, ar] = diag
+    num = lengths.sum().double()
+    t2v = -(att4.max(3).values.log_softmax(1).diagonal().T * tmarg).sum()                         # :473-478
+    v2t = -(att4.max(2).values.log_softmax(0).diagonal().T * vmask).sum()                         # :480-489
+    mt = t2v / (t2v.detach() + 1e-6) * num + v2t / (v2t.detach() + 1e-6) * num
+    dep = -ts.DMV1o([md, ma], lengths).max.sum()                                                  # ldndmv.py:277-281
+    return (alpha * mt + (1 - alpha) * dep) / (num + 1e-12), heads                                # joint.py:709, fn.py:56
+
+
+def test_training_step_reference_wiring_config_size():
+    """tools/train_step.build at BASELINE.json configs[4]'s size (B = 256, L = 40, V = 36, d = 128, h = 256; float32 features, the
+    reference's precision) against the reference's formulation restated in float64 torch ops on the same leaves
+    (`_reference_step_in_torch`): loss to 1e-5 relative, Viterbi heads identical, and every gradient with >= 99.99 % of its
+    elements within 3e-4 * max|g| and none beyond 5e-3 * max|g| -- at this size a handful of the 7.7 M arg-max decisions of the
+    alignment and of the 2.7 M LeakyReLU branches sit within fp32 rounding of a tie and move one term of a row's sum."""
+    _tools_path()
+    import train_step
+    B, L, V, d = 256, 40, 36, 128
+    drop = (torch.rand(4, B, d, generator=torch.Generator().manual_seed(5)) >= 0.33).float() / 0.67
+    with torch.autograd.set_multithreading_enabled(False):
+        step = train_step.build(B, L, V, dev(), dtype=torch.float32, E=96, Et=16, H=64, nb=24, given=dict(drop=drop), seed=21)
+        loss, grads, _ = step()
+        heads = step.last["heads"]
+        P64 = {k: v.detach().double().requires_grad_(True) for k, v in step.P.items()}
+        bt = step.batch
+        ref_loss, ref_heads = _reference_step_in_torch(step, P64, bt["token"], bt["tag"], bt["vis_mask"], drop.permute(1, 0, 2).to(dev()),
+                                                       bt["alpha"], (bt["factor_names"], bt["vis_split"], bt["pos_for"]))
+        ref = torch.autograd.grad(ref_loss, [P64[k] for k in step.names])
+    assert torch.equal(heads, ref_heads)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    gmax = max(float(r.abs().max()) for r in ref)
+    report = {}
+    for k, want in zip(step.names, ref):
+        got = grads[k].double()
+        if k.endswith("project2.bias"):   # a bias shared by all arguments of a (log-)softmax: its gradient is exactly zero in exact
+            assert float(got.abs().max()) <= 1e-5 * gmax and float(want.abs().max()) <= 1e-5 * gmax, k   # arithmetic, rounding noise in both
+            continue
+        scale = max(float(want.abs().max()), 1e-6 * gmax)
+        err = (got - want).abs() / scale
+        report[k] = (float(err.max()), float((err > 3e-4).double().mean()))
+        assert float((err > 3e-4).double().mean()) <= 1e-4 and float(err.max()) <= 5e-3, (k, report[k])
+    print("config-size training step vs float64 torch formulation: loss", float(loss), float(ref_loss), "worst (max rel err, frac > 3e-4):",
+          sorted(report.items(), key=lambda kv: -kv[1][0])[:5])
+
+
 @pytest.mark.parametrize("B,L,V,d", [(6, 9, 12, 32), (256, 40, 36, 128)], ids=["toy", "config2"])
 def test_training_step_chain(oracle_mod, B, L, V, d):
     """One pass over the whole path as the model wires it (joint.py:245-287 lang_feat_max_tree, :406-491 grounding):

@@ -296,7 +296,9 @@ def round3_entries(B, L, dtype, dev, g):
         "shape": f"dY [{M},{3 * d}]^T x [{M},{hdim}] bf16 -> fp32 [{3 * d},{hdim}] + bias [{3 * d}]; split-K over the rows on "
                  "ds_read_b64_tr_b16 + bf16 MFMA, fixed-order partial sums; library = torch matmul (4 output tiles on 256 CUs) + sum"}
     # lang_feat_max_tree (joint.py:235-292), forward + gradients, both DPs included
-    xw = rnd(B, L, hdim, sc=0.5).requires_grad_(True)
+    xw = rnd(B, L, hdim, sc=0.5).to(dtype).requires_grad_(True)
+    xw32 = xw.detach().float().requires_grad_(True)
+    params32 = None
     params = [rnd(3 * d, hdim, sc=hdim ** -0.5).to(bf).requires_grad_(True), rnd(3 * d, sc=0.1).to(bf).requires_grad_(True),
               rnd(d, d, d, sc=1.0 / d).to(bf).requires_grad_(True), rnd(d, d, sc=d ** -0.5).to(bf).requires_grad_(True),
               rnd(d, sc=0.1).to(bf).requires_grad_(True)]
@@ -310,7 +312,11 @@ def round3_entries(B, L, dtype, dev, g):
     def lf():
         txt, _, _ = langfeat.lang_feat_max_tree(xw, lengths, md, ma, *params)
         return torch.autograd.grad(txt, [xw] + params, dout)
-    res["lang_feat_max_tree"] = {"fwd_bwd_ms": timed(lf, 20, dev),
+    def lf32():   # float32 features and parameters: computed in float32 end to end (the reference's `precision: 32`)
+        txt, _, _ = langfeat.lang_feat_max_tree(xw32, lengths, md, ma, *params32)
+        return torch.autograd.grad(txt, [xw32] + params32, dout.float())
+    params32 = [p_.detach().float().requires_grad_(True) for p_ in params]
+    res["lang_feat_max_tree"] = {"fwd_bwd_ms": timed(lf, 20, dev), "fwd_bwd_ms_float32_features": timed(lf32, 20, dev),
                                  "shape": f"B={B} L={L} h={hdim} d={d}: DMV marginals || Viterbi heads, masked-mean root row, word|child|parent "
                                           "encoders as one GEMM, arc encoder, txt [B,2N,d] bf16; gradients to x and every parameter (joint.py:235-292)"}
     # score construction feeding the DP (ldndmv.py:184-209): fused vs the reference's formulation in torch ops, both followed by the same DP

@@ -3,8 +3,9 @@ import sys, time, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
 import train_step
 dev = torch.device('cuda:0')
-B, L, V = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 40, 36)
-step = train_step.build(B, L, V, dev)
+pos = [a for a in sys.argv[1:] if not a.startswith('--')]
+B, L, V = (int(pos[0]), int(pos[1]), int(pos[2])) if len(pos) > 2 else (256, 40, 36)
+step = train_step.build(B, L, V, dev, wiring='r3' if '--r3' in sys.argv else 'reference', dtype=torch.float32 if '--f32' in sys.argv else torch.bfloat16)
 for _ in range(5): step()
 torch.cuda.synchronize()
 def wall(fn, n):

@@ -233,6 +233,8 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         return loss.detach(), dict(zip(names, grads)), ()
 
     step.names, step.P, step.lengths, step.wiring = names, P, lengths, wiring
+    step.batch = dict(token=token, tag=tag, vis_mask=vmask, alpha=alpha, factor_names=factor_names, vis_split=vis_split, pos_for=pos_for,
+                      use_pos_prior=use_pos_prior, vis2txt=vis2txt)
     step.trainable = tuple(k for k in names if k not in ("enc_x", "emb", "vis_mid"))
     # Parameters in the order their gradients become FINAL during the backward pass (autograd runs the later-created node first:
     # -max, grounding loss, lang_feat_max_tree | score construction, the parser's feed-forwards | attention fuse, word-only encoder,
@@ -290,7 +292,7 @@ def _build_r3(B, L, V, dev, dtype, d, h, seed, with_scorer, T, r):
         else:
             cmd, cma, loss_pot = md, ma, pot
         txt, tmask, txt_marginal = langfeat.lang_feat_max_tree(x, lengths, cmd, cma, P["w_enc"], P["b_enc"], P["w1"], P["w2"], P["b"],
-                                                               keep_viterbi=True)
+                                                               keep_viterbi=True, compute_dtype=dtype)   # (x is the fuse's fp32 output)
         if stage_hook is not None:
             txt.register_hook(lambda g_: stage_hook())
         total, _ = align.grounding_loss_factor_ce(txt, P["vis_feat"], tmask, vmask, txt_marginal, num_token, 1.0)
