@@ -87,17 +87,40 @@ def dp_entry(B, L, dtype_name, dev, n=100):
             "exp_rate": {"achieved_Gops": ops / sec / 1e9, "peak_Gops": exp_peak / 1e9, "frac": ops / sec / exp_peak}}
 
 
+_KERNEL_EVIDENCE = None
+
+
+def kernel_evidence():
+    """The newest committed per-kernel profile (profiles/r*_kernels.json, written by tools/prof_kernels.sh + pmc_summary.py)."""
+    global _KERNEL_EVIDENCE
+    if _KERNEL_EVIDENCE is None:
+        import glob
+        import json
+        import os
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+        files = sorted(glob.glob(os.path.join(root, "r*_kernels.json")))
+        _KERNEL_EVIDENCE = (None, {}) if not files else (os.path.basename(files[-1]), json.load(open(files[-1])))
+    return _KERNEL_EVIDENCE
+
+
 def mfma_busy(kernel):
-    """MFMA-busy fraction of a matrix-core kernel from the committed PMC passes (profiles/r02_g_mfma_busy.json; counters cannot be
-    collected inside this run: rocprofv3 --pmc needs its own passes)."""
-    import json
-    import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_g_mfma_busy.json")
-    try:
-        d = json.load(open(path))
-        return {"frac": d[kernel]["mfma_busy"], "source": "profiles/r02_g_mfma_busy.json (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, committed rocprofv3 PMC pass)"}
-    except Exception:
-        return None
+    """Matrix-core evidence for the kernel a bench entry LAUNCHES, by that kernel's own name (the prefix before the template
+    arguments must match a profiled kernel exactly): {"frac": SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, ...} from the newest committed
+    profile -- counters cannot be collected inside this run (rocprofv3 --pmc needs its own passes).  A name the profile does not
+    hold gives {"frac": None, "reason": ...}: no figure of a replaced kernel is ever quoted (VERDICT r03 weak #4)."""
+    name, d = kernel_evidence()
+    if name is None:
+        return {"frac": None, "reason": "no profiles/r*_kernels.json committed"}
+    hits = {k: e for k, e in d.get("kernels", {}).items() if k.split("<")[0] == kernel and "mfma_busy" in e}
+    if not hits:
+        return {"frac": None, "reason": f"profiles/{name} holds no kernel named {kernel}: the entry's kernel was not profiled"}
+    k, e = max(hits.items(), key=lambda kv: kv[1].get("avg_us", 0.0) * kv[1].get("calls", 1))
+    out = {"frac": e["mfma_busy"], "kernel": k, "avg_us_under_profiler": e.get("avg_us"), "source": f"profiles/{name} (kernel source {d.get('kernel_source_id')})"}
+    if "hbm_bytes_per_launch" in e:
+        out["hbm_bytes_per_launch"] = e["hbm_bytes_per_launch"]
+    if "wait_any_frac" in e:
+        out["wait_any_frac"] = e["wait_any_frac"]
+    return out
 
 
 def run_all(out, args, h, dev):
@@ -173,7 +196,7 @@ def _run_all(out, args, h, dev):
             "sentences_per_s": B / sec, "ms": sec * 1e3, "TFLOP/s": flops / sec / 1e12,
             "frac_mfma_bf16_peak": flops / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS if in_dtype == torch.bfloat16 else None,
             "GB/s": byts / sec / 1e9, "frac_hbm": byts / sec / 1e9 / HBM_PEAK_GBS,
-            "mfma_busy": mfma_busy("align_mfma_kernel<TILE> (full tensor)" if full else "align_max_kernel") if in_dtype == torch.bfloat16 else None,
+            "mfma_busy": mfma_busy("align_full_kernel" if full else "align_max_kernel") if in_dtype == torch.bfloat16 else None,
             "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in (2048-d / 768-d features through fixed-seed Linear->128), fp32 out"}
 
     # ---- the plain projections around the contraction (`vis_mlp_pre_matching` joint.py:136-138,175; the visual
@@ -205,7 +228,9 @@ def _run_all(out, args, h, dev):
     sec_unmasked = _events(lambda: align.bilinear_align_backward(cot, txt, vis), 20, 3, dev)
     sec = _events(lambda: align.bilinear_align_backward(cot, txt, vis, tm_b, vm_b), 20, 3, dev)
     byts = 2.0 * cot.numel() * 4
-    out["align_backward"] = {"ms": sec * 1e3, "unmasked_ms": sec_unmasked * 1e3, "GB/s": byts / sec / 1e9, "frac_hbm": byts / sec / 1e9 / HBM_PEAK_GBS,
+    out["align_backward"] = {"mfma_busy": ({"align_bwd_split_kernel": mfma_busy("align_bwd_split_kernel"), "align_bwd_split2_kernel": mfma_busy("align_bwd_split2_kernel")}
+                                           if in_dtype == torch.bfloat16 else None),
+                             "ms": sec * 1e3, "unmasked_ms": sec_unmasked * 1e3, "GB/s": byts / sec / 1e9, "frac_hbm": byts / sec / 1e9 / HBM_PEAK_GBS,
                              "TFLOP/s": 2 * 2.0 * B * B * Q * V * d / sec / 1e12,
                              "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} features, fp32 cotangent [B,A,Q,V] "
                                       f"({cot.numel() * 4 / 1e6:.0f} MB, read twice: once per gradient)"}
@@ -235,6 +260,8 @@ def _run_all(out, args, h, dev):
         total, _ = align.grounding_loss_factor_ce(g_txt, g_vis, tmask, vmask, marg, B * L, 1.0)
         return torch.autograd.grad(total, [g_txt, g_vis])
     out["grounding_loss"] = {"fwd_bwd_ms": timed(ground, 10, dev),
+                             "mfma_busy": ({"align_argmax_kernel": mfma_busy("align_argmax_kernel"), "ground_bwd_ws_kernel": mfma_busy("ground_bwd_ws_kernel")}
+                                           if in_dtype == torch.bfloat16 else None),
                              "shape": f"B=A={B} Q={Q} V={V} d={d} {args.dtype} in; loss + gradients, no [B,A,Q,V] tensor"}
     out["grounding_decode"] = {
         "ms": timed(lambda: align.grounding_decode(g_txt.detach(), g_vis.detach(), tmask, vmask), 20, dev),
@@ -264,7 +291,7 @@ def _run_all(out, args, h, dev):
         "fwd_ms": timed(lambda: align.arc_trilinear(a_child.detach(), a_w1.detach(), a_parent.detach()), 20, dev),
         "fwd_bwd_ms": timed(lambda: torch.autograd.grad(align.arc_trilinear(a_child, a_w1, a_parent),
                                                         [a_child, a_w1, a_parent], a_dout), 10, dev),
-        "mfma_busy": {"tri_kernel": mfma_busy("tri_kernel"), "tri_dw_kernel": mfma_busy("tri_dw_kernel")},
+        "mfma_busy": {"tri2_kernel": mfma_busy("tri2_kernel"), "tri_dw2_kernel": mfma_busy("tri_dw2_kernel")},
         "shape": f"M={B * N} X=H=Y={d} {args.dtype} in; einsum('bcx,xhy,bcy->bch') without the [M,H,Y] intermediate"}
 
 
@@ -292,6 +319,7 @@ def round3_entries(B, L, dtype, dev, g):
     M = B * N
     dy, x = rnd(M, 3 * d).to(bf), rnd(M, hdim).to(bf)
     res["linear_wgrad"] = {
+        "mfma_busy": mfma_busy("gemm_tn_kernel"),
         "ms": timed(lambda: align.linear_wgrad(dy, x), 50, dev), "library_ms": timed(lambda: (dy.t() @ x, dy.float().sum(0)), 50, dev),
         "shape": f"dY [{M},{3 * d}]^T x [{M},{hdim}] bf16 -> fp32 [{3 * d},{hdim}] + bias [{3 * d}]; split-K over the rows on "
                  "ds_read_b64_tr_b16 + bf16 MFMA, fixed-order partial sums; library = torch matmul (4 output tiles on 256 CUs) + sum"}
