@@ -19,5 +19,8 @@ def t(fn, n=200):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) * 1e3 / n
 out = F.dmv1o_run(md, ma, lengths, 0, True)
-print('fused %.2f us   inside %.2f us   logZ[0] %.6f  sum|g| %.6f' % (t(lambda: F.dmv1o_run(md, ma, lengths, 0, True)), t(lambda: F.dmv1o_run(md, ma, lengths, 0, False)),
-      float(out[0][0]), float(sum(x.float().abs().sum() for x in out[1:] if x is not None))))
+import hashlib
+torch.cuda.synchronize()
+digest = hashlib.sha256(b''.join(x.detach().cpu().numpy().tobytes() for x in out if x is not None)).hexdigest()[:16]
+print('fused %.2f us   inside %.2f us   logZ[0] %.6f  sum|g| %.6f  sha256(logZ|counts) %s' % (t(lambda: F.dmv1o_run(md, ma, lengths, 0, True)), t(lambda: F.dmv1o_run(md, ma, lengths, 0, False)),
+      float(out[0][0]), float(sum(x.float().abs().sum() for x in out[1:] if x is not None)), digest))

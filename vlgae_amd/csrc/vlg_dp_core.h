@@ -166,8 +166,8 @@ VLG_HD float fold_term(float m, float s, int am, float t, int rt, bool t_first, 
 #define VLG_DP_LANES_FW 256
 #endif
 #ifndef VLG_DP_LANES_BW
-#define VLG_DP_LANES_BW 256   // per direction (the two directions of a span run on separate halves of the workgroup)
-#endif
+#define VLG_DP_LANES_BW 256   // per direction (the two directions of a span run on separate halves of the workgroup); the outside pass has
+#endif                        // no cross-lane reduction, so its results do not depend on this (unlike the inside pass's summation trees)
 VLG_HD int group_log2(int spans, int w, int nt, int budget) {
     const int cap = budget < nt ? budget : nt;
     int lg = 0;
@@ -505,10 +505,14 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
                 vv[u] = c.I[eV + rc];
                 xa[u] = Cf[eA + 2 * rc];
                 xb[u] = Cf[eB + 2 * rc];
+#ifdef VLG_ABL_BW_NOADJLOAD   // timing ablation (wrong results): what the four adjoint loads per split point cost
+                o_gi[u] = vv[u]; o_c[u] = uu[u]; o_ga[u] = xa[u]; o_gb[u] = xb[u];
+#else
                 o_gi[u] = c.gI[eV + rc];
                 o_c[u] = c.gCc[eU + rP];
                 o_ga[u] = gCif[eA + 2 * rc];
                 o_gb[u] = gCif[eB + 2 * rc];
+#endif
             }
 #pragma unroll
             for (int u = 0; u < TU; ++u) {
@@ -597,6 +601,13 @@ VLG_HD void dmv_bw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& 
     }
 }
 
+// (Round 4, measured and not kept: the outside pass has no cross-lane reduction, so its lane groups need not be powers of two --
+//  G = 7 / 10 / 12 between them cut the split points per lane from 3 to 2 for the widths 17 ... 24 and from 2 to 1 for 5 ... 7 at
+//  N = 41, with bit-identical results.  Three more segment instantiations made the launch 1 us SLOWER: each width already runs
+//  code the instruction cache has not seen since the previous launch, and ten segments x two directions x four unrollings is more
+//  of it.  Also measured: the read-modify-writes of the adjoint charts as non-returning ds_add_f32 (one writer per word and phase,
+//  so the same sums): 77 -> 200 us, LDS float atomics are that slow; the four adjoint loads per split point replaced by register
+//  copies (wrong results, an upper bound for interleaving value and adjoint cells): 77.3 -> 74.4 us.)
 template <int SR, bool LONGSPAN = true, typename X>
 VLG_HD void dmv_bw_all(const DmvCtx& c, int tid, int nt, X& x) {
     const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_BW);
@@ -1084,7 +1095,9 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     }
     st_end = __builtin_amdgcn_s_memtime();
 #else
+#ifndef VLG_ABL_NOBW
     dmv_bw_all<SR, LONGSPAN>(cb, tid, nt, x);
+#endif
 #endif
     }
     // expected counts out (coalesced; padded positions get exact zeros like the reference).  Decode mode
@@ -1094,6 +1107,9 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     x.sync();
     const int E = io.out_extent(Ne);
     const float inv_e = 1.0f / (float)E;
+#ifdef VLG_ABL_NOOUT
+    if (E > 0) return;
+#endif
     for (int idx = tid; idx < E * E; idx += nt) {
         const int h = (int)(((float)idx + 0.5f) * inv_e), ch = idx - h * E;
         float2 g = oo;
@@ -1103,24 +1119,38 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
         }
         io.st_attach(h, ch, g);
     }
-    if (io.wants_dec())
-        for (int idx = tid; idx < E * 8; idx += nt) {
-            const int h = idx >> 3, k = idx & 7;
+    if (io.wants_dec()) {
+        // STOP counts: the adjoint of the width-0 span (one cell each)
+        for (int idx = tid; idx < E * 4; idx += nt) {
+            const int h = idx >> 2, dir = (idx >> 1) & 1, v = idx & 1;
             float g = 0.f;
             if (h < Ne) {
-                const int dir = k >> 2, v = (k >> 1) & 1;
-                if ((k & 1) == 0) {   // GO: dec[h,dir,v,GO] enters every incomplete span headed by h towards dir (dmv.py:36-37)
-                    const float* gi = reinterpret_cast<const float*>(c.gI + h * P) + v;
-                    if (dir == 0) for (int ch = 0; ch < h; ++ch) g += gi[2 * ch];
-                    else for (int ch = h + 1; ch < Ne; ++ch) g += gi[2 * (ch + 1)];
-                }
-                else {                                                                      // STOP = width-0 span
-                    const int q = h * P + h + dir;
-                    g = (v == 1 ? c.gCc[q] : 0.f) + reinterpret_cast<const float*>(c.gCi + q)[v];
-                }
+                const int q = h * P + h + dir;
+                g = (v == 1 ? c.gCc[q] : 0.f) + reinterpret_cast<const float*>(c.gCi + q)[v];
             }
-            io.st_dec(h, k, g);
+            io.st_dec(h, (dir * 2 + v) * 2 + 1, g);
         }
+        // GO counts: dec[h,dir,v,GO] enters every incomplete span headed by h towards dir (dmv.py:36-37), so its count is a sum
+        // over a row of the finished gI chart.  Four lanes per (h, dir) take every fourth cell (both valences at once) and meet in
+        // a two-step butterfly: a fixed summation tree, ~10 dependent LDS reads instead of the 40 of one lane per sum (this loop was
+        // 2.2 us of the 77 us launch as a serial walk).
+        constexpr int GL = 4;
+        for (int base = 0; base < E * 2; base += nt / GL) {
+            const int grp = base + tid / GL, rr = tid % GL;
+            const int h = grp >> 1, dir = grp & 1;
+            float sum[2] = {0.f, 0.f};
+            if (grp < E * 2 && h < Ne) {
+                const float2* row = c.gI + h * P + (dir == 0 ? 0 : h + 2);      // cells (h, ch) for ch < h  |  (h, ch + 1) for ch > h
+                const int n = dir == 0 ? h : Ne - 1 - h;
+                for (int k = rr; k < n; k += GL) { sum[0] += row[k].x; sum[1] += row[k].y; }
+            }
+            x.template allreduce_sum<2>(sum, GL);
+            if (grp < E * 2 && rr == 0) {
+                io.st_dec(h, (dir * 2 + 0) * 2, sum[0]);
+                io.st_dec(h, (dir * 2 + 1) * 2, sum[1]);
+            }
+        }
+    }
 #if defined(VLG_STAMP) && defined(__HIPCC__)
     x.sync();
     if ((tid & 63) == 0) {   // diagnostic build only: per-wave cycle sums overwrite the (padded) last rows of grad_dec

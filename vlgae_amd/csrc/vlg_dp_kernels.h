@@ -12,7 +12,9 @@
 namespace vlg {
 
 #ifndef VLG_DP_THREADS
-#define VLG_DP_THREADS 512
+#define VLG_DP_THREADS 512   // eight wavefronts, two per SIMD.  (Round 4 measured 640 / 768 threads with a 320 / 384-lane outside pass: the single
+                             //  launch gains 1.5 us, but ten wavefronts of ~120 VGPRs no longer let a second DP workgroup share the CU -- the
+                             //  marginals || Viterbi pair of lang_feat_max_tree went from 101 to 145 us -- so it stays 512.)
 #endif
 constexpr int kThreads = VLG_DP_THREADS;    // lanes per sentence (workgroup size)
 constexpr size_t kLdsBudget = 160 * 1024;   // CDNA4 LDS per CU / per workgroup
