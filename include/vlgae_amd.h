@@ -266,7 +266,7 @@ int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* 
  * loss.backward(), i.e. the word / child / parent encoders of src/model/joint.py:270-277 and `vis_mlp_pre_matching`
  * (joint.py:136-138,175):   d_weight[M(out), N(in)] = dy^T x,   d_bias[M] = sum_rows dy.
  *   dy [K, ld_dy] (first M columns used), x [K, ld_x] (first N columns used): bf16, row-major, K = B*N token rows;
- *   M and N multiples of 64, row strides multiples of 8 elements, all buffers 16-byte aligned.
+ *   M and N multiples of 8 (64 x 64 output tiles, partial at the edges), row strides multiples of 8 elements, all buffers 16-byte aligned.
  *   d_weight [M, N] fp32, d_bias [M] fp32 or NULL; x_colsum [N] fp32 or NULL = sum_rows x (the bias gradient when the roles
  *   are swapped: a weight stored [in, out] as in `matmul(child + parent, arc_encoder_w2) + arc_encoder_b`, joint.py:285-286,
  *   takes dy := the layer input and x := the cotangent).  ws: vlg_linear_wgrad_workspace(K, M, N) bytes (0 = unsupported shape).

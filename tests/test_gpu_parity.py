@@ -1367,6 +1367,66 @@ def test_training_step_reference_wiring(path, dtype):
           {k: float(f"{v:.2e}") for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
 
 
+@pytest.mark.parametrize("dtype,nb", [(torch.float32, 24), (torch.float32, 0), (torch.bfloat16, 40)], ids=["f32_nb24", "f32_nb0", "bf16_nb40"])
+def test_parser_feed_forward_vs_module_by_module(dtype, nb):
+    """vlgae_amd.parser_ff.parser_feed_forward (ONE pass of mid_ff over all rows, folded bottlenecks and linear2, fused GEMMs,
+    hand-written adjoint) against the reference's module-by-module formulation (tools/train_step.scorer_feed_forward: the restatement
+    of MLP / DMVSkipConnectEncoder / DMVFactorizedBilinear.project* that the trainstep fixtures pin on the reference's own modules) in
+    float64: the five outputs and the gradient w.r.t. every input and parameter.  float32: 2e-5 * max (folding W1 W0 and P W2 re-associates
+    fp32 products); bf16: 3e-2 * max values, 8e-2 relative L2 gradients."""
+    _tools_path()
+    import train_step
+    from vlgae_amd import parser_ff
+    B, L, E, h, Et, T, H, r = 24, 11, 40, 64, 16, 9, 64, 8
+    gen = torch.Generator().manual_seed(3)
+    P = train_step.init_feed_forward(gen, dev(), dtype, E, h, Et, T, H, nb, r)
+    for k in list(P):
+        if k.endswith(".bias"):      # (init_feed_forward's small biases; make them matter)
+            P[k] = (torch.randn(P[k].shape, generator=gen) * 0.3).to(dev(), dtype).requires_grad_(True)
+    emb = (torch.randn(B, L, E, generator=gen) * 0.5).to(dev(), dtype).requires_grad_(True)
+    x = torch.randn(B, L, h, generator=gen).to(dev(), dtype).requires_grad_(True)
+    names = sorted(P)
+    leaves = [emb, x] + [P[k] for k in names]
+    outs = parser_ff.parser_feed_forward(P, emb, x)
+    cot = [torch.randn(o.shape, generator=gen).to(dev()) for o in outs]
+    got = torch.autograd.grad([o.float() for o in outs], leaves, cot)
+    P64 = {k: v.detach().double().requires_grad_(True) for k, v in P.items()}
+    e64, x64 = emb.detach().double().requires_grad_(True), x.detach().double().requires_grad_(True)
+    ref = train_step.scorer_feed_forward(P64, e64, x64)
+    want = torch.autograd.grad(list(ref), [e64, x64] + [P64[k] for k in names], [c.double() for c in cot])
+    f32 = dtype == torch.float32
+    for name, a, b in zip(("x1", "x2", "y1", "y2", "root_rule"), outs, ref):
+        assert a.shape == b.shape, name
+        assert float((a.double() - b).abs().max()) <= (2e-5 if f32 else 3e-2) * max(1.0, float(b.abs().max())), name
+    gmax = max(float(w.abs().max()) for w in want)
+    for name, a, b in zip(["emb", "x"] + names, got, want):
+        assert a.shape == b.shape, name
+        if f32:
+            assert float((a.double() - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-3 * gmax), name
+        else:
+            assert float((a.double() - b).norm()) <= 8e-2 * float(b.norm()) + 2e-3 * gmax * b.numel() ** 0.5, name
+
+
+def test_linear_wgrad_partial_tiles():
+    """vlg_linear_wgrad on output / input widths that are not multiples of its 64 x 64 tile (round 4: multiples of 8 suffice; the
+    edge tiles are staged with zeros and stored masked), strided operands, against float64; run-to-run bit equality."""
+    from vlgae_amd import align
+    gen = torch.Generator().manual_seed(11)
+    K = 10496
+    for M, N, ldy, ldx in ((384, 256, 384, 256), (256, 800, 256, 800), (32, 256, 32, 256), (24, 72, 40, 88), (512, 8, 512, 8), (8, 8, 8, 8)):
+        dy_full = torch.randn(K, ldy, generator=gen).to(dev(), torch.bfloat16)
+        x_full = torch.randn(K, ldx, generator=gen).to(dev(), torch.bfloat16)
+        dy, x = dy_full[:, :M], x_full[:, :N]
+        dw, db = align.linear_wgrad(dy, x)
+        dw2, db2 = align.linear_wgrad(dy, x)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+        rw, rb = dy.double().t() @ x.double(), dy.double().sum(0)
+        assert float((dw.double() - rw).abs().max()) <= 1e-5 * float(rw.abs().max()) + 1e-3, (M, N)
+        assert float((db.double() - rb).abs().max()) <= 1e-5 * float(rb.abs().max()) + 1e-3, (M, N)
+        _, xs = align.linear_wgrad(dy, x, want_x_colsum=True)
+        assert float((xs.double() - x.double().sum(0)).abs().max()) <= 1e-3, (M, N)
+
+
 def _reference_step_in_torch(step, P64, token, tag, vmask, drop, alpha, pen_args):
     """The reference's lines for one training step (the order and the formulas of make_golden.trainstep_cases' calls: joint.py:658-711,
     ldndmv.py:171-216,277-281, fn.py:50-56) as float64 torch ops on the step's own leaves -- an independent formulation of everything

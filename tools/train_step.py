@@ -13,7 +13,8 @@ run this very function on fixtures produced by the reference's own methods (test
     DiscriminativeNDMV._forward    src/model/ldndmv.py:171-216  on that copy
       context_mode 'mean'          :226,:254  h = cat([emb, mean_l(fused x)])                                          (torch)
       head_ff / child_ff / root_ff / dec_ff (MLP, nn/common.py:23-51), mid_ff (DMVSkipConnectEncoder, nn/dmv_spec.py:6-54),
-      the scorers' project1 / project2 (nn.Linear, nn/dmv_spec.py:63-68): plain feed-forwards = library GEMMs          (torch, `scorer_feed_forward`)
+      the scorers' project1 / project2 (nn.Linear, nn/dmv_spec.py:63-68): plain feed-forwards = library GEMMs          -> parser_ff.parser_feed_forward
+                                                                     (module by module in torch: `scorer_feed_forward` below, the tests' comparison)
       scores -> log-softmax over tokens -> gather / direction select / root gather / merge   :184-209                   -> scorer.ndmv_potentials
     DependencyBoxRel._vis_forward  joint.py:677-691
       lang_feat_max_tree           :235-292   on the caller's `encoded`, i.e. the UN-fused x: DMV1o marginals + Viterbi heads of
@@ -122,7 +123,7 @@ def init_feed_forward(g, dev, dtype, E, h, Et, T, H, nb, r):
 # ----------------------------------------------------------------------------------------------------------------------------
 def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer=True, T=45, r=16, wiring="reference", given=None,
           alpha=0.5, use_pos_prior=True, vis2txt=1.0, p_drop=0.33, E=800, Et=32, H=256, nb=150, p_ff_drop=0.0, p_mid_drop=0.0,
-          factor_names=("obj",), vis_split=None, pos_for=None, ln_eps=1e-5, ff_dtype=None):
+          factor_names=("obj",), vis_split=None, pos_for=None, ln_eps=1e-5, ff_dtype=None, fused_ff=True):
     """The step function of one training step at B sentences of <= L words and V region columns.
 
     wiring="reference": the chain of the module docstring.  `given` (a dict) replaces any of the synthetic inputs / parameters by
@@ -130,7 +131,8 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     vis_mask [B,V], drop [4,B,d] (the SharedDropout masks in the reference's call order: word-only, then word | child | parent; or
     None); parameters w_vis [d,h], w_enc [3d,h], b_enc [3d], ln_w, ln_b [h], w1 [d,d,d], w2 [d,d], b [d], token_emb / root_emb /
     dec_emb and the "ff.*" feed-forward parameters.  With `given` drop absent, fresh masks are drawn every step (p_drop).
-    ff_dtype: storage / compute type of the parser's feed-forwards (torch ops; default = dtype).
+    ff_dtype: storage / compute type of the parser's feed-forwards (default = dtype); fused_ff: vlgae_amd.parser_ff (folded / fused
+    library GEMMs, hand-written adjoint) instead of the module-by-module torch formulation `scorer_feed_forward` (same values).
     alpha / use_pos_prior / vis2txt: config/model/vlgae.yaml:62-67.  Returns step(); step() -> (loss, {name: gradient}, ()).
 
     wiring="r3": round 3's chain (see the module docstring); `with_scorer` only matters there."""
@@ -139,7 +141,7 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     if wiring != "reference":
         raise ValueError(wiring)
     import vlgae_amd.torch_struct as ts
-    from vlgae_amd import align, langfeat, scorer
+    from vlgae_amd import align, langfeat, parser_ff, scorer
     N, Q = L + 1, 2 * (L + 1)
     given = dict(given or {})
     ff_dtype = dtype if ff_dtype is None else ff_dtype
@@ -212,7 +214,10 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         word0, _, _ = langfeat.lang_feat_word_only(P["enc_x"], lengths, w_word, b_word, drop=d0)            # :667
         x_f = align.attention_fuse(vis_feat, word0, P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], ln_eps)   # :670-674
         # ---- DiscriminativeNDMV._forward on the fused copy, ldndmv.py:171-216 ----
-        x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, p_mid_drop, ff_drop)
+        if fused_ff and p_mid_drop == 0 and ff_drop is None:   # the same mathematics with folded / fused GEMMs and a hand-written adjoint
+            x1, x2, y1, y2, root_rule = parser_ff.parser_feed_forward(P, P["emb"], x_f)
+        else:                                                  # module by module, as the reference runs it
+            x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, p_mid_drop, ff_drop)
         md, ma = scorer.ndmv_potentials(x1, x2, y1, y2, root_rule, token)
         # ---- DependencyBoxRel._vis_forward, joint.py:677-691: the UN-fused x; the potentials are constants of this stage (:252-253) ----
         txt, tmask, tmarg = langfeat.lang_feat_max_tree(P["enc_x"], lengths, md.detach(), ma.detach(), P["w_enc"], P["b_enc"], P["w1"],

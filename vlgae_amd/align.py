@@ -537,7 +537,7 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None):
     cotangent as x).  out = (d_weight, second) writes into caller-owned float32 tensors.
 
     dy [K, out], x [K, in]: bf16, row-major (row strides that are multiples of 8 elements are taken in place -- column
-    slices of wider buffers), out and in multiples of 64.  Split over the rows across the whole chip, fixed summation
+    slices of wider buffers), out and in multiples of 8 (64 x 64 output tiles; the last tile of either side may be partial).  Split over the rows across the whole chip, fixed summation
     order (vlg_linear_wgrad); other shapes / dtypes raise -- callers decide (see `_Linear.backward`)."""
     _C.require_gpu(dy, "linear_wgrad")
     K, M = dy.shape
@@ -550,7 +550,7 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None):
         x = x.contiguous()
     nbytes = _C.lib().vlg_linear_wgrad_workspace(K, M, N)
     if nbytes == 0:
-        raise ValueError(f"linear_wgrad: unsupported shape K={K} out={M} in={N} (out, in must be multiples of 64)")
+        raise ValueError(f"linear_wgrad: unsupported shape K={K} out={M} in={N} (out, in must be multiples of 8)")
     second = (N,) if want_x_colsum else ((M,) if want_bias else None)
     if out is None:
         (dw, db), ws = _C.alloc_f32(dy.device, ((M, N), second), nbytes)
@@ -564,7 +564,7 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None):
 
 
 def _wgrad_ok(K, M, N, dtype):
-    return dtype == torch.bfloat16 and M % 64 == 0 and N % 64 == 0 and M >= 64 and N >= 64 and K >= 2048
+    return dtype == torch.bfloat16 and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8 and K >= 2048
 
 
 class _Linear(torch.autograd.Function):

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
     __shared__ __attribute__((aligned(16))) char sA[kStage * kPitch];
     __shared__ __attribute__((aligned(16))) char sB[kStage * kPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mt = blockIdx.x % (M / kTile), nt = blockIdx.x / (M / kTile);
+    const int MT = (M + kTile - 1) / kTile;   // M, N: multiples of 8 (16-byte row segments); the last tile of either side may be partial
+    const int mt = blockIdx.x % MT, nt = blockIdx.x / MT;
     const int m0 = mt * kTile, n0 = nt * kTile;
     const int s = blockIdx.y;
     const int k_begin = s * KC, k_end = min(K, k_begin + KC);
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
 
     // global -> register staging: a tile row is 64 bf16 = 8 x 16 bytes; 256 threads cover 32 rows per pass, 4 passes per stage
     const int c16 = tid & 7, r0 = tid >> 3;
+    const bool col_a = m0 + c16 * 8 < M, col_b = n0 + c16 * 8 < N;   // columns past a partial tile's edge are staged as zeros
     const uint16_t* pa = A + (size_t)(k_begin + r0) * lda + m0 + c16 * 8;
     const uint16_t* pb = B + (size_t)(k_begin + r0) * ldb + n0 + c16 * 8;
     // two register sets, each one stage (4 x 16 bytes per operand and thread), loaded two stages ahead of their use
@@ -52,8 +54,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const bool ok = k_begin + ks + r0 + 32 * p < k_end;
-            ra[set][p] = ok ? *reinterpret_cast<const uint4*>(pa + (size_t)(ks + 32 * p) * lda) : make_uint4(0, 0, 0, 0);
-            rb[set][p] = ok ? *reinterpret_cast<const uint4*>(pb + (size_t)(ks + 32 * p) * ldb) : make_uint4(0, 0, 0, 0);
+            ra[set][p] = ok && col_a ? *reinterpret_cast<const uint4*>(pa + (size_t)(ks + 32 * p) * lda) : make_uint4(0, 0, 0, 0);
+            rb[set][p] = ok && col_b ? *reinterpret_cast<const uint4*>(pb + (size_t)(ks + 32 * p) * ldb) : make_uint4(0, 0, 0, 0);
         }
     };
     auto stash = [&](int set) {
@@ -129,17 +131,23 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * 32 + i * 16 + 4 * g + r, col = n0 + wn * 32 + j * 16 + (lane & 15);
-                out[(size_t)row * N + col] = acc[i][j][r];
+                if (row < M && col < N) out[(size_t)row * N + col] = acc[i][j][r];
             }
     if (want_cs && (lane & 15) == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part_cs[(size_t)s * M + m0 + wm * 32 + i * 16 + 4 * g + r] = cs[i][r];
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 32 + i * 16 + 4 * g + r;
+                if (row < M) part_cs[(size_t)s * M + row] = cs[i][r];
+            }
     }
     if (want_csb && lane < 16) {   // row 0 of the tile: lanes 0..15, register 0
 #pragma unroll
-        for (int j = 0; j < 2; ++j) part_csb[(size_t)s * N + n0 + wn * 32 + j * 16 + lane] = csb[j][0];
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 32 + j * 16 + lane;
+            if (col < N) part_csb[(size_t)s * N + col] = csb[j][0];
+        }
     }
 }
 
@@ -176,7 +184,7 @@ struct TnPlan {
 };
 
 TnPlan plan_tn(int K, int M, int N) {
-    const int tiles = (M / kTile) * (N / kTile);
+    const int tiles = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
     int S = (512 + tiles - 1) / tiles;                              // ~2 workgroups per CU, 3 resident at a time
     const int max_s = (K + 2 * kStage - 1) / (2 * kStage);          // at least two stages per split: both register sets in flight from the start
     S = S < 1 ? 1 : (S > max_s ? max_s : S);
@@ -192,15 +200,15 @@ TnPlan plan_tn(int K, int M, int N) {
 extern "C" {
 
 size_t vlg_linear_wgrad_workspace(int K, int M, int N) {
-    if (K < 1 || M < vlg::kTile || N < vlg::kTile || M % vlg::kTile || N % vlg::kTile) return 0;
+    if (K < 1 || M < 8 || N < 8 || M % 8 || N % 8) return 0;
     return vlg::plan_tn(K, M, N).bytes;
 }
 
 int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes,
                      float* d_weight, float* d_bias, float* x_colsum, void* stream) {
     using namespace vlg;
-    if (K < 1 || M < kTile || N < kTile || M % kTile || N % kTile)
-        return set_error(VLG_ERR_SHAPE, "linear_wgrad: need K >= 1 and M, N positive multiples of %d (got K=%d M=%d N=%d)", kTile, K, M, N);
+    if (K < 1 || M < 8 || N < 8 || M % 8 || N % 8)
+        return set_error(VLG_ERR_SHAPE, "linear_wgrad: need K >= 1 and M, N positive multiples of 8 (got K=%d M=%d N=%d)", K, M, N);
     if (ld_dy < M || ld_x < N || ld_dy % 8 || ld_x % 8)
         return set_error(VLG_ERR_SHAPE, "linear_wgrad: row strides must cover the columns and be multiples of 8 elements (ld_dy=%d ld_x=%d)", ld_dy, ld_x);
     if (!dy || !x || !d_weight || !ws) return set_error(VLG_ERR_ARG, "linear_wgrad: null buffer");
@@ -213,7 +221,7 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
     float* part = (float*)ws;
     float* part_cs = d_bias ? part + (size_t)pl.S * M * N : nullptr;
     float* part_csb = x_colsum ? part + (size_t)pl.S * ((size_t)M * N + M) : nullptr;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((M / kTile) * (N / kTile), pl.S), dim3(kGemmThreads), 0, s, (const uint16_t*)dy, ld_dy,
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile), pl.S), dim3(kGemmThreads), 0, s, (const uint16_t*)dy, ld_dy,
                        (const uint16_t*)x, ld_x, K, M, N, pl.KC, part, part_cs, part_csb);
     if (int rc = check_launch("gemm_tn_kernel")) return rc;
     const int n = M * N, n_cs = d_bias ? M : 0, n_csb = x_colsum ? N : 0;

@@ -1,0 +1,260 @@
+"""The parser's feed-forwards in front of the score construction -- host-side mirror of `DiscriminativeNDMV._forward`,
+src/model/ldndmv.py:174-205 (context_mode 'mean'), from the embeddings to the scorers' projected inputs:
+
+    h        = cat([emb, mean_l(x)])                                    :174-177, extract_sent_repr :226, construct_token_repr :254
+    h_parent = mid_ff(head_ff(h))        [B,L,2,2,H]                    :180   (MLP nn/common.py:23-51; DMVSkipConnectEncoder nn/dmv_spec.py:6-54)
+    h_child  = mid_ff(child_ff(token_emb)), h_root = mid_ff(root_ff(root_emb)), h_dec = mid_ff(dec_ff(dec_emb))     :181-183
+    x1, x2   = attach_scorer.project1(h_parent), .project2(h_child)      nn/dmv_spec.py:67-68
+    y1, y2   = dec_scorer.project1(h_parent),    .project2(h_dec)
+    root_rule = root_scorer(h_root, h_child).sum([-1,-2]).log_softmax(-1)                                           :205
+
+These are plain Linear / LeakyReLU stacks: the GEMMs stay with the library (rocBLAS / hipBLASLt).  What this module changes is how
+many of them there are and what surrounds them -- as the reference's modules run them (5-D inputs, one nn.Linear at a time, autograd)
+the stage is ~190 launches and 5 ms of device time at B = 256, L = 40 in bf16, most of it weight-gradient GEMMs on four workgroups,
+bias-gradient reductions and un-fused bias / residual adds.  Here, with identical mathematics:
+  * ONE pass of mid_ff over the rows of all four inputs (B L + T + 1 + 2 rows);
+  * every Linear on a 2-D view with its bias inside the GEMM (addmm);
+  * each bottleneck pair Linear(H, nb) -> Linear(nb, H) (no activation between them, nn/dmv_spec.py:52-54) folded into one H x H
+    weight, W1 W0, and HASCHILD | NOCHILD (LEFT | RIGHT) concatenated into one [2H, H] GEMM; the adjoint unfolds the pair;
+  * linear2 folded into the six scorer projections that follow it without an activation (h W2^T + b2) P^T + p = h (P W2)^T + (P b2 + p),
+    so the [4 B L, H] x [H, H] GEMM of linear2 and its two adjoints never run;
+  * head_ff's weight split into its embedding and context columns: the context term is one [B, h] x [h, H] product per sentence
+    instead of L copies of it inside a concatenated [B L, E + h] operand;
+  * a hand-written backward in the same granularity with every weight / bias gradient on the split-K kernel (vlg_linear_wgrad).
+The reference formulation (tools/train_step.scorer_feed_forward, module by module) is what the tests compare this with.
+"""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _C
+from .align import _wgrad_ok, linear_wgrad
+
+SLOPE = 0.01   # nn.LeakyReLU() default (nn/common.py:31, nn/dmv_spec.py:10)
+_BOTTLENECKS = ("NOCHILD_linear", "HASCHILD_linear", "LEFT_linear", "RIGHT_linear")   # stack order: [no, has] (:42), [left, right] (:47)
+_PROJ = ("attach_scorer.project1", "dec_scorer.project1", "attach_scorer.project2", "root_scorer.project2", "root_scorer.project1",
+         "dec_scorer.project2")      # first two: the rows of h_parent; then h_child (x2, root's second operand), h_root, h_dec
+
+
+def param_names(n_bottleneck):
+    """The reference modules' parameter names (behind "ff.") in the order `parser_feed_forward` takes them."""
+    names = []
+    for m in ("head_ff", "child_ff", "root_ff", "dec_ff"):
+        names += [f"ff.{m}.linear.weight", f"ff.{m}.linear.bias"]
+    for b in _BOTTLENECKS:
+        if n_bottleneck:
+            names += [f"ff.mid_ff.{b}.0.weight", f"ff.mid_ff.{b}.0.bias", f"ff.mid_ff.{b}.1.weight", f"ff.mid_ff.{b}.1.bias"]
+        else:
+            names += [f"ff.mid_ff.{b}.weight", f"ff.mid_ff.{b}.bias"]
+    for m in ("valence_linear", "direction_linear", "linear1", "linear2"):
+        names += [f"ff.mid_ff.{m}.weight", f"ff.mid_ff.{m}.bias"]
+    for p in _PROJ:
+        names += [f"ff.{p}.weight", f"ff.{p}.bias"]
+    return names
+
+
+def _lrelu_(t):
+    return torch.nn.functional.leaky_relu_(t, SLOPE)
+
+
+def _lrelu_bwd(g, out):
+    """g * LeakyReLU'(pre) from the activation's OUTPUT (its sign is the pre-activation's), one launch."""
+    return torch.ops.aten.leaky_relu_backward(g, out, SLOPE, True)
+
+
+def _wgrad(dy, x):
+    """(dy^T x [out,in] fp32, sum_rows dy [out] fp32): the split-K kernel for bf16 token-row counts, the library otherwise."""
+    if dy.dtype == x.dtype and _wgrad_ok(x.shape[0], dy.shape[1], x.shape[1], dy.dtype):
+        return linear_wgrad(dy, x)
+    return dy.float().t() @ x.float(), dy.float().sum(0)
+
+
+class _ParserFF(torch.autograd.Function):
+    """(emb [B,L,E], x [B,L,h], token_emb [T,Et], root_emb [1,er], dec_emb [2,ed], *params) -> (big [4 B L, 2r], small [4 (T+3), 4r]):
+    columns of `big`: attach.project1 | dec.project1; of `small`: attach.project2 | root.project2 | root.project1 | dec.project2."""
+
+    @staticmethod
+    def forward(ctx, nb, emb, x, token_emb, root_emb, dec_emb, *params):
+        names = param_names(nb)
+        P = dict(zip(names, (p.detach() for p in params)))
+        act = emb.dtype
+        B, L, E = emb.shape
+        h = x.shape[2]
+        T = token_emb.shape[0]
+        M0, Ms = B * L, T + 3
+        M = M0 + Ms
+        dev = emb.device
+        c = lambda t: t.to(act)
+        Wh, bh = c(P["ff.head_ff.linear.weight"]), c(P["ff.head_ff.linear.bias"])
+        H = Wh.shape[0]
+        We, Wc = Wh[:, :E], Wh[:, E:]
+        emb2 = emb.detach().reshape(M0, E)
+        # ---- MLPs: all rows into one [M, H] buffer ----
+        X = torch.empty((M, H), dtype=act, device=dev)
+        torch.mm(emb2, We.t(), out=X[:M0])
+        cmean = x.detach().to(act).mean(1)                                             # context_mode 'mean', ldndmv.py:226
+        cterm = torch.addmm(bh, cmean, Wc.t())                                          # [B,H]: the context columns + bias, once per sentence
+        Xb = X[:M0].view(B, L, H)
+        Xb += cterm.unsqueeze(1)
+        small_in = (token_emb, root_emb, dec_emb)
+        o = M0
+        for m, inp in zip(("child_ff", "root_ff", "dec_ff"), small_in):
+            n = inp.shape[0]
+            torch.addmm(c(P[f"ff.{m}.linear.bias"]), c(inp.detach()), c(P[f"ff.{m}.linear.weight"]).t(), out=X[o:o + n])
+            o += n
+        _lrelu_(X)
+        # ---- folded bottlenecks ----
+        if nb:
+            W0s = torch.stack([c(P[f"ff.mid_ff.{b}.0.weight"]) for b in _BOTTLENECKS])     # [4,nb,H]
+            b0s = torch.stack([c(P[f"ff.mid_ff.{b}.0.bias"]) for b in _BOTTLENECKS])       # [4,nb]
+            W1s = torch.stack([c(P[f"ff.mid_ff.{b}.1.weight"]) for b in _BOTTLENECKS])     # [4,H,nb]
+            b1s = torch.stack([c(P[f"ff.mid_ff.{b}.1.bias"]) for b in _BOTTLENECKS])       # [4,H]
+            Weff = torch.bmm(W1s, W0s)                                                      # [4,H,H]
+            beff = torch.baddbmm(b1s.unsqueeze(2), W1s, b0s.unsqueeze(2)).squeeze(2)        # [4,H]
+        else:
+            W0s = b0s = W1s = b1s = None
+            Weff = torch.stack([c(P[f"ff.mid_ff.{b}.weight"]) for b in _BOTTLENECKS])
+            beff = torch.stack([c(P[f"ff.mid_ff.{b}.bias"]) for b in _BOTTLENECKS])
+        W_nh, b_nh = Weff[0:2].reshape(2 * H, H), beff[0:2].reshape(2 * H)
+        W_lr, b_lr = Weff[2:4].reshape(2 * H, H), beff[2:4].reshape(2 * H)
+        # ---- valence stage, nn/dmv_spec.py:41-44 ----
+        A1 = torch.addmm(b_nh, X, W_nh.t())                                             # [M,2H] = (no | has) bottleneck outputs
+        A1v = A1.view(M, 2, H)
+        A1v += X.unsqueeze(1)                                                           # + x (the skip connection)
+        _lrelu_(A1)                                                                     # act(h)
+        Wv, bv = c(P["ff.mid_ff.valence_linear.weight"]), c(P["ff.mid_ff.valence_linear.bias"])
+        A2 = torch.addmm(bv, A1.view(2 * M, H), Wv.t())
+        _lrelu_(A2)                                                                     # h [M,val,H]
+        # ---- direction stage, :46-50 ----
+        Z = torch.addmm(b_lr, A2, W_lr.t())                                             # [2M,2H]: rows (m,val), columns (dir,c)
+        A3 = torch.empty((M, 2, 2, H), dtype=act, device=dev)                           # [m,dir,val,c]
+        torch.add(Z.view(M, 2, 2, H).permute(0, 2, 1, 3), X.view(M, 1, 1, H), out=A3)
+        _lrelu_(A3)
+        Wd, bd = c(P["ff.mid_ff.direction_linear.weight"]), c(P["ff.mid_ff.direction_linear.bias"])
+        A4 = torch.addmm(bd, A3.view(4 * M, H), Wd.t())
+        _lrelu_(A4)
+        # ---- output stage, :52-54 with linear2 folded into the projections ----
+        W1_, b1_ = c(P["ff.mid_ff.linear1.weight"]), c(P["ff.mid_ff.linear1.bias"])
+        A5 = torch.addmm(b1_, A4, W1_.t())
+        _lrelu_(A5)
+        W2_, b2_ = c(P["ff.mid_ff.linear2.weight"]), c(P["ff.mid_ff.linear2.bias"])
+        PW = torch.cat([c(P[f"ff.{p}.weight"]) for p in _PROJ])                          # [6r,H]
+        Pb = torch.cat([c(P[f"ff.{p}.bias"]) for p in _PROJ])                            # [6r]
+        r = PW.shape[0] // 6
+        Wp = PW @ W2_                                                                   # [6r,H]: P W2
+        bp = torch.addmv(Pb, PW, b2_)                                                   # P b2 + p
+        big = torch.addmm(bp[:2 * r], A5[:4 * M0], Wp[:2 * r].t())                      # [4 M0, 2r]
+        small = torch.addmm(bp[2 * r:], A5[4 * M0:], Wp[2 * r:].t())                    # [4 Ms, 4r]
+        ctx.save_for_backward(emb2, cmean, X, A1, A2, A3, A4, A5, We, Wc, W_nh, W_lr, Wv, Wd, W1_, W2_, b2_, PW, Wp, W0s, b0s, W1s,
+                              *(c(t.detach()) for t in small_in), *(c(P[f"ff.{m}.linear.weight"]) for m in ("child_ff", "root_ff", "dec_ff")))
+        ctx.meta = (nb, B, L, E, h, T, H, r, act, [t.dtype for t in (emb, x, token_emb, root_emb, dec_emb)], [p.dtype for p in params])
+        return big, small
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_big, g_small):
+        (emb2, cmean, X, A1, A2, A3, A4, A5, We, Wc, W_nh, W_lr, Wv, Wd, W1_, W2_, b2_, PW, Wp, W0s, b0s, W1s, tok, rootE, decE,
+         Wchild, Wroot, Wdec) = ctx.saved_tensors
+        nb, B, L, E, h, T, H, r, act, in_dt, p_dt = ctx.meta
+        M0, Ms = B * L, T + 3
+        M = M0 + Ms
+        G = {}
+        g_big, g_small = g_big.to(act).contiguous(), g_small.to(act).contiguous()
+        # ---- folded projections ----
+        gA5 = torch.empty_like(A5)
+        torch.mm(g_big, Wp[:2 * r], out=gA5[:4 * M0])
+        torch.mm(g_small, Wp[2 * r:], out=gA5[4 * M0:])
+        dWp_b, dbp_b = _wgrad(g_big, A5[:4 * M0])                                       # [2r,H], [2r]
+        dWp_s, dbp_s = _wgrad(g_small, A5[4 * M0:])                                     # [4r,H], [4r]  (4 (T + 3) rows: the library)
+        dWp, dbp = torch.cat([dWp_b, dWp_s]), torch.cat([dbp_b, dbp_s])                 # fp32 [6r,H], [6r]
+        PWf, W2f = PW.float(), W2_.float()
+        dPW = torch.addmm(torch.outer(dbp, b2_.float()), dWp, W2f.t())                   # Wp = PW W2, bp = PW b2 + Pb
+        G["linear2.w"], G["linear2.b"] = PWf.t() @ dWp, PWf.t() @ dbp
+        # ---- linear1, direction ----
+        g = _lrelu_bwd(gA5, A5)
+        G["linear1.w"], G["linear1.b"] = _wgrad(g, A4)
+        g = _lrelu_bwd(g @ W1_, A4)
+        G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H))
+        g3 = _lrelu_bwd(g @ Wd, A3.view(4 * M, H)).view(M, 2, 2, H)                      # d (Z^T-ordered pre-activation) [m,dir,val,c]
+        gX = g3.sum((1, 2), dtype=torch.float32)                                         # the skip connection of the direction stage
+        gZ = torch.empty((M, 2, 2, H), dtype=act, device=g3.device)                      # [m,val,dir,c]
+        gZ.copy_(g3.permute(0, 2, 1, 3))
+        gZ = gZ.view(2 * M, 2 * H)
+        dW_lr, db_lr = _wgrad(gZ, A2)
+        # ---- valence ----
+        g = _lrelu_bwd(gZ @ W_lr, A2)
+        G["valence.w"], G["valence.b"] = _wgrad(g, A1.view(2 * M, H))
+        gY = _lrelu_bwd(g @ Wv, A1.view(2 * M, H)).view(M, 2 * H)
+        gX += gY.view(M, 2, H).sum(1, dtype=torch.float32)
+        dW_nh, db_nh = _wgrad(gY, X)
+        gX += (gY @ W_nh).float()
+        dWeff = torch.cat([dW_nh.view(2, H, H), dW_lr.view(2, H, H)])                    # [4,H,H] fp32: no, has, left, right
+        dbeff = torch.cat([db_nh.view(2, H), db_lr.view(2, H)])
+        # ---- MLPs ----
+        gpre = _lrelu_bwd(gX.to(act), X)                                                 # [M,H]
+        gb = gpre[:M0]
+        dWe, dbh = _wgrad(gb, emb2)                                                      # [H,E], [H]
+        g_emb = gb @ We                                                                  # [M0,E]
+        gc = gb.view(B, L, H).sum(1, dtype=torch.float32)                                # [B,H]
+        dWc = gc.t() @ cmean.float()                                                     # [H,h]
+        g_cmean = (gc.to(act) @ Wc) / L                                                  # [B,h]
+        G["head.w"], G["head.b"] = torch.cat([dWe, dWc], 1), dbh
+        o = M0
+        g_small_in = []
+        for name, inp, W in (("child", tok, Wchild), ("root", rootE, Wroot), ("dec", decE, Wdec)):
+            n = inp.shape[0]
+            gs = gpre[o:o + n].float()
+            G[name + ".w"], G[name + ".b"] = gs.t() @ inp.float(), gs.sum(0)
+            g_small_in.append(gs @ W.float())
+            o += n
+        # ---- unfold the bottleneck pairs: Weff = W1 W0, beff = W1 b0 + b1 ----
+        if nb:
+            W0f, W1f, b0f = W0s.float(), W1s.float(), b0s.float()
+            dW1s = torch.baddbmm(torch.einsum("kh,kn->khn", dbeff, b0f), dWeff, W0f.transpose(1, 2))   # [4,H,nb]
+            dW0s = torch.bmm(W1f.transpose(1, 2), dWeff)                                 # [4,nb,H]
+            db0s = torch.bmm(W1f.transpose(1, 2), dbeff.unsqueeze(2)).squeeze(2)         # [4,nb]
+        # ---- gradients in the order of param_names ----
+        out = [G["head.w"], G["head.b"], G["child.w"], G["child.b"], G["root.w"], G["root.b"], G["dec.w"], G["dec.b"]]
+        for k in range(4):
+            out += [dW0s[k], db0s[k], dW1s[k], dbeff[k]] if nb else [dWeff[k], dbeff[k]]
+        out += [G["valence.w"], G["valence.b"], G["direction.w"], G["direction.b"], G["linear1.w"], G["linear1.b"], G["linear2.w"],
+                G["linear2.b"]]
+        for k in range(6):
+            out += [dPW[k * r:(k + 1) * r], dbp[k * r:(k + 1) * r]]
+        out = [t if t.dtype == d else t.to(d) for t, d in zip(out, p_dt)]
+        g_x = g_cmean.unsqueeze(1).expand(B, L, h)
+        ins = [g_emb.view(B, L, E), g_x, g_small_in[0], g_small_in[1], g_small_in[2]]
+        ins = [t if t.dtype == d else t.to(d) for t, d in zip(ins, in_dt)]
+        need = ctx.needs_input_grad
+        return (None, *(t if n else None for t, n in zip(ins, need[1:6])), *(t if n else None for t, n in zip(out, need[6:])))
+
+
+def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None):
+    """ldndmv.py:174-205 up to the scorers' projected inputs -> (x1 [B,L,2,2,r], x2 [T,2,2,r], y1 [B,L,2,2,r], y2 [2,2,2,r],
+    root_rule [T]), the arguments of `scorer.ndmv_potentials`.
+
+    P: dict of the reference modules' parameters under their own names behind "ff." ("ff.head_ff.linear.weight", ...,
+    "ff.mid_ff.HASCHILD_linear.0.weight" (n_bottleneck > 0) or "ff.mid_ff.HASCHILD_linear.weight", ..., "ff.root_scorer.project2.bias");
+    token_emb / root_emb / dec_emb default to P's entries of those names.  emb [B,L,E] (`encoded['emb']`), x [B,L,h] (the encodings the
+    parser sees: the attention-fused copy, joint.py:670-675).  Dropout (head_ff / mid_ff, training mode) is not applied here: callers
+    that train with it use the module-by-module formulation (tools/train_step.scorer_feed_forward)."""
+    _C.require_gpu(emb, "parser_feed_forward")
+    token_emb = P["token_emb"] if token_emb is None else token_emb
+    root_emb = P["root_emb"] if root_emb is None else root_emb
+    dec_emb = P["dec_emb"] if dec_emb is None else dec_emb
+    nb = P["ff.mid_ff.HASCHILD_linear.0.weight"].shape[0] if "ff.mid_ff.HASCHILD_linear.0.weight" in P else 0
+    if emb.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"parser_feed_forward: float32 or bfloat16 embeddings, got {emb.dtype}")
+    B, L, _ = emb.shape
+    T = token_emb.shape[0]
+    if tuple(x.shape[:2]) != (B, L) or tuple(root_emb.shape[:1]) != (1,) or tuple(dec_emb.shape[:1]) != (2,):
+        raise ValueError(f"parser_feed_forward: emb {tuple(emb.shape)} x {tuple(x.shape)} root_emb {tuple(root_emb.shape)} dec_emb {tuple(dec_emb.shape)}")
+    big, small = _ParserFF.apply(nb, emb, x, token_emb, root_emb, dec_emb, *(P[k] for k in param_names(nb)))
+    r = big.shape[1] // 2
+    x1 = big[:, :r].reshape(B, L, 2, 2, r)
+    y1 = big[:, r:].reshape(B, L, 2, 2, r)
+    x2 = small[:4 * T, :r].reshape(T, 2, 2, r)
+    r2 = small[:4 * T, r:2 * r].reshape(T, 2, 2, r)
+    r1 = small[4 * T:4 * T + 4, 2 * r:3 * r].reshape(1, 2, 2, r)
+    y2 = small[4 * T + 4:, 3 * r:].reshape(2, 2, 2, r)
+    root_rule = torch.einsum("hdve,cdve->hc", r1.float(), r2.float()).log_softmax(-1)[0]   # ldndmv.py:205
+    return x1, x2, y1, y2, root_rule
