@@ -165,10 +165,10 @@ class _ParserFF(torch.autograd.Function):
         torch.mm(g_small, Wp[2 * r:], out=gA5[4 * M0:])
         dWp_b, dbp_b = _wgrad(g_big, A5[:4 * M0])                                       # [2r,H], [2r]
         dWp_s, dbp_s = _wgrad(g_small, A5[4 * M0:])                                     # [4r,H], [4r]  (4 (T + 3) rows: the library)
-        dWp, dbp = torch.cat([dWp_b, dWp_s]), torch.cat([dbp_b, dbp_s])                 # fp32 [6r,H], [6r]
-        PWf, W2f = PW.float(), W2_.float()
-        dPW = torch.addmm(torch.outer(dbp, b2_.float()), dWp, W2f.t())                   # Wp = PW W2, bp = PW b2 + Pb
-        G["linear2.w"], G["linear2.b"] = PWf.t() @ dWp, PWf.t() @ dbp
+        # (the small products below run in the activations' dtype: as fp32 GEMMs on one workgroup each the library takes 30-50 us for them)
+        dWp, dbp = torch.cat([dWp_b, dWp_s]).to(act), torch.cat([dbp_b, dbp_s]).to(act)  # [6r,H], [6r]
+        dPW = torch.addmm(torch.outer(dbp, b2_), dWp, W2_.t())                           # Wp = PW W2, bp = PW b2 + Pb
+        G["linear2.w"], G["linear2.b"] = PW.t() @ dWp, PW.t() @ dbp
         # ---- linear1, direction ----
         g = _lrelu_bwd(gA5, A5)
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4)
@@ -194,24 +194,24 @@ class _ParserFF(torch.autograd.Function):
         gb = gpre[:M0]
         dWe, dbh = _wgrad(gb, emb2)                                                      # [H,E], [H]
         g_emb = gb @ We                                                                  # [M0,E]
-        gc = gb.view(B, L, H).sum(1, dtype=torch.float32)                                # [B,H]
-        dWc = gc.t() @ cmean.float()                                                     # [H,h]
-        g_cmean = (gc.to(act) @ Wc) / L                                                  # [B,h]
-        G["head.w"], G["head.b"] = torch.cat([dWe, dWc], 1), dbh
+        gc = gb.view(B, L, H).sum(1, dtype=torch.float32).to(act)                        # [B,H]
+        dWc = gc.t() @ cmean                                                             # [H,h]
+        g_cmean = (gc @ Wc) / L                                                          # [B,h]
+        G["head.w"], G["head.b"] = torch.cat([dWe.to(act), dWc], 1), dbh
         o = M0
         g_small_in = []
         for name, inp, W in (("child", tok, Wchild), ("root", rootE, Wroot), ("dec", decE, Wdec)):
             n = inp.shape[0]
-            gs = gpre[o:o + n].float()
-            G[name + ".w"], G[name + ".b"] = gs.t() @ inp.float(), gs.sum(0)
-            g_small_in.append(gs @ W.float())
+            gs = gpre[o:o + n]
+            G[name + ".w"], G[name + ".b"] = gs.t() @ inp, gs.sum(0)
+            g_small_in.append(gs @ W)
             o += n
         # ---- unfold the bottleneck pairs: Weff = W1 W0, beff = W1 b0 + b1 ----
-        if nb:
-            W0f, W1f, b0f = W0s.float(), W1s.float(), b0s.float()
-            dW1s = torch.baddbmm(torch.einsum("kh,kn->khn", dbeff, b0f), dWeff, W0f.transpose(1, 2))   # [4,H,nb]
-            dW0s = torch.bmm(W1f.transpose(1, 2), dWeff)                                 # [4,nb,H]
-            db0s = torch.bmm(W1f.transpose(1, 2), dbeff.unsqueeze(2)).squeeze(2)         # [4,nb]
+        if nb:   # (in the activations' dtype: the library's batched fp32 kernels take ~50 us each for these 40-MFLOP products)
+            dWe_a, dbe_a = dWeff.to(act), dbeff.to(act)
+            dW1s = torch.baddbmm(torch.einsum("kh,kn->khn", dbe_a, b0s), dWe_a, W0s.transpose(1, 2))   # [4,H,nb]
+            dW0s = torch.bmm(W1s.transpose(1, 2), dWe_a)                                 # [4,nb,H]
+            db0s = torch.bmm(W1s.transpose(1, 2), dbe_a.unsqueeze(2)).squeeze(2)         # [4,nb]
         # ---- gradients in the order of param_names ----
         out = [G["head.w"], G["head.b"], G["child.w"], G["child.b"], G["root.w"], G["root.b"], G["dec.w"], G["dec.b"]]
         for k in range(4):
@@ -220,7 +220,16 @@ class _ParserFF(torch.autograd.Function):
                 G["linear2.b"]]
         for k in range(6):
             out += [dPW[k * r:(k + 1) * r], dbp[k * r:(k + 1) * r]]
-        out = [t if t.dtype == d else t.to(d) for t, d in zip(out, p_dt)]
+        # one multi-tensor conversion for the ~45 fp32 gradients instead of a cast launch each
+        todo = [k for k, (t, d) in enumerate(zip(out, p_dt)) if t.dtype != d]
+        if todo and len({p_dt[k] for k in todo}) == 1:
+            flat = torch.empty(sum(out[k].numel() for k in todo), dtype=p_dt[todo[0]], device=out[todo[0]].device)
+            dsts = [v.view(out[k].shape) for v, k in zip(flat.split_with_sizes([out[k].numel() for k in todo]), todo)]
+            torch._foreach_copy_(dsts, [out[k] for k in todo])
+            for k, v in zip(todo, dsts):
+                out[k] = v
+        else:
+            out = [t if t.dtype == d else t.to(d) for t, d in zip(out, p_dt)]
         g_x = g_cmean.unsqueeze(1).expand(B, L, h)
         ins = [g_emb.view(B, L, E), g_x, g_small_in[0], g_small_in[1], g_small_in[2]]
         ins = [t if t.dtype == d else t.to(d) for t, d in zip(ins, in_dt)]
