@@ -395,7 +395,7 @@ def train_step_entry(B, L, V, dtype, dev, wiring="reference"):
     if wiring == "reference":
         what = ("one training step as the reference wires it (base.py:215-241, joint.py:658-711, ldndmv.py:171-216,260-285, fn.py:50-56): "
                 "vis_mlp_pre_matching -> lang_feat_word_only -> attention fuse -> [fused x] context mean + the parser's feed-forwards "
-                "(head_ff / mid_ff / scorer projections: torch library ops, E=800 H=256 n_bottleneck=150 r=16) -> score construction -> "
+                "(vlgae_amd.parser_ff: head_ff / mid_ff / scorer projections, E=800 H=256 n_bottleneck=150 r=16) -> score construction -> "
                 "[un-fused x] lang_feat_max_tree (DMV1o marginals || one Viterbi pass, word|child|parent encoders with SharedDropout p=0.33 "
                 "drawn per step, arc encoder) -> alignment maxima with the POS prior + grounding cross-entropies (ragged vis_mask) -> "
                 "-DMV1o.max -> 0.5 mt + 0.5 dep -> / num_token -> gradients to every input feature and parameter")
@@ -424,10 +424,10 @@ def train_step_entry(B, L, V, dtype, dev, wiring="reference"):
                     "eager_ms - graph_ms is what the Python / autograd host path still costs")
     if wiring == "reference":
         del gr, step
-        try:   # the device time of the out-of-scope torch glue alone (the parser's feed-forwards, forward + backward), for the breakdown
-            res["parser_feed_forward_torch_ms"] = parser_ff_ms(B, L, dtype, dev)
+        try:   # the parser's feed-forwards alone (forward + backward), for the breakdown
+            res["parser_feed_forward"] = parser_ff_ms(B, L, dtype, dev)
         except Exception as e:
-            res["parser_feed_forward_torch_ms"] = {"error": repr(e)[:200]}
+            res["parser_feed_forward"] = {"error": repr(e)[:200]}
         try:
             c = train_step_entry(B, L, V, dtype, dev, wiring="r3")
             res["round3_chain"] = {"graph_ms": c["graph_ms"], "eager_ms": c["eager_ms"], "what": c["what"]}
@@ -437,14 +437,20 @@ def train_step_entry(B, L, V, dtype, dev, wiring="reference"):
 
 
 def parser_ff_ms(B, L, dtype, dev, E=800, h=256, Et=32, T=45, H=256, nb=150, r=16):
+    """The parser's feed-forwards (ldndmv.py:174-205), forward + backward: vlgae_amd.parser_ff against the module-by-module torch
+    formulation the reference's modules amount to."""
     import train_step
+    from vlgae_amd import parser_ff
     g = torch.Generator().manual_seed(3)
     P = train_step.init_feed_forward(g, dev, dtype, E, h, Et, T, H, nb, r)
     emb = torch.randn(B, L, E, generator=g).to(dev, dtype).requires_grad_(True)
     x = torch.randn(B, L, h, generator=g).to(dev, dtype).requires_grad_(True)
     leaves = [emb, x] + list(P.values())
 
-    def run():
-        outs = train_step.scorer_feed_forward(P, emb, x)
+    def run(fn):
+        outs = fn(P, emb, x)
         torch.autograd.grad([o.float().sum() for o in outs], leaves, allow_unused=True)
-    return timed(run, 20, dev)
+    return {"fused_ms": timed(lambda: run(parser_ff.parser_feed_forward), 20, dev),
+            "module_by_module_torch_ms": timed(lambda: run(train_step.scorer_feed_forward), 20, dev),
+            "what": f"emb [B,L,{E}] + fused encodings -> head_ff / mid_ff (H={H}, n_bottleneck={nb}) / scorer projections (r={r}) -> gradients; "
+                    "eager, event-timed (the module-by-module form is host-bound: ~190 launches)"}
