@@ -1401,6 +1401,9 @@ def test_parser_feed_forward_vs_module_by_module(dtype, nb):
     gmax = max(float(w.abs().max()) for w in want)
     for name, a, b in zip(["emb", "x"] + names, got, want):
         assert a.shape == b.shape, name
+        if name == "ff.root_scorer.project2.bias":   # shared by every argument of root_rule's softmax: exactly zero in exact arithmetic
+            assert float(a.double().abs().max()) <= (1e-5 if f32 else 2e-3) * gmax and float(b.abs().max()) <= 1e-5 * gmax
+            continue
         if f32:
             assert float((a.double() - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-3 * gmax), name
         else:

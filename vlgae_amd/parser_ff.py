@@ -69,8 +69,7 @@ def _wgrad(dy, x):
 
 
 class _ParserFF(torch.autograd.Function):
-    """(emb [B,L,E], x [B,L,h], token_emb [T,Et], root_emb [1,er], dec_emb [2,ed], *params) -> (big [4 B L, 2r], small [4 (T+3), 4r]):
-    columns of `big`: attach.project1 | dec.project1; of `small`: attach.project2 | root.project2 | root.project1 | dec.project2."""
+    """(emb [B,L,E], x [B,L,h], token_emb [T,Et], root_emb [1,er], dec_emb [2,ed], *params) -> (x1, x2, y1, y2, root_rule)."""
 
     @staticmethod
     def forward(ctx, nb, emb, x, token_emb, root_emb, dec_emb, *params):
@@ -142,23 +141,40 @@ class _ParserFF(torch.autograd.Function):
         r = PW.shape[0] // 6
         Wp = PW @ W2_                                                                   # [6r,H]: P W2
         bp = torch.addmv(Pb, PW, b2_)                                                   # P b2 + p
-        big = torch.addmm(bp[:2 * r], A5[:4 * M0], Wp[:2 * r].t())                      # [4 M0, 2r]
-        small = torch.addmm(bp[2 * r:], A5[4 * M0:], Wp[2 * r:].t())                    # [4 Ms, 4r]
+        big = torch.addmm(bp[:2 * r], A5[:4 * M0], Wp[:2 * r].t())                      # [4 M0, 2r]: attach.project1 | dec.project1
+        small = torch.addmm(bp[2 * r:], A5[4 * M0:], Wp[2 * r:].t())                    # [4 Ms, 4r]: attach.p2 | root.p2 | root.p1 | dec.p2
+        # the five tensors the score construction takes, contiguous (slices of `big` / `small` handed to autograd would come back as a
+        # zero-fill + copy + add per slice)
+        x1 = big[:, :r].reshape(B, L, 2, 2, r)
+        y1 = big[:, r:].reshape(B, L, 2, 2, r)
+        x2 = small[:4 * T, :r].reshape(T, 2, 2, r)
+        y2 = small[4 * T + 4:, 3 * r:].reshape(2, 2, 2, r)
+        r2f = small[:4 * T, r:2 * r].reshape(T, 4 * r).float()
+        r1f = small[4 * T:4 * T + 4, 2 * r:3 * r].reshape(1, 4 * r).float()
+        root_rule = (r1f @ r2f.t()).log_softmax(-1)[0]                                  # ldndmv.py:205: sum over (dir, val), softmax over tokens
         ctx.save_for_backward(emb2, cmean, X, A1, A2, A3, A4, A5, We, Wc, W_nh, W_lr, Wv, Wd, W1_, W2_, b2_, PW, Wp, W0s, b0s, W1s,
-                              *(c(t.detach()) for t in small_in), *(c(P[f"ff.{m}.linear.weight"]) for m in ("child_ff", "root_ff", "dec_ff")))
+                              *(c(t.detach()) for t in small_in), *(c(P[f"ff.{m}.linear.weight"]) for m in ("child_ff", "root_ff", "dec_ff")),
+                              r1f, r2f, root_rule)
         ctx.meta = (nb, B, L, E, h, T, H, r, act, [t.dtype for t in (emb, x, token_emb, root_emb, dec_emb)], [p.dtype for p in params])
-        return big, small
+        return x1, x2, y1, y2, root_rule
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_big, g_small):
+    def backward(ctx, g_x1, g_x2, g_y1, g_y2, g_root):
         (emb2, cmean, X, A1, A2, A3, A4, A5, We, Wc, W_nh, W_lr, Wv, Wd, W1_, W2_, b2_, PW, Wp, W0s, b0s, W1s, tok, rootE, decE,
-         Wchild, Wroot, Wdec) = ctx.saved_tensors
+         Wchild, Wroot, Wdec, r1f, r2f, root_rule) = ctx.saved_tensors
         nb, B, L, E, h, T, H, r, act, in_dt, p_dt = ctx.meta
         M0, Ms = B * L, T + 3
         M = M0 + Ms
         G = {}
-        g_big, g_small = g_big.to(act).contiguous(), g_small.to(act).contiguous()
+        g_big = torch.cat([g_x1.reshape(4 * M0, r), g_y1.reshape(4 * M0, r)], 1).to(act)
+        gl = g_root.float()
+        dlogit = (gl - root_rule.exp() * gl.sum()).unsqueeze(0)                          # log_softmax adjoint [1,T]
+        g_small = torch.zeros((4 * Ms, 4 * r), dtype=act, device=g_big.device)
+        g_small[:4 * T, :r] = g_x2.reshape(4 * T, r)
+        g_small[:4 * T, r:2 * r] = (dlogit.t() @ r1f).reshape(4 * T, r)                  # d r2[c] = dlogit[c] r1
+        g_small[4 * T:4 * T + 4, 2 * r:3 * r] = (dlogit @ r2f).reshape(4, r)             # d r1 = sum_c dlogit[c] r2[c]
+        g_small[4 * T + 4:, 3 * r:] = g_y2.reshape(8, r)
         # ---- folded projections ----
         gA5 = torch.empty_like(A5)
         torch.mm(g_big, Wp[:2 * r], out=gA5[:4 * M0])
@@ -257,13 +273,4 @@ def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None):
     T = token_emb.shape[0]
     if tuple(x.shape[:2]) != (B, L) or tuple(root_emb.shape[:1]) != (1,) or tuple(dec_emb.shape[:1]) != (2,):
         raise ValueError(f"parser_feed_forward: emb {tuple(emb.shape)} x {tuple(x.shape)} root_emb {tuple(root_emb.shape)} dec_emb {tuple(dec_emb.shape)}")
-    big, small = _ParserFF.apply(nb, emb, x, token_emb, root_emb, dec_emb, *(P[k] for k in param_names(nb)))
-    r = big.shape[1] // 2
-    x1 = big[:, :r].reshape(B, L, 2, 2, r)
-    y1 = big[:, r:].reshape(B, L, 2, 2, r)
-    x2 = small[:4 * T, :r].reshape(T, 2, 2, r)
-    r2 = small[:4 * T, r:2 * r].reshape(T, 2, 2, r)
-    r1 = small[4 * T:4 * T + 4, 2 * r:3 * r].reshape(1, 2, 2, r)
-    y2 = small[4 * T + 4:, 3 * r:].reshape(2, 2, 2, r)
-    root_rule = torch.einsum("hdve,cdve->hc", r1.float(), r2.float()).log_softmax(-1)[0]   # ldndmv.py:205
-    return x1, x2, y1, y2, root_rule
+    return _ParserFF.apply(nb, emb, x, token_emb, root_emb, dec_emb, *(P[k] for k in param_names(nb)))
