@@ -1509,6 +1509,19 @@ __global__ __launch_bounds__(256) void align_bwd_transpose_kernel(const T* __res
 // NF = fixed indices (captions / images) per workgroup: their wave sets share every staged feature tile.  Round 3: per step a block
 // moves 11.8 KB of cotangent from HBM and a 16-24 KB feature tile from L2; at the ~5.5 TB/s the HBM + L2 -> CU paths delivered
 // together in every kernel of this shape, the RE-STREAMED features were more than half of what bounds it.  NF = 2 halves them.
+// four consecutive cotangent words (4-byte aligned).  (Round 4: a NON-TEMPORAL load here -- the cotangent is read once per side --
+// measured 0.53 -> 0.59 ms for the call: the second side's pass finds part of the 774 MB in the Infinity Cache only if the first
+// side's loads were allowed to stay there.  -DVLG_BWD_NT selects it.)
+typedef float ab_g4_t __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 ld_g4(const char* p) {
+#ifdef VLG_BWD_NT
+    const ab_g4_t v = __builtin_nontemporal_load(reinterpret_cast<const ab_g4_t*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+
 template <bool KCONTIG, int NKC, int MT, int CW, int NT, int FS, int NF = 1>
 __device__ __forceinline__ void align_bwd_split_body(const float* __restrict__ g, const uint16_t* __restrict__ featT,
                                                      const uint8_t* __restrict__ rmask, int O, int M, int K, long so, long sr,
@@ -1584,7 +1597,7 @@ __device__ __forceinline__ void align_bwd_split_body(const float* __restrict__ g
                     for (int h = 0; h < 2; ++h) {
                         if (k_quads) {   // K % 4 == 0 (block-uniform): every quad is whole or empty; the empty ones re-read the
                                          // row's last quad and meet zero feature columns
-                            const float4 v = *reinterpret_cast<const float4*>(go + goff[r][kc][h]);   // 4-byte aligned is enough
+                            const float4 v = ld_g4(go + goff[r][kc][h]);   // 4-byte aligned is enough
                             graw[r][kc][4 * h + 0] = v.x; graw[r][kc][4 * h + 1] = v.y;
                             graw[r][kc][4 * h + 2] = v.z; graw[r][kc][4 * h + 3] = v.w;
                         } else {         // clamped words
@@ -1784,7 +1797,7 @@ __global__ __launch_bounds__(384 * NF) __attribute__((amdgpu_waves_per_eu(3, 4))
         for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float4 q = *reinterpret_cast<const float4*>(go + goff[kc][h] + (gsec[kc][h] ? step2 : 0u));   // 4-byte aligned is enough
+                const float4 q = ld_g4(go + goff[kc][h] + (gsec[kc][h] ? step2 : 0u));   // 4-byte aligned is enough
                 graw[kc][4 * h + 0] = q.x; graw[kc][4 * h + 1] = q.y; graw[kc][4 * h + 2] = q.z; graw[kc][4 * h + 3] = q.w;
             }
     };

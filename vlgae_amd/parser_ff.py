@@ -108,7 +108,8 @@ class _ParserFF(torch.autograd.Function):
             W1s = torch.stack([c(P[f"ff.mid_ff.{b}.1.weight"]) for b in _BOTTLENECKS])     # [4,H,nb]
             b1s = torch.stack([c(P[f"ff.mid_ff.{b}.1.bias"]) for b in _BOTTLENECKS])       # [4,H]
             Weff = torch.bmm(W1s, W0s)                                                      # [4,H,H]
-            beff = torch.baddbmm(b1s.unsqueeze(2), W1s, b0s.unsqueeze(2)).squeeze(2)        # [4,H]
+            # (as a multiply + sum: the library's batched bf16 matrix-VECTOR product costs ~10 ms of HOST time per call on this stack)
+            beff = (W1s * b0s.unsqueeze(1)).sum(2) + b1s                                    # [4,H] = W1 b0 + b1
         else:
             W0s = b0s = W1s = b1s = None
             Weff = torch.stack([c(P[f"ff.mid_ff.{b}.weight"]) for b in _BOTTLENECKS])
@@ -184,7 +185,7 @@ class _ParserFF(torch.autograd.Function):
         # (the small products below run in the activations' dtype: as fp32 GEMMs on one workgroup each the library takes 30-50 us for them)
         dWp, dbp = torch.cat([dWp_b, dWp_s]).to(act), torch.cat([dbp_b, dbp_s]).to(act)  # [6r,H], [6r]
         dPW = torch.addmm(torch.outer(dbp, b2_), dWp, W2_.t())                           # Wp = PW W2, bp = PW b2 + Pb
-        G["linear2.w"], G["linear2.b"] = PW.t() @ dWp, PW.t() @ dbp
+        G["linear2.w"], G["linear2.b"] = PW.t() @ dWp, (PW * dbp.unsqueeze(1)).sum(0)     # (PW^T dbp as multiply + sum: the bf16 transposed mat-vec is ~10 ms of host time)
         # ---- linear1, direction ----
         g = _lrelu_bwd(gA5, A5)
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4)
@@ -227,7 +228,7 @@ class _ParserFF(torch.autograd.Function):
             dWe_a, dbe_a = dWeff.to(act), dbeff.to(act)
             dW1s = torch.baddbmm(torch.einsum("kh,kn->khn", dbe_a, b0s), dWe_a, W0s.transpose(1, 2))   # [4,H,nb]
             dW0s = torch.bmm(W1s.transpose(1, 2), dWe_a)                                 # [4,nb,H]
-            db0s = torch.bmm(W1s.transpose(1, 2), dbe_a.unsqueeze(2)).squeeze(2)         # [4,nb]
+            db0s = (W1s * dbe_a.unsqueeze(2)).sum(1)                                     # [4,nb] = W1^T dbeff (not a batched mat-vec: see forward)
         # ---- gradients in the order of param_names ----
         out = [G["head.w"], G["head.b"], G["child.w"], G["child.b"], G["root.w"], G["root.b"], G["dec.w"], G["dec.b"]]
         for k in range(4):
