@@ -1221,7 +1221,7 @@ def test_training_step_chain_as_one_hip_graph():
     with torch.autograd.set_multithreading_enabled(False):
         # fixed SharedDropout masks: a replay must reproduce the eager step (masks drawn inside the step differ per replay by design)
         drop = (torch.rand(4, 64, 128, generator=torch.Generator().manual_seed(5)) >= 0.33).float() / 0.67
-        step = train_step.build(64, 24, 20, dev(), dtype=torch.bfloat16, E=96, H=64, nb=24, given=dict(drop=drop))
+        step = train_step.build(64, 24, 20, dev(), dtype=torch.bfloat16, E=96, H=64, nb=24, given=dict(drop=drop), p_ff_drop=0.0, p_mid_drop=0.0)
         for _ in range(3):
             total, grads, pot_grads = step()
         want = [total.detach().clone()] + [grads[k].clone() for k in step.names] + [g.clone() for g in pot_grads]
@@ -1284,6 +1284,7 @@ def trainstep_from_fixture(g, dtype):
     # (the parser's feed-forwards are torch ops outside the hot path: float32 in both runs, so that the bf16 run's potentials -- and
     #  with them the Viterbi heads every later value depends on -- differ from the reference's only through the hot path's own rounding)
     step = train_step.build(B, L, V, dev(), dtype=dtype, ff_dtype=torch.float32, d=d, h=h, given=given, alpha=float(g["alpha"]), use_pos_prior=True,
+                            p_ff_drop=0.0, p_mid_drop=0.0,   # (the fixtures ran the parser's feed-forwards without their dropout)
                             vis2txt=float(g["vis2txt_weight"]), factor_names=[str(n) for n in g["factor_names"]],
                             vis_split=[int(w) for w in g["vis_split"]], pos_for=pos_for, ln_eps=float(g["ln_eps"]))
     ref = {k: g["g_" + k] for k in ("enc_x", "emb", "vis_mid", "w_vis", "ln_w", "ln_b", "w2", "token_emb", "root_emb", "dec_emb")}
@@ -1373,7 +1374,8 @@ def test_parser_feed_forward_vs_module_by_module(dtype, nb):
     hand-written adjoint) against the reference's module-by-module formulation (tools/train_step.scorer_feed_forward: the restatement
     of MLP / DMVSkipConnectEncoder / DMVFactorizedBilinear.project* that the trainstep fixtures pin on the reference's own modules) in
     float64: the five outputs and the gradient w.r.t. every input and parameter.  float32: 2e-5 * max (folding W1 W0 and P W2 re-associates
-    fp32 products); bf16: 3e-2 * max values, 8e-2 relative L2 gradients."""
+    fp32 products); bf16: 3e-2 * max values, 0.15 relative L2 gradients.  The cases with a bottleneck also run with training-mode dropout
+    (SharedDropout masks of the MLPs, nn.Dropout mask of mid_ff) given explicitly to both formulations."""
     _tools_path()
     import train_step
     from vlgae_amd import parser_ff
@@ -1387,12 +1389,14 @@ def test_parser_feed_forward_vs_module_by_module(dtype, nb):
     x = torch.randn(B, L, h, generator=gen).to(dev(), dtype).requires_grad_(True)
     names = sorted(P)
     leaves = [emb, x] + [P[k] for k in names]
-    outs = parser_ff.parser_feed_forward(P, emb, x)
+    # training-mode dropout as explicit masks, the same ones on both sides (every second case; rates of the shipped config)
+    masks = parser_ff.dropout_masks(B, L, T, H, 0.33, 0.3, device=dev(), dtype=torch.float32) if nb else (None, None, None)
+    outs = parser_ff.parser_feed_forward(P, emb, x, None, None, None, *masks)
     cot = [torch.randn(o.shape, generator=gen).to(dev()) for o in outs]
     got = torch.autograd.grad([o.float() for o in outs], leaves, cot)
     P64 = {k: v.detach().double().requires_grad_(True) for k, v in P.items()}
     e64, x64 = emb.detach().double().requires_grad_(True), x.detach().double().requires_grad_(True)
-    ref = train_step.scorer_feed_forward(P64, e64, x64)
+    ref = train_step.scorer_feed_forward(P64, e64, x64, *(None if m is None else m.double() for m in masks))
     want = torch.autograd.grad(list(ref), [e64, x64] + [P64[k] for k in names], [c.double() for c in cot])
     f32 = dtype == torch.float32
     for name, a, b in zip(("x1", "x2", "y1", "y2", "root_rule"), outs, ref):
@@ -1407,7 +1411,9 @@ def test_parser_feed_forward_vs_module_by_module(dtype, nb):
         if f32:
             assert float((a.double() - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-3 * gmax), name
         else:
-            assert float((a.double() - b).norm()) <= 8e-2 * float(b.norm()) + 2e-3 * gmax * b.numel() ** 0.5, name
+            # (bf16: six LeakyReLUs deep, a pre-activation within bf16 rounding of zero takes the other branch than in float64 and its
+            #  term changes by 1 / slope = 100x; the float32 cases above are the check of the mathematics)
+            assert float((a.double() - b).norm()) <= 0.15 * float(b.norm()) + 2e-3 * gmax * b.numel() ** 0.5, name
 
 
 def test_linear_wgrad_partial_tiles():
@@ -1503,7 +1509,8 @@ def test_training_step_reference_wiring_config_size():
     B, L, V, d = 256, 40, 36, 128
     drop = (torch.rand(4, B, d, generator=torch.Generator().manual_seed(5)) >= 0.33).float() / 0.67
     with torch.autograd.set_multithreading_enabled(False):
-        step = train_step.build(B, L, V, dev(), dtype=torch.float32, E=96, Et=16, H=64, nb=24, given=dict(drop=drop), seed=21)
+        step = train_step.build(B, L, V, dev(), dtype=torch.float32, E=96, Et=16, H=64, nb=24, given=dict(drop=drop), seed=21,
+                                p_ff_drop=0.0, p_mid_drop=0.0)
         loss, grads, _ = step()
         heads = step.last["heads"]
         P64 = {k: v.detach().double().requires_grad_(True) for k, v in step.P.items()}

@@ -395,7 +395,7 @@ def train_step_entry(B, L, V, dtype, dev, wiring="reference"):
     if wiring == "reference":
         what = ("one training step as the reference wires it (base.py:215-241, joint.py:658-711, ldndmv.py:171-216,260-285, fn.py:50-56): "
                 "vis_mlp_pre_matching -> lang_feat_word_only -> attention fuse -> [fused x] context mean + the parser's feed-forwards "
-                "(vlgae_amd.parser_ff: head_ff / mid_ff / scorer projections, E=800 H=256 n_bottleneck=150 r=16) -> score construction -> "
+                "(vlgae_amd.parser_ff: head_ff / mid_ff / scorer projections, E=800 H=256 n_bottleneck=150 r=16, their dropout 0.33 / 0.3 drawn per step) -> score construction -> "
                 "[un-fused x] lang_feat_max_tree (DMV1o marginals || one Viterbi pass, word|child|parent encoders with SharedDropout p=0.33 "
                 "drawn per step, arc encoder) -> alignment maxima with the POS prior + grounding cross-entropies (ragged vis_mask) -> "
                 "-DMV1o.max -> 0.5 mt + 0.5 dep -> / num_token -> gradients to every input feature and parameter")

@@ -46,9 +46,9 @@ def _lin(P, name, x):
 
 
 def _mlp(P, name, x, drop=None):
-    """MLP (nn/common.py:23-51): Linear -> LeakyReLU -> SharedDropout (mask [B,1,H] or None)."""
+    """MLP (nn/common.py:23-51): Linear -> LeakyReLU -> SharedDropout (a mask broadcastable to the output, or None)."""
     y = F.leaky_relu(_lin(P, f"ff.{name}.linear", x), SLOPE)
-    return y if drop is None else y * drop
+    return y if drop is None else y * drop.to(y.dtype)
 
 
 def _bottleneck(P, name, x):
@@ -57,8 +57,8 @@ def _bottleneck(P, name, x):
     return _lin(P, name + ".1", _lin(P, name + ".0", x))      # nn.Sequential(Linear(H, nb), Linear(nb, H)), no activation between
 
 
-def _skip_connect(P, x, p_drop=0.0):
-    """DMVSkipConnectEncoder.forward (nn/dmv_spec.py:38-54): [..., H] -> [..., dir, val, H]."""
+def _skip_connect(P, x, drop=None):
+    """DMVSkipConnectEncoder.forward (nn/dmv_spec.py:38-54): [..., H] -> [..., dir, val, H].  drop: nn.Dropout's mask [..., 2, 2, H] or None."""
     act = lambda t: F.leaky_relu(t, SLOPE)
     m = "ff.mid_ff."
     has_child = _bottleneck(P, m + "HASCHILD_linear", x) + x
@@ -70,21 +70,27 @@ def _skip_connect(P, x, p_drop=0.0):
     right = _bottleneck(P, m + "RIGHT_linear", h) + x4
     h = torch.stack([left, right], dim=-3)
     h = act(_lin(P, m + "direction_linear", act(h)))
-    if p_drop > 0:
-        h = F.dropout(h, p_drop, True)
+    if drop is not None:
+        h = h * drop.to(h.dtype)
     return _lin(P, m + "linear2", act(_lin(P, m + "linear1", h)))
 
 
-def scorer_feed_forward(P, emb, x_fused, p_mid_drop=0.0, ff_drop=None):
-    """ldndmv.py:174-205 up to the scorers' projected inputs: (x1 [B,L,2,2,r], x2 [T,2,2,r], y1 [B,L,2,2,r], y2 [2,2,2,r],
-    root_rule [T]).  context_mode 'mean' (:226): every token's representation is cat([emb, mean over ALL L positions of x])."""
+def scorer_feed_forward(P, emb, x_fused, drop_head=None, drop_small=None, drop_mid=None):
+    """ldndmv.py:174-205 up to the scorers' projected inputs, MODULE BY MODULE as the reference runs it: (x1 [B,L,2,2,r], x2 [T,2,2,r],
+    y1 [B,L,2,2,r], y2 [2,2,2,r], root_rule [T]).  context_mode 'mean' (:226): every token's representation is cat([emb, mean over ALL L
+    positions of x]).  Dropout masks as in vlgae_amd.parser_ff.parser_feed_forward (explicit, so that the two formulations can be compared)."""
     B, L, _ = emb.shape
+    T = P["token_emb"].shape[0]
+    H = P["ff.head_ff.linear.weight"].shape[0]
+    M0 = B * L
     ctx = x_fused.mean(1, keepdim=True).expand(-1, L, -1)
     h = torch.cat([emb, ctx.to(emb.dtype)], dim=-1)
-    h_parent = _skip_connect(P, _mlp(P, "head_ff", h, ff_drop), p_mid_drop)
-    h_child = _skip_connect(P, _mlp(P, "child_ff", P["token_emb"]), p_mid_drop)          # [T,2,2,H]
-    h_root = _skip_connect(P, _mlp(P, "root_ff", P["root_emb"]), p_mid_drop)             # [1,2,2,H]
-    h_dec = _skip_connect(P, _mlp(P, "dec_ff", P["dec_emb"]), p_mid_drop)                # [2,2,2,H]
+    ds = (lambda a, b: None) if drop_small is None else (lambda a, b: drop_small[a:b].unsqueeze(1))
+    dm = (lambda a, b, shp: None) if drop_mid is None else (lambda a, b, shp: drop_mid[4 * a:4 * b].reshape(*shp, 2, 2, H))
+    h_parent = _skip_connect(P, _mlp(P, "head_ff", h, None if drop_head is None else drop_head.unsqueeze(1)), dm(0, M0, (B, L)))
+    h_child = _skip_connect(P, _mlp(P, "child_ff", P["token_emb"], ds(0, T)), dm(M0, M0 + T, (T,)))                  # [T,2,2,H]
+    h_root = _skip_connect(P, _mlp(P, "root_ff", P["root_emb"], ds(T, T + 1)), dm(M0 + T, M0 + T + 1, (1,)))        # [1,2,2,H]
+    h_dec = _skip_connect(P, _mlp(P, "dec_ff", P["dec_emb"], ds(T + 1, T + 3)), dm(M0 + T + 1, M0 + T + 3, (2,)))   # [2,2,2,H]
     x1, x2 = _lin(P, "ff.attach_scorer.project1", h_parent), _lin(P, "ff.attach_scorer.project2", h_child)
     y1, y2 = _lin(P, "ff.dec_scorer.project1", h_parent), _lin(P, "ff.dec_scorer.project2", h_dec)
     r1, r2 = _lin(P, "ff.root_scorer.project1", h_root), _lin(P, "ff.root_scorer.project2", h_child)
@@ -122,7 +128,7 @@ def init_feed_forward(g, dev, dtype, E, h, Et, T, H, nb, r):
 
 # ----------------------------------------------------------------------------------------------------------------------------
 def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer=True, T=45, r=16, wiring="reference", given=None,
-          alpha=0.5, use_pos_prior=True, vis2txt=1.0, p_drop=0.33, E=800, Et=32, H=256, nb=150, p_ff_drop=0.0, p_mid_drop=0.0,
+          alpha=0.5, use_pos_prior=True, vis2txt=1.0, p_drop=0.33, E=800, Et=32, H=256, nb=150, p_ff_drop=0.33, p_mid_drop=0.3,
           factor_names=("obj",), vis_split=None, pos_for=None, ln_eps=1e-5, ff_dtype=None, fused_ff=True):
     """The step function of one training step at B sentences of <= L words and V region columns.
 
@@ -133,6 +139,7 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     dec_emb and the "ff.*" feed-forward parameters.  With `given` drop absent, fresh masks are drawn every step (p_drop).
     ff_dtype: storage / compute type of the parser's feed-forwards (default = dtype); fused_ff: vlgae_amd.parser_ff (folded / fused
     library GEMMs, hand-written adjoint) instead of the module-by-module torch formulation `scorer_feed_forward` (same values).
+    p_ff_drop / p_mid_drop: the parser feed-forwards' dropout (shipped: 0.33 / 0.3; masks drawn per step; 0 = off, as in the fixtures).
     alpha / use_pos_prior / vis2txt: config/model/vlgae.yaml:62-67.  Returns step(); step() -> (loss, {name: gradient}, ()).
 
     wiring="r3": round 3's chain (see the module docstring); `with_scorer` only matters there."""
@@ -193,7 +200,6 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     num_token_f = float(num_token.item())
     names = sorted(P)
     leaves = [P[k] for k in names]
-    ff_drop = None
     aux = {}
     # the POS prior table (joint.py:446-470) is a function of the batch's tags only -- data, like the masks: built once per batch
     pen = seg = None
@@ -214,10 +220,12 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         word0, _, _ = langfeat.lang_feat_word_only(P["enc_x"], lengths, w_word, b_word, drop=d0)            # :667
         x_f = align.attention_fuse(vis_feat, word0, P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], ln_eps)   # :670-674
         # ---- DiscriminativeNDMV._forward on the fused copy, ldndmv.py:171-216 ----
-        if fused_ff and p_mid_drop == 0 and ff_drop is None:   # the same mathematics with folded / fused GEMMs and a hand-written adjoint
-            x1, x2, y1, y2, root_rule = parser_ff.parser_feed_forward(P, P["emb"], x_f)
-        else:                                                  # module by module, as the reference runs it
-            x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, p_mid_drop, ff_drop)
+        ff_masks = parser_ff.dropout_masks(B, L, P["token_emb"].shape[0], P["ff.head_ff.linear.weight"].shape[0], p_ff_drop, p_mid_drop,
+                                           device=dev, dtype=ff_dtype)
+        if fused_ff:   # the same mathematics with folded / fused GEMMs and a hand-written adjoint
+            x1, x2, y1, y2, root_rule = parser_ff.parser_feed_forward(P, P["emb"], x_f, None, None, None, *ff_masks)
+        else:          # module by module, as the reference runs it
+            x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, *ff_masks)
         md, ma = scorer.ndmv_potentials(x1, x2, y1, y2, root_rule, token)
         # ---- DependencyBoxRel._vis_forward, joint.py:677-691: the UN-fused x; the potentials are constants of this stage (:252-253) ----
         txt, tmask, tmarg = langfeat.lang_feat_max_tree(P["enc_x"], lengths, md.detach(), ma.detach(), P["w_enc"], P["b_enc"], P["w1"],

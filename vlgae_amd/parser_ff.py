@@ -72,7 +72,7 @@ class _ParserFF(torch.autograd.Function):
     """(emb [B,L,E], x [B,L,h], token_emb [T,Et], root_emb [1,er], dec_emb [2,ed], *params) -> (x1, x2, y1, y2, root_rule)."""
 
     @staticmethod
-    def forward(ctx, nb, emb, x, token_emb, root_emb, dec_emb, *params):
+    def forward(ctx, nb, drops, emb, x, token_emb, root_emb, dec_emb, *params):
         names = param_names(nb)
         P = dict(zip(names, (p.detach() for p in params)))
         act = emb.dtype
@@ -101,6 +101,11 @@ class _ParserFF(torch.autograd.Function):
             torch.addmm(c(P[f"ff.{m}.linear.bias"]), c(inp.detach()), c(P[f"ff.{m}.linear.weight"]).t(), out=X[o:o + n])
             o += n
         _lrelu_(X)
+        drop_head, drop_small, drop_mid = drops        # SharedDropout of the MLPs (after the activation, nn/common.py:47-51), nn.Dropout of mid_ff
+        if drop_head is not None:
+            Xb *= drop_head.to(act).unsqueeze(1)        # [B,1,H]: shared over the positions of a sentence
+        if drop_small is not None:
+            X[M0:] *= drop_small.to(act).unsqueeze(1)   # 2-D inputs: SharedDropout's mask is [rows,1] -- whole rows (nn/dropout.py:52-53)
         # ---- folded bottlenecks ----
         if nb:
             W0s = torch.stack([c(P[f"ff.mid_ff.{b}.0.weight"]) for b in _BOTTLENECKS])     # [4,nb,H]
@@ -132,6 +137,8 @@ class _ParserFF(torch.autograd.Function):
         Wd, bd = c(P["ff.mid_ff.direction_linear.weight"]), c(P["ff.mid_ff.direction_linear.bias"])
         A4 = torch.addmm(bd, A3.view(4 * M, H), Wd.t())
         _lrelu_(A4)
+        if drop_mid is not None:
+            A4 *= drop_mid.to(act)                      # nn.Dropout after the direction stage (nn/dmv_spec.py:52)
         # ---- output stage, :52-54 with linear2 folded into the projections ----
         W1_, b1_ = c(P["ff.mid_ff.linear1.weight"]), c(P["ff.mid_ff.linear1.bias"])
         A5 = torch.addmm(b1_, A4, W1_.t())
@@ -156,6 +163,7 @@ class _ParserFF(torch.autograd.Function):
         ctx.save_for_backward(emb2, cmean, X, A1, A2, A3, A4, A5, We, Wc, W_nh, W_lr, Wv, Wd, W1_, W2_, b2_, PW, Wp, W0s, b0s, W1s,
                               *(c(t.detach()) for t in small_in), *(c(P[f"ff.{m}.linear.weight"]) for m in ("child_ff", "root_ff", "dec_ff")),
                               r1f, r2f, root_rule)
+        ctx.drops = drops
         ctx.meta = (nb, B, L, E, h, T, H, r, act, [t.dtype for t in (emb, x, token_emb, root_emb, dec_emb)], [p.dtype for p in params])
         return x1, x2, y1, y2, root_rule
 
@@ -189,7 +197,10 @@ class _ParserFF(torch.autograd.Function):
         # ---- linear1, direction ----
         g = _lrelu_bwd(gA5, A5)
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4)
-        g = _lrelu_bwd(g @ W1_, A4)
+        g = g @ W1_
+        if ctx.drops[2] is not None:
+            g *= ctx.drops[2].to(act)
+        g = _lrelu_bwd(g, A4)
         G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H))
         g3 = _lrelu_bwd(g @ Wd, A3.view(4 * M, H)).view(M, 2, 2, H)                      # d (Z^T-ordered pre-activation) [m,dir,val,c]
         gX = g3.sum((1, 2), dtype=torch.float32)                                         # the skip connection of the direction stage
@@ -207,7 +218,12 @@ class _ParserFF(torch.autograd.Function):
         dWeff = torch.cat([dW_nh.view(2, H, H), dW_lr.view(2, H, H)])                    # [4,H,H] fp32: no, has, left, right
         dbeff = torch.cat([db_nh.view(2, H), db_lr.view(2, H)])
         # ---- MLPs ----
-        gpre = _lrelu_bwd(gX.to(act), X)                                                 # [M,H]
+        gXa = gX.to(act)
+        if ctx.drops[0] is not None:
+            gXa[:M0].view(B, L, H).mul_(ctx.drops[0].to(act).unsqueeze(1))
+        if ctx.drops[1] is not None:
+            gXa[M0:] *= ctx.drops[1].to(act).unsqueeze(1)
+        gpre = _lrelu_bwd(gXa, X)                                                        # [M,H]
         gb = gpre[:M0]
         dWe, dbh = _wgrad(gb, emb2)                                                      # [H,E], [H]
         g_emb = gb @ We                                                                  # [M0,E]
@@ -251,18 +267,21 @@ class _ParserFF(torch.autograd.Function):
         ins = [g_emb.view(B, L, E), g_x, g_small_in[0], g_small_in[1], g_small_in[2]]
         ins = [t if t.dtype == d else t.to(d) for t, d in zip(ins, in_dt)]
         need = ctx.needs_input_grad
-        return (None, *(t if n else None for t, n in zip(ins, need[1:6])), *(t if n else None for t, n in zip(out, need[6:])))
+        return (None, None, *(t if n else None for t, n in zip(ins, need[2:7])), *(t if n else None for t, n in zip(out, need[7:])))
 
 
-def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None):
+def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None, drop_head=None, drop_small=None, drop_mid=None):
     """ldndmv.py:174-205 up to the scorers' projected inputs -> (x1 [B,L,2,2,r], x2 [T,2,2,r], y1 [B,L,2,2,r], y2 [2,2,2,r],
     root_rule [T]), the arguments of `scorer.ndmv_potentials`.
 
     P: dict of the reference modules' parameters under their own names behind "ff." ("ff.head_ff.linear.weight", ...,
     "ff.mid_ff.HASCHILD_linear.0.weight" (n_bottleneck > 0) or "ff.mid_ff.HASCHILD_linear.weight", ..., "ff.root_scorer.project2.bias");
     token_emb / root_emb / dec_emb default to P's entries of those names.  emb [B,L,E] (`encoded['emb']`), x [B,L,h] (the encodings the
-    parser sees: the attention-fused copy, joint.py:670-675).  Dropout (head_ff / mid_ff, training mode) is not applied here: callers
-    that train with it use the module-by-module formulation (tools/train_step.scorer_feed_forward)."""
+    parser sees: the attention-fused copy, joint.py:670-675).
+    Training-mode dropout as explicit masks (entries 0 or 1/(1-p); `dropout_masks` draws them): drop_head [B,H] -- head_ff's SharedDropout,
+    one mask per sentence; drop_small [T+3] -- child_ff / root_ff / dec_ff see 2-D inputs, where SharedDropout's mask is one scalar per
+    row (nn/dropout.py:52-53); drop_mid [4 (B L + T + 3), H] -- mid_ff's nn.Dropout after its direction stage (nn/dmv_spec.py:52), rows in
+    the order (input row, direction, valence) with the B L parent rows first.  None = identity (eval)."""
     _C.require_gpu(emb, "parser_feed_forward")
     token_emb = P["token_emb"] if token_emb is None else token_emb
     root_emb = P["root_emb"] if root_emb is None else root_emb
@@ -272,6 +291,21 @@ def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None):
         raise ValueError(f"parser_feed_forward: float32 or bfloat16 embeddings, got {emb.dtype}")
     B, L, _ = emb.shape
     T = token_emb.shape[0]
+    H = P["ff.head_ff.linear.weight"].shape[0]
     if tuple(x.shape[:2]) != (B, L) or tuple(root_emb.shape[:1]) != (1,) or tuple(dec_emb.shape[:1]) != (2,):
         raise ValueError(f"parser_feed_forward: emb {tuple(emb.shape)} x {tuple(x.shape)} root_emb {tuple(root_emb.shape)} dec_emb {tuple(dec_emb.shape)}")
-    return _ParserFF.apply(nb, emb, x, token_emb, root_emb, dec_emb, *(P[k] for k in param_names(nb)))
+    for name, m, shape in (("drop_head", drop_head, (B, H)), ("drop_small", drop_small, (T + 3,)), ("drop_mid", drop_mid, (4 * (B * L + T + 3), H))):
+        if m is not None and tuple(m.shape) != shape:
+            raise ValueError(f"parser_feed_forward: {name} must be {shape}, got {tuple(m.shape)}")
+    drops = tuple(None if m is None else m.detach() for m in (drop_head, drop_small, drop_mid))
+    return _ParserFF.apply(nb, drops, emb, x, token_emb, root_emb, dec_emb, *(P[k] for k in param_names(nb)))
+
+
+def dropout_masks(B, L, T, H, p_ff=0.33, p_mid=0.3, device=None, dtype=torch.float32, generator=None):
+    """One training step's masks for `parser_feed_forward` at the shipped rates (config/model/vlgae.yaml: _dropout 0.33, mid_ff 0.3):
+    (drop_head [B,H], drop_small [T+3], drop_mid [4 (B L + T + 3), H]); a rate of 0 gives None."""
+    def draw(shape, p):
+        if p <= 0:
+            return None
+        return torch.empty(shape, dtype=dtype, device=device).bernoulli_(1 - p, generator=generator).div_(1 - p)
+    return draw((B, H), p_ff), draw((T + 3,), p_ff), draw((4 * (B * L + T + 3), H), p_mid)
