@@ -3,12 +3,17 @@
 Sub-modules
     torch_struct   drop-in for the reference's `src.model.torch_struct` (DMV1o, DependencyCRF, ...)
     align          region x word bilinear alignment (`gather_logit_simple`) and the attention-fuse
+    langfeat       `lang_feat_max_tree` / `lang_feat_word_only` as fused stages (encoders with SharedDropout masks, arc encoder)
+    scorer         score construction feeding the DP (factorised-bilinear scores -> merged potentials)
+    parser_ff      the parser's feed-forwards in front of it (head_ff / mid_ff / scorer projections)
+    vis_encoder    the visual encoder's pairwise relation features
+    feed           token-budget batch sampler and region-feature collate (host C++)
     dist           batch sharding + the single RCCL gradient all-reduce
     build          hipcc driver for the in-tree HIP extension
 
 Everything computes through hand-written gfx950 kernels behind the C ABI of include/vlgae_amd.h.
 """
-__version__ = "0.1.0"
+__version__ = "0.1.3"
 
 
 def configure_autograd():
