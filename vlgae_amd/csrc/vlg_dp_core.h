@@ -222,8 +222,9 @@ VLG_HD Sched make_sched(int Ne, int lanes, int budget) {
 // LDS read cannot fault (past the allocation it returns 0), its value is masked to the lowest float like the clamped duplicate was,
 // and without the clamp the addresses of a lane's TU terms are one base plus compile-time multiples of G: immediate offsets instead
 // of a min, a multiply and a shift-add per term.  (The host emulator's charts are heap arrays: it keeps the clamp.)
-template <int SR, bool BWD, int DIR, int TU, typename X, bool NOCLAMP = false>
-VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x) {
+template <int SR, bool BWD, int DIRT, int TU, typename X, bool NOCLAMP = false>
+VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x, int dir_rt = 0) {
+    const int DIR = DIRT < 0 ? dir_rt : DIRT;   // DIRT < 0: the direction is a (wave-uniform) run-time value -- both wave halves run ONE copy of the code
     VLG_STAMP_AT(x, 6);   // since the end of the previous span: phase preamble + barrier
     const int P = c.P, DW = D + VLG_MUL24(w, P);   // DW: chart index of (row j, column i)
     const float* Cf = reinterpret_cast<const float*>(c.C);
@@ -397,7 +398,7 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
 
 // one width of the inside pass for this lane: G = 2^LG lanes per (span, direction); LG < 0: G is a run-time value
 template <int SR, bool BWD, int DIR, int LG, bool LONGSPAN, typename X>
-VLG_HD void dmv_fw_width(const DmvCtx& c, int w, int lgr, int t, int nd, X& x) {
+VLG_HD void dmv_fw_width(const DmvCtx& c, int w, int lgr, int t, int nd, X& x, int dir_rt = 0) {
     const int lg = LG >= 0 ? LG : lgr, G = 1 << lg, per = nd >> lg;
     const int rr = t & (G - 1), slot = t >> lg, spans = c.Ne - w;
     const int T = (w + G - 1) >> lg;   // split points per lane; uniform over the workgroup
@@ -407,11 +408,11 @@ VLG_HD void dmv_fw_width(const DmvCtx& c, int w, int lgr, int t, int nd, X& x) {
         if (X::kSkipDeadWaves && (base + ((t & ~63) >> lg)) >= spans) continue;   // whole wavefront past the last span
         const int D = VLG_MUL24(i, c.P + 1);
         constexpr bool NC = !LONGSPAN && X::kChartsInLds;
-        if (T == 1) dmv_fw_span<SR, BWD, DIR, 1, X, NC>(c, w, G, D, live, rr, x);
-        else if (T == 2) dmv_fw_span<SR, BWD, DIR, 2, X, NC>(c, w, G, D, live, rr, x);
-        else if (T == 3) dmv_fw_span<SR, BWD, DIR, 3, X, NC>(c, w, G, D, live, rr, x);
-        else if (T == 4) dmv_fw_span<SR, BWD, DIR, 4, X, NC>(c, w, G, D, live, rr, x);
-        else dmv_fw_span<SR, BWD, DIR, LONGSPAN ? -1 : 0>(c, w, G, D, live, rr, x);
+        if (T == 1) dmv_fw_span<SR, BWD, DIR, 1, X, NC>(c, w, G, D, live, rr, x, dir_rt);
+        else if (T == 2) dmv_fw_span<SR, BWD, DIR, 2, X, NC>(c, w, G, D, live, rr, x, dir_rt);
+        else if (T == 3) dmv_fw_span<SR, BWD, DIR, 3, X, NC>(c, w, G, D, live, rr, x, dir_rt);
+        else if (T == 4) dmv_fw_span<SR, BWD, DIR, 4, X, NC>(c, w, G, D, live, rr, x, dir_rt);
+        else dmv_fw_span<SR, BWD, DIR, LONGSPAN ? -1 : 0>(c, w, G, D, live, rr, x, dir_rt);
     }
 }
 
@@ -423,8 +424,12 @@ VLG_HD void dmv_fw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& 
     const int t = right ? tid - nd : tid;
     for (int w = w0; w < w1; ++w) {
 #ifndef VLG_ABL_NOBODY
+#ifdef VLG_DIR_RT_FW   // (measured: 33.4 -> 39.4 us for the inside pass -- its selects sit in the per-term loop; see dmv_bw_segment)
+        dmv_fw_width<SR, BWD, -1, LG, LONGSPAN>(c, w, LG, t, nd, x, right ? 1 : 0);
+#else
         if (right) dmv_fw_width<SR, BWD, 1, LG, LONGSPAN>(c, w, LG, t, nd, x);
         else dmv_fw_width<SR, BWD, 0, LG, LONGSPAN>(c, w, LG, t, nd, x);
+#endif
 #endif
 #ifndef VLG_ABL_NOBARRIER
         x.sync();
@@ -452,8 +457,9 @@ VLG_HD void dmv_fw_all(const DmvCtx& c, int tid, int nt, X& x) {
 // All loads -- including the read half of every read-modify-write -- are issued before the first store, so
 // nothing waits on an earlier store of the same phase.
 // ------------------------------------------------------------------------------------------------
-template <int SR, int DIR, int TU, typename X, bool CHUNKED = false, bool NOCLAMP = false>   // NOCLAMP: see dmv_fw_span
-VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x, int nchunk = 1) {
+template <int SR, int DIRT, int TU, typename X, bool CHUNKED = false, bool NOCLAMP = false>   // NOCLAMP: see dmv_fw_span
+VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x, int nchunk = 1, int dir_rt = 0) {
+    const int DIR = DIRT < 0 ? dir_rt : DIRT;
     const int P = c.P, DW = D + VLG_MUL24(w, P);
     const float* Cf = reinterpret_cast<const float*>(c.C);
     float* gCif = reinterpret_cast<float*>(c.gCi);
@@ -570,7 +576,7 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
 }
 
 template <int SR, int DIR, int LG, bool LONGSPAN, typename X>
-VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x) {
+VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x, int dir_rt = 0) {
     constexpr int G = 1 << LG;
     constexpr bool NC = !LONGSPAN && X::kChartsInLds;
     const int per = nd >> LG, rr = t & (G - 1), slot = t >> LG, spans = c.Ne - w;
@@ -580,11 +586,11 @@ VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x) {
         const int i = live ? base + slot : 0;
         if (X::kSkipDeadWaves && (base + ((t & ~63) >> LG)) >= spans) continue;
         const int D = VLG_MUL24(i, c.P + 1);
-        if (T == 1) dmv_bw_span<SR, DIR, 1, X, false, NC>(c, w, G, D, live, rr, x);
-        else if (T == 2) dmv_bw_span<SR, DIR, 2, X, false, NC>(c, w, G, D, live, rr, x);
-        else if (T == 3) dmv_bw_span<SR, DIR, 3, X, false, NC>(c, w, G, D, live, rr, x);
-        else if (T == 4) dmv_bw_span<SR, DIR, 4, X, false, NC>(c, w, G, D, live, rr, x);
-        else dmv_bw_span<SR, DIR, 4, X, true>(c, w, G, D, live, rr, x, (T + 3) >> 2);   // chunks of four split points per lane
+        if (T == 1) dmv_bw_span<SR, DIR, 1, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
+        else if (T == 2) dmv_bw_span<SR, DIR, 2, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
+        else if (T == 3) dmv_bw_span<SR, DIR, 3, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
+        else if (T == 4) dmv_bw_span<SR, DIR, 4, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
+        else dmv_bw_span<SR, DIR, 4, X, true>(c, w, G, D, live, rr, x, (T + 3) >> 2, dir_rt);   // chunks of four split points per lane
     }
 }
 
@@ -595,8 +601,17 @@ VLG_HD void dmv_bw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& 
     const bool right = x.uniform(tid >= nd);
     const int t = right ? tid - nd : tid;
     for (int w = w1 - 1; w >= w0; --w) {
+#ifndef VLG_DIR_TEMPLATE_BW
+        // Round 4: the direction is a wave-uniform RUN-TIME value in the outside pass -- both halves of the workgroup execute one copy
+        // of the code, so each instruction-cache line serves eight wavefronts instead of four (the kernel is ~200 KB and 11 % of its wave
+        // cycles wait for instructions); the direction-dependent indices become a few scalar selects per span.  Fused launch 75.8 ->
+        // 75.5 us, bit-identical, half the outside-pass code.  (The same change in the inside pass costs 6 us: its direction-dependent
+        // predicates sit per term.)
+        dmv_bw_width<SR, -1, LG, LONGSPAN>(c, w, t, nd, x, right ? 1 : 0);
+#else
         if (right) dmv_bw_width<SR, 1, LG, LONGSPAN>(c, w, t, nd, x);
         else dmv_bw_width<SR, 0, LG, LONGSPAN>(c, w, t, nd, x);
+#endif
         x.sync();
     }
 }
