@@ -64,6 +64,15 @@ def test_version_and_error_plumbing(lib):
     assert lib.vlg_bilinear_align_backward_workspace(4, 4, 82, 36, 128, 1) == (128 * (4 * 36 + 96) + 4 * 128 * 96) * 2 and lib.vlg_bilinear_align_backward_workspace(4, 4, 82, 36, 64, 0) == 0 and lib.vlg_bilinear_align_backward_workspace(4, 4, 82, 36, 128, 0) == 2 * (4 * 128 * 64 + 4 * 128 * 96) * 2
     assert lib.vlg_bilinear_align_backward(one, one, one, None, None, 4, 4, 82, 36, 128, 1, None, 0, one, one, None) == 0x1004   # fast path without its scratch
     assert lib.vlg_dmv1o_count_sum(None, None, 4, 8, None, None) == 0x1003
+    # round 4: the language-side kernels take the activations' storage type and the SharedDropout masks
+    assert lib.vlg_version() >= 130
+    assert lib.vlg_langfeat_root_cat(one, one, 2, 5, 64, 0, one, 7, None) == 0x1002                               # out_dtype
+    assert lib.vlg_langfeat_split(one, one, one, 8, 2, 6, 32, 0, 0.01, one, one, one, None, None) == 0x1001       # ld_drop < 3 d
+    assert lib.vlg_langfeat_split(one, one, None, 0, 2, 6, 32, 5, 0.01, one, one, one, None, None) == 0x1002      # act_dtype
+    assert lib.vlg_langfeat_rowscale(one, one, 2, 6, 36, 36, 0, one, None) == 0x1001                              # d % 8
+    assert lib.vlg_langfeat_rowscale(one, None, 2, 6, 32, 32, 0, one, None) == 0x1003                             # null masks
+    assert lib.vlg_langfeat_arc_out(one, None, 2, 6, 32, 9, one, None) == 0x1002
+    assert lib.vlg_linear_wgrad_workspace(4096, 24, 72) > 0 and lib.vlg_linear_wgrad_workspace(4096, 20, 72) == 0     # multiples of 8
     with pytest.raises(RuntimeError, match="N >= 2"):
         _C.check(lib.vlg_dmv1o_inside(None, None, None, 4, 1, 0, 0, None, None, 0, None), "dmv1o_inside")
     # empty batches are a no-op success

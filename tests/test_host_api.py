@@ -94,3 +94,29 @@ def test_shard_bounds():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [e - s for s, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_train_shapes_match_the_step_and_parser_ff_names():
+    """The dry-run stand-in of the sharded training step (tools/bench_train._param_shapes) must list exactly the trainable leaves of
+    tools/train_step.build with their shapes, and vlgae_amd.parser_ff.param_names must cover every "ff." parameter -- otherwise the
+    gloo plumbing tests would exercise a different flat-gradient layout than the GPU run."""
+    import os
+    import sys
+    import torch
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_train
+    import train_step
+    from vlgae_amd import parser_ff
+    f = bench_train.FF_SHAPES
+    P = train_step.init_feed_forward(torch.Generator().manual_seed(0), torch.device("cpu"), torch.float32, f["E"], f["h"], f["Et"], f["T"],
+                                     f["H"], f["nb"], f["r"])
+    shapes, groups = bench_train._param_shapes()
+    ff_keys = {k for k in shapes if k.startswith("ff.") or k in ("token_emb", "root_emb", "dec_emb")}
+    assert ff_keys == set(P), ff_keys ^ set(P)
+    assert all(tuple(P[k].shape) == tuple(shapes[k]) for k in P)
+    assert set(parser_ff.param_names(f["nb"])) == {k for k in P if k.startswith("ff.")}
+    assert set(parser_ff.param_names(0)) == {k for k in train_step.init_feed_forward(torch.Generator().manual_seed(0), torch.device("cpu"),
+                                                                                    torch.float32, 8, 8, 8, 3, 8, 0, 4) if k.startswith("ff.")}
+    assert sorted(k for g in groups for k in g) == sorted(shapes)          # the readiness groups partition the trainable leaves
+    assert groups[0] == ["w1", "w2", "b"] and "w_vis" in groups[2]
