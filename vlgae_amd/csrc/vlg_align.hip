@@ -1123,10 +1123,16 @@ __global__ __launch_bounds__(64) void align_prior_diag_kernel(
 // contiguous 1 KB stores.  (Storing the accumulators straight to global memory -- 16 rows x 64 bytes per instruction -- was
 // measured first: 0.271 ms, write-combining of half cache lines is slower than the LDS detour.)
 // =====================================================================================================
-__global__ __launch_bounds__(kAMThreads, 2) void align_full_kernel(
+#ifndef VLG_AF_RT
+#define VLG_AF_RT 6
+#endif
+#ifndef VLG_AF_WPE
+#define VLG_AF_WPE 2
+#endif
+__global__ __launch_bounds__(kAMThreads, VLG_AF_WPE) void align_full_kernel(
     const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
     const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_full, int a_per_block) {
-    constexpr int d = 128, KCH = 4, RT = 6;
+    constexpr int d = 128, KCH = 4, RT = VLG_AF_RT;
     __shared__ uint4 tiles[2][kAMSlots];
     __shared__ uint8_t ckeep_s[2][kAMRows];
     extern __shared__ __attribute__((aligned(16))) float af_otile[];   // [8 waves][96 queries][V] fp32: the output block's own layout
@@ -1169,13 +1175,13 @@ __global__ __launch_bounds__(kAMThreads, 2) void align_full_kernel(
 #pragma unroll
             for (int kc = 0; kc < KCH; ++kc) qf[rt][kc] = rowp[kc * 4];
         }
-        unsigned qkeep = 0x3fu;   // bit rt: this lane's query of row tile rt is kept
+        unsigned qkeep = (1u << RT) - 1u;   // bit rt: this lane's query of row tile rt is kept
         if (tmask) {
             qkeep = 0;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) qkeep |= (tmask[(size_t)bc * Q + min(q0 + rt * 16 + ccol, Q - 1)] ? 1u : 0u) << rt;
         }
-        const bool q_masked = __builtin_amdgcn_ballot_w64(qkeep != 0x3fu) != 0;
+        const bool q_masked = __builtin_amdgcn_ballot_w64(qkeep != (1u << RT) - 1u) != 0;
         uint4 xs[NS] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
         unsigned ck = 1;
         if (n_img > 0) {
@@ -1251,7 +1257,7 @@ static int launch_align_full(const void* txt, const void* vis, const uint8_t* tm
     if (a_per_block < 8) a_per_block = 8;
     if (a_per_block > A) a_per_block = A;
     dim3 grid((A + a_per_block - 1) / a_per_block, by);
-    const size_t lds = sizeof(float) * (size_t)kAMWaves * 96 * V;
+    const size_t lds = sizeof(float) * (size_t)kAMWaves * (VLG_AF_RT * 16) * V;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_full_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(align_full_kernel, grid, dim3(kAMThreads), lds, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask, vmask, B, A, Q, V,
