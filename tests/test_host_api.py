@@ -120,3 +120,17 @@ def test_bench_train_shapes_match_the_step_and_parser_ff_names():
                                                                                     torch.float32, 8, 8, 8, 3, 8, 0, 4) if k.startswith("ff.")}
     assert sorted(k for g in groups for k in g) == sorted(shapes)          # the readiness groups partition the trainable leaves
     assert groups[0] == ["w1", "w2", "b"] and "w_vis" in groups[2]
+
+
+def test_drop_in_import_selects_backward_on_the_calling_thread():
+    """Importing vlgae_amd.torch_struct (what the reference's import alias does) keeps autograd's backward on the calling thread unless
+    VLGAE_AMD_AUTOGRAD_THREAD=engine (checked in child interpreters: the setting is process-global)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = "import torch, vlgae_amd.torch_struct; print(torch.autograd.is_multithreading_enabled())"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("VLGAE_AMD_AUTOGRAD_THREAD", None)
+    assert subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True, check=True).stdout.strip() == "False"
+    env["VLGAE_AMD_AUTOGRAD_THREAD"] = "engine"
+    assert subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True, check=True).stdout.strip() == "True"
