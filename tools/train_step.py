@@ -183,10 +183,10 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     tag = given.pop("tag").to(dev) if "tag" in given else torch.randint(0, 7, (B, L), generator=g).to(dev)
     if "vis_mask" in given:
         vmask = given.pop("vis_mask").to(dev, torch.bool)
-    else:   # ragged region lists: a random ~85 % of the boxes are real (vis_box_mask, src/datamodule/task/vlparse.py:75-92)
-        vmask = (torch.rand(B, V, generator=g) > 0.15)
-        vmask[:, 0] = True
-        vmask = vmask.to(dev)
+    else:   # ragged region lists as the reference's collate builds them: image i has n_i <= V boxes, `masks_output[i, :n_i] = True` and
+        # padding behind them (src/datamodule/task/vlparse.py:68-83) -- a PREFIX mask per image, n_i drawn from [0.6 V, V]
+        n_box = torch.randint(max(1, (3 * V) // 5), V + 1, (B,), generator=g)
+        vmask = (torch.arange(V)[None] < n_box[:, None]).to(dev)
     fixed_drop = given.pop("drop") if "drop" in given else "draw"
     if fixed_drop is not None and not isinstance(fixed_drop, str):
         fixed_drop = fixed_drop.to(dev, torch.float32).permute(1, 0, 2).contiguous()      # [B,4,d]
