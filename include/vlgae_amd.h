@@ -312,6 +312,28 @@ int vlg_langfeat_marginal(const float* grad_attach, const int64_t* heads, const 
 int vlg_langfeat_arc_out(const float* tri, const void* aff, int B, int N, int d, int act_dtype, void* txt, void* stream);
 int vlg_langfeat_rowscale(const void* pre, const float* drop, int B, int N, int d, int ld_drop, int act_dtype, void* out, void* stream);
 
+/* Element-wise passes between the library GEMMs of the parser's feed-forwards (vlgae_amd/parser_ff.py): `MLP`
+ * (src/model/nn/common.py:23-51: Linear -> LeakyReLU -> SharedDropout) and `DMVSkipConnectEncoder` (src/model/nn/dmv_spec.py:38-54).
+ * Activations in act_dtype (VLG_BF16 / VLG_F32), rows of H channels (H a multiple of 8), 16-byte aligned; fp32 arithmetic.
+ *   vlg_ff_mlp_act            x [B L + Ms, H] in place.  Rows < B L: LeakyReLU(x + cterm[row / L]) * drop_head[row / L] (cterm [B,H]
+ *                             act_dtype: the sentence's context columns + bias; drop_head [B,H] fp32 or NULL); the Ms rows behind
+ *                             them (2-D inputs of their MLPs): LeakyReLU(x) * drop_small[row - B L] (fp32 [Ms] or NULL).
+ *   vlg_ff_act                out[m,j'] = LeakyReLU(in[m,j] + residual[m]) * mask[m,j'], in [M,J,H], residual [M,H] or NULL, mask
+ *                             (act_dtype, indexed like out) or NULL.  swap = 0: j' = j, out may be in.  swap = 1 (J = 4): in is
+ *                             [m,val,dir], out [m,dir,val] -- the stack of nn/dmv_spec.py:47 as a store permutation.
+ *   vlg_ff_act_backward       out[m,j'] = LeakyReLU'(act[m,j]) * g[m,j] * mask[m,j] (g, act, mask [M,J,H] in the same order; the
+ *                             derivative from the sign of the stored activation); sum [M,H] fp32 (or NULL) = / += (accumulate)
+ *                             sum_j of the stored out values.  swap as above (g, act in [m,dir,val]; out in [m,val,dir]).
+ *   vlg_ff_mlp_act_backward   gpre = LeakyReLU'(x) * mask * (gx + t): gx fp32, t act_dtype or NULL, masks as in vlg_ff_mlp_act. */
+int vlg_ff_mlp_act(void* x, const void* cterm, const float* drop_head, const float* drop_small, int B, int L, int Ms, int H, int act_dtype,
+                   float slope, void* stream);
+int vlg_ff_act(const void* in, const void* residual, const void* mask, void* out, long long M, int J, int H, int swap, int act_dtype, float slope,
+               void* stream);
+int vlg_ff_act_backward(const void* g, const void* act, const void* mask, void* out, float* sum, long long M, int J, int H, int swap, int accumulate,
+                        int act_dtype, float slope, void* stream);
+int vlg_ff_mlp_act_backward(const float* gx, const void* t, const void* x, const float* drop_head, const float* drop_small, void* gpre, int B, int L,
+                            int Ms, int H, int act_dtype, float slope, void* stream);
+
 /* Score construction feeding the DP -- the tensor half of `DiscriminativeNDMV._forward`, src/model/ldndmv.py:179-209 with the
  * factorised-bilinear scorers of src/model/nn/dmv_spec.py:57-76: from the scorers' projected inputs to the root-merged
  * potentials, without the [B,L,T,2,2] rule table.

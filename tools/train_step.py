@@ -205,14 +205,28 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     pen = seg = None
     if use_pos_prior:
         pen, seg = align.grounding_prior(tag, factor_names, vis_split, pos_for, Q)
+    # loss = (alpha mt + (1 - alpha) dep) / (num_token + 1e-12), dep = -sum_b max_b: two per-batch coefficients.  They seed the
+    # backward pass directly (autograd.grad's grad_outputs), so the scalar arithmetic of the combination has no adjoint launches.
+    coef = (torch.tensor([alpha, -(1.0 - alpha)], dtype=torch.float32, device=dev) / (num_token.to(torch.float32) + 1e-12))
+    c_mt, c_max = coef[0], coef[1]
+    seed_max = c_max.repeat(B)
+    T_, H_ = P["token_emb"].shape[0], P["ff.head_ff.linear.weight"].shape[0]
+
+    def draw_masks():
+        """(drop [B,4,d] or None, parser_ff masks): the per-sentence masks of one step come out of ONE draw when the rates agree."""
+        if isinstance(fixed_drop, str) and p_drop == p_ff_drop and 0 < p_drop < 1:
+            n0, n1 = B * 4 * d, B * H_
+            buf = torch.empty(n0 + n1 + T_ + 3, dtype=torch.float32, device=dev).bernoulli_(1 - p_drop).div_(1 - p_drop)
+            mid = parser_ff.dropout_masks(B, L, T_, H_, 0.0, p_mid_drop, device=dev, dtype=ff_dtype)[2]
+            return buf[:n0].view(B, 4, d), (buf[n0:n0 + n1].view(B, H_), buf[n0 + n1:], mid)
+        drop = langfeat.shared_dropout_masks(B, d, p_drop, n=4, device=dev) if isinstance(fixed_drop, str) else fixed_drop
+        return drop, parser_ff.dropout_masks(B, L, T_, H_, p_ff_drop, p_mid_drop, device=dev, dtype=ff_dtype)
 
     def step(stage_hook=None):
         """forward + backward; returns (reduced loss, gradients by leaf name, ()).  stage_hook (optional) is called from inside the
         backward pass once the adjoints of the DP and of the grounding loss have run (the cotangent of `txt` exists) -- where a
         data-parallel trainer starts reducing its first gradient bucket."""
-        drop = fixed_drop
-        if isinstance(drop, str):
-            drop = langfeat.shared_dropout_masks(B, d, p_drop, n=4, device=dev)
+        drop, ff_masks = draw_masks()
         d0, d3 = (None, None) if drop is None else (drop[:, 0:1], drop[:, 1:4])
         w_word, b_word = P["w_enc"][:d], P["b_enc"][:d]
         # ---- DependencyBoxRel._forward, joint.py:658-675 ----
@@ -220,8 +234,6 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         word0, _, _ = langfeat.lang_feat_word_only(P["enc_x"], lengths, w_word, b_word, drop=d0)            # :667
         x_f = align.attention_fuse(vis_feat, word0, P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], ln_eps)   # :670-674
         # ---- DiscriminativeNDMV._forward on the fused copy, ldndmv.py:171-216 ----
-        ff_masks = parser_ff.dropout_masks(B, L, P["token_emb"].shape[0], P["ff.head_ff.linear.weight"].shape[0], p_ff_drop, p_mid_drop,
-                                           device=dev, dtype=ff_dtype)
         if fused_ff:   # the same mathematics with folded / fused GEMMs and a hand-written adjoint
             x1, x2, y1, y2, root_rule = parser_ff.parser_feed_forward(P, P["emb"], x_f, None, None, None, *ff_masks)
         else:          # module by module, as the reference runs it
@@ -234,16 +246,16 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
             txt.register_hook(lambda g_: stage_hook())
         # ---- DependencyBoxRel.loss, joint.py:693-711 ----
         mt, sums = align.grounding_loss_factor_ce(txt, vis_feat, tmask, vmask, tmarg, num_token_f, vis2txt, pen, seg)
-        dep = -ts.DMV1o([md, ma], lengths).max.sum()              # ldndmv.py:277-281; the Viterbi pass of lang_feat_max_tree is reused
-        total = alpha * mt + (1 - alpha) * dep
-        loss = total / (num_token + 1e-12)                        # reduce_loss('token')
-        grads = torch.autograd.grad(loss, leaves)
+        mx = ts.DMV1o([md, ma], lengths).max                      # ldndmv.py:277-281: dep = -max.sum(); lang_feat_max_tree's Viterbi pass is reused
+        with torch.no_grad():                                     # alpha mt + (1 - alpha) dep, reduce_loss('token')
+            loss = torch.addcmul(c_mt * mt, mx.sum(), c_max)
+        grads = torch.autograd.grad([mt, mx], leaves, [c_mt, seed_max.view(mx.shape)])
         # intermediates for the parity tests, DETACHED: a reference to a previous step's autograd graph kept alive across a HIP-graph
         # capture makes torch 2.10 / ROCm 7 crash in capture_end
         step.last = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in dict(
             x_fused=x_f, merged_dec=md, merged_attach=ma, txt=txt, txt_mask=tmask, txt_marginal=tmarg, vis_feat=vis_feat, sums=sums,
-            dep_loss=dep, mt_loss=mt, total=total, heads=aux.get("heads")).items()}
-        return loss.detach(), dict(zip(names, grads)), ()
+            viterbi_max=mx, mt_loss=mt, heads=aux.get("heads")).items()}
+        return loss, dict(zip(names, grads)), ()
 
     step.names, step.P, step.lengths, step.wiring = names, P, lengths, wiring
     step.batch = dict(token=token, tag=tag, vis_mask=vmask, alpha=alpha, factor_names=factor_names, vis_split=vis_split, pos_for=pos_for,

@@ -15,7 +15,7 @@ F32, BF16 = 0, 1
 SEMIRING_LOG, SEMIRING_MAX = 0, 1
 OP_DMV1O_INSIDE, OP_DMV1O_INSIDE_OUTSIDE, OP_DEPTREE_INSIDE, OP_DEPTREE_INSIDE_OUTSIDE = 0, 1, 2, 3
 
-_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_vp, _i, _f, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_longlong
 
 # symbol -> (restype, argtypes); one entry per declaration in include/vlgae_amd.h
 SIGNATURES = {
@@ -63,6 +63,10 @@ SIGNATURES = {
     "vlg_langfeat_marginal": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "vlg_langfeat_arc_out": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "vlg_langfeat_rowscale": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vlg_ff_mlp_act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "vlg_ff_act": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _vp]),
+    "vlg_ff_act_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp]),
+    "vlg_ff_mlp_act_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "vlg_ndmv_potentials": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "vlg_ndmv_potentials_backward_workspace": (_sz, [_i, _i, _i, _i]),
     "vlg_ndmv_potentials_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -23,23 +23,13 @@
 #include <stdint.h>
 
 #include "vlg_common.h"
+#include "vlg_rows.h"
 
 namespace vlg {
 
 namespace {
 
-__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
-__device__ __forceinline__ uint16_t f2bf(float v) {   // round to nearest even, like torch's cast
-    const uint32_t u = __float_as_uint(v);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ float ldf(const float* p, size_t i) { return p[i]; }
-__device__ __forceinline__ float ldf(const uint16_t* p, size_t i) { return bf2f(p[i]); }
-
 // x [B,L,h] (T) -> x1 [B,L+1,h] bf16: row 0 = sum_{l < len} x[b,l] / len, rows 1.. = x.  grid = (B, ceil(h / 256)).
-__device__ __forceinline__ void stf(float* p, size_t i, float v) { p[i] = v; }
-__device__ __forceinline__ void stf(uint16_t* p, size_t i, float v) { p[i] = f2bf(v); }
-
 template <typename T, typename A>
 __global__ __launch_bounds__(256) void langfeat_x1_kernel(const T* __restrict__ x, const int64_t* __restrict__ lengths, int L,
                                                           int h, A* __restrict__ x1) {
@@ -71,34 +61,6 @@ __global__ __launch_bounds__(256) void langfeat_x1_bwd_kernel(const T* __restric
 #pragma unroll 4
     for (int l = 0; l < L; ++l) dst[(size_t)l * h] = ldf(src, (size_t)(l + 1) * h) + (l < len ? share : 0.f);
 }
-
-__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
-
-// eight consecutive channels of a row, as floats
-__device__ __forceinline__ void load8(const uint16_t* p, float (&o)[8]) {
-    const uint4 w = *reinterpret_cast<const uint4*>(p);
-    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(u[i] << 16); o[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
-}
-__device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
-    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-}
-__device__ __forceinline__ void store8(uint16_t* p, const float (&v)[8]) {
-    uint4 w;
-    w.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); w.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    w.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); w.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-    *reinterpret_cast<uint4*>(p) = w;
-}
-__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-}
-// the value a tensor of storage type A holds after a store (bf16: rounded; fp32: itself)
-template <typename A> __device__ __forceinline__ float stored(float v);
-template <> __device__ __forceinline__ float stored<uint16_t>(float v) { return bf2f(f2bf(v)); }
-template <> __device__ __forceinline__ float stored<float>(float v) { return v; }
 
 // pre [B*N, 3d] (A) -> txt[b, n, :] = pre[:, 0:d] * m_word;  child[m] = leaky(pre[m, d:2d]) * m_child;
 // parent[b,n] = leaky(pre[b, heads[b,n], 2d:3d]) * m_parent;  sum[m] = child + parent (the add of the STORED values, like torch's).

@@ -20,7 +20,10 @@ bias-gradient reductions and un-fused bias / residual adds.  Here, with identica
     so the [4 B L, H] x [H, H] GEMM of linear2 and its two adjoints never run;
   * head_ff's weight split into its embedding and context columns: the context term is one [B, h] x [h, H] product per sentence
     instead of L copies of it inside a concatenated [B L, E + h] operand;
-  * a hand-written backward in the same granularity with every weight / bias gradient on the split-K kernel (vlg_linear_wgrad).
+  * a hand-written backward in the same granularity with every weight / bias gradient on the split-K kernel (vlg_linear_wgrad);
+  * everything BETWEEN two GEMMs -- bias / context / residual add, LeakyReLU, dropout mask, the (val, dir) -> (dir, val) stack, the
+    skip connections' cotangent sums, LeakyReLU' -- as one pass per stage (csrc/vlg_ff.hip) instead of 2-4 torch launches over a
+    [4 B L, H] activation each.
 The reference formulation (tools/train_step.scorer_feed_forward, module by module) is what the tests compare this with.
 """
 import torch
@@ -52,13 +55,29 @@ def param_names(n_bottleneck):
     return names
 
 
-def _lrelu_(t):
-    return torch.nn.functional.leaky_relu_(t, SLOPE)
+def _adt(t):
+    return _C.BF16 if t.dtype == torch.bfloat16 else _C.F32
 
 
-def _lrelu_bwd(g, out):
-    """g * LeakyReLU'(pre) from the activation's OUTPUT (its sign is the pre-activation's), one launch."""
-    return torch.ops.aten.leaky_relu_backward(g, out, SLOPE, True)
+def _act(inp, out, M, J, H, residual=None, mask=None, swap=False):
+    """out[m,j'] = LeakyReLU(inp[m,j] + residual[m]) * mask[m,j'] in one pass (vlg_ff_act); out may be inp unless swap."""
+    _C.check(_C.lib().vlg_ff_act(_C.ptr(inp), _C.ptr(residual), _C.ptr(mask), _C.ptr(out), M, J, H, int(swap), _adt(inp), SLOPE,
+                                 _C.stream_of(inp)), "ff_act")
+    return out
+
+
+def _act_bwd(g, act, out, M, J, H, mask=None, total=None, accumulate=False, swap=False):
+    """out[m,j'] = LeakyReLU'(act[m,j]) * g[m,j] * mask[m,j]; total [M,H] fp32 (+)= sum_j (vlg_ff_act_backward)."""
+    _C.check(_C.lib().vlg_ff_act_backward(_C.ptr(g), _C.ptr(act), _C.ptr(mask), _C.ptr(out), _C.ptr(total), M, J, H, int(swap),
+                                          int(accumulate), _adt(g), SLOPE, _C.stream_of(g)), "ff_act_backward")
+    return out
+
+
+def _mask32(m):
+    if m is None:
+        return None
+    m = m.detach().to(torch.float32).contiguous()
+    return m.clone() if m.data_ptr() % 16 else m       # (the kernels read the [B,H] masks 16 bytes at a time)
 
 
 def _wgrad(dy, x):
@@ -90,22 +109,19 @@ class _ParserFF(torch.autograd.Function):
         # ---- MLPs: all rows into one [M, H] buffer ----
         X = torch.empty((M, H), dtype=act, device=dev)
         torch.mm(emb2, We.t(), out=X[:M0])
-        cmean = x.detach().to(act).mean(1)                                             # context_mode 'mean', ldndmv.py:226
+        cmean = x.detach().mean(1, dtype=act)                                           # context_mode 'mean', ldndmv.py:226
         cterm = torch.addmm(bh, cmean, Wc.t())                                          # [B,H]: the context columns + bias, once per sentence
-        Xb = X[:M0].view(B, L, H)
-        Xb += cterm.unsqueeze(1)
         small_in = (token_emb, root_emb, dec_emb)
         o = M0
         for m, inp in zip(("child_ff", "root_ff", "dec_ff"), small_in):
             n = inp.shape[0]
             torch.addmm(c(P[f"ff.{m}.linear.bias"]), c(inp.detach()), c(P[f"ff.{m}.linear.weight"]).t(), out=X[o:o + n])
             o += n
-        _lrelu_(X)
-        drop_head, drop_small, drop_mid = drops        # SharedDropout of the MLPs (after the activation, nn/common.py:47-51), nn.Dropout of mid_ff
-        if drop_head is not None:
-            Xb *= drop_head.to(act).unsqueeze(1)        # [B,1,H]: shared over the positions of a sentence
-        if drop_small is not None:
-            X[M0:] *= drop_small.to(act).unsqueeze(1)   # 2-D inputs: SharedDropout's mask is [rows,1] -- whole rows (nn/dropout.py:52-53)
+        # + context term, LeakyReLU, SharedDropout of the MLPs (after the activation, nn/common.py:47-51): [B,1,H] masks shared over a
+        # sentence's positions for head_ff, one value per ROW for the 2-D inputs of the other three (nn/dropout.py:52-53)
+        drop_head, drop_small, drop_mid = drops
+        lib, st, adt = _C.lib(), _C.stream_of(emb), _C.BF16 if act == torch.bfloat16 else _C.F32
+        _C.check(lib.vlg_ff_mlp_act(_C.ptr(X), _C.ptr(cterm), _C.ptr(drop_head), _C.ptr(drop_small), B, L, Ms, H, adt, SLOPE, st), "ff_mlp_act")
         # ---- folded bottlenecks ----
         if nb:
             W0s = torch.stack([c(P[f"ff.mid_ff.{b}.0.weight"]) for b in _BOTTLENECKS])     # [4,nb,H]
@@ -123,26 +139,21 @@ class _ParserFF(torch.autograd.Function):
         W_lr, b_lr = Weff[2:4].reshape(2 * H, H), beff[2:4].reshape(2 * H)
         # ---- valence stage, nn/dmv_spec.py:41-44 ----
         A1 = torch.addmm(b_nh, X, W_nh.t())                                             # [M,2H] = (no | has) bottleneck outputs
-        A1v = A1.view(M, 2, H)
-        A1v += X.unsqueeze(1)                                                           # + x (the skip connection)
-        _lrelu_(A1)                                                                     # act(h)
+        _act(A1, A1, M, 2, H, residual=X)                                               # act(bottleneck + x) (the skip connection)
         Wv, bv = c(P["ff.mid_ff.valence_linear.weight"]), c(P["ff.mid_ff.valence_linear.bias"])
         A2 = torch.addmm(bv, A1.view(2 * M, H), Wv.t())
-        _lrelu_(A2)                                                                     # h [M,val,H]
+        _act(A2, A2, 2 * M, 1, H)                                                       # h [M,val,H]
         # ---- direction stage, :46-50 ----
         Z = torch.addmm(b_lr, A2, W_lr.t())                                             # [2M,2H]: rows (m,val), columns (dir,c)
         A3 = torch.empty((M, 2, 2, H), dtype=act, device=dev)                           # [m,dir,val,c]
-        torch.add(Z.view(M, 2, 2, H).permute(0, 2, 1, 3), X.view(M, 1, 1, H), out=A3)
-        _lrelu_(A3)
+        _act(Z, A3, M, 4, H, residual=X, swap=True)
         Wd, bd = c(P["ff.mid_ff.direction_linear.weight"]), c(P["ff.mid_ff.direction_linear.bias"])
         A4 = torch.addmm(bd, A3.view(4 * M, H), Wd.t())
-        _lrelu_(A4)
-        if drop_mid is not None:
-            A4 *= drop_mid.to(act)                      # nn.Dropout after the direction stage (nn/dmv_spec.py:52)
+        _act(A4, A4, 4 * M, 1, H, mask=drop_mid)                                        # nn.Dropout after the direction stage (nn/dmv_spec.py:52)
         # ---- output stage, :52-54 with linear2 folded into the projections ----
         W1_, b1_ = c(P["ff.mid_ff.linear1.weight"]), c(P["ff.mid_ff.linear1.bias"])
         A5 = torch.addmm(b1_, A4, W1_.t())
-        _lrelu_(A5)
+        _act(A5, A5, 4 * M, 1, H)
         W2_, b2_ = c(P["ff.mid_ff.linear2.weight"]), c(P["ff.mid_ff.linear2.bias"])
         PW = torch.cat([c(P[f"ff.{p}.weight"]) for p in _PROJ])                          # [6r,H]
         Pb = torch.cat([c(P[f"ff.{p}.bias"]) for p in _PROJ])                            # [6r]
@@ -157,8 +168,10 @@ class _ParserFF(torch.autograd.Function):
         y1 = big[:, r:].reshape(B, L, 2, 2, r)
         x2 = small[:4 * T, :r].reshape(T, 2, 2, r)
         y2 = small[4 * T + 4:, 3 * r:].reshape(2, 2, 2, r)
-        r2f = small[:4 * T, r:2 * r].reshape(T, 4 * r).float()
-        r1f = small[4 * T:4 * T + 4, 2 * r:3 * r].reshape(1, 4 * r).float()
+        r2f = torch.empty((T, 4 * r), dtype=torch.float32, device=dev)                   # (cast + gather of the strided slice: one launch each)
+        r2f.view(4 * T, r).copy_(small[:4 * T, r:2 * r])
+        r1f = torch.empty((1, 4 * r), dtype=torch.float32, device=dev)
+        r1f.view(4, r).copy_(small[4 * T:4 * T + 4, 2 * r:3 * r])
         root_rule = (r1f @ r2f.t()).log_softmax(-1)[0]                                  # ldndmv.py:205: sum over (dir, val), softmax over tokens
         ctx.save_for_backward(emb2, cmean, X, A1, A2, A3, A4, A5, We, Wc, W_nh, W_lr, Wv, Wd, W1_, W2_, b2_, PW, Wp, W0s, b0s, W1s,
                               *(c(t.detach()) for t in small_in), *(c(P[f"ff.{m}.linear.weight"]) for m in ("child_ff", "root_ff", "dec_ff")),
@@ -177,8 +190,7 @@ class _ParserFF(torch.autograd.Function):
         M = M0 + Ms
         G = {}
         g_big = torch.cat([g_x1.reshape(4 * M0, r), g_y1.reshape(4 * M0, r)], 1).to(act)
-        gl = g_root.float()
-        dlogit = (gl - root_rule.exp() * gl.sum()).unsqueeze(0)                          # log_softmax adjoint [1,T]
+        dlogit = torch._log_softmax_backward_data(g_root.float(), root_rule, 0, torch.float32).unsqueeze(0)   # [1,T]
         g_small = torch.zeros((4 * Ms, 4 * r), dtype=act, device=g_big.device)
         g_small[:4 * T, :r] = g_x2.reshape(4 * T, r)
         g_small[:4 * T, r:2 * r] = (dlogit.t() @ r1f).reshape(4 * T, r)                  # d r2[c] = dlogit[c] r1
@@ -195,35 +207,31 @@ class _ParserFF(torch.autograd.Function):
         dPW = torch.addmm(torch.outer(dbp, b2_), dWp, W2_.t())                           # Wp = PW W2, bp = PW b2 + Pb
         G["linear2.w"], G["linear2.b"] = PW.t() @ dWp, (PW * dbp.unsqueeze(1)).sum(0)     # (PW^T dbp as multiply + sum: the bf16 transposed mat-vec is ~10 ms of host time)
         # ---- linear1, direction ----
-        g = _lrelu_bwd(gA5, A5)
+        g = _act_bwd(gA5, A5, gA5, 4 * M, 1, H)
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4)
         g = g @ W1_
-        if ctx.drops[2] is not None:
-            g *= ctx.drops[2].to(act)
-        g = _lrelu_bwd(g, A4)
+        _act_bwd(g, A4, g, 4 * M, 1, H, mask=ctx.drops[2])
         G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H))
-        g3 = _lrelu_bwd(g @ Wd, A3.view(4 * M, H)).view(M, 2, 2, H)                      # d (Z^T-ordered pre-activation) [m,dir,val,c]
-        gX = g3.sum((1, 2), dtype=torch.float32)                                         # the skip connection of the direction stage
-        gZ = torch.empty((M, 2, 2, H), dtype=act, device=g3.device)                      # [m,val,dir,c]
-        gZ.copy_(g3.permute(0, 2, 1, 3))
-        gZ = gZ.view(2 * M, 2 * H)
+        g = g @ Wd                                                                       # [m,dir,val,c]
+        gX = torch.empty((M, H), dtype=torch.float32, device=g.device)                   # the skip connections' cotangent
+        gZ = torch.empty((2 * M, 2 * H), dtype=act, device=g.device)                     # [m,val,dir,c]
+        _act_bwd(g, A3, gZ, M, 4, H, total=gX, swap=True)
         dW_lr, db_lr = _wgrad(gZ, A2)
         # ---- valence ----
-        g = _lrelu_bwd(gZ @ W_lr, A2)
+        g = gZ @ W_lr
+        _act_bwd(g, A2, g, 2 * M, 1, H)
         G["valence.w"], G["valence.b"] = _wgrad(g, A1.view(2 * M, H))
-        gY = _lrelu_bwd(g @ Wv, A1.view(2 * M, H)).view(M, 2 * H)
-        gX += gY.view(M, 2, H).sum(1, dtype=torch.float32)
+        gY = g @ Wv                                                                      # [M,2,H]
+        _act_bwd(gY, A1, gY, M, 2, H, total=gX, accumulate=True)
+        gY = gY.view(M, 2 * H)
         dW_nh, db_nh = _wgrad(gY, X)
-        gX += (gY @ W_nh).float()
         dWeff = torch.cat([dW_nh.view(2, H, H), dW_lr.view(2, H, H)])                    # [4,H,H] fp32: no, has, left, right
         dbeff = torch.cat([db_nh.view(2, H), db_lr.view(2, H)])
-        # ---- MLPs ----
-        gXa = gX.to(act)
-        if ctx.drops[0] is not None:
-            gXa[:M0].view(B, L, H).mul_(ctx.drops[0].to(act).unsqueeze(1))
-        if ctx.drops[1] is not None:
-            gXa[M0:] *= ctx.drops[1].to(act).unsqueeze(1)
-        gpre = _lrelu_bwd(gXa, X)                                                        # [M,H]
+        # ---- MLPs: gpre = LeakyReLU'(X) * SharedDropout mask * (gX + gY W_nh) ----
+        gpre = torch.empty((M, H), dtype=act, device=g.device)
+        gT = gY @ W_nh
+        _C.check(_C.lib().vlg_ff_mlp_act_backward(_C.ptr(gX), _C.ptr(gT), _C.ptr(X), _C.ptr(ctx.drops[0]), _C.ptr(ctx.drops[1]),
+                                                  _C.ptr(gpre), B, L, Ms, H, _adt(gpre), SLOPE, _C.stream_of(gpre)), "ff_mlp_act_backward")
         gb = gpre[:M0]
         dWe, dbh = _wgrad(gb, emb2)                                                      # [H,E], [H]
         g_emb = gb @ We                                                                  # [M0,E]
@@ -297,15 +305,20 @@ def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None, 
     for name, m, shape in (("drop_head", drop_head, (B, H)), ("drop_small", drop_small, (T + 3,)), ("drop_mid", drop_mid, (4 * (B * L + T + 3), H))):
         if m is not None and tuple(m.shape) != shape:
             raise ValueError(f"parser_feed_forward: {name} must be {shape}, got {tuple(m.shape)}")
-    drops = tuple(None if m is None else m.detach() for m in (drop_head, drop_small, drop_mid))
+    if H % 8:
+        raise ValueError(f"parser_feed_forward: hidden size {H} must be a multiple of 8")
+    drops = (_mask32(drop_head), _mask32(drop_small), None if drop_mid is None else drop_mid.detach().to(emb.dtype).contiguous())
     return _ParserFF.apply(nb, drops, emb, x, token_emb, root_emb, dec_emb, *(P[k] for k in param_names(nb)))
 
 
 def dropout_masks(B, L, T, H, p_ff=0.33, p_mid=0.3, device=None, dtype=torch.float32, generator=None):
     """One training step's masks for `parser_feed_forward` at the shipped rates (config/model/vlgae.yaml: _dropout 0.33, mid_ff 0.3):
-    (drop_head [B,H], drop_small [T+3], drop_mid [4 (B L + T + 3), H]); a rate of 0 gives None."""
-    def draw(shape, p):
+    (drop_head [B,H] float32, drop_small [T+3] float32, drop_mid [4 (B L + T + 3), H] in `dtype`, the activations'); a rate of 0 gives
+    None.  The two small ones come out of ONE draw."""
+    def draw(shape, p, dt):
         if p <= 0:
             return None
-        return torch.empty(shape, dtype=dtype, device=device).bernoulli_(1 - p, generator=generator).div_(1 - p)
-    return draw((B, H), p_ff), draw((T + 3,), p_ff), draw((4 * (B * L + T + 3), H), p_mid)
+        return torch.empty(shape, dtype=dt, device=device).bernoulli_(1 - p, generator=generator).div_(1 - p)
+    small = draw((B * H + T + 3,), p_ff, torch.float32)
+    head, rows = (None, None) if small is None else (small[:B * H].view(B, H), small[B * H:])
+    return head, rows, draw((4 * (B * L + T + 3), H), p_mid, dtype)
