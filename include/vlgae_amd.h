@@ -343,18 +343,22 @@ int vlg_ff_mlp_act_backward(const float* gx, const void* t, const void* x, const
  *   token [B,L] int64 in [0,T), head_mask [B,L] u8 or NULL (function-word heads, ldndmv.py:195-199), mask_fill = -INF of
  *   src/__init__.py:110.   Outputs (out_dtype): merged_dec [B,L+1,2,2,2], merged_attach [B,L+1,L+1,2] exactly as
  *   `DMV1o.merge(dec, attach, root)` lays them out (distributions.py:253-265; zero = -1e12, one = 0).
- * backward: cotangents of the two merged tensors (fp32; e.g. the DP's expected counts) -> d_x1, d_y1 [B,L,2,2,r],
- *   d_x2 [T,2,2,r], d_y2 [2,2,2,r], d_root_rule [T] (fp32).  The softmax weights are recomputed; the batch-shared tables'
- *   gradients are per-sentence partials added in sentence order (ws: vlg_ndmv_potentials_backward_workspace bytes).
+ *   x1, x2, y1, y2 are rows of r values (one per (position | token | decision, direction, valence)) ld_* ELEMENTS apart: ld = r
+ *   is a contiguous tensor, a wider stride takes a column slice of a GEMM output that holds several projections side by side
+ *   (vlgae_amd/parser_ff.py computes attach.project1 | dec.project1 in one product) without a copy.
+ * backward: cotangents of the two merged tensors (fp32; e.g. the DP's expected counts) -> d_x1, d_y1 [B,L,2,2,r] (rows ld_dx1 /
+ *   ld_dy1 apart), d_x2 [T,2,2,r], d_y2 [2,2,2,r] (contiguous) in grad_dtype (VLG_F32 / VLG_BF16: the storage type of the layer
+ *   that receives them), d_root_rule [T] fp32.  The softmax weights are recomputed; the batch-shared tables' gradients are
+ *   per-sentence fp32 partials added in sentence order (ws: vlg_ndmv_potentials_backward_workspace bytes).
  * One workgroup per sentence with the token table in LDS: L, T, r must fit 160 KiB (VLG_ERR_SHAPE otherwise). */
-int vlg_ndmv_potentials(const void* x1, const void* x2, const void* y1, const void* y2, const float* root_rule, const int64_t* token,
-                        const uint8_t* head_mask, int B, int L, int T, int r, int in_dtype, float mask_fill, int out_dtype,
-                        void* merged_dec, void* merged_attach, void* stream);
+int vlg_ndmv_potentials(const void* x1, int ld_x1, const void* x2, int ld_x2, const void* y1, int ld_y1, const void* y2, int ld_y2,
+                        const float* root_rule, const int64_t* token, const uint8_t* head_mask, int B, int L, int T, int r, int in_dtype,
+                        float mask_fill, int out_dtype, void* merged_dec, void* merged_attach, void* stream);
 size_t vlg_ndmv_potentials_backward_workspace(int B, int L, int T, int r);
-int vlg_ndmv_potentials_backward(const void* x1, const void* x2, const void* y1, const void* y2, const int64_t* token,
-                                 const uint8_t* head_mask, const float* g_merged_dec, const float* g_merged_attach, int B, int L,
-                                 int T, int r, int in_dtype, void* ws, size_t ws_bytes, float* d_x1, float* d_x2, float* d_y1,
-                                 float* d_y2, float* d_root_rule, void* stream);
+int vlg_ndmv_potentials_backward(const void* x1, int ld_x1, const void* x2, int ld_x2, const void* y1, int ld_y1, const void* y2, int ld_y2,
+                                 const int64_t* token, const uint8_t* head_mask, const float* g_merged_dec, const float* g_merged_attach,
+                                 int B, int L, int T, int r, int in_dtype, void* ws, size_t ws_bytes, int grad_dtype, void* d_x1, int ld_dx1,
+                                 void* d_x2, void* d_y1, int ld_dy1, void* d_y2, float* d_root_rule, void* stream);
 
 /* Viterbi pass with every output of the Max semiring in ONE launch: best score, the 0/1 counts of the best tree (what
  * `-DMV1o(...).max.sum()` back-propagates, ldndmv.py:277-281) and its head vector (`argmax`, joint.py:256-258) -- the two
@@ -408,8 +412,8 @@ int vlg_selftest_xlane(int* scratch, void* stream);
 /* Thread-local message for the last non-zero return on this thread ("" if none). */
 const char* vlg_last_error(void);
 
-/* Library / ABI version, e.g. 130 = 0.1.3 (round 4: vlg_langfeat_* take the activations' storage type and the SharedDropout masks,
- * vlg_langfeat_rowscale added; round 3, 120: vlg_linear_wgrad, vlg_langfeat_*, vlg_ndmv_potentials*, vlg_dmv1o_viterbi added;
+/* Library / ABI version, e.g. 131 = 0.1.3.1 (round 4: vlg_langfeat_* take the activations' storage type and the SharedDropout masks,
+ * vlg_langfeat_rowscale, vlg_ff_* added, vlg_ndmv_potentials* take row strides and the gradients' storage type; round 3, 120: vlg_linear_wgrad, vlg_langfeat_*, vlg_ndmv_potentials*, vlg_dmv1o_viterbi added;
  * round 2, 110: vlg_bilinear_align_backward takes a workspace; vlg_scale_counts, vlg_feed_* added). */
 int vlg_version(void);
 

@@ -67,9 +67,10 @@ SIGNATURES = {
     "vlg_ff_act": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _vp]),
     "vlg_ff_act_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp]),
     "vlg_ff_mlp_act_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "vlg_ndmv_potentials": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "vlg_ndmv_potentials": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "vlg_ndmv_potentials_backward_workspace": (_sz, [_i, _i, _i, _i]),
-    "vlg_ndmv_potentials_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vlg_ndmv_potentials_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp, _i, _vp,
+                                          _vp, _i, _vp, _vp, _vp]),
     "vlg_dmv1o_viterbi": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vlg_scale_counts": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "vlg_feed_kmeans": (_i, [_vp, ctypes.c_int64, _vp, _i, _i, _vp, _vp, _vp]),

@@ -10,5 +10,5 @@ char* error_buffer() {
 
 extern "C" {
 const char* vlg_last_error(void) { return vlg::error_buffer(); }
-int vlg_version(void) { return 130; }   // 0.1.3: vlg_langfeat_* take act_dtype + SharedDropout masks, vlg_langfeat_rowscale (round 4)
+int vlg_version(void) { return 131; }   // round 4: vlg_langfeat_* take act_dtype + SharedDropout masks, vlg_langfeat_rowscale, vlg_ff_*, scorer row strides
 }

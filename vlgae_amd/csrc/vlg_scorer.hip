@@ -50,12 +50,21 @@ struct ScLayout {   // LDS carving, in floats
     }
 };
 
+// rows of r values, `ld` elements apart (ld = r: contiguous; wider: column slices of a GEMM output holding several projections)
+struct ScLd { int x1, x2, y1, y2; };
+
 template <typename In>
-__device__ __forceinline__ void load_rows(const typename In::T* src, size_t n_rows, int r, int rp, float* dst, int tid) {
+__device__ __forceinline__ void load_rows(const typename In::T* src, size_t n_rows, int r, int rp, float* dst, int tid, int ld) {
     for (int i = tid; i < (int)n_rows * r; i += kScThreads) {
         const int row = i / r, e = i - row * r;
-        dst[row * rp + e] = In::ld(src, (size_t)i);
+        dst[row * rp + e] = In::ld(src, (size_t)row * ld + e);
     }
+}
+
+__device__ __forceinline__ void st_grad(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void st_grad(uint16_t* p, size_t i, float v) {   // bf16, round to nearest even
+    const uint32_t u = __float_as_uint(v);
+    p[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
 // length-r dot of two LDS rows; R > 0: compile-time rank (all 2R reads issued together), R = 0: run-time loop
@@ -107,17 +116,17 @@ template <typename In, typename Out, int R>
 __global__ __launch_bounds__(kScThreads) void scorer_fwd_kernel(
     const typename In::T* __restrict__ x1, const typename In::T* __restrict__ x2, const typename In::T* __restrict__ y1,
     const typename In::T* __restrict__ y2, const float* __restrict__ root_rule, const int64_t* __restrict__ token,
-    const uint8_t* __restrict__ head_mask, int L, int T, int r, float mask_fill, Out* __restrict__ mdec, Out* __restrict__ matt) {
+    const uint8_t* __restrict__ head_mask, int L, int T, int r, ScLd ld, float mask_fill, Out* __restrict__ mdec, Out* __restrict__ matt) {
     extern __shared__ float smem[];
     const ScLayout lay(L, T, r, false);
     const int b = blockIdx.x, tid = threadIdx.x, N = L + 1, rp = lay.rp;
     float *x1s = smem + lay.x1, *x2s = smem + lay.x2, *y1s = smem + lay.y1, *y2s = smem + lay.y2, *lse = smem + lay.lse;
     int* tok = reinterpret_cast<int*>(smem + lay.tok);
     int* hm = reinterpret_cast<int*>(smem + lay.hm);
-    load_rows<In>(x1 + (size_t)b * L * 4 * r, (size_t)L * 4, r, rp, x1s, tid);
-    load_rows<In>(x2, (size_t)T * 4, r, rp, x2s, tid);
-    load_rows<In>(y1 + (size_t)b * L * 4 * r, (size_t)L * 4, r, rp, y1s, tid);
-    load_rows<In>(y2, 8, r, rp, y2s, tid);
+    load_rows<In>(x1 + (size_t)b * L * 4 * ld.x1, (size_t)L * 4, r, rp, x1s, tid, ld.x1);
+    load_rows<In>(x2, (size_t)T * 4, r, rp, x2s, tid, ld.x2);
+    load_rows<In>(y1 + (size_t)b * L * 4 * ld.y1, (size_t)L * 4, r, rp, y1s, tid, ld.y1);
+    load_rows<In>(y2, 8, r, rp, y2s, tid, ld.y2);
     for (int i = tid; i < L; i += kScThreads) {
         tok[i] = (int)min(max(token[(size_t)b * L + i], (int64_t)0), (int64_t)(T - 1));
         hm[i] = head_mask ? head_mask[(size_t)b * L + i] : 0;
@@ -168,14 +177,14 @@ __global__ __launch_bounds__(kScThreads) void scorer_fwd_kernel(
 }
 
 // --------------------------------------------------------------------------------------------------------------- backward
-// g_matt [B,N,N,2], g_mdec [B,N,2,2,2] fp32 -> d_x1, d_y1 [B,L,2,2,r] fp32 and per-sentence partials of d_x2 [T,2,2,r],
-// d_y2 [2,2,2,r], d_root_rule [T] (part [B][T*4*r + 8*r + T]).
-template <typename In, int R>
+// g_matt [B,N,N,2], g_mdec [B,N,2,2,2] fp32 -> d_x1, d_y1 [B,L,2,2,r] (G: fp32 or bf16, rows ld_dx1 / ld_dy1 apart) and per-sentence
+// partials of d_x2 [T,2,2,r], d_y2 [2,2,2,r], d_root_rule [T] (part [B][T*4*r + 8*r + T]).
+template <typename In, int R, typename G>
 __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
     const typename In::T* __restrict__ x1, const typename In::T* __restrict__ x2, const typename In::T* __restrict__ y1,
     const typename In::T* __restrict__ y2, const int64_t* __restrict__ token, const uint8_t* __restrict__ head_mask,
-    const float* __restrict__ g_mdec, const float* __restrict__ g_matt, int L, int T, int r, float* __restrict__ d_x1,
-    float* __restrict__ d_y1, float* __restrict__ part) {
+    const float* __restrict__ g_mdec, const float* __restrict__ g_matt, int L, int T, int r, ScLd ld, G* __restrict__ d_x1, int ld_dx1,
+    G* __restrict__ d_y1, int ld_dy1, float* __restrict__ part) {
     extern __shared__ float smem[];
     const ScLayout lay(L, T, r, true);
     const int b = blockIdx.x, tid = threadIdx.x, N = L + 1, rp = lay.rp;
@@ -184,10 +193,10 @@ __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
     float* dsd = tot + L * 4;               // [L*4][2]: cotangent of the dec scores
     int* tok = reinterpret_cast<int*>(smem + lay.tok);
     int* hm = reinterpret_cast<int*>(smem + lay.hm);
-    load_rows<In>(x1 + (size_t)b * L * 4 * r, (size_t)L * 4, r, rp, x1s, tid);
-    load_rows<In>(x2, (size_t)T * 4, r, rp, x2s, tid);
-    load_rows<In>(y1 + (size_t)b * L * 4 * r, (size_t)L * 4, r, rp, y1s, tid);
-    load_rows<In>(y2, 8, r, rp, y2s, tid);
+    load_rows<In>(x1 + (size_t)b * L * 4 * ld.x1, (size_t)L * 4, r, rp, x1s, tid, ld.x1);
+    load_rows<In>(x2, (size_t)T * 4, r, rp, x2s, tid, ld.x2);
+    load_rows<In>(y1 + (size_t)b * L * 4 * ld.y1, (size_t)L * 4, r, rp, y1s, tid, ld.y1);
+    load_rows<In>(y2, 8, r, rp, y2s, tid, ld.y2);
     for (int i = tid; i < L; i += kScThreads) {
         tok[i] = (int)min(max(token[(size_t)b * L + i], (int64_t)0), (int64_t)(T - 1));
         hm[i] = head_mask ? head_mask[(size_t)b * L + i] : 0;
@@ -230,8 +239,8 @@ __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
         float acc = 0.f;
 #pragma unroll 8
         for (int t = 0; t < T; ++t) acc = fmaf(coef[p * T + t], x2s[(t * 4 + dv) * rp + e], acc);
-        d_x1[((size_t)b * L * 4 + p) * r + e] = acc;
-        d_y1[((size_t)b * L * 4 + p) * r + e] = dsd[p * 2] * y2s[(0 * 4 + dv) * rp + e] + dsd[p * 2 + 1] * y2s[(1 * 4 + dv) * rp + e];
+        st_grad(d_x1, ((size_t)b * L * 4 + p) * ld_dx1 + e, acc);
+        st_grad(d_y1, ((size_t)b * L * 4 + p) * ld_dy1 + e, dsd[p * 2] * y2s[(0 * 4 + dv) * rp + e] + dsd[p * 2 + 1] * y2s[(1 * 4 + dv) * rp + e]);
     }
     // ---- partials of the batch-shared tables ----
     float* pt = part + (size_t)b * ((size_t)T * 4 * r + 8 * r + T);
@@ -260,8 +269,9 @@ __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
 
 // out[i] = sum_b part[b][i] in a fixed order: 64 outputs x 4 sentence groups per block (group g adds b = g, g + 4, ...
 // ascending), then (g0 + g1) + (g2 + g3)
-__global__ __launch_bounds__(256) void scorer_reduce_kernel(const float* __restrict__ part, int B, int n, float* __restrict__ d_x2,
-                                                            int n_x2, float* __restrict__ d_y2, int n_y2, float* __restrict__ d_root) {
+template <typename G>
+__global__ __launch_bounds__(256) void scorer_reduce_kernel(const float* __restrict__ part, int B, int n, G* __restrict__ d_x2,
+                                                            int n_x2, G* __restrict__ d_y2, int n_y2, float* __restrict__ d_root) {
     __shared__ float sm[4][64];
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float t = 0.f;
@@ -280,8 +290,8 @@ __global__ __launch_bounds__(256) void scorer_reduce_kernel(const float* __restr
     __syncthreads();
     if (grp != 0 || i >= n) return;
     t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
-    if (i < n_x2) d_x2[i] = t;
-    else if (i < n_x2 + n_y2) d_y2[i - n_x2] = t;
+    if (i < n_x2) st_grad(d_x2, (size_t)i, t);
+    else if (i < n_x2 + n_y2) st_grad(d_y2, (size_t)(i - n_x2), t);
     else d_root[i - n_x2 - n_y2] = t;
 }
 
@@ -309,12 +319,15 @@ int prep_lds(K kernel, size_t lds) {
 
 extern "C" {
 
-int vlg_ndmv_potentials(const void* x1, const void* x2, const void* y1, const void* y2, const float* root_rule, const int64_t* token,
-                        const uint8_t* head_mask, int B, int L, int T, int r, int in_dtype, float mask_fill, int out_dtype,
-                        void* merged_dec, void* merged_attach, void* stream) {
+int vlg_ndmv_potentials(const void* x1, int ld_x1, const void* x2, int ld_x2, const void* y1, int ld_y1, const void* y2, int ld_y2,
+                        const float* root_rule, const int64_t* token, const uint8_t* head_mask, int B, int L, int T, int r, int in_dtype,
+                        float mask_fill, int out_dtype, void* merged_dec, void* merged_attach, void* stream) {
     using namespace vlg;
     size_t lds;
     if (int rc = check_shape("ndmv_potentials", B, L, T, r, false, &lds)) return rc;
+    if (ld_x1 < r || ld_x2 < r || ld_y1 < r || ld_y2 < r)
+        return set_error(VLG_ERR_SHAPE, "ndmv_potentials: row strides %d %d %d %d below r=%d", ld_x1, ld_x2, ld_y1, ld_y2, r);
+    const ScLd ld{ld_x1, ld_x2, ld_y1, ld_y2};
     if ((in_dtype != VLG_F32 && in_dtype != VLG_BF16) || (out_dtype != VLG_F32 && out_dtype != VLG_BF16))
         return set_error(VLG_ERR_DTYPE, "ndmv_potentials: dtypes %d -> %d", in_dtype, out_dtype);
     if (B == 0) return 0;
@@ -325,7 +338,7 @@ int vlg_ndmv_potentials(const void* x1, const void* x2, const void* y1, const vo
         auto k = scorer_fwd_kernel<IN, OUT, RR>;                                                                                    \
         if (int rc = prep_lds(k, lds)) return rc;                                                                                   \
         hipLaunchKernelGGL(k, dim3(B), dim3(kScThreads), lds, s, (const IN::T*)x1, (const IN::T*)x2, (const IN::T*)y1, (const IN::T*)y2, \
-                           root_rule, token, head_mask, L, T, r, mask_fill, (OUT*)merged_dec, (OUT*)merged_attach);                \
+                           root_rule, token, head_mask, L, T, r, ld, mask_fill, (OUT*)merged_dec, (OUT*)merged_attach);            \
     }
 #define VLG_GO(IN, OUT)                                  \
     {                                                    \
@@ -348,46 +361,59 @@ size_t vlg_ndmv_potentials_backward_workspace(int B, int L, int T, int r) {
     return sizeof(float) * (size_t)B * ((size_t)T * 4 * r + 8 * (size_t)r + T);
 }
 
-int vlg_ndmv_potentials_backward(const void* x1, const void* x2, const void* y1, const void* y2, const int64_t* token,
-                                 const uint8_t* head_mask, const float* g_merged_dec, const float* g_merged_attach, int B, int L,
-                                 int T, int r, int in_dtype, void* ws, size_t ws_bytes, float* d_x1, float* d_x2, float* d_y1,
-                                 float* d_y2, float* d_root_rule, void* stream) {
+int vlg_ndmv_potentials_backward(const void* x1, int ld_x1, const void* x2, int ld_x2, const void* y1, int ld_y1, const void* y2, int ld_y2,
+                                 const int64_t* token, const uint8_t* head_mask, const float* g_merged_dec, const float* g_merged_attach,
+                                 int B, int L, int T, int r, int in_dtype, void* ws, size_t ws_bytes, int grad_dtype, void* d_x1, int ld_dx1,
+                                 void* d_x2, void* d_y1, int ld_dy1, void* d_y2, float* d_root_rule, void* stream) {
     using namespace vlg;
     size_t lds;
     if (int rc = check_shape("ndmv_potentials_backward", B, L, T, r, true, &lds)) return rc;
     if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "ndmv_potentials_backward: in_dtype %d", in_dtype);
+    if (grad_dtype != VLG_F32 && grad_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "ndmv_potentials_backward: grad_dtype %d", grad_dtype);
+    if (ld_x1 < r || ld_x2 < r || ld_y1 < r || ld_y2 < r || ld_dx1 < r || ld_dy1 < r)
+        return set_error(VLG_ERR_SHAPE, "ndmv_potentials_backward: row strides %d %d %d %d / %d %d below r=%d", ld_x1, ld_x2, ld_y1, ld_y2, ld_dx1,
+                         ld_dy1, r);
     if (!d_x2 || !d_y2 || !d_root_rule || (B > 0 && (!d_x1 || !d_y1))) return set_error(VLG_ERR_ARG, "ndmv_potentials_backward: null output");
     hipStream_t s = (hipStream_t)stream;
     const int n_x2 = T * 4 * r, n_y2 = 8 * r, n = n_x2 + n_y2 + T;
+    const size_t gsz = grad_dtype == VLG_F32 ? sizeof(float) : sizeof(uint16_t);
     if (B == 0) {
-        hipError_t e = hipMemsetAsync(d_x2, 0, sizeof(float) * n_x2, s);
-        if (e == hipSuccess) e = hipMemsetAsync(d_y2, 0, sizeof(float) * n_y2, s);
+        hipError_t e = hipMemsetAsync(d_x2, 0, gsz * n_x2, s);
+        if (e == hipSuccess) e = hipMemsetAsync(d_y2, 0, gsz * n_y2, s);
         if (e == hipSuccess) e = hipMemsetAsync(d_root_rule, 0, sizeof(float) * T, s);
         return e == hipSuccess ? 0 : set_error((int)e, "ndmv_potentials_backward: %s", hipGetErrorString(e));
     }
     if (!x1 || !x2 || !y1 || !y2 || !token || !g_merged_dec || !g_merged_attach) return set_error(VLG_ERR_ARG, "ndmv_potentials_backward: null buffer");
     const size_t need = vlg_ndmv_potentials_backward_workspace(B, L, T, r);
     if (!ws || ws_bytes < need) return set_error(VLG_ERR_WORKSPACE, "ndmv_potentials_backward: workspace %zu bytes < %zu", ws_bytes, need);
-#define VLG_GO_R(IN, RR)                                                                                                            \
+    const ScLd ld{ld_x1, ld_x2, ld_y1, ld_y2};
+#define VLG_GO_R(IN, RR, G)                                                                                                         \
     {                                                                                                                               \
-        auto k = scorer_bwd_kernel<IN, RR>;                                                                                         \
+        auto k = scorer_bwd_kernel<IN, RR, G>;                                                                                      \
         if (int rc = prep_lds(k, lds)) return rc;                                                                                   \
         hipLaunchKernelGGL(k, dim3(B), dim3(kScThreads), lds, s, (const IN::T*)x1, (const IN::T*)x2, (const IN::T*)y1, (const IN::T*)y2, \
-                           token, head_mask, g_merged_dec, g_merged_attach, L, T, r, d_x1, d_y1, (float*)ws);                      \
+                           token, head_mask, g_merged_dec, g_merged_attach, L, T, r, ld, (G*)d_x1, ld_dx1, (G*)d_y1, ld_dy1, (float*)ws); \
     }
-#define VLG_GO(IN)                                  \
-    {                                               \
-        if (r == 16) VLG_GO_R(IN, 16)               \
-        else if (r == 8) VLG_GO_R(IN, 8)            \
-        else if (r == 32) VLG_GO_R(IN, 32)          \
-        else VLG_GO_R(IN, 0)                        \
+#define VLG_GO(IN, G)                                  \
+    {                                                  \
+        if (r == 16) VLG_GO_R(IN, 16, G)               \
+        else if (r == 8) VLG_GO_R(IN, 8, G)            \
+        else if (r == 32) VLG_GO_R(IN, 32, G)          \
+        else VLG_GO_R(IN, 0, G)                        \
     }
-    if (in_dtype == VLG_F32) VLG_GO(F32In)
-    else VLG_GO(BF16In)
+    if (in_dtype == VLG_F32 && grad_dtype == VLG_F32) VLG_GO(F32In, float)
+    else if (in_dtype == VLG_F32) VLG_GO(F32In, uint16_t)
+    else if (grad_dtype == VLG_F32) VLG_GO(BF16In, float)
+    else VLG_GO(BF16In, uint16_t)
 #undef VLG_GO
 #undef VLG_GO_R
     if (int rc = check_launch("scorer_bwd_kernel")) return rc;
-    hipLaunchKernelGGL(scorer_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, (const float*)ws, B, n, d_x2, n_x2, d_y2, n_y2, d_root_rule);
+    if (grad_dtype == VLG_F32)
+        hipLaunchKernelGGL(scorer_reduce_kernel<float>, dim3((n + 63) / 64), dim3(256), 0, s, (const float*)ws, B, n, (float*)d_x2, n_x2, (float*)d_y2,
+                           n_y2, d_root_rule);
+    else
+        hipLaunchKernelGGL(scorer_reduce_kernel<uint16_t>, dim3((n + 63) / 64), dim3(256), 0, s, (const float*)ws, B, n, (uint16_t*)d_x2, n_x2,
+                           (uint16_t*)d_y2, n_y2, d_root_rule);
     return check_launch("scorer_reduce_kernel");
 }
 

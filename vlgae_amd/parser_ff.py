@@ -55,6 +55,13 @@ def param_names(n_bottleneck):
     return names
 
 
+def _numel(shape):
+    n = 1
+    for v in shape:
+        n *= v
+    return n
+
+
 def _adt(t):
     return _C.BF16 if t.dtype == torch.bfloat16 else _C.F32
 
@@ -122,19 +129,26 @@ class _ParserFF(torch.autograd.Function):
         drop_head, drop_small, drop_mid = drops
         lib, st, adt = _C.lib(), _C.stream_of(emb), _C.BF16 if act == torch.bfloat16 else _C.F32
         _C.check(lib.vlg_ff_mlp_act(_C.ptr(X), _C.ptr(cterm), _C.ptr(drop_head), _C.ptr(drop_small), B, L, Ms, H, adt, SLOPE, st), "ff_mlp_act")
-        # ---- folded bottlenecks ----
+        # ---- folded bottlenecks; the projections stacked: the 16 + 12 parameter tensors gathered (and cast) by ONE multi-tensor copy ----
+        r = P[f"ff.{_PROJ[0]}.weight"].shape[0]
+        shapes = ([(4, nb, H), (4, nb), (4, H, nb), (4, H)] if nb else [(4, H, H), (4, H)]) + [(6, r, H), (6, r)]
+        flat = torch.empty(sum(-(-_numel(sh) // 128) * 128 for sh in shapes), dtype=act, device=dev)   # (every stack 256-byte aligned)
+        stacks, o = [], 0
+        for sh in shapes:
+            stacks.append(flat[o:o + _numel(sh)].view(sh))
+            o += -(-_numel(sh) // 128) * 128
+        srcs = [[P[f"ff.mid_ff.{b}{sfx}"] for b in _BOTTLENECKS] for sfx in ((".0.weight", ".0.bias", ".1.weight", ".1.bias") if nb else (".weight", ".bias"))]
+        srcs += [[P[f"ff.{p}.weight"] for p in _PROJ], [P[f"ff.{p}.bias"] for p in _PROJ]]
+        torch._foreach_copy_([st[k] for st, src in zip(stacks, srcs) for k in range(len(src))], [t for src in srcs for t in src])
+        PW, Pb = stacks[-2].view(6 * r, H), stacks[-1].view(6 * r)
         if nb:
-            W0s = torch.stack([c(P[f"ff.mid_ff.{b}.0.weight"]) for b in _BOTTLENECKS])     # [4,nb,H]
-            b0s = torch.stack([c(P[f"ff.mid_ff.{b}.0.bias"]) for b in _BOTTLENECKS])       # [4,nb]
-            W1s = torch.stack([c(P[f"ff.mid_ff.{b}.1.weight"]) for b in _BOTTLENECKS])     # [4,H,nb]
-            b1s = torch.stack([c(P[f"ff.mid_ff.{b}.1.bias"]) for b in _BOTTLENECKS])       # [4,H]
+            W0s, b0s, W1s, b1s = stacks[:4]                                                 # [4,nb,H], [4,nb], [4,H,nb], [4,H]
             Weff = torch.bmm(W1s, W0s)                                                      # [4,H,H]
             # (as a multiply + sum: the library's batched bf16 matrix-VECTOR product costs ~10 ms of HOST time per call on this stack)
             beff = (W1s * b0s.unsqueeze(1)).sum(2) + b1s                                    # [4,H] = W1 b0 + b1
         else:
             W0s = b0s = W1s = b1s = None
-            Weff = torch.stack([c(P[f"ff.mid_ff.{b}.weight"]) for b in _BOTTLENECKS])
-            beff = torch.stack([c(P[f"ff.mid_ff.{b}.bias"]) for b in _BOTTLENECKS])
+            Weff, beff = stacks[:2]
         W_nh, b_nh = Weff[0:2].reshape(2 * H, H), beff[0:2].reshape(2 * H)
         W_lr, b_lr = Weff[2:4].reshape(2 * H, H), beff[2:4].reshape(2 * H)
         # ---- valence stage, nn/dmv_spec.py:41-44 ----
@@ -155,19 +169,16 @@ class _ParserFF(torch.autograd.Function):
         A5 = torch.addmm(b1_, A4, W1_.t())
         _act(A5, A5, 4 * M, 1, H)
         W2_, b2_ = c(P["ff.mid_ff.linear2.weight"]), c(P["ff.mid_ff.linear2.bias"])
-        PW = torch.cat([c(P[f"ff.{p}.weight"]) for p in _PROJ])                          # [6r,H]
-        Pb = torch.cat([c(P[f"ff.{p}.bias"]) for p in _PROJ])                            # [6r]
-        r = PW.shape[0] // 6
         Wp = PW @ W2_                                                                   # [6r,H]: P W2
         bp = torch.addmv(Pb, PW, b2_)                                                   # P b2 + p
         big = torch.addmm(bp[:2 * r], A5[:4 * M0], Wp[:2 * r].t())                      # [4 M0, 2r]: attach.project1 | dec.project1
         small = torch.addmm(bp[2 * r:], A5[4 * M0:], Wp[2 * r:].t())                    # [4 Ms, 4r]: attach.p2 | root.p2 | root.p1 | dec.p2
-        # the five tensors the score construction takes, contiguous (slices of `big` / `small` handed to autograd would come back as a
-        # zero-fill + copy + add per slice)
-        x1 = big[:, :r].reshape(B, L, 2, 2, r)
-        y1 = big[:, r:].reshape(B, L, 2, 2, r)
-        x2 = small[:4 * T, :r].reshape(T, 2, 2, r)
-        y2 = small[4 * T + 4:, 3 * r:].reshape(2, 2, 2, r)
+        # the scorers' inputs as VIEWS of the two products (vlgae_amd.scorer takes rows a constant stride apart in place); they are outputs
+        # of this Function, so autograd hands their cotangents straight to backward -- no slice nodes, no copies
+        x1 = big[:, :r].view(B, L, 2, 2, r)
+        y1 = big[:, r:].view(B, L, 2, 2, r)
+        x2 = small[:4 * T, :r].view(T, 2, 2, r)
+        y2 = small[4 * T + 4:, 3 * r:].view(2, 2, 2, r)
         r2f = torch.empty((T, 4 * r), dtype=torch.float32, device=dev)                   # (cast + gather of the strided slice: one launch each)
         r2f.view(4 * T, r).copy_(small[:4 * T, r:2 * r])
         r1f = torch.empty((1, 4 * r), dtype=torch.float32, device=dev)
@@ -189,7 +200,11 @@ class _ParserFF(torch.autograd.Function):
         M0, Ms = B * L, T + 3
         M = M0 + Ms
         G = {}
-        g_big = torch.cat([g_x1.reshape(4 * M0, r), g_y1.reshape(4 * M0, r)], 1).to(act)
+        if (g_x1.dtype == act and g_y1.dtype == act and g_x1.stride() == g_y1.stride() == (L * 8 * r, 8 * r, 4 * r, 2 * r, 1)
+                and g_y1.data_ptr() == g_x1.data_ptr() + r * g_x1.element_size()):
+            g_big = g_x1.as_strided((4 * M0, 2 * r), (2 * r, 1), g_x1.storage_offset())   # the scorer's adjoint wrote them side by side
+        else:
+            g_big = torch.cat([g_x1.reshape(4 * M0, r), g_y1.reshape(4 * M0, r)], 1).to(act)
         dlogit = torch._log_softmax_backward_data(g_root.float(), root_rule, 0, torch.float32).unsqueeze(0)   # [1,T]
         g_small = torch.zeros((4 * Ms, 4 * r), dtype=act, device=g_big.device)
         g_small[:4 * T, :r] = g_x2.reshape(4 * T, r)
@@ -200,10 +215,13 @@ class _ParserFF(torch.autograd.Function):
         gA5 = torch.empty_like(A5)
         torch.mm(g_big, Wp[:2 * r], out=gA5[:4 * M0])
         torch.mm(g_small, Wp[2 * r:], out=gA5[4 * M0:])
-        dWp_b, dbp_b = _wgrad(g_big, A5[:4 * M0])                                       # [2r,H], [2r]
-        dWp_s, dbp_s = _wgrad(g_small, A5[4 * M0:])                                     # [4r,H], [4r]  (4 (T + 3) rows: the library)
-        # (the small products below run in the activations' dtype: as fp32 GEMMs on one workgroup each the library takes 30-50 us for them)
-        dWp, dbp = torch.cat([dWp_b, dWp_s]).to(act), torch.cat([dbp_b, dbp_s]).to(act)  # [6r,H], [6r]
+        # (everything below in the activations' dtype: as fp32 GEMMs on one workgroup each the library takes 30-50 us for these products)
+        dWp, dbp = torch.empty((6 * r, H), dtype=act, device=g_big.device), torch.empty((6 * r,), dtype=act, device=g_big.device)
+        dWp_b, dbp_b = _wgrad(g_big, A5[:4 * M0])                                       # [2r,H], [2r] fp32 (split-K)
+        dWp[:2 * r].copy_(dWp_b)
+        dbp[:2 * r].copy_(dbp_b)
+        torch.mm(g_small.t(), A5[4 * M0:], out=dWp[2 * r:])                             # [4r,H]: 4 (T + 3) rows, the library
+        torch.sum(g_small, 0, out=dbp[2 * r:])
         dPW = torch.addmm(torch.outer(dbp, b2_), dWp, W2_.t())                           # Wp = PW W2, bp = PW b2 + Pb
         G["linear2.w"], G["linear2.b"] = PW.t() @ dWp, (PW * dbp.unsqueeze(1)).sum(0)     # (PW^T dbp as multiply + sum: the bf16 transposed mat-vec is ~10 ms of host time)
         # ---- linear1, direction ----
@@ -235,7 +253,7 @@ class _ParserFF(torch.autograd.Function):
         gb = gpre[:M0]
         dWe, dbh = _wgrad(gb, emb2)                                                      # [H,E], [H]
         g_emb = gb @ We                                                                  # [M0,E]
-        gc = gb.view(B, L, H).sum(1, dtype=torch.float32).to(act)                        # [B,H]
+        gc = gb.view(B, L, H).sum(1)                                                     # [B,H] (fp32 accumulation inside the reduction)
         dWc = gc.t() @ cmean                                                             # [H,h]
         g_cmean = (gc @ Wc) / L                                                          # [B,h]
         G["head.w"], G["head.b"] = torch.cat([dWe.to(act), dWc], 1), dbh

@@ -18,39 +18,75 @@ from . import _C
 INF = 1e20   # src/__init__.py:110
 
 
+def _rows(t, r, dtype):
+    """(tensor, row stride in elements) for a [..., r] operand: rows of r contiguous values a constant stride apart are taken in
+    place (a column slice of a wider row-major buffer); anything else is made contiguous."""
+    t = t.detach()
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    n = t.numel() // r
+    if t.stride(-1) == 1 and n > 0:
+        ld = t.stride(-2) if t.dim() > 1 else r
+        flat = t.as_strided((n, r), (ld, 1), t.storage_offset()) if ld >= r else None
+        # the view [n, r] with stride ld addresses the same elements iff the leading dimensions collapse onto one row index
+        want, acc = [], ld
+        for size in reversed(t.shape[:-1]):
+            want.append(acc)
+            acc *= size
+        if flat is not None and list(reversed(want)) == list(t.stride()[:-1]):
+            return t, ld
+    return t.contiguous(), r
+
+
+def _side_by_side(a, lda, b, ldb, r):
+    """b's rows start r elements behind a's in one [rows, 2r] buffer (two projections out of one GEMM)?"""
+    return lda == ldb == 2 * r and a.dtype == b.dtype and b.data_ptr() == a.data_ptr() + r * a.element_size()
+
+
 class _NdmvPotentials(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, y1, y2, root_rule, token, head_mask, mask_fill, out_dtype):
         B, L, _, _, r = x1.shape
         T = x2.shape[0]
         N = L + 1
-        dt, x1_c = _C.in_dtype(x1.detach())
-        x2_c, y1_c, y2_c = (t.detach().to(x1_c.dtype).contiguous() for t in (x2, y1, y2))
+        st = x1.dtype if x1.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        dt = _C.BF16 if st == torch.bfloat16 else _C.F32
+        (x1_c, l1), (x2_c, l2), (y1_c, l3), (y2_c, l4) = (_rows(t, r, st) for t in (x1, x2, y1, y2))
         root_c = root_rule.detach().to(torch.float32).contiguous()
         hm = _C.mask_u8(head_mask, x1_c.device)
         dev = x1.device
         md = torch.empty((B, N, 2, 2, 2), dtype=out_dtype, device=dev)
         ma = torch.empty((B, N, N, 2), dtype=out_dtype, device=dev)
-        _C.check(_C.lib().vlg_ndmv_potentials(_C.ptr(x1_c), _C.ptr(x2_c), _C.ptr(y1_c), _C.ptr(y2_c), _C.ptr(root_c), _C.ptr(token),
-                                              _C.ptr(hm), B, L, T, r, dt, float(mask_fill),
+        _C.check(_C.lib().vlg_ndmv_potentials(_C.ptr(x1_c), l1, _C.ptr(x2_c), l2, _C.ptr(y1_c), l3, _C.ptr(y2_c), l4, _C.ptr(root_c),
+                                              _C.ptr(token), _C.ptr(hm), B, L, T, r, dt, float(mask_fill),
                                               _C.BF16 if out_dtype == torch.bfloat16 else _C.F32, _C.ptr(md), _C.ptr(ma),
                                               _C.stream_of(x1)), "ndmv_potentials")
         ctx.save_for_backward(x1_c, x2_c, y1_c, y2_c, token, hm)
-        ctx.meta = (B, L, T, r, dt, x1.dtype, x2.dtype, y1.dtype, y2.dtype, root_rule.dtype)
+        ctx.meta = (B, L, T, r, dt, (l1, l2, l3, l4), x1.dtype, x2.dtype, y1.dtype, y2.dtype, root_rule.dtype)
         return md, ma
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_md, g_ma):
         x1_c, x2_c, y1_c, y2_c, token, hm = ctx.saved_tensors
-        B, L, T, r, dt, *dtypes = ctx.meta
+        B, L, T, r, dt, (l1, l2, l3, l4), *dtypes = ctx.meta
         dev = x1_c.device
         g_md, g_ma = (g if g.dtype == torch.float32 and g.is_contiguous() else g.to(torch.float32).contiguous() for g in (g_md, g_ma))
         nbytes = _C.lib().vlg_ndmv_potentials_backward_workspace(B, L, T, r)
-        (d_x1, d_x2, d_y1, d_y2, d_root), ws = _C.alloc_f32(dev, ((B, L, 2, 2, r), (T, 2, 2, r), (B, L, 2, 2, r), (2, 2, 2, r), (T,)), nbytes)
-        _C.check(_C.lib().vlg_ndmv_potentials_backward(_C.ptr(x1_c), _C.ptr(x2_c), _C.ptr(y1_c), _C.ptr(y2_c), _C.ptr(token), _C.ptr(hm),
-                                                       _C.ptr(g_md), _C.ptr(g_ma), B, L, T, r, dt, _C.ptr(ws), nbytes, _C.ptr(d_x1),
-                                                       _C.ptr(d_x2), _C.ptr(d_y1), _C.ptr(d_y2), _C.ptr(d_root), _C.stream_of(x1_c)),
+        # gradients leave in the storage type of the layers that receive them (one type for the four: else fp32 + a cast each)
+        gdt = dtypes[0] if dtypes[0] in (torch.float32, torch.bfloat16) and all(t == dtypes[0] for t in dtypes[:4]) else torch.float32
+        (d_root,), ws = _C.alloc_f32(dev, ((T,),), nbytes)
+        if _side_by_side(x1_c, l1, y1_c, l3, r):   # the cotangents of two slices of one buffer, side by side again: no cat downstream
+            both = torch.empty((B * L * 4, 2 * r), dtype=gdt, device=dev)
+            d_x1, d_y1, ldd = both[:, :r].view(B, L, 2, 2, r), both[:, r:].view(B, L, 2, 2, r), 2 * r
+        else:
+            d_x1, d_y1, ldd = torch.empty((B, L, 2, 2, r), dtype=gdt, device=dev), torch.empty((B, L, 2, 2, r), dtype=gdt, device=dev), r
+        small = torch.empty((T * 4 + 8, r), dtype=gdt, device=dev)
+        d_x2, d_y2 = small[:T * 4].view(T, 2, 2, r), small[T * 4:].view(2, 2, 2, r)
+        _C.check(_C.lib().vlg_ndmv_potentials_backward(_C.ptr(x1_c), l1, _C.ptr(x2_c), l2, _C.ptr(y1_c), l3, _C.ptr(y2_c), l4, _C.ptr(token),
+                                                       _C.ptr(hm), _C.ptr(g_md), _C.ptr(g_ma), B, L, T, r, dt, _C.ptr(ws), nbytes,
+                                                       _C.BF16 if gdt == torch.bfloat16 else _C.F32, _C.ptr(d_x1), ldd, _C.ptr(d_x2),
+                                                       _C.ptr(d_y1), ldd, _C.ptr(d_y2), _C.ptr(d_root), _C.stream_of(x1_c)),
                  "ndmv_potentials_backward")
         grads = [g if g.dtype == t else g.to(t) for g, t in zip((d_x1, d_x2, d_y1, d_y2, d_root), dtypes)]
         return (*(g if n else None for g, n in zip(grads, ctx.needs_input_grad[:5])), None, None, None, None)
