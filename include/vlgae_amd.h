@@ -237,16 +237,18 @@ int vlg_attn_fuse(const void* vis, const void* txt, const void* vis_mid, const v
 
 /* Adjoint of vlg_attn_fuse -- what autograd derives for src/model/joint.py:670-674 (the fuse sits inside
  * DependencyBoxRel._forward, so training back-propagates through it into the feature encoders and the LayerNorm).
- *   dout [B,L,h] fp32 = cotangent of `out`; inputs as in vlg_attn_fuse (in_dtype), gamma [h] fp32.
+ *   dout [B,L,h] fp32 = cotangent of `out`, its rows at dout + b ld_dout_b + l ld_dout_l (elements; contiguous: L h and h; the
+ *   parser's context_mode 'mean' sends every position of a sentence the same row: h and 0, nothing materialised);
+ *   inputs as in vlg_attn_fuse (in_dtype), gamma [h] fp32.
  *   d_vis [B,V,d], d_txt [B,L+1,d] (root slot row = 0), d_vis_mid [B,V,h], d_enc_x [B,L,h], d_gamma [h], d_beta [h]: fp32,
  *   all written (no accumulation).  Needs d, h multiples of 16 and <= 256 (VLG_ERR_SHAPE otherwise).
  *   ws: vlg_attn_fuse_backward_workspace(B, L, V, h) bytes of device scratch (softmax / score-gradient tiles, partial
  *   LayerNorm-parameter sums).  Bit-reproducible: no atomics, fixed summation orders. */
 size_t vlg_attn_fuse_backward_workspace(int B, int L, int V, int h);
 int vlg_attn_fuse_backward(const void* vis, const void* txt, const void* vis_mid, const void* enc_x, const float* gamma,
-                           const float* dout, int B, int L, int V, int d, int h, int in_dtype, float eps, void* ws,
-                           size_t ws_bytes, float* d_vis, float* d_txt, float* d_vis_mid, float* d_enc_x, float* d_gamma,
-                           float* d_beta, void* stream);
+                           const float* dout, long long ld_dout_b, long long ld_dout_l, int B, int L, int V, int d, int h, int in_dtype,
+                           float eps, void* ws, size_t ws_bytes, float* d_vis, float* d_txt, float* d_vis_mid, float* d_enc_x,
+                           float* d_gamma, float* d_beta, void* stream);
 
 /* Pairwise relation features of the visual encoder -- VisBoxRelSimpleEncoder.forward, src/model/vis_encoder/box_rel.py:41-45:
  *   rel[b,i,j,:] = LeakyReLU( rel_fc.linear( (inputs[b,i] + inputs[b,j]) / 2 ) )
@@ -266,15 +268,16 @@ int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* 
  * loss.backward(), i.e. the word / child / parent encoders of src/model/joint.py:270-277 and `vis_mlp_pre_matching`
  * (joint.py:136-138,175):   d_weight[M(out), N(in)] = dy^T x,   d_bias[M] = sum_rows dy.
  *   dy [K, ld_dy] (first M columns used), x [K, ld_x] (first N columns used): bf16, row-major, K = B*N token rows;
- *   M and N multiples of 8 (64 x 64 output tiles, partial at the edges), row strides multiples of 8 elements, all buffers 16-byte aligned.
- *   d_weight [M, N] fp32, d_bias [M] fp32 or NULL; x_colsum [N] fp32 or NULL = sum_rows x (the bias gradient when the roles
+ *   M and N multiples of 8 (64 x 64 output tiles, partial at the edges), row strides multiples of 8 elements, dy / x / ws 16-byte aligned.
+ *   d_weight [M, N], d_bias [M] or NULL, x_colsum [N] or NULL in out_dtype (VLG_F32, or VLG_BF16 = the parameter's storage type: no cast
+ *   launch behind the reduction; accumulation is fp32 either way); x_colsum = sum_rows x (the bias gradient when the roles
  *   are swapped: a weight stored [in, out] as in `matmul(child + parent, arc_encoder_w2) + arc_encoder_b`, joint.py:285-286,
  *   takes dy := the layer input and x := the cotangent).  ws: vlg_linear_wgrad_workspace(K, M, N) bytes (0 = unsupported shape).
  * Split over the token rows across the whole chip (bf16 MFMA, fp32 accumulate); partial tiles are added in a fixed
  * order: bit-reproducible, no atomics. */
 size_t vlg_linear_wgrad_workspace(int K, int M, int N);
-int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes,
-                     float* d_weight, float* d_bias, float* x_colsum, void* stream);
+int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
+                     void* d_weight, void* d_bias, void* x_colsum, void* stream);
 
 /* The byte work of `lang_feat_max_tree` (src/model/joint.py:235-292) between the DP, the encoder GEMMs and the arc encoder.
  * Shapes: B sentences, L words, N = L + 1 positions (root first), h encoder width, d matching width; M = B*N rows.
@@ -300,7 +303,7 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
  *                     `lang_feat_word_only`, joint.py:193-211, and its adjoint; in place allowed) */
 int vlg_langfeat_root_cat(const void* x, const int64_t* lengths, int B, int L, int h, int in_dtype, void* x1, int out_dtype,
                           void* stream);
-int vlg_langfeat_root_cat_backward(const void* d_x1, const int64_t* lengths, int B, int L, int h, int in_dtype, float* d_x,
+int vlg_langfeat_root_cat_backward(const void* d_x1, const int64_t* lengths, int B, int L, int h, int in_dtype, void* d_x, int out_dtype,
                                    void* stream);
 int vlg_langfeat_split(const void* pre, const int64_t* heads, const float* drop, int ld_drop, int B, int N, int d, int act_dtype, float slope,
                        void* txt, void* child, void* parent, void* sum, void* stream);

@@ -100,14 +100,15 @@ def test_attn_and_grounding_entry_points_validate_on_the_host(lib):
     one = P(16)   # any non-null pointer: validation must fail before it is dereferenced
     # attention-fuse adjoint: d, h multiples of 16 and <= 256
     bw = lib.vlg_attn_fuse_backward
-    assert bw(one, one, one, one, one, one, 2, 5, 7, 24, 64, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1001
+    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 24, 64, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1001
     assert b"multiples of 16" in lib.vlg_last_error()
-    assert bw(one, one, one, one, one, one, 2, 5, 7, 32, 512, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1001
-    assert bw(one, one, one, one, one, one, 2, 5, 7, 32, 64, 9, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1002
-    assert bw(None, one, one, one, one, one, 2, 5, 7, 32, 64, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1003
+    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 512, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1001
+    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 64, 9, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1002
+    assert bw(None, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 64, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1003
+    assert bw(one, one, one, one, one, one, 64, 2, 2, 5, 7, 32, 64, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1001   # dout stride
     need = lib.vlg_attn_fuse_backward_workspace(2, 5, 7, 64)
     assert need > 0 and lib.vlg_attn_fuse_backward_workspace(4, 5, 7, 64) > need and lib.vlg_attn_fuse_backward_workspace(0, 5, 7, 64) == 0
-    assert bw(one, one, one, one, one, one, 2, 5, 7, 32, 64, 0, 1e-5, one, need - 1, one, one, one, one, one, one, None) == 0x1004
+    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 64, 0, 1e-5, one, need - 1, one, one, one, one, one, one, None) == 0x1004
     assert b"workspace" in lib.vlg_last_error()
     # grounding loss: d in {32, 64, 128}, 16-bit positions, prior table needs its segment map
     gl = lib.vlg_grounding_loss

@@ -2222,3 +2222,74 @@ def test_ndmv_potentials_shapes(oracle_mod, B, L, T, r, dt):
         with pytest.raises(RuntimeError, match="LDS"):
             scorer.ndmv_potentials(t(mk(1, 40, 2, 2, 64)), t(mk(5000, 2, 2, 64)), t(mk(1, 40, 2, 2, 64)), t(mk(2, 2, 2, 64)),
                                    t(np.zeros(5000, np.float32)), t(np.zeros((1, 40), np.int64)))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_ndmv_potentials_strided_side_by_side(oracle_mod, dt):
+    """The scorers' inputs as column slices of wider GEMM outputs (rows a constant stride apart, read in place): attach.project1 |
+    dec.project1 side by side in one [4 B L, 2r] buffer and x2 / y2 inside a [4 (T + 3), 4r] one, as vlgae_amd.parser_ff hands them.
+    Values equal the contiguous call's bit for bit; the adjoint returns d_x1 | d_y1 side by side again, in the inputs' dtype."""
+    from vlgae_amd import scorer
+    B, L, T, r = 4, 9, 7, 16
+    rng = np.random.default_rng(77)
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    big = t((rng.standard_normal((B * L * 4, 2 * r)) * 0.5).astype(np.float32)).to(dtype)
+    small = t((rng.standard_normal((4 * (T + 3), 4 * r)) * 0.5).astype(np.float32)).to(dtype)
+    root = t(np.log(rng.dirichlet(np.ones(T))).astype(np.float32))
+    token, hm = t(rng.integers(0, T, size=(B, L))), t(rng.random((B, L)) < 0.2)
+    views = [big[:, :r].view(B, L, 2, 2, r), small[:4 * T, :r].view(T, 2, 2, r), big[:, r:].view(B, L, 2, 2, r),
+             small[4 * T + 4:, 3 * r:].view(2, 2, 2, r)]
+    assert not any(v.is_contiguous() for v in views)
+    g_md, g_ma = t(rng.random((B, L + 1, 2, 2, 2)).astype(np.float32)), t(rng.random((B, L + 1, L + 1, 2)).astype(np.float32))
+    res = []
+    for ins in (views, [v.contiguous() for v in views]):
+        ins = [v.detach().requires_grad_(True) for v in ins] + [root.clone().requires_grad_(True)]
+        md, ma = scorer.ndmv_potentials(*ins, token, hm)
+        res.append((md, ma, torch.autograd.grad([md, ma], ins, [g_md, g_ma])))
+    (md_s, ma_s, g_s), (md_c, ma_c, g_c) = res
+    assert torch.equal(md_s, md_c) and torch.equal(ma_s, ma_c)
+    for a, b in zip(g_s, g_c):
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b)
+    assert g_s[0].dtype == dtype and g_s[4].dtype == torch.float32
+    assert g_s[2].data_ptr() == g_s[0].data_ptr() + r * g_s[0].element_size() and g_s[0].stride() == (L * 8 * r, 8 * r, 4 * r, 2 * r, 1)
+    arrs = [v.float().cpu().numpy() for v in views]
+    omd, oma, og = oracle_mod.ndmv_potentials(*arrs, root.cpu().numpy(), token.cpu().numpy(), hm.cpu().numpy(), -1e20, g_md.cpu().numpy(),
+                                              g_ma.cpu().numpy())
+    fin = np.abs(oma) < 1e11
+    assert np.abs(ma_s.detach().cpu().numpy()[fin] - oma[fin]).max() <= 5e-5
+    for k, v in zip(("x1", "x2", "y1", "y2", "root_rule"), g_s):
+        assert np.abs(v.float().cpu().numpy() - og[k]).max() <= (1e-2 if dt == "bf16" else 1e-4) * max(1.0, np.abs(og[k]).max()), k
+
+
+def test_linear_wgrad_bf16_outputs():
+    """vlg_linear_wgrad writing the parameter's storage type: the bf16 results are the fp32 results rounded once (same reduction)."""
+    from vlgae_amd import align
+    gen = torch.Generator().manual_seed(4)
+    K, M, N = 4200, 96, 136
+    dy, x = torch.randn(K, M, generator=gen).to(dev(), torch.bfloat16), torch.randn(K, N, generator=gen).to(dev(), torch.bfloat16)
+    dw32, db32 = align.linear_wgrad(dy, x)
+    dw16, db16 = align.linear_wgrad(dy, x, out_dtype=torch.bfloat16)
+    assert dw16.dtype == db16.dtype == torch.bfloat16 and torch.equal(dw16, dw32.bfloat16()) and torch.equal(db16, db32.bfloat16())
+    _, xs16 = align.linear_wgrad(dy, x, want_x_colsum=True, out_dtype=torch.bfloat16)
+    assert torch.equal(xs16, align.linear_wgrad(dy, x, want_x_colsum=True)[1].bfloat16())
+    out = (torch.empty(M, N, dtype=torch.bfloat16, device=dev()), torch.empty(M, dtype=torch.bfloat16, device=dev()))
+    align.linear_wgrad(dy, x, out=out)
+    assert torch.equal(out[0], dw16) and torch.equal(out[1], db16)
+
+
+def test_attn_fuse_backward_broadcast_cotangent():
+    """The cotangent of the fused encodings as the parser's context_mode 'mean' produces it -- one row per sentence broadcast over the
+    positions (a stride-0 view) -- is read in place and gives the gradients of the materialised tensor, bit for bit."""
+    from vlgae_amd import align
+    gen = torch.Generator().manual_seed(8)
+    B, L, V, d, h = 5, 13, 9, 32, 64
+    mk = lambda *s: torch.randn(*s, generator=gen).to(dev())
+    leaves = [mk(B, V, d), mk(B, L + 1, d), mk(B, V, h), mk(B, L, h), mk(h), mk(h)]
+    for a in leaves:
+        a.requires_grad_(True)
+    row = mk(B, h)
+    out = align.attention_fuse(*leaves, 1e-5)
+    g_view = torch.autograd.grad(out, leaves, row.unsqueeze(1).expand(B, L, h), retain_graph=True)
+    g_full = torch.autograd.grad(out, leaves, row.unsqueeze(1).expand(B, L, h).contiguous())
+    for a, b in zip(g_view, g_full):
+        assert torch.equal(a, b)

@@ -49,15 +49,15 @@ SIGNATURES = {
     "vlg_trilinear_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "vlg_attn_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "vlg_attn_fuse_backward_workspace": (_sz, [_i, _i, _i, _i]),
-    "vlg_attn_fuse_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp, _vp,
+    "vlg_attn_fuse_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
     "vlg_box_rel_pairwise": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "vlg_box_rel_pairwise_backward_workspace": (_sz, [_i, _i, _i]),
     "vlg_box_rel_pairwise_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "vlg_linear_wgrad_workspace": (_sz, [_i, _i, _i]),
-    "vlg_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "vlg_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp, _vp, _vp]),
     "vlg_langfeat_root_cat": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
-    "vlg_langfeat_root_cat_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vlg_langfeat_root_cat_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_langfeat_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "vlg_langfeat_split_backward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "vlg_langfeat_marginal": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

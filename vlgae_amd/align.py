@@ -219,13 +219,15 @@ class _AttnFuse(torch.autograd.Function):
         B, V, d = vis_c.shape
         L, h = txt_c.shape[1] - 1, mid_c.shape[2]
         dev = vis_c.device
-        if dout.dtype != torch.float32 or not dout.is_contiguous():
-            dout = dout.to(torch.float32).contiguous()
+        sb, sl, sh = dout.stride()
+        if dout.dtype != torch.float32 or sh != 1 or sb % 4 or sl % 4 or dout.data_ptr() % 16:
+            dout = dout.to(torch.float32).contiguous()     # (a broadcast over the positions -- stride 0 -- is read in place)
+            sb, sl = L * h, h
         nbytes = _C.lib().vlg_attn_fuse_backward_workspace(B, L, V, h)
         # one allocation for the six gradients and the scratch (host overhead matters at these sizes)
         outs, ws = _C.alloc_f32(dev, ((B, V, d), (B, L + 1, d), (B, V, h), (B, L, h), (h,), (h,)), nbytes)
         _C.check(_C.lib().vlg_attn_fuse_backward(_C.ptr(vis_c), _C.ptr(txt_c), _C.ptr(mid_c), _C.ptr(enc_c), _C.ptr(gamma),
-                                                 _C.ptr(dout), B, L, V, d, h, dt, eps, _C.ptr(ws), nbytes,
+                                                 _C.ptr(dout), sb, sl, B, L, V, d, h, dt, eps, _C.ptr(ws), nbytes,
                                                  *(_C.ptr(o) for o in outs), _C.stream_of(vis_c)), "attn_fuse_backward")
         if dtypes[0] == dtypes[1] == dtypes[2] == dtypes[3] != torch.float32:   # the four feature gradients: one cast launch
             outs = outs.cast(4, dtypes[0]) + list(outs[4:])
@@ -531,10 +533,11 @@ def arc_encoder(child_repr, parent_repr, arc_encoder_w1, arc_encoder_w2, arc_enc
 # ----------------------------------------------------------------------------------------------
 # Encoder projections around the contraction (MLP, src/model/nn/common.py:23-51; joint.py:136-138,175,270-277)
 # ----------------------------------------------------------------------------------------------
-def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None):
+def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None, out_dtype=torch.float32):
     """Weight / bias gradient of `y = x @ weight.T + bias` over all token rows: (dy^T x [out, in], sum_rows dy [out]), float32.
     want_x_colsum: the second result is sum_rows x [in] instead (a weight stored [in, out]: pass the layer input as dy and the
-    cotangent as x).  out = (d_weight, second) writes into caller-owned float32 tensors.
+    cotangent as x).  out = (d_weight, second) writes into caller-owned tensors (both of one type); out_dtype (float32 / bfloat16):
+    the type of the results when `out` is not given -- the parameter's own, so that no cast launch follows the reduction.
 
     dy [K, out], x [K, in]: bf16, row-major (row strides that are multiples of 8 elements are taken in place -- column
     slices of wider buffers), out and in multiples of 8 (64 x 64 output tiles; the last tile of either side may be partial).  Split over the rows across the whole chip, fixed summation
@@ -553,11 +556,21 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None):
         raise ValueError(f"linear_wgrad: unsupported shape K={K} out={M} in={N} (out, in must be multiples of 8)")
     second = (N,) if want_x_colsum else ((M,) if want_bias else None)
     if out is None:
-        (dw, db), ws = _C.alloc_f32(dy.device, ((M, N), second), nbytes)
+        if out_dtype == torch.float32:
+            (dw, db), ws = _C.alloc_f32(dy.device, ((M, N), second), nbytes)
+        else:
+            n2 = 0 if second is None else second[0]
+            buf = torch.empty(M * N + n2, dtype=out_dtype, device=dy.device)
+            dw, db = buf[:M * N].view(M, N), (buf[M * N:] if n2 else None)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     else:
         dw, db = out
+        out_dtype = dw.dtype
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    if out_dtype not in (torch.float32, torch.bfloat16) or (db is not None and db.dtype != out_dtype) or not dw.is_contiguous():
+        raise ValueError(f"linear_wgrad: outputs must be contiguous float32 or bfloat16 of one type, got {dw.dtype} / {None if db is None else db.dtype}")
     _C.check(_C.lib().vlg_linear_wgrad(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, _C.ptr(ws), nbytes,
+                                       _C.BF16 if out_dtype == torch.bfloat16 else _C.F32,
                                        _C.ptr(dw), None if want_x_colsum else _C.ptr(db), _C.ptr(db) if want_x_colsum else None,
                                        _C.stream_of(dy)), "linear_wgrad")
     return dw, db
@@ -587,9 +600,8 @@ class _Linear(torch.autograd.Function):
         dw = db = None
         if need_w or need_b:
             if g2.dtype == x2.dtype and _wgrad_ok(x2.shape[0], g2.shape[1], x2.shape[1], g2.dtype):
-                dw, db = linear_wgrad(g2, x2, want_bias=need_b)
-                dw = dw.to(weight.dtype) if need_w else None
-                db = db.to(weight.dtype) if need_b else None
+                dw, db = linear_wgrad(g2, x2, want_bias=need_b, out_dtype=weight.dtype)
+                dw = dw if need_w else None
             else:   # small or oddly shaped: the library's GEMM is the right tool
                 dw = (g2.t() @ x2) if need_w else None
                 db = g2.sum(0) if need_b else None

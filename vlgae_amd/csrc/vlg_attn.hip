@@ -356,7 +356,7 @@ template <typename In, int T, int FTM>
 __global__ __launch_bounds__(64) void attn_fuse_bwd_words_kernel(
     const typename In::T* __restrict__ vis, const typename In::T* __restrict__ txt,
     const typename In::T* __restrict__ vis_mid, const typename In::T* __restrict__ enc_x,
-    const float* __restrict__ gamma, const float* __restrict__ dout, int Lq, int V, int d, int h, float eps,
+    const float* __restrict__ gamma, const float* __restrict__ dout, size_t ld_dout_b, size_t ld_dout_l, int Lq, int V, int d, int h, float eps,
     float* __restrict__ PT, float* __restrict__ DST, int Vp, int Lp, float* __restrict__ part,
     float* __restrict__ d_txt, float* __restrict__ d_enc) {
     const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
@@ -387,9 +387,10 @@ __global__ __launch_bounds__(64) void attn_fuse_bwd_words_kernel(
     // enc_x / dout rows are read here, not at kernel start: 128 more live registers across the forward tile spill.
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const size_t row = ((size_t)b * Lq + min(q0 + i, Lq - 1)) * h + cl;
+        const int qi = min(q0 + i, Lq - 1);
+        const size_t row = ((size_t)b * Lq + qi) * h + cl;
         const float4 xr = ld4(enc_x + row);
-        const float4 gr = *reinterpret_cast<const float4*>(dout + row);
+        const float4 gr = *reinterpret_cast<const float4*>(dout + (size_t)b * ld_dout_b + (size_t)qi * ld_dout_l + cl);
         if (cin) {
             *reinterpret_cast<float4*>(tile_x + i * hp + 4 * lane) = xr;
             *reinterpret_cast<float4*>(tile_g + i * hp + 4 * lane) = gr;
@@ -670,13 +671,13 @@ struct AttnBwdPlan {   // scratch carving shared by the size query and the launc
 
 template <typename In, int T, int FTM>
 static void launch_attn_bwd_words(const void* vis, const void* txt, const void* vis_mid, const void* enc_x,
-                                  const float* gamma, const float* dout, int B, int L, int V, int d, int h, float eps,
-                                  const AttnBwdPlan& p, float* ws, float* d_txt, float* d_enc, hipStream_t s) {
+                                  const float* gamma, const float* dout, size_t ld_dout_b, size_t ld_dout_l, int B, int L, int V, int d, int h,
+                                  float eps, const AttnBwdPlan& p, float* ws, float* d_txt, float* d_enc, hipStream_t s) {
     using P = const typename In::T*;
     float *PT = ws, *DST = ws + p.pt_floats, *part = ws + 2 * p.pt_floats;
     hipLaunchKernelGGL((attn_fuse_bwd_words_kernel<In, T, FTM>), dim3(p.WT, B), dim3(64), sizeof(float) * 32 * (h + 4), s,
-                       (P)vis, (P)txt, (P)vis_mid, (P)enc_x, gamma, dout, L, V, d, h, eps, PT, DST, p.Vp, p.Lp, part, d_txt,
-                       d_enc);
+                       (P)vis, (P)txt, (P)vis_mid, (P)enc_x, gamma, dout, ld_dout_b, ld_dout_l, L, V, d, h, eps, PT, DST, p.Vp, p.Lp, part,
+                       d_txt, d_enc);
 }
 
 }  // namespace vlg
@@ -738,8 +739,8 @@ size_t vlg_attn_fuse_backward_workspace(int B, int L, int V, int h) {
 }
 
 int vlg_attn_fuse_backward(const void* vis, const void* txt, const void* vis_mid, const void* enc_x, const float* gamma,
-                           const float* dout, int B, int L, int V, int d, int h, int in_dtype, float eps, void* ws,
-                           size_t ws_bytes, float* d_vis, float* d_txt, float* d_vis_mid, float* d_enc_x, float* d_gamma,
+                           const float* dout, long long ld_dout_b, long long ld_dout_l, int B, int L, int V, int d, int h, int in_dtype,
+                           float eps, void* ws, size_t ws_bytes, float* d_vis, float* d_txt, float* d_vis_mid, float* d_enc_x, float* d_gamma,
                            float* d_beta, void* stream) {
     using namespace vlg;
     if (B < 0 || L < 1 || V < 1 || d < 1 || h < 1)
@@ -750,6 +751,8 @@ int vlg_attn_fuse_backward(const void* vis, const void* txt, const void* vis_mid
         (size_t)L * d * 4 >= (1u << 31))
         return set_error(VLG_ERR_SHAPE, "attn_fuse_backward: a sentence's rows exceed 2 GiB");
     if (!d_gamma || !d_beta) return set_error(VLG_ERR_ARG, "attn_fuse_backward: null output");
+    if (ld_dout_b < 0 || ld_dout_l < 0 || ld_dout_b % 4 || ld_dout_l % 4)
+        return set_error(VLG_ERR_SHAPE, "attn_fuse_backward: dout strides %lld, %lld (>= 0, multiples of 4 elements)", ld_dout_b, ld_dout_l);
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) {
         hipError_t e = hipMemsetAsync(d_gamma, 0, sizeof(float) * h, s);
@@ -767,13 +770,13 @@ int vlg_attn_fuse_backward(const void* vis, const void* txt, const void* vis_mid
 #define VLG_BW(INV, TT)                                                                                            \
     do {                                                                                                           \
         if (d > 128) {                                                                                             \
-            launch_attn_bwd_words<INV, TT, 16>(vis, txt, vis_mid, enc_x, gamma, dout, B, L, V, d, h, eps, p, wsf, d_txt, \
+            launch_attn_bwd_words<INV, TT, 16>(vis, txt, vis_mid, enc_x, gamma, dout, (size_t)ld_dout_b, (size_t)ld_dout_l, B, L, V, d, h, eps, p, wsf, d_txt, \
                                                d_enc_x, s);                                                        \
             hipLaunchKernelGGL((attn_fuse_bwd_regions_kernel<INV, 16>), dim3((V + 15) / 16, B), dim3(64), 0, s,    \
                                (const INV::T*)txt, d_enc_x, wsf, wsf + p.pt_floats, p.Vp, p.Lp, L, V, d, h, d_vis_mid, \
                                d_vis);                                                                             \
         } else {                                                                                                   \
-            launch_attn_bwd_words<INV, TT, 8>(vis, txt, vis_mid, enc_x, gamma, dout, B, L, V, d, h, eps, p, wsf, d_txt, \
+            launch_attn_bwd_words<INV, TT, 8>(vis, txt, vis_mid, enc_x, gamma, dout, (size_t)ld_dout_b, (size_t)ld_dout_l, B, L, V, d, h, eps, p, wsf, d_txt, \
                                               d_enc_x, s);                                                         \
             hipLaunchKernelGGL((attn_fuse_bwd_regions_kernel<INV, 8>), dim3((V + 15) / 16, B), dim3(64), 0, s,     \
                                (const INV::T*)txt, d_enc_x, wsf, wsf + p.pt_floats, p.Vp, p.Lp, L, V, d, h, d_vis_mid, \

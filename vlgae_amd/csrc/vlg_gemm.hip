@@ -154,12 +154,19 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
 // out[i] = sum_s part[s][i] in the order s = 0, 1, ... over the n tile elements followed by the n_cs column sums (the
 // partial column sums sit behind the partial tiles, split-major).  One element per thread: the loads of one thread are
 // independent, so eight are in flight per lane; the additions keep the order.
-__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int S, int n, float* __restrict__ out,
-                                                          const float* __restrict__ part_cs, int n_cs, float* __restrict__ out_cs,
-                                                          const float* __restrict__ part_csb, int n_csb, float* __restrict__ out_csb) {
+__device__ __forceinline__ void st_out(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st_out(uint16_t* p, float v) {   // bf16, round to nearest even
+    const uint32_t u = __float_as_uint(v);
+    *p = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename O>
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int S, int n, O* __restrict__ out,
+                                                          const float* __restrict__ part_cs, int n_cs, O* __restrict__ out_cs,
+                                                          const float* __restrict__ part_csb, int n_csb, O* __restrict__ out_csb) {
     int i = blockIdx.x * 256 + threadIdx.x;
     const float* src;
-    float* dst;
+    O* dst;
     size_t pitch;
     if (i < n) { src = part + i; dst = out + i; pitch = n; }
     else if (i - n < n_cs) { i -= n; src = part_cs + i; dst = out_cs + i; pitch = n_cs; }
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restric
         for (int u = 0; u < 8; ++u) t += v[u];
     }
     for (; s < S; ++s) t += src[(size_t)s * pitch];
-    *dst = t;
+    st_out(dst, t);
 }
 
 struct TnPlan {
@@ -204,17 +211,17 @@ size_t vlg_linear_wgrad_workspace(int K, int M, int N) {
     return vlg::plan_tn(K, M, N).bytes;
 }
 
-int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes,
-                     float* d_weight, float* d_bias, float* x_colsum, void* stream) {
+int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
+                     void* d_weight, void* d_bias, void* x_colsum, void* stream) {
     using namespace vlg;
+    if (out_dtype != VLG_F32 && out_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "linear_wgrad: out_dtype %d", out_dtype);
     if (K < 1 || M < 8 || N < 8 || M % 8 || N % 8)
         return set_error(VLG_ERR_SHAPE, "linear_wgrad: need K >= 1 and M, N positive multiples of 8 (got K=%d M=%d N=%d)", K, M, N);
     if (ld_dy < M || ld_x < N || ld_dy % 8 || ld_x % 8)
         return set_error(VLG_ERR_SHAPE, "linear_wgrad: row strides must cover the columns and be multiples of 8 elements (ld_dy=%d ld_x=%d)", ld_dy, ld_x);
     if (!dy || !x || !d_weight || !ws) return set_error(VLG_ERR_ARG, "linear_wgrad: null buffer");
-    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(d_weight) |
-         reinterpret_cast<uintptr_t>(d_bias) | reinterpret_cast<uintptr_t>(x_colsum) | reinterpret_cast<uintptr_t>(ws)) & 15)
-        return set_error(VLG_ERR_ARG, "linear_wgrad: buffers must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ws)) & 15)
+        return set_error(VLG_ERR_ARG, "linear_wgrad: dy, x and the workspace must be 16-byte aligned");
     const TnPlan pl = plan_tn(K, M, N);
     if (ws_bytes < pl.bytes) return set_error(VLG_ERR_WORKSPACE, "linear_wgrad: needs a %zu-byte workspace (got %zu)", pl.bytes, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -225,8 +232,12 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
                        (const uint16_t*)x, ld_x, K, M, N, pl.KC, part, part_cs, part_csb);
     if (int rc = check_launch("gemm_tn_kernel")) return rc;
     const int n = M * N, n_cs = d_bias ? M : 0, n_csb = x_colsum ? N : 0;
-    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((n + n_cs + n_csb + 255) / 256), dim3(256), 0, s, part, pl.S, n, d_weight, part_cs,
-                       n_cs, d_bias, part_csb, n_csb, x_colsum);
+    if (out_dtype == VLG_F32)
+        hipLaunchKernelGGL(gemm_reduce_kernel<float>, dim3((n + n_cs + n_csb + 255) / 256), dim3(256), 0, s, part, pl.S, n, (float*)d_weight, part_cs,
+                           n_cs, (float*)d_bias, part_csb, n_csb, (float*)x_colsum);
+    else
+        hipLaunchKernelGGL(gemm_reduce_kernel<uint16_t>, dim3((n + n_cs + n_csb + 255) / 256), dim3(256), 0, s, part, pl.S, n, (uint16_t*)d_weight,
+                           part_cs, n_cs, (uint16_t*)d_bias, part_csb, n_csb, (uint16_t*)x_colsum);
     return check_launch("gemm_reduce_kernel");
 }
 

@@ -49,17 +49,17 @@ __global__ __launch_bounds__(256) void langfeat_x1_kernel(const T* __restrict__ 
 }
 
 // d_x1 [B,L+1,h] (T) -> d_x [B,L,h] fp32: d_x[b,l] = d_x1[b,l+1] + (l < len) d_x1[b,0] / len
-template <typename T>
+template <typename T, typename O>
 __global__ __launch_bounds__(256) void langfeat_x1_bwd_kernel(const T* __restrict__ d_x1, const int64_t* __restrict__ lengths,
-                                                              int L, int h, float* __restrict__ d_x) {
+                                                              int L, int h, O* __restrict__ d_x) {
     const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
     if (c >= h) return;
     const int len = min(max((int)lengths[b], 0), L);
     const T* src = d_x1 + (size_t)b * (L + 1) * h + c;
-    float* dst = d_x + (size_t)b * L * h + c;
+    O* dst = d_x + (size_t)b * L * h + c;
     const float share = ldf(src, 0) / (float)max(len, 1);
 #pragma unroll 4
-    for (int l = 0; l < L; ++l) dst[(size_t)l * h] = ldf(src, (size_t)(l + 1) * h) + (l < len ? share : 0.f);
+    for (int l = 0; l < L; ++l) stf(dst, (size_t)l * h, ldf(src, (size_t)(l + 1) * h) + (l < len ? share : 0.f));
 }
 
 // pre [B*N, 3d] (A) -> txt[b, n, :] = pre[:, 0:d] * m_word;  child[m] = leaky(pre[m, d:2d]) * m_child;
@@ -284,18 +284,23 @@ int vlg_langfeat_root_cat(const void* x, const int64_t* lengths, int B, int L, i
     return check_launch("langfeat_x1_kernel");
 }
 
-int vlg_langfeat_root_cat_backward(const void* d_x1, const int64_t* lengths, int B, int L, int h, int in_dtype, float* d_x,
+int vlg_langfeat_root_cat_backward(const void* d_x1, const int64_t* lengths, int B, int L, int h, int in_dtype, void* d_x, int out_dtype,
                                    void* stream) {
     using namespace vlg;
     if (B < 0 || L < 1 || h < 1) return set_error(VLG_ERR_SHAPE, "langfeat_root_cat_backward: bad shape B=%d L=%d h=%d", B, L, h);
-    if (!ok_dtype(in_dtype)) return set_error(VLG_ERR_DTYPE, "langfeat_root_cat_backward: in_dtype %d", in_dtype);
+    if (!ok_dtype(in_dtype) || !ok_dtype(out_dtype)) return set_error(VLG_ERR_DTYPE, "langfeat_root_cat_backward: dtypes %d -> %d", in_dtype, out_dtype);
     if (B == 0) return 0;
     if (!d_x1 || !lengths || !d_x) return set_error(VLG_ERR_ARG, "langfeat_root_cat_backward: null buffer");
     const dim3 grid(B, (h + 255) / 256);
-    if (in_dtype == VLG_F32)
-        hipLaunchKernelGGL(langfeat_x1_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_x1, lengths, L, h, d_x);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == VLG_F32 && out_dtype == VLG_F32)
+        hipLaunchKernelGGL((langfeat_x1_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)d_x1, lengths, L, h, (float*)d_x);
+    else if (in_dtype == VLG_F32)
+        hipLaunchKernelGGL((langfeat_x1_bwd_kernel<float, uint16_t>), grid, dim3(256), 0, s, (const float*)d_x1, lengths, L, h, (uint16_t*)d_x);
+    else if (out_dtype == VLG_F32)
+        hipLaunchKernelGGL((langfeat_x1_bwd_kernel<uint16_t, float>), grid, dim3(256), 0, s, (const uint16_t*)d_x1, lengths, L, h, (float*)d_x);
     else
-        hipLaunchKernelGGL(langfeat_x1_bwd_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)d_x1, lengths, L, h, d_x);
+        hipLaunchKernelGGL((langfeat_x1_bwd_kernel<uint16_t, uint16_t>), grid, dim3(256), 0, s, (const uint16_t*)d_x1, lengths, L, h, (uint16_t*)d_x);
     return check_launch("langfeat_x1_bwd_kernel");
 }
 

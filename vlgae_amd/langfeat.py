@@ -69,9 +69,12 @@ def _wgrad_into(dy, x, d_w, d_b, x_colsum=False):
     """d_w, d_b <- (dy^T x, sum_rows dy) [or, x_colsum: sum_rows x]: the split-K kernel for bf16, the library in fp32."""
     if dy.dtype == x.dtype and _wgrad_ok(x.shape[0], dy.shape[1], x.shape[1], dy.dtype):
         linear_wgrad(dy, x, want_x_colsum=x_colsum, out=(d_w, d_b))
-    else:
+    elif d_w.dtype == torch.float32:
         torch.matmul(dy.float().t(), x.float(), out=d_w)
         torch.sum((x if x_colsum else dy).float(), 0, out=d_b)
+    else:
+        d_w.copy_(dy.float().t() @ x.float())
+        d_b.copy_((x if x_colsum else dy).float().sum(0))
 
 
 class _LangFeat(torch.autograd.Function):
@@ -141,9 +144,10 @@ class _LangFeat(torch.autograd.Function):
                  "langfeat_split_backward")
         _wgrad_into(d_pre, x1, d_wenc, d_benc)
         d_x1 = d_pre @ w_enc_c                                                              # [M,h], library GEMM
-        d_x = torch.empty((B, L, h), dtype=torch.float32, device=dev)
-        _C.check(lib.vlg_langfeat_root_cat_backward(_C.ptr(d_x1), _C.ptr(lengths), B, L, h, adt, _C.ptr(d_x), st),
-                 "langfeat_root_cat_backward")
+        xdt = t_x if t_x in (torch.float32, torch.bfloat16) else torch.float32
+        d_x = torch.empty((B, L, h), dtype=xdt, device=dev)
+        _C.check(lib.vlg_langfeat_root_cat_backward(_C.ptr(d_x1), _C.ptr(lengths), B, L, h, adt, _C.ptr(d_x),
+                                                    _C.BF16 if xdt == torch.bfloat16 else _C.F32, st), "langfeat_root_cat_backward")
         need = ctx.needs_input_grad
         pdt = (t_wenc, t_benc, t_w1, t_w2, t_barc)
         pg = [d_wenc, d_benc, d_w1, d_w2, d_barc]
@@ -188,15 +192,18 @@ class _WordOnly(torch.autograd.Function):
             gs = torch.empty_like(g)
             _C.check(lib.vlg_langfeat_rowscale(_C.ptr(g), _C.ptr(drop), B, N, d, drop.stride(0), adt, _C.ptr(gs), st), "langfeat_rowscale")
             g = gs
-        (d_w, d_b), _ = _C.alloc_f32(dev, ((d, h), (d,)))
+        # gradients leave in the types of what receives them: no cast launches behind the kernels
+        pdt = t_w if t_w == t_b and t_w in (torch.float32, torch.bfloat16) else torch.float32
+        d_w, d_b = torch.empty((d, h), dtype=pdt, device=dev), torch.empty((d,), dtype=pdt, device=dev)
         _wgrad_into(g, x1, d_w, d_b)
         d_x1 = g @ w_c
-        d_x = torch.empty((B, L, h), dtype=torch.float32, device=dev)
-        _C.check(lib.vlg_langfeat_root_cat_backward(_C.ptr(d_x1), _C.ptr(lengths), B, L, h, adt, _C.ptr(d_x), st),
-                 "langfeat_root_cat_backward")
+        xdt = t_x if t_x in (torch.float32, torch.bfloat16) else torch.float32
+        d_x = torch.empty((B, L, h), dtype=xdt, device=dev)
+        _C.check(lib.vlg_langfeat_root_cat_backward(_C.ptr(d_x1), _C.ptr(lengths), B, L, h, adt, _C.ptr(d_x),
+                                                    _C.BF16 if xdt == torch.bfloat16 else _C.F32, st), "langfeat_root_cat_backward")
         need = ctx.needs_input_grad
-        return ((d_x if d_x.dtype == t_x else d_x.to(t_x)) if need[0] else None, None, d_w.to(t_w) if need[2] else None,
-                d_b.to(t_b) if need[3] else None, None, None)
+        return ((d_x if d_x.dtype == t_x else d_x.to(t_x)) if need[0] else None, None, (d_w if pdt == t_w else d_w.to(t_w)) if need[2] else None,
+                (d_b if pdt == t_b else d_b.to(t_b)) if need[3] else None, None, None)
 
 
 def lang_feat_word_only(x, lengths, w_word, b_word, drop=None, compute_dtype=None):

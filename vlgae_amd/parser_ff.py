@@ -289,7 +289,9 @@ class _ParserFF(torch.autograd.Function):
                 out[k] = v
         else:
             out = [t if t.dtype == d else t.to(d) for t, d in zip(out, p_dt)]
-        g_x = g_cmean.unsqueeze(1).expand(B, L, h)
+        # d mean_l(x): every position of a sentence gets the same row -- cast the [B,h] rows, then broadcast as a stride-0 view (the
+        # attention fuse's adjoint reads it in place; materialised it would be a [B,L,h] fp32 tensor)
+        g_x = (g_cmean if g_cmean.dtype == in_dt[1] else g_cmean.to(in_dt[1])).unsqueeze(1).expand(B, L, h)
         ins = [g_emb.view(B, L, E), g_x, g_small_in[0], g_small_in[1], g_small_in[2]]
         ins = [t if t.dtype == d else t.to(d) for t, d in zip(ins, in_dt)]
         need = ctx.needs_input_grad
