@@ -157,7 +157,7 @@ struct Arena {
 template <int SR, bool BWD, typename In>
 void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int len, int N, float glogZ, float* logZ,
                  float* gdec, float* gatt, int nt, int order, long long* heads = nullptr) {
-    const bool walk = BWD && SR == VLG_SR_MAX && gdec == nullptr;   // the launcher's rule (vlg_dp.hip: run_dmv)
+    const bool walk = BWD && SR == VLG_SR_MAX;   // the launcher's rule (vlg_dp.hip: run_dmv)
     const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, g_mode, walk);   // mode 0: one contiguous carve, like LDS
     Arena A(L.lds_bytes), W(L.ws_bytes);
     auto at = [&](const vlg::Region& r) { return r.lds ? A.at(r.off) : W.at(r.off); };
@@ -184,7 +184,7 @@ void emu_dmv_one(const typename In::T* dec, const typename In::T* attach, int le
 template <int SR, bool BWD>
 void emu_rules_one(const vlg::RuleIO<vlg::F32In>& io, int len, float glogZ, float* logZ, int nt, int order) {
     const int N = io.L + 1;
-    const bool walk = BWD && SR == VLG_SR_MAX && io.g_dec == nullptr;
+    const bool walk = BWD && SR == VLG_SR_MAX;
     const vlg::DmvLayout L(N, BWD, SR == VLG_SR_MAX, 0, walk);
     Arena A(L.lds_bytes);
     vlg::DmvCtx c;

@@ -3,6 +3,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 tag=${1:-r02}
 mkdir -p gpurun_out
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_ts -- python tools/time_train_step.py ${@:2} > gpurun_out/${tag}_train_step.log 2>&1
+rm -rf gpurun_out/prof_${tag}_ts; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_ts -- python tools/time_train_step.py ${@:2} > gpurun_out/${tag}_train_step.log 2>&1
 f=$(find gpurun_out/prof_${tag}_ts -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${tag}_train_step_kernel_stats.csv
 grep "ms/step" gpurun_out/${tag}_train_step.log

@@ -5,7 +5,8 @@ than 8 us (the fold-able tail)."""
 import csv, glob, re, sys
 
 d = sys.argv[1]
-f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+import os
+f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)   # the newest run in the directory
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 marks = [i for i, n in enumerate(names) if "attn_fuse_mfma_kernel" in n]     # once per step

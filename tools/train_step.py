@@ -308,6 +308,7 @@ def _build_r3(B, L, V, dev, dtype, d, h, seed, with_scorer, T, r):
     names = sorted(P)
     leaves = [P[k] for k in names]
     pot = [md.detach().requires_grad_(True), ma.detach().requires_grad_(True)]
+    one, minus_one = torch.ones((), device=dev), torch.full((B,), -1.0, device=dev)
 
     def step(stage_hook=None):
         x = align.attention_fuse(P["vis_feat"], P["txt_word"], P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], 1e-5)
@@ -320,9 +321,12 @@ def _build_r3(B, L, V, dev, dtype, d, h, seed, with_scorer, T, r):
                                                                keep_viterbi=True, compute_dtype=dtype)   # (x is the fuse's fp32 output)
         if stage_hook is not None:
             txt.register_hook(lambda g_: stage_hook())
-        total, _ = align.grounding_loss_factor_ce(txt, P["vis_feat"], tmask, vmask, txt_marginal, num_token, 1.0)
-        total = total - ts.DMV1o(loss_pot, lengths).max.sum()
-        grads = torch.autograd.grad(total, leaves + ([] if with_scorer else pot))
+        mt, _ = align.grounding_loss_factor_ce(txt, P["vis_feat"], tmask, vmask, txt_marginal, num_token, 1.0)
+        mx = ts.DMV1o(loss_pot, lengths).max
+        with torch.no_grad():
+            total = mt - mx.sum()
+        # total = mt - sum_b max_b: the two cotangents (+1, -1 per sentence) seed the backward pass directly
+        grads = torch.autograd.grad([mt, mx], leaves + ([] if with_scorer else pot), [one, minus_one.view(mx.shape)])
         return total, dict(zip(names, grads[:len(names)])), grads[len(names):]
 
     step.names, step.P, step.lengths, step.wiring = names, P, lengths, "r3"

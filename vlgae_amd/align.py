@@ -313,6 +313,7 @@ class _GroundingLoss(torch.autograd.Function):
         ctx.save_for_backward(g_txt, g_vis)
         ctx.dtypes = (txt_feat.dtype, vis_feat.dtype)
         ctx.mark_non_differentiable(sums)
+        ctx.set_materialize_grads(False)   # (no zero-fill launch for the cotangent `sums` never gets)
         return sums[2], sums   # (a 0-d view of the non-differentiable sums: no clone launch; nothing writes either in place)
 
     @staticmethod
@@ -320,6 +321,8 @@ class _GroundingLoss(torch.autograd.Function):
     def backward(ctx, g_total, _g_sums):
         g_txt, g_vis = ctx.saved_tensors
         out = [None] * 10
+        if g_total is None:
+            return tuple(out)
         want_t, want_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dt = ctx.dtypes[0]
         if dt == ctx.dtypes[1] and dt in (torch.float32, torch.bfloat16) and g_total.dtype == torch.float32 and g_total.numel() == 1:

@@ -151,7 +151,7 @@ static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, 
     if (!dec || !attach || !lengths || !logZ || (BWD && !heads && !gatt))   // gdec may be null: attach counts only
         if (B > 0) return set_error(VLG_ERR_ARG, "dmv1o: null buffer");
     if (B == 0) return 0;
-    const bool walk = BWD && semiring == VLG_SR_MAX && !gdec;   // tree only: lean layout, back-pointer walk (the kernel derives the same flag)
+    const bool walk = BWD && semiring == VLG_SR_MAX;   // the Max semiring's outside pass is the back-pointer walk: lean layout (the kernel derives the same flag)
     const int mode = pick_mode<DmvLayout>(N, BWD, semiring == VLG_SR_MAX, kLdsBudget, walk);
     const DmvLayout L(N, BWD, semiring == VLG_SR_MAX, mode, walk);
     const size_t ws_stride = L.ws_bytes, lds = L.lds_bytes;
@@ -255,7 +255,7 @@ int vlg_dmv1o_rules(const void* attach_rule, const void* dec, const void* root_r
     if (bwd && !heads && !(grad_rule && grad_dec && grad_root))
         return set_error(VLG_ERR_ARG, "dmv1o_rules: pass all three gradient buffers (or only heads)");
     const bool is_max = semiring == VLG_SR_MAX;
-    const bool walk = bwd && is_max && !grad_dec;
+    const bool walk = bwd && is_max;
     const int mode = pick_mode<DmvLayout>(N, bwd, is_max, kLdsBudget, walk);
     const DmvLayout Lay(N, bwd, is_max, mode, walk);
     if (Lay.ws_bytes * (size_t)B > ws_bytes || (Lay.ws_bytes && !ws))

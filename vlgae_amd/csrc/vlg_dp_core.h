@@ -122,10 +122,10 @@ struct DmvCtx {
     float2* gCi;    // adjoint of C, part contributed by incomplete-span parents
     float2* gI;     // adjoint of I (== d logZ / d attach once complete)
     float* decs;    // staged dec        [Ne][8]
-    float* gdecs;   // adjoint of dec    [Ne][8]
+    float* gdecs;   // the walk's STOP counts [Ne][dir][val] (Max semiring; empty otherwise: the replay reads them off gCc / gCi)
     unsigned char* bpS;   // Max semiring back-pointers (first arg-max r), same indexing as S
     unsigned char* bpC;   // [Ne][P][2]
-    bool walk;            // Max semiring, tree only: no S / gCi / gdecs, gCc is just the walk's stack (lean layout)
+    bool walk;            // Max semiring with an outside pass: no S / gCi, gCc is just the walk's stack (lean layout)
 };
 
 // weight of term r in a reduction with result `out`, scaled by the upstream adjoint g
@@ -385,7 +385,7 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
         c.C[kO] = make_float2(Cx, Cy);
         if (BWD) {
             const int kS = DIR == 0 ? DW : D + w;      // SL(i,j) at S[j*P+i], SR(i,j) at S[i*P+j]
-            if (!c.walk) c.S[kS] = Sv;                 // the tape of the outside replay; the back-pointer walk does not read it
+            if (SR != VLG_SR_MAX) c.S[kS] = Sv;        // the tape of the outside replay; the Max semiring's back-pointer walk does not read it
             if (SR == VLG_SR_MAX) {
                 c.bpS[kS] = (unsigned char)am[0];
                 c.bpC[kO * 2] = (unsigned char)b0;
@@ -973,8 +973,11 @@ struct RuleIO {
 // ------------------------------------------------------------------------------------------------
 // Best tree from the Max semiring's back-pointers, by walking the derivation from the root span instead of replaying
 // the whole outside pass with one-hot weights (which costs as much as the inside pass; the walk visits ~4N spans).
-// One lane walks; the stack lives in the (unused) gCc chart.  Every attachment it meets sets gI[...] = 1 at that
-// (head, child, valence), which the common output loop turns into the one-hot attach tensor and the head vector.
+// One lane walks; the stack lives in the (unused) gCc chart.  Every attachment it meets sets gI[...] = g at that
+// (head, child, valence), which the common output loop turns into the one-hot attach tensor, the head vector and the GO counts
+// (row sums of gI); every width-0 complete span it ends in is a STOP decision of that head, direction and valence (dmv.py:39-40):
+// gdecs[h][dir][v] = g.  Together these are ALL the counts of the Max semiring's gradient (round 4: the one-hot replay of the
+// outside pass -- as long as the inside pass, 87 us against 58 us per launch at B = 256, L = 40 -- is no longer run for it).
 //   entry = kind | a << 2 | b << 10 | v << 18     kind: 0 CL(a=head, b=left end)   1 CR(a=head, b=right end)
 //                                                       2 IL(a=head j, b=child)     3 IR(a=head i, b=child)
 //   recurrences as in dmv_fw_span (valence index 0 = .x HASCHILD, 1 = .y NOCHILD):
@@ -992,7 +995,8 @@ VLG_HD void dmv_walk(const DmvCtx& c, float g) {
     // the stack, so a step costs one dependent LDS read (the back-pointer), not a push-pop round trip as well
     for (;;) {
         const int kind = e & 3, a = (e >> 2) & 255, b = (e >> 10) & 255, v = (e >> 18) & 1;
-        if (kind < 2 && a == b) {   // width-0 complete span: a leaf
+        if (kind < 2 && a == b) {   // width-0 complete span: a leaf = the STOP decision of head a towards kind (0 LEFT, 1 RIGHT) at valence v
+            c.gdecs[a * 4 + kind * 2 + v] = g;
             if (top == 0) break;
             e = stack[--top];
             continue;
@@ -1090,13 +1094,14 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     }
     for (int i = tid; i < Ne * P; i += nt) {
         c.gI[i] = oo;
-        if (!c.walk) { c.gCc[i] = 0.f; c.gCi[i] = oo; }
+        if (SR != VLG_SR_MAX) { c.gCc[i] = 0.f; c.gCi[i] = oo; }
     }
+    if (SR == VLG_SR_MAX) for (int i = tid; i < Ne * 4; i += nt) c.gdecs[i] = 0.f;
     x.sync();
     DmvCtx cb = c;   // the outside pass's view: value charts where the layout keeps them for this pass
     cb.C = c.C2;
     cb.I = c.I2;
-    if (SR == VLG_SR_MAX && c.walk) {   // only the tree is wanted (the launcher chose the lean layout): walk the back-pointers
+    if (SR == VLG_SR_MAX) {   // the Max semiring's gradient IS the best tree: walk the back-pointers (compile-time: no one-hot replay is built)
         if (tid == 0) dmv_walk(cb, glogZ);
         x.sync();
     } else {
@@ -1141,7 +1146,7 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
             float g = 0.f;
             if (h < Ne) {
                 const int q = h * P + h + dir;
-                g = (v == 1 ? c.gCc[q] : 0.f) + reinterpret_cast<const float*>(c.gCi + q)[v];
+                g = SR == VLG_SR_MAX ? c.gdecs[h * 4 + dir * 2 + v] : (v == 1 ? c.gCc[q] : 0.f) + reinterpret_cast<const float*>(c.gCi + q)[v];
             }
             io.st_dec(h, (dir * 2 + v) * 2 + 1, g);
         }
@@ -1298,8 +1303,8 @@ struct DmvLayout {
     Region C, I, S, bpS, bpC, gCc, gCi, gI, decs, gdecs;
     Region C_in, I_in;   // the value charts as the INSIDE pass sees them (== C, I except in the overlay mode below)
     size_t lds_bytes, ws_bytes;
-    // walk: Max semiring with only the tree wanted -- no replay tape (S), no adjoint charts; gCc shrinks to the walk's
-    // stack, gI stays (the one-hot attach output / head vector is read from it).  Its modes keep the value charts and
+    // walk: Max semiring with an outside pass (tree, counts or both) -- no replay tape (S), no adjoint charts; gCc shrinks to the
+    // walk's stack, gI stays (the one-hot attach output / head vector / GO counts are read from it).  Its modes keep the value charts and
     // back-pointers in LDS longest:  0: everything   1: gI in the workspace   2+: value charts too.
     VLG_HOSTDEV_M DmvLayout(int N, bool bwd, bool is_max, int mode, bool walk = false) {
         const size_t cells = (size_t)N * chart_pitch(N);
@@ -1315,7 +1320,7 @@ struct DmvLayout {
             gCi = k.take(0, true);
             gI = k.take(cells * 8, a2);
             decs = k.take((size_t)N * 32, true);
-            gdecs = k.take(0, true);
+            gdecs = k.take((size_t)N * 16, true);            // the walk's STOP counts [N][dir][val]
             C_in = C;
             I_in = I;
         } else {

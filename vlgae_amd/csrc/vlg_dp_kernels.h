@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
     }
 
     char* wsb = ws + (size_t)b * ws_stride;
-    const DmvCtx c = carve_dmv<SR, MODE, BWD>(N, len, smem, wsb, BWD && SR == VLG_SR_MAX && gdec == nullptr);
+    const DmvCtx c = carve_dmv<SR, MODE, BWD>(N, len, smem, wsb, BWD && SR == VLG_SR_MAX);
     MergedIO<In> io;
     io.dec = dec + dec_off;
     io.attach = attach + att_off;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kThreads) void dmv1o_rules_kernel(
         return;
     }
     char* wsb = ws + (size_t)b * ws_stride;
-    const DmvCtx c = carve_dmv<SR, MODE, BWD>(N, len, smem, wsb, BWD && SR == VLG_SR_MAX && g_dec == nullptr);
+    const DmvCtx c = carve_dmv<SR, MODE, BWD>(N, len, smem, wsb, BWD && SR == VLG_SR_MAX);
     RuleIO<In> io;
     io.rule = rule + (size_t)b * Lw * T * 4;
     io.dec = dec + (size_t)b * Lw * 8;
