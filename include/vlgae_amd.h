@@ -370,6 +370,18 @@ int vlg_dmv1o_viterbi(const void* dec, const void* attach, const int64_t* length
                       const float* grad_best, float* best_score, float* grad_dec, float* grad_attach, int64_t* heads,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* Marginals AND the Viterbi tree of the same potentials in one launch -- the pair `lang_feat_max_tree` takes every step
+ * (src/model/joint.py:251-258), plus, for the parser's Viterbi-tree loss (src/model/ldndmv.py:277-281), the tree counts: grid (B, 2), the
+ * two workgroups of a sentence (Log inside-outside | Max inside + back-pointer walk) share a CU as they do on two streams, without
+ * the fork / join between queues.  Outputs as vlg_dmv1o_inside_outside (logZ [B], grad_dec [B,N,2,2,2] or NULL, grad_attach
+ * [B,N,N,2]: unit upstream gradient) and vlg_dmv1o_viterbi (best_score [B], tree_dec / tree_attach or NULL, heads [B,N]); no
+ * workspace.  Only where both passes keep everything in LDS and fit one CU together (vlg_dmv1o_marginals_viterbi_supported(N) == 1:
+ * N <= 44); VLG_ERR_SHAPE otherwise -- launch the two entry points on two streams then. */
+int vlg_dmv1o_marginals_viterbi_supported(int N);
+int vlg_dmv1o_marginals_viterbi(const void* dec, const void* attach, const int64_t* lengths, int B, int N, int in_dtype, float* logZ,
+                                float* grad_dec, float* grad_attach, float* best_score, float* tree_dec, float* tree_attach, int64_t* heads,
+                                void* stream);
+
 /* Chain rule on the API path (helpers.py:116-157: autograd scales the unit-upstream counts by d loss / d logZ):
  *   out_a[b,:] = counts_a[b,:] * g[b*g_stride], out_b likewise; counts fp32, outputs out_dtype (VLG_F32 / VLG_BF16, round to
  *   nearest even like torch's cast).  g_stride 1: g [B]; 0: one scalar (the expanded gradient of `.sum()`).  n_a / n_b =

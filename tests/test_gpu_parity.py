@@ -2293,3 +2293,43 @@ def test_attn_fuse_backward_broadcast_cotangent():
     g_full = torch.autograd.grad(out, leaves, row.unsqueeze(1).expand(B, L, h).contiguous())
     for a, b in zip(g_view, g_full):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_dmv1o_marginals_viterbi_one_launch(ts, dt):
+    """vlg_dmv1o_marginals_viterbi (both DPs of lang_feat_max_tree as one grid (B, 2) launch) against the two separate launches it
+    replaces, bit for bit: logZ / marginals of the Log semiring, best score / heads / tree counts of the Max semiring; ragged lengths,
+    a sentence of length 1, an invalid length (NaN score, zero counts).  Longer sentences take the two-stream form, same results."""
+    from vlgae_amd import _C
+    from vlgae_amd.torch_struct import functional as F
+    gen = torch.Generator().manual_seed(21)
+    for B, L in ((37, 40), (5, 7), (3, 43), (3, 44), (4, 60)):
+        N = L + 1
+        dec = torch.randn(B, L, 2, 2, 2, generator=gen).log_softmax(-1).to(dev())
+        attach = (torch.randn(B, L, L, 2, generator=gen) * 2).to(dev())
+        root = torch.randn(B, L, generator=gen).log_softmax(-1).to(dev())
+        md, ma = ts.DMV1o.merge(dec, attach, root)
+        if dt == "bf16":
+            md, ma = md.bfloat16(), ma.bfloat16()
+        lengths = torch.randint(1, L + 1, (B,), generator=gen)
+        lengths[0], lengths[1] = L, 1
+        lengths = lengths.to(dev())
+        assert bool(_C.lib().vlg_dmv1o_marginals_viterbi_supported(N)) == (N <= 44)
+        F.viterbi_forget()
+        logZ, gatt, heads = F.dmv1o_marginals_and_heads(md, ma, lengths, keep_viterbi=True)
+        best, vdec, vatt, vheads = F._viterbi_lookup(md, ma, lengths)
+        lz2, _, ga2 = F.dmv1o_run(md, ma, lengths, _C.SEMIRING_LOG, True, want_dec=False)
+        b2, vd2, va2, h2 = F.dmv1o_viterbi(md, ma, lengths)
+        assert torch.equal(logZ, lz2) and torch.equal(gatt, ga2)
+        assert torch.equal(best, b2) and torch.equal(vdec, vd2) and torch.equal(vatt, va2) and torch.equal(heads, h2) and vheads is heads
+        _, _, heads3 = F.dmv1o_marginals_and_heads(md, ma, lengths)          # heads only: the tree counts are not written
+        assert torch.equal(heads3, h2)
+        # one attachment per word; STOP decisions: two per word and the root's RIGHT one; one GO decision per attachment
+        assert float(vatt.sum()) == float(lengths.sum()) and float(vdec[..., 1].sum()) == float((2 * lengths + 1).sum())
+        assert float(vdec[..., 0].sum()) == float(lengths.sum())
+    F.viterbi_forget()
+    bad = torch.tensor([3, 0, 9], device=dev())
+    md, ma = ts.DMV1o.merge(torch.zeros(3, 6, 2, 2, 2, device=dev()), torch.zeros(3, 6, 6, 2, device=dev()), torch.zeros(3, 6, device=dev()))
+    logZ, gatt, heads = F.dmv1o_marginals_and_heads(md, ma, bad, keep_viterbi=True)
+    assert torch.isnan(logZ[1:]).all() and not gatt[1:].any() and not heads[1:].any() and torch.isfinite(logZ[0])
+    F.viterbi_forget()

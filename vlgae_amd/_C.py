@@ -25,6 +25,8 @@ SIGNATURES = {
     "vlg_deptree_inside_outside": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vlg_dmv1o_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vlg_deptree_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "vlg_dmv1o_marginals_viterbi_supported": (_i, [_i]),
+    "vlg_dmv1o_marginals_viterbi": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vlg_dmv1o_rules": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                              _sz, _vp]),
     "vlg_dmv1o_merge": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),

@@ -248,16 +248,13 @@ __device__ __forceinline__ DepCtx carve_dep(int N, int len, char* smem, char* ws
     return c;
 }
 
+// one sentence b = one workgroup: the whole DP (shared by dmv1o_kernel and, with two semirings in one grid, dmv1o_pair_kernel)
 template <int SR, int MODE, bool BWD, typename In>
-__global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* __restrict__ dec,
-                                                         const typename In::T* __restrict__ attach,
-                                                         const int64_t* __restrict__ lengths, int N,
-                                                         const float* __restrict__ glogZ, float* __restrict__ logZ,
-                                                         float* __restrict__ gdec, float* __restrict__ gatt,
-                                                         long long* __restrict__ heads, char* __restrict__ ws,
-                                                         size_t ws_stride) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void dmv1o_sentence(int b, const typename In::T* __restrict__ dec, const typename In::T* __restrict__ attach,
+                                               const int64_t* __restrict__ lengths, int N, const float* __restrict__ glogZ,
+                                               float* __restrict__ logZ, float* __restrict__ gdec, float* __restrict__ gatt,
+                                               long long* __restrict__ heads, char* __restrict__ ws, size_t ws_stride, char* smem) {
+    const int tid = threadIdx.x;
     const int len = (int)lengths[b];
     const size_t dec_off = (size_t)b * N * 8, att_off = (size_t)b * N * N * 2;
 
@@ -282,6 +279,36 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
     io.heads = (BWD && heads) ? heads + (size_t)b * N : nullptr;
     DevX x;
     dmv_run<SR, BWD, (MODE != 0)>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);   // long-sentence placements: chunked long spans
+}
+
+template <int SR, int MODE, bool BWD, typename In>
+__global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* __restrict__ dec,
+                                                         const typename In::T* __restrict__ attach,
+                                                         const int64_t* __restrict__ lengths, int N,
+                                                         const float* __restrict__ glogZ, float* __restrict__ logZ,
+                                                         float* __restrict__ gdec, float* __restrict__ gatt,
+                                                         long long* __restrict__ heads, char* __restrict__ ws,
+                                                         size_t ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    dmv1o_sentence<SR, MODE, BWD, In>(blockIdx.x, dec, attach, lengths, N, glogZ, logZ, gdec, gatt, heads, ws, ws_stride, smem);
+}
+
+// The pair lang_feat_max_tree asks for every step (joint.py:251-258) in ONE launch: blockIdx.y = 0 runs the Log semiring's
+// inside-outside pass of sentence blockIdx.x (marginals), blockIdx.y = 1 the Max semiring's inside pass + back-pointer walk of the
+// same sentence (best score, heads, optionally the tree counts).  Both are everything-in-LDS placements (mode 0) whose footprints
+// share a CU, so the two workgroups of a sentence run side by side as they did on two streams -- without the two cross-queue
+// dependencies (fork after the potentials' producer, join before the first consumer: ~15 us of a 110 us pair at B = 256, L = 40).
+template <typename In>
+__global__ __launch_bounds__(kThreads) void dmv1o_pair_kernel(const typename In::T* __restrict__ dec, const typename In::T* __restrict__ attach,
+                                                              const int64_t* __restrict__ lengths, int N, float* __restrict__ logZ,
+                                                              float* __restrict__ gdec_log, float* __restrict__ gatt_log,
+                                                              float* __restrict__ best, float* __restrict__ gdec_max,
+                                                              float* __restrict__ gatt_max, long long* __restrict__ heads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.y == 0)
+        dmv1o_sentence<VLG_SR_LOG, 0, true, In>(blockIdx.x, dec, attach, lengths, N, nullptr, logZ, gdec_log, gatt_log, nullptr, nullptr, 0, smem);
+    else
+        dmv1o_sentence<VLG_SR_MAX, 0, true, In>(blockIdx.x, dec, attach, lengths, N, nullptr, best, gdec_max, gatt_max, heads, nullptr, 0, smem);
 }
 
 // The same DP fed from the scorer's rule tables (RuleIO): no gathered [B,L,L,2,2]
