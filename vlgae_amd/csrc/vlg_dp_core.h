@@ -1102,7 +1102,12 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     cb.C = c.C2;
     cb.I = c.I2;
     if (SR == VLG_SR_MAX) {   // the Max semiring's gradient IS the best tree: walk the back-pointers (compile-time: no one-hot replay is built)
+#ifndef VLG_ABL_NOWALK       // (tools/ ablation: the one-lane walk is 21 of the 56 us of a Viterbi launch at B = 256, L = 40.  A level-synchronous
+                             //  form -- one lane per open span, an LDS fetch-add for the next level's queue slots, a barrier per level -- was built
+                             //  and measured in round 4: 60 us.  A derivation of 40 random-score words is 50+ levels deep, and a level costs
+                             //  more than the three dependent LDS reads of a serial step: not kept.)
         if (tid == 0) dmv_walk(cb, glogZ);
+#endif
         x.sync();
     } else {
     if (tid == 0) c.gCc[len + 1] = glogZ;
