@@ -1102,10 +1102,12 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
     cb.C = c.C2;
     cb.I = c.I2;
     if (SR == VLG_SR_MAX) {   // the Max semiring's gradient IS the best tree: walk the back-pointers (compile-time: no one-hot replay is built)
-#ifndef VLG_ABL_NOWALK       // (tools/ ablation: the one-lane walk is 21 of the 56 us of a Viterbi launch at B = 256, L = 40.  A level-synchronous
-                             //  form -- one lane per open span, an LDS fetch-add for the next level's queue slots, a barrier per level -- was built
-                             //  and measured in round 4: 60 us.  A derivation of 40 random-score words is 50+ levels deep, and a level costs
-                             //  more than the three dependent LDS reads of a serial step: not kept.)
+#ifndef VLG_ABL_NOWALK       // (tools/ ablation: the one-lane walk is 21 of the 56 us of a Viterbi launch at B = 256, L = 40 -- ~400 cycles per
+                             //  span, one dependent LDS read each.  Two parallel forms were built and measured in round 4, both 60 us: a
+                             //  level-synchronous walk (one lane per open span, an LDS fetch-add for the next level's queue slots, a barrier per
+                             //  level) and that walk handing over to one serial walker per wavefront once eight sub-derivations are open.
+                             //  Neither finds parallelism: with the width-0 spans pruned a derivation is a chain -- most spans have ONE
+                             //  non-leaf child -- so the frontier stays at 1-3 spans for ~100 levels, each dearer than a serial step.)
         if (tid == 0) dmv_walk(cb, glogZ);
 #endif
         x.sync();
