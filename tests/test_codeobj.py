@@ -65,3 +65,19 @@ def test_register_budgets_match_the_launch_shapes(kernels):
         assert total <= 512, (name[:100], total)
         if "dmv1o_kernel<0, 0, true, vlg::BF16In>" in name:
             assert total <= 128, total
+
+
+def test_round4_second_half_kernels_are_on_the_hot_list(kernels):
+    """The kernels added after the list above was written: both DPs of lang_feat_max_tree as one launch, the element-wise passes of the
+    parser's feed-forwards.  No scratch, no VGPR spills; the pair kernel within the 128 registers that let a sentence's two workgroups share a CU."""
+    names = ("dmv1o_pair_kernel<", "ff_mlp_act_kernel<", "ff_act_kernel<", "ff_act_bwd_kernel<", "ff_mlp_act_bwd_kernel<")
+    found = {}
+    for k in kernels:
+        dem = k.get("demangled", k.get("name", ""))
+        for name in names:
+            if name in dem:
+                found[name] = found.get(name, 0) + 1
+                assert not k.get("private_segment_fixed_size", 0) and not k.get("vgpr_spill_count", 0), dem
+                if name == "dmv1o_pair_kernel<":
+                    assert k.get("vgpr_count", 999) <= 128, (dem, k.get("vgpr_count"))
+    assert len(found) == len(names), found

@@ -175,7 +175,11 @@ def _run_all(out, args, h, dev):
     out["decode"] = {"us": sec * 1e6, "sentences_per_s": B / sec, "what": "dmv1o_decode: best tree as heads [B,N], on device"}
     sec = _events(lambda: ts.DMV1o([md, ma], lengths).marginals_and_heads(), 50, 5, dev)
     out["marginals_and_heads"] = {"us": sec * 1e6,
-                                  "what": "arc marginals + Viterbi heads of one batch (joint.py:251-258), two HIP streams"}
+                                  "what": "arc marginals + Viterbi heads of one batch (joint.py:251-258): ONE launch, grid (B, 2) "
+                                          "(vlg_dmv1o_marginals_viterbi; two HIP streams before round 4's second half and beyond N = 44)"}
+    sec = _events(lambda: Fn.dmv1o_viterbi(md, ma, lengths), 50, 5, dev)
+    out["viterbi_with_counts"] = {"us": sec * 1e6, "what": "Max semiring: best score + tree counts (d max / d potentials) + heads, one launch "
+                                                           "(inside pass + back-pointer walk; the one-hot outside replay is no longer run)"}
 
     # ---- the region x word alignment that feeds / consumes the DP (joint.py:406-419) ----
     # features as SURVEY 8(d) specifies: 2048-d region / 768-d word vectors through fixed-seed Linear(-> 128), no bias
