@@ -177,3 +177,37 @@ def test_trilinear_entry_points_validate_on_the_host(lib):
     assert bwd(one, one, one, one, 100, 32, 64, 32, 1, one, need - 1, one, one, one, None) == 0x1004
     assert bwd(one, one, one, one, 100, 32, 48, 32, 1, one, need, one, one, one, None) == 0x1001
     assert bwd(one, one, one, None, 100, 32, 64, 32, 1, one, need, one, one, one, None) == 0x1003
+
+
+def test_round4_entry_points_validate_on_the_host(lib):
+    """vlg_ff_* (element-wise passes of the parser's feed-forwards), vlg_dmv1o_marginals_viterbi and the strided score construction:
+    shape / dtype / alignment / null errors before any HIP call."""
+    P = ctypes.c_void_p
+    one, odd = P(64), P(68)
+    f = ctypes.c_float(0.01)
+    assert lib.vlg_ff_act(one, None, None, one, 10, 1, 12, 0, 1, f, None) == 0x1001                 # H not a multiple of 8
+    assert b"multiple of 8" in lib.vlg_last_error()
+    assert lib.vlg_ff_act(one, None, None, one, 10, 2, 64, 1, 1, f, None) == 0x1001                 # the permutation is of J = 4
+    assert lib.vlg_ff_act(one, None, None, one, 10, 4, 64, 1, 1, f, None) == 0x1003                 # ... and not in place
+    assert lib.vlg_ff_act(one, None, None, one, 10, 1, 64, 0, 5, f, None) == 0x1002
+    assert lib.vlg_ff_act(odd, None, None, one, 10, 1, 64, 0, 1, f, None) == 0x1003 and b"aligned" in lib.vlg_last_error()
+    assert lib.vlg_ff_act(one, None, None, one, 0, 1, 64, 0, 1, f, None) == 0                       # nothing to do
+    assert lib.vlg_ff_act_backward(one, one, None, one, None, 10, 4, 64, 1, 0, 1, f, None) == 0x1003
+    assert lib.vlg_ff_act_backward(one, None, None, one, None, 10, 1, 64, 0, 0, 1, f, None) == 0x1003
+    assert lib.vlg_ff_mlp_act(one, None, None, None, 2, 5, 3, 64, 1, f, None) == 0x1003             # parent rows need the context term
+    assert lib.vlg_ff_mlp_act(one, one, None, None, 2, 0, 3, 64, 1, f, None) == 0x1001
+    assert lib.vlg_ff_mlp_act_backward(None, None, one, None, None, one, 2, 5, 3, 64, 1, f, None) == 0x1003
+    assert lib.vlg_dmv1o_marginals_viterbi_supported(41) == 1 and lib.vlg_dmv1o_marginals_viterbi_supported(81) == 0
+    assert lib.vlg_dmv1o_marginals_viterbi_supported(1) == 0 and lib.vlg_dmv1o_marginals_viterbi_supported(300) == 0
+    mv = lib.vlg_dmv1o_marginals_viterbi
+    assert mv(one, one, one, 4, 81, 0, one, None, one, one, None, None, one, None) == 0x1001 and b"two streams" in lib.vlg_last_error()
+    assert mv(one, one, one, 4, 41, 7, one, None, one, one, None, None, one, None) == 0x1002
+    assert mv(one, one, one, 4, 41, 0, one, None, None, one, None, None, one, None) == 0x1003        # the marginals are not optional
+    assert mv(one, one, one, 4, 41, 0, one, None, one, one, one, None, one, None) == 0x1003         # tree_dec needs tree_attach
+    assert mv(one, one, one, 0, 41, 0, one, None, one, one, None, None, one, None) == 0
+    # score construction: row strides below the rank are refused
+    sc = lib.vlg_ndmv_potentials
+    assert sc(one, 8, one, 16, one, 16, one, 16, one, one, None, 2, 5, 7, 16, 0, ctypes.c_float(-1e20), 0, one, one, None) == 0x1001
+    assert b"row strides" in lib.vlg_last_error()
+    assert lib.vlg_linear_wgrad(one, 64, one, 64, 4096, 64, 64, one, 1 << 30, 9, one, one, None, None) == 0x1002
+    assert lib.vlg_langfeat_root_cat_backward(one, one, 2, 5, 64, 0, one, 9, None) == 0x1002

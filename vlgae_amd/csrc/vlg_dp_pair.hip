@@ -48,7 +48,6 @@ int vlg_dmv1o_marginals_viterbi(const void* dec, const void* attach, const int64
         return set_error(VLG_ERR_SHAPE, "dmv1o_marginals_viterbi: N=%d -- the two passes do not share a CU's LDS (see vlg_dmv1o_marginals_viterbi_supported); "
                          "launch vlg_dmv1o_inside_outside and vlg_dmv1o_viterbi on two streams", N);
     if (B == 0) return 0;
-    if (B > 65535 * 32) return set_error(VLG_ERR_SHAPE, "dmv1o_marginals_viterbi: B=%d", B);
     if (!dec || !attach || !lengths || !logZ || !grad_attach || !best_score || !heads)
         return set_error(VLG_ERR_ARG, "dmv1o_marginals_viterbi: null buffer");
     if (tree_dec && !tree_attach) return set_error(VLG_ERR_ARG, "dmv1o_marginals_viterbi: tree_dec needs tree_attach");

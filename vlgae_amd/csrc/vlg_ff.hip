@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <initializer_list>
+
 #include "vlg_common.h"
 #include "vlg_rows.h"
 
@@ -161,6 +163,13 @@ int ff_check(const char* what, long long rows, int H, int act_dtype) {
 
 inline dim3 ff_grid(size_t threads) { return dim3((unsigned)((threads + kFfThreads - 1) / kFfThreads)); }
 
+// rows are read and written 16 bytes at a time
+inline bool ff_aligned(std::initializer_list<const void*> ps) {
+    for (const void* p : ps)
+        if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+    return true;
+}
+
 }  // namespace
 
 }  // namespace vlg
@@ -175,6 +184,7 @@ int vlg_ff_mlp_act(void* x, const void* cterm, const float* drop_head, const flo
     if (int rc = ff_check("ff_mlp_act", M0 + Ms, H, act_dtype)) return rc;
     if (M0 + Ms == 0) return 0;
     if (!x || (M0 > 0 && !cterm)) return set_error(VLG_ERR_ARG, "ff_mlp_act: null buffer");
+    if (!ff_aligned({x, cterm, drop_head})) return set_error(VLG_ERR_ARG, "ff_mlp_act: x, cterm and drop_head must be 16-byte aligned");
     const dim3 grid = ff_grid((size_t)(M0 + Ms) * (H / 8));
     hipStream_t s = (hipStream_t)stream;
     if (act_dtype == VLG_BF16)
@@ -193,6 +203,7 @@ int vlg_ff_act(const void* in, const void* residual, const void* mask, void* out
     if (int rc = ff_check("ff_act", M * J, H, act_dtype)) return rc;
     if (M == 0) return 0;
     if (!in || !out || (swap && in == out)) return set_error(VLG_ERR_ARG, "ff_act: null buffer, or in-place with the permutation");
+    if (!ff_aligned({in, residual, mask, out})) return set_error(VLG_ERR_ARG, "ff_act: buffers must be 16-byte aligned");
     const size_t rows = (size_t)M * J;
     const dim3 grid = ff_grid(rows * (H / 8));
     hipStream_t s = (hipStream_t)stream;
@@ -212,6 +223,7 @@ int vlg_ff_act_backward(const void* g, const void* act, const void* mask, void* 
     if (int rc = ff_check("ff_act_backward", M * J, H, act_dtype)) return rc;
     if (M == 0) return 0;
     if (!g || !act || !out || (swap && g == out)) return set_error(VLG_ERR_ARG, "ff_act_backward: null buffer, or in-place with the permutation");
+    if (!ff_aligned({g, act, mask, out, sum})) return set_error(VLG_ERR_ARG, "ff_act_backward: buffers must be 16-byte aligned");
     const dim3 grid = ff_grid((size_t)M * (H / 8));
     hipStream_t s = (hipStream_t)stream;
     if (act_dtype == VLG_BF16)
@@ -231,6 +243,7 @@ int vlg_ff_mlp_act_backward(const float* gx, const void* t, const void* x, const
     if (int rc = ff_check("ff_mlp_act_backward", M0 + Ms, H, act_dtype)) return rc;
     if (M0 + Ms == 0) return 0;
     if (!gx || !x || !gpre) return set_error(VLG_ERR_ARG, "ff_mlp_act_backward: null buffer");
+    if (!ff_aligned({gx, t, x, drop_head, gpre})) return set_error(VLG_ERR_ARG, "ff_mlp_act_backward: buffers must be 16-byte aligned");
     const dim3 grid = ff_grid((size_t)(M0 + Ms) * (H / 8));
     hipStream_t s = (hipStream_t)stream;
     if (act_dtype == VLG_BF16)
