@@ -315,6 +315,17 @@ int vlg_langfeat_marginal(const float* grad_attach, const int64_t* heads, const 
 int vlg_langfeat_arc_out(const float* tri, const void* aff, int B, int N, int d, int act_dtype, void* txt, void* stream);
 int vlg_langfeat_rowscale(const void* pre, const float* drop, int B, int N, int d, int ld_drop, int act_dtype, void* out, void* stream);
 
+/* Small (batched) matrix products in weight space -- the folded bottleneck weights W1 W0 of `DMVSkipConnectEncoder`
+ * (src/model/nn/dmv_spec.py:52-54) and their unfolding, the per-sentence context term of `head_ff` (src/model/ldndmv.py:174-177): products
+ * whose OUTPUT is a few hundred rows and columns, which a library GEMM maps to one workgroup.  One wavefront per 32 x 32 tile per batch entry.
+ *   C[z][m][n] = alpha * sum_k A[z](m,k) B[z](k,n) + bias[z][n] + u[z][m] v[z][n] (+ C[z][m][n] if accumulate)
+ *   A(m,k) at a + z sab + m sam + k sak,  B(k,n) at b + z sbb + k sbk + n sbn  (ELEMENT strides: transposed / sliced operands in place);
+ *   C row-major, rows ldc apart, batch entries scb apart; bias [N] (batch stride sbias), u [M] (su), v [N] (sv): in_dtype, any may be NULL
+ *   (u and v together).  in_dtype VLG_BF16 (bf16 products) or VLG_F32 (exact fp32 products), fp32 accumulation, out_dtype either. */
+int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, const void* b, long long sbb, long long sbk, long long sbn,
+                   void* c, long long scb, long long ldc, const void* bias, long long sbias, const void* u, long long su, const void* v,
+                   long long sv, int batch, int M, int N, int K, float alpha, int accumulate, int in_dtype, int out_dtype, void* stream);
+
 /* Element-wise passes between the library GEMMs of the parser's feed-forwards (vlgae_amd/parser_ff.py): `MLP`
  * (src/model/nn/common.py:23-51: Linear -> LeakyReLU -> SharedDropout) and `DMVSkipConnectEncoder` (src/model/nn/dmv_spec.py:38-54).
  * Activations in act_dtype (VLG_BF16 / VLG_F32), rows of H channels (H a multiple of 8), 16-byte aligned; fp32 arithmetic.

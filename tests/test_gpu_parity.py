@@ -2337,3 +2337,53 @@ def test_dmv1o_marginals_viterbi_one_launch(ts, dt):
     logZ, gatt, heads = F.dmv1o_marginals_and_heads(md, ma, bad, keep_viterbi=True)
     assert torch.isnan(logZ[1:]).all() and not gatt[1:].any() and not heads[1:].any() and torch.isfinite(logZ[0])
     F.viterbi_forget()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_small_matmul(dtype):
+    """vlg_small_gemm (one wavefront per 32 x 32 output tile, operands through element strides) against float64: plain / batched / broadcast
+    operands, transposed and column-sliced views read in place, ragged M / N / K, bias, rank-one term, alpha, accumulate, both output types.
+    float32 operands: exact products (v_mfma_f32_16x16x4_f32), 2e-6 relative to the magnitude sum; bf16: the products of bf16 inputs are
+    exact in fp32, so the same bound on the fp32 output and one bf16 rounding on a bf16 output."""
+    from vlgae_amd import align
+    gen = torch.Generator().manual_seed(17)
+    mk = lambda *s: torch.randn(*s, generator=gen).to(dev(), dtype)
+
+    def check(name, got, a, b, alpha=1.0, bias=None, rank1=None, base=None):
+        a64, b64 = a.double(), b.double()
+        ref = alpha * (a64 @ b64)
+        mag = abs(alpha) * (a64.abs() @ b64.abs())
+        if bias is not None:
+            ref = ref + bias.double().unsqueeze(-2)
+        if rank1 is not None:
+            ref = ref + rank1[0].double().unsqueeze(-1) * rank1[1].double().unsqueeze(-2)
+        if base is not None:
+            ref = ref + base.double()
+        tol = 2e-6 * (mag + ref.abs()) + (2.0 ** -8 * ref.abs() if got.dtype == torch.bfloat16 else 0.0) + 1e-30
+        err = (got.double() - ref).abs()
+        assert got.shape == ref.shape and bool((err <= tol).all()), (name, float((err / tol).max()))
+
+    a, b = mk(256, 150), mk(150, 256)
+    check("plain", align.small_matmul(a, b), a, b)
+    a3, b3 = mk(4, 256, 150), mk(4, 150, 256)
+    check("batched", align.small_matmul(a3, b3), a3, b3)
+    check("batched, fp32 out", align.small_matmul(a3, b3, out_dtype=torch.float32), a3, b3)
+    check("transposed views", align.small_matmul(a3.transpose(1, 2), b3.transpose(1, 2)), a3.transpose(1, 2), b3.transpose(1, 2))
+    wide = mk(70, 300)
+    sl, bt = wide[:, 40:141], mk(33, 101).t()                      # column slice [70,101] x transposed [101,33]: ragged everything
+    check("sliced x transposed", align.small_matmul(sl, bt), sl, bt)
+    bias, u, v = mk(33), mk(70), mk(33)
+    check("bias + rank one + alpha", align.small_matmul(sl, bt, alpha=0.25, bias=bias, rank1=(u, v)), sl, bt, 0.25, bias, (u, v))
+    ub, vb, biasb = mk(4, 256), mk(4, 256), mk(4, 256)
+    check("batched bias + rank one", align.small_matmul(a3, b3, bias=biasb, rank1=(ub, vb)), a3, b3, 1.0, biasb, (ub, vb))
+    check("broadcast b", align.small_matmul(a3, b), a3, b.unsqueeze(0).expand(4, -1, -1))
+    base = torch.randn(4, 256, 256, generator=gen).to(dev())
+    out = base.clone()
+    align.small_matmul(a3, b3, out=out, accumulate=True)
+    check("accumulate into fp32", out, a3, b3, base=base)
+    one = mk(1, 7), mk(7, 1)
+    check("1 x 1", align.small_matmul(*one), *one)
+    with pytest.raises(ValueError):
+        align.small_matmul(a, b.float() if dtype == torch.bfloat16 else b.bfloat16())
+    with pytest.raises(ValueError):
+        align.small_matmul(a, mk(151, 256))

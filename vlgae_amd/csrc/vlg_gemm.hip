@@ -185,6 +185,93 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restric
     st_out(dst, t);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Small (batched) products in weight space: C[z] = alpha * A[z] B[z] + bias + u v^T (+ C[z]) with M, N, K of a few hundred.  The
+// library maps an output of 256 x 256 to ONE workgroup (tiles of 256 x 256: 15-28 us for 33-80 MFLOP on a 256-CU chip); here every
+// 32 x 32 tile of every batch entry is one wavefront: 256 workgroups for the four folded bottleneck weights of the parser's mid_ff
+// (W1 W0, `nn/dmv_spec.py:52-54`; vlgae_amd/parser_ff.py).  Operands are addressed through element strides (a transposed or
+// column-sliced weight is read where it lies); each lane gathers its MFMA fragment with 2- or 4-byte loads (the operands are a few
+// hundred KB and L2-resident; edges and K tails are zero-filled), fp32 accumulation, bf16 (v_mfma_f32_16x16x32_bf16) or exact fp32
+// (v_mfma_f32_16x16x4_f32) products.
+struct SgArgs {
+    const void *a, *b, *bias, *u, *v;
+    void* c;
+    long long sab, sam, sak, sbb, sbk, sbn, scb, ldc, sbias, su, sv;
+    int M, N, K, accumulate;
+    float alpha;
+};
+
+__device__ __forceinline__ float sg_ld(const float* p, long long i) { return p[i]; }
+__device__ __forceinline__ float sg_ld(const uint16_t* p, long long i) { return __uint_as_float((uint32_t)p[i] << 16); }
+__device__ __forceinline__ void sg_set(f32x4& f, int e, const float* p, long long i, bool ok) { f[e] = ok ? p[i] : 0.f; }
+__device__ __forceinline__ void sg_set(bf16x8& f, int e, const uint16_t* p, long long i, bool ok) {
+    const uint16_t bits = ok ? p[i] : (uint16_t)0;
+    f[e] = __builtin_bit_cast(__bf16, bits);
+}
+__device__ __forceinline__ void sg_st(float* p, long long i, float v) { p[i] = v; }
+__device__ __forceinline__ void sg_st(uint16_t* p, long long i, float v) {
+    const uint32_t u = __float_as_uint(v);
+    p[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <bool F32IN, typename Out>
+__global__ __launch_bounds__(64) void small_gemm_kernel(SgArgs p) {
+    using Cfg = MfmaCfg<F32IN>;
+    using T = typename Cfg::T;
+    using Frag = typename Cfg::Frag;
+    constexpr int KW = Cfg::KW, EPL = Cfg::EPL;
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    const int tiles_n = (p.N + 31) / 32;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n, z = blockIdx.y;
+    const T* A = static_cast<const T*>(p.a) + (long long)z * p.sab;
+    const T* B = static_cast<const T*>(p.b) + (long long)z * p.sbb;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += KW) {
+        Frag af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = tm * 32 + i * 16 + r, col = tn * 32 + i * 16 + r;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int k = k0 + EPL * g + e;
+                sg_set(af[i], e, A, (long long)row * p.sam + (long long)k * p.sak, row < p.M && k < p.K);
+                sg_set(bf[i], e, B, (long long)k * p.sbk + (long long)col * p.sbn, col < p.N && k < p.K);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mma_chunk<F32IN>(af[i], bf[j], acc[i][j]);
+    }
+    Out* C = static_cast<Out*>(p.c) + (long long)z * p.scb;
+    const T* bias = p.bias ? static_cast<const T*>(p.bias) + (long long)z * p.sbias : nullptr;
+    const T* u = p.u ? static_cast<const T*>(p.u) + (long long)z * p.su : nullptr;
+    const T* v = p.v ? static_cast<const T*>(p.v) + (long long)z * p.sv : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = tn * 32 + j * 16 + r;
+            if (col >= p.N) continue;
+            const float bj = bias ? sg_ld(bias, col) : 0.f, vj = v ? sg_ld(v, col) : 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {   // accumulator layout: lane (r, g), register n <-> row 4 g + n, column r
+                const int row = tm * 32 + i * 16 + 4 * g + n;
+                if (row >= p.M) continue;
+                float val = p.alpha * acc[i][j][n] + bj;
+                if (u) val = fmaf(sg_ld(u, row), vj, val);
+                const long long at = (long long)row * p.ldc + col;
+                if (p.accumulate) val += sizeof(Out) == 4 ? reinterpret_cast<const float*>(C)[at] : __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(C)[at] << 16);
+                sg_st(C, at, val);
+            }
+        }
+}
+
 struct TnPlan {
     int KC, S;
     size_t bytes;
@@ -239,6 +326,28 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
         hipLaunchKernelGGL(gemm_reduce_kernel<uint16_t>, dim3((n + n_cs + n_csb + 255) / 256), dim3(256), 0, s, part, pl.S, n, (uint16_t*)d_weight,
                            part_cs, n_cs, (uint16_t*)d_bias, part_csb, n_csb, (uint16_t*)x_colsum);
     return check_launch("gemm_reduce_kernel");
+}
+
+int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, const void* b, long long sbb, long long sbk, long long sbn,
+                   void* c, long long scb, long long ldc, const void* bias, long long sbias, const void* u, long long su, const void* v,
+                   long long sv, int batch, int M, int N, int K, float alpha, int accumulate, int in_dtype, int out_dtype, void* stream) {
+    using namespace vlg;
+    if (batch < 0 || M < 1 || N < 1 || K < 1 || batch > 65535)
+        return set_error(VLG_ERR_SHAPE, "small_gemm: bad shape batch=%d M=%d N=%d K=%d", batch, M, N, K);
+    if ((in_dtype != VLG_F32 && in_dtype != VLG_BF16) || (out_dtype != VLG_F32 && out_dtype != VLG_BF16))
+        return set_error(VLG_ERR_DTYPE, "small_gemm: dtypes %d -> %d", in_dtype, out_dtype);
+    if (ldc < N) return set_error(VLG_ERR_SHAPE, "small_gemm: ldc=%lld below N=%d", ldc, N);
+    if ((u == nullptr) != (v == nullptr)) return set_error(VLG_ERR_ARG, "small_gemm: the rank-one term needs both u and v");
+    if (batch == 0) return 0;
+    if (!a || !b || !c) return set_error(VLG_ERR_ARG, "small_gemm: null buffer");
+    const SgArgs p{a, b, bias, u, v, c, sab, sam, sak, sbb, sbk, sbn, scb, ldc, sbias, su, sv, M, N, K, accumulate, alpha};
+    const dim3 grid(((M + 31) / 32) * ((N + 31) / 32), batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == VLG_F32 && out_dtype == VLG_F32) hipLaunchKernelGGL((small_gemm_kernel<true, float>), grid, dim3(64), 0, s, p);
+    else if (in_dtype == VLG_F32) hipLaunchKernelGGL((small_gemm_kernel<true, uint16_t>), grid, dim3(64), 0, s, p);
+    else if (out_dtype == VLG_F32) hipLaunchKernelGGL((small_gemm_kernel<false, float>), grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((small_gemm_kernel<false, uint16_t>), grid, dim3(64), 0, s, p);
+    return check_launch("small_gemm_kernel");
 }
 
 }  // extern "C"

@@ -30,7 +30,7 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _C
-from .align import _wgrad_ok, linear_wgrad
+from .align import _wgrad_ok, linear_wgrad, small_matmul
 
 SLOPE = 0.01   # nn.LeakyReLU() default (nn/common.py:31, nn/dmv_spec.py:10)
 _BOTTLENECKS = ("NOCHILD_linear", "HASCHILD_linear", "LEFT_linear", "RIGHT_linear")   # stack order: [no, has] (:42), [left, right] (:47)
@@ -117,7 +117,7 @@ class _ParserFF(torch.autograd.Function):
         X = torch.empty((M, H), dtype=act, device=dev)
         torch.mm(emb2, We.t(), out=X[:M0])
         cmean = x.detach().mean(1, dtype=act)                                           # context_mode 'mean', ldndmv.py:226
-        cterm = torch.addmm(bh, cmean, Wc.t())                                          # [B,H]: the context columns + bias, once per sentence
+        cterm = small_matmul(cmean, Wc.t(), bias=bh)                                    # [B,H]: the context columns + bias, once per sentence
         small_in = (token_emb, root_emb, dec_emb)
         o = M0
         for m, inp in zip(("child_ff", "root_ff", "dec_ff"), small_in):
@@ -143,7 +143,7 @@ class _ParserFF(torch.autograd.Function):
         PW, Pb = stacks[-2].view(6 * r, H), stacks[-1].view(6 * r)
         if nb:
             W0s, b0s, W1s, b1s = stacks[:4]                                                 # [4,nb,H], [4,nb], [4,H,nb], [4,H]
-            Weff = torch.bmm(W1s, W0s)                                                      # [4,H,H]
+            Weff = small_matmul(W1s, W0s)                                                   # [4,H,H] (one wavefront per 32 x 32 tile: the library runs this on 4 workgroups)
             # (as a multiply + sum: the library's batched bf16 matrix-VECTOR product costs ~10 ms of HOST time per call on this stack)
             beff = (W1s * b0s.unsqueeze(1)).sum(2) + b1s                                    # [4,H] = W1 b0 + b1
         else:
@@ -169,7 +169,7 @@ class _ParserFF(torch.autograd.Function):
         A5 = torch.addmm(b1_, A4, W1_.t())
         _act(A5, A5, 4 * M, 1, H)
         W2_, b2_ = c(P["ff.mid_ff.linear2.weight"]), c(P["ff.mid_ff.linear2.bias"])
-        Wp = PW @ W2_                                                                   # [6r,H]: P W2
+        Wp = small_matmul(PW, W2_)                                                      # [6r,H]: P W2
         bp = torch.addmv(Pb, PW, b2_)                                                   # P b2 + p
         big = torch.addmm(bp[:2 * r], A5[:4 * M0], Wp[:2 * r].t())                      # [4 M0, 2r]: attach.project1 | dec.project1
         small = torch.addmm(bp[2 * r:], A5[4 * M0:], Wp[2 * r:].t())                    # [4 Ms, 4r]: attach.p2 | root.p2 | root.p1 | dec.p2
@@ -222,8 +222,8 @@ class _ParserFF(torch.autograd.Function):
         dbp[:2 * r].copy_(dbp_b)
         torch.mm(g_small.t(), A5[4 * M0:], out=dWp[2 * r:])                             # [4r,H]: 4 (T + 3) rows, the library
         torch.sum(g_small, 0, out=dbp[2 * r:])
-        dPW = torch.addmm(torch.outer(dbp, b2_), dWp, W2_.t())                           # Wp = PW W2, bp = PW b2 + Pb
-        G["linear2.w"], G["linear2.b"] = PW.t() @ dWp, (PW * dbp.unsqueeze(1)).sum(0)     # (PW^T dbp as multiply + sum: the bf16 transposed mat-vec is ~10 ms of host time)
+        dPW = small_matmul(dWp, W2_.t(), rank1=(dbp, b2_))                               # Wp = PW W2, bp = PW b2 + Pb: dPW = dWp W2^T + dbp b2^T
+        G["linear2.w"], G["linear2.b"] = small_matmul(PW.t(), dWp), (PW * dbp.unsqueeze(1)).sum(0)     # (PW^T dbp as multiply + sum: the bf16 transposed mat-vec is ~10 ms of host time)
         # ---- linear1, direction ----
         g = _act_bwd(gA5, A5, gA5, 4 * M, 1, H)
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4)
@@ -254,8 +254,8 @@ class _ParserFF(torch.autograd.Function):
         dWe, dbh = _wgrad(gb, emb2)                                                      # [H,E], [H]
         g_emb = gb @ We                                                                  # [M0,E]
         gc = gb.view(B, L, H).sum(1)                                                     # [B,H] (fp32 accumulation inside the reduction)
-        dWc = gc.t() @ cmean                                                             # [H,h]
-        g_cmean = (gc @ Wc) / L                                                          # [B,h]
+        dWc = small_matmul(gc.t(), cmean)                                                # [H,h]
+        g_cmean = small_matmul(gc, Wc, alpha=1.0 / L)                                    # [B,h]: d mean_l
         G["head.w"], G["head.b"] = torch.cat([dWe.to(act), dWc], 1), dbh
         o = M0
         g_small_in = []
@@ -268,8 +268,8 @@ class _ParserFF(torch.autograd.Function):
         # ---- unfold the bottleneck pairs: Weff = W1 W0, beff = W1 b0 + b1 ----
         if nb:   # (in the activations' dtype: the library's batched fp32 kernels take ~50 us each for these 40-MFLOP products)
             dWe_a, dbe_a = dWeff.to(act), dbeff.to(act)
-            dW1s = torch.baddbmm(torch.einsum("kh,kn->khn", dbe_a, b0s), dWe_a, W0s.transpose(1, 2))   # [4,H,nb]
-            dW0s = torch.bmm(W1s.transpose(1, 2), dWe_a)                                 # [4,nb,H]
+            dW1s = small_matmul(dWe_a, W0s.transpose(1, 2), rank1=(dbe_a, b0s))          # [4,H,nb] = dWeff W0^T + dbeff b0^T
+            dW0s = small_matmul(W1s.transpose(1, 2), dWe_a)                              # [4,nb,H] = W1^T dWeff
             db0s = (W1s * dbe_a.unsqueeze(2)).sum(1)                                     # [4,nb] = W1^T dbeff (not a batched mat-vec: see forward)
         # ---- gradients in the order of param_names ----
         out = [G["head.w"], G["head.b"], G["child.w"], G["child.b"], G["root.w"], G["root.b"], G["dec.w"], G["dec.b"]]
