@@ -122,7 +122,7 @@ class _ParserFF(torch.autograd.Function):
         o = M0
         for m, inp in zip(("child_ff", "root_ff", "dec_ff"), small_in):
             n = inp.shape[0]
-            torch.addmm(c(P[f"ff.{m}.linear.bias"]), c(inp.detach()), c(P[f"ff.{m}.linear.weight"]).t(), out=X[o:o + n])
+            small_matmul(c(inp.detach()), c(P[f"ff.{m}.linear.weight"]).t(), bias=c(P[f"ff.{m}.linear.bias"]), out=X[o:o + n])   # (T | 1 | 2 rows)
             o += n
         # + context term, LeakyReLU, SharedDropout of the MLPs (after the activation, nn/common.py:47-51): [B,1,H] masks shared over a
         # sentence's positions for head_ff, one value per ROW for the 2-D inputs of the other three (nn/dropout.py:52-53)
@@ -172,7 +172,7 @@ class _ParserFF(torch.autograd.Function):
         Wp = small_matmul(PW, W2_)                                                      # [6r,H]: P W2
         bp = torch.addmv(Pb, PW, b2_)                                                   # P b2 + p
         big = torch.addmm(bp[:2 * r], A5[:4 * M0], Wp[:2 * r].t())                      # [4 M0, 2r]: attach.project1 | dec.project1
-        small = torch.addmm(bp[2 * r:], A5[4 * M0:], Wp[2 * r:].t())                    # [4 Ms, 4r]: attach.p2 | root.p2 | root.p1 | dec.p2
+        small = small_matmul(A5[4 * M0:], Wp[2 * r:].t(), bias=bp[2 * r:])                # [4 Ms, 4r]: attach.p2 | root.p2 | root.p1 | dec.p2
         # the scorers' inputs as VIEWS of the two products (vlgae_amd.scorer takes rows a constant stride apart in place); they are outputs
         # of this Function, so autograd hands their cotangents straight to backward -- no slice nodes, no copies
         x1 = big[:, :r].view(B, L, 2, 2, r)
@@ -183,7 +183,7 @@ class _ParserFF(torch.autograd.Function):
         r2f.view(4 * T, r).copy_(small[:4 * T, r:2 * r])
         r1f = torch.empty((1, 4 * r), dtype=torch.float32, device=dev)
         r1f.view(4, r).copy_(small[4 * T:4 * T + 4, 2 * r:3 * r])
-        root_rule = (r1f @ r2f.t()).log_softmax(-1)[0]                                  # ldndmv.py:205: sum over (dir, val), softmax over tokens
+        root_rule = small_matmul(r1f, r2f.t()).log_softmax(-1)[0]                                  # ldndmv.py:205: sum over (dir, val), softmax over tokens
         ctx.save_for_backward(emb2, cmean, X, A1, A2, A3, A4, A5, We, Wc, W_nh, W_lr, Wv, Wd, W1_, W2_, b2_, PW, Wp, W0s, b0s, W1s,
                               *(c(t.detach()) for t in small_in), *(c(P[f"ff.{m}.linear.weight"]) for m in ("child_ff", "root_ff", "dec_ff")),
                               r1f, r2f, root_rule)
@@ -208,19 +208,19 @@ class _ParserFF(torch.autograd.Function):
         dlogit = torch._log_softmax_backward_data(g_root.float(), root_rule, 0, torch.float32).unsqueeze(0)   # [1,T]
         g_small = torch.zeros((4 * Ms, 4 * r), dtype=act, device=g_big.device)
         g_small[:4 * T, :r] = g_x2.reshape(4 * T, r)
-        g_small[:4 * T, r:2 * r] = (dlogit.t() @ r1f).reshape(4 * T, r)                  # d r2[c] = dlogit[c] r1
-        g_small[4 * T:4 * T + 4, 2 * r:3 * r] = (dlogit @ r2f).reshape(4, r)             # d r1 = sum_c dlogit[c] r2[c]
+        g_small[:4 * T, r:2 * r] = small_matmul(dlogit.t(), r1f).reshape(4 * T, r)       # d r2[c] = dlogit[c] r1
+        g_small[4 * T:4 * T + 4, 2 * r:3 * r] = small_matmul(dlogit, r2f).reshape(4, r)  # d r1 = sum_c dlogit[c] r2[c]
         g_small[4 * T + 4:, 3 * r:] = g_y2.reshape(8, r)
         # ---- folded projections ----
         gA5 = torch.empty_like(A5)
         torch.mm(g_big, Wp[:2 * r], out=gA5[:4 * M0])
-        torch.mm(g_small, Wp[2 * r:], out=gA5[4 * M0:])
+        small_matmul(g_small, Wp[2 * r:], out=gA5[4 * M0:])
         # (everything below in the activations' dtype: as fp32 GEMMs on one workgroup each the library takes 30-50 us for these products)
         dWp, dbp = torch.empty((6 * r, H), dtype=act, device=g_big.device), torch.empty((6 * r,), dtype=act, device=g_big.device)
         dWp_b, dbp_b = _wgrad(g_big, A5[:4 * M0])                                       # [2r,H], [2r] fp32 (split-K)
         dWp[:2 * r].copy_(dWp_b)
         dbp[:2 * r].copy_(dbp_b)
-        torch.mm(g_small.t(), A5[4 * M0:], out=dWp[2 * r:])                             # [4r,H]: 4 (T + 3) rows, the library
+        small_matmul(g_small.t(), A5[4 * M0:], out=dWp[2 * r:])                         # [4r,H]: 4 (T + 3) rows
         torch.sum(g_small, 0, out=dbp[2 * r:])
         dPW = small_matmul(dWp, W2_.t(), rank1=(dbp, b2_))                               # Wp = PW W2, bp = PW b2 + Pb: dPW = dWp W2^T + dbp b2^T
         G["linear2.w"], G["linear2.b"] = small_matmul(PW.t(), dWp), (PW * dbp.unsqueeze(1)).sum(0)     # (PW^T dbp as multiply + sum: the bf16 transposed mat-vec is ~10 ms of host time)
@@ -262,8 +262,8 @@ class _ParserFF(torch.autograd.Function):
         for name, inp, W in (("child", tok, Wchild), ("root", rootE, Wroot), ("dec", decE, Wdec)):
             n = inp.shape[0]
             gs = gpre[o:o + n]
-            G[name + ".w"], G[name + ".b"] = gs.t() @ inp, gs.sum(0)
-            g_small_in.append(gs @ W)
+            G[name + ".w"], G[name + ".b"] = small_matmul(gs.t(), inp), gs.sum(0)
+            g_small_in.append(small_matmul(gs, W))
             o += n
         # ---- unfold the bottleneck pairs: Weff = W1 W0, beff = W1 b0 + b1 ----
         if nb:   # (in the activations' dtype: the library's batched fp32 kernels take ~50 us each for these 40-MFLOP products)
