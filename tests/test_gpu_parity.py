@@ -2383,6 +2383,14 @@ def test_small_matmul(dtype):
     check("accumulate into fp32", out, a3, b3, base=base)
     one = mk(1, 7), mk(7, 1)
     check("1 x 1", align.small_matmul(*one), *one)
+    # both contraction indices unit-stride and 16-byte aligned rows: the one-load-per-fragment path; K = 264 has a ragged last chunk in bf16
+    av, bv = mk(96, 264), mk(72, 264).t()
+    check("16-byte fragments", align.small_matmul(av, bv), av, bv)
+    av2 = mk(3, 40, 272)[:, :, 8:264]                                  # K = 256 inside a wider row: aligned, full chunks only
+    bv2 = mk(3, 50, 256).transpose(1, 2)
+    check("16-byte fragments, batched", align.small_matmul(av2, bv2, out_dtype=torch.float32), av2, bv2)
+    odd, bo = mk(20, 131)[:, 1:], mk(130, 24)                          # rows an odd number of elements apart, start misaligned: element loads
+    check("element loads", align.small_matmul(odd, bo), odd, bo)
     with pytest.raises(ValueError):
         align.small_matmul(a, b.float() if dtype == torch.bfloat16 else b.bfloat16())
     with pytest.raises(ValueError):

@@ -198,12 +198,48 @@ struct SgArgs {
     const void *a, *b, *bias, *u, *v;
     void* c;
     long long sab, sam, sak, sbb, sbk, sbn, scb, ldc, sbias, su, sv;
-    int M, N, K, accumulate;
+    int M, N, K, accumulate, veca, vecb;
     float alpha;
 };
 
 __device__ __forceinline__ float sg_ld(const float* p, long long i) { return p[i]; }
 __device__ __forceinline__ float sg_ld(const uint16_t* p, long long i) { return __uint_as_float((uint32_t)p[i] << 16); }
+// One MFMA fragment of an operand: EPL consecutive contraction positions k, k + 1, ... of one row / column.  `p` points at position k
+// (the address is always in bounds: the caller clamps the row and only takes the fast paths on full chunks); `st` is the element
+// stride between contraction positions, `vec` what the host found the operand to allow when st == 1: EPL = one 16-byte load,
+// 2 = 4-byte loads (bf16 rows an even number of elements apart), 1 = element loads.  A gathered 2-byte load touches up to 64 cache
+// lines per wave instruction (16 rows x 4 k-groups); the 16-byte form is one line per lane and an eighth of the instructions.
+__device__ __forceinline__ void sg_frag(f32x4& f, const float* p, long long st, int vec) {
+    if (vec == 4) {
+        f = *reinterpret_cast<const f32x4*>(p);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = p[e * st];
+    }
+}
+__device__ __forceinline__ void sg_frag(bf16x8& f, const uint16_t* p, long long st, int vec) {
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    v8i16 w;
+    if (vec == 8) {
+        w = *reinterpret_cast<const v8i16*>(p);
+    } else if (vec == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t two = *reinterpret_cast<const uint32_t*>(p + 2 * e);
+            w[2 * e] = (short)(two & 0xffffu);
+            w[2 * e + 1] = (short)(two >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = (short)p[e * st];
+    }
+    f = __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ void sg_zero(f32x4& f) { f = f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void sg_zero(bf16x8& f) {
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    f = __builtin_bit_cast(bf16x8, v8i16{0, 0, 0, 0, 0, 0, 0, 0});
+}
 __device__ __forceinline__ void sg_set(f32x4& f, int e, const float* p, long long i, bool ok) { f[e] = ok ? p[i] : 0.f; }
 __device__ __forceinline__ void sg_set(bf16x8& f, int e, const uint16_t* p, long long i, bool ok) {
     const uint16_t bits = ok ? p[i] : (uint16_t)0;
@@ -231,18 +267,63 @@ __global__ __launch_bounds__(64) void small_gemm_kernel(SgArgs p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < p.K; k0 += KW) {
+    const int kfull = p.K / KW * KW;
+    // rows / columns beyond the edge read a clamped (valid) address and are zeroed afterwards
+    const T* arow[2];
+    const T* bcol[2];
+    bool aok[2], bok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = tm * 32 + i * 16 + r, col = tn * 32 + i * 16 + r;
+        aok[i] = row < p.M;
+        bok[i] = col < p.N;
+        arow[i] = A + (long long)min(row, p.M - 1) * p.sam + (long long)(EPL * g) * p.sak;
+        bcol[i] = B + (long long)min(col, p.N - 1) * p.sbn + (long long)(EPL * g) * p.sbk;
+    }
+    int k0 = 0;
+    constexpr int U = 4;                            // chunks whose loads are ALL issued before the first product: a chunk per dependent
+    for (; k0 + U * KW <= kfull; k0 += U * KW) {   // L2 / HBM round trip made a 256 x 256 x 256 product 9.5 us (8 round trips)
+        Frag af[U][2], bf[U][2];
+#pragma unroll
+        for (int q = 0; q < U; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                sg_frag(af[q][i], arow[i] + (long long)(k0 + q * KW) * p.sak, p.sak, p.veca);
+                sg_frag(bf[q][i], bcol[i] + (long long)(k0 + q * KW) * p.sbk, p.sbk, p.vecb);
+                if (!aok[i]) sg_zero(af[q][i]);
+                if (!bok[i]) sg_zero(bf[q][i]);
+            }
+#pragma unroll
+        for (int q = 0; q < U; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma_chunk<F32IN>(af[q][i], bf[q][j], acc[i][j]);
+    }
+    for (; k0 < kfull; k0 += KW) {                 // remaining full chunks: no bounds on k
         Frag af[2], bf[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = tm * 32 + i * 16 + r, col = tn * 32 + i * 16 + r;
+            sg_frag(af[i], arow[i] + (long long)k0 * p.sak, p.sak, p.veca);
+            sg_frag(bf[i], bcol[i] + (long long)k0 * p.sbk, p.sbk, p.vecb);
+            if (!aok[i]) sg_zero(af[i]);
+            if (!bok[i]) sg_zero(bf[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mma_chunk<F32IN>(af[i], bf[j], acc[i][j]);
+    }
+    if (kfull < p.K) {                              // the ragged tail: element loads, zero beyond K
+        Frag af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
-                const int k = k0 + EPL * g + e;
-                sg_set(af[i], e, A, (long long)row * p.sam + (long long)k * p.sak, row < p.M && k < p.K);
-                sg_set(bf[i], e, B, (long long)k * p.sbk + (long long)col * p.sbn, col < p.N && k < p.K);
+                const bool kin = kfull + EPL * g + e < p.K;
+                sg_set(af[i], e, arow[i], (long long)(kfull + (kin ? e : -EPL * g)) * p.sak, aok[i] && kin);
+                sg_set(bf[i], e, bcol[i], (long long)(kfull + (kin ? e : -EPL * g)) * p.sbk, bok[i] && kin);
             }
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -340,7 +421,19 @@ int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, c
     if ((u == nullptr) != (v == nullptr)) return set_error(VLG_ERR_ARG, "small_gemm: the rank-one term needs both u and v");
     if (batch == 0) return 0;
     if (!a || !b || !c) return set_error(VLG_ERR_ARG, "small_gemm: null buffer");
-    const SgArgs p{a, b, bias, u, v, c, sab, sam, sak, sbb, sbk, sbn, scb, ldc, sbias, su, sv, M, N, K, accumulate, alpha};
+    // widest load per fragment of each operand (see sg_frag): its contraction index must be the unit-stride one
+    const int epl = in_dtype == VLG_F32 ? 4 : 8;
+    const long long esz = in_dtype == VLG_F32 ? 4 : 2;
+    auto width = [&](const void* ptr, long long s_contract, long long s_other, long long s_batch) -> int {
+        if (s_contract != 1) return 1;
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(ptr);
+        if (s_other % epl == 0 && s_batch % epl == 0 && addr % 16 == 0) return epl;
+        if (in_dtype == VLG_BF16 && s_other % 2 == 0 && s_batch % 2 == 0 && addr % 4 == 0) return 2;
+        return 1;
+    };
+    (void)esz;
+    const SgArgs p{a, b, bias, u, v, c, sab, sam, sak, sbb, sbk, sbn, scb, ldc, sbias, su, sv, M, N, K, accumulate,
+                   width(a, sak, sam, sab), width(b, sbk, sbn, sbb), alpha};
     const dim3 grid(((M + 31) / 32) * ((N + 31) / 32), batch);
     hipStream_t s = (hipStream_t)stream;
     if (in_dtype == VLG_F32 && out_dtype == VLG_F32) hipLaunchKernelGGL((small_gemm_kernel<true, float>), grid, dim3(64), 0, s, p);
