@@ -70,7 +70,7 @@ def test_register_budgets_match_the_launch_shapes(kernels):
 def test_round4_second_half_kernels_are_on_the_hot_list(kernels):
     """The kernels added after the list above was written: both DPs of lang_feat_max_tree as one launch, the element-wise passes of the
     parser's feed-forwards.  No scratch, no VGPR spills; the pair kernel within the 128 registers that let a sentence's two workgroups share a CU."""
-    names = ("dmv1o_pair_kernel<", "ff_mlp_act_kernel<", "ff_act_kernel<", "ff_act_bwd_kernel<", "ff_mlp_act_bwd_kernel<")
+    names = ("dmv1o_pair_kernel<", "ff_mlp_act_kernel<", "ff_act_kernel<", "ff_act_bwd_kernel<", "ff_mlp_act_bwd_kernel<", "small_gemm_kernel<")
     found = {}
     for k in kernels:
         dem = k.get("demangled", k.get("name", ""))
