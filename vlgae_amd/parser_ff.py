@@ -87,11 +87,28 @@ def _mask32(m):
     return m.clone() if m.data_ptr() % 16 else m       # (the kernels read the [B,H] masks 16 bytes at a time)
 
 
-def _wgrad(dy, x):
-    """(dy^T x [out,in] fp32, sum_rows dy [out] fp32): the split-K kernel for bf16 token-row counts, the library otherwise."""
+def _wgrad(dy, x, out=None):
+    """(dy^T x [out,in], sum_rows dy [out]): the split-K kernel for bf16 token-row counts, the library otherwise.  float32 results, or
+    written into `out` = (d_weight, d_bias) in their own dtype (contiguous views of a caller's stack: no cat, no cast afterwards)."""
     if dy.dtype == x.dtype and _wgrad_ok(x.shape[0], dy.shape[1], x.shape[1], dy.dtype):
-        return linear_wgrad(dy, x)
-    return dy.float().t() @ x.float(), dy.float().sum(0)
+        return linear_wgrad(dy, x, out=out)
+    dw, db = dy.float().t() @ x.float(), dy.float().sum(0)
+    if out is None:
+        return dw, db
+    out[0].copy_(dw)
+    out[1].copy_(db)
+    return out
+
+
+_ONES = {}
+
+
+def _ones(n, dtype, device):
+    """A cached [n,1] tensor of ones (the column that turns small_matmul's rank-one term into a per-row bias)."""
+    key = (n, dtype, device)
+    if key not in _ONES:
+        _ONES[key] = torch.ones((n, 1), dtype=dtype, device=device)
+    return _ONES[key]
 
 
 class _ParserFF(torch.autograd.Function):
@@ -144,8 +161,8 @@ class _ParserFF(torch.autograd.Function):
         if nb:
             W0s, b0s, W1s, b1s = stacks[:4]                                                 # [4,nb,H], [4,nb], [4,H,nb], [4,H]
             Weff = small_matmul(W1s, W0s)                                                   # [4,H,H] (one wavefront per 32 x 32 tile: the library runs this on 4 workgroups)
-            # (as a multiply + sum: the library's batched bf16 matrix-VECTOR product costs ~10 ms of HOST time per call on this stack)
-            beff = (W1s * b0s.unsqueeze(1)).sum(2) + b1s                                    # [4,H] = W1 b0 + b1
+            # (the library's batched bf16 matrix-VECTOR product costs ~10 ms of HOST time per call on this stack; here: one column, b1 as the rank-one term)
+            beff = small_matmul(W1s, b0s.unsqueeze(-1), rank1=(b1s, _ones(4, act, dev))).squeeze(-1)   # [4,H] = W1 b0 + b1
         else:
             W0s = b0s = W1s = b1s = None
             Weff, beff = stacks[:2]
@@ -223,7 +240,7 @@ class _ParserFF(torch.autograd.Function):
         small_matmul(g_small.t(), A5[4 * M0:], out=dWp[2 * r:])                         # [4r,H]: 4 (T + 3) rows
         torch.sum(g_small, 0, out=dbp[2 * r:])
         dPW = small_matmul(dWp, W2_.t(), rank1=(dbp, b2_))                               # Wp = PW W2, bp = PW b2 + Pb: dPW = dWp W2^T + dbp b2^T
-        G["linear2.w"], G["linear2.b"] = small_matmul(PW.t(), dWp), (PW * dbp.unsqueeze(1)).sum(0)     # (PW^T dbp as multiply + sum: the bf16 transposed mat-vec is ~10 ms of host time)
+        G["linear2.w"], G["linear2.b"] = small_matmul(PW.t(), dWp), small_matmul(PW.t(), dbp.unsqueeze(-1)).squeeze(-1)   # P^T dWp, P^T dbp
         # ---- linear1, direction ----
         g = _act_bwd(gA5, A5, gA5, 4 * M, 1, H)
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4)
@@ -234,7 +251,9 @@ class _ParserFF(torch.autograd.Function):
         gX = torch.empty((M, H), dtype=torch.float32, device=g.device)                   # the skip connections' cotangent
         gZ = torch.empty((2 * M, 2 * H), dtype=act, device=g.device)                     # [m,val,dir,c]
         _act_bwd(g, A3, gZ, M, 4, H, total=gX, swap=True)
-        dW_lr, db_lr = _wgrad(gZ, A2)
+        # the gradients of the folded weights straight into their stack, in the activations' dtype (what the unfold products read)
+        dWeff, dbeff = torch.empty((4, H, H), dtype=act, device=g.device), torch.empty((4, H), dtype=act, device=g.device)   # no, has, left, right
+        _wgrad(gZ, A2, out=(dWeff[2:4].view(2 * H, H), dbeff[2:4].view(2 * H)))
         # ---- valence ----
         g = gZ @ W_lr
         _act_bwd(g, A2, g, 2 * M, 1, H)
@@ -242,9 +261,7 @@ class _ParserFF(torch.autograd.Function):
         gY = g @ Wv                                                                      # [M,2,H]
         _act_bwd(gY, A1, gY, M, 2, H, total=gX, accumulate=True)
         gY = gY.view(M, 2 * H)
-        dW_nh, db_nh = _wgrad(gY, X)
-        dWeff = torch.cat([dW_nh.view(2, H, H), dW_lr.view(2, H, H)])                    # [4,H,H] fp32: no, has, left, right
-        dbeff = torch.cat([db_nh.view(2, H), db_lr.view(2, H)])
+        _wgrad(gY, X, out=(dWeff[0:2].view(2 * H, H), dbeff[0:2].view(2 * H)))
         # ---- MLPs: gpre = LeakyReLU'(X) * SharedDropout mask * (gX + gY W_nh) ----
         gpre = torch.empty((M, H), dtype=act, device=g.device)
         gT = gY @ W_nh
@@ -267,10 +284,9 @@ class _ParserFF(torch.autograd.Function):
             o += n
         # ---- unfold the bottleneck pairs: Weff = W1 W0, beff = W1 b0 + b1 ----
         if nb:   # (in the activations' dtype: the library's batched fp32 kernels take ~50 us each for these 40-MFLOP products)
-            dWe_a, dbe_a = dWeff.to(act), dbeff.to(act)
-            dW1s = small_matmul(dWe_a, W0s.transpose(1, 2), rank1=(dbe_a, b0s))          # [4,H,nb] = dWeff W0^T + dbeff b0^T
-            dW0s = small_matmul(W1s.transpose(1, 2), dWe_a)                              # [4,nb,H] = W1^T dWeff
-            db0s = (W1s * dbe_a.unsqueeze(2)).sum(1)                                     # [4,nb] = W1^T dbeff (not a batched mat-vec: see forward)
+            dW1s = small_matmul(dWeff, W0s.transpose(1, 2), rank1=(dbeff, b0s))          # [4,H,nb] = dWeff W0^T + dbeff b0^T
+            dW0s = small_matmul(W1s.transpose(1, 2), dWeff)                              # [4,nb,H] = W1^T dWeff
+            db0s = small_matmul(W1s.transpose(1, 2), dbeff.unsqueeze(-1)).squeeze(-1)    # [4,nb] = W1^T dbeff
         # ---- gradients in the order of param_names ----
         out = [G["head.w"], G["head.b"], G["child.w"], G["child.b"], G["root.w"], G["root.b"], G["dec.w"], G["dec.b"]]
         for k in range(4):
