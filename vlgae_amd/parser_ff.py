@@ -87,14 +87,15 @@ def _mask32(m):
     return m.clone() if m.data_ptr() % 16 else m       # (the kernels read the [B,H] masks 16 bytes at a time)
 
 
-def _wgrad(dy, x, out=None):
-    """(dy^T x [out,in], sum_rows dy [out]): the split-K kernel for bf16 token-row counts, the library otherwise.  float32 results, or
-    written into `out` = (d_weight, d_bias) in their own dtype (contiguous views of a caller's stack: no cat, no cast afterwards)."""
+def _wgrad(dy, x, out=None, dtype=torch.float32):
+    """(dy^T x [out,in], sum_rows dy [out]): the split-K kernel for bf16 token-row counts, the library otherwise.  Results in `dtype` (the
+    parameter's own: the reduction writes it, no cast launch follows), or written into `out` = (d_weight, d_bias) in their own dtype
+    (contiguous views of a caller's stack: no cat afterwards either)."""
     if dy.dtype == x.dtype and _wgrad_ok(x.shape[0], dy.shape[1], x.shape[1], dy.dtype):
-        return linear_wgrad(dy, x, out=out)
+        return linear_wgrad(dy, x, out=out, out_dtype=dtype)
     dw, db = dy.float().t() @ x.float(), dy.float().sum(0)
     if out is None:
-        return dw, db
+        return dw.to(dtype), db.to(dtype)
     out[0].copy_(dw)
     out[1].copy_(db)
     return out
@@ -187,7 +188,7 @@ class _ParserFF(torch.autograd.Function):
         _act(A5, A5, 4 * M, 1, H)
         W2_, b2_ = c(P["ff.mid_ff.linear2.weight"]), c(P["ff.mid_ff.linear2.bias"])
         Wp = small_matmul(PW, W2_)                                                      # [6r,H]: P W2
-        bp = torch.addmv(Pb, PW, b2_)                                                   # P b2 + p
+        bp = small_matmul(PW, b2_.unsqueeze(-1), rank1=(Pb, _ones(1, act, dev)[0])).squeeze(-1)   # P b2 + p
         big = torch.addmm(bp[:2 * r], A5[:4 * M0], Wp[:2 * r].t())                      # [4 M0, 2r]: attach.project1 | dec.project1
         small = small_matmul(A5[4 * M0:], Wp[2 * r:].t(), bias=bp[2 * r:])                # [4 Ms, 4r]: attach.p2 | root.p2 | root.p1 | dec.p2
         # the scorers' inputs as VIEWS of the two products (vlgae_amd.scorer takes rows a constant stride apart in place); they are outputs
@@ -225,8 +226,10 @@ class _ParserFF(torch.autograd.Function):
         dlogit = torch._log_softmax_backward_data(g_root.float(), root_rule, 0, torch.float32).unsqueeze(0)   # [1,T]
         g_small = torch.zeros((4 * Ms, 4 * r), dtype=act, device=g_big.device)
         g_small[:4 * T, :r] = g_x2.reshape(4 * T, r)
-        g_small[:4 * T, r:2 * r] = small_matmul(dlogit.t(), r1f).reshape(4 * T, r)       # d r2[c] = dlogit[c] r1
-        g_small[4 * T:4 * T + 4, 2 * r:3 * r] = small_matmul(dlogit, r2f).reshape(4, r)  # d r1 = sum_c dlogit[c] r2[c]
+        # d r2[c,dv,:] = dlogit[c] r1[dv,:] and d r1[dv,:] = sum_c dlogit[c] r2[c,dv,:], batched over the four (dir, val) and written (cast) in place:
+        # the [4,T,r] / [4,1,r] views of the two blocks of g_small have unit last stride
+        small_matmul(dlogit.t(), r1f.view(4, 1, r), out=g_small[:4 * T, r:2 * r].view(T, 4, r).transpose(0, 1))
+        small_matmul(dlogit, r2f.view(T, 4, r).transpose(0, 1), out=g_small[4 * T:4 * T + 4, 2 * r:3 * r].unsqueeze(1))
         g_small[4 * T + 4:, 3 * r:] = g_y2.reshape(8, r)
         # ---- folded projections ----
         gA5 = torch.empty_like(A5)
@@ -234,19 +237,17 @@ class _ParserFF(torch.autograd.Function):
         small_matmul(g_small, Wp[2 * r:], out=gA5[4 * M0:])
         # (everything below in the activations' dtype: as fp32 GEMMs on one workgroup each the library takes 30-50 us for these products)
         dWp, dbp = torch.empty((6 * r, H), dtype=act, device=g_big.device), torch.empty((6 * r,), dtype=act, device=g_big.device)
-        dWp_b, dbp_b = _wgrad(g_big, A5[:4 * M0])                                       # [2r,H], [2r] fp32 (split-K)
-        dWp[:2 * r].copy_(dWp_b)
-        dbp[:2 * r].copy_(dbp_b)
+        _wgrad(g_big, A5[:4 * M0], out=(dWp[:2 * r], dbp[:2 * r]))                      # [2r,H], [2r]: split-K, written in place
         small_matmul(g_small.t(), A5[4 * M0:], out=dWp[2 * r:])                         # [4r,H]: 4 (T + 3) rows
         torch.sum(g_small, 0, out=dbp[2 * r:])
         dPW = small_matmul(dWp, W2_.t(), rank1=(dbp, b2_))                               # Wp = PW W2, bp = PW b2 + Pb: dPW = dWp W2^T + dbp b2^T
         G["linear2.w"], G["linear2.b"] = small_matmul(PW.t(), dWp), small_matmul(PW.t(), dbp.unsqueeze(-1)).squeeze(-1)   # P^T dWp, P^T dbp
         # ---- linear1, direction ----
         g = _act_bwd(gA5, A5, gA5, 4 * M, 1, H)
-        G["linear1.w"], G["linear1.b"] = _wgrad(g, A4)
+        G["linear1.w"], G["linear1.b"] = _wgrad(g, A4, dtype=act)
         g = g @ W1_
         _act_bwd(g, A4, g, 4 * M, 1, H, mask=ctx.drops[2])
-        G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H))
+        G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H), dtype=act)
         g = g @ Wd                                                                       # [m,dir,val,c]
         gX = torch.empty((M, H), dtype=torch.float32, device=g.device)                   # the skip connections' cotangent
         gZ = torch.empty((2 * M, 2 * H), dtype=act, device=g.device)                     # [m,val,dir,c]
@@ -257,7 +258,7 @@ class _ParserFF(torch.autograd.Function):
         # ---- valence ----
         g = gZ @ W_lr
         _act_bwd(g, A2, g, 2 * M, 1, H)
-        G["valence.w"], G["valence.b"] = _wgrad(g, A1.view(2 * M, H))
+        G["valence.w"], G["valence.b"] = _wgrad(g, A1.view(2 * M, H), dtype=act)
         gY = g @ Wv                                                                      # [M,2,H]
         _act_bwd(gY, A1, gY, M, 2, H, total=gX, accumulate=True)
         gY = gY.view(M, 2 * H)
@@ -268,12 +269,12 @@ class _ParserFF(torch.autograd.Function):
         _C.check(_C.lib().vlg_ff_mlp_act_backward(_C.ptr(gX), _C.ptr(gT), _C.ptr(X), _C.ptr(ctx.drops[0]), _C.ptr(ctx.drops[1]),
                                                   _C.ptr(gpre), B, L, Ms, H, _adt(gpre), SLOPE, _C.stream_of(gpre)), "ff_mlp_act_backward")
         gb = gpre[:M0]
-        dWe, dbh = _wgrad(gb, emb2)                                                      # [H,E], [H]
+        dWe, dbh = _wgrad(gb, emb2, dtype=act)                                           # [H,E], [H]
         g_emb = gb @ We                                                                  # [M0,E]
         gc = gb.view(B, L, H).sum(1)                                                     # [B,H] (fp32 accumulation inside the reduction)
         dWc = small_matmul(gc.t(), cmean)                                                # [H,h]
         g_cmean = small_matmul(gc, Wc, alpha=1.0 / L)                                    # [B,h]: d mean_l
-        G["head.w"], G["head.b"] = torch.cat([dWe.to(act), dWc], 1), dbh
+        G["head.w"], G["head.b"] = torch.cat([dWe, dWc], 1), dbh
         o = M0
         g_small_in = []
         for name, inp, W in (("child", tok, Wchild), ("root", rootE, Wroot), ("dec", decE, Wdec)):
