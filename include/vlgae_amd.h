@@ -329,22 +329,25 @@ int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, c
 /* Element-wise passes between the library GEMMs of the parser's feed-forwards (vlgae_amd/parser_ff.py): `MLP`
  * (src/model/nn/common.py:23-51: Linear -> LeakyReLU -> SharedDropout) and `DMVSkipConnectEncoder` (src/model/nn/dmv_spec.py:38-54).
  * Activations in act_dtype (VLG_BF16 / VLG_F32), rows of H channels (H a multiple of 8), 16-byte aligned; fp32 arithmetic.
+ *   vlg_ff_context_mean       out [B,h] (out_dtype) = mean over ALL L positions of x [B,L,h] (in_dtype) read as out_dtype values: `extract_sent_repr`
+ *                             of context_mode 'mean' (src/model/ldndmv.py:226), cast + reduction in one launch.
  *   vlg_ff_mlp_act            x [B L + Ms, H] in place.  Rows < B L: LeakyReLU(x + cterm[row / L]) * drop_head[row / L] (cterm [B,H]
  *                             act_dtype: the sentence's context columns + bias; drop_head [B,H] fp32 or NULL); the Ms rows behind
  *                             them (2-D inputs of their MLPs): LeakyReLU(x) * drop_small[row - B L] (fp32 [Ms] or NULL).
- *   vlg_ff_act                out[m,j'] = LeakyReLU(in[m,j] + residual[m]) * mask[m,j'], in [M,J,H], residual [M,H] or NULL, mask
- *                             (act_dtype, indexed like out) or NULL.  swap = 0: j' = j, out may be in.  swap = 1 (J = 4): in is
+ *   vlg_ff_act                out[m,j'] = LeakyReLU(in[m,j] + residual[m]) * mask[m,j'] * mask_scale, in [M,J,H], residual [M,H] or NULL, mask
+ *                             (act_dtype, indexed like out; e.g. an nn.Dropout keep-mask of 0 / 1 with mask_scale = 1 / (1 - p)) or NULL.  swap = 0: j' = j, out may be in.  swap = 1 (J = 4): in is
  *                             [m,val,dir], out [m,dir,val] -- the stack of nn/dmv_spec.py:47 as a store permutation.
- *   vlg_ff_act_backward       out[m,j'] = LeakyReLU'(act[m,j]) * g[m,j] * mask[m,j] (g, act, mask [M,J,H] in the same order; the
+ *   vlg_ff_act_backward       out[m,j'] = LeakyReLU'(act[m,j]) * g[m,j] * mask[m,j] * mask_scale (g, act, mask [M,J,H] in the same order; the
  *                             derivative from the sign of the stored activation); sum [M,H] fp32 (or NULL) = / += (accumulate)
  *                             sum_j of the stored out values.  swap as above (g, act in [m,dir,val]; out in [m,val,dir]).
  *   vlg_ff_mlp_act_backward   gpre = LeakyReLU'(x) * mask * (gx + t): gx fp32, t act_dtype or NULL, masks as in vlg_ff_mlp_act. */
+int vlg_ff_context_mean(const void* x, int in_dtype, int B, int L, int h, void* out, int out_dtype, void* stream);
 int vlg_ff_mlp_act(void* x, const void* cterm, const float* drop_head, const float* drop_small, int B, int L, int Ms, int H, int act_dtype,
                    float slope, void* stream);
-int vlg_ff_act(const void* in, const void* residual, const void* mask, void* out, long long M, int J, int H, int swap, int act_dtype, float slope,
-               void* stream);
-int vlg_ff_act_backward(const void* g, const void* act, const void* mask, void* out, float* sum, long long M, int J, int H, int swap, int accumulate,
-                        int act_dtype, float slope, void* stream);
+int vlg_ff_act(const void* in, const void* residual, const void* mask, float mask_scale, void* out, long long M, int J, int H, int swap, int act_dtype,
+               float slope, void* stream);
+int vlg_ff_act_backward(const void* g, const void* act, const void* mask, float mask_scale, void* out, float* sum, long long M, int J, int H, int swap,
+                        int accumulate, int act_dtype, float slope, void* stream);
 int vlg_ff_mlp_act_backward(const float* gx, const void* t, const void* x, const float* drop_head, const float* drop_small, void* gpre, int B, int L,
                             int Ms, int H, int act_dtype, float slope, void* stream);
 

@@ -1466,8 +1466,13 @@ def test_ff_elementwise_kernels(dtype):
             w = w.view(M, 2, 2, H).permute(0, 2, 1, 3).reshape(M, J, H)
         if with_mask:
             w = w * mask.double()
+        if with_mask and J == 3:        # a 0 / 1 keep-mask with the scale as an argument (nn.Dropout without the division pass)
+            keep = (mask != 0).to(dtype)
+            out2 = inp.clone()
+            _C.check(lib.vlg_ff_act(_C.ptr(out2), _C.ptr(res), _C.ptr(keep), 1.0 / 0.7, _C.ptr(out2), M, J, H, 0, adt, slope, st), "ff_act")
+            close("act, keep-mask x scale", out2, lrelu(inp.double() + res.double().unsqueeze(1)) * keep.double() * float(np.float32(1.0 / 0.7)))
         out = torch.empty_like(inp) if swap else inp.clone()
-        _C.check(lib.vlg_ff_act(_C.ptr(inp if swap else out), _C.ptr(res), _C.ptr(mask), _C.ptr(out), M, J, H, int(swap), adt, slope, st), "ff_act")
+        _C.check(lib.vlg_ff_act(_C.ptr(inp if swap else out), _C.ptr(res), _C.ptr(mask), 1.0, _C.ptr(out), M, J, H, int(swap), adt, slope, st), "ff_act")
         close(f"act J={J} swap={swap}", out, w)
     # adjoint: LeakyReLU' from the stored activation, mask, group sum (= / +=), permutation
     for J, swap, with_mask, acc in ((1, False, True, False), (4, True, False, False), (2, False, False, True), (4, True, True, True)):
@@ -1479,14 +1484,14 @@ def test_ff_elementwise_kernels(dtype):
         total0 = torch.randn(M, H, generator=gen).to(dev())
         total = total0.clone()
         out = torch.empty_like(g)
-        _C.check(lib.vlg_ff_act_backward(_C.ptr(g), _C.ptr(act), _C.ptr(mask), _C.ptr(out), _C.ptr(total), M, J, H, int(swap), int(acc), adt,
+        _C.check(lib.vlg_ff_act_backward(_C.ptr(g), _C.ptr(act), _C.ptr(mask), 1.0, _C.ptr(out), _C.ptr(total), M, J, H, int(swap), int(acc), adt,
                                          slope, st), "ff_act_backward")
         close(f"act_bwd J={J} swap={swap}", out, t.view(M, 2, 2, H).permute(0, 2, 1, 3).reshape(M, J, H) if swap else t)
         want_total = out.double().sum(1) + (total0.double() if acc else 0.0)      # the sum is of the STORED values (what the next GEMM reads)
         assert float((total.double() - want_total).abs().max()) <= 1e-5 * max(1.0, float(want_total.abs().max()))
         if not swap:                              # in place, without the sum
             g2 = g.clone()
-            _C.check(lib.vlg_ff_act_backward(_C.ptr(g2), _C.ptr(act), _C.ptr(mask), _C.ptr(g2), None, M, J, H, 0, 0, adt, slope, st), "ff_act_backward")
+            _C.check(lib.vlg_ff_act_backward(_C.ptr(g2), _C.ptr(act), _C.ptr(mask), 1.0, _C.ptr(g2), None, M, J, H, 0, 0, adt, slope, st), "ff_act_backward")
             assert torch.equal(g2, out)
     # MLP adjoint
     gX, T_, Xs = torch.randn(M, H, generator=gen).to(dev()), rnd(M, H), rnd(M, H)
@@ -1498,11 +1503,16 @@ def test_ff_elementwise_kernels(dtype):
     _C.check(lib.vlg_ff_mlp_act_backward(_C.ptr(gX), _C.ptr(T_), _C.ptr(Xs), _C.ptr(dh), _C.ptr(ds), _C.ptr(gpre), B, L, Ms, H, adt, slope, st),
              "ff_mlp_act_backward")
     close("mlp_act_bwd", gpre, w)
+    # the sentence's context vector (ldndmv.py:226): mean over the positions of float32 encodings, in the activations' dtype
+    xs = torch.randn(B, L, 72, generator=gen).to(dev())
+    cm = torch.empty((B, 72), dtype=dtype, device=dev())
+    _C.check(lib.vlg_ff_context_mean(_C.ptr(xs), _C.F32, B, L, 72, _C.ptr(cm), adt, st), "ff_context_mean")
+    assert float((cm.double() - xs.to(dtype).double().mean(1)).abs().max()) <= (1e-6 if dtype == torch.float32 else 2.0 ** -8)   # (a mean near zero: absolute)
     # argument checks (host side)
-    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, _C.ptr(Xs), M, 1, 12, 0, adt, slope, st) == 0x1001          # H not a multiple of 8
-    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, _C.ptr(Xs), M, 2, H, 1, adt, slope, st) == 0x1001           # the permutation is of J = 4
-    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, _C.ptr(Xs), M // 4, 4, H, 1, adt, slope, st) == 0x1003      # ... and not in place
-    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, _C.ptr(Xs), M, 1, H, 0, 7, slope, st) == 0x1002
+    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, _C.ptr(Xs), M, 1, 12, 0, adt, slope, st) == 0x1001          # H not a multiple of 8
+    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, _C.ptr(Xs), M, 2, H, 1, adt, slope, st) == 0x1001           # the permutation is of J = 4
+    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, _C.ptr(Xs), M // 4, 4, H, 1, adt, slope, st) == 0x1003      # ... and not in place
+    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, _C.ptr(Xs), M, 1, H, 0, 7, slope, st) == 0x1002
 
 
 def test_linear_wgrad_partial_tiles():

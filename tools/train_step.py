@@ -217,10 +217,10 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         if isinstance(fixed_drop, str) and p_drop == p_ff_drop and 0 < p_drop < 1:
             n0, n1 = B * 4 * d, B * H_
             buf = torch.empty(n0 + n1 + T_ + 3, dtype=torch.float32, device=dev).bernoulli_(1 - p_drop).div_(1 - p_drop)
-            mid = parser_ff.dropout_masks(B, L, T_, H_, 0.0, p_mid_drop, device=dev, dtype=ff_dtype)[2]
-            return buf[:n0].view(B, 4, d), (buf[n0:n0 + n1].view(B, H_), buf[n0 + n1:], mid)
+            _, _, mid, mid_scale = parser_ff.dropout_masks(B, L, T_, H_, 0.0, p_mid_drop, device=dev, dtype=ff_dtype, scaled_mid=False)
+            return buf[:n0].view(B, 4, d), (buf[n0:n0 + n1].view(B, H_), buf[n0 + n1:], mid, mid_scale)
         drop = langfeat.shared_dropout_masks(B, d, p_drop, n=4, device=dev) if isinstance(fixed_drop, str) else fixed_drop
-        return drop, parser_ff.dropout_masks(B, L, T_, H_, p_ff_drop, p_mid_drop, device=dev, dtype=ff_dtype)
+        return drop, parser_ff.dropout_masks(B, L, T_, H_, p_ff_drop, p_mid_drop, device=dev, dtype=ff_dtype, scaled_mid=False)
 
     def step(stage_hook=None):
         """forward + backward; returns (reduced loss, gradients by leaf name, ()).  stage_hook (optional) is called from inside the
@@ -237,7 +237,7 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         if fused_ff:   # the same mathematics with folded / fused GEMMs and a hand-written adjoint
             x1, x2, y1, y2, root_rule = parser_ff.parser_feed_forward(P, P["emb"], x_f, None, None, None, *ff_masks)
         else:          # module by module, as the reference runs it
-            x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, *ff_masks)
+            x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, *ff_masks[:2], None if ff_masks[2] is None else ff_masks[2] * ff_masks[3])
         md, ma = scorer.ndmv_potentials(x1, x2, y1, y2, root_rule, token)
         # ---- DependencyBoxRel._vis_forward, joint.py:677-691: the UN-fused x; the potentials are constants of this stage (:252-253) ----
         txt, tmask, tmarg = langfeat.lang_feat_max_tree(P["enc_x"], lengths, md.detach(), ma.detach(), P["w_enc"], P["b_enc"], P["w1"],

@@ -66,9 +66,10 @@ SIGNATURES = {
     "vlg_langfeat_arc_out": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "vlg_langfeat_rowscale": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "vlg_small_gemm": (_i, [_vp, _ll, _ll, _ll, _vp, _ll, _ll, _ll, _vp, _ll, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
+    "vlg_ff_context_mean": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_ff_mlp_act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "vlg_ff_act": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _vp]),
-    "vlg_ff_act_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp]),
+    "vlg_ff_act": (_i, [_vp, _vp, _vp, _f, _vp, _ll, _i, _i, _i, _i, _f, _vp]),
+    "vlg_ff_act_backward": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp]),
     "vlg_ff_mlp_act_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "vlg_ndmv_potentials": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "vlg_ndmv_potentials_backward_workspace": (_sz, [_i, _i, _i, _i]),

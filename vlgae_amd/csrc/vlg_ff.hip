@@ -10,6 +10,7 @@
 //   ff_act_bwd_kernel                             out[m,j'] = LeakyReLU'(act[m,j]) * (g[m,j] * mask[m,j]); sum[m] (+)= sum_j of it
 //                                                 (the skip connection's cotangent), same optional permutation
 //   ff_mlp_act_bwd_kernel                         gpre = LeakyReLU'(X) * mask * (gX + T)
+//   ff_colmean_kernel       ldndmv.py:226         the sentence's context vector: mean over the positions, cast included
 // Storage type A (bf16 / fp32) as in vlg_langfeat.hip; arithmetic in fp32, ONE rounding per stored element (torch rounds after
 // every launch of the chain it replaces).  LeakyReLU' is taken from the sign of the activation's stored OUTPUT (the mask multiply
 // cannot flip it; where the mask is 0 the cotangent is 0 as well).  One thread = eight channels of a row; H a multiple of 8.
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(kFfThreads) void ff_mlp_act_kernel(A* X, const A* _
 }
 
 template <typename A>
-__global__ __launch_bounds__(kFfThreads) void ff_act_kernel(const A* in, const A* __restrict__ res, const A* __restrict__ mask, A* out,
+__global__ __launch_bounds__(kFfThreads) void ff_act_kernel(const A* in, const A* __restrict__ res, const A* __restrict__ mask, float mask_scale, A* out,
                                                             size_t rows, int J, int H, int swap, float slope) {
     const int hv = H >> 3;
     const size_t i = (size_t)blockIdx.x * kFfThreads + threadIdx.x;
@@ -84,13 +85,13 @@ __global__ __launch_bounds__(kFfThreads) void ff_act_kernel(const A* in, const A
         float t[8];
         load8(mask + orow * H + c, t);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] *= t[k];
+        for (int k = 0; k < 8; ++k) v[k] *= t[k] * mask_scale;
     }
     store8(out + orow * H + c, v);
 }
 
 template <typename A>
-__global__ __launch_bounds__(kFfThreads) void ff_act_bwd_kernel(const A* g, const A* __restrict__ act, const A* __restrict__ mask, A* out,
+__global__ __launch_bounds__(kFfThreads) void ff_act_bwd_kernel(const A* g, const A* __restrict__ act, const A* __restrict__ mask, float mask_scale, A* out,
                                                                 float* sum, size_t M, int J, int H, int swap, int accumulate, float slope) {
     const int hv = H >> 3;
     const size_t i = (size_t)blockIdx.x * kFfThreads + threadIdx.x;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(kFfThreads) void ff_act_bwd_kernel(const A* g, cons
             float t[8];
             load8(mask + row * H + c, t);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) gv[k] *= t[k];
+            for (int k = 0; k < 8; ++k) gv[k] *= t[k] * mask_scale;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -154,6 +155,19 @@ __global__ __launch_bounds__(kFfThreads) void ff_mlp_act_bwd_kernel(const float*
     store8(gpre + o, v);
 }
 
+// context_mode 'mean' (src/model/ldndmv.py:226): out[b,:] = mean_l x[b,l,:] over ALL L positions, any (float32 | bf16) -> any: torch
+// does this as a cast launch + a reduction launch.  One thread per (sentence, channel), rows read coalesced across the threads.
+template <typename T, typename A>
+__global__ __launch_bounds__(256) void ff_colmean_kernel(const T* __restrict__ x, int L, int h, A* __restrict__ out) {
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= h) return;
+    const T* src = x + (size_t)b * L * h + c;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int l = 0; l < L; ++l) acc += stored<A>(ldf(src, (size_t)l * h));   // (the values a cast to the activations' dtype would have produced)
+    stf(out, (size_t)b * h + c, acc / (float)L);
+}
+
 int ff_check(const char* what, long long rows, int H, int act_dtype) {
     if (rows < 0 || H < 8 || H % 8) return set_error(VLG_ERR_SHAPE, "%s: rows=%lld H=%d (H must be a positive multiple of 8)", what, rows, H);
     if (act_dtype != VLG_F32 && act_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "%s: act_dtype %d", what, act_dtype);
@@ -196,8 +210,8 @@ int vlg_ff_mlp_act(void* x, const void* cterm, const float* drop_head, const flo
     return check_launch("ff_mlp_act_kernel");
 }
 
-int vlg_ff_act(const void* in, const void* residual, const void* mask, void* out, long long M, int J, int H, int swap, int act_dtype, float slope,
-               void* stream) {
+int vlg_ff_act(const void* in, const void* residual, const void* mask, float mask_scale, void* out, long long M, int J, int H, int swap, int act_dtype,
+               float slope, void* stream) {
     using namespace vlg;
     if (M < 0 || J < 1 || (swap && J != 4)) return set_error(VLG_ERR_SHAPE, "ff_act: M=%lld J=%d swap=%d (the permutation is of J = 4 = (val, dir))", M, J, swap);
     if (int rc = ff_check("ff_act", M * J, H, act_dtype)) return rc;
@@ -209,15 +223,15 @@ int vlg_ff_act(const void* in, const void* residual, const void* mask, void* out
     hipStream_t s = (hipStream_t)stream;
     if (act_dtype == VLG_BF16)
         hipLaunchKernelGGL(ff_act_kernel<uint16_t>, grid, dim3(kFfThreads), 0, s, (const uint16_t*)in, (const uint16_t*)residual, (const uint16_t*)mask,
-                           (uint16_t*)out, rows, J, H, swap, slope);
+                           mask_scale, (uint16_t*)out, rows, J, H, swap, slope);
     else
-        hipLaunchKernelGGL(ff_act_kernel<float>, grid, dim3(kFfThreads), 0, s, (const float*)in, (const float*)residual, (const float*)mask, (float*)out,
-                           rows, J, H, swap, slope);
+        hipLaunchKernelGGL(ff_act_kernel<float>, grid, dim3(kFfThreads), 0, s, (const float*)in, (const float*)residual, (const float*)mask, mask_scale,
+                           (float*)out, rows, J, H, swap, slope);
     return check_launch("ff_act_kernel");
 }
 
-int vlg_ff_act_backward(const void* g, const void* act, const void* mask, void* out, float* sum, long long M, int J, int H, int swap, int accumulate,
-                        int act_dtype, float slope, void* stream) {
+int vlg_ff_act_backward(const void* g, const void* act, const void* mask, float mask_scale, void* out, float* sum, long long M, int J, int H, int swap,
+                        int accumulate, int act_dtype, float slope, void* stream) {
     using namespace vlg;
     if (M < 0 || J < 1 || (swap && J != 4)) return set_error(VLG_ERR_SHAPE, "ff_act_backward: M=%lld J=%d swap=%d", M, J, swap);
     if (int rc = ff_check("ff_act_backward", M * J, H, act_dtype)) return rc;
@@ -228,10 +242,10 @@ int vlg_ff_act_backward(const void* g, const void* act, const void* mask, void* 
     hipStream_t s = (hipStream_t)stream;
     if (act_dtype == VLG_BF16)
         hipLaunchKernelGGL(ff_act_bwd_kernel<uint16_t>, grid, dim3(kFfThreads), 0, s, (const uint16_t*)g, (const uint16_t*)act, (const uint16_t*)mask,
-                           (uint16_t*)out, sum, (size_t)M, J, H, swap, accumulate, slope);
+                           mask_scale, (uint16_t*)out, sum, (size_t)M, J, H, swap, accumulate, slope);
     else
-        hipLaunchKernelGGL(ff_act_bwd_kernel<float>, grid, dim3(kFfThreads), 0, s, (const float*)g, (const float*)act, (const float*)mask, (float*)out,
-                           sum, (size_t)M, J, H, swap, accumulate, slope);
+        hipLaunchKernelGGL(ff_act_bwd_kernel<float>, grid, dim3(kFfThreads), 0, s, (const float*)g, (const float*)act, (const float*)mask, mask_scale,
+                           (float*)out, sum, (size_t)M, J, H, swap, accumulate, slope);
     return check_launch("ff_act_bwd_kernel");
 }
 
@@ -253,6 +267,22 @@ int vlg_ff_mlp_act_backward(const float* gx, const void* t, const void* x, const
         hipLaunchKernelGGL(ff_mlp_act_bwd_kernel<float>, grid, dim3(kFfThreads), 0, s, gx, (const float*)t, (const float*)x, drop_head, drop_small,
                            (float*)gpre, (int)M0, Ms, L, H, slope);
     return check_launch("ff_mlp_act_bwd_kernel");
+}
+
+int vlg_ff_context_mean(const void* x, int in_dtype, int B, int L, int h, void* out, int out_dtype, void* stream) {
+    using namespace vlg;
+    if (B < 0 || L < 1 || h < 1 || B > 0x7fffffff / 1) return set_error(VLG_ERR_SHAPE, "ff_context_mean: B=%d L=%d h=%d", B, L, h);
+    if ((in_dtype != VLG_F32 && in_dtype != VLG_BF16) || (out_dtype != VLG_F32 && out_dtype != VLG_BF16))
+        return set_error(VLG_ERR_DTYPE, "ff_context_mean: dtypes %d -> %d", in_dtype, out_dtype);
+    if (B == 0) return 0;
+    if (!x || !out) return set_error(VLG_ERR_ARG, "ff_context_mean: null buffer");
+    const dim3 grid(B, (h + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == VLG_F32 && out_dtype == VLG_F32) hipLaunchKernelGGL((ff_colmean_kernel<float, float>), grid, dim3(256), 0, s, (const float*)x, L, h, (float*)out);
+    else if (in_dtype == VLG_F32) hipLaunchKernelGGL((ff_colmean_kernel<float, uint16_t>), grid, dim3(256), 0, s, (const float*)x, L, h, (uint16_t*)out);
+    else if (out_dtype == VLG_F32) hipLaunchKernelGGL((ff_colmean_kernel<uint16_t, float>), grid, dim3(256), 0, s, (const uint16_t*)x, L, h, (float*)out);
+    else hipLaunchKernelGGL((ff_colmean_kernel<uint16_t, uint16_t>), grid, dim3(256), 0, s, (const uint16_t*)x, L, h, (uint16_t*)out);
+    return check_launch("ff_colmean_kernel");
 }
 
 }  // extern "C"

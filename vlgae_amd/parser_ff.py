@@ -66,16 +66,16 @@ def _adt(t):
     return _C.BF16 if t.dtype == torch.bfloat16 else _C.F32
 
 
-def _act(inp, out, M, J, H, residual=None, mask=None, swap=False):
-    """out[m,j'] = LeakyReLU(inp[m,j] + residual[m]) * mask[m,j'] in one pass (vlg_ff_act); out may be inp unless swap."""
-    _C.check(_C.lib().vlg_ff_act(_C.ptr(inp), _C.ptr(residual), _C.ptr(mask), _C.ptr(out), M, J, H, int(swap), _adt(inp), SLOPE,
+def _act(inp, out, M, J, H, residual=None, mask=None, swap=False, mask_scale=1.0):
+    """out[m,j'] = LeakyReLU(inp[m,j] + residual[m]) * mask[m,j'] * mask_scale in one pass (vlg_ff_act); out may be inp unless swap."""
+    _C.check(_C.lib().vlg_ff_act(_C.ptr(inp), _C.ptr(residual), _C.ptr(mask), float(mask_scale), _C.ptr(out), M, J, H, int(swap), _adt(inp), SLOPE,
                                  _C.stream_of(inp)), "ff_act")
     return out
 
 
-def _act_bwd(g, act, out, M, J, H, mask=None, total=None, accumulate=False, swap=False):
-    """out[m,j'] = LeakyReLU'(act[m,j]) * g[m,j] * mask[m,j]; total [M,H] fp32 (+)= sum_j (vlg_ff_act_backward)."""
-    _C.check(_C.lib().vlg_ff_act_backward(_C.ptr(g), _C.ptr(act), _C.ptr(mask), _C.ptr(out), _C.ptr(total), M, J, H, int(swap),
+def _act_bwd(g, act, out, M, J, H, mask=None, total=None, accumulate=False, swap=False, mask_scale=1.0):
+    """out[m,j'] = LeakyReLU'(act[m,j]) * g[m,j] * mask[m,j] * mask_scale; total [M,H] fp32 (+)= sum_j (vlg_ff_act_backward)."""
+    _C.check(_C.lib().vlg_ff_act_backward(_C.ptr(g), _C.ptr(act), _C.ptr(mask), float(mask_scale), _C.ptr(out), _C.ptr(total), M, J, H, int(swap),
                                           int(accumulate), _adt(g), SLOPE, _C.stream_of(g)), "ff_act_backward")
     return out
 
@@ -134,7 +134,13 @@ class _ParserFF(torch.autograd.Function):
         # ---- MLPs: all rows into one [M, H] buffer ----
         X = torch.empty((M, H), dtype=act, device=dev)
         torch.mm(emb2, We.t(), out=X[:M0])
-        cmean = x.detach().mean(1, dtype=act)                                           # context_mode 'mean', ldndmv.py:226
+        xd = x.detach()
+        if xd.dtype in (torch.float32, torch.bfloat16) and xd.is_contiguous():           # context_mode 'mean', ldndmv.py:226: cast + mean in one launch
+            cmean = torch.empty((B, h), dtype=act, device=dev)
+            _C.check(_C.lib().vlg_ff_context_mean(_C.ptr(xd), _adt(xd), B, L, h, _C.ptr(cmean), _C.BF16 if act == torch.bfloat16 else _C.F32,
+                                                  _C.stream_of(xd)), "ff_context_mean")
+        else:
+            cmean = xd.mean(1, dtype=act)
         cterm = small_matmul(cmean, Wc.t(), bias=bh)                                    # [B,H]: the context columns + bias, once per sentence
         small_in = (token_emb, root_emb, dec_emb)
         o = M0
@@ -144,7 +150,7 @@ class _ParserFF(torch.autograd.Function):
             o += n
         # + context term, LeakyReLU, SharedDropout of the MLPs (after the activation, nn/common.py:47-51): [B,1,H] masks shared over a
         # sentence's positions for head_ff, one value per ROW for the 2-D inputs of the other three (nn/dropout.py:52-53)
-        drop_head, drop_small, drop_mid = drops
+        drop_head, drop_small, drop_mid, mid_scale = drops
         lib, st, adt = _C.lib(), _C.stream_of(emb), _C.BF16 if act == torch.bfloat16 else _C.F32
         _C.check(lib.vlg_ff_mlp_act(_C.ptr(X), _C.ptr(cterm), _C.ptr(drop_head), _C.ptr(drop_small), B, L, Ms, H, adt, SLOPE, st), "ff_mlp_act")
         # ---- folded bottlenecks; the projections stacked: the 16 + 12 parameter tensors gathered (and cast) by ONE multi-tensor copy ----
@@ -181,7 +187,7 @@ class _ParserFF(torch.autograd.Function):
         _act(Z, A3, M, 4, H, residual=X, swap=True)
         Wd, bd = c(P["ff.mid_ff.direction_linear.weight"]), c(P["ff.mid_ff.direction_linear.bias"])
         A4 = torch.addmm(bd, A3.view(4 * M, H), Wd.t())
-        _act(A4, A4, 4 * M, 1, H, mask=drop_mid)                                        # nn.Dropout after the direction stage (nn/dmv_spec.py:52)
+        _act(A4, A4, 4 * M, 1, H, mask=drop_mid, mask_scale=mid_scale)                  # nn.Dropout after the direction stage (nn/dmv_spec.py:52)
         # ---- output stage, :52-54 with linear2 folded into the projections ----
         W1_, b1_ = c(P["ff.mid_ff.linear1.weight"]), c(P["ff.mid_ff.linear1.bias"])
         A5 = torch.addmm(b1_, A4, W1_.t())
@@ -246,7 +252,7 @@ class _ParserFF(torch.autograd.Function):
         g = _act_bwd(gA5, A5, gA5, 4 * M, 1, H)
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4, dtype=act)
         g = g @ W1_
-        _act_bwd(g, A4, g, 4 * M, 1, H, mask=ctx.drops[2])
+        _act_bwd(g, A4, g, 4 * M, 1, H, mask=ctx.drops[2], mask_scale=ctx.drops[3])
         G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H), dtype=act)
         g = g @ Wd                                                                       # [m,dir,val,c]
         gX = torch.empty((M, H), dtype=torch.float32, device=g.device)                   # the skip connections' cotangent
@@ -315,7 +321,7 @@ class _ParserFF(torch.autograd.Function):
         return (None, None, *(t if n else None for t, n in zip(ins, need[2:7])), *(t if n else None for t, n in zip(out, need[7:])))
 
 
-def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None, drop_head=None, drop_small=None, drop_mid=None):
+def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None, drop_head=None, drop_small=None, drop_mid=None, mid_scale=1.0):
     """ldndmv.py:174-205 up to the scorers' projected inputs -> (x1 [B,L,2,2,r], x2 [T,2,2,r], y1 [B,L,2,2,r], y2 [2,2,2,r],
     root_rule [T]), the arguments of `scorer.ndmv_potentials`.
 
@@ -326,7 +332,8 @@ def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None, 
     Training-mode dropout as explicit masks (entries 0 or 1/(1-p); `dropout_masks` draws them): drop_head [B,H] -- head_ff's SharedDropout,
     one mask per sentence; drop_small [T+3] -- child_ff / root_ff / dec_ff see 2-D inputs, where SharedDropout's mask is one scalar per
     row (nn/dropout.py:52-53); drop_mid [4 (B L + T + 3), H] -- mid_ff's nn.Dropout after its direction stage (nn/dmv_spec.py:52), rows in
-    the order (input row, direction, valence) with the B L parent rows first.  None = identity (eval)."""
+    the order (input row, direction, valence) with the B L parent rows first; mid_scale multiplies it (a 0 / 1 keep-mask with mid_scale = 1 / (1 - p)
+    is nn.Dropout without the division pass over the 21 MB mask: `dropout_masks(..., scaled_mid=False)`).  None = identity (eval)."""
     _C.require_gpu(emb, "parser_feed_forward")
     token_emb = P["token_emb"] if token_emb is None else token_emb
     root_emb = P["root_emb"] if root_emb is None else root_emb
@@ -344,18 +351,21 @@ def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None, 
             raise ValueError(f"parser_feed_forward: {name} must be {shape}, got {tuple(m.shape)}")
     if H % 8:
         raise ValueError(f"parser_feed_forward: hidden size {H} must be a multiple of 8")
-    drops = (_mask32(drop_head), _mask32(drop_small), None if drop_mid is None else drop_mid.detach().to(emb.dtype).contiguous())
+    drops = (_mask32(drop_head), _mask32(drop_small), None if drop_mid is None else drop_mid.detach().to(emb.dtype).contiguous(), float(mid_scale))
     return _ParserFF.apply(nb, drops, emb, x, token_emb, root_emb, dec_emb, *(P[k] for k in param_names(nb)))
 
 
-def dropout_masks(B, L, T, H, p_ff=0.33, p_mid=0.3, device=None, dtype=torch.float32, generator=None):
+def dropout_masks(B, L, T, H, p_ff=0.33, p_mid=0.3, device=None, dtype=torch.float32, generator=None, scaled_mid=True):
     """One training step's masks for `parser_feed_forward` at the shipped rates (config/model/vlgae.yaml: _dropout 0.33, mid_ff 0.3):
     (drop_head [B,H] float32, drop_small [T+3] float32, drop_mid [4 (B L + T + 3), H] in `dtype`, the activations'); a rate of 0 gives
-    None.  The two small ones come out of ONE draw."""
-    def draw(shape, p, dt):
+    None.  The two small ones come out of ONE draw.  scaled_mid=False: drop_mid is the 0 / 1 keep-mask and a fourth value, 1 / (1 - p_mid),
+    is returned for `mid_scale` (one launch less per step over the largest mask)."""
+    def draw(shape, p, dt, scale=True):
         if p <= 0:
             return None
-        return torch.empty(shape, dtype=dt, device=device).bernoulli_(1 - p, generator=generator).div_(1 - p)
+        m = torch.empty(shape, dtype=dt, device=device).bernoulli_(1 - p, generator=generator)
+        return m.div_(1 - p) if scale else m
     small = draw((B * H + T + 3,), p_ff, torch.float32)
     head, rows = (None, None) if small is None else (small[:B * H].view(B, H), small[B * H:])
-    return head, rows, draw((4 * (B * L + T + 3), H), p_mid, dtype)
+    mid = draw((4 * (B * L + T + 3), H), p_mid, dtype, scaled_mid)
+    return (head, rows, mid) if scaled_mid else (head, rows, mid, 1.0 if mid is None else 1.0 / (1 - p_mid))
