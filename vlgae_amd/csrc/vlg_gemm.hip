@@ -28,18 +28,24 @@ constexpr int kStage = 128;         // contraction rows per LDS stage
 constexpr int kPitch = kTile * 2 + 32;
 
 // C_part[s] (64 x 64 tile) = sum over the rows of split s of A[k, m0..m0+63]^T B[k, n0..n0+63]; optionally the column sums of A.
-// grid = (M/64 * N/64, S); A [K, lda], B [K, ldb] bf16; part [S][M][N] fp32, part_cs [S][M] fp32 (or null).
+// grid = tiles x ceil(S / 8) x 8 workgroups (see the block order below); A [K, lda], B [K, ldb] bf16; part [S][M][N] fp32, part_cs [S][M] fp32 (or null).
 __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
                                                                const uint16_t* __restrict__ B, int ldb, int K, int M,
-                                                               int N, int KC, float* __restrict__ part,
+                                                               int N, int KC, int S, float* __restrict__ part,
                                                                float* __restrict__ part_cs, float* __restrict__ part_csb) {
     __shared__ __attribute__((aligned(16))) char sA[kStage * kPitch];
     __shared__ __attribute__((aligned(16))) char sB[kStage * kPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int MT = (M + kTile - 1) / kTile;   // M, N: multiples of 8 (16-byte row segments); the last tile of either side may be partial
-    const int mt = blockIdx.x % MT, nt = blockIdx.x / MT;
+    // XCD-aware block order: consecutive workgroup ids go round-robin over the eight XCDs (one L2 each), so id % 8 picks the XCD.  All
+    // tiles of one row split s get ids with the same id % 8: the split's rows of A and B are then fetched into ONE L2 and shared by its
+    // MT x NT tiles there, instead of every 64-column block being pulled into 2 (A) or 4 (B) different L2s (grid (tiles, S) order).
+    const int tiles = MT * ((N + kTile - 1) / kTile);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int s = (j / tiles) * 8 + xcd, tile = j % tiles;
+    if (s >= S) return;                        // (the last group of eight splits may be partial; block-uniform)
+    const int mt = tile % MT, nt = tile / MT;
     const int m0 = mt * kTile, n0 = nt * kTile;
-    const int s = blockIdx.y;
     const int k_begin = s * KC, k_end = min(K, k_begin + KC);
     const int wm = wave & 1, wn = wave >> 1;   // this wave's 32 x 32 quadrant
 
@@ -396,8 +402,9 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
     float* part = (float*)ws;
     float* part_cs = d_bias ? part + (size_t)pl.S * M * N : nullptr;
     float* part_csb = x_colsum ? part + (size_t)pl.S * ((size_t)M * N + M) : nullptr;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile), pl.S), dim3(kGemmThreads), 0, s, (const uint16_t*)dy, ld_dy,
-                       (const uint16_t*)x, ld_x, K, M, N, pl.KC, part, part_cs, part_csb);
+    const int tiles = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * ((pl.S + 7) / 8) * 8), dim3(kGemmThreads), 0, s, (const uint16_t*)dy, ld_dy,
+                       (const uint16_t*)x, ld_x, K, M, N, pl.KC, pl.S, part, part_cs, part_csb);
     if (int rc = check_launch("gemm_tn_kernel")) return rc;
     const int n = M * N, n_cs = d_bias ? M : 0, n_csb = x_colsum ? N : 0;
     if (out_dtype == VLG_F32)
