@@ -8,7 +8,7 @@ src/model/ldndmv.py:174-205 (context_mode 'mean'), from the embeddings to the sc
     y1, y2   = dec_scorer.project1(h_parent),    .project2(h_dec)
     root_rule = root_scorer(h_root, h_child).sum([-1,-2]).log_softmax(-1)                                           :205
 
-These are plain Linear / LeakyReLU stacks: the GEMMs stay with the library (rocBLAS / hipBLASLt).  What this module changes is how
+These are plain Linear / LeakyReLU stacks: the GEMMs over the ~10^4 token rows stay with the library (rocBLAS / hipBLASLt).  What this module changes is how
 many of them there are and what surrounds them -- as the reference's modules run them (5-D inputs, one nn.Linear at a time, autograd)
 the stage is ~190 launches and 5 ms of device time at B = 256, L = 40 in bf16, most of it weight-gradient GEMMs on four workgroups,
 bias-gradient reductions and un-fused bias / residual adds.  Here, with identical mathematics:
@@ -23,7 +23,10 @@ bias-gradient reductions and un-fused bias / residual adds.  Here, with identica
   * a hand-written backward in the same granularity with every weight / bias gradient on the split-K kernel (vlg_linear_wgrad);
   * everything BETWEEN two GEMMs -- bias / context / residual add, LeakyReLU, dropout mask, the (val, dir) -> (dir, val) stack, the
     skip connections' cotangent sums, LeakyReLU' -- as one pass per stage (csrc/vlg_ff.hip) instead of 2-4 torch launches over a
-    [4 B L, H] activation each.
+    [4 B L, H] activation each;
+  * the products in WEIGHT space (the fold W1 W0 and its unfolding, the per-sentence context term, the token / root / decision MLPs, the
+    root rule, the small projection block) on `align.small_matmul` (vlg_small_gemm: one wavefront per 32 x 32 output tile, operands read
+    through their strides) -- the library maps an output of a few hundred rows and columns to one workgroup.
 The reference formulation (tools/train_step.scorer_feed_forward, module by module) is what the tests compare this with.
 """
 import torch
