@@ -25,7 +25,12 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 36):
         ez = np.abs(logZ.cpu().numpy() - rz).max() / max(1.0, np.abs(rz).max())
         if sr == 0:
             eg = max(np.abs(gdec.cpu().numpy() - rgd).max(), np.abs(gatt.cpu().numpy() - rga).max())
-        else:
+        else:   # Max semiring: the counts are the 0 / 1 indicators of ONE tree (round 4: from the back-pointer walk, every placement mode).
+            # Chart values are exact in either precision order (max of two-term fp32 sums), so the fp32 oracle picks the same tree.
+            r32m = oracle.dmv1o(mdn, man, lengths, semiring='max', grad=True, dtype=np.float32)
+            assert np.array_equal(gdec.cpu().numpy(), r32m[1]) and np.array_equal(gatt.cpu().numpy(), r32m[2]), (it, B, L, 'max counts')
+            bv, vd, va, vh = F.dmv1o_viterbi(md, ma, ln)
+            assert np.array_equal(vd.cpu().numpy(), r32m[1]) and np.array_equal(va.cpu().numpy(), r32m[2]), (it, B, L, 'viterbi counts')
             eg = 0.0
         worst = max(worst, ez, eg)
         if not (ez < 3e-5 and eg < 1e-4):   # long sentences with peaky scores: is it fp32 rounding?  ask the fp32 oracle
