@@ -586,39 +586,44 @@ def small_matmul(a, b, out=None, alpha=1.0, bias=None, rank1=None, accumulate=Fa
     a [M,K] or [Z,M,K], b [K,N] or [Z,K,N] with ANY strides (transposes / slices are read in place), both bfloat16 (bf16 products) or both
     float32 (exact fp32 products), fp32 accumulation; bias [N] or [Z,N]; rank1 = (u [M] or [Z,M], v [N] or [Z,N]); out: a [.., M, N] tensor
     with unit last stride to write (or, accumulate=True, add) into; out_dtype defaults to the operands' dtype."""
-    _C.require_gpu(a, "small_matmul")
-    if a.dtype != b.dtype or a.dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError(f"small_matmul: both operands bfloat16 or both float32, got {a.dtype} / {b.dtype}")
-    if a.dim() not in (2, 3) or b.dim() not in (2, 3):
-        raise ValueError(f"small_matmul: 2-D or batched 3-D operands, got {tuple(a.shape)} @ {tuple(b.shape)}")
-    Z = a.shape[0] if a.dim() == 3 else (b.shape[0] if b.dim() == 3 else 0)
-    M, K = a.shape[-2:]
-    K2, N = b.shape[-2:]
-    if K != K2 or (a.dim() == 3 and b.dim() == 3 and a.shape[0] != b.shape[0]):
-        raise ValueError(f"small_matmul: {tuple(a.shape)} @ {tuple(b.shape)}")
+    adt, ash, bsh, ast, bst = a.dtype, a.shape, b.shape, a.stride(), b.stride()     # (host time matters: ~28 calls per training step)
+    if adt != b.dtype or (adt != torch.bfloat16 and adt != torch.float32):
+        raise ValueError(f"small_matmul: both operands bfloat16 or both float32, got {adt} / {b.dtype}")
+    if not a.is_cuda:
+        _C.require_gpu(a, "small_matmul")
+    na, nb_ = len(ash), len(bsh)
+    if na not in (2, 3) or nb_ not in (2, 3):
+        raise ValueError(f"small_matmul: 2-D or batched 3-D operands, got {tuple(ash)} @ {tuple(bsh)}")
+    Z = ash[0] if na == 3 else (bsh[0] if nb_ == 3 else 0)
+    M, K = ash[-2], ash[-1]
+    N = bsh[-1]
+    if K != bsh[-2] or (na == 3 and nb_ == 3 and ash[0] != bsh[0]):
+        raise ValueError(f"small_matmul: {tuple(ash)} @ {tuple(bsh)}")
     shape = (Z, M, N) if Z else (M, N)
     if out is None:
         if accumulate:
             raise ValueError("small_matmul: accumulate needs out")
-        out = torch.empty(shape, dtype=out_dtype or a.dtype, device=a.device)
-    elif tuple(out.shape) != shape or out.stride(-1) != 1 or out.dtype not in (torch.float32, torch.bfloat16):
+        out = torch.empty(shape, dtype=out_dtype or adt, device=a.device)
+    elif tuple(out.shape) != shape or out.stride(-1) != 1 or (out.dtype != torch.float32 and out.dtype != torch.bfloat16):
         raise ValueError(f"small_matmul: out must be {shape} float32 / bfloat16 with unit last stride, got {tuple(out.shape)} {out.dtype} {out.stride()}")
+    ost = out.stride()
 
     def vec(t, n, name):
         if t is None:
             return None, 0
-        if t.dtype != a.dtype or t.shape[-1] != n or t.stride(-1) != 1 or t.dim() not in (1, 2) or (t.dim() == 2 and t.shape[0] != max(Z, 1)):
-            raise ValueError(f"small_matmul: {name} must be [{n}] or [{max(Z, 1)},{n}] {a.dtype} with unit last stride, got {tuple(t.shape)} {t.dtype}")
+        if t.dtype != adt or t.shape[-1] != n or t.stride(-1) != 1 or t.dim() not in (1, 2) or (t.dim() == 2 and t.shape[0] != max(Z, 1)):
+            raise ValueError(f"small_matmul: {name} must be [{n}] or [{max(Z, 1)},{n}] {adt} with unit last stride, got {tuple(t.shape)} {t.dtype}")
         return t, (t.stride(0) if t.dim() == 2 else 0)
 
-    bias, sbias = vec(bias, N, "bias")
+    bias, sbias = vec(bias, N, "bias") if bias is not None else (None, 0)
     (u, su), (v, sv) = (vec(rank1[0], M, "u"), vec(rank1[1], N, "v")) if rank1 is not None else ((None, 0), (None, 0))
     bf = torch.bfloat16
-    _C.check(_C.lib().vlg_small_gemm(_C.ptr(a), a.stride(0) if a.dim() == 3 else 0, a.stride(-2), a.stride(-1),
-                                     _C.ptr(b), b.stride(0) if b.dim() == 3 else 0, b.stride(-2), b.stride(-1),
-                                     _C.ptr(out), out.stride(0) if Z else 0, out.stride(-2), _C.ptr(bias), sbias, _C.ptr(u), su, _C.ptr(v), sv,
-                                     max(Z, 1), M, N, K, float(alpha), int(accumulate), _C.BF16 if a.dtype == bf else _C.F32,
-                                     _C.BF16 if out.dtype == bf else _C.F32, _C.stream_of(a)), "small_gemm")
+    rc = _C.lib().vlg_small_gemm(a.data_ptr(), ast[0] if na == 3 else 0, ast[-2], ast[-1], b.data_ptr(), bst[0] if nb_ == 3 else 0, bst[-2], bst[-1],
+                                 out.data_ptr(), ost[0] if Z else 0, ost[-2], _C.ptr(bias), sbias, _C.ptr(u), su, _C.ptr(v), sv,
+                                 Z if Z else 1, M, N, K, float(alpha), 1 if accumulate else 0, _C.BF16 if adt == bf else _C.F32,
+                                 _C.BF16 if out.dtype == bf else _C.F32, _C.stream_of(a))
+    if rc:
+        _C.check(rc, "small_gemm")
     return out
 
 
