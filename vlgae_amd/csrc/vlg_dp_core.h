@@ -1107,7 +1107,10 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
                              //  level-synchronous walk (one lane per open span, an LDS fetch-add for the next level's queue slots, a barrier per
                              //  level) and that walk handing over to one serial walker per wavefront once eight sub-derivations are open.
                              //  Neither finds parallelism: with the width-0 spans pruned a derivation is a chain -- most spans have ONE
-                             //  non-leaf child -- so the frontier stays at 1-3 spans for ~100 levels, each dearer than a serial step.)
+                             //  non-leaf child -- so the frontier stays at 1-3 spans for ~100 levels, each dearer than a serial step.  A third form
+                             //  -- still one lane, but width-0 spans handled where they are produced (half the iterations) and every span's
+                             //  back-pointer read at production and carried through the stack (a pop is one LDS round trip) -- measured 57.8 us
+                             //  against 55.3-56.0: the walk is bound by one wavefront's instruction issue (~100 per span), not by LDS latency.)
         if (tid == 0) dmv_walk(cb, glogZ);
 #endif
         x.sync();
