@@ -1110,7 +1110,9 @@ VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int
                              //  non-leaf child -- so the frontier stays at 1-3 spans for ~100 levels, each dearer than a serial step.  A third form
                              //  -- still one lane, but width-0 spans handled where they are produced (half the iterations) and every span's
                              //  back-pointer read at production and carried through the stack (a pop is one LDS round trip) -- measured 57.8 us
-                             //  against 55.3-56.0: the walk is bound by one wavefront's instruction issue (~100 per span), not by LDS latency.)
+                             //  against 55.3-56.0.  A fourth -- the walk on every lane of the first wavefront with its state pinned to scalar
+                             //  registers (x.uniform on every LDS value: scalar address arithmetic and branches) -- 55.7 us: no change either.
+                             //  ~300 cycles per span whichever way its instructions are issued or its reads are grouped.)
         if (tid == 0) dmv_walk(cb, glogZ);
 #endif
         x.sync();
