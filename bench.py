@@ -50,11 +50,13 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"], help="storage type of the potentials")
     ap.add_argument("--ragged", action="store_true", help="random lengths instead of all = L")
     ap.add_argument("--grad-mb", type=float, default=28.0,
-                    help="size of the all-reduced flat gradient in MB (default: the VLGAE model's ~7 M fp32 parameters)")
+                    help="dp workload: size of the all-reduced flat gradient in MB (default: the VLGAE model's ~7 M fp32 parameters)")
+    ap.add_argument("--factors", nargs="*", default=[], choices=["rel", "attr", "img"],
+                    help="train_step workload: visual factors beside the objects (shipped model: rel attr img -> 1369 columns at 36 regions)")
     ap.add_argument("--workload", default="dp", choices=["dp", "train_step"],
                     help="dp: the headline DMV1o inside+outside step (BASELINE.json metric); train_step: the chained "
-                         "training-step hot path of configs[4], sharded data-parallel (tools/bench_train.py)")
-    ap.add_argument("--buckets", type=int, default=3, help="train_step: pieces the flat gradient is all-reduced in")
+                         "training-step hot path of configs[4], sharded data-parallel (vlgae_amd/bench/sharded_step.py)")
+    ap.add_argument("--buckets", type=int, default=4, help="train_step: pieces the flat gradient is all-reduced in")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-secondary", "--no-align", action="store_true", dest="no_secondary",
                     help="headline only: skip the secondary single-GPU measurements")
@@ -251,8 +253,7 @@ def run(args):
         sync()
 
     if args.workload == "train_step":
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_train
+        from vlgae_amd.bench import sharded_step as bench_train
         res = bench_train.measure(args, rank, world, dev, dry, barrier)
         if rank == 0:
             print(json.dumps(bench_train.json_line(args, world, res, dry, share)), flush=True)
@@ -337,15 +338,14 @@ def run(args):
     # ---- multi-GPU: the sharded training step (configs[4]) beside the DP line, on every rank ----
     train_sharded = None
     if world > 1 and not args.no_secondary:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_train
+        from vlgae_amd.bench import sharded_step as bench_train
         import copy
         targs = copy.copy(args)
         targs.steps, targs.warmup = min(args.steps, 50), min(args.warmup, 10)
         try:
             train_sharded = bench_train.measure(targs, rank, world, dev, dry, barrier)
             train_sharded.update(steps=targs.steps, warmup=targs.warmup,
-                                 what="bench.py --workload train_step on the same ranks (tools/bench_train.py): value = "
+                                 what="bench.py --workload train_step on the same ranks (vlgae_amd/bench/sharded_step.py): value = "
                                       "sentences/s of the whole job, synchronous-SGD all-reduce of the model-sized gradient")
         except Exception as e:   # every rank fails or none does (same code path); never costs the headline line
             train_sharded = {"error": repr(e)[:300]}
@@ -419,8 +419,7 @@ def run(args):
                                "256 CU x 4 SIMD x 8 lanes/clk x 2.4 GHz"}
 
     if world == 1 and not args.no_secondary:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_secondary
+        from vlgae_amd.bench import secondary as bench_secondary
         bench_secondary.run_all(out, args, h, dev)
 
     if world == 1 and args.cpu_seconds > 0:

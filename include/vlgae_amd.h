@@ -269,7 +269,8 @@ int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* 
  * (joint.py:136-138,175):   d_weight[M(out), N(in)] = dy^T x,   d_bias[M] = sum_rows dy.
  *   dy [K, ld_dy] (first M columns used), x [K, ld_x] (first N columns used): bf16, row-major, K = B*N token rows;
  *   M and N multiples of 8 (64 x 64 output tiles, partial at the edges), row strides multiples of 8 elements, dy / x / ws 16-byte aligned.
- *   d_weight [M, N], d_bias [M] or NULL, x_colsum [N] or NULL in out_dtype (VLG_F32, or VLG_BF16 = the parameter's storage type: no cast
+ *   d_weight [M, N] with rows ld_dw >= N elements apart (round 5: a column block of a wider gradient tensor -- the [H, n] halves of the
+ *   visual encoder's [H, 2n] weights, box_rel.py:21-27 -- is written in place), d_bias [M] or NULL, x_colsum [N] or NULL in out_dtype (VLG_F32, or VLG_BF16 = the parameter's storage type: no cast
  *   launch behind the reduction; accumulation is fp32 either way); x_colsum = sum_rows x (the bias gradient when the roles
  *   are swapped: a weight stored [in, out] as in `matmul(child + parent, arc_encoder_w2) + arc_encoder_b`, joint.py:285-286,
  *   takes dy := the layer input and x := the cotangent).  ws: vlg_linear_wgrad_workspace(K, M, N) bytes (0 = unsupported shape).
@@ -277,7 +278,38 @@ int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* 
  * order: bit-reproducible, no atomics. */
 size_t vlg_linear_wgrad_workspace(int K, int M, int N);
 int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
-                     void* d_weight, void* d_bias, void* x_colsum, void* stream);
+                     void* d_weight, int ld_dw, void* d_bias, void* x_colsum, void* stream);
+
+/* The two TRAINABLE encoders between the frozen features and the structured step (round 5; BASELINE.json configs[4]) -- what
+ * `JointModelBase.forward` runs first, src/model/base.py:229,235.  The GEMMs are the caller's (library); these are the passes around them.
+ *
+ * vlg_dropout: nn.Dropout of `MLPEncoder.forward` (src/model/text_encoder/mlp_encoder.py:36-38) on the [rows, cols] embeddings, and its
+ *   adjoint (the same call on the cotangent).  out = x * m (+ add), m = 0 or 1/(1-p):
+ *     mask != NULL: explicit fp32 values [rows, cols] -- or, shared_rows > 0, one [cols] row per `shared_rows` consecutive rows
+ *                   (SharedDropout, nn/dropout.py:42-63, `shared_dropout` of the encoder's config);
+ *     rng  != NULL: a counter-based draw, Philox4x32-10 keyed by the DEVICE-resident pair rng[0] = seed, rng[1] = step over the element
+ *                   index (`site` is added to the seed: one state serves every dropout layer of a step with independent streams) -- nothing is stored, the adjoint regenerates the same bits, and a HIP-graph replay sees the step that
+ *                   vlg_rng_advance (a one-thread launch: rng[1] += 1) left there.  p is applied in steps of 2^-16.
+ *   x (`dtype`), add / out (`out_dtype`; add NULL = none: the other producer of a gradient that has two), cols a multiple of 8,
+ *   buffers 16-byte aligned.
+ * vlg_vis_encoder: `VisBoxRelSimpleEncoder.forward` (src/model/vis_encoder/box_rel.py:29-52, img_feat: inputs = [box ; mean_r box]) and
+ *   the concatenation of `vis_feat_unprune` (src/model/joint.py:137-171) behind its Linear layers: by linearity the caller computes
+ *   P [B R, ldp] = X W_a^T (X [B R, n] the region features, W_a the first n columns of the F stacked [H, 2n] weights) and
+ *   C [B, ldp] = mean_r(X) W_b^T + bias; this writes mid [B, V, H] (`dtype`):
+ *     rows off_box + r          LeakyReLU(P[b r, col_box..] + C[b, col_box..])                       box_fc          (:47)
+ *     rows off_rel + i R + j    LeakyReLU((P[b i, col_rel..] + P[b j, col_rel..]) / 2 + C[b, col_rel..])   rel_fc   (:41-45; 657 GFLOP as written)
+ *     rows off_attr + r         as box, attr_fc                                                       (:48-49)
+ *     row  off_img              mean_r of the box rows (all R of them, as joint.py:163 does)          add_image
+ *   (-1 for an absent factor; the present encoders' column blocks are adjacent from column 0; H/4 divides 256; ldp a multiple of 8).
+ * vlg_vis_encoder_backward: grad_mid [B, V, H] -> dP [B R, ldp] and dC [B, ldp] = sum_r dP[b r] (the per-image term's cotangent; fixed order);
+ *   the weight gradients are then two vlg_linear_wgrad calls, dP^T X into columns [0, n) and dC^T mean_r(X) into [n, 2n) of the stack. */
+int vlg_dropout(const void* x, const float* mask, int shared_rows, const uint64_t* rng, unsigned site, float p, const void* add, void* out, long long rows,
+                int cols, int dtype, int out_dtype, void* stream);
+int vlg_rng_advance(uint64_t* rng, void* stream);
+int vlg_vis_encoder(const void* P, const void* C, int B, int R, int H, int V, int ldp, int col_box, int col_rel, int col_attr, int off_box, int off_rel,
+                    int off_attr, int off_img, int dtype, float slope, void* mid, void* stream);
+int vlg_vis_encoder_backward(const void* P, const void* C, const void* grad_mid, int B, int R, int H, int V, int ldp, int col_box, int col_rel, int col_attr,
+                             int off_box, int off_rel, int off_attr, int off_img, int dtype, float slope, void* dP, void* dC, void* stream);
 
 /* The byte work of `lang_feat_max_tree` (src/model/joint.py:235-292) between the DP, the encoder GEMMs and the arc encoder.
  * Shapes: B sentences, L words, N = L + 1 positions (root first), h encoder width, d matching width; M = B*N rows.
@@ -441,7 +473,8 @@ int vlg_selftest_xlane(int* scratch, void* stream);
 /* Thread-local message for the last non-zero return on this thread ("" if none). */
 const char* vlg_last_error(void);
 
-/* Library / ABI version, e.g. 131 = 0.1.3.1 (round 4: vlg_langfeat_* take the activations' storage type and the SharedDropout masks,
+/* Library / ABI version, e.g. 140 = 0.1.4.0 (round 5: vlg_dropout, vlg_rng_advance, vlg_vis_encoder(_backward) added, vlg_linear_wgrad takes ld_dw;
+ * the Python binding refuses a library whose version differs from the one it was written against; round 4: vlg_langfeat_* take the activations' storage type and the SharedDropout masks,
  * vlg_langfeat_rowscale, vlg_ff_* added, vlg_ndmv_potentials* take row strides and the gradients' storage type; round 3, 120: vlg_linear_wgrad, vlg_langfeat_*, vlg_ndmv_potentials*, vlg_dmv1o_viterbi added;
  * round 2, 110: vlg_bilinear_align_backward takes a workspace; vlg_scale_counts, vlg_feed_* added). */
 int vlg_version(void);

@@ -578,7 +578,14 @@ def trainstep_cases():
     called unbound on namespaces that carry what they read (the modules are the reference's `MLP`, `DMVSkipConnectEncoder`,
     `DMVFactorizedBilinear`, `SharedDropout`; `VarPool`, `reduce_loss` and `DMV1o` are the reference's too):
 
-      JointModelBase.forward order (base.py:215-241)
+      JointModelBase.forward order (base.py:215-241), starting at the FROZEN features (round 5):
+        VisBoxRelSimpleEncoder.forward   vis_encoder/box_rel.py:29-52   base.py:229: the reference's own module on vis_box_feat [B,R,n]
+                                                            (img_feat, use_attr as the case has the factor, dropout 0, use_img False: vlgae.yaml:27-35)
+        MLPEncoder.forward               text_encoder/mlp_encoder.py:36-40   base.py:68 (ModelBase.forward): called unbound on a namespace with
+                                                            `linear` = nn.Linear(E, h, bias=False), `shared_dropout` = Identity (shared_dropout: 0,
+                                                            vlgae.yaml:21-25) and `dropout` = a recorder that multiplies by a mask drawn from this
+                                                            script's generator ((rand >= p) / (1 - p), what nn.Dropout(p) does in training): the mask
+                                                            is an input of the fixture (`enc_drop_mask`)
         DependencyBoxRel._forward        joint.py:658-675   feat_fuse_attention (a pass-through copy, :362-398), vis_feat_unprune with
                                                             return_mid (:137-178), lang_feat_word_only (:193-211), the attention fuse
                                                             (:670-674) into a COPY of `encoded` (replace: false), then
@@ -595,8 +602,9 @@ def trainstep_cases():
     `get_mask` is replaced by a recorder that draws from this script's generator so that the masks are inputs of the fixture
     (call order: word encoder in lang_feat_word_only; word, child, parent encoders in lang_feat_max_tree).  The scorer's
     feed-forwards run with dropout 0 (out of the hot path; their dropout is torch's).  Stored: every input, every parameter,
-    the dropout masks, intermediate values (fused x, potentials, heads, txt, marginal, the loss terms) and the gradient of the
-    reduced loss w.r.t. every input feature and parameter.  `w1` of the d = 128 case is stored as rank-4 factors and only a
+    the dropout masks, intermediate values (the encoders' outputs, fused x, potentials, heads, txt, marginal, the loss terms) and the
+    gradient of the reduced loss w.r.t. every input feature (the raw E-d embeddings and n-d region features) and parameter (the two
+    encoders' included; `rel_fc` / `attr_fc` of a case whose model has no such factor get no gradient: listed in `unused`).  `w1` of the d = 128 case is stored as rank-4 factors and only a
     strided sample of its gradient is kept."""
     from functools import partial
     from types import SimpleNamespace as NS
@@ -604,15 +612,17 @@ def trainstep_cases():
     from src.model import ldndmv
     from src.model.nn import MLP, DMVSkipConnectEncoder, DMVFactorizedBilinear
     from src.model.nn.dropout import SharedDropout
+    from src.model.text_encoder.mlp_encoder import MLPEncoder
+    from src.model.vis_encoder import VisBoxRelSimpleEncoder
     from src.utility.var_pool import VarPool
     from src.utility.fn import reduce_loss
     JB, ND = joint.DependencyBoxRel, ldndmv.DiscriminativeNDMV
     src.trainer = NS(current_epoch=100)
     real_get_mask = SharedDropout.get_mask
-    for name, seed, B, L, boxes, factors, h, d, E, Et, T, H, nb, r, rank, p_drop, sc_gain in (
-            ("trainstep_B3_L6_box4_rel_attr_h64_d32_s0", 0, 3, 6, 4, ("rel", "attr"), 64, 32, 12, 10, 9, 24, 6, 8, 0, 0.33, 6.0),
-            ("trainstep_B4_L9_box5_rel_attr_img_h64_d32_s1_nodrop", 1, 4, 9, 5, ("rel", "attr", "img"), 64, 32, 12, 10, 11, 24, 0, 8, 0, 0.0, 8.0),
-            ("trainstep_B8_L40_box36_h256_d128_s2", 2, 8, 40, 36, (), 256, 128, 40, 24, 45, 96, 40, 16, 4, 0.33, 10.0)):
+    for name, seed, B, L, boxes, factors, h, d, E, Et, T, H, nb, r, rank, p_drop, sc_gain, n_vis in (
+            ("trainstep_B3_L6_box4_rel_attr_h64_d32_s0", 0, 3, 6, 4, ("rel", "attr"), 64, 32, 16, 10, 9, 24, 6, 8, 0, 0.33, 6.0, 24),
+            ("trainstep_B4_L9_box5_rel_attr_img_h64_d32_s1_nodrop", 1, 4, 9, 5, ("rel", "attr", "img"), 64, 32, 16, 10, 11, 24, 0, 8, 0, 0.0, 8.0, 40),
+            ("trainstep_B8_L40_box36_h256_d128_s2", 2, 8, 40, 36, (), 256, 128, 40, 24, 45, 96, 40, 16, 4, 0.33, 10.0, 96)):
         torch.manual_seed(seed)
         g = torch.Generator().manual_seed(seed)
         rnd = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
@@ -629,6 +639,14 @@ def trainstep_cases():
         w2 = torch.nn.Parameter(rnd(d, d, sc=d ** -0.5))
         b_arc = torch.nn.Parameter(rnd(d, sc=0.1))
         pre_match = torch.nn.Linear(h, d, bias=False)
+        # the two trainable encoders in front of everything (base.py:229,68): the reference's VisBoxRelSimpleEncoder as a module, and
+        # MLPEncoder.forward unbound on a namespace (its __init__ wants an Embedding object; forward reads three attributes)
+        venc = VisBoxRelSimpleEncoder(n_in=n_vis, n_hidden=h, dropout=0., activate=True, use_attr="attr" in factors, use_img=False, img_feat=True)
+        text_linear = torch.nn.Linear(E, h, bias=False)
+        with torch.no_grad():
+            for m in (venc.box_fc, venc.rel_fc) + ((venc.attr_fc,) if "attr" in factors else ()):
+                m.linear.bias.copy_(rnd(h, sc=0.1))                              # (reset_parameters zeroes it)
+            text_linear.weight.copy_(rnd(h, E, sc=E ** -0.5))
         ln = torch.nn.LayerNorm(h)
         with torch.no_grad():
             ln.weight.copy_(torch.rand(h, generator=g) + 0.5)
@@ -666,13 +684,8 @@ def trainstep_cases():
         wmask = torch.arange(L)[None] < lengths[:, None]
         box_mask = torch.rand(B, boxes, generator=g) > 0.2
         box_mask[:, 0] = True
-        enc_x = rnd(B, L, h, sc=0.5).requires_grad_(True)
-        emb = rnd(B, L, E, sc=0.5).requires_grad_(True)
-        vis_enc = {"box": rnd(B, boxes, h, sc=0.5).requires_grad_(True)}
-        if "rel" in factors:
-            vis_enc["rel"] = rnd(B, boxes * boxes, h, sc=0.5).requires_grad_(True)
-        if "attr" in factors:
-            vis_enc["attr"] = rnd(B, boxes, h, sc=0.5).requires_grad_(True)
+        emb = rnd(B, L, E, sc=0.5).requires_grad_(True)                         # what `self.embedding` emits: [BERT subword ; tag embedding]
+        vis_box_feat = rnd(B, boxes, n_vis, sc=0.5).requires_grad_(True)         # the frozen Faster-RCNN region features
         token = torch.randint(0, T, (B, L), generator=g)
         tag = torch.randint(0, 7, (B, L), generator=g)
         inputs = {"token": token, "tag": tag, "vis_box_mask": box_mask, "vis_rel_mask": True}
@@ -680,9 +693,9 @@ def trainstep_cases():
         # every input feature and parameter sits on the bfloat16 grid (the reference still computes in fp32 on them), so that a
         # bf16-storage run of the same step starts from identical numbers
         with torch.no_grad():
-            all_mods = [*enc.values(), pre_match, ln, dep.head_ff, dep.child_ff, dep.root_ff, dep.dec_ff, dep.mid_ff, dep.attach_scorer,
+            all_mods = [*enc.values(), pre_match, venc, text_linear, ln, dep.head_ff, dep.child_ff, dep.root_ff, dep.dec_ff, dep.mid_ff, dep.attach_scorer,
                         dep.dec_scorer, dep.root_scorer]
-            for t_ in [enc_x, emb, *vis_enc.values(), w1, w2, b_arc, dep.token_emb, dep.root_emb, dep.dec_emb,
+            for t_ in [emb, vis_box_feat, w1, w2, b_arc, dep.token_emb, dep.root_emb, dep.dec_emb,
                        *(p_ for m in all_mods for p_ in m.parameters())]:
                 t_.copy_(t_.to(torch.bfloat16).to(torch.float32))
         # ---- recorders: dropout masks, the two `_mid` tensors, the scorers' projected inputs ----
@@ -697,8 +710,24 @@ def trainstep_cases():
         hooks += [m.register_forward_hook(lambda mod, inp, out, k=k: cap.__setitem__(k, out))
                   for k, m in (("x1", dep.attach_scorer.project1), ("x2", dep.attach_scorer.project2), ("y1", dep.dec_scorer.project1),
                                ("y2", dep.dec_scorer.project2))]
-        # ---- JointModelBase.forward (base.py:215-241) with the encoders' outputs given ----
-        encoded = {"x": enc_x, "emb": emb, **{f"vis_{k}": t for k, t in vis_enc.items()}}
+        # ---- JointModelBase.forward (base.py:215-241) from the frozen features ----
+        p_enc = 0.33 if p_drop > 0 else 0.0                                      # encoder.dropout, vlgae.yaml:23 (the "nodrop" case runs without)
+        enc_masks = []
+
+        def enc_dropout(x):                                                      # nn.Dropout(p) in training mode, with the mask recorded
+            if p_enc == 0:
+                return x
+            m = (torch.rand(x.shape, generator=g) >= p_enc).to(x.dtype) / (1 - p_enc)
+            enc_masks.append(m)
+            return x * m
+        text_enc = NS(dropout=enc_dropout, shared_dropout=torch.nn.Identity(), linear=text_linear)
+        vis_all = venc({"vis_box_feat": vis_box_feat}, vp)                       # base.py:229
+        # (the encoder always emits `rel`, and `attr` with use_attr; `vis_feat_unprune` reads what cfg.add_rel / add_attr select)
+        vis_enc = {k: t for k, t in vis_all.items() if k == "box" or k in factors}
+        encoded = {f"vis_{k}": t for k, t in vis_enc.items()}                    # base.py:233-234
+        encoded |= MLPEncoder.forward(text_enc, emb, vp)                         # base.py:68 (ModelBase.forward)
+        encoded["emb"] = emb                                                     # base.py:69
+        enc_x = encoded["x"]
         score = JB._forward(me, inputs, encoded, vp)
         assert encoded["x"] is enc_x                                             # the fuse went into a copy (replace: false)
         score = {**score, **JB._vis_forward(me, inputs, vis_enc, encoded, score, vp)}
@@ -712,15 +741,16 @@ def trainstep_cases():
         ff = dict(head_ff=dep.head_ff, child_ff=dep.child_ff, root_ff=dep.root_ff, dec_ff=dep.dec_ff, mid_ff=dep.mid_ff,
                   attach_scorer=dep.attach_scorer, dec_scorer=dep.dec_scorer, root_scorer=dep.root_scorer)
         ff_params = {f"ff.{mod}.{k}": t for mod, m in ff.items() for k, t in m.named_parameters()}
-        named = {"enc_x": enc_x, "emb": emb, **{f"vis_{k}": t for k, t in vis_enc.items()},
+        vis_params = {f"vis.{m}.{k}": t for m in ("box_fc", "rel_fc", "attr_fc") if hasattr(venc, m) for k, t in getattr(venc, m).linear.named_parameters()}
+        named = {"emb": emb, "vis_box_feat": vis_box_feat, "w_text": text_linear.weight, **vis_params,
                  "w_word": enc["word"].linear.weight, "b_word": enc["word"].linear.bias, "w_child": enc["child"].linear.weight,
                  "b_child": enc["child"].linear.bias, "w_parent": enc["parent"].linear.weight, "b_parent": enc["parent"].linear.bias,
                  "w1": w1, "w2": w2, "b_arc": b_arc, "w_vis": pre_match.weight, "ln_w": ln.weight, "ln_b": ln.bias,
                  "token_emb": dep.token_emb, "root_emb": dep.root_emb, "dec_emb": dep.dec_emb, **ff_params}
-        extra_t = [mids[0], mids[1], cap["x1"], cap["x2"], cap["y1"], cap["y2"], score["merged_dec"], score["merged_attach"]]
+        extra_t = [mids[0], mids[1], cap["x1"], cap["x2"], cap["y1"], cap["y2"], score["merged_dec"], score["merged_attach"], enc_x]
         grads = torch.autograd.grad(loss, list(named.values()) + extra_t, allow_unused=True)
         gn = dict(zip(named, grads[:len(named)]))
-        g_mid0, g_mid1, g_x1, g_x2, g_y1, g_y2, g_md, g_ma = grads[len(named):]
+        g_mid0, g_mid1, g_x1, g_x2, g_y1, g_y2, g_md, g_ma, g_enc_x = grads[len(named):]
         # the fused x (the copy `_forward` handed to the parser) and the heads, recomputed with the reference's lines on the same tensors
         with torch.no_grad():
             vis0 = pre_match(mids[0])
@@ -749,6 +779,8 @@ def trainstep_cases():
             p_drop=np.float32(p_drop), alpha=np.float32(me.cfg.grounding_interpolation), vis2txt_weight=np.float32(1.0),
             slope=np.float32(enc["child"].activation.negative_slope), ln_eps=np.float32(ln.eps), neg_inf=np.float32(-src.INF),
             n_bottleneck=np.int64(nb), unused=np.array(unused),
+            enc_x=_np(enc_x), g_enc_x=_np(g_enc_x), p_enc=np.float32(p_enc), n_vis=np.int64(n_vis),
+            enc_drop_mask=(_np(enc_masks[0]) if enc_masks else np.zeros((0, L, E), np.float32)),
             vis_mid=_np(mids[0]), g_vis_mid=_np(g_mid0 + g_mid1), vis_mask=_np(vmask), x_fused=_np(x_fused),
             sc_x1=_np(cap["x1"]), sc_x2=_np(cap["x2"][0]), sc_y1=_np(cap["y1"]), sc_y2=_np(cap["y2"][0]), root_rule=_np(score["root_rule"][0]),
             g_sc_x1=_np(g_x1), g_sc_x2=_np(g_x2[0]), g_sc_y1=_np(g_y1), g_sc_y2=_np(g_y2[0]),

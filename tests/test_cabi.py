@@ -88,7 +88,10 @@ def test_workspace_sizing(lib):
     w81 = lib.vlg_workspace_bytes(_C.OP_DMV1O_INSIDE_OUTSIDE, 256, 81, 0)
     assert w81 > 0 and w81 % 256 == 0
     assert lib.vlg_workspace_bytes(_C.OP_DMV1O_INSIDE_OUTSIDE, 512, 81, 0) == 2 * w81
-    assert lib.vlg_workspace_bytes(_C.OP_DMV1O_INSIDE_OUTSIDE, 256, 81, 1) > w81          # back-pointers
+    # the Max semiring's outside pass is the back-pointer walk (round 4): its lean layout spills only gI at N = 81 -- the query must size
+    # THAT layout, not the unreachable one-hot replay
+    wmax = lib.vlg_workspace_bytes(_C.OP_DMV1O_INSIDE_OUTSIDE, 256, 81, 1)
+    assert 0 < wmax < w81 and lib.vlg_workspace_bytes(_C.OP_DMV1O_INSIDE_OUTSIDE, 256, 41, 1) == 0
     assert lib.vlg_workspace_bytes(_C.OP_DEPTREE_INSIDE_OUTSIDE, 256, 81, 0) == 0
     assert lib.vlg_workspace_bytes(_C.OP_DEPTREE_INSIDE_OUTSIDE, 4, 200, 0) > 0
     assert lib.vlg_workspace_bytes(99, 4, 41, 0) == 0 and lib.vlg_workspace_bytes(0, 0, 41, 0) == 0
@@ -209,7 +212,7 @@ def test_round4_entry_points_validate_on_the_host(lib):
     sc = lib.vlg_ndmv_potentials
     assert sc(one, 8, one, 16, one, 16, one, 16, one, one, None, 2, 5, 7, 16, 0, ctypes.c_float(-1e20), 0, one, one, None) == 0x1001
     assert b"row strides" in lib.vlg_last_error()
-    assert lib.vlg_linear_wgrad(one, 64, one, 64, 4096, 64, 64, one, 1 << 30, 9, one, one, None, None) == 0x1002
+    assert lib.vlg_linear_wgrad(one, 64, one, 64, 4096, 64, 64, one, 1 << 30, 9, one, 64, one, None, None) == 0x1002
     sg = lambda **kw: lib.vlg_small_gemm(kw.get("a", one), 0, 16, 1, one, 0, 8, 1, kw.get("c", one), 0, kw.get("ldc", 8), None, 0, kw.get("u", None), 0, None, 0,
                                          kw.get("batch", 1), kw.get("M", 4), 8, 16, ctypes.c_float(1.0), 0, kw.get("dt", 1), 1, None)
     assert sg(M=0) == 0x1001 and sg(ldc=4) == 0x1001 and sg(dt=5) == 0x1002 and sg(a=None) == 0x1003 and sg(batch=0) == 0

@@ -144,13 +144,17 @@ def test_bench_train_step_workload_sharded_dry_run():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "configs[4]" in out["config"]["workload"]
     assert out["config"]["global_batch"] == 512 and out["config"]["parallelism"] == "dp2"
     comm = out["comm"]
-    assert comm["rccl_ranks_seen"] == 2 and comm["backend"] == "gloo" and comm["buckets"] == 3
-    assert comm["allreduce_bytes"] == out["config"]["allreduce_floats"] * 4 and out["config"]["allreduce_floats"] >= 3_000_000
-    # three buckets in readiness order: the arc encoder's (w1 | w2 | b), the parser's feed-forwards, then the encoders / LayerNorm /
-    # pre-matching projection + the check slot + filler; together they tile the buffer
-    b0, b1, b2 = comm["bucket_bounds"]
-    assert b0 == [0, 128 ** 3 + 128 * 128 + 128] and b1[0] == b0[1] and b2[0] == b1[1] and b2[1] == out["config"]["allreduce_floats"]
-    assert comm["bucket_contents"][0] == ["w1", "w2", "b"] and "w_vis" in comm["bucket_contents"][2]
+    assert comm["rccl_ranks_seen"] == 2 and comm["backend"] == "gloo" and comm["buckets"] == 4
+    # the whole shipped model: 6.48 M trainable floats (text encoder, three visual-encoder MLPs, ... -- no filler), whatever --grad-mb says
+    assert comm["allreduce_bytes"] == out["config"]["allreduce_floats"] * 4 and 6_300_000 <= out["config"]["allreduce_floats"] <= 7_500_000
+    assert "no filler" in comm["payload"]
+    # four buckets in readiness order: the arc encoder's (w1 | w2 | b), the parser's feed-forwards, the language-side encoders / LayerNorm /
+    # pre-matching projection, then the check slot + the text and visual encoders (+ the zeros of the visual-encoder MLPs the object-only
+    # layout does not reach); together they tile the buffer
+    b0, b1, b2, b3 = comm["bucket_bounds"]
+    assert b0 == [0, 128 ** 3 + 128 * 128 + 128] and b1[0] == b0[1] and b2[0] == b1[1] and b3[0] == b2[1] and b3[1] == out["config"]["allreduce_floats"]
+    assert comm["bucket_contents"][0] == ["w1", "w2", "b"] and "w_vis" in comm["bucket_contents"][2] and comm["bucket_contents"][3] == ["w_text", "w_venc", "b_venc"]
+    assert out["real_gradient_floats"] == out["config"]["allreduce_floats"] - 1 - 2 * 256 * (4096 + 1)
     chk = comm["mean_over_ranks_check"]
     assert chk["slot"] == chk["expected"] == 256 * 40        # DDP averages: the mean of the two ranks' word counts
     assert out["value"] > 0 and out["step_ms"] > 0 and out["compute_ms"] > 0 and comm["allreduce_ms"] > 0
@@ -164,7 +168,7 @@ def test_bench_dp_line_carries_the_sharded_train_step():
                       "--cpu-seconds", "0"], {})
     ts = out["train_step_sharded"]
     assert "error" not in ts, ts
-    assert ts["comm"]["rccl_ranks_seen"] == 2 and ts["comm"]["buckets"] == 3 and ts["value"] > 0
+    assert ts["comm"]["rccl_ranks_seen"] == 2 and ts["comm"]["buckets"] == 4 and ts["value"] > 0
 
 
 def _bucket_worker(rank, world, port, out_dir):
@@ -189,7 +193,7 @@ def _bucket_worker(rank, world, port, out_dir):
         # DDP semantics by default: the MEAN over ranks (one case asks for the plain sum)
         want = torch.arange(numel, dtype=torch.float32) * 2 * sum(r + 1 for r in range(world)) / (1 if numel == 7 else world)
         ok &= bool(torch.allclose(red.flat, want, rtol=1e-6, atol=0))
-    # explicit bounds in launch order (what tools/bench_train.py passes): must tile the buffer
+    # explicit bounds in launch order (what vlgae_amd/bench/sharded_step.py passes): must tile the buffer
     red = vdist.BucketedGradReducer(10, torch.device("cpu"), bounds=[(0, 4), (4, 6), (6, 10)])
     ok &= red.n_buckets == 3 and red.bounds == [(0, 4), (4, 6), (6, 10)]
     try:

@@ -1212,16 +1212,18 @@ def test_arc_trilinear_shapes(oracle_mod, M, X, H, Y, dt):
 
 
 def test_training_step_chain_as_one_hip_graph():
-    """The chained training-step hot path (tools/train_step.py: attention-fuse -> library GEMMs -> DMV marginals + heads on two
+    """The chained training-step hot path (vlgae_amd/train_step.py: attention-fuse -> library GEMMs -> DMV marginals + heads on two
     streams -> arc encoder -> grounding loss -> -DMV.max -> every gradient) captured as ONE HIP graph: capture succeeds (no
     entry point synchronises, allocates through the driver or reads a device value on the host), and a replay gives the eager
     step's loss bit for bit and its gradients to one bf16 ulp."""
-    _tools_path()
-    import train_step
+    from vlgae_amd import train_step
     with torch.autograd.set_multithreading_enabled(False):
         # fixed SharedDropout masks: a replay must reproduce the eager step (masks drawn inside the step differ per replay by design)
-        drop = (torch.rand(4, 64, 128, generator=torch.Generator().manual_seed(5)) >= 0.33).float() / 0.67
-        step = train_step.build(64, 24, 20, dev(), dtype=torch.bfloat16, E=96, H=64, nb=24, given=dict(drop=drop), p_ff_drop=0.0, p_mid_drop=0.0)
+        gen = torch.Generator().manual_seed(5)
+        drop = (torch.rand(4, 64, 128, generator=gen) >= 0.33).float() / 0.67
+        enc_drop = (torch.rand(64, 24, 96, generator=gen) >= 0.33).float() / 0.67
+        step = train_step.build(64, 24, 20, dev(), dtype=torch.bfloat16, E=96, H=64, nb=24, n_vis=256, given=dict(drop=drop, enc_drop=enc_drop),
+                                p_ff_drop=0.0, p_mid_drop=0.0)
         for _ in range(3):
             total, grads, pot_grads = step()
         want = [total.detach().clone()] + [grads[k].clone() for k in step.names] + [g.clone() for g in pot_grads]
@@ -1260,35 +1262,42 @@ def _bf16_grid(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
 
 
-def trainstep_from_fixture(g, dtype):
-    """tools/train_step.build (the function bench.py times) on a trainstep_* fixture's tensors.  Returns (step, reference gradients
-    keyed like the step's leaves)."""
-    _tools_path()
-    import train_step
-    B, L, h = g["enc_x"].shape
-    V, d = g["vis_mid"].shape[1], g["w2"].shape[0]
+def trainstep_from_fixture(g, dtype, ff_dtype=None):
+    """vlgae_amd.train_step.build (the function bench.py times) on a trainstep_* fixture's tensors: the raw embeddings and region
+    features, every parameter (the two encoders' included), the recorded dropout masks.  Everything -- the parser's feed-forwards
+    too -- runs in `dtype`, exactly as `bench.py` runs it, unless ff_dtype says otherwise.  Returns (step, reference gradients keyed
+    like the step's leaves)."""
+    from vlgae_amd import train_step
+    B, L, E = g["emb"].shape
+    R, n_vis = g["vis_box_feat"].shape[1:]
+    h, d = g["w_text"].shape[0], g["w2"].shape[0]
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     if "w1" in g:
         w1, g_w1 = g["w1"], g["g_w1"]
     else:   # rank factors; the reference ran on the bf16-rounded product (make_golden.trainstep_cases)
         w1 = _bf16_grid(np.einsum("xr,hr,yr->xhy", g["w1_u"], g["w1_v"], g["w1_z"]).astype(np.float32))
         g_w1 = None
-    given = dict(enc_x=tt(g["enc_x"]), emb=tt(g["emb"]), vis_mid=tt(g["vis_mid"]), w_vis=tt(g["w_vis"]),
+    factors = [str(n) for n in g["factor_names"]][1:]
+    fcs = ["box_fc"] + [f + "_fc" for f in ("rel", "attr") if f in factors]          # the encoders whose outputs the model reads, stacked
+    cat = lambda pre, suf: np.concatenate([g[f"{pre}vis.{m}.{suf}"] for m in fcs], 0)
+    given = dict(emb=tt(g["emb"]), vis_box_feat=tt(g["vis_box_feat"]), w_text=tt(g["w_text"]), w_venc=tt(cat("", "weight")), b_venc=tt(cat("", "bias")),
+                 w_vis=tt(g["w_vis"]),
                  w_enc=tt(np.concatenate([g["w_word"], g["w_child"], g["w_parent"]], 0)),
                  b_enc=tt(np.concatenate([g["b_word"], g["b_child"], g["b_parent"]], 0)), ln_w=tt(g["ln_w"]), ln_b=tt(g["ln_b"]),
                  w1=tt(w1), w2=tt(g["w2"]), b=tt(g["b_arc"]), token_emb=tt(g["token_emb"]), root_emb=tt(g["root_emb"]),
-                 dec_emb=tt(g["dec_emb"]), lengths=tt(g["lengths"]), token=tt(g["token"]), tag=tt(g["tag"]), vis_mask=tt(g["vis_mask"]),
-                 drop=tt(g["drop_masks"]) if g["drop_masks"].shape[0] else None)
+                 dec_emb=tt(g["dec_emb"]), lengths=tt(g["lengths"]), token=tt(g["token"]), tag=tt(g["tag"]), box_mask=tt(g["box_mask"]),
+                 drop=tt(g["drop_masks"]) if g["drop_masks"].shape[0] else None,
+                 enc_drop=tt(g["enc_drop_mask"]) if g["enc_drop_mask"].shape[0] else None)
     given.update({k: tt(v) for k, v in g.items() if k.startswith("ff.")})
     pos_for = {k: tt(g["pos_for_" + k]) for k in ("obj", "rel", "attr")}
-    # (the parser's feed-forwards are torch ops outside the hot path: float32 in both runs, so that the bf16 run's potentials -- and
-    #  with them the Viterbi heads every later value depends on -- differ from the reference's only through the hot path's own rounding)
-    step = train_step.build(B, L, V, dev(), dtype=dtype, ff_dtype=torch.float32, d=d, h=h, given=given, alpha=float(g["alpha"]), use_pos_prior=True,
+    step = train_step.build(B, L, R, dev(), dtype=dtype, ff_dtype=ff_dtype, d=d, h=h, E=E, n_vis=int(n_vis), given=given, alpha=float(g["alpha"]), use_pos_prior=True,
                             p_ff_drop=0.0, p_mid_drop=0.0,   # (the fixtures ran the parser's feed-forwards without their dropout)
-                            vis2txt=float(g["vis2txt_weight"]), factor_names=[str(n) for n in g["factor_names"]],
-                            vis_split=[int(w) for w in g["vis_split"]], pos_for=pos_for, ln_eps=float(g["ln_eps"]))
-    ref = {k: g["g_" + k] for k in ("enc_x", "emb", "vis_mid", "w_vis", "ln_w", "ln_b", "w2", "token_emb", "root_emb", "dec_emb")}
+                            p_enc=float(g["p_enc"]), vis2txt=float(g["vis2txt_weight"]), factors=factors, pos_for=pos_for, ln_eps=float(g["ln_eps"]),
+                            feature_grads=True)
+    assert step.batch["vis_split"] == [int(w) for w in g["vis_split"]] and np.array_equal(step.batch["vis_mask"].cpu().numpy(), g["vis_mask"])
+    ref = {k: g["g_" + k] for k in ("emb", "vis_box_feat", "w_text", "w_vis", "ln_w", "ln_b", "w2", "token_emb", "root_emb", "dec_emb")}
     ref.update({k: g["g_" + k] for k in g if k.startswith("ff.")})
+    ref["w_venc"], ref["b_venc"] = cat("g_", "weight"), cat("g_", "bias")
     ref["w_enc"] = np.concatenate([g["g_w_word"], g["g_w_child"], g["g_w_parent"]], 0)
     ref["b_enc"] = np.concatenate([g["g_b_word"], g["g_b_child"], g["g_b_parent"]], 0)
     ref["b"] = g["g_b_arc"]
@@ -1296,24 +1305,31 @@ def trainstep_from_fixture(g, dtype):
     return step, ref
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype,ff_dtype", [(torch.float32, None), (torch.bfloat16, None), (torch.bfloat16, torch.float32)], ids=["f32", "bf16", "bf16_ff32"])
 @pytest.mark.parametrize("path", golden_files("trainstep_"), ids=golden_ids("trainstep_"))
-def test_training_step_reference_wiring(path, dtype):
-    """THE function `bench.py` times as configs[4] (tools/train_step.build, wiring="reference") against one whole training step
-    executed by the reference's own methods (make_golden.trainstep_cases: DependencyBoxRel._forward -> DiscriminativeNDMV._forward
-    -> _vis_forward -> loss with alpha = 0.5, POS prior, ragged vis_mask, live SharedDropout masks -> reduce_loss('token') ->
-    autograd): every intermediate the fixture holds and the gradient of the reduced loss w.r.t. every input feature and parameter.
+def test_training_step_reference_wiring(path, dtype, ff_dtype):
+    """THE function `bench.py` times as configs[4] (vlgae_amd.train_step.build, wiring="reference") against one whole training step
+    executed by the reference's own modules and methods (make_golden.trainstep_cases: VisBoxRelSimpleEncoder.forward + MLPEncoder.forward
+    on the frozen features -> DependencyBoxRel._forward -> DiscriminativeNDMV._forward -> _vis_forward -> loss with alpha = 0.5, POS
+    prior, ragged vis_mask, live nn.Dropout / SharedDropout masks -> reduce_loss('token') -> autograd): every intermediate the fixture
+    holds and the gradient of the reduced loss w.r.t. every input feature (raw embeddings, raw region features) and parameter.
 
-    float32 (the reference's `precision: 32`): values to 1e-4 * max|.|, heads and masks exact, loss to 1e-5 relative, gradients to
+    f32 (the reference's `precision: 32`): values to 1e-4 * max|.|, heads and masks exact, loss to 1e-5 relative, gradients to
     3e-4 * max|g| (fp32 summation order in the split reductions; the alignment's arg-max positions are exact at this precision).
-    bfloat16 storage (BASELINE.json configs[4]): inputs sit on the bf16 grid, so both sides start from identical numbers; activations
-    are rounded to bf16 between kernels: values to 3e-2 * max|.|, loss to 1e-2 relative, heads equal on >= 95 % of the words, and -- when the
-    whole batch's Viterbi trees agree -- gradients to 8e-2 relative L2 error per tensor (a pre-activation within bf16 rounding of zero
-    flips a LeakyReLU branch, a near-tie flips an arg-max position: single elements move, the tensor does not)."""
+    bf16 (BASELINE.json configs[4], EXACTLY what bench.py times: every feature, parameter and activation between kernels stored in bf16,
+    fp32 accumulation, the parser's six-layer feed-forwards included): inputs sit on the bf16 grid, so both sides start from identical
+    numbers: values to 3e-2 * max|.| (potentials 5e-2 absolute), loss and the Viterbi score -max to 1e-2 relative.  The potentials of
+    these small fixtures are scorer outputs amplified 36-100x to give the trees a spread of ~1.5 nats (make_golden: sc_gain), so a
+    bf16 potential carries ~2e-2 nats of rounding and attachments whose best alternatives lie within that flip: heads equal on >= 45 %
+    of the words here (observed 50 / 86 / 90 %; 96.7 % at B = 256 with unamplified scorers, ..._config_size[bf16]) -- what stays pinned
+    is that the tree chosen is a near-tie (the -max score bound).  Gradients: 8e-2 relative L2 per tensor when every tree agrees, a
+    sanity bound (0.5) otherwise.
+    bf16_ff32: the same with the parser's feed-forwards kept in float32 -- the potentials then differ from the reference's only through
+    the hot path's own rounding: heads equal on >= 95 % of the words; the other bounds as for bf16."""
     g = load(path)
     f32 = dtype == torch.float32
     with torch.autograd.set_multithreading_enabled(False):
-        step, ref = trainstep_from_fixture(g, dtype)
+        step, ref = trainstep_from_fixture(g, dtype, ff_dtype)
         loss, grads, _ = step()
         last = step.last
     npf = lambda x: x.detach().float().cpu().numpy()
@@ -1323,6 +1339,8 @@ def test_training_step_reference_wiring(path, dtype):
         err = np.abs(got - want).max()
         assert err <= tol * max(1.0, np.abs(want).max()), (name, err, np.abs(want).max())
 
+    close("enc_x", npf(last["enc_x"]), g["enc_x"])
+    close("vis_mid", npf(last["vis_mid"]), g["vis_mid"])
     close("x_fused", npf(last["x_fused"]), g["x_fused"])
     fin = g["merged_attach"] > -1e11
     close("merged_attach", npf(last["merged_attach"])[fin], g["merged_attach"][fin], 2e-5 if f32 else 5e-2)
@@ -1332,7 +1350,7 @@ def test_training_step_reference_wiring(path, dtype):
     heads = last["heads"].cpu().numpy()
     valid = np.concatenate([np.zeros((len(g["lengths"]), 1), bool), np.arange(g["token"].shape[1])[None] < g["lengths"][:, None]], 1)
     agree = (heads == g["predicted"])[valid].mean()
-    assert agree == 1.0 if f32 else agree >= 0.95, agree
+    assert agree == 1.0 if f32 else agree >= (0.95 if ff_dtype == torch.float32 else 0.45), agree
     assert np.array_equal(last["txt_mask"].cpu().numpy(), g["txt_mask"])
     if f32 or agree == 1.0:
         close("txt", npf(last["txt"]), g["txt"])
@@ -1373,13 +1391,12 @@ def test_training_step_reference_wiring(path, dtype):
 @pytest.mark.parametrize("dtype,nb", [(torch.float32, 24), (torch.float32, 0), (torch.bfloat16, 40)], ids=["f32_nb24", "f32_nb0", "bf16_nb40"])
 def test_parser_feed_forward_vs_module_by_module(dtype, nb):
     """vlgae_amd.parser_ff.parser_feed_forward (ONE pass of mid_ff over all rows, folded bottlenecks and linear2, fused GEMMs,
-    hand-written adjoint) against the reference's module-by-module formulation (tools/train_step.scorer_feed_forward: the restatement
+    hand-written adjoint) against the reference's module-by-module formulation (vlgae_amd.train_step.scorer_feed_forward: the restatement
     of MLP / DMVSkipConnectEncoder / DMVFactorizedBilinear.project* that the trainstep fixtures pin on the reference's own modules) in
     float64: the five outputs and the gradient w.r.t. every input and parameter.  float32: 2e-5 * max (folding W1 W0 and P W2 re-associates
     fp32 products); bf16: 3e-2 * max values, 0.2 relative L2 gradients.  The cases with a bottleneck also run with training-mode dropout
     (SharedDropout masks of the MLPs, nn.Dropout mask of mid_ff) given explicitly to both formulations."""
-    _tools_path()
-    import train_step
+    from vlgae_amd import train_step
     from vlgae_amd import parser_ff
     B, L, E, h, Et, T, H, r = 24, 11, 40, 64, 16, 9, 64, 8
     gen = torch.Generator().manual_seed(3)
@@ -1539,27 +1556,47 @@ def _reference_step_in_torch(step, P64, token, tag, vmask, drop, alpha, pen_args
     """The reference's lines for one training step (the order and the formulas of make_golden.trainstep_cases' calls: joint.py:658-711,
     ldndmv.py:171-216,277-281, fn.py:50-56) as float64 torch ops on the step's own leaves -- an independent formulation of everything
     except the structured DP itself (DMV1o marginals / heads / max come from this package's DP kernels on the torch-made potentials;
-    those kernels are parity-tested on their own at this size) and the parser's feed-forwards (tools/train_step.scorer_feed_forward:
+    those kernels are parity-tested on their own at this size) and the parser's feed-forwards (vlgae_amd.train_step.scorer_feed_forward:
     plain torch ops, pinned by the trainstep fixtures).  Returns (loss, heads)."""
-    import train_step
+    from vlgae_amd import train_step
     import vlgae_amd.torch_struct as ts
     from vlgae_amd import align
     F = torch.nn.functional
     lengths = step.lengths
-    B, L, h = P64["enc_x"].shape
-    d = P64["w2"].shape[0]
+    B, L, E = P64["emb"].shape
+    h, d = P64["w_text"].shape[0], P64["w2"].shape[0]
     N = L + 1
+    # ---- the two encoders, base.py:229 / :68: VisBoxRelSimpleEncoder.forward (box_rel.py:29-52) as written there -- the concatenated
+    # [box ; mean box] input and, for `rel`, the pairwise-mean tensor -- and MLPEncoder.forward (mlp_encoder.py:36-40) ----
+    feat = P64["vis_box_feat"]
+    R, n = feat.shape[1:]
+    inputs = torch.cat([feat, feat.mean(1, keepdim=True).expand(-1, R, -1)], -1)                   # box_rel.py:33-38
+    factors = step.batch["factors"]
+    Wv, bv = P64["w_venc"], P64["b_venc"]
+    fc = lambda k, inp: F.leaky_relu(inp @ Wv[k * h:(k + 1) * h].T + bv[k * h:(k + 1) * h], 0.01)    # MLP: Linear -> LeakyReLU (dropout 0)
+    box = fc(0, inputs)                                                                            # :47
+    parts, k = [box], 1
+    if "rel" in factors:
+        parts.append(fc(k, (inputs.unsqueeze(1) + inputs.unsqueeze(2)) / 2).view(B, R * R, h))      # :41-45
+        k += 1
+    if "attr" in factors:
+        parts.append(fc(k, inputs))                                                                # :48-49
+    if "img" in factors:
+        parts.append(box.mean(1, keepdim=True))                                                    # joint.py:163
+    vis_mid = torch.cat(parts, 1)                                                                  # joint.py:171
+    enc_drop = step.batch["enc_drop"]
+    emb_d = P64["emb"] if enc_drop is None else P64["emb"] * enc_drop.double()                     # nn.Dropout with the step's own mask
+    x = emb_d @ P64["w_text"].T                                                                    # mlp_encoder.py:39
     wmask = torch.arange(L, device=lengths.device)[None] < lengths[:, None]
     mask1 = torch.cat([wmask.new_zeros(B, 1), wmask], 1)
     D = None if drop is None else drop.double()                                                    # [B,4,d]
     We, be = P64["w_enc"], P64["b_enc"]
     lin = lambda k, inp: inp @ We[k * d:(k + 1) * d].T + be[k * d:(k + 1) * d]
-    x = P64["enc_x"]
     x1 = torch.cat([(x.masked_fill(~wmask.unsqueeze(2), 0).sum(1) / lengths.unsqueeze(1)).unsqueeze(1), x], 1)   # joint.py:204-208
-    vis = P64["vis_mid"] @ P64["w_vis"].T                                                         # :175
+    vis = vis_mid @ P64["w_vis"].T                                                                # :175
     word0 = lin(0, x1) * (1.0 if D is None else D[:, 0:1])                                        # :209 (+ SharedDropout)
     att = torch.einsum("bvd,bqd->bqv", vis, word0[:, 1:]).softmax(2)                              # :670-672
-    x_f = F.layer_norm(x + torch.einsum("bqv,bvh->bqh", att, P64["vis_mid"]), (h,), P64["ln_w"], P64["ln_b"], 1e-5)   # :673-674
+    x_f = F.layer_norm(x + torch.einsum("bqv,bvh->bqh", att, vis_mid), (h,), P64["ln_w"], P64["ln_b"], 1e-5)   # :673-674
     sx1, sx2, sy1, sy2, root_rule = train_step.scorer_feed_forward(P64, P64["emb"], x_f)          # ldndmv.py:174-205
     attach_rule = torch.einsum("bhdve,cdve->bhcdv", sx1, sx2).log_softmax(2)                      # :184
     ap = attach_rule.gather(2, token.reshape(B, 1, L, 1, 1).expand(B, L, L, 2, 2))                # :188
@@ -1597,41 +1634,62 @@ def _reference_step_in_torch(step, P64, token, tag, vmask, drop, alpha, pen_args
     return (alpha * mt + (1 - alpha) * dep) / (num + 1e-12), heads                                # joint.py:709, fn.py:56
 
 
-def test_training_step_reference_wiring_config_size():
-    """tools/train_step.build at BASELINE.json configs[4]'s size (B = 256, L = 40, V = 36, d = 128, h = 256; float32 features, the
-    reference's precision) against the reference's formulation restated in float64 torch ops on the same leaves
-    (`_reference_step_in_torch`): loss to 1e-5 relative, Viterbi heads identical, and every gradient with >= 99.99 % of its
-    elements within 3e-4 * max|g| and none beyond 5e-3 * max|g| -- at this size a handful of the 7.7 M arg-max decisions of the
-    alignment and of the 2.7 M LeakyReLU branches sit within fp32 rounding of a tie and move one term of a row's sum."""
-    _tools_path()
-    import train_step
-    B, L, V, d = 256, 40, 36, 128
-    drop = (torch.rand(4, B, d, generator=torch.Generator().manual_seed(5)) >= 0.33).float() / 0.67
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_training_step_reference_wiring_config_size(dtype):
+    """vlgae_amd.train_step.build at BASELINE.json configs[4]'s size (B = 256, L = 40, R = 36, d = 128, h = 256), from the frozen
+    features, against the reference's formulation restated in float64 torch ops on the same leaves (`_reference_step_in_torch`).
+
+    f32 (the reference's `precision: 32`; narrower feed-forwards so that the float64 side stays small): loss to 1e-5 relative, Viterbi
+    heads identical, and every gradient with >= 99.99 % of its elements within 3e-4 * max|g| and none beyond 5e-3 * max|g| -- at this
+    size a handful of the 7.7 M arg-max decisions of the alignment and of the 2.7 M LeakyReLU branches sit within fp32 rounding of a
+    tie and move one term of a row's sum.
+    bf16 (what `bench.py` times: bf16 storage of every feature, parameter and activation between kernels, fp32 accumulation, the
+    SHIPPED widths E = 800, n_vis = 2048, H = 256, n_bottleneck = 150): loss to 2e-2 relative; Viterbi heads equal on >= 90 % of the
+    words (a bf16 potential is ~3 significant digits: near-tied attachments flip); every gradient tensor within 0.35 relative L2 of
+    the float64 one (plus an absolute floor of 2e-3 * max|g| per element) -- the sentences whose tree flipped feed other parents into
+    the arc encoder and another derivation into -max, so this is a bound on the tensor, not on elements; the float32 case above is the
+    check of the mathematics."""
+    from vlgae_amd import train_step
+    B, L, R, d = 256, 40, 36, 128
+    f32 = dtype == torch.float32
+    widths = dict(E=96, Et=16, H=64, nb=24, n_vis=128) if f32 else {}
+    E = widths.get("E", 800)
+    gen = torch.Generator().manual_seed(5)
+    drop = (torch.rand(4, B, d, generator=gen) >= 0.33).float() / 0.67
+    enc_drop = (torch.rand(B, L, E, generator=gen) >= 0.33).float() / 0.67
     with torch.autograd.set_multithreading_enabled(False):
-        step = train_step.build(B, L, V, dev(), dtype=torch.float32, E=96, Et=16, H=64, nb=24, given=dict(drop=drop), seed=21,
-                                p_ff_drop=0.0, p_mid_drop=0.0)
+        step = train_step.build(B, L, R, dev(), dtype=dtype, given=dict(drop=drop, enc_drop=enc_drop), seed=21, p_ff_drop=0.0, p_mid_drop=0.0,
+                                **widths)
         loss, grads, _ = step()
         heads = step.last["heads"]
-        P64 = {k: v.detach().double().requires_grad_(True) for k, v in step.P.items()}
+        P64 = {k: v.detach().double().requires_grad_(v.requires_grad) for k, v in step.P.items()}
         bt = step.batch
         ref_loss, ref_heads = _reference_step_in_torch(step, P64, bt["token"], bt["tag"], bt["vis_mask"], drop.permute(1, 0, 2).to(dev()),
                                                        bt["alpha"], (bt["factor_names"], bt["vis_split"], bt["pos_for"]))
         ref = torch.autograd.grad(ref_loss, [P64[k] for k in step.names])
-    assert torch.equal(heads, ref_heads)
-    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    valid = torch.cat([torch.zeros(B, 1, dtype=torch.bool, device=heads.device), torch.arange(L, device=heads.device)[None] < step.lengths[:, None]], 1)
+    agree = float((heads == ref_heads)[valid].double().mean())
+    assert torch.equal(heads, ref_heads) if f32 else (agree >= 0.90), agree
+    assert abs(float(loss) - float(ref_loss)) <= (1e-5 if f32 else 2e-2) * abs(float(ref_loss)), (float(loss), float(ref_loss))
     gmax = max(float(r.abs().max()) for r in ref)
     report = {}
     for k, want in zip(step.names, ref):
         got = grads[k].double()
         if k.endswith("project2.bias"):   # a bias shared by all arguments of a (log-)softmax: its gradient is exactly zero in exact
-            assert float(got.abs().max()) <= 1e-5 * gmax and float(want.abs().max()) <= 1e-5 * gmax, k   # arithmetic, rounding noise in both
+            assert float(got.abs().max()) <= (1e-5 if f32 else 2e-3) * gmax and float(want.abs().max()) <= 1e-5 * gmax, k   # arithmetic, rounding noise in both
             continue
-        scale = max(float(want.abs().max()), 1e-6 * gmax)
-        err = (got - want).abs() / scale
-        report[k] = (float(err.max()), float((err > 3e-4).double().mean()))
-        assert float((err > 3e-4).double().mean()) <= 1e-4 and float(err.max()) <= 5e-3, (k, report[k])
-    print("config-size training step vs float64 torch formulation: loss", float(loss), float(ref_loss), "worst (max rel err, frac > 3e-4):",
-          sorted(report.items(), key=lambda kv: -kv[1][0])[:5])
+        if f32:
+            scale = max(float(want.abs().max()), 1e-6 * gmax)
+            err = (got - want).abs() / scale
+            report[k] = (float(err.max()), float((err > 3e-4).double().mean()))
+            assert float((err > 3e-4).double().mean()) <= 1e-4 and float(err.max()) <= 5e-3, (k, report[k])
+        else:
+            floor = 2e-3 * gmax * want.numel() ** 0.5
+            rel = max(float((got - want).norm()) - floor, 0.0) / max(float(want.norm()), 1e-30)
+            report[k] = (float((got - want).norm()) / max(float(want.norm()), floor), 0.0)
+            assert rel <= 0.35, (k, rel, agree)
+    print(f"config-size training step ({'f32' if f32 else 'bf16'}) vs float64 torch formulation: loss", float(loss), float(ref_loss), f"heads agree {agree:.4f};",
+          "worst:", sorted(report.items(), key=lambda kv: -kv[1][0])[:6])
 
 
 @pytest.mark.parametrize("B,L,V,d", [(6, 9, 12, 32), (256, 40, 36, 128)], ids=["toy", "config2"])
@@ -1847,6 +1905,133 @@ def test_box_rel_config_size():
     # one such flip moves a gradient entry by ~ |dout| |w| ~ 4e-3
     for k, (a, r) in enumerate(zip(*outs)):
         assert float((a - r).abs().max()) <= (2e-5 if k == 0 else 3e-3) * max(1.0, float(r.abs().max())), k
+
+
+def _vis_encoder_reference(feat, W, b, factors, slope=0.01):
+    """VisBoxRelSimpleEncoder.forward (box_rel.py:29-52) + the cat of vis_feat_unprune (joint.py:143-171) as those lines write them:
+    the concatenated [box ; mean box] input, the pairwise-mean tensor, one Linear + LeakyReLU per encoder."""
+    B, R, n = feat.shape
+    h = W.shape[0] // (1 + ("rel" in factors) + ("attr" in factors))
+    F = torch.nn.functional
+    inputs = torch.cat([feat, feat.mean(1, keepdim=True).expand(-1, R, -1)], -1)
+    fc = lambda k, inp: F.leaky_relu(inp @ W[k * h:(k + 1) * h].T + b[k * h:(k + 1) * h], slope)
+    box = fc(0, inputs)
+    parts, k = [box], 1
+    if "rel" in factors:
+        parts.append(fc(k, (inputs.unsqueeze(1) + inputs.unsqueeze(2)) / 2).view(B, R * R, h))
+        k += 1
+    if "attr" in factors:
+        parts.append(fc(k, inputs))
+    if "img" in factors:
+        parts.append(box.mean(1, keepdim=True))
+    return torch.cat(parts, 1)
+
+
+@pytest.mark.parametrize("B,R,n,H,factors,dt", [(3, 5, 24, 32, ("rel", "attr", "img"), "f32"), (4, 36, 64, 256, (), "f32"), (2, 7, 40, 64, ("rel",), "f32"),
+                                                (5, 9, 16, 128, ("attr", "img"), "f32"), (6, 36, 96, 256, ("rel", "attr", "img"), "bf16"),
+                                                (64, 36, 2048, 256, (), "bf16")])
+def test_vis_box_rel_encoder(B, R, n, H, factors, dt):
+    """encoders.vis_box_rel_encoder (one GEMM for the F encoders + one per-image GEMM + the HIP epilogue; adjoint + two split-K weight
+    gradients written into the two column halves of one tensor) against the reference's formulation in float64 torch ops: the factor
+    tensor, and the gradients w.r.t. the region features, the stacked weights and biases.  float32: 2e-5 / 5e-5 of max; bf16 storage:
+    the forward value to 2e-2 of max, gradients to 5e-2 relative L2 (LeakyReLU' flips where a bf16 pre-activation rounds across 0)."""
+    from vlgae_amd import encoders
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(B * 100 + R)
+    F_ = 1 + ("rel" in factors) + ("attr" in factors)
+    feat = (torch.randn(B, R, n, generator=g) * 0.5).to(dev(), tdt).requires_grad_(True)
+    W = (torch.randn(F_ * H, 2 * n, generator=g) * (2 * n) ** -0.5).to(dev(), tdt).requires_grad_(True)
+    b = (torch.randn(F_ * H, generator=g) * 0.1).to(dev(), tdt).requires_grad_(True)
+    mid, split, names = encoders.vis_box_rel_encoder(feat, W, b, "rel" in factors, "attr" in factors, "img" in factors)
+    V = R + ("rel" in factors) * R * R + ("attr" in factors) * R + ("img" in factors)
+    assert tuple(mid.shape) == (B, V, H) and sum(split) == V and names[0] == "obj" and mid.dtype == tdt
+    cot = torch.randn(B, V, H, generator=g).to(dev(), tdt)
+    got = torch.autograd.grad(mid, [feat, W, b], cot)
+    f64, W64, b64 = (x.detach().double().requires_grad_(True) for x in (feat, W, b))
+    ref = _vis_encoder_reference(f64, W64, b64, factors)
+    want = torch.autograd.grad(ref, [f64, W64, b64], cot.double())
+    if dt == "f32":
+        assert float((mid.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+        for name, a, w in zip(("feat", "W", "b"), got, want):
+            assert float((a.double() - w).abs().max()) <= 5e-5 * max(1.0, float(w.abs().max())), name
+    else:
+        assert float((mid.double() - ref).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
+        for name, a, w in zip(("feat", "W", "b"), got, want):
+            assert float((a.double() - w).norm()) <= 5e-2 * float(w.norm()), (name, float((a.double() - w).norm()) / float(w.norm()))
+    mid2, _, _ = encoders.vis_box_rel_encoder(feat, W, b, "rel" in factors, "attr" in factors, "img" in factors)
+    got2 = torch.autograd.grad(mid2, [feat, W, b], cot)
+    assert torch.equal(mid, mid2) and all(torch.equal(a, c) for a, c in zip(got, got2))       # fixed summation orders: bit-reproducible
+    # the mask vis_feat_unprune builds for this layout (joint.py:140-170)
+    box_mask = (torch.rand(B, R, generator=g) > 0.3).to(dev())
+    vm = encoders.factor_mask(box_mask, "rel" in factors, "attr" in factors, "img" in factors)
+    assert tuple(vm.shape) == (B, V) and torch.equal(vm[:, :R], box_mask)
+    if "rel" in factors:
+        rel = (box_mask.unsqueeze(1) * box_mask.unsqueeze(2)).triu(1).view(B, -1)
+        assert torch.equal(vm[:, R:R + R * R], rel)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_mlp_encoder_and_counter_based_dropout(dt):
+    """encoders.mlp_encoder = MLPEncoder.forward (mlp_encoder.py:36-40).  (i) With an explicit nn.Dropout mask: value and gradients
+    against float64 torch ops on the same mask.  (ii) With the counter-based draw (DeviceRng): the result is x * m @ W^T for SOME mask m
+    with entries in {0, 1/(1-p)} (recovered by running the same draw on a tensor of ones), the backward pass regenerates the SAME mask
+    (d_emb = (g W) * m exactly as recomputed from m), the keep rate is 1 - p within 4 sigma, `advance()` changes the mask, two sites
+    draw different masks from one state, and a re-created generator with the same seed reproduces the bits."""
+    from vlgae_amd import encoders
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    B, L, E, h, p = 16, 40, 800, 256, 0.33
+    g = torch.Generator().manual_seed(4)
+    emb = (torch.randn(B, L, E, generator=g) * 0.5).to(dev(), tdt).requires_grad_(True)
+    W = (torch.randn(h, E, generator=g) * E ** -0.5).to(dev(), tdt).requires_grad_(True)
+    cot = torch.randn(B, L, h, generator=g).to(dev(), tdt)
+    mask = ((torch.rand(B, L, E, generator=g) >= p).float() / (1 - p)).to(dev())
+    tol = 1e-5 if dt == "f32" else 2e-2
+    # (i) explicit mask
+    x = encoders.mlp_encoder(emb, W, p, mask=mask)
+    ge, gw = torch.autograd.grad(x, [emb, W], cot)
+    e64, W64 = emb.detach().double().requires_grad_(True), W.detach().double().requires_grad_(True)
+    ref = (e64 * mask.double()) @ W64.T
+    re, rw = torch.autograd.grad(ref, [e64, W64], cot.double())
+    for name, a, w in (("x", x, ref), ("d_emb", ge, re), ("d_W", gw, rw)):
+        assert float((a.double() - w).abs().max()) <= tol * max(1.0, float(w.abs().max())), name
+    # eval mode: the Linear alone
+    assert float((encoders.mlp_encoder(emb, W, p, training=False).double() - e64 @ W64.T).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    # (ii) counter-based draw
+    rng = encoders.DeviceRng(1234, dev())
+    ones = torch.ones(B, L, E, device=dev(), dtype=torch.float32)
+    m0 = encoders.dropout(ones, p, rng=rng, site=encoders.SITE_TEXT_ENCODER)
+    vals = torch.unique(m0)
+    thr = round(p * 65536)
+    scale = 1.0 / (1.0 - thr / 65536.0)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - scale) < 1e-6
+    keep = float((m0 != 0).double().mean())
+    n_el = B * L * E
+    assert abs(keep - (1 - p)) <= 4 * (p * (1 - p) / n_el) ** 0.5 + 2.0 ** -16, keep
+    x = encoders.mlp_encoder(emb, W, p, rng=rng)
+    ge, gw = torch.autograd.grad(x, [emb, W], cot)
+    ref = (e64 * m0.double()) @ W64.T
+    re, rw = torch.autograd.grad(ref, [e64, W64], cot.double())
+    for name, a, w in (("x", x, ref), ("d_emb", ge, re), ("d_W", gw, rw)):
+        assert float((a.double() - w).abs().max()) <= tol * max(1.0, float(w.abs().max())), "rng " + name
+    assert torch.equal(ge == 0, (m0 == 0) | (ge == 0))                      # dropped elements get exactly zero gradient
+    m_other_site = encoders.dropout(ones, p, rng=rng, site=encoders.SITE_MID_FF)
+    assert not torch.equal(m_other_site, m0) and abs(float(((m_other_site != 0) & (m0 != 0)).double().mean()) - (1 - p) ** 2) < 5e-3   # independent
+    rng.advance()
+    m1 = encoders.dropout(ones, p, rng=rng, site=encoders.SITE_TEXT_ENCODER)
+    assert not torch.equal(m1, m0)
+    rng2 = encoders.DeviceRng(1234, dev())
+    assert torch.equal(encoders.dropout(ones, p, rng=rng2, site=encoders.SITE_TEXT_ENCODER), m0)
+    rng2.advance()
+    assert torch.equal(encoders.dropout(ones, p, rng=rng2, site=encoders.SITE_TEXT_ENCODER), m1)
+    # SharedDropout ([B,1,E] masks, nn/dropout.py:52-53) through the same kernel
+    sm = ((torch.rand(B, E, generator=g) >= 0.2).float() / 0.8).to(dev())
+    xs = encoders.dropout(emb, 0.0, mask=sm, shared_rows=L)
+    assert float((xs.double() - emb.detach().double() * sm.double().unsqueeze(1)).abs().max()) <= (1e-6 if dt == "f32" else 2.0 ** -8 * 4)
+    # argument checks
+    with pytest.raises(ValueError):
+        encoders.dropout(emb, p)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        encoders.mlp_encoder(emb.detach().cpu(), W.detach().cpu(), p, training=False)
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU (RCCL)

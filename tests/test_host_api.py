@@ -97,17 +97,12 @@ def test_shard_bounds():
 
 
 def test_bench_train_shapes_match_the_step_and_parser_ff_names():
-    """The dry-run stand-in of the sharded training step (tools/bench_train._param_shapes) must list exactly the trainable leaves of
-    tools/train_step.build with their shapes, and vlgae_amd.parser_ff.param_names must cover every "ff." parameter -- otherwise the
-    gloo plumbing tests would exercise a different flat-gradient layout than the GPU run."""
-    import os
-    import sys
+    """The dry-run stand-in of the sharded training step (vlgae_amd.bench.sharded_step._param_shapes) must list exactly the trainable
+    leaves of vlgae_amd.train_step.build with their shapes, and vlgae_amd.parser_ff.param_names must cover every "ff." parameter --
+    otherwise the gloo plumbing tests would exercise a different flat-gradient layout than the GPU run."""
     import torch
-    from conftest import ROOT
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import bench_train
-    import train_step
-    from vlgae_amd import parser_ff
+    from vlgae_amd import parser_ff, train_step
+    from vlgae_amd.bench import sharded_step as bench_train
     f = bench_train.FF_SHAPES
     P = train_step.init_feed_forward(torch.Generator().manual_seed(0), torch.device("cpu"), torch.float32, f["E"], f["h"], f["Et"], f["T"],
                                      f["H"], f["nb"], f["r"])
@@ -119,7 +114,31 @@ def test_bench_train_shapes_match_the_step_and_parser_ff_names():
     assert set(parser_ff.param_names(0)) == {k for k in train_step.init_feed_forward(torch.Generator().manual_seed(0), torch.device("cpu"),
                                                                                     torch.float32, 8, 8, 8, 3, 8, 0, 4) if k.startswith("ff.")}
     assert sorted(k for g in groups for k in g) == sorted(shapes)          # the readiness groups partition the trainable leaves
-    assert groups[0] == ["w1", "w2", "b"] and "w_vis" in groups[2]
+    assert groups[0] == ["w1", "w2", "b"] and "w_vis" in groups[2] and groups[3] == ["w_text", "w_venc", "b_venc"]
+    # the two encoders in front of the step: MLPEncoder.linear [h, E] without bias, the visual encoder's stacked [F h, 2 n] / [F h]
+    assert shapes["w_text"] == (f["h"], f["E"]) and shapes["w_venc"] == (f["h"], 2 * bench_train.N_VIS) and shapes["b_venc"] == (f["h"],)
+    # every float of the shipped model's path is in the all-reduced buffer: 6.48 M parameters = 25.9 MB (SURVEY.md section 8e says ~7 M)
+    n_model = sum(int(torch.Size(s).numel()) for s in bench_train._param_shapes(n_enc=3)[0].values())
+    assert 6.3e6 < n_model < 7.5e6, n_model
+
+
+def test_parser_ff_refuses_unsupported_widths():
+    """n_mid != hidden_size or unequal scorer ranks are valid reference configurations that the fused pass does not cover --
+    it must refuse them by shape (no GPU needed: the check runs before any kernel)."""
+    import pytest
+    import torch
+    from vlgae_amd import parser_ff, train_step
+    P = train_step.init_feed_forward(torch.Generator().manual_seed(0), torch.device("cpu"), torch.float32, 16, 8, 8, 3, 8, 0, 4)
+    P = {k: v.detach() for k, v in P.items()}
+    parser_ff._validate_shapes(P, 0, 8, 24)
+    bad = dict(P)
+    bad["ff.mid_ff.linear1.weight"] = torch.zeros(12, 8)                     # n_mid = 12 != hidden_size
+    with pytest.raises(ValueError, match="n_mid == hidden_size"):
+        parser_ff._validate_shapes(bad, 0, 8, 24)
+    bad = dict(P)
+    bad["ff.dec_scorer.project1.weight"] = torch.zeros(6, 8)                 # dec_rank != attach_rank
+    with pytest.raises(ValueError, match="one rank shared"):
+        parser_ff._validate_shapes(bad, 0, 8, 24)
 
 
 def test_drop_in_import_selects_backward_on_the_calling_thread():

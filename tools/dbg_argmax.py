@@ -18,15 +18,26 @@ def run(B, L, V, with_pen, masked, seed=0):
     pen = seg = None
     if with_pen:
         pen = t((rng.integers(0, 3, (B, Q, 3)) * 100.0).astype(np.float32)); seg = t(rng.integers(0, 3, V).astype(np.uint8))
-    out = []
-    for old in ("1", ""):
-        if old: os.environ["VLG_ALIGN_ARGMAX_OLD"] = "1"
-        else: os.environ.pop("VLG_ALIGN_ARGMAX_OLD", None)
-        with torch.no_grad():
-            total, sums = align.grounding_loss_factor_ce(txt, vis, t(tmask), t(vmask), marg, int(lengths.sum()), 1.0, pen, seg)
-        out.append(sums.cpu().numpy())
-    print(B, L, V, 'pen' if with_pen else '-', 'masked' if masked else '-', out[0], out[1], 'OK' if np.allclose(out[0], out[1], rtol=1e-5) else 'DIFF')
-for B, L, V in ((6, 40, 36), (8, 40, 36), (16, 20, 36), (6, 40, 32)):
-    for wp in (False, True):
-        for mk in (False, True):
-            run(B, L, V, wp, mk)
+    with torch.no_grad():
+        total, sums = align.grounding_loss_factor_ce(txt, vis, t(tmask), t(vmask), marg, int(lengths.sum()), 1.0, pen, seg)
+    return sums.cpu().numpy().tolist()
+
+
+SHAPES = ((6, 40, 36), (8, 40, 36), (16, 20, 36), (6, 40, 32))
+CASES = [(B, L, V, wp, mk) for B, L, V in SHAPES for wp in (False, True) for mk in (False, True)]
+if os.environ.get("VLG_DBG_ARGMAX_CHILD"):
+    # one kernel variant per PROCESS: the VLG_* switches are read once per process (VLG_ENV, csrc/vlg_common.h), so toggling
+    # os.environ between two calls of one process compares a kernel with itself
+    import json
+    print(json.dumps([run(*c) for c in CASES]))
+    sys.exit(0)
+import json, subprocess
+res = {}
+for old in ("1", ""):
+    env = dict(os.environ, VLG_DBG_ARGMAX_CHILD="1")
+    env.pop("VLG_ALIGN_ARGMAX_OLD", None)
+    if old:
+        env["VLG_ALIGN_ARGMAX_OLD"] = "1"
+    res[old] = json.loads(subprocess.run([sys.executable, __file__], env=env, check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])
+for c, a, b in zip(CASES, res["1"], res[""]):
+    print(*c, a, b, 'OK' if np.allclose(a, b, rtol=1e-5) else 'DIFF')

@@ -3,7 +3,7 @@
 import sys
 import torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
-import train_step
+from vlgae_amd import train_step
 from vlgae_amd import align
 import vlgae_amd.torch_struct as ts
 dev = torch.device('cuda:0')

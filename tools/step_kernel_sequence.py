@@ -9,12 +9,16 @@ import os
 f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)   # the newest run in the directory
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-marks = [i for i, n in enumerate(names) if "attn_fuse_mfma_kernel" in n]     # once per step
-a, b = marks[-2], marks[-1]
-back = 0
-while back < 40 and "attn_fuse_bwd" not in names[a - back - 1] and "gemm_reduce" not in names[a - back - 1]:
-    back += 1                                                                    # the step starts behind the previous step's last adjoint
-seq = rows[a - back:b - back]
+ends = [i for i, n in enumerate(names) if "rng_advance_kernel" in n]             # round 5: the step's LAST launch (the dropout generator's step counter)
+if len(ends) >= 2:
+    seq = rows[ends[-2] + 1:ends[-1] + 1]
+else:                                                                            # round 3's chain (no encoders in front): once-per-step marker + walk back
+    marks = [i for i, n in enumerate(names) if "attn_fuse_mfma_kernel" in n]
+    a, b = marks[-2], marks[-1]
+    back = 0
+    while back < 40 and "attn_fuse_bwd" not in names[a - back - 1] and "gemm_reduce" not in names[a - back - 1]:
+        back += 1                                                                # the step starts behind the previous step's last adjoint
+    seq = rows[a - back:b - back]
 
 
 def short(n):

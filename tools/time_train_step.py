@@ -1,11 +1,13 @@
-"""Eager vs HIP-graph timing of the chained training-step hot path (tools/train_step.py) + host-side profile."""
+"""Eager vs HIP-graph timing of the training step (vlgae_amd/train_step.py) + host-side profile.
+    python tools/time_train_step.py [B L R] [--f32] [--r3] [--shipped: factors rel attr img, i.e. 1369 columns at R = 36] [--profile]"""
 import sys, time, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
-import train_step
+from vlgae_amd import train_step
 dev = torch.device('cuda:0')
 pos = [a for a in sys.argv[1:] if not a.startswith('--')]
 B, L, V = (int(pos[0]), int(pos[1]), int(pos[2])) if len(pos) > 2 else (256, 40, 36)
-step = train_step.build(B, L, V, dev, wiring='r3' if '--r3' in sys.argv else 'reference', dtype=torch.float32 if '--f32' in sys.argv else torch.bfloat16)
+kw = dict(factors=('rel', 'attr', 'img')) if '--shipped' in sys.argv else {}
+step = train_step.build(B, L, V, dev, wiring='r3' if '--r3' in sys.argv else 'reference', dtype=torch.float32 if '--f32' in sys.argv else torch.bfloat16, **kw)
 for _ in range(5): step()
 torch.cuda.synchronize()
 def wall(fn, n):

@@ -1,6 +1,6 @@
 import sys, time, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
-import train_step
+from vlgae_amd import train_step
 torch.autograd.set_multithreading_enabled(False)
 dev = torch.device('cuda:0')
 for dt in (torch.bfloat16, torch.float32):

@@ -8,7 +8,7 @@ tun.tuning_enable(True)
 tun.set_max_tuning_duration(30)        # ms per solution
 tun.set_max_tuning_iterations(20)
 tun.set_filename("gpurun_out/tunableop_results.csv")
-import train_step
+from vlgae_amd import train_step
 dev = torch.device('cuda:0')
 step = train_step.build(256, 40, 36, dev, dtype=torch.bfloat16)
 t0 = time.perf_counter()

@@ -57,7 +57,11 @@ SIGNATURES = {
     "vlg_box_rel_pairwise_backward_workspace": (_sz, [_i, _i, _i]),
     "vlg_box_rel_pairwise_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "vlg_linear_wgrad_workspace": (_sz, [_i, _i, _i]),
-    "vlg_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp, _vp, _vp]),
+    "vlg_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _i, _vp, _i, _vp, _vp, _vp]),
+    "vlg_dropout": (_i, [_vp, _vp, _i, _vp, ctypes.c_uint, _f, _vp, _vp, _ll, _i, _i, _i, _vp]),
+    "vlg_rng_advance": (_i, [_vp, _vp]),
+    "vlg_vis_encoder": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "vlg_vis_encoder_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "vlg_langfeat_root_cat": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_langfeat_root_cat_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_langfeat_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
@@ -87,6 +91,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 140   # what include/vlgae_amd.h declares at this revision; lib() refuses any other library (argument lists differ between versions)
 
 
 def lib():
@@ -104,6 +109,12 @@ def lib():
                 continue
             fn = getattr(handle, name)   # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
+        # same symbol names, different argument lists across ABI versions: an older library (a tools/_v A/B variant through VLGAE_AMD_LIB, a
+        # stale build) would be called with the wrong pointers and strides -- refuse it, in partial mode too
+        got = handle.vlg_version() if hasattr(handle, "vlg_version") else None
+        if got != ABI_VERSION:
+            raise RuntimeError(f"vlgae_amd: {LIB_PATH} has ABI version {got}, this package binds version {ABI_VERSION}: rebuild it "
+                               "(`python -m vlgae_amd.build --force`; A/B variants: tools/build_variant.sh from this tree)")
         _lib = handle
     return _lib
 

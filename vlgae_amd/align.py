@@ -570,11 +570,13 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None, out_dtype
         dw, db = out
         out_dtype = dw.dtype
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
-    if out_dtype not in (torch.float32, torch.bfloat16) or (db is not None and db.dtype != out_dtype) or not dw.is_contiguous():
-        raise ValueError(f"linear_wgrad: outputs must be contiguous float32 or bfloat16 of one type, got {dw.dtype} / {None if db is None else db.dtype}")
+    if (out_dtype not in (torch.float32, torch.bfloat16) or (db is not None and db.dtype != out_dtype) or tuple(dw.shape) != (M, N)
+            or dw.stride(1) != 1 or dw.stride(0) < N):
+        raise ValueError(f"linear_wgrad: outputs must be float32 or bfloat16 of one type, d_weight [out, in] with unit column stride (a column "
+                         f"block of a wider gradient is fine), got {dw.dtype} {tuple(dw.shape)} {dw.stride()} / {None if db is None else db.dtype}")
     _C.check(_C.lib().vlg_linear_wgrad(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, _C.ptr(ws), nbytes,
                                        _C.BF16 if out_dtype == torch.bfloat16 else _C.F32,
-                                       _C.ptr(dw), None if want_x_colsum else _C.ptr(db), _C.ptr(db) if want_x_colsum else None,
+                                       _C.ptr(dw), dw.stride(0), None if want_x_colsum else _C.ptr(db), _C.ptr(db) if want_x_colsum else None,
                                        _C.stream_of(dy)), "linear_wgrad")
     return dw, db
 

@@ -97,7 +97,7 @@ def kernel_evidence():
         import glob
         import json
         import os
-        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles")   # <repo>/profiles
         files = sorted(glob.glob(os.path.join(root, "r*_kernels.json")))
         _KERNEL_EVIDENCE = (None, {}) if not files else (os.path.basename(files[-1]), json.load(open(files[-1])))
     return _KERNEL_EVIDENCE
@@ -130,9 +130,6 @@ def run_all(out, args, h, dev):
 
 
 def _run_all(out, args, h, dev):
-    import os
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import vlgae_amd.torch_struct as ts
     from vlgae_amd.torch_struct import functional as Fn
     from vlgae_amd import align
@@ -305,7 +302,7 @@ def _run_all(out, args, h, dev):
     except Exception as e:
         out["round3_entries_error"] = repr(e)[:300]
 
-    # ---- configs[4]: the chained training-step hot path (tools/train_step.py), eager and as one captured HIP graph ----
+    # ---- configs[4]: the chained training-step hot path (vlgae_amd/train_step.py), eager and as one captured HIP graph ----
     try:
         out["train_step"] = train_step_entry(B, L, V, in_dtype, dev)
     except Exception as e:   # a capture failure must not cost the headline line
@@ -378,12 +375,13 @@ def round3_entries(B, L, dtype, dev, g):
     return res
 
 
-def train_step_entry(B, L, V, dtype, dev, wiring="reference"):
-    """configs[4]: tools/train_step.build -- the function tests/test_gpu_parity.py::test_training_step_reference_wiring pins on
-    fixtures made by the reference's own methods -- eager and as one captured HIP graph.  wiring="r3": round 3's chain (bench
-    continuity only; it is not what the reference wires)."""
-    import train_step
-    step = train_step.build(B, L, V, dev, dtype=dtype, wiring=wiring)
+def train_step_entry(B, L, V, dtype, dev, wiring="reference", factors=()):
+    """configs[4]: vlgae_amd.train_step.build -- the function tests/test_gpu_parity.py::test_training_step_reference_wiring pins on
+    fixtures made by the reference's own methods, from the frozen features to every trainable gradient -- eager and as one captured
+    HIP graph.  factors: the visual factors beside the objects (the shipped model: rel, attr, img = 1369 columns at 36 regions).
+    wiring="r3": round 3's chain (bench continuity only; it is not what the reference wires)."""
+    from vlgae_amd import train_step
+    step = train_step.build(B, L, V, dev, dtype=dtype, wiring=wiring, factors=factors)
     for _ in range(5):
         step()
 
@@ -397,8 +395,9 @@ def train_step_entry(B, L, V, dtype, dev, wiring="reference"):
         return (time.perf_counter() - t0) / n * 1e3, (t1 - t0) / n * 1e3
     eager_ms, enqueue_ms = wall(step, 30)
     if wiring == "reference":
-        what = ("one training step as the reference wires it (base.py:215-241, joint.py:658-711, ldndmv.py:171-216,260-285, fn.py:50-56): "
-                "vis_mlp_pre_matching -> lang_feat_word_only -> attention fuse -> [fused x] context mean + the parser's feed-forwards "
+        what = ("one training step as the reference wires it (base.py:215-241, joint.py:658-711, ldndmv.py:171-216,260-285, fn.py:50-56), from "
+                "the FROZEN features: VisBoxRelSimpleEncoder (box_fc" + ("".join(f" | {f}_fc" for f in factors if f != "img")) + " on [box ; mean box], 2048-d "
+                "region features) + MLPEncoder (nn.Dropout p=0.33 drawn per step + Linear 800->256) -> vis_mlp_pre_matching -> lang_feat_word_only -> attention fuse -> [fused x] context mean + the parser's feed-forwards "
                 "(vlgae_amd.parser_ff: head_ff / mid_ff / scorer projections, E=800 H=256 n_bottleneck=150 r=16, their dropout 0.33 / 0.3 drawn per step) -> score construction -> "
                 "[un-fused x] lang_feat_max_tree (DMV1o marginals || one Viterbi pass, word|child|parent encoders with SharedDropout p=0.33 "
                 "drawn per step, arc encoder) -> alignment maxima with the POS prior + grounding cross-entropies (ragged vis_mask) -> "
@@ -408,8 +407,8 @@ def train_step_entry(B, L, V, dtype, dev, wiring="reference"):
                 "features as leaves, no prior / dropout / alpha): score construction -> attention_fuse -> lang_feat_max_tree -> "
                 "grounding loss -> -DMV1o.max -> gradients")
     res = {"eager_ms": eager_ms, "host_enqueue_ms": enqueue_ms, "wiring": wiring,
-           "what": what + f" (tools/train_step.py), B={B} L={L} V={V} d=128 h=256, synthetic encoder outputs (frozen BERT / Faster-RCNN "
-                          "weights are not in the container)",
+           "what": what + f" (vlgae_amd/train_step.py), B={B} L={L} R={V} regions, {getattr(step, 'shape', {}).get('V', V)} factor columns, d=128 h=256, "
+                          "synthetic frozen features: random 800-d embeddings / 2048-d region features (BERT / Faster-RCNN weights are not in the container)",
            "sentences_per_s_eager": B / (eager_ms * 1e-3)}
     gr = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream(device=dev)
@@ -426,8 +425,13 @@ def train_step_entry(B, L, V, dtype, dev, wiring="reference"):
     res.update(graph_ms=graph_ms, sentences_per_s_graph=B / (graph_ms * 1e-3),
                note="graph replay has no host work between kernels: graph_ms is the device time of the chain; "
                     "eager_ms - graph_ms is what the Python / autograd host path still costs")
-    if wiring == "reference":
+    if wiring == "reference" and not factors:
         del gr, step
+        try:   # the same step at the shipped factor layout (add_rel / add_attr / add_image, B = 64 as config/data/vlparse.yaml:24-27 batches it)
+            c = train_step_entry(64, L, V, dtype, dev, factors=("rel", "attr", "img"))
+            res["shipped_factor_layout"] = {k: c[k] for k in ("graph_ms", "eager_ms", "sentences_per_s_graph", "what")}
+        except Exception as e:
+            res["shipped_factor_layout"] = {"error": repr(e)[:200]}
         try:   # the parser's feed-forwards alone (forward + backward), for the breakdown
             res["parser_feed_forward"] = parser_ff_ms(B, L, dtype, dev)
         except Exception as e:
@@ -443,7 +447,7 @@ def train_step_entry(B, L, V, dtype, dev, wiring="reference"):
 def parser_ff_ms(B, L, dtype, dev, E=800, h=256, Et=32, T=45, H=256, nb=150, r=16):
     """The parser's feed-forwards (ldndmv.py:174-205), forward + backward: vlgae_amd.parser_ff against the module-by-module torch
     formulation the reference's modules amount to."""
-    import train_step
+    from vlgae_amd import train_step
     from vlgae_amd import parser_ff
     g = torch.Generator().manual_seed(3)
     P = train_step.init_feed_forward(g, dev, dtype, E, h, Et, T, H, nb, r)

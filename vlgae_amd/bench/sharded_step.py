@@ -1,38 +1,37 @@
-"""bench.py --workload train_step: one training step (BASELINE.json configs[4], tools/train_step.py in the reference's wiring) sharded
-data-parallel.
+"""bench.py --workload train_step: one training step (BASELINE.json configs[4], vlgae_amd/train_step.py in the reference's wiring, from
+the frozen features) sharded data-parallel.
 
 Every rank builds its own shard of the step (B sentences / GPU, rank-specific synthetic batch -- the
-`ConstantTokenNumSampler(rank=, world_size=)` arrangement: rank r takes batches r, r+W, ...), runs forward + backward and all-reduces a
-flat fp32 gradient of the VLGAE model's size (--grad-mb, ~7 M fp32 = 28 MB) over RCCL with synchronous-SGD semantics and
-DDP's averaging -- every bucket is complete (stream-wise) before the next step's first kernel, as under Lightning DDP (/root/reference
-config/trainer/train.yaml:27-29, src/pipeline.py:112-126).  The REAL gradients of the step's parameters (arc encoder, the parser's
-feed-forwards and scorers, LayerNorm, word | child | parent encoders, vis_mlp_pre_matching: ~3.4 M floats) sit in `--buckets` pieces in
-the order they become final during the backward pass (tools/train_step.py `ready_groups`), and a piece starts reducing from a leaf hook
-the moment its last gradient exists, overlapping the adjoints still to run.  The rest of the buffer is filler for the parameters upstream
-of the encoder outputs the step starts from (embedding / encoder MLP): their backward is not part of the step, so they ride in the LAST
-piece, where nothing overlaps them.
+`ConstantTokenNumSampler(rank=, world_size=)` arrangement: rank r takes batches r, r+W, ...), runs forward + backward and all-reduces the
+flat fp32 gradient of EVERY trainable parameter of the VLGAE model (~7 M fp32 = 28 MB, SURVEY.md 8e: the text encoder, the visual encoder's
+box_fc / rel_fc / attr_fc, vis_mlp_pre_matching, LayerNorm, word | child | parent encoders, arc encoder, the parser's feed-forwards and
+scorers) over RCCL with synchronous-SGD semantics and DDP's averaging -- every bucket is complete (stream-wise) before the next step's
+first kernel, as under Lightning DDP (/root/reference config/trainer/train.yaml:27-29, src/pipeline.py:112-126).  Every float of the
+buffer is a gradient the step computed (round 5: the step starts at the frozen features, so no stand-in filler is left); the gradients
+sit in `--buckets` pieces in the order they become final during the backward pass (train_step `ready_groups`), and a piece starts
+reducing from a leaf hook the moment its last gradient exists, overlapping the adjoints still to run.  At the object-factor-only layout
+of BASELINE.json configs[1] (R = 36 region columns) the model's rel_fc / attr_fc receive no gradient -- they ride along as the zeros DDP
+all-reduces for unused parameters (`find_unused_parameters`), so that the collective has the shipped model's size at either layout.
 
 Reported: value (sentences/s, whole job), step_ms (with the collectives), compute_ms (same step, no collective),
 allreduce_ms (the pieces alone, back to back), overlap_frac = 1 - (step_ms - compute_ms) / allreduce_ms.
 """
-import os
-import sys
 import time
 
 import torch
 import torch.distributed as dist
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-if HERE not in sys.path:
-    sys.path.insert(0, HERE)
-
 FF_SHAPES = dict(E=800, h=256, Et=32, T=45, H=256, nb=150, r=16)   # the parser's feed-forwards at the shipped widths (vlgae.yaml)
+N_VIS = 2048                                                        # Faster-RCNN region feature width (vis_encoder.n_in, vlgae.yaml:29)
+MODEL_VIS_ENCODERS = 3                                              # box_fc, rel_fc, attr_fc of the shipped model (use_attr: true)
 
 
-def _param_shapes(d=128, h=256):
-    """name -> shape of every trainable leaf of train_step.build(wiring="reference"), and the readiness groups (no GPU needed)."""
+def _param_shapes(d=128, h=256, n_enc=1):
+    """name -> shape of every trainable leaf of train_step.build(wiring="reference") with n_enc visual-encoder MLPs on the path, and the
+    readiness groups (no GPU needed)."""
     f = FF_SHAPES
     shapes = dict(b=(d,), b_enc=(3 * d,), ln_b=(h,), ln_w=(h,), w1=(d, d, d), w2=(d, d), w_enc=(3 * d, h), w_vis=(d, h),
+                  w_text=(h, f["E"]), w_venc=(n_enc * h, 2 * N_VIS), b_venc=(n_enc * h,),
                   token_emb=(f["T"], f["Et"]), root_emb=(1, 10), dec_emb=(2, 10))
 
     def lin(name, n_in, n_out):
@@ -48,7 +47,7 @@ def _param_shapes(d=128, h=256):
         lin(f"ff.{name}.project1", f["H"], f["r"])
         lin(f"ff.{name}.project2", f["H"], f["r"])
     ff_names = sorted(k for k in shapes if k.startswith("ff.") or k in ("token_emb", "root_emb", "dec_emb"))
-    return shapes, (["w1", "w2", "b"], ff_names, ["ln_w", "ln_b", "w_enc", "b_enc", "w_vis"])
+    return shapes, (["w1", "w2", "b"], ff_names, ["ln_w", "ln_b", "w_enc", "b_enc", "w_vis"], ["w_text", "w_venc", "b_venc"])
 
 
 class _DryStep:
@@ -92,15 +91,16 @@ def _all_ranks_ok(ok, world, dev, dry):
 
 def _measure(args, rank, world, dev, dry, barrier):
     from vlgae_amd import dist as vdist
-    import train_step
+    from vlgae_amd import train_step
     B, L, V = args.batch, args.L, args.regions
+    factors = tuple(getattr(args, "factors", ()) or ())
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     step, err = None, None
     try:
         if dry:
             step = _DryStep(B, L)
         else:
-            step = train_step.build(B, L, V, dev, dtype=dtype, seed=11 + rank, **FF_SHAPES)
+            step = train_step.build(B, L, V, dev, dtype=dtype, seed=11 + rank, factors=factors, n_vis=N_VIS, **FF_SHAPES)
             step()                                         # one untimed step: every kernel and allocation path exercised
     except Exception as e:                                 # noqa: BLE001 -- reported on every rank below
         err = e
@@ -121,8 +121,12 @@ def _measure(args, rank, world, dev, dry, barrier):
             o += numel(k)
         bounds.append([lo, o])
     n_real = o - 1
-    n_model = max(o, int(args.grad_mb * 1e6 / 4))
-    bounds[-1][1] = n_model                                 # filler: see json_line / DESIGN.md section 4
+    # the visual-encoder MLPs of the shipped model that this factor layout does not reach (rel_fc / attr_fc at the object-only layout):
+    # no gradient, all-reduced as zeros like DDP's unused parameters -- the buffer has the model's size at either layout
+    n_enc = shapes["w_venc"][0] // shapes["w_text"][0]
+    n_unused = (MODEL_VIS_ENCODERS - n_enc) * (shapes["w_venc"][0] // n_enc) * (shapes["w_venc"][1] + 1)
+    n_model = o + max(0, n_unused)
+    bounds[-1][1] = n_model
     red = vdist.BucketedGradReducer(n_model, dev, bounds=[tuple(b) for b in bounds], average=True)
     check = bounds[-1][0]
     views = {k: red.flat[off:off + numel(k)] for k, off in offsets.items()}
@@ -205,10 +209,10 @@ def _measure(args, rank, world, dev, dry, barrier):
                        "semantics": "synchronous SGD, gradients AVERAGED over ranks (DDP): every bucket of step k is reduced "
                                     "(stream-ordered) before step k+1's first kernel; a bucket starts from inside the backward pass "
                                     "the moment the last of ITS parameters' gradients exists (leaf hooks)",
-                       "payload": f"{n_real} real gradient floats of the parameters on the step's path, in readiness order; the "
-                                  f"remaining {n_model - n_real - 1} floats of the last bucket are FILLER standing for the model's parameters "
-                                  "upstream of the encoder outputs this step starts from (their backward compute is not part of the "
-                                  "step, so nothing overlaps them: they go last, as their gradients would)"}
+                       "payload": f"{n_real} gradient floats, one per trainable parameter the step reaches (text encoder, visual encoder, "
+                                  "vis_mlp_pre_matching, LayerNorm, word | child | parent encoders, arc encoder, parser feed-forwards and scorers), "
+                                  f"in readiness order; + {n_model - n_real - 1} zeros for the shipped model's visual-encoder MLPs this factor "
+                                  "layout does not reach (DDP all-reduces unused parameters as zeros); no filler"}
     else:
         el = el_compute
         step_ms = compute_ms = el * 1e3 / args.steps
@@ -224,15 +228,16 @@ def json_line(args, world, res, dry, share=False):
            "ms_per_step": res["step_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype,
            "data": "synthetic" if not dry else "DRY RUN: no kernels ran (launcher / collective plumbing on CPU, gloo); not a measurement",
-           "config": {"workload": "one training step as the reference wires it (tools/train_step.py, pinned on reference-made fixtures): "
-                                  "attention fuse -> parser feed-forwards -> score construction -> DMV1o marginals + Viterbi heads -> "
-                                  "word | child | parent encoders + arc encoder -> alignment maxima + grounding cross-entropy -> "
-                                  f"-DMV1o.max -> 0.5/0.5 -> gradients; B={B}/GPU L={L} V={V} d=128 h=256, {args.dtype} features, "
-                                  "synthetic encoder outputs; BASELINE.json configs[4]",
+           "config": {"workload": "one training step as the reference wires it (vlgae_amd/train_step.py, pinned on reference-made fixtures), from "
+                                  "the frozen features: text encoder (dropout + Linear 800->256) + visual encoder (box_fc [; rel_fc; attr_fc] on "
+                                  "2048-d region features) -> attention fuse -> parser feed-forwards -> score construction -> DMV1o marginals + "
+                                  "Viterbi heads -> word | child | parent encoders + arc encoder -> alignment maxima + grounding cross-entropy -> "
+                                  f"-DMV1o.max -> 0.5/0.5 -> gradients of every trainable parameter; B={B}/GPU L={L} R={V} d=128 h=256, "
+                                  f"{args.dtype} storage, synthetic frozen features (random 800-d embeddings / 2048-d region features); BASELINE.json configs[4]",
                       "global_batch": B * world, "seq_len": L,
                       "parallelism": (f"dp{world}" if world > 1 else "single") + (" (DEBUG: ranks share one GPU, gloo)" if share else ""),
                       "allreduce_floats": res["allreduce_floats"]},
-           "compute_ms": res["compute_ms"], "step_ms": res["step_ms"]}
+           "compute_ms": res["compute_ms"], "step_ms": res["step_ms"], "real_gradient_floats": res["real_gradient_floats"]}
     if "comm" in res:
         out["comm"] = res["comm"]
     if dry:

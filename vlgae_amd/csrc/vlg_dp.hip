@@ -279,11 +279,9 @@ size_t vlg_workspace_bytes(int op, int B, int N, int semiring) {
     switch (op) {
         case VLG_OP_DMV1O_INSIDE:
             return DmvLayout(N, false, is_max, pick_mode<DmvLayout>(N, false, is_max, kLdsBudget)).ws_bytes * B;
-        case VLG_OP_DMV1O_INSIDE_OUTSIDE: {   // covers both the replay layout and (Max, tree only) the leaner walk layout
-            const size_t full = DmvLayout(N, true, is_max, pick_mode<DmvLayout>(N, true, is_max, kLdsBudget)).ws_bytes;
-            const size_t lean = is_max ? DmvLayout(N, true, true, pick_mode<DmvLayout>(N, true, true, kLdsBudget, true), true).ws_bytes : 0;
-            return (full > lean ? full : lean) * B;
-        }
+        case VLG_OP_DMV1O_INSIDE_OUTSIDE:   // Log: the replay layout; Max: the walk layout (the one-hot replay is not compiled any more, round 4)
+            if (is_max) return DmvLayout(N, true, true, pick_mode<DmvLayout>(N, true, true, kLdsBudget, true), true).ws_bytes * B;
+            return DmvLayout(N, true, false, pick_mode<DmvLayout>(N, true, false, kLdsBudget)).ws_bytes * B;
         case VLG_OP_DEPTREE_INSIDE:
             return DepLayout(N, false, is_max, pick_mode<DepLayout>(N, false, is_max, kLdsBudget)).ws_bytes * B;
         case VLG_OP_DEPTREE_INSIDE_OUTSIDE:

@@ -167,14 +167,17 @@ __device__ __forceinline__ void st_out(uint16_t* p, float v) {   // bf16, round 
 }
 
 template <typename O>
-__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int S, int n, O* __restrict__ out,
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int S, int n, int N, int ld_out, O* __restrict__ out,
                                                           const float* __restrict__ part_cs, int n_cs, O* __restrict__ out_cs,
                                                           const float* __restrict__ part_csb, int n_csb, O* __restrict__ out_csb) {
     int i = blockIdx.x * 256 + threadIdx.x;
     const float* src;
     O* dst;
     size_t pitch;
-    if (i < n) { src = part + i; dst = out + i; pitch = n; }
+    if (i < n) {   // the weight gradient: rows ld_out elements apart (a column block of a wider gradient tensor is written in place)
+        src = part + i; pitch = n;
+        dst = ld_out == N ? out + i : out + (size_t)(i / N) * ld_out + (i % N);
+    }
     else if (i - n < n_cs) { i -= n; src = part_cs + i; dst = out_cs + i; pitch = n_cs; }
     else if (i - n - n_cs < n_csb) { i -= n + n_cs; src = part_csb + i; dst = out_csb + i; pitch = n_csb; }
     else return;
@@ -386,13 +389,14 @@ size_t vlg_linear_wgrad_workspace(int K, int M, int N) {
 }
 
 int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
-                     void* d_weight, void* d_bias, void* x_colsum, void* stream) {
+                     void* d_weight, int ld_dw, void* d_bias, void* x_colsum, void* stream) {
     using namespace vlg;
     if (out_dtype != VLG_F32 && out_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "linear_wgrad: out_dtype %d", out_dtype);
     if (K < 1 || M < 8 || N < 8 || M % 8 || N % 8)
         return set_error(VLG_ERR_SHAPE, "linear_wgrad: need K >= 1 and M, N positive multiples of 8 (got K=%d M=%d N=%d)", K, M, N);
     if (ld_dy < M || ld_x < N || ld_dy % 8 || ld_x % 8)
         return set_error(VLG_ERR_SHAPE, "linear_wgrad: row strides must cover the columns and be multiples of 8 elements (ld_dy=%d ld_x=%d)", ld_dy, ld_x);
+    if (ld_dw < N) return set_error(VLG_ERR_SHAPE, "linear_wgrad: ld_dw=%d below N=%d", ld_dw, N);
     if (!dy || !x || !d_weight || !ws) return set_error(VLG_ERR_ARG, "linear_wgrad: null buffer");
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ws)) & 15)
         return set_error(VLG_ERR_ARG, "linear_wgrad: dy, x and the workspace must be 16-byte aligned");
@@ -408,10 +412,10 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
     if (int rc = check_launch("gemm_tn_kernel")) return rc;
     const int n = M * N, n_cs = d_bias ? M : 0, n_csb = x_colsum ? N : 0;
     if (out_dtype == VLG_F32)
-        hipLaunchKernelGGL(gemm_reduce_kernel<float>, dim3((n + n_cs + n_csb + 255) / 256), dim3(256), 0, s, part, pl.S, n, (float*)d_weight, part_cs,
+        hipLaunchKernelGGL(gemm_reduce_kernel<float>, dim3((n + n_cs + n_csb + 255) / 256), dim3(256), 0, s, part, pl.S, n, N, ld_dw, (float*)d_weight, part_cs,
                            n_cs, (float*)d_bias, part_csb, n_csb, (float*)x_colsum);
     else
-        hipLaunchKernelGGL(gemm_reduce_kernel<uint16_t>, dim3((n + n_cs + n_csb + 255) / 256), dim3(256), 0, s, part, pl.S, n, (uint16_t*)d_weight,
+        hipLaunchKernelGGL(gemm_reduce_kernel<uint16_t>, dim3((n + n_cs + n_csb + 255) / 256), dim3(256), 0, s, part, pl.S, n, N, ld_dw, (uint16_t*)d_weight,
                            part_cs, n_cs, (uint16_t*)d_bias, part_csb, n_csb, (uint16_t*)x_colsum);
     return check_launch("gemm_reduce_kernel");
 }

@@ -42,6 +42,22 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
+// four consecutive channels (8 / 16 bytes)
+__device__ __forceinline__ void load4(const uint16_t* p, float (&o)[4]) {
+    const uint2 w = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(w.x << 16); o[1] = __uint_as_float(w.x & 0xffff0000u);
+    o[2] = __uint_as_float(w.y << 16); o[3] = __uint_as_float(w.y & 0xffff0000u);
+}
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+}
+__device__ __forceinline__ void store4(uint16_t* p, const float (&v)[4]) {
+    uint2 w;
+    w.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); w.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = w;
+}
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 // the value a tensor of storage type A holds after a store (bf16: rounded; fp32: itself)
 template <typename A> __device__ __forceinline__ float stored(float v);
 template <> __device__ __forceinline__ float stored<uint16_t>(float v) { return bf2f(f2bf(v)); }

@@ -58,6 +58,34 @@ def param_names(n_bottleneck):
     return names
 
 
+def _validate_shapes(P, nb, H, n_head_in):
+    """The fused pass walks every mid_ff activation as rows of H channels and stacks the six scorer projections into one [6r, H] block:
+    the reference's DMVSkipConnectEncoder also accepts n_mid != hidden_size and separate attach / dec / root ranks (nn/dmv_spec.py:6-36,
+    57-68), which this formulation does NOT cover -- refuse them instead of reading past a buffer."""
+    def want(name, shape):
+        got = tuple(P[name].shape)
+        if got != tuple(shape):
+            raise ValueError(f"parser_feed_forward: {name} is {got}, this fused pass needs {tuple(shape)} "
+                             "(n_mid == hidden_size and one rank shared by attach / dec / root scorers, as config/model/vlgae.yaml ships)")
+    want("ff.head_ff.linear.weight", (H, n_head_in))
+    for m in ("child_ff", "root_ff", "dec_ff"):
+        if P[f"ff.{m}.linear.weight"].shape[0] != H:
+            want(f"ff.{m}.linear.weight", (H, P[f"ff.{m}.linear.weight"].shape[1]))
+    for b in _BOTTLENECKS:
+        if nb:
+            want(f"ff.mid_ff.{b}.0.weight", (nb, H))
+            want(f"ff.mid_ff.{b}.1.weight", (H, nb))
+        else:
+            want(f"ff.mid_ff.{b}.weight", (H, H))
+    for m in ("valence_linear", "direction_linear", "linear1", "linear2"):
+        want(f"ff.mid_ff.{m}.weight", (H, H))
+        want(f"ff.mid_ff.{m}.bias", (H,))
+    r = P[f"ff.{_PROJ[0]}.weight"].shape[0]
+    for p_ in _PROJ:
+        want(f"ff.{p_}.weight", (r, H))
+        want(f"ff.{p_}.bias", (r,))
+
+
 def _numel(shape):
     n = 1
     for v in shape:
@@ -133,6 +161,7 @@ class _ParserFF(torch.autograd.Function):
         Wh, bh = c(P["ff.head_ff.linear.weight"]), c(P["ff.head_ff.linear.bias"])
         H = Wh.shape[0]
         We, Wc = Wh[:, :E], Wh[:, E:]
+        _validate_shapes(P, nb, H, E + h)
         emb2 = emb.detach().reshape(M0, E)
         # ---- MLPs: all rows into one [M, H] buffer ----
         X = torch.empty((M, H), dtype=act, device=dev)

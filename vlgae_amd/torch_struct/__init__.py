@@ -19,5 +19,13 @@ __all__ = ["DMV1o", "DMV1oRules", "DependencyCRF", "StructDistribution", "LogSem
 import os as _os
 
 if _os.environ.get("VLGAE_AMD_AUTOGRAD_THREAD", "caller").lower() != "engine":
+    import logging as _logging
     import torch as _torch
-    _torch.autograd.set_multithreading_enabled(False)
+    if _torch.autograd.is_multithreading_enabled():
+        # a process-wide setting changed by an import: say so once, with the way out -- multi-device-per-process users
+        # (DataParallel, model parallel) want torch's per-device engine threads back
+        _logging.getLogger("vlgae_amd").info(
+            "vlgae_amd.torch_struct: autograd backward now runs on the calling thread for this process "
+            "(torch.autograd.set_multithreading_enabled(False)); set VLGAE_AMD_AUTOGRAD_THREAD=engine before the import to keep torch's "
+            "per-device engine threads")
+        _torch.autograd.set_multithreading_enabled(False)

@@ -1,19 +1,29 @@
-"""One VLGAE training step (BASELINE.json configs[4]) on synthetic encoder outputs, wired AS THE REFERENCE WIRES IT.
+"""One VLGAE training step (BASELINE.json configs[4]: "frozen BERT + Faster-RCNN feats -> biaffine -> inside-outside marginal loss")
+from the FROZEN FEATURES to the gradient of every trainable parameter, wired AS THE REFERENCE WIRES IT -- host-side mirror of
+`JointModelBase.forward` + `DependencyBoxRel.loss` + `reduce_loss` + `loss.backward()`.  Paths are relative to /root/reference.
 
-`build(...)` returns `step()`: forward + backward of the chain below; `tests/test_gpu_parity.py::test_training_step_reference_*`
-run this very function on fixtures produced by the reference's own methods (tests/golden/trainstep_*.npz, make_golden.py
-`trainstep_cases`), and `bench.py` / `tools/bench_secondary.py` time it.  Paths are relative to /root/reference.
+Contract.  `build(...)` returns `step()`; `step()` runs forward + backward of the chain below on the current HIP stream (no host
+synchronisation, no allocation through the driver: capturable as one HIP graph) and returns (reduced loss, {leaf name: gradient}, ()).
+The SAME function is what
+  * `tests/test_gpu_parity.py::test_training_step_reference_wiring[*]` runs on fixtures produced by the reference's own methods
+    (tests/golden/trainstep_*.npz, make_golden.py `trainstep_cases`), in float32 and in the bf16 configuration the bench times,
+  * `..._config_size[*]` runs at B = 256 against the reference's formulation in float64 torch ops,
+  * `bench.py`'s `train_step` entries time (vlgae_amd/bench/secondary.py), and
+  * `bench.py --workload train_step [--gpus N]` shards (vlgae_amd/bench/sharded_step.py).
 
-  JointModelBase.forward (src/model/base.py:215-241), encoder outputs given (frozen BERT / Faster-RCNN + MLPEncoder are out of scope):
+  JointModelBase.forward           src/model/base.py:215-241
+    VisBoxRelSimpleEncoder.forward src/model/vis_encoder/box_rel.py:29-52   base.py:229   box_fc / rel_fc / attr_fc on [box ; mean box],
+      + the cat of vis_feat_unprune src/model/joint.py:143-171              one [B,V,H] factor tensor (obj | rel | attr | img)        -> encoders.vis_box_rel_encoder
+    MLPEncoder.forward             src/model/text_encoder/mlp_encoder.py:36-40   base.py:68   x = Linear(Dropout(emb))               -> encoders.mlp_encoder
     DependencyBoxRel._forward      src/model/joint.py:658-675
       vis_feat_unprune             :137-178   vis_feat = vis_mlp_pre_matching(vis_mid)  (bias-free nn.Linear)          -> align.linear
       lang_feat_word_only          :193-211   root row = masked mean, word encoder (+ SharedDropout)                  -> langfeat.lang_feat_word_only
       attention fuse               :670-674   softmax(vis_feat . word^T) vis_mid, residual, LayerNorm                  -> align.attention_fuse
         the fused x goes into a COPY of `encoded` (feat_fuse_args.replace: false, :376-377): only the parser sees it
     DiscriminativeNDMV._forward    src/model/ldndmv.py:171-216  on that copy
-      context_mode 'mean'          :226,:254  h = cat([emb, mean_l(fused x)])                                          (torch)
+      context_mode 'mean'          :226,:254  h = cat([emb, mean_l(fused x)])
       head_ff / child_ff / root_ff / dec_ff (MLP, nn/common.py:23-51), mid_ff (DMVSkipConnectEncoder, nn/dmv_spec.py:6-54),
-      the scorers' project1 / project2 (nn.Linear, nn/dmv_spec.py:63-68): plain feed-forwards = library GEMMs          -> parser_ff.parser_feed_forward
+      the scorers' project1 / project2 (nn.Linear, nn/dmv_spec.py:63-68)                                               -> parser_ff.parser_feed_forward
                                                                      (module by module in torch: `scorer_feed_forward` below, the tests' comparison)
       scores -> log-softmax over tokens -> gather / direction select / root gather / merge   :184-209                   -> scorer.ndmv_potentials
     DependencyBoxRel._vis_forward  joint.py:677-691
@@ -26,6 +36,11 @@ run this very function on fixtures produced by the reference's own methods (test
       alpha * mt_loss + (1 - alpha) * dep_loss, alpha = grounding_interpolation = 0.5 (config/model/vlgae.yaml:67)
   reduce_loss('token')             src/utility/fn.py:50-56 (src/pipeline.py:124,249-250): / (num_token + 1e-12)
   loss.backward()                  every adjoint of the above
+
+Leaves: the frozen features `emb` [B,L,E] (= what `self.embedding` emits: [BERT subword ; tag embedding]; its gradient is computed, the
+tag embedding is trainable) and `vis_box_feat` [B,R,n] (no gradient unless `feature_grads`), and every trainable tensor: `w_text`
+(MLPEncoder.linear), `w_venc` / `b_venc` (the visual encoder's box_fc | rel_fc | attr_fc stacked), `w_vis`, `w_enc` / `b_enc` (word | child |
+parent encoders stacked), `ln_w` / `ln_b`, `w1` / `w2` / `b` (arc encoder), `token_emb` / `root_emb` / `dec_emb` and the "ff.*" feed-forwards.
 
 `wiring="r3"` keeps round 3's chain for continuity of the bench history (fused x fed to lang_feat_max_tree, scorer inputs and
 matching-space features as leaves, plain sum of the two losses): NOT what the reference does; see DESIGN.md section 5.
@@ -127,41 +142,55 @@ def init_feed_forward(g, dev, dtype, E, h, Et, T, H, nb, r):
 
 
 # ----------------------------------------------------------------------------------------------------------------------------
-def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer=True, T=45, r=16, wiring="reference", given=None,
+def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer=True, T=45, r=16, wiring="reference", given=None,
           alpha=0.5, use_pos_prior=True, vis2txt=1.0, p_drop=0.33, E=800, Et=32, H=256, nb=150, p_ff_drop=0.33, p_mid_drop=0.3,
-          factor_names=("obj",), vis_split=None, pos_for=None, ln_eps=1e-5, ff_dtype=None, fused_ff=True):
-    """The step function of one training step at B sentences of <= L words and V region columns.
+          factors=(), n_vis=2048, p_enc=0.33, pos_for=None, ln_eps=1e-5, ff_dtype=None, fused_ff=True, feature_grads=False):
+    """The step function of one training step at B sentences of <= L words and R region boxes per image.
 
-    wiring="reference": the chain of the module docstring.  `given` (a dict) replaces any of the synthetic inputs / parameters by
-    name (tests: the fixture's tensors) -- features enc_x [B,L,h], emb [B,L,E], vis_mid [B,V,h]; batch lengths / token / tag [B,L],
-    vis_mask [B,V], drop [4,B,d] (the SharedDropout masks in the reference's call order: word-only, then word | child | parent; or
-    None); parameters w_vis [d,h], w_enc [3d,h], b_enc [3d], ln_w, ln_b [h], w1 [d,d,d], w2 [d,d], b [d], token_emb / root_emb /
-    dec_emb and the "ff.*" feed-forward parameters.  With `given` drop absent, fresh masks are drawn every step (p_drop).
-    ff_dtype: storage / compute type of the parser's feed-forwards (default = dtype); fused_ff: vlgae_amd.parser_ff (folded / fused
-    library GEMMs, hand-written adjoint) instead of the module-by-module torch formulation `scorer_feed_forward` (same values).
+    factors: which of ("rel", "attr", "img") the model adds to the object factor (cfg.add_rel / add_attr / add_image; the shipped
+    config/model/vlgae.yaml:39-41 has all three: V = R + R^2 + R + 1 columns, 1369 at R = 36; BASELINE.json configs[1] names R = 36
+    region columns: the object factor alone, the default).  n_vis / E: widths of the frozen region features / embeddings (2048 / 800).
+    `given` (a dict) replaces any of the synthetic inputs / parameters by name (tests: the fixture's tensors) -- features emb [B,L,E],
+    vis_box_feat [B,R,n_vis]; batch lengths / token / tag [B,L], box_mask [B,R], drop [4,B,d] (the SharedDropout masks in the reference's
+    call order: word-only, then word | child | parent; or None), enc_drop [B,L,E] (MLPEncoder's nn.Dropout mask; or None); parameters
+    w_text [h,E], w_venc [F h, 2 n_vis] / b_venc [F h], w_vis [d,h], w_enc [3d,h], b_enc [3d], ln_w, ln_b [h], w1 [d,d,d], w2 [d,d], b [d],
+    token_emb / root_emb / dec_emb and the "ff.*" feed-forward parameters.  With `given` drop / enc_drop absent, fresh masks are drawn
+    every step (p_drop / p_enc; the embedding dropout from a device-resident counter-based generator, encoders.DeviceRng).
+    ff_dtype: storage / compute type of the parser's feed-forwards and of `emb` (default = dtype); fused_ff: vlgae_amd.parser_ff (folded /
+    fused library GEMMs, hand-written adjoint) instead of the module-by-module torch formulation `scorer_feed_forward` (same values).
     p_ff_drop / p_mid_drop: the parser feed-forwards' dropout (shipped: 0.33 / 0.3; masks drawn per step; 0 = off, as in the fixtures).
-    alpha / use_pos_prior / vis2txt: config/model/vlgae.yaml:62-67.  Returns step(); step() -> (loss, {name: gradient}, ()).
+    alpha / use_pos_prior / vis2txt: config/model/vlgae.yaml:62-67.  feature_grads: also return the gradient w.r.t. vis_box_feat (the
+    reference does not compute it -- the region features are data; the parity tests do).
+    Returns step(); step() -> (loss, {name: gradient}, ()).
 
-    wiring="r3": round 3's chain (see the module docstring); `with_scorer` only matters there."""
+    wiring="r3": round 3's chain (see the module docstring); `with_scorer` only matters there, and R is its V."""
     if wiring == "r3":
-        return _build_r3(B, L, V, dev, dtype, d, h, seed, with_scorer, T, r)
+        return _build_r3(B, L, R, dev, dtype, d, h, seed, with_scorer, T, r)
     if wiring != "reference":
         raise ValueError(wiring)
     import vlgae_amd.torch_struct as ts
-    from vlgae_amd import align, langfeat, parser_ff, scorer
+    from vlgae_amd import align, encoders, langfeat, parser_ff, scorer
     N, Q = L + 1, 2 * (L + 1)
     given = dict(given or {})
+    factors = tuple(factors)
+    if any(f not in ("rel", "attr", "img") for f in factors):
+        raise ValueError(f"train_step.build: factors {factors}")
+    add_rel, add_attr, add_image = "rel" in factors, "attr" in factors, "img" in factors
+    _, V, vis_split, factor_names = encoders.factor_layout(R, add_rel, add_attr, add_image)
+    n_enc = 1 + add_rel + add_attr
     ff_dtype = dtype if ff_dtype is None else ff_dtype
     g = torch.Generator().manual_seed(seed)
     rnd = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
 
-    def leaf(name, make, dt=dtype):
+    def leaf(name, make, dt=dtype, grad=True):
         t = given.pop(name) if name in given else make()
-        return t.detach().to(dev, dt).contiguous().requires_grad_(True)
+        return t.detach().to(dev, dt).contiguous().requires_grad_(grad)
 
-    # ---- features as the (frozen / out-of-scope) encoders emit them, and the trainable weights on the path ----
+    # ---- the frozen features (BERT subword + tag embedding; Faster-RCNN region features) and every trainable weight behind them ----
     P = dict(
-        enc_x=leaf("enc_x", lambda: rnd(B, L, h)), emb=leaf("emb", lambda: rnd(B, L, E, sc=0.5), ff_dtype), vis_mid=leaf("vis_mid", lambda: rnd(B, V, h)),
+        emb=leaf("emb", lambda: rnd(B, L, E, sc=0.5), ff_dtype), vis_box_feat=leaf("vis_box_feat", lambda: rnd(B, R, n_vis, sc=0.5), grad=feature_grads),
+        w_text=leaf("w_text", lambda: rnd(h, E, sc=E ** -0.5), ff_dtype),
+        w_venc=leaf("w_venc", lambda: rnd(n_enc * h, 2 * n_vis, sc=(2 * n_vis) ** -0.5)), b_venc=leaf("b_venc", lambda: rnd(n_enc * h, sc=0.1)),
         w_vis=leaf("w_vis", lambda: rnd(d, h, sc=h ** -0.5)),
         w_enc=leaf("w_enc", lambda: rnd(3 * d, h, sc=h ** -0.5)), b_enc=leaf("b_enc", lambda: rnd(3 * d, sc=0.1)),
         ln_w=leaf("ln_w", lambda: torch.ones(h), torch.float32), ln_b=leaf("ln_b", lambda: torch.zeros(h), torch.float32),
@@ -181,24 +210,28 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         lengths = lengths.to(dev)
     token = given.pop("token").to(dev) if "token" in given else torch.randint(0, P["token_emb"].shape[0], (B, L), generator=g).to(dev)
     tag = given.pop("tag").to(dev) if "tag" in given else torch.randint(0, 7, (B, L), generator=g).to(dev)
-    if "vis_mask" in given:
-        vmask = given.pop("vis_mask").to(dev, torch.bool)
-    else:   # ragged region lists as the reference's collate builds them: image i has n_i <= V boxes, `masks_output[i, :n_i] = True` and
-        # padding behind them (src/datamodule/task/vlparse.py:68-83) -- a PREFIX mask per image, n_i drawn from [0.6 V, V]
-        n_box = torch.randint(max(1, (3 * V) // 5), V + 1, (B,), generator=g)
-        vmask = (torch.arange(V)[None] < n_box[:, None]).to(dev)
+    if "box_mask" in given:
+        box_mask = given.pop("box_mask").to(dev, torch.bool)
+    else:   # ragged region lists as the reference's collate builds them: image i has n_i <= R boxes, `masks_output[i, :n_i] = True` and
+        # padding behind them (src/datamodule/task/vlparse.py:68-83) -- a PREFIX mask per image, n_i drawn from [0.6 R, R]
+        n_box = torch.randint(max(1, (3 * R) // 5), R + 1, (B,), generator=g)
+        box_mask = (torch.arange(R)[None] < n_box[:, None]).to(dev)
+    vmask = encoders.factor_mask(box_mask, add_rel, add_attr, add_image)       # vis_feat_unprune's mask (joint.py:140-170): data, built once per batch
     fixed_drop = given.pop("drop") if "drop" in given else "draw"
     if fixed_drop is not None and not isinstance(fixed_drop, str):
         fixed_drop = fixed_drop.to(dev, torch.float32).permute(1, 0, 2).contiguous()      # [B,4,d]
+    enc_drop = given.pop("enc_drop") if "enc_drop" in given else "draw"
+    if enc_drop is not None and not isinstance(enc_drop, str):
+        enc_drop = enc_drop.to(dev, torch.float32).contiguous()                           # [B,L,E]
     if given:
         raise ValueError(f"train_step.build: unknown given entries {sorted(given)}")
-    vis_split = list(vis_split) if vis_split is not None else [V]
+    rng = encoders.DeviceRng(seed * 7919 + 17, dev)       # the counter-based dropout draws of the step (advanced on the device once per step)
     if pos_for is None:
         pos_for = dict(obj=torch.tensor([0, 1, 2]), rel=torch.tensor([2, 3]), attr=torch.tensor([4]))
     pos_for = {k: t.to(dev) for k, t in pos_for.items()}
     num_token = lengths.sum()                                     # a 0-d tensor like vp.num_token (var_pool.py:18)
     num_token_f = float(num_token.item())
-    names = sorted(P)
+    names = sorted(k for k in P if P[k].requires_grad)
     leaves = [P[k] for k in names]
     aux = {}
     # the POS prior table (joint.py:446-470) is a function of the batch's tags only -- data, like the masks: built once per batch
@@ -229,10 +262,20 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         drop, ff_masks = draw_masks()
         d0, d3 = (None, None) if drop is None else (drop[:, 0:1], drop[:, 1:4])
         w_word, b_word = P["w_enc"][:d], P["b_enc"][:d]
+        # ---- JointModelBase.forward, base.py:229 / :68: the two trainable encoders on the frozen features ----
+        vis_mid, _, _ = encoders.vis_box_rel_encoder(P["vis_box_feat"], P["w_venc"], P["b_venc"], add_rel, add_attr, add_image, SLOPE)
+        if enc_drop is None or p_enc == 0:
+            enc_x = encoders.mlp_encoder(P["emb"], P["w_text"], training=False)
+        elif isinstance(enc_drop, str):
+            enc_x = encoders.mlp_encoder(P["emb"], P["w_text"], p_enc, rng=rng)
+        else:
+            enc_x = encoders.mlp_encoder(P["emb"], P["w_text"], p_enc, mask=enc_drop)
+        if enc_x.dtype != dtype:                                          # (ff_dtype != dtype: the language side runs in `dtype`)
+            enc_x = enc_x.to(dtype)
         # ---- DependencyBoxRel._forward, joint.py:658-675 ----
-        vis_feat = align.linear(P["vis_mid"], P["w_vis"])                                                    # :175 (and again :688: same values)
-        word0, _, _ = langfeat.lang_feat_word_only(P["enc_x"], lengths, w_word, b_word, drop=d0)            # :667
-        x_f = align.attention_fuse(vis_feat, word0, P["vis_mid"], P["enc_x"], P["ln_w"], P["ln_b"], ln_eps)   # :670-674
+        vis_feat = align.linear(vis_mid, P["w_vis"])                                                         # :175 (and again :688: same values)
+        word0, _, _ = langfeat.lang_feat_word_only(enc_x, lengths, w_word, b_word, drop=d0)                 # :667
+        x_f = align.attention_fuse(vis_feat, word0, vis_mid, enc_x, P["ln_w"], P["ln_b"], ln_eps)             # :670-674
         # ---- DiscriminativeNDMV._forward on the fused copy, ldndmv.py:171-216 ----
         if fused_ff:   # the same mathematics with folded / fused GEMMs and a hand-written adjoint
             x1, x2, y1, y2, root_rule = parser_ff.parser_feed_forward(P, P["emb"], x_f, None, None, None, *ff_masks)
@@ -240,7 +283,7 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
             x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, *ff_masks[:2], None if ff_masks[2] is None else ff_masks[2] * ff_masks[3])
         md, ma = scorer.ndmv_potentials(x1, x2, y1, y2, root_rule, token)
         # ---- DependencyBoxRel._vis_forward, joint.py:677-691: the UN-fused x; the potentials are constants of this stage (:252-253) ----
-        txt, tmask, tmarg = langfeat.lang_feat_max_tree(P["enc_x"], lengths, md.detach(), ma.detach(), P["w_enc"], P["b_enc"], P["w1"],
+        txt, tmask, tmarg = langfeat.lang_feat_max_tree(enc_x, lengths, md.detach(), ma.detach(), P["w_enc"], P["b_enc"], P["w1"],
                                                         P["w2"], P["b"], keep_viterbi=True, drop=d3, aux=aux)
         if stage_hook is not None:
             txt.register_hook(lambda g_: stage_hook())
@@ -250,23 +293,26 @@ def build(B, L, V, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         with torch.no_grad():                                     # alpha mt + (1 - alpha) dep, reduce_loss('token')
             loss = torch.addcmul(c_mt * mt, mx.sum(), c_max)
         grads = torch.autograd.grad([mt, mx], leaves, [c_mt, seed_max.view(mx.shape)])
+        if isinstance(enc_drop, str) and p_enc > 0:
+            rng.advance()                                             # the next step (or graph replay) draws new embedding-dropout masks
         # intermediates for the parity tests, DETACHED: a reference to a previous step's autograd graph kept alive across a HIP-graph
         # capture makes torch 2.10 / ROCm 7 crash in capture_end
         step.last = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in dict(
-            x_fused=x_f, merged_dec=md, merged_attach=ma, txt=txt, txt_mask=tmask, txt_marginal=tmarg, vis_feat=vis_feat, sums=sums,
+            enc_x=enc_x, vis_mid=vis_mid, x_fused=x_f, merged_dec=md, merged_attach=ma, txt=txt, txt_mask=tmask, txt_marginal=tmarg, vis_feat=vis_feat, sums=sums,
             viterbi_max=mx, mt_loss=mt, heads=aux.get("heads")).items()}
         return loss, dict(zip(names, grads)), ()
 
     step.names, step.P, step.lengths, step.wiring = names, P, lengths, wiring
-    step.batch = dict(token=token, tag=tag, vis_mask=vmask, alpha=alpha, factor_names=factor_names, vis_split=vis_split, pos_for=pos_for,
-                      use_pos_prior=use_pos_prior, vis2txt=vis2txt)
-    step.trainable = tuple(k for k in names if k not in ("enc_x", "emb", "vis_mid"))
+    step.batch = dict(token=token, tag=tag, box_mask=box_mask, vis_mask=vmask, alpha=alpha, factor_names=factor_names, vis_split=vis_split,
+                      factors=factors, pos_for=pos_for, use_pos_prior=use_pos_prior, vis2txt=vis2txt, enc_drop=enc_drop, p_enc=p_enc)
+    step.shape = dict(B=B, L=L, R=R, V=V, d=d, h=h, E=E, n_vis=n_vis)
+    step.trainable = tuple(k for k in names if k not in ("emb", "vis_box_feat"))
     # Parameters in the order their gradients become FINAL during the backward pass (autograd runs the later-created node first:
     # -max, grounding loss, lang_feat_max_tree | score construction, the parser's feed-forwards | attention fuse, word-only encoder,
-    # vis_mlp_pre_matching): what a data-parallel trainer's buckets follow.  `step.on_grad(name, grad)`, if set, is called from
+    # vis_mlp_pre_matching | the text and visual encoders): what a data-parallel trainer's buckets follow.  `step.on_grad(name, grad)`, if set, is called from
     # inside the backward pass the moment a parameter's (accumulated) gradient exists.
     ff_names = [k for k in names if k.startswith("ff.") or k in ("token_emb", "root_emb", "dec_emb")]
-    step.ready_groups = (["w1", "w2", "b"], ff_names, ["ln_w", "ln_b", "w_enc", "b_enc", "w_vis"])
+    step.ready_groups = (["w1", "w2", "b"], ff_names, ["ln_w", "ln_b", "w_enc", "b_enc", "w_vis"], ["w_text", "w_venc", "b_venc"])
     step.on_grad = None
     for k in step.trainable:
         P[k].register_hook(lambda g_, k=k: step.on_grad(k, g_) if step.on_grad is not None else None)
