@@ -306,6 +306,9 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
 int vlg_dropout(const void* x, const float* mask, int shared_rows, const uint64_t* rng, unsigned site, float p, const void* add, void* out, long long rows,
                 int cols, int dtype, int out_dtype, void* stream);
 int vlg_rng_advance(uint64_t* rng, void* stream);
+/* out[i] = 0 or 1/(1-p), i < n: the same draw written out as explicit fp32 masks -- for the SMALL dropout layers of a step (the SharedDropout
+ * rows [B, d] of the word / child / parent encoders and of head_ff, nn/dropout.py:42-63), all of them in one launch. */
+int vlg_dropout_mask(const uint64_t* rng, unsigned site, float p, float* out, long long n, void* stream);
 int vlg_vis_encoder(const void* P, const void* C, int B, int R, int H, int V, int ldp, int col_box, int col_rel, int col_attr, int off_box, int off_rel,
                     int off_attr, int off_img, int dtype, float slope, void* mid, void* stream);
 int vlg_vis_encoder_backward(const void* P, const void* C, const void* grad_mid, int B, int R, int H, int V, int ldp, int col_box, int col_rel, int col_attr,
@@ -358,6 +361,18 @@ int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, c
                    void* c, long long scb, long long ldc, const void* bias, long long sbias, const void* u, long long su, const void* v,
                    long long sv, int batch, int M, int N, int K, float alpha, int accumulate, int in_dtype, int out_dtype, void* stream);
 
+/* Several INDEPENDENT small products as ONE launch (round 5): one dependency level of the weight-space products of the parser's
+ * feed-forwards (src/model/ldndmv.py:174-183, nn/dmv_spec.py:38-54) -- each field as the vlg_small_gemm argument of the same name.
+ * Problems may differ in shape, strides and dtypes; none may read what another one of the same call writes. */
+typedef struct VlgSmallGemm {
+    const void *a, *b, *bias, *u, *v;
+    void* c;
+    long long sab, sam, sak, sbb, sbk, sbn, scb, ldc, sbias, su, sv;
+    int batch, M, N, K, accumulate, in_dtype, out_dtype;
+    float alpha;
+} VlgSmallGemm;
+int vlg_small_gemm_group(const VlgSmallGemm* problems, int count, void* stream);
+
 /* Element-wise passes between the library GEMMs of the parser's feed-forwards (vlgae_amd/parser_ff.py): `MLP`
  * (src/model/nn/common.py:23-51: Linear -> LeakyReLU -> SharedDropout) and `DMVSkipConnectEncoder` (src/model/nn/dmv_spec.py:38-54).
  * Activations in act_dtype (VLG_BF16 / VLG_F32), rows of H channels (H a multiple of 8), 16-byte aligned; fp32 arithmetic.
@@ -369,6 +384,8 @@ int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, c
  *   vlg_ff_act                out[m,j'] = LeakyReLU(in[m,j] + residual[m]) * mask[m,j'] * mask_scale, in [M,J,H], residual [M,H] or NULL, mask
  *                             (act_dtype, indexed like out; e.g. an nn.Dropout keep-mask of 0 / 1 with mask_scale = 1 / (1 - p)) or NULL.  swap = 0: j' = j, out may be in.  swap = 1 (J = 4): in is
  *                             [m,val,dir], out [m,dir,val] -- the stack of nn/dmv_spec.py:47 as a store permutation.
+ *                             rng != NULL (then mask = NULL, swap = 0): the keep-mask is the counter-based draw of vlg_dropout (site, p) over the output's
+ *                             element index and mask_scale is 1 / (1 - p) -- mid_ff's nn.Dropout (nn/dmv_spec.py:52) without its 21 MB mask tensor.
  *   vlg_ff_act_backward       out[m,j'] = LeakyReLU'(act[m,j]) * g[m,j] * mask[m,j] * mask_scale (g, act, mask [M,J,H] in the same order; the
  *                             derivative from the sign of the stored activation); sum [M,H] fp32 (or NULL) = / += (accumulate)
  *                             sum_j of the stored out values.  swap as above (g, act in [m,dir,val]; out in [m,val,dir]).
@@ -376,12 +393,22 @@ int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, c
 int vlg_ff_context_mean(const void* x, int in_dtype, int B, int L, int h, void* out, int out_dtype, void* stream);
 int vlg_ff_mlp_act(void* x, const void* cterm, const float* drop_head, const float* drop_small, int B, int L, int Ms, int H, int act_dtype,
                    float slope, void* stream);
-int vlg_ff_act(const void* in, const void* residual, const void* mask, float mask_scale, void* out, long long M, int J, int H, int swap, int act_dtype,
-               float slope, void* stream);
-int vlg_ff_act_backward(const void* g, const void* act, const void* mask, float mask_scale, void* out, float* sum, long long M, int J, int H, int swap,
-                        int accumulate, int act_dtype, float slope, void* stream);
+int vlg_ff_act(const void* in, const void* residual, const void* mask, float mask_scale, const uint64_t* rng, unsigned site, float p, void* out,
+               long long M, int J, int H, int swap, int act_dtype, float slope, void* stream);
+int vlg_ff_act_backward(const void* g, const void* act, const void* mask, float mask_scale, const uint64_t* rng, unsigned site, float p, void* out,
+                        float* sum, long long M, int J, int H, int swap, int accumulate, int act_dtype, float slope, void* stream);
 int vlg_ff_mlp_act_backward(const float* gx, const void* t, const void* x, const float* drop_head, const float* drop_small, void* gpre, int B, int L,
                             int Ms, int H, int act_dtype, float slope, void* stream);
+/* The root rule and the cotangent of the small projection product (round 5; src/model/ldndmv.py:205 `root_scorer(h_root, h_child).sum([-1,-2])
+ * .log_softmax(-1)`).  small [4 (T + 3), ld] (act_dtype) holds, for row (token c, (dir,val) dv) = 4c + dv, the column blocks attach.project2 |
+ * root.project2 | . | . and, in rows 4T + dv, block 2 = root.project1 of the root's representation; r = the scorers' rank.
+ *   vlg_ff_root_rule           root_rule [T] fp32 = log_softmax_c sum_{dv,e} r1[dv,e] r2[c,dv,e]
+ *   vlg_ff_root_rule_backward  g_small [4 (T + 3), 4r] (act_dtype, contiguous) = the whole cotangent of `small`: block 0 <- g_x2 [4T, r] (rows ld_x2 apart;
+ *                              NULL = 0), block 1 / 2 <- the root rule's adjoint from g_root [T] fp32, block 3 of the last 8 rows <- g_y2 [8, r] (ld_y2),
+ *                              zeros elsewhere: one pass instead of a zero-fill, two copies, a softmax adjoint and two products. */
+int vlg_ff_root_rule(const void* small, int ld, int T, int r, int act_dtype, float* root_rule, void* stream);
+int vlg_ff_root_rule_backward(const void* small, int ld, int T, int r, int act_dtype, const float* root_rule, const float* g_root, const void* g_x2,
+                              int ld_x2, const void* g_y2, int ld_y2, void* g_small, void* stream);
 
 /* Score construction feeding the DP -- the tensor half of `DiscriminativeNDMV._forward`, src/model/ldndmv.py:179-209 with the
  * factorised-bilinear scorers of src/model/nn/dmv_spec.py:57-76: from the scorers' projected inputs to the root-merged

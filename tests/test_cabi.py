@@ -188,15 +188,15 @@ def test_round4_entry_points_validate_on_the_host(lib):
     P = ctypes.c_void_p
     one, odd = P(64), P(68)
     f = ctypes.c_float(0.01)
-    assert lib.vlg_ff_act(one, None, None, f, one, 10, 1, 12, 0, 1, f, None) == 0x1001                 # H not a multiple of 8
+    assert lib.vlg_ff_act(one, None, None, f, None, 0, 0.0, one, 10, 1, 12, 0, 1, f, None) == 0x1001                 # H not a multiple of 8
     assert b"multiple of 8" in lib.vlg_last_error()
-    assert lib.vlg_ff_act(one, None, None, f, one, 10, 2, 64, 1, 1, f, None) == 0x1001                 # the permutation is of J = 4
-    assert lib.vlg_ff_act(one, None, None, f, one, 10, 4, 64, 1, 1, f, None) == 0x1003                 # ... and not in place
-    assert lib.vlg_ff_act(one, None, None, f, one, 10, 1, 64, 0, 5, f, None) == 0x1002
-    assert lib.vlg_ff_act(odd, None, None, f, one, 10, 1, 64, 0, 1, f, None) == 0x1003 and b"aligned" in lib.vlg_last_error()
-    assert lib.vlg_ff_act(one, None, None, f, one, 0, 1, 64, 0, 1, f, None) == 0                       # nothing to do
-    assert lib.vlg_ff_act_backward(one, one, None, f, one, None, 10, 4, 64, 1, 0, 1, f, None) == 0x1003
-    assert lib.vlg_ff_act_backward(one, None, None, f, one, None, 10, 1, 64, 0, 0, 1, f, None) == 0x1003
+    assert lib.vlg_ff_act(one, None, None, f, None, 0, 0.0, one, 10, 2, 64, 1, 1, f, None) == 0x1001                 # the permutation is of J = 4
+    assert lib.vlg_ff_act(one, None, None, f, None, 0, 0.0, one, 10, 4, 64, 1, 1, f, None) == 0x1003                 # ... and not in place
+    assert lib.vlg_ff_act(one, None, None, f, None, 0, 0.0, one, 10, 1, 64, 0, 5, f, None) == 0x1002
+    assert lib.vlg_ff_act(odd, None, None, f, None, 0, 0.0, one, 10, 1, 64, 0, 1, f, None) == 0x1003 and b"aligned" in lib.vlg_last_error()
+    assert lib.vlg_ff_act(one, None, None, f, None, 0, 0.0, one, 0, 1, 64, 0, 1, f, None) == 0                       # nothing to do
+    assert lib.vlg_ff_act_backward(one, one, None, f, None, 0, 0.0, one, None, 10, 4, 64, 1, 0, 1, f, None) == 0x1003
+    assert lib.vlg_ff_act_backward(one, None, None, f, None, 0, 0.0, one, None, 10, 1, 64, 0, 0, 1, f, None) == 0x1003
     assert lib.vlg_ff_mlp_act(one, None, None, None, 2, 5, 3, 64, 1, f, None) == 0x1003             # parent rows need the context term
     assert lib.vlg_ff_mlp_act(one, one, None, None, 2, 0, 3, 64, 1, f, None) == 0x1001
     assert lib.vlg_ff_mlp_act_backward(None, None, one, None, None, one, 2, 5, 3, 64, 1, f, None) == 0x1003

@@ -1442,6 +1442,42 @@ def test_parser_feed_forward_vs_module_by_module(dtype, nb):
             assert float((a.double() - b).norm()) <= 0.2 * float(b.norm()) + 2e-3 * gmax * b.numel() ** 0.5, name
 
 
+def test_parser_feed_forward_counter_based_mid_dropout():
+    """mid_ff's nn.Dropout (nn/dmv_spec.py:52) drawn INSIDE the activation kernel from the step's DeviceRng (no mask tensor): the result
+    and every gradient are BIT-identical to the same call with the explicit mask that the same generator state writes out through
+    encoders.dropout (same site, same element indexing), forward and adjoint regenerate the same bits, and advancing the state changes
+    them.  Also: encoders.dropout_mask (the small SharedDropout rows) has the right support and rate."""
+    from vlgae_amd import encoders, parser_ff, train_step
+    B, L, E, h, Et, T, H, r, nb, p = 24, 11, 40, 64, 16, 9, 64, 8, 24, 0.3
+    gen = torch.Generator().manual_seed(9)
+    P = train_step.init_feed_forward(gen, dev(), torch.bfloat16, E, h, Et, T, H, nb, r)
+    emb = (torch.randn(B, L, E, generator=gen) * 0.5).to(dev(), torch.bfloat16).requires_grad_(True)
+    x = torch.randn(B, L, h, generator=gen).to(dev(), torch.bfloat16).requires_grad_(True)
+    names = sorted(P)
+    leaves = [emb, x] + [P[k] for k in names]
+    rng = encoders.DeviceRng(77, dev())
+    rows = 4 * (B * L + T + 3)
+
+    def run(**kw):
+        outs = parser_ff.parser_feed_forward(P, emb, x, **kw)
+        cot = [torch.ones_like(o) * 0.5 for o in outs]
+        return outs, torch.autograd.grad([o.float() for o in outs], leaves, [c.float() for c in cot])
+    got = run(mid_rng=rng, p_mid=p)
+    mask = encoders.dropout(torch.ones(rows, H, device=dev()), p, rng=rng, site=encoders.SITE_MID_FF)      # the same state written out
+    keep = float((mask != 0).double().mean())
+    assert abs(keep - (1 - p)) < 4 * (p * (1 - p) / mask.numel()) ** 0.5 + 1e-4
+    want = run(drop_mid=(mask != 0).to(torch.bfloat16), mid_scale=float(mask.max()))
+    for a, b in zip(got[0] + got[1], want[0] + want[1]):
+        assert torch.equal(a, b)
+    rng.advance()
+    again = run(mid_rng=rng, p_mid=p)
+    assert not torch.equal(again[0][0], got[0][0])
+    small = encoders.dropout_mask(rng, encoders.SITE_SHARED, 0.33, 100003)
+    vals = torch.unique(small)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1.0 / (1.0 - round(0.33 * 65536) / 65536.0)) < 1e-6
+    assert abs(float((small != 0).double().mean()) - 0.67) < 4 * (0.33 * 0.67 / 100003) ** 0.5 + 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_ff_elementwise_kernels(dtype):
     """csrc/vlg_ff.hip through the C ABI against the torch chains they replace (nn/common.py:47-51, nn/dmv_spec.py:41-52), computed in
@@ -1489,10 +1525,10 @@ def test_ff_elementwise_kernels(dtype):
         if with_mask and J == 3:        # a 0 / 1 keep-mask with the scale as an argument (nn.Dropout without the division pass)
             keep = (mask != 0).to(dtype)
             out2 = inp.clone()
-            _C.check(lib.vlg_ff_act(_C.ptr(out2), _C.ptr(res), _C.ptr(keep), 1.0 / 0.7, _C.ptr(out2), M, J, H, 0, adt, slope, st), "ff_act")
+            _C.check(lib.vlg_ff_act(_C.ptr(out2), _C.ptr(res), _C.ptr(keep), 1.0 / 0.7, None, 0, 0.0, _C.ptr(out2), M, J, H, 0, adt, slope, st), "ff_act")
             close("act, keep-mask x scale", out2, lrelu(inp.double() + res.double().unsqueeze(1)) * keep.double() * float(np.float32(1.0 / 0.7)))
         out = torch.empty_like(inp) if swap else inp.clone()
-        _C.check(lib.vlg_ff_act(_C.ptr(inp if swap else out), _C.ptr(res), _C.ptr(mask), 1.0, _C.ptr(out), M, J, H, int(swap), adt, slope, st), "ff_act")
+        _C.check(lib.vlg_ff_act(_C.ptr(inp if swap else out), _C.ptr(res), _C.ptr(mask), 1.0, None, 0, 0.0, _C.ptr(out), M, J, H, int(swap), adt, slope, st), "ff_act")
         close(f"act J={J} swap={swap}", out, w)
     # adjoint: LeakyReLU' from the stored activation, mask, group sum (= / +=), permutation
     for J, swap, with_mask, acc in ((1, False, True, False), (4, True, False, False), (2, False, False, True), (4, True, True, True)):
@@ -1504,14 +1540,14 @@ def test_ff_elementwise_kernels(dtype):
         total0 = torch.randn(M, H, generator=gen).to(dev())
         total = total0.clone()
         out = torch.empty_like(g)
-        _C.check(lib.vlg_ff_act_backward(_C.ptr(g), _C.ptr(act), _C.ptr(mask), 1.0, _C.ptr(out), _C.ptr(total), M, J, H, int(swap), int(acc), adt,
+        _C.check(lib.vlg_ff_act_backward(_C.ptr(g), _C.ptr(act), _C.ptr(mask), 1.0, None, 0, 0.0, _C.ptr(out), _C.ptr(total), M, J, H, int(swap), int(acc), adt,
                                          slope, st), "ff_act_backward")
         close(f"act_bwd J={J} swap={swap}", out, t.view(M, 2, 2, H).permute(0, 2, 1, 3).reshape(M, J, H) if swap else t)
         want_total = out.double().sum(1) + (total0.double() if acc else 0.0)      # the sum is of the STORED values (what the next GEMM reads)
         assert float((total.double() - want_total).abs().max()) <= 1e-5 * max(1.0, float(want_total.abs().max()))
         if not swap:                              # in place, without the sum
             g2 = g.clone()
-            _C.check(lib.vlg_ff_act_backward(_C.ptr(g2), _C.ptr(act), _C.ptr(mask), 1.0, _C.ptr(g2), None, M, J, H, 0, 0, adt, slope, st), "ff_act_backward")
+            _C.check(lib.vlg_ff_act_backward(_C.ptr(g2), _C.ptr(act), _C.ptr(mask), 1.0, None, 0, 0.0, _C.ptr(g2), None, M, J, H, 0, 0, adt, slope, st), "ff_act_backward")
             assert torch.equal(g2, out)
     # MLP adjoint
     gX, T_, Xs = torch.randn(M, H, generator=gen).to(dev()), rnd(M, H), rnd(M, H)
@@ -1529,10 +1565,10 @@ def test_ff_elementwise_kernels(dtype):
     _C.check(lib.vlg_ff_context_mean(_C.ptr(xs), _C.F32, B, L, 72, _C.ptr(cm), adt, st), "ff_context_mean")
     assert float((cm.double() - xs.to(dtype).double().mean(1)).abs().max()) <= (1e-6 if dtype == torch.float32 else 2.0 ** -8)   # (a mean near zero: absolute)
     # argument checks (host side)
-    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, _C.ptr(Xs), M, 1, 12, 0, adt, slope, st) == 0x1001          # H not a multiple of 8
-    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, _C.ptr(Xs), M, 2, H, 1, adt, slope, st) == 0x1001           # the permutation is of J = 4
-    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, _C.ptr(Xs), M // 4, 4, H, 1, adt, slope, st) == 0x1003      # ... and not in place
-    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, _C.ptr(Xs), M, 1, H, 0, 7, slope, st) == 0x1002
+    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, None, 0, 0.0, _C.ptr(Xs), M, 1, 12, 0, adt, slope, st) == 0x1001          # H not a multiple of 8
+    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, None, 0, 0.0, _C.ptr(Xs), M, 2, H, 1, adt, slope, st) == 0x1001           # the permutation is of J = 4
+    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, None, 0, 0.0, _C.ptr(Xs), M // 4, 4, H, 1, adt, slope, st) == 0x1003      # ... and not in place
+    assert lib.vlg_ff_act(_C.ptr(Xs), None, None, 1.0, None, 0, 0.0, _C.ptr(Xs), M, 1, H, 0, 7, slope, st) == 0x1002
 
 
 def test_linear_wgrad_partial_tiles():
@@ -2593,3 +2629,21 @@ def test_small_matmul(dtype):
         align.small_matmul(a, b.float() if dtype == torch.bfloat16 else b.bfloat16())
     with pytest.raises(ValueError):
         align.small_matmul(a, mk(151, 256))
+    # ---- several independent problems as ONE launch (vlg_small_gemm_group): bit-identical to the single launches, mixed shapes / dtypes / strides;
+    # 14 problems span two launches of up to 12 ----
+    other = torch.float32 if dtype == torch.bfloat16 else torch.bfloat16
+    mo = lambda *s: torch.randn(*s, generator=gen).to(dev(), other)
+    ao, bo2 = mo(40, 72), mo(72, 24)
+    specs = [dict(a=a, b=b), dict(a=a3, b=b3, out_dtype=torch.float32), dict(a=sl, b=bt, alpha=0.25, bias=bias, rank1=(u, v)),
+             dict(a=a3, b=b3, bias=biasb, rank1=(ub, vb)), dict(a=a3, b=b), dict(a=one[0], b=one[1]), dict(a=av, b=bv), dict(a=av2, b=bv2, out_dtype=torch.float32),
+             dict(a=odd, b=bo), dict(a=ao, b=bo2), dict(a=ao, b=bo2, out_dtype=dtype), dict(a=a3.transpose(1, 2), b=b3.transpose(1, 2)),
+             dict(a=bt.t(), b=sl.t()), dict(a=b, b=a)]
+    grp = align.SmallMatmulGroup()
+    outs = [grp.add(**sp) for sp in specs]
+    acc_out = base.clone()
+    grp.add(a3, b3, out=acc_out, accumulate=True)
+    grp.launch()
+    for k, (sp, got) in enumerate(zip(specs, outs)):
+        assert torch.equal(got, align.small_matmul(**sp)), k
+    assert torch.equal(acc_out, out)
+    grp.launch()                                                       # an empty group is a no-op

@@ -1,0 +1,24 @@
+"""Weight-gradient products of the two encoders: vlg_linear_wgrad (split-K) vs the library, event-timed.
+    python tools/time_wgrad_shapes.py"""
+import sys, torch
+sys.path.insert(0, '.')
+from vlgae_amd import align
+dev = torch.device('cuda:0')
+def ev(fn, n=50):
+    for _ in range(5): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+for K, M, N, ld in ((9216, 256, 2048, 4096), (9216, 768, 2048, 4096), (2304, 768, 2048, 4096), (10240, 256, 800, 800), (256, 256, 2048, 4096), (64, 768, 2048, 4096)):
+    dy = torch.randn(K, M, device=dev).bfloat16(); x = torch.randn(K, N, device=dev).bfloat16()
+    out = torch.empty(M, ld, device=dev, dtype=torch.bfloat16)
+    t_k = ev(lambda: align.linear_wgrad(dy, x, want_bias=False, out=(out[:, :N], None)))
+    t_l = ev(lambda: torch.mm(dy.t(), x, out=out[:, :N]))
+    outc = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    t_lc = ev(lambda: torch.mm(dy.t(), x, out=outc))
+    ref = dy.float().t() @ x.float()
+    align.linear_wgrad(dy, x, want_bias=False, out=(out[:, :N], None)); e1 = float((out[:, :N].float() - ref).abs().max() / ref.abs().max())
+    torch.mm(dy.t(), x, out=out[:, :N]); e2 = float((out[:, :N].float() - ref).abs().max() / ref.abs().max())
+    print(f"K={K} M={M} N={N}: split-K {t_k:.1f} us (err {e1:.1e}), library strided-out {t_l:.1f} us (err {e2:.1e}), library contiguous {t_lc:.1f} us; {2*K*M*N/1e9:.1f} GFLOP")

@@ -17,6 +17,13 @@ OP_DMV1O_INSIDE, OP_DMV1O_INSIDE_OUTSIDE, OP_DEPTREE_INSIDE, OP_DEPTREE_INSIDE_O
 
 _vp, _i, _f, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_longlong
 
+class SmallGemm(ctypes.Structure):
+    """VlgSmallGemm of include/vlgae_amd.h: one problem of vlg_small_gemm_group."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("a", "b", "bias", "u", "v", "c")]
+                + [(n, ctypes.c_longlong) for n in ("sab", "sam", "sak", "sbb", "sbk", "sbn", "scb", "ldc", "sbias", "su", "sv")]
+                + [(n, ctypes.c_int) for n in ("batch", "M", "N", "K", "accumulate", "in_dtype", "out_dtype")] + [("alpha", ctypes.c_float)])
+
+
 # symbol -> (restype, argtypes); one entry per declaration in include/vlgae_amd.h
 SIGNATURES = {
     "vlg_dmv1o_inside": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -70,10 +77,14 @@ SIGNATURES = {
     "vlg_langfeat_arc_out": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "vlg_langfeat_rowscale": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "vlg_small_gemm": (_i, [_vp, _ll, _ll, _ll, _vp, _ll, _ll, _ll, _vp, _ll, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
+    "vlg_small_gemm_group": (_i, [_vp, _i, _vp]),
     "vlg_ff_context_mean": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_ff_mlp_act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "vlg_ff_act": (_i, [_vp, _vp, _vp, _f, _vp, _ll, _i, _i, _i, _i, _f, _vp]),
-    "vlg_ff_act_backward": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp]),
+    "vlg_ff_act": (_i, [_vp, _vp, _vp, _f, _vp, ctypes.c_uint, _f, _vp, _ll, _i, _i, _i, _i, _f, _vp]),
+    "vlg_ff_act_backward": (_i, [_vp, _vp, _vp, _f, _vp, ctypes.c_uint, _f, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp]),
+    "vlg_ff_root_rule": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "vlg_ff_root_rule_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "vlg_dropout_mask": (_i, [_vp, ctypes.c_uint, _f, _vp, _ll, _vp]),
     "vlg_ff_mlp_act_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "vlg_ndmv_potentials": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "vlg_ndmv_potentials_backward_workspace": (_sz, [_i, _i, _i, _i]),

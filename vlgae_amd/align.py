@@ -581,13 +581,8 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None, out_dtype
     return dw, db
 
 
-def small_matmul(a, b, out=None, alpha=1.0, bias=None, rank1=None, accumulate=False, out_dtype=None):
-    """alpha * a @ b (+ bias over the rows, + outer(u, v), + out) for products whose OUTPUT is small -- a few hundred rows and columns,
-    optionally batched: weight-space products such as the folded bottleneck W1 W0 of `DMVSkipConnectEncoder` (nn/dmv_spec.py:52-54), which
-    a library GEMM runs on one workgroup (15-28 us); here one wavefront per 32 x 32 tile (vlg_small_gemm).
-    a [M,K] or [Z,M,K], b [K,N] or [Z,K,N] with ANY strides (transposes / slices are read in place), both bfloat16 (bf16 products) or both
-    float32 (exact fp32 products), fp32 accumulation; bias [N] or [Z,N]; rank1 = (u [M] or [Z,M], v [N] or [Z,N]); out: a [.., M, N] tensor
-    with unit last stride to write (or, accumulate=True, add) into; out_dtype defaults to the operands' dtype."""
+def _small_problem(a, b, out=None, alpha=1.0, bias=None, rank1=None, accumulate=False, out_dtype=None):
+    """Validates one small product and returns (argument tuple in vlg_small_gemm's order without the stream, out tensor)."""
     adt, ash, bsh, ast, bst = a.dtype, a.shape, b.shape, a.stride(), b.stride()     # (host time matters: ~28 calls per training step)
     if adt != b.dtype or (adt != torch.bfloat16 and adt != torch.float32):
         raise ValueError(f"small_matmul: both operands bfloat16 or both float32, got {adt} / {b.dtype}")
@@ -620,13 +615,54 @@ def small_matmul(a, b, out=None, alpha=1.0, bias=None, rank1=None, accumulate=Fa
     bias, sbias = vec(bias, N, "bias") if bias is not None else (None, 0)
     (u, su), (v, sv) = (vec(rank1[0], M, "u"), vec(rank1[1], N, "v")) if rank1 is not None else ((None, 0), (None, 0))
     bf = torch.bfloat16
-    rc = _C.lib().vlg_small_gemm(a.data_ptr(), ast[0] if na == 3 else 0, ast[-2], ast[-1], b.data_ptr(), bst[0] if nb_ == 3 else 0, bst[-2], bst[-1],
-                                 out.data_ptr(), ost[0] if Z else 0, ost[-2], _C.ptr(bias), sbias, _C.ptr(u), su, _C.ptr(v), sv,
-                                 Z if Z else 1, M, N, K, float(alpha), 1 if accumulate else 0, _C.BF16 if adt == bf else _C.F32,
-                                 _C.BF16 if out.dtype == bf else _C.F32, _C.stream_of(a))
+    dp = lambda t: None if t is None else t.data_ptr()
+    return (a.data_ptr(), ast[0] if na == 3 else 0, ast[-2], ast[-1], b.data_ptr(), bst[0] if nb_ == 3 else 0, bst[-2], bst[-1],
+            out.data_ptr(), ost[0] if Z else 0, ost[-2], dp(bias), sbias, dp(u), su, dp(v), sv,
+            Z if Z else 1, M, N, K, float(alpha), 1 if accumulate else 0, _C.BF16 if adt == bf else _C.F32,
+            _C.BF16 if out.dtype == bf else _C.F32), out
+
+
+def small_matmul(a, b, out=None, alpha=1.0, bias=None, rank1=None, accumulate=False, out_dtype=None):
+    """alpha * a @ b (+ bias over the rows, + outer(u, v), + out) for products whose OUTPUT is small -- a few hundred rows and columns,
+    optionally batched: weight-space products such as the folded bottleneck W1 W0 of `DMVSkipConnectEncoder` (nn/dmv_spec.py:52-54), which
+    a library GEMM runs on one workgroup (15-28 us); here one wavefront per 32 x 32 tile (vlg_small_gemm).
+    a [M,K] or [Z,M,K], b [K,N] or [Z,K,N] with ANY strides (transposes / slices are read in place), both bfloat16 (bf16 products) or both
+    float32 (exact fp32 products), fp32 accumulation; bias [N] or [Z,N]; rank1 = (u [M] or [Z,M], v [N] or [Z,N]); out: a [.., M, N] tensor
+    with unit last stride to write (or, accumulate=True, add) into; out_dtype defaults to the operands' dtype."""
+    args, out = _small_problem(a, b, out, alpha, bias, rank1, accumulate, out_dtype)
+    rc = _C.lib().vlg_small_gemm(*args, _C.stream_of(a))
     if rc:
         _C.check(rc, "small_gemm")
     return out
+
+
+class SmallMatmulGroup:
+    """Independent small products collected into ONE launch (vlg_small_gemm_group): `add(...)` takes small_matmul's arguments and returns
+    the output tensor (allocated now, written by `launch()`); no problem of a group may read what another one writes.  One dependency
+    level of the weight-space products of the parser's feed-forwards is one group (vlgae_amd/parser_ff.py)."""
+    _ORDER = ("a", "sab", "sam", "sak", "b", "sbb", "sbk", "sbn", "c", "scb", "ldc", "bias", "sbias", "u", "su", "v", "sv", "batch", "M", "N", "K",
+              "alpha", "accumulate", "in_dtype", "out_dtype")
+
+    def __init__(self):
+        self.problems, self.first = [], None
+
+    def add(self, a, b, out=None, alpha=1.0, bias=None, rank1=None, accumulate=False, out_dtype=None):
+        args, out = _small_problem(a, b, out, alpha, bias, rank1, accumulate, out_dtype)
+        self.problems.append(args)
+        if self.first is None:
+            self.first = a
+        return out
+
+    def launch(self):
+        n = len(self.problems)
+        if n == 0:
+            return
+        arr = (_C.SmallGemm * n)()
+        for rec, args in zip(arr, self.problems):
+            for name, val in zip(self._ORDER, args):
+                setattr(rec, name, val)
+        _C.check(_C.lib().vlg_small_gemm_group(arr, n, _C.stream_of(self.first)), "small_gemm_group")
+        self.problems, self.first = [], None
 
 
 def _wgrad_ok(K, M, N, dtype):

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "vlg_common.h"
+#include "vlg_rng.h"
 #include "vlg_rows.h"
 
 namespace vlg {
@@ -30,32 +31,6 @@ namespace vlg {
 namespace {
 
 constexpr int kEncThreads = 256;
-
-// ---- Philox4x32-10 (Salmon et al., SC'11): counter (idx_lo, idx_hi, step_lo, step_hi), key (seed_lo, seed_hi) ----
-__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
-        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-        key.x += 0x9E3779B9u;
-        key.y += 0xBB67AE85u;
-    }
-    return ctr;
-}
-
-// keep flags of eight consecutive elements (group index g): 16 random bits each, keep <=> bits >= thr, thr = round(p * 65536)
-__device__ __forceinline__ void keep8(const uint64_t* __restrict__ rng, uint32_t site, uint64_t g, uint32_t thr, float scale, float (&m)[8]) {
-    const uint64_t seed = rng[0] + site, step = rng[1];      // `site`: which dropout layer of the step draws (independent streams off one state)
-    const uint4 r = philox4x32_10(make_uint4((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)step, (uint32_t)(step >> 32)),
-                                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        m[2 * k] = (w[k] & 0xffffu) >= thr ? scale : 0.f;
-        m[2 * k + 1] = (w[k] >> 16) >= thr ? scale : 0.f;
-    }
-}
 
 // out = x * mask (+ add): mask = explicit fp32 values (0 or 1/(1-p); [rows, cols] or, shared != 0, one [cols] row per `shared` rows) or
 // the counter-based draw.  `add` (same storage type as out) is the other contribution of a gradient with two producers.
@@ -84,6 +59,18 @@ __global__ __launch_bounds__(kEncThreads) void dropout_kernel(const A* __restric
 }
 
 __global__ void rng_advance_kernel(uint64_t* rng) { rng[1] += 1; }
+
+// explicit masks for the SMALL dropout layers of a step (SharedDropout's [B, d] rows, nn/dropout.py:42-63): out[i] = 0 or scale
+__global__ __launch_bounds__(kEncThreads) void dropout_mask_kernel(const uint64_t* __restrict__ rng, uint32_t site, uint32_t thr, float scale,
+                                                                   float* __restrict__ out, size_t n) {
+    const size_t g = (size_t)blockIdx.x * kEncThreads + threadIdx.x;
+    if (g * 8 >= n) return;
+    float m[8];
+    keep8(rng, site, g, thr, scale, m);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (g * 8 + k < n) out[g * 8 + k] = m[k];
+}
 
 // ---- visual encoder ----
 struct VisArgs {
@@ -264,8 +251,8 @@ int vlg_dropout(const void* x, const float* mask, int shared_rows, const uint64_
     if (!(p >= 0.f && p < 1.f)) return set_error(VLG_ERR_ARG, "dropout: p=%f outside [0, 1)", (double)p);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(add)) & 15)
         return set_error(VLG_ERR_ARG, "dropout: buffers must be 16-byte aligned");
-    const uint32_t thr = (uint32_t)(p * 65536.f + 0.5f);          // keep <=> 16 random bits >= thr: p in steps of 2^-16
-    const float scale = 1.f / (1.f - (float)thr / 65536.f);
+    const uint32_t thr = drop_threshold(p);                       // keep <=> 16 random bits >= thr: p in steps of 2^-16
+    const float scale = drop_scale(p);
     const size_t n = (size_t)rows * (cols >> 3);
     const dim3 grid((unsigned)((n + kEncThreads - 1) / kEncThreads));
     hipStream_t s = (hipStream_t)stream;
@@ -276,6 +263,17 @@ int vlg_dropout(const void* x, const float* mask, int shared_rows, const uint64_
     else VLG_DROP(uint16_t, uint16_t);
 #undef VLG_DROP
     return check_launch("dropout_kernel");
+}
+
+int vlg_dropout_mask(const uint64_t* rng, unsigned site, float p, float* out, long long n, void* stream) {
+    using namespace vlg;
+    if (n < 0 || !(p >= 0.f && p < 1.f)) return set_error(VLG_ERR_ARG, "dropout_mask: n=%lld p=%f", n, (double)p);
+    if (n == 0) return 0;
+    if (!rng || !out) return set_error(VLG_ERR_ARG, "dropout_mask: null buffer");
+    const size_t groups = ((size_t)n + 7) / 8;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((groups + kEncThreads - 1) / kEncThreads)), dim3(kEncThreads), 0, (hipStream_t)stream, rng, site,
+                       drop_threshold(p), drop_scale(p), out, (size_t)n);
+    return check_launch("dropout_mask_kernel");
 }
 
 int vlg_rng_advance(uint64_t* rng, void* stream) {

@@ -20,6 +20,7 @@
 #include <initializer_list>
 
 #include "vlg_common.h"
+#include "vlg_rng.h"
 #include "vlg_rows.h"
 
 namespace vlg {
@@ -60,8 +61,11 @@ __global__ __launch_bounds__(kFfThreads) void ff_mlp_act_kernel(A* X, const A* _
     store8(p, v);
 }
 
+// mask: an explicit keep-mask (times mask_scale), or -- rng != null -- the counter-based draw over the OUTPUT element index (mask_scale =
+// 1 / (1 - p), thr = round(p 2^16)): nn.Dropout without a mask tensor (21 MB per step at B = 256, L = 40 for mid_ff's, nn/dmv_spec.py:52)
 template <typename A>
-__global__ __launch_bounds__(kFfThreads) void ff_act_kernel(const A* in, const A* __restrict__ res, const A* __restrict__ mask, float mask_scale, A* out,
+__global__ __launch_bounds__(kFfThreads) void ff_act_kernel(const A* in, const A* __restrict__ res, const A* __restrict__ mask, float mask_scale,
+                                                            const uint64_t* __restrict__ rng, uint32_t site, uint32_t thr, A* out,
                                                             size_t rows, int J, int H, int swap, float slope) {
     const int hv = H >> 3;
     const size_t i = (size_t)blockIdx.x * kFfThreads + threadIdx.x;
@@ -86,12 +90,18 @@ __global__ __launch_bounds__(kFfThreads) void ff_act_kernel(const A* in, const A
         load8(mask + orow * H + c, t);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] *= t[k] * mask_scale;
+    } else if (rng) {
+        float t[8];
+        keep8(rng, site, orow * hv + (c >> 3), thr, mask_scale, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= t[k];
     }
     store8(out + orow * H + c, v);
 }
 
 template <typename A>
-__global__ __launch_bounds__(kFfThreads) void ff_act_bwd_kernel(const A* g, const A* __restrict__ act, const A* __restrict__ mask, float mask_scale, A* out,
+__global__ __launch_bounds__(kFfThreads) void ff_act_bwd_kernel(const A* g, const A* __restrict__ act, const A* __restrict__ mask, float mask_scale,
+                                                                const uint64_t* __restrict__ rng, uint32_t site, uint32_t thr, A* out,
                                                                 float* sum, size_t M, int J, int H, int swap, int accumulate, float slope) {
     const int hv = H >> 3;
     const size_t i = (size_t)blockIdx.x * kFfThreads + threadIdx.x;
@@ -110,6 +120,11 @@ __global__ __launch_bounds__(kFfThreads) void ff_act_bwd_kernel(const A* g, cons
             load8(mask + row * H + c, t);
 #pragma unroll
             for (int k = 0; k < 8; ++k) gv[k] *= t[k] * mask_scale;
+        } else if (rng) {       // the forward pass's bits again (its mask index is the row it WROTE; no permutation with a mask: checked on the host)
+            float t[8];
+            keep8(rng, site, row * hv + (c >> 3), thr, mask_scale, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gv[k] *= t[k];
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -168,6 +183,82 @@ __global__ __launch_bounds__(256) void ff_colmean_kernel(const T* __restrict__ x
     stf(out, (size_t)b * h + c, acc / (float)L);
 }
 
+// The root rule (ldndmv.py:205): logits[c] = sum_{dv,e} r1[dv,e] r2[c,dv,e] (root_scorer(h_root, h_child).sum over (dir, val)),
+// root_rule = log_softmax over the T tokens.  r1 / r2 are blocks of the small projection product S [4 (T + 3), ld] (rows (c, dv) of the
+// tokens, then the root's four (dir, val) rows): r2 = S[4c + dv, col2..col2+r), r1 = S[4T + dv, col1..col1+r).  One workgroup.
+template <typename A>
+__global__ __launch_bounds__(256) void ff_root_rule_kernel(const A* __restrict__ S, int ld, int T, int r, int col1, int col2, float* __restrict__ root_rule) {
+    extern __shared__ float sh[];          // T logits + 256 reduction slots
+    float* logit = sh;
+    float* red = sh + T;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < T; c += 256) {
+        float acc = 0.f;
+        for (int dv = 0; dv < 4; ++dv)
+            for (int e = 0; e < r; ++e) acc = fmaf(ldf(S, (size_t)(4 * T + dv) * ld + col1 + e), ldf(S, (size_t)(4 * c + dv) * ld + col2 + e), acc);
+        logit[c] = acc;
+    }
+    __syncthreads();
+    float m = -3.4e38f;
+    for (int c = tid; c < T; c += 256) m = fmaxf(m, logit[c]);
+    red[tid] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    m = red[0];
+    __syncthreads();
+    float z = 0.f;
+    for (int c = tid; c < T; c += 256) z += expf(logit[c] - m);
+    red[tid] = z;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float lz = m + logf(red[0]);
+    for (int c = tid; c < T; c += 256) root_rule[c] = logit[c] - lz;
+}
+
+// Its adjoint, and the whole cotangent of S assembled in ONE pass: gS [4 (T + 3), 4r] (column blocks x2 | r2 | r1 | y2) =
+//   rows 4c+dv, block 0: g_x2 (the scorer's cotangent of attach.project2)       block 1: dlogit[c] r1[dv,:]
+//   rows 4T+dv, block 2: sum_c dlogit[c] r2[c,dv,:]                             rows 4T+4.., block 3: g_y2 (8 rows)        zeros elsewhere
+// with dlogit = g_root - softmax * sum(g_root).  One workgroup per 64 rows of gS; every workgroup recomputes the T-term sum of g_root.
+template <typename A>
+__global__ __launch_bounds__(256) void ff_root_rule_bwd_kernel(const A* __restrict__ S, int ld, int T, int r, const float* __restrict__ root_rule,
+                                                               const float* __restrict__ g_root, const A* __restrict__ g_x2, int ld_x2,
+                                                               const A* __restrict__ g_y2, int ld_y2, A* __restrict__ gS) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x, rows = 4 * (T + 3), W = 4 * r;
+    float t = 0.f;
+    for (int c = tid; c < T; c += 256) t += g_root[c];
+    red[tid] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float gsum = red[0];
+    for (int i = blockIdx.x * 64 * W + tid; i < min(rows, (int)(blockIdx.x + 1) * 64) * W; i += 256) {
+        const int row = i / W, col = i - row * W, blk = col / r, e = col - blk * r;
+        float v = 0.f;
+        if (row < 4 * T) {
+            const int c = row >> 2, dv = row & 3;
+            if (blk == 0) v = g_x2 ? ldf(g_x2, (size_t)row * ld_x2 + e) : 0.f;
+            else if (blk == 1) v = (g_root[c] - expf(root_rule[c]) * gsum) * ldf(S, (size_t)(4 * T + dv) * ld + 2 * r + e);
+        } else if (row < 4 * T + 4) {
+            if (blk == 2) {
+                const int dv = row - 4 * T;
+                for (int c = 0; c < T; ++c) v = fmaf(g_root[c] - expf(root_rule[c]) * gsum, ldf(S, (size_t)(4 * c + dv) * ld + r + e), v);
+            }
+        } else if (blk == 3) {
+            v = g_y2 ? ldf(g_y2, (size_t)(row - 4 * T - 4) * ld_y2 + e) : 0.f;
+        }
+        stf(gS, (size_t)i, v);
+    }
+}
+
 int ff_check(const char* what, long long rows, int H, int act_dtype) {
     if (rows < 0 || H < 8 || H % 8) return set_error(VLG_ERR_SHAPE, "%s: rows=%lld H=%d (H must be a positive multiple of 8)", what, rows, H);
     if (act_dtype != VLG_F32 && act_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "%s: act_dtype %d", what, act_dtype);
@@ -210,9 +301,12 @@ int vlg_ff_mlp_act(void* x, const void* cterm, const float* drop_head, const flo
     return check_launch("ff_mlp_act_kernel");
 }
 
-int vlg_ff_act(const void* in, const void* residual, const void* mask, float mask_scale, void* out, long long M, int J, int H, int swap, int act_dtype,
-               float slope, void* stream) {
+int vlg_ff_act(const void* in, const void* residual, const void* mask, float mask_scale, const uint64_t* rng, unsigned site, float p, void* out,
+               long long M, int J, int H, int swap, int act_dtype, float slope, void* stream) {
     using namespace vlg;
+    if (rng && (mask || swap || !(p >= 0.f && p < 1.f))) return set_error(VLG_ERR_ARG, "ff_act: the counter-based draw excludes an explicit mask and the permutation; p=%f", (double)p);
+    const uint32_t thr = rng ? drop_threshold(p) : 0;
+    if (rng) mask_scale = drop_scale(p);
     if (M < 0 || J < 1 || (swap && J != 4)) return set_error(VLG_ERR_SHAPE, "ff_act: M=%lld J=%d swap=%d (the permutation is of J = 4 = (val, dir))", M, J, swap);
     if (int rc = ff_check("ff_act", M * J, H, act_dtype)) return rc;
     if (M == 0) return 0;
@@ -223,16 +317,19 @@ int vlg_ff_act(const void* in, const void* residual, const void* mask, float mas
     hipStream_t s = (hipStream_t)stream;
     if (act_dtype == VLG_BF16)
         hipLaunchKernelGGL(ff_act_kernel<uint16_t>, grid, dim3(kFfThreads), 0, s, (const uint16_t*)in, (const uint16_t*)residual, (const uint16_t*)mask,
-                           mask_scale, (uint16_t*)out, rows, J, H, swap, slope);
+                           mask_scale, rng, site, thr, (uint16_t*)out, rows, J, H, swap, slope);
     else
         hipLaunchKernelGGL(ff_act_kernel<float>, grid, dim3(kFfThreads), 0, s, (const float*)in, (const float*)residual, (const float*)mask, mask_scale,
-                           (float*)out, rows, J, H, swap, slope);
+                           rng, site, thr, (float*)out, rows, J, H, swap, slope);
     return check_launch("ff_act_kernel");
 }
 
-int vlg_ff_act_backward(const void* g, const void* act, const void* mask, float mask_scale, void* out, float* sum, long long M, int J, int H, int swap,
-                        int accumulate, int act_dtype, float slope, void* stream) {
+int vlg_ff_act_backward(const void* g, const void* act, const void* mask, float mask_scale, const uint64_t* rng, unsigned site, float p, void* out,
+                        float* sum, long long M, int J, int H, int swap, int accumulate, int act_dtype, float slope, void* stream) {
     using namespace vlg;
+    if (rng && (mask || swap || !(p >= 0.f && p < 1.f))) return set_error(VLG_ERR_ARG, "ff_act_backward: the counter-based draw excludes an explicit mask and the permutation; p=%f", (double)p);
+    const uint32_t thr = rng ? drop_threshold(p) : 0;
+    if (rng) mask_scale = drop_scale(p);
     if (M < 0 || J < 1 || (swap && J != 4)) return set_error(VLG_ERR_SHAPE, "ff_act_backward: M=%lld J=%d swap=%d", M, J, swap);
     if (int rc = ff_check("ff_act_backward", M * J, H, act_dtype)) return rc;
     if (M == 0) return 0;
@@ -242,10 +339,10 @@ int vlg_ff_act_backward(const void* g, const void* act, const void* mask, float 
     hipStream_t s = (hipStream_t)stream;
     if (act_dtype == VLG_BF16)
         hipLaunchKernelGGL(ff_act_bwd_kernel<uint16_t>, grid, dim3(kFfThreads), 0, s, (const uint16_t*)g, (const uint16_t*)act, (const uint16_t*)mask,
-                           mask_scale, (uint16_t*)out, sum, (size_t)M, J, H, swap, accumulate, slope);
+                           mask_scale, rng, site, thr, (uint16_t*)out, sum, (size_t)M, J, H, swap, accumulate, slope);
     else
         hipLaunchKernelGGL(ff_act_bwd_kernel<float>, grid, dim3(kFfThreads), 0, s, (const float*)g, (const float*)act, (const float*)mask, mask_scale,
-                           (float*)out, sum, (size_t)M, J, H, swap, accumulate, slope);
+                           rng, site, thr, (float*)out, sum, (size_t)M, J, H, swap, accumulate, slope);
     return check_launch("ff_act_bwd_kernel");
 }
 
@@ -283,6 +380,36 @@ int vlg_ff_context_mean(const void* x, int in_dtype, int B, int L, int h, void* 
     else if (out_dtype == VLG_F32) hipLaunchKernelGGL((ff_colmean_kernel<uint16_t, float>), grid, dim3(256), 0, s, (const uint16_t*)x, L, h, (float*)out);
     else hipLaunchKernelGGL((ff_colmean_kernel<uint16_t, uint16_t>), grid, dim3(256), 0, s, (const uint16_t*)x, L, h, (uint16_t*)out);
     return check_launch("ff_colmean_kernel");
+}
+
+int vlg_ff_root_rule(const void* small, int ld, int T, int r, int act_dtype, float* root_rule, void* stream) {
+    using namespace vlg;
+    if (T < 1 || r < 1 || ld < 4 * r || T > 8192) return set_error(VLG_ERR_SHAPE, "ff_root_rule: T=%d r=%d ld=%d", T, r, ld);
+    if (act_dtype != VLG_F32 && act_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "ff_root_rule: act_dtype %d", act_dtype);
+    if (!small || !root_rule) return set_error(VLG_ERR_ARG, "ff_root_rule: null buffer");
+    const size_t lds = sizeof(float) * ((size_t)T + 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (act_dtype == VLG_BF16) hipLaunchKernelGGL(ff_root_rule_kernel<uint16_t>, dim3(1), dim3(256), lds, s, (const uint16_t*)small, ld, T, r, 2 * r, r, root_rule);
+    else hipLaunchKernelGGL(ff_root_rule_kernel<float>, dim3(1), dim3(256), lds, s, (const float*)small, ld, T, r, 2 * r, r, root_rule);
+    return check_launch("ff_root_rule_kernel");
+}
+
+int vlg_ff_root_rule_backward(const void* small, int ld, int T, int r, int act_dtype, const float* root_rule, const float* g_root, const void* g_x2,
+                              int ld_x2, const void* g_y2, int ld_y2, void* g_small, void* stream) {
+    using namespace vlg;
+    if (T < 1 || r < 1 || ld < 4 * r || T > 8192) return set_error(VLG_ERR_SHAPE, "ff_root_rule_backward: T=%d r=%d ld=%d", T, r, ld);
+    if (act_dtype != VLG_F32 && act_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "ff_root_rule_backward: act_dtype %d", act_dtype);
+    if (!small || !root_rule || !g_root || !g_small) return set_error(VLG_ERR_ARG, "ff_root_rule_backward: null buffer");
+    if ((g_x2 && ld_x2 < r) || (g_y2 && ld_y2 < r)) return set_error(VLG_ERR_SHAPE, "ff_root_rule_backward: ld_x2=%d ld_y2=%d below r=%d", ld_x2, ld_y2, r);
+    const dim3 grid((4 * (T + 3) + 63) / 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (act_dtype == VLG_BF16)
+        hipLaunchKernelGGL(ff_root_rule_bwd_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)small, ld, T, r, root_rule, g_root, (const uint16_t*)g_x2, ld_x2,
+                           (const uint16_t*)g_y2, ld_y2, (uint16_t*)g_small);
+    else
+        hipLaunchKernelGGL(ff_root_rule_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)small, ld, T, r, root_rule, g_root, (const float*)g_x2, ld_x2,
+                           (const float*)g_y2, ld_y2, (float*)g_small);
+    return check_launch("ff_root_rule_bwd_kernel");
 }
 
 }  // extern "C"

@@ -261,14 +261,14 @@ __device__ __forceinline__ void sg_st(uint16_t* p, long long i, float v) {
 }
 
 template <bool F32IN, typename Out>
-__global__ __launch_bounds__(64) void small_gemm_kernel(SgArgs p) {
+__device__ __forceinline__ void small_gemm_tile(const SgArgs& p, int tile, int z) {
     using Cfg = MfmaCfg<F32IN>;
     using T = typename Cfg::T;
     using Frag = typename Cfg::Frag;
     constexpr int KW = Cfg::KW, EPL = Cfg::EPL;
     const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
     const int tiles_n = (p.N + 31) / 32;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n, z = blockIdx.y;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const T* A = static_cast<const T*>(p.a) + (long long)z * p.sab;
     const T* B = static_cast<const T*>(p.b) + (long long)z * p.sbb;
     f32x4 acc[2][2];
@@ -362,6 +362,38 @@ __global__ __launch_bounds__(64) void small_gemm_kernel(SgArgs p) {
         }
 }
 
+template <bool F32IN, typename Out>
+__global__ __launch_bounds__(64) void small_gemm_kernel(SgArgs p) {
+    small_gemm_tile<F32IN, Out>(p, blockIdx.x, blockIdx.y);
+}
+
+// Several INDEPENDENT small products in one launch (round 5): the weight-space products of one dependency level of the parser's
+// feed-forwards (the four folded bottlenecks, the folded projections, the token / root / decision MLP rows, the context term: eight
+// launches of 4.5-15 us each, ~7 us of it launch + tail) as one grid.  The descriptors travel by value in the kernel argument
+// (12 x 176 bytes); workgroup x finds its problem by a scan of the tile prefix (uniform: scalar code).
+constexpr int kSgGroupMax = 12;
+struct SgGroup {
+    SgArgs p[kSgGroupMax];
+    int start[kSgGroupMax + 1];      // first workgroup of problem i; start[count] = grid size
+    int tiles[kSgGroupMax];          // tiles per batch entry
+    unsigned char f32in[kSgGroupMax], f32out[kSgGroupMax];
+    int count;
+};
+
+__global__ __launch_bounds__(64) void small_gemm_group_kernel(SgGroup gp) {
+    int i = 0;
+    while (i + 1 < gp.count && (int)blockIdx.x >= gp.start[i + 1]) ++i;
+    const int local = blockIdx.x - gp.start[i], z = local / gp.tiles[i], tile = local - z * gp.tiles[i];
+    const SgArgs& p = gp.p[i];
+    if (gp.f32in[i]) {
+        if (gp.f32out[i]) small_gemm_tile<true, float>(p, tile, z);
+        else small_gemm_tile<true, uint16_t>(p, tile, z);
+    } else {
+        if (gp.f32out[i]) small_gemm_tile<false, float>(p, tile, z);
+        else small_gemm_tile<false, uint16_t>(p, tile, z);
+    }
+}
+
 struct TnPlan {
     int KC, S;
     size_t bytes;
@@ -420,9 +452,9 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
     return check_launch("gemm_reduce_kernel");
 }
 
-int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, const void* b, long long sbb, long long sbk, long long sbn,
+static int sg_make(vlg::SgArgs& p, const void* a, long long sab, long long sam, long long sak, const void* b, long long sbb, long long sbk, long long sbn,
                    void* c, long long scb, long long ldc, const void* bias, long long sbias, const void* u, long long su, const void* v,
-                   long long sv, int batch, int M, int N, int K, float alpha, int accumulate, int in_dtype, int out_dtype, void* stream) {
+                   long long sv, int batch, int M, int N, int K, float alpha, int accumulate, int in_dtype, int out_dtype) {
     using namespace vlg;
     if (batch < 0 || M < 1 || N < 1 || K < 1 || batch > 65535)
         return set_error(VLG_ERR_SHAPE, "small_gemm: bad shape batch=%d M=%d N=%d K=%d", batch, M, N, K);
@@ -430,11 +462,9 @@ int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, c
         return set_error(VLG_ERR_DTYPE, "small_gemm: dtypes %d -> %d", in_dtype, out_dtype);
     if (ldc < N) return set_error(VLG_ERR_SHAPE, "small_gemm: ldc=%lld below N=%d", ldc, N);
     if ((u == nullptr) != (v == nullptr)) return set_error(VLG_ERR_ARG, "small_gemm: the rank-one term needs both u and v");
-    if (batch == 0) return 0;
-    if (!a || !b || !c) return set_error(VLG_ERR_ARG, "small_gemm: null buffer");
+    if (batch && (!a || !b || !c)) return set_error(VLG_ERR_ARG, "small_gemm: null buffer");
     // widest load per fragment of each operand (see sg_frag): its contraction index must be the unit-stride one
     const int epl = in_dtype == VLG_F32 ? 4 : 8;
-    const long long esz = in_dtype == VLG_F32 ? 4 : 2;
     auto width = [&](const void* ptr, long long s_contract, long long s_other, long long s_batch) -> int {
         if (s_contract != 1) return 1;
         const uintptr_t addr = reinterpret_cast<uintptr_t>(ptr);
@@ -442,9 +472,50 @@ int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, c
         if (in_dtype == VLG_BF16 && s_other % 2 == 0 && s_batch % 2 == 0 && addr % 4 == 0) return 2;
         return 1;
     };
-    (void)esz;
-    const SgArgs p{a, b, bias, u, v, c, sab, sam, sak, sbb, sbk, sbn, scb, ldc, sbias, su, sv, M, N, K, accumulate,
-                   width(a, sak, sam, sab), width(b, sbk, sbn, sbb), alpha};
+    p = SgArgs{a, b, bias, u, v, c, sab, sam, sak, sbb, sbk, sbn, scb, ldc, sbias, su, sv, M, N, K, accumulate,
+               width(a, sak, sam, sab), width(b, sbk, sbn, sbb), alpha};
+    return 0;
+}
+
+int vlg_small_gemm_group(const VlgSmallGemm* problems, int count, void* stream) {
+    using namespace vlg;
+    if (count < 0 || (count && !problems)) return set_error(VLG_ERR_ARG, "small_gemm_group: count=%d", count);
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < count; base += kSgGroupMax) {       // more than 12 problems: several launches of up to 12
+        SgGroup gp;
+        gp.count = 0;
+        int blocks = 0;
+        for (int i = base; i < count && i < base + kSgGroupMax; ++i) {
+            const VlgSmallGemm& q = problems[i];
+            SgArgs p;
+            if (int rc = sg_make(p, q.a, q.sab, q.sam, q.sak, q.b, q.sbb, q.sbk, q.sbn, q.c, q.scb, q.ldc, q.bias, q.sbias, q.u, q.su, q.v, q.sv, q.batch,
+                                 q.M, q.N, q.K, q.alpha, q.accumulate, q.in_dtype, q.out_dtype))
+                return rc;
+            if (q.batch == 0) continue;
+            const int k = gp.count++;
+            gp.p[k] = p;
+            gp.tiles[k] = ((q.M + 31) / 32) * ((q.N + 31) / 32);
+            gp.start[k] = blocks;
+            gp.f32in[k] = q.in_dtype == VLG_F32;
+            gp.f32out[k] = q.out_dtype == VLG_F32;
+            blocks += gp.tiles[k] * q.batch;
+        }
+        if (gp.count == 0) continue;
+        gp.start[gp.count] = blocks;
+        hipLaunchKernelGGL(small_gemm_group_kernel, dim3(blocks), dim3(64), 0, s, gp);
+        if (int rc = check_launch("small_gemm_group_kernel")) return rc;
+    }
+    return 0;
+}
+
+int vlg_small_gemm(const void* a, long long sab, long long sam, long long sak, const void* b, long long sbb, long long sbk, long long sbn,
+                   void* c, long long scb, long long ldc, const void* bias, long long sbias, const void* u, long long su, const void* v,
+                   long long sv, int batch, int M, int N, int K, float alpha, int accumulate, int in_dtype, int out_dtype, void* stream) {
+    using namespace vlg;
+    SgArgs p;
+    if (int rc = sg_make(p, a, sab, sam, sak, b, sbb, sbk, sbn, c, scb, ldc, bias, sbias, u, su, v, sv, batch, M, N, K, alpha, accumulate, in_dtype, out_dtype))
+        return rc;
+    if (batch == 0) return 0;
     const dim3 grid(((M + 31) / 32) * ((N + 31) / 32), batch);
     hipStream_t s = (hipStream_t)stream;
     if (in_dtype == VLG_F32 && out_dtype == VLG_F32) hipLaunchKernelGGL((small_gemm_kernel<true, float>), grid, dim3(64), 0, s, p);

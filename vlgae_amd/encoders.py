@@ -28,7 +28,7 @@ from . import _C
 from .align import linear, linear_wgrad
 
 SLOPE = 0.01   # nn.LeakyReLU() default (nn/common.py:31)
-SITE_TEXT_ENCODER, SITE_MID_FF = 1, 2   # which dropout layer of a step draws from the shared DeviceRng state
+SITE_TEXT_ENCODER, SITE_MID_FF, SITE_SHARED, SITE_SHARED_FF = 1, 2, 3, 4   # which dropout layer of a step draws from the shared DeviceRng state
 
 
 class DeviceRng:
@@ -41,6 +41,15 @@ class DeviceRng:
 
     def advance(self):
         _C.check(_C.lib().vlg_rng_advance(_C.ptr(self.state), _C.stream_of(self.state)), "rng_advance")
+
+
+def dropout_mask(rng, site, p, n=None, out=None):
+    """Explicit float32 masks (0 or 1/(1-p)) from the counter-based generator, n values or into `out` (float32, contiguous): the small
+    SharedDropout layers of a step (rows of [B, d]) in one launch (vlg_dropout_mask)."""
+    if out is None:
+        out = torch.empty((int(n),), dtype=torch.float32, device=rng.state.device)
+    _C.check(_C.lib().vlg_dropout_mask(_C.ptr(rng.state), int(site), float(p), _C.ptr(out), out.numel(), _C.stream_of(out)), "dropout_mask")
+    return out
 
 
 def _adt(t):

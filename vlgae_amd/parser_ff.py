@@ -33,9 +33,10 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _C
-from .align import _wgrad_ok, linear_wgrad, small_matmul
+from .align import SmallMatmulGroup, _wgrad_ok, linear_wgrad, small_matmul
 
 SLOPE = 0.01   # nn.LeakyReLU() default (nn/common.py:31, nn/dmv_spec.py:10)
+SITE_MID_FF = 2   # the dropout layer id of mid_ff's nn.Dropout in the step's shared counter-based generator (encoders.SITE_MID_FF)
 _BOTTLENECKS = ("NOCHILD_linear", "HASCHILD_linear", "LEFT_linear", "RIGHT_linear")   # stack order: [no, has] (:42), [left, right] (:47)
 _PROJ = ("attach_scorer.project1", "dec_scorer.project1", "attach_scorer.project2", "root_scorer.project2", "root_scorer.project1",
          "dec_scorer.project2")      # first two: the rows of h_parent; then h_child (x2, root's second operand), h_root, h_dec
@@ -97,17 +98,19 @@ def _adt(t):
     return _C.BF16 if t.dtype == torch.bfloat16 else _C.F32
 
 
-def _act(inp, out, M, J, H, residual=None, mask=None, swap=False, mask_scale=1.0):
-    """out[m,j'] = LeakyReLU(inp[m,j] + residual[m]) * mask[m,j'] * mask_scale in one pass (vlg_ff_act); out may be inp unless swap."""
-    _C.check(_C.lib().vlg_ff_act(_C.ptr(inp), _C.ptr(residual), _C.ptr(mask), float(mask_scale), _C.ptr(out), M, J, H, int(swap), _adt(inp), SLOPE,
-                                 _C.stream_of(inp)), "ff_act")
+def _act(inp, out, M, J, H, residual=None, mask=None, swap=False, mask_scale=1.0, rng=None, p=0.0):
+    """out[m,j'] = LeakyReLU(inp[m,j] + residual[m]) * mask[m,j'] * mask_scale in one pass (vlg_ff_act); out may be inp unless swap.
+    rng (a DeviceRng) instead of mask: the keep-mask is drawn inside the kernel (rate p, site SITE_MID_FF)."""
+    _C.check(_C.lib().vlg_ff_act(_C.ptr(inp), _C.ptr(residual), _C.ptr(mask), float(mask_scale), None if rng is None else _C.ptr(rng.state), SITE_MID_FF,
+                                 float(p), _C.ptr(out), M, J, H, int(swap), _adt(inp), SLOPE, _C.stream_of(inp)), "ff_act")
     return out
 
 
-def _act_bwd(g, act, out, M, J, H, mask=None, total=None, accumulate=False, swap=False, mask_scale=1.0):
+def _act_bwd(g, act, out, M, J, H, mask=None, total=None, accumulate=False, swap=False, mask_scale=1.0, rng=None, p=0.0):
     """out[m,j'] = LeakyReLU'(act[m,j]) * g[m,j] * mask[m,j] * mask_scale; total [M,H] fp32 (+)= sum_j (vlg_ff_act_backward)."""
-    _C.check(_C.lib().vlg_ff_act_backward(_C.ptr(g), _C.ptr(act), _C.ptr(mask), float(mask_scale), _C.ptr(out), _C.ptr(total), M, J, H, int(swap),
-                                          int(accumulate), _adt(g), SLOPE, _C.stream_of(g)), "ff_act_backward")
+    _C.check(_C.lib().vlg_ff_act_backward(_C.ptr(g), _C.ptr(act), _C.ptr(mask), float(mask_scale), None if rng is None else _C.ptr(rng.state),
+                                          SITE_MID_FF, float(p), _C.ptr(out), _C.ptr(total), M, J, H, int(swap), int(accumulate), _adt(g), SLOPE,
+                                          _C.stream_of(g)), "ff_act_backward")
     return out
 
 
@@ -163,29 +166,10 @@ class _ParserFF(torch.autograd.Function):
         We, Wc = Wh[:, :E], Wh[:, E:]
         _validate_shapes(P, nb, H, E + h)
         emb2 = emb.detach().reshape(M0, E)
-        # ---- MLPs: all rows into one [M, H] buffer ----
-        X = torch.empty((M, H), dtype=act, device=dev)
-        torch.mm(emb2, We.t(), out=X[:M0])
-        xd = x.detach()
-        if xd.dtype in (torch.float32, torch.bfloat16) and xd.is_contiguous():           # context_mode 'mean', ldndmv.py:226: cast + mean in one launch
-            cmean = torch.empty((B, h), dtype=act, device=dev)
-            _C.check(_C.lib().vlg_ff_context_mean(_C.ptr(xd), _adt(xd), B, L, h, _C.ptr(cmean), _C.BF16 if act == torch.bfloat16 else _C.F32,
-                                                  _C.stream_of(xd)), "ff_context_mean")
-        else:
-            cmean = xd.mean(1, dtype=act)
-        cterm = small_matmul(cmean, Wc.t(), bias=bh)                                    # [B,H]: the context columns + bias, once per sentence
-        small_in = (token_emb, root_emb, dec_emb)
-        o = M0
-        for m, inp in zip(("child_ff", "root_ff", "dec_ff"), small_in):
-            n = inp.shape[0]
-            small_matmul(c(inp.detach()), c(P[f"ff.{m}.linear.weight"]).t(), bias=c(P[f"ff.{m}.linear.bias"]), out=X[o:o + n])   # (T | 1 | 2 rows)
-            o += n
-        # + context term, LeakyReLU, SharedDropout of the MLPs (after the activation, nn/common.py:47-51): [B,1,H] masks shared over a
-        # sentence's positions for head_ff, one value per ROW for the 2-D inputs of the other three (nn/dropout.py:52-53)
         drop_head, drop_small, drop_mid, mid_scale = drops
+        mid_rng, mid_mask, p_mid = (drop_mid[0], None, drop_mid[1]) if isinstance(drop_mid, tuple) else (None, drop_mid, 0.0)
         lib, st, adt = _C.lib(), _C.stream_of(emb), _C.BF16 if act == torch.bfloat16 else _C.F32
-        _C.check(lib.vlg_ff_mlp_act(_C.ptr(X), _C.ptr(cterm), _C.ptr(drop_head), _C.ptr(drop_small), B, L, Ms, H, adt, SLOPE, st), "ff_mlp_act")
-        # ---- folded bottlenecks; the projections stacked: the 16 + 12 parameter tensors gathered (and cast) by ONE multi-tensor copy ----
+        # ---- the parameters stacked: the 16 + 12 bottleneck / projection tensors gathered (and cast) by ONE multi-tensor copy ----
         r = P[f"ff.{_PROJ[0]}.weight"].shape[0]
         shapes = ([(4, nb, H), (4, nb), (4, H, nb), (4, H)] if nb else [(4, H, H), (4, H)]) + [(6, r, H), (6, r)]
         flat = torch.empty(sum(-(-_numel(sh) // 128) * 128 for sh in shapes), dtype=act, device=dev)   # (every stack 256-byte aligned)
@@ -195,16 +179,42 @@ class _ParserFF(torch.autograd.Function):
             o += -(-_numel(sh) // 128) * 128
         srcs = [[P[f"ff.mid_ff.{b}{sfx}"] for b in _BOTTLENECKS] for sfx in ((".0.weight", ".0.bias", ".1.weight", ".1.bias") if nb else (".weight", ".bias"))]
         srcs += [[P[f"ff.{p}.weight"] for p in _PROJ], [P[f"ff.{p}.bias"] for p in _PROJ]]
-        torch._foreach_copy_([st[k] for st, src in zip(stacks, srcs) for k in range(len(src))], [t for src in srcs for t in src])
+        torch._foreach_copy_([st_[k] for st_, src in zip(stacks, srcs) for k in range(len(src))], [t for src in srcs for t in src])
         PW, Pb = stacks[-2].view(6 * r, H), stacks[-1].view(6 * r)
+        W2_, b2_ = c(P["ff.mid_ff.linear2.weight"]), c(P["ff.mid_ff.linear2.bias"])
+        # ---- MLPs: all rows into one [M, H] buffer ----
+        X = torch.empty((M, H), dtype=act, device=dev)
+        torch.mm(emb2, We.t(), out=X[:M0])
+        xd = x.detach()
+        if xd.dtype in (torch.float32, torch.bfloat16) and xd.is_contiguous():           # context_mode 'mean', ldndmv.py:226: cast + mean in one launch
+            cmean = torch.empty((B, h), dtype=act, device=dev)
+            _C.check(lib.vlg_ff_context_mean(_C.ptr(xd), _adt(xd), B, L, h, _C.ptr(cmean), adt, st), "ff_context_mean")
+        else:
+            cmean = xd.mean(1, dtype=act)
+        # ---- every product in WEIGHT space that depends on parameters (and the sentence means) only, as ONE grouped launch: the context term,
+        # the token / root / decision MLP rows, the folded bottlenecks W1 W0 (+ biases), the folded projections P W2 (+ biases) ----
+        grp = SmallMatmulGroup()
+        cterm = grp.add(cmean, Wc.t(), bias=bh)                                          # [B,H]: the context columns + bias, once per sentence
+        small_in = (token_emb, root_emb, dec_emb)
+        o = M0
+        for m, inp in zip(("child_ff", "root_ff", "dec_ff"), small_in):
+            n = inp.shape[0]
+            grp.add(c(inp.detach()), c(P[f"ff.{m}.linear.weight"]).t(), bias=c(P[f"ff.{m}.linear.bias"]), out=X[o:o + n])   # (T | 1 | 2 rows)
+            o += n
         if nb:
             W0s, b0s, W1s, b1s = stacks[:4]                                                 # [4,nb,H], [4,nb], [4,H,nb], [4,H]
-            Weff = small_matmul(W1s, W0s)                                                   # [4,H,H] (one wavefront per 32 x 32 tile: the library runs this on 4 workgroups)
+            Weff = grp.add(W1s, W0s)                                                        # [4,H,H] (one wavefront per 32 x 32 tile: the library runs this on 4 workgroups)
             # (the library's batched bf16 matrix-VECTOR product costs ~10 ms of HOST time per call on this stack; here: one column, b1 as the rank-one term)
-            beff = small_matmul(W1s, b0s.unsqueeze(-1), rank1=(b1s, _ones(4, act, dev))).squeeze(-1)   # [4,H] = W1 b0 + b1
+            beff = grp.add(W1s, b0s.unsqueeze(-1), rank1=(b1s, _ones(4, act, dev))).squeeze(-1)   # [4,H] = W1 b0 + b1
         else:
             W0s = b0s = W1s = b1s = None
             Weff, beff = stacks[:2]
+        Wp = grp.add(PW, W2_)                                                            # [6r,H]: P W2 (linear2 folded into the projections)
+        bp = grp.add(PW, b2_.unsqueeze(-1), rank1=(Pb, _ones(1, act, dev)[0])).squeeze(-1)   # P b2 + p
+        grp.launch()
+        # + context term, LeakyReLU, SharedDropout of the MLPs (after the activation, nn/common.py:47-51): [B,1,H] masks shared over a
+        # sentence's positions for head_ff, one value per ROW for the 2-D inputs of the other three (nn/dropout.py:52-53)
+        _C.check(lib.vlg_ff_mlp_act(_C.ptr(X), _C.ptr(cterm), _C.ptr(drop_head), _C.ptr(drop_small), B, L, Ms, H, adt, SLOPE, st), "ff_mlp_act")
         W_nh, b_nh = Weff[0:2].reshape(2 * H, H), beff[0:2].reshape(2 * H)
         W_lr, b_lr = Weff[2:4].reshape(2 * H, H), beff[2:4].reshape(2 * H)
         # ---- valence stage, nn/dmv_spec.py:41-44 ----
@@ -219,14 +229,11 @@ class _ParserFF(torch.autograd.Function):
         _act(Z, A3, M, 4, H, residual=X, swap=True)
         Wd, bd = c(P["ff.mid_ff.direction_linear.weight"]), c(P["ff.mid_ff.direction_linear.bias"])
         A4 = torch.addmm(bd, A3.view(4 * M, H), Wd.t())
-        _act(A4, A4, 4 * M, 1, H, mask=drop_mid, mask_scale=mid_scale)                  # nn.Dropout after the direction stage (nn/dmv_spec.py:52)
+        _act(A4, A4, 4 * M, 1, H, mask=mid_mask, mask_scale=mid_scale, rng=mid_rng, p=p_mid)   # nn.Dropout after the direction stage (nn/dmv_spec.py:52)
         # ---- output stage, :52-54 with linear2 folded into the projections ----
         W1_, b1_ = c(P["ff.mid_ff.linear1.weight"]), c(P["ff.mid_ff.linear1.bias"])
         A5 = torch.addmm(b1_, A4, W1_.t())
         _act(A5, A5, 4 * M, 1, H)
-        W2_, b2_ = c(P["ff.mid_ff.linear2.weight"]), c(P["ff.mid_ff.linear2.bias"])
-        Wp = small_matmul(PW, W2_)                                                      # [6r,H]: P W2
-        bp = small_matmul(PW, b2_.unsqueeze(-1), rank1=(Pb, _ones(1, act, dev)[0])).squeeze(-1)   # P b2 + p
         big = torch.addmm(bp[:2 * r], A5[:4 * M0], Wp[:2 * r].t())                      # [4 M0, 2r]: attach.project1 | dec.project1
         small = small_matmul(A5[4 * M0:], Wp[2 * r:].t(), bias=bp[2 * r:])                # [4 Ms, 4r]: attach.p2 | root.p2 | root.p1 | dec.p2
         # the scorers' inputs as VIEWS of the two products (vlgae_amd.scorer takes rows a constant stride apart in place); they are outputs
@@ -235,14 +242,11 @@ class _ParserFF(torch.autograd.Function):
         y1 = big[:, r:].view(B, L, 2, 2, r)
         x2 = small[:4 * T, :r].view(T, 2, 2, r)
         y2 = small[4 * T + 4:, 3 * r:].view(2, 2, 2, r)
-        r2f = torch.empty((T, 4 * r), dtype=torch.float32, device=dev)                   # (cast + gather of the strided slice: one launch each)
-        r2f.view(4 * T, r).copy_(small[:4 * T, r:2 * r])
-        r1f = torch.empty((1, 4 * r), dtype=torch.float32, device=dev)
-        r1f.view(4, r).copy_(small[4 * T:4 * T + 4, 2 * r:3 * r])
-        root_rule = small_matmul(r1f, r2f.t()).log_softmax(-1)[0]                                  # ldndmv.py:205: sum over (dir, val), softmax over tokens
+        root_rule = torch.empty((T,), dtype=torch.float32, device=dev)                   # ldndmv.py:205: sum over (dir, val), softmax over tokens: one launch
+        _C.check(lib.vlg_ff_root_rule(_C.ptr(small), 4 * r, T, r, adt, _C.ptr(root_rule), st), "ff_root_rule")
         ctx.save_for_backward(emb2, cmean, X, A1, A2, A3, A4, A5, We, Wc, W_nh, W_lr, Wv, Wd, W1_, W2_, b2_, PW, Wp, W0s, b0s, W1s,
                               *(c(t.detach()) for t in small_in), *(c(P[f"ff.{m}.linear.weight"]) for m in ("child_ff", "root_ff", "dec_ff")),
-                              r1f, r2f, root_rule)
+                              small, root_rule)
         ctx.drops = drops
         ctx.meta = (nb, B, L, E, h, T, H, r, act, [t.dtype for t in (emb, x, token_emb, root_emb, dec_emb)], [p.dtype for p in params])
         return x1, x2, y1, y2, root_rule
@@ -251,40 +255,46 @@ class _ParserFF(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, g_x1, g_x2, g_y1, g_y2, g_root):
         (emb2, cmean, X, A1, A2, A3, A4, A5, We, Wc, W_nh, W_lr, Wv, Wd, W1_, W2_, b2_, PW, Wp, W0s, b0s, W1s, tok, rootE, decE,
-         Wchild, Wroot, Wdec, r1f, r2f, root_rule) = ctx.saved_tensors
+         Wchild, Wroot, Wdec, small, root_rule) = ctx.saved_tensors
         nb, B, L, E, h, T, H, r, act, in_dt, p_dt = ctx.meta
         M0, Ms = B * L, T + 3
         M = M0 + Ms
+        dev = A5.device
+        drop_mid = ctx.drops[2]
+        mid_rng, mid_mask, p_mid = (drop_mid[0], None, drop_mid[1]) if isinstance(drop_mid, tuple) else (None, drop_mid, 0.0)
+        lib, st, adt = _C.lib(), _C.stream_of(A5), _C.BF16 if act == torch.bfloat16 else _C.F32
         G = {}
         if (g_x1.dtype == act and g_y1.dtype == act and g_x1.stride() == g_y1.stride() == (L * 8 * r, 8 * r, 4 * r, 2 * r, 1)
                 and g_y1.data_ptr() == g_x1.data_ptr() + r * g_x1.element_size()):
             g_big = g_x1.as_strided((4 * M0, 2 * r), (2 * r, 1), g_x1.storage_offset())   # the scorer's adjoint wrote them side by side
         else:
             g_big = torch.cat([g_x1.reshape(4 * M0, r), g_y1.reshape(4 * M0, r)], 1).to(act)
-        dlogit = torch._log_softmax_backward_data(g_root.float(), root_rule, 0, torch.float32).unsqueeze(0)   # [1,T]
-        g_small = torch.zeros((4 * Ms, 4 * r), dtype=act, device=g_big.device)
-        g_small[:4 * T, :r] = g_x2.reshape(4 * T, r)
-        # d r2[c,dv,:] = dlogit[c] r1[dv,:] and d r1[dv,:] = sum_c dlogit[c] r2[c,dv,:], batched over the four (dir, val) and written (cast) in place:
-        # the [4,T,r] / [4,1,r] views of the two blocks of g_small have unit last stride
-        small_matmul(dlogit.t(), r1f.view(4, 1, r), out=g_small[:4 * T, r:2 * r].view(T, 4, r).transpose(0, 1))
-        small_matmul(dlogit, r2f.view(T, 4, r).transpose(0, 1), out=g_small[4 * T:4 * T + 4, 2 * r:3 * r].unsqueeze(1))
-        g_small[4 * T + 4:, 3 * r:] = g_y2.reshape(8, r)
+        # the cotangent of the small product in ONE pass: the scorers' g_x2 / g_y2 blocks, the root rule's adjoint (log-softmax backward,
+        # d r2[c,dv,:] = dlogit[c] r1[dv,:], d r1[dv,:] = sum_c dlogit[c] r2[c,dv,:]), zeros elsewhere
+        def rows_of(t, n):
+            t = t.reshape(n, r)
+            t = t if t.dtype == act else t.to(act)
+            return t if t.stride(1) == 1 else t.contiguous()
+        gx2, gy2 = rows_of(g_x2, 4 * T), rows_of(g_y2, 8)
+        g_small = torch.empty((4 * Ms, 4 * r), dtype=act, device=dev)
+        _C.check(lib.vlg_ff_root_rule_backward(_C.ptr(small), 4 * r, T, r, adt, _C.ptr(root_rule), _C.ptr(g_root.float().contiguous()), _C.ptr(gx2),
+                                               gx2.stride(0), _C.ptr(gy2), gy2.stride(0), _C.ptr(g_small), st), "ff_root_rule_backward")
         # ---- folded projections ----
         gA5 = torch.empty_like(A5)
         torch.mm(g_big, Wp[:2 * r], out=gA5[:4 * M0])
-        small_matmul(g_small, Wp[2 * r:], out=gA5[4 * M0:])
         # (everything below in the activations' dtype: as fp32 GEMMs on one workgroup each the library takes 30-50 us for these products)
-        dWp, dbp = torch.empty((6 * r, H), dtype=act, device=g_big.device), torch.empty((6 * r,), dtype=act, device=g_big.device)
+        dWp, dbp = torch.empty((6 * r, H), dtype=act, device=dev), torch.empty((6 * r,), dtype=act, device=dev)
         _wgrad(g_big, A5[:4 * M0], out=(dWp[:2 * r], dbp[:2 * r]))                      # [2r,H], [2r]: split-K, written in place
-        small_matmul(g_small.t(), A5[4 * M0:], out=dWp[2 * r:])                         # [4r,H]: 4 (T + 3) rows
-        torch.sum(g_small, 0, out=dbp[2 * r:])
-        dPW = small_matmul(dWp, W2_.t(), rank1=(dbp, b2_))                               # Wp = PW W2, bp = PW b2 + Pb: dPW = dWp W2^T + dbp b2^T
-        G["linear2.w"], G["linear2.b"] = small_matmul(PW.t(), dWp), small_matmul(PW.t(), dbp.unsqueeze(-1)).squeeze(-1)   # P^T dWp, P^T dbp
+        grp = SmallMatmulGroup()
+        grp.add(g_small, Wp[2 * r:], out=gA5[4 * M0:])
+        grp.add(g_small.t(), A5[4 * M0:], out=dWp[2 * r:])                              # [4r,H]: 4 (T + 3) rows
+        grp.add(_ones(4 * Ms, act, dev).t(), g_small, out=dbp[2 * r:].unsqueeze(0))     # column sums as a product with ones (no reduce launch)
+        grp.launch()
         # ---- linear1, direction ----
         g = _act_bwd(gA5, A5, gA5, 4 * M, 1, H)
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4, dtype=act)
         g = g @ W1_
-        _act_bwd(g, A4, g, 4 * M, 1, H, mask=ctx.drops[2], mask_scale=ctx.drops[3])
+        _act_bwd(g, A4, g, 4 * M, 1, H, mask=mid_mask, mask_scale=ctx.drops[3], rng=mid_rng, p=p_mid)
         G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H), dtype=act)
         g = g @ Wd                                                                       # [m,dir,val,c]
         gX = torch.empty((M, H), dtype=torch.float32, device=g.device)                   # the skip connections' cotangent
@@ -307,25 +317,32 @@ class _ParserFF(torch.autograd.Function):
         _C.check(_C.lib().vlg_ff_mlp_act_backward(_C.ptr(gX), _C.ptr(gT), _C.ptr(X), _C.ptr(ctx.drops[0]), _C.ptr(ctx.drops[1]),
                                                   _C.ptr(gpre), B, L, Ms, H, _adt(gpre), SLOPE, _C.stream_of(gpre)), "ff_mlp_act_backward")
         gb = gpre[:M0]
-        dWe, dbh = _wgrad(gb, emb2, dtype=act)                                           # [H,E], [H]
+        dWh = torch.empty((H, E + h), dtype=act, device=dev)                             # head_ff's [H, E + h] gradient: both column blocks written in place
+        dbh = torch.empty((H,), dtype=act, device=dev)
+        _wgrad(gb, emb2, out=(dWh[:, :E], dbh))                                          # [H,E], [H]
         g_emb = gb @ We                                                                  # [M0,E]
         gc = gb.view(B, L, H).sum(1)                                                     # [B,H] (fp32 accumulation inside the reduction)
-        dWc = small_matmul(gc.t(), cmean)                                                # [H,h]
-        g_cmean = small_matmul(gc, Wc, alpha=1.0 / L)                                    # [B,h]: d mean_l
-        G["head.w"], G["head.b"] = torch.cat([dWe, dWc], 1), dbh
+        # ---- the remaining products in weight space, ONE grouped launch: the context columns, the token / root / decision MLPs (weight, bias
+        # as a product with ones, input gradients), the unfolding of the bottleneck pairs Weff = W1 W0, beff = W1 b0 + b1 ----
+        grp = SmallMatmulGroup()
+        dPW = grp.add(dWp, W2_.t(), rank1=(dbp, b2_))                                   # Wp = PW W2, bp = PW b2 + Pb: dPW = dWp W2^T + dbp b2^T
+        G["linear2.w"], G["linear2.b"] = grp.add(PW.t(), dWp), grp.add(PW.t(), dbp.unsqueeze(-1)).squeeze(-1)   # P^T dWp, P^T dbp
+        grp.add(gc.t(), cmean, out=dWh[:, E:])                                           # [H,h]
+        g_cmean = grp.add(gc, Wc, alpha=1.0 / L)                                         # [B,h]: d mean_l
+        G["head.w"], G["head.b"] = dWh, dbh
         o = M0
         g_small_in = []
         for name, inp, W in (("child", tok, Wchild), ("root", rootE, Wroot), ("dec", decE, Wdec)):
             n = inp.shape[0]
             gs = gpre[o:o + n]
-            G[name + ".w"], G[name + ".b"] = small_matmul(gs.t(), inp), gs.sum(0)
-            g_small_in.append(small_matmul(gs, W))
+            G[name + ".w"], G[name + ".b"] = grp.add(gs.t(), inp), grp.add(_ones(n, act, dev).t(), gs).squeeze(0)
+            g_small_in.append(grp.add(gs, W))
             o += n
-        # ---- unfold the bottleneck pairs: Weff = W1 W0, beff = W1 b0 + b1 ----
         if nb:   # (in the activations' dtype: the library's batched fp32 kernels take ~50 us each for these 40-MFLOP products)
-            dW1s = small_matmul(dWeff, W0s.transpose(1, 2), rank1=(dbeff, b0s))          # [4,H,nb] = dWeff W0^T + dbeff b0^T
-            dW0s = small_matmul(W1s.transpose(1, 2), dWeff)                              # [4,nb,H] = W1^T dWeff
-            db0s = small_matmul(W1s.transpose(1, 2), dbeff.unsqueeze(-1)).squeeze(-1)    # [4,nb] = W1^T dbeff
+            dW1s = grp.add(dWeff, W0s.transpose(1, 2), rank1=(dbeff, b0s))               # [4,H,nb] = dWeff W0^T + dbeff b0^T
+            dW0s = grp.add(W1s.transpose(1, 2), dWeff)                                   # [4,nb,H] = W1^T dWeff
+            db0s = grp.add(W1s.transpose(1, 2), dbeff.unsqueeze(-1)).squeeze(-1)         # [4,nb] = W1^T dbeff
+        grp.launch()
         # ---- gradients in the order of param_names ----
         out = [G["head.w"], G["head.b"], G["child.w"], G["child.b"], G["root.w"], G["root.b"], G["dec.w"], G["dec.b"]]
         for k in range(4):
@@ -353,7 +370,8 @@ class _ParserFF(torch.autograd.Function):
         return (None, None, *(t if n else None for t, n in zip(ins, need[2:7])), *(t if n else None for t, n in zip(out, need[7:])))
 
 
-def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None, drop_head=None, drop_small=None, drop_mid=None, mid_scale=1.0):
+def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None, drop_head=None, drop_small=None, drop_mid=None, mid_scale=1.0,
+                        mid_rng=None, p_mid=0.0):
     """ldndmv.py:174-205 up to the scorers' projected inputs -> (x1 [B,L,2,2,r], x2 [T,2,2,r], y1 [B,L,2,2,r], y2 [2,2,2,r],
     root_rule [T]), the arguments of `scorer.ndmv_potentials`.
 
@@ -365,7 +383,9 @@ def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None, 
     one mask per sentence; drop_small [T+3] -- child_ff / root_ff / dec_ff see 2-D inputs, where SharedDropout's mask is one scalar per
     row (nn/dropout.py:52-53); drop_mid [4 (B L + T + 3), H] -- mid_ff's nn.Dropout after its direction stage (nn/dmv_spec.py:52), rows in
     the order (input row, direction, valence) with the B L parent rows first; mid_scale multiplies it (a 0 / 1 keep-mask with mid_scale = 1 / (1 - p)
-    is nn.Dropout without the division pass over the 21 MB mask: `dropout_masks(..., scaled_mid=False)`).  None = identity (eval)."""
+    is nn.Dropout without the division pass over the 21 MB mask: `dropout_masks(..., scaled_mid=False)`).  None = identity (eval).
+    mid_rng (an encoders.DeviceRng) with p_mid > 0 instead of drop_mid: mid_ff's keep-mask is drawn INSIDE the activation kernel of the
+    direction stage and regenerated by its adjoint (counter-based, site SITE_MID_FF) -- no mask tensor at all."""
     _C.require_gpu(emb, "parser_feed_forward")
     token_emb = P["token_emb"] if token_emb is None else token_emb
     root_emb = P["root_emb"] if root_emb is None else root_emb
@@ -383,7 +403,13 @@ def parser_feed_forward(P, emb, x, token_emb=None, root_emb=None, dec_emb=None, 
             raise ValueError(f"parser_feed_forward: {name} must be {shape}, got {tuple(m.shape)}")
     if H % 8:
         raise ValueError(f"parser_feed_forward: hidden size {H} must be a multiple of 8")
-    drops = (_mask32(drop_head), _mask32(drop_small), None if drop_mid is None else drop_mid.detach().to(emb.dtype).contiguous(), float(mid_scale))
+    if mid_rng is not None and p_mid > 0:
+        if drop_mid is not None:
+            raise ValueError("parser_feed_forward: drop_mid and mid_rng exclude each other")
+        mid = (mid_rng, float(p_mid))
+    else:
+        mid = None if drop_mid is None else drop_mid.detach().to(emb.dtype).contiguous()
+    drops = (_mask32(drop_head), _mask32(drop_small), mid, float(mid_scale))
     return _ParserFF.apply(nb, drops, emb, x, token_emb, root_emb, dec_emb, *(P[k] for k in param_names(nb)))
 
 

@@ -246,14 +246,22 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     T_, H_ = P["token_emb"].shape[0], P["ff.head_ff.linear.weight"].shape[0]
 
     def draw_masks():
-        """(drop [B,4,d] or None, parser_ff masks): the per-sentence masks of one step come out of ONE draw when the rates agree."""
+        """(drop [B,4,d] or None, parser_ff masks): the per-sentence SharedDropout masks of one step come out of ONE launch of the
+        counter-based generator when the rates agree; mid_ff's nn.Dropout is drawn inside its activation kernel (no tensor)."""
+        mid = dict(mid_rng=rng, p_mid=p_mid_drop) if p_mid_drop > 0 else {}
         if isinstance(fixed_drop, str) and p_drop == p_ff_drop and 0 < p_drop < 1:
             n0, n1 = B * 4 * d, B * H_
-            buf = torch.empty(n0 + n1 + T_ + 3, dtype=torch.float32, device=dev).bernoulli_(1 - p_drop).div_(1 - p_drop)
-            _, _, mid, mid_scale = parser_ff.dropout_masks(B, L, T_, H_, 0.0, p_mid_drop, device=dev, dtype=ff_dtype, scaled_mid=False)
-            return buf[:n0].view(B, 4, d), (buf[n0:n0 + n1].view(B, H_), buf[n0 + n1:], mid, mid_scale)
-        drop = langfeat.shared_dropout_masks(B, d, p_drop, n=4, device=dev) if isinstance(fixed_drop, str) else fixed_drop
-        return drop, parser_ff.dropout_masks(B, L, T_, H_, p_ff_drop, p_mid_drop, device=dev, dtype=ff_dtype, scaled_mid=False)
+            buf = encoders.dropout_mask(rng, encoders.SITE_SHARED, p_drop, n0 + n1 + T_ + 3)
+            return buf[:n0].view(B, 4, d), dict(drop_head=buf[n0:n0 + n1].view(B, H_), drop_small=buf[n0 + n1:], **mid)
+        if isinstance(fixed_drop, str):
+            drop = encoders.dropout_mask(rng, encoders.SITE_SHARED, p_drop, B * 4 * d).view(B, 4, d) if 0 < p_drop < 1 else None
+        else:
+            drop = fixed_drop
+        ff = {}
+        if 0 < p_ff_drop < 1:
+            buf = encoders.dropout_mask(rng, encoders.SITE_SHARED_FF, p_ff_drop, B * H_ + T_ + 3)
+            ff = dict(drop_head=buf[:B * H_].view(B, H_), drop_small=buf[B * H_:])
+        return drop, dict(**ff, **mid)
 
     def step(stage_hook=None):
         """forward + backward; returns (reduced loss, gradients by leaf name, ()).  stage_hook (optional) is called from inside the
@@ -278,9 +286,10 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         x_f = align.attention_fuse(vis_feat, word0, vis_mid, enc_x, P["ln_w"], P["ln_b"], ln_eps)             # :670-674
         # ---- DiscriminativeNDMV._forward on the fused copy, ldndmv.py:171-216 ----
         if fused_ff:   # the same mathematics with folded / fused GEMMs and a hand-written adjoint
-            x1, x2, y1, y2, root_rule = parser_ff.parser_feed_forward(P, P["emb"], x_f, None, None, None, *ff_masks)
-        else:          # module by module, as the reference runs it
-            x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, *ff_masks[:2], None if ff_masks[2] is None else ff_masks[2] * ff_masks[3])
+            x1, x2, y1, y2, root_rule = parser_ff.parser_feed_forward(P, P["emb"], x_f, **ff_masks)
+        else:          # module by module, as the reference runs it (explicit masks: the comparison form of the tests)
+            mid = None if p_mid_drop <= 0 else encoders.dropout(torch.ones(4 * (B * L + T_ + 3), H_, device=dev), p_mid_drop, rng=rng, site=encoders.SITE_MID_FF)
+            x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, ff_masks.get("drop_head"), ff_masks.get("drop_small"), mid)
         md, ma = scorer.ndmv_potentials(x1, x2, y1, y2, root_rule, token)
         # ---- DependencyBoxRel._vis_forward, joint.py:677-691: the UN-fused x; the potentials are constants of this stage (:252-253) ----
         txt, tmask, tmarg = langfeat.lang_feat_max_tree(enc_x, lengths, md.detach(), ma.detach(), P["w_enc"], P["b_enc"], P["w1"],
@@ -293,8 +302,7 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         with torch.no_grad():                                     # alpha mt + (1 - alpha) dep, reduce_loss('token')
             loss = torch.addcmul(c_mt * mt, mx.sum(), c_max)
         grads = torch.autograd.grad([mt, mx], leaves, [c_mt, seed_max.view(mx.shape)])
-        if isinstance(enc_drop, str) and p_enc > 0:
-            rng.advance()                                             # the next step (or graph replay) draws new embedding-dropout masks
+        rng.advance()                                                 # the next step (or graph replay) draws new dropout masks at every site
         # intermediates for the parity tests, DETACHED: a reference to a previous step's autograd graph kept alive across a HIP-graph
         # capture makes torch 2.10 / ROCm 7 crash in capture_end
         step.last = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in dict(
