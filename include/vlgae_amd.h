@@ -334,8 +334,10 @@ int vlg_vis_encoder_backward(const void* P, const void* C, const void* grad_mid,
  *                     arc_margin.gather(-1, predicted)]) (joint.py:246-261; use_marginal 0: cat([mask, mask]), :262),
  *                     txt_mask [B,2N] u8 = cat([mask, mask]) with the root slot masked (:248-249)
  *   arc_out           tri [M,d] fp32 (+ aff [M,d] act_dtype or NULL) -> txt[b, N+n, :] (arc_repr, joint.py:278-288)
- *   rowscale          out[b,n,:] = pre[b,n,:] * drop[b*ld_drop + :]  (one encoder's SharedDropout on [B,N,d]: the word encoder of
- *                     `lang_feat_word_only`, joint.py:193-211, and its adjoint; in place allowed) */
+ *   rowscale          out[b,n,c] = pre[b,n,c] * drop[b*ld_drop + c] for c < d, 0 for d <= c < width  (one encoder's SharedDropout on [B,N,d]: the word
+ *                     encoder of `lang_feat_word_only`, joint.py:193-211, and its adjoint; drop NULL = identity; rows ld_in / ld_out elements apart
+ *                     (round 5): the word third of the three encoders' SHARED projection [B N, 3d] is read in place, and the adjoint writes the
+ *                     full-width cotangent of that projection, zeros for the other thirds, in one pass; in place allowed with equal strides) */
 int vlg_langfeat_root_cat(const void* x, const int64_t* lengths, int B, int L, int h, int in_dtype, void* x1, int out_dtype,
                           void* stream);
 int vlg_langfeat_root_cat_backward(const void* d_x1, const int64_t* lengths, int B, int L, int h, int in_dtype, void* d_x, int out_dtype,
@@ -348,7 +350,8 @@ int vlg_langfeat_split_backward(const void* d_txt, int d_txt_dtype, const float*
 int vlg_langfeat_marginal(const float* grad_attach, const int64_t* heads, const int64_t* lengths, int B, int N, int use_marginal,
                           float* txt_marginal, uint8_t* txt_mask, void* stream);
 int vlg_langfeat_arc_out(const float* tri, const void* aff, int B, int N, int d, int act_dtype, void* txt, void* stream);
-int vlg_langfeat_rowscale(const void* pre, const float* drop, int B, int N, int d, int ld_drop, int act_dtype, void* out, void* stream);
+int vlg_langfeat_rowscale(const void* pre, int ld_in, const float* drop, int B, int N, int d, int ld_drop, int act_dtype, void* out, int ld_out, int width,
+                          void* stream);
 
 /* Small (batched) matrix products in weight space -- the folded bottleneck weights W1 W0 of `DMVSkipConnectEncoder`
  * (src/model/nn/dmv_spec.py:52-54) and their unfolding, the per-sentence context term of `head_ff` (src/model/ldndmv.py:174-177): products

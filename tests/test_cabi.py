@@ -69,8 +69,9 @@ def test_version_and_error_plumbing(lib):
     assert lib.vlg_langfeat_root_cat(one, one, 2, 5, 64, 0, one, 7, None) == 0x1002                               # out_dtype
     assert lib.vlg_langfeat_split(one, one, one, 8, 2, 6, 32, 0, 0.01, one, one, one, None, None) == 0x1001       # ld_drop < 3 d
     assert lib.vlg_langfeat_split(one, one, None, 0, 2, 6, 32, 5, 0.01, one, one, one, None, None) == 0x1002      # act_dtype
-    assert lib.vlg_langfeat_rowscale(one, one, 2, 6, 36, 36, 0, one, None) == 0x1001                              # d % 8
-    assert lib.vlg_langfeat_rowscale(one, None, 2, 6, 32, 32, 0, one, None) == 0x1003                             # null masks
+    assert lib.vlg_langfeat_rowscale(one, 36, one, 2, 6, 36, 36, 0, one, 36, 36, None) == 0x1001                  # d % 8
+    assert lib.vlg_langfeat_rowscale(one, 32, one, 2, 6, 32, 32, 0, one, 32, 24, None) == 0x1001                  # width < d
+    assert lib.vlg_langfeat_rowscale(None, 32, one, 2, 6, 32, 32, 0, one, 32, 32, None) == 0x1003                 # null input
     assert lib.vlg_langfeat_arc_out(one, None, 2, 6, 32, 9, one, None) == 0x1002
     assert lib.vlg_linear_wgrad_workspace(4096, 24, 72) > 0 and lib.vlg_linear_wgrad_workspace(4096, 20, 72) == 0     # multiples of 8
     with pytest.raises(RuntimeError, match="N >= 2"):

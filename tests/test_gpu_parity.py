@@ -1589,6 +1589,10 @@ def test_linear_wgrad_partial_tiles():
         assert float((db.double() - rb).abs().max()) <= 1e-5 * float(rb.abs().max()) + 1e-3, (M, N)
         _, xs = align.linear_wgrad(dy, x, want_x_colsum=True)
         assert float((xs.double() - x.double().sum(0)).abs().max()) <= 1e-3, (M, N)
+        # a column block of a wider gradient tensor written in place (ld_dw > N), bf16 output
+        wide = torch.zeros(M, N + 40, device=dev(), dtype=torch.bfloat16)
+        align.linear_wgrad(dy, x, want_bias=False, out=(wide[:, 16:16 + N], None))
+        assert torch.equal(wide[:, 16:16 + N], dw.to(torch.bfloat16)) and float(wide[:, :16].abs().max()) == 0 and float(wide[:, 16 + N:].abs().max()) == 0
 
 
 def _reference_step_in_torch(step, P64, token, tag, vmask, drop, alpha, pen_args):

@@ -75,7 +75,7 @@ SIGNATURES = {
     "vlg_langfeat_split_backward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "vlg_langfeat_marginal": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "vlg_langfeat_arc_out": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "vlg_langfeat_rowscale": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vlg_langfeat_rowscale": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "vlg_small_gemm": (_i, [_vp, _ll, _ll, _ll, _vp, _ll, _ll, _ll, _vp, _ll, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     "vlg_small_gemm_group": (_i, [_vp, _i, _vp]),
     "vlg_ff_context_mean": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -215,22 +215,29 @@ __global__ __launch_bounds__(256) void langfeat_arc_out_kernel(const float* __re
     store8(txt + ((size_t)b * 2 * N + N + n) * d + c8, v);
 }
 
-// out[b, n, :] = pre[b, n, :] * drop[b, :]  (word-only features, joint.py:193-211 in training mode); in place allowed
+// out[b, n, c] = pre[b, n, c] * drop[b, c] for c < d, 0 for d <= c < width  (word-only features, joint.py:193-211 in training mode; drop null =
+// identity).  Rows ld_in / ld_out elements apart: the word third of the three encoders' shared projection [M, 3d] is read where it lies, and the
+// adjoint writes the full-width cotangent of that projection (zeros for the child | parent thirds) in one pass.  In place allowed (equal strides).
 template <typename A>
-__global__ __launch_bounds__(256) void langfeat_rowscale_kernel(const A* __restrict__ pre, const float* __restrict__ drop, int B, int N,
-                                                                int d, int ld_drop, A* __restrict__ out) {
-    const int per_row = d >> 3;
+__global__ __launch_bounds__(256) void langfeat_rowscale_kernel(const A* __restrict__ pre, int ld_in, const float* __restrict__ drop, int B, int N,
+                                                                int d, int ld_drop, A* __restrict__ out, int ld_out, int width) {
+    const int per_row = width >> 3;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t m = t / per_row;
     if (m >= (size_t)B * N) return;
     const int c8 = (int)(t - m * per_row) * 8;
     const int b = (int)(m / N);
-    float v[8], k[8];
-    load8(pre + m * d + c8, v);
-    load8(drop + (size_t)b * ld_drop + c8, k);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c8 < d) {
+        load8(pre + m * ld_in + c8, v);
+        if (drop) {
+            float k[8];
+            load8(drop + (size_t)b * ld_drop + c8, k);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] *= k[i];
-    store8(out + m * d + c8, v);
+            for (int i = 0; i < 8; ++i) v[i] *= k[i];
+        }
+    }
+    store8(out + m * ld_out + c8, v);
 }
 
 }  // namespace
@@ -369,19 +376,23 @@ int vlg_langfeat_arc_out(const float* tri, const void* aff, int B, int N, int d,
     return check_launch("langfeat_arc_out_kernel");
 }
 
-int vlg_langfeat_rowscale(const void* pre, const float* drop, int B, int N, int d, int ld_drop, int act_dtype, void* out, void* stream) {
+int vlg_langfeat_rowscale(const void* pre, int ld_in, const float* drop, int B, int N, int d, int ld_drop, int act_dtype, void* out, int ld_out, int width,
+                          void* stream) {
     using namespace vlg;
-    if (B < 0 || N < 1 || d < 8 || d % 8 || ld_drop < d || ld_drop % 4)
-        return set_error(VLG_ERR_SHAPE, "langfeat_rowscale: bad shape B=%d N=%d d=%d ld_drop=%d (d a multiple of 8)", B, N, d, ld_drop);
+    if (B < 0 || N < 1 || d < 8 || d % 8 || (drop && (ld_drop < d || ld_drop % 4)) || width < d || width % 8 || ld_in < d || ld_out < width || ld_in % 8 || ld_out % 8)
+        return set_error(VLG_ERR_SHAPE, "langfeat_rowscale: bad shape B=%d N=%d d=%d ld_drop=%d ld_in=%d ld_out=%d width=%d (multiples of 8)", B, N, d, ld_drop,
+                         ld_in, ld_out, width);
     if (!ok_dtype(act_dtype)) return set_error(VLG_ERR_DTYPE, "langfeat_rowscale: act_dtype %d", act_dtype);
     if (B == 0) return 0;
-    if (!pre || !drop || !out) return set_error(VLG_ERR_ARG, "langfeat_rowscale: null buffer");
-    const size_t threads = (size_t)B * N * (d / 8);
+    if (!pre || !out) return set_error(VLG_ERR_ARG, "langfeat_rowscale: null buffer");
+    const size_t threads = (size_t)B * N * (width / 8);
     const dim3 grid((unsigned)((threads + 255) / 256));
     if (act_dtype == VLG_F32)
-        hipLaunchKernelGGL(langfeat_rowscale_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)pre, drop, B, N, d, ld_drop, (float*)out);
+        hipLaunchKernelGGL(langfeat_rowscale_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)pre, ld_in, drop, B, N, d, ld_drop, (float*)out,
+                           ld_out, width);
     else
-        hipLaunchKernelGGL(langfeat_rowscale_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)pre, drop, B, N, d, ld_drop, (uint16_t*)out);
+        hipLaunchKernelGGL(langfeat_rowscale_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)pre, ld_in, drop, B, N, d, ld_drop,
+                           (uint16_t*)out, ld_out, width);
     return check_launch("langfeat_rowscale_kernel");
 }
 

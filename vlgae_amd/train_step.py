@@ -269,7 +269,6 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         data-parallel trainer starts reducing its first gradient bucket."""
         drop, ff_masks = draw_masks()
         d0, d3 = (None, None) if drop is None else (drop[:, 0:1], drop[:, 1:4])
-        w_word, b_word = P["w_enc"][:d], P["b_enc"][:d]
         # ---- JointModelBase.forward, base.py:229 / :68: the two trainable encoders on the frozen features ----
         vis_mid, _, _ = encoders.vis_box_rel_encoder(P["vis_box_feat"], P["w_venc"], P["b_venc"], add_rel, add_attr, add_image, SLOPE)
         if enc_drop is None or p_enc == 0:
@@ -282,7 +281,10 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
             enc_x = enc_x.to(dtype)
         # ---- DependencyBoxRel._forward, joint.py:658-675 ----
         vis_feat = align.linear(vis_mid, P["w_vis"])                                                         # :175 (and again :688: same values)
-        word0, _, _ = langfeat.lang_feat_word_only(enc_x, lengths, w_word, b_word, drop=d0)                 # :667
+        # the word | child | parent encoders' Linear on cat([masked mean, x]) ONCE: joint.py:204-209 (word-only) and :262-273 (max-tree) read the
+        # same un-fused encodings through the same word encoder, under two SharedDropout masks
+        pre = langfeat.encoder_projection(enc_x, lengths, P["w_enc"], P["b_enc"])
+        word0, _, _ = langfeat.lang_feat_word_only(None, lengths, drop=d0, pre=pre)                          # :667
         x_f = align.attention_fuse(vis_feat, word0, vis_mid, enc_x, P["ln_w"], P["ln_b"], ln_eps)             # :670-674
         # ---- DiscriminativeNDMV._forward on the fused copy, ldndmv.py:171-216 ----
         if fused_ff:   # the same mathematics with folded / fused GEMMs and a hand-written adjoint
@@ -292,8 +294,8 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
             x1, x2, y1, y2, root_rule = scorer_feed_forward(P, P["emb"], x_f, ff_masks.get("drop_head"), ff_masks.get("drop_small"), mid)
         md, ma = scorer.ndmv_potentials(x1, x2, y1, y2, root_rule, token)
         # ---- DependencyBoxRel._vis_forward, joint.py:677-691: the UN-fused x; the potentials are constants of this stage (:252-253) ----
-        txt, tmask, tmarg = langfeat.lang_feat_max_tree(enc_x, lengths, md.detach(), ma.detach(), P["w_enc"], P["b_enc"], P["w1"],
-                                                        P["w2"], P["b"], keep_viterbi=True, drop=d3, aux=aux)
+        txt, tmask, tmarg = langfeat.lang_feat_max_tree(None, lengths, md.detach(), ma.detach(), None, None, P["w1"],
+                                                        P["w2"], P["b"], keep_viterbi=True, drop=d3, aux=aux, pre=pre)
         if stage_hook is not None:
             txt.register_hook(lambda g_: stage_hook())
         # ---- DependencyBoxRel.loss, joint.py:693-711 ----
