@@ -279,6 +279,18 @@ int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* 
 size_t vlg_linear_wgrad_workspace(int K, int M, int N);
 int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
                      void* d_weight, int ld_dw, void* d_bias, void* x_colsum, void* stream);
+/* The same in two steps, for a caller that issues SEVERAL weight gradients and needs none of them before its end (the parser's feed-forwards,
+ * src/model/ldndmv.py:174-183 under loss.backward(): seven products): vlg_linear_wgrad_partial is the split-K launch alone (the partial tiles stay
+ * in `ws`, which must stay alive and untouched; want_bias / want_x_colsum: which column sums to carry), vlg_linear_wgrad_reduce_group adds the
+ * partial tiles of up to 12 such products per launch -- the same fixed-order sums, the same bits as vlg_linear_wgrad. */
+typedef struct VlgWgradReduce {
+    const void* ws;                      /* the workspace vlg_linear_wgrad_partial filled for (K, M, N) */
+    void *d_weight, *d_bias, *x_colsum;  /* as in vlg_linear_wgrad (d_bias / x_colsum NULL when not carried) */
+    int K, M, N, ld_dw, out_dtype;
+} VlgWgradReduce;
+int vlg_linear_wgrad_partial(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int want_bias,
+                             int want_x_colsum, void* stream);
+int vlg_linear_wgrad_reduce_group(const VlgWgradReduce* items, int count, void* stream);
 
 /* The two TRAINABLE encoders between the frozen features and the structured step (round 5; BASELINE.json configs[4]) -- what
  * `JointModelBase.forward` runs first, src/model/base.py:229,235.  The GEMMs are the caller's (library); these are the passes around them.

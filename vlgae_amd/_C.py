@@ -24,6 +24,11 @@ class SmallGemm(ctypes.Structure):
                 + [(n, ctypes.c_int) for n in ("batch", "M", "N", "K", "accumulate", "in_dtype", "out_dtype")] + [("alpha", ctypes.c_float)])
 
 
+class WgradReduce(ctypes.Structure):
+    """VlgWgradReduce of include/vlgae_amd.h: one deferred split-K reduction of vlg_linear_wgrad_reduce_group."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("ws", "d_weight", "d_bias", "x_colsum")] + [(n, ctypes.c_int) for n in ("K", "M", "N", "ld_dw", "out_dtype")]
+
+
 # symbol -> (restype, argtypes); one entry per declaration in include/vlgae_amd.h
 SIGNATURES = {
     "vlg_dmv1o_inside": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -69,6 +74,8 @@ SIGNATURES = {
     "vlg_rng_advance": (_i, [_vp, _vp]),
     "vlg_vis_encoder": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "vlg_vis_encoder_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "vlg_linear_wgrad_partial": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _i, _i, _vp]),
+    "vlg_linear_wgrad_reduce_group": (_i, [_vp, _i, _vp]),
     "vlg_langfeat_root_cat": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_langfeat_root_cat_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_langfeat_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),

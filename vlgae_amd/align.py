@@ -536,7 +536,26 @@ def arc_encoder(child_repr, parent_repr, arc_encoder_w1, arc_encoder_w2, arc_enc
 # ----------------------------------------------------------------------------------------------
 # Encoder projections around the contraction (MLP, src/model/nn/common.py:23-51; joint.py:136-138,175,270-277)
 # ----------------------------------------------------------------------------------------------
-def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None, out_dtype=torch.float32):
+class WgradGroup:
+    """Deferred split-K reductions: `linear_wgrad(..., defer=group)` issues the split-K launch only; `group.flush()` adds the partial tiles of
+    every deferred product in ONE launch (up to 12 per launch; vlg_linear_wgrad_reduce_group) -- same fixed-order sums, same bits.  The
+    outputs are valid after flush()."""
+
+    def __init__(self):
+        self.items, self.keep, self.first = [], [], None
+
+    def flush(self):
+        n = len(self.items)
+        if n == 0:
+            return
+        arr = (_C.WgradReduce * n)()
+        for rec, vals in zip(arr, self.items):
+            rec.ws, rec.d_weight, rec.d_bias, rec.x_colsum, rec.K, rec.M, rec.N, rec.ld_dw, rec.out_dtype = vals
+        _C.check(_C.lib().vlg_linear_wgrad_reduce_group(arr, n, _C.stream_of(self.first)), "linear_wgrad_reduce_group")
+        self.items, self.keep, self.first = [], [], None
+
+
+def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None, out_dtype=torch.float32, defer=None):
     """Weight / bias gradient of `y = x @ weight.T + bias` over all token rows: (dy^T x [out, in], sum_rows dy [out]), float32.
     want_x_colsum: the second result is sum_rows x [in] instead (a weight stored [in, out]: pass the layer input as dy and the
     cotangent as x).  out = (d_weight, second) writes into caller-owned tensors (both of one type); out_dtype (float32 / bfloat16):
@@ -544,7 +563,7 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None, out_dtype
 
     dy [K, out], x [K, in]: bf16, row-major (row strides that are multiples of 8 elements are taken in place -- column
     slices of wider buffers), out and in multiples of 8 (64 x 64 output tiles; the last tile of either side may be partial).  Split over the rows across the whole chip, fixed summation
-    order (vlg_linear_wgrad); other shapes / dtypes raise -- callers decide (see `_Linear.backward`)."""
+    order (vlg_linear_wgrad); other shapes / dtypes raise -- callers decide (see `_Linear.backward`).  defer: a WgradGroup (see there)."""
     _C.require_gpu(dy, "linear_wgrad")
     K, M = dy.shape
     N = x.shape[1]
@@ -574,8 +593,18 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None, out_dtype
             or dw.stride(1) != 1 or dw.stride(0) < N):
         raise ValueError(f"linear_wgrad: outputs must be float32 or bfloat16 of one type, d_weight [out, in] with unit column stride (a column "
                          f"block of a wider gradient is fine), got {dw.dtype} {tuple(dw.shape)} {dw.stride()} / {None if db is None else db.dtype}")
-    _C.check(_C.lib().vlg_linear_wgrad(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, _C.ptr(ws), nbytes,
-                                       _C.BF16 if out_dtype == torch.bfloat16 else _C.F32,
+    odt = _C.BF16 if out_dtype == torch.bfloat16 else _C.F32
+    if defer is not None:   # the split-K launch alone; the reduction joins the group's single launch
+        _C.check(_C.lib().vlg_linear_wgrad_partial(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, _C.ptr(ws), nbytes,
+                                                   int(db is not None and not want_x_colsum), int(db is not None and want_x_colsum), _C.stream_of(dy)),
+                 "linear_wgrad_partial")
+        dpt = lambda t: None if t is None else t.data_ptr()
+        defer.items.append((ws.data_ptr(), dw.data_ptr(), None if want_x_colsum else dpt(db), dpt(db) if want_x_colsum else None, K, M, N, dw.stride(0), odt))
+        defer.keep.append((ws, dw, db))
+        if defer.first is None:
+            defer.first = dy
+        return dw, db
+    _C.check(_C.lib().vlg_linear_wgrad(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, _C.ptr(ws), nbytes, odt,
                                        _C.ptr(dw), dw.stride(0), None if want_x_colsum else _C.ptr(db), _C.ptr(db) if want_x_colsum else None,
                                        _C.stream_of(dy)), "linear_wgrad")
     return dw, db

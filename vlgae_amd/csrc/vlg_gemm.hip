@@ -195,6 +195,52 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restric
 }
 
 
+// The reductions of SEVERAL split-K products in one launch (round 5): a Function that issues many weight gradients whose results it only
+// needs at its end (the parser's feed-forwards: seven of them) defers their second launches and flushes them together.
+constexpr int kRedGroupMax = 12;
+struct RedArgs {
+    const float *part, *part_cs, *part_csb;
+    void *out, *out_cs, *out_csb;
+    int S, n, N, ld_out, n_cs, n_csb, bf16, start;   // start: first workgroup of this problem
+};
+struct RedGroup {
+    RedArgs p[kRedGroupMax];
+    int count, blocks;
+};
+
+template <typename O>
+__device__ __forceinline__ void reduce_one(const RedArgs& a, int i) {
+    const float* src;
+    O* dst;
+    size_t pitch;
+    if (i < a.n) {
+        src = a.part + i; pitch = a.n;
+        dst = a.ld_out == a.N ? (O*)a.out + i : (O*)a.out + (size_t)(i / a.N) * a.ld_out + (i % a.N);
+    } else if (i - a.n < a.n_cs) { i -= a.n; src = a.part_cs + i; dst = (O*)a.out_cs + i; pitch = a.n_cs; }
+    else if (i - a.n - a.n_cs < a.n_csb) { i -= a.n + a.n_cs; src = a.part_csb + i; dst = (O*)a.out_csb + i; pitch = a.n_csb; }
+    else return;
+    float t = 0.f;
+    int s = 0;
+    for (; s + 8 <= a.S; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * pitch];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; s < a.S; ++s) t += src[(size_t)s * pitch];
+    st_out(dst, t);
+}
+
+__global__ __launch_bounds__(256) void gemm_reduce_group_kernel(RedGroup g) {
+    int k = 0;
+    while (k + 1 < g.count && (int)blockIdx.x >= g.p[k + 1].start) ++k;
+    const RedArgs& a = g.p[k];
+    const int i = (blockIdx.x - a.start) * 256 + threadIdx.x;
+    if (a.bf16) reduce_one<uint16_t>(a, i);
+    else reduce_one<float>(a, i);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------------
 // Small (batched) products in weight space: C[z] = alpha * A[z] B[z] + bias + u v^T (+ C[z]) with M, N, K of a few hundred.  The
 // library maps an output of 256 x 256 to ONE workgroup (tiles of 256 x 256: 15-28 us for 33-80 MFLOP on a 256-CU chip); here every
@@ -420,8 +466,55 @@ size_t vlg_linear_wgrad_workspace(int K, int M, int N) {
     return vlg::plan_tn(K, M, N).bytes;
 }
 
+static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
+                        void* d_weight, int ld_dw, void* d_bias, void* x_colsum, bool reduce_now, void* stream);
+
 int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
                      void* d_weight, int ld_dw, void* d_bias, void* x_colsum, void* stream) {
+    return wgrad_launch(dy, ld_dy, x, ld_x, K, M, N, ws, ws_bytes, out_dtype, d_weight, ld_dw, d_bias, x_colsum, true, stream);
+}
+
+int vlg_linear_wgrad_partial(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int want_bias,
+                             int want_x_colsum, void* stream) {
+    // the split-K launch alone: the partial tiles stay in `ws` until vlg_linear_wgrad_reduce_group adds them (ws must stay alive and untouched)
+    static char dummy;
+    return wgrad_launch(dy, ld_dy, x, ld_x, K, M, N, ws, ws_bytes, VLG_F32, &dummy, N, want_bias ? &dummy : nullptr, want_x_colsum ? &dummy : nullptr, false, stream);
+}
+
+int vlg_linear_wgrad_reduce_group(const VlgWgradReduce* items, int count, void* stream) {
+    using namespace vlg;
+    if (count < 0 || (count && !items)) return set_error(VLG_ERR_ARG, "linear_wgrad_reduce_group: count=%d", count);
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < count; base += kRedGroupMax) {
+        RedGroup g;
+        g.count = 0;
+        g.blocks = 0;
+        for (int i = base; i < count && i < base + kRedGroupMax; ++i) {
+            const VlgWgradReduce& q = items[i];
+            if (q.K < 1 || q.M < 8 || q.N < 8 || q.M % 8 || q.N % 8 || q.ld_dw < q.N) return set_error(VLG_ERR_SHAPE, "linear_wgrad_reduce_group: item %d K=%d M=%d N=%d ld_dw=%d", i, q.K, q.M, q.N, q.ld_dw);
+            if (q.out_dtype != VLG_F32 && q.out_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "linear_wgrad_reduce_group: out_dtype %d", q.out_dtype);
+            if (!q.ws || !q.d_weight) return set_error(VLG_ERR_ARG, "linear_wgrad_reduce_group: null buffer");
+            const TnPlan pl = plan_tn(q.K, q.M, q.N);
+            const float* part = (const float*)q.ws;
+            RedArgs& a = g.p[g.count++];
+            a.part = part;
+            a.part_cs = q.d_bias ? part + (size_t)pl.S * q.M * q.N : nullptr;
+            a.part_csb = q.x_colsum ? part + (size_t)pl.S * ((size_t)q.M * q.N + q.M) : nullptr;
+            a.out = q.d_weight; a.out_cs = q.d_bias; a.out_csb = q.x_colsum;
+            a.S = pl.S; a.n = q.M * q.N; a.N = q.N; a.ld_out = q.ld_dw; a.n_cs = q.d_bias ? q.M : 0; a.n_csb = q.x_colsum ? q.N : 0;
+            a.bf16 = q.out_dtype == VLG_BF16;
+            a.start = g.blocks;
+            g.blocks += (a.n + a.n_cs + a.n_csb + 255) / 256;
+        }
+        if (g.count == 0) continue;
+        hipLaunchKernelGGL(gemm_reduce_group_kernel, dim3(g.blocks), dim3(256), 0, s, g);
+        if (int rc = check_launch("gemm_reduce_group_kernel")) return rc;
+    }
+    return 0;
+}
+
+static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
+                        void* d_weight, int ld_dw, void* d_bias, void* x_colsum, bool reduce_now, void* stream) {
     using namespace vlg;
     if (out_dtype != VLG_F32 && out_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "linear_wgrad: out_dtype %d", out_dtype);
     if (K < 1 || M < 8 || N < 8 || M % 8 || N % 8)
@@ -442,6 +535,7 @@ int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, 
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * ((pl.S + 7) / 8) * 8), dim3(kGemmThreads), 0, s, (const uint16_t*)dy, ld_dy,
                        (const uint16_t*)x, ld_x, K, M, N, pl.KC, pl.S, part, part_cs, part_csb);
     if (int rc = check_launch("gemm_tn_kernel")) return rc;
+    if (!reduce_now) return 0;
     const int n = M * N, n_cs = d_bias ? M : 0, n_csb = x_colsum ? N : 0;
     if (out_dtype == VLG_F32)
         hipLaunchKernelGGL(gemm_reduce_kernel<float>, dim3((n + n_cs + n_csb + 255) / 256), dim3(256), 0, s, part, pl.S, n, N, ld_dw, (float*)d_weight, part_cs,

@@ -25,7 +25,7 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _C
-from .align import linear, linear_wgrad
+from .align import WgradGroup, linear, linear_wgrad
 
 SLOPE = 0.01   # nn.LeakyReLU() default (nn/common.py:31)
 SITE_TEXT_ENCODER, SITE_MID_FF, SITE_SHARED, SITE_SHARED_FF = 1, 2, 3, 4   # which dropout layer of a step draws from the shared DeviceRng state
@@ -197,8 +197,10 @@ class _VisEncoder(torch.autograd.Function):
                 out_dt = w_dt if w_dt in (torch.float32, torch.bfloat16) else torch.float32
                 dW = torch.empty((FH, 2 * n), dtype=out_dt, device=P.device)
                 db = torch.empty((FH,), dtype=out_dt, device=P.device)
-                linear_wgrad(dP, x2, want_bias=False, out=(dW[:, :n], None))
-                linear_wgrad(dC, xm, want_bias=True, out=(dW[:, n:], db))
+                wg = WgradGroup()                                            # the two reductions as one launch
+                linear_wgrad(dP, x2, want_bias=False, out=(dW[:, :n], None), defer=wg)
+                linear_wgrad(dC, xm, want_bias=True, out=(dW[:, n:], db), defer=wg)
+                wg.flush()
                 db = db.to(b_dt)
             else:                       # float32 (the reference's `precision: 32`): exact fp32 products on the library
                 dW = torch.cat([dP.t() @ x2, dC.t() @ xm], 1).to(w_dt)

@@ -33,7 +33,7 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _C
-from .align import SmallMatmulGroup, _wgrad_ok, linear_wgrad, small_matmul
+from .align import SmallMatmulGroup, WgradGroup, _wgrad_ok, linear_wgrad, small_matmul
 
 SLOPE = 0.01   # nn.LeakyReLU() default (nn/common.py:31, nn/dmv_spec.py:10)
 SITE_MID_FF = 2   # the dropout layer id of mid_ff's nn.Dropout in the step's shared counter-based generator (encoders.SITE_MID_FF)
@@ -121,12 +121,12 @@ def _mask32(m):
     return m.clone() if m.data_ptr() % 16 else m       # (the kernels read the [B,H] masks 16 bytes at a time)
 
 
-def _wgrad(dy, x, out=None, dtype=torch.float32):
+def _wgrad(dy, x, out=None, dtype=torch.float32, defer=None):
     """(dy^T x [out,in], sum_rows dy [out]): the split-K kernel for bf16 token-row counts, the library otherwise.  Results in `dtype` (the
     parameter's own: the reduction writes it, no cast launch follows), or written into `out` = (d_weight, d_bias) in their own dtype
     (contiguous views of a caller's stack: no cat afterwards either)."""
     if dy.dtype == x.dtype and _wgrad_ok(x.shape[0], dy.shape[1], x.shape[1], dy.dtype):
-        return linear_wgrad(dy, x, out=out, out_dtype=dtype)
+        return linear_wgrad(dy, x, out=out, out_dtype=dtype, defer=defer)
     dw, db = dy.float().t() @ x.float(), dy.float().sum(0)
     if out is None:
         return dw.to(dtype), db.to(dtype)
@@ -284,7 +284,8 @@ class _ParserFF(torch.autograd.Function):
         torch.mm(g_big, Wp[:2 * r], out=gA5[:4 * M0])
         # (everything below in the activations' dtype: as fp32 GEMMs on one workgroup each the library takes 30-50 us for these products)
         dWp, dbp = torch.empty((6 * r, H), dtype=act, device=dev), torch.empty((6 * r,), dtype=act, device=dev)
-        _wgrad(g_big, A5[:4 * M0], out=(dWp[:2 * r], dbp[:2 * r]))                      # [2r,H], [2r]: split-K, written in place
+        wg = WgradGroup()      # the seven split-K weight gradients of this pass: their reductions run as ONE launch before the last group
+        _wgrad(g_big, A5[:4 * M0], out=(dWp[:2 * r], dbp[:2 * r]), defer=wg)            # [2r,H], [2r]: split-K, written in place
         grp = SmallMatmulGroup()
         grp.add(g_small, Wp[2 * r:], out=gA5[4 * M0:])
         grp.add(g_small.t(), A5[4 * M0:], out=dWp[2 * r:])                              # [4r,H]: 4 (T + 3) rows
@@ -292,25 +293,25 @@ class _ParserFF(torch.autograd.Function):
         grp.launch()
         # ---- linear1, direction ----
         g = _act_bwd(gA5, A5, gA5, 4 * M, 1, H)
-        G["linear1.w"], G["linear1.b"] = _wgrad(g, A4, dtype=act)
+        G["linear1.w"], G["linear1.b"] = _wgrad(g, A4, dtype=act, defer=wg)
         g = g @ W1_
         _act_bwd(g, A4, g, 4 * M, 1, H, mask=mid_mask, mask_scale=ctx.drops[3], rng=mid_rng, p=p_mid)
-        G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H), dtype=act)
+        G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H), dtype=act, defer=wg)
         g = g @ Wd                                                                       # [m,dir,val,c]
         gX = torch.empty((M, H), dtype=torch.float32, device=g.device)                   # the skip connections' cotangent
         gZ = torch.empty((2 * M, 2 * H), dtype=act, device=g.device)                     # [m,val,dir,c]
         _act_bwd(g, A3, gZ, M, 4, H, total=gX, swap=True)
         # the gradients of the folded weights straight into their stack, in the activations' dtype (what the unfold products read)
         dWeff, dbeff = torch.empty((4, H, H), dtype=act, device=g.device), torch.empty((4, H), dtype=act, device=g.device)   # no, has, left, right
-        _wgrad(gZ, A2, out=(dWeff[2:4].view(2 * H, H), dbeff[2:4].view(2 * H)))
+        _wgrad(gZ, A2, out=(dWeff[2:4].view(2 * H, H), dbeff[2:4].view(2 * H)), defer=wg)
         # ---- valence ----
         g = gZ @ W_lr
         _act_bwd(g, A2, g, 2 * M, 1, H)
-        G["valence.w"], G["valence.b"] = _wgrad(g, A1.view(2 * M, H), dtype=act)
+        G["valence.w"], G["valence.b"] = _wgrad(g, A1.view(2 * M, H), dtype=act, defer=wg)
         gY = g @ Wv                                                                      # [M,2,H]
         _act_bwd(gY, A1, gY, M, 2, H, total=gX, accumulate=True)
         gY = gY.view(M, 2 * H)
-        _wgrad(gY, X, out=(dWeff[0:2].view(2 * H, H), dbeff[0:2].view(2 * H)))
+        _wgrad(gY, X, out=(dWeff[0:2].view(2 * H, H), dbeff[0:2].view(2 * H)), defer=wg)
         # ---- MLPs: gpre = LeakyReLU'(X) * SharedDropout mask * (gX + gY W_nh) ----
         gpre = torch.empty((M, H), dtype=act, device=g.device)
         gT = gY @ W_nh
@@ -319,7 +320,8 @@ class _ParserFF(torch.autograd.Function):
         gb = gpre[:M0]
         dWh = torch.empty((H, E + h), dtype=act, device=dev)                             # head_ff's [H, E + h] gradient: both column blocks written in place
         dbh = torch.empty((H,), dtype=act, device=dev)
-        _wgrad(gb, emb2, out=(dWh[:, :E], dbh))                                          # [H,E], [H]
+        _wgrad(gb, emb2, out=(dWh[:, :E], dbh), defer=wg)                                # [H,E], [H]
+        wg.flush()
         g_emb = gb @ We                                                                  # [M0,E]
         gc = gb.view(B, L, H).sum(1)                                                     # [B,H] (fp32 accumulation inside the reduction)
         # ---- the remaining products in weight space, ONE grouped launch: the context columns, the token / root / decision MLPs (weight, bias
