@@ -22,3 +22,8 @@ for K, M, N, ld in ((9216, 256, 2048, 4096), (9216, 768, 2048, 4096), (2304, 768
     align.linear_wgrad(dy, x, want_bias=False, out=(out[:, :N], None)); e1 = float((out[:, :N].float() - ref).abs().max() / ref.abs().max())
     torch.mm(dy.t(), x, out=out[:, :N]); e2 = float((out[:, :N].float() - ref).abs().max() / ref.abs().max())
     print(f"K={K} M={M} N={N}: split-K {t_k:.1f} us (err {e1:.1e}), library strided-out {t_l:.1f} us (err {e2:.1e}), library contiguous {t_lc:.1f} us; {2*K*M*N/1e9:.1f} GFLOP")
+for K, M, N in ((40960, 256, 256), (40960, 512, 256), (10496, 384, 256), (41000, 32, 256)):
+    dy = torch.randn(K, M, device=dev).bfloat16(); x = torch.randn(K, N, device=dev).bfloat16()
+    t_k = ev(lambda: align.linear_wgrad(dy, x, out_dtype=torch.bfloat16))
+    t_l = ev(lambda: torch.mm(dy.t(), x))
+    print(f"K={K} M={M} N={N}: split-K (+bias) {t_k:.1f} us, library {t_l:.1f} us; {2*K*M*N/1e9:.1f} GFLOP")

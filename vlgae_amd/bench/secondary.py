@@ -79,11 +79,15 @@ def dp_entry(B, L, dtype_name, dev, n=100):
     alg = bench.algorithmic_bytes(B, N, 2 if dtype_name == "bf16" else 4)
     ops = bench.exp_class_ops(np.full(B, L))
     exp_peak = N_CU * SIMD_PER_CU * TRANS_LANES_PER_CLK * CLOCK_GHZ * 1e9
+    # counter traffic of THIS workload from the committed PMC passes (tools/prof_headline.sh -> tools/dp_workload.py), keyed by workload and
+    # labelled with the kernel-source hash it was taken at; None only when no committed profile holds the workload
+    traffic, traffic_src = bench.pmc_traffic(f"dmv1o_B{B}_L{L}_{dtype_name}")
     return {"us": sec * 1e6, "sentences_per_s": B / sec,
             "workload": f"DMV1o inside+outside (Log), B={B} L={L} N={N}, potentials stored {dtype_name}, raw C-ABI launches",
             "workspace_bytes": int(launch.ws_bytes),
             "roofline": {"bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg, "traffic": None},
+                         "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg, "traffic": traffic,
+                         "traffic_over_algorithmic": None if traffic is None else traffic / alg, "traffic_source": traffic_src},
             "exp_rate": {"achieved_Gops": ops / sec / 1e9, "peak_Gops": exp_peak / 1e9, "frac": ops / sec / exp_peak}}
 
 

@@ -20,26 +20,41 @@ namespace vlg {
 
 namespace {
 
-constexpr int kGemmThreads = 256;   // 4 wavefronts, 2 x 2 over the 64 x 64 output tile
-constexpr int kTile = 64;           // output tile edge (rows of C = columns of A; columns of C = columns of B)
-constexpr int kStage = 128;         // contraction rows per LDS stage
-// LDS row pitch in bytes: 64 bf16 + 32 bytes.  A transposed read of one 32-lane half covers 8 consecutive rows x 32 bytes;
-// 160 r mod 256 = {0,160,64,224,128,32,192,96} for r = 0..7 puts them on 8 disjoint 8-bank groups (64 banks x 4 bytes).
-constexpr int kPitch = kTile * 2 + 32;
+constexpr int kGemmThreads = 256;   // 4 wavefronts, 2 x 2 over the output tile
 
-// C_part[s] (64 x 64 tile) = sum over the rows of split s of A[k, m0..m0+63]^T B[k, n0..n0+63]; optionally the column sums of A.
+// Tile shapes.  TILE = output tile edge (rows of C = columns of A; columns of C = columns of B), KSTAGE = contraction rows per LDS stage.
+//   <64, 128>   round 3: the encoder projections ([B N, 256] x [B N, 128..384]: few output tiles, deep split)
+//   <128, 64>   round 5: outputs of >= 128 x 128 (the parser's 256 x 256 weights over 4 B L rows, the text / visual encoders' 256 x 800 /
+//               256 x 2048): a wave owns 64 x 64 -- 16 transposed LDS reads feed 16 MFMAs per 32 contraction rows where the 64-tile's 8 reads
+//               feed 4 (it was LDS-read-bound), and every operand column block is streamed by half as many workgroups.
+// LDS row pitch in bytes: TILE bf16 + 32 bytes.  A transposed read of one 32-lane half covers 8 consecutive rows x 32 bytes;
+// (2 TILE + 32) r mod 256 = 160 r (TILE 64) / 32 r (TILE 128) mod 256 for r = 0..7 puts them on 8 disjoint 8-bank groups (64 banks x 4 bytes).
+template <int TILE, int KSTAGE>
+struct TnCfg {
+    static constexpr int kTile = TILE, kStage = KSTAGE, kPitch = TILE * 2 + 32;
+    static constexpr int kQ = TILE / 2, kF = TILE / 32;               // a wave's quadrant edge; 16-wide fragments per quadrant edge
+    static constexpr int kSeg = TILE / 8;                             // 16-byte segments per tile row
+    static constexpr int kRowsPerPass = kGemmThreads / kSeg, kPasses = KSTAGE / kRowsPerPass;
+};
+
+// C_part[s] (TILE x TILE tile) = sum over the rows of split s of A[k, m0..]^T B[k, n0..]; optionally the column sums of A / of B.
 // grid = tiles x ceil(S / 8) x 8 workgroups (see the block order below); A [K, lda], B [K, ldb] bf16; part [S][M][N] fp32, part_cs [S][M] fp32 (or null).
-__global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
+// SETS: register sets of one stage each, loaded SETS stages ahead of their use (the 128-tile holds one: with its 64 accumulator registers a
+// second set spills at the 256 registers that two resident workgroups per CU allow); CS / CSB: carry the column sums of A / of B.
+template <int TILE, int KSTAGE, int SETS, bool CS, bool CSB>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
                                                                const uint16_t* __restrict__ B, int ldb, int K, int M,
                                                                int N, int KC, int S, float* __restrict__ part,
                                                                float* __restrict__ part_cs, float* __restrict__ part_csb) {
+    using C = TnCfg<TILE, KSTAGE>;
+    constexpr int kTile = C::kTile, kStage = C::kStage, kPitch = C::kPitch, kQ = C::kQ, kF = C::kF, kP = C::kPasses, kRP = C::kRowsPerPass;
     __shared__ __attribute__((aligned(16))) char sA[kStage * kPitch];
     __shared__ __attribute__((aligned(16))) char sB[kStage * kPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int MT = (M + kTile - 1) / kTile;   // M, N: multiples of 8 (16-byte row segments); the last tile of either side may be partial
     // XCD-aware block order: consecutive workgroup ids go round-robin over the eight XCDs (one L2 each), so id % 8 picks the XCD.  All
     // tiles of one row split s get ids with the same id % 8: the split's rows of A and B are then fetched into ONE L2 and shared by its
-    // MT x NT tiles there, instead of every 64-column block being pulled into 2 (A) or 4 (B) different L2s (grid (tiles, S) order).
+    // MT x NT tiles there, instead of every column block being pulled into several different L2s (grid (tiles, S) order).
     const int tiles = MT * ((N + kTile - 1) / kTile);
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int s = (j / tiles) * 8 + xcd, tile = j % tiles;
@@ -47,28 +62,28 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
     const int mt = tile % MT, nt = tile / MT;
     const int m0 = mt * kTile, n0 = nt * kTile;
     const int k_begin = s * KC, k_end = min(K, k_begin + KC);
-    const int wm = wave & 1, wn = wave >> 1;   // this wave's 32 x 32 quadrant
+    const int wm = wave & 1, wn = wave >> 1;   // this wave's quadrant
 
-    // global -> register staging: a tile row is 64 bf16 = 8 x 16 bytes; 256 threads cover 32 rows per pass, 4 passes per stage
-    const int c16 = tid & 7, r0 = tid >> 3;
+    // global -> register staging: a tile row is kSeg x 16 bytes; 256 threads cover kRP rows per pass, kP passes per stage
+    const int c16 = tid % C::kSeg, r0 = tid / C::kSeg;
     const bool col_a = m0 + c16 * 8 < M, col_b = n0 + c16 * 8 < N;   // columns past a partial tile's edge are staged as zeros
     const uint16_t* pa = A + (size_t)(k_begin + r0) * lda + m0 + c16 * 8;
     const uint16_t* pb = B + (size_t)(k_begin + r0) * ldb + n0 + c16 * 8;
-    // two register sets, each one stage (4 x 16 bytes per operand and thread), loaded two stages ahead of their use
-    uint4 ra[2][4], rb[2][4];
-    auto fetch = [&](int set, int ks) {   // rows k_begin + ks + r0 + 32 p
+    // two register sets, each one stage (kP x 16 bytes per operand and thread), loaded two stages ahead of their use
+    uint4 ra[SETS][kP], rb[SETS][kP];
+    auto fetch = [&](int set, int ks) {   // rows k_begin + ks + r0 + kRP p
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const bool ok = k_begin + ks + r0 + 32 * p < k_end;
-            ra[set][p] = ok && col_a ? *reinterpret_cast<const uint4*>(pa + (size_t)(ks + 32 * p) * lda) : make_uint4(0, 0, 0, 0);
-            rb[set][p] = ok && col_b ? *reinterpret_cast<const uint4*>(pb + (size_t)(ks + 32 * p) * ldb) : make_uint4(0, 0, 0, 0);
+        for (int p = 0; p < kP; ++p) {
+            const bool ok = k_begin + ks + r0 + kRP * p < k_end;
+            ra[set][p] = ok && col_a ? *reinterpret_cast<const uint4*>(pa + (size_t)(ks + kRP * p) * lda) : make_uint4(0, 0, 0, 0);
+            rb[set][p] = ok && col_b ? *reinterpret_cast<const uint4*>(pb + (size_t)(ks + kRP * p) * ldb) : make_uint4(0, 0, 0, 0);
         }
     };
     auto stash = [&](int set) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<uint4*>(sA + (r0 + 32 * p) * kPitch + c16 * 16) = ra[set][p];
-            *reinterpret_cast<uint4*>(sB + (r0 + 32 * p) * kPitch + c16 * 16) = rb[set][p];
+        for (int p = 0; p < kP; ++p) {
+            *reinterpret_cast<uint4*>(sA + (r0 + kRP * p) * kPitch + c16 * 16) = ra[set][p];
+            *reinterpret_cast<uint4*>(sB + (r0 + kRP * p) * kPitch + c16 * 16) = rb[set][p];
         }
     };
 
@@ -76,82 +91,96 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const uint16_t* _
     // takes rows 4g..4g+3 (first read) and 16+4g.. (second read) of a 32-row step -- the same row assignment on both operands
     const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
     const int row_off = (4 * g + q) * kPitch + p4 * 8;
-    const char* a_base = sA + row_off + (wm * 32) * 2;
-    const char* b_base = sB + row_off + (wn * 32) * 2;
+    const char* a_base = sA + row_off + (wm * kQ) * 2;
+    const char* b_base = sB + row_off + (wn * kQ) * 2;
 
-    f32x4 acc[2][2] = {};
-    f32x4 cs[2] = {};
-    f32x4 csb[2] = {};
-    const bool want_cs = part_cs != nullptr && nt == 0 && wn == 0;   // wave-uniform
-    const bool want_csb = part_csb != nullptr && mt == 0 && wm == 0;
+    f32x4 acc[kF][kF] = {};
+    f32x4 cs[CS ? kF : 1] = {};
+    f32x4 csb[CSB ? kF : 1] = {};
+    const bool want_cs = CS && part_cs != nullptr && nt == 0 && wn == 0;   // wave-uniform
+    const bool want_csb = CSB && part_csb != nullptr && mt == 0 && wm == 0;
     typedef short v8i16 __attribute__((ext_vector_type(8)));
     const bf16x8 ones = __builtin_bit_cast(bf16x8, (v8i16){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
     auto stage_mma = [&]() {
 #pragma unroll
         for (int kk = 0; kk < kStage / 32; ++kk) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[kF], fb[kF];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < kF; ++t) {
                 fa[t] = tr_frag(tr_read(a_base + kk * 32 * kPitch + t * 32), tr_read(a_base + (kk * 32 + 16) * kPitch + t * 32));
                 fb[t] = tr_frag(tr_read(b_base + kk * 32 * kPitch + t * 32), tr_read(b_base + (kk * 32 + 16) * kPitch + t * 32));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < kF; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            if (want_cs) {
-                cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], ones, cs[0], 0, 0, 0);
-                cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], ones, cs[1], 0, 0, 0);
+                for (int j = 0; j < kF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if constexpr (CS) {
+                if (want_cs) {
+#pragma unroll
+                    for (int i = 0; i < kF; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, cs[i], 0, 0, 0);
+                }
             }
-            if (want_csb) {   // ones^T B: every row of the result tile is the column sum
-                csb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[0], csb[0], 0, 0, 0);
-                csb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[1], csb[1], 0, 0, 0);
+            if constexpr (CSB) {
+                if (want_csb) {   // ones^T B: every row of the result tile is the column sum
+#pragma unroll
+                    for (int j = 0; j < kF; ++j) csb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[j], csb[j], 0, 0, 0);
+                }
             }
         }
     };
 
     const int rows = k_end - k_begin;
     fetch(0, 0);
-    if (kStage < rows) fetch(1, kStage);
-    for (int ks = 0; ks < rows; ks += 2 * kStage) {
-        __syncthreads();   // the previous stage's fragment reads are done
-        stash(0);
-        __syncthreads();
-        if (ks + 2 * kStage < rows) fetch(0, ks + 2 * kStage);
-        stage_mma();
-        if (ks + kStage >= rows) break;
-        __syncthreads();
-        stash(1);
-        __syncthreads();
-        if (ks + 3 * kStage < rows) fetch(1, ks + 3 * kStage);
-        stage_mma();
+    if constexpr (SETS == 2) {
+        if (kStage < rows) fetch(1, kStage);
+        for (int ks = 0; ks < rows; ks += 2 * kStage) {
+            __syncthreads();   // the previous stage's fragment reads are done
+            stash(0);
+            __syncthreads();
+            if (ks + 2 * kStage < rows) fetch(0, ks + 2 * kStage);
+            stage_mma();
+            if (ks + kStage >= rows) break;
+            __syncthreads();
+            stash(SETS - 1);
+            __syncthreads();
+            if (ks + 3 * kStage < rows) fetch(SETS - 1, ks + 3 * kStage);
+            stage_mma();
+        }
+    } else {
+        for (int ks = 0; ks < rows; ks += kStage) {
+            __syncthreads();
+            stash(0);
+            __syncthreads();
+            if (ks + kStage < rows) fetch(0, ks + kStage);
+            stage_mma();
+        }
     }
 
     // accumulator tile: lane l, register r <-> row 4 (l >> 4) + r, column l & 15
     float* out = part + (size_t)s * M * N;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kF; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < kF; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 32 + i * 16 + 4 * g + r, col = n0 + wn * 32 + j * 16 + (lane & 15);
+                const int row = m0 + wm * kQ + i * 16 + 4 * g + r, col = n0 + wn * kQ + j * 16 + (lane & 15);
                 if (row < M && col < N) out[(size_t)row * N + col] = acc[i][j][r];
             }
-    if (want_cs && (lane & 15) == 0) {
+    if (CS && want_cs && (lane & 15) == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < (CS ? kF : 1); ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 32 + i * 16 + 4 * g + r;
+                const int row = m0 + wm * kQ + i * 16 + 4 * g + r;
                 if (row < M) part_cs[(size_t)s * M + row] = cs[i][r];
             }
     }
-    if (want_csb && lane < 16) {   // row 0 of the tile: lanes 0..15, register 0
+    if (CSB && want_csb && lane < 16) {   // row 0 of the tile: lanes 0..15, register 0
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 32 + j * 16 + lane;
+        for (int j = 0; j < (CSB ? kF : 1); ++j) {
+            const int col = n0 + wn * kQ + j * 16 + lane;
             if (col < N) part_csb[(size_t)s * N + col] = csb[j][0];
         }
     }
@@ -445,9 +474,15 @@ struct TnPlan {
     size_t bytes;
 };
 
-TnPlan plan_tn(int K, int M, int N) {
+// the tile shape of a product: the 128-tile once both output dimensions fill one (VLG_WGRAD_TILE64 forces the round-3 kernel: A/B timing)
+// (with both column sums wanted: see wgrad_launch).  Below ~8 tiles of 128 the split count that fills the chip makes the partial tiles -- S x M x N
+// floats written and read back -- cost more than the 64-tile's extra operand traffic: [4 B L, 256]^T [4 B L, 256] measured 23.0 vs 21.8 us.
+inline bool tn_big(int M, int N) { return M >= 128 && N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) >= 8 && !VLG_ENV("VLG_WGRAD_TILE64"); }
+
+TnPlan plan_tn(int K, int M, int N, bool big) {
+    const int kTile = big ? 128 : 64, kStage = big ? 64 : 128;
     const int tiles = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
-    int S = (512 + tiles - 1) / tiles;                              // ~2 workgroups per CU, 3 resident at a time
+    int S = (512 + tiles - 1) / tiles;                              // ~2 workgroups per CU (swept 256 ... 1024 for both tile shapes: 512)
     const int max_s = (K + 2 * kStage - 1) / (2 * kStage);          // at least two stages per split: both register sets in flight from the start
     S = S < 1 ? 1 : (S > max_s ? max_s : S);
     int KC = ((K + S - 1) / S + kStage - 1) / kStage * kStage;      // whole stages per split
@@ -463,7 +498,8 @@ extern "C" {
 
 size_t vlg_linear_wgrad_workspace(int K, int M, int N) {
     if (K < 1 || M < 8 || N < 8 || M % 8 || N % 8) return 0;
-    return vlg::plan_tn(K, M, N).bytes;
+    const size_t a = vlg::plan_tn(K, M, N, false).bytes, b = vlg::tn_big(M, N) ? vlg::plan_tn(K, M, N, true).bytes : 0;
+    return a > b ? a : b;
 }
 
 static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
@@ -494,7 +530,7 @@ int vlg_linear_wgrad_reduce_group(const VlgWgradReduce* items, int count, void* 
             if (q.K < 1 || q.M < 8 || q.N < 8 || q.M % 8 || q.N % 8 || q.ld_dw < q.N) return set_error(VLG_ERR_SHAPE, "linear_wgrad_reduce_group: item %d K=%d M=%d N=%d ld_dw=%d", i, q.K, q.M, q.N, q.ld_dw);
             if (q.out_dtype != VLG_F32 && q.out_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "linear_wgrad_reduce_group: out_dtype %d", q.out_dtype);
             if (!q.ws || !q.d_weight) return set_error(VLG_ERR_ARG, "linear_wgrad_reduce_group: null buffer");
-            const TnPlan pl = plan_tn(q.K, q.M, q.N);
+            const TnPlan pl = plan_tn(q.K, q.M, q.N, tn_big(q.M, q.N) && !(q.d_bias && q.x_colsum));
             const float* part = (const float*)q.ws;
             RedArgs& a = g.p[g.count++];
             a.part = part;
@@ -525,15 +561,23 @@ static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int 
     if (!dy || !x || !d_weight || !ws) return set_error(VLG_ERR_ARG, "linear_wgrad: null buffer");
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ws)) & 15)
         return set_error(VLG_ERR_ARG, "linear_wgrad: dy, x and the workspace must be 16-byte aligned");
-    const TnPlan pl = plan_tn(K, M, N);
+    const bool big = tn_big(M, N) && !(d_bias && x_colsum);     // (the 128-tile carries one kind of column sum)
+    const TnPlan pl = plan_tn(K, M, N, big);
     if (ws_bytes < pl.bytes) return set_error(VLG_ERR_WORKSPACE, "linear_wgrad: needs a %zu-byte workspace (got %zu)", pl.bytes, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)ws;
     float* part_cs = d_bias ? part + (size_t)pl.S * M * N : nullptr;
     float* part_csb = x_colsum ? part + (size_t)pl.S * ((size_t)M * N + M) : nullptr;
+    const int kTile = big ? 128 : 64;
     const int tiles = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * ((pl.S + 7) / 8) * 8), dim3(kGemmThreads), 0, s, (const uint16_t*)dy, ld_dy,
-                       (const uint16_t*)x, ld_x, K, M, N, pl.KC, pl.S, part, part_cs, part_csb);
+    const dim3 grid(tiles * ((pl.S + 7) / 8) * 8);
+#define VLG_TN(...) hipLaunchKernelGGL((gemm_tn_kernel<__VA_ARGS__>), grid, dim3(kGemmThreads), 0, s, (const uint16_t*)dy, ld_dy, (const uint16_t*)x, ld_x, K, M, N, \
+                                       pl.KC, pl.S, part, part_cs, part_csb)
+    if (!big) VLG_TN(64, 128, 2, true, true);
+    else if (d_bias) VLG_TN(128, 64, 1, true, false);
+    else if (x_colsum) VLG_TN(128, 64, 1, false, true);
+    else VLG_TN(128, 64, 1, false, false);
+#undef VLG_TN
     if (int rc = check_launch("gemm_tn_kernel")) return rc;
     if (!reduce_now) return 0;
     const int n = M * N, n_cs = d_bias ? M : 0, n_csb = x_colsum ? N : 0;
