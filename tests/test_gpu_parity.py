@@ -166,6 +166,46 @@ def test_dmv1o_vs_oracle_random(ts, oracle_mod, B, L, seed):
             assert np.array_equal(gd.detach().cpu().numpy(), ref_gd.astype(np.float32))
 
 
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_dp_short_sentence_image_equals_general_image(ts, storage):
+    """Round 5: for N <= 41 the host launches kernels whose span bodies are compiled for <= 3 split points per lane only (half the code
+    image: 106 -> 53 KB for the headline kernel, 75.9 -> ~70 us).  Same arithmetic in the same order: the results must be BIT-identical to
+    the general image, which the same sentences reach when their potentials are padded to N = 42 (same chart pitch, same lane groups).
+    DMV1o Log (logZ, both count tensors), Max (score, tree counts, heads), the marginals + Viterbi pair launch, DepTree Log and Max."""
+    from vlgae_amd.torch_struct import functional as Fn
+    B, L = 192, 40
+    N = L + 1
+    gen = torch.Generator().manual_seed(31)
+    dec = torch.randn(B, L, 2, 2, 2, generator=gen).log_softmax(-1).to(dev())
+    attach = (torch.randn(B, L, L, 2, generator=gen) * 2).to(dev())
+    root = torch.randn(B, L, generator=gen).log_softmax(-1).to(dev())
+    lengths = torch.randint(1, L + 1, (B,), generator=gen)
+    lengths[:3] = torch.tensor([L, 1, 2])
+    lengths = lengths.to(dev())
+    md, ma = ts.DMV1o.merge(dec, attach, root)
+    md, ma = md.to(storage), ma.to(storage)
+    md2 = torch.full((B, N + 1, 2, 2, 2), -7.0, device=dev(), dtype=storage)
+    ma2 = torch.full((B, N + 1, N + 1, 2), -7.0, device=dev(), dtype=storage)
+    md2[:, :N] = md
+    ma2[:, :N, :N] = ma
+    for sr in (0, 1):
+        a = Fn.dmv1o_run(md, ma, lengths, sr, True)                     # (logZ, gdec, gatt): N = 41 -> the short image
+        b = Fn.dmv1o_run(md2, ma2, lengths, sr, True)                   # N = 42 -> the general image
+        assert torch.equal(a[0], b[0]), sr
+        assert torch.equal(a[1], b[1][:, :N]) and torch.equal(a[2], b[2][:, :N, :N]), sr
+        assert float(b[1][:, N:].abs().max()) == 0.0 and float(b[2][:, N:].abs().max()) == 0.0 and float(b[2][:, :, N:].abs().max()) == 0.0
+        assert torch.equal(Fn.dmv1o_run(md, ma, lengths, sr, False)[0], Fn.dmv1o_run(md2, ma2, lengths, sr, False)[0])   # inside only
+    m1, h1 = ts.DMV1o([md, ma], lengths).marginals_and_heads()        # the pair launch
+    m2, h2 = ts.DMV1o([md2, ma2], lengths).marginals_and_heads()
+    assert torch.equal(m1, m2[:, :N, :N]) and torch.equal(h1, h2[:, :N])
+    arc = ma[..., 0].float().contiguous()
+    arc2 = ma2[..., 0].float().contiguous()
+    for sr in (0, 1):
+        a = Fn.deptree_run(arc, lengths, sr, True)
+        b = Fn.deptree_run(arc2, lengths, sr, True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1][:, :N, :N]), sr
+
+
 def test_dmv1o_properties_full_size(ts, oracle_mod):
     """BASELINE.json config 2 (B=256, L=40): size-independent identities, and a 12-sentence fp64-oracle
     slice of the full-size launch for both storage types of the potentials (the headline configuration stores bf16)."""

@@ -32,8 +32,16 @@ def kernels_of(obj_path):
                 continue
             doc = notes.split("---", 1)[1].split("\n...", 1)[0]
             meta = yaml.safe_load(doc) or {}
+            # .text bytes of every kernel: the FUNC symbols of the code object (the kernel descriptor `name.kd` is a separate OBJECT symbol)
+            sizes = {}
+            for line in subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--symbols", "--wide", co], stdout=subprocess.PIPE, text=True).stdout.splitlines():
+                f = line.split()
+                if len(f) >= 8 and f[3] == "FUNC":
+                    sizes[f[7]] = int(f[2], 0) if not f[2].isdigit() else int(f[2])
             for k in meta.get("amdhsa.kernels", []):
-                out.append({key.lstrip("."): val for key, val in k.items() if key != ".args"})
+                rec = {key.lstrip("."): val for key, val in k.items() if key != ".args"}
+                rec["text_bytes"] = sizes.get(rec.get("name"), 0)
+                out.append(rec)
     if out:
         dem = subprocess.run(["c++filt"], input="\n".join(k["name"] for k in out), stdout=subprocess.PIPE, text=True).stdout.splitlines()
         for k, d in zip(out, dem):
@@ -55,4 +63,4 @@ if __name__ == "__main__":
     for k in all_kernels():
         if pat in k.get("demangled", ""):
             print(f'{k["object"]:20s} vgpr {k.get("vgpr_count", -1):3d} agpr {k.get("agpr_count", -1):3d} spill v{k.get("vgpr_spill_count", 0):<3d} s{k.get("sgpr_spill_count", 0):<3d} '
-                  f'scratch {k.get("private_segment_fixed_size", 0):4d} lds {k.get("group_segment_fixed_size", 0):6d} wg {k.get("max_flat_workgroup_size", 0):4d}  {k.get("demangled", "?")[:120]}')
+                  f'scratch {k.get("private_segment_fixed_size", 0):4d} text {k.get("text_bytes", 0) / 1024:6.1f}K lds {k.get("group_segment_fixed_size", 0):6d} wg {k.get("max_flat_workgroup_size", 0):4d}  {k.get("demangled", "?")[:120]}')

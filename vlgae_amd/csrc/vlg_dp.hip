@@ -159,7 +159,7 @@ static int run_dmv(const void* dec, const void* attach, const int64_t* lengths, 
         return set_error(VLG_ERR_WORKSPACE, "dmv1o: N=%d needs a %zu-byte workspace (got %zu); see vlg_workspace_bytes",
                          N, ws_stride * (size_t)B, ws_bytes);
     const DmvArgs a{dec, attach, lengths, B, N, glogZ, logZ, gdec, gatt, heads, ws, ws_stride, lds, (hipStream_t)stream};
-    return VLG_DP_PICK(0, semiring, in_dtype)(BWD, mode, a);
+    return VLG_DP_PICK(0, semiring, in_dtype)(BWD, mode == 0 && N <= kShortN ? kModeShort : mode, a);   // short sentences: the smaller code image
 }
 
 template <bool BWD>
@@ -180,7 +180,7 @@ static int run_dep(const void* arc, const int64_t* lengths, int B, int N, int in
         return set_error(VLG_ERR_WORKSPACE, "deptree: N=%d needs a %zu-byte workspace (got %zu)", N,
                          ws_stride * (size_t)B, ws_bytes);
     const DepArgs a{arc, lengths, B, N, glogZ, logZ, garc, heads, ws, ws_stride, lds, (hipStream_t)stream};
-    return VLG_DP_PICK(2, semiring, in_dtype)(BWD, mode, a);
+    return VLG_DP_PICK(2, semiring, in_dtype)(BWD, mode == 0 && N <= kShortN ? kModeShort : mode, a);
 }
 
 }  // namespace vlg
@@ -269,7 +269,7 @@ int vlg_dmv1o_rules(const void* attach_rule, const void* dec, const void* root_r
     }
     RulesArgs a{attach_rule, dec, root_rule, root_per_sentence ? T : 0, token, head_mask, lengths, B, L, T, mask_fill,
                 grad_logZ, logZ, grad_rule, grad_dec, grad_root, heads, ws, Lay.ws_bytes, Lay.lds_bytes, s};
-    return VLG_DP_PICK(1, semiring, in_dtype)(bwd, mode, a);
+    return VLG_DP_PICK(1, semiring, in_dtype)(bwd, mode == 0 && N <= kShortN ? kModeShort : mode, a);
 }
 
 size_t vlg_workspace_bytes(int op, int B, int N, int semiring) {

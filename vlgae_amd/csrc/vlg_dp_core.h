@@ -202,6 +202,43 @@ VLG_HD Sched make_sched(int Ne, int lanes, int budget) {
     return s;
 }
 
+// ---- the short-sentence code image (round 5) ---------------------------------------------------------------------------------------
+// A lane holds T = ceil(w / G) split points of a span; the span bodies are unrolled for T = 1 ... 4 with generic loops behind them, per
+// segment and direction: ~70 + 35 bodies, of which a sentence of <= 40 words executes 18 + 9.  The bodies it never executes still cost:
+// the fused headline launch measured 75.9 us with them compiled in and 69.7 us without (same bits) -- the code image, not the
+// arithmetic.  For N <= kShortN every width has T <= 3 (checked at compile time below for the lane budgets in force), so the kernels
+// are instantiated once more with the span-count policy kSpansShort, whose dispatch ends at T = 3, and the host launches that
+// instantiation for N <= kShortN.  Span-count policy (the LONGSPAN template parameter): 0 general, 1 long sentences (chunked long
+// spans, workspace placements), 2 short sentences.
+constexpr int kSpansGeneral = 0, kSpansLong = 1, kSpansShort = 2;
+constexpr int kShortN = 41;
+constexpr int group_log2_c(int spans, int w, int cap) {
+    int lg = 0;
+    while (lg < 6 && (1 << lg) < w && spans * (2 << lg) <= cap) ++lg;
+    return lg;
+}
+constexpr bool short_sentence_ok(int n_max, int cap) {
+    for (int ne = 2; ne <= n_max; ++ne)
+        for (int w = 1; w < ne; ++w) {
+            const int lg = group_log2_c(ne - w, w, cap);
+            if (((w + (1 << lg) - 1) >> lg) > 3) return false;
+        }
+    return true;
+}
+// the largest T that a segment of group size 2^lg meets in ANY sentence of N <= n_max: the short image's dispatch of that segment ends there
+// (N <= 41 at 256 lanes per direction: lg 0, 1, 6 -> 1; lg 2, 4, 5 -> 2; lg 3 -> 3: 12 of the 21 bodies per direction are compiled)
+constexpr int short_tmax(int lg_want, int n_max, int cap) {
+    int m = 1;
+    for (int ne = 2; ne <= n_max; ++ne)
+        for (int w = 1; w < ne; ++w) {
+            const int lg = group_log2_c(ne - w, w, cap), t = (w + (1 << lg) - 1) >> lg;
+            if (lg == lg_want && t > m) m = t;
+        }
+    return m;
+}
+static_assert(short_sentence_ok(kShortN, VLG_DP_LANES_FW) && short_sentence_ok(kShortN, VLG_DP_LANES_BW),
+              "kShortN: a sentence of that length has a width with more than three split points per lane at these lane budgets");
+
 #if defined(__HIPCC__)
 #define VLG_MUL24(a, b) __mul24((a), (b))   // v_mul_i32_i24: full rate (v_mul_lo_u32 is quarter rate); all chart indices < 2^17
 #else
@@ -397,7 +434,7 @@ VLG_HD void dmv_fw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
 }
 
 // one width of the inside pass for this lane: G = 2^LG lanes per (span, direction); LG < 0: G is a run-time value
-template <int SR, bool BWD, int DIR, int LG, bool LONGSPAN, typename X>
+template <int SR, bool BWD, int DIR, int LG, int LONGSPAN, typename X>
 VLG_HD void dmv_fw_width(const DmvCtx& c, int w, int lgr, int t, int nd, X& x, int dir_rt = 0) {
     const int lg = LG >= 0 ? LG : lgr, G = 1 << lg, per = nd >> lg;
     const int rr = t & (G - 1), slot = t >> lg, spans = c.Ne - w;
@@ -407,17 +444,22 @@ VLG_HD void dmv_fw_width(const DmvCtx& c, int w, int lgr, int t, int nd, X& x, i
         const int i = live ? base + slot : 0;   // dead lanes shadow span 0 and never store
         if (X::kSkipDeadWaves && (base + ((t & ~63) >> lg)) >= spans) continue;   // whole wavefront past the last span
         const int D = VLG_MUL24(i, c.P + 1);
-        constexpr bool NC = !LONGSPAN && X::kChartsInLds;
-        if (T == 1) dmv_fw_span<SR, BWD, DIR, 1, X, NC>(c, w, G, D, live, rr, x, dir_rt);
+        constexpr bool NC = LONGSPAN != 1 && X::kChartsInLds;
+        if constexpr (LONGSPAN == kSpansShort && LG >= 0) {   // N <= kShortN: this segment never sees more than TM split points per lane
+            constexpr int TM = short_tmax(LG, kShortN, VLG_DP_LANES_FW);
+            if (TM == 1 || T == 1) dmv_fw_span<SR, BWD, DIR, 1, X, NC>(c, w, G, D, live, rr, x, dir_rt);
+            else if (TM == 2 || T == 2) dmv_fw_span<SR, BWD, DIR, 2, X, NC>(c, w, G, D, live, rr, x, dir_rt);
+            else dmv_fw_span<SR, BWD, DIR, 3, X, NC>(c, w, G, D, live, rr, x, dir_rt);
+        } else if (T == 1) dmv_fw_span<SR, BWD, DIR, 1, X, NC>(c, w, G, D, live, rr, x, dir_rt);
         else if (T == 2) dmv_fw_span<SR, BWD, DIR, 2, X, NC>(c, w, G, D, live, rr, x, dir_rt);
         else if (T == 3) dmv_fw_span<SR, BWD, DIR, 3, X, NC>(c, w, G, D, live, rr, x, dir_rt);
         else if (T == 4) dmv_fw_span<SR, BWD, DIR, 4, X, NC>(c, w, G, D, live, rr, x, dir_rt);
-        else dmv_fw_span<SR, BWD, DIR, LONGSPAN ? -1 : 0>(c, w, G, D, live, rr, x, dir_rt);
+        else dmv_fw_span<SR, BWD, DIR, LONGSPAN == kSpansLong ? -1 : 0>(c, w, G, D, live, rr, x, dir_rt);
     }
 }
 
 // all widths of one segment (constant group size), one barrier per width
-template <int SR, bool BWD, int LG, bool LONGSPAN, typename X>
+template <int SR, bool BWD, int LG, int LONGSPAN, typename X>
 VLG_HD void dmv_fw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& x) {
     const int nd = nt >> 1;                 // lanes per direction
     const bool right = x.uniform(tid >= nd);   // wave-uniform on the device (nd is a multiple of 64)
@@ -437,7 +479,7 @@ VLG_HD void dmv_fw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& 
     }
 }
 
-template <int SR, bool BWD, bool LONGSPAN, typename X>
+template <int SR, bool BWD, int LONGSPAN, typename X>
 VLG_HD void dmv_fw_all(const DmvCtx& c, int tid, int nt, X& x) {
     const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_FW);
     dmv_fw_segment<SR, BWD, 0, LONGSPAN>(c, sc.first[0], sc.first[1], tid, nt, x);
@@ -575,10 +617,10 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
     if (live && rr == 0) c.gI[kO] = gi;
 }
 
-template <int SR, int DIR, int LG, bool LONGSPAN, typename X>
+template <int SR, int DIR, int LG, int LONGSPAN, typename X>
 VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x, int dir_rt = 0) {
     constexpr int G = 1 << LG;
-    constexpr bool NC = !LONGSPAN && X::kChartsInLds;
+    constexpr bool NC = LONGSPAN != 1 && X::kChartsInLds;
     const int per = nd >> LG, rr = t & (G - 1), slot = t >> LG, spans = c.Ne - w;
     const int T = (w + G - 1) >> LG;
     for (int base = 0; base < spans; base += per) {
@@ -586,7 +628,12 @@ VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x, int dir_rt
         const int i = live ? base + slot : 0;
         if (X::kSkipDeadWaves && (base + ((t & ~63) >> LG)) >= spans) continue;
         const int D = VLG_MUL24(i, c.P + 1);
-        if (T == 1) dmv_bw_span<SR, DIR, 1, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
+        if constexpr (LONGSPAN == kSpansShort) {
+            constexpr int TM = short_tmax(LG, kShortN, VLG_DP_LANES_BW);
+            if (TM == 1 || T == 1) dmv_bw_span<SR, DIR, 1, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
+            else if (TM == 2 || T == 2) dmv_bw_span<SR, DIR, 2, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
+            else dmv_bw_span<SR, DIR, 3, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
+        } else if (T == 1) dmv_bw_span<SR, DIR, 1, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
         else if (T == 2) dmv_bw_span<SR, DIR, 2, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
         else if (T == 3) dmv_bw_span<SR, DIR, 3, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
         else if (T == 4) dmv_bw_span<SR, DIR, 4, X, false, NC>(c, w, G, D, live, rr, x, 1, dir_rt);
@@ -595,7 +642,7 @@ VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x, int dir_rt
 }
 
 // widths w1-1 ... w0 of one segment, descending, one barrier per width
-template <int SR, int LG, bool LONGSPAN, typename X>
+template <int SR, int LG, int LONGSPAN, typename X>
 VLG_HD void dmv_bw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& x) {
     const int nd = nt >> 1;
     const bool right = x.uniform(tid >= nd);
@@ -623,7 +670,7 @@ VLG_HD void dmv_bw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& 
 //  of it.  Also measured: the read-modify-writes of the adjoint charts as non-returning ds_add_f32 (one writer per word and phase,
 //  so the same sums): 77 -> 200 us, LDS float atomics are that slow; the four adjoint loads per split point replaced by register
 //  copies (wrong results, an upper bound for interleaving value and adjoint cells): 77.3 -> 74.4 us.)
-template <int SR, bool LONGSPAN = true, typename X>
+template <int SR, int LONGSPAN = true, typename X>
 VLG_HD void dmv_bw_all(const DmvCtx& c, int tid, int nt, X& x) {
     const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_BW);
     dmv_bw_segment<SR, 6, LONGSPAN>(c, sc.first[6], sc.first[7], tid, nt, x);
@@ -733,7 +780,7 @@ VLG_HD void dep_fw_span(const DepCtx& c, int w, int G, int D, bool live, int rr,
     }
 }
 
-template <int SR, bool BWD, int DIR, int LG, typename X>
+template <int SR, bool BWD, int DIR, int LG, int SPANS, typename X>
 VLG_HD void dep_fw_width(const DepCtx& c, int w, int t, int nd, X& x) {
     constexpr int G = 1 << LG;
     const int per = nd >> LG, rr = t & (G - 1), slot = t >> LG, spans = c.Ne - w;
@@ -743,7 +790,12 @@ VLG_HD void dep_fw_width(const DepCtx& c, int w, int t, int nd, X& x) {
         const int i = live ? base + slot : 0;
         if (X::kSkipDeadWaves && (base + ((t & ~63) >> LG)) >= spans) continue;
         const int D = VLG_MUL24(i, c.P + 1);
-        if (T == 1) dep_fw_span<SR, BWD, DIR, 1>(c, w, G, D, live, rr, x);
+        if constexpr (SPANS == kSpansShort) {
+            constexpr int TM = short_tmax(LG, kShortN, VLG_DP_LANES_FW);
+            if (TM == 1 || T == 1) dep_fw_span<SR, BWD, DIR, 1>(c, w, G, D, live, rr, x);
+            else if (TM == 2 || T == 2) dep_fw_span<SR, BWD, DIR, 2>(c, w, G, D, live, rr, x);
+            else dep_fw_span<SR, BWD, DIR, 3>(c, w, G, D, live, rr, x);
+        } else if (T == 1) dep_fw_span<SR, BWD, DIR, 1>(c, w, G, D, live, rr, x);
         else if (T == 2) dep_fw_span<SR, BWD, DIR, 2>(c, w, G, D, live, rr, x);
         else if (T == 3) dep_fw_span<SR, BWD, DIR, 3>(c, w, G, D, live, rr, x);
         else if (T == 4) dep_fw_span<SR, BWD, DIR, 4>(c, w, G, D, live, rr, x);
@@ -751,28 +803,28 @@ VLG_HD void dep_fw_width(const DepCtx& c, int w, int t, int nd, X& x) {
     }
 }
 
-template <int SR, bool BWD, int LG, typename X>
+template <int SR, bool BWD, int LG, int SPANS, typename X>
 VLG_HD void dep_fw_segment(const DepCtx& c, int w0, int w1, int tid, int nt, X& x) {
     const int nd = nt >> 1;
     const bool right = x.uniform(tid >= nd);
     const int t = right ? tid - nd : tid;
     for (int w = w0; w < w1; ++w) {
-        if (right) dep_fw_width<SR, BWD, 1, LG>(c, w, t, nd, x);
-        else dep_fw_width<SR, BWD, 0, LG>(c, w, t, nd, x);
+        if (right) dep_fw_width<SR, BWD, 1, LG, SPANS>(c, w, t, nd, x);
+        else dep_fw_width<SR, BWD, 0, LG, SPANS>(c, w, t, nd, x);
         x.sync();
     }
 }
 
-template <int SR, bool BWD, typename X>
+template <int SR, bool BWD, int SPANS, typename X>
 VLG_HD void dep_fw_all(const DepCtx& c, int tid, int nt, X& x) {
     const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_FW);
-    dep_fw_segment<SR, BWD, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
-    dep_fw_segment<SR, BWD, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
-    dep_fw_segment<SR, BWD, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
-    dep_fw_segment<SR, BWD, 3>(c, sc.first[3], sc.first[4], tid, nt, x);
-    dep_fw_segment<SR, BWD, 4>(c, sc.first[4], sc.first[5], tid, nt, x);
-    dep_fw_segment<SR, BWD, 5>(c, sc.first[5], sc.first[6], tid, nt, x);
-    dep_fw_segment<SR, BWD, 6>(c, sc.first[6], sc.first[7], tid, nt, x);
+    dep_fw_segment<SR, BWD, 0, SPANS>(c, sc.first[0], sc.first[1], tid, nt, x);
+    dep_fw_segment<SR, BWD, 1, SPANS>(c, sc.first[1], sc.first[2], tid, nt, x);
+    dep_fw_segment<SR, BWD, 2, SPANS>(c, sc.first[2], sc.first[3], tid, nt, x);
+    dep_fw_segment<SR, BWD, 3, SPANS>(c, sc.first[3], sc.first[4], tid, nt, x);
+    dep_fw_segment<SR, BWD, 4, SPANS>(c, sc.first[4], sc.first[5], tid, nt, x);
+    dep_fw_segment<SR, BWD, 5, SPANS>(c, sc.first[5], sc.first[6], tid, nt, x);
+    dep_fw_segment<SR, BWD, 6, SPANS>(c, sc.first[6], sc.first[7], tid, nt, x);
 }
 
 // The self term of IL(j,i) / IR(i,j): the weight of the same-width term in CL(j,i) / CR(i,j) (r = 0 | w-1).  gI never
@@ -845,7 +897,7 @@ VLG_HD void dep_bw_span(const DepCtx& c, int w, int G, int D, bool live, int rr,
     }
 }
 
-template <int SR, int DIR, int LG, typename X>
+template <int SR, int DIR, int LG, int SPANS, typename X>
 VLG_HD void dep_bw_width(const DepCtx& c, int w, int t, int nd, X& x) {
     constexpr int G = 1 << LG;
     const int per = nd >> LG, rr = t & (G - 1), slot = t >> LG, spans = c.Ne - w;
@@ -855,7 +907,12 @@ VLG_HD void dep_bw_width(const DepCtx& c, int w, int t, int nd, X& x) {
         const int i = live ? base + slot : 0;
         if (X::kSkipDeadWaves && (base + ((t & ~63) >> LG)) >= spans) continue;
         const int D = VLG_MUL24(i, c.P + 1);
-        if (T == 1) dep_bw_span<SR, DIR, 1>(c, w, G, D, live, rr, x);
+        if constexpr (SPANS == kSpansShort) {
+            constexpr int TM = short_tmax(LG, kShortN, VLG_DP_LANES_BW);
+            if (TM == 1 || T == 1) dep_bw_span<SR, DIR, 1>(c, w, G, D, live, rr, x);
+            else if (TM == 2 || T == 2) dep_bw_span<SR, DIR, 2>(c, w, G, D, live, rr, x);
+            else dep_bw_span<SR, DIR, 3>(c, w, G, D, live, rr, x);
+        } else if (T == 1) dep_bw_span<SR, DIR, 1>(c, w, G, D, live, rr, x);
         else if (T == 2) dep_bw_span<SR, DIR, 2>(c, w, G, D, live, rr, x);
         else if (T == 3) dep_bw_span<SR, DIR, 3>(c, w, G, D, live, rr, x);
         else if (T == 4) dep_bw_span<SR, DIR, 4>(c, w, G, D, live, rr, x);
@@ -863,28 +920,28 @@ VLG_HD void dep_bw_width(const DepCtx& c, int w, int t, int nd, X& x) {
     }
 }
 
-template <int SR, int LG, typename X>
+template <int SR, int LG, int SPANS, typename X>
 VLG_HD void dep_bw_segment(const DepCtx& c, int w0, int w1, int tid, int nt, X& x) {
     const int nd = nt >> 1;
     const bool right = x.uniform(tid >= nd);
     const int t = right ? tid - nd : tid;
     for (int w = w1 - 1; w >= w0; --w) {
-        if (right) dep_bw_width<SR, 1, LG>(c, w, t, nd, x);
-        else dep_bw_width<SR, 0, LG>(c, w, t, nd, x);
+        if (right) dep_bw_width<SR, 1, LG, SPANS>(c, w, t, nd, x);
+        else dep_bw_width<SR, 0, LG, SPANS>(c, w, t, nd, x);
         x.sync();
     }
 }
 
-template <int SR, typename X>
+template <int SR, int SPANS, typename X>
 VLG_HD void dep_bw_all(const DepCtx& c, int tid, int nt, X& x) {
     const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_BW);
-    dep_bw_segment<SR, 6>(c, sc.first[6], sc.first[7], tid, nt, x);
-    dep_bw_segment<SR, 5>(c, sc.first[5], sc.first[6], tid, nt, x);
-    dep_bw_segment<SR, 4>(c, sc.first[4], sc.first[5], tid, nt, x);
-    dep_bw_segment<SR, 3>(c, sc.first[3], sc.first[4], tid, nt, x);
-    dep_bw_segment<SR, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
-    dep_bw_segment<SR, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
-    dep_bw_segment<SR, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
+    dep_bw_segment<SR, 6, SPANS>(c, sc.first[6], sc.first[7], tid, nt, x);
+    dep_bw_segment<SR, 5, SPANS>(c, sc.first[5], sc.first[6], tid, nt, x);
+    dep_bw_segment<SR, 4, SPANS>(c, sc.first[4], sc.first[5], tid, nt, x);
+    dep_bw_segment<SR, 3, SPANS>(c, sc.first[3], sc.first[4], tid, nt, x);
+    dep_bw_segment<SR, 2, SPANS>(c, sc.first[2], sc.first[3], tid, nt, x);
+    dep_bw_segment<SR, 1, SPANS>(c, sc.first[1], sc.first[2], tid, nt, x);
+    dep_bw_segment<SR, 0, SPANS>(c, sc.first[0], sc.first[1], tid, nt, x);
 }
 
 // ================================================================================================
@@ -1025,7 +1082,7 @@ VLG_HD void dmv_walk(const DmvCtx& c, float g) {
     }
 }
 
-template <int SR, bool BWD, bool LONGSPAN = false, typename IO, typename X>
+template <int SR, bool BWD, int LONGSPAN = false, typename IO, typename X>
 VLG_HD void dmv_run(const DmvCtx& c, const IO& io, float glogZ, float* logZ, int tid, int nt, X& x) {
     const int Ne = c.Ne, P = c.P, len = c.len;
     // ---- stage: charts to the semiring zero (dmv.py:34-35), potentials into fast memory -------------------------
@@ -1232,7 +1289,7 @@ VLG_HD void dep_walk(const DepCtx& c, float g) {
     }
 }
 
-template <int SR, bool BWD, typename In, typename X>
+template <int SR, bool BWD, typename In, int SPANS = kSpansGeneral, typename X>
 VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glogZ, float* logZ, float* garc,
                     long long* heads, int tid, int nt, X& x) {
     const int Ne = c.Ne, P = c.P, len = c.len;
@@ -1258,7 +1315,7 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
         }
     }
     x.sync();
-    dep_fw_all<SR, BWD>(c, tid, nt, x);
+    dep_fw_all<SR, BWD, SPANS>(c, tid, nt, x);
     if (tid == 0) *logZ = c.C[len + 1] * VLG_LN2;   // CR(0,len), deptree.py:74-75
     if (!BWD) return;
     if (SR == VLG_SR_MAX) {   // the best tree's arcs are all the Max semiring's gradient is: walk the back-pointers
@@ -1267,7 +1324,7 @@ VLG_HD void dep_run(const DepCtx& c, const typename In::T* arc, int N, float glo
     } else {
         if (tid == 0) c.gCc[len + 1] = glogZ;
         x.sync();
-        dep_bw_all<SR>(c, tid, nt, x);
+        dep_bw_all<SR, SPANS>(c, tid, nt, x);
     }
     if (heads) {
         for (int i = tid; i < N; i += nt) heads[i] = 0;

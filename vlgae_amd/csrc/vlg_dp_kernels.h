@@ -207,9 +207,15 @@ __device__ __forceinline__ T* region_ptr(const Region& r, char* smem, char* wsb)
     return reinterpret_cast<T*>((r.lds ? smem : wsb) + r.off);
 }
 
+// Kernel variant MODE: 0 ... 3 = the placement modes of DmvLayout / DepLayout; kModeShort = placement 0 (everything in LDS) with the
+// short-sentence code image (vlg_dp_core.h: kSpansShort), launched for N <= kShortN.
+constexpr int kModeShort = 4;
+constexpr int placement_of(int mode) { return mode == kModeShort ? 0 : mode; }
+constexpr int spans_of(int mode) { return mode == kModeShort ? kSpansShort : (mode != 0 ? kSpansLong : kSpansGeneral); }
+
 template <int SR, int MODE, bool BWD>
 __device__ __forceinline__ DmvCtx carve_dmv(int N, int len, char* smem, char* wsb, bool walk) {
-    const DmvLayout L(N, BWD, SR == VLG_SR_MAX, MODE, walk);
+    const DmvLayout L(N, BWD, SR == VLG_SR_MAX, placement_of(MODE), walk);
     DmvCtx c;
     c.walk = walk;
     c.Ne = len + 1;
@@ -232,7 +238,7 @@ __device__ __forceinline__ DmvCtx carve_dmv(int N, int len, char* smem, char* ws
 
 template <int SR, int MODE, bool BWD>
 __device__ __forceinline__ DepCtx carve_dep(int N, int len, char* smem, char* wsb) {
-    const DepLayout L(N, BWD, SR == VLG_SR_MAX, MODE);
+    const DepLayout L(N, BWD, SR == VLG_SR_MAX, placement_of(MODE));
     DepCtx c;
     c.Ne = len + 1;
     c.len = len;
@@ -278,7 +284,7 @@ __device__ __forceinline__ void dmv1o_sentence(int b, const typename In::T* __re
     io.gatt = (BWD && gatt) ? gatt + att_off : nullptr;
     io.heads = (BWD && heads) ? heads + (size_t)b * N : nullptr;
     DevX x;
-    dmv_run<SR, BWD, (MODE != 0)>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);   // long-sentence placements: chunked long spans
+    dmv_run<SR, BWD, spans_of(MODE)>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);   // long-sentence placements: chunked long spans
 }
 
 template <int SR, int MODE, bool BWD, typename In>
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(kThreads) void dmv1o_kernel(const typename In::T* _
 // same sentence (best score, heads, optionally the tree counts).  Both are everything-in-LDS placements (mode 0) whose footprints
 // share a CU, so the two workgroups of a sentence run side by side as they did on two streams -- without the two cross-queue
 // dependencies (fork after the potentials' producer, join before the first consumer: ~15 us of a 110 us pair at B = 256, L = 40).
-template <typename In>
+template <typename In, int MODE>   // MODE: 0 or kModeShort
 __global__ __launch_bounds__(kThreads) void dmv1o_pair_kernel(const typename In::T* __restrict__ dec, const typename In::T* __restrict__ attach,
                                                               const int64_t* __restrict__ lengths, int N, float* __restrict__ logZ,
                                                               float* __restrict__ gdec_log, float* __restrict__ gatt_log,
@@ -306,9 +312,9 @@ __global__ __launch_bounds__(kThreads) void dmv1o_pair_kernel(const typename In:
                                                               float* __restrict__ gatt_max, long long* __restrict__ heads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (blockIdx.y == 0)
-        dmv1o_sentence<VLG_SR_LOG, 0, true, In>(blockIdx.x, dec, attach, lengths, N, nullptr, logZ, gdec_log, gatt_log, nullptr, nullptr, 0, smem);
+        dmv1o_sentence<VLG_SR_LOG, MODE, true, In>(blockIdx.x, dec, attach, lengths, N, nullptr, logZ, gdec_log, gatt_log, nullptr, nullptr, 0, smem);
     else
-        dmv1o_sentence<VLG_SR_MAX, 0, true, In>(blockIdx.x, dec, attach, lengths, N, nullptr, best, gdec_max, gatt_max, heads, nullptr, 0, smem);
+        dmv1o_sentence<VLG_SR_MAX, MODE, true, In>(blockIdx.x, dec, attach, lengths, N, nullptr, best, gdec_max, gatt_max, heads, nullptr, 0, smem);
 }
 
 // The same DP fed from the scorer's rule tables (RuleIO): no gathered [B,L,L,2,2]
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(kThreads) void dmv1o_rules_kernel(
     io.g_root = (BWD && g_root) ? g_root + (size_t)b * T : nullptr;
     io.heads = (BWD && heads) ? heads + (size_t)b * N : nullptr;
     DevX x;
-    dmv_run<SR, BWD, (MODE != 0)>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);   // long-sentence placements: chunked long spans
+    dmv_run<SR, BWD, spans_of(MODE)>(c, io, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b, tid, kThreads, x);   // long-sentence placements: chunked long spans
 }
 
 template <int SR, int MODE, bool BWD, typename In>
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void deptree_kernel(const typename In::T*
     char* wsb = ws + (size_t)b * ws_stride;
     const DepCtx c = carve_dep<SR, MODE, BWD>(N, len, smem, wsb);
     DevX x;
-    dep_run<SR, BWD, In>(c, arc + arc_off, N, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b,
+    dep_run<SR, BWD, In, (MODE == kModeShort ? kSpansShort : kSpansGeneral)>(c, arc + arc_off, N, (BWD && glogZ) ? glogZ[b] : 1.f, logZ + b,
                          (BWD && garc) ? garc + arc_off : nullptr, (BWD && heads) ? heads + (size_t)b * N : nullptr, tid,
                          kThreads, x);
 }

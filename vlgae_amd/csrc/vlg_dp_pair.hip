@@ -19,10 +19,17 @@ bool pair_ok(int N, size_t* lds) {
 template <typename In>
 int launch_pair(const void* dec, const void* attach, const int64_t* lengths, int B, int N, size_t lds, float* logZ, float* gdec_log,
                 float* gatt_log, float* best, float* gdec_max, float* gatt_max, int64_t* heads, hipStream_t s) {
-    auto k = dmv1o_pair_kernel<In>;
-    if (int rc = prep(k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(B, 2), dim3(kThreads), lds, s, (const typename In::T*)dec, (const typename In::T*)attach, lengths, N, logZ,
-                       gdec_log, gatt_log, best, gdec_max, gatt_max, (long long*)heads);
+    if (N <= kShortN) {   // the short-sentence code image (vlg_dp_core.h: kSpansShort)
+        auto k = dmv1o_pair_kernel<In, kModeShort>;
+        if (int rc = prep(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(B, 2), dim3(kThreads), lds, s, (const typename In::T*)dec, (const typename In::T*)attach, lengths, N, logZ,
+                           gdec_log, gatt_log, best, gdec_max, gatt_max, (long long*)heads);
+    } else {
+        auto k = dmv1o_pair_kernel<In, 0>;
+        if (int rc = prep(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(B, 2), dim3(kThreads), lds, s, (const typename In::T*)dec, (const typename In::T*)attach, lengths, N, logZ,
+                           gdec_log, gatt_log, best, gdec_max, gatt_max, (long long*)heads);
+    }
     return check_launch("dmv1o_pair_kernel");
 }
 

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(kEncThreads) void vis_encoder_fwd_kernel(VisArgs a)
 struct VisBwdArgs {
     const void *P, *C, *g;    // g: cotangent of mid [B, V, H]
     void* dP;                 // [B R, ldp]
+    void* dC;                 // [B, ldp] written by the box / attr workgroups themselves, or null (a relation factor: vis_segsum_kernel follows)
     int R, H, V, ldp;
     int col_box, col_rel, col_attr, off_box, off_rel, off_attr, off_img;
     float slope;
@@ -201,13 +202,28 @@ __global__ __launch_bounds__(kEncThreads) void vis_encoder_bwd_kernel(VisBwdArgs
 #pragma unroll
         for (int k = 0; k < 4; ++k) gi[k] *= inv;
     }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int r = jl; r < R; r += jstep) {
         float gv[4];
         load4(Pb + (size_t)r * a.ldp + col + c4, q);
         load4(gb + ((size_t)off + r) * H + c4, gv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gv[k] = (q[k] + cc[k] > 0.f ? 1.f : a.slope) * (gv[k] + gi[k]);
+        for (int k = 0; k < 4; ++k) {
+            gv[k] = (q[k] + cc[k] > 0.f ? 1.f : a.slope) * (gv[k] + gi[k]);
+            acc[k] += stored<A>(gv[k]);
+        }
         store4(dPb + (size_t)r * a.ldp + col + c4, gv);
+    }
+    if (a.dC != nullptr) {   // no relation factor: this workgroup holds all R rows of its column block -> the per-image sum dC[b] here (fixed order)
+        red[threadIdx.x] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __syncthreads();
+        if (jl == 0) {
+            for (int k = 1; k < jstep; ++k) {
+                const float4 t = red[threadIdx.x + k * tpr];
+                acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+            }
+            store4((A*)a.dC + (size_t)b * a.ldp + col + c4, acc);
+        }
     }
 }
 
@@ -317,9 +333,14 @@ int vlg_vis_encoder_backward(const void* P, const void* C, const void* grad_mid,
     using namespace vlg;
     if (int rc = vis_check("vis_encoder_backward", B, R, H, V, ldp, dtype, col_box, col_rel, col_attr, off_box, off_rel, off_attr, off_img)) return rc;
     if (!P || !C || !grad_mid || !dP || !dC) return set_error(VLG_ERR_ARG, "vis_encoder_backward: null buffer");
-    const VisBwdArgs a{P, C, grad_mid, dP, R, H, V, ldp, col_box, col_rel, col_attr, off_box, off_rel, off_attr, off_img, slope};
+    const VisBwdArgs a{P, C, grad_mid, dP, off_rel >= 0 ? nullptr : dC, R, H, V, ldp, col_box, col_rel, col_attr, off_box, off_rel, off_attr, off_img, slope};
     const dim3 grid((off_rel >= 0 ? R : 0) + 1 + (off_attr >= 0 ? 1 : 0), B);
     hipStream_t s = (hipStream_t)stream;
+    if (off_rel < 0) {    // one launch: the per-image sums come out of the workgroups that hold whole images
+        if (dtype == VLG_F32) hipLaunchKernelGGL(vis_encoder_bwd_kernel<float>, grid, dim3(kEncThreads), 0, s, a);
+        else hipLaunchKernelGGL(vis_encoder_bwd_kernel<uint16_t>, grid, dim3(kEncThreads), 0, s, a);
+        return check_launch("vis_encoder_bwd_kernel");
+    }
     const int cols = H * (1 + (off_rel >= 0) + (off_attr >= 0));       // the encoders' column blocks are adjacent from col 0 (checked by the host mirror)
     const size_t n = (size_t)B * (cols >> 2);
     if (dtype == VLG_F32) {

@@ -301,8 +301,8 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         # ---- DependencyBoxRel.loss, joint.py:693-711 ----
         mt, sums = align.grounding_loss_factor_ce(txt, vis_feat, tmask, vmask, tmarg, num_token_f, vis2txt, pen, seg)
         mx = ts.DMV1o([md, ma], lengths).max                      # ldndmv.py:277-281: dep = -max.sum(); lang_feat_max_tree's Viterbi pass is reused
-        with torch.no_grad():                                     # alpha mt + (1 - alpha) dep, reduce_loss('token')
-            loss = torch.addcmul(c_mt * mt, mx.sum(), c_max)
+        with torch.no_grad():                                     # alpha mt + (1 - alpha) dep, reduce_loss('token'): c_mt mt + sum_b c_max max_b, two launches
+            loss = torch.addcmul(torch.dot(mx.view(-1), seed_max), c_mt, mt)
         grads = torch.autograd.grad([mt, mx], leaves, [c_mt, seed_max.view(mx.shape)])
         rng.advance()                                                 # the next step (or graph replay) draws new dropout masks at every site
         # intermediates for the parity tests, DETACHED: a reference to a previous step's autograd graph kept alive across a HIP-graph
