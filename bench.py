@@ -57,6 +57,9 @@ def parse_args(argv=None):
                     help="dp: the headline DMV1o inside+outside step (BASELINE.json metric); train_step: the chained "
                          "training-step hot path of configs[4], sharded data-parallel (vlgae_amd/bench/sharded_step.py)")
     ap.add_argument("--buckets", type=int, default=4, help="train_step: pieces the flat gradient is all-reduced in")
+    ap.add_argument("--step-mode", default="graph", choices=["graph", "eager"], dest="step_mode",
+                    help="train_step: replay the captured step as one HIP graph and enqueue the collectives behind it (default), or run it eagerly "
+                         "with the collectives launched from leaf hooks inside the backward pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-secondary", "--no-align", action="store_true", dest="no_secondary",
                     help="headline only: skip the secondary single-GPU measurements")

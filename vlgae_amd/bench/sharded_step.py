@@ -146,7 +146,7 @@ def _measure(args, rank, world, dev, dry, barrier):
             red.launch(gi)
     step.on_grad = on_grad
 
-    def run(comm):
+    def run_eager(comm):
         state["comm"] = comm
         for gi, gp in enumerate(groups):
             pending[gi] = len(gp)
@@ -154,6 +154,41 @@ def _measure(args, rank, world, dev, dry, barrier):
             red.wait()                                     # synchronous SGD: last step's reduced gradient before this step's first kernel
         step(None)
         assert not any(pending), pending                   # every parameter's gradient arrived through its hook
+
+    # step_mode "graph" (default on a GPU): forward + backward + the packing of every gradient into the flat buffer are captured ONCE as a
+    # HIP graph; a step is one replay, and the buckets' collectives are enqueued behind it.  Eager, the step is host-bound (~2.6 ms of
+    # Python / autograd enqueue for ~1.95 ms of device work at B = 256): ranks would run at the speed of their interpreters and drift
+    # apart between collectives.  What the graph form gives up is the overlap of a bucket's all-reduce with the adjoints still to run
+    # (the leaf-hook launches of the eager form); with ~26 MB per step over xGMI that is ~0.2 ms against the 0.6 ms the host costs.
+    mode = "eager" if dry else getattr(args, "step_mode", "graph")
+    graph = None
+    if mode == "graph":
+        state["comm"] = False
+        for gi, gp in enumerate(groups):
+            pending[gi] = len(gp)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                run_eager(False)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        for gi, gp in enumerate(groups):
+            pending[gi] = len(gp)
+        with torch.cuda.graph(graph):
+            step(None)
+            red.flat[check:check + 1].fill_(words_local)   # (the averaged slot of the previous step is overwritten every replay)
+        assert not any(pending), pending
+
+    def run(comm):
+        if graph is None:
+            return run_eager(comm)
+        if comm:
+            red.wait()                                     # synchronous SGD: last step's reduced gradient before this step's first kernel
+        graph.replay()
+        if comm:
+            for gi in range(len(groups)):                  # stream-ordered behind the replay; in readiness order
+                red.launch(gi)
 
     def timed(fn, tail=None):
         for _ in range(args.warmup):
@@ -207,8 +242,8 @@ def _measure(args, rank, world, dev, dry, barrier):
                        "overlap_frac": max(0.0, min(1.0, 1.0 - (step_ms - compute_ms) / ar_ms)) if ar_ms > 0 else None,
                        "mean_over_ranks_check": {"slot": got, "expected": want},
                        "semantics": "synchronous SGD, gradients AVERAGED over ranks (DDP): every bucket of step k is reduced "
-                                    "(stream-ordered) before step k+1's first kernel; a bucket starts from inside the backward pass "
-                                    "the moment the last of ITS parameters' gradients exists (leaf hooks)",
+                                    "(stream-ordered) before step k+1's first kernel; " + ("the buckets are enqueued behind the replayed step graph, in readiness order"
+                                    if mode == "graph" else "a bucket starts from inside the backward pass the moment the last of ITS parameters' gradients exists (leaf hooks)"),
                        "payload": f"{n_real} gradient floats, one per trainable parameter the step reaches (text encoder, visual encoder, "
                                   "vis_mlp_pre_matching, LayerNorm, word | child | parent encoders, arc encoder, parser feed-forwards and scorers), "
                                   f"in readiness order; + {n_model - n_real - 1} zeros for the shipped model's visual-encoder MLPs this factor "
@@ -216,7 +251,7 @@ def _measure(args, rank, world, dev, dry, barrier):
     else:
         el = el_compute
         step_ms = compute_ms = el * 1e3 / args.steps
-    res.update(value=B * world * args.steps / el, step_ms=step_ms, compute_ms=compute_ms,
+    res.update(value=B * world * args.steps / el, step_ms=step_ms, compute_ms=compute_ms, step_mode=mode,
                real_gradient_floats=n_real, allreduce_floats=n_model if world > 1 else 0)
     return res
 
@@ -237,7 +272,10 @@ def json_line(args, world, res, dry, share=False):
                       "global_batch": B * world, "seq_len": L,
                       "parallelism": (f"dp{world}" if world > 1 else "single") + (" (DEBUG: ranks share one GPU, gloo)" if share else ""),
                       "allreduce_floats": res["allreduce_floats"]},
-           "compute_ms": res["compute_ms"], "step_ms": res["step_ms"], "real_gradient_floats": res["real_gradient_floats"]}
+           "compute_ms": res["compute_ms"], "step_ms": res["step_ms"], "real_gradient_floats": res["real_gradient_floats"],
+           "step_mode": res.get("step_mode", "eager") + (": forward + backward + gradient packing replayed as ONE captured HIP graph, the buckets' collectives "
+                                                         "enqueued behind it" if res.get("step_mode") == "graph" else
+                                                         ": Python / autograd enqueue per step, a bucket's collective launched from a leaf hook inside the backward pass")}
     if "comm" in res:
         out["comm"] = res["comm"]
     if dry:

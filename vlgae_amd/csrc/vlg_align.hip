@@ -913,7 +913,13 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
 #pragma unroll
                 for (int kc = 0; kc < KCH; ++kc) bfr[ct][kc] = *reinterpret_cast<const bf16x8*>(tb + ct * 256 + foff[kc]);
             // ---- maxima over the regions: S^T, one query tile at a time ----
+            // (tools/time_argmax_ablation.sh: -DVLG_ABL_AM_NOST / _NOS drop one of the two products, _NOSEARCH the first-equal searches -- wrong
+            //  results, measured ceilings: DESIGN.md section 3.1a)
+#ifdef VLG_ABL_AM_NOST
+            if (false) {
+#else
             if (out_maxV) {   // (kernel-uniform)
+#endif
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 f32x4 st[3];   // rows = regions 16 ct + 4 g + n, column = query 16 rt + ccol
@@ -939,7 +945,11 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                                   am_max3(am_max3(st[1][2], st[1][3], st[2][0]), t3, t3));
                 m = am_xg_max(m);
                 unsigned vi = 0;
+#ifdef VLG_ABL_AM_NOSEARCH
+                if (false) {
+#else
                 if (ARGS) {
+#endif
                     vi = am_first_eq12<0, 1, 2, 3, 16, 17, 18, 19, 32, 33, 34, 35>(BIG, m, st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1],
                                                                                     st[1][2], st[1][3], st[2][0], st[2][1], st[2][2], st[2][3]);
                     vi = am_xg_min(vi + (unsigned)crow);
@@ -977,7 +987,11 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
             }
             }   // out_maxV
             // ---- maxima over the queries: S, one region tile at a time ----
+#ifdef VLG_ABL_AM_NOS
+            if (false) {
+#else
             if (HASQ) {
+#endif
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) {
                     f32x4 sq[RT];   // rows = queries 16 rt + 4 g + n, column = region 16 ct + ccol
@@ -1003,7 +1017,11 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                     m = am_xg_max(m);
                     // position code 4 rt + n (query 16 rt + 4 g + n; 80.. is no inline constant), later row tiles first
                     unsigned qi = 0;
+#ifdef VLG_ABL_AM_NOSEARCH
+                    if (false) {
+#else
                     if (ARGS) {
+#endif
                         unsigned qc = am_first_eq12<12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23>(BIG, m, sq[3][0], sq[3][1], sq[3][2], sq[3][3], sq[4][0],
                                                                                                      sq[4][1], sq[4][2], sq[4][3], sq[5][0], sq[5][1], sq[5][2], sq[5][3]);
                         qc = am_first_eq12<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11>(qc, m, sq[0][0], sq[0][1], sq[0][2], sq[0][3], sq[1][0], sq[1][1], sq[1][2],
