@@ -839,6 +839,24 @@ def test_attn_fuse_large_v(oracle_mod):
     assert np.abs(out.detach().cpu().numpy() - ref_out).max() <= 1e-4
     out2 = align.attention_fuse(t(vis), t(txt), t(mid), t(enc), t(gm), t(bt), 1e-5)
     assert np.abs(out2.cpu().numpy() - ref_out).max() <= 1e-4
+    # round 5: above align.WIDE_KEYS keys the differentiable call runs as batched library GEMMs (float32) + torch's softmax / LayerNorm;
+    # value and all six gradients against the fused kernels on the same inputs (forced by lifting the threshold)
+    leaves = [t(a).requires_grad_(True) for a in (vis, txt, mid, enc, gm, bt)]
+    cot = t(rng.standard_normal((B, L, h)).astype(np.float32))
+    wide = align.attention_fuse(*leaves, 1e-5)
+    assert wide.grad_fn is not None and "AttnFuse" not in type(wide.grad_fn).__name__
+    g_wide = torch.autograd.grad(wide, leaves, cot)
+    keep = align.WIDE_KEYS
+    try:
+        align.WIDE_KEYS = 1 << 30
+        fused = align.attention_fuse(*leaves, 1e-5)
+        assert "AttnFuse" in type(fused.grad_fn).__name__
+        g_fused = torch.autograd.grad(fused, leaves, cot)
+    finally:
+        align.WIDE_KEYS = keep
+    assert float((wide - fused).abs().max()) <= 1e-4 and float((wide.detach().cpu() - torch.from_numpy(ref_out)).abs().max()) <= 1e-4
+    for name, a, b in zip(("vis", "txt", "vis_mid", "enc_x", "ln_w", "ln_b"), g_wide, g_fused):
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), name
     # a mid-sized V: four region chunks in the matrix-core kernel, ragged last chunk, three word tiles
     B, L, V = 3, 47, 203
     vis, txt = rng.standard_normal((B, V, d)).astype(np.float32) * 0.3, rng.standard_normal((B, L + 1, d)).astype(np.float32) * 0.3

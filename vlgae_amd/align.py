@@ -195,6 +195,9 @@ def _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, want_att
     return out, att
 
 
+WIDE_KEYS = 256   # above this many keys per image the attention fuse runs as batched library GEMMs (see attention_fuse)
+
+
 class _AttnFuse(torch.autograd.Function):
     """joint.py:670-674 with gradients to the four feature tensors and the LayerNorm parameters (the fuse sits in
     DependencyBoxRel._forward, so the parser's loss back-propagates through it).  The adjoint recomputes the forward
@@ -241,7 +244,8 @@ def attention_fuse(vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps=1
 
     vis_feat [B,V,d], txt_feat [B,L+1,d] (root slot first), vis_mid [B,V,h], enc_x [B,L,h]; LayerNorm
     parameters [h].  Returns float32 [B,L,h]; differentiable in all six tensors (the adjoint kernels need d and h
-    to be multiples of 16 and <= 256).  `return_attmap=True` also returns attmap [B,L,V] (inspection; no autograd)."""
+    to be multiples of 16 and <= 256).  `return_attmap=True` also returns attmap [B,L,V] (inspection; no autograd).
+    V <= WIDE_KEYS: the fused matrix-core kernels (vlg_attn.hip); above: batched library GEMMs (see the branch below)."""
     vis_feat, txt_feat, vis_mid, enc_x = (_plain(t) for t in (vis_feat, txt_feat, vis_mid, enc_x))
     _C.require_gpu(vis_feat, "attention_fuse")
     B, V, d = vis_feat.shape
@@ -251,6 +255,16 @@ def attention_fuse(vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps=1
         raise ValueError(f"attention_fuse: vis {tuple(vis_feat.shape)} txt {tuple(txt_feat.shape)} "
                          f"vis_mid {tuple(vis_mid.shape)} enc_x {tuple(enc_x.shape)}")
     tensors = (vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias)
+    if V > WIDE_KEYS and not return_attmap:
+        # Many keys (the shipped factor layout: 36 + 36^2 + 36 + 1 = 1369 columns per image).  The fused kernels are built for the tens of
+        # regions of an object-only layout -- one wavefront owns 16 words and walks ALL keys, B x ceil(L / 16) wavefronts in total: at
+        # B = 64, V = 1369 that is 192 wavefronts on a 1024-SIMD chip (measured: forward 271 us, adjoint 954 + 61 us of a 3.64 ms step).
+        # Here the two contractions are what the library is good at -- batched [L, d] x [d, V] and [L, V] x [V, h] GEMMs in float32, as
+        # the reference's einsums are -- with torch's softmax / LayerNorm between them and torch's autograd behind them: ~0.25 ms.
+        f32 = torch.float32
+        s = torch.bmm(txt_feat[:, 1:].to(f32), vis_feat.to(f32).transpose(1, 2))             # joint.py:670-672 (no region masking there)
+        x = torch.bmm(torch.softmax(s, -1), vis_mid.to(f32))                                  # :673
+        return torch.nn.functional.layer_norm(enc_x.to(f32) + x, (h,), ln_weight.to(f32), ln_bias.to(f32), float(eps))   # :674
     if not return_attmap and torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
         return _AttnFuse.apply(*tensors, float(eps))
     dt, vis_c = _C.in_dtype(vis_feat)

@@ -1050,80 +1050,110 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
 }
 
 // The diagonal pairs (a == b) again, with the POS prior pen[b,q,seg(v)] subtracted before the maxima (joint.py:466-469): B
-// pairs of 65 536, one wavefront each, no attempt at speed -- the scores go to LDS and one lane scans a row / a column in
-// order (first position on ties, by construction).  Runs after align_argmax_kernel on the same stream and overwrites its
-// outputs for these pairs.
-__global__ __launch_bounds__(64) void align_prior_diag_kernel(
+// pairs of 65 536 -- the scores go to LDS and one lane scans a row / a column in order (first position on ties, by construction).
+// Runs after align_argmax_kernel on the same stream and overwrites its outputs for these pairs.
+// NW wavefronts per pair (round 5): wavefront w takes the region groups w, w + NW, ... of the image, each into its own LDS score
+// tile; a region belongs to one group, so the maxima over the queries are final per group, while every wavefront carries its own
+// running maxima over the regions and the NW of them meet at the end (larger value, then SMALLER region: the first position).  With one
+// wavefront the shipped factor layout's 29 groups of 48 columns were walked serially by 64 wavefronts on the whole chip: 404 us.
+constexpr int kPdP = 49, kPdRT = 6;
+__global__ __launch_bounds__(256) void align_prior_diag_kernel(
     const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
     const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_maxV,
     float* __restrict__ out_maxQ, AlignArgs xa) {
-    constexpr int d = 128, KCH = 4, RT = 6, P = 49;
-    __shared__ float S[RT * 16 * P];
-    __shared__ uint8_t kq_s[RT * 16], kv_s[48];
-    const int b = blockIdx.x, a = b, lane = threadIdx.x, g = lane >> 4, ccol = lane & 15, crow = g * 4;
+    constexpr int d = 128, KCH = 4, RT = kPdRT, P = kPdP;
+    extern __shared__ __attribute__((aligned(16))) float pd_smem[];   // [NW][RT 16 P] score tiles, then [NW][128] (max, position) pairs
+    __shared__ uint8_t kq_s[RT * 16], kv_s[4][48];
+    const int NW = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    float* S = pd_smem + (size_t)wave * RT * 16 * P;
+    float* mrg_m = pd_smem + (size_t)NW * RT * 16 * P;                 // [NW][128]
+    int* mrg_i = reinterpret_cast<int*>(mrg_m + NW * 128);
+    const int b = blockIdx.x, a = b, lane = threadIdx.x & 63, g = lane >> 4, ccol = lane & 15, crow = g * 4;
     if (a >= A) return;
     const float ninf = neg_infinity();
     const float* pen_b = xa.pen + (size_t)b * Q * xa.n_seg;
+    const int NG = (V + 47) / 48, n_it = (NG + NW - 1) / NW;           // every wavefront runs n_it rounds (the barriers are workgroup-wide)
     for (int q0 = 0; q0 < Q; q0 += RT * 16) {
-        for (int i = lane; i < RT * 16; i += 64) kq_s[i] = tmask ? (uint8_t)(tmask[(size_t)b * Q + min(q0 + i, Q - 1)] != 0) : (uint8_t)1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < RT * 16; i += blockDim.x) kq_s[i] = tmask ? (uint8_t)(tmask[(size_t)b * Q + min(q0 + i, Q - 1)] != 0) : (uint8_t)1;
         const int nq = min(RT * 16, Q - q0);
-        float m_run[2] = {ninf, ninf};   // maxima over the regions of queries lane, lane + 64: carried across the region groups
+        float m_run[2] = {ninf, ninf};   // maxima over the regions of queries lane, lane + 64: carried across this wavefront's region groups
         int vi_run[2] = {0, 0};
-        for (int v0 = 0; v0 < V; v0 += 48) {
-            if (lane < 48) kv_s[lane] = vmask ? (uint8_t)(vmask[(size_t)a * V + min(v0 + lane, V - 1)] != 0) : (uint8_t)1;
+        for (int it = 0; it < n_it; ++it) {
+            const int grp = it * NW + wave, v0 = grp * 48;
+            const bool on = grp < NG;                                   // (wave-uniform)
+            if (on && lane < 48) kv_s[wave][lane] = vmask ? (uint8_t)(vmask[(size_t)a * V + min(v0 + lane, V - 1)] != 0) : (uint8_t)1;
             __syncthreads();
+            if (on) {
 #pragma unroll 1
-            for (int rt = 0; rt < RT; ++rt)
+                for (int rt = 0; rt < RT; ++rt)
 #pragma unroll 1
-                for (int ct = 0; ct < 3; ++ct) {
-                    const bf16x8* ap = reinterpret_cast<const bf16x8*>(txt + ((size_t)b * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
-                    const int v = min(v0 + ct * 16 + ccol, V - 1);
-                    const bf16x8* bp = reinterpret_cast<const bf16x8*>(vis + ((size_t)a * V + v) * d + g * 8);
-                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int ct = 0; ct < 3; ++ct) {
+                        const bf16x8* ap = reinterpret_cast<const bf16x8*>(txt + ((size_t)b * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
+                        const int v = min(v0 + ct * 16 + ccol, V - 1);
+                        const bf16x8* bp = reinterpret_cast<const bf16x8*>(vis + ((size_t)a * V + v) * d + g * 8);
+                        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[kc * 4], bp[kc * 4], acc, 0, 0, 0);
-                    const unsigned vk = kv_s[ct * 16 + ccol];
-                    const float* pen_v = pen_b + xa.seg_of_v[v];
+                        for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[kc * 4], bp[kc * 4], acc, 0, 0, 0);
+                        const unsigned vk = kv_s[wave][ct * 16 + ccol];
+                        const float* pen_v = pen_b + xa.seg_of_v[v];
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        const int q = min(q0 + rt * 16 + crow + n, Q - 1);
-                        const bool keep = (vk & kq_s[rt * 16 + crow + n]) != 0;
-                        S[(rt * 16 + crow + n) * P + ct * 16 + ccol] = (keep ? acc[n] : neg_inf) - pen_v[(size_t)q * xa.n_seg];
-                    }
-                }
-            __syncthreads();
-            const int nv = min(48, V - v0);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int q = lane + 64 * h;
-                if (q < nq)
-                    for (int v = 0; v < nv; ++v) {
-                        const float x = S[q * P + v];
-                        if (x > m_run[h]) { m_run[h] = x; vi_run[h] = v0 + v; }
+                        for (int n = 0; n < 4; ++n) {
+                            const int q = min(q0 + rt * 16 + crow + n, Q - 1);
+                            const bool keep = (vk & kq_s[rt * 16 + crow + n]) != 0;
+                            S[(rt * 16 + crow + n) * P + ct * 16 + ccol] = (keep ? acc[n] : neg_inf) - pen_v[(size_t)q * xa.n_seg];
+                        }
                     }
             }
-            if (out_maxQ && lane < nv) {
-                const size_t at = ((size_t)b * A + a) * V + v0 + lane;
-                float m = q0 == 0 ? ninf : out_maxQ[at];
-                int qi = q0 == 0 ? 0 : (int)xa.argQ[at];
-                for (int q = 0; q < nq; ++q) {
-                    const float x = S[q * P + lane];
-                    if (x > m) { m = x; qi = q0 + q; }
-                }
-                out_maxQ[at] = m;
-                xa.argQ[at] = (uint16_t)qi;
-            }
             __syncthreads();
+            if (on) {
+                const int nv = min(48, V - v0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = lane + 64 * h;
+                    if (q < nq)
+                        for (int v = 0; v < nv; ++v) {
+                            const float x = S[q * P + v];
+                            if (x > m_run[h]) { m_run[h] = x; vi_run[h] = v0 + v; }   // ascending groups within a wavefront: strict keeps the first
+                        }
+                }
+                if (out_maxQ && lane < nv) {
+                    const size_t at = ((size_t)b * A + a) * V + v0 + lane;
+                    float m = q0 == 0 ? ninf : out_maxQ[at];
+                    int qi = q0 == 0 ? 0 : (int)xa.argQ[at];
+                    for (int q = 0; q < nq; ++q) {
+                        const float x = S[q * P + lane];
+                        if (x > m) { m = x; qi = q0 + q; }
+                    }
+                    out_maxQ[at] = m;
+                    xa.argQ[at] = (uint16_t)qi;
+                }
+            }
         }
-        if (out_maxV)
+        if (out_maxV) {   // the NW running maxima of a query meet: larger value, then the smaller region (= the first position in order)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int q = lane + 64 * h;
-                if (q < nq) {
-                    out_maxV[((size_t)b * A + a) * Q + q0 + q] = m_run[h];
-                    xa.argV[((size_t)b * A + a) * Q + q0 + q] = (uint16_t)vi_run[h];
-                }
+                mrg_m[wave * 128 + lane + 64 * h] = m_run[h];
+                mrg_i[wave * 128 + lane + 64 * h] = vi_run[h];
             }
+            __syncthreads();
+            if (wave == 0)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = lane + 64 * h;
+                    if (q < nq) {
+                        float m = m_run[h];
+                        int vi = vi_run[h];
+                        for (int w = 1; w < NW; ++w) {
+                            const float x = mrg_m[w * 128 + q];
+                            const int xi = mrg_i[w * 128 + q];
+                            if (x > m || (x == m && xi < vi)) { m = x; vi = xi; }
+                        }
+                        out_maxV[((size_t)b * A + a) * Q + q0 + q] = m;
+                        xa.argV[((size_t)b * A + a) * Q + q0 + q] = (uint16_t)vi;
+                    }
+                }
+        }
     }
 }
 
@@ -1309,7 +1339,11 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
 #undef VLG_AAM
             if (xa.pen) {
                 if (int rc = check_launch("align_argmax_kernel")) return rc;
-                hipLaunchKernelGGL(align_prior_diag_kernel, dim3(std::min(A, B)), dim3(64), 0, s, (const uint16_t*)txt, (const uint16_t*)vis,
+                const int pd_nw = ng >= 4 ? 4 : 1;   // wavefronts per diagonal pair: the region groups of a many-column image are dealt round
+                const size_t pd_lds = sizeof(float) * ((size_t)pd_nw * kPdRT * 16 * kPdP + (size_t)pd_nw * 256);
+                hipError_t pe = hipFuncSetAttribute(reinterpret_cast<const void*>(align_prior_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds);
+                if (pe != hipSuccess) return set_error((int)pe, "hipFuncSetAttribute: %s", hipGetErrorString(pe));
+                hipLaunchKernelGGL(align_prior_diag_kernel, dim3(std::min(A, B)), dim3(64 * pd_nw), pd_lds, s, (const uint16_t*)txt, (const uint16_t*)vis,
                                    tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, xa);
                 return check_launch("align_prior_diag_kernel");
             }
