@@ -267,7 +267,7 @@ int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* 
 /* Weight / bias gradient of an nn.Linear over all token rows -- `MLP.linear` (src/model/nn/common.py:30,47-51) under
  * loss.backward(), i.e. the word / child / parent encoders of src/model/joint.py:270-277 and `vis_mlp_pre_matching`
  * (joint.py:136-138,175):   d_weight[M(out), N(in)] = dy^T x,   d_bias[M] = sum_rows dy.
- *   dy [K, ld_dy] (first M columns used), x [K, ld_x] (first N columns used): bf16, row-major, K = B*N token rows;
+ *   dy [K, ld_dy] (first M columns used), x [K, ld_x] (first N columns used): `in_dtype`, row-major, K = B*N token rows;
  *   M and N multiples of 8 (64 x 64 output tiles, partial at the edges), row strides multiples of 8 elements, dy / x / ws 16-byte aligned.
  *   d_weight [M, N] with rows ld_dw >= N elements apart (round 5: a column block of a wider gradient tensor -- the [H, n] halves of the
  *   visual encoder's [H, 2n] weights, box_rel.py:21-27 -- is written in place), d_bias [M] or NULL, x_colsum [N] or NULL in out_dtype (VLG_F32, or VLG_BF16 = the parameter's storage type: no cast
@@ -275,9 +275,12 @@ int vlg_box_rel_pairwise_backward(const void* y, const float* bias, const void* 
  *   are swapped: a weight stored [in, out] as in `matmul(child + parent, arc_encoder_w2) + arc_encoder_b`, joint.py:285-286,
  *   takes dy := the layer input and x := the cotangent).  ws: vlg_linear_wgrad_workspace(K, M, N) bytes (0 = unsupported shape).
  * Split over the token rows across the whole chip (bf16 MFMA, fp32 accumulate); partial tiles are added in a fixed
- * order: bit-reproducible, no atomics. */
+ * order: bit-reproducible, no atomics.
+ *   in_dtype (round 5): VLG_BF16 as above, or VLG_F32 (the reference's `precision: 32`, config/trainer/train.yaml:20): dy and x are float32
+ *   and every product a b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16 matrix cores (hi = bf16(v), lo = bf16(v - hi), split
+ *   between the staging registers and LDS): relative error <= ~2^-16 per product before the fp32 accumulation, operands read once. */
 size_t vlg_linear_wgrad_workspace(int K, int M, int N);
-int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
+int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, int in_dtype, void* ws, size_t ws_bytes, int out_dtype,
                      void* d_weight, int ld_dw, void* d_bias, void* x_colsum, void* stream);
 /* The same in two steps, for a caller that issues SEVERAL weight gradients and needs none of them before its end (the parser's feed-forwards,
  * src/model/ldndmv.py:174-183 under loss.backward(): seven products): vlg_linear_wgrad_partial is the split-K launch alone (the partial tiles stay
@@ -287,9 +290,10 @@ typedef struct VlgWgradReduce {
     const void* ws;                      /* the workspace vlg_linear_wgrad_partial filled for (K, M, N) */
     void *d_weight, *d_bias, *x_colsum;  /* as in vlg_linear_wgrad (d_bias / x_colsum NULL when not carried) */
     int K, M, N, ld_dw, out_dtype;
+    int in_dtype;                        /* the operand type the partial launch was given (it decides the split plan) */
 } VlgWgradReduce;
-int vlg_linear_wgrad_partial(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int want_bias,
-                             int want_x_colsum, void* stream);
+int vlg_linear_wgrad_partial(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, int in_dtype, void* ws, size_t ws_bytes,
+                             int want_bias, int want_x_colsum, void* stream);
 int vlg_linear_wgrad_reduce_group(const VlgWgradReduce* items, int count, void* stream);
 
 /* The two TRAINABLE encoders between the frozen features and the structured step (round 5; BASELINE.json configs[4]) -- what
@@ -515,7 +519,7 @@ int vlg_selftest_xlane(int* scratch, void* stream);
 /* Thread-local message for the last non-zero return on this thread ("" if none). */
 const char* vlg_last_error(void);
 
-/* Library / ABI version, e.g. 140 = 0.1.4.0 (round 5: vlg_dropout, vlg_rng_advance, vlg_vis_encoder(_backward) added, vlg_linear_wgrad takes ld_dw;
+/* Library / ABI version, e.g. 141 = 0.1.4.1 (round 5: vlg_dropout, vlg_rng_advance, vlg_vis_encoder(_backward) added, vlg_linear_wgrad takes ld_dw and in_dtype;
  * the Python binding refuses a library whose version differs from the one it was written against; round 4: vlg_langfeat_* take the activations' storage type and the SharedDropout masks,
  * vlg_langfeat_rowscale, vlg_ff_* added, vlg_ndmv_potentials* take row strides and the gradients' storage type; round 3, 120: vlg_linear_wgrad, vlg_langfeat_*, vlg_ndmv_potentials*, vlg_dmv1o_viterbi added;
  * round 2, 110: vlg_bilinear_align_backward takes a workspace; vlg_scale_counts, vlg_feed_* added). */

@@ -213,7 +213,7 @@ def test_round4_entry_points_validate_on_the_host(lib):
     sc = lib.vlg_ndmv_potentials
     assert sc(one, 8, one, 16, one, 16, one, 16, one, one, None, 2, 5, 7, 16, 0, ctypes.c_float(-1e20), 0, one, one, None) == 0x1001
     assert b"row strides" in lib.vlg_last_error()
-    assert lib.vlg_linear_wgrad(one, 64, one, 64, 4096, 64, 64, one, 1 << 30, 9, one, 64, one, None, None) == 0x1002
+    assert lib.vlg_linear_wgrad(one, 64, one, 64, 4096, 64, 64, 1, one, 1 << 30, 9, one, 64, one, None, None) == 0x1002
     sg = lambda **kw: lib.vlg_small_gemm(kw.get("a", one), 0, 16, 1, one, 0, 8, 1, kw.get("c", one), 0, kw.get("ldc", 8), None, 0, kw.get("u", None), 0, None, 0,
                                          kw.get("batch", 1), kw.get("M", 4), 8, 16, ctypes.c_float(1.0), 0, kw.get("dt", 1), 1, None)
     assert sg(M=0) == 0x1001 and sg(ldc=4) == 0x1001 and sg(dt=5) == 0x1002 and sg(a=None) == 0x1003 and sg(batch=0) == 0

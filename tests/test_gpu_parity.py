@@ -1653,6 +1653,35 @@ def test_linear_wgrad_partial_tiles():
         assert torch.equal(wide[:, 16:16 + N], dw.to(torch.bfloat16)) and float(wide[:, :16].abs().max()) == 0 and float(wide[:, 16 + N:].abs().max()) == 0
 
 
+def test_linear_wgrad_float32_operands():
+    """vlg_linear_wgrad with float32 operands (the reference's `precision: 32`): three bf16 products per pair on hi / lo parts split on the way
+    into LDS.  Against float64: the error is that of the dropped lo x lo term and the split residues (~2^-16 relative per PRODUCT, random in
+    sign over the K rows), i.e. a few 1e-6 of the largest entry -- the bound here is 2e-5 of it; bias / column sums (hi + lo against ones)
+    likewise; bit-reproducible; both tile shapes, partial tiles, strided operands, in-place column blocks."""
+    from vlgae_amd import align
+    gen = torch.Generator().manual_seed(12)
+    for K, M, N, ldy, ldx in ((10496, 384, 256, 384, 256), (9216, 256, 2048, 256, 2048), (10240, 256, 800, 256, 800), (4100, 24, 72, 40, 88), (2048, 8, 8, 8, 8),
+                              (256, 256, 512, 256, 512)):
+        dy_full = (torch.randn(K, ldy, generator=gen) * torch.rand(K, 1, generator=gen) * 1e-3).to(dev())     # cotangent-sized values
+        x_full = torch.randn(K, ldx, generator=gen).to(dev())
+        dy, x = dy_full[:, :M], x_full[:, :N]
+        dw, db = align.linear_wgrad(dy, x)
+        dw2, db2 = align.linear_wgrad(dy, x)
+        assert dw.dtype == torch.float32 and torch.equal(dw, dw2) and torch.equal(db, db2)
+        rw, rb = dy.double().t() @ x.double(), dy.double().sum(0)
+        assert float((dw.double() - rw).abs().max()) <= 2e-5 * float(rw.abs().max()), (K, M, N, float((dw.double() - rw).abs().max()) / float(rw.abs().max()))
+        assert float((db.double() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-9, (K, M, N)
+        _, xs = align.linear_wgrad(dy, x, want_x_colsum=True)
+        assert float((xs.double() - x.double().sum(0)).abs().max()) <= 2e-5 * float(x.double().sum(0).abs().max()) + 1e-6, (K, M, N)
+        wide = torch.zeros(M, N + 40, device=dev())
+        wg = align.WgradGroup()
+        align.linear_wgrad(dy, x, want_bias=False, out=(wide[:, 16:16 + N], None), defer=wg)
+        wg.flush()
+        assert torch.equal(wide[:, 16:16 + N], dw) and float(wide[:, :16].abs().max()) == 0 and float(wide[:, 16 + N:].abs().max()) == 0
+    with pytest.raises(ValueError):
+        align.linear_wgrad(dy, x.bfloat16())
+
+
 def _reference_step_in_torch(step, P64, token, tag, vmask, drop, alpha, pen_args):
     """The reference's lines for one training step (the order and the formulas of make_golden.trainstep_cases' calls: joint.py:658-711,
     ldndmv.py:171-216,277-281, fn.py:50-56) as float64 torch ops on the step's own leaves -- an independent formulation of everything

@@ -27,3 +27,12 @@ for K, M, N in ((40960, 256, 256), (40960, 512, 256), (10496, 384, 256), (41000,
     t_k = ev(lambda: align.linear_wgrad(dy, x, out_dtype=torch.bfloat16))
     t_l = ev(lambda: torch.mm(dy.t(), x))
     print(f"K={K} M={M} N={N}: split-K (+bias) {t_k:.1f} us, library {t_l:.1f} us; {2*K*M*N/1e9:.1f} GFLOP")
+
+# float32 operands (three bf16 products per pair) against the library's fp32 GEMM
+for K, M, N in ((9216, 256, 2048), (10240, 256, 800), (40960, 256, 256), (40960, 512, 256), (10496, 384, 256), (10496, 128, 128), (41000, 32, 256), (256, 256, 2048)):
+    dy = torch.randn(K, M, device=dev) * 1e-3; x = torch.randn(K, N, device=dev)
+    t_k = ev(lambda: align.linear_wgrad(dy, x))
+    t_l = ev(lambda: (torch.mm(dy.t(), x), dy.sum(0)))
+    ref = dy.double().t() @ x.double()
+    e1 = float((align.linear_wgrad(dy, x)[0].double() - ref).abs().max() / ref.abs().max()); e2 = float((torch.mm(dy.t(), x).double() - ref).abs().max() / ref.abs().max())
+    print(f"f32 K={K} M={M} N={N}: split-K x3 (+bias) {t_k:.1f} us (err {e1:.1e}), library fp32 {t_l:.1f} us (err {e2:.1e})")

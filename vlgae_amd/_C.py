@@ -26,7 +26,7 @@ class SmallGemm(ctypes.Structure):
 
 class WgradReduce(ctypes.Structure):
     """VlgWgradReduce of include/vlgae_amd.h: one deferred split-K reduction of vlg_linear_wgrad_reduce_group."""
-    _fields_ = [(n, ctypes.c_void_p) for n in ("ws", "d_weight", "d_bias", "x_colsum")] + [(n, ctypes.c_int) for n in ("K", "M", "N", "ld_dw", "out_dtype")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("ws", "d_weight", "d_bias", "x_colsum")] + [(n, ctypes.c_int) for n in ("K", "M", "N", "ld_dw", "out_dtype", "in_dtype")]
 
 
 # symbol -> (restype, argtypes); one entry per declaration in include/vlgae_amd.h
@@ -69,12 +69,12 @@ SIGNATURES = {
     "vlg_box_rel_pairwise_backward_workspace": (_sz, [_i, _i, _i]),
     "vlg_box_rel_pairwise_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "vlg_linear_wgrad_workspace": (_sz, [_i, _i, _i]),
-    "vlg_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _i, _vp, _i, _vp, _vp, _vp]),
+    "vlg_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp, _i, _vp, _vp, _vp]),
     "vlg_dropout": (_i, [_vp, _vp, _i, _vp, ctypes.c_uint, _f, _vp, _vp, _ll, _i, _i, _i, _vp]),
     "vlg_rng_advance": (_i, [_vp, _vp]),
     "vlg_vis_encoder": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "vlg_vis_encoder_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
-    "vlg_linear_wgrad_partial": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _i, _i, _vp]),
+    "vlg_linear_wgrad_partial": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _i, _vp]),
     "vlg_linear_wgrad_reduce_group": (_i, [_vp, _i, _vp]),
     "vlg_langfeat_root_cat": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_langfeat_root_cat_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -109,7 +109,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 140   # what include/vlgae_amd.h declares at this revision; lib() refuses any other library (argument lists differ between versions)
+ABI_VERSION = 141   # what include/vlgae_amd.h declares at this revision; lib() refuses any other library (argument lists differ between versions)
 
 
 def lib():

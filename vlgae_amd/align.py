@@ -564,7 +564,7 @@ class WgradGroup:
             return
         arr = (_C.WgradReduce * n)()
         for rec, vals in zip(arr, self.items):
-            rec.ws, rec.d_weight, rec.d_bias, rec.x_colsum, rec.K, rec.M, rec.N, rec.ld_dw, rec.out_dtype = vals
+            rec.ws, rec.d_weight, rec.d_bias, rec.x_colsum, rec.K, rec.M, rec.N, rec.ld_dw, rec.out_dtype, rec.in_dtype = vals
         _C.check(_C.lib().vlg_linear_wgrad_reduce_group(arr, n, _C.stream_of(self.first)), "linear_wgrad_reduce_group")
         self.items, self.keep, self.first = [], [], None
 
@@ -575,14 +575,17 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None, out_dtype
     cotangent as x).  out = (d_weight, second) writes into caller-owned tensors (both of one type); out_dtype (float32 / bfloat16):
     the type of the results when `out` is not given -- the parameter's own, so that no cast launch follows the reduction.
 
-    dy [K, out], x [K, in]: bf16, row-major (row strides that are multiples of 8 elements are taken in place -- column
+    dy [K, out], x [K, in]: both bf16 or both float32, row-major (row strides that are multiples of 8 elements are taken in place -- column
     slices of wider buffers), out and in multiples of 8 (64 x 64 output tiles; the last tile of either side may be partial).  Split over the rows across the whole chip, fixed summation
-    order (vlg_linear_wgrad); other shapes / dtypes raise -- callers decide (see `_Linear.backward`).  defer: a WgradGroup (see there)."""
+    order (vlg_linear_wgrad); other shapes / dtypes raise -- callers decide (see `_Linear.backward`).  defer: a WgradGroup (see there).
+    float32 operands (the reference's `precision: 32`) run on the bf16 matrix cores as three products per pair, a_hi b_hi + a_hi b_lo + a_lo b_hi
+    (hi = bf16(v), lo = bf16(v - hi)): <= ~2^-16 relative per product before the fp32 accumulation."""
     _C.require_gpu(dy, "linear_wgrad")
     K, M = dy.shape
     N = x.shape[1]
-    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or x.shape[0] != K:
-        raise ValueError(f"linear_wgrad: bf16 [K,out] / [K,in] expected, got {dy.dtype} {tuple(dy.shape)} / {x.dtype} {tuple(x.shape)}")
+    if dy.dtype != x.dtype or dy.dtype not in (torch.bfloat16, torch.float32) or x.shape[0] != K:
+        raise ValueError(f"linear_wgrad: [K,out] / [K,in] of one type (bf16 or float32) expected, got {dy.dtype} {tuple(dy.shape)} / {x.dtype} {tuple(x.shape)}")
+    idt = _C.BF16 if dy.dtype == torch.bfloat16 else _C.F32
     if dy.stride(1) != 1 or dy.stride(0) % 8 or dy.data_ptr() % 16:
         dy = dy.contiguous()
     if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
@@ -609,16 +612,16 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None, out_dtype
                          f"block of a wider gradient is fine), got {dw.dtype} {tuple(dw.shape)} {dw.stride()} / {None if db is None else db.dtype}")
     odt = _C.BF16 if out_dtype == torch.bfloat16 else _C.F32
     if defer is not None:   # the split-K launch alone; the reduction joins the group's single launch
-        _C.check(_C.lib().vlg_linear_wgrad_partial(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, _C.ptr(ws), nbytes,
+        _C.check(_C.lib().vlg_linear_wgrad_partial(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, idt, _C.ptr(ws), nbytes,
                                                    int(db is not None and not want_x_colsum), int(db is not None and want_x_colsum), _C.stream_of(dy)),
                  "linear_wgrad_partial")
         dpt = lambda t: None if t is None else t.data_ptr()
-        defer.items.append((ws.data_ptr(), dw.data_ptr(), None if want_x_colsum else dpt(db), dpt(db) if want_x_colsum else None, K, M, N, dw.stride(0), odt))
+        defer.items.append((ws.data_ptr(), dw.data_ptr(), None if want_x_colsum else dpt(db), dpt(db) if want_x_colsum else None, K, M, N, dw.stride(0), odt, idt))
         defer.keep.append((ws, dw, db))
         if defer.first is None:
             defer.first = dy
         return dw, db
-    _C.check(_C.lib().vlg_linear_wgrad(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, _C.ptr(ws), nbytes, odt,
+    _C.check(_C.lib().vlg_linear_wgrad(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, idt, _C.ptr(ws), nbytes, odt,
                                        _C.ptr(dw), dw.stride(0), None if want_x_colsum else _C.ptr(db), _C.ptr(db) if want_x_colsum else None,
                                        _C.stream_of(dy)), "linear_wgrad")
     return dw, db
@@ -709,7 +712,7 @@ class SmallMatmulGroup:
 
 
 def _wgrad_ok(K, M, N, dtype):
-    return dtype == torch.bfloat16 and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8 and K >= 2048
+    return dtype in (torch.bfloat16, torch.float32) and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8 and K >= 2048
 
 
 class _Linear(torch.autograd.Function):

@@ -186,6 +186,172 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const uint16_t
     }
 }
 
+// ---- float32 operands on the bf16 matrix cores (round 5: the reference's `precision: 32`, config/trainer/train.yaml:20) -----------------
+// x = hi + lo + e with hi = bf16(x), lo = bf16(x - hi) (both round-to-nearest: v_cvt_pk_bf16_f32), |e| <= 2^-17 |x|: the product
+// a b = a_hi b_hi + a_hi b_lo + a_lo b_hi + O(2^-16 |a b|) is three bf16 MFMAs into the same fp32 accumulator -- against the library's
+// fp32 GEMM (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 rate, and 4 output tiles on 256 CUs for these shapes).  The split happens between
+// the staging registers and LDS (four LDS images: hi / lo of both operands), so the operands are read once, as float32.  Same split-K
+// plan, same block order and the same partial-tile layout as gemm_tn_kernel: the reductions are shared.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f32x2_t v = {a, b};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
+}
+__device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, uint4& hi, uint4& lo) {
+    split_pair(u[0], u[1], hi.x, lo.x);
+    split_pair(u[2], u[3], hi.y, lo.y);
+    split_pair(v[0], v[1], hi.z, lo.z);
+    split_pair(v[2], v[3], hi.w, lo.w);
+}
+
+template <int TILE, int KSTAGE, bool CS, bool CSB>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                                int K, int M, int N, int KC, int S, float* __restrict__ part,
+                                                                float* __restrict__ part_cs, float* __restrict__ part_csb) {
+    using C = TnCfg<TILE, KSTAGE>;
+    constexpr int kTile = C::kTile, kStage = C::kStage, kPitch = C::kPitch, kQ = C::kQ, kF = C::kF, kP = C::kPasses, kRP = C::kRowsPerPass;
+    __shared__ __attribute__((aligned(16))) char sAh[kStage * kPitch];
+    __shared__ __attribute__((aligned(16))) char sAl[kStage * kPitch];
+    __shared__ __attribute__((aligned(16))) char sBh[kStage * kPitch];
+    __shared__ __attribute__((aligned(16))) char sBl[kStage * kPitch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int MT = (M + kTile - 1) / kTile;
+    const int tiles = MT * ((N + kTile - 1) / kTile);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;       // (block order: see gemm_tn_kernel)
+    const int s = (j / tiles) * 8 + xcd, tile = j % tiles;
+    if (s >= S) return;
+    const int mt = tile % MT, nt = tile / MT;
+    const int m0 = mt * kTile, n0 = nt * kTile;
+    const int k_begin = s * KC, k_end = min(K, k_begin + KC);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    const int c16 = tid % C::kSeg, r0 = tid / C::kSeg;        // a staging slot = 8 consecutive columns of one row: 32 bytes of float32
+    const bool col_a = m0 + c16 * 8 < M, col_b = n0 + c16 * 8 < N;
+    const float* pa = A + (size_t)(k_begin + r0) * lda + m0 + c16 * 8;
+    const float* pb = B + (size_t)(k_begin + r0) * ldb + n0 + c16 * 8;
+    f32x4 ra[kP][2], rb[kP][2];
+    auto fetch = [&](int ks) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < kP; ++p) {
+            const bool ok = k_begin + ks + r0 + kRP * p < k_end;
+            const f32x4* qa = reinterpret_cast<const f32x4*>(pa + (size_t)(ks + kRP * p) * lda);
+            const f32x4* qb = reinterpret_cast<const f32x4*>(pb + (size_t)(ks + kRP * p) * ldb);
+            ra[p][0] = ok && col_a ? qa[0] : z;
+            ra[p][1] = ok && col_a ? qa[1] : z;
+            rb[p][0] = ok && col_b ? qb[0] : z;
+            rb[p][1] = ok && col_b ? qb[1] : z;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int p = 0; p < kP; ++p) {
+            uint4 h, l;
+            const int o = (r0 + kRP * p) * kPitch + c16 * 16;
+            split8(ra[p][0], ra[p][1], h, l);
+            *reinterpret_cast<uint4*>(sAh + o) = h;
+            *reinterpret_cast<uint4*>(sAl + o) = l;
+            split8(rb[p][0], rb[p][1], h, l);
+            *reinterpret_cast<uint4*>(sBh + o) = h;
+            *reinterpret_cast<uint4*>(sBl + o) = l;
+        }
+    };
+
+    const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+    const int a_off = (4 * g + q) * kPitch + p4 * 8 + (wm * kQ) * 2, b_off = (4 * g + q) * kPitch + p4 * 8 + (wn * kQ) * 2;
+
+    f32x4 acc[kF][kF] = {};
+    f32x4 cs[CS ? kF : 1] = {};
+    f32x4 csb[CSB ? kF : 1] = {};
+    const bool want_cs = CS && part_cs != nullptr && nt == 0 && wn == 0;   // wave-uniform
+    const bool want_csb = CSB && part_csb != nullptr && mt == 0 && wm == 0;
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (v8i16){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
+    auto frag = [&](const char* base, int off, int kk, int t) {
+        return tr_frag(tr_read(base + off + kk * 32 * kPitch + t * 32), tr_read(base + off + (kk * 32 + 16) * kPitch + t * 32));
+    };
+    auto stage_mma = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < kStage / 32; ++kk) {
+            bf16x8 fah[kF], fal[kF], fbh[kF], fbl[kF];
+#pragma unroll
+            for (int t = 0; t < kF; ++t) {
+                fah[t] = frag(sAh, a_off, kk, t);
+                fal[t] = frag(sAl, a_off, kk, t);
+                fbh[t] = frag(sBh, b_off, kk, t);
+                fbl[t] = frag(sBl, b_off, kk, t);
+            }
+#pragma unroll
+            for (int i = 0; i < kF; ++i)
+#pragma unroll
+                for (int jj = 0; jj < kF; ++jj) {   // the two small terms first
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[jj], acc[i][jj], 0, 0, 0);
+                }
+            if constexpr (CS) {
+                if (want_cs) {
+#pragma unroll
+                    for (int i = 0; i < kF; ++i) {
+                        cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], ones, cs[i], 0, 0, 0);
+                        cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], ones, cs[i], 0, 0, 0);
+                    }
+                }
+            }
+            if constexpr (CSB) {
+                if (want_csb) {
+#pragma unroll
+                    for (int jj = 0; jj < kF; ++jj) {
+                        csb[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fbl[jj], csb[jj], 0, 0, 0);
+                        csb[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fbh[jj], csb[jj], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    const int rows = k_end - k_begin;
+    fetch(0);
+    for (int ks = 0; ks < rows; ks += kStage) {
+        __syncthreads();   // the previous stage's fragment reads are done
+        stash();
+        __syncthreads();
+        if (ks + kStage < rows) fetch(ks + kStage);
+        stage_mma();
+    }
+
+    float* out = part + (size_t)s * M * N;
+#pragma unroll
+    for (int i = 0; i < kF; ++i)
+#pragma unroll
+        for (int jj = 0; jj < kF; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * kQ + i * 16 + 4 * g + r, col = n0 + wn * kQ + jj * 16 + (lane & 15);
+                if (row < M && col < N) out[(size_t)row * N + col] = acc[i][jj][r];
+            }
+    if (CS && want_cs && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < (CS ? kF : 1); ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * kQ + i * 16 + 4 * g + r;
+                if (row < M) part_cs[(size_t)s * M + row] = cs[i][r];
+            }
+    }
+    if (CSB && want_csb && lane < 16) {
+#pragma unroll
+        for (int jj = 0; jj < (CSB ? kF : 1); ++jj) {
+            const int col = n0 + wn * kQ + jj * 16 + lane;
+            if (col < N) part_csb[(size_t)s * N + col] = csb[jj][0];
+        }
+    }
+}
+
 // out[i] = sum_s part[s][i] in the order s = 0, 1, ... over the n tile elements followed by the n_cs column sums (the
 // partial column sums sit behind the partial tiles, split-major).  One element per thread: the loads of one thread are
 // independent, so eight are in flight per lane; the additions keep the order.
@@ -479,8 +645,8 @@ struct TnPlan {
 // floats written and read back -- cost more than the 64-tile's extra operand traffic: [4 B L, 256]^T [4 B L, 256] measured 23.0 vs 21.8 us.
 inline bool tn_big(int M, int N) { return M >= 128 && N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) >= 8 && !VLG_ENV("VLG_WGRAD_TILE64"); }
 
-TnPlan plan_tn(int K, int M, int N, bool big) {
-    const int kTile = big ? 128 : 64, kStage = big ? 64 : 128;
+TnPlan plan_tn(int K, int M, int N, bool big, bool f32 = false) {   // (float32 operands: half the stage depth -- four LDS images instead of two)
+    const int kTile = big ? 128 : 64, kStage = (big ? 64 : 128) >> (f32 ? 1 : 0);
     const int tiles = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
     int S = (512 + tiles - 1) / tiles;                              // ~2 workgroups per CU (swept 256 ... 1024 for both tile shapes: 512)
     const int max_s = (K + 2 * kStage - 1) / (2 * kStage);          // at least two stages per split: both register sets in flight from the start
@@ -498,23 +664,29 @@ extern "C" {
 
 size_t vlg_linear_wgrad_workspace(int K, int M, int N) {
     if (K < 1 || M < 8 || N < 8 || M % 8 || N % 8) return 0;
-    const size_t a = vlg::plan_tn(K, M, N, false).bytes, b = vlg::tn_big(M, N) ? vlg::plan_tn(K, M, N, true).bytes : 0;
-    return a > b ? a : b;
+    size_t need = 0;                                                   // the largest of the plans any operand type / tile shape may take
+    for (int f32 = 0; f32 < 2; ++f32)
+        for (int big = 0; big < (vlg::tn_big(M, N) ? 2 : 1); ++big) {
+            const size_t b = vlg::plan_tn(K, M, N, big != 0, f32 != 0).bytes;
+            need = b > need ? b : need;
+        }
+    return need;
 }
 
-static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
+static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, int in_dtype, void* ws, size_t ws_bytes, int out_dtype,
                         void* d_weight, int ld_dw, void* d_bias, void* x_colsum, bool reduce_now, void* stream);
 
-int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
+int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, int in_dtype, void* ws, size_t ws_bytes, int out_dtype,
                      void* d_weight, int ld_dw, void* d_bias, void* x_colsum, void* stream) {
-    return wgrad_launch(dy, ld_dy, x, ld_x, K, M, N, ws, ws_bytes, out_dtype, d_weight, ld_dw, d_bias, x_colsum, true, stream);
+    return wgrad_launch(dy, ld_dy, x, ld_x, K, M, N, in_dtype, ws, ws_bytes, out_dtype, d_weight, ld_dw, d_bias, x_colsum, true, stream);
 }
 
-int vlg_linear_wgrad_partial(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int want_bias,
-                             int want_x_colsum, void* stream) {
+int vlg_linear_wgrad_partial(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, int in_dtype, void* ws, size_t ws_bytes,
+                             int want_bias, int want_x_colsum, void* stream) {
     // the split-K launch alone: the partial tiles stay in `ws` until vlg_linear_wgrad_reduce_group adds them (ws must stay alive and untouched)
     static char dummy;
-    return wgrad_launch(dy, ld_dy, x, ld_x, K, M, N, ws, ws_bytes, VLG_F32, &dummy, N, want_bias ? &dummy : nullptr, want_x_colsum ? &dummy : nullptr, false, stream);
+    return wgrad_launch(dy, ld_dy, x, ld_x, K, M, N, in_dtype, ws, ws_bytes, VLG_F32, &dummy, N, want_bias ? &dummy : nullptr, want_x_colsum ? &dummy : nullptr, false,
+                        stream);
 }
 
 int vlg_linear_wgrad_reduce_group(const VlgWgradReduce* items, int count, void* stream) {
@@ -530,7 +702,8 @@ int vlg_linear_wgrad_reduce_group(const VlgWgradReduce* items, int count, void* 
             if (q.K < 1 || q.M < 8 || q.N < 8 || q.M % 8 || q.N % 8 || q.ld_dw < q.N) return set_error(VLG_ERR_SHAPE, "linear_wgrad_reduce_group: item %d K=%d M=%d N=%d ld_dw=%d", i, q.K, q.M, q.N, q.ld_dw);
             if (q.out_dtype != VLG_F32 && q.out_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "linear_wgrad_reduce_group: out_dtype %d", q.out_dtype);
             if (!q.ws || !q.d_weight) return set_error(VLG_ERR_ARG, "linear_wgrad_reduce_group: null buffer");
-            const TnPlan pl = plan_tn(q.K, q.M, q.N, tn_big(q.M, q.N) && !(q.d_bias && q.x_colsum));
+            if (q.in_dtype != VLG_F32 && q.in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "linear_wgrad_reduce_group: in_dtype %d", q.in_dtype);
+            const TnPlan pl = plan_tn(q.K, q.M, q.N, tn_big(q.M, q.N) && !(q.d_bias && q.x_colsum), q.in_dtype == VLG_F32);
             const float* part = (const float*)q.ws;
             RedArgs& a = g.p[g.count++];
             a.part = part;
@@ -549,10 +722,12 @@ int vlg_linear_wgrad_reduce_group(const VlgWgradReduce* items, int count, void* 
     return 0;
 }
 
-static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, int out_dtype,
+static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, int in_dtype, void* ws, size_t ws_bytes, int out_dtype,
                         void* d_weight, int ld_dw, void* d_bias, void* x_colsum, bool reduce_now, void* stream) {
     using namespace vlg;
+    if (in_dtype != VLG_F32 && in_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "linear_wgrad: in_dtype %d", in_dtype);
     if (out_dtype != VLG_F32 && out_dtype != VLG_BF16) return set_error(VLG_ERR_DTYPE, "linear_wgrad: out_dtype %d", out_dtype);
+    const bool f32 = in_dtype == VLG_F32;
     if (K < 1 || M < 8 || N < 8 || M % 8 || N % 8)
         return set_error(VLG_ERR_SHAPE, "linear_wgrad: need K >= 1 and M, N positive multiples of 8 (got K=%d M=%d N=%d)", K, M, N);
     if (ld_dy < M || ld_x < N || ld_dy % 8 || ld_x % 8)
@@ -562,7 +737,7 @@ static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int 
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ws)) & 15)
         return set_error(VLG_ERR_ARG, "linear_wgrad: dy, x and the workspace must be 16-byte aligned");
     const bool big = tn_big(M, N) && !(d_bias && x_colsum);     // (the 128-tile carries one kind of column sum)
-    const TnPlan pl = plan_tn(K, M, N, big);
+    const TnPlan pl = plan_tn(K, M, N, big, f32);
     if (ws_bytes < pl.bytes) return set_error(VLG_ERR_WORKSPACE, "linear_wgrad: needs a %zu-byte workspace (got %zu)", pl.bytes, ws_bytes);
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)ws;
@@ -573,11 +748,19 @@ static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int 
     const dim3 grid(tiles * ((pl.S + 7) / 8) * 8);
 #define VLG_TN(...) hipLaunchKernelGGL((gemm_tn_kernel<__VA_ARGS__>), grid, dim3(kGemmThreads), 0, s, (const uint16_t*)dy, ld_dy, (const uint16_t*)x, ld_x, K, M, N, \
                                        pl.KC, pl.S, part, part_cs, part_csb)
-    if (!big) VLG_TN(64, 128, 2, true, true);
+#define VLG_TN3(...) hipLaunchKernelGGL((gemm_tn3_kernel<__VA_ARGS__>), grid, dim3(kGemmThreads), 0, s, (const float*)dy, ld_dy, (const float*)x, ld_x, K, M, N, \
+                                        pl.KC, pl.S, part, part_cs, part_csb)
+    if (f32) {   // float32 operands: three bf16 products per pair (gemm_tn3_kernel)
+        if (!big) VLG_TN3(64, 64, true, true);
+        else if (d_bias) VLG_TN3(128, 32, true, false);
+        else if (x_colsum) VLG_TN3(128, 32, false, true);
+        else VLG_TN3(128, 32, false, false);
+    } else if (!big) VLG_TN(64, 128, 2, true, true);
     else if (d_bias) VLG_TN(128, 64, 1, true, false);
     else if (x_colsum) VLG_TN(128, 64, 1, false, true);
     else VLG_TN(128, 64, 1, false, false);
 #undef VLG_TN
+#undef VLG_TN3
     if (int rc = check_launch("gemm_tn_kernel")) return rc;
     if (!reduce_now) return 0;
     const int n = M * N, n_cs = d_bias ? M : 0, n_csb = x_colsum ? N : 0;

@@ -193,7 +193,7 @@ class _VisEncoder(torch.autograd.Function):
                  "vis_encoder_backward")
         dW = db = dx = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            if act == torch.bfloat16:   # both halves of the [F H, 2n] gradient written in place by the split-K kernel
+            if act in (torch.bfloat16, torch.float32):   # both halves of the [F H, 2n] gradient written in place by the split-K kernel
                 out_dt = w_dt if w_dt in (torch.float32, torch.bfloat16) else torch.float32
                 dW = torch.empty((FH, 2 * n), dtype=out_dt, device=P.device)
                 db = torch.empty((FH,), dtype=out_dt, device=P.device)
@@ -202,7 +202,7 @@ class _VisEncoder(torch.autograd.Function):
                 linear_wgrad(dC, xm, want_bias=True, out=(dW[:, n:], db), defer=wg)
                 wg.flush()
                 db = db.to(b_dt)
-            else:                       # float32 (the reference's `precision: 32`): exact fp32 products on the library
+            else:                       # (other types: the library)
                 dW = torch.cat([dP.t() @ x2, dC.t() @ xm], 1).to(w_dt)
                 db = dC.sum(0).to(b_dt)
         if ctx.needs_input_grad[0]:     # the region features are frozen inputs in training (no gradient asked); parity tests ask
