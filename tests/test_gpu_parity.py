@@ -1269,6 +1269,36 @@ def test_arc_trilinear_shapes(oracle_mod, M, X, H, Y, dt):
         assert torch.equal(out, out2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
 
 
+@pytest.mark.parametrize("M", [1050, 10496])
+def test_arc_trilinear_float32_on_fp16_parts(M):
+    """float32 operands at X = H = Y = 128 (the reference's `precision: 32`): every MFMA operand row as two fp16 parts under a power-of-two row
+    scale, three products per pair (tri3_kernel, tri_dw3_kernel).  Against float64 torch: the error must stay at float32's own level -- 2e-6 of the
+    largest entry (the exact-fp32 kernels measured 6e-6 at M = 10 496; two bf16 parts, round 4: 2e-5) -- with rows / cotangents whose magnitudes
+    span 2^24 (every ROW of the row-wise results is held to 1e-5 of its own largest entry: the row scales), bit-reproducible, and equal to the
+    exact-fp32 kernels (VLG_TRI_F32_EXACT, a child process) within the same bound."""
+    from vlgae_amd import align
+    gen = torch.Generator().manual_seed(M)
+    rows = torch.exp2(torch.randint(-12, 13, (M, 1), generator=gen).float())             # per-row magnitudes 2^-12 .. 2^12
+    child = (torch.randn(M, 128, generator=gen) * 0.5 * rows).to(dev()).requires_grad_(True)
+    parent = (torch.randn(M, 128, generator=gen) * 0.5 * rows.flip(0)).to(dev()).requires_grad_(True)
+    w1 = (torch.randn(128, 128, 128, generator=gen) / 128 * torch.exp2(torch.randint(-6, 7, (128, 128, 1), generator=gen).float())).to(dev()).requires_grad_(True)
+    g = (torch.randn(M, 128, generator=gen) * 1e-4 * torch.exp2(torch.randint(-10, 11, (M, 1), generator=gen).float())).to(dev())
+    out = align.arc_trilinear(child, w1, parent)
+    grads = torch.autograd.grad(out, [child, w1, parent], g)
+    out2 = align.arc_trilinear(child, w1, parent)
+    grads2 = torch.autograd.grad(out2, [child, w1, parent], g)
+    assert torch.equal(out, out2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
+    c64, w64, p64 = (a.detach().double().requires_grad_(True) for a in (child, w1, parent))
+    t = torch.einsum("mhy,my->mh", torch.einsum("mx,xhy->mhy", c64, w64), p64)
+    r_c, r_w, r_p = torch.autograd.grad(t, [c64, w64, p64], g.double())
+    for name, got, want, rowwise in (("out", out, t.detach(), True), ("d_child", grads[0], r_c, True), ("d_w", grads[1], r_w, False), ("d_parent", grads[2], r_p, True)):
+        err = (got.double() - want).abs()
+        assert float(err.max()) <= 2e-6 * float(want.abs().max()), (name, float(err.max()) / float(want.abs().max()))
+        if rowwise:
+            rel = err.amax(1) / want.abs().amax(1).clamp_min(1e-300)
+            assert float(rel.max()) <= 1e-5, (name, float(rel.max()))
+
+
 def test_training_step_chain_as_one_hip_graph():
     """The chained training-step hot path (vlgae_amd/train_step.py: attention-fuse -> library GEMMs -> DMV marginals + heads on two
     streams -> arc encoder -> grounding loss -> -DMV.max -> every gradient) captured as ONE HIP graph: capture succeeds (no

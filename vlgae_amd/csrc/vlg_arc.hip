@@ -300,6 +300,233 @@ static int launch_tri2(const void* c, const void* w, const void* p, int M, int X
     return 0;
 }
 
+// ---- round 5: float32 operands on the fp16 matrix cores (H = Y = 128) -- the reference's `precision: 32`, config/trainer/train.yaml:20 ----
+// tri_kernel<fp32> runs on v_mfma_f32_16x16x4_f32 (1/16 of the 16-bit rate): 3 x 0.43 ms + 0.37 ms per training step.  Here every float32
+// row r of an MFMA operand is written as two fp16 rows, v s_r = hi + lo + e with hi = fp16(v s_r), lo = fp16(v s_r - hi), s_r the power of two
+// that puts the row's largest magnitude in [2^14, 2^15): |e| <= max(2^-23 |v s_r|, 2^-25), i.e. 22 bits of every element within 2^-17 of its
+// row's maximum and an ABSOLUTE floor of 2^-39 of that maximum below.  A product is then hi hi + hi lo + lo hi (three v_mfma_f32_16x16x32_f16
+// into one fp32 accumulator), the dropped lo lo term is <= 2^-22 of it -- float32's own rounding level, where two bf16 parts (8 + 8 bits)
+// stop at 2^-16 (round 4 measured that form: 2e-5 against the 6e-6 the float32 tests hold).  Powers of two scale exactly; 1 / s_r of the p
+// rows goes into the per-row factor c[m,x] (float32, never split), 1 / s of the weight rows (x, h) scales the plane's result column-wise.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ void split_f16_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+// the power of two s with m s in [2^14, 2^15) (m > 0, normal), as (s, 1 / s); 1 for m = 0
+__device__ __forceinline__ void pow2_scale(float m, float& sc, float& inv) {
+    int k = m > 0.f ? 14 - ((int)((__float_as_uint(m) >> 23) & 0xffu) - 127) : 0;
+    k = k < -110 ? -110 : (k > 110 ? 110 : k);
+    sc = __uint_as_float((uint32_t)(127 + k) << 23);
+    inv = __uint_as_float((uint32_t)(127 - k) << 23);
+}
+
+// rows of 128 float32 -> hi / lo fp16 planes of the scaled row and inv[row] = 1 / s_row.  16 lanes per row, 16 rows per workgroup.
+__global__ __launch_bounds__(256) void tri_split_rows_kernel(const float* __restrict__ src, size_t rows, uint16_t* __restrict__ hi,
+                                                             uint16_t* __restrict__ lo, float* __restrict__ inv) {
+    const size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    const bool ok = row < rows;
+    const size_t rr = ok ? row : rows - 1;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + rr * 128 + sub * 8), b = *reinterpret_cast<const f32x4*>(src + rr * 128 + sub * 8 + 4);
+    float m = fmaxf(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))), fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3]))));
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+    float sc, iv;
+    pow2_scale(m, sc, iv);
+    uint4 h, l;
+    split_f16_pair(a[0] * sc, a[1] * sc, h.x, l.x);
+    split_f16_pair(a[2] * sc, a[3] * sc, h.y, l.y);
+    split_f16_pair(b[0] * sc, b[1] * sc, h.z, l.z);
+    split_f16_pair(b[2] * sc, b[3] * sc, h.w, l.w);
+    if (ok) {
+        *reinterpret_cast<uint4*>(hi + row * 128 + sub * 8) = h;
+        *reinterpret_cast<uint4*>(lo + row * 128 + sub * 8) = l;
+        if (sub == 0) inv[row] = iv;
+    }
+}
+
+// tri2_kernel's scheme on two fp16 parts per operand: a workgroup owns 256 rows x all 128 h for a range of x; wave w holds the hi / lo
+// fragments of ITS 32 rows of p for the whole x loop (64 VGPRs) and all eight h tiles (64 accumulator registers).  The weights are staged
+// HALF a plane at a time (64 h rows, hi | lo: 32 KB, double-buffered; their 64 inverse row scales behind them): 16 staging registers per
+// lane instead of 32 -- with whole planes the kernel needed 270 registers at the 256 that two wavefronts per SIMD leave.
+constexpr int kTri3Threads = 512, kTri3Rows = 256;
+
+__global__ __launch_bounds__(kTri3Threads) void tri3_kernel(const float* __restrict__ c, const uint16_t* __restrict__ wh,
+                                                            const uint16_t* __restrict__ wl, const float* __restrict__ winv,
+                                                            const uint16_t* __restrict__ ph, const uint16_t* __restrict__ pl,
+                                                            const float* __restrict__ pinv, int M, int X, int xs, float* __restrict__ out,
+                                                            size_t part_stride, int use_atomic) {
+    constexpr int H = 128, Y = 128, KCH = 4, HALF = 64 * 16;   // half a plane part: 64 rows x 16 segments of 16 bytes
+    extern __shared__ __attribute__((aligned(16))) char tri3_smem[];
+    uint4* wbuf = reinterpret_cast<uint4*>(tri3_smem);                                   // [2 buffers][hi | lo][64 rows][16 segments]
+    float* wis = reinterpret_cast<float*>(tri3_smem + 4 * (size_t)HALF * 16);             // [2 buffers][64] inverse row scales
+    float* cT = wis + 2 * 64;                                                             // [x range][256 rows]: c[m,x] / s_p[m]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n_rb = (M + kTri3Rows - 1) / kTri3Rows;
+    const int rb = blockIdx.x % n_rb, yb = blockIdx.x / n_rb;
+    const int m0 = rb * kTri3Rows;
+    const int xper = (X + xs - 1) / xs, xb = yb * xper, xe = min(X, xb + xper), nx = max(xe - xb, 0);
+    for (int i = tid; i < kTri3Rows * nx; i += kTri3Threads) {
+        const int row = i / nx, x = i - row * nx;
+        cT[x * kTri3Rows + row] = m0 + row < M ? c[(size_t)(m0 + row) * X + xb + x] * pinv[m0 + row] : 0.f;
+    }
+    f16x8 pfh[2][KCH], pfl[2][KCH];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const size_t off = (size_t)min(m0 + wave * 32 + 16 * rt + r, M - 1) * Y + 8 * g;
+        const f16x8 *rh = reinterpret_cast<const f16x8*>(ph + off), *rl = reinterpret_cast<const f16x8*>(pl + off);
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            pfh[rt][kc] = rh[kc * 4];
+            pfl[rt][kc] = rl[kc * 4];
+        }
+    }
+    uint4 rwh0, rwh1, rwl0, rwl1;   // (scalars: as arrays captured by the lambdas they stayed in scratch memory)
+    float rwi = 0.f;
+    const int so0 = (tid >> 4) * 16 + ((tid & 15) ^ ((tid >> 4) & 15)), so1 = so0 + 32 * 16;   // (row + 32: the same row & 15)
+    auto fetch = [&](int t) {   // stage t = (x, half)
+        const size_t seg = (size_t)(xb + (t >> 1)) * (H * 16) + (size_t)(t & 1) * HALF + tid;
+        const uint4 *sh = reinterpret_cast<const uint4*>(wh) + seg, *sl = reinterpret_cast<const uint4*>(wl) + seg;
+        rwh0 = sh[0]; rwh1 = sh[kTri3Threads];
+        rwl0 = sl[0]; rwl1 = sl[kTri3Threads];
+        if (tid < 64) rwi = winv[(size_t)(xb + (t >> 1)) * H + (t & 1) * 64 + tid];
+    };
+    auto stash = [&](int buf) {
+        uint4* dh = wbuf + buf * (2 * HALF);
+        dh[so0] = rwh0; dh[so1] = rwh1;
+        dh[HALF + so0] = rwl0; dh[HALF + so1] = rwl1;
+        if (tid < 64) wis[buf * 64 + tid] = rwi;
+    };
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nt = 2 * nx;
+    if (nt > 0) {
+        fetch(0);
+        stash(0);
+        fetch(1);
+    }
+    __syncthreads();
+    int foff[KCH];
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) foff[kc] = r * 16 + ((kc * 4 + g) ^ r);
+    for (int xi = 0; xi < nx; ++xi) {
+        f32x4 cv[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) cv[rt] = *reinterpret_cast<const f32x4*>(cT + xi * kTri3Rows + wave * 32 + 16 * rt + 4 * g);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {   // stage 2 xi + half sits in buffer `half`
+            const uint4* wb = wbuf + half * (2 * HALF);
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const float wi = wis[half * 64 + j4 * 16 + r];
+                f32x4 d[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) {
+                    const f16x8 bh = __builtin_bit_cast(f16x8, wb[j4 * 256 + foff[kc]]), bl = __builtin_bit_cast(f16x8, wb[HALF + j4 * 256 + foff[kc]]);
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {   // the two small terms first
+                        d[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfl[rt][kc], bh, d[rt], 0, 0, 0);
+                        d[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh[rt][kc], bl, d[rt], 0, 0, 0);
+                        d[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh[rt][kc], bh, d[rt], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[rt][half * 4 + j4][n] = fmaf(cv[rt][n] * wi, d[rt][n], acc[rt][half * 4 + j4][n]);
+                __builtin_amdgcn_sched_barrier(0);   // (left alone, hipcc hoists the 32 fragment reads of a stage to its top: 128 more registers, scratch)
+            }
+            const int t = 2 * xi + half;
+            if (t + 1 < nt) {
+                stash(half ^ 1);
+                if (t + 2 < nt) fetch(t + 2);
+            }
+            __syncthreads();
+        }
+    }
+    float* dstb = out + (use_atomic ? 0 : (size_t)yb * part_stride);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int m = m0 + wave * 32 + 16 * rt + 4 * g + n;
+                if (m < M) {
+                    float* o = dstb + (size_t)m * H + j * 16 + r;
+                    if (use_atomic) atomicAdd(o, acc[rt][j][n]);
+                    else *o = acc[rt][j][n];
+                }
+            }
+}
+
+static bool tri3_applies(int M, int X, int H, int Y) { return H == 128 && Y == 128 && M >= 1024 && X >= 2 && X <= 256; }
+static int tri3_splits(int M, int X) {   // tri2's; the x range's [range][256] float32 factors sit behind the 64 KB of weight buffers
+    int xs = tri2_splits(M, X);
+    while ((X + xs - 1) / xs > 80) ++xs;
+    return xs;
+}
+static size_t tri3_part_bytes(int M, int X) { const int xs = tri3_splits(M, X); return xs > 1 ? sizeof(float) * (size_t)xs * M * 128 : 0; }
+
+struct Tri3Ops {   // one operand in two fp16 parts + the inverse row scales
+    uint16_t *hi, *lo;
+    float* inv;
+};
+// carving of a [rows][128] operand's split form out of a scratch region; returns the bytes used (256-byte granules)
+static size_t tri3_carve(char* base, size_t rows, Tri3Ops* o) {
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t plane = up(rows * 128 * 2), iv = up(rows * 4);
+    if (o) {
+        o->hi = reinterpret_cast<uint16_t*>(base);
+        o->lo = reinterpret_cast<uint16_t*>(base + plane);
+        o->inv = reinterpret_cast<float*>(base + 2 * plane);
+    }
+    return 2 * plane + iv;
+}
+static void launch_split_rows(const float* src, size_t rows, const Tri3Ops& o, hipStream_t s) {
+    hipLaunchKernelGGL(tri_split_rows_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, src, rows, o.hi, o.lo, o.inv);
+}
+
+// out[m,h] = sum_x c[m,x] sum_y w[x,h,y] p[m,y] from the split forms of w ([X 128 rows]) and p ([M rows]); part: tri3_part_bytes(M, X)
+static int launch_tri3(const float* c, const Tri3Ops& w, const Tri3Ops& p, int M, int X, float* out, float* part, hipStream_t s) {
+    const int xs = tri3_splits(M, X);
+    const int n_rb = (M + kTri3Rows - 1) / kTri3Rows;
+    const size_t lds = 4 * (size_t)64 * 128 * 2 + sizeof(float) * (2 * 64 + (size_t)kTri3Rows * ((X + xs - 1) / xs));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(tri3_kernel, dim3(n_rb * xs), dim3(kTri3Threads), lds, s, c, w.hi, w.lo, w.inv, p.hi, p.lo, p.inv, M, X, xs, xs > 1 ? part : out,
+                       (size_t)M * 128, 0);
+    if (xs > 1) {
+        const size_t n = (size_t)M * 128;
+        hipLaunchKernelGGL(tri2_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, part, xs, n, out);
+    }
+    return 0;
+}
+
+// workspace of the float32 forward: split w | split p | partial slabs
+static size_t tri3_fwd_bytes(int M, int X) {
+    return tri3_carve(nullptr, (size_t)X * 128, nullptr) + tri3_carve(nullptr, (size_t)M, nullptr) + ((tri3_part_bytes(M, X) + 255) & ~(size_t)255);
+}
+static int launch_tri3_forward(const void* c, const void* w, const void* p, int M, int X, float* out, char* ws, hipStream_t s) {
+    Tri3Ops wo, po;
+    size_t off = tri3_carve(ws, (size_t)X * 128, &wo);
+    off += tri3_carve(ws + off, (size_t)M, &po);
+    launch_split_rows((const float*)w, (size_t)X * 128, wo, s);
+    launch_split_rows((const float*)p, (size_t)M, po, s);
+    return launch_tri3((const float*)c, wo, po, M, X, out, reinterpret_cast<float*>(ws + off), s);
+}
+
 template <bool F32IN, int KCH, int RT>
 static int launch_tri_rt(const void* c, const void* w, const void* p, int M, int X, int H, int xs, float* out, hipStream_t s) {
     using T = typename MfmaCfg<F32IN>::T;
@@ -362,7 +589,8 @@ static int dispatch_tri(const void* c, const void* w, const void* p, int M, int 
                         hipStream_t s, float* part = nullptr) {
     if (f32in) {
         int rc;
-        if (Y == 128) rc = launch_tri<true, 8>(c, w, p, M, X, H, out, s);
+        if (part && tri3_applies(M, X, H, Y) && !VLG_ENV("VLG_TRI_F32_EXACT")) rc = launch_tri3_forward(c, w, p, M, X, out, reinterpret_cast<char*>(part), s);   // (part: tri3_fwd_bytes)
+        else if (Y == 128) rc = launch_tri<true, 8>(c, w, p, M, X, H, out, s);
         else if (Y == 64) rc = launch_tri<true, 4>(c, w, p, M, X, H, out, s);
         else if (Y == 32) rc = launch_tri<true, 2>(c, w, p, M, X, H, out, s);
         else return set_error(VLG_ERR_SHAPE, "trilinear: contracted dimension %d (supported: 32, 64, 128)", Y);
@@ -693,6 +921,163 @@ static int dw2_splits(int M, int X) {   // 1, 2, 4 or 8 (a divisor of the XCD co
     return S;
 }
 
+// ---- round 5: d_w with float32 operands on two fp16 parts (see tri3_kernel) ------------------------------------------------------------
+// The contraction index is the row m, so a per-row scale cannot be factored out: the operands are scaled by ONE power of two each, from the
+// largest magnitudes of c, g and p (tri_absmax3_kernel: per-workgroup maxima, met in this kernel's prologue) -- A = (g c[:,x]) S_A with
+// |g|max |c|max S_A in [2^14, 2^15), B = p S_B.  An element 2^-k below that bound keeps 22 - max(0, k - 17) bits: against the fp32 accumulation
+// over 10^4 rows that is nothing.  The split happens between the staging registers and LDS; otherwise tri_dw2_kernel's scheme at half its stage
+// depth (six tiles of hi | lo per buffer).
+__global__ __launch_bounds__(256) void tri_absmax3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                          size_t n4, float* __restrict__ out) {
+    __shared__ float red[4][3];
+    float ma = 0.f, mb = 0.f, mc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 va = reinterpret_cast<const f32x4*>(a)[i], vb = reinterpret_cast<const f32x4*>(b)[i], vc = reinterpret_cast<const f32x4*>(c)[i];
+        ma = fmaxf(ma, fmaxf(fmaxf(fabsf(va[0]), fabsf(va[1])), fmaxf(fabsf(va[2]), fabsf(va[3]))));
+        mb = fmaxf(mb, fmaxf(fmaxf(fabsf(vb[0]), fabsf(vb[1])), fmaxf(fabsf(vb[2]), fabsf(vb[3]))));
+        mc = fmaxf(mc, fmaxf(fmaxf(fabsf(vc[0]), fabsf(vc[1])), fmaxf(fabsf(vc[2]), fabsf(vc[3]))));
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        ma = fmaxf(ma, __shfl_xor(ma, o));
+        mb = fmaxf(mb, __shfl_xor(mb, o));
+        mc = fmaxf(mc, __shfl_xor(mc, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6][0] = ma;
+        red[threadIdx.x >> 6][1] = mb;
+        red[threadIdx.x >> 6][2] = mc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        out[blockIdx.x * 3 + threadIdx.x] = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+}
+
+constexpr int kDw3Threads = 1024, kDw3Stage = 32, kDw3XB = 2, kDw3MaxBlocks = 64;
+constexpr int kDw3Pitch = 128 * 2 + 32;
+
+__global__ __launch_bounds__(kDw3Threads) void tri_dw3_kernel(const float* __restrict__ c, const float* __restrict__ g, const float* __restrict__ p,
+                                                              const float* __restrict__ maxes, int M, int X, int KC, int S,
+                                                              float* __restrict__ part) {
+    constexpr int HY = 128;
+    extern __shared__ __attribute__((aligned(16))) char dw3_smem[];   // two stage buffers of (XB + 1) tiles in hi | lo parts
+    constexpr int kTileBytes = kDw3Stage * kDw3Pitch, kBufBytes = 2 * (kDw3XB + 1) * kTileBytes;
+    __shared__ float mx[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
+    if (wave < 3) {   // the three maxima: wave k reduces column k of the [64][3] per-workgroup maxima
+        float m = maxes[lane * 3 + wave];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) mx[wave] = m;
+    }
+    __syncthreads();
+    float sA, iA, sB, iB;
+    pow2_scale(mx[0] * mx[1], sA, iA);   // (maxes: c, g, p)
+    pow2_scale(mx[2], sB, iB);
+    const int s = blockIdx.x % S, x0 = (blockIdx.x / S) * kDw3XB;
+    const int k_begin = s * KC, k_end = min(M, k_begin + KC), rows = k_end - k_begin;
+    // staging: a tile row is 128 float32 = 32 x 16 bytes; 1024 threads cover the 32 rows of a stage in one pass
+    const int c4 = tid & 31, r0 = tid >> 5;
+    f32x4 rg, rp;
+    f32x2 rc;
+    auto fetch = [&](int ks) {
+        const int k = k_begin + ks + r0;
+        const bool ok = k < k_end;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        rg = ok ? *reinterpret_cast<const f32x4*>(g + (size_t)k * HY + c4 * 4) : z;
+        rp = ok ? *reinterpret_cast<const f32x4*>(p + (size_t)k * HY + c4 * 4) : z;
+        rc = ok ? *reinterpret_cast<const f32x2*>(c + (size_t)k * X + x0) : f32x2{0.f, 0.f};
+    };
+    auto put = [&](char* tile_hi, int off, const f32x4& v, float f) {   // (v f) -> hi | lo, 4 elements = 8 bytes per part
+        uint2 h, l;
+        split_f16_pair(v[0] * f, v[1] * f, h.x, l.x);
+        split_f16_pair(v[2] * f, v[3] * f, h.y, l.y);
+        *reinterpret_cast<uint2*>(tile_hi + off) = h;
+        *reinterpret_cast<uint2*>(tile_hi + kTileBytes + off) = l;
+    };
+    auto stash = [&](int buf) {
+        char* base = dw3_smem + buf * kBufBytes;
+        const int off = r0 * kDw3Pitch + c4 * 8;
+        put(base + 2 * kDw3XB * kTileBytes, off, rp, sB);
+#pragma unroll
+        for (int xb = 0; xb < kDw3XB; ++xb) put(base + 2 * xb * kTileBytes, off, rg, rc[xb] * sA);
+    };
+    const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    const int row_off = (4 * g4 + q4) * kDw3Pitch + p4 * 8;
+    auto frag = [&](const char* t) { return __builtin_bit_cast(f16x8, tr_frag(tr_read(t), tr_read(t + 16 * kDw3Pitch))); };
+    f32x4 acc[kDw3XB][2][2] = {};
+    fetch(0);
+    stash(0);
+    if (kDw3Stage < rows) fetch(kDw3Stage);
+    __syncthreads();
+    for (int ks = 0, buf = 0; ks < rows; ks += kDw3Stage, buf ^= 1) {
+        const char* base = dw3_smem + buf * kBufBytes;
+        f16x8 fbh[2], fbl[2];
+        const char* pb = base + 2 * kDw3XB * kTileBytes + row_off + (wn * 32) * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fbh[j] = frag(pb + j * 32);
+            fbl[j] = frag(pb + kTileBytes + j * 32);
+        }
+#pragma unroll
+        for (int xb = 0; xb < kDw3XB; ++xb) {
+            const char* pa = base + 2 * xb * kTileBytes + row_off + (wm * 32) * 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f16x8 fah = frag(pa + i * 32), fal = frag(pa + kTileBytes + i * 32);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[xb][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fal, fbh[j], acc[xb][i][j], 0, 0, 0);
+                    acc[xb][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah, fbl[j], acc[xb][i][j], 0, 0, 0);
+                    acc[xb][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah, fbh[j], acc[xb][i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (ks + kDw3Stage < rows) {
+            stash(buf ^ 1);
+            if (ks + 2 * kDw3Stage < rows) fetch(ks + 2 * kDw3Stage);
+        }
+        __syncthreads();
+    }
+    const float un = iA * iB;
+#pragma unroll
+    for (int xb = 0; xb < kDw3XB; ++xb) {
+        if (x0 + xb >= X) break;
+        float* out = part + ((size_t)s * X + x0 + xb) * HY * HY;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(size_t)(wm * 32 + i * 16 + 4 * g4 + r) * HY + wn * 32 + j * 16 + (lane & 15)] = acc[xb][i][j][r] * un;
+    }
+}
+
+static bool dw3_applies(int M, int X, int H, int Y) { return H == 128 && Y == 128 && X == 128 && M >= 1024; }   // (X = 128: the three operands share a shape)
+static int dw3_splits(int M, int X) {
+    int S = 8;
+    while (S > 1 && ((X / kDw3XB) * (S / 2) >= 256 || (M + S - 1) / S < 8 * kDw3Stage)) S /= 2;
+    return S;
+}
+
+// the float32 backward on fp16 parts (X = H = Y = 128): scratch behind the permuted float32 weight copies
+struct Tri3BwdPlan {
+    size_t off_wA, off_wB, off_g, off_max, off_part, bytes;
+    Tri3BwdPlan(int M, int X, int H, int Y, size_t base) {
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        off_wA = base;
+        off_wB = off_wA + tri3_carve(nullptr, (size_t)Y * X, nullptr);
+        off_g = off_wB + tri3_carve(nullptr, (size_t)X * Y, nullptr);
+        off_max = off_g + tri3_carve(nullptr, (size_t)M, nullptr);
+        off_part = off_max + up(sizeof(float) * 3 * kDw3MaxBlocks);
+        size_t pb = sizeof(float) * (size_t)dw3_splits(M, X) * X * H * Y;
+        pb = pb > tri3_part_bytes(M, Y) ? pb : tri3_part_bytes(M, Y);
+        pb = pb > tri3_part_bytes(M, X) ? pb : tri3_part_bytes(M, X);
+        bytes = off_part + up(pb);
+    }
+};
+
 struct TriBwdPlan {   // scratch carving (bytes), shared by the size query and the launcher
     size_t esz, Mp, off_wA, off_wB, off_gB, off_cT, off_gT, off_pT, off_part, bytes;
     TriBwdPlan(int M, int X, int H, int Y, bool f32in) {
@@ -713,13 +1098,59 @@ struct TriBwdPlan {   // scratch carving (bytes), shared by the size query and t
         if (tri2_applies(M, Y, X, H, f32in)) pb = pb > tri2_part_bytes(M, Y) ? pb : tri2_part_bytes(M, Y);
         if (tri2_applies(M, X, Y, H, f32in)) pb = pb > tri2_part_bytes(M, X) ? pb : tri2_part_bytes(M, X);
         bytes = off_part + up(pb);
+        if (f32in && tri3_applies(M, X, H, Y) && dw3_applies(M, X, H, Y)) {   // the fp16-parts path: only the permuted weight copies of the layout above
+            const size_t b3 = Tri3BwdPlan(M, X, H, Y, off_gB).bytes;
+            bytes = bytes > b3 ? bytes : b3;
+        }
     }
 };
+
+// float32 operands, X = H = Y = 128: every product on two fp16 parts per operand (tri3_kernel, tri_dw3_kernel)
+static int run_tri_backward_f16x3(const float* child, const float* w, const float* parent, const float* g, int M, int X, int H, int Y, char* ws,
+                                  const TriBwdPlan& p, float* d_child, float* d_w, float* d_parent, hipStream_t s) {
+    const Tri3BwdPlan q(M, X, H, Y, p.off_gB);
+    float *wA = (float*)(ws + p.off_wA), *wB = (float*)(ws + p.off_wB);
+    float* part = reinterpret_cast<float*>(ws + q.off_part);
+    Tri3Ops wAo, wBo, go;
+    tri3_carve(ws + q.off_wA, (size_t)Y * X, &wAo);
+    tri3_carve(ws + q.off_wB, (size_t)X * Y, &wBo);
+    tri3_carve(ws + q.off_g, (size_t)M, &go);
+    if (d_child || d_parent) {
+        hipLaunchKernelGGL((tri_permute2_kernel<float>), dim3(X, (Y + 31) / 32), dim3(256), 0, s, w, wA, wB, X, H, Y);
+        launch_split_rows(g, (size_t)M, go, s);
+    }
+    if (d_child) {   // roles (c, w, p) := (parent, wA [Y][X][H], g)
+        launch_split_rows(wA, (size_t)Y * X, wAo, s);
+        if (int rc = launch_tri3(parent, wAo, go, M, Y, d_child, part, s)) return rc;
+    }
+    if (d_parent) {  // roles (c, w, p) := (child, wB [X][Y][H], g)
+        launch_split_rows(wB, (size_t)X * Y, wBo, s);
+        if (int rc = launch_tri3(child, wBo, go, M, X, d_parent, part, s)) return rc;
+    }
+    if (d_w) {
+        float* maxes = reinterpret_cast<float*>(ws + q.off_max);
+        hipLaunchKernelGGL(tri_absmax3_kernel, dim3(kDw3MaxBlocks), dim3(256), 0, s, child, g, parent, (size_t)M * 128 / 4, maxes);
+        const int S = dw3_splits(M, X);
+        const int KC = ((M + S - 1) / S + kDw3Stage - 1) / kDw3Stage * kDw3Stage;
+        const size_t lds = 2 * (size_t)2 * (kDw3XB + 1) * kDw3Stage * kDw3Pitch;   // 108 KB
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_dw3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(tri_dw3_kernel, dim3((X / kDw3XB) * S), dim3(kDw3Threads), lds, s, child, g, parent, maxes, M, X, KC, S, part);
+        const size_t n = (size_t)X * H * Y;
+        hipLaunchKernelGGL(tri_dw2_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, part, S, n, d_w);
+    }
+    return check_launch("trilinear_backward (fp16 parts)");
+}
 
 template <bool F32IN>
 static int run_tri_backward(const void* child, const void* w, const void* parent, const void* g, bool g_is_bf16, int M, int X, int H,
                             int Y, char* ws, const TriBwdPlan& p, float* d_child, float* d_w, float* d_parent, hipStream_t s) {
     using T = typename MfmaCfg<F32IN>::T;
+    if constexpr (F32IN) {
+        if (tri3_applies(M, X, H, Y) && dw3_applies(M, X, H, Y) && !VLG_ENV("VLG_TRI_F32_EXACT"))
+            return run_tri_backward_f16x3((const float*)child, (const float*)w, (const float*)parent, (const float*)g, M, X, H, Y, ws, p, d_child, d_w,
+                                          d_parent, s);
+    }
     T *wA = (T*)(ws + p.off_wA), *wB = (T*)(ws + p.off_wB), *gB = (T*)(ws + p.off_gB);
     T *cT = (T*)(ws + p.off_cT), *gT = (T*)(ws + p.off_gT), *pT = (T*)(ws + p.off_pT);
     const int pblocks = 1024;
@@ -737,12 +1168,12 @@ static int run_tri_backward(const void* child, const void* w, const void* parent
     if (d_child) {   // d_child[m,x] = sum_y p[m,y] * sum_h wA[y,x,h] g[m,h]: roles (c, w, p) := (p, wA, g); "X" = Y, "H" = X, "Y" = H
         if (X % 16 || X > 16 * kTriWaves * kTriHPW) return set_error(VLG_ERR_SHAPE, "trilinear_backward: X=%d must be a multiple of 16 and <= 128", X);
         if (!permuted) hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wA, X, H, Y, 0);
-        if (int rc = dispatch_tri(parent, wA, g_op, M, Y, X, H, F32IN, d_child, s, reinterpret_cast<float*>(ws + p.off_part))) return rc;
+        if (int rc = dispatch_tri(parent, wA, g_op, M, Y, X, H, F32IN, d_child, s, F32IN ? nullptr : reinterpret_cast<float*>(ws + p.off_part))) return rc;
     }
     if (d_parent) {  // d_parent[m,y] = sum_x c[m,x] * sum_h wB[x,y,h] g[m,h]: roles (c, w, p) := (c, wB, g); "H" = Y, "Y" = H
         if (Y % 16 || Y > 16 * kTriWaves * kTriHPW) return set_error(VLG_ERR_SHAPE, "trilinear_backward: Y=%d must be a multiple of 16 and <= 128", Y);
         if (!permuted) hipLaunchKernelGGL((tri_permute_kernel<T>), dim3(pblocks), dim3(256), 0, s, (const T*)w, wB, X, H, Y, 1);
-        if (int rc = dispatch_tri(child, wB, g_op, M, X, Y, H, F32IN, d_parent, s, reinterpret_cast<float*>(ws + p.off_part))) return rc;
+        if (int rc = dispatch_tri(child, wB, g_op, M, X, Y, H, F32IN, d_parent, s, F32IN ? nullptr : reinterpret_cast<float*>(ws + p.off_part))) return rc;
     }
     if (d_w && dw2_applies(M, X, H, Y, F32IN)) {
         if constexpr (!F32IN) {
@@ -800,7 +1231,8 @@ int vlg_trilinear(const void* child, const void* w, const void* parent, int M, i
 
 size_t vlg_trilinear_workspace(int M, int X, int H, int Y, int in_dtype) {
     if (M < 1 || X < 1 || H < 1 || Y < 1) return 0;
-    return vlg::tri2_applies(M, X, H, Y, in_dtype == VLG_F32) ? vlg::tri2_part_bytes(M, X) : 0;
+    if (in_dtype == VLG_F32) return vlg::tri3_applies(M, X, H, Y) ? vlg::tri3_fwd_bytes(M, X) : 0;
+    return vlg::tri2_applies(M, X, H, Y, false) ? vlg::tri2_part_bytes(M, X) : 0;
 }
 
 int vlg_trilinear_ws(const void* child, const void* w, const void* parent, int M, int X, int H, int Y, int in_dtype, void* ws,
