@@ -1254,6 +1254,11 @@ __global__ __launch_bounds__(kAMThreads, VLG_AF_WPE) void align_full_kernel(
                     for (int n = 0; n < 4; ++n) vkeep |= (unsigned)ckeep_s[buf][ct * 16 + 4 * g + n] << (4 * ct + n);
                 v_masked = __builtin_amdgcn_ballot_w64(vkeep != 0xfffu) != 0;
             }
+            // (tools/time_align_full_ablation.sh: -DVLG_ABL_AF_NOMFMA drops the products and the LDS writes, -DVLG_ABL_AF_NOSTORE the global stores --
+            //  wrong results, measured ceilings: DESIGN.md section 3)
+#ifdef VLG_ABL_AF_NOMFMA
+            if (false)
+#endif
 #pragma unroll 1
             for (int ct = 0; ct < 3; ++ct) {
                 bf16x8 vf[KCH];   // A operand: regions 16 ct + (lane & 15) of the image tile
@@ -1276,24 +1281,48 @@ __global__ __launch_bounds__(kAMThreads, VLG_AF_WPE) void align_full_kernel(
             // linear copy-out of the wave's block (same layout as the output): all reads first, then contiguous 1 KB stores
             __builtin_amdgcn_wave_barrier();
             if (b < B) {
+#ifdef VLG_ABL_AF_SEQ   // (ablation: the same bytes, but the eight waves of a workgroup write NEIGHBOURING chunks instead of chunks 3 MB apart)
+#ifndef VLG_ABL_AF_SEQ_STRIDE
+#define VLG_ABL_AF_SEQ_STRIDE ((size_t)Q * V)
+#endif
+                f32x4* dst4 = reinterpret_cast<f32x4*>(out_full + ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kAMWaves + wave) * a_per_block + i) * VLG_ABL_AF_SEQ_STRIDE);
+#else
                 f32x4* dst4 = reinterpret_cast<f32x4*>(out_full + (((size_t)bc * A + a) * Q + q0) * V);
+#endif
                 const f32x4* src4 = reinterpret_cast<const f32x4*>(otile);
-                constexpr int NC = (RT * 16 * 48 / 4 + 63) / 64;   // V <= 48
+                // (round 5) store instruction k covers the 16-byte pieces 64 k - sh + lane, sh = the chunk's first piece within its 128-byte line:
+                // every instruction then writes eight WHOLE lines -- a chunk is Q V floats = 11 808 bytes at config-2, 32 bytes past a line
+                // boundary, and with pieces 64 k + lane every one of the twelve instructions split two lines with its neighbour (measured on the
+                // store stream alone: 181 -> 161 us with line-aligned chunks; tools/time_align_full_ablation.sh)
+                const int sh = (int)((reinterpret_cast<uintptr_t>(dst4) >> 4) & 7);
+                constexpr int NC = (RT * 16 * 48 / 4 + 63) / 64 + 1;   // V <= 48; + 1: the shifted last pieces
                 // non-temporal: the 774 MB tensor is written once and read by a later kernel, never by this one (round 4:
-                // 0.197 -> 0.185 ms unmasked, 0.201 -> 0.160 ms with masks on the same box).  In two halves: twelve 16-byte registers
-                // in flight at once put the kernel 6 registers over its 256 (the nt form keeps an address pair per store).
+                // 0.197 -> 0.185 ms unmasked, 0.201 -> 0.160 ms with masks on the same box).  In two halves: all 16-byte registers
+                // in flight at once put the kernel over its 256 registers (the nt form keeps an address pair per store).
                 constexpr int NH = (NC + 1) / 2;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     f32x4 tv[NH];
 #pragma unroll
-                    for (int k = 0; k < NH; ++k) tv[k] = src4[min(lane + 64 * (half * NH + k), n4 - 1)];
+                    for (int k = 0; k < NH; ++k) tv[k] = src4[min(max(lane + 64 * (half * NH + k) - sh, 0), n4 - 1)];
 #pragma unroll
-                    for (int k = 0; k < NH; ++k)
-                        if (half * NH + k < NC && lane + 64 * (half * NH + k) < n4) __builtin_nontemporal_store(tv[k], dst4 + lane + 64 * (half * NH + k));
+                    for (int k = 0; k < NH; ++k) {
+                        const int j = lane + 64 * (half * NH + k) - sh;
+#ifdef VLG_ABL_AF_NOSTORE
+                        if (half * NH + k < NC && j >= 0 && j < n4 && tv[k][0] == 1.2345e-33f) __builtin_nontemporal_store(tv[k], dst4 + j);
+#elif defined(VLG_ABL_AF_PLAINST)
+                        if (half * NH + k < NC && j >= 0 && j < n4) dst4[j] = tv[k];
+#else
+                        if (half * NH + k < NC && j >= 0 && j < n4) __builtin_nontemporal_store(tv[k], dst4 + j);
+#endif
+                    }
                 }
             }
+#ifdef VLG_ABL_AF_LDSBAR
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
             __syncthreads();   // (an LDS-only barrier -- s_waitcnt lgkmcnt(0) + s_barrier, leaving the stores in flight -- measured the same: 0.197 ms)
+#endif
         }
     }
 }
@@ -1304,6 +1333,9 @@ static int launch_align_full(const void* txt, const void* vis, const uint8_t* tm
     int a_per_block = (int)(((long)A * by + 255) / 256);
     if (a_per_block < 8) a_per_block = 8;
     if (a_per_block > A) a_per_block = A;
+#ifdef VLG_AF_APB   // (tools/ A/B builds)
+    a_per_block = VLG_AF_APB;
+#endif
     dim3 grid((A + a_per_block - 1) / a_per_block, by);
     const size_t lds = sizeof(float) * (size_t)kAMWaves * (VLG_AF_RT * 16) * V;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_full_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
