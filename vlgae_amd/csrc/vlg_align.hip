@@ -803,14 +803,33 @@ static __device__ __forceinline__ unsigned am_keep_u(unsigned bits, int pos, uns
 // Several region groups per image (V > 48, the shipped factor layout): the staged tile is one GROUP of 48 regions, the loop runs over
 // (image, group) steps; a region belongs to one group, so the maxima over the queries are per step as before, while the maxima over
 // the regions are carried across an image's groups (strictly larger wins: the earlier group keeps a tie) and stored after its last one.
-template <bool HASQ, bool ARGS, bool MULTI>   // MULTI = false: one group (V <= 48), the group arithmetic folds away
+// NP = 2 (round 5): float32 features as two fp16 parts each under ONE power-of-two scale per tensor (align_split_kernel: hi = fp16(x s),
+// lo = fp16(x s - hi); txt / vis = the hi parts, parts.txt_lo / vis_lo the lo parts) -- a product is hi hi + hi lo + lo hi, three
+// v_mfma_f32_16x16x32_f16 into one accumulator, 2^-22 relative: float32's own level -- where align_mfma_kernel<fp32> runs on
+// v_mfma_f32_16x16x4_f32 at 1/16 of the rate (1.18 ms at config-2).  48 queries per pass (the two parts of 96 would need 190 fragment
+// registers); comparisons run on the scaled scores (a power of two: same order, same ties), the stored maxima are multiplied by
+// 1 / (s_txt s_vis) (parts.inv, written by the split), a masked maximum stays neg_inf.
+struct AlignParts {
+    const uint16_t *txt_lo, *vis_lo;
+    const float* inv;   // device: {1 / s_txt, 1 / s_vis}
+};
+template <int NP>
+static __device__ __forceinline__ f32x4 am_mma(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+    if constexpr (NP == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool HASQ, bool ARGS, bool MULTI, int NP = 1>   // MULTI = false: one group (V <= 48), the group arithmetic folds away
 __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
     const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
     const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_maxV,
-    float* __restrict__ out_maxQ, int a_per_block, AlignArgs xa) {
-    constexpr int d = 128, KCH = 4, RT = 6;
+    float* __restrict__ out_maxQ, int a_per_block, AlignArgs xa, AlignParts parts) {
+    constexpr int d = 128, KCH = 4, RT = NP == 2 ? 3 : 6;
     constexpr unsigned BIG = 0x7000u;
-    __shared__ uint4 tiles[2][kAMSlots];
+    __shared__ uint4 tiles[2][NP][kAMSlots];
+    float unscale = 1.f;
+    if constexpr (NP == 2) unscale = parts.inv[0] * parts.inv[1];
+    auto fin = [&](float m) { return NP == 2 ? (m == neg_inf ? neg_inf : m * unscale) : m; };   // a stored maximum
     __shared__ unsigned long long kmask_s[2];   // region-side keep bits of the staged image (bit v), by wave 0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything that depends on the caption lives in SGPRs
@@ -828,17 +847,24 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
         srow[k] = r;
         sseg[k] = 2u * (unsigned)(((sl & 15) ^ (r & 15)) * 8);
     }
-    auto stage_load = [&](int st, uint4* x, unsigned& ck) {   // step st = (image, group)
+    auto stage_load = [&](int st, uint4* x, unsigned& ck) {   // step st = (image, group); x[part * NS + slot]
         const int a = MULTI ? a0 + st / NG : a0 + st, v0 = MULTI ? (st % NG) * kAMRows : 0;
-        const char* img = reinterpret_cast<const char*>(vis + (size_t)a * V * d);
         // (32-bit offsets from a scalar base; rows past V are copies of the last region: they cannot change a maximum, lose every tie)
-        x[0] = *reinterpret_cast<const uint4*>(img + (2u * (unsigned)(min(v0 + srow[0], V - 1) * d) + sseg[0]));
-        if (has2) x[1] = *reinterpret_cast<const uint4*>(img + (2u * (unsigned)(min(v0 + srow[1], V - 1) * d) + sseg[1]));
+        const unsigned o0 = 2u * (unsigned)(min(v0 + srow[0], V - 1) * d) + sseg[0], o1 = 2u * (unsigned)(min(v0 + srow[1], V - 1) * d) + sseg[1];
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            const char* img = reinterpret_cast<const char*>((pp == 0 ? vis : parts.vis_lo) + (size_t)a * V * d);
+            x[pp * NS] = *reinterpret_cast<const uint4*>(img + o0);
+            if (has2) x[pp * NS + 1] = *reinterpret_cast<const uint4*>(img + o1);
+        }
         if (vmask && tid < kAMRows) ck = vmask[(size_t)a * V + min(v0 + tid, V - 1)];
     };
     auto stage_write = [&](int buf, const uint4* x, unsigned ck) {
-        tiles[buf][tid] = x[0];
-        if (has2) tiles[buf][tid + kAMThreads] = x[1];
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            tiles[buf][pp][tid] = x[pp * NS];
+            if (has2) tiles[buf][pp][tid + kAMThreads] = x[pp * NS + 1];
+        }
         if (vmask && wave == 0) {   // (lanes 48.. hold ck = 1)
             const unsigned long long km = __builtin_amdgcn_ballot_w64(ck != 0);
             if (lane == 0) kmask_s[buf] = km;
@@ -849,18 +875,20 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
     for (int kc = 0; kc < KCH; ++kc) foff[kc] = ccol * 16 + ((kc * 4 + g) ^ ccol);
 
     for (int q0 = 0; q0 < Q; q0 += RT * 16) {   // one pass up to 96 queries
-        bf16x8 af[RT][KCH];
+        bf16x8 af[NP][RT][KCH];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const bf16x8* rowp = reinterpret_cast<const bf16x8*>(txt + ((size_t)bc * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
+        for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
-            for (int kc = 0; kc < KCH; ++kc) af[rt][kc] = rowp[kc * 4];
-        }
+            for (int rt = 0; rt < RT; ++rt) {
+                const bf16x8* rowp = reinterpret_cast<const bf16x8*>((pp == 0 ? txt : parts.txt_lo) + ((size_t)bc * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) af[pp][rt][kc] = rowp[kc * 4];
+            }
         // Masks (masked_fill_ of joint.py:417-418) are applied per element only along the axis a maximum runs over -- queries in
         // S (rows 16 rt + 4 g + n: bit 4 rt + n of tkeep; only the row tiles that have a masked query, rt_masked, wave-uniform),
         // regions in S^T -- and to the RESULT for the other axis: a masked query's row of S^T is all neg_inf, so its maximum
         // is neg_inf at position 0 (tkeepT: bit rt = query 16 rt + ccol), likewise a masked region's column of S.
-        unsigned tkeep = 0xffffffu, tkeepT = 0x3fu, rt_masked = 0;
+        unsigned tkeep = (1u << (4 * RT)) - 1u, tkeepT = (1u << RT) - 1u, rt_masked = 0;
         if (tmask) {
             tkeep = 0;
             tkeepT = 0;
@@ -876,7 +904,9 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                 if (__builtin_amdgcn_ballot_w64(((tkeep >> (rt * 4)) & 15u) != 15u) != 0) rt_masked |= 1u << rt;
         }
         const bool t_any = rt_masked != 0;   // (wave-uniform)
-        uint4 xs[NS] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        uint4 xs[NP * NS];
+#pragma unroll
+        for (int k = 0; k < NP * NS; ++k) xs[k] = make_uint4(0, 0, 0, 0);
         unsigned ck = 1;
         if (n_step > 0) {
             stage_load(0, xs, ck);
@@ -890,7 +920,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
             const int a = MULTI ? a0 + i / NG : a0 + i, grp = MULTI ? i % NG : 0, v0 = grp * kAMRows, buf = i & 1;
             if (i + 1 < n_step) stage_write(buf ^ 1, xs, ck);       // tile i+1: loaded during the previous step's MFMAs
             if (i + 2 < n_step) stage_load(i + 2, xs, ck);          // tile i+2: lands during this step's MFMAs
-            const uint4* tb = tiles[buf];
+            const uint4* tb = tiles[buf][0];
             // region-side keep bits: S column 16 ct + ccol (bit ct of ckl), S^T rows 16 ct + 4 g + n (bit 4 ct + n of cklT);
             // the image's 48-bit mask is wave-uniform, the per-lane views are only built for an image that has masked regions
             unsigned ckl = 7u, cklT = 0xfffu;
@@ -907,11 +937,42 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
             }
             float* const rowV = out_maxV + ((size_t)bc * A + a) * Q + q0;          // wave-uniform bases
             uint16_t* const rowA = ARGS ? xa.argV + ((size_t)bc * A + a) * Q + q0 : nullptr;
-            bf16x8 bfr[3][KCH];
+            // NP = 1: the image's fragments stay in registers for both products (48).  NP = 2: hi | lo of all three region tiles would be 96
+            // registers next to the 96 of the caption: a region tile's fragments are read when it is used (once per product), and the S^T
+            // tiles of the pass (36 accumulators) are computed region tile by region tile before their maxima are taken query tile by query tile.
+            bf16x8 bfr[NP == 1 ? 3 : 1][KCH];
+            if constexpr (NP == 1) {
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct)
+                for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-                for (int kc = 0; kc < KCH; ++kc) bfr[ct][kc] = *reinterpret_cast<const bf16x8*>(tb + ct * 256 + foff[kc]);
+                    for (int kc = 0; kc < KCH; ++kc) bfr[ct][kc] = *reinterpret_cast<const bf16x8*>(tb + ct * 256 + foff[kc]);
+            }
+            auto frag = [&](int pp, int ct, int kc) { return *reinterpret_cast<const bf16x8*>(tb + pp * kAMSlots + ct * 256 + foff[kc]); };
+            f32x4 stA[NP == 2 ? RT : 1][3];
+            if constexpr (NP == 2) {
+                if (out_maxV) {
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) {
+                        bf16x8 bh[KCH], bl[KCH];
+#pragma unroll
+                        for (int kc = 0; kc < KCH; ++kc) {
+                            bh[kc] = frag(0, ct, kc);
+                            bl[kc] = frag(1, ct, kc);
+                        }
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int kc = 0; kc < KCH; ++kc) {   // the two small terms first
+                                t = am_mma<NP>(bl[kc], af[0][rt][kc], t);
+                                t = am_mma<NP>(bh[kc], af[NP - 1][rt][kc], t);
+                                t = am_mma<NP>(bh[kc], af[0][rt][kc], t);
+                            }
+                            stA[rt][ct] = t;
+                        }
+                    }
+                }
+            }
             // ---- maxima over the regions: S^T, one query tile at a time ----
             // (tools/time_argmax_ablation.sh: -DVLG_ABL_AM_NOST / _NOS drop one of the two products, _NOSEARCH the first-equal searches -- wrong
             //  results, measured ceilings: DESIGN.md section 3.1a)
@@ -925,10 +986,14 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                 f32x4 st[3];   // rows = regions 16 ct + 4 g + n, column = query 16 rt + ccol
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) {
-                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (NP == 2) {
+                        st[ct] = stA[rt][ct];
+                    } else {
+                        f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kc = 0; kc < KCH; ++kc) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ct][kc], af[rt][kc], t, 0, 0, 0);
-                    st[ct] = t;
+                        for (int kc = 0; kc < KCH; ++kc) t = am_mma<NP>(bfr[ct][kc], af[0][rt][kc], t);
+                        st[ct] = t;
+                    }
                 }
                 VLG_AM_MFMA_DRAIN3(st[0], st[1], st[2]);
                 if (v_any) {   // wave-uniform: this image has masked regions
@@ -972,17 +1037,28 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
             // every lane of a column holds the six results of its column: row group g stores query tiles g and 4 + g, so that
             // a store instruction writes 64 (32) consecutive queries
             if (b < B && grp == NG - 1) {
-                const float m_lo = g == 0 ? mrow[0] : g == 1 ? mrow[1] : g == 2 ? mrow[2] : mrow[3];
-                const unsigned i_lo = g == 0 ? irow[0] : g == 1 ? irow[1] : g == 2 ? irow[2] : irow[3];
-                const float m_hi = g == 0 ? mrow[4] : mrow[5];
-                const unsigned i_hi = g == 0 ? irow[4] : irow[5];
-                if (q0 + lane < Q) {
-                    rowV[lane] = m_lo;
+                float m_lo;
+                unsigned i_lo;
+                if constexpr (RT == 6) {
+                    m_lo = g == 0 ? mrow[0] : g == 1 ? mrow[1] : g == 2 ? mrow[2] : mrow[RT - 3];
+                    i_lo = g == 0 ? irow[0] : g == 1 ? irow[1] : g == 2 ? irow[2] : irow[RT - 3];
+                } else {   // (three tiles: row group 3 stores nothing)
+                    const float m01 = g == 0 ? mrow[0] : mrow[1];
+                    const unsigned i01 = g == 0 ? irow[0] : irow[1];
+                    m_lo = g >= 2 ? mrow[2] : m01;
+                    i_lo = g >= 2 ? irow[2] : i01;
+                }
+                if (lane < 16 * RT && q0 + lane < Q) {
+                    rowV[lane] = fin(m_lo);
                     if (ARGS) rowA[lane] = (uint16_t)i_lo;
                 }
-                if (lane < 32 && q0 + 64 + lane < Q) {
-                    rowV[64 + lane] = m_hi;
-                    if (ARGS) rowA[64 + lane] = (uint16_t)i_hi;
+                if constexpr (RT == 6) {
+                    const float m_hi = g == 0 ? mrow[RT - 2] : mrow[RT - 1];
+                    const unsigned i_hi = g == 0 ? irow[RT - 2] : irow[RT - 1];
+                    if (lane < 32 && q0 + 64 + lane < Q) {
+                        rowV[64 + lane] = fin(m_hi);
+                        if (ARGS) rowA[64 + lane] = (uint16_t)i_hi;
+                    }
                 }
             }
             }   // out_maxV
@@ -995,14 +1071,31 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) {
                     f32x4 sq[RT];   // rows = queries 16 rt + 4 g + n, column = region 16 ct + ccol
+                    bf16x8 bh[KCH], bl[NP == 2 ? KCH : 1];
+#pragma unroll
+                    for (int kc = 0; kc < KCH; ++kc) {
+                        if constexpr (NP == 2) {
+                            bh[kc] = frag(0, ct, kc);
+                            bl[kc] = frag(1, ct, kc);
+                        } else {
+                            bh[kc] = bfr[ct][kc];
+                        }
+                    }
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
                         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][kc], bfr[ct][kc], acc, 0, 0, 0);
+                        for (int kc = 0; kc < KCH; ++kc) {
+                            if constexpr (NP == 2) {
+                                acc = am_mma<NP>(af[NP - 1][rt][kc], bh[kc], acc);
+                                acc = am_mma<NP>(af[0][rt][kc], bl[kc], acc);
+                            }
+                            acc = am_mma<NP>(af[0][rt][kc], bh[kc], acc);
+                        }
                         sq[rt] = acc;
                     }
-                    VLG_AM_MFMA_DRAIN6(sq[0], sq[1], sq[2], sq[3], sq[4], sq[5]);
+                    if constexpr (RT == 6) VLG_AM_MFMA_DRAIN6(sq[0], sq[1], sq[2], sq[3], sq[4], sq[5]);
+                    else VLG_AM_MFMA_DRAIN3(sq[0], sq[1], sq[2]);
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
                         if ((rt_masked >> rt) & 1u) {   // wave-uniform: this row tile has a masked query
@@ -1011,9 +1104,15 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                             for (int n = 0; n < 4; ++n) sq[rt][n] = am_keep(tkeep, rt * 4 + n, sq[rt][n], neg_inf);
                         }
                     const float u0 = am_max3(am_max3(sq[0][0], sq[0][1], sq[0][2]), am_max3(sq[0][3], sq[1][0], sq[1][1]), am_max3(sq[1][2], sq[1][3], sq[2][0]));
-                    const float u1 = am_max3(am_max3(sq[2][1], sq[2][2], sq[2][3]), am_max3(sq[3][0], sq[3][1], sq[3][2]), am_max3(sq[3][3], sq[4][0], sq[4][1]));
-                    const float u2 = am_max3(sq[4][2], sq[4][3], sq[5][0]), u3 = am_max3(sq[5][1], sq[5][2], sq[5][3]);
-                    float m = am_max3(u0, u1, am_max3(u2, u3, u3));
+                    float m;
+                    if constexpr (RT == 6) {
+                        const float u1 = am_max3(am_max3(sq[2][1], sq[2][2], sq[2][3]), am_max3(sq[RT - 3][0], sq[RT - 3][1], sq[RT - 3][2]), am_max3(sq[RT - 3][3], sq[RT - 2][0], sq[RT - 2][1]));
+                        const float u2 = am_max3(sq[RT - 2][2], sq[RT - 2][3], sq[RT - 1][0]), u3 = am_max3(sq[RT - 1][1], sq[RT - 1][2], sq[RT - 1][3]);
+                        m = am_max3(u0, u1, am_max3(u2, u3, u3));
+                    } else {
+                        const float u1 = am_max3(sq[2][1], sq[2][2], sq[2][3]);
+                        m = am_max3(u0, u1, u1);
+                    }
                     m = am_xg_max(m);
                     // position code 4 rt + n (query 16 rt + 4 g + n; 80.. is no inline constant), later row tiles first
                     unsigned qi = 0;
@@ -1022,8 +1121,10 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
 #else
                     if (ARGS) {
 #endif
-                        unsigned qc = am_first_eq12<12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23>(BIG, m, sq[3][0], sq[3][1], sq[3][2], sq[3][3], sq[4][0],
-                                                                                                     sq[4][1], sq[4][2], sq[4][3], sq[5][0], sq[5][1], sq[5][2], sq[5][3]);
+                        unsigned qc = BIG;
+                        if constexpr (RT == 6)
+                            qc = am_first_eq12<12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23>(BIG, m, sq[RT - 3][0], sq[RT - 3][1], sq[RT - 3][2], sq[RT - 3][3], sq[RT - 2][0],
+                                                                                                sq[RT - 2][1], sq[RT - 2][2], sq[RT - 2][3], sq[RT - 1][0], sq[RT - 1][1], sq[RT - 1][2], sq[RT - 1][3]);
                         qc = am_first_eq12<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11>(qc, m, sq[0][0], sq[0][1], sq[0][2], sq[0][3], sq[1][0], sq[1][1], sq[1][2],
                                                                                  sq[1][3], sq[2][0], sq[2][1], sq[2][2], sq[2][3]);
                         qi = ((qc & ~3u) << 2) + (qc & 3u) + (unsigned)crow;   // BIG stays far above every query
@@ -1037,8 +1138,9 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
                     const int v = v0 + ct * 16 + ccol;
                     if (b < B && lane < 16 && v < V) {
                         float* const colV = out_maxQ + ((size_t)bc * A + a) * V;   // wave-uniform bases
-                        if (q0 == 0 || m > colV[v]) {   // later passes (Q > 96) only win with a strictly larger value
-                            colV[v] = m;
+                        const float mu = fin(m);
+                        if (q0 == 0 || mu > colV[v]) {   // later passes (Q > 16 RT) only win with a strictly larger value
+                            colV[v] = mu;
                             if (ARGS) xa.argQ[((size_t)bc * A + a) * V + v] = (uint16_t)qi;
                         }
                     }
@@ -1057,10 +1159,11 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
 // running maxima over the regions and the NW of them meet at the end (larger value, then SMALLER region: the first position).  With one
 // wavefront the shipped factor layout's 29 groups of 48 columns were walked serially by 64 wavefronts on the whole chip: 404 us.
 constexpr int kPdP = 49, kPdRT = 6;
+template <int NP>   // NP = 2: float32 features on two fp16 parts (see align_argmax_kernel); the scores are unscaled BEFORE the prior is subtracted
 __global__ __launch_bounds__(256) void align_prior_diag_kernel(
     const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
     const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_maxV,
-    float* __restrict__ out_maxQ, AlignArgs xa) {
+    float* __restrict__ out_maxQ, AlignArgs xa, AlignParts parts) {
     constexpr int d = 128, KCH = 4, RT = kPdRT, P = kPdP;
     extern __shared__ __attribute__((aligned(16))) float pd_smem[];   // [NW][RT 16 P] score tiles, then [NW][128] (max, position) pairs
     __shared__ uint8_t kq_s[RT * 16], kv_s[4][48];
@@ -1093,8 +1196,22 @@ __global__ __launch_bounds__(256) void align_prior_diag_kernel(
                         const int v = min(v0 + ct * 16 + ccol, V - 1);
                         const bf16x8* bp = reinterpret_cast<const bf16x8*>(vis + ((size_t)a * V + v) * d + g * 8);
                         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (NP == 2) {
+                            const bf16x8* al = reinterpret_cast<const bf16x8*>(parts.txt_lo + ((size_t)b * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
+                            const bf16x8* bl = reinterpret_cast<const bf16x8*>(parts.vis_lo + ((size_t)a * V + v) * d + g * 8);
 #pragma unroll
-                        for (int kc = 0; kc < KCH; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[kc * 4], bp[kc * 4], acc, 0, 0, 0);
+                            for (int kc = 0; kc < KCH; ++kc) {
+                                acc = am_mma<2>(al[kc * 4], bp[kc * 4], acc);
+                                acc = am_mma<2>(ap[kc * 4], bl[kc * 4], acc);
+                            }
+                        }
+#pragma unroll
+                        for (int kc = 0; kc < KCH; ++kc) acc = am_mma<NP>(ap[kc * 4], bp[kc * 4], acc);
+                        if constexpr (NP == 2) {
+                            const float un = parts.inv[0] * parts.inv[1];
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) acc[n] *= un;
+                        }
                         const unsigned vk = kv_s[wave][ct * 16 + ccol];
                         const float* pen_v = pen_b + xa.seg_of_v[v];
 #pragma unroll
@@ -1345,6 +1462,90 @@ static int launch_align_full(const void* txt, const void* vis, const uint8_t* tm
     return check_launch("align_full_kernel");
 }
 
+// ---- float32 features -> two fp16 parts under one power-of-two scale per tensor (round 5; see align_argmax_kernel<NP = 2>) ----
+// blockIdx.y = tensor (0: txt [n0 floats], 1: vis [n1 floats]).  First the 64 per-workgroup maxima of |x|, then the split: s = 2^k with
+// |x|max s in [2^14, 2^15); an element 2^-j below the maximum keeps min(22, 39 - j) bits.
+constexpr int kSplitBlocks = 64;
+__global__ __launch_bounds__(256) void align_absmax_kernel(const float* __restrict__ x0, size_t n0, const float* __restrict__ x1, size_t n1,
+                                                           float* __restrict__ part) {
+    __shared__ float red[4];
+    const float* x = blockIdx.y ? x1 : x0;
+    const size_t n4 = (blockIdx.y ? n1 : n0) >> 2;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)kSplitBlocks * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.y * kSplitBlocks + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void align_split_kernel(const float* __restrict__ x0, size_t n0, const float* __restrict__ x1, size_t n1,
+                                                          const float* __restrict__ part, uint16_t* __restrict__ hi0, uint16_t* __restrict__ lo0,
+                                                          uint16_t* __restrict__ hi1, uint16_t* __restrict__ lo1, float* __restrict__ inv) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    const int t = blockIdx.y;
+    float m = part[t * kSplitBlocks + (threadIdx.x & 63)];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    int k = m > 0.f ? 14 - ((int)((__float_as_uint(m) >> 23) & 0xffu) - 127) : 0;
+    k = k < -110 ? -110 : (k > 110 ? 110 : k);
+    const float sc = __uint_as_float((uint32_t)(127 + k) << 23);
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv[t] = __uint_as_float((uint32_t)(127 - k) << 23);
+    const float* x = t ? x1 : x0;
+    uint16_t *hi = t ? hi1 : hi0, *lo = t ? lo1 : lo0;
+    const size_t n4 = (t ? n1 : n0) >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f2 a = {v[0] * sc, v[1] * sc}, b = {v[2] * sc, v[3] * sc};
+        const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
+        const h2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f2), h2), lb = __builtin_convertvector(b - __builtin_convertvector(hb, f2), h2);
+        reinterpret_cast<uint2*>(hi)[i] = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
+        reinterpret_cast<uint2*>(lo)[i] = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+    }
+}
+
+// maxima + positions of float32 features (d = 128) on two fp16 parts: scratch = hi | lo of txt [B Q 128] and vis [A V 128] (uint16), then 128 partial
+// maxima and the two inverse scales (floats): (B Q + A V) 128 floats + 256 floats in all
+static int launch_align_argmax_f32(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A, int Q, int V,
+                                   float neg_inf, float* out_maxV, float* out_maxQ, hipStream_t s, AlignArgs xa, float* scratch) {
+    const size_t n0 = (size_t)B * Q * 128, n1 = (size_t)A * V * 128;
+    uint16_t* th = reinterpret_cast<uint16_t*>(scratch);
+    uint16_t *tl = th + n0, *vh = tl + n0, *vl = vh + n1;
+    float* part = scratch + (n0 + n1);
+    float* inv = part + 2 * kSplitBlocks;
+    hipLaunchKernelGGL(align_absmax_kernel, dim3(kSplitBlocks, 2), dim3(256), 0, s, (const float*)txt, n0, (const float*)vis, n1, part);
+    hipLaunchKernelGGL(align_split_kernel, dim3(256, 2), dim3(256), 0, s, (const float*)txt, n0, (const float*)vis, n1, part, th, tl, vh, vl, inv);
+    if (int rc = check_launch("align_split_kernel")) return rc;
+    const AlignParts parts{tl, vl, inv};
+    const int by = (B + kAMWaves - 1) / kAMWaves;
+    const int ng = (V + kAMRows - 1) / kAMRows;
+    int a_per_block = (int)(((long)A * by + 255) / 256);
+    if (a_per_block < (8 + ng - 1) / ng) a_per_block = (8 + ng - 1) / ng;
+    if (a_per_block > A) a_per_block = A;
+    dim3 grid((A + a_per_block - 1) / a_per_block, by);
+#define VLG_AAM2(HQ, MU)                                                                                                      \
+    hipLaunchKernelGGL((align_argmax_kernel<HQ, true, MU, 2>), grid, dim3(kAMThreads), 0, s, th, vh, tmask, vmask, B, A, Q, V, neg_inf, out_maxV, \
+                       out_maxQ, a_per_block, xa, parts)
+    if (out_maxQ) { if (ng > 1) VLG_AAM2(true, true); else VLG_AAM2(true, false); }
+    else { if (ng > 1) VLG_AAM2(false, true); else VLG_AAM2(false, false); }
+#undef VLG_AAM2
+    if (int rc = check_launch("align_argmax_kernel (fp16 parts)")) return rc;
+    if (xa.pen) {
+        const int pd_nw = ng >= 4 ? 4 : 1;
+        const size_t pd_lds = sizeof(float) * ((size_t)pd_nw * kPdRT * 16 * kPdP + (size_t)pd_nw * 256);
+        hipError_t pe = hipFuncSetAttribute(reinterpret_cast<const void*>(align_prior_diag_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds);
+        if (pe != hipSuccess) return set_error((int)pe, "hipFuncSetAttribute: %s", hipGetErrorString(pe));
+        hipLaunchKernelGGL(align_prior_diag_kernel<2>, dim3(std::min(A, B)), dim3(64 * pd_nw), pd_lds, s, th, vh, tmask, vmask, B, A, Q, V, neg_inf, out_maxV,
+                           out_maxQ, xa, parts);
+        return check_launch("align_prior_diag_kernel (fp16 parts)");
+    }
+    return 0;
+}
+
 template <bool ARGS>
 static int launch_align_max(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, int B, int A, int Q,
                             int V, float neg_inf, float* out_maxV, float* out_maxQ, hipStream_t s,
@@ -1364,7 +1565,7 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
             if (out_maxQ)
 #define VLG_AAM(HQ, MU)                                                                                                       \
     hipLaunchKernelGGL((align_argmax_kernel<HQ, true, MU>), grid, dim3(kAMThreads), 0, s, (const uint16_t*)txt, (const uint16_t*)vis, tmask, \
-                       vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa)
+                       vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, a_per_block, xa, AlignParts{nullptr, nullptr, nullptr})
                 { if (ng > 1) VLG_AAM(true, true); else VLG_AAM(true, false); }
             else
                 { if (ng > 1) VLG_AAM(false, true); else VLG_AAM(false, false); }
@@ -1373,10 +1574,10 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
                 if (int rc = check_launch("align_argmax_kernel")) return rc;
                 const int pd_nw = ng >= 4 ? 4 : 1;   // wavefronts per diagonal pair: the region groups of a many-column image are dealt round
                 const size_t pd_lds = sizeof(float) * ((size_t)pd_nw * kPdRT * 16 * kPdP + (size_t)pd_nw * 256);
-                hipError_t pe = hipFuncSetAttribute(reinterpret_cast<const void*>(align_prior_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds);
+                hipError_t pe = hipFuncSetAttribute(reinterpret_cast<const void*>(align_prior_diag_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds);
                 if (pe != hipSuccess) return set_error((int)pe, "hipFuncSetAttribute: %s", hipGetErrorString(pe));
-                hipLaunchKernelGGL(align_prior_diag_kernel, dim3(std::min(A, B)), dim3(64 * pd_nw), pd_lds, s, (const uint16_t*)txt, (const uint16_t*)vis,
-                                   tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, xa);
+                hipLaunchKernelGGL(align_prior_diag_kernel<1>, dim3(std::min(A, B)), dim3(64 * pd_nw), pd_lds, s, (const uint16_t*)txt, (const uint16_t*)vis,
+                                   tmask, vmask, B, A, Q, V, neg_inf, out_maxV, out_maxQ, xa, AlignParts{nullptr, nullptr, nullptr});
                 return check_launch("align_prior_diag_kernel");
             }
             return check_launch("align_argmax_kernel");
@@ -2240,6 +2441,8 @@ int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, c
     else if (!f32in && d == 128) VLG_GA(false, 4);
     else if (!f32in && d == 64) VLG_GA(false, 2);
     else if (!f32in && d == 32) VLG_GA(false, 1);
+    else if (f32in && d == 128 && Q <= 65535 && !VLG_ENV("VLG_ALIGN_F32_EXACT"))   // two fp16 parts per feature on the shared-image-tile kernel
+        rc = launch_align_argmax_f32(txt, vis, tmask, vmask, B, B, Q, V, neg_inf, wsf + p.off_maxV, wsf + p.off_maxQ, s, xa, wsf + p.off_parts);
     else if (f32in && d == 128) VLG_GA(true, 8);
     else if (f32in && d == 64) VLG_GA(true, 4);
     else if (f32in && d == 32) VLG_GA(true, 2);

@@ -10,7 +10,7 @@ int ground_dense_split_txt(int B, int V);
 
 // Scratch carving for vlg_grounding_loss (offsets in floats from the workspace base).
 struct GroundPlan {
-    size_t off_maxV, off_maxQ, off_part, off_coef, off_argV, off_argQ, off_featT, off_partial, bytes;
+    size_t off_maxV, off_maxQ, off_part, off_coef, off_argV, off_argQ, off_featT, off_partial, off_parts, bytes;   // (offsets in floats)
     GroundPlan(int B, int Q, int V);
 };
 

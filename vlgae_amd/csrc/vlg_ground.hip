@@ -1500,7 +1500,9 @@ GroundPlan::GroundPlan(int B, int Q, int V) {
     const size_t KtV = V > 64 ? (size_t)(V + 127) / 128 * 128 : 64;
     off_partial = off_featT + (dense ? up((size_t)B * 128 * (KtV + 96) / 2) : 0);
     const size_t partial = dense && V > 64 ? (size_t)ground_dense_split_txt(B, V) * B * Q * 128 : 0;
-    bytes = sizeof(float) * (off_partial + up(partial));
+    // float32 features on two fp16 parts (align_argmax_kernel<NP = 2>): hi | lo of txt and vis (d <= 128), 2 x 64 partial maxima, 2 inverse scales
+    off_parts = off_partial + up(partial);
+    bytes = sizeof(float) * (off_parts + up((size_t)B * (Q + V) * 128) + 256);
 }
 
 int launch_grounding_tail(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marg,
