@@ -429,8 +429,14 @@ def train_step_entry(B, L, V, dtype, dev, wiring="reference", factors=()):
     res.update(graph_ms=graph_ms, sentences_per_s_graph=B / (graph_ms * 1e-3),
                note="graph replay has no host work between kernels: graph_ms is the device time of the chain; "
                     "eager_ms - graph_ms is what the Python / autograd host path still costs")
-    if wiring == "reference" and not factors:
+    if wiring == "reference" and not factors and dtype != torch.float32:
         del gr, step
+        try:   # the same step in float32 (the reference's `precision: 32`, config/trainer/train.yaml:20): split-K weight gradients on three bf16 products,
+            # arc trilinear and arg-max alignment on two fp16 parts per operand (three MFMAs per product; float32-level results)
+            c = train_step_entry(B, L, V, torch.float32, dev)
+            res["float32"] = {"graph_ms": c["graph_ms"], "eager_ms": c["eager_ms"], "ratio_to_this_dtype": c["graph_ms"] / graph_ms}
+        except Exception as e:
+            res["float32"] = {"error": repr(e)[:200]}
         try:   # the same step at the shipped factor layout (add_rel / add_attr / add_image, B = 64 as config/data/vlparse.yaml:24-27 batches it)
             c = train_step_entry(64, L, V, dtype, dev, factors=("rel", "attr", "img"))
             res["shipped_factor_layout"] = {k: c[k] for k in ("graph_ms", "eager_ms", "sentences_per_s_graph", "what")}
