@@ -267,6 +267,38 @@ def test_dmv1o_properties_full_size(ts, oracle_mod):
             assert np.abs(ca.cpu().numpy()[pick] - rga).max() <= MARG_TOL and np.abs(cd.cpu().numpy()[pick] - rgd).max() <= MARG_TOL
 
 
+def test_dmv1o_batch_of_2048_equals_its_eight_shards(ts, oracle_mod):
+    """BASELINE.json configs[2] on ONE GPU (B = 2048, L = 40, bf16 potentials; eight GPUs are the driver's to launch): the batch is sharded
+    along dim 0 with no data-path exchange (`vlgae_amd.dist.shard_batch`), so the launch over all 2048 sentences must equal the eight
+    256-sentence launches a node would run -- bit for bit, logZ and every expected count (a workgroup sees one sentence) -- the flat
+    gradient buffer summed over the shards must equal the full batch's, and a slice spread over the shards meets the fp64 oracle."""
+    from vlgae_amd import dist as vdist
+    from vlgae_amd.torch_struct import functional as F
+    B, L, W = 2048, 40, 8
+    gen = torch.Generator().manual_seed(2048)
+    md, ma = ts.DMV1o.merge(torch.randn(B, L, 2, 2, 2, generator=gen).log_softmax(-1).to(dev()), torch.randn(B, L, L, 2, generator=gen).to(dev()),
+                            torch.randn(B, L, generator=gen).log_softmax(-1).to(dev()))
+    dec, attach = md.bfloat16(), ma.bfloat16()
+    lengths = torch.randint(L // 2, L + 1, (B,), generator=gen)
+    lengths[::256] = L
+    lengths = lengths.to(dev())
+    lz, cd, ca = F.dmv1o_run(dec, attach, lengths, 0, True)
+    total = torch.zeros_like(cd[0])
+    for r in range(W):
+        sd, sa, sl = vdist.shard_batch([dec, attach, lengths], r, W)
+        s, e = vdist.shard_bounds(B, r, W)
+        assert e - s == B // W
+        z, gd, ga = F.dmv1o_run(sd.contiguous(), sa.contiguous(), sl.contiguous(), 0, True)
+        assert torch.equal(z, lz[s:e]) and torch.equal(gd, cd[s:e]) and torch.equal(ga, ca[s:e]), r
+        total += gd.sum(0)
+    assert torch.allclose(total, cd.sum(0), rtol=1e-5, atol=1e-3)   # what the all-reduce of the shards' flat buffers adds up to
+    pick = np.array([0, 255, 256, 777, 1024, 1500, 2047])
+    rlz, rgd, rga = oracle_mod.dmv1o(dec[pick].float().cpu().numpy(), attach[pick].float().cpu().numpy(), lengths[pick].cpu().numpy(), "log", np.float64)
+    rlz = np.asarray(rlz).reshape(-1)
+    assert (np.abs(lz.float().cpu().numpy().reshape(B, -1)[pick, 0] - rlz) <= logz_tol(rlz)).all()
+    assert np.abs(ca.cpu().numpy()[pick] - rga).max() <= MARG_TOL and np.abs(cd.cpu().numpy()[pick] - rgd).max() <= MARG_TOL
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_dmv1o_long_sentences_full_size(ts, oracle_mod, dt):
     """BASELINE.json configs[3] (B=256, L=80): the overlay placement (value charts in LDS for the inside pass, copied to
