@@ -164,7 +164,10 @@ int vlg_bilinear_align_backward(const float* grad_out, const void* txt, const vo
  *   out_sums[3] = {txt2vis, vis2txt, total} (device, fp32); g_txt [B,Q,d], g_vis [B,V,d] = d total / d features (fp32,
  *   both or either may be NULL).  The gradient passes through the first arg-max of each maximum and only where both
  *   masks are on.  txt, vis in in_dtype; marginal [B,Q] fp32; masks uint8 or NULL; d in {32, 64, 128}.
- *   ws: vlg_grounding_loss_workspace(B, Q, V) bytes.  No atomics: results are bit-reproducible. */
+ *   ws: vlg_grounding_loss_workspace(B, Q, V) bytes.  No atomics: results are bit-reproducible.
+ *   Round 5, in_dtype = VLG_F32 with d = 128 (the reference's `precision: 32`, config/trainer/train.yaml:20): the alignment's maxima and
+ *   positions are taken on two fp16 parts per feature under one power-of-two scale per tensor, three matrix-core products per pair
+ *   (2^-22 relative: float32's own level; 1.18 -> 0.36 ms at B = 256, Q = 82, V = 36); the workspace holds the split features. */
 size_t vlg_grounding_loss_workspace(int B, int Q, int V);
 int vlg_grounding_loss(const void* txt, const void* vis, const uint8_t* tmask, const uint8_t* vmask, const float* marginal,
                        const float* pen, const uint8_t* seg_of_v, int n_seg, int B, int Q, int V, int d, int in_dtype,
@@ -210,7 +213,10 @@ int vlg_trilinear(const void* child, const void* w, const void* parent, int M, i
 
 /* The same with a caller-owned scratch for fixed-order partial sums (vlg_trilinear_workspace bytes; 0 = none needed): for bf16 and
  * H = Y = 128 the x range is then split over ~one workgroup per CU (slabs added in a fixed order by a second launch) instead of
- * two ranges met by atomics.  ws may be NULL / too small: the call then behaves like vlg_trilinear. */
+ * two ranges met by atomics.  ws may be NULL / too small: the call then behaves like vlg_trilinear.
+ * Round 5, in_dtype = VLG_F32 with H = Y = 128, M >= 1024: with the workspace the product runs on two fp16 parts per operand row under
+ * power-of-two row scales (three v_mfma_f32_16x16x32_f16 per pair, 2^-22 relative) instead of v_mfma_f32_16x16x4_f32: 444 -> 145 us at
+ * M = 10 496, closer to float64 than the fp32 MFMAs; vlg_trilinear_backward(_g) likewise for X = H = Y = 128 (its workspace query covers it). */
 size_t vlg_trilinear_workspace(int M, int X, int H, int Y, int in_dtype);
 int vlg_trilinear_ws(const void* child, const void* w, const void* parent, int M, int X, int H, int Y, int in_dtype, void* ws,
                      size_t ws_bytes, float* out, void* stream);
