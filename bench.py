@@ -12,7 +12,8 @@ grad_dec [B,N,2,2,2] / grad_attach [B,N,N,2] -- what `torch.autograd.grad(DMV1o(
 costs in the reference (src/model/joint.py:254-255).  With N > 1 ranks every rank owns 256 sentences (weak
 scaling, global batch 256*N, configs[2]) and each step ends with ONE RCCL all-reduce of the gradient: the
 batch-summed expected counts at the head of a flat fp32 buffer padded to the size of the VLGAE model's
-gradient (--grad-mb, default 28 MB), issued asynchronously so it overlaps the next step's
+gradient (--grad-mb, default 25.9 MB = the 6.48 M trainable floats of the shipped model's path, the buffer
+`--workload train_step` fills with real gradients), issued asynchronously so it overlaps the next step's
 kernel; all of them complete inside the timed region.  `value` is measured with that model-sized
 collective; `value_dp_grad_only` repeats the timed region with only the DP's own 14.8 KB gradient.
 
@@ -49,8 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--regions", type=int, default=36)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"], help="storage type of the potentials")
     ap.add_argument("--ragged", action="store_true", help="random lengths instead of all = L")
-    ap.add_argument("--grad-mb", type=float, default=28.0,
-                    help="dp workload: size of the all-reduced flat gradient in MB (default: the VLGAE model's ~7 M fp32 parameters)")
+    ap.add_argument("--grad-mb", type=float, default=25.92,
+                    help="dp workload: size of the all-reduced flat gradient in MB (default: the 6.48 M trainable fp32 parameters of the shipped model's path "
+                         "-- what --workload train_step all-reduces as real gradients)")
     ap.add_argument("--factors", nargs="*", default=[], choices=["rel", "attr", "img"],
                     help="train_step workload: visual factors beside the objects (shipped model: rel attr img -> 1369 columns at 36 regions)")
     ap.add_argument("--workload", default="dp", choices=["dp", "train_step"],
