@@ -153,3 +153,28 @@ def test_drop_in_import_selects_backward_on_the_calling_thread():
     assert subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True, check=True).stdout.strip() == "False"
     env["VLGAE_AMD_AUTOGRAD_THREAD"] = "engine"
     assert subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True, check=True).stdout.strip() == "True"
+
+
+def test_factor_layout_and_mask_match_the_reference_made_fixtures():
+    """`encoders.factor_layout` / `factor_mask` (the layout and mask `vis_feat_unprune` builds, joint.py:140-171) against the three trainstep
+    fixtures, whose `vis_mask`, `vis_split` and `factor_names` were produced by the reference's own method: object | relation (strict upper
+    triangle of the box-mask outer product) | attribute | image rows, in that order.  Host logic only: runs without a GPU."""
+    import glob
+    import os
+    import numpy as np
+    import torch
+    from vlgae_amd import encoders
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "trainstep_*.npz")))
+    assert len(files) == 3
+    seen = set()
+    for f in files:
+        g = np.load(f, allow_pickle=True)
+        names = [str(n) for n in g["factor_names"]]
+        add = dict(add_rel="rel" in names, add_attr="attr" in names, add_image="img" in names)
+        box_mask = torch.from_numpy(g["box_mask"]).bool()
+        off, V, split, fn = encoders.factor_layout(box_mask.shape[1], **add)
+        assert fn == names and split == [int(x) for x in g["vis_split"]] and V == g["vis_mask"].shape[1] == sum(split)
+        assert off["box"] == 0 and all((off[k] >= 0) == v for k, v in (("rel", add["add_rel"]), ("attr", add["add_attr"]), ("img", add["add_image"])))
+        assert np.array_equal(encoders.factor_mask(box_mask, **add).numpy(), g["vis_mask"].astype(bool))
+        seen.add(tuple(names))
+    assert len(seen) == 3   # obj | obj rel attr | obj rel attr img
