@@ -17,3 +17,8 @@ for name, fn, nbytes in (("fill_(1.5)", lambda: x.fill_(1.5), 4 * n), ("zero_()"
                          ("mul_ (read + write in place)", lambda: x.mul_(1.0001), 8 * n)):
     ms = ev(fn)
     print(f"{name}: {ms * 1e3:.1f} us, {nbytes / ms / 1e9:.2f} TB/s moved ({4 * n / ms / 1e9:.2f} TB/s of stores)")
+
+# pure READ streams of the same 774 MB (the cotangent of the materialised tensor is read once per gradient by the a9 backward kernels)
+for name, fn in (("sum() (read)", lambda: y.sum()), ("max() (read)", lambda: y.max()), ("dot(y, y) (read twice the bytes? no: one tensor, two operands)", lambda: torch.dot(y, y))):
+    ms = ev(fn)
+    print(f"{name}: {ms * 1e3:.1f} us, {4 * n / ms / 1e9:.2f} TB/s of reads")
