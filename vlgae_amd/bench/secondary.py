@@ -91,6 +91,23 @@ def dp_entry(B, L, dtype_name, dev, n=100):
             "exp_rate": {"achieved_Gops": ops / sec / 1e9, "peak_Gops": exp_peak / 1e9, "frac": ops / sec / exp_peak}}
 
 
+def dp_capacity_entry(B, L, dtype_name, dev):
+    """What bounds the headline: at B = 256 there is ONE workgroup per CU and a launch takes the critical path of one sentence.  Reported beside it
+    (not as `value`): single launches of 2 B and 8 B sentences (8 B = configs[2]'s batch on one GPU), where a CU holds a second workgroup --
+    the chip's capacity for this DP.  (Two B-sentence launches alternating on two HIP streams do NOT get there: 152 us per batch, measured --
+    the queues do not interleave their workgroups the way one launch does.)"""
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    res = {}
+    for mult in (2, 8):
+        launch = dp_raw(mult * B, L, dtype, dev, seed=2000 + mult)
+        sec = _events(launch, 50, 10, dev)
+        res[f"one_launch_of_{mult * B}"] = {"us": sec * 1e6, "sentences_per_s": mult * B / sec}
+        del launch
+    res["note"] = ("the headline `value` is ONE B-sentence launch at a time, as BASELINE.json quotes it (B = 256: one workgroup per CU, latency-bound); "
+                   "these figures show what a second workgroup per CU adds")
+    return res
+
+
 _KERNEL_EVIDENCE = None
 
 
@@ -144,6 +161,11 @@ def _run_all(out, args, h, dev):
     # ---- the same headline step with fp32-stored potentials (what DMV1o.merge emits, distributions.py:253-265) ----
     other = "f32" if args.dtype == "bf16" else "bf16"
     out["headline_" + other] = dp_entry(B, L, other, dev)
+
+    try:   # the chip's capacity for this DP beside the latency-bound headline
+        out["dp_capacity"] = dp_capacity_entry(B, L, args.dtype, dev)
+    except Exception as e:
+        out["dp_capacity"] = {"error": repr(e)[:200]}
 
     # ---- configs[3]: B=256 L=80 long-sentence stress, fused inside+outside ----
     if L != 80:
