@@ -313,11 +313,12 @@ class _WordOnly(torch.autograd.Function):
                 (d_b if pdt == t_b else d_b.to(t_b)) if need[3] else None, None, None)
 
 
-def lang_feat_word_only(x, lengths, w_word=None, b_word=None, drop=None, compute_dtype=None, pre=None):
+def lang_feat_word_only(x, lengths, w_word=None, b_word=None, drop=None, compute_dtype=None, pre=None, masks=True):
     """`DependencyBoxRel.lang_feat_word_only` (joint.py:193-211) -> (word_repr [B,N,d], mask [B,N] bool, mask as float32):
     root row = masked mean of the word encodings, then the word encoder (`MLP` without activation, config/model/vlgae.yaml:69-73).
     w_word [d,h] / b_word [d]: its Linear (nn.Linear layout); drop [B,1,d] float32 or None: its SharedDropout mask (training).
-    pre = `encoder_projection(x, ...)` [B,N,3d]: the shared projection (x / w_word / b_word are then not read)."""
+    pre = `encoder_projection(x, ...)` [B,N,3d]: the shared projection (x / w_word / b_word are then not read).
+    masks=False: (word_repr, None, None) -- the caller only fuses the word features (joint.py:667-674 does not read the mask): one launch less."""
     if lengths.dtype != torch.int64:
         raise ValueError("lang_feat_word_only: lengths must be int64 [B]")
     lengths = lengths.contiguous()
@@ -337,6 +338,8 @@ def lang_feat_word_only(x, lengths, w_word=None, b_word=None, drop=None, compute
         act = _act(x, compute_dtype)
         drop = _check_drop(drop, B, 1, d, x.device)
         word = _WordOnly.apply(x, lengths, w_word, b_word, drop, act)
+    if not masks:
+        return word, None, None
     with torch.no_grad():
         marg, mask = txt_marginal_and_mask(None, None, lengths, add_marginal=False, B=B, N=L + 1)
     return word, mask[:, :L + 1], marg[:, :L + 1]

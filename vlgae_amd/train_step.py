@@ -284,7 +284,7 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         # the word | child | parent encoders' Linear on cat([masked mean, x]) ONCE: joint.py:204-209 (word-only) and :262-273 (max-tree) read the
         # same un-fused encodings through the same word encoder, under two SharedDropout masks
         pre = langfeat.encoder_projection(enc_x, lengths, P["w_enc"], P["b_enc"])
-        word0, _, _ = langfeat.lang_feat_word_only(None, lengths, drop=d0, pre=pre)                          # :667
+        word0, _, _ = langfeat.lang_feat_word_only(None, lengths, drop=d0, pre=pre, masks=False)             # :667 (the fuse reads the features only)
         x_f = align.attention_fuse(vis_feat, word0, vis_mid, enc_x, P["ln_w"], P["ln_b"], ln_eps)             # :670-674
         # ---- DiscriminativeNDMV._forward on the fused copy, ldndmv.py:171-216 ----
         if fused_ff:   # the same mathematics with folded / fused GEMMs and a hand-written adjoint
