@@ -38,6 +38,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 N_CU, SIMD_PER_CU = 256, 4
 TRANS_LANES_PER_CLK = 8        # v_exp_f32 / v_log_f32: 8 cycles per wave64 instruction per SIMD -> 8 lanes/clk
 CLOCK_GHZ = 2.4
+N_REGIONS = 5                  # timed regions per headline figure: value = the first, value_spread = min / median / max of all
 
 
 def parse_args(argv=None):
@@ -116,10 +117,24 @@ def exp_class_ops(lengths):
     return float((3 * (n ** 3 - n)).sum())
 
 
-def cpu_baseline(B, L, seed, budget_s):
+def cpu_model_string():
+    """The host CPU's model name (SURVEY.md 8d asks for it beside the core count)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
+def cpu_baseline(B, L, seed, budget_s, one_thread=True):
     """The CPU oracle (C restatement of the reference algorithm, fp32, OpenMP over sentences) timed on this
     box's host cores on a bounded sample of the same workload.  BASELINE.md section 4 relates it to the
-    reference's own PyTorch-CPU path (measured side by side in the build container)."""
+    reference's own PyTorch-CPU path (measured side by side in the build container).  SURVEY.md 8(d): the thread
+    count, the CPU model string and a 1-thread figure are reported with it."""
     import numpy as np
     import torch
     import oracle
@@ -130,17 +145,34 @@ def cpu_baseline(B, L, seed, budget_s):
     md, ma = oracle.dmv1o_merge(dec.numpy(), attach.numpy(), root.numpy())
     lengths = np.full(Bc, L, dtype=np.int64)
     oracle.dmv1o(md[:8], ma[:8], lengths[:8], "log", np.float32)      # warm
-    reps, t_total = 0, 0.0
-    while t_total < budget_s and reps < 400:
-        t0 = time.perf_counter()
-        oracle.dmv1o(md, ma, lengths, "log", np.float32)
-        t_total += time.perf_counter() - t0
-        reps += 1
-    return {"value": Bc * reps / t_total, "unit": "sentences/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x (B={Bc}, L={L}) fp32 inside+outside, C oracle (oracle/vlg_oracle.c), "
-                      f"{threads} OpenMP threads, {t_total:.1f} s",
-            "reference_equivalent_note": "the reference's own PyTorch-CPU path ran 0.08-0.12x of this port on the same "
-                                         "8 threads in the build container (BASELINE.md section 4)"}
+
+    def timed(n_sent, budget, max_reps):
+        reps, t_total = 0, 0.0
+        while t_total < budget and reps < max_reps:
+            t0 = time.perf_counter()
+            oracle.dmv1o(md[:n_sent], ma[:n_sent], lengths[:n_sent], "log", np.float32)
+            t_total += time.perf_counter() - t0
+            reps += 1
+        return reps, t_total
+
+    share_1t = 0.25 if one_thread else 0.0
+    reps, t_total = timed(Bc, budget_s * (1.0 - share_1t), 400)
+    res = {"value": Bc * reps / t_total, "unit": "sentences/s", "cores": threads, "kind": "port",
+           "cpu_model": cpu_model_string(),
+           "sample": f"{reps} x (B={Bc}, L={L}) fp32 inside+outside, C oracle (oracle/vlg_oracle.c), "
+                     f"{threads} OpenMP threads, {t_total:.1f} s",
+           "reference_equivalent_note": "the reference's own PyTorch-CPU path ran 0.08-0.12x of this port on the same "
+                                        "8 threads in the build container (BASELINE.md section 4)"}
+    if one_thread:
+        B1 = min(Bc, 64)                # a 1-thread pass over 64 sentences is ~0.1 s at L=40
+        oracle.set_threads(1)
+        try:
+            reps1, t1 = timed(B1, budget_s * share_1t, 200)
+        finally:
+            oracle.set_threads(threads)
+        res["value_1_thread"] = B1 * reps1 / t1
+        res["sample_1_thread"] = f"{reps1} x (B={B1}, L={L}), 1 OpenMP thread, {t1:.1f} s"
+    return res
 
 
 def kernel_source_id():
@@ -326,6 +358,7 @@ def run(args):
         comm.update(allreduce_ms=ar_s * 1e3, allreduce_bytes=n_model * 4,
                     allreduce_busbw_GBs=2.0 * (world - 1) / world * n_model * 4 / ar_s / 1e9)
         elapsed, gpu_ms = timed_region(big)
+        spread_s = [elapsed] + [timed_region(big)[0] for _ in range(N_REGIONS - 1)]
         small = vdist.GradAllReducer(h.n_grad, dev)
         elapsed_small, _ = timed_region(small)
         big3 = vdist.GradAllReducer(n_model, dev)
@@ -338,6 +371,9 @@ def run(args):
             assert abs(got - float(total_words.item())) < 1e-3 * float(total_words.item()), (got, float(total_words.item()))
     else:
         elapsed, gpu_ms = timed_region(None)
+        # `value` is the FIRST region (ms_per_step x steps is what was timed); the other regions only quantify the spread of a
+        # timed region this short (20 steps = 1.4 ms on the driver's command line)
+        spread_s = [elapsed] + [timed_region(None)[0] for _ in range(N_REGIONS - 1)]
         elapsed_small = None
 
     # ---- multi-GPU: the sharded training step (configs[4]) beside the DP line, on every rank ----
@@ -373,6 +409,10 @@ def run(args):
         "value": sent_per_s, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "storage_dtype": args.dtype,
+        "value_spread": dict(zip(("min", "median", "max"), (float(v) for v in np.percentile(
+            [B * world * args.steps / e for e in spread_s], [0, 50, 100]))), regions=len(spread_s),
+            note=f"{len(spread_s)} timed regions of `steps` steps each (each with its own warmup, barrier and synchronize); "
+                 "`value` is the first of them"),
         "data": "synthetic" if not dry else "DRY RUN: no kernels ran (launcher / collective plumbing on CPU, gloo); not a measurement",
         "config": {"workload": "DMV1o inside+outside (Log semiring) -> logZ + expected counts, "
                                f"B={B}/GPU L={L} N={N}, potentials stored {args.dtype}, fp32 charts and arithmetic; "

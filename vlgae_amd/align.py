@@ -690,11 +690,14 @@ class SmallMatmulGroup:
               "alpha", "accumulate", "in_dtype", "out_dtype")
 
     def __init__(self):
-        self.problems, self.first = [], None
+        self.problems, self.keep, self.first = [], [], None
 
     def add(self, a, b, out=None, alpha=1.0, bias=None, rank1=None, accumulate=False, out_dtype=None):
         args, out = _small_problem(a, b, out, alpha, bias, rank1, accumulate, out_dtype)
         self.problems.append(args)
+        # the records hold raw addresses and the kernel runs at launch(): every operand stays referenced until then (a caller's
+        # temporary -- `w.to(bf16)`, `.t()` of one -- would otherwise go back to the caching allocator and be handed to the next cast)
+        self.keep.append((a, b, out, bias, rank1))
         if self.first is None:
             self.first = a
         return out
@@ -708,7 +711,7 @@ class SmallMatmulGroup:
             for name, val in zip(self._ORDER, args):
                 setattr(rec, name, val)
         _C.check(_C.lib().vlg_small_gemm_group(arr, n, _C.stream_of(self.first)), "small_gemm_group")
-        self.problems, self.first = [], None
+        self.problems, self.keep, self.first = [], [], None     # stream order protects the operands from here on (same stream)
 
 
 def _wgrad_ok(K, M, N, dtype):

@@ -172,13 +172,22 @@ def _measure(args, rank, world, dev, dry, barrier):
             for _ in range(3):
                 run_eager(False)
         torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
+        # Capture with a process group alive (its communicator was created eagerly in dist.warm_up, before this point; the watchdog
+        # thread only polls work objects of collectives, none of which is in flight here).  capture_error_mode "thread_local": calls
+        # other threads make while this one captures (the watchdog's event queries) do not invalidate the capture.  A capture that
+        # throws anyway must not cost the line: fall back to the eager step in-process and report the mode that actually ran.
         for gi, gp in enumerate(groups):
             pending[gi] = len(gp)
-        with torch.cuda.graph(graph):
-            step(None)
-            red.flat[check:check + 1].fill_(words_local)   # (the averaged slot of the previous step is overwritten every replay)
-        assert not any(pending), pending
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                step(None)
+                red.flat[check:check + 1].fill_(words_local)   # (the averaged slot of the previous step is overwritten every replay)
+            assert not any(pending), pending
+        except Exception as e:                                 # noqa: BLE001 -- any capture failure takes the same exit
+            graph, mode = None, "eager"
+            state["capture_error"] = repr(e)[:300]
+            torch.cuda.synchronize(dev)
 
     def run(comm):
         if graph is None:
@@ -253,6 +262,8 @@ def _measure(args, rank, world, dev, dry, barrier):
         step_ms = compute_ms = el * 1e3 / args.steps
     res.update(value=B * world * args.steps / el, step_ms=step_ms, compute_ms=compute_ms, step_mode=mode,
                real_gradient_floats=n_real, allreduce_floats=n_model if world > 1 else 0)
+    if "capture_error" in state:
+        res["capture_error"] = state["capture_error"]          # graph mode was asked for and fell back to eager
     return res
 
 
@@ -278,6 +289,8 @@ def json_line(args, world, res, dry, share=False):
                                                          ": Python / autograd enqueue per step, a bucket's collective launched from a leaf hook inside the backward pass")}
     if "comm" in res:
         out["comm"] = res["comm"]
+    if "capture_error" in res:
+        out["capture_error"] = res["capture_error"]
     if dry:
         out["dry_run"] = True
     return out
