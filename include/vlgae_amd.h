@@ -236,25 +236,35 @@ int vlg_trilinear_backward_g(const void* child, const void* w, const void* paren
 /* Attention-fuse that feeds the parser -- DependencyBoxRel._forward, src/model/joint.py:670-674:
  *   att = softmax_v(vis[b] . txt[b,1:]) ; x = att . vis_mid[b] ; out = LayerNorm(enc_x + x) * gamma + beta
  *   vis [B,V,d], txt [B,L+1,d] (root slot first, skipped), vis_mid [B,V,h], enc_x [B,L,h] (in_dtype);
- *   gamma, beta [h] fp32; out [B,L,h] fp32; out_att [B,L,V] fp32 optional (NULL = skip). */
+ *   gamma, beta [h] fp32; out [B,L,h] fp32; out_att [B,L,V] fp32 optional (NULL = skip).
+ *   key_chunk: 0 = automatic -- one pass over the keys for V <= 256 (tens of regions), the key-split form above that (the shipped
+ *   factor layout of config/model/vlgae.yaml:40-42 has V = 36 + 36^2 + 36 + 1 = 1369 keys per image): chunks of keys per wavefront,
+ *   streaming-softmax records merged in chunk order; > 0 = that many keys per chunk (rounded up to a multiple of 64; >= V: one pass).
+ *   ws: vlg_attn_fuse_workspace(B, L, V, h, key_chunk) bytes of device scratch (0 when the keys are not split; NULL is fine then).
+ *   saved (optional): vlg_attn_fuse_saved_bytes(...) bytes (0 when the keys are not split) that receive the merged streaming-softmax
+ *   records of every (sentence, 16-word tile); handed to vlg_attn_fuse_backward they spare it the recomputation of the forward. */
+size_t vlg_attn_fuse_workspace(int B, int L, int V, int h, int key_chunk);
+size_t vlg_attn_fuse_saved_bytes(int B, int L, int V, int h, int key_chunk);
 int vlg_attn_fuse(const void* vis, const void* txt, const void* vis_mid, const void* enc_x, const float* gamma,
-                  const float* beta, int B, int L, int V, int d, int h, int in_dtype, float eps, float* out_att,
-                  float* out, void* stream);
+                  const float* beta, int B, int L, int V, int d, int h, int in_dtype, float eps, int key_chunk, void* ws,
+                  size_t ws_bytes, float* saved, float* out_att, float* out, void* stream);
 
 /* Adjoint of vlg_attn_fuse -- what autograd derives for src/model/joint.py:670-674 (the fuse sits inside
  * DependencyBoxRel._forward, so training back-propagates through it into the feature encoders and the LayerNorm).
  *   dout [B,L,h] fp32 = cotangent of `out`, its rows at dout + b ld_dout_b + l ld_dout_l (elements; contiguous: L h and h; the
  *   parser's context_mode 'mean' sends every position of a sentence the same row: h and 0, nothing materialised);
- *   inputs as in vlg_attn_fuse (in_dtype), gamma [h] fp32.
- *   d_vis [B,V,d], d_txt [B,L+1,d] (root slot row = 0), d_vis_mid [B,V,h], d_enc_x [B,L,h], d_gamma [h], d_beta [h]: fp32,
- *   all written (no accumulation).  Needs d, h multiples of 16 and <= 256 (VLG_ERR_SHAPE otherwise).
- *   ws: vlg_attn_fuse_backward_workspace(B, L, V, h) bytes of device scratch (softmax / score-gradient tiles, partial
- *   LayerNorm-parameter sums).  Bit-reproducible: no atomics, fixed summation orders. */
-size_t vlg_attn_fuse_backward_workspace(int B, int L, int V, int h);
+ *   inputs as in vlg_attn_fuse (in_dtype), gamma [h] fp32; key_chunk as in vlg_attn_fuse; saved: what vlg_attn_fuse wrote for the
+ *   same inputs and key_chunk, or NULL (the forward's records are then recomputed: same results).
+ *   d_vis [B,V,d], d_txt [B,L+1,d] (root slot row = 0), d_vis_mid [B,V,h], d_enc_x [B,L,h] in grad_dtype (VLG_F32, or VLG_BF16 with
+ *   bf16 inputs: rounded to nearest even once from the fp32 accumulators -- the bits an fp32 result and a cast give); d_gamma [h],
+ *   d_beta [h] fp32; all written (no accumulation).  Needs d, h multiples of 16 and <= 256 (VLG_ERR_SHAPE otherwise).
+ *   ws: vlg_attn_fuse_backward_workspace(B, L, V, d, h, grad_dtype, key_chunk) bytes of device scratch (softmax / score-gradient
+ *   tiles, partial LayerNorm-parameter sums, chunk records).  Bit-reproducible: no atomics, fixed summation orders. */
+size_t vlg_attn_fuse_backward_workspace(int B, int L, int V, int d, int h, int grad_dtype, int key_chunk);
 int vlg_attn_fuse_backward(const void* vis, const void* txt, const void* vis_mid, const void* enc_x, const float* gamma,
                            const float* dout, long long ld_dout_b, long long ld_dout_l, int B, int L, int V, int d, int h, int in_dtype,
-                           float eps, void* ws, size_t ws_bytes, float* d_vis, float* d_txt, float* d_vis_mid, float* d_enc_x,
-                           float* d_gamma, float* d_beta, void* stream);
+                           float eps, int key_chunk, int grad_dtype, const float* saved, void* ws, size_t ws_bytes, void* d_vis,
+                           void* d_txt, void* d_vis_mid, void* d_enc_x, float* d_gamma, float* d_beta, void* stream);
 
 /* Pairwise relation features of the visual encoder -- VisBoxRelSimpleEncoder.forward, src/model/vis_encoder/box_rel.py:41-45:
  *   rel[b,i,j,:] = LeakyReLU( rel_fc.linear( (inputs[b,i] + inputs[b,j]) / 2 ) )
@@ -525,7 +535,8 @@ int vlg_selftest_xlane(int* scratch, void* stream);
 /* Thread-local message for the last non-zero return on this thread ("" if none). */
 const char* vlg_last_error(void);
 
-/* Library / ABI version, e.g. 141 = 0.1.4.1 (round 5: vlg_dropout, vlg_rng_advance, vlg_vis_encoder(_backward) added, vlg_linear_wgrad takes ld_dw and in_dtype;
+/* Library / ABI version, e.g. 142 = 0.1.4.2 (round 6, 142: vlg_attn_fuse / vlg_attn_fuse_backward take key_chunk and a workspace -- the key-split form for the
+ * shipped 1369-key factor layout -- and the gradients' storage type; vlg_attn_fuse_workspace added; round 5, 141: vlg_dropout, vlg_rng_advance, vlg_vis_encoder(_backward) added, vlg_linear_wgrad takes ld_dw and in_dtype;
  * the Python binding refuses a library whose version differs from the one it was written against; round 4: vlg_langfeat_* take the activations' storage type and the SharedDropout masks,
  * vlg_langfeat_rowscale, vlg_ff_* added, vlg_ndmv_potentials* take row strides and the gradients' storage type; round 3, 120: vlg_linear_wgrad, vlg_langfeat_*, vlg_ndmv_potentials*, vlg_dmv1o_viterbi added;
  * round 2, 110: vlg_bilinear_align_backward takes a workspace; vlg_scale_counts, vlg_feed_* added). */

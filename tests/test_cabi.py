@@ -104,15 +104,21 @@ def test_attn_and_grounding_entry_points_validate_on_the_host(lib):
     one = P(16)   # any non-null pointer: validation must fail before it is dereferenced
     # attention-fuse adjoint: d, h multiples of 16 and <= 256
     bw = lib.vlg_attn_fuse_backward
-    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 24, 64, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1001
+    tail = (None, one, 1 << 30, one, one, one, one, one, one, None)
+    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 24, 64, 0, 1e-5, 0, 0, *tail) == 0x1001
     assert b"multiples of 16" in lib.vlg_last_error()
-    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 512, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1001
-    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 64, 9, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1002
-    assert bw(None, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 64, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1003
-    assert bw(one, one, one, one, one, one, 64, 2, 2, 5, 7, 32, 64, 0, 1e-5, one, 1 << 30, one, one, one, one, one, one, None) == 0x1001   # dout stride
-    need = lib.vlg_attn_fuse_backward_workspace(2, 5, 7, 64)
-    assert need > 0 and lib.vlg_attn_fuse_backward_workspace(4, 5, 7, 64) > need and lib.vlg_attn_fuse_backward_workspace(0, 5, 7, 64) == 0
-    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 64, 0, 1e-5, one, need - 1, one, one, one, one, one, one, None) == 0x1004
+    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 512, 0, 1e-5, 0, 0, *tail) == 0x1001
+    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 64, 9, 1e-5, 0, 0, *tail) == 0x1002
+    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 64, 0, 1e-5, 0, 1, *tail) == 0x1002      # bf16 gradients of fp32 inputs
+    assert b"grad_dtype" in lib.vlg_last_error()
+    assert bw(None, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 64, 0, 1e-5, 0, 0, *tail) == 0x1003
+    assert bw(one, one, one, one, one, one, 64, 2, 2, 5, 7, 32, 64, 0, 1e-5, 0, 0, *tail) == 0x1001   # dout stride
+    wsq = lib.vlg_attn_fuse_backward_workspace
+    need = wsq(2, 5, 7, 32, 64, 0, 0)
+    assert need > 0 and wsq(4, 5, 7, 32, 64, 0, 0) > need and wsq(0, 5, 7, 32, 64, 0, 0) == 0
+    assert wsq(2, 5, 7, 32, 64, 1, 0) > need                        # bf16 gradients: the fp32 dy rows live in the scratch
+    assert wsq(2, 5, 300, 32, 64, 0, 0) > wsq(2, 5, 300, 32, 64, 0, 300)   # above 256 keys: chunk records of the key-split form
+    assert bw(one, one, one, one, one, one, 5 * 64, 64, 2, 5, 7, 32, 64, 0, 1e-5, 0, 0, None, one, need - 1, one, one, one, one, one, one, None) == 0x1004
     assert b"workspace" in lib.vlg_last_error()
     # grounding loss: d in {32, 64, 128}, 16-bit positions, prior table needs its segment map
     gl = lib.vlg_grounding_loss
@@ -129,8 +135,19 @@ def test_attn_and_grounding_entry_points_validate_on_the_host(lib):
     assert gl(*args(pen=one)) == 0x1003 and b"segments" in lib.vlg_last_error()
     assert gl(*args(ws=need - 1)) == 0x1004
     # attention-fuse forward
-    assert lib.vlg_attn_fuse(one, one, one, one, one, one, 2, 0, 7, 32, 64, 0, 1e-5, None, one, None) == 0x1001
-    assert lib.vlg_attn_fuse(one, one, one, one, one, one, 0, 5, 7, 32, 64, 0, 1e-5, None, one, None) == 0      # empty batch
+    assert lib.vlg_attn_fuse(one, one, one, one, one, one, 2, 0, 7, 32, 64, 0, 1e-5, 0, None, 0, None, None, one, None) == 0x1001
+    assert lib.vlg_attn_fuse(one, one, one, one, one, one, 0, 5, 7, 32, 64, 0, 1e-5, 0, None, 0, None, None, one, None) == 0      # empty batch
+    # key-split form: workspace only above 256 keys (or when a chunk size is forced), and it is checked before any launch
+    fq = lib.vlg_attn_fuse_workspace
+    assert fq(2, 5, 7, 64, 0) == 0 and fq(2, 5, 256, 64, 0) == 0 and fq(2, 5, 257, 64, 0) > 0 and fq(2, 5, 130, 64, 64) > 0
+    rec = 4 * (16 * 256 + 32)                                             # one record: [16 channel tiles][64 lanes][4] + max[16] + sum[16] floats
+    chunks = lambda B, L: fq(B, L, 1369, 256, 0) // rec // (B * ((L + 15) // 16)) - 1   # (+ one merged record per (sentence, word tile))
+    assert fq(64, 40, 1369, 256, 0) % (64 * 3 * rec) == 0 and 4 <= chunks(64, 40) <= 11   # B = 64: a few 64-key steps per chunk
+    assert chunks(256, 40) < chunks(64, 40)                                            # a big batch needs few chunks per sentence (or none: -1)
+    assert chunks(2, 5) == 22                                                          # a small one gets 64-key chunks
+    assert fq(2, 5, 1369, 256, 128) == 2 * 1 * (11 + 1) * rec                          # forced: 128 keys per chunk
+    assert lib.vlg_attn_fuse(one, one, one, one, one, one, 2, 5, 300, 32, 64, 0, 1e-5, 0, one, 16, None, None, one, None) == 0x1004
+    assert lib.vlg_attn_fuse_saved_bytes(2, 5, 300, 64, 0) == 2 * 1 * 4 * (4 * 256 + 32) and lib.vlg_attn_fuse_saved_bytes(2, 5, 36, 64, 0) == 0
 
 
 def test_align_reduced_validates_on_the_host(lib):

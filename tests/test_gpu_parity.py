@@ -871,24 +871,23 @@ def test_attn_fuse_large_v(oracle_mod):
     assert np.abs(out.detach().cpu().numpy() - ref_out).max() <= 1e-4
     out2 = align.attention_fuse(t(vis), t(txt), t(mid), t(enc), t(gm), t(bt), 1e-5)
     assert np.abs(out2.cpu().numpy() - ref_out).max() <= 1e-4
-    # round 5: above align.WIDE_KEYS keys the differentiable call runs as batched library GEMMs (float32) + torch's softmax / LayerNorm;
-    # value and all six gradients against the fused kernels on the same inputs (forced by lifting the threshold)
+    # round 6: above 256 keys the differentiable call runs the key-split kernels (chunks of keys per wavefront, chunk records merged in
+    # chunk order); value and all six gradients against the fp64 oracle DIRECTLY, and against the one-pass kernels on the same inputs
+    # (forced with key_chunk >= V)
     leaves = [t(a).requires_grad_(True) for a in (vis, txt, mid, enc, gm, bt)]
-    cot = t(rng.standard_normal((B, L, h)).astype(np.float32))
+    dout = rng.standard_normal((B, L, h)).astype(np.float32)
+    cot = t(dout)
+    ref_g = oracle_mod.attn_fuse_backward(vis, txt, mid, enc, gm, dout, 1e-5, np.float64)
     wide = align.attention_fuse(*leaves, 1e-5)
-    assert wide.grad_fn is not None and "AttnFuse" not in type(wide.grad_fn).__name__
+    assert "AttnFuse" in type(wide.grad_fn).__name__
     g_wide = torch.autograd.grad(wide, leaves, cot)
-    keep = align.WIDE_KEYS
-    try:
-        align.WIDE_KEYS = 1 << 30
-        fused = align.attention_fuse(*leaves, 1e-5)
-        assert "AttnFuse" in type(fused.grad_fn).__name__
-        g_fused = torch.autograd.grad(fused, leaves, cot)
-    finally:
-        align.WIDE_KEYS = keep
-    assert float((wide - fused).abs().max()) <= 1e-4 and float((wide.detach().cpu() - torch.from_numpy(ref_out)).abs().max()) <= 1e-4
-    for name, a, b in zip(("vis", "txt", "vis_mid", "enc_x", "ln_w", "ln_b"), g_wide, g_fused):
+    one = align.attention_fuse(*leaves, 1e-5, key_chunk=V)
+    g_one = torch.autograd.grad(one, leaves, cot)
+    assert float((wide.detach().cpu() - torch.from_numpy(ref_out)).abs().max()) <= 1e-4 and float((wide - one).abs().max()) <= 1e-4
+    for name, a, b, want in zip(ATTN_GRAD_NAMES, g_wide, g_one, ref_g):
+        assert np.abs(a.cpu().numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), name
         assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), name
+    assert not g_wide[1][:, 0].any()   # root slot
     # a mid-sized V: four region chunks in the matrix-core kernel, ragged last chunk, three word tiles
     B, L, V = 3, 47, 203
     vis, txt = rng.standard_normal((B, V, d)).astype(np.float32) * 0.3, rng.standard_normal((B, L + 1, d)).astype(np.float32) * 0.3
@@ -980,6 +979,89 @@ def test_attn_fuse_backward_shapes(oracle_mod, B, L, V, d, h, dt):
         assert got.dtype == (torch.bfloat16 if dt == "bf16" and i < 4 else torch.float32), name
         tol = (1e-2 if dt == "bf16" and i < 4 else 1e-4) * max(1.0, np.abs(want).max())   # bf16 grads are rounded on return
         assert np.abs(got.float().cpu().numpy() - want).max() <= tol, name
+
+
+@pytest.mark.parametrize("B,L,V,d,h,ck", [
+    (2, 9, 65, 256, 128, 64),      # two chunks, the second holds a single key; sixteen feature tiles in the adjoint
+    (1, 50, 130, 64, 256, 64),     # three chunks, ragged last; four word tiles, ragged last
+    (3, 47, 203, 128, 256, 128),   # two chunks of two 64-key steps (second ragged)
+    (2, 17, 300, 48, 80, 0),       # automatic: above 256 keys -> 64-key chunks at this batch; d and h not powers of two
+    (2, 40, 1369, 128, 256, 0),    # the shipped factor layout (config/model/vlgae.yaml:40-42): 36 + 36^2 + 36 + 1 keys
+])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_attn_fuse_key_split_vs_oracle(oracle_mod, B, L, V, d, h, ck, dt):
+    """The key-split form of the attention-fuse (joint.py:670-674 at many keys), forward and all six gradients, against the fp64 oracle
+    directly.  bf16: the oracle sees the same bf16-rounded inputs; the four feature gradients come back as bf16 (rounded once from the
+    fp32 accumulators inside the kernels), so they are held to a bf16 rounding (1e-2 of the tensor's largest magnitude)."""
+    from vlgae_amd import _C, align
+    rng = np.random.default_rng(B * 811 + L * 23 + V)
+    vis, txt = rng.standard_normal((B, V, d)).astype(np.float32) * 0.4, rng.standard_normal((B, L + 1, d)).astype(np.float32) * 0.4
+    mid, enc = rng.standard_normal((B, V, h)).astype(np.float32), rng.standard_normal((B, L, h)).astype(np.float32)
+    gm, bt = (rng.random(h) + 0.5).astype(np.float32), rng.standard_normal(h).astype(np.float32)
+    dout = rng.standard_normal((B, L, h)).astype(np.float32)
+    arrs = [vis, txt, mid, enc]
+    if dt == "bf16":
+        arrs = [torch.from_numpy(a).bfloat16().float().numpy() for a in arrs]
+    assert _C.lib().vlg_attn_fuse_workspace(B, L, V, h, ck) > 0          # the split path is what runs
+    _, ref_out = oracle_mod.attn_fuse(*arrs, gm, bt, 1e-5, np.float64)
+    ref = oracle_mod.attn_fuse_backward(*arrs, gm, dout, 1e-5, np.float64)
+    leaves = [t(a) for a in arrs]
+    if dt == "bf16":
+        leaves = [a.bfloat16() for a in leaves]
+    leaves += [t(gm), t(bt)]
+    for a in leaves:
+        a.requires_grad_(True)
+    out = align.attention_fuse(*leaves, 1e-5, key_chunk=ck)
+    grads = torch.autograd.grad(out, leaves, t(dout))
+    with torch.no_grad():
+        out_ng = align.attention_fuse(*leaves, 1e-5, key_chunk=ck)
+    assert torch.equal(out, out_ng)
+    assert np.abs(out.detach().cpu().numpy() - ref_out).max() <= 1e-4
+    for i, (name, got, want) in enumerate(zip(ATTN_GRAD_NAMES, grads, ref)):
+        assert got.dtype == (torch.bfloat16 if dt == "bf16" and i < 4 else torch.float32) and tuple(got.shape) == want.shape, name
+        tol = (1e-2 if dt == "bf16" and i < 4 else 1e-4) * max(1.0, np.abs(want).max())
+        assert np.abs(got.float().cpu().numpy() - want).max() <= tol, name
+    assert not grads[1][:, 0].any()   # root slot
+    # bit-reproducible: no atomics, chunk records merged in chunk order
+    grads2 = torch.autograd.grad(align.attention_fuse(*leaves, 1e-5, key_chunk=ck), leaves, t(dout))
+    assert all(torch.equal(a, b) for a, b in zip(grads, grads2))
+
+
+def test_attn_fuse_bf16_gradients_equal_fp32_then_cast():
+    """grad_dtype = bf16 rounds the fp32 accumulators once inside the kernels: the same bits as the fp32 gradients cast afterwards
+    (one-pass kernels at V = 36, key-split kernels at V = 300)."""
+    from vlgae_amd import _C, align
+    lib = _C.lib()
+    rng = np.random.default_rng(17)
+    for B, L, V, d, h in ((5, 40, 36, 128, 256), (2, 21, 300, 64, 96)):
+        vis, txt, mid, enc = (t(rng.standard_normal(s).astype(np.float32) * 0.5).bfloat16().contiguous()
+                              for s in ((B, V, d), (B, L + 1, d), (B, V, h), (B, L, h)))
+        gm, dout = t((rng.random(h) + 0.5).astype(np.float32)), t(rng.standard_normal((B, L, h)).astype(np.float32))
+        res = []
+        for gdt, tdt in ((_C.F32, torch.float32), (_C.BF16, torch.bfloat16)):
+            nbytes = lib.vlg_attn_fuse_backward_workspace(B, L, V, d, h, gdt, 0)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+            outs = [torch.empty(s, dtype=tdt, device=dev()) for s in ((B, V, d), (B, L + 1, d), (B, V, h), (B, L, h))]
+            outs += [torch.empty(h, dtype=torch.float32, device=dev()) for _ in range(2)]
+            # (saved = NULL: the adjoint recomputes the forward's records -- the path torch.autograd does not take, it hands them over)
+            _C.check(lib.vlg_attn_fuse_backward(_C.ptr(vis), _C.ptr(txt), _C.ptr(mid), _C.ptr(enc), _C.ptr(gm), _C.ptr(dout), L * h, h, B, L,
+                                                V, d, h, _C.BF16, 1e-5, 0, gdt, None, _C.ptr(ws), nbytes, *(_C.ptr(o) for o in outs),
+                                                _C.stream_of(vis)), "attn_fuse_backward")
+            res.append(outs)
+        for a, b in zip(res[0][:4], res[1][:4]):
+            assert torch.equal(a.bfloat16(), b)
+        for a, b in zip(res[0][4:], res[1][4:]):
+            assert torch.equal(a, b)
+        # through torch.autograd the adjoint receives the forward's merged records instead of recomputing them: the same bits
+        leaves = [x.clone().requires_grad_(True) for x in (vis, txt, mid, enc)] + [gm.clone().requires_grad_(True), torch.zeros(h, device=dev(), requires_grad=True)]
+        auto = torch.autograd.grad(align.attention_fuse(*leaves, 1e-5), leaves, dout)
+        for a, b in zip(auto, res[1]):
+            assert torch.equal(a, b)
+    # fp32 inputs with bf16 gradients is not a combination the library builds
+    f = [x.float() for x in (vis, txt, mid, enc)]
+    rc = lib.vlg_attn_fuse_backward(*(_C.ptr(x) for x in f), _C.ptr(gm), _C.ptr(dout), L * h, h, B, L, V, d, h, _C.F32, 1e-5, 0, _C.BF16,
+                                    None, _C.ptr(ws), nbytes, *(_C.ptr(o) for o in res[1]), _C.stream_of(vis))
+    assert rc != 0 and b"grad_dtype" in lib.vlg_last_error()
 
 
 def test_attn_fuse_backward_reproducible():

@@ -61,10 +61,12 @@ SIGNATURES = {
     "vlg_trilinear_backward_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "vlg_trilinear_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "vlg_trilinear_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
-    "vlg_attn_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
-    "vlg_attn_fuse_backward_workspace": (_sz, [_i, _i, _i, _i]),
-    "vlg_attn_fuse_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp, _vp,
-                                    _vp, _vp, _vp]),
+    "vlg_attn_fuse_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "vlg_attn_fuse_saved_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "vlg_attn_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "vlg_attn_fuse_backward_workspace": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "vlg_attn_fuse_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _vp]),
     "vlg_box_rel_pairwise": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "vlg_box_rel_pairwise_backward_workspace": (_sz, [_i, _i, _i]),
     "vlg_box_rel_pairwise_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
@@ -109,7 +111,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 141   # what include/vlgae_amd.h declares at this revision; lib() refuses any other library (argument lists differ between versions)
+ABI_VERSION = 142   # what include/vlgae_amd.h declares at this revision; lib() refuses any other library (argument lists differ between versions)
 
 
 def lib():

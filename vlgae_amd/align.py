@@ -8,6 +8,8 @@ tensors in, named ('B','A','Q','V') tensor out) so it can be registered under th
 registry unchanged:  JointModelBase.add_impl_to_group("gather_logit", "mi355x")(gather_logit_simple)
 (base.py:118-142; selected by `gather_logit_mode` in config/model/vlgae.yaml:57).
 """
+import math
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -184,18 +186,19 @@ def gather_logit_reduced(self, inputs, vis, txt, vp):
     return _GatherLogitReduced.apply(txt_feat, vis_feat, txt_mask, vis_mask, txt_marginal, -INF)
 
 
-def _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, want_att):
+def _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, want_att, key_chunk=0, save=False):
     B, V, d = vis_c.shape
     L, h = txt_c.shape[1] - 1, mid_c.shape[2]
-    out = torch.empty((B, L, h), dtype=torch.float32, device=vis_c.device)
-    att = torch.empty((B, L, V), dtype=torch.float32, device=vis_c.device) if want_att else None
-    _C.check(_C.lib().vlg_attn_fuse(_C.ptr(vis_c), _C.ptr(txt_c), _C.ptr(mid_c), _C.ptr(enc_c), _C.ptr(gamma),
-                                    _C.ptr(beta), B, L, V, d, h, dt, float(eps), _C.ptr(att), _C.ptr(out),
-                                    _C.stream_of(vis_c)), "attn_fuse")
-    return out, att
-
-
-WIDE_KEYS = 256   # above this many keys per image the attention fuse runs as batched library GEMMs (see attention_fuse)
+    lib = _C.lib()
+    nbytes = 0 if want_att else lib.vlg_attn_fuse_workspace(B, L, V, h, key_chunk)   # chunk records of the key-split form (many keys)
+    sbytes = lib.vlg_attn_fuse_saved_bytes(B, L, V, h, key_chunk) if save and not want_att else 0
+    (out, att), ws = _C.alloc_f32(vis_c.device, ((B, L, h), (B, L, V) if want_att else None), nbytes)
+    # the merged records of the key-split form, kept for the adjoint (a tensor of its own: the chunk records above are ~8x its size)
+    saved = torch.empty(sbytes // 4, dtype=torch.float32, device=vis_c.device) if sbytes else None
+    _C.check(lib.vlg_attn_fuse(_C.ptr(vis_c), _C.ptr(txt_c), _C.ptr(mid_c), _C.ptr(enc_c), _C.ptr(gamma), _C.ptr(beta), B, L, V, d, h, dt,
+                               float(eps), key_chunk, _C.ptr(ws) if nbytes else None, nbytes, _C.ptr(saved), _C.ptr(att), _C.ptr(out),
+                               _C.stream_of(vis_c)), "attn_fuse")
+    return (out, att, saved) if save else (out, att)
 
 
 class _AttnFuse(torch.autograd.Function):
@@ -204,21 +207,22 @@ class _AttnFuse(torch.autograd.Function):
     per 16-word tile instead of saving the attention map."""
 
     @staticmethod
-    def forward(ctx, vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps):
+    def forward(ctx, vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps, key_chunk):
         dt, vis_c = _C.in_dtype(vis_feat)
         txt_c, mid_c, enc_c = (t.detach().to(vis_c.dtype).contiguous() for t in (txt_feat, vis_mid, enc_x))
         gamma = ln_weight.detach().to(torch.float32).contiguous()
         beta = ln_bias.detach().to(torch.float32).contiguous()
-        out, _ = _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, False)
+        out, _, saved = _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, False, key_chunk, save=True)
         ctx.save_for_backward(vis_c, txt_c, mid_c, enc_c, gamma)
-        ctx.meta = (dt, float(eps), vis_feat.dtype, txt_feat.dtype, vis_mid.dtype, enc_x.dtype, ln_weight.dtype, ln_bias.dtype)
+        ctx.fwd_records = saved   # (many keys) the forward's merged streaming-softmax records: the adjoint does not recompute them
+        ctx.meta = (dt, float(eps), key_chunk, vis_feat.dtype, txt_feat.dtype, vis_mid.dtype, enc_x.dtype, ln_weight.dtype, ln_bias.dtype)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         vis_c, txt_c, mid_c, enc_c, gamma = ctx.saved_tensors
-        dt, eps, *dtypes = ctx.meta
+        dt, eps, key_chunk, *dtypes = ctx.meta
         B, V, d = vis_c.shape
         L, h = txt_c.shape[1] - 1, mid_c.shape[2]
         dev = vis_c.device
@@ -226,26 +230,42 @@ class _AttnFuse(torch.autograd.Function):
         if dout.dtype != torch.float32 or sh != 1 or sb % 4 or sl % 4 or dout.data_ptr() % 16:
             dout = dout.to(torch.float32).contiguous()     # (a broadcast over the positions -- stride 0 -- is read in place)
             sb, sl = L * h, h
-        nbytes = _C.lib().vlg_attn_fuse_backward_workspace(B, L, V, h)
-        # one allocation for the six gradients and the scratch (host overhead matters at these sizes)
-        outs, ws = _C.alloc_f32(dev, ((B, V, d), (B, L + 1, d), (B, V, h), (B, L, h), (h,), (h,)), nbytes)
-        _C.check(_C.lib().vlg_attn_fuse_backward(_C.ptr(vis_c), _C.ptr(txt_c), _C.ptr(mid_c), _C.ptr(enc_c), _C.ptr(gamma),
-                                                 _C.ptr(dout), sb, sl, B, L, V, d, h, dt, eps, _C.ptr(ws), nbytes,
-                                                 *(_C.ptr(o) for o in outs), _C.stream_of(vis_c)), "attn_fuse_backward")
-        if dtypes[0] == dtypes[1] == dtypes[2] == dtypes[3] != torch.float32:   # the four feature gradients: one cast launch
-            outs = outs.cast(4, dtypes[0]) + list(outs[4:])
+        lib = _C.lib()
+        # bf16 features throughout: the four feature gradients leave the kernels as bf16 (rounded once from the fp32 accumulators -- no
+        # fp32 round trip through HBM, no cast launch; at V = 1369, B = 64 the fp32 d_vis_mid alone is 90 MB)
+        bf = dt == _C.BF16 and dtypes[0] == dtypes[1] == dtypes[2] == dtypes[3] == torch.bfloat16
+        gdt = _C.BF16 if bf else _C.F32
+        nbytes = lib.vlg_attn_fuse_backward_workspace(B, L, V, d, h, gdt, key_chunk)
+        shapes = ((B, V, d), (B, L + 1, d), (B, V, h), (B, L, h))
+        if bf:   # one bf16 allocation for the four feature gradients, one fp32 one for the affine pair + the scratch
+            numels = [math.prod(sh_) for sh_ in shapes]
+            padded = [(n + 127) & ~127 for n in numels]
+            flat = torch.empty(sum(padded), dtype=torch.bfloat16, device=dev)
+            feats, o = [], 0
+            for sh_, n, pn in zip(shapes, numels, padded):
+                feats.append(flat[o:o + n].view(sh_))
+                o += pn
+            (dg, db), ws = _C.alloc_f32(dev, ((h,), (h,)), nbytes)
+            outs = feats + [dg, db]
+        else:   # one allocation for the six gradients and the scratch (host overhead matters at these sizes)
+            outs, ws = _C.alloc_f32(dev, shapes + ((h,), (h,)), nbytes)
+        _C.check(lib.vlg_attn_fuse_backward(_C.ptr(vis_c), _C.ptr(txt_c), _C.ptr(mid_c), _C.ptr(enc_c), _C.ptr(gamma), _C.ptr(dout), sb, sl,
+                                            B, L, V, d, h, dt, eps, key_chunk, gdt, _C.ptr(ctx.fwd_records), _C.ptr(ws), nbytes, *(_C.ptr(o) for o in outs),
+                                            _C.stream_of(vis_c)), "attn_fuse_backward")
         grads = [(o if o.dtype == t else o.to(t)) if ctx.needs_input_grad[i] else None
                  for i, (o, t) in enumerate(zip(outs, dtypes))]
-        return (*grads, None)
+        return (*grads, None, None)
 
 
-def attention_fuse(vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps=1e-5, return_attmap=False):
+def attention_fuse(vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps=1e-5, return_attmap=False, key_chunk=0):
     """joint.py:670-674:  LayerNorm(enc_x + softmax_v(<vis, txt[:,1:]>) @ vis_mid).
 
     vis_feat [B,V,d], txt_feat [B,L+1,d] (root slot first), vis_mid [B,V,h], enc_x [B,L,h]; LayerNorm
     parameters [h].  Returns float32 [B,L,h]; differentiable in all six tensors (the adjoint kernels need d and h
     to be multiples of 16 and <= 256).  `return_attmap=True` also returns attmap [B,L,V] (inspection; no autograd).
-    V <= WIDE_KEYS: the fused matrix-core kernels (vlg_attn.hip); above: batched library GEMMs (see the branch below)."""
+    key_chunk: 0 = automatic -- one pass over the keys for V <= 256, the key-split kernels above that (the shipped factor layout has
+    36 + 36^2 + 36 + 1 = 1369 keys per image: chunks of keys per wavefront, streaming-softmax records merged in chunk order, forward
+    and adjoint; csrc/vlg_attn.hip); > 0 = that many keys per chunk (tests)."""
     vis_feat, txt_feat, vis_mid, enc_x = (_plain(t) for t in (vis_feat, txt_feat, vis_mid, enc_x))
     _C.require_gpu(vis_feat, "attention_fuse")
     B, V, d = vis_feat.shape
@@ -255,23 +275,13 @@ def attention_fuse(vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias, eps=1
         raise ValueError(f"attention_fuse: vis {tuple(vis_feat.shape)} txt {tuple(txt_feat.shape)} "
                          f"vis_mid {tuple(vis_mid.shape)} enc_x {tuple(enc_x.shape)}")
     tensors = (vis_feat, txt_feat, vis_mid, enc_x, ln_weight, ln_bias)
-    if V > WIDE_KEYS and not return_attmap:
-        # Many keys (the shipped factor layout: 36 + 36^2 + 36 + 1 = 1369 columns per image).  The fused kernels are built for the tens of
-        # regions of an object-only layout -- one wavefront owns 16 words and walks ALL keys, B x ceil(L / 16) wavefronts in total: at
-        # B = 64, V = 1369 that is 192 wavefronts on a 1024-SIMD chip (measured: forward 271 us, adjoint 954 + 61 us of a 3.64 ms step).
-        # Here the two contractions are what the library is good at -- batched [L, d] x [d, V] and [L, V] x [V, h] GEMMs in float32, as
-        # the reference's einsums are -- with torch's softmax / LayerNorm between them and torch's autograd behind them: ~0.25 ms.
-        f32 = torch.float32
-        s = torch.bmm(txt_feat[:, 1:].to(f32), vis_feat.to(f32).transpose(1, 2))             # joint.py:670-672 (no region masking there)
-        x = torch.bmm(torch.softmax(s, -1), vis_mid.to(f32))                                  # :673
-        return torch.nn.functional.layer_norm(enc_x.to(f32) + x, (h,), ln_weight.to(f32), ln_bias.to(f32), float(eps))   # :674
     if not return_attmap and torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-        return _AttnFuse.apply(*tensors, float(eps))
+        return _AttnFuse.apply(*tensors, float(eps), int(key_chunk))
     dt, vis_c = _C.in_dtype(vis_feat)
     txt_c, mid_c, enc_c = (t.detach().to(vis_c.dtype).contiguous() for t in (txt_feat, vis_mid, enc_x))
     gamma = ln_weight.detach().to(torch.float32).contiguous()
     beta = ln_bias.detach().to(torch.float32).contiguous()
-    out, att = _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, return_attmap)
+    out, att = _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, return_attmap, int(key_chunk))
     return (out, att) if return_attmap else out
 
 

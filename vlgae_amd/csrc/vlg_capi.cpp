@@ -10,5 +10,5 @@ char* error_buffer() {
 
 extern "C" {
 const char* vlg_last_error(void) { return vlg::error_buffer(); }
-int vlg_version(void) { return 141; }   // round 5: vlg_encoders.hip (text / visual encoder stages, counter-based dropout), vlg_linear_wgrad takes ld_dw and in_dtype
+int vlg_version(void) { return 142; }   // round 6: vlg_attn_fuse / _backward take key_chunk + workspace (key-split form) and grad_dtype
 }
