@@ -1593,6 +1593,56 @@ def test_training_step_reference_wiring(path, dtype, ff_dtype):
           {k: float(f"{v:.2e}") for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("path", golden_files("trainstep_"), ids=golden_ids("trainstep_"))
+def test_training_step_reference_wiring_teacher_forced(path, dtype):
+    """The same function on the same fixtures with the TREE TAKEN OUT of the comparison: `step.forced_heads` = the fixture's `predicted`
+    (the reference's own Viterbi heads, joint.py:256-258), so lang_feat_max_tree reads the reference's parents and marginals and the
+    parser's loss is -score(that tree) -- the function of the parameters the reference differentiated (it treats its tree as a constant,
+    joint.py:256-273, ldndmv.py:277-281).  What is left between the two sides in bf16 is rounding alone: EVERY gradient tensor is bounded
+    on ALL fixtures (0.12 relative L2 on the hot path, 0.3 for the parser's feed-forwards: see the end of the test; the free-running
+    variant above can only assert finiteness where bf16 flipped near-tied attachments), txt and its marginals to the bf16 value tolerance.  f32: the bounds of the free-running case (the trees agree there)."""
+    g = load(path)
+    f32 = dtype == torch.float32
+    with torch.autograd.set_multithreading_enabled(False):
+        step, ref = trainstep_from_fixture(g, dtype)
+        step.forced_heads = t(g["predicted"]).long()
+        loss, grads, _ = step()
+        last = step.last
+    npf = lambda x: x.detach().float().cpu().numpy()
+    assert np.array_equal(last["heads"].cpu().numpy(), g["predicted"])
+    vtol = 1e-4 if f32 else 3e-2
+    for name, tol in (("txt", vtol), ("txt_marginal", 1e-4 if f32 else 2e-2), ("vis_feat", vtol), ("x_fused", vtol)):
+        got, want = npf(last[name]), g[name]
+        assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), name
+    ltol = 1e-5 if f32 else 1e-2
+    assert abs(float(loss) - float(g["loss"])) <= ltol * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    gmax = max(float(np.abs(v).max()) for v in list(ref.values()) + [g["g_w1_sample"] if ref["w1"] is None else ref["w1"]] if v is not None)
+    worst, bad = {}, {}
+    for k in step.names:
+        got = npf(grads[k])
+        got, want = (got[::5, ::7, ::3], g["g_w1_sample"]) if k == "w1" and ref[k] is None else (got, ref[k])
+        assert got.shape == want.shape, k
+        if f32:
+            err = max(np.abs(got - want).max() - 1e-6 * gmax, 0.0) / max(np.abs(want).max(), 1e-12)
+            worst[k] = err
+            assert err <= 3e-4, (k, err)
+        else:   # absolute floor 2e-3 * max|g| per element, as in the free-running case (softmax-invariant biases are rounding noise)
+            floor = 2e-3 * gmax * np.sqrt(want.size)
+            err = max(np.linalg.norm((got - want).ravel()) - floor, 0.0) / max(np.linalg.norm(want.ravel()), 1e-12)
+            worst[k] = np.linalg.norm((got - want).ravel()) / max(np.linalg.norm(want.ravel()), floor)
+            bad[k] = err
+    print("teacher-forced", "f32" if f32 else "bf16", "worst gradient errors:", {k: float(f"{v:.2e}") for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})
+    # bf16, same tree on both sides: 0.12 relative L2 for every tensor of the hot path (observed over the three fixtures: <= 0.104 -- the raw
+    # region features' gradient on the B = 8 fixture; w_venc / b_venc / b 0.08; everything else <= 0.07), 0.3 for the parser's six-layer
+    # LeakyReLU feed-forwards and their embeddings (observed <= 0.27 on the 3-sentence fixture, <= 0.10 on the 8-sentence one: a
+    # pre-activation within bf16 rounding of zero takes the other branch and its term changes by 1 / slope = 100x, and a 24-to-150-element
+    # bias gradient of a 3-sentence batch is a handful of such terms; these fixtures also amplify the scorer outputs 36-100x).  The
+    # free-running variant could only assert finiteness here.
+    for k, err in bad.items():
+        assert err <= (0.3 if k.startswith("ff.") or k.endswith("_emb") else 0.12), (k, err)
+
+
 @pytest.mark.parametrize("dtype,nb", [(torch.float32, 24), (torch.float32, 0), (torch.bfloat16, 40)], ids=["f32_nb24", "f32_nb0", "bf16_nb40"])
 def test_parser_feed_forward_vs_module_by_module(dtype, nb):
     """vlgae_amd.parser_ff.parser_feed_forward (ONE pass of mid_ff over all rows, folded bottlenecks and linear2, fused GEMMs,
@@ -1861,7 +1911,7 @@ def test_linear_wgrad_float32_operands():
         align.linear_wgrad(dy, x.bfloat16())
 
 
-def _reference_step_in_torch(step, P64, token, tag, vmask, drop, alpha, pen_args):
+def _reference_step_in_torch(step, P64, token, tag, vmask, drop, alpha, pen_args, forced_heads=None):
     """The reference's lines for one training step (the order and the formulas of make_golden.trainstep_cases' calls: joint.py:658-711,
     ldndmv.py:171-216,277-281, fn.py:50-56) as float64 torch ops on the step's own leaves -- an independent formulation of everything
     except the structured DP itself (DMV1o marginals / heads / max come from this package's DP kernels on the torch-made potentials;
@@ -1920,6 +1970,8 @@ def _reference_step_in_torch(step, P64, token, tag, vmask, drop, alpha, pen_args
                     torch.cat([ma[:, 1:, :1], ap], 2)], 1)
     with torch.no_grad():                                                                          # joint.py:251-258
         marg, heads = ts.DMV1o([md.float(), ma.float()], lengths).marginals_and_heads()
+        if forced_heads is not None:
+            heads = forced_heads
         arc_margin = marg.sum(-1).double().gather(-1, heads.unsqueeze(-1)).squeeze(-1)
         tmarg = torch.cat([mask1.double(), arc_margin], 1)
     tmask = torch.cat([mask1, mask1], 1)
@@ -1939,12 +1991,15 @@ def _reference_step_in_torch(step, P64, token, tag, vmask, drop, alpha, pen_args
     t2v = -(att4.max(3).values.log_softmax(1).diagonal().T * tmarg).sum()                         # :473-478
     v2t = -(att4.max(2).values.log_softmax(0).diagonal().T * vmask).sum()                         # :480-489
     mt = t2v / (t2v.detach() + 1e-6) * num + v2t / (v2t.detach() + 1e-6) * num
-    dep = -ts.DMV1o([md, ma], lengths).max.sum()                                                  # ldndmv.py:277-281
+    if forced_heads is None:
+        dep = -ts.DMV1o([md, ma], lengths).max.sum()                                              # ldndmv.py:277-281
+    else:   # the same tree on both sides: -score(tree) (vlgae_amd.train_step.forced_tree_score on this side's float64 potentials)
+        dep = -train_step.forced_tree_score(md, ma, forced_heads, lengths).double().sum()
     return (alpha * mt + (1 - alpha) * dep) / (num + 1e-12), heads                                # joint.py:709, fn.py:56
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_training_step_reference_wiring_config_size(dtype):
+@pytest.mark.parametrize("case", ["f32", "bf16", "bf16_forced", "f32_shipped", "bf16_shipped_forced"])
+def test_training_step_reference_wiring_config_size(case):
     """vlgae_amd.train_step.build at BASELINE.json configs[4]'s size (B = 256, L = 40, R = 36, d = 128, h = 256), from the frozen
     features, against the reference's formulation restated in float64 torch ops on the same leaves (`_reference_step_in_torch`).
 
@@ -1957,10 +2012,17 @@ def test_training_step_reference_wiring_config_size(dtype):
     words (a bf16 potential is ~3 significant digits: near-tied attachments flip); every gradient tensor within 0.35 relative L2 of
     the float64 one (plus an absolute floor of 2e-3 * max|g| per element) -- the sentences whose tree flipped feed other parents into
     the arc encoder and another derivation into -max, so this is a bound on the tensor, not on elements; the float32 case above is the
-    check of the mathematics."""
+    check of the mathematics.
+    bf16_forced (round 6): the same bf16 step with the float64 side's Viterbi heads handed to it (`step.forced_heads`): the same tree on both
+    sides, so the bound is on rounding alone -- every gradient tensor within 0.12 relative L2 (observed <= 0.105; 0.25 free-running).
+    *_shipped (round 6): the SHIPPED factor layout (config/model/vlgae.yaml:40-42: add_rel / add_attr / add_image -> V = 36 + 36^2 + 36
+    + 1 = 1369 columns; rel_fc / attr_fc on the path, joint.py:143-171, box_rel.py:41-45; the attention fuse over 1369 keys = the
+    key-split kernels) at B = 64: f32 as above; bf16 teacher-forced as above."""
     from vlgae_amd import train_step
-    B, L, R, d = 256, 40, 36, 128
-    f32 = dtype == torch.float32
+    f32, forced, shipped = case.startswith("f32"), case.endswith("forced"), "shipped" in case
+    dtype = torch.float32 if f32 else torch.bfloat16
+    B, L, R, d = (64 if shipped else 256), 40, 36, 128
+    factors = ("rel", "attr", "img") if shipped else ()
     widths = dict(E=96, Et=16, H=64, nb=24, n_vis=128) if f32 else {}
     E = widths.get("E", 800)
     gen = torch.Generator().manual_seed(5)
@@ -1968,17 +2030,20 @@ def test_training_step_reference_wiring_config_size(dtype):
     enc_drop = (torch.rand(B, L, E, generator=gen) >= 0.33).float() / 0.67
     with torch.autograd.set_multithreading_enabled(False):
         step = train_step.build(B, L, R, dev(), dtype=dtype, given=dict(drop=drop, enc_drop=enc_drop), seed=21, p_ff_drop=0.0, p_mid_drop=0.0,
-                                **widths)
-        loss, grads, _ = step()
-        heads = step.last["heads"]
+                                factors=factors, **widths)
+        assert step.shape["V"] == (1369 if shipped else 36)
         P64 = {k: v.detach().double().requires_grad_(v.requires_grad) for k, v in step.P.items()}
         bt = step.batch
         ref_loss, ref_heads = _reference_step_in_torch(step, P64, bt["token"], bt["tag"], bt["vis_mask"], drop.permute(1, 0, 2).to(dev()),
                                                        bt["alpha"], (bt["factor_names"], bt["vis_split"], bt["pos_for"]))
         ref = torch.autograd.grad(ref_loss, [P64[k] for k in step.names])
+        if forced:
+            step.forced_heads = ref_heads
+        loss, grads, _ = step()
+        heads = step.last["heads"]
     valid = torch.cat([torch.zeros(B, 1, dtype=torch.bool, device=heads.device), torch.arange(L, device=heads.device)[None] < step.lengths[:, None]], 1)
     agree = float((heads == ref_heads)[valid].double().mean())
-    assert torch.equal(heads, ref_heads) if f32 else (agree >= 0.90), agree
+    assert torch.equal(heads, ref_heads) if (f32 or forced) else (agree >= 0.90), agree
     assert abs(float(loss) - float(ref_loss)) <= (1e-5 if f32 else 2e-2) * abs(float(ref_loss)), (float(loss), float(ref_loss))
     gmax = max(float(r.abs().max()) for r in ref)
     report = {}
@@ -1991,13 +2056,14 @@ def test_training_step_reference_wiring_config_size(dtype):
             scale = max(float(want.abs().max()), 1e-6 * gmax)
             err = (got - want).abs() / scale
             report[k] = (float(err.max()), float((err > 3e-4).double().mean()))
-            assert float((err > 3e-4).double().mean()) <= 1e-4 and float(err.max()) <= 5e-3, (k, report[k])
+            # (shipped layout: 38x the columns, so 38x the alignment's arg-max decisions near a tie: 5e-4 of the elements)
+            assert float((err > 3e-4).double().mean()) <= (5e-4 if shipped else 1e-4) and float(err.max()) <= 5e-3, (k, report[k])
         else:
             floor = 2e-3 * gmax * want.numel() ** 0.5
             rel = max(float((got - want).norm()) - floor, 0.0) / max(float(want.norm()), 1e-30)
             report[k] = (float((got - want).norm()) / max(float(want.norm()), floor), 0.0)
-            assert rel <= 0.35, (k, rel, agree)
-    print(f"config-size training step ({'f32' if f32 else 'bf16'}) vs float64 torch formulation: loss", float(loss), float(ref_loss), f"heads agree {agree:.4f};",
+            assert rel <= (0.12 if forced else 0.35), (k, rel, agree)   # forced, observed: <= 0.105 (ff.child_ff.linear.bias: 45 token rows), hot path <= 0.065
+    print(f"config-size training step ({case}) vs float64 torch formulation: loss", float(loss), float(ref_loss), f"heads agree {agree:.4f};",
           "worst:", sorted(report.items(), key=lambda kv: -kv[1][0])[:6])
 
 

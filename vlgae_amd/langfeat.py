@@ -396,11 +396,13 @@ def start_structure(merged_dec, merged_attach, lengths, keep_viterbi=False):
 
 
 def lang_feat_max_tree(x, lengths, merged_dec, merged_attach, w_enc, b_enc, w1, w2, b_arc, add_marginal=True, slope=0.01,
-                       keep_viterbi=False, aux=None, structure=None, drop=None, compute_dtype=None, pre=None):
+                       keep_viterbi=False, aux=None, structure=None, drop=None, compute_dtype=None, pre=None, heads=None):
     """`DependencyBoxRel.lang_feat_max_tree` (joint.py:235-292) -> (txt [B,2N,d] in x's dtype, txt_mask [B,2N] bool, txt_marginal
     [B,2N] float32).  drop [B,3,d]: the word | child | parent encoders' SharedDropout masks (training; `shared_dropout_masks`).  The potentials are constants of this stage (detached, joint.py:252-253).  `structure` = the handle of an
     earlier `start_structure(...)` (then merged_dec / merged_attach / keep_viterbi are not used here).  pre = `encoder_projection(...)`: the
-    encoders' projection shared with `lang_feat_word_only` (x / w_enc / b_enc are then not read here).
+    encoders' projection shared with `lang_feat_word_only` (x / w_enc / b_enc are then not read here).  heads [B,N] (optional): use this
+    tree instead of the Viterbi tree of the potentials (teacher forcing: the parity tests hand over the reference's `predicted`, so that a
+    bf16 run is compared on the SAME tree and rounding is not mistaken for a flipped attachment).
     Measured: the two DPs are joined BEFORE the root row and the projection GEMM.  Letting those launches run beside the DPs
     (they do not need the heads) made the training step 90 us SLOWER (1.39 -> 1.48 ms as one HIP graph, same box): each DP is one
     workgroup per CU on a 93 us critical path, and a workgroup that has to wait for a CU behind a GEMM tile lengthens that path."""
@@ -409,7 +411,8 @@ def lang_feat_max_tree(x, lengths, merged_dec, merged_attach, w_enc, b_enc, w1, 
         if structure is not None:
             _, marg, heads = structure.wait()
         else:
-            marg, heads = ts.DMV1o([merged_dec.detach(), merged_attach.detach()], lengths).marginals_and_heads(keep_viterbi)
+            marg, own_heads = ts.DMV1o([merged_dec.detach(), merged_attach.detach()], lengths).marginals_and_heads(keep_viterbi)
+            heads = own_heads if heads is None else heads.to(own_heads.device, own_heads.dtype)   # teacher forcing (tests): the caller's tree
         txt_marginal, txt_mask = txt_marginal_and_mask(marg, heads, lengths, add_marginal)
     if aux is not None:
         aux["heads"] = heads

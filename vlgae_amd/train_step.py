@@ -141,6 +141,27 @@ def init_feed_forward(g, dev, dtype, E, h, Et, T, H, nb, r):
     return P
 
 
+def forced_tree_score(md, ma, heads, lengths, big=1e4):
+    """Score of the dependency tree `heads` [B,N] (heads[b,c] = head of word c, 0 = the root token) under root-merged DMV1o potentials
+    md [B,N,2,2,2] / ma [B,N,N,2 (head, child, valence)]: [B,1], differentiable w.r.t. both (its gradient is the tree's derivation
+    counts).  The counts come from the Max-semiring DP itself on potentials whose arcs (heads[c] -> c) carry a bonus that no other tree
+    can make up: the valence of every attachment and every continue / stop decision are functions of the tree, so the arg-max derivation
+    of the biased potentials IS the derivation of that tree, under exactly the conventions the kernel uses."""
+    import vlgae_amd.torch_struct as ts
+    B, N = heads.shape
+    with torch.no_grad():
+        child = torch.arange(N, device=heads.device)[None].expand(B, -1)
+        live = (child >= 1) & (child <= lengths[:, None])
+        bonus = torch.zeros((B, N, N), dtype=torch.float32, device=heads.device)
+        b_idx = torch.arange(B, device=heads.device)[:, None].expand(-1, N)
+        bonus[b_idx[live], heads[live], child[live]] = big
+    with torch.enable_grad():
+        pot = [md.detach().float().requires_grad_(True), (ma.detach().float() + bonus.unsqueeze(-1)).requires_grad_(True)]
+        cd, ca = torch.autograd.grad(ts.DMV1o(pot, lengths).max.sum(), pot)
+    ct = torch.float64 if md.dtype == torch.float64 else torch.float32   # (the tests' float64 formulation keeps its precision)
+    return ((cd.to(ct) * md.to(ct)).flatten(1).sum(1) + (ca.to(ct) * ma.to(ct)).flatten(1).sum(1)).view(B, 1)
+
+
 # ----------------------------------------------------------------------------------------------------------------------------
 def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer=True, T=45, r=16, wiring="reference", given=None,
           alpha=0.5, use_pos_prior=True, vis2txt=1.0, p_drop=0.33, E=800, Et=32, H=256, nb=150, p_ff_drop=0.33, p_mid_drop=0.3,
@@ -152,7 +173,8 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     region columns: the object factor alone, the default).  n_vis / E: widths of the frozen region features / embeddings (2048 / 800).
     `given` (a dict) replaces any of the synthetic inputs / parameters by name (tests: the fixture's tensors) -- features emb [B,L,E],
     vis_box_feat [B,R,n_vis]; batch lengths / token / tag [B,L], box_mask [B,R], drop [4,B,d] (the SharedDropout masks in the reference's
-    call order: word-only, then word | child | parent; or None), enc_drop [B,L,E] (MLPEncoder's nn.Dropout mask; or None); parameters
+    call order: word-only, then word | child | parent; or None), enc_drop [B,L,E] (MLPEncoder's nn.Dropout mask; or None), heads [B,L+1] (a tree
+    to use INSTEAD of the Viterbi tree of the step's own potentials -- teacher forcing, see `step.forced_heads` below); parameters
     w_text [h,E], w_venc [F h, 2 n_vis] / b_venc [F h], w_vis [d,h], w_enc [3d,h], b_enc [3d], ln_w, ln_b [h], w1 [d,d,d], w2 [d,d], b [d],
     token_emb / root_emb / dec_emb and the "ff.*" feed-forward parameters.  With `given` drop / enc_drop absent, fresh masks are drawn
     every step (p_drop / p_enc; the embedding dropout from a device-resident counter-based generator, encoders.DeviceRng).
@@ -220,6 +242,7 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
     fixed_drop = given.pop("drop") if "drop" in given else "draw"
     if fixed_drop is not None and not isinstance(fixed_drop, str):
         fixed_drop = fixed_drop.to(dev, torch.float32).permute(1, 0, 2).contiguous()      # [B,4,d]
+    forced_heads = given.pop("heads").to(dev, torch.int64) if "heads" in given else None
     enc_drop = given.pop("enc_drop") if "enc_drop" in given else "draw"
     if enc_drop is not None and not isinstance(enc_drop, str):
         enc_drop = enc_drop.to(dev, torch.float32).contiguous()                           # [B,L,E]
@@ -295,12 +318,15 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         md, ma = scorer.ndmv_potentials(x1, x2, y1, y2, root_rule, token)
         # ---- DependencyBoxRel._vis_forward, joint.py:677-691: the UN-fused x; the potentials are constants of this stage (:252-253) ----
         txt, tmask, tmarg = langfeat.lang_feat_max_tree(None, lengths, md.detach(), ma.detach(), None, None, P["w1"],
-                                                        P["w2"], P["b"], keep_viterbi=True, drop=d3, aux=aux, pre=pre)
+                                                        P["w2"], P["b"], keep_viterbi=True, drop=d3, aux=aux, pre=pre, heads=step.forced_heads)
         if stage_hook is not None:
             txt.register_hook(lambda g_: stage_hook())
         # ---- DependencyBoxRel.loss, joint.py:693-711 ----
         mt, sums = align.grounding_loss_factor_ce(txt, vis_feat, tmask, vmask, tmarg, num_token_f, vis2txt, pen, seg)
-        mx = ts.DMV1o([md, ma], lengths).max                      # ldndmv.py:277-281: dep = -max.sum(); lang_feat_max_tree's Viterbi pass is reused
+        if step.forced_heads is None:
+            mx = ts.DMV1o([md, ma], lengths).max                  # ldndmv.py:277-281: dep = -max.sum(); lang_feat_max_tree's Viterbi pass is reused
+        else:
+            mx = forced_tree_score(md, ma, step.forced_heads, lengths)   # teacher forcing: the given tree's score in place of the best tree's
         with torch.no_grad():                                     # alpha mt + (1 - alpha) dep, reduce_loss('token'): c_mt mt + sum_b c_max max_b, two launches
             loss = torch.addcmul(torch.dot(mx.view(-1), seed_max), c_mt, mt)
         grads = torch.autograd.grad([mt, mx], leaves, [c_mt, seed_max.view(mx.shape)])
@@ -313,6 +339,11 @@ def build(B, L, R, dev, dtype=torch.bfloat16, d=128, h=256, seed=11, with_scorer
         return loss, dict(zip(names, grads)), ()
 
     step.names, step.P, step.lengths, step.wiring = names, P, lengths, wiring
+    # Teacher forcing (parity tests only; None = the reference's behaviour): with a tree given, lang_feat_max_tree reads ITS parents and
+    # marginals, and the parser's loss is -score(that tree) instead of -max -- the same function of the parameters the reference
+    # differentiates when its own Viterbi tree is that tree (joint.py:256-273 and ldndmv.py:277-281 treat the tree as a constant).  A bf16
+    # run whose near-tied attachments flip is thereby compared on the reference's tree: rounding is separated from tree flips.
+    step.forced_heads = forced_heads
     step.batch = dict(token=token, tag=tag, box_mask=box_mask, vis_mask=vmask, alpha=alpha, factor_names=factor_names, vis_split=vis_split,
                       factors=factors, pos_for=pos_for, use_pos_prior=use_pos_prior, vis2txt=vis2txt, enc_drop=enc_drop, p_enc=p_enc)
     step.shape = dict(B=B, L=L, R=R, V=V, d=d, h=h, E=E, n_vis=n_vis)
