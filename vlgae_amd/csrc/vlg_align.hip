@@ -1160,13 +1160,13 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
 // wavefront the shipped factor layout's 29 groups of 48 columns were walked serially by 64 wavefronts on the whole chip: 404 us.
 constexpr int kPdP = 49, kPdRT = 6;
 template <int NP>   // NP = 2: float32 features on two fp16 parts (see align_argmax_kernel); the scores are unscaled BEFORE the prior is subtracted
-__global__ __launch_bounds__(256) void align_prior_diag_kernel(
+__global__ __launch_bounds__(512) void align_prior_diag_kernel(
     const uint16_t* __restrict__ txt, const uint16_t* __restrict__ vis, const uint8_t* __restrict__ tmask,
     const uint8_t* __restrict__ vmask, int B, int A, int Q, int V, float neg_inf, float* __restrict__ out_maxV,
     float* __restrict__ out_maxQ, AlignArgs xa, AlignParts parts) {
     constexpr int d = 128, KCH = 4, RT = kPdRT, P = kPdP;
     extern __shared__ __attribute__((aligned(16))) float pd_smem[];   // [NW][RT 16 P] score tiles, then [NW][128] (max, position) pairs
-    __shared__ uint8_t kq_s[RT * 16], kv_s[4][48];
+    __shared__ uint8_t kq_s[RT * 16], kv_s[8][48];
     const int NW = blockDim.x >> 6, wave = threadIdx.x >> 6;
     float* S = pd_smem + (size_t)wave * RT * 16 * P;
     float* mrg_m = pd_smem + (size_t)NW * RT * 16 * P;                 // [NW][128]
@@ -1190,8 +1190,8 @@ __global__ __launch_bounds__(256) void align_prior_diag_kernel(
             if (on) {
 #pragma unroll 1
                 for (int rt = 0; rt < RT; ++rt)
-#pragma unroll 1
-                    for (int ct = 0; ct < 3; ++ct) {
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) {   // (the three column tiles' operand reads in flight together)
                         const bf16x8* ap = reinterpret_cast<const bf16x8*>(txt + ((size_t)b * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
                         const int v = min(v0 + ct * 16 + ccol, V - 1);
                         const bf16x8* bp = reinterpret_cast<const bf16x8*>(vis + ((size_t)a * V + v) * d + g * 8);
@@ -1572,7 +1572,10 @@ static int launch_align_max(const void* txt, const void* vis, const uint8_t* tma
 #undef VLG_AAM
             if (xa.pen) {
                 if (int rc = check_launch("align_argmax_kernel")) return rc;
-                const int pd_nw = ng >= 4 ? 4 : 1;   // wavefronts per diagonal pair: the region groups of a many-column image are dealt round
+                // wavefronts per diagonal pair: the region groups of a many-column image are dealt round.  Eight (round 6: 157 KB of score
+                // tiles, the whole LDS of a CU) for the shipped layout's 29 groups: there are only B workgroups, the kernel is a chain of
+                // dependent rounds, and 4 rounds instead of 8 took it from 162 to ~90 us at B = 64
+                const int pd_nw = ng >= 8 ? 8 : ng >= 4 ? 4 : 1;
                 const size_t pd_lds = sizeof(float) * ((size_t)pd_nw * kPdRT * 16 * kPdP + (size_t)pd_nw * 256);
                 hipError_t pe = hipFuncSetAttribute(reinterpret_cast<const void*>(align_prior_diag_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds);
                 if (pe != hipSuccess) return set_error((int)pe, "hipFuncSetAttribute: %s", hipGetErrorString(pe));
