@@ -231,7 +231,7 @@ __device__ __forceinline__ void attn_keys_product_lds(f32x4 (&acc)[NT], const ui
 
 // GEMM 1 of one region chunk: S^T[region v0+16t+4g+n][word r] = <vis[region], txt[word]>  (joint.py:670-672).
 // trow = this lane's word row (element 0).
-template <typename In, int T>
+template <typename In, int T, bool F32MATH = false>   // F32MATH: bf16 features widened on load, fp32 MFMAs (the forward of a few dozen keys)
 __device__ __forceinline__ void attn_scores(f32x4 (&S)[T], const typename In::T* trow, const typename In::T* vis_b, int V,
                                             int d, int v0, int r, int g) {
 #pragma unroll
@@ -239,7 +239,7 @@ __device__ __forceinline__ void attn_scores(f32x4 (&S)[T], const typename In::T*
     const typename In::T* vrow[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) vrow[t] = vis_b + (size_t)min(v0 + 16 * t + r, V - 1) * d;
-    if constexpr (kIsBF16<In>) {
+    if constexpr (kIsBF16<In> && !F32MATH) {
         constexpr int KJ = 4;   // 32-feature steps per chunk (128 features)
         for (int k0 = 0; k0 < d; k0 += 32 * KJ) {
             int koff[KJ];
@@ -469,7 +469,10 @@ __device__ __forceinline__ void attn_forward_tile(f32x4 (&Y)[kAttnMaxCT], float&
                                                   const typename In::T* trow, const typename In::T* vis_b,
                                                   const typename In::T* mid_ptr, int V, int d, int h, int r, int g,
                                                   int v_begin, int v_end, bool normalize, char* lds) {
-    if constexpr (kIsBF16<In>) {
+    // bf16 features: the streaming bf16-MFMA tile for key ranges of several 64-key steps (T = 4: V > 48); a few dozen keys (object-only
+    // layouts, one step) keep round 3's form -- values widened on load, exact fp32 MFMAs, vis_mid gathered straight into the operand ring:
+    // with nothing to stream, the LDS image and the step-ahead loads only add latency (measured at V = 36, B = 256: 24.5 vs 18.6 us)
+    if constexpr (kIsBF16<In> && T == 4) {
         attn_forward_tile_bf16<T>(Y, m_run, z_run, trow, vis_b, mid_ptr, V, d, h, r, g, v_begin, v_end, normalize, lds);
         return;
     }
@@ -483,7 +486,7 @@ __device__ __forceinline__ void attn_forward_tile(f32x4 (&Y)[kAttnMaxCT], float&
     z_run = 0.f;
     for (int v0 = v_begin; v0 < V; v0 += 16 * T) {
         f32x4 S[T];
-        attn_scores<In, T>(S, trow, vis_b, V, d, v0, r, g);
+        attn_scores<In, T, true>(S, trow, vis_b, V, d, v0, r, g);
         // ---- softmax over regions (NO region masking: faithful to joint.py:670-672; only the tile padding is dropped) ----
         float m = m_run;
 #pragma unroll
@@ -511,21 +514,7 @@ __device__ __forceinline__ void attn_forward_tile(f32x4 (&Y)[kAttnMaxCT], float&
         }
 
         // ---- GEMM 2: Y^T[channel 16ct+4g+n][word r] += mid[region][channel] * exp(score - max) ----
-        if constexpr (kIsBF16<In>) {
-            constexpr int NS = (T + 1) / 2;   // K steps of 32 keys = two region tiles
-            bf16x8 Ph[NS], Pl[NS];
-#pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int t = 2 * s2 + (j >> 2);
-                    const float p = t < T ? S[t < T ? t : 0][j & 3] : 0.f;
-                    const __bf16 hi = (__bf16)p;
-                    Ph[s2][j] = hi;
-                    Pl[s2][j] = (__bf16)(p - (float)hi);
-                }
-            attn_keys_product_lds<T, kAttnMaxCT, true>(Y, mid_ptr, h, v0, V, Ph, Pl, lds);
-        } else {
+        {
             int mid_lane[T][4];   // region (clamped: padding rows carry zero weight), channel r (+ 16ct uniform)
 #pragma unroll
             for (int t = 0; t < T; ++t)

@@ -617,6 +617,162 @@ VLG_HD void dmv_bw_span(const DmvCtx& c, int w, int G, int D, bool live, int rr,
     if (live && rr == 0) c.gI[kO] = gi;
 }
 
+// ---- Outside pass, short-sentence image: the VALUE reads of a width issued one width ahead (round 6) -------------------------------
+// A span body of the outside pass reads (a) inside-pass results -- its own C / S cells, the same-width term, and per split point the
+// four value cells the weights exp(t - out) are made of: nothing writes them during this pass -- and (b) adjoint cells: its own
+// total (final only after the previous width's barrier) and the read-modify-write targets.  With everything requested behind the
+// barrier, the (a) reads queue in front of the (b) reads of all eight wavefronts and the exponentials wait for both.  Here the (a)
+// reads of width w - 1 are issued inside width w's body -- behind its adjoint reads, ahead of its stores, so they are complete at the
+// barrier like everything else and cost no wait of their own -- and stay in registers across the barrier: behind it only the
+// adjoint reads are requested, and the exponentials of the weights run while those are in flight.  Same operations on the same
+// operands in the same order per result: bit-identical counts (tools/time_headline.py's SHA-256).
+template <int TM>
+struct BwVals {
+    float2 oc, sv, vv[TM];
+    float Sv, su, uu[TM], xa[TM], xb[TM];
+};
+
+template <int DIRT, int TM, bool NOCLAMP>
+VLG_HD void dmv_bw_load_vals(const DmvCtx& c, int w, int G, int D, int rr, BwVals<TM>& v, int dir_rt) {
+    const int DIR = DIRT < 0 ? dir_rt : DIRT;
+    const int P = c.P, DW = D + VLG_MUL24(w, P);
+    const float* Cf = reinterpret_cast<const float*>(c.C);
+    const int eA = 2 * (D + 1) + (DIR == 0 ? 1 : 0), eB = 2 * (DW + 1) + (DIR == 0 ? 0 : 1);
+    const int eU = DIR == 0 ? D : D + P + w + 1, eV = DIR == 0 ? DW : D + 2;
+    const int kO = DIR == 0 ? DW : D + w + 1, kS = DIR == 0 ? DW : D + w;
+    const int selfr = DIR == 0 ? 0 : w - 1;
+    v.oc = c.C[kO];
+    v.Sv = c.S[kS];
+    v.su = Cf[2 * (eU + VLG_MUL24(selfr, P)) + 1];
+    v.sv = c.I[eV + selfr];
+#pragma unroll
+    for (int u = 0; u < TM; ++u) {
+        const int r = rr + u * G, rc = NOCLAMP ? r : (r < w ? r : w - 1), rP = VLG_MUL24(rc, P);
+        v.uu[u] = Cf[2 * (eU + rP) + 1];
+        v.vv[u] = c.I[eV + rc];
+        v.xa[u] = Cf[eA + 2 * rc];
+        v.xb[u] = Cf[eB + 2 * rc];
+    }
+}
+
+// dmv_bw_span (TU > 0, one chunk) on prefetched values `v`; with `more`, `nxt` receives the values of width wn for the span at Dn
+template <int SR, int DIRT, int TU, int TM, typename X, bool NOCLAMP>
+VLG_HD void dmv_bw_span_p(const DmvCtx& c, int w, int G, int D, bool live, int rr, X& x, const BwVals<TM>& v, BwVals<TM>& nxt, bool more,
+                          int wn, int Dn, int dir_rt) {
+    const int DIR = DIRT < 0 ? dir_rt : DIRT;
+    const int P = c.P, DW = D + VLG_MUL24(w, P);
+    float* gCif = reinterpret_cast<float*>(c.gCi);
+    const int eA = 2 * (D + 1) + (DIR == 0 ? 1 : 0), eB = 2 * (DW + 1) + (DIR == 0 ? 0 : 1);
+    const int eU = DIR == 0 ? D : D + P + w + 1, eV = DIR == 0 ? DW : D + 2;
+    const int kO = DIR == 0 ? DW : D + w + 1, kS = DIR == 0 ? DW : D + w;
+    const int selfr = DIR == 0 ? 0 : w - 1;
+    // ---- adjoint reads: what the barrier was for ----
+    const float ga = c.gCc[kO];
+    const float2 gb = c.gCi[kO];
+    const float2 gi_old = c.gI[kO];
+    int b0 = 0, b1 = 0, bs = 0;
+    if (SR == VLG_SR_MAX) { b0 = c.bpC[kO * 2]; b1 = c.bpC[kO * 2 + 1]; bs = c.bpS[kS]; }
+    float o_c[TU], o_ga[TU], o_gb[TU];
+    float2 o_gi[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+        const int r = rr + u * G, rc = NOCLAMP ? r : (r < w ? r : w - 1), rP = VLG_MUL24(rc, P);
+        o_gi[u] = c.gI[eV + rc];
+        o_c[u] = c.gCc[eU + rP];
+        o_ga[u] = gCif[eA + 2 * rc];
+        o_gb[u] = gCif[eB + 2 * rc];
+    }
+    // ---- the weights' exponentials, from registers, while those reads are in flight (adj_w = g * 2^min(t - out, 0): the factor first) ----
+    float e0[TU], e1[TU], es[TU], s0 = 0.f, s1 = 0.f;
+    if (SR != VLG_SR_MAX) {
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            e0[u] = VLG_EXP(fminf(v.uu[u] + v.vv[u].x - v.oc.x, 0.f));
+            e1[u] = VLG_EXP(fminf(v.uu[u] + v.vv[u].y - v.oc.y, 0.f));
+            es[u] = VLG_EXP(fminf(v.xa[u] + v.xb[u] - v.Sv, 0.f));
+        }
+        s0 = VLG_EXP(fminf(v.su + v.sv.x - v.oc.x, 0.f));
+        s1 = VLG_EXP(fminf(v.su + v.sv.y - v.oc.y, 0.f));
+    }
+    float2 gc = make_float2(0.f, 0.f);                        // total adjoint of CL(j,i) | CR(i,j)
+    if (live && !(DIR == 1 && D == 0 && w != c.len)) gc = make_float2(gb.x, ga + gb.y);   // masked root cell: dmv.py:63
+    float w0[TU], w1[TU], self[2];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+        const int r = rr + u * G;
+        const bool ok = r < w;
+        if (SR == VLG_SR_MAX) {
+            w0[u] = ok ? adj_w<SR>(gc.x, 0.f, 0.f, r, b0) : 0.f;
+            w1[u] = ok ? adj_w<SR>(gc.y, 0.f, 0.f, r, b1) : 0.f;
+        } else {
+            w0[u] = ok ? gc.x * e0[u] : 0.f;
+            w1[u] = ok ? gc.y * e1[u] : 0.f;
+        }
+    }
+    if (SR == VLG_SR_MAX) {
+        self[0] = adj_w<SR>(gc.x, 0.f, 0.f, selfr, b0);
+        self[1] = adj_w<SR>(gc.y, 0.f, 0.f, selfr, b1);
+    } else {
+        self[0] = gc.x * s0;
+        self[1] = gc.y * s1;
+    }
+    // ---- the next width's value reads: ahead of this width's stores ----
+    if (more) dmv_bw_load_vals<DIRT, TM, NOCLAMP>(c, wn, G, Dn, rr, nxt, dir_rt);
+    x.lockstep();   // the lanes of a group sit in one wavefront: every load above precedes every store below
+    const float2 gi = make_float2(gi_old.x + self[0], gi_old.y + self[1]);   // complete adjoint of IL(j,i) | IR(i,j)
+    const float gs = gi.x + gi.y;
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+        const int r = rr + u * G;
+        if (live && r < w) {
+            const float ws = SR == VLG_SR_MAX ? adj_w<SR>(gs, 0.f, 0.f, r, bs) : gs * es[u];
+            if (r != selfr) c.gI[eV + r] = make_float2(o_gi[u].x + w0[u], o_gi[u].y + w1[u]);
+            c.gCc[eU + VLG_MUL24(r, P)] = o_c[u] + (w0[u] + w1[u]);
+            gCif[eA + 2 * r] = o_ga[u] + ws;
+            gCif[eB + 2 * r] = o_gb[u] + ws;
+        }
+    }
+    if (live && rr == 0) c.gI[kO] = gi;   // == d logZ / d attach[j,i,:] | attach[i,j,:]
+}
+
+// widths w1-1 ... w0 of one segment of the short-sentence image (one span per lane group and width: (Ne - w) G <= the lanes of a direction)
+template <int SR, int LG, typename X>
+VLG_HD void dmv_bw_segment_p(const DmvCtx& c, int w0, int w1, int tid, int nt, X& x) {
+    constexpr int G = 1 << LG;
+    constexpr int TM = short_tmax(LG, kShortN, VLG_DP_LANES_BW);
+    constexpr bool NC = X::kChartsInLds;
+    if (w1 <= w0) return;
+    const int nd = nt >> 1;
+    const bool right = x.uniform(tid >= nd);
+    const int dir = right ? 1 : 0;
+    const int t = right ? tid - nd : tid;
+    const int rr = t & (G - 1), slot = t >> LG, wslot = (t & ~63) >> LG;   // wslot: the first span of this lane's wavefront
+    const int Ds = VLG_MUL24(slot, c.P + 1);
+    BwVals<TM> va, vb;   // ping-pong: the body of one width reads one and fills the other (no copies)
+    {
+        const int spans = c.Ne - (w1 - 1);
+        dmv_bw_load_vals<-1, TM, NC>(c, w1 - 1, G, slot < spans ? Ds : 0, rr, va, dir);
+    }
+    auto one_width = [&](int w, const BwVals<TM>& cur, BwVals<TM>& nxt) {
+        const int spans = c.Ne - w;
+        const bool live = slot < spans;
+        const int D = live ? Ds : 0;
+        const bool more = w > w0;
+        const int Dn = slot < spans + 1 ? Ds : 0;   // the span of width w - 1 (one more span than this width has)
+        const int T = (w + G - 1) >> LG;
+        if (X::kSkipDeadWaves && wslot >= spans) {   // (wave-uniform) no span of this width in this wavefront: only the prefetch
+            if (more) dmv_bw_load_vals<-1, TM, NC>(c, w - 1, G, Dn, rr, nxt, dir);
+        } else if (TM == 1 || T == 1) dmv_bw_span_p<SR, -1, 1, TM, X, NC>(c, w, G, D, live, rr, x, cur, nxt, more, w - 1, Dn, dir);
+        else if (TM == 2 || T == 2) dmv_bw_span_p<SR, -1, 2, TM, X, NC>(c, w, G, D, live, rr, x, cur, nxt, more, w - 1, Dn, dir);
+        else dmv_bw_span_p<SR, -1, 3, TM, X, NC>(c, w, G, D, live, rr, x, cur, nxt, more, w - 1, Dn, dir);
+        x.sync();
+    };
+    for (int w = w1 - 1; w >= w0; w -= 2) {
+        one_width(w, va, vb);
+        if (w - 1 >= w0) one_width(w - 1, vb, va);
+    }
+}
+
 template <int SR, int DIR, int LG, int LONGSPAN, typename X>
 VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x, int dir_rt = 0) {
     constexpr int G = 1 << LG;
@@ -673,6 +829,18 @@ VLG_HD void dmv_bw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& 
 template <int SR, int LONGSPAN = true, typename X>
 VLG_HD void dmv_bw_all(const DmvCtx& c, int tid, int nt, X& x) {
     const Sched sc = make_sched(c.Ne, nt >> 1, VLG_DP_LANES_BW);
+#ifndef VLG_NO_BW_PREFETCH
+    if constexpr (LONGSPAN == kSpansShort) {   // the short-sentence image: value reads one width ahead (dmv_bw_segment_p)
+        dmv_bw_segment_p<SR, 6>(c, sc.first[6], sc.first[7], tid, nt, x);
+        dmv_bw_segment_p<SR, 5>(c, sc.first[5], sc.first[6], tid, nt, x);
+        dmv_bw_segment_p<SR, 4>(c, sc.first[4], sc.first[5], tid, nt, x);
+        dmv_bw_segment_p<SR, 3>(c, sc.first[3], sc.first[4], tid, nt, x);
+        dmv_bw_segment_p<SR, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
+        dmv_bw_segment_p<SR, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
+        dmv_bw_segment_p<SR, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
+        return;
+    }
+#endif
     dmv_bw_segment<SR, 6, LONGSPAN>(c, sc.first[6], sc.first[7], tid, nt, x);
     dmv_bw_segment<SR, 5, LONGSPAN>(c, sc.first[5], sc.first[6], tid, nt, x);
     dmv_bw_segment<SR, 4, LONGSPAN>(c, sc.first[4], sc.first[5], tid, nt, x);
