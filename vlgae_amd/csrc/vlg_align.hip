@@ -1167,6 +1167,9 @@ __global__ __launch_bounds__(512) void align_prior_diag_kernel(
     constexpr int d = 128, KCH = 4, RT = kPdRT, P = kPdP;
     extern __shared__ __attribute__((aligned(16))) float pd_smem[];   // [NW][RT 16 P] score tiles, then [NW][128] (max, position) pairs
     __shared__ uint8_t kq_s[RT * 16], kv_s[8][48];
+    __shared__ float pen_s[RT * 16][8];   // this pass's rows of the prior table (n_seg <= 8): looked up from LDS beside the operand reads --
+                                          // read from memory behind the MFMAs they were a second round trip per tile batch (66 % of the
+                                          // kernel's wave cycles were s_waitcnt)
     const int NW = blockDim.x >> 6, wave = threadIdx.x >> 6;
     float* S = pd_smem + (size_t)wave * RT * 16 * P;
     float* mrg_m = pd_smem + (size_t)NW * RT * 16 * P;                 // [NW][128]
@@ -1179,6 +1182,12 @@ __global__ __launch_bounds__(512) void align_prior_diag_kernel(
     for (int q0 = 0; q0 < Q; q0 += RT * 16) {
         __syncthreads();
         for (int i = threadIdx.x; i < RT * 16; i += blockDim.x) kq_s[i] = tmask ? (uint8_t)(tmask[(size_t)b * Q + min(q0 + i, Q - 1)] != 0) : (uint8_t)1;
+        const bool pen_lds = xa.n_seg <= 8;   // (uniform)
+        if (pen_lds)
+            for (int i = threadIdx.x; i < RT * 16 * xa.n_seg; i += blockDim.x) {
+                const int row = i / xa.n_seg, sg = i - row * xa.n_seg;
+                pen_s[row][sg] = pen_b[(size_t)min(q0 + row, Q - 1) * xa.n_seg + sg];
+            }
         const int nq = min(RT * 16, Q - q0);
         float m_run[2] = {ninf, ninf};   // maxima over the regions of queries lane, lane + 64: carried across this wavefront's region groups
         int vi_run[2] = {0, 0};
@@ -1188,10 +1197,13 @@ __global__ __launch_bounds__(512) void align_prior_diag_kernel(
             if (on && lane < 48) kv_s[wave][lane] = vmask ? (uint8_t)(vmask[(size_t)a * V + min(v0 + lane, V - 1)] != 0) : (uint8_t)1;
             __syncthreads();
             if (on) {
-#pragma unroll 1
-                for (int rt = 0; rt < RT; ++rt)
+                int seg3[3];   // the factor segment of this lane's column in each of the three column tiles: once per round, not per row tile
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) {   // (the three column tiles' operand reads in flight together)
+                for (int ct = 0; ct < 3; ++ct) seg3[ct] = xa.seg_of_v[min(v0 + ct * 16 + ccol, V - 1)];
+#pragma unroll 2
+                for (int rt = 0; rt < RT; ++rt)   // (two row tiles x three column tiles of operand reads in flight: the kernel is a chain of round trips)
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) {
                         const bf16x8* ap = reinterpret_cast<const bf16x8*>(txt + ((size_t)b * Q + min(q0 + rt * 16 + ccol, Q - 1)) * d + g * 8);
                         const int v = min(v0 + ct * 16 + ccol, V - 1);
                         const bf16x8* bp = reinterpret_cast<const bf16x8*>(vis + ((size_t)a * V + v) * d + g * 8);
@@ -1213,12 +1225,13 @@ __global__ __launch_bounds__(512) void align_prior_diag_kernel(
                             for (int n = 0; n < 4; ++n) acc[n] *= un;
                         }
                         const unsigned vk = kv_s[wave][ct * 16 + ccol];
-                        const float* pen_v = pen_b + xa.seg_of_v[v];
+                        const float* pen_v = pen_b + seg3[ct];
 #pragma unroll
                         for (int n = 0; n < 4; ++n) {
                             const int q = min(q0 + rt * 16 + crow + n, Q - 1);
                             const bool keep = (vk & kq_s[rt * 16 + crow + n]) != 0;
-                            S[(rt * 16 + crow + n) * P + ct * 16 + ccol] = (keep ? acc[n] : neg_inf) - pen_v[(size_t)q * xa.n_seg];
+                            const float pn = pen_lds ? pen_s[rt * 16 + crow + n][seg3[ct]] : pen_v[(size_t)q * xa.n_seg];
+                            S[(rt * 16 + crow + n) * P + ct * 16 + ccol] = (keep ? acc[n] : neg_inf) - pn;
                         }
                     }
             }
