@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 from vlgae_amd.torch_struct import functional as F
 import vlgae_amd.torch_struct as ts
 dev = torch.device('cuda:0')
-B, L = 256, 40
+B, L = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 40)
 g = torch.Generator().manual_seed(1)
 dec = torch.randn(B, L, 2, 2, 2, generator=g).log_softmax(-1).to(dev)
 attach = torch.randn(B, L, L, 2, generator=g).to(dev)

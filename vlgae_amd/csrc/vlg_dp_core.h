@@ -797,6 +797,137 @@ VLG_HD void dmv_bw_width(const DmvCtx& c, int w, int t, int nd, X& x, int dir_rt
     }
 }
 
+// ---- Outside pass, long-sentence placements (value charts in the workspace): ONE stream of value reads over the whole segment ------
+// With the value charts in global memory every chunk of four split points per lane began with a round trip to the L2 (~1-2 us at one
+// workgroup per CU): 314 us of outside pass at N = 81 against 185 us of inside pass (3.9 us per width where N = 41 takes 1.0).  What those
+// reads fetch is the inside pass's tape -- nothing writes it now -- so they need not wait for anything: the items (width, span block,
+// chunk) of a segment form one sequence, and while item k is processed the value reads of item k + 1 -- the next chunk of the span, or
+// the first chunk and the own cells of the next width's span -- are in flight (issued behind item k's adjoint reads, ahead of its
+// stores).  Behind a width's barrier only the adjoint reads (LDS) are requested.  Same operations per result as dmv_bw_span's chunked
+// form: bit-identical counts.
+struct BwOwn { float2 oc, sv; float Sv, su; };
+struct BwChunk { float2 vv[4]; float uu[4], xa[4], xb[4]; };
+
+template <typename X>
+VLG_HD void dmv_bw_item_loads(const DmvCtx& c, int w, int G, int D, int r0, int DIR, bool first, BwOwn& own, BwChunk& ch) {
+    const int P = c.P, DW = D + VLG_MUL24(w, P);
+    const float* Cf = reinterpret_cast<const float*>(c.C);
+    const int eA = 2 * (D + 1) + (DIR == 0 ? 1 : 0), eB = 2 * (DW + 1) + (DIR == 0 ? 0 : 1);
+    const int eU = DIR == 0 ? D : D + P + w + 1, eV = DIR == 0 ? DW : D + 2;
+    if (first) {
+        const int kO = DIR == 0 ? DW : D + w + 1, kS = DIR == 0 ? DW : D + w, selfr = DIR == 0 ? 0 : w - 1;
+        own.oc = c.C[kO];
+        own.Sv = c.S[kS];
+        own.su = Cf[2 * (eU + VLG_MUL24(selfr, P)) + 1];
+        own.sv = c.I[eV + selfr];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * G, rc = r < w ? r : w - 1, rP = VLG_MUL24(rc, P);
+        ch.uu[u] = Cf[2 * (eU + rP) + 1];
+        ch.vv[u] = c.I[eV + rc];
+        ch.xa[u] = Cf[eA + 2 * rc];
+        ch.xb[u] = Cf[eB + 2 * rc];
+    }
+}
+
+template <int SR, int LG, typename X>
+VLG_HD void dmv_bw_segment_s(const DmvCtx& c, int w0, int w1, int tid, int nt, X& x) {
+    constexpr int G = 1 << LG;
+    if (w1 <= w0) return;
+    const int nd = nt >> 1;
+    const bool right = x.uniform(tid >= nd);
+    const int DIR = right ? 1 : 0;
+    const int t = right ? tid - nd : tid;
+    const int per = nd >> LG, rr = t & (G - 1), slot = t >> LG, P = c.P;
+    float* gCif = reinterpret_cast<float*>(c.gCi);
+    auto span_D = [&](int w_, int base_) { return VLG_MUL24(base_ + slot < c.Ne - w_ ? base_ + slot : 0, P + 1); };
+    BwOwn own, own_n;
+    BwChunk cur, nxt;
+    int w = w1 - 1, base = 0, ch = 0;
+    dmv_bw_item_loads<X>(c, w, G, span_D(w, 0), rr, DIR, true, own, cur);
+    // per-span state, set at the span's first chunk
+    float2 gc = make_float2(0.f, 0.f), gi = make_float2(0.f, 0.f), oc = make_float2(0.f, 0.f);
+    float gs = 0.f, Sv = 0.f;
+    int b0 = 0, b1 = 0, bs = 0;
+    for (;;) {
+        const int spans = c.Ne - w, nch = (((w + G - 1) >> LG) + 3) >> 2;
+        const bool live = base + slot < spans;
+        const int D = span_D(w, base), DW = D + VLG_MUL24(w, P);
+        const int eA = 2 * (D + 1) + (DIR == 0 ? 1 : 0), eB = 2 * (DW + 1) + (DIR == 0 ? 0 : 1);
+        const int eU = DIR == 0 ? D : D + P + w + 1, eV = DIR == 0 ? DW : D + 2;
+        const int kO = DIR == 0 ? DW : D + w + 1, kS = DIR == 0 ? DW : D + w, selfr = DIR == 0 ? 0 : w - 1;
+        // the item after this one (uniform over the workgroup)
+        int wn = w, bn = base, chn = ch + 1;
+        bool more = true;
+        if (chn == nch) {
+            chn = 0;
+            bn = base + per;
+            if (bn >= spans) { bn = 0; wn = w - 1; more = wn >= w0; }
+        }
+        const bool width_ends = wn != w;
+        const int r0 = rr + ch * (4 * G);
+        // ---- adjoint reads (LDS): the own cells at a span's first chunk, the read-modify-write targets of this chunk ----
+        float ga = 0.f;
+        float2 gb = make_float2(0.f, 0.f), gi_old = make_float2(0.f, 0.f);
+        if (ch == 0) {
+            ga = c.gCc[kO];
+            gb = c.gCi[kO];
+            gi_old = c.gI[kO];
+            if (SR == VLG_SR_MAX) { b0 = c.bpC[kO * 2]; b1 = c.bpC[kO * 2 + 1]; bs = c.bpS[kS]; }
+        }
+        float o_c[4], o_ga[4], o_gb[4];
+        float2 o_gi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * G, rc = r < w ? r : w - 1, rP = VLG_MUL24(rc, P);
+            o_gi[u] = c.gI[eV + rc];
+            o_c[u] = c.gCc[eU + rP];
+            o_ga[u] = gCif[eA + 2 * rc];
+            o_gb[u] = gCif[eB + 2 * rc];
+        }
+        // ---- the next item's value reads (workspace): in flight while this item is processed ----
+        if (more) dmv_bw_item_loads<X>(c, wn, G, span_D(wn, bn), rr + chn * (4 * G), DIR, chn == 0, own_n, nxt);
+        if (ch == 0) {   // span state: total adjoint of the own complete cell, the same-width term's share, gs
+            oc = own.oc;
+            Sv = own.Sv;
+            gc = make_float2(0.f, 0.f);
+            if (live && !(DIR == 1 && D == 0 && w != c.len)) gc = make_float2(gb.x, ga + gb.y);   // masked root cell: dmv.py:63
+            const float self0 = adj_w<SR>(gc.x, own.su + own.sv.x, oc.x, selfr, b0);
+            const float self1 = adj_w<SR>(gc.y, own.su + own.sv.y, oc.y, selfr, b1);
+            gi = make_float2(gi_old.x + self0, gi_old.y + self1);   // complete adjoint of IL(j,i) | IR(i,j)
+            gs = gi.x + gi.y;
+        }
+        float q0[4], q1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * G;
+            const bool ok = r < w;
+            q0[u] = ok ? adj_w<SR>(gc.x, cur.uu[u] + cur.vv[u].x, oc.x, r, b0) : 0.f;
+            q1[u] = ok ? adj_w<SR>(gc.y, cur.uu[u] + cur.vv[u].y, oc.y, r, b1) : 0.f;
+        }
+        x.lockstep();   // the lanes of a group sit in one wavefront: every load above precedes every store below
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * G;
+            if (live && r < w) {
+                const float ws = adj_w<SR>(gs, cur.xa[u] + cur.xb[u], Sv, r, bs);
+                if (r != selfr) c.gI[eV + r] = make_float2(o_gi[u].x + q0[u], o_gi[u].y + q1[u]);
+                c.gCc[eU + VLG_MUL24(r, P)] = o_c[u] + (q0[u] + q1[u]);
+                gCif[eA + 2 * r] = o_ga[u] + ws;
+                gCif[eB + 2 * r] = o_gb[u] + ws;
+            }
+        }
+        if (chn == 0 && live && rr == 0) c.gI[kO] = gi;   // the span's last chunk: == d logZ / d attach[j,i,:] | attach[i,j,:]
+        if (width_ends) x.sync();
+        if (!more) break;
+        if (chn == 0) { own.oc = own_n.oc; own.sv = own_n.sv; own.Sv = own_n.Sv; own.su = own_n.su; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cur.vv[u] = nxt.vv[u]; cur.uu[u] = nxt.uu[u]; cur.xa[u] = nxt.xa[u]; cur.xb[u] = nxt.xb[u]; }
+        w = wn; base = bn; ch = chn;
+    }
+}
+
 // widths w1-1 ... w0 of one segment, descending, one barrier per width
 template <int SR, int LG, int LONGSPAN, typename X>
 VLG_HD void dmv_bw_segment(const DmvCtx& c, int w0, int w1, int tid, int nt, X& x) {
@@ -838,6 +969,18 @@ VLG_HD void dmv_bw_all(const DmvCtx& c, int tid, int nt, X& x) {
         dmv_bw_segment_p<SR, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
         dmv_bw_segment_p<SR, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
         dmv_bw_segment_p<SR, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
+        return;
+    }
+#endif
+#ifndef VLG_NO_BW_STREAM
+    if constexpr (LONGSPAN == kSpansLong) {   // long-sentence placements: the value reads as one stream over each segment (dmv_bw_segment_s)
+        dmv_bw_segment_s<SR, 6>(c, sc.first[6], sc.first[7], tid, nt, x);
+        dmv_bw_segment_s<SR, 5>(c, sc.first[5], sc.first[6], tid, nt, x);
+        dmv_bw_segment_s<SR, 4>(c, sc.first[4], sc.first[5], tid, nt, x);
+        dmv_bw_segment_s<SR, 3>(c, sc.first[3], sc.first[4], tid, nt, x);
+        dmv_bw_segment_s<SR, 2>(c, sc.first[2], sc.first[3], tid, nt, x);
+        dmv_bw_segment_s<SR, 1>(c, sc.first[1], sc.first[2], tid, nt, x);
+        dmv_bw_segment_s<SR, 0>(c, sc.first[0], sc.first[1], tid, nt, x);
         return;
     }
 #endif
