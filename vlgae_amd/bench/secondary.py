@@ -309,6 +309,40 @@ def _run_all(out, args, h, dev):
         "grounding_decode_ms": timed(lambda: align.grounding_decode(s_txt.detach(), s_vis.detach(), s_tmask, s_vmask), 10, dev),
         "shape": f"B=A={Bs} Q={Q} V={Vs} d={d} {args.dtype} in"}
     del s_txt, s_vis
+    # the attention fuse at that layout (1369 keys per image: the key-split kernels, csrc/vlg_attn.hip), forward and forward + adjoint,
+    # as captured HIP graphs (device time: a handful of launches of 5-45 us each is host-bound when enqueued eagerly)
+    try:
+        w_vis, w_txt, w_mid, w_enc = mk(Bs, Vs, d), mk(Bs, N, d), mk(Bs, Vs, hdim), mk(Bs, L, hdim)
+        w_leaves = [w_vis, w_txt, w_mid, w_enc, ln_w, ln_b]
+        w_dout = dout[:Bs].contiguous()
+
+        def graph_ms(fn, n=30):
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fn()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                keep = fn()
+            for _ in range(5):
+                gr.replay()
+            sec = _events(gr.replay, n, 3, dev)
+            del keep, gr
+            return sec * 1e3
+        with torch.autograd.set_multithreading_enabled(False):
+            fwd = graph_ms(lambda: align.attention_fuse(*(x.detach() for x in w_leaves), 1e-5))
+            fwd_bwd = graph_ms(lambda: torch.autograd.grad(align.attention_fuse(*w_leaves, 1e-5), w_leaves, w_dout))
+        flops_f = 2.0 * Bs * L * Vs * (d + hdim)
+        out["shipped_layout"]["attention_fuse"] = {
+            "fwd_ms": fwd, "fwd_bwd_ms": fwd_bwd, "fwd_TFLOP/s": flops_f / (fwd * 1e-3) / 1e12,
+            "key_bytes_GB/s": Bs * Vs * (d + hdim) * (2 if in_dtype == torch.bfloat16 else 4) / (fwd * 1e-3) / 1e9,
+            "shape": f"B={Bs} L={L} V={Vs} d={d} h={hdim} {args.dtype} in; HIP-graph replays (forward: split + merge + combine launches; "
+                     "adjoint: combine + sweep + d_txt + regions + affine, the forward's merged records handed over)"}
+        del w_vis, w_txt, w_mid, w_enc
+    except Exception as e:   # never costs the line
+        out["shipped_layout"]["attention_fuse"] = {"error": repr(e)[:200]}
 
     # arc encoder's trilinear term (joint.py:282-284): M = B * (L + 1) rows, 128^3 weights
     a_child, a_parent = mk(B, N, d), mk(B, N, d)
