@@ -339,7 +339,7 @@ def test_dmv1o_long_sentences_full_size(ts, oracle_mod, dt):
     omd, oma = md[:n].float().cpu().numpy(), ma[:n].float().cpu().numpy()
     rlz, rgd, rga = oracle_mod.dmv1o(omd, oma, lengths[:n].numpy(), "log", np.float64)
     assert np.all(np.abs(lz[:n].detach().cpu().numpy().reshape(rlz.shape) - rlz) <= logz_tol(rlz))
-    # fp32 charts at |logZ| ~ 300: one ulp of a chart value is 3e-5 (2e-4 at the peakiest L >= 62 cases)
+    # fp32 charts at |logZ| ~ 300: one ulp of a chart value is 3e-5 (HISTORY.md section 6: 2e-4 at the peakiest L >= 62 cases)
     assert np.abs(ga[:n].cpu().numpy() - rga).max() <= 1e-4 and np.abs(gd[:n].cpu().numpy() - rgd).max() <= 2e-4
     # Viterbi at full size: a tree per sentence, single root
     heads_am = ts.DMV1o([md, ma], lengths_d).argmax.sum(-1)
@@ -357,7 +357,7 @@ def test_dmv1o_long_peaky_sentences(ts, oracle_mod, L, scale):
       L <= 40:  expected counts within 1e-4 of the fp64 oracle even at score scale 6 (the bound of BASELINE.json's north_star)
       L  > 40:  within max(1e-4, 6 x the error of the SEQUENTIAL fp32 oracle on the same inputs) and never above 6e-4
                 (observed: 1.4e-4 at L = 63, 1.9e-4 at L = 88, 4.9e-4 at L = 89 against 0.2-0.9e-4 for the fp32 oracle: the
-                butterfly summation order and the 1-ulp v_exp_f32 / v_log_f32)
+                butterfly summation order and the 1-ulp v_exp_f32 / v_log_f32, HISTORY.md section 6)
     logZ to 2e-5 relative, Max-semiring values to 1e-5 relative with a valid projective tree of exactly that score."""
     from vlgae_amd.torch_struct import functional as Fn
     rng = np.random.default_rng(1000 + L)

@@ -975,7 +975,7 @@ __global__ __launch_bounds__(kAMThreads) void align_argmax_kernel(
             }
             // ---- maxima over the regions: S^T, one query tile at a time ----
             // (tools/time_argmax_ablation.sh: -DVLG_ABL_AM_NOST / _NOS drop one of the two products, _NOSEARCH the first-equal searches -- wrong
-            //  results, measured ceilings: DESIGN.md section 3.1a)
+            //  results, measured ceilings: HISTORY.md section 3.1a)
 #ifdef VLG_ABL_AM_NOST
             if (false) {
 #else
@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(kAMThreads, VLG_AF_WPE) void align_full_kernel(
                 v_masked = __builtin_amdgcn_ballot_w64(vkeep != 0xfffu) != 0;
             }
             // (tools/time_align_full_ablation.sh: -DVLG_ABL_AF_NOMFMA drops the products and the LDS writes, -DVLG_ABL_AF_NOSTORE the global stores --
-            //  wrong results, measured ceilings: DESIGN.md section 3)
+            //  wrong results, measured ceilings: HISTORY.md section 3)
 #ifdef VLG_ABL_AF_NOMFMA
             if (false)
 #endif

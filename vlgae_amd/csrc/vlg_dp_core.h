@@ -35,7 +35,7 @@
 // complete-span parents; those only ever reach the NOCHILD component, so gCc is a plain float
 // chart) and gCi (from incomplete-span parents): within a phase every
 // read-modify-write target is then owned by exactly one (span, r) pair -- no atomics, results are
-// bit-reproducible (ownership argument: DESIGN.md, "Outside pass").
+// bit-reproducible (ownership argument: DESIGN.md section 2, HISTORY.md section 2.2).
 #pragma once
 
 #if defined(__HIPCC__)

@@ -43,7 +43,7 @@ tag embedding is trainable) and `vis_box_feat` [B,R,n] (no gradient unless `feat
 parent encoders stacked), `ln_w` / `ln_b`, `w1` / `w2` / `b` (arc encoder), `token_emb` / `root_emb` / `dec_emb` and the "ff.*" feed-forwards.
 
 `wiring="r3"` keeps round 3's chain for continuity of the bench history (fused x fed to lang_feat_max_tree, scorer inputs and
-matching-space features as leaves, plain sum of the two losses): NOT what the reference does; see DESIGN.md section 5.
+matching-space features as leaves, plain sum of the two losses): NOT what the reference does; see HISTORY.md section 5.
 """
 import torch
 import torch.nn.functional as F
