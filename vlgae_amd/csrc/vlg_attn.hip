@@ -373,12 +373,12 @@ __device__ __forceinline__ void attn_forward_tile_bf16(f32x4 (&Y)[kAttnMaxCT], f
         // ---- GEMM 1: S^T[key][word] (joint.py:670-672) ----
         f32x4 S[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < KJ; ++j)
+        for (int j = 0; j < KJ; ++j)   // (K step outermost: the T accumulation chains interleave instead of four dependent MFMAs in a row)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
                 S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf[t][j]), wf0[j], S[t], 0, 0, 0);
-        }
         for (int k0 = 32 * KJ; k0 < d; k0 += 32 * KJ) {   // features past 128: read in place
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
@@ -1045,9 +1045,10 @@ __device__ __forceinline__ void attn_bwd_sweep(f32x4 (&dT)[FTM], const f32x4 (&D
                 const float ds = p * (dP[t][n] - Dsum);
                 S[t][n] = ds;
                 // v < Vp by construction; zero for v >= V.  bf16 features: the scratch holds bf16 (what the regions kernel multiplies)
-                if constexpr (kIsBF16<In>) {
-                    reinterpret_cast<uint16_t*>(PT)[((size_t)b * Vp + v) * Lp + q0 + r] = __builtin_bit_cast(uint16_t, (__bf16)p);
-                    reinterpret_cast<uint16_t*>(DST)[((size_t)b * Vp + v) * Lp + q0 + r] = __builtin_bit_cast(uint16_t, (__bf16)ds);
+                if constexpr (kIsBF16<In>) {   // bf16 scratch: [b][word tile][key][16 words] (a key's 16 words are one 32-byte row: what the regions kernel reads)
+                    const size_t at = ((((size_t)b * (Lp >> 4) + (q0 >> 4)) * Vp + v) << 4) + r;
+                    reinterpret_cast<uint16_t*>(PT)[at] = __builtin_bit_cast(uint16_t, (__bf16)p);
+                    reinterpret_cast<uint16_t*>(DST)[at] = __builtin_bit_cast(uint16_t, (__bf16)ds);
                 } else {
                     PT[((size_t)b * Vp + v) * Lp + q0 + r] = p;
                     DST[((size_t)b * Vp + v) * Lp + q0 + r] = ds;
@@ -1152,6 +1153,7 @@ __device__ __forceinline__ void attn_bwd_sweep_stream_bf16(f32x4 (&dT)[FTM], con
         for (int t = 0; t < T; ++t) mf[s2][t] = buf_ld128(mid_rs, mlane + 64 * s2, (v_begin + 16 * t) * h * 2);
         asm volatile("" ::: "memory");
     }
+    char* pimg = lds + kSweepBytes;                                // [64 keys][16 words] bf16: P^T, then dS^T
     char* wr = lds + r * kSweepPitch + 16 * g;                     // image[key 16t + r][feature 32j + 8g ..]
     const char* rd = lds + (4 * g + q) * kSweepPitch + p4 * 8;     // transposed reads: rows 4g + q (and + 16) of a 32-key half
 
@@ -1159,12 +1161,12 @@ __device__ __forceinline__ void attn_bwd_sweep_stream_bf16(f32x4 (&dT)[FTM], con
         // ---- GEMM 1 + the image ----
         f32x4 S[T], dP[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < KJ; ++j)
+        for (int j = 0; j < KJ; ++j)   // (K step outermost: the T accumulation chains interleave instead of four dependent MFMAs in a row)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
                 S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf[t][j]), wf0[j], S[t], 0, 0, 0);
-        }
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -1197,9 +1199,23 @@ __device__ __forceinline__ void attn_bwd_sweep_stream_bf16(f32x4 (&dT)[FTM], con
                 const float p = S[t][n] * livef;                       // words past Lq contribute nothing downstream
                 const float ds = p * (dP[t][n] - Dsum);
                 S[t][n] = ds;
-                PT[((size_t)b * Vp + v) * Lp + q0 + r] = __builtin_bit_cast(uint16_t, (__bf16)p);   // v < Vp by construction; zero for v >= V
-                DST[((size_t)b * Vp + v) * Lp + q0 + r] = __builtin_bit_cast(uint16_t, (__bf16)ds);
+                // P^T / dS^T of the step as bf16 [64 keys][16 words] images in LDS (zero for keys >= V): they leave below as four contiguous
+                // 1-KiB stores (the 32 two-byte stores per step they replace held the vector-memory queue: 60 % of the wave cycles were issue stalls)
+                *reinterpret_cast<uint16_t*>(pimg + (16 * t + 4 * g + n) * 32 + r * 2) = __builtin_bit_cast(uint16_t, (__bf16)p);
+                *reinterpret_cast<uint16_t*>(pimg + 2048 + (16 * t + 4 * g + n) * 32 + r * 2) = __builtin_bit_cast(uint16_t, (__bf16)ds);
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            const size_t row0 = ((((size_t)b * (Lp >> 4) + (q0 >> 4)) * Vp + v0) << 4);   // scratch layout [b][word tile][key][16 words]
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const u32x4 xp = *reinterpret_cast<const u32x4*>(pimg + hh * 1024 + lane * 16);
+                const u32x4 xs = *reinterpret_cast<const u32x4*>(pimg + 2048 + hh * 1024 + lane * 16);
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(PT + row0) + hh * 1024 + lane * 16) = xp;
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(DST + row0) + hh * 1024 + lane * 16) = xs;
+            }
+        }
+        asm volatile("" ::: "memory");
         bf16x8 dSh[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
@@ -1383,13 +1399,14 @@ __global__ __launch_bounds__(64) void attn_bwd_regions_bf16_kernel(
     for (int ct = 0; ct < kAttnMaxCT; ++ct) dM[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ft = 0; ft < FTM; ++ft) dV[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const uint16_t* prow = reinterpret_cast<const uint16_t*>(PT) + ((size_t)b * Vp + v) * Lp + 4 * g;   // bf16 with bf16 features
-    const uint16_t* srow = reinterpret_cast<const uint16_t*>(DST) + ((size_t)b * Vp + v) * Lp + 4 * g;
+    // bf16 scratch [b][word tile][key][16 words]: a wavefront's 16 keys x 32 bytes of one word tile are 512 contiguous bytes
+    const uint16_t* prow = reinterpret_cast<const uint16_t*>(PT) + (((size_t)b * WT * Vp + v) << 4) + 4 * g;
+    const uint16_t* srow = reinterpret_cast<const uint16_t*>(DST) + (((size_t)b * WT * Vp + v) << 4) + 4 * g;
     const uint16_t* afrag = dyF + (size_t)b * WT * CT * 256 + lane * 4;   // fragment (word tile, channel tile): 64 lanes x 8 contiguous bytes
     const uint16_t* tfrag = txtF + (size_t)b * WT * FT * 256 + lane * 4;
     for (int wt = 0; wt < WT; ++wt) {
-        const v4i16 pb = *reinterpret_cast<const v4i16*>(prow + 16 * wt);
-        const v4i16 sb = *reinterpret_cast<const v4i16*>(srow + 16 * wt);
+        const v4i16 pb = *reinterpret_cast<const v4i16*>(prow + (((size_t)wt * Vp) << 4));
+        const v4i16 sb = *reinterpret_cast<const v4i16*>(srow + (((size_t)wt * Vp) << 4));
         v4i16 af[kAttnMaxCT], tf[FTM];
 #pragma unroll
         for (int ct = 0; ct < kAttnMaxCT; ++ct) af[ct] = *reinterpret_cast<const v4i16*>(afrag + ((size_t)wt * CT + min(ct, CT - 1)) * 256);
@@ -1657,7 +1674,7 @@ static void attn_backward_launch(const void* vis, const void* txt, const void* v
         }
         hipLaunchKernelGGL((attn_bwd_combine_kernel<In, GOut>), tiles, dim3(64), lds, s, merged, 1, (P)enc_x, gamma, dout,
                            ld_b, ld_l, L, h, eps, stats, part, dy_rows, (G)d_enc_x, (P)txt, d, p.Lp, dyT, txtT);
-        hipLaunchKernelGGL((attn_bwd_sweep_kernel<In, FTM>), chunks, dim3(64), (kSweepBytes > kStageBytes ? kSweepBytes : kStageBytes), s, (P)vis, (P)txt, (P)vis_mid, (const float*)dy_rows,
+        hipLaunchKernelGGL((attn_bwd_sweep_kernel<In, FTM>), chunks, dim3(64), (kSweepBytes + 4096 > kStageBytes ? kSweepBytes + 4096 : kStageBytes), s, (P)vis, (P)txt, (P)vis_mid, (const float*)dy_rows,
                            (const float*)stats, L, V, d, h, p.sp.CK, p.sp.NC, pairs, PT, DST, p.Vp, p.Lp, rec);
         hipLaunchKernelGGL((attn_bwd_dtxt_kernel<GOut>), dim3(p.WT, B, d >> 4), dim3(64), 0, s, (const float*)rec, p.sp.NC, L, d, (G)d_txt);
     } else {
