@@ -883,7 +883,7 @@ def test_attn_fuse_large_v(oracle_mod):
     g_wide = torch.autograd.grad(wide, leaves, cot)
     one = align.attention_fuse(*leaves, 1e-5, key_chunk=V)
     g_one = torch.autograd.grad(one, leaves, cot)
-    assert float((wide.detach().cpu() - torch.from_numpy(ref_out)).abs().max()) <= 1e-4 and float((wide - one).abs().max()) <= 1e-4
+    assert float((wide.detach().cpu() - torch.from_numpy(ref_out)).abs().max()) <= 1e-4 and float((wide - one).detach().abs().max()) <= 1e-4
     for name, a, b, want in zip(ATTN_GRAD_NAMES, g_wide, g_one, ref_g):
         assert np.abs(a.cpu().numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), name
         assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), name

@@ -8,7 +8,9 @@ tensors in, named ('B','A','Q','V') tensor out) so it can be registered under th
 registry unchanged:  JointModelBase.add_impl_to_group("gather_logit", "mi355x")(gather_logit_simple)
 (base.py:118-142; selected by `gather_logit_mode` in config/model/vlgae.yaml:57).
 """
+import functools
 import math
+import os
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -186,12 +188,22 @@ def gather_logit_reduced(self, inputs, vis, txt, vp):
     return _GatherLogitReduced.apply(txt_feat, vis_feat, txt_mask, vis_mask, txt_marginal, -INF)
 
 
+@functools.lru_cache(maxsize=256)
+def _attn_sizes(B, L, V, d, h, key_chunk):
+    """(forward workspace, saved-record bytes, adjoint workspace fp32 grads, adjoint workspace bf16 grads): pure functions of the shape --
+    asked once per shape (four ctypes calls per step are host time an eager step does not have)."""
+    lib = _C.lib()
+    return (lib.vlg_attn_fuse_workspace(B, L, V, h, key_chunk), lib.vlg_attn_fuse_saved_bytes(B, L, V, h, key_chunk),
+            lib.vlg_attn_fuse_backward_workspace(B, L, V, d, h, _C.F32, key_chunk), lib.vlg_attn_fuse_backward_workspace(B, L, V, d, h, _C.BF16, key_chunk))
+
+
 def _attn_fuse_launch(vis_c, txt_c, mid_c, enc_c, gamma, beta, eps, dt, want_att, key_chunk=0, save=False):
     B, V, d = vis_c.shape
     L, h = txt_c.shape[1] - 1, mid_c.shape[2]
     lib = _C.lib()
-    nbytes = 0 if want_att else lib.vlg_attn_fuse_workspace(B, L, V, h, key_chunk)   # chunk records of the key-split form (many keys)
-    sbytes = lib.vlg_attn_fuse_saved_bytes(B, L, V, h, key_chunk) if save and not want_att else 0
+    sizes = _attn_sizes(B, L, V, d, h, key_chunk)
+    nbytes = 0 if want_att else sizes[0]                     # chunk records of the key-split form (many keys)
+    sbytes = sizes[1] if save and not want_att else 0
     (out, att), ws = _C.alloc_f32(vis_c.device, ((B, L, h), (B, L, V) if want_att else None), nbytes)
     # the merged records of the key-split form, kept for the adjoint (a tensor of its own: the chunk records above are ~8x its size)
     saved = torch.empty(sbytes // 4, dtype=torch.float32, device=vis_c.device) if sbytes else None
@@ -235,7 +247,7 @@ class _AttnFuse(torch.autograd.Function):
         # fp32 round trip through HBM, no cast launch; at V = 1369, B = 64 the fp32 d_vis_mid alone is 90 MB)
         bf = dt == _C.BF16 and dtypes[0] == dtypes[1] == dtypes[2] == dtypes[3] == torch.bfloat16
         gdt = _C.BF16 if bf else _C.F32
-        nbytes = lib.vlg_attn_fuse_backward_workspace(B, L, V, d, h, gdt, key_chunk)
+        nbytes = _attn_sizes(B, L, V, d, h, key_chunk)[3 if bf else 2]
         shapes = ((B, V, d), (B, L + 1, d), (B, V, h), (B, L, h))
         if bf:   # one bf16 allocation for the four feature gradients, one fp32 one for the affine pair + the scratch
             numels = [math.prod(sh_) for sh_ in shapes]
@@ -724,7 +736,16 @@ class SmallMatmulGroup:
         self.problems, self.keep, self.first = [], [], None     # stream order protects the operands from here on (same stream)
 
 
+_FP32_WGRAD_LIBRARY = bool(os.environ.get("VLGAE_WGRAD_FP32_LIBRARY"))   # opt-out: float32 weight gradients through the library's fp32 GEMM
+
+
 def _wgrad_ok(K, M, N, dtype):
+    """Whether the split-K kernel serves this weight gradient.  Accuracy contract for float32 operands (`precision: 32`): every product is
+    three bf16 matrix-core products of hi / lo split operands (a_hi b_hi + a_hi b_lo + a_lo b_hi), ~2^-16 relative per product with fp32
+    accumulation -- float32-level results (checked against float64 in tests), not bit-equal to an fp32-FMA GEMM.  A caller that wants the
+    library's true fp32 GEMM sets VLGAE_WGRAD_FP32_LIBRARY=1 before importing this package (2-9x slower at these shapes)."""
+    if dtype == torch.float32 and _FP32_WGRAD_LIBRARY:
+        return False
     return dtype in (torch.bfloat16, torch.float32) and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8 and K >= 2048
 
 

@@ -341,7 +341,12 @@ int vlg_vis_encoder_backward(const void* P, const void* C, const void* grad_mid,
         else hipLaunchKernelGGL(vis_encoder_bwd_kernel<uint16_t>, grid, dim3(kEncThreads), 0, s, a);
         return check_launch("vis_encoder_bwd_kernel");
     }
-    const int cols = H * (1 + (off_rel >= 0) + (off_attr >= 0));       // the encoders' column blocks are adjacent from col 0 (checked by the host mirror)
+    // the per-image sums run over the columns [0, cols): the encoders' blocks must be adjacent from column 0 in the order box | rel | attr
+    // (what the Python mirror lays out; a C caller with another layout must hear about it -- ADVICE r05)
+    if (col_box != 0 || col_rel != H || (off_attr >= 0 && col_attr != 2 * H))
+        return set_error(VLG_ERR_SHAPE, "vis_encoder_backward: with a relation factor the column blocks must be box | rel | attr from column 0 "
+                                        "(col_box=%d col_rel=%d col_attr=%d, H=%d)", col_box, col_rel, col_attr, H);
+    const int cols = H * (1 + (off_rel >= 0) + (off_attr >= 0));
     const size_t n = (size_t)B * (cols >> 2);
     if (dtype == VLG_F32) {
         hipLaunchKernelGGL(vis_encoder_bwd_kernel<float>, grid, dim3(kEncThreads), 0, s, a);

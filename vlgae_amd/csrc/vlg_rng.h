@@ -24,9 +24,12 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 // keep flags of eight consecutive elements (group index g): 16 random bits each, keep <=> bits >= thr, thr = round(p * 65536);
 // m[k] = `scale` where kept, 0 where dropped.  `site`: which dropout layer of the step draws (independent streams off one state).
 __device__ __forceinline__ void keep8(const uint64_t* __restrict__ rng, uint32_t site, uint64_t g, uint32_t thr, float scale, float (&m)[8]) {
-    const uint64_t seed = rng[0] + site, step = rng[1];
+    // The site goes into the key's second word on its own (times an odd constant), NOT into the seed's arithmetic: with `seed + site` the
+    // stream of (seed s, site 2) was that of (seed s + 1, site 1) -- a trainer seeding its ranks with seed + rank would have drawn rank 0's
+    // mid_ff mask and rank 1's text-encoder mask from the same bits.
+    const uint64_t seed = rng[0], step = rng[1];
     const uint4 r = philox4x32_10(make_uint4((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)step, (uint32_t)(step >> 32)),
-                                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+                                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (site * 0x9E3779B9u)));
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
