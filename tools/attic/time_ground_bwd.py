@@ -23,3 +23,7 @@ e0.record()
 for _ in range(30): ours()
 e1.record(); torch.cuda.synchronize()
 print('grounding loss forward + both gradients: %.3f ms' % (e0.elapsed_time(e1) / 30))
+ga, gb = ours()
+torch.cuda.synchronize()
+import hashlib
+print('sha256(d_txt|d_vis) %s   sum|d_txt| %.6f sum|d_vis| %.6f' % (hashlib.sha256(ga.float().cpu().numpy().tobytes() + gb.float().cpu().numpy().tobytes()).hexdigest()[:16], float(ga.float().abs().sum()), float(gb.float().abs().sum())))

@@ -937,6 +937,15 @@ __global__ __launch_bounds__(256) void ground_bwd_dense_kernel(
 // otherwise need a barrier of their own between the last read of a chunk and the store of the next one).  No split of the outer
 // range by default: a block sweeps all partners of its caption / image, the result is written once -- no atomics, no zero fill.
 // =====================================================================================================
+#ifdef VLG_GW_STAMP   // tools/ experiment: per-role cycles from a barrier's release to the arrival at the next one (printed for two blocks)
+#define GW_STAMP_DECL unsigned long long st_busy = 0, st_t = __builtin_amdgcn_s_memtime();
+#define GW_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_busy += __builtin_amdgcn_s_memtime() - st_t; __syncthreads(); st_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define GW_STAMP_OUT(role) do { if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) printf("block %d wave %d role %s: %llu cycles busy over %d steps = %llu per step\n", (int)blockIdx.x, wave, role, st_busy, T, st_busy / (unsigned long long)T); } while (0)
+#else
+#define GW_STAMP_DECL
+#define GW_SYNC() __syncthreads()
+#define GW_STAMP_OUT(role)
+#endif
 constexpr int kGwThreads = 768;   // twelve waves: 4 consumers, 2 builders, 4 tile stagers, 2 array stagers
 // KS = 2: the consumers split the contraction axis between two wave pairs (each wave twice the column tiles, half the chunks:
 // fewer fragment reads per MFMA -- the image side's 3 x 2 tiles per wave read 5 fragments per 6 MFMAs and the LDS, not the matrix
@@ -1029,6 +1038,7 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
         if (SPC < T) chunk_load(o_begin + CHP, carg, cval, cpar);
         __syncthreads();                                 // (chunk 0 visible to the builders)
         __syncthreads();
+        GW_STAMP_DECL
         for (int t = 0; t < T; ++t) {
             const int u = t + 1;
             // the chunk that starts with the NEXT step: its half was last read a whole chunk ago (the current chunk sits in the
@@ -1040,8 +1050,9 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
                 if ((c + 1) * SPC < T) chunk_load(o_begin + (c + 1) * CHP, carg, cval, cpar);
             }
 #endif
-            __syncthreads();
+            GW_SYNC();
         }
+        GW_STAMP_OUT("arrays");
         return;
     }
 
@@ -1049,25 +1060,43 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
         // ---- waves 6-9: the other side's feature tiles, L2 -> registers one step ahead -> LDS (the buffer the consumers are not reading) ----
         const int ttid = tid - 384;
         constexpr int nthr = 256, NV = (kGdD * SEGL + nthr - 1) / nthr, segs = SEGL, nvec = kGdD * SEGL;
-        uint4 xs[PP][NV];
+        // the register set of the tile in flight, addressed by a compile-time set number.  (Round 6 measured TWO sets -- step u + 2
+        // requested when step u is written, counted vmcnt waits: 131.4 / 102.0 us against 132.0 / 101.5: a tile's reads are back within a
+        // step.  Arrays handed to the lambdas by pointer or reference went to scratch memory once there were two of them.)
+        uint4 xs[1][PP][NV];
 #pragma unroll
         for (int q = 0; q < PP; ++q)
 #pragma unroll
-            for (int j = 0; j < NV; ++j) xs[q][j] = make_uint4(0, 0, 0, 0);
-        auto stage_load = [&](int o, uint4 (*xs)[NV]) __attribute__((always_inline)) {
+            for (int j = 0; j < NV; ++j) xs[0][q][j] = make_uint4(0, 0, 0, 0);
+        // a thread's source offsets inside a pair's [d][Kp] block never change: one buffer descriptor over the feature tensor, the
+        // per-thread byte offsets in NV registers and the pair's base as the scalar offset -- a read is one `buffer_load_dwordx4` with no
+        // address arithmetic in the loop.  (The 64-bit per-thread addresses the compiler built every step reused registers of the step
+        // before, and the hazard it then assumed put an s_waitcnt vmcnt(2..4) between the reads of ONE step: every step waited for
+        // reads it had issued a few instructions earlier.)
+        typedef unsigned int gw_u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t feat_rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)featT, 0, A * kGdD * Kp * 2, 0x00020000);
+        int soff[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = min(ttid + j * nthr, nvec - 1);
+            const int row = i / segs, seg = i - row * segs;
+            soff[j] = (row * (Kp >> 3) + seg) * 16;
+        }
+        auto stage_load = [&](int o, auto set) __attribute__((always_inline)) {
+            constexpr int S = decltype(set)::value;
 #pragma unroll
             for (int q = 0; q < PP; ++q) {
                 const int oo = min(o + q, O - 1);
-                const uint4* src = reinterpret_cast<const uint4*>(featT + (size_t)oo * kGdD * Kp);
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
-                    const int i = min(ttid + j * nthr, nvec - 1);
-                    const int row = i / segs, seg = i - row * segs;
-                    xs[q][j] = src[row * (Kp >> 3) + seg];
+                    const gw_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, soff[j], oo * (kGdD * Kp * 2), 0);
+                    xs[S][q][j] = make_uint4(v[0], v[1], v[2], v[3]);
                 }
             }
         };
-        auto stage_tile = [&](char* tile, const uint4 (*xs)[NV]) __attribute__((always_inline)) {
+        auto stage_tile = [&](char* tile, auto set) __attribute__((always_inline)) {
+            constexpr int S = decltype(set)::value;
 #pragma unroll
             for (int q = 0; q < PP; ++q)
 #pragma unroll
@@ -1075,26 +1104,29 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
                     const int i = ttid + j * nthr;
                     if (i < nvec) {
                         const int row = i / segs, seg = i - row * segs;
-                        *reinterpret_cast<uint4*>(tile + row * PITCH + q * UW * 2 + seg * 16) = xs[q][j];
+                        *reinterpret_cast<uint4*>(tile + row * PITCH + q * UW * 2 + seg * 16) = xs[S][q][j];
                     }
                 }
         };
-        stage_load(o_begin, xs);
+        constexpr std::integral_constant<int, 0> s0{};
+        stage_load(o_begin, s0);
         __syncthreads();                                 // (the zero fill)
         __syncthreads();
-        stage_tile(tile0, xs);
-        stage_load(o_begin + PP, xs);
+        stage_tile(tile0, s0);
+        stage_load(o_begin + PP, s0);
         __syncthreads();
+        GW_STAMP_DECL
         for (int t = 0; t < T; ++t) {
             const int u = t + 1;
 #ifndef VLG_GW_NOSTAGE
             if (u < T) {
-                stage_tile(tile0 + (u & 1) * TILE_B, xs);
-                stage_load(o_begin + (u + 1) * PP, xs);
+                stage_tile(tile0 + (u & 1) * TILE_B, s0);
+                stage_load(o_begin + (u + 1) * PP, s0);
             }
 #endif
-            __syncthreads();
+            GW_SYNC();
         }
+        GW_STAMP_OUT("tiles");
         return;
     }
 
@@ -1174,6 +1206,7 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
         __syncthreads();                                 // (chunk 0 of the small arrays)
         build(0, wt0, ps_old[0], po_old[0]);
         __syncthreads();
+        GW_STAMP_DECL
         for (int t = 0; t < T; ++t) {
             const int u = t + 1;
 #ifndef VLG_GW_NOBUILD
@@ -1182,8 +1215,9 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
                 else build(u, wt0, ps_old[0], po_old[0]);
             }
 #endif
-            __syncthreads();
+            GW_SYNC();
         }
+        GW_STAMP_OUT("build");
         return;
     }
 
@@ -1200,6 +1234,7 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
     __syncthreads();
     __syncthreads();
     __syncthreads();
+    GW_STAMP_DECL
     for (int t = 0; t < T; ++t) {
         const char* wt = wt0 + (t & 1) * W_B;
         const char* tile = tile0 + (t & 1) * TILE_B;
@@ -1226,8 +1261,9 @@ __global__ __launch_bounds__(kGwThreads) void ground_bwd_ws_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
 #endif
-        __syncthreads();
+        GW_SYNC();
     }
+    GW_STAMP_OUT("mfma");
     if (KS == 2) {   // (the producers have left: a barrier counts the waves that are still running)
         float* xch = reinterpret_cast<float*>(smem_raw) + (size_t)w2 * (RT * CT * 4 * 64);
         if (ks == 1) {
@@ -1300,7 +1336,7 @@ static int launch_bwd_dense(const void* txt, const void* vis, const float* gV, c
         return (size_t)(kGdD + mt * 16) * (pp * Kp * 2 + 32) + (size_t)kGdChunk * (mt * 16 + Kp) * (2 + 4);
     };
     // config-2's widths: producer / consumer wavefronts, one block per caption / image, written once (ground_bwd_ws_kernel)
-    const bool ws_ok = !wide && !VLG_ENV("VLG_GD_OLD");
+    const bool ws_ok = !wide && !VLG_ENV("VLG_GD_OLD") && (size_t)B * kGdD * 128 * 2 < ((size_t)1 << 31);   // (32-bit buffer offsets of the tile reads)
     auto lds_ws = [](int Kp, int mt, int pp, int uw) {
         const int kt = (pp * uw + 31) / 32 * 32, chp = pp == 3 ? 6 : kGdChunk;
         return 2 * (size_t)(kGdD + mt * 16) * (kt * 2 + 32) + 2 * (size_t)chp * (mt * 16 + Kp) * (2 + 4);
