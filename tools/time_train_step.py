@@ -8,8 +8,10 @@ pos = [a for a in sys.argv[1:] if not a.startswith('--')]
 B, L, V = (int(pos[0]), int(pos[1]), int(pos[2])) if len(pos) > 2 else (256, 40, 36)
 kw = dict(factors=('rel', 'attr', 'img')) if '--shipped' in sys.argv else {}
 step = train_step.build(B, L, V, dev, wiring='r3' if '--r3' in sys.argv else 'reference', dtype=torch.float32 if '--f32' in sys.argv else torch.bfloat16, **kw)
-for _ in range(5): step()
+for _ in range(5): res = step()
 torch.cuda.synchronize()
+import hashlib
+print('sha256(loss|grads) %s' % hashlib.sha256(b''.join(t.detach().float().cpu().numpy().tobytes() for t in [res[0]] + [res[1][k] for k in sorted(res[1])])).hexdigest()[:16])
 def wall(fn, n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
