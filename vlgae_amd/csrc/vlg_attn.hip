@@ -915,9 +915,24 @@ __device__ __forceinline__ void attn_ln_adjoint(f32x4 (&Y)[kAttnMaxCT], f32x4 (&
     a2 = group_sum4(a2);
     a3 = group_sum4(a3);
     Dsum = rstd * (a1 - c1 * a2 - c2 * a3);
+    // bf16 features: the sweep's dP = <dy, mid_v> runs on the matrix cores with dy ROUNDED to bf16, so D is taken over the same rounded
+    // cotangent, D = sum_c bf16(dy_c) M_c (M = y - x again from the normalised row): dS = P (dP - D) is then the exact softmax adjoint of
+    // ONE cotangent -- its rows sum to zero over the keys and, with a single key, vanish -- instead of the difference of two roundings
+    // (tools/stress_attn.py: V = 1 gave |d_vis| 0.04 ... 0.12 where the gradient is zero)
+    const float sd = 1.f / rstd;
+    float dq = 0.f;
 #pragma unroll
     for (int ct = 0; ct < kAttnMaxCT; ++ct) {
         const float keep = ct < CT ? 1.f : 0.f;
+        if constexpr (kIsBF16<In>) {
+            const float4 e = *reinterpret_cast<const float4*>(tile_x + r * hp + 16 * min(ct, CT - 1) + 4 * g);   // (x: read before dy takes its place)
+            const float ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const float dyv = keep * rstd * (DY[ct][n] - c1 - Y[ct][n] * c2);
+                dq = fmaf((float)(__bf16)dyv, keep * (fmaf(Y[ct][n], sd, mean) - ev[n]), dq);
+            }
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) DY[ct][n] = keep * rstd * (DY[ct][n] - c1 - Y[ct][n] * c2);   // dy
         if (ct < CT) {
@@ -932,6 +947,7 @@ __device__ __forceinline__ void attn_ln_adjoint(f32x4 (&Y)[kAttnMaxCT], f32x4 (&
             }
         }
     }
+    if constexpr (kIsBF16<In>) Dsum = group_sum4(dq);
     {   // d_gamma partial (column sums of dout*yhat) and d_enc_x rows, both as whole rows
         float4 acc = zero4;
 #pragma unroll
