@@ -2844,7 +2844,8 @@ def test_bilinear_align_full_tensor_direct_kernel(oracle_mod, B, A, Q, V):
         assert (g[big] == np.float32(-1e20)).all() and np.abs(g[~big] - ref[~big]).max() <= 1e-3
 
 
-@pytest.mark.parametrize("B,L,T,r,dt", [(5, 11, 100, 12, "f32"), (3, 40, 45, 32, "bf16"), (2, 80, 30, 16, "f32"), (4, 6, 3, 5, "f32")])
+@pytest.mark.parametrize("B,L,T,r,dt", [(5, 11, 100, 12, "f32"), (3, 40, 45, 32, "bf16"), (2, 80, 30, 16, "f32"), (4, 6, 3, 5, "f32"),
+                                        (2, 80, 45, 32, "f32"), (3, 63, 100, 16, "bf16")])   # the adjoint's coefficient table in several passes
 def test_ndmv_potentials_shapes(oracle_mod, B, L, T, r, dt):
     """Ranks without a compile-time instantiation (run-time loop), long sentences, more tokens than positions, bf16 inputs;
     and the shape the workgroup's LDS cannot hold is refused, not mis-computed."""

@@ -1,0 +1,144 @@
+"""Randomised shape sweep of the stage kernels around the DP, each against its fp64 oracle / fp64 torch formulation, every case twice for
+bit-reproducibility:
+  scorer.ndmv_potentials (ldndmv.py:205-216 + the merge), align.arc_trilinear (joint.py:282-284), align.linear_wgrad and
+  align.small_matmul (the weight-space products of the parser's feed-forwards), align.grounding decode maxima (bilinear_align).
+Run on the GPU box: python tools/stress_stages.py [seed] [cases per stage]"""
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+import oracle
+from vlgae_amd import align, scorer
+oracle.build()
+dev = torch.device('cuda:0')
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 2026
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+rng = np.random.default_rng(seed)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+rb = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+
+
+def same(a, b, what):
+    assert all(torch.equal(x, y) for x, y in zip(a, b)), ("not reproducible", what)
+
+
+# ---- the rule scorers + merge ----------------------------------------------------------------------------------------------------
+worst = 0.0
+for it in range(N):
+    B, L = int(rng.integers(1, 9)), int(rng.choice([1, 2, 3, 7, 16, 31, 40, 41, 63, 80]))
+    # (the adjoint keeps the cotangent of score[h][dv][t] in LDS next to the rows: in several passes over the head positions when L x 4 x T floats do not fit)
+    T, r = int(rng.choice([1, 3, 17, 45, 100, 300])), int(rng.choice([1, 4, 5, 8, 12, 16, 32]))
+    r = min(r, 12) if T == 300 else r      # (300 x 4 rows of 33 floats alone are the LDS: such tables are refused, forward and adjoint)
+    bf16 = it % 2 == 1
+    mk = lambda *s: (rng.standard_normal(s) * 0.5).astype(np.float32)
+    arrs = [mk(B, L, 2, 2, r), mk(T, 2, 2, r), mk(B, L, 2, 2, r), mk(2, 2, 2, r)]
+    root = np.log(rng.dirichlet(np.ones(T))).astype(np.float32)
+    token = rng.integers(0, T, size=(B, L))
+    hm = rng.random((B, L)) < rng.choice([0.0, 0.2, 0.9])
+    if bf16:
+        arrs = [rb(a) for a in arrs]
+    g_md, g_ma = rng.random((B, L + 1, 2, 2, 2)).astype(np.float32), rng.random((B, L + 1, L + 1, 2)).astype(np.float32)
+    omd, oma, og = oracle.ndmv_potentials(*arrs, root, token, hm, -1e20, g_md, g_ma)
+    ins = [t(a).bfloat16() if bf16 else t(a) for a in arrs] + [t(root)]
+    for a in ins:
+        a.requires_grad_(True)
+    runs = []
+    for rep in range(2):
+        md, ma = scorer.ndmv_potentials(*ins, t(token), t(hm))
+        grads = torch.autograd.grad([md, ma], ins, [t(g_md), t(g_ma)])
+        runs.append([md.detach(), ma.detach(), *grads])
+    same(runs[0], runs[1], ("ndmv", it, B, L, T, r))
+    case = ("ndmv_potentials", it, B, L, T, r, bf16)
+    for got, ref in ((runs[0][0], omd), (runs[0][1], oma)):
+        got = got.cpu().numpy()
+        big = np.abs(ref) > 1e11
+        assert (got[big] == ref[big].astype(np.float32)).all() and (not (~big).any() or np.abs(got[~big] - ref[~big]).max() <= 5e-5), case
+    for k, v in zip(("x1", "x2", "y1", "y2", "root_rule"), runs[0][2:]):
+        e = np.abs(v.float().cpu().numpy() - og[k]).max() / max(1.0, np.abs(og[k]).max())
+        assert e <= (1e-2 if bf16 else 1e-4), (case, k, e)
+        worst = max(worst, e)
+print("ndmv_potentials ok (%d cases), worst gradient error %.2e" % (N, worst))
+
+# ---- the arc encoder's trilinear term ---------------------------------------------------------------------------------------------
+worst = 0.0
+for it in range(N):
+    M = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 1023, 1024, 1025, 2047, 3001, 5000]))
+    X, H, Y = (int(rng.choice([32, 64, 128])) for _ in range(3))
+    bf16 = it % 2 == 1
+    child, parent = (rng.standard_normal((M, X)) * 0.5).astype(np.float32), (rng.standard_normal((M, Y)) * 0.5).astype(np.float32)
+    w1 = (rng.standard_normal((X, H, Y)) / np.sqrt(X * Y)).astype(np.float32)
+    g = rng.standard_normal((M, H)).astype(np.float32)
+    if bf16:
+        child, parent, w1 = rb(child), rb(parent), rb(w1)
+    ref = oracle.arc_encoder(child, parent, w1, None, None, np.float64)
+    d_child, d_parent, d_w1, _, _ = oracle.arc_encoder_backward(child, parent, w1, None, g, np.float64)
+    leaves = [t(child), t(w1), t(parent)]
+    if bf16:
+        leaves = [a.bfloat16() for a in leaves]
+    for a in leaves:
+        a.requires_grad_(True)
+    runs = []
+    for rep in range(2):
+        out = align.arc_trilinear(*leaves)
+        runs.append([out.detach(), *torch.autograd.grad(out, leaves, t(g))])
+    case = ("arc_trilinear", it, M, X, H, Y, bf16)
+    if M >= 1024:      # (the LDS-staged kernels sum fixed-order slabs; the small-M kernels' two-range atomics are order-free for two addends)
+        same(runs[0], runs[1], case)
+    assert np.abs(runs[0][0].cpu().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), case
+    for name, got, want in (("d_child", runs[0][1], d_child), ("d_w1", runs[0][2], d_w1), ("d_parent", runs[0][3], d_parent)):
+        e = np.abs(got.float().cpu().numpy() - want).max() / max(1.0, np.abs(want).max())
+        assert e <= (2e-2 if bf16 else 1e-4), (case, name, e)
+        worst = max(worst, e)
+print("arc_trilinear ok (%d cases), worst gradient error %.2e" % (N, worst))
+
+# ---- split-K weight gradients -----------------------------------------------------------------------------------------------------
+worst = 0.0
+for it in range(N):
+    K = int(rng.choice([1, 7, 64, 100, 2047, 2048, 2049, 4100, 10288, 20000, 41152]))
+    M, Nn = int(rng.choice([8, 16, 24, 64, 72, 96, 256, 384])), int(rng.choice([8, 16, 40, 64, 128, 256, 800]))
+    bf16 = it % 3 != 2
+    wide = it % 4 == 1                                # operands as column slices of wider buffers (row strides multiples of 8)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    dyw = torch.from_numpy(rng.standard_normal((K, M + (16 if wide else 0))).astype(np.float32)).to(dev, dt)
+    xw = torch.from_numpy(rng.standard_normal((K, Nn + (8 if wide else 0))).astype(np.float32)).to(dev, dt)
+    dy, x = (dyw[:, 8:8 + M], xw[:, :Nn]) if wide else (dyw, xw)
+    colsum = it % 5 == 4
+    runs = []
+    for rep in range(2):
+        dw, second = align.linear_wgrad(dy, x, want_bias=not colsum, want_x_colsum=colsum)
+        runs.append([dw.clone(), second.clone()])
+    case = ("linear_wgrad", it, K, M, Nn, bf16, wide, colsum)
+    same(runs[0], runs[1], case)
+    ref_w = dy.double().t() @ x.double()
+    ref_s = (x if colsum else dy).double().sum(0)
+    for got, want in ((runs[0][0], ref_w), (runs[0][1], ref_s)):
+        e = float((got.double() - want).abs().max() / max(1.0, float(want.abs().max())))
+        assert e <= (2e-5 if bf16 else 1e-4), (case, e)      # bf16 operands: exact products, fp32 sums; float32: three bf16 products per pair
+        worst = max(worst, e)
+print("linear_wgrad ok (%d cases), worst error %.2e" % (N, worst))
+
+# ---- small products (weight space) ------------------------------------------------------------------------------------------------
+worst = 0.0
+for it in range(N):
+    Z = int(rng.choice([0, 0, 1, 3, 4]))
+    M, K, Nn = int(rng.integers(1, 300)), int(rng.integers(1, 700)), int(rng.integers(1, 300))
+    bf16 = it % 2 == 1
+    dt = torch.bfloat16 if bf16 else torch.float32
+    mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev, dt)
+    a = mk(*((Z,) if Z else ()), K, M).transpose(-1, -2) if it % 3 == 0 else mk(*((Z,) if Z else ()), M, K)
+    b = mk(*((Z,) if Z and it % 4 else ()), Nn, K).transpose(-1, -2) if it % 5 == 0 else mk(*((Z,) if Z and it % 4 else ()), K, Nn)
+    bias = mk(Nn) if it % 2 else None
+    rank1 = (mk(M), mk(Nn)) if it % 3 == 1 else None
+    alpha = float(rng.choice([1.0, 0.5, -2.0]))
+    got = align.small_matmul(a, b, alpha=alpha, bias=bias, rank1=rank1, out_dtype=torch.float32)
+    got2 = align.small_matmul(a, b, alpha=alpha, bias=bias, rank1=rank1, out_dtype=torch.float32)
+    case = ("small_matmul", it, Z, M, K, Nn, bf16)
+    assert torch.equal(got, got2), case
+    ref = alpha * (a.double() @ b.double())
+    if bias is not None:
+        ref = ref + bias.double()
+    if rank1 is not None:
+        ref = ref + rank1[0].double().unsqueeze(-1) * rank1[1].double().unsqueeze(-2)
+    e = float((got.double() - ref).abs().max() / max(1.0, float(ref.abs().max())))
+    assert e <= 2e-5, (case, e)
+    worst = max(worst, e)
+print("small_matmul ok (%d cases), worst error %.2e" % (N, worst))
+print("stress ok")

@@ -31,9 +31,11 @@ namespace {
 constexpr int kScThreads = 1024;   // 16 wavefronts per sentence: the loops are LDS-latency chains, more waves hide them
 constexpr float kMergeZero = -1e12f;   // DMV1o.merge's `zero` (distributions.py:253, bound at import: semirings.py:16)
 
+constexpr int kScLdsFloats = 160 * 1024 / 4;
 struct ScLayout {   // LDS carving, in floats
     int L, T, r, rp;
     int x1, x2, y1, y2, lse, tok, hm, tot, coef, total;
+    int HC;   // backward: head positions per pass of the coefficient table (L when everything fits; fewer -> several passes)
     __host__ __device__ ScLayout(int L_, int T_, int r_, bool bwd) : L(L_), T(T_), r(r_) {
         rp = r | 1;                        // odd row pitch: rows of different tokens on different banks
         int o = 0;
@@ -45,8 +47,14 @@ struct ScLayout {   // LDS carving, in floats
         tok = o; o += L;
         hm = o; o += L;
         tot = o; o += bwd ? L * 4 * 3 : 0;   // backward: tot[h][dv], ds_dec[h][dv][2]
-        coef = o; o += bwd ? L * 4 * T : 0;  // backward: cotangent of score[h][dv][t]
-        total = o;
+        coef = o;                            // backward: cotangent of score[h][dv][t] for HC head positions at a time
+        HC = L;
+        if (bwd) {
+            const int room = (kScLdsFloats - o) / (4 * T);
+            HC = room >= L ? L : (room > 0 ? room : 0);
+            o += HC * 4 * T;
+        }
+        total = HC > 0 ? o : kScLdsFloats + 1;   // (not even one head position: refused by check_shape)
     }
 };
 
@@ -222,34 +230,41 @@ __global__ __launch_bounds__(kScThreads) void scorer_bwd_kernel(
         dsd[p * 2 + 1] = g1 - e1 * inv * (g0 + g1);
     }
     __syncthreads();
-    for (int i = tid; i < L * 4 * T; i += kScThreads) {   // - softmax weight * tot
-        const int p = i / T, t = i - p * T;
-        const float tt = tot[p];
-        coef[i] = tt != 0.f ? -tt * __expf(dot_r<R>(x1s + p * rp, x2s + (t * 4 + (p & 3)) * rp, r) - lse[p]) : 0.f;
-    }
-    __syncthreads();
-    for (int p = tid; p < L * 4; p += kScThreads) {       // + the children's counts at their tokens; row p has one owner, c ascending
-        const int h = p >> 2, d = (p >> 1) & 1, v = p & 1;
-        for (int c = d ? h + 1 : 0; c < (d ? L : h); ++c) coef[p * T + tok[c]] += cnt(h, c, v);
-    }
-    __syncthreads();
-    // ---- d_x1[h][dv][:] = sum_t coef[t] x2[t][dv][:];  d_y1[h][dv][:] = sum_k dsd[k] y2[k][dv][:] ----
-    for (int i = tid; i < L * 4 * r; i += kScThreads) {
-        const int p = i / r, e = i - p * r, dv = p & 3;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int t = 0; t < T; ++t) acc = fmaf(coef[p * T + t], x2s[(t * 4 + dv) * rp + e], acc);
-        st_grad(d_x1, ((size_t)b * L * 4 + p) * ld_dx1 + e, acc);
-        st_grad(d_y1, ((size_t)b * L * 4 + p) * ld_dy1 + e, dsd[p * 2] * y2s[(0 * 4 + dv) * rp + e] + dsd[p * 2 + 1] * y2s[(1 * 4 + dv) * rp + e]);
-    }
-    // ---- partials of the batch-shared tables ----
     float* pt = part + (size_t)b * ((size_t)T * 4 * r + 8 * r + T);
-    for (int i = tid; i < T * 4 * r; i += kScThreads) {   // d_x2[t][dv][e] = sum_h coef[h][dv][t] x1[h][dv][e], h ascending
-        const int q = i / r, e = i - q * r, t = q >> 2, dv = q & 3;
-        float acc = 0.f;
+    // The coefficient table for the head positions [hb, he) at a time: one pass when it fits beside the rows (HC = L: every configuration
+    // of BASELINE.json), else several -- d_x2's partial then adds the passes in order (its thread owns the element in every pass).
+    const int HC = lay.HC;
+    for (int hb = 0; hb < L; hb += HC) {
+        const int he = min(L, hb + HC), p0 = hb * 4, np = (he - hb) * 4;
+        for (int i = tid; i < np * T; i += kScThreads) {      // - softmax weight * tot
+            const int pl = i / T, t = i - pl * T, p = p0 + pl;
+            const float tt = tot[p];
+            coef[i] = tt != 0.f ? -tt * __expf(dot_r<R>(x1s + p * rp, x2s + (t * 4 + (p & 3)) * rp, r) - lse[p]) : 0.f;
+        }
+        __syncthreads();
+        for (int pl = tid; pl < np; pl += kScThreads) {       // + the children's counts at their tokens; row p has one owner, c ascending
+            const int p = p0 + pl, h = p >> 2, d = (p >> 1) & 1, v = p & 1;
+            for (int c = d ? h + 1 : 0; c < (d ? L : h); ++c) coef[pl * T + tok[c]] += cnt(h, c, v);
+        }
+        __syncthreads();
+        // ---- d_x1[h][dv][:] = sum_t coef[t] x2[t][dv][:];  d_y1[h][dv][:] = sum_k dsd[k] y2[k][dv][:] ----
+        for (int i = tid; i < np * r; i += kScThreads) {
+            const int pl = i / r, e = i - pl * r, p = p0 + pl, dv = p & 3;
+            float acc = 0.f;
 #pragma unroll 8
-        for (int h = 0; h < L; ++h) acc = fmaf(coef[(h * 4 + dv) * T + t], x1s[(h * 4 + dv) * rp + e], acc);
-        pt[i] = acc;
+            for (int t = 0; t < T; ++t) acc = fmaf(coef[pl * T + t], x2s[(t * 4 + dv) * rp + e], acc);
+            st_grad(d_x1, ((size_t)b * L * 4 + p) * ld_dx1 + e, acc);
+            st_grad(d_y1, ((size_t)b * L * 4 + p) * ld_dy1 + e, dsd[p * 2] * y2s[(0 * 4 + dv) * rp + e] + dsd[p * 2 + 1] * y2s[(1 * 4 + dv) * rp + e]);
+        }
+        // ---- partials of the batch-shared tables ----
+        for (int i = tid; i < T * 4 * r; i += kScThreads) {   // d_x2[t][dv][e] = sum_h coef[h][dv][t] x1[h][dv][e], h ascending
+            const int q = i / r, e = i - q * r, t = q >> 2, dv = q & 3;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int h = hb; h < he; ++h) acc = fmaf(coef[((h - hb) * 4 + dv) * T + t], x1s[(h * 4 + dv) * rp + e], acc);
+            pt[i] = hb == 0 ? acc : pt[i] + acc;
+        }
+        if (he < L) __syncthreads();                          // (the next pass overwrites the table)
     }
     float* pty = pt + (size_t)T * 4 * r;
     for (int i = tid; i < 8 * r; i += kScThreads) {   // d_y2[k][dv][e] = sum_h dsd[h][dv][k] y1[h][dv][e]
@@ -299,7 +314,7 @@ int check_shape(const char* what, int B, int L, int T, int r, bool bwd, size_t* 
     if (B < 0 || L < 1 || T < 1 || r < 1) return set_error(VLG_ERR_SHAPE, "%s: bad shape B=%d L=%d T=%d r=%d", what, B, L, T, r);
     *lds = sizeof(float) * (size_t)ScLayout(L, T, r, bwd).total;
     if (*lds > 160 * 1024)
-        return set_error(VLG_ERR_SHAPE, "%s: L=%d T=%d r=%d need %zu bytes of LDS (limit 160 KiB): the token table does not fit one workgroup",
+        return set_error(VLG_ERR_SHAPE, "%s: L=%d T=%d r=%d need %zu bytes of LDS (limit 160 KiB): the sentence's and the tokens' projected rows do not fit one workgroup",
                          what, L, T, r, *lds);
     return 0;
 }
