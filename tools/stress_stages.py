@@ -141,4 +141,70 @@ for it in range(N):
     assert e <= 2e-5, (case, e)
     worst = max(worst, e)
 print("small_matmul ok (%d cases), worst error %.2e" % (N, worst))
+
+# ---- lang_feat_max_tree (joint.py:235-292): Viterbi tree of random potentials -> word | arc representations ------------------------
+import vlgae_amd.torch_struct as ts
+from vlgae_amd import langfeat, vis_encoder
+worst = 0.0
+for it in range(N):
+    B, L = int(rng.integers(1, 9)), int(rng.choice([1, 2, 3, 7, 16, 31, 40, 41, 63]))
+    h, d = int(rng.choice([16, 40, 64, 256])), int(rng.choice([32, 64, 128]))
+    bf16 = it % 2 == 1
+    dt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.Generator().manual_seed(int(rng.integers(1, 1 << 30)))
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    x = rnd(B, L, h, sc=0.5).to(dt).requires_grad_(True)
+    params = [rnd(3 * d, h, sc=h ** -0.5), rnd(3 * d, sc=0.1), rnd(d, d, d, sc=1.0 / d), rnd(d, d, sc=d ** -0.5), rnd(d, sc=0.1)]
+    params = [p_.to(dt).requires_grad_(True) for p_ in params]
+    dec = torch.randn(B, L, 2, 2, 2, generator=g).log_softmax(-1).to(dev)
+    attach, root = torch.randn(B, L, L, 2, generator=g).to(dev), torch.randn(B, L, generator=g).log_softmax(-1).to(dev)
+    md, ma = ts.DMV1o.merge(dec, attach, root)
+    lengths = torch.randint(1, L + 1, (B,), generator=g)
+    lengths[0] = L
+    lengths = lengths.to(dev)
+    runs, aux = [], {}
+    for rep in range(2):
+        aux = {}
+        txt, tmask, tmarg = langfeat.lang_feat_max_tree(x, lengths, md, ma, *params, aux=aux)
+        dout = (torch.randn(B, 2 * (L + 1), d, generator=torch.Generator().manual_seed(it)).to(dev) * tmask.unsqueeze(-1)).to(dt)
+        runs.append([txt.detach(), tmarg, *torch.autograd.grad(txt, [x] + params, dout)])
+    case = ("lang_feat_max_tree", it, B, L, h, d, bf16)
+    same(runs[0], runs[1], case)
+    f64 = lambda a: a.detach().float().cpu().numpy().astype(np.float64)
+    wn, bn = f64(params[0]), f64(params[1])
+    cb, pb = (aux[k].float().cpu().numpy() > 0 for k in ("child", "parent"))       # the LeakyReLU branches the device took
+    heads = aux["heads"].cpu().numpy()
+    otxt, og = oracle.lang_feat(f64(x), lengths.cpu().numpy(), heads, wn[:d], bn[:d], wn[d:2 * d], bn[d:2 * d], wn[2 * d:], bn[2 * d:],
+                                f64(params[2]), f64(params[3]), f64(params[4]), 0.01, f64(dout), cb, pb)
+    tol = 2e-2 if bf16 else 1e-4
+    assert np.abs(f64(runs[0][0]) - otxt).max() <= tol * max(1.0, np.abs(otxt).max()), case
+    refs = {"x": og["x"], "w_enc": np.concatenate([og["w_word"], og["w_child"], og["w_parent"]]),
+            "b_enc": np.concatenate([og["b_word"], og["b_child"], og["b_parent"]]), "w1": og["w1"], "w2": og["w2"], "b_arc": og["b_arc"]}
+    for (k, ref), got in zip(refs.items(), runs[0][2:]):
+        e = np.abs(f64(got) - ref).max() / max(1.0, np.abs(ref).max())
+        assert e <= tol, (case, k, e)
+        worst = max(worst, e)
+print("lang_feat_max_tree ok (%d cases), worst gradient error %.2e" % (N, worst))
+
+# ---- the relation encoder's pairwise features (box_rel.py:29-52), float32 ---------------------------------------------------------------
+worst = 0.0
+for it in range(N):
+    B, R = int(rng.integers(1, 7)), int(rng.choice([1, 2, 7, 16, 33, 36]))
+    n, H = int(rng.choice([8, 40, 96])), int(rng.choice([4, 64, 128, 256]))
+    feat = rng.standard_normal((B, R, n)).astype(np.float32)
+    w = (rng.standard_normal((H, 2 * n)) / np.sqrt(2 * n)).astype(np.float32)
+    b = (rng.standard_normal(H) * 0.1).astype(np.float32)
+    dout = rng.standard_normal((B, R * R, H)).astype(np.float32)
+    tf, tw, tb = (t(a).requires_grad_(True) for a in (feat, w, b))
+    ref = oracle.box_rel(feat, w, b, 0.01, True, dout)
+    rel = vis_encoder.rel_features(tf, tw, tb)
+    grads = torch.autograd.grad(rel, [tf, tw, tb], t(dout))
+    rel2 = vis_encoder.rel_features(tf, tw, tb)
+    case = ("box_rel", it, B, R, n, H)
+    assert torch.equal(rel, rel2), case
+    for got, want in zip((rel.detach(), *grads), ref):
+        e = np.abs(got.float().cpu().numpy() - want).max() / max(1.0, np.abs(want).max())
+        assert e <= 5e-5, (case, e)
+        worst = max(worst, e)
+print("box_rel ok (%d cases), worst error %.2e" % (N, worst))
 print("stress ok")
