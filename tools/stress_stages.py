@@ -207,4 +207,35 @@ for it in range(N):
         assert e <= 5e-5, (case, e)
         worst = max(worst, e)
 print("box_rel ok (%d cases), worst error %.2e" % (N, worst))
+
+# ---- gather_logit_simple (joint.py:406-419): the materialised alignment tensor and its adjoint -----------------------------------------
+worst = 0.0
+for it in range(N):
+    B, A = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+    Q, V = int(rng.choice([1, 2, 7, 17, 33, 50, 82, 97, 100])), int(rng.choice([1, 4, 5, 20, 36, 37, 40, 44, 48, 64, 130, 201]))
+    d = int(rng.choice([32, 64, 128]))
+    bf16 = it % 2 == 1
+    txt, vis = rng.standard_normal((B, Q, d)).astype(np.float32), rng.standard_normal((A, V, d)).astype(np.float32)
+    tm, vm = rng.random((B, Q)) > 0.2, rng.random((A, V)) > 0.2
+    g = rng.standard_normal((B, A, Q, V)).astype(np.float32)
+    tdt = torch.bfloat16 if bf16 else torch.float32
+    tt, tv = t(txt).to(tdt), t(vis).to(tdt)
+    txt, vis = tt.float().cpu().numpy(), tv.float().cpu().numpy()
+    ref = oracle.bilinear_align(txt, vis, tm, vm, np.float64)["full"]
+    ref_t, ref_v = oracle.bilinear_align_backward(g, txt, vis, tm, vm, np.float64)
+    a_, b_ = tt.clone().requires_grad_(True), tv.clone().requires_grad_(True)
+    runs = []
+    for rep in range(2):
+        out = align.gather_logit(None, (b_, t(vm), None), (a_, t(tm), None), None).rename(None)
+        runs.append([out.detach(), *torch.autograd.grad(out, [a_, b_], t(g))])
+    case = ("gather_logit", it, B, A, Q, V, d, bf16)
+    same(runs[0], runs[1], case)
+    got = runs[0][0].float().cpu().numpy()
+    big = np.abs(ref) > 1e11
+    assert (got[big] == ref[big].astype(np.float32)).all() and (not (~big).any() or np.abs(got[~big] - ref[~big]).max() <= 1e-4 * max(1.0, np.abs(ref[~big]).max())), case
+    for got, want in ((runs[0][1], ref_t), (runs[0][2], ref_v)):
+        e = np.abs(got.float().cpu().numpy() - want).max() / max(1.0, np.abs(want).max())
+        assert e <= (8e-3 if bf16 else 2e-5), (case, e)
+        worst = max(worst, e)
+print("gather_logit ok (%d cases), worst gradient error %.2e" % (N, worst))
 print("stress ok")
