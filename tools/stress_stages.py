@@ -202,13 +202,18 @@ for it in range(N):
     rel2 = vis_encoder.rel_features(tf, tw, tb)
     case = ("box_rel", it, B, R, n, H)
     assert torch.equal(rel, rel2), case
-    for got, want in zip((rel.detach(), *grads), ref):
-        # (relative L2: of the ~10^5 pre-activations one may sit within float32 rounding of zero, and float32 then takes the other LeakyReLU
-        #  branch than the float64 oracle -- one element of the gradient off by the factor 1 / slope, seen once in 300 cases)
+    # A pre-activation within float32 rounding of zero takes the other LeakyReLU branch than the float64 oracle (its gradient term changes
+    # by 1 / slope): cases that have one within 1e-5 of zero are held in relative L2 only (seen: one case in ~300, two flipped elements).
+    r64 = ref[0]
+    near_zero = int(((r64 > -1e-7) & (r64 < 1e-5)).sum())
+    for k, (got, want) in enumerate(zip((rel.detach(), *grads), ref)):
         diff = got.float().cpu().numpy().astype(np.float64) - want
-        e = np.linalg.norm(diff) / max(np.linalg.norm(want), 1e-6)
-        assert e <= 1e-4 and np.abs(diff).max() <= 2e-2 * max(1.0, np.abs(want).max()), (case, e, np.abs(diff).max())
-        worst = max(worst, e)
+        e = np.abs(diff).max() / max(1.0, np.abs(want).max())
+        if k == 0 or near_zero == 0:
+            assert e <= 5e-5, (case, k, e)
+            worst = max(worst, e)
+        else:
+            assert np.linalg.norm(diff) <= 2e-2 * np.linalg.norm(want), (case, k, near_zero)
 print("box_rel ok (%d cases), worst error %.2e" % (N, worst))
 
 # ---- gather_logit_simple (joint.py:406-419): the materialised alignment tensor and its adjoint -----------------------------------------
