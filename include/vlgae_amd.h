@@ -444,6 +444,27 @@ int vlg_ff_mlp_act_backward(const float* gx, const void* t, const void* x, const
 int vlg_ff_root_rule(const void* small, int ld, int T, int r, int act_dtype, float* root_rule, void* stream);
 int vlg_ff_root_rule_backward(const void* small, int ld, int T, int r, int act_dtype, const float* root_rule, const float* g_root, const void* g_x2,
                               int ld_x2, const void* g_y2, int ld_y2, void* g_small, void* stream);
+/* A feed-forward Linear over all token rows FUSED with the element-wise pass behind it (round 6; the DMVSkipConnectEncoder stages of
+ * src/model/nn/dmv_spec.py:38-54): one row-streaming launch in place of a library GEMM + vlg_ff_act / vlg_ff_act_backward pair.  bf16 storage,
+ * exactly 256 input channels and 256 output channels per column block; every pointer 16-byte aligned, rows of x / g `ld` elements apart.
+ *   vlg_ff_linear_act           x [rows, 256], w [nb 256, 256] (nn.Linear layout: w[n][k]), bias [nb 256] or NULL, nb = 1 or 2 column blocks y:
+ *                               out[orow][c] = LeakyReLU(bf16(x[row] . w[256 y + c] + bias) + residual[row >> rs][c]) * keep[orow][c],
+ *                               orow = (row >> rs) om + y oy + (row & ((1 << rs) - 1)); residual [rows >> rs, 256] or NULL.
+ *                                 plain layer: nb 1, rs 0, om 1, oy 0;  the (no | has) bottlenecks with their skip connection: nb 2, rs 0, om 2, oy 1,
+ *                                 residual = x;  the (left | right) bottlenecks: rows (m,val), nb 2, rs 1, om 4, oy 2 -> out [m,dir,val] (the stack of :47).
+ *                               keep: mask [out rows, 256] bf16 times mask_scale, or -- rng -- the counter-based draw of (site, p) over the output's
+ *                               element index, as vlg_ff_act; both NULL: none.
+ *   vlg_ff_linear_act_backward  g [rows, 256], w_t [256, 256] = the layer's weight TRANSPOSED (w_t[n][k] = weight[k][n], so that g . w_t[n] is the
+ *                               cotangent of input channel n): out[orow][c] = LeakyReLU'(act[row][c]) * bf16(g[row] . w_t[c]) * keep[row][c];
+ *                               rows are groups m J + j (J = 1, 2 or 4), sum [rows / J, 256] fp32 (or NULL) = / += (accumulate) sum_j of the stored
+ *                               out values; swap (J = 4): orow = 4 m + (dir,val <- val,dir)(j) -- as vlg_ff_act_backward on the product. */
+int vlg_ff_linear_act(const void* x, int ldx, const void* w, const void* bias, long long rows, int nb, const void* residual, int rs, int om, int oy,
+                      const void* mask, float mask_scale, const uint64_t* rng, unsigned site, float p, void* out, float slope, void* stream);
+int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, long long rows, int J, const void* act, const void* mask, float mask_scale,
+                               const uint64_t* rng, unsigned site, float p, void* out, float* sum, int swap, int accumulate, float slope,
+                               void* stream);
+/* out [n, 256, 256] (bf16): out[z][j][k] = w_z[k][j] for n <= 4 contiguous 256 x 256 bf16 matrices -- the `w_t` operands of vlg_ff_linear_act_backward in one launch. */
+int vlg_ff_transpose256(const void* w0, const void* w1, const void* w2, const void* w3, int n, void* out, void* stream);
 
 /* Score construction feeding the DP -- the tensor half of `DiscriminativeNDMV._forward`, src/model/ldndmv.py:179-209 with the
  * factorised-bilinear scorers of src/model/nn/dmv_spec.py:57-76: from the scorers' projected inputs to the root-merged

@@ -3063,3 +3063,133 @@ def test_small_matmul(dtype):
         assert torch.equal(got, align.small_matmul(**sp)), k
     assert torch.equal(acc_out, out)
     grp.launch()                                                       # an empty group is a no-op
+
+
+# ------------------------------------------------------------------------------------------------ fused Linear + element-wise pass (round 6)
+def _leaky(v, slope=0.01):
+    return torch.where(v > 0, v, v * slope)
+
+
+@pytest.mark.parametrize("rows,nb,rs,om,oy,with_res,keep", [
+    (41, 1, 0, 1, 0, False, None),         # plain layer, ragged last tile
+    (96, 2, 0, 2, 1, True, None),          # (no | has) bottlenecks + skip connection: out [m,2,H], residual = the input row
+    (130, 2, 1, 4, 2, True, None),         # (left | right) bottlenecks on rows (m,val): out [m,dir,val,H]
+    (4096 + 64 + 7, 1, 0, 1, 0, False, "mask"),
+    (1000, 1, 0, 1, 0, False, "rng"),
+    (1, 1, 0, 1, 0, False, None),
+])
+def test_ff_linear_act_forward(rows, nb, rs, om, oy, with_res, keep):
+    """vlg_ff_linear_act (row-streaming Linear fused with bias, skip connection, LeakyReLU, dropout and the store permutation) against the pair
+    it replaces -- library GEMM with a bf16 result, then vlg_ff_act -- computed in float64 on the same bf16 inputs: equal up to the product's
+    summation order (one bf16 rounding of the Linear's output, one of the result)."""
+    from vlgae_amd import _C, encoders
+    from vlgae_amd import parser_ff
+    H = 256
+    g = torch.Generator().manual_seed(rows * 7 + nb)
+    bf = torch.bfloat16
+    x = (torch.randn(rows, H, generator=g) * 0.5).to(dev(), bf)
+    w = (torch.randn(nb * H, H, generator=g) / 16).to(dev(), bf)
+    bias = (torch.randn(nb * H, generator=g) * 0.2).to(dev(), bf)
+    res = (torch.randn(rows >> rs, H, generator=g) * 0.5).to(dev(), bf) if with_res else None
+    if with_res and rs == 0:
+        res = x
+    n_out = (rows >> rs) * om if nb == 2 else rows
+    out = torch.full((n_out, H), float("nan"), dtype=bf, device=dev())
+    mask, rng, p, scale = None, None, 0.0, 1.0
+    if keep == "mask":
+        mask = (torch.rand(n_out, H, generator=g) > 0.3).to(dev(), bf)
+        scale = 1.0 / 0.7
+    elif keep == "rng":
+        rng, p = encoders.DeviceRng(123, dev()), 0.3
+    parser_ff._linear_act(x, w, bias, out, nb=nb, residual=res, rs=rs, om=om, oy=oy, mask=mask, mask_scale=scale, rng=rng, p=p)
+    lin = (x.double() @ w.double().t() + bias.double()).to(bf).double()                 # the library GEMM's bf16 output
+    rowi = torch.arange(rows, device=dev())
+    ref = torch.empty(n_out, H, dtype=torch.float64, device=dev())
+    for y in range(nb):
+        v = lin[:, y * H:(y + 1) * H]
+        if res is not None:
+            v = v + res.double()[rowi >> rs]
+        orow = (rowi >> rs) * om + y * oy + (rowi & ((1 << rs) - 1))
+        ref[orow] = _leaky(v)
+    if keep == "mask":
+        ref = ref * mask.double() * scale
+    if keep == "rng":   # the kernel's own draw, as vlg_ff_act makes it over the same element indices
+        ones = torch.ones(n_out, H, dtype=bf, device=dev())
+        drawn = parser_ff._act(ones, torch.empty_like(ones), n_out, 1, H, rng=rng, p=p)
+        assert 0.6 < float((drawn > 0).float().mean()) < 0.8
+        ref = ref * drawn.double()
+    assert not torch.isnan(out.float()).any()
+    err = (out.double() - ref).abs()
+    # one bf16 ulp where the two summation orders round the Linear's output differently (then LeakyReLU' <= 1 and one more rounding)
+    assert float((err / ref.abs().clamp_min(1.0)).max()) <= 2.0 ** -6 and float(err.mean()) <= 2e-3
+    assert float((err > 2.0 ** -7 * ref.abs().clamp_min(0.5)).float().mean()) <= 0.02       # (beyond the result's own bf16 rounding: rare)
+    out2 = torch.empty_like(out)
+    parser_ff._linear_act(x, w, bias, out2, nb=nb, residual=res, rs=rs, om=om, oy=oy, mask=mask, mask_scale=scale, rng=rng, p=p)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("rows,J,swap,acc,keep", [(4 * 35, 4, True, False, None), (2 * 77, 2, False, True, None), (333, 1, False, False, "mask"),
+                                                  (4096 + 8, 1, False, False, "rng"), (4, 4, True, False, None)])
+def test_ff_linear_act_backward(rows, J, swap, acc, keep):
+    """vlg_ff_linear_act_backward against library GEMM (bf16 result) + vlg_ff_act_backward in float64 on the same bf16 inputs."""
+    from vlgae_amd import encoders, parser_ff
+    H = 256
+    g = torch.Generator().manual_seed(rows + J)
+    bf = torch.bfloat16
+    gin = torch.randn(rows, H, generator=g).to(dev(), bf)
+    W = (torch.randn(H, H, generator=g) / 16).to(dev(), bf)                              # the layer's weight [out, in]: d x = g @ W
+    act = torch.randn(rows, H, generator=g).to(dev(), bf)
+    wT = torch.empty(1, H, H, dtype=bf, device=dev())
+    from vlgae_amd import _C
+    _C.check(_C.lib().vlg_ff_transpose256(_C.ptr(W), None, None, None, 1, _C.ptr(wT), _C.stream_of(W)), "ff_transpose256")
+    assert torch.equal(wT[0], W.t().contiguous())
+    mask, rng, p, scale = None, None, 0.0, 1.0
+    if keep == "mask":
+        mask, scale = (torch.rand(rows, H, generator=g) > 0.3).to(dev(), bf), 1.0 / 0.7
+    elif keep == "rng":
+        rng, p = encoders.DeviceRng(5, dev()), 0.3
+    total0 = torch.randn(rows // J, H, generator=g).to(dev()) if acc else None
+    total = total0.clone() if acc else torch.full((rows // J, H), float("nan"), device=dev())
+    out = torch.full((rows, H), float("nan"), dtype=bf, device=dev())
+    parser_ff._linear_act_bwd(gin, wT[0], act, out, J=J, mask=mask, mask_scale=scale, rng=rng, p=p, total=total, accumulate=acc, swap=swap)
+    lin = (gin.double() @ W.double()).to(bf)                                             # the library product's bf16 output
+    want_out, want_total = torch.empty_like(out), (total0.clone() if acc else torch.empty_like(total))
+    parser_ff._act_bwd(lin, act, want_out, rows // J, J, H, mask=mask, total=want_total, accumulate=acc, swap=swap, mask_scale=scale, rng=rng, p=p)
+    err = (out.double() - want_out.double()).abs()
+    assert float((err / want_out.double().abs().clamp_min(1.0)).max()) <= 2.0 ** -6 and float(err.mean()) <= 2e-3
+    assert float((err > 2.0 ** -7 * want_out.double().abs().clamp_min(0.5)).float().mean()) <= 0.02
+    assert float((total - want_total).abs().max()) <= 0.05 * J and float((total - want_total).abs().mean()) <= 4e-3
+    # the group sums are sums of the STORED values (what the next product reads)
+    o = out.float().view(rows // J, J, H)
+    if swap:
+        o = o   # (the permutation moves rows inside a group: the sum is the same)
+    assert float((total - ((total0 if acc else 0) + o.sum(1))).abs().max()) <= 1e-5 * max(1.0, float(total.abs().max()))
+
+
+def test_parser_feed_forward_fused_layers_equal_library_path(monkeypatch):
+    """parser_feed_forward at the shipped width (H = 256, bf16) with its skip-connect encoder as fused row-streaming launches against the same call with
+    library GEMMs + element-wise passes (VLGAE_FF_LIBRARY): outputs and every gradient agree to bf16 rounding; the fused path is what runs by default."""
+    from vlgae_amd import parser_ff, train_step
+    B, L, E, h, Et, T, H, r, nb = 9, 13, 104, 64, 16, 11, 256, 16, 40
+    gen = torch.Generator().manual_seed(4)
+    bf = torch.bfloat16
+    P = train_step.init_feed_forward(gen, dev(), bf, E, h, Et, T, H, nb, r)
+    emb = (torch.randn(B, L, E, generator=gen) * 0.5).to(dev(), bf).requires_grad_(True)
+    x = torch.randn(B, L, h, generator=gen).to(dev(), bf).requires_grad_(True)
+    names = sorted(P)
+    leaves = [emb, x] + [P[k] for k in names]
+    dgen = torch.Generator(device=dev()).manual_seed(11)
+    masks = parser_ff.dropout_masks(B, L, T, H, 0.33, 0.3, device=dev(), dtype=torch.float32, generator=dgen)
+    assert parser_ff._fused(bf, H)
+    runs = []
+    for library in (False, True):
+        monkeypatch.setattr(parser_ff, "_FF_LIBRARY", library)
+        outs = parser_ff.parser_feed_forward(P, emb, x, None, None, None, *masks)
+        cot = [torch.randn(o.shape, generator=torch.Generator().manual_seed(3)).to(dev()) for o in outs]
+        runs.append(([o.detach().float() for o in outs], [g_.float() for g_ in torch.autograd.grad([o.float() for o in outs], leaves, cot)]))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert float((a - b).abs().max()) <= 3e-2 * max(1.0, float(b.abs().max()))
+    gmax = max(float(w.abs().max()) for w in runs[1][1])
+    for name, a, b in zip(["emb", "x"] + names, runs[0][1], runs[1][1]):
+        # (both paths in bf16: a pre-activation within rounding of zero may take different LeakyReLU branches -- relative L2, as the float64 comparison above)
+        assert float((a - b).norm()) <= 0.1 * float(b.norm()) + 2e-3 * gmax * b.numel() ** 0.5, name

@@ -1,0 +1,45 @@
+"""The fused row-streaming Linear + element-wise pass (vlg_ff_linear_act / _backward) alone, at the training step's row counts:
+python tools/time_ffgemm.py [rows] [only: a substring of the variant name]  -- graph-timed, with the library GEMM + vlg_ff_act pair beside it."""
+import sys, torch
+sys.path.insert(0, '.')
+from vlgae_amd import parser_ff
+dev = torch.device('cuda:0')
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 41152
+H, bf = 256, torch.bfloat16
+g = torch.Generator().manual_seed(0)
+x = (torch.randn(rows, H, generator=g) * 0.5).to(dev, bf)
+w = (torch.randn(H, H, generator=g) / 16).to(dev, bf)
+w2 = (torch.randn(2 * H, H, generator=g) / 16).to(dev, bf)
+b, b2 = torch.zeros(H, device=dev, dtype=bf), torch.zeros(2 * H, device=dev, dtype=bf)
+out, out2 = torch.empty(rows, H, device=dev, dtype=bf), torch.empty(2 * rows, H, device=dev, dtype=bf)
+act = torch.randn(rows, H, generator=g).to(dev, bf)
+tot = torch.zeros(rows // 4, H, device=dev)
+def t(fn, n=20, reps=10):
+    """GPU time per call: n calls captured as one HIP graph (eager launches of this size are host-bound), replayed."""
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(n): fn()
+    gr.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): gr.replay()
+    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) * 1e3 / (n * reps)
+def lib():
+    y = torch.addmm(b, x, w.t())
+    parser_ff._act(y, y, rows, 1, H)
+mb = rows * H * 2 * 2 / 1e6
+for name, fn, mbytes in (("fused plain", lambda: parser_ff._linear_act(x, w, b, out), mb),
+                         ("fused 2 blocks + residual", lambda: parser_ff._linear_act(x, w2, b2, out2, nb=2, residual=x, om=2, oy=1), mb * 1.5 + mb / 2),
+                         ("fused backward J=1", lambda: parser_ff._linear_act_bwd(x, w, act, out), mb * 1.5),
+                         ("fused backward J=4 swap sum", lambda: parser_ff._linear_act_bwd(x, w, act, out, J=4, total=tot, swap=True), mb * 1.5),
+                         ("library GEMM + ff_act", lib, mb * 2)):
+    if len(sys.argv) > 2 and sys.argv[2] not in name: continue
+    us = t(fn)
+    print("%-30s %7.1f us   %6.2f TB/s of its own bytes" % (name, us, mbytes / us))

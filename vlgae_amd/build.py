@@ -27,7 +27,7 @@ DP_INST = tuple(("vlg_dp_inst.hip", f"vlg_dp_inst_{f}{s}{i}", DP_FLAGS + (f"-DVL
                 for f in (0, 1, 2) for s in (0, 1) for i in (0, 1))
 UNITS = DP_INST + (("vlg_dp.hip", "vlg_dp", DP_FLAGS), ("vlg_dp_pair.hip", "vlg_dp_pair", DP_FLAGS)) + tuple(
     (src, os.path.splitext(src)[0], ()) for src in
-    ("vlg_align.hip", "vlg_attn.hip", "vlg_ground.hip", "vlg_decode.hip", "vlg_arc.hip", "vlg_rel.hip", "vlg_gemm.hip", "vlg_langfeat.hip", "vlg_ff.hip", "vlg_encoders.hip", "vlg_scorer.hip", "vlg_feed.cpp", "vlg_capi.cpp"))
+    ("vlg_align.hip", "vlg_attn.hip", "vlg_ground.hip", "vlg_decode.hip", "vlg_arc.hip", "vlg_rel.hip", "vlg_gemm.hip", "vlg_langfeat.hip", "vlg_ff.hip", "vlg_ffgemm.hip", "vlg_encoders.hip", "vlg_scorer.hip", "vlg_feed.cpp", "vlg_capi.cpp"))
 SOURCES = tuple(sorted({u[0] for u in UNITS}))
 JOBS = max(1, min(len(UNITS), int(os.environ.get("VLGAE_BUILD_JOBS", os.cpu_count() or 4))))
 

@@ -1,0 +1,396 @@
+// vlg_ffgemm.hip -- the parser feed-forwards' Linear layers over ALL token rows fused with the element-wise pass behind them
+// (`DMVSkipConnectEncoder`, src/model/nn/dmv_spec.py:38-54: Linear -> [+ skip connection] -> LeakyReLU [-> nn.Dropout], five times per
+// step on up to 4 (B L + T + 3) = 41 152 rows of H = 256 channels, and the same five backwards).
+//
+// As a library GEMM + vlg_ff_act pair every stage writes its pre-activation (21 MB in bf16), reads it back, and writes the
+// activation: 4 passes over the activation where the mathematics needs 2, and the library's 256 x 192 tiles stream [41 152 x 256] x
+// [256 x 256] at ~2.1 TB/s (profiles/r06_z_train_step_sequence.txt: 12-26 us per product + 6-12 us per element-wise pass).  Here the
+// layer is a ROW-STREAMING product: K = 256, so the whole weight block [256 outputs x 256] of a workgroup lives in its wavefronts'
+// REGISTERS as MFMA B fragments (wave w of eight: output columns 32 w .. 32 w + 31, 16 fragments of 8 bf16 = 64 VGPRs), the rows stream
+// through -- 32-row tiles, global -> registers one tile ahead -> LDS -> A fragments (ds_read_b128, pitch 544 B: conflict-free) ->
+// v_mfma_f32_16x16x32_bf16 -- and the fp32 accumulators go through an LDS tile into the SAME element-wise code the separate pass ran
+// (vlg_ff.hip: eight channels of a row per thread, 16-byte loads / stores, one rounding per stored element): bias, skip connection,
+// LeakyReLU, mask or counter-based dropout and the (dir,val) store permutation forward; LeakyReLU' of the stored activation, mask and
+// the skip connection's group sum backward.  Bytes per stage: rows x 256 x 2 in + out (+ the residual / activation rows): the
+// floor of the pair it replaces is twice that.
+//
+// bf16 storage only (fp32 activations keep the library path); H = K = 256 exactly (config/model/vlgae.yaml: the parser's hidden width).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "vlg_common.h"
+#include "vlg_mfma.h"
+#include "vlg_rng.h"
+#include "vlg_rows.h"
+
+namespace vlg {
+
+namespace {
+
+constexpr int kFgH = 256;                 // channels in and out per column block
+constexpr int kFgRows = 32;               // rows per tile
+constexpr int kFgThreads = 512;           // eight wavefronts: 32 output columns each (ONE workgroup per CU: its 128 KB weight block is read once per CU)
+constexpr int kFgXPitch = kFgH * 2 + 32;  // bytes per LDS row of the input tile (136 words = 8 mod 64: the b128 lane groups hit disjoint banks)
+constexpr int kFgLds = 2 * kFgRows * kFgXPitch;   // two input images
+
+struct FgArgs {
+    const uint16_t* x;      // [rows][ldx] input rows (bf16), the first 256 channels
+    int ldx;
+    const uint16_t* w;      // [nb * 256][256]: w[n][k], the weight of output channel n (nn.Linear layout; a transposed copy for x @ W)
+    const uint16_t* bias;   // [nb * 256] or null
+    long long rows;
+    float slope;
+    // ---- forward epilogue: out[orow][c] = leaky(acc + bias[y 256 + c] + res[row >> rs][c]) * keep, orow = (row >> rs) om + y oy + (row & ((1 << rs) - 1))
+    const uint16_t* res;    // [rows >> rs][256] or null
+    int rs, om, oy;
+    // ---- backward epilogue (bwd != 0): out[orow][c] = leaky'(act[row][c]) * acc * keep[row]; sum[m][c] (+)= sum_j stored(out), rows m J + j; orow = swap ? 4 m + swap2(j) : row
+    int bwd, J, lj, swap, accumulate;
+    const uint16_t* act;    // [rows][256] stored activations (backward)
+    float* sum;             // [rows / J][256] fp32 or null
+    // ---- keep: an explicit mask (times mask_scale) or the counter-based draw (rng), indexed by orow forward and by row backward (as vlg_ff_act*)
+    const uint16_t* mask;
+    float mask_scale;
+    const uint64_t* rng;
+    uint32_t site, thr;
+    uint16_t* out;          // [.][256]
+};
+
+__device__ __forceinline__ int fg_swap2(int j) { return ((j & 1) << 1) | (j >> 1); }
+
+// bf16 conversions on the hardware path (v_cvt_pk_bf16_f32, round to nearest even like vlg_rows.h's f2bf: the epilogue rounds 16 values per item)
+__device__ __forceinline__ float fg_round(float v) { return (float)(__bf16)v; }
+__device__ __forceinline__ void fg_store8(uint16_t* p, const float (&v)[8]) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const bf16x2 a = {(__bf16)v[0], (__bf16)v[1]}, b = {(__bf16)v[2], (__bf16)v[3]}, c = {(__bf16)v[4], (__bf16)v[5]}, d = {(__bf16)v[6], (__bf16)v[7]};
+    uint4 w;
+    w.x = __builtin_bit_cast(uint32_t, a); w.y = __builtin_bit_cast(uint32_t, b); w.z = __builtin_bit_cast(uint32_t, c); w.w = __builtin_bit_cast(uint32_t, d);
+    *reinterpret_cast<uint4*>(p) = w;
+}
+
+__device__ __forceinline__ void fg_store4(uint16_t* p, const float (&v)[4]) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const bf16x2 a = {(__bf16)v[0], (__bf16)v[1]}, b = {(__bf16)v[2], (__bf16)v[3]};
+    uint2 w;
+    w.x = __builtin_bit_cast(uint32_t, a); w.y = __builtin_bit_cast(uint32_t, b);
+    *reinterpret_cast<uint2*>(p) = w;
+}
+// sum over the J (1, 2 or 4) consecutive lanes of a row group (lanes r, r ^ 1, r ^ 2, r ^ 3 of a quad): every lane gets the group's sum
+// (DPP quad permutations: one vector instruction each; __shfl_xor goes through the LDS crossbar)
+__device__ __forceinline__ float fg_quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float fg_quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float fg_group_sum(float v, int J) {
+    if (J >= 2) v += fg_quad_xor1(v);
+    if (J >= 4) v += fg_quad_xor2(v);
+    return v;
+}
+// The counter-based keep flags of a tile for this lane: km[rt][nt][k] for its four channels of the 8-channel groups (orow(rt), c >> 3).  The lane
+// 16 further on holds the other half of the same groups: of the two, the one with even kg draws the groups of row tile 0 and the other those of
+// row tile 1 (one Philox call per group and lane pair, as vlg_ff_act makes one per group), and they exchange the halves they owe each other.
+__device__ __forceinline__ void fg_tile_keep(const FgArgs& a, long long krow0, long long krow1, int wave, int kg, float (&km)[2][2][4]) {
+    const int hv = kFgH >> 3, mine = kg & 1;
+    const uint64_t seed = a.rng[0], step = a.rng[1];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int c = wave * 32 + nt * 16 + kg * 4;
+        const uint64_t g = (uint64_t)(mine ? krow1 : krow0) * hv + (c >> 3);
+        const uint4 q = philox4x32_10(make_uint4((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)step, (uint32_t)(step >> 32)),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (a.site * 0x9E3779B9u)));
+        // my half of my row tile's group; the partner's half (the other one) of it goes over
+        const uint32_t own0 = mine ? q.z : q.x, own1 = mine ? q.w : q.y, give0 = mine ? q.x : q.z, give1 = mine ? q.y : q.w;
+        const uint32_t got0 = (uint32_t)__shfl_xor((int)give0, 16, 64), got1 = (uint32_t)__shfl_xor((int)give1, 16, 64);
+        // (named words, explicit selects: small arrays indexed by a lane-dependent flag were placed in scratch memory)
+        const uint32_t a0 = mine ? got0 : own0, a1 = mine ? got1 : own1, b0 = mine ? own0 : got0, b1 = mine ? own1 : got1;   // row tile 0 | 1
+        km[0][nt][0] = (a0 & 0xffffu) >= a.thr ? a.mask_scale : 0.f;
+        km[0][nt][1] = (a0 >> 16) >= a.thr ? a.mask_scale : 0.f;
+        km[0][nt][2] = (a1 & 0xffffu) >= a.thr ? a.mask_scale : 0.f;
+        km[0][nt][3] = (a1 >> 16) >= a.thr ? a.mask_scale : 0.f;
+        km[1][nt][0] = (b0 & 0xffffu) >= a.thr ? a.mask_scale : 0.f;
+        km[1][nt][1] = (b0 >> 16) >= a.thr ? a.mask_scale : 0.f;
+        km[1][nt][2] = (b1 & 0xffffu) >= a.thr ? a.mask_scale : 0.f;
+        km[1][nt][3] = (b1 >> 16) >= a.thr ? a.mask_scale : 0.f;
+    }
+}
+
+// One 32-row tile.  The product runs TRANSPOSED on the matrix cores -- D[channel][row] = W (A operand, from registers) x X^T (B operand, from the
+// LDS image `xs`) -- so that a lane's accumulator registers are FOUR CONSECUTIVE CHANNELS of ONE ROW (lane l, register n <-> channel
+// c0 + 4 (l >> 4) + n, row l & 15): the element-wise pass runs on the accumulators in registers, with 8-byte loads / stores of the row's
+// other tensors, and nothing goes back through the LDS (the first version wrote the fp32 accumulators to an LDS tile and read them back
+// row-major behind a barrier: eight waves in lock step, ~6 700 cycles per tile for 512 cycles of MFMA).
+__device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char* xs, const bf16x8 (&wf)[8][2], const float (&bias4)[2][4], int tid, int y) {
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 15, kg = lane >> 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 xf[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) xf[rt] = *reinterpret_cast<const bf16x8*>(xs + (rt * 16 + r) * kFgXPitch + (ks * 32 + kg * 8) * 2);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nt], xf[rt], acc[rt][nt], 0, 0, 0);
+#ifdef VLG_FG_ONE_KSTEP   // tools/ ablation (results are wrong): one of the eight contraction steps
+        break;
+#endif
+    }
+    const long long row0 = t * kFgRows;
+    float km[2][2][4];
+    if (a.rng) {       // (uniform) the dropout draws of the tile, indexed by the OUTPUT row forward and by the row backward (as vlg_ff_act*)
+        const long long ra = row0 + r, rb = row0 + 16 + r;
+        const long long ka = a.bwd ? ra : (ra >> a.rs) * a.om + (long long)y * a.oy + (ra & ((1 << a.rs) - 1));
+        const long long kb = a.bwd ? rb : (rb >> a.rs) * a.om + (long long)y * a.oy + (rb & ((1 << a.rs) - 1));
+        fg_tile_keep(a, ka, kb, wave, kg, km);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const long long row = row0 + rt * 16 + r;
+        const bool live = row < a.rows;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = wave * 32 + nt * 16 + kg * 4;        // this lane's four channels
+            float val[4] = {acc[rt][nt][0], acc[rt][nt][1], acc[rt][nt][2], acc[rt][nt][3]};
+            if (!a.bwd) {
+                // (the pair this replaces rounds the Linear's output to bf16 before the skip connection is added: the same rounding here, so
+                //  that the two paths agree to the last bit of what the next layer reads wherever the product's own summation order does)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) val[k] = fg_round(val[k] + bias4[nt][k]);
+                const long long m = row >> a.rs;
+                const long long orow = m * a.om + (long long)y * a.oy + (row & ((1 << a.rs) - 1));
+                if (live) {
+                    if (a.res) {
+                        float t4[4];
+                        load4(a.res + (size_t)m * kFgH + c, t4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) val[k] += t4[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) val[k] = leaky(val[k], a.slope);
+                    if (a.mask) {
+                        float t4[4];
+                        load4(a.mask + (size_t)orow * kFgH + c, t4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) val[k] *= t4[k] * a.mask_scale;
+                    } else if (a.rng) {      // the draw of the 8-channel group this lane holds half of (the element indexing of vlg_ff_act)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) val[k] *= km[rt][nt][k];
+                    }
+#ifndef VLG_FG_NOSTORE     // tools/ ablation
+                    fg_store4(a.out + (size_t)orow * kFgH + c, val);
+#else
+                    if (val[0] == 123.456f) fg_store4(a.out + (size_t)orow * kFgH + c, val);
+#endif
+                }
+            } else {
+                const int J = a.J, j = (int)(row & (J - 1));
+                const long long m = row >> a.lj, orow = a.swap ? m * 4 + fg_swap2(j) : row;      // (J = 1 << lj: no 64-bit division per element)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) val[k] = fg_round(val[k]);      // (the product's bf16 output, as the pair rounds it)
+                float sv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (live) {
+                    float av[4];
+                    load4(a.act + (size_t)row * kFgH + c, av);
+                    if (a.mask) {
+                        float t4[4];
+                        load4(a.mask + (size_t)row * kFgH + c, t4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) val[k] *= t4[k] * a.mask_scale;
+                    } else if (a.rng) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) val[k] *= km[rt][nt][k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        val[k] = av[k] > 0.f ? val[k] : val[k] * a.slope;
+                        sv[k] = fg_round(val[k]);                           // the sum of what the next product reads
+                    }
+                    fg_store4(a.out + (size_t)orow * kFgH + c, val);
+                }
+                if (a.sum) {     // (uniform) the J rows of a group sit on J consecutive lanes: the group's sum in row order j = 0, 1, ..
+                    float s[4];
+                    if (J == 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) s[k] = sv[k];
+                    } else {
+                        // fixed order ((j0 + j1) + (j2 + j3)): every lane of the group computes the same sum
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) s[k] = fg_group_sum(sv[k], J);
+                    }
+                    if (live && j == 0) {
+                        float* sp = a.sum + (size_t)m * kFgH + c;
+                        if (a.accumulate) {
+                            const float4 o = *reinterpret_cast<const float4*>(sp);
+                            s[0] += o.x; s[1] += o.y; s[2] += o.z; s[3] += o.w;
+                        }
+                        *reinterpret_cast<float4*>(sp) = make_float4(s[0], s[1], s[2], s[3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const xs0 = smem;
+    char* const xs1 = smem + kFgRows * kFgXPitch;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int y = blockIdx.y;
+    const long long tiles = (a.rows + kFgRows - 1) / kFgRows, G = gridDim.x;
+    long long t = blockIdx.x;
+    if (t >= tiles) return;
+    // Input tile staging: thread t moves the 16-byte segments v = t + 512 j (j < 2) of a tile (row v >> 5, segment v & 31) through named
+    // registers (as an array, written under a condition and read an epilogue later, the segments were kept in scratch memory).  TWO tiles are in
+    // flight -- set A holds the tile after this one, set B the one after that.
+    uint4 xa0, xa1, xb0, xb1;
+#define FG_SEG_LOAD(T_, J_) \
+    *reinterpret_cast<const uint4*>(a.x + (size_t)min((T_) * kFgRows + ((tid + kFgThreads * (J_)) >> 5), a.rows - 1) * a.ldx + ((tid + kFgThreads * (J_)) & 31) * 8)
+#define FG_SEG_STORE(XS_, J_, V_) \
+    *reinterpret_cast<uint4*>((XS_) + ((tid + kFgThreads * (J_)) >> 5) * kFgXPitch + ((tid + kFgThreads * (J_)) & 31) * 16) = (V_)
+#define FG_LOAD_A(T_) { xa0 = FG_SEG_LOAD(T_, 0); xa1 = FG_SEG_LOAD(T_, 1); }
+#define FG_LOAD_B(T_) { xb0 = FG_SEG_LOAD(T_, 0); xb1 = FG_SEG_LOAD(T_, 1); }
+#define FG_STORE_A(XS_) { FG_SEG_STORE(XS_, 0, xa0); FG_SEG_STORE(XS_, 1, xa1); }
+#define FG_STORE_B(XS_) { FG_SEG_STORE(XS_, 0, xb0); FG_SEG_STORE(XS_, 1, xb1); }
+    FG_LOAD_A(t)
+    // ---- the weight block of this workgroup's column block, in registers for the whole launch ----
+    bf16x8 wf[8][2];
+    {
+        const uint16_t* wb = a.w + ((size_t)y * kFgH + wave * 32) * kFgH;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#ifndef VLG_FG_NOW         // tools/ ablation: every fragment from the first 16 rows of the block
+                wf[ks][nt] = *reinterpret_cast<const bf16x8*>(wb + (size_t)(nt * 16 + r) * kFgH + ks * 32 + kg * 8);
+#else
+                wf[ks][nt] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)r * kFgH + kg * 8);
+#endif
+    }
+    float bias4[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bias4[nt][k] = a.bias ? bf2f(a.bias[y * kFgH + wave * 32 + nt * 16 + kg * 4 + k]) : 0.f;
+    FG_STORE_A(xs0)
+    // (tiles past the end re-read the last row: no branches around the loads; their registers are never stored)
+    FG_LOAD_A(t + G)
+    FG_LOAD_B(t + 2 * G)
+    __syncthreads();
+    for (;;) {
+        fg_tile(a, t, xs0, wf, bias4, tid, y);                // tile t from image 0
+        if (t + G >= tiles) break;
+        FG_STORE_A(xs1)                                        // tile t + G -> image 1 (only set A's reads are waited for)
+        FG_LOAD_A(t + 3 * G)
+        __syncthreads();
+        fg_tile(a, t + G, xs1, wf, bias4, tid, y);            // tile t + G from image 1
+        if (t + 2 * G >= tiles) break;
+        FG_STORE_B(xs0)
+        FG_LOAD_B(t + 4 * G)
+        __syncthreads();
+        t += 2 * G;
+    }
+}
+
+// out[z][n][k] = w_z[k][n] for up to four 256 x 256 bf16 matrices (the layers' weights as the backward launches read them): 32 x 32 tiles through LDS
+struct FgTr { const uint16_t* w[4]; };
+__global__ __launch_bounds__(256) void ff_transpose256_kernel(const FgTr a, uint16_t* __restrict__ out) {
+    __shared__ uint16_t tile[32][34];
+    const uint16_t* w = a.w[blockIdx.z];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = w[(size_t)(k0 + ty + 8 * i) * kFgH + n0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[((size_t)blockIdx.z * kFgH + n0 + ty + 8 * i) * kFgH + k0 + tx] = tile[tx][ty + 8 * i];
+}
+
+#undef FG_SEG_LOAD
+#undef FG_SEG_STORE
+#undef FG_LOAD_A
+#undef FG_LOAD_B
+#undef FG_STORE_A
+#undef FG_STORE_B
+
+int fg_launch(const FgArgs& a, int nb, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_gemm_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kFgLds);
+        if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const long long tiles = (a.rows + kFgRows - 1) / kFgRows;
+    // ONE workgroup per CU holds its weight block for the whole launch (the block is re-read from the L2 by every workgroup: with 512
+    // workgroups those reads -- 64 MB of 64-byte pieces out of the same 128 KB -- took ~15 us per launch); the tiles are dealt round-robin
+    const int per_block = 256 / nb;
+    const int gx = (int)std::min<long long>(tiles, per_block);
+    hipLaunchKernelGGL(ff_gemm_act_kernel, dim3(gx, nb), dim3(kFgThreads), kFgLds, s, a);
+    return check_launch("ff_gemm_act_kernel");
+}
+
+int fg_check(const char* what, const void* x, int ldx, const void* w, long long rows, const void* out) {
+    if (rows < 0) return set_error(VLG_ERR_SHAPE, "%s: rows=%lld", what, rows);
+    if (ldx < kFgH || ldx % 8) return set_error(VLG_ERR_SHAPE, "%s: input row stride %d (>= 256, a multiple of 8 elements)", what, ldx);
+    if (rows > 0 && (!x || !w || !out)) return set_error(VLG_ERR_ARG, "%s: null buffer", what);
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) return set_error(VLG_ERR_ARG, "%s: buffers must be 16-byte aligned", what);
+    return 0;
+}
+
+}  // namespace
+
+}  // namespace vlg
+
+extern "C" {
+
+int vlg_ff_linear_act(const void* x, int ldx, const void* w, const void* bias, long long rows, int nb, const void* residual, int rs, int om,
+                      int oy, const void* mask, float mask_scale, const uint64_t* rng, unsigned site, float p, void* out, float slope,
+                      void* stream) {
+    using namespace vlg;
+    if (int rc = fg_check("ff_linear_act", x, ldx, w, rows, out)) return rc;
+    if (nb < 1 || nb > 2 || rs < 0 || rs > 1 || om < 1 || oy < 0) return set_error(VLG_ERR_ARG, "ff_linear_act: nb=%d rs=%d om=%d oy=%d", nb, rs, om, oy);
+    if (mask && rng) return set_error(VLG_ERR_ARG, "ff_linear_act: mask and rng are exclusive");
+    if (rows == 0) return 0;
+    FgArgs a{};
+    a.x = (const uint16_t*)x; a.ldx = ldx; a.w = (const uint16_t*)w; a.bias = (const uint16_t*)bias; a.rows = rows; a.slope = slope;
+    a.res = (const uint16_t*)residual; a.rs = rs; a.om = om; a.oy = oy;
+    a.bwd = 0; a.J = 1;
+    a.mask = (const uint16_t*)mask; a.mask_scale = rng ? drop_scale(p) : mask_scale; a.rng = rng; a.site = site; a.thr = rng ? drop_threshold(p) : 0;
+    a.out = (uint16_t*)out;
+    return fg_launch(a, nb, (hipStream_t)stream);
+}
+
+int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, long long rows, int J, const void* act, const void* mask, float mask_scale,
+                               const uint64_t* rng, unsigned site, float p, void* out, float* sum, int swap, int accumulate, float slope,
+                               void* stream) {
+    using namespace vlg;
+    if (int rc = fg_check("ff_linear_act_backward", g, ldg, w_t, rows, out)) return rc;
+    if ((J != 1 && J != 2 && J != 4) || rows % J || (swap && J != 4)) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: rows=%lld J=%d swap=%d", rows, J, swap);
+    if ((mask || rng) && swap) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: no permutation with a mask");
+    if (mask && rng) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: mask and rng are exclusive");
+    if (rows > 0 && !act) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: null activation");
+    if (rows == 0) return 0;
+    FgArgs a{};
+    a.x = (const uint16_t*)g; a.ldx = ldg; a.w = (const uint16_t*)w_t; a.bias = nullptr; a.rows = rows; a.slope = slope;
+    a.bwd = 1; a.J = J; a.lj = J == 4 ? 2 : (J == 2 ? 1 : 0); a.swap = swap; a.accumulate = accumulate; a.act = (const uint16_t*)act; a.sum = sum;
+    a.mask = (const uint16_t*)mask; a.mask_scale = rng ? drop_scale(p) : mask_scale; a.rng = rng; a.site = site; a.thr = rng ? drop_threshold(p) : 0;
+    a.out = (uint16_t*)out;
+    return fg_launch(a, 1, (hipStream_t)stream);
+}
+
+int vlg_ff_transpose256(const void* w0, const void* w1, const void* w2, const void* w3, int n, void* out, void* stream) {
+    using namespace vlg;
+    if (n < 1 || n > 4 || !out || !w0 || (n > 1 && !w1) || (n > 2 && !w2) || (n > 3 && !w3)) return set_error(VLG_ERR_ARG, "ff_transpose256: n=%d or a null buffer", n);
+    FgTr a{{(const uint16_t*)w0, (const uint16_t*)w1, (const uint16_t*)w2, (const uint16_t*)w3}};
+    hipLaunchKernelGGL(ff_transpose256_kernel, dim3(8, 8, n), dim3(256), 0, (hipStream_t)stream, a, (uint16_t*)out);
+    return check_launch("ff_transpose256_kernel");
+}
+
+}  // extern "C"

@@ -29,6 +29,8 @@ bias-gradient reductions and un-fused bias / residual adds.  Here, with identica
     through their strides) -- the library maps an output of a few hundred rows and columns to one workgroup.
 The reference formulation (tools/train_step.scorer_feed_forward, module by module) is what the tests compare this with.
 """
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -111,6 +113,33 @@ def _act_bwd(g, act, out, M, J, H, mask=None, total=None, accumulate=False, swap
     _C.check(_C.lib().vlg_ff_act_backward(_C.ptr(g), _C.ptr(act), _C.ptr(mask), float(mask_scale), None if rng is None else _C.ptr(rng.state),
                                           SITE_MID_FF, float(p), _C.ptr(out), _C.ptr(total), M, J, H, int(swap), int(accumulate), _adt(g), SLOPE,
                                           _C.stream_of(g)), "ff_act_backward")
+    return out
+
+
+_FF_LIBRARY = bool(os.environ.get("VLGAE_FF_LIBRARY"))   # opt-out: every Linear of the skip-connect encoder as library GEMM + element-wise pass
+
+
+def _fused(act, H):
+    """Whether the skip-connect encoder's Linear layers run as the row-streaming product fused with their element-wise pass
+    (vlg_ff_linear_act: bf16 storage, exactly 256 channels -- the shipped width); otherwise library GEMM + vlg_ff_act as before."""
+    return act == torch.bfloat16 and H == 256 and not _FF_LIBRARY
+
+
+def _linear_act(x, w, bias, out, nb=1, residual=None, rs=0, om=1, oy=0, mask=None, mask_scale=1.0, rng=None, p=0.0):
+    """out[orow] = LeakyReLU(bf16(x[row] @ w[256 y:256 y + 256].T + bias) + residual[row >> rs]) * keep, orow = (row >> rs) om + y oy + (row & ((1 << rs) - 1))
+    for the nb column blocks y of w [nb 256, 256]: Linear + skip connection + LeakyReLU (+ dropout) in one launch (vlg_ff_linear_act)."""
+    _C.check(_C.lib().vlg_ff_linear_act(_C.ptr(x), x.stride(0), _C.ptr(w), _C.ptr(bias), x.shape[0], nb, _C.ptr(residual), rs, om, oy, _C.ptr(mask),
+                                        float(mask_scale), None if rng is None else _C.ptr(rng.state), SITE_MID_FF, float(p), _C.ptr(out), SLOPE,
+                                        _C.stream_of(x)), "ff_linear_act")
+    return out
+
+
+def _linear_act_bwd(g, w_t, act, out, J=1, mask=None, mask_scale=1.0, rng=None, p=0.0, total=None, accumulate=False, swap=False):
+    """out = LeakyReLU'(act) * bf16(g @ W) * keep with W given transposed (w_t = W.T contiguous); total [rows / J, 256] fp32 (+)= the group sums
+    (vlg_ff_linear_act_backward: the input-gradient product of a layer fused with the adjoint of the element-wise pass in front of it)."""
+    _C.check(_C.lib().vlg_ff_linear_act_backward(_C.ptr(g), g.stride(0), _C.ptr(w_t), g.shape[0], J, _C.ptr(act), _C.ptr(mask), float(mask_scale),
+                                                 None if rng is None else _C.ptr(rng.state), SITE_MID_FF, float(p), _C.ptr(out), _C.ptr(total),
+                                                 int(swap), int(accumulate), SLOPE, _C.stream_of(g)), "ff_linear_act_backward")
     return out
 
 
@@ -217,23 +246,38 @@ class _ParserFF(torch.autograd.Function):
         _C.check(lib.vlg_ff_mlp_act(_C.ptr(X), _C.ptr(cterm), _C.ptr(drop_head), _C.ptr(drop_small), B, L, Ms, H, adt, SLOPE, st), "ff_mlp_act")
         W_nh, b_nh = Weff[0:2].reshape(2 * H, H), beff[0:2].reshape(2 * H)
         W_lr, b_lr = Weff[2:4].reshape(2 * H, H), beff[2:4].reshape(2 * H)
-        # ---- valence stage, nn/dmv_spec.py:41-44 ----
-        A1 = torch.addmm(b_nh, X, W_nh.t())                                             # [M,2H] = (no | has) bottleneck outputs
-        _act(A1, A1, M, 2, H, residual=X)                                               # act(bottleneck + x) (the skip connection)
         Wv, bv = c(P["ff.mid_ff.valence_linear.weight"]), c(P["ff.mid_ff.valence_linear.bias"])
-        A2 = torch.addmm(bv, A1.view(2 * M, H), Wv.t())
-        _act(A2, A2, 2 * M, 1, H)                                                       # h [M,val,H]
-        # ---- direction stage, :46-50 ----
-        Z = torch.addmm(b_lr, A2, W_lr.t())                                             # [2M,2H]: rows (m,val), columns (dir,c)
-        A3 = torch.empty((M, 2, 2, H), dtype=act, device=dev)                           # [m,dir,val,c]
-        _act(Z, A3, M, 4, H, residual=X, swap=True)
         Wd, bd = c(P["ff.mid_ff.direction_linear.weight"]), c(P["ff.mid_ff.direction_linear.bias"])
-        A4 = torch.addmm(bd, A3.view(4 * M, H), Wd.t())
-        _act(A4, A4, 4 * M, 1, H, mask=mid_mask, mask_scale=mid_scale, rng=mid_rng, p=p_mid)   # nn.Dropout after the direction stage (nn/dmv_spec.py:52)
-        # ---- output stage, :52-54 with linear2 folded into the projections ----
         W1_, b1_ = c(P["ff.mid_ff.linear1.weight"]), c(P["ff.mid_ff.linear1.bias"])
-        A5 = torch.addmm(b1_, A4, W1_.t())
-        _act(A5, A5, 4 * M, 1, H)
+        A3 = torch.empty((M, 2, 2, H), dtype=act, device=dev)                           # [m,dir,val,c]
+        wT = None
+        if _fused(act, H):
+            # every stage ONE launch: the rows stream through a product whose weight block sits in registers, and the element-wise pass runs on the
+            # accumulators (vlg_ff_linear_act) -- no pre-activation tensor is written or read.  The backward pass's transposed weights in one launch.
+            A1 = torch.empty((M, 2 * H), dtype=act, device=dev)
+            A2, A4, A5 = (torch.empty((n, H), dtype=act, device=dev) for n in (2 * M, 4 * M, 4 * M))
+            W_nh, b_nh, W_lr, b_lr, Wv, Wd, W1_ = (t.contiguous() for t in (W_nh, b_nh, W_lr, b_lr, Wv, Wd, W1_))
+            _linear_act(X, W_nh, b_nh, A1, nb=2, residual=X, om=2, oy=1)                   # valence stage, nn/dmv_spec.py:41-44: act(bottleneck + x)
+            _linear_act(A1.view(2 * M, H), Wv, bv, A2)                                     # h [M,val,H]
+            _linear_act(A2, W_lr, b_lr, A3, nb=2, residual=X, rs=1, om=4, oy=2)            # direction stage, :46-50: rows (m,val) -> [m,dir,val]
+            _linear_act(A3.view(4 * M, H), Wd, bd, A4, mask=mid_mask, mask_scale=mid_scale, rng=mid_rng, p=p_mid)   # + nn.Dropout (:52)
+            _linear_act(A4, W1_, b1_, A5)                                                  # output stage, :52-54 (linear2 folded into the projections)
+            wT = torch.empty((3, H, H), dtype=act, device=dev)
+            _C.check(lib.vlg_ff_transpose256(_C.ptr(W1_), _C.ptr(Wd), _C.ptr(Wv), None, 3, _C.ptr(wT), st), "ff_transpose256")
+        else:
+            # ---- valence stage, nn/dmv_spec.py:41-44 ----
+            A1 = torch.addmm(b_nh, X, W_nh.t())                                             # [M,2H] = (no | has) bottleneck outputs
+            _act(A1, A1, M, 2, H, residual=X)                                               # act(bottleneck + x) (the skip connection)
+            A2 = torch.addmm(bv, A1.view(2 * M, H), Wv.t())
+            _act(A2, A2, 2 * M, 1, H)                                                       # h [M,val,H]
+            # ---- direction stage, :46-50 ----
+            Z = torch.addmm(b_lr, A2, W_lr.t())                                             # [2M,2H]: rows (m,val), columns (dir,c)
+            _act(Z, A3, M, 4, H, residual=X, swap=True)
+            A4 = torch.addmm(bd, A3.view(4 * M, H), Wd.t())
+            _act(A4, A4, 4 * M, 1, H, mask=mid_mask, mask_scale=mid_scale, rng=mid_rng, p=p_mid)   # nn.Dropout after the direction stage (nn/dmv_spec.py:52)
+            # ---- output stage, :52-54 with linear2 folded into the projections ----
+            A5 = torch.addmm(b1_, A4, W1_.t())
+            _act(A5, A5, 4 * M, 1, H)
         big = torch.addmm(bp[:2 * r], A5[:4 * M0], Wp[:2 * r].t())                      # [4 M0, 2r]: attach.project1 | dec.project1
         small = small_matmul(A5[4 * M0:], Wp[2 * r:].t(), bias=bp[2 * r:])                # [4 Ms, 4r]: attach.p2 | root.p2 | root.p1 | dec.p2
         # the scorers' inputs as VIEWS of the two products (vlgae_amd.scorer takes rows a constant stride apart in place); they are outputs
@@ -247,6 +291,7 @@ class _ParserFF(torch.autograd.Function):
         ctx.save_for_backward(emb2, cmean, X, A1, A2, A3, A4, A5, We, Wc, W_nh, W_lr, Wv, Wd, W1_, W2_, b2_, PW, Wp, W0s, b0s, W1s,
                               *(c(t.detach()) for t in small_in), *(c(P[f"ff.{m}.linear.weight"]) for m in ("child_ff", "root_ff", "dec_ff")),
                               small, root_rule)
+        ctx.wT = wT     # (an intermediate of this Function, not an input or output: kept on the context)
         ctx.drops = drops
         ctx.meta = (nb, B, L, E, h, T, H, r, act, [t.dtype for t in (emb, x, token_emb, root_emb, dec_emb)], [p.dtype for p in params])
         return x1, x2, y1, y2, root_rule
@@ -294,13 +339,20 @@ class _ParserFF(torch.autograd.Function):
         # ---- linear1, direction ----
         g = _act_bwd(gA5, A5, gA5, 4 * M, 1, H)
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4, dtype=act, defer=wg)
-        g = g @ W1_
-        _act_bwd(g, A4, g, 4 * M, 1, H, mask=mid_mask, mask_scale=ctx.drops[3], rng=mid_rng, p=p_mid)
-        G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H), dtype=act, defer=wg)
-        g = g @ Wd                                                                       # [m,dir,val,c]
+        wT = ctx.wT          # [3,H,H]: linear1 | direction | valence weights transposed (the fused launches' operand) or None
         gX = torch.empty((M, H), dtype=torch.float32, device=g.device)                   # the skip connections' cotangent
         gZ = torch.empty((2 * M, 2 * H), dtype=act, device=g.device)                     # [m,val,dir,c]
-        _act_bwd(g, A3, gZ, M, 4, H, total=gX, swap=True)
+        if wT is not None:   # the input-gradient product of a layer and the adjoint of the element-wise pass in front of it in ONE launch
+            g = _linear_act_bwd(g, wT[0], A4, torch.empty_like(g), mask=mid_mask, mask_scale=ctx.drops[3], rng=mid_rng, p=p_mid)
+        else:
+            g = g @ W1_
+            _act_bwd(g, A4, g, 4 * M, 1, H, mask=mid_mask, mask_scale=ctx.drops[3], rng=mid_rng, p=p_mid)
+        G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H), dtype=act, defer=wg)
+        if wT is not None:
+            _linear_act_bwd(g, wT[1], A3, gZ, J=4, total=gX, swap=True)                  # [m,dir,val,c] -> [m,val,dir,c], gX = the four rows' sum
+        else:
+            g = g @ Wd                                                                   # [m,dir,val,c]
+            _act_bwd(g, A3, gZ, M, 4, H, total=gX, swap=True)
         # the gradients of the folded weights straight into their stack, in the activations' dtype (what the unfold products read)
         dWeff, dbeff = torch.empty((4, H, H), dtype=act, device=g.device), torch.empty((4, H), dtype=act, device=g.device)   # no, has, left, right
         _wgrad(gZ, A2, out=(dWeff[2:4].view(2 * H, H), dbeff[2:4].view(2 * H)), defer=wg)
@@ -308,8 +360,11 @@ class _ParserFF(torch.autograd.Function):
         g = gZ @ W_lr
         _act_bwd(g, A2, g, 2 * M, 1, H)
         G["valence.w"], G["valence.b"] = _wgrad(g, A1.view(2 * M, H), dtype=act, defer=wg)
-        gY = g @ Wv                                                                      # [M,2,H]
-        _act_bwd(gY, A1, gY, M, 2, H, total=gX, accumulate=True)
+        if wT is not None:
+            gY = _linear_act_bwd(g, wT[2], A1, torch.empty_like(g), J=2, total=gX, accumulate=True)
+        else:
+            gY = g @ Wv                                                                  # [M,2,H]
+            _act_bwd(gY, A1, gY, M, 2, H, total=gX, accumulate=True)
         gY = gY.view(M, 2 * H)
         _wgrad(gY, X, out=(dWeff[0:2].view(2 * H, H), dbeff[0:2].view(2 * H)), defer=wg)
         # ---- MLPs: gpre = LeakyReLU'(X) * SharedDropout mask * (gX + gY W_nh) ----
