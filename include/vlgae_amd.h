@@ -446,7 +446,7 @@ int vlg_ff_root_rule_backward(const void* small, int ld, int T, int r, int act_d
                               int ld_x2, const void* g_y2, int ld_y2, void* g_small, void* stream);
 /* A feed-forward Linear over all token rows FUSED with the element-wise pass behind it (round 6; the DMVSkipConnectEncoder stages of
  * src/model/nn/dmv_spec.py:38-54): one row-streaming launch in place of a library GEMM + vlg_ff_act / vlg_ff_act_backward pair.  bf16 storage,
- * exactly 256 input channels and 256 output channels per column block; every pointer 16-byte aligned, rows of x / g `ld` elements apart.
+ * exactly 256 output channels per column block and 256 input channels (the backward launch also takes 512 and 32); every pointer 16-byte aligned, rows of x / g `ld` elements apart.
  *   vlg_ff_linear_act           x [rows, 256], w [nb 256, 256] (nn.Linear layout: w[n][k]), bias [nb 256] or NULL, nb = 1 or 2 column blocks y:
  *                               out[orow][c] = LeakyReLU(bf16(x[row] . w[256 y + c] + bias) + residual[row >> rs][c]) * keep[orow][c],
  *                               orow = (row >> rs) om + y oy + (row & ((1 << rs) - 1)); residual [rows >> rs, 256] or NULL.
@@ -457,14 +457,25 @@ int vlg_ff_root_rule_backward(const void* small, int ld, int T, int r, int act_d
  *   vlg_ff_linear_act_backward  g [rows, 256], w_t [256, 256] = the layer's weight TRANSPOSED (w_t[n][k] = weight[k][n], so that g . w_t[n] is the
  *                               cotangent of input channel n): out[orow][c] = LeakyReLU'(act[row][c]) * bf16(g[row] . w_t[c]) * keep[row][c];
  *                               rows are groups m J + j (J = 1, 2 or 4), sum [rows / J, 256] fp32 (or NULL) = / += (accumulate) sum_j of the stored
- *                               out values; swap (J = 4): orow = 4 m + (dir,val <- val,dir)(j) -- as vlg_ff_act_backward on the product. */
+ *                               out values; swap (J = 4): orow = 4 m + (dir,val <- val,dir)(j) -- as vlg_ff_act_backward on the product.
+ *                               k = the contraction length (columns of g): 256 as above; 512: g [rows, 512] is the cotangent of a two-block stage
+ *                               and w_t [2, 256, 256] the transposes of the weight's two [256, 256] row blocks one after the other (vlg_ff_transpose256
+ *                               of the blocks); 32 with w_kn = 1: g [rows, 32] and w_t is the weight ITSELF, [32, 256] (w[k][n]: the folded
+ *                               projections' cotangent, 2 r = 32 columns).  w_kn = 0 otherwise. */
 int vlg_ff_linear_act(const void* x, int ldx, const void* w, const void* bias, long long rows, int nb, const void* residual, int rs, int om, int oy,
                       const void* mask, float mask_scale, const uint64_t* rng, unsigned site, float p, void* out, float slope, void* stream);
-int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, long long rows, int J, const void* act, const void* mask, float mask_scale,
+int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, int k, int w_kn, long long rows, int J, const void* act, const void* mask, float mask_scale,
                                const uint64_t* rng, unsigned site, float p, void* out, float* sum, int swap, int accumulate, float slope,
                                void* stream);
-/* out [n, 256, 256] (bf16): out[z][j][k] = w_z[k][j] for n <= 4 contiguous 256 x 256 bf16 matrices -- the `w_t` operands of vlg_ff_linear_act_backward in one launch. */
-int vlg_ff_transpose256(const void* w0, const void* w1, const void* w2, const void* w3, int n, void* out, void* stream);
+/* The head of the skip-connect encoder's adjoint in one launch (vlg_ff_linear_act_backward at k = 512 with vlg_ff_mlp_act_backward's element-wise pass):
+ * out[row][c] = LeakyReLU'(x[row][c]) * keep * (add[row][c] + bf16(g[row] . w_t[c])), g [rows, 512] bf16, w_t [2, 256, 256] as above, add [rows, 256] fp32
+ * (the skip connections' cotangent), x [rows, 256] the stored MLP outputs; keep = drop_head[row / L] (fp32 [M0 / L, 256], one SharedDropout mask per
+ * sentence) for rows < M0 and drop_small[row - M0] (fp32, one value per row) behind them, either NULL = none (src/model/nn/common.py:47-51). */
+int vlg_ff_linear_mlp_act_backward(const void* g, int ldg, const void* w_t, long long rows, const float* add, const void* x, const float* drop_head,
+                                   const float* drop_small, long long M0, int L, void* out, float slope, void* stream);
+/* out [n, 256, 256] (bf16): out[z][j][k] = w[z][k][j] for the n <= 8 contiguous 256 x 256 bf16 matrices w[0..n-1] (a HOST array of n device
+ * pointers) -- the `w_t` operands of the backward launches above in one launch. */
+int vlg_ff_transpose256(const void* const* w, int n, void* out, void* stream);
 
 /* Score construction feeding the DP -- the tensor half of `DiscriminativeNDMV._forward`, src/model/ldndmv.py:179-209 with the
  * factorised-bilinear scorers of src/model/nn/dmv_spec.py:57-76: from the scorers' projected inputs to the root-merged

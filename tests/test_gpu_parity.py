@@ -3140,8 +3140,7 @@ def test_ff_linear_act_backward(rows, J, swap, acc, keep):
     W = (torch.randn(H, H, generator=g) / 16).to(dev(), bf)                              # the layer's weight [out, in]: d x = g @ W
     act = torch.randn(rows, H, generator=g).to(dev(), bf)
     wT = torch.empty(1, H, H, dtype=bf, device=dev())
-    from vlgae_amd import _C
-    _C.check(_C.lib().vlg_ff_transpose256(_C.ptr(W), None, None, None, 1, _C.ptr(wT), _C.stream_of(W)), "ff_transpose256")
+    parser_ff._transpose256([W], wT)
     assert torch.equal(wT[0], W.t().contiguous())
     mask, rng, p, scale = None, None, 0.0, 1.0
     if keep == "mask":
@@ -3164,6 +3163,70 @@ def test_ff_linear_act_backward(rows, J, swap, acc, keep):
     if swap:
         o = o   # (the permutation moves rows inside a group: the sum is the same)
     assert float((total - ((total0 if acc else 0) + o.sum(1))).abs().max()) <= 1e-5 * max(1.0, float(total.abs().max()))
+
+
+@pytest.mark.parametrize("rows,k", [(333, 512), (4096 + 40, 512), (32 * 300, 32), (77, 32), (1, 512)])
+def test_ff_linear_act_backward_other_contractions(rows, k):
+    """vlg_ff_linear_act_backward at k = 512 (the cotangent of a two-block stage, the weight as two transposed [256,256] blocks) and k = 32 (the
+    folded projections' cotangent, the weight rows as they lie) against the library product (bf16 result) + vlg_ff_act_backward."""
+    from vlgae_amd import parser_ff
+    H = 256
+    g = torch.Generator().manual_seed(rows + k)
+    bf = torch.bfloat16
+    gin = torch.randn(rows, k, generator=g).to(dev(), bf)
+    W = (torch.randn(k, H, generator=g) / k ** 0.5).to(dev(), bf)                         # d x = g @ W, W [k, 256]
+    act = torch.randn(rows, H, generator=g).to(dev(), bf)
+    out = torch.full((rows, H), float("nan"), dtype=bf, device=dev())
+    if k == 512:
+        wT = parser_ff._transpose256([W[:H].contiguous(), W[H:].contiguous()], torch.empty(2, H, H, dtype=bf, device=dev()))
+        assert torch.equal(wT[1], W[H:].t().contiguous())
+        parser_ff._linear_act_bwd(gin, wT, act, out)
+    else:
+        parser_ff._linear_act_bwd(gin, W, act, out, w_kn=True)
+    lin = (gin.double() @ W.double()).to(bf)
+    want = torch.empty_like(out)
+    parser_ff._act_bwd(lin, act, want, rows, 1, H)
+    err = (out.double() - want.double()).abs()
+    assert not torch.isnan(out.float()).any()
+    assert float((err / want.double().abs().clamp_min(1.0)).max()) <= 2.0 ** -6 and float(err.mean()) <= 2e-3
+    assert float((err > 2.0 ** -7 * want.double().abs().clamp_min(0.5)).float().mean()) <= 0.02
+    from vlgae_amd import _C
+    with pytest.raises(RuntimeError):      # the [k][256] layout belongs to k = 32, the blocked one to the others
+        parser_ff._linear_act_bwd(gin, W, act, out, w_kn=(k != 32))
+    if k == 512:
+        with pytest.raises(RuntimeError):  # a plain layer's adjoint only
+            parser_ff._linear_act_bwd(gin, wT, act, out, total=torch.zeros(rows, H, device=dev()))
+
+
+@pytest.mark.parametrize("B,L,Ms,masks", [(7, 13, 14, True), (3, 40, 5, False), (64, 40, 35, True)])
+def test_ff_linear_mlp_act_backward(B, L, Ms, masks):
+    """vlg_ff_linear_mlp_act_backward (the head of the skip-connect encoder's adjoint in one launch) against the library product (bf16 result) +
+    vlg_ff_mlp_act_backward on the same inputs."""
+    from vlgae_amd import _C, parser_ff
+    H, M0 = 256, B * L
+    M = M0 + Ms
+    g = torch.Generator().manual_seed(B + L)
+    bf = torch.bfloat16
+    gY = torch.randn(M, 2 * H, generator=g).to(dev(), bf)
+    W = (torch.randn(2 * H, H, generator=g) / 22).to(dev(), bf)
+    X = torch.randn(M, H, generator=g).to(dev(), bf)
+    gX = torch.randn(M, H, generator=g).to(dev())
+    dh = ((torch.rand(B, H, generator=g) > 0.33).float() / 0.67).to(dev()) if masks else None
+    ds = ((torch.rand(Ms, generator=g) > 0.33).float() / 0.67).to(dev()) if masks else None
+    wT = parser_ff._transpose256([W[:H].contiguous(), W[H:].contiguous()], torch.empty(2, H, H, dtype=bf, device=dev()))
+    out = torch.full((M, H), float("nan"), dtype=bf, device=dev())
+    _C.check(_C.lib().vlg_ff_linear_mlp_act_backward(_C.ptr(gY), gY.stride(0), _C.ptr(wT), M, _C.ptr(gX), _C.ptr(X), _C.ptr(dh), _C.ptr(ds), M0, L,
+                                                     _C.ptr(out), parser_ff.SLOPE, _C.stream_of(out)), "ff_linear_mlp_act_backward")
+    gT = (gY.double() @ W.double()).to(bf)
+    want = torch.empty_like(out)
+    _C.check(_C.lib().vlg_ff_mlp_act_backward(_C.ptr(gX), _C.ptr(gT), _C.ptr(X), _C.ptr(dh), _C.ptr(ds), _C.ptr(want), B, L, Ms, H, _C.BF16,
+                                              parser_ff.SLOPE, _C.stream_of(want)), "ff_mlp_act_backward")
+    assert not torch.isnan(out.float()).any()
+    err = (out.double() - want.double()).abs()
+    assert float((err / want.double().abs().clamp_min(1.0)).max()) <= 2.0 ** -6 and float(err.mean()) <= 3e-3
+    assert float((err > 2.0 ** -7 * want.double().abs().clamp_min(0.5)).float().mean()) <= 0.02
+    if masks:      # masked rows / channels are exact zeros
+        assert float(out[:M0].view(B, L, H)[(dh == 0).unsqueeze(1).expand(B, L, H)].abs().max()) == 0.0
 
 
 def test_parser_feed_forward_fused_layers_equal_library_path(monkeypatch):

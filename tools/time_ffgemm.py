@@ -14,6 +14,11 @@ b, b2 = torch.zeros(H, device=dev, dtype=bf), torch.zeros(2 * H, device=dev, dty
 out, out2 = torch.empty(rows, H, device=dev, dtype=bf), torch.empty(2 * rows, H, device=dev, dtype=bf)
 act = torch.randn(rows, H, generator=g).to(dev, bf)
 tot = torch.zeros(rows // 4, H, device=dev)
+x512 = (torch.randn(rows, 2 * H, generator=g) * 0.5).to(dev, bf)
+x32 = (torch.randn(rows, 32, generator=g) * 0.5).to(dev, bf)
+w32 = (torch.randn(32, H, generator=g) / 6).to(dev, bf)
+w512 = (torch.randn(2, H, H, generator=g) / 22).to(dev, bf)            # the two transposed blocks
+w512_kn = torch.cat([w512[0].t(), w512[1].t()], 0).contiguous()        # [512, 256]
 def t(fn, n=20, reps=10):
     """GPU time per call: n calls captured as one HIP graph (eager launches of this size are host-bound), replayed."""
     for _ in range(3): fn()
@@ -34,11 +39,21 @@ def t(fn, n=20, reps=10):
 def lib():
     y = torch.addmm(b, x, w.t())
     parser_ff._act(y, y, rows, 1, H)
+def lib512():
+    y = x512 @ w512_kn
+    parser_ff._act_bwd(y, act, y, rows, 1, H)
+def lib32():
+    torch.mm(x32, w32, out=out)
+    parser_ff._act_bwd(out, act, out, rows, 1, H)
 mb = rows * H * 2 * 2 / 1e6
 for name, fn, mbytes in (("fused plain", lambda: parser_ff._linear_act(x, w, b, out), mb),
                          ("fused 2 blocks + residual", lambda: parser_ff._linear_act(x, w2, b2, out2, nb=2, residual=x, om=2, oy=1), mb * 1.5 + mb / 2),
                          ("fused backward J=1", lambda: parser_ff._linear_act_bwd(x, w, act, out), mb * 1.5),
                          ("fused backward J=4 swap sum", lambda: parser_ff._linear_act_bwd(x, w, act, out, J=4, total=tot, swap=True), mb * 1.5),
+                         ("fused backward k=512", lambda: parser_ff._linear_act_bwd(x512, w512, act, out), mb * 2),
+                         ("library k=512 + ff_act_bwd", lib512, mb * 2),
+                         ("fused backward k=32", lambda: parser_ff._linear_act_bwd(x32, w32, act, out, w_kn=True), mb * 17 / 16),
+                         ("library k=32 + ff_act_bwd", lib32, mb * 17 / 16),
                          ("library GEMM + ff_act", lib, mb * 2)):
     if len(sys.argv) > 2 and sys.argv[2] not in name: continue
     us = t(fn)

@@ -94,8 +94,9 @@ SIGNATURES = {
     "vlg_ff_root_rule": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "vlg_ff_root_rule_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "vlg_ff_linear_act": (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _i, _i, _i, _vp, _f, _vp, ctypes.c_uint, _f, _vp, _f, _vp]),
-    "vlg_ff_linear_act_backward": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _f, _vp, ctypes.c_uint, _f, _vp, _vp, _i, _i, _f, _vp]),
-    "vlg_ff_transpose256": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "vlg_ff_linear_act_backward": (_i, [_vp, _i, _vp, _i, _i, _ll, _i, _vp, _vp, _f, _vp, ctypes.c_uint, _f, _vp, _vp, _i, _i, _f, _vp]),
+    "vlg_ff_linear_mlp_act_backward": (_i, [_vp, _i, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _i, _vp, _f, _vp]),
+    "vlg_ff_transpose256": (_i, [_vp, _i, _vp, _vp]),
     "vlg_dropout_mask": (_i, [_vp, ctypes.c_uint, _f, _vp, _ll, _vp]),
     "vlg_ff_mlp_act_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "vlg_ndmv_potentials": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
@@ -114,7 +115,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 143   # what include/vlgae_amd.h declares at this revision; lib() refuses any other library (argument lists differ between versions)
+ABI_VERSION = 144   # what include/vlgae_amd.h declares at this revision; lib() refuses any other library (argument lists differ between versions)
 
 
 def lib():

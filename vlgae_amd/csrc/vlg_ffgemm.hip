@@ -14,7 +14,9 @@
 // the skip connection's group sum backward.  Bytes per stage: rows x 256 x 2 in + out (+ the residual / activation rows): the
 // floor of the pair it replaces is twice that.
 //
-// bf16 storage only (fp32 activations keep the library path); H = K = 256 exactly (config/model/vlgae.yaml: the parser's hidden width).
+// bf16 storage only (fp32 activations keep the library path); H = 256 exactly (config/model/vlgae.yaml: the parser's hidden width).  The
+// contraction is K = 256 forward; the backward launches also take K = 512 (the cotangent of a two-block stage: 128 weight VGPRs) and K = 32
+// (the cotangent of the folded projections, 2 r = 32 columns, the weight in its own [k][n] layout).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,13 +34,17 @@ namespace {
 constexpr int kFgH = 256;                 // channels in and out per column block
 constexpr int kFgRows = 32;               // rows per tile
 constexpr int kFgThreads = 512;           // eight wavefronts: 32 output columns each (ONE workgroup per CU: its 128 KB weight block is read once per CU)
-constexpr int kFgXPitch = kFgH * 2 + 32;  // bytes per LDS row of the input tile (136 words = 8 mod 64: the b128 lane groups hit disjoint banks)
-constexpr int kFgLds = 2 * kFgRows * kFgXPitch;   // two input images
+// bytes per LDS row of the input tile of K channels: K = 256 -> 544 (136 words = 8 mod 64), K = 512 -> 1056 (264 = 8 mod 64), K = 32 -> 96 (24 words):
+// in each case the four 16-lane groups of a ds_read_b128 hit disjoint banks
+constexpr int fg_pitch(int K) { return K * 2 + 32; }
+constexpr int fg_lds(int K) { return 2 * kFgRows * fg_pitch(K); }   // two input images
 
 struct FgArgs {
-    const uint16_t* x;      // [rows][ldx] input rows (bf16), the first 256 channels
+    const uint16_t* x;      // [rows][ldx] input rows (bf16), the first K channels
     int ldx;
-    const uint16_t* w;      // [nb * 256][256]: w[n][k], the weight of output channel n (nn.Linear layout; a transposed copy for x @ W)
+    const uint16_t* w;      // [nb * 256][K]: w[n][k], the weight of output channel n (nn.Linear layout; a transposed copy for x @ W; K = 512: two
+                            // [256][256] blocks) -- or, w_kn, [K][256]: w[k][n]
+    int w_kn;
     const uint16_t* bias;   // [nb * 256] or null
     long long rows;
     float slope;
@@ -55,6 +61,12 @@ struct FgArgs {
     const uint64_t* rng;
     uint32_t site, thr;
     uint16_t* out;          // [.][256]
+    // ---- K = 512 backward only: the head of the encoder (as vlg_ff_mlp_act_backward): out = leaky'(act) * keep * (add[row] + acc), keep = drop_head[row / L] for
+    // rows < M0 (one mask per sentence) and drop_small[row - M0] behind them (one value per row); add null: none of it
+    const float* add;       // [rows][256] fp32
+    const float* drop_head; // [M0 / L][256] fp32 or null
+    const float* drop_small;// [rows - M0] fp32 or null
+    int M0, L;
 };
 
 __device__ __forceinline__ int fg_swap2(int j) { return ((j & 1) << 1) | (j >> 1); }
@@ -122,7 +134,9 @@ __device__ __forceinline__ void fg_tile_keep(const FgArgs& a, long long krow0, l
 // c0 + 4 (l >> 4) + n, row l & 15): the element-wise pass runs on the accumulators in registers, with 8-byte loads / stores of the row's
 // other tensors, and nothing goes back through the LDS (the first version wrote the fp32 accumulators to an LDS tile and read them back
 // row-major behind a barrier: eight waves in lock step, ~6 700 cycles per tile for 512 cycles of MFMA).
-__device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char* xs, const bf16x8 (&wf)[8][2], const float (&bias4)[2][4], int tid, int y) {
+template <int KS>
+__device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char* xs, const bf16x8 (&wf)[KS][2], const float (&bias4)[2][4], int tid, int y) {
+    constexpr int kFgXPitch = fg_pitch(KS * 32);
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, kg = lane >> 4;
     f32x4 acc[2][2];
 #pragma unroll
@@ -130,7 +144,7 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         bf16x8 xf[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) xf[rt] = *reinterpret_cast<const bf16x8*>(xs + (rt * 16 + r) * kFgXPitch + (ks * 32 + kg * 8) * 2);
@@ -143,8 +157,9 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
 #endif
     }
     const long long row0 = t * kFgRows;
+    constexpr bool kPlain = KS > 8;     // the K = 512 image: a plain layer's adjoint (no mask, no draw, no group sum: 128 of its 256 registers hold the weights)
     float km[2][2][4];
-    if (a.rng) {       // (uniform) the dropout draws of the tile, indexed by the OUTPUT row forward and by the row backward (as vlg_ff_act*)
+    if (!kPlain && a.rng) {       // (uniform) the dropout draws of the tile, indexed by the OUTPUT row forward and by the row backward (as vlg_ff_act*)
         const long long ra = row0 + r, rb = row0 + 16 + r;
         const long long ka = a.bwd ? ra : (ra >> a.rs) * a.om + (long long)y * a.oy + (ra & ((1 << a.rs) - 1));
         const long long kb = a.bwd ? rb : (rb >> a.rs) * a.om + (long long)y * a.oy + (rb & ((1 << a.rs) - 1));
@@ -158,7 +173,7 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
         for (int nt = 0; nt < 2; ++nt) {
             const int c = wave * 32 + nt * 16 + kg * 4;        // this lane's four channels
             float val[4] = {acc[rt][nt][0], acc[rt][nt][1], acc[rt][nt][2], acc[rt][nt][3]};
-            if (!a.bwd) {
+            if (!kPlain && !a.bwd) {
                 // (the pair this replaces rounds the Linear's output to bf16 before the skip connection is added: the same rounding here, so
                 //  that the two paths agree to the last bit of what the next layer reads wherever the product's own summation order does)
 #pragma unroll
@@ -198,14 +213,28 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                 if (live) {
                     float av[4];
                     load4(a.act + (size_t)row * kFgH + c, av);
-                    if (a.mask) {
+                    if (!kPlain && a.mask) {
                         float t4[4];
                         load4(a.mask + (size_t)row * kFgH + c, t4);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) val[k] *= t4[k] * a.mask_scale;
-                    } else if (a.rng) {
+                    } else if (!kPlain && a.rng) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) val[k] *= km[rt][nt][k];
+                    }
+                    if (kPlain && a.add) {      // (uniform)
+                        const float4 o = *reinterpret_cast<const float4*>(a.add + (size_t)row * kFgH + c);
+                        val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
+                        if (row < a.M0) {
+                            if (a.drop_head) {
+                                const float4 mk = *reinterpret_cast<const float4*>(a.drop_head + (size_t)(row / a.L) * kFgH + c);
+                                val[0] *= mk.x; val[1] *= mk.y; val[2] *= mk.z; val[3] *= mk.w;
+                            }
+                        } else if (a.drop_small) {
+                            const float mk = a.drop_small[row - a.M0];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) val[k] *= mk;
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -214,7 +243,7 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                     }
                     fg_store4(a.out + (size_t)orow * kFgH + c, val);
                 }
-                if (a.sum) {     // (uniform) the J rows of a group sit on J consecutive lanes: the group's sum in row order j = 0, 1, ..
+                if (!kPlain && a.sum) {     // (uniform) the J rows of a group sit on J consecutive lanes: the group's sum in row order j = 0, 1, ..
                     float s[4];
                     if (J == 1) {
 #pragma unroll
@@ -238,7 +267,10 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
     }
 }
 
+template <int KS>   // K = 32 KS input channels
 __global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a) {
+    constexpr int K = KS * 32, kFgXPitch = fg_pitch(K), SEGS = K / 8, SPT = (kFgRows * SEGS + kFgThreads - 1) / kFgThreads;   // 16-byte segments per row / per thread and tile
+    static_assert(SPT >= 1 && SPT <= 4, "segments per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs0 = smem;
     char* const xs1 = smem + kFgRows * kFgXPitch;
@@ -248,32 +280,48 @@ __global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a)
     const long long tiles = (a.rows + kFgRows - 1) / kFgRows, G = gridDim.x;
     long long t = blockIdx.x;
     if (t >= tiles) return;
-    // Input tile staging: thread t moves the 16-byte segments v = t + 512 j (j < 2) of a tile (row v >> 5, segment v & 31) through named
+    // Input tile staging: thread t moves the 16-byte segments v = t + 512 j (j < SPT) of a tile (row v / SEGS, segment v % SEGS) through named
     // registers (as an array, written under a condition and read an epilogue later, the segments were kept in scratch memory).  TWO tiles are in
     // flight -- set A holds the tile after this one, set B the one after that.
-    uint4 xa0, xa1, xb0, xb1;
+    uint4 xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3;
+    xa1 = xa2 = xa3 = xb1 = xb2 = xb3 = make_uint4(0, 0, 0, 0);
+#define FG_V(J_) min(tid + kFgThreads * (J_), kFgRows * SEGS - 1)
 #define FG_SEG_LOAD(T_, J_) \
-    *reinterpret_cast<const uint4*>(a.x + (size_t)min((T_) * kFgRows + ((tid + kFgThreads * (J_)) >> 5), a.rows - 1) * a.ldx + ((tid + kFgThreads * (J_)) & 31) * 8)
+    *reinterpret_cast<const uint4*>(a.x + (size_t)min((T_) * kFgRows + FG_V(J_) / SEGS, a.rows - 1) * a.ldx + (FG_V(J_) % SEGS) * 8)
 #define FG_SEG_STORE(XS_, J_, V_) \
-    *reinterpret_cast<uint4*>((XS_) + ((tid + kFgThreads * (J_)) >> 5) * kFgXPitch + ((tid + kFgThreads * (J_)) & 31) * 16) = (V_)
-#define FG_LOAD_A(T_) { xa0 = FG_SEG_LOAD(T_, 0); xa1 = FG_SEG_LOAD(T_, 1); }
-#define FG_LOAD_B(T_) { xb0 = FG_SEG_LOAD(T_, 0); xb1 = FG_SEG_LOAD(T_, 1); }
-#define FG_STORE_A(XS_) { FG_SEG_STORE(XS_, 0, xa0); FG_SEG_STORE(XS_, 1, xa1); }
-#define FG_STORE_B(XS_) { FG_SEG_STORE(XS_, 0, xb0); FG_SEG_STORE(XS_, 1, xb1); }
+    if (tid + kFgThreads * (J_) < kFgRows * SEGS) *reinterpret_cast<uint4*>((XS_) + (FG_V(J_) / SEGS) * kFgXPitch + (FG_V(J_) % SEGS) * 16) = (V_)
+#define FG_LOAD_A(T_) { xa0 = FG_SEG_LOAD(T_, 0); if (SPT > 1) xa1 = FG_SEG_LOAD(T_, 1); if (SPT > 2) { xa2 = FG_SEG_LOAD(T_, 2); xa3 = FG_SEG_LOAD(T_, 3); } }
+#define FG_LOAD_B(T_) { xb0 = FG_SEG_LOAD(T_, 0); if (SPT > 1) xb1 = FG_SEG_LOAD(T_, 1); if (SPT > 2) { xb2 = FG_SEG_LOAD(T_, 2); xb3 = FG_SEG_LOAD(T_, 3); } }
+#define FG_STORE_A(XS_) { FG_SEG_STORE(XS_, 0, xa0); if (SPT > 1) { FG_SEG_STORE(XS_, 1, xa1); } if (SPT > 2) { FG_SEG_STORE(XS_, 2, xa2); FG_SEG_STORE(XS_, 3, xa3); } }
+#define FG_STORE_B(XS_) { FG_SEG_STORE(XS_, 0, xb0); if (SPT > 1) { FG_SEG_STORE(XS_, 1, xb1); } if (SPT > 2) { FG_SEG_STORE(XS_, 2, xb2); FG_SEG_STORE(XS_, 3, xb3); } }
     FG_LOAD_A(t)
     // ---- the weight block of this workgroup's column block, in registers for the whole launch ----
-    bf16x8 wf[8][2];
-    {
-        const uint16_t* wb = a.w + ((size_t)y * kFgH + wave * 32) * kFgH;
+    bf16x8 wf[KS][2];
+    if (KS > 1 || !a.w_kn) {
+        // (K = 512: two [256][256] blocks one after the other, contraction channels 0..255 | 256..511 -- what vlg_ff_transpose256 writes for the
+        //  two halves of a [512, 256] weight)
+        constexpr int KP = K < kFgH ? K : kFgH;
+        const uint16_t* wb = a.w + ((size_t)y * kFgH + wave * 32) * KP;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #ifndef VLG_FG_NOW         // tools/ ablation: every fragment from the first 16 rows of the block
-                wf[ks][nt] = *reinterpret_cast<const bf16x8*>(wb + (size_t)(nt * 16 + r) * kFgH + ks * 32 + kg * 8);
+                wf[ks][nt] = *reinterpret_cast<const bf16x8*>(wb + (size_t)(ks >> 3) * kFgH * kFgH + (size_t)(nt * 16 + r) * KP + (ks & 7) * 32 + kg * 8);
 #else
-                wf[ks][nt] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)r * kFgH + kg * 8);
+                wf[ks][nt] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)r * KP + kg * 8);
 #endif
+    } else {      // w [K][256] (a short contraction: the eight elements of a fragment are eight rows of w apart)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                typedef short fg_v8 __attribute__((ext_vector_type(8)));
+                fg_v8 v;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (short)a.w[(size_t)(ks * 32 + kg * 8 + i) * kFgH + wave * 32 + nt * 16 + r];
+                wf[ks][nt] = __builtin_bit_cast(bf16x8, v);
+            }
     }
     float bias4[2][4];
 #pragma unroll
@@ -286,12 +334,12 @@ __global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a)
     FG_LOAD_B(t + 2 * G)
     __syncthreads();
     for (;;) {
-        fg_tile(a, t, xs0, wf, bias4, tid, y);                // tile t from image 0
+        fg_tile<KS>(a, t, xs0, wf, bias4, tid, y);            // tile t from image 0
         if (t + G >= tiles) break;
         FG_STORE_A(xs1)                                        // tile t + G -> image 1 (only set A's reads are waited for)
         FG_LOAD_A(t + 3 * G)
         __syncthreads();
-        fg_tile(a, t + G, xs1, wf, bias4, tid, y);            // tile t + G from image 1
+        fg_tile<KS>(a, t + G, xs1, wf, bias4, tid, y);        // tile t + G from image 1
         if (t + 2 * G >= tiles) break;
         FG_STORE_B(xs0)
         FG_LOAD_B(t + 4 * G)
@@ -300,8 +348,8 @@ __global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a)
     }
 }
 
-// out[z][n][k] = w_z[k][n] for up to four 256 x 256 bf16 matrices (the layers' weights as the backward launches read them): 32 x 32 tiles through LDS
-struct FgTr { const uint16_t* w[4]; };
+// out[z][n][k] = w_z[k][n] for up to eight 256 x 256 bf16 matrices (the layers' weights as the backward launches read them): 32 x 32 tiles through LDS
+struct FgTr { const uint16_t* w[8]; };
 __global__ __launch_bounds__(256) void ff_transpose256_kernel(const FgTr a, uint16_t* __restrict__ out) {
     __shared__ uint16_t tile[32][34];
     const uint16_t* w = a.w[blockIdx.z];
@@ -313,6 +361,7 @@ __global__ __launch_bounds__(256) void ff_transpose256_kernel(const FgTr a, uint
     for (int i = 0; i < 4; ++i) out[((size_t)blockIdx.z * kFgH + n0 + ty + 8 * i) * kFgH + k0 + tx] = tile[tx][ty + 8 * i];
 }
 
+#undef FG_V
 #undef FG_SEG_LOAD
 #undef FG_SEG_STORE
 #undef FG_LOAD_A
@@ -320,10 +369,12 @@ __global__ __launch_bounds__(256) void ff_transpose256_kernel(const FgTr a, uint
 #undef FG_STORE_A
 #undef FG_STORE_B
 
-int fg_launch(const FgArgs& a, int nb, hipStream_t s) {
+template <int KS>
+int fg_launch_k(const FgArgs& a, int nb, hipStream_t s) {
     static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_gemm_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kFgLds);
+    constexpr int lds = fg_lds(KS * 32);
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_gemm_act_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -332,13 +383,18 @@ int fg_launch(const FgArgs& a, int nb, hipStream_t s) {
     // workgroups those reads -- 64 MB of 64-byte pieces out of the same 128 KB -- took ~15 us per launch); the tiles are dealt round-robin
     const int per_block = 256 / nb;
     const int gx = (int)std::min<long long>(tiles, per_block);
-    hipLaunchKernelGGL(ff_gemm_act_kernel, dim3(gx, nb), dim3(kFgThreads), kFgLds, s, a);
+    hipLaunchKernelGGL(ff_gemm_act_kernel<KS>, dim3(gx, nb), dim3(kFgThreads), lds, s, a);
     return check_launch("ff_gemm_act_kernel");
 }
 
-int fg_check(const char* what, const void* x, int ldx, const void* w, long long rows, const void* out) {
+int fg_launch(const FgArgs& a, int k, int nb, hipStream_t s) {
+    return k == 32 ? fg_launch_k<1>(a, nb, s) : (k == 512 ? fg_launch_k<16>(a, nb, s) : fg_launch_k<8>(a, nb, s));
+}
+
+int fg_check(const char* what, const void* x, int ldx, int k, const void* w, long long rows, const void* out) {
     if (rows < 0) return set_error(VLG_ERR_SHAPE, "%s: rows=%lld", what, rows);
-    if (ldx < kFgH || ldx % 8) return set_error(VLG_ERR_SHAPE, "%s: input row stride %d (>= 256, a multiple of 8 elements)", what, ldx);
+    if (k != 32 && k != 256 && k != 512) return set_error(VLG_ERR_SHAPE, "%s: %d input channels (32, 256 or 512)", what, k);
+    if (ldx < k || ldx % 8) return set_error(VLG_ERR_SHAPE, "%s: input row stride %d (>= %d, a multiple of 8 elements)", what, ldx, k);
     if (rows > 0 && (!x || !w || !out)) return set_error(VLG_ERR_ARG, "%s: null buffer", what);
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) return set_error(VLG_ERR_ARG, "%s: buffers must be 16-byte aligned", what);
     return 0;
@@ -354,7 +410,7 @@ int vlg_ff_linear_act(const void* x, int ldx, const void* w, const void* bias, l
                       int oy, const void* mask, float mask_scale, const uint64_t* rng, unsigned site, float p, void* out, float slope,
                       void* stream) {
     using namespace vlg;
-    if (int rc = fg_check("ff_linear_act", x, ldx, w, rows, out)) return rc;
+    if (int rc = fg_check("ff_linear_act", x, ldx, 256, w, rows, out)) return rc;
     if (nb < 1 || nb > 2 || rs < 0 || rs > 1 || om < 1 || oy < 0) return set_error(VLG_ERR_ARG, "ff_linear_act: nb=%d rs=%d om=%d oy=%d", nb, rs, om, oy);
     if (mask && rng) return set_error(VLG_ERR_ARG, "ff_linear_act: mask and rng are exclusive");
     if (rows == 0) return 0;
@@ -364,31 +420,52 @@ int vlg_ff_linear_act(const void* x, int ldx, const void* w, const void* bias, l
     a.bwd = 0; a.J = 1;
     a.mask = (const uint16_t*)mask; a.mask_scale = rng ? drop_scale(p) : mask_scale; a.rng = rng; a.site = site; a.thr = rng ? drop_threshold(p) : 0;
     a.out = (uint16_t*)out;
-    return fg_launch(a, nb, (hipStream_t)stream);
+    return fg_launch(a, 256, nb, (hipStream_t)stream);
 }
 
-int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, long long rows, int J, const void* act, const void* mask, float mask_scale,
+int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, int k, int w_kn, long long rows, int J, const void* act, const void* mask, float mask_scale,
                                const uint64_t* rng, unsigned site, float p, void* out, float* sum, int swap, int accumulate, float slope,
                                void* stream) {
     using namespace vlg;
-    if (int rc = fg_check("ff_linear_act_backward", g, ldg, w_t, rows, out)) return rc;
+    if (int rc = fg_check("ff_linear_act_backward", g, ldg, k, w_t, rows, out)) return rc;
+    if ((w_kn != 0) != (k == 32)) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: the [k][256] weight layout (w_kn) is the one of k = 32 and only its");
+    if (k == 512 && (J != 1 || mask || rng || sum)) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: k = 512 is a plain layer's adjoint (J = 1, no mask, draw or sum)");
     if ((J != 1 && J != 2 && J != 4) || rows % J || (swap && J != 4)) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: rows=%lld J=%d swap=%d", rows, J, swap);
     if ((mask || rng) && swap) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: no permutation with a mask");
     if (mask && rng) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: mask and rng are exclusive");
     if (rows > 0 && !act) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: null activation");
     if (rows == 0) return 0;
     FgArgs a{};
-    a.x = (const uint16_t*)g; a.ldx = ldg; a.w = (const uint16_t*)w_t; a.bias = nullptr; a.rows = rows; a.slope = slope;
+    a.x = (const uint16_t*)g; a.ldx = ldg; a.w = (const uint16_t*)w_t; a.w_kn = w_kn; a.bias = nullptr; a.rows = rows; a.slope = slope;
     a.bwd = 1; a.J = J; a.lj = J == 4 ? 2 : (J == 2 ? 1 : 0); a.swap = swap; a.accumulate = accumulate; a.act = (const uint16_t*)act; a.sum = sum;
     a.mask = (const uint16_t*)mask; a.mask_scale = rng ? drop_scale(p) : mask_scale; a.rng = rng; a.site = site; a.thr = rng ? drop_threshold(p) : 0;
     a.out = (uint16_t*)out;
-    return fg_launch(a, 1, (hipStream_t)stream);
+    return fg_launch(a, k, 1, (hipStream_t)stream);
 }
 
-int vlg_ff_transpose256(const void* w0, const void* w1, const void* w2, const void* w3, int n, void* out, void* stream) {
+int vlg_ff_linear_mlp_act_backward(const void* g, int ldg, const void* w_t, long long rows, const float* add, const void* x, const float* drop_head,
+                                   const float* drop_small, long long M0, int L, void* out, float slope, void* stream) {
     using namespace vlg;
-    if (n < 1 || n > 4 || !out || !w0 || (n > 1 && !w1) || (n > 2 && !w2) || (n > 3 && !w3)) return set_error(VLG_ERR_ARG, "ff_transpose256: n=%d or a null buffer", n);
-    FgTr a{{(const uint16_t*)w0, (const uint16_t*)w1, (const uint16_t*)w2, (const uint16_t*)w3}};
+    if (int rc = fg_check("ff_linear_mlp_act_backward", g, ldg, 512, w_t, rows, out)) return rc;
+    if (M0 < 0 || M0 > rows || L < 1 || M0 % L || M0 > 0x7fffffffLL) return set_error(VLG_ERR_SHAPE, "ff_linear_mlp_act_backward: rows=%lld M0=%lld L=%d", rows, M0, L);
+    if (rows > 0 && (!add || !x)) return set_error(VLG_ERR_ARG, "ff_linear_mlp_act_backward: null buffer");
+    if (((uintptr_t)add | (uintptr_t)x | (uintptr_t)drop_head) & 15) return set_error(VLG_ERR_ARG, "ff_linear_mlp_act_backward: buffers must be 16-byte aligned");
+    if (rows == 0) return 0;
+    FgArgs a{};
+    a.x = (const uint16_t*)g; a.ldx = ldg; a.w = (const uint16_t*)w_t; a.rows = rows; a.slope = slope;
+    a.bwd = 1; a.J = 1; a.act = (const uint16_t*)x; a.out = (uint16_t*)out;
+    a.add = add; a.drop_head = drop_head; a.drop_small = drop_small; a.M0 = (int)M0; a.L = L;
+    return fg_launch(a, 512, 1, (hipStream_t)stream);
+}
+
+int vlg_ff_transpose256(const void* const* w, int n, void* out, void* stream) {
+    using namespace vlg;
+    if (n < 1 || n > 8 || !out || !w) return set_error(VLG_ERR_ARG, "ff_transpose256: n=%d (1..8) or a null buffer", n);
+    FgTr a{};
+    for (int z = 0; z < n; ++z) {
+        if (!w[z]) return set_error(VLG_ERR_ARG, "ff_transpose256: matrix %d is null", z);
+        a.w[z] = (const uint16_t*)w[z];
+    }
     hipLaunchKernelGGL(ff_transpose256_kernel, dim3(8, 8, n), dim3(256), 0, (hipStream_t)stream, a, (uint16_t*)out);
     return check_launch("ff_transpose256_kernel");
 }

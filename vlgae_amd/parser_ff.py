@@ -29,6 +29,7 @@ bias-gradient reductions and un-fused bias / residual adds.  Here, with identica
     through their strides) -- the library maps an output of a few hundred rows and columns to one workgroup.
 The reference formulation (tools/train_step.scorer_feed_forward, module by module) is what the tests compare this with.
 """
+import ctypes
 import os
 
 import torch
@@ -134,12 +135,20 @@ def _linear_act(x, w, bias, out, nb=1, residual=None, rs=0, om=1, oy=0, mask=Non
     return out
 
 
-def _linear_act_bwd(g, w_t, act, out, J=1, mask=None, mask_scale=1.0, rng=None, p=0.0, total=None, accumulate=False, swap=False):
+def _linear_act_bwd(g, w_t, act, out, J=1, mask=None, mask_scale=1.0, rng=None, p=0.0, total=None, accumulate=False, swap=False, w_kn=False):
     """out = LeakyReLU'(act) * bf16(g @ W) * keep with W given transposed (w_t = W.T contiguous); total [rows / J, 256] fp32 (+)= the group sums
-    (vlg_ff_linear_act_backward: the input-gradient product of a layer fused with the adjoint of the element-wise pass in front of it)."""
-    _C.check(_C.lib().vlg_ff_linear_act_backward(_C.ptr(g), g.stride(0), _C.ptr(w_t), g.shape[0], J, _C.ptr(act), _C.ptr(mask), float(mask_scale),
+    (vlg_ff_linear_act_backward: the input-gradient product of a layer fused with the adjoint of the element-wise pass in front of it).
+    g [rows, 512]: w_t [2,256,256], the transposes of W's two row blocks; g [rows, 32] with w_kn: w_t is W itself, [32, 256]."""
+    _C.check(_C.lib().vlg_ff_linear_act_backward(_C.ptr(g), g.stride(0), _C.ptr(w_t), g.shape[1], int(w_kn), g.shape[0], J, _C.ptr(act), _C.ptr(mask), float(mask_scale),
                                                  None if rng is None else _C.ptr(rng.state), SITE_MID_FF, float(p), _C.ptr(out), _C.ptr(total),
                                                  int(swap), int(accumulate), SLOPE, _C.stream_of(g)), "ff_linear_act_backward")
+    return out
+
+
+def _transpose256(mats, out):
+    """out[z] = mats[z].T for up to eight contiguous [256,256] bf16 matrices in one launch (vlg_ff_transpose256)."""
+    arr = (ctypes.c_void_p * len(mats))(*(m.data_ptr() for m in mats))
+    _C.check(_C.lib().vlg_ff_transpose256(arr, len(mats), _C.ptr(out), _C.stream_of(out)), "ff_transpose256")
     return out
 
 
@@ -262,8 +271,8 @@ class _ParserFF(torch.autograd.Function):
             _linear_act(A2, W_lr, b_lr, A3, nb=2, residual=X, rs=1, om=4, oy=2)            # direction stage, :46-50: rows (m,val) -> [m,dir,val]
             _linear_act(A3.view(4 * M, H), Wd, bd, A4, mask=mid_mask, mask_scale=mid_scale, rng=mid_rng, p=p_mid)   # + nn.Dropout (:52)
             _linear_act(A4, W1_, b1_, A5)                                                  # output stage, :52-54 (linear2 folded into the projections)
-            wT = torch.empty((3, H, H), dtype=act, device=dev)
-            _C.check(lib.vlg_ff_transpose256(_C.ptr(W1_), _C.ptr(Wd), _C.ptr(Wv), None, 3, _C.ptr(wT), st), "ff_transpose256")
+            # linear1 | direction | valence | the (left, right) blocks | the (no, has) blocks, transposed: what the backward launches read
+            wT = _transpose256([W1_, Wd, Wv, W_lr[:H], W_lr[H:], W_nh[:H], W_nh[H:]], torch.empty((7, H, H), dtype=act, device=dev))
         else:
             # ---- valence stage, nn/dmv_spec.py:41-44 ----
             A1 = torch.addmm(b_nh, X, W_nh.t())                                             # [M,2H] = (no | has) bottleneck outputs
@@ -326,7 +335,13 @@ class _ParserFF(torch.autograd.Function):
                                                gx2.stride(0), _C.ptr(gy2), gy2.stride(0), _C.ptr(g_small), st), "ff_root_rule_backward")
         # ---- folded projections ----
         gA5 = torch.empty_like(A5)
-        torch.mm(g_big, Wp[:2 * r], out=gA5[:4 * M0])
+        wT = ctx.wT          # [7,H,H]: linear1 | direction | valence | left | right | no | has weights transposed (the fused launches' operand) or None
+        # the 2r = 32 columns of the parents' cotangent: product and linear1's LeakyReLU' in one launch (the weight rows are the operand as they lie)
+        fuse5 = wT is not None and 2 * r == 32 and g_big.stride(1) == 1 and g_big.stride(0) % 8 == 0 and g_big.data_ptr() % 16 == 0 and M0 > 0
+        if fuse5:
+            _linear_act_bwd(g_big, Wp[:2 * r], A5[:4 * M0], gA5[:4 * M0], w_kn=True)
+        else:
+            torch.mm(g_big, Wp[:2 * r], out=gA5[:4 * M0])
         # (everything below in the activations' dtype: as fp32 GEMMs on one workgroup each the library takes 30-50 us for these products)
         dWp, dbp = torch.empty((6 * r, H), dtype=act, device=dev), torch.empty((6 * r,), dtype=act, device=dev)
         wg = WgradGroup()      # the seven split-K weight gradients of this pass: their reductions run as ONE launch before the last group
@@ -337,9 +352,12 @@ class _ParserFF(torch.autograd.Function):
         grp.add(_ones(4 * Ms, act, dev).t(), g_small, out=dbp[2 * r:].unsqueeze(0))     # column sums as a product with ones (no reduce launch)
         grp.launch()
         # ---- linear1, direction ----
-        g = _act_bwd(gA5, A5, gA5, 4 * M, 1, H)
+        if fuse5:
+            _act_bwd(gA5[4 * M0:], A5[4 * M0:], gA5[4 * M0:], 4 * Ms, 1, H)                # (the token / root / decision rows: 4 (T + 3))
+            g = gA5
+        else:
+            g = _act_bwd(gA5, A5, gA5, 4 * M, 1, H)
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4, dtype=act, defer=wg)
-        wT = ctx.wT          # [3,H,H]: linear1 | direction | valence weights transposed (the fused launches' operand) or None
         gX = torch.empty((M, H), dtype=torch.float32, device=g.device)                   # the skip connections' cotangent
         gZ = torch.empty((2 * M, 2 * H), dtype=act, device=g.device)                     # [m,val,dir,c]
         if wT is not None:   # the input-gradient product of a layer and the adjoint of the element-wise pass in front of it in ONE launch
@@ -357,8 +375,11 @@ class _ParserFF(torch.autograd.Function):
         dWeff, dbeff = torch.empty((4, H, H), dtype=act, device=g.device), torch.empty((4, H), dtype=act, device=g.device)   # no, has, left, right
         _wgrad(gZ, A2, out=(dWeff[2:4].view(2 * H, H), dbeff[2:4].view(2 * H)), defer=wg)
         # ---- valence ----
-        g = gZ @ W_lr
-        _act_bwd(g, A2, g, 2 * M, 1, H)
+        if wT is not None:
+            g = _linear_act_bwd(gZ, wT[3:5], A2, torch.empty((2 * M, H), dtype=act, device=gZ.device))   # 512 cotangent columns (dir, c)
+        else:
+            g = gZ @ W_lr
+            _act_bwd(g, A2, g, 2 * M, 1, H)
         G["valence.w"], G["valence.b"] = _wgrad(g, A1.view(2 * M, H), dtype=act, defer=wg)
         if wT is not None:
             gY = _linear_act_bwd(g, wT[2], A1, torch.empty_like(g), J=2, total=gX, accumulate=True)
@@ -369,9 +390,13 @@ class _ParserFF(torch.autograd.Function):
         _wgrad(gY, X, out=(dWeff[0:2].view(2 * H, H), dbeff[0:2].view(2 * H)), defer=wg)
         # ---- MLPs: gpre = LeakyReLU'(X) * SharedDropout mask * (gX + gY W_nh) ----
         gpre = torch.empty((M, H), dtype=act, device=g.device)
-        gT = gY @ W_nh
-        _C.check(_C.lib().vlg_ff_mlp_act_backward(_C.ptr(gX), _C.ptr(gT), _C.ptr(X), _C.ptr(ctx.drops[0]), _C.ptr(ctx.drops[1]),
-                                                  _C.ptr(gpre), B, L, Ms, H, _adt(gpre), SLOPE, _C.stream_of(gpre)), "ff_mlp_act_backward")
+        if wT is not None:   # gY W_nh (512 columns (no | has, c)) + the skip connections' sum, the MLPs' LeakyReLU' and SharedDropout masks in one launch
+            _C.check(_C.lib().vlg_ff_linear_mlp_act_backward(_C.ptr(gY), gY.stride(0), _C.ptr(wT[5:7]), M, _C.ptr(gX), _C.ptr(X), _C.ptr(ctx.drops[0]),
+                                                             _C.ptr(ctx.drops[1]), M0, L, _C.ptr(gpre), SLOPE, _C.stream_of(gpre)), "ff_linear_mlp_act_backward")
+        else:
+            gT = gY @ W_nh
+            _C.check(_C.lib().vlg_ff_mlp_act_backward(_C.ptr(gX), _C.ptr(gT), _C.ptr(X), _C.ptr(ctx.drops[0]), _C.ptr(ctx.drops[1]),
+                                                      _C.ptr(gpre), B, L, Ms, H, _adt(gpre), SLOPE, _C.stream_of(gpre)), "ff_mlp_act_backward")
         gb = gpre[:M0]
         dWh = torch.empty((H, E + h), dtype=act, device=dev)                             # head_ff's [H, E + h] gradient: both column blocks written in place
         dbh = torch.empty((H,), dtype=act, device=dev)
