@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "vlg_common.h"
 #include "vlg_mfma.h"
 
@@ -20,7 +22,22 @@ namespace vlg {
 
 namespace {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int kGemmThreads = 256;   // 4 wavefronts, 2 x 2 over the output tile
+// contraction rows per LDS stage and register sets in flight of the two bf16 tile shapes (tools/build_variant_gemm.sh overrides them for A/B timing)
+#ifndef VLG_TN64_STAGE
+#define VLG_TN64_STAGE 128
+#endif
+#ifndef VLG_TN64_SETS
+#define VLG_TN64_SETS 2
+#endif
+#ifndef VLG_TN128_STAGE
+#define VLG_TN128_STAGE 64
+#endif
+#ifndef VLG_TN128_SETS
+#define VLG_TN128_SETS 1
+#endif
 
 // Tile shapes.  TILE = output tile edge (rows of C = columns of A; columns of C = columns of B), KSTAGE = contraction rows per LDS stage.
 //   <64, 128>   round 3: the encoder projections ([B N, 256] x [B N, 128..384]: few output tiles, deep split)
@@ -64,26 +81,36 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const uint16_t
     const int k_begin = s * KC, k_end = min(K, k_begin + KC);
     const int wm = wave & 1, wn = wave >> 1;   // this wave's quadrant
 
-    // global -> register staging: a tile row is kSeg x 16 bytes; 256 threads cover kRP rows per pass, kP passes per stage
+    // global -> register staging: a tile row is kSeg x 16 bytes; 256 threads cover kRP rows per pass, kP passes per stage.  The reads are
+    // BUFFER loads over this split's rows of each operand (descriptor: base = row k_begin, extent = the split's rows): a row past the split's
+    // end or a column past a partial tile's edge is out of range and comes back as zeros -- no branch around any load, so the staging is
+    // straight-line code whose outstanding reads the compiler can COUNT (with a condition around every load each stage waited for vmcnt(0),
+    // i.e. for the set fetched last as well: one stage in flight, not SETS)
     const int c16 = tid % C::kSeg, r0 = tid / C::kSeg;
-    const bool col_a = m0 + c16 * 8 < M, col_b = n0 + c16 * 8 < N;   // columns past a partial tile's edge are staged as zeros
-    const uint16_t* pa = A + (size_t)(k_begin + r0) * lda + m0 + c16 * 8;
-    const uint16_t* pb = B + (size_t)(k_begin + r0) * ldb + n0 + c16 * 8;
-    // two register sets, each one stage (kP x 16 bytes per operand and thread), loaded two stages ahead of their use
-    uint4 ra[SETS][kP], rb[SETS][kP];
+    const bool col_a = m0 + c16 * 8 < M, col_b = n0 + c16 * 8 < N;
+    const int rows = k_end - k_begin;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)k_begin * lda), 0, rows * lda * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)k_begin * ldb), 0, rows * ldb * 2, 0x00020000);
+    constexpr int kOut = 0x40000000;                                   // (a byte offset past any extent: the host bounds rows x ld x 2 below 2^30)
+    const int vo_a = col_a ? (r0 * lda + m0 + c16 * 8) * 2 : kOut, vo_b = col_b ? (r0 * ldb + n0 + c16 * 8) * 2 : kOut;
+    // register sets of one stage each (kP x 16 bytes per operand and thread), loaded SETS stages ahead of their use
+    u32x4 ra[SETS][kP], rb[SETS][kP];
     auto fetch = [&](int set, int ks) {   // rows k_begin + ks + r0 + kRP p
+#ifdef VLG_TN_HOT          // tools/ ablation (results are wrong): every stage re-reads the split's first stage (cache-resident operands)
+        ks = 0;
+#endif
 #pragma unroll
         for (int p = 0; p < kP; ++p) {
-            const bool ok = k_begin + ks + r0 + kRP * p < k_end;
-            ra[set][p] = ok && col_a ? *reinterpret_cast<const uint4*>(pa + (size_t)(ks + kRP * p) * lda) : make_uint4(0, 0, 0, 0);
-            rb[set][p] = ok && col_b ? *reinterpret_cast<const uint4*>(pb + (size_t)(ks + kRP * p) * ldb) : make_uint4(0, 0, 0, 0);
+            ra[set][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, vo_a, (ks + kRP * p) * lda * 2, 0);
+            rb[set][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, vo_b, (ks + kRP * p) * ldb * 2, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);     // (the scheduler sank the reads below the stage's products: issued a stage late)
     };
     auto stash = [&](int set) {
 #pragma unroll
         for (int p = 0; p < kP; ++p) {
-            *reinterpret_cast<uint4*>(sA + (r0 + kRP * p) * kPitch + c16 * 16) = ra[set][p];
-            *reinterpret_cast<uint4*>(sB + (r0 + kRP * p) * kPitch + c16 * 16) = rb[set][p];
+            *reinterpret_cast<u32x4*>(sA + (r0 + kRP * p) * kPitch + c16 * 16) = ra[set][p];
+            *reinterpret_cast<u32x4*>(sB + (r0 + kRP * p) * kPitch + c16 * 16) = rb[set][p];
         }
     };
 
@@ -97,64 +124,96 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const uint16_t
     f32x4 acc[kF][kF] = {};
     f32x4 cs[CS ? kF : 1] = {};
     f32x4 csb[CSB ? kF : 1] = {};
-    const bool want_cs = CS && part_cs != nullptr && nt == 0 && wn == 0;   // wave-uniform
-    const bool want_csb = CSB && part_csb != nullptr && mt == 0 && wm == 0;
+    // the column sums ride on the matrix cores (A^T 1 / 1^T B).  Which workgroups carry them is BLOCK-uniform (the first tile column / row), and the
+    // whole pipeline below is instantiated per case: inside it the extra products are unconditional, so that every stage is one basic block
+    // (a wave-level condition around them cut the stage into pieces the scheduler could not move fragment reads across)
+    const bool blk_cs = CS && part_cs != nullptr && nt == 0, blk_csb = CSB && part_csb != nullptr && mt == 0;
+    const bool want_cs = blk_cs && wn == 0, want_csb = blk_csb && wm == 0;   // (the waves that store them)
     typedef short v8i16 __attribute__((ext_vector_type(8)));
     const bf16x8 ones = __builtin_bit_cast(bf16x8, (v8i16){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
-    auto stage_mma = [&]() {
+    auto pipeline = [&](auto do_cs, auto do_csb) {
+        constexpr bool kCs = decltype(do_cs)::value, kCsb = decltype(do_csb)::value;
+        constexpr int KK = kStage / 32;
+        // one stage: the fragments of contraction step kk + 1 are read while the products of step kk run (two fragment sets)
+        auto stage_mma = [&]() {
+#ifdef VLG_TN_NOMMA        // tools/ ablation (results are wrong): loads, LDS stores and barriers only
+            return;
+#endif
+            bf16x8 fa[2][kF], fb[2][kF];
+            auto read = [&](int kk) {
 #pragma unroll
-        for (int kk = 0; kk < kStage / 32; ++kk) {
-            bf16x8 fa[kF], fb[kF];
+                for (int t = 0; t < kF; ++t) {
+                    fa[kk & 1][t] = tr_frag(tr_read(a_base + kk * 32 * kPitch + t * 32), tr_read(a_base + (kk * 32 + 16) * kPitch + t * 32));
+                    fb[kk & 1][t] = tr_frag(tr_read(b_base + kk * 32 * kPitch + t * 32), tr_read(b_base + (kk * 32 + 16) * kPitch + t * 32));
+                }
+            };
+            read(0);
 #pragma unroll
-            for (int t = 0; t < kF; ++t) {
-                fa[t] = tr_frag(tr_read(a_base + kk * 32 * kPitch + t * 32), tr_read(a_base + (kk * 32 + 16) * kPitch + t * 32));
-                fb[t] = tr_frag(tr_read(b_base + kk * 32 * kPitch + t * 32), tr_read(b_base + (kk * 32 + 16) * kPitch + t * 32));
-            }
+            for (int kk = 0; kk < KK; ++kk) {
+                if (kk + 1 < KK) read(kk + 1);
 #pragma unroll
-            for (int i = 0; i < kF; ++i)
+                for (int i = 0; i < kF; ++i)
 #pragma unroll
-                for (int j = 0; j < kF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            if constexpr (CS) {
-                if (want_cs) {
+                    for (int j = 0; j < kF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
+                if constexpr (kCs) {
 #pragma unroll
-                    for (int i = 0; i < kF; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, cs[i], 0, 0, 0);
+                    for (int i = 0; i < kF; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk & 1][i], ones, cs[i], 0, 0, 0);
+                }
+                if constexpr (kCsb) {   // ones^T B: every row of the result tile is the column sum
+#pragma unroll
+                    for (int j = 0; j < kF; ++j) csb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[kk & 1][j], csb[j], 0, 0, 0);
                 }
             }
-            if constexpr (CSB) {
-                if (want_csb) {   // ones^T B: every row of the result tile is the column sum
-#pragma unroll
-                    for (int j = 0; j < kF; ++j) csb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[j], csb[j], 0, 0, 0);
-                }
+        };
+        fetch(0, 0);
+        if constexpr (SETS == 2) {
+            // two stages per trip and NO exit between them: the trip is one basic block (with a `break` after the first stage the reads of the
+            // set fetched there were sunk into the block behind it -- below the stage's products, a stage late); an odd last stage follows the loop
+            fetch(1, kStage);                  // (past the split's end: zeros)
+            const int n_stages = (rows + kStage - 1) / kStage;
+            int ks = 0;
+            for (int trip = 0; trip < (n_stages >> 1); ++trip, ks += 2 * kStage) {
+                __syncthreads();   // the previous stage's fragment reads are done
+                stash(0);
+                __syncthreads();
+                fetch(0, ks + 2 * kStage);
+                stage_mma();
+                __syncthreads();
+                stash(SETS - 1);
+                __syncthreads();
+                fetch(SETS - 1, ks + 3 * kStage);
+                stage_mma();
+            }
+            if (n_stages & 1) {
+                __syncthreads();
+                stash(0);
+                __syncthreads();
+                stage_mma();
+            }
+        } else {
+            for (int ks = 0; ks < rows; ks += kStage) {
+                __syncthreads();
+                stash(0);
+                __syncthreads();
+                fetch(0, ks + kStage);
+                stage_mma();
             }
         }
     };
-
-    const int rows = k_end - k_begin;
-    fetch(0, 0);
-    if constexpr (SETS == 2) {
-        if (kStage < rows) fetch(1, kStage);
-        for (int ks = 0; ks < rows; ks += 2 * kStage) {
-            __syncthreads();   // the previous stage's fragment reads are done
-            stash(0);
-            __syncthreads();
-            if (ks + 2 * kStage < rows) fetch(0, ks + 2 * kStage);
-            stage_mma();
-            if (ks + kStage >= rows) break;
-            __syncthreads();
-            stash(SETS - 1);
-            __syncthreads();
-            if (ks + 3 * kStage < rows) fetch(SETS - 1, ks + 3 * kStage);
-            stage_mma();
-        }
+    if constexpr (CS && CSB) {
+        if (blk_cs && blk_csb) pipeline(std::true_type{}, std::true_type{});
+        else if (blk_cs) pipeline(std::true_type{}, std::false_type{});
+        else if (blk_csb) pipeline(std::false_type{}, std::true_type{});
+        else pipeline(std::false_type{}, std::false_type{});
+    } else if constexpr (CS) {
+        if (blk_cs) pipeline(std::true_type{}, std::false_type{});
+        else pipeline(std::false_type{}, std::false_type{});
+    } else if constexpr (CSB) {
+        if (blk_csb) pipeline(std::false_type{}, std::true_type{});
+        else pipeline(std::false_type{}, std::false_type{});
     } else {
-        for (int ks = 0; ks < rows; ks += kStage) {
-            __syncthreads();
-            stash(0);
-            __syncthreads();
-            if (ks + kStage < rows) fetch(0, ks + kStage);
-            stage_mma();
-        }
+        pipeline(std::false_type{}, std::false_type{});
     }
 
     // accumulator tile: lane l, register r <-> row 4 (l >> 4) + r, column l & 15
@@ -166,7 +225,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const uint16_t
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * kQ + i * 16 + 4 * g + r, col = n0 + wn * kQ + j * 16 + (lane & 15);
+#ifdef VLG_TN_NOSTORE      // tools/ ablation (results are wrong): no partial tiles
+                if (row < M && col < N && acc[i][j][r] == 123.456f) out[(size_t)row * N + col] = acc[i][j][r];
+#else
                 if (row < M && col < N) out[(size_t)row * N + col] = acc[i][j][r];
+#endif
             }
     if (CS && want_cs && (lane & 15) == 0) {
 #pragma unroll
@@ -646,9 +709,12 @@ struct TnPlan {
 inline bool tn_big(int M, int N) { return M >= 128 && N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) >= 8 && !VLG_ENV("VLG_WGRAD_TILE64"); }
 
 TnPlan plan_tn(int K, int M, int N, bool big, bool f32 = false) {   // (float32 operands: half the stage depth -- four LDS images instead of two)
-    const int kTile = big ? 128 : 64, kStage = (big ? 64 : 128) >> (f32 ? 1 : 0);
+    const int kTile = big ? 128 : 64, kStage = f32 ? (big ? 32 : 64) : (big ? VLG_TN128_STAGE : VLG_TN64_STAGE);
     const int tiles = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
-    int S = (512 + tiles - 1) / tiles;                              // ~2 workgroups per CU (swept 256 ... 1024 for both tile shapes: 512)
+#ifndef VLG_TN_WGS
+#define VLG_TN_WGS 512
+#endif
+    int S = (VLG_TN_WGS + tiles - 1) / tiles;                       // ~2 workgroups per CU (swept 256 ... 1024 for both tile shapes: 512)
     const int max_s = (K + 2 * kStage - 1) / (2 * kStage);          // at least two stages per split: both register sets in flight from the start
     S = S < 1 ? 1 : (S > max_s ? max_s : S);
     int KC = ((K + S - 1) / S + kStage - 1) / kStage * kStage;      // whole stages per split
@@ -755,10 +821,10 @@ static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int 
         else if (d_bias) VLG_TN3(128, 32, true, false);
         else if (x_colsum) VLG_TN3(128, 32, false, true);
         else VLG_TN3(128, 32, false, false);
-    } else if (!big) VLG_TN(64, 128, 2, true, true);
-    else if (d_bias) VLG_TN(128, 64, 1, true, false);
-    else if (x_colsum) VLG_TN(128, 64, 1, false, true);
-    else VLG_TN(128, 64, 1, false, false);
+    } else if (!big) VLG_TN(64, VLG_TN64_STAGE, VLG_TN64_SETS, true, true);
+    else if (d_bias) VLG_TN(128, VLG_TN128_STAGE, VLG_TN128_SETS, true, false);
+    else if (x_colsum) VLG_TN(128, VLG_TN128_STAGE, VLG_TN128_SETS, false, true);
+    else VLG_TN(128, VLG_TN128_STAGE, VLG_TN128_SETS, false, false);
 #undef VLG_TN
 #undef VLG_TN3
     if (int rc = check_launch("gemm_tn_kernel")) return rc;
