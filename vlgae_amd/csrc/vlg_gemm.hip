@@ -38,6 +38,12 @@ constexpr int kGemmThreads = 256;   // 4 wavefronts, 2 x 2 over the output tile
 #ifndef VLG_TN128_SETS
 #define VLG_TN128_SETS 1
 #endif
+#ifndef VLG_TN_WGS
+#define VLG_TN_WGS 256      // workgroups a product is split into (tiles x row splits)
+#endif
+#ifndef VLG_TN_BIG_MIN
+#define VLG_TN_BIG_MIN 8    // 128-tiles an output must have to take the 128-tile kernel
+#endif
 
 // Tile shapes.  TILE = output tile edge (rows of C = columns of A; columns of C = columns of B), KSTAGE = contraction rows per LDS stage.
 //   <64, 128>   round 3: the encoder projections ([B N, 256] x [B N, 128..384]: few output tiles, deep split)
@@ -706,15 +712,15 @@ struct TnPlan {
 // the tile shape of a product: the 128-tile once both output dimensions fill one (VLG_WGRAD_TILE64 forces the round-3 kernel: A/B timing)
 // (with both column sums wanted: see wgrad_launch).  Below ~8 tiles of 128 the split count that fills the chip makes the partial tiles -- S x M x N
 // floats written and read back -- cost more than the 64-tile's extra operand traffic: [4 B L, 256]^T [4 B L, 256] measured 23.0 vs 21.8 us.
-inline bool tn_big(int M, int N) { return M >= 128 && N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) >= 8 && !VLG_ENV("VLG_WGRAD_TILE64"); }
+inline bool tn_big(int M, int N) { return M >= 128 && N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) >= VLG_TN_BIG_MIN && !VLG_ENV("VLG_WGRAD_TILE64"); }
 
 TnPlan plan_tn(int K, int M, int N, bool big, bool f32 = false) {   // (float32 operands: half the stage depth -- four LDS images instead of two)
     const int kTile = big ? 128 : 64, kStage = f32 ? (big ? 32 : 64) : (big ? VLG_TN128_STAGE : VLG_TN64_STAGE);
     const int tiles = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
-#ifndef VLG_TN_WGS
-#define VLG_TN_WGS 512
-#endif
-    int S = (VLG_TN_WGS + tiles - 1) / tiles;                       // ~2 workgroups per CU (swept 256 ... 1024 for both tile shapes: 512)
+    // ~1 workgroup per CU.  (Rounds 3-5 ran 512: with a condition around every staged load only one stage was in flight and the second resident
+    // workgroup hid the latency.  With counted waits 256 workgroups stream as fast and the partial tiles -- S x M x N floats written, then read
+    // by the reduction -- halve: the training step 1.808 -> 1.797 ms; 320 / 384 were slower than either.)
+    int S = (VLG_TN_WGS + tiles - 1) / tiles;
     const int max_s = (K + 2 * kStage - 1) / (2 * kStage);          // at least two stages per split: both register sets in flight from the start
     S = S < 1 ? 1 : (S > max_s ? max_s : S);
     int KC = ((K + S - 1) / S + kStage - 1) / kStage * kStage;      // whole stages per split
