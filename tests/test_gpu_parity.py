@@ -3198,6 +3198,37 @@ def test_ff_linear_act_backward_other_contractions(rows, k):
             parser_ff._linear_act_bwd(gin, wT, act, out, total=torch.zeros(rows, H, device=dev()))
 
 
+@pytest.mark.parametrize("rows,n,ldw,ldo", [(2048, 800, 864, 800), (10240, 800, 800, 800), (2055, 256, 256, 320), (4100, 40, 48, 40), (3000, 1032, 1032, 1036)])
+def test_ff_linear_kn(rows, n, ldw, ldo):
+    """vlg_ff_linear_kn (a 256-output Linear's input gradient g @ weight as one row-streaming launch, the weight read where it lies) against
+    the float64 product of the same bf16 operands; column slices of wider weights, padded outputs, ragged last column block and row tile."""
+    from vlgae_amd import align
+    g = torch.Generator().manual_seed(rows + n)
+    bf = torch.bfloat16
+    x = torch.randn(rows, 256, generator=g).to(dev(), bf)
+    wide = (torch.randn(256, ldw, generator=g) / 16).to(dev(), bf)
+    w = wide[:, ldw - n:]                                                                # a column slice (2-byte aligned only)
+    out_wide = torch.full((rows, ldo), float("nan"), dtype=bf, device=dev())
+    out = out_wide[:, :n]
+    assert align.linear_kn_ok(x, w)
+    align.linear_kn(x, w, out=out)
+    want = x.double() @ w.double()
+    assert not torch.isnan(out.float()).any()
+    err = (out.double() - want).abs()
+    assert float((err / want.abs().clamp_min(1.0)).max()) <= 2.0 ** -7, float((err / want.abs().clamp_min(1.0)).max())
+    if ldo > n:
+        assert bool(torch.isnan(out_wide[:, n:].float()).all())                            # nothing written past the valid columns
+    assert torch.equal(out, align.linear_kn(x, w))                                        # reproducible
+    # through autograd: the input gradient of align.linear with 256 outputs is this launch
+    xin = torch.randn(rows, n, generator=g).to(dev(), bf).requires_grad_(True)
+    weight = w.detach().contiguous().requires_grad_(True)                                # [256, n]
+    y = align.linear(xin, weight)
+    cot = x
+    gx, gw = torch.autograd.grad(y, [xin, weight], cot)
+    assert torch.equal(gx, align.linear_kn(cot, weight.detach()))
+    assert float((gw.double() - cot.double().t() @ xin.detach().double()).abs().max()) <= 2e-2 * float(gw.abs().max())
+
+
 @pytest.mark.parametrize("B,L,Ms,masks", [(7, 13, 14, True), (3, 40, 5, False), (64, 40, 35, True)])
 def test_ff_linear_mlp_act_backward(B, L, Ms, masks):
     """vlg_ff_linear_mlp_act_backward (the head of the skip-connect encoder's adjoint in one launch) against the library product (bf16 result) +

@@ -42,6 +42,11 @@ def lib():
 def lib512():
     y = x512 @ w512_kn
     parser_ff._act_bwd(y, act, y, rows, 1, H)
+from vlgae_amd import align
+wkn = (torch.randn(H, 800, generator=g) / 16).to(dev, bf)
+out800 = torch.empty(rows, 800, device=dev, dtype=bf)
+def lib_kn():
+    torch.mm(x, wkn, out=out800)
 def lib32():
     torch.mm(x32, w32, out=out)
     parser_ff._act_bwd(out, act, out, rows, 1, H)
@@ -54,6 +59,8 @@ for name, fn, mbytes in (("fused plain", lambda: parser_ff._linear_act(x, w, b, 
                          ("library k=512 + ff_act_bwd", lib512, mb * 2),
                          ("fused backward k=32", lambda: parser_ff._linear_act_bwd(x32, w32, act, out, w_kn=True), mb * 17 / 16),
                          ("library k=32 + ff_act_bwd", lib32, mb * 17 / 16),
+                         ("linear_kn 256 -> 800 k=256", lambda: align.linear_kn(x, wkn, out=out800), rows * (256 + 800) * 2 / 1e6),
+                         ("library 256 -> 800 k=256", lib_kn, rows * (256 + 800) * 2 / 1e6),
                          ("library GEMM + ff_act", lib, mb * 2)):
     if len(sys.argv) > 2 and sys.argv[2] not in name: continue
     us = t(fn)

@@ -749,9 +749,30 @@ def _wgrad_ok(K, M, N, dtype):
     return dtype in (torch.bfloat16, torch.float32) and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8 and K >= 2048
 
 
+_KN_LIBRARY = bool(os.environ.get("VLGAE_FF_LIBRARY"))   # opt-out, as parser_ff's
+
+
+def linear_kn(x, w, out=None):
+    """x [rows, 256] @ w [256, n] -> [rows, n] (bf16): the input gradient of a Linear with 256 outputs (g @ weight) as ONE row-streaming launch
+    with the weight block in registers (vlg_ff_linear_kn); w may be a column slice of a wider matrix.  The library ran these
+    [10^4, 256] x [256, 800] products on 200 workgroups at ~0.8 TB/s of their own bytes (27 us where the bytes take ~8)."""
+    rows, n = x.shape[0], w.shape[1]
+    if out is None:
+        out = torch.empty((rows, n), dtype=x.dtype, device=x.device)
+    _C.check(_C.lib().vlg_ff_linear_kn(_C.ptr(x), x.stride(0), _C.ptr(w), w.stride(0), rows, n, _C.ptr(out), out.stride(0), _C.stream_of(x)), "ff_linear_kn")
+    return out
+
+
+def linear_kn_ok(x, w):
+    """Whether `x @ w` can take vlg_ff_linear_kn: bf16, 256 contraction channels, enough rows to fill the chip, strides it reads in place."""
+    return (not _KN_LIBRARY and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2 and x.shape[1] == 256
+            and w.shape[0] == 256 and x.shape[0] >= 2048 and w.shape[1] % 8 == 0 and w.shape[1] >= 8 and x.stride(1) == 1 and w.stride(1) == 1
+            and x.stride(0) % 8 == 0 and x.stride(0) >= 256 and x.data_ptr() % 16 == 0)
+
+
 class _Linear(torch.autograd.Function):
     """x @ weight.T + bias with the tall-skinny weight gradient on the split-K kernel; forward and the input gradient are
-    plain library GEMMs (they have ~10^4 output rows and fill the chip)."""
+    library GEMMs, except the input gradient of a 256-output layer in bf16 (linear_kn)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -765,7 +786,10 @@ class _Linear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
-        dx = (g2 @ weight).reshape(x.shape) if need_x else None
+        if need_x and linear_kn_ok(g2, weight):
+            dx = linear_kn(g2, weight).reshape(x.shape)
+        else:
+            dx = (g2 @ weight).reshape(x.shape) if need_x else None
         dw = db = None
         if need_w or need_b:
             if g2.dtype == x2.dtype and _wgrad_ok(x2.shape[0], g2.shape[1], x2.shape[1], g2.dtype):

@@ -45,6 +45,8 @@ struct FgArgs {
     const uint16_t* w;      // [nb * 256][K]: w[n][k], the weight of output channel n (nn.Linear layout; a transposed copy for x @ W; K = 512: two
                             // [256][256] blocks) -- or, w_kn, [K][256]: w[k][n]
     int w_kn;
+    int ldw, ncols;         // w_kn: elements between the rows of w, and its valid columns (columns past them read as zeros)
+    int plain, ldo;         // plain: out[row][256 y + c] = bf16(acc + bias), rows ldo elements apart, columns < ncols only (no element-wise pass)
     const uint16_t* bias;   // [nb * 256] or null
     long long rows;
     float slope;
@@ -178,6 +180,10 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                 //  that the two paths agree to the last bit of what the next layer reads wherever the product's own summation order does)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) val[k] = fg_round(val[k] + bias4[nt][k]);
+                if (a.plain) {        // (uniform) the product alone
+                    if (live && y * kFgH + c < a.ncols) fg_store4(a.out + (size_t)row * a.ldo + y * kFgH + c, val);
+                    continue;
+                }
                 const long long m = row >> a.rs;
                 const long long orow = m * a.om + (long long)y * a.oy + (row & ((1 << a.rs) - 1));
                 if (live) {
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a)
     FG_LOAD_A(t)
     // ---- the weight block of this workgroup's column block, in registers for the whole launch ----
     bf16x8 wf[KS][2];
-    if (KS > 1 || !a.w_kn) {
+    if (KS > 8 || !a.w_kn) {
         // (K = 512: two [256][256] blocks one after the other, contraction channels 0..255 | 256..511 -- what vlg_ff_transpose256 writes for the
         //  two halves of a [512, 256] weight)
         constexpr int KP = K < kFgH ? K : kFgH;
@@ -311,17 +317,21 @@ __global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a)
 #else
                 wf[ks][nt] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)r * KP + kg * 8);
 #endif
-    } else {      // w [K][256] (a short contraction: the eight elements of a fragment are eight rows of w apart)
+    } else {      // w [K][ldw], w[k][n] (the eight elements of a fragment are eight rows of w apart: 2-byte reads, once per launch)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = y * kFgH + wave * 32 + nt * 16 + r;
+            const bool ok = n < a.ncols;
+            const uint16_t* wc = a.w + (ok ? n : 0);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int ks = 0; ks < KS; ++ks) {
                 typedef short fg_v8 __attribute__((ext_vector_type(8)));
                 fg_v8 v;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = (short)a.w[(size_t)(ks * 32 + kg * 8 + i) * kFgH + wave * 32 + nt * 16 + r];
+                for (int i = 0; i < 8; ++i) v[i] = ok ? (short)wc[(size_t)(ks * 32 + kg * 8 + i) * a.ldw] : (short)0;
                 wf[ks][nt] = __builtin_bit_cast(bf16x8, v);
             }
+        }
     }
     float bias4[2][4];
 #pragma unroll
@@ -381,7 +391,7 @@ int fg_launch_k(const FgArgs& a, int nb, hipStream_t s) {
     const long long tiles = (a.rows + kFgRows - 1) / kFgRows;
     // ONE workgroup per CU holds its weight block for the whole launch (the block is re-read from the L2 by every workgroup: with 512
     // workgroups those reads -- 64 MB of 64-byte pieces out of the same 128 KB -- took ~15 us per launch); the tiles are dealt round-robin
-    const int per_block = 256 / nb;
+    const int per_block = std::max(1, 256 / nb);
     const int gx = (int)std::min<long long>(tiles, per_block);
     hipLaunchKernelGGL(ff_gemm_act_kernel<KS>, dim3(gx, nb), dim3(kFgThreads), lds, s, a);
     return check_launch("ff_gemm_act_kernel");
@@ -436,11 +446,23 @@ int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, int k, i
     if (rows > 0 && !act) return set_error(VLG_ERR_ARG, "ff_linear_act_backward: null activation");
     if (rows == 0) return 0;
     FgArgs a{};
-    a.x = (const uint16_t*)g; a.ldx = ldg; a.w = (const uint16_t*)w_t; a.w_kn = w_kn; a.bias = nullptr; a.rows = rows; a.slope = slope;
+    a.x = (const uint16_t*)g; a.ldx = ldg; a.w = (const uint16_t*)w_t; a.w_kn = w_kn; a.ldw = kFgH; a.ncols = kFgH; a.bias = nullptr; a.rows = rows; a.slope = slope;
     a.bwd = 1; a.J = J; a.lj = J == 4 ? 2 : (J == 2 ? 1 : 0); a.swap = swap; a.accumulate = accumulate; a.act = (const uint16_t*)act; a.sum = sum;
     a.mask = (const uint16_t*)mask; a.mask_scale = rng ? drop_scale(p) : mask_scale; a.rng = rng; a.site = site; a.thr = rng ? drop_threshold(p) : 0;
     a.out = (uint16_t*)out;
     return fg_launch(a, k, 1, (hipStream_t)stream);
+}
+
+int vlg_ff_linear_kn(const void* x, int ldx, const void* w, int ldw, long long rows, int ncols, void* out, int ldo, void* stream) {
+    using namespace vlg;
+    if (int rc = fg_check("ff_linear_kn", x, ldx, 256, w, rows, out)) return rc;
+    if (ncols < 8 || ncols % 8 || ldw < ncols || ldo < ncols || ldo % 4 || ncols > 64 * kFgH)
+        return set_error(VLG_ERR_SHAPE, "ff_linear_kn: ncols=%d (a multiple of 8, <= 16384) ldw=%d ldo=%d (>= ncols, ldo a multiple of 4)", ncols, ldw, ldo);
+    if (rows == 0) return 0;
+    FgArgs a{};
+    a.x = (const uint16_t*)x; a.ldx = ldx; a.w = (const uint16_t*)w; a.w_kn = 1; a.ldw = ldw; a.ncols = ncols; a.plain = 1; a.ldo = ldo;
+    a.rows = rows; a.J = 1; a.out = (uint16_t*)out;
+    return fg_launch(a, 256, (ncols + kFgH - 1) / kFgH, (hipStream_t)stream);
 }
 
 int vlg_ff_linear_mlp_act_backward(const void* g, int ldg, const void* w_t, long long rows, const float* add, const void* x, const float* drop_head,

@@ -36,7 +36,7 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _C
-from .align import SmallMatmulGroup, WgradGroup, _wgrad_ok, linear_wgrad, small_matmul
+from .align import SmallMatmulGroup, WgradGroup, _wgrad_ok, linear_kn, linear_kn_ok, linear_wgrad, small_matmul
 
 SLOPE = 0.01   # nn.LeakyReLU() default (nn/common.py:31, nn/dmv_spec.py:10)
 SITE_MID_FF = 2   # the dropout layer id of mid_ff's nn.Dropout in the step's shared counter-based generator (encoders.SITE_MID_FF)
@@ -402,7 +402,7 @@ class _ParserFF(torch.autograd.Function):
         dbh = torch.empty((H,), dtype=act, device=dev)
         _wgrad(gb, emb2, out=(dWh[:, :E], dbh), defer=wg)                                # [H,E], [H]
         wg.flush()
-        g_emb = gb @ We                                                                  # [M0,E]
+        g_emb = linear_kn(gb, We) if wT is not None and linear_kn_ok(gb, We) else gb @ We   # [M0,E]
         gc = gb.view(B, L, H).sum(1)                                                     # [B,H] (fp32 accumulation inside the reduction)
         # ---- the remaining products in weight space, ONE grouped launch: the context columns, the token / root / decision MLPs (weight, bias
         # as a product with ones, input gradients), the unfolding of the bottleneck pairs Weff = W1 W0, beff = W1 b0 + b1 ----
