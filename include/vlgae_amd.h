@@ -470,8 +470,10 @@ int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, int k, i
 /* out[rows, ncols] (bf16, rows ldo elements apart) = bf16(x[rows, 256] @ w[256, ncols]): a Linear's INPUT gradient (g @ weight, weight [256, in] as nn.Linear
  * stores it) or any product of token rows with a weight whose contraction index is its slow one, as one row-streaming launch: the weight is read
  * where it lies (rows ldw elements apart: a column slice of a wider matrix is fine), 256 output columns per workgroup column block.  ncols a multiple
- * of 8, ldo of 4; x / out 16-byte aligned.  (MLP.linear / MLPEncoder.linear under loss.backward(): src/model/nn/common.py:30, text_encoder/mlp_encoder.py:36-40.) */
-int vlg_ff_linear_kn(const void* x, int ldx, const void* w, int ldw, long long rows, int ncols, void* out, int ldo, void* stream);
+ * of 8, ldo of 4; x / out 16-byte aligned.  rng (or NULL): the result times the counter-based keep-mask of (site, p) drawn over out's [rows, ncols]
+ * element index exactly as vlg_dropout draws it -- the adjoint of Linear(Dropout(x)) in one launch.  (MLP.linear / MLPEncoder.linear under loss.backward(): src/model/nn/common.py:30, text_encoder/mlp_encoder.py:36-40.) */
+int vlg_ff_linear_kn(const void* x, int ldx, const void* w, int ldw, long long rows, int ncols, const uint64_t* rng, unsigned site, float p, void* out, int ldo,
+                     void* stream);
 /* The head of the skip-connect encoder's adjoint in one launch (vlg_ff_linear_act_backward at k = 512 with vlg_ff_mlp_act_backward's element-wise pass):
  * out[row][c] = LeakyReLU'(x[row][c]) * keep * (add[row][c] + bf16(g[row] . w_t[c])), g [rows, 512] bf16, w_t [2, 256, 256] as above, add [rows, 256] fp32
  * (the skip connections' cotangent), x [rows, 256] the stored MLP outputs; keep = drop_head[row / L] (fp32 [M0 / L, 256], one SharedDropout mask per

@@ -3219,6 +3219,13 @@ def test_ff_linear_kn(rows, n, ldw, ldo):
     if ldo > n:
         assert bool(torch.isnan(out_wide[:, n:].float()).all())                            # nothing written past the valid columns
     assert torch.equal(out, align.linear_kn(x, w))                                        # reproducible
+    # with the counter-based draw in the epilogue: the same bits as the product followed by encoders.dropout at the same (state, site, p)
+    from vlgae_amd import encoders
+    rng = encoders.DeviceRng(11, dev())
+    drawn = align.linear_kn(x, w, rng=rng, site=encoders.SITE_TEXT_ENCODER, p=0.33)
+    ref = encoders.dropout(align.linear_kn(x, w), 0.33, rng=rng, site=encoders.SITE_TEXT_ENCODER)
+    assert 0.6 < float((drawn != 0).float().mean()) < 0.75
+    assert torch.equal(drawn, ref)
     # through autograd: the input gradient of align.linear with 256 outputs is this launch
     xin = torch.randn(rows, n, generator=g).to(dev(), bf).requires_grad_(True)
     weight = w.detach().contiguous().requires_grad_(True)                                # [256, n]
@@ -3227,6 +3234,31 @@ def test_ff_linear_kn(rows, n, ldw, ldo):
     gx, gw = torch.autograd.grad(y, [xin, weight], cot)
     assert torch.equal(gx, align.linear_kn(cot, weight.detach()))
     assert float((gw.double() - cot.double().t() @ xin.detach().double()).abs().max()) <= 2e-2 * float(gw.abs().max())
+
+
+def test_mlp_encoder_fused_adjoint_equals_unfused(monkeypatch):
+    """encoders.mlp_encoder with the counter-based draw at a row count that takes the fused adjoint (_DropoutLinear: (g @ W) * keep in one launch)
+    against the same call on the dropout + linear Functions: identical output, identical d_emb bits, d_W equal (same split-K product)."""
+    from vlgae_amd import align, encoders
+    B, L, E, h, p = 64, 40, 800, 256, 0.33
+    g = torch.Generator().manual_seed(9)
+    bf = torch.bfloat16
+    emb = (torch.randn(B, L, E, generator=g) * 0.5).to(dev(), bf).requires_grad_(True)
+    W = (torch.randn(h, E, generator=g) * E ** -0.5).to(dev(), bf).requires_grad_(True)
+    cot = torch.randn(B, L, h, generator=g).to(dev(), bf)
+    runs = []
+    for library in (False, True):
+        monkeypatch.setattr(align, "_KN_LIBRARY", library)
+        rng = encoders.DeviceRng(77, dev())
+        x = encoders.mlp_encoder(emb, W, p, rng=rng)
+        assert (type(x.grad_fn).__name__.startswith("_DropoutLinear")) == (not library)
+        runs.append((x.detach(), *torch.autograd.grad(x, [emb, W], cot)))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][2], runs[1][2])
+    # d_emb: the fused launch rounds the product to bf16 once and multiplies by the keep value; the unfused path does the same in two launches
+    a, b = runs[0][1].double(), runs[1][1].double()
+    assert torch.equal(a == 0, b == 0)
+    assert float((a - b).abs().max()) <= 2.0 ** -7 * max(1.0, float(b.abs().max()))
 
 
 @pytest.mark.parametrize("B,L,Ms,masks", [(7, 13, 14, True), (3, 40, 5, False), (64, 40, 35, True)])

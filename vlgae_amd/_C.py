@@ -95,7 +95,7 @@ SIGNATURES = {
     "vlg_ff_root_rule_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "vlg_ff_linear_act": (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _i, _i, _i, _vp, _f, _vp, ctypes.c_uint, _f, _vp, _f, _vp]),
     "vlg_ff_linear_act_backward": (_i, [_vp, _i, _vp, _i, _i, _ll, _i, _vp, _vp, _f, _vp, ctypes.c_uint, _f, _vp, _vp, _i, _i, _f, _vp]),
-    "vlg_ff_linear_kn": (_i, [_vp, _i, _vp, _i, _ll, _i, _vp, _i, _vp]),
+    "vlg_ff_linear_kn": (_i, [_vp, _i, _vp, _i, _ll, _i, _vp, ctypes.c_uint, _f, _vp, _i, _vp]),
     "vlg_ff_linear_mlp_act_backward": (_i, [_vp, _i, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _i, _vp, _f, _vp]),
     "vlg_ff_transpose256": (_i, [_vp, _i, _vp, _vp]),
     "vlg_dropout_mask": (_i, [_vp, ctypes.c_uint, _f, _vp, _ll, _vp]),

@@ -752,14 +752,17 @@ def _wgrad_ok(K, M, N, dtype):
 _KN_LIBRARY = bool(os.environ.get("VLGAE_FF_LIBRARY"))   # opt-out, as parser_ff's
 
 
-def linear_kn(x, w, out=None):
+def linear_kn(x, w, out=None, rng=None, site=0, p=0.0):
     """x [rows, 256] @ w [256, n] -> [rows, n] (bf16): the input gradient of a Linear with 256 outputs (g @ weight) as ONE row-streaming launch
     with the weight block in registers (vlg_ff_linear_kn); w may be a column slice of a wider matrix.  The library ran these
-    [10^4, 256] x [256, 800] products on 200 workgroups at ~0.8 TB/s of their own bytes (27 us where the bytes take ~8)."""
+    [10^4, 256] x [256, 800] products on 200 workgroups at ~0.8 TB/s of their own bytes (27 us where the bytes take ~8).
+    rng (an encoders.DeviceRng) with (site, p): the result times the keep-mask `encoders.dropout(..., rng=rng, site=site)` draws over [rows, n] --
+    the adjoint of Linear(Dropout(x)) in one launch."""
     rows, n = x.shape[0], w.shape[1]
     if out is None:
         out = torch.empty((rows, n), dtype=x.dtype, device=x.device)
-    _C.check(_C.lib().vlg_ff_linear_kn(_C.ptr(x), x.stride(0), _C.ptr(w), w.stride(0), rows, n, _C.ptr(out), out.stride(0), _C.stream_of(x)), "ff_linear_kn")
+    _C.check(_C.lib().vlg_ff_linear_kn(_C.ptr(x), x.stride(0), _C.ptr(w), w.stride(0), rows, n, None if rng is None else _C.ptr(rng.state), int(site), float(p),
+                                       _C.ptr(out), out.stride(0), _C.stream_of(x)), "ff_linear_kn")
     return out
 
 

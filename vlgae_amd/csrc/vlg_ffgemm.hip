@@ -106,12 +106,12 @@ __device__ __forceinline__ float fg_group_sum(float v, int J) {
 // The counter-based keep flags of a tile for this lane: km[rt][nt][k] for its four channels of the 8-channel groups (orow(rt), c >> 3).  The lane
 // 16 further on holds the other half of the same groups: of the two, the one with even kg draws the groups of row tile 0 and the other those of
 // row tile 1 (one Philox call per group and lane pair, as vlg_ff_act makes one per group), and they exchange the halves they owe each other.
-__device__ __forceinline__ void fg_tile_keep(const FgArgs& a, long long krow0, long long krow1, int wave, int kg, float (&km)[2][2][4]) {
-    const int hv = kFgH >> 3, mine = kg & 1;
+__device__ __forceinline__ void fg_tile_keep(const FgArgs& a, long long krow0, long long krow1, int wave, int kg, int hv, int c0, float (&km)[2][2][4]) {
+    const int mine = kg & 1;      // (hv: 8-channel groups per row of the tensor the draw is indexed over; c0: this workgroup's first column in it)
     const uint64_t seed = a.rng[0], step = a.rng[1];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int c = wave * 32 + nt * 16 + kg * 4;
+        const int c = c0 + wave * 32 + nt * 16 + kg * 4;
         const uint64_t g = (uint64_t)(mine ? krow1 : krow0) * hv + (c >> 3);
         const uint4 q = philox4x32_10(make_uint4((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)step, (uint32_t)(step >> 32)),
                                       make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (a.site * 0x9E3779B9u)));
@@ -163,9 +163,10 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
     float km[2][2][4];
     if (!kPlain && a.rng) {       // (uniform) the dropout draws of the tile, indexed by the OUTPUT row forward and by the row backward (as vlg_ff_act*)
         const long long ra = row0 + r, rb = row0 + 16 + r;
-        const long long ka = a.bwd ? ra : (ra >> a.rs) * a.om + (long long)y * a.oy + (ra & ((1 << a.rs) - 1));
-        const long long kb = a.bwd ? rb : (rb >> a.rs) * a.om + (long long)y * a.oy + (rb & ((1 << a.rs) - 1));
-        fg_tile_keep(a, ka, kb, wave, kg, km);
+        const bool by_row = a.bwd || a.plain;
+        const long long ka = by_row ? ra : (ra >> a.rs) * a.om + (long long)y * a.oy + (ra & ((1 << a.rs) - 1));
+        const long long kb = by_row ? rb : (rb >> a.rs) * a.om + (long long)y * a.oy + (rb & ((1 << a.rs) - 1));
+        fg_tile_keep(a, ka, kb, wave, kg, a.plain ? a.ncols >> 3 : kFgH >> 3, a.plain ? y * kFgH : 0, km);
     }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -180,7 +181,11 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                 //  that the two paths agree to the last bit of what the next layer reads wherever the product's own summation order does)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) val[k] = fg_round(val[k] + bias4[nt][k]);
-                if (a.plain) {        // (uniform) the product alone
+                if (a.plain) {        // (uniform) the product alone, or times the counter-based draw over out's [rows, ncols] elements (as vlg_dropout)
+                    if (a.rng) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) val[k] *= km[rt][nt][k];
+                    }
                     if (live && y * kFgH + c < a.ncols) fg_store4(a.out + (size_t)row * a.ldo + y * kFgH + c, val);
                     continue;
                 }
@@ -453,7 +458,8 @@ int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, int k, i
     return fg_launch(a, k, 1, (hipStream_t)stream);
 }
 
-int vlg_ff_linear_kn(const void* x, int ldx, const void* w, int ldw, long long rows, int ncols, void* out, int ldo, void* stream) {
+int vlg_ff_linear_kn(const void* x, int ldx, const void* w, int ldw, long long rows, int ncols, const uint64_t* rng, unsigned site, float p, void* out, int ldo,
+                     void* stream) {
     using namespace vlg;
     if (int rc = fg_check("ff_linear_kn", x, ldx, 256, w, rows, out)) return rc;
     if (ncols < 8 || ncols % 8 || ldw < ncols || ldo < ncols || ldo % 4 || ncols > 64 * kFgH)
@@ -462,6 +468,7 @@ int vlg_ff_linear_kn(const void* x, int ldx, const void* w, int ldw, long long r
     FgArgs a{};
     a.x = (const uint16_t*)x; a.ldx = ldx; a.w = (const uint16_t*)w; a.w_kn = 1; a.ldw = ldw; a.ncols = ncols; a.plain = 1; a.ldo = ldo;
     a.rows = rows; a.J = 1; a.out = (uint16_t*)out;
+    a.rng = rng; a.site = site; a.mask_scale = rng ? drop_scale(p) : 1.f; a.thr = rng ? drop_threshold(p) : 0;
     return fg_launch(a, 256, (ncols + kFgH - 1) / kFgH, (hipStream_t)stream);
 }
 

@@ -104,6 +104,39 @@ def dropout(x, p, mask=None, rng=None, site=0, shared_rows=0):
     return _Dropout.apply(x, mask, shared_rows, rng, site, p)
 
 
+class _DropoutLinear(torch.autograd.Function):
+    """Linear_nobias(Dropout_p(x)) with the counter-based draw: forward = the dropout pass + the library product; the adjoint's input gradient
+    (g @ weight) * keep is ONE launch (align.linear_kn with the draw in its epilogue) instead of a product, a mask pass and their [rows, E] round trip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, rng, site, p):
+        x2 = x.detach().reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        xd = _dropout_launch(x2, None, 0, rng, site, p, None, torch.empty_like(x2))
+        ctx.save_for_backward(xd, weight.detach())
+        ctx.args = (rng, site, p, x.shape)
+        return torch.nn.functional.linear(xd, weight.detach()).view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from .align import _wgrad_ok, linear_kn
+        xd, weight = ctx.saved_tensors
+        rng, site, p, shape = ctx.args
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        dx = linear_kn(g2, weight, rng=rng, site=site, p=p).view(shape) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if _wgrad_ok(xd.shape[0], g2.shape[1], xd.shape[1], g2.dtype):
+                dw, _ = linear_wgrad(g2, xd, want_bias=False, out_dtype=weight.dtype)
+            else:
+                dw = g2.t() @ xd
+        return dx, dw, None, None, None
+
+
 def mlp_encoder(emb, weight, p=0.33, mask=None, rng=None, shared_mask=None, training=True):
     """`MLPEncoder.forward` (mlp_encoder.py:36-40): emb [B,L,E] -> x [B,L,n_hidden] = Linear_nobias(SharedDropout(Dropout_p(emb))).
     weight: `linear.weight` [n_hidden, E].  Training mode draws nn.Dropout's mask from `rng` (DeviceRng) or takes it as `mask`
@@ -111,6 +144,12 @@ def mlp_encoder(emb, weight, p=0.33, mask=None, rng=None, shared_mask=None, trai
     vlgae.yaml has 0 = Identity).  Eval mode (training=False) or p == 0: the Linear alone."""
     _C.require_gpu(emb, "mlp_encoder")
     x = emb
+    if training and p > 0 and rng is not None and mask is None and shared_mask is None and emb.dtype == weight.dtype:
+        from . import align
+        rows = emb.numel() // emb.shape[-1]   # (the conditions of align.linear_kn_ok on the adjoint's cotangent [rows, 256] and this weight)
+        if (not align._KN_LIBRARY and weight.dtype == torch.bfloat16 and weight.dim() == 2 and weight.shape[0] == 256 and rows >= 2048
+                and weight.shape[1] % 8 == 0 and weight.stride(1) == 1):
+            return _DropoutLinear.apply(emb, weight, rng, SITE_TEXT_ENCODER, p)
     if training and p > 0:
         x = dropout(x, p, mask=mask, rng=rng, site=SITE_TEXT_ENCODER)
     if training and shared_mask is not None:
