@@ -4,8 +4,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 tag=${1:-r02}
 mkdir -p gpurun_out
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 100 --warmup 10 --cpu-seconds 0 --no-secondary > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
-f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${tag}_kernel_stats.csv; head -4 "$f" | cut -c1-220
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --no-secondary > gpurun_out/pmc_${tag}_$c.log 2>&1
 done
@@ -40,3 +38,7 @@ for key in ('B256_L80_bf16', 'B256_L40_f32'):
 print(json.dumps(res, indent=1))
 json.dump(res, open('gpurun_out/${tag}_pmc_traffic.json', 'w'), indent=1)
 PY
+# the traffic figure into profiles/ BEFORE the stats run, so that the bench line it prints cites the passes taken at this kernel source
+mkdir -p profiles; cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 100 --warmup 10 --cpu-seconds 0 --no-secondary > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
+f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${tag}_kernel_stats.csv; head -4 "$f" | cut -c1-220

@@ -3,8 +3,10 @@
 cd $GRAFT_REPO_ROOT
 tag=${1:-r06_z}
 mkdir -p gpurun_out
-python bench.py > gpurun_out/${tag}_bench_full.json 2> gpurun_out/${tag}_bench_full.err
 bash tools/prof_headline.sh $tag > gpurun_out/${tag}_prof_headline.log 2>&1
+# (the traffic passes run first and land in profiles/: bench.py labels its roofline.traffic with the newest profiles/*_pmc_traffic.json and says whether
+#  it was taken at THIS kernel source)
+python bench.py > gpurun_out/${tag}_bench_full.json 2> gpurun_out/${tag}_bench_full.err
 bash tools/prof_dp4.sh $tag > /dev/null 2>&1
 bash tools/prof_train_step.sh $tag > gpurun_out/${tag}_prof_train_step.log 2>&1
 python tools/step_kernel_sequence.py gpurun_out/prof_${tag}_ts --all > gpurun_out/${tag}_train_step_sequence.txt 2>&1
