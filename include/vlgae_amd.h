@@ -311,6 +311,17 @@ typedef struct VlgWgradReduce {
 int vlg_linear_wgrad_partial(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, int in_dtype, void* ws, size_t ws_bytes,
                              int want_bias, int want_x_colsum, void* stream);
 int vlg_linear_wgrad_reduce_group(const VlgWgradReduce* items, int count, void* stream);
+/* The split-K launches of SEVERAL products as one grid per kernel image (round 6): what vlg_linear_wgrad_partial does for each item, in up to four
+ * launches for any number of bf16 items (a product is 256 workgroups -- one per CU -- and alone pays the chip's fill and drain; in one grid the next
+ * product's workgroups start as the previous one's finish).  Same partial tiles, same bits; float32 items are launched one by one.  Every item's
+ * operands and workspace must stay alive and untouched until vlg_linear_wgrad_reduce_group has run. */
+typedef struct VlgWgradPartial {
+    const void *dy, *x;                  /* [K, M] (rows ld_dy apart), [K, N] (ld_x) */
+    void* ws;
+    size_t ws_bytes;
+    int ld_dy, ld_x, K, M, N, in_dtype, want_bias, want_x_colsum;
+} VlgWgradPartial;
+int vlg_linear_wgrad_partial_group(const VlgWgradPartial* items, int count, void* stream);
 
 /* The two TRAINABLE encoders between the frozen features and the structured step (round 5; BASELINE.json configs[4]) -- what
  * `JointModelBase.forward` runs first, src/model/base.py:229,235.  The GEMMs are the caller's (library); these are the passes around them.

@@ -1884,6 +1884,35 @@ def test_linear_wgrad_partial_tiles():
         assert torch.equal(wide[:, 16:16 + N], dw.to(torch.bfloat16)) and float(wide[:, :16].abs().max()) == 0 and float(wide[:, 16 + N:].abs().max()) == 0
 
 
+def test_linear_wgrad_lazy_group_equals_single_launches():
+    """A lazy WgradGroup (the split-K launches of several products as one grid per kernel image, vlg_linear_wgrad_partial_group) gives the bits of
+    the products launched one by one: every image class (64-tile, 128-tile with bias sum / x column sum / none), more items than one launch
+    holds, a float32 item among them, operands that are column slices."""
+    from vlgae_amd import align
+    g = torch.Generator().manual_seed(21)
+    bf = torch.bfloat16
+    cases = [(4100, 32, 256, True, False), (4099, 256, 256, True, False), (2400, 512, 256, True, False), (2400, 256, 800, False, True),
+             (2200, 384, 384, False, False), (2304, 768, 256, True, False)] + [(2048 + 8 * i, 64, 72, True, False) for i in range(9)]
+    ops = []
+    for K, M, N, bias, colsum in cases:
+        wide = torch.randn(K, M + 8, generator=g).to(dev(), bf)
+        ops.append((wide[:, 8:], torch.randn(K, N, generator=g).to(dev(), bf), bias, colsum))
+    ops.append((torch.randn(2100, 64, generator=g).to(dev()), torch.randn(2100, 40, generator=g).to(dev()), True, False))     # float32 operands
+    def run(lazy):
+        wg = align.WgradGroup(lazy=lazy)
+        outs = [align.linear_wgrad(dy, x, want_bias=b, want_x_colsum=c, defer=wg) for dy, x, b, c in ops]
+        wg.flush()
+        return outs
+    single = [align.linear_wgrad(dy, x, want_bias=b, want_x_colsum=c) for dy, x, b, c in ops]
+    for outs in (run(False), run(True), run(True)):
+        for (dw, db), (sw, sb), (dy, x, b, c) in zip(outs, single, ops):
+            assert torch.equal(dw, sw)
+            assert (db is None and sb is None) or torch.equal(db, sb)
+    dy, x = ops[1][0], ops[1][1]
+    want = dy.double().t() @ x.double()
+    assert float((run(True)[1][0].double() - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-3
+
+
 def test_linear_wgrad_float32_operands():
     """vlg_linear_wgrad with float32 operands (the reference's `precision: 32`): three bf16 products per pair on hi / lo parts split on the way
     into LDS.  Against float64: the error is that of the dropped lo x lo term and the split residues (~2^-16 relative per PRODUCT, random in

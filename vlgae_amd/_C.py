@@ -29,6 +29,12 @@ class WgradReduce(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("ws", "d_weight", "d_bias", "x_colsum")] + [(n, ctypes.c_int) for n in ("K", "M", "N", "ld_dw", "out_dtype", "in_dtype")]
 
 
+class WgradPartial(ctypes.Structure):
+    """VlgWgradPartial of include/vlgae_amd.h: one split-K product of vlg_linear_wgrad_partial_group."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("dy", "x", "ws")] + [("ws_bytes", ctypes.c_size_t)]
+                + [(n, ctypes.c_int) for n in ("ld_dy", "ld_x", "K", "M", "N", "in_dtype", "want_bias", "want_x_colsum")])
+
+
 # symbol -> (restype, argtypes); one entry per declaration in include/vlgae_amd.h
 SIGNATURES = {
     "vlg_dmv1o_inside": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -78,6 +84,7 @@ SIGNATURES = {
     "vlg_vis_encoder_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "vlg_linear_wgrad_partial": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _i, _vp]),
     "vlg_linear_wgrad_reduce_group": (_i, [_vp, _i, _vp]),
+    "vlg_linear_wgrad_partial_group": (_i, [_vp, _i, _vp]),
     "vlg_langfeat_root_cat": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_langfeat_root_cat_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vlg_langfeat_split": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -577,13 +577,22 @@ class WgradGroup:
     every deferred product in ONE launch (up to 12 per launch; vlg_linear_wgrad_reduce_group) -- same fixed-order sums, same bits.  The
     outputs are valid after flush()."""
 
-    def __init__(self):
-        self.items, self.keep, self.first = [], [], None
+    def __init__(self, lazy=False):
+        # lazy: the split-K launches wait for flush() too and go out as ONE grid per kernel image (vlg_linear_wgrad_partial_group): the weight
+        # gradients of a backward pass are leaves, and a product of 256 workgroups launched alone pays the chip's fill and drain.  The operands
+        # are referenced until then and must not be overwritten in place after linear_wgrad(..., defer=group) took them.
+        self.items, self.keep, self.first, self.lazy, self.partials = [], [], None, lazy, []
 
     def flush(self):
         n = len(self.items)
         if n == 0:
             return
+        if self.partials:
+            parr = (_C.WgradPartial * len(self.partials))()
+            for rec, vals in zip(parr, self.partials):
+                rec.dy, rec.x, rec.ws, rec.ws_bytes, rec.ld_dy, rec.ld_x, rec.K, rec.M, rec.N, rec.in_dtype, rec.want_bias, rec.want_x_colsum = vals
+            _C.check(_C.lib().vlg_linear_wgrad_partial_group(parr, len(self.partials), _C.stream_of(self.first)), "linear_wgrad_partial_group")
+            self.partials = []
         arr = (_C.WgradReduce * n)()
         for rec, vals in zip(arr, self.items):
             rec.ws, rec.d_weight, rec.d_bias, rec.x_colsum, rec.K, rec.M, rec.N, rec.ld_dw, rec.out_dtype, rec.in_dtype = vals
@@ -633,10 +642,15 @@ def linear_wgrad(dy, x, want_bias=True, want_x_colsum=False, out=None, out_dtype
         raise ValueError(f"linear_wgrad: outputs must be float32 or bfloat16 of one type, d_weight [out, in] with unit column stride (a column "
                          f"block of a wider gradient is fine), got {dw.dtype} {tuple(dw.shape)} {dw.stride()} / {None if db is None else db.dtype}")
     odt = _C.BF16 if out_dtype == torch.bfloat16 else _C.F32
-    if defer is not None:   # the split-K launch alone; the reduction joins the group's single launch
-        _C.check(_C.lib().vlg_linear_wgrad_partial(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, idt, _C.ptr(ws), nbytes,
-                                                   int(db is not None and not want_x_colsum), int(db is not None and want_x_colsum), _C.stream_of(dy)),
-                 "linear_wgrad_partial")
+    if defer is not None:   # the split-K launch alone (or, a lazy group, not even that yet); the reduction joins the group's single launch
+        if defer.lazy:
+            defer.partials.append((dy.data_ptr(), x.data_ptr(), ws.data_ptr(), nbytes, dy.stride(0), x.stride(0), K, M, N, idt,
+                                   int(db is not None and not want_x_colsum), int(db is not None and want_x_colsum)))
+            defer.keep.append((dy, x))
+        else:
+            _C.check(_C.lib().vlg_linear_wgrad_partial(_C.ptr(dy), dy.stride(0), _C.ptr(x), x.stride(0), K, M, N, idt, _C.ptr(ws), nbytes,
+                                                       int(db is not None and not want_x_colsum), int(db is not None and want_x_colsum), _C.stream_of(dy)),
+                     "linear_wgrad_partial")
         dpt = lambda t: None if t is None else t.data_ptr()
         defer.items.append((ws.data_ptr(), dw.data_ptr(), None if want_x_colsum else dpt(db), dpt(db) if want_x_colsum else None, K, M, N, dw.stride(0), odt, idt))
         defer.keep.append((ws, dw, db))

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "vlg_common.h"
@@ -65,21 +66,18 @@ struct TnCfg {
 // SETS: register sets of one stage each, loaded SETS stages ahead of their use (the 128-tile holds one: with its 64 accumulator registers a
 // second set spills at the 256 registers that two resident workgroups per CU allow); CS / CSB: carry the column sums of A / of B.
 template <int TILE, int KSTAGE, int SETS, bool CS, bool CSB>
-__global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
-                                                               const uint16_t* __restrict__ B, int ldb, int K, int M,
-                                                               int N, int KC, int S, float* __restrict__ part,
-                                                               float* __restrict__ part_cs, float* __restrict__ part_csb) {
+__device__ __forceinline__ void tn_body(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, int K, int M, int N, int KC, int S,
+                                        float* __restrict__ part, float* __restrict__ part_cs, float* __restrict__ part_csb, const int bid, char* sA,
+                                        char* sB) {
     using C = TnCfg<TILE, KSTAGE>;
     constexpr int kTile = C::kTile, kStage = C::kStage, kPitch = C::kPitch, kQ = C::kQ, kF = C::kF, kP = C::kPasses, kRP = C::kRowsPerPass;
-    __shared__ __attribute__((aligned(16))) char sA[kStage * kPitch];
-    __shared__ __attribute__((aligned(16))) char sB[kStage * kPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int MT = (M + kTile - 1) / kTile;   // M, N: multiples of 8 (16-byte row segments); the last tile of either side may be partial
     // XCD-aware block order: consecutive workgroup ids go round-robin over the eight XCDs (one L2 each), so id % 8 picks the XCD.  All
     // tiles of one row split s get ids with the same id % 8: the split's rows of A and B are then fetched into ONE L2 and shared by its
     // MT x NT tiles there, instead of every column block being pulled into several different L2s (grid (tiles, S) order).
     const int tiles = MT * ((N + kTile - 1) / kTile);
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = bid & 7, j = bid >> 3;
     const int s = (j / tiles) * 8 + xcd, tile = j % tiles;
     if (s >= S) return;                        // (the last group of eight splits may be partial; block-uniform)
     const int mt = tile % MT, nt = tile / MT;
@@ -143,9 +141,6 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const uint16_t
         constexpr int KK = kStage / 32;
         // one stage: the fragments of contraction step kk + 1 are read while the products of step kk run (two fragment sets)
         auto stage_mma = [&]() {
-#ifdef VLG_TN_NOMMA        // tools/ ablation (results are wrong): loads, LDS stores and barriers only
-            return;
-#endif
             bf16x8 fa[2][kF], fb[2][kF];
             auto read = [&](int kk) {
 #pragma unroll
@@ -253,6 +248,45 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const uint16_t
             if (col < N) part_csb[(size_t)s * N + col] = csb[j][0];
         }
     }
+}
+
+template <int TILE, int KSTAGE, int SETS, bool CS, bool CSB>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
+                                                               const uint16_t* __restrict__ B, int ldb, int K, int M,
+                                                               int N, int KC, int S, float* __restrict__ part,
+                                                               float* __restrict__ part_cs, float* __restrict__ part_csb) {
+    using C = TnCfg<TILE, KSTAGE>;
+    __shared__ __attribute__((aligned(16))) char sA[C::kStage * C::kPitch];
+    __shared__ __attribute__((aligned(16))) char sB[C::kStage * C::kPitch];
+    tn_body<TILE, KSTAGE, SETS, CS, CSB>(A, lda, B, ldb, K, M, N, KC, S, part, part_cs, part_csb, (int)blockIdx.x, sA, sB);
+}
+
+// SEVERAL split-K products in one launch (round 6): the weight gradients of one backward pass are leaves -- nothing downstream reads them --
+// so a Function defers them to its end and issues them as one grid per tile shape: a product is only 256 workgroups (one per CU), and
+// launched alone each pays the chip's fill and drain; in one grid the next product's workgroups start as the previous one's finish.
+// The descriptors travel by value; workgroup x finds its product by a scan of the block prefix (uniform: scalar code).  Each item's block
+// count is a multiple of 8, so its local block index keeps the XCD assignment of the single launch.
+constexpr int kTnGroupMax = 8;
+struct TnItem {
+    const uint16_t *A, *B;
+    float *part, *part_cs, *part_csb;
+    int lda, ldb, K, M, N, KC, S;
+};
+struct TnGroup {
+    TnItem p[kTnGroupMax];
+    int start[kTnGroupMax + 1];
+    int count;
+};
+
+template <int TILE, int KSTAGE, int SETS, bool CS, bool CSB>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_group_kernel(const TnGroup g) {
+    using C = TnCfg<TILE, KSTAGE>;
+    __shared__ __attribute__((aligned(16))) char sA[C::kStage * C::kPitch];
+    __shared__ __attribute__((aligned(16))) char sB[C::kStage * C::kPitch];
+    int i = 0;
+    while (i + 1 < g.count && (int)blockIdx.x >= g.start[i + 1]) ++i;
+    const TnItem& t = g.p[i];
+    tn_body<TILE, KSTAGE, SETS, CS, CSB>(t.A, t.lda, t.B, t.ldb, t.K, t.M, t.N, t.KC, t.S, t.part, t.part_cs, t.part_csb, (int)blockIdx.x - g.start[i], sA, sB);
 }
 
 // ---- float32 operands on the bf16 matrix cores (round 5: the reference's `precision: 32`, config/trainer/train.yaml:20) -----------------
@@ -748,6 +782,31 @@ size_t vlg_linear_wgrad_workspace(int K, int M, int N) {
 static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, int in_dtype, void* ws, size_t ws_bytes, int out_dtype,
                         void* d_weight, int ld_dw, void* d_bias, void* x_colsum, bool reduce_now, void* stream);
 
+// one bf16 product of a grouped split-K launch: wgrad_launch's checks and plan -> the kernel's descriptor and its image class
+static int wgrad_item(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, void* ws, size_t ws_bytes, bool want_bias, bool want_colsum,
+                      vlg::TnItem& t, int& cls) {
+    using namespace vlg;
+    if (K < 1 || M < 8 || N < 8 || M % 8 || N % 8)
+        return set_error(VLG_ERR_SHAPE, "linear_wgrad: need K >= 1 and M, N positive multiples of 8 (got K=%d M=%d N=%d)", K, M, N);
+    if (ld_dy < M || ld_x < N || ld_dy % 8 || ld_x % 8)
+        return set_error(VLG_ERR_SHAPE, "linear_wgrad: row strides must cover the columns and be multiples of 8 elements (ld_dy=%d ld_x=%d)", ld_dy, ld_x);
+    if (!dy || !x || !ws) return set_error(VLG_ERR_ARG, "linear_wgrad: null buffer");
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ws)) & 15)
+        return set_error(VLG_ERR_ARG, "linear_wgrad: dy, x and the workspace must be 16-byte aligned");
+    const bool big = tn_big(M, N) && !(want_bias && want_colsum);
+    const TnPlan pl = plan_tn(K, M, N, big, false);
+    if (ws_bytes < pl.bytes) return set_error(VLG_ERR_WORKSPACE, "linear_wgrad: needs a %zu-byte workspace (got %zu)", pl.bytes, ws_bytes);
+    if ((long long)pl.KC * std::max(ld_dy, ld_x) * 2 >= (1LL << 30))
+        return set_error(VLG_ERR_SHAPE, "linear_wgrad: a row split of %d rows x %d elements exceeds 1 GiB", pl.KC, std::max(ld_dy, ld_x));
+    float* part = (float*)ws;
+    t.A = (const uint16_t*)dy; t.B = (const uint16_t*)x; t.lda = ld_dy; t.ldb = ld_x; t.K = K; t.M = M; t.N = N; t.KC = pl.KC; t.S = pl.S;
+    t.part = part;
+    t.part_cs = want_bias ? part + (size_t)pl.S * M * N : nullptr;
+    t.part_csb = want_colsum ? part + (size_t)pl.S * ((size_t)M * N + M) : nullptr;
+    cls = !big ? 0 : (want_bias ? 1 : (want_colsum ? 2 : 3));
+    return 0;
+}
+
 int vlg_linear_wgrad(const void* dy, int ld_dy, const void* x, int ld_x, int K, int M, int N, int in_dtype, void* ws, size_t ws_bytes, int out_dtype,
                      void* d_weight, int ld_dw, void* d_bias, void* x_colsum, void* stream) {
     return wgrad_launch(dy, ld_dy, x, ld_x, K, M, N, in_dtype, ws, ws_bytes, out_dtype, d_weight, ld_dw, d_bias, x_colsum, true, stream);
@@ -759,6 +818,48 @@ int vlg_linear_wgrad_partial(const void* dy, int ld_dy, const void* x, int ld_x,
     static char dummy;
     return wgrad_launch(dy, ld_dy, x, ld_x, K, M, N, in_dtype, ws, ws_bytes, VLG_F32, &dummy, N, want_bias ? &dummy : nullptr, want_x_colsum ? &dummy : nullptr, false,
                         stream);
+}
+
+int vlg_linear_wgrad_partial_group(const VlgWgradPartial* items, int count, void* stream) {
+    using namespace vlg;
+    if (count < 0 || (count && !items)) return set_error(VLG_ERR_ARG, "linear_wgrad_partial_group: count=%d", count);
+    static char dummy;
+    hipStream_t s = (hipStream_t)stream;
+    TnGroup grp[4];                      // by kernel image: 64-tile (both column sums) | 128-tile with the bias sum | with x's column sum | with none
+    for (auto& g : grp) { g.count = 0; g.start[0] = 0; }
+    auto flush = [&](int c) -> int {
+        TnGroup& g = grp[c];
+        if (g.count == 0) return 0;
+        const dim3 grid(g.start[g.count]);
+        if (c == 0) hipLaunchKernelGGL((gemm_tn_group_kernel<64, VLG_TN64_STAGE, VLG_TN64_SETS, true, true>), grid, dim3(kGemmThreads), 0, s, g);
+        else if (c == 1) hipLaunchKernelGGL((gemm_tn_group_kernel<128, VLG_TN128_STAGE, VLG_TN128_SETS, true, false>), grid, dim3(kGemmThreads), 0, s, g);
+        else if (c == 2) hipLaunchKernelGGL((gemm_tn_group_kernel<128, VLG_TN128_STAGE, VLG_TN128_SETS, false, true>), grid, dim3(kGemmThreads), 0, s, g);
+        else hipLaunchKernelGGL((gemm_tn_group_kernel<128, VLG_TN128_STAGE, VLG_TN128_SETS, false, false>), grid, dim3(kGemmThreads), 0, s, g);
+        g.count = 0;
+        return check_launch("gemm_tn_group_kernel");
+    };
+    for (int i = 0; i < count; ++i) {
+        const VlgWgradPartial& q = items[i];
+        void* bias = q.want_bias ? &dummy : nullptr;
+        void* colsum = q.want_x_colsum ? &dummy : nullptr;
+        if (q.in_dtype != VLG_BF16) {     // float32 operands: the three-product kernel has no grouped form -- its own launch
+            if (int rc = wgrad_launch(q.dy, q.ld_dy, q.x, q.ld_x, q.K, q.M, q.N, q.in_dtype, q.ws, q.ws_bytes, VLG_F32, &dummy, q.N, bias, colsum, false, stream)) return rc;
+            continue;
+        }
+        TnItem t;
+        int cls;
+        if (int rc = wgrad_item(q.dy, q.ld_dy, q.x, q.ld_x, q.K, q.M, q.N, q.ws, q.ws_bytes, bias != nullptr, colsum != nullptr, t, cls)) return rc;
+        TnGroup& g = grp[cls];
+        const int kTile = cls == 0 ? 64 : 128;
+        const int tiles = ((q.M + kTile - 1) / kTile) * ((q.N + kTile - 1) / kTile);
+        g.p[g.count] = t;
+        g.start[g.count + 1] = g.start[g.count] + tiles * ((t.S + 7) / 8) * 8;
+        if (++g.count == kTnGroupMax)
+            if (int rc = flush(cls)) return rc;
+    }
+    for (int c = 0; c < 4; ++c)
+        if (int rc = flush(c)) return rc;
+    return 0;
 }
 
 int vlg_linear_wgrad_reduce_group(const VlgWgradReduce* items, int count, void* stream) {
@@ -811,6 +912,8 @@ static int wgrad_launch(const void* dy, int ld_dy, const void* x, int ld_x, int 
     const bool big = tn_big(M, N) && !(d_bias && x_colsum);     // (the 128-tile carries one kind of column sum)
     const TnPlan pl = plan_tn(K, M, N, big, f32);
     if (ws_bytes < pl.bytes) return set_error(VLG_ERR_WORKSPACE, "linear_wgrad: needs a %zu-byte workspace (got %zu)", pl.bytes, ws_bytes);
+    if (!f32 && (long long)pl.KC * std::max(ld_dy, ld_x) * 2 >= (1LL << 30))     // (the bf16 kernel's 32-bit buffer offsets over one split's rows)
+        return set_error(VLG_ERR_SHAPE, "linear_wgrad: a row split of %d rows x %d elements exceeds 1 GiB", pl.KC, std::max(ld_dy, ld_x));
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)ws;
     float* part_cs = d_bias ? part + (size_t)pl.S * M * N : nullptr;

@@ -236,7 +236,7 @@ class _VisEncoder(torch.autograd.Function):
                 out_dt = w_dt if w_dt in (torch.float32, torch.bfloat16) else torch.float32
                 dW = torch.empty((FH, 2 * n), dtype=out_dt, device=P.device)
                 db = torch.empty((FH,), dtype=out_dt, device=P.device)
-                wg = WgradGroup()                                            # the two reductions as one launch
+                wg = WgradGroup(lazy=True)                                   # the two products as one grid per kernel image, the two reductions as one launch
                 linear_wgrad(dP, x2, want_bias=False, out=(dW[:, :n], None), defer=wg)
                 linear_wgrad(dC, xm, want_bias=True, out=(dW[:, n:], db), defer=wg)
                 wg.flush()

@@ -344,7 +344,7 @@ class _ParserFF(torch.autograd.Function):
             torch.mm(g_big, Wp[:2 * r], out=gA5[:4 * M0])
         # (everything below in the activations' dtype: as fp32 GEMMs on one workgroup each the library takes 30-50 us for these products)
         dWp, dbp = torch.empty((6 * r, H), dtype=act, device=dev), torch.empty((6 * r,), dtype=act, device=dev)
-        wg = WgradGroup()      # the seven split-K weight gradients of this pass: their reductions run as ONE launch before the last group
+        wg = WgradGroup(lazy=True)   # the seven split-K weight gradients of this pass: ONE grid per kernel image at the end, their reductions one launch
         _wgrad(g_big, A5[:4 * M0], out=(dWp[:2 * r], dbp[:2 * r]), defer=wg)            # [2r,H], [2r]: split-K, written in place
         grp = SmallMatmulGroup()
         grp.add(g_small, Wp[2 * r:], out=gA5[4 * M0:])
