@@ -478,6 +478,24 @@ int vlg_ff_linear_act(const void* x, int ldx, const void* w, const void* bias, l
 int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, int k, int w_kn, long long rows, int J, const void* act, const void* mask, float mask_scale,
                                const uint64_t* rng, unsigned site, float p, void* out, float* sum, int swap, int accumulate, float slope,
                                void* stream);
+/* TWO consecutive 256 -> 256 stages in one launch (round 6): stage 2 runs on stage 1's stored rows without their round trip through memory (stage 1's
+ * epilogue leaves its tile in LDS as well; both weight blocks sit in registers).  Each stage is what vlg_ff_linear_act (backward = 0: w in nn.Linear
+ * layout, bias) / vlg_ff_linear_act_backward at k = 256 (backward = 1: w = the transposed weight, act, J / sum / swap / accumulate) computes with these
+ * arguments; stage 1 keeps its rows (a plain layer: one column block, no skip connection; backward: J = 1, no sum, no permutation) and still writes
+ * its own `out` (the weight gradients read it), stage 2 forward is a plain layer too.  The parser's direction -> output stages (nn/dmv_spec.py:52-54)
+ * and their adjoints.  mask / rng / site / p / mask_scale as in vlg_ff_linear_act; unused fields zero. */
+typedef struct VlgFfStage {
+    const void *w, *bias;                /* [256, 256] bf16; bias [256] or NULL (forward) */
+    const void* mask;                    /* keep-mask [rows, 256] bf16 or NULL */
+    const uint64_t* rng;                 /* or the counter-based draw */
+    void* out;                           /* [rows, 256] bf16 */
+    const void* act;                     /* backward: the stored activations [rows, 256] */
+    float* sum;                          /* backward: [rows / J, 256] fp32 or NULL */
+    float mask_scale, p;
+    unsigned site;
+    int J, swap, accumulate;
+} VlgFfStage;
+int vlg_ff_linear_act_chain2(const void* x, int ldx, long long rows, int backward, const VlgFfStage* s1, const VlgFfStage* s2, float slope, void* stream);
 /* out[rows, ncols] (bf16, rows ldo elements apart) = bf16(x[rows, 256] @ w[256, ncols]): a Linear's INPUT gradient (g @ weight, weight [256, in] as nn.Linear
  * stores it) or any product of token rows with a weight whose contraction index is its slow one, as one row-streaming launch: the weight is read
  * where it lies (rows ldw elements apart: a column slice of a wider matrix is fine), 256 output columns per workgroup column block.  ncols a multiple

@@ -3265,6 +3265,47 @@ def test_ff_linear_kn(rows, n, ldw, ldo):
     assert float((gw.double() - cot.double().t() @ xin.detach().double()).abs().max()) <= 2e-2 * float(gw.abs().max())
 
 
+@pytest.mark.parametrize("rows,keep", [(4 * 300, "rng"), (4 * 9, "mask"), (4 * 1031, None)])
+def test_ff_linear_act_chain2_equals_two_launches(rows, keep):
+    """vlg_ff_linear_act_chain2 (two consecutive 256 -> 256 stages in one launch, the second on the first's rows through LDS) gives the bits of the
+    two single launches, forward (a plain layer with dropout, then a plain layer) and backward (a plain layer's adjoint with the regenerated
+    mask, then an adjoint with the (dir,val) permutation and the group sums)."""
+    from vlgae_amd import encoders, parser_ff
+    H = 256
+    g = torch.Generator().manual_seed(rows)
+    bf = torch.bfloat16
+    x = torch.randn(rows, H, generator=g).to(dev(), bf)
+    W1, W2 = ((torch.randn(H, H, generator=g) / 16).to(dev(), bf) for _ in range(2))
+    b1, b2 = ((torch.randn(H, generator=g) / 4).to(dev(), bf) for _ in range(2))
+    act1, act2 = (torch.randn(rows, H, generator=g).to(dev(), bf) for _ in range(2))
+    mask, rng, p, scale = None, None, 0.0, 1.0
+    if keep == "mask":
+        mask, scale = (torch.rand(rows, H, generator=g) > 0.3).to(dev(), bf), 1.0 / 0.7
+    elif keep == "rng":
+        rng, p = encoders.DeviceRng(5, dev()), 0.3
+    new = lambda *sh, dt=bf: torch.full(sh, float("nan"), dtype=dt, device=dev())
+    # forward
+    o1, o2, c1, c2 = new(rows, H), new(rows, H), new(rows, H), new(rows, H)
+    parser_ff._linear_act(x, W1, b1, o1, mask=mask, mask_scale=scale, rng=rng, p=p)
+    parser_ff._linear_act(o1, W2, b2, o2)
+    parser_ff._linear_act_chain2(x, parser_ff._stage(W1, c1, bias=b1, mask=mask, mask_scale=scale, rng=rng, p=p), parser_ff._stage(W2, c2, bias=b2))
+    assert not torch.isnan(c2.float()).any()
+    assert torch.equal(o1, c1) and torch.equal(o2, c2)
+    # backward
+    wT = parser_ff._transpose256([W1, W2], torch.empty(2, H, H, dtype=bf, device=dev()))
+    o1, o2, c1, c2 = new(rows, H), new(rows, H), new(rows, H), new(rows, H)
+    t1, t2 = new(rows // 4, H, dt=torch.float32), new(rows // 4, H, dt=torch.float32)
+    parser_ff._linear_act_bwd(x, wT[0], act1, o1, mask=mask, mask_scale=scale, rng=rng, p=p)
+    parser_ff._linear_act_bwd(o1, wT[1], act2, o2, J=4, total=t1, swap=True)
+    parser_ff._linear_act_chain2(x, parser_ff._stage(wT[0], c1, act=act1, mask=mask, mask_scale=scale, rng=rng, p=p),
+                                 parser_ff._stage(wT[1], c2, act=act2, J=4, total=t2, swap=True), backward=True)
+    assert not torch.isnan(c2.float()).any() and not torch.isnan(t2).any()
+    assert torch.equal(o1, c1) and torch.equal(o2, c2) and torch.equal(t1, t2)
+    from vlgae_amd import _C
+    with pytest.raises(RuntimeError):       # the first stage keeps its rows
+        parser_ff._linear_act_chain2(x, parser_ff._stage(wT[0], c1, act=act1, J=4, swap=True), parser_ff._stage(wT[1], c2, act=act2), backward=True)
+
+
 def test_mlp_encoder_fused_adjoint_equals_unfused(monkeypatch):
     """encoders.mlp_encoder with the counter-based draw at a row count that takes the fused adjoint (_DropoutLinear: (g @ W) * keep in one launch)
     against the same call on the dropout + linear Functions: identical output, identical d_emb bits, d_W equal (same split-K product)."""

@@ -47,6 +47,19 @@ wkn = (torch.randn(H, 800, generator=g) / 16).to(dev, bf)
 out800 = torch.empty(rows, 800, device=dev, dtype=bf)
 def lib_kn():
     torch.mm(x, wkn, out=out800)
+outb = torch.empty(rows, H, device=dev, dtype=bf)
+from vlgae_amd import encoders
+rng = encoders.DeviceRng(3, dev)
+def two_fwd():
+    parser_ff._linear_act(x, w, b, out, rng=rng, p=0.3)
+    parser_ff._linear_act(out, w, b, outb)
+def chain_fwd():
+    parser_ff._linear_act_chain2(x, parser_ff._stage(w, out, bias=b, rng=rng, p=0.3), parser_ff._stage(w, outb, bias=b))
+def two_bwd():
+    parser_ff._linear_act_bwd(x, w, act, out, rng=rng, p=0.3)
+    parser_ff._linear_act_bwd(out, w, act, outb, J=4, total=tot, swap=True)
+def chain_bwd():
+    parser_ff._linear_act_chain2(x, parser_ff._stage(w, out, act=act, rng=rng, p=0.3), parser_ff._stage(w, outb, act=act, J=4, total=tot, swap=True), backward=True)
 def lib32():
     torch.mm(x32, w32, out=out)
     parser_ff._act_bwd(out, act, out, rows, 1, H)
@@ -61,6 +74,10 @@ for name, fn, mbytes in (("fused plain", lambda: parser_ff._linear_act(x, w, b, 
                          ("library k=32 + ff_act_bwd", lib32, mb * 17 / 16),
                          ("linear_kn 256 -> 800 k=256", lambda: align.linear_kn(x, wkn, out=out800), rows * (256 + 800) * 2 / 1e6),
                          ("library 256 -> 800 k=256", lib_kn, rows * (256 + 800) * 2 / 1e6),
+                         ("two forward launches (dropout | plain)", two_fwd, mb * 2),
+                         ("chain2 forward", chain_fwd, mb * 1.5),
+                         ("two backward launches (dropout | J=4 swap sum)", two_bwd, mb * 3),
+                         ("chain2 backward", chain_bwd, mb * 2.5),
                          ("library GEMM + ff_act", lib, mb * 2)):
     if len(sys.argv) > 2 and sys.argv[2] not in name: continue
     us = t(fn)

@@ -29,6 +29,12 @@ class WgradReduce(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("ws", "d_weight", "d_bias", "x_colsum")] + [(n, ctypes.c_int) for n in ("K", "M", "N", "ld_dw", "out_dtype", "in_dtype")]
 
 
+class FfStage(ctypes.Structure):
+    """VlgFfStage of include/vlgae_amd.h: one stage of vlg_ff_linear_act_chain2."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("w", "bias", "mask", "rng", "out", "act", "sum")] + [("mask_scale", ctypes.c_float), ("p", ctypes.c_float),
+                ("site", ctypes.c_uint), ("J", ctypes.c_int), ("swap", ctypes.c_int), ("accumulate", ctypes.c_int)])
+
+
 class WgradPartial(ctypes.Structure):
     """VlgWgradPartial of include/vlgae_amd.h: one split-K product of vlg_linear_wgrad_partial_group."""
     _fields_ = ([(n, ctypes.c_void_p) for n in ("dy", "x", "ws")] + [("ws_bytes", ctypes.c_size_t)]
@@ -102,6 +108,7 @@ SIGNATURES = {
     "vlg_ff_root_rule_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "vlg_ff_linear_act": (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _i, _i, _i, _vp, _f, _vp, ctypes.c_uint, _f, _vp, _f, _vp]),
     "vlg_ff_linear_act_backward": (_i, [_vp, _i, _vp, _i, _i, _ll, _i, _vp, _vp, _f, _vp, ctypes.c_uint, _f, _vp, _vp, _i, _i, _f, _vp]),
+    "vlg_ff_linear_act_chain2": (_i, [_vp, _i, _ll, _i, _vp, _vp, _f, _vp]),
     "vlg_ff_linear_kn": (_i, [_vp, _i, _vp, _i, _ll, _i, _vp, ctypes.c_uint, _f, _vp, _i, _vp]),
     "vlg_ff_linear_mlp_act_backward": (_i, [_vp, _i, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _i, _vp, _f, _vp]),
     "vlg_ff_transpose256": (_i, [_vp, _i, _vp, _vp]),

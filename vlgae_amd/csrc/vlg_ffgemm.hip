@@ -137,7 +137,8 @@ __device__ __forceinline__ void fg_tile_keep(const FgArgs& a, long long krow0, l
 // other tensors, and nothing goes back through the LDS (the first version wrote the fp32 accumulators to an LDS tile and read them back
 // row-major behind a barrier: eight waves in lock step, ~6 700 cycles per tile for 512 cycles of MFMA).
 template <int KS>
-__device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char* xs, const bf16x8 (&wf)[KS][2], const float (&bias4)[2][4], int tid, int y) {
+__device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char* xs, const bf16x8 (&wf)[KS][2], const float (&bias4)[2][4], int tid, int y,
+                                        char* ys = nullptr) {      // ys: an LDS image (the input tile's layout) that takes the stored values as well -- the next stage's input
     constexpr int kFgXPitch = fg_pitch(KS * 32);
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, kg = lane >> 4;
     f32x4 acc[2][2];
@@ -211,6 +212,7 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                     }
 #ifndef VLG_FG_NOSTORE     // tools/ ablation
                     fg_store4(a.out + (size_t)orow * kFgH + c, val);
+                    if (ys) fg_store4(reinterpret_cast<uint16_t*>(ys + (rt * 16 + r) * kFgXPitch) + c, val);
 #else
                     if (val[0] == 123.456f) fg_store4(a.out + (size_t)orow * kFgH + c, val);
 #endif
@@ -253,6 +255,7 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                         sv[k] = fg_round(val[k]);                           // the sum of what the next product reads
                     }
                     fg_store4(a.out + (size_t)orow * kFgH + c, val);
+                    if (ys) fg_store4(reinterpret_cast<uint16_t*>(ys + (rt * 16 + r) * kFgXPitch) + c, val);
                 }
                 if (!kPlain && a.sum) {     // (uniform) the J rows of a group sit on J consecutive lanes: the group's sum in row order j = 0, 1, ..
                     float s[4];
@@ -278,13 +281,18 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
     }
 }
 
-template <int KS>   // K = 32 KS input channels
-__global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a) {
+// TWO: a second 256 -> 256 stage `b` runs on the first one's stored rows without their round trip through memory: stage a's epilogue writes its
+// tile into a third LDS image as well, and stage b's product reads its input fragments there (both weight blocks in registers: 128 VGPRs).  Stage a
+// keeps its rows (one column block, no row permutation); it still writes its own output -- the weight gradients read it.
+template <int KS, bool TWO>   // K = 32 KS input channels
+__device__ __forceinline__ void ff_gemm_act_body(const FgArgs& a, const FgArgs& b) {
     constexpr int K = KS * 32, kFgXPitch = fg_pitch(K), SEGS = K / 8, SPT = (kFgRows * SEGS + kFgThreads - 1) / kFgThreads;   // 16-byte segments per row / per thread and tile
     static_assert(SPT >= 1 && SPT <= 4, "segments per thread");
+    static_assert(!TWO || KS == 8, "the second stage reads a 256-channel image");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs0 = smem;
     char* const xs1 = smem + kFgRows * kFgXPitch;
+    char* const ys = TWO ? smem + 2 * kFgRows * kFgXPitch : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kg = lane >> 4;
     const int y = blockIdx.y;
@@ -343,18 +351,58 @@ __global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a)
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int k = 0; k < 4; ++k) bias4[nt][k] = a.bias ? bf2f(a.bias[y * kFgH + wave * 32 + nt * 16 + kg * 4 + k]) : 0.f;
+    // ---- the second stage's weight block and bias ----
+    bf16x8 wf2[TWO ? KS : 1][2];
+    float bias2[2][4];
+    if constexpr (TWO) {
+        const uint16_t* wb = b.w + (size_t)(wave * 32) * kFgH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wf2[ks][nt] = *reinterpret_cast<const bf16x8*>(wb + (size_t)(nt * 16 + r) * kFgH + ks * 32 + kg * 8);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bias2[nt][k] = b.bias ? bf2f(b.bias[wave * 32 + nt * 16 + kg * 4 + k]) : 0.f;
+    }
+    auto tile = [&](long long tt, const char* xs) {
+        if constexpr (TWO) {
+            fg_tile<KS>(a, tt, xs, wf, bias4, tid, y, ys);
+            __syncthreads();                                   // stage a's rows are in `ys` (the next write of it is behind the trip's barrier)
+            fg_tile<KS>(b, tt, ys, wf2, bias2, tid, 0);
+        } else {
+            fg_tile<KS>(a, tt, xs, wf, bias4, tid, y);
+        }
+    };
     FG_STORE_A(xs0)
     // (tiles past the end re-read the last row: no branches around the loads; their registers are never stored)
     FG_LOAD_A(t + G)
+    if constexpr (TWO) {       // ONE tile in flight (a tile is two stages long here, and the second set's registers hold weights)
+        __syncthreads();
+        for (;;) {
+            tile(t, xs0);
+            if (t + G >= tiles) break;
+            FG_STORE_A(xs1)
+            FG_LOAD_A(t + 2 * G)
+            __syncthreads();
+            tile(t + G, xs1);
+            if (t + 2 * G >= tiles) break;
+            FG_STORE_A(xs0)
+            FG_LOAD_A(t + 3 * G)
+            __syncthreads();
+            t += 2 * G;
+        }
+        return;
+    }
     FG_LOAD_B(t + 2 * G)
     __syncthreads();
     for (;;) {
-        fg_tile<KS>(a, t, xs0, wf, bias4, tid, y);            // tile t from image 0
+        tile(t, xs0);                                          // tile t from image 0
         if (t + G >= tiles) break;
         FG_STORE_A(xs1)                                        // tile t + G -> image 1 (only set A's reads are waited for)
         FG_LOAD_A(t + 3 * G)
         __syncthreads();
-        fg_tile<KS>(a, t + G, xs1, wf, bias4, tid, y);        // tile t + G from image 1
+        tile(t + G, xs1);                                      // tile t + G from image 1
         if (t + 2 * G >= tiles) break;
         FG_STORE_B(xs0)
         FG_LOAD_B(t + 4 * G)
@@ -362,6 +410,11 @@ __global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a)
         t += 2 * G;
     }
 }
+
+template <int KS>
+__global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a) { ff_gemm_act_body<KS, false>(a, a); }
+
+__global__ __launch_bounds__(kFgThreads) void ff_gemm_act2_kernel(const FgArgs a, const FgArgs b) { ff_gemm_act_body<8, true>(a, b); }
 
 // out[z][n][k] = w_z[k][n] for up to eight 256 x 256 bf16 matrices (the layers' weights as the backward launches read them): 32 x 32 tiles through LDS
 struct FgTr { const uint16_t* w[8]; };
@@ -456,6 +509,50 @@ int vlg_ff_linear_act_backward(const void* g, int ldg, const void* w_t, int k, i
     a.mask = (const uint16_t*)mask; a.mask_scale = rng ? drop_scale(p) : mask_scale; a.rng = rng; a.site = site; a.thr = rng ? drop_threshold(p) : 0;
     a.out = (uint16_t*)out;
     return fg_launch(a, k, 1, (hipStream_t)stream);
+}
+
+// one stage of vlg_ff_linear_act_chain2 -> the kernel's argument block (x / rows filled by the caller)
+static int fg_stage(const char* what, const VlgFfStage& q, int backward, bool first, float slope, vlg::FgArgs& a) {
+    using namespace vlg;
+    if (!q.w || !q.out) return set_error(VLG_ERR_ARG, "%s: null weight / output", what);
+    if (((uintptr_t)q.w | (uintptr_t)q.out | (uintptr_t)q.act | (uintptr_t)q.mask | (uintptr_t)q.sum) & 15) return set_error(VLG_ERR_ARG, "%s: buffers must be 16-byte aligned", what);
+    if (q.mask && q.rng) return set_error(VLG_ERR_ARG, "%s: mask and rng are exclusive", what);
+    a = FgArgs{};
+    a.w = (const uint16_t*)q.w; a.slope = slope; a.out = (uint16_t*)q.out; a.om = 1; a.J = 1;
+    a.mask = (const uint16_t*)q.mask; a.mask_scale = q.rng ? drop_scale(q.p) : q.mask_scale; a.rng = q.rng; a.site = q.site; a.thr = q.rng ? drop_threshold(q.p) : 0;
+    if (!backward) {
+        a.bias = (const uint16_t*)q.bias;
+        return 0;
+    }
+    if (!q.act) return set_error(VLG_ERR_ARG, "%s: null activation", what);
+    const int J = q.J ? q.J : 1;
+    if ((J != 1 && J != 2 && J != 4) || (q.swap && J != 4) || ((q.mask || q.rng) && q.swap)) return set_error(VLG_ERR_ARG, "%s: J=%d swap=%d", what, J, q.swap);
+    if (first && (J != 1 || q.sum || q.swap)) return set_error(VLG_ERR_ARG, "%s: the first stage keeps its rows (J = 1, no sum, no permutation)", what);
+    a.bwd = 1; a.J = J; a.lj = J == 4 ? 2 : (J == 2 ? 1 : 0); a.swap = q.swap; a.accumulate = q.accumulate; a.act = (const uint16_t*)q.act; a.sum = q.sum;
+    return 0;
+}
+
+int vlg_ff_linear_act_chain2(const void* x, int ldx, long long rows, int backward, const VlgFfStage* s1, const VlgFfStage* s2, float slope, void* stream) {
+    using namespace vlg;
+    if (!s1 || !s2) return set_error(VLG_ERR_ARG, "ff_linear_act_chain2: null stage");
+    if (int rc = fg_check("ff_linear_act_chain2", x, ldx, 256, s1->w, rows, s1->out)) return rc;
+    FgArgs a, b;
+    if (int rc = fg_stage("ff_linear_act_chain2 (stage 1)", *s1, backward, true, slope, a)) return rc;
+    if (int rc = fg_stage("ff_linear_act_chain2 (stage 2)", *s2, backward, false, slope, b)) return rc;
+    if (backward && rows % b.J) return set_error(VLG_ERR_ARG, "ff_linear_act_chain2: rows=%lld J=%d", rows, b.J);
+    if (rows == 0) return 0;
+    a.x = (const uint16_t*)x; a.ldx = ldx; a.rows = rows;
+    b.x = (const uint16_t*)s1->out; b.ldx = kFgH; b.rows = rows;          // (read from the LDS image, never from memory)
+    static bool attr_set = false;
+    constexpr int lds = 3 * kFgRows * fg_pitch(256);
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_gemm_act2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const long long tiles = (rows + kFgRows - 1) / kFgRows;
+    hipLaunchKernelGGL(ff_gemm_act2_kernel, dim3((unsigned)std::min<long long>(tiles, 256)), dim3(kFgThreads), lds, (hipStream_t)stream, a, b);
+    return check_launch("ff_gemm_act2_kernel");
 }
 
 int vlg_ff_linear_kn(const void* x, int ldx, const void* w, int ldw, long long rows, int ncols, const uint64_t* rng, unsigned site, float p, void* out, int ldo,

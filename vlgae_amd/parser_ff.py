@@ -145,6 +145,22 @@ def _linear_act_bwd(g, w_t, act, out, J=1, mask=None, mask_scale=1.0, rng=None, 
     return out
 
 
+def _stage(w, out, bias=None, mask=None, mask_scale=1.0, rng=None, p=0.0, act=None, total=None, J=1, swap=False, accumulate=False):
+    """A VlgFfStage record (and the tensors it points at, to be kept alive until the launch is enqueued)."""
+    st = _C.FfStage()
+    pt = lambda t: None if t is None else t.data_ptr()
+    st.w, st.bias, st.mask, st.rng, st.out, st.act, st.sum = pt(w), pt(bias), pt(mask), (None if rng is None else rng.state.data_ptr()), pt(out), pt(act), pt(total)
+    st.mask_scale, st.p, st.site, st.J, st.swap, st.accumulate = float(mask_scale), float(p), SITE_MID_FF, int(J), int(swap), int(accumulate)
+    return st
+
+
+def _linear_act_chain2(x, s1, s2, backward=False):
+    """Two consecutive 256 -> 256 stages (`_stage` records) on the rows of x in ONE launch: stage 2 reads stage 1's stored rows from LDS
+    (vlg_ff_linear_act_chain2); both outputs are written."""
+    _C.check(_C.lib().vlg_ff_linear_act_chain2(_C.ptr(x), x.stride(0), x.shape[0], int(backward), ctypes.byref(s1), ctypes.byref(s2), SLOPE, _C.stream_of(x)),
+             "ff_linear_act_chain2")
+
+
 def _transpose256(mats, out):
     """out[z] = mats[z].T for up to eight contiguous [256,256] bf16 matrices in one launch (vlg_ff_transpose256)."""
     arr = (ctypes.c_void_p * len(mats))(*(m.data_ptr() for m in mats))
@@ -269,8 +285,9 @@ class _ParserFF(torch.autograd.Function):
             _linear_act(X, W_nh, b_nh, A1, nb=2, residual=X, om=2, oy=1)                   # valence stage, nn/dmv_spec.py:41-44: act(bottleneck + x)
             _linear_act(A1.view(2 * M, H), Wv, bv, A2)                                     # h [M,val,H]
             _linear_act(A2, W_lr, b_lr, A3, nb=2, residual=X, rs=1, om=4, oy=2)            # direction stage, :46-50: rows (m,val) -> [m,dir,val]
-            _linear_act(A3.view(4 * M, H), Wd, bd, A4, mask=mid_mask, mask_scale=mid_scale, rng=mid_rng, p=p_mid)   # + nn.Dropout (:52)
-            _linear_act(A4, W1_, b1_, A5)                                                  # output stage, :52-54 (linear2 folded into the projections)
+            # direction_linear + nn.Dropout (:52) and the output stage (:52-54, linear2 folded into the projections) in ONE launch: A4's rows go
+            # from the first product's epilogue to the second product through LDS (both are still written: the adjoint reads them)
+            _linear_act_chain2(A3.view(4 * M, H), _stage(Wd, A4, bias=bd, mask=mid_mask, mask_scale=mid_scale, rng=mid_rng, p=p_mid), _stage(W1_, A5, bias=b1_))
             # linear1 | direction | valence | the (left, right) blocks | the (no, has) blocks, transposed: what the backward launches read
             wT = _transpose256([W1_, Wd, Wv, W_lr[:H], W_lr[H:], W_nh[:H], W_nh[H:]], torch.empty((7, H, H), dtype=act, device=dev))
         else:
@@ -360,15 +377,16 @@ class _ParserFF(torch.autograd.Function):
         G["linear1.w"], G["linear1.b"] = _wgrad(g, A4, dtype=act, defer=wg)
         gX = torch.empty((M, H), dtype=torch.float32, device=g.device)                   # the skip connections' cotangent
         gZ = torch.empty((2 * M, 2 * H), dtype=act, device=g.device)                     # [m,val,dir,c]
-        if wT is not None:   # the input-gradient product of a layer and the adjoint of the element-wise pass in front of it in ONE launch
-            g = _linear_act_bwd(g, wT[0], A4, torch.empty_like(g), mask=mid_mask, mask_scale=ctx.drops[3], rng=mid_rng, p=p_mid)
+        if wT is not None:   # linear1's and direction_linear's adjoints (each: the input-gradient product + the element-wise adjoint in front of it) in ONE launch
+            g4 = torch.empty_like(g)
+            _linear_act_chain2(g, _stage(wT[0], g4, act=A4, mask=mid_mask, mask_scale=ctx.drops[3], rng=mid_rng, p=p_mid),
+                               _stage(wT[1], gZ, act=A3, J=4, total=gX, swap=True), backward=True)   # [m,dir,val,c] -> [m,val,dir,c], gX = the four rows' sum
+            g = g4
         else:
             g = g @ W1_
             _act_bwd(g, A4, g, 4 * M, 1, H, mask=mid_mask, mask_scale=ctx.drops[3], rng=mid_rng, p=p_mid)
         G["direction.w"], G["direction.b"] = _wgrad(g, A3.view(4 * M, H), dtype=act, defer=wg)
-        if wT is not None:
-            _linear_act_bwd(g, wT[1], A3, gZ, J=4, total=gX, swap=True)                  # [m,dir,val,c] -> [m,val,dir,c], gX = the four rows' sum
-        else:
+        if wT is None:
             g = g @ Wd                                                                   # [m,dir,val,c]
             _act_bwd(g, A3, gZ, M, 4, H, total=gX, swap=True)
         # the gradients of the folded weights straight into their stack, in the activations' dtype (what the unfold products read)
