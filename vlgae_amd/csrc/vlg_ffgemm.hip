@@ -71,6 +71,11 @@ struct FgArgs {
     int M0, L;
 };
 
+__device__ __forceinline__ void unpack4(uint2 w, float (&v)[4]) {   // four bf16 in two words -> fp32
+    v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
+    v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
+}
+
 __device__ __forceinline__ int fg_swap2(int j) { return ((j & 1) << 1) | (j >> 1); }
 
 // bf16 conversions on the hardware path (v_cvt_pk_bf16_f32, round to nearest even like vlg_rows.h's f2bf: the epilogue rounds 16 values per item)
@@ -136,11 +141,25 @@ __device__ __forceinline__ void fg_tile_keep(const FgArgs& a, long long krow0, l
 // c0 + 4 (l >> 4) + n, row l & 15): the element-wise pass runs on the accumulators in registers, with 8-byte loads / stores of the row's
 // other tensors, and nothing goes back through the LDS (the first version wrote the fp32 accumulators to an LDS tile and read them back
 // row-major behind a barrier: eight waves in lock step, ~6 700 cycles per tile for 512 cycles of MFMA).
-template <int KS>
+template <int KS, bool PRE = true>
 __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char* xs, const bf16x8 (&wf)[KS][2], const float (&bias4)[2][4], int tid, int y,
                                         char* ys = nullptr) {      // ys: an LDS image (the input tile's layout) that takes the stored values as well -- the next stage's input
     constexpr int kFgXPitch = fg_pitch(KS * 32);
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, kg = lane >> 4;
+    // The element-wise pass's row operand of this tile (backward: the stored activations; forward: the skip connection's rows) is requested HERE, ahead
+    // of the products, and used behind them: issued inside the epilogue (under its row conditions) every tile paid its round trip in full, eight
+    // waves in lock step.  Unconditional: a row past the end re-reads the last row, a stage without the operand re-reads its own input.
+    const uint16_t* const ep = a.bwd ? a.act : (a.res ? a.res : a.x);
+    const int ep_ld = (a.bwd || a.res) ? kFgH : a.ldx, ep_sh = a.bwd ? 0 : (a.res ? a.rs : 0);
+    uint2 epv[PRE ? 2 : 1][2];
+    if constexpr (PRE) if (!a.plain) {      // (PRE = false -- the two-stage image, whose registers hold two weight blocks: requested where it is used)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const long long er = min(t * kFgRows + rt * 16 + r, a.rows - 1) >> ep_sh;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) epv[rt][nt] = *reinterpret_cast<const uint2*>(ep + (size_t)er * ep_ld + wave * 32 + nt * 16 + kg * 4);
+        }
+    }
     f32x4 acc[2][2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -195,7 +214,8 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                 if (live) {
                     if (a.res) {
                         float t4[4];
-                        load4(a.res + (size_t)m * kFgH + c, t4);
+                        if constexpr (PRE) unpack4(epv[rt][nt], t4);
+                        else load4(a.res + (size_t)m * kFgH + c, t4);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) val[k] += t4[k];
                     }
@@ -225,7 +245,8 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                 float sv[4] = {0.f, 0.f, 0.f, 0.f};
                 if (live) {
                     float av[4];
-                    load4(a.act + (size_t)row * kFgH + c, av);
+                    if constexpr (PRE) unpack4(epv[rt][nt], av);
+                    else load4(a.act + (size_t)row * kFgH + c, av);
                     if (!kPlain && a.mask) {
                         float t4[4];
                         load4(a.mask + (size_t)row * kFgH + c, t4);
@@ -367,9 +388,9 @@ __device__ __forceinline__ void ff_gemm_act_body(const FgArgs& a, const FgArgs& 
     }
     auto tile = [&](long long tt, const char* xs) {
         if constexpr (TWO) {
-            fg_tile<KS>(a, tt, xs, wf, bias4, tid, y, ys);
+            fg_tile<KS, false>(a, tt, xs, wf, bias4, tid, y, ys);
             __syncthreads();                                   // stage a's rows are in `ys` (the next write of it is behind the trip's barrier)
-            fg_tile<KS>(b, tt, ys, wf2, bias2, tid, 0);
+            fg_tile<KS, false>(b, tt, ys, wf2, bias2, tid, 0);
         } else {
             fg_tile<KS>(a, tt, xs, wf, bias4, tid, y);
         }
