@@ -71,6 +71,12 @@ struct FgArgs {
     int M0, L;
 };
 
+// The element-wise pass's options as a compile-time word M (>= 0) or read from the argument block (M = -1, the generic image).  The options are
+// uniform, but as RUN-TIME conditions they were ~140 scalar branches per 32-row tile (the unrolled (row tile, column tile) bodies each test them):
+// a tile is ~6 500 cycles of which the products are 500, so the kernel family was bound by its own control flow.  fg_mode() names the combinations
+// the training step launches; anything else takes the generic image.
+enum : int { kMBwd = 1, kMRes = 2, kMMask = 4, kMRng = 8, kMSum = 16, kMSwap = 32, kMAcc = 64, kMPlain = 128, kMJ2 = 256, kMJ4 = 512, kMRs1 = 1024, kMAdd = 2048 };
+
 __device__ __forceinline__ void unpack4(uint2 w, float (&v)[4]) {   // four bf16 in two words -> fp32
     v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
     v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
@@ -141,18 +147,26 @@ __device__ __forceinline__ void fg_tile_keep(const FgArgs& a, long long krow0, l
 // c0 + 4 (l >> 4) + n, row l & 15): the element-wise pass runs on the accumulators in registers, with 8-byte loads / stores of the row's
 // other tensors, and nothing goes back through the LDS (the first version wrote the fp32 accumulators to an LDS tile and read them back
 // row-major behind a barrier: eight waves in lock step, ~6 700 cycles per tile for 512 cycles of MFMA).
-template <int KS, bool PRE = true>
+template <int KS, bool PRE = true, int M = -1>
 __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char* xs, const bf16x8 (&wf)[KS][2], const float (&bias4)[2][4], int tid, int y,
                                         char* ys = nullptr) {      // ys: an LDS image (the input tile's layout) that takes the stored values as well -- the next stage's input
     constexpr int kFgXPitch = fg_pitch(KS * 32);
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, kg = lane >> 4;
+    // the options: constants of this image (M >= 0) or the argument block's fields
+    const bool f_bwd = M >= 0 ? (M & kMBwd) != 0 : a.bwd != 0, f_res = M >= 0 ? (M & kMRes) != 0 : a.res != nullptr;
+    const bool f_mask = M >= 0 ? (M & kMMask) != 0 : a.mask != nullptr, f_rng = M >= 0 ? (M & kMRng) != 0 : a.rng != nullptr;
+    const bool f_sum = M >= 0 ? (M & kMSum) != 0 : a.sum != nullptr, f_swap = M >= 0 ? (M & kMSwap) != 0 : a.swap != 0;
+    const bool f_acc = M >= 0 ? (M & kMAcc) != 0 : a.accumulate != 0, f_plain = M >= 0 ? (M & kMPlain) != 0 : a.plain != 0;
+    const bool f_add = M >= 0 ? (M & kMAdd) != 0 : a.add != nullptr;
+    const int f_J = M >= 0 ? ((M & kMJ4) ? 4 : ((M & kMJ2) ? 2 : 1)) : a.J, f_lj = M >= 0 ? ((M & kMJ4) ? 2 : ((M & kMJ2) ? 1 : 0)) : a.lj;
+    const int f_rs = M >= 0 ? ((M & kMRs1) ? 1 : 0) : a.rs;
     // The element-wise pass's row operand of this tile (backward: the stored activations; forward: the skip connection's rows) is requested HERE, ahead
     // of the products, and used behind them: issued inside the epilogue (under its row conditions) every tile paid its round trip in full, eight
     // waves in lock step.  Unconditional: a row past the end re-reads the last row, a stage without the operand re-reads its own input.
-    const uint16_t* const ep = a.bwd ? a.act : (a.res ? a.res : a.x);
-    const int ep_ld = (a.bwd || a.res) ? kFgH : a.ldx, ep_sh = a.bwd ? 0 : (a.res ? a.rs : 0);
+    const uint16_t* const ep = f_bwd ? a.act : (f_res ? a.res : a.x);
+    const int ep_ld = (f_bwd || f_res) ? kFgH : a.ldx, ep_sh = f_bwd ? 0 : (f_res ? f_rs : 0);
     uint2 epv[PRE ? 2 : 1][2];
-    if constexpr (PRE) if (!a.plain) {      // (PRE = false -- the two-stage image, whose registers hold two weight blocks: requested where it is used)
+    if constexpr (PRE) if (!f_plain && (M < 0 || f_bwd || f_res)) {      // (PRE = false -- the two-stage image, whose registers hold two weight blocks: requested where it is used)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const long long er = min(t * kFgRows + rt * 16 + r, a.rows - 1) >> ep_sh;
@@ -181,12 +195,12 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
     const long long row0 = t * kFgRows;
     constexpr bool kPlain = KS > 8;     // the K = 512 image: a plain layer's adjoint (no mask, no draw, no group sum: 128 of its 256 registers hold the weights)
     float km[2][2][4];
-    if (!kPlain && a.rng) {       // (uniform) the dropout draws of the tile, indexed by the OUTPUT row forward and by the row backward (as vlg_ff_act*)
+    if (!kPlain && f_rng) {       // (uniform) the dropout draws of the tile, indexed by the OUTPUT row forward and by the row backward (as vlg_ff_act*)
         const long long ra = row0 + r, rb = row0 + 16 + r;
-        const bool by_row = a.bwd || a.plain;
-        const long long ka = by_row ? ra : (ra >> a.rs) * a.om + (long long)y * a.oy + (ra & ((1 << a.rs) - 1));
-        const long long kb = by_row ? rb : (rb >> a.rs) * a.om + (long long)y * a.oy + (rb & ((1 << a.rs) - 1));
-        fg_tile_keep(a, ka, kb, wave, kg, a.plain ? a.ncols >> 3 : kFgH >> 3, a.plain ? y * kFgH : 0, km);
+        const bool by_row = f_bwd || f_plain;
+        const long long ka = by_row ? ra : (ra >> f_rs) * a.om + (long long)y * a.oy + (ra & ((1 << f_rs) - 1));
+        const long long kb = by_row ? rb : (rb >> f_rs) * a.om + (long long)y * a.oy + (rb & ((1 << f_rs) - 1));
+        fg_tile_keep(a, ka, kb, wave, kg, f_plain ? a.ncols >> 3 : kFgH >> 3, f_plain ? y * kFgH : 0, km);
     }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -196,23 +210,23 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
         for (int nt = 0; nt < 2; ++nt) {
             const int c = wave * 32 + nt * 16 + kg * 4;        // this lane's four channels
             float val[4] = {acc[rt][nt][0], acc[rt][nt][1], acc[rt][nt][2], acc[rt][nt][3]};
-            if (!kPlain && !a.bwd) {
+            if (!kPlain && !f_bwd) {
                 // (the pair this replaces rounds the Linear's output to bf16 before the skip connection is added: the same rounding here, so
                 //  that the two paths agree to the last bit of what the next layer reads wherever the product's own summation order does)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) val[k] = fg_round(val[k] + bias4[nt][k]);
-                if (a.plain) {        // (uniform) the product alone, or times the counter-based draw over out's [rows, ncols] elements (as vlg_dropout)
-                    if (a.rng) {
+                if (f_plain) {        // (uniform) the product alone, or times the counter-based draw over out's [rows, ncols] elements (as vlg_dropout)
+                    if (f_rng) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) val[k] *= km[rt][nt][k];
                     }
                     if (live && y * kFgH + c < a.ncols) fg_store4(a.out + (size_t)row * a.ldo + y * kFgH + c, val);
                     continue;
                 }
-                const long long m = row >> a.rs;
-                const long long orow = m * a.om + (long long)y * a.oy + (row & ((1 << a.rs) - 1));
+                const long long m = row >> f_rs;
+                const long long orow = m * a.om + (long long)y * a.oy + (row & ((1 << f_rs) - 1));
                 if (live) {
-                    if (a.res) {
+                    if (f_res) {
                         float t4[4];
                         if constexpr (PRE) unpack4(epv[rt][nt], t4);
                         else load4(a.res + (size_t)m * kFgH + c, t4);
@@ -221,12 +235,12 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) val[k] = leaky(val[k], a.slope);
-                    if (a.mask) {
+                    if (f_mask) {
                         float t4[4];
                         load4(a.mask + (size_t)orow * kFgH + c, t4);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) val[k] *= t4[k] * a.mask_scale;
-                    } else if (a.rng) {      // the draw of the 8-channel group this lane holds half of (the element indexing of vlg_ff_act)
+                    } else if (f_rng) {      // the draw of the 8-channel group this lane holds half of (the element indexing of vlg_ff_act)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) val[k] *= km[rt][nt][k];
                     }
@@ -238,8 +252,8 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
 #endif
                 }
             } else {
-                const int J = a.J, j = (int)(row & (J - 1));
-                const long long m = row >> a.lj, orow = a.swap ? m * 4 + fg_swap2(j) : row;      // (J = 1 << lj: no 64-bit division per element)
+                const int J = f_J, j = (int)(row & (J - 1));
+                const long long m = row >> f_lj, orow = f_swap ? m * 4 + fg_swap2(j) : row;      // (J = 1 << lj: no 64-bit division per element)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) val[k] = fg_round(val[k]);      // (the product's bf16 output, as the pair rounds it)
                 float sv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -247,16 +261,16 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                     float av[4];
                     if constexpr (PRE) unpack4(epv[rt][nt], av);
                     else load4(a.act + (size_t)row * kFgH + c, av);
-                    if (!kPlain && a.mask) {
+                    if (!kPlain && f_mask) {
                         float t4[4];
                         load4(a.mask + (size_t)row * kFgH + c, t4);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) val[k] *= t4[k] * a.mask_scale;
-                    } else if (!kPlain && a.rng) {
+                    } else if (!kPlain && f_rng) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) val[k] *= km[rt][nt][k];
                     }
-                    if (kPlain && a.add) {      // (uniform)
+                    if (kPlain && f_add) {      // (uniform)
                         const float4 o = *reinterpret_cast<const float4*>(a.add + (size_t)row * kFgH + c);
                         val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
                         if (row < a.M0) {
@@ -278,7 +292,7 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                     fg_store4(a.out + (size_t)orow * kFgH + c, val);
                     if (ys) fg_store4(reinterpret_cast<uint16_t*>(ys + (rt * 16 + r) * kFgXPitch) + c, val);
                 }
-                if (!kPlain && a.sum) {     // (uniform) the J rows of a group sit on J consecutive lanes: the group's sum in row order j = 0, 1, ..
+                if (!kPlain && f_sum) {     // (uniform) the J rows of a group sit on J consecutive lanes: the group's sum in row order j = 0, 1, ..
                     float s[4];
                     if (J == 1) {
 #pragma unroll
@@ -290,7 +304,7 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
                     }
                     if (live && j == 0) {
                         float* sp = a.sum + (size_t)m * kFgH + c;
-                        if (a.accumulate) {
+                        if (f_acc) {
                             const float4 o = *reinterpret_cast<const float4*>(sp);
                             s[0] += o.x; s[1] += o.y; s[2] += o.z; s[3] += o.w;
                         }
@@ -305,7 +319,7 @@ __device__ __forceinline__ void fg_tile(const FgArgs& a, long long t, const char
 // TWO: a second 256 -> 256 stage `b` runs on the first one's stored rows without their round trip through memory: stage a's epilogue writes its
 // tile into a third LDS image as well, and stage b's product reads its input fragments there (both weight blocks in registers: 128 VGPRs).  Stage a
 // keeps its rows (one column block, no row permutation); it still writes its own output -- the weight gradients read it.
-template <int KS, bool TWO>   // K = 32 KS input channels
+template <int KS, bool TWO, int MA, int MB>   // K = 32 KS input channels; MA / MB: the stages' option words (-1: read from the argument blocks)
 __device__ __forceinline__ void ff_gemm_act_body(const FgArgs& a, const FgArgs& b) {
     constexpr int K = KS * 32, kFgXPitch = fg_pitch(K), SEGS = K / 8, SPT = (kFgRows * SEGS + kFgThreads - 1) / kFgThreads;   // 16-byte segments per row / per thread and tile
     static_assert(SPT >= 1 && SPT <= 4, "segments per thread");
@@ -388,11 +402,11 @@ __device__ __forceinline__ void ff_gemm_act_body(const FgArgs& a, const FgArgs& 
     }
     auto tile = [&](long long tt, const char* xs) {
         if constexpr (TWO) {
-            fg_tile<KS, false>(a, tt, xs, wf, bias4, tid, y, ys);
+            fg_tile<KS, false, MA>(a, tt, xs, wf, bias4, tid, y, ys);
             __syncthreads();                                   // stage a's rows are in `ys` (the next write of it is behind the trip's barrier)
-            fg_tile<KS, false>(b, tt, ys, wf2, bias2, tid, 0);
+            fg_tile<KS, false, MB>(b, tt, ys, wf2, bias2, tid, 0);
         } else {
-            fg_tile<KS>(a, tt, xs, wf, bias4, tid, y);
+            fg_tile<KS, true, MA>(a, tt, xs, wf, bias4, tid, y);
         }
     };
     FG_STORE_A(xs0)
@@ -432,10 +446,11 @@ __device__ __forceinline__ void ff_gemm_act_body(const FgArgs& a, const FgArgs& 
     }
 }
 
-template <int KS>
-__global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a) { ff_gemm_act_body<KS, false>(a, a); }
+template <int KS, int M>
+__global__ __launch_bounds__(kFgThreads) void ff_gemm_act_kernel(const FgArgs a) { ff_gemm_act_body<KS, false, M, -1>(a, a); }
 
-__global__ __launch_bounds__(kFgThreads) void ff_gemm_act2_kernel(const FgArgs a, const FgArgs b) { ff_gemm_act_body<8, true>(a, b); }
+template <int MA, int MB>
+__global__ __launch_bounds__(kFgThreads) void ff_gemm_act2_kernel(const FgArgs a, const FgArgs b) { ff_gemm_act_body<8, true, MA, MB>(a, b); }
 
 // out[z][n][k] = w_z[k][n] for up to eight 256 x 256 bf16 matrices (the layers' weights as the backward launches read them): 32 x 32 tiles through LDS
 struct FgTr { const uint16_t* w[8]; };
@@ -458,12 +473,18 @@ __global__ __launch_bounds__(256) void ff_transpose256_kernel(const FgTr a, uint
 #undef FG_STORE_A
 #undef FG_STORE_B
 
-template <int KS>
-int fg_launch_k(const FgArgs& a, int nb, hipStream_t s) {
+// the option word of an argument block (what fg_tile reads from it in the generic image)
+int fg_mode(const FgArgs& a) {
+    return (a.bwd ? kMBwd : 0) | (a.res ? kMRes : 0) | (a.mask ? kMMask : 0) | (a.rng ? kMRng : 0) | (a.sum ? kMSum : 0) | (a.swap ? kMSwap : 0) |
+           (a.accumulate ? kMAcc : 0) | (a.plain ? kMPlain : 0) | (a.J == 2 ? kMJ2 : 0) | (a.J == 4 ? kMJ4 : 0) | (a.rs == 1 ? kMRs1 : 0) | (a.add ? kMAdd : 0);
+}
+
+template <int KS, int M>
+int fg_launch_km(const FgArgs& a, int nb, hipStream_t s) {
     static bool attr_set = false;
     constexpr int lds = fg_lds(KS * 32);
     if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_gemm_act_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_gemm_act_kernel<KS, M>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -472,12 +493,36 @@ int fg_launch_k(const FgArgs& a, int nb, hipStream_t s) {
     // workgroups those reads -- 64 MB of 64-byte pieces out of the same 128 KB -- took ~15 us per launch); the tiles are dealt round-robin
     const int per_block = std::max(1, 256 / nb);
     const int gx = (int)std::min<long long>(tiles, per_block);
-    hipLaunchKernelGGL(ff_gemm_act_kernel<KS>, dim3(gx, nb), dim3(kFgThreads), lds, s, a);
+    hipLaunchKernelGGL((ff_gemm_act_kernel<KS, M>), dim3(gx, nb), dim3(kFgThreads), lds, s, a);
     return check_launch("ff_gemm_act_kernel");
 }
 
+// the images with their options compiled in: the combinations vlgae_amd.parser_ff / align.linear_kn launch in a training step (VLG_FF_GENERIC=1: the
+// generic image everywhere, A/B timing); any other combination of a C-ABI caller takes the generic image
 int fg_launch(const FgArgs& a, int k, int nb, hipStream_t s) {
-    return k == 32 ? fg_launch_k<1>(a, nb, s) : (k == 512 ? fg_launch_k<16>(a, nb, s) : fg_launch_k<8>(a, nb, s));
+    const int m = VLG_ENV("VLG_FF_GENERIC") ? -2 : fg_mode(a);
+#define FG_CASE(KS_, M_) if (m == (M_)) return fg_launch_km<KS_, (M_)>(a, nb, s)
+    if (k == 32) {
+        FG_CASE(1, kMBwd);
+        return fg_launch_km<1, -1>(a, nb, s);
+    }
+    if (k == 512) {
+        FG_CASE(16, kMBwd);
+        FG_CASE(16, kMBwd | kMAdd);
+        return fg_launch_km<16, -1>(a, nb, s);
+    }
+    FG_CASE(8, 0);                                         // a plain layer
+    FG_CASE(8, kMRes);                                     // (no | has) bottlenecks + skip connection
+    FG_CASE(8, kMRes | kMRs1);                             // (left | right) bottlenecks + skip connection
+    FG_CASE(8, kMRng);                                     // direction stage + nn.Dropout
+    FG_CASE(8, kMBwd);
+    FG_CASE(8, kMBwd | kMRng);
+    FG_CASE(8, kMBwd | kMJ4 | kMSwap | kMSum);
+    FG_CASE(8, kMBwd | kMJ2 | kMSum | kMAcc);
+    FG_CASE(8, kMPlain);                                   // linear_kn
+    FG_CASE(8, kMPlain | kMRng);
+#undef FG_CASE
+    return fg_launch_km<8, -1>(a, nb, s);
 }
 
 int fg_check(const char* what, const void* x, int ldx, int k, const void* w, long long rows, const void* out) {
@@ -564,15 +609,15 @@ int vlg_ff_linear_act_chain2(const void* x, int ldx, long long rows, int backwar
     if (rows == 0) return 0;
     a.x = (const uint16_t*)x; a.ldx = ldx; a.rows = rows;
     b.x = (const uint16_t*)s1->out; b.ldx = kFgH; b.rows = rows;          // (read from the LDS image, never from memory)
-    static bool attr_set = false;
-    constexpr int lds = 3 * kFgRows * fg_pitch(256);
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_gemm_act2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    constexpr int lds = 3 * kFgRows * fg_pitch(256);        // 51 KB: below the 64 KB that need no attribute
+    static_assert(lds <= 64 * 1024, "dynamic LDS attribute needed");
     const long long tiles = (rows + kFgRows - 1) / kFgRows;
-    hipLaunchKernelGGL(ff_gemm_act2_kernel, dim3((unsigned)std::min<long long>(tiles, 256)), dim3(kFgThreads), lds, (hipStream_t)stream, a, b);
+    const dim3 grid((unsigned)std::min<long long>(tiles, 256));
+    const int ma = VLG_ENV("VLG_FF_GENERIC") ? -2 : fg_mode(a), mb = fg_mode(b);
+    if (ma == kMRng && mb == 0) hipLaunchKernelGGL((ff_gemm_act2_kernel<kMRng, 0>), grid, dim3(kFgThreads), lds, (hipStream_t)stream, a, b);
+    else if (ma == (kMBwd | kMRng) && mb == (kMBwd | kMJ4 | kMSwap | kMSum))
+        hipLaunchKernelGGL((ff_gemm_act2_kernel<kMBwd | kMRng, kMBwd | kMJ4 | kMSwap | kMSum>), grid, dim3(kFgThreads), lds, (hipStream_t)stream, a, b);
+    else hipLaunchKernelGGL((ff_gemm_act2_kernel<-1, -1>), grid, dim3(kFgThreads), lds, (hipStream_t)stream, a, b);
     return check_launch("ff_gemm_act2_kernel");
 }
 
