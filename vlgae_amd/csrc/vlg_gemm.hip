@@ -42,6 +42,9 @@ constexpr int kGemmThreads = 256;   // 4 wavefronts, 2 x 2 over the output tile
 #ifndef VLG_TN_WGS
 #define VLG_TN_WGS 256      // workgroups a product is split into (tiles x row splits)
 #endif
+#ifndef VLG_SG_U
+#define VLG_SG_U 4          // small products: contraction chunks whose loads are all issued before the first product
+#endif
 #ifndef VLG_TN_BIG_MIN
 #define VLG_TN_BIG_MIN 8    // 128-tiles an output must have to take the 128-tile kernel
 #endif
@@ -633,8 +636,23 @@ __device__ __forceinline__ void small_gemm_tile(const SgArgs& p, int tile, int z
         arow[i] = A + (long long)min(row, p.M - 1) * p.sam + (long long)(EPL * g) * p.sak;
         bcol[i] = B + (long long)min(col, p.N - 1) * p.sbn + (long long)(EPL * g) * p.sbk;
     }
+    // the epilogue's operands (bias, the rank-one term's vectors) are requested HERE, ahead of the contraction: read behind it they were one more
+    // dependent round trip of a wavefront that has its SIMD to itself
+    Out* C = static_cast<Out*>(p.c) + (long long)z * p.scb;
+    const T* bias = p.bias ? static_cast<const T*>(p.bias) + (long long)z * p.sbias : nullptr;
+    const T* u = p.u ? static_cast<const T*>(p.u) + (long long)z * p.su : nullptr;
+    const T* v = p.v ? static_cast<const T*>(p.v) + (long long)z * p.sv : nullptr;
+    float e_b[2], e_v[2], e_u[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = min(tn * 32 + j * 16 + r, p.N - 1);
+        e_b[j] = bias ? sg_ld(bias, col) : 0.f;
+        e_v[j] = v ? sg_ld(v, col) : 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) e_u[j][n] = u ? sg_ld(u, min(tm * 32 + j * 16 + 4 * g + n, p.M - 1)) : 0.f;     // (index j = the row tile here)
+    }
     int k0 = 0;
-    constexpr int U = 4;                            // chunks whose loads are ALL issued before the first product: a chunk per dependent
+    constexpr int U = VLG_SG_U;                     // chunks whose loads are ALL issued before the first product: a chunk per dependent
     for (; k0 + U * KW <= kfull; k0 += U * KW) {   // L2 / HBM round trip made a 256 x 256 x 256 product 9.5 us (8 round trips)
         Frag af[U][2], bf[U][2];
 #pragma unroll
@@ -682,23 +700,19 @@ __device__ __forceinline__ void small_gemm_tile(const SgArgs& p, int tile, int z
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = mma_chunk<F32IN>(af[i], bf[j], acc[i][j]);
     }
-    Out* C = static_cast<Out*>(p.c) + (long long)z * p.scb;
-    const T* bias = p.bias ? static_cast<const T*>(p.bias) + (long long)z * p.sbias : nullptr;
-    const T* u = p.u ? static_cast<const T*>(p.u) + (long long)z * p.su : nullptr;
-    const T* v = p.v ? static_cast<const T*>(p.v) + (long long)z * p.sv : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = tn * 32 + j * 16 + r;
             if (col >= p.N) continue;
-            const float bj = bias ? sg_ld(bias, col) : 0.f, vj = v ? sg_ld(v, col) : 0.f;
+            const float bj = e_b[j], vj = e_v[j];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {   // accumulator layout: lane (r, g), register n <-> row 4 g + n, column r
                 const int row = tm * 32 + i * 16 + 4 * g + n;
                 if (row >= p.M) continue;
                 float val = p.alpha * acc[i][j][n] + bj;
-                if (u) val = fmaf(sg_ld(u, row), vj, val);
+                if (u) val = fmaf(e_u[i][n], vj, val);
                 const long long at = (long long)row * p.ldc + col;
                 if (p.accumulate) val += sizeof(Out) == 4 ? reinterpret_cast<const float*>(C)[at] : __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(C)[at] << 16);
                 sg_st(C, at, val);
