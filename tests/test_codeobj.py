@@ -14,7 +14,8 @@ HOT = ("dmv1o_kernel<", "dmv1o_rules_kernel<", "deptree_kernel<", "align_max_ker
        "ground_ce_tile_kernel<", "gemm_tn_kernel", "scorer_fwd_kernel<", "scorer_bwd_kernel<", "langfeat_", "box_rel_", "merge_kernel<",
        "grounding_decode_kernel", "align_bwd_split_kernel<", "align_full_kernel", "tri2_kernel", "align_argmax_kernel<",
        "ground_bwd_ws_kernel<", "ground_ce_tile2_kernel", "align_prior_diag_kernel", "attn_fuse_split_kernel<", "attn_bwd_sweep_kernel<",
-       "attn_bwd_combine_kernel<", "attn_fuse_combine_kernel<", "attn_bwd_regions_bf16_kernel<", "ff_gemm_act_kernel")
+       "attn_bwd_combine_kernel<", "attn_fuse_combine_kernel<", "attn_bwd_regions_bf16_kernel<", "ff_gemm_act_kernel", "ff_gemm_act2_kernel",
+       "gemm_tn_group_kernel")
 # known exceptions, each with its reason (fallback paths the benchmarked configurations do not take, or work in progress)
 ALLOWED = {
     "tri_dw_kernel<": "fallback of tri_dw2_kernel (fp32 features / widths other than 128): 128 accumulators + operand ring",

@@ -608,7 +608,7 @@ int vlg_ff_linear_act_chain2(const void* x, int ldx, long long rows, int backwar
     if (backward && rows % b.J) return set_error(VLG_ERR_ARG, "ff_linear_act_chain2: rows=%lld J=%d", rows, b.J);
     if (rows == 0) return 0;
     a.x = (const uint16_t*)x; a.ldx = ldx; a.rows = rows;
-    b.x = (const uint16_t*)s1->out; b.ldx = kFgH; b.rows = rows;          // (read from the LDS image, never from memory)
+    b.x = (const uint16_t*)s1->out; b.ldx = kFgH; b.rows = rows;          // (the two-stage image reads it from LDS; the two-launch route from memory)
     constexpr int lds = 3 * kFgRows * fg_pitch(256);        // 51 KB: below the 64 KB that need no attribute
     static_assert(lds <= 64 * 1024, "dynamic LDS attribute needed");
     const long long tiles = (rows + kFgRows - 1) / kFgRows;
@@ -617,7 +617,10 @@ int vlg_ff_linear_act_chain2(const void* x, int ldx, long long rows, int backwar
     if (ma == kMRng && mb == 0) hipLaunchKernelGGL((ff_gemm_act2_kernel<kMRng, 0>), grid, dim3(kFgThreads), lds, (hipStream_t)stream, a, b);
     else if (ma == (kMBwd | kMRng) && mb == (kMBwd | kMJ4 | kMSwap | kMSum))
         hipLaunchKernelGGL((ff_gemm_act2_kernel<kMBwd | kMRng, kMBwd | kMJ4 | kMSwap | kMSum>), grid, dim3(kFgThreads), lds, (hipStream_t)stream, a, b);
-    else hipLaunchKernelGGL((ff_gemm_act2_kernel<-1, -1>), grid, dim3(kFgThreads), lds, (hipStream_t)stream, a, b);
+    else {   // any other pair of option words: the two stages as two launches (the same bits; a generic two-stage image would not fit 256 registers)
+        if (int rc = fg_launch(a, 256, 1, (hipStream_t)stream)) return rc;
+        return fg_launch(b, 256, 1, (hipStream_t)stream);
+    }
     return check_launch("ff_gemm_act2_kernel");
 }
 
