@@ -10,7 +10,7 @@ dev = torch.device('cuda:0')
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2026)
 worst = 0.0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 16):
-    B = int(rng.choice([1, 2, 3, 5, 8, 17, 33]))
+    B = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 64, 96]))      # (64, 96: enough token rows for the row-streaming input-gradient launches)
     L = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 40, 41, 47]))
     R = int(rng.choice([1, 2, 5, 16, 17, 36]))
     factors = [(), ("rel",), ("attr",), ("img",), ("rel", "attr", "img")][int(rng.integers(0, 5))]
